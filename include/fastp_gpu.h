@@ -1,0 +1,304 @@
+/* fastp_gpu.h - C ABI of the MI355X-native per-read engine that drops in for the
+ * body of fastp's worker loop.
+ *
+ * What it replaces (reference = OpenGene/fastp v1.3.6, paths relative to the
+ * reference root):
+ *   bool PairEndProcessor::processPairEnd(ReadPack*, ReadPack*, ThreadConfig*)
+ *        src/peprocessor.h:33, src/peprocessor.cpp:362-708
+ *   bool SingleEndProcessor::processSingleEnd(ReadPack*, ThreadConfig*)
+ *        src/seprocessor.h:32, src/seprocessor.cpp:197-325
+ * i.e. everything the loop body computes per read / per pair:
+ *   Stats::statRead (stats.cpp:191-291), Duplicate::checkRead/checkPair
+ *   (duplicate.cpp:111-163), Filter::trimAndCut (filter.cpp:68-207),
+ *   PolyX::trimPolyG/trimPolyX (polyx.cpp:16-116), OverlapAnalysis::analyze
+ *   (overlapanalysis.cpp:17-146), BaseCorrector (basecorrector.cpp:16-83),
+ *   AdapterTrimmer (adaptertrimmer.cpp:17-157) + Matcher (matcher.cpp:10-54),
+ *   Filter::passFilter (filter.cpp:15-66), statInsertSize
+ *   (peprocessor.cpp:710-723) and the integer side of FilterResult
+ *   (filterresult.cpp:28-36,99-107,182-189).
+ * The host keeps FASTQ decode/encode, read names, output routing, the
+ * adapter-string map and the JSON/HTML reporters.
+ *
+ * Plain C: pointers and sizes only.  No function here ever calls exit();
+ * every failure is a negative return code (reference: error_exit, util.h:270).
+ */
+#ifndef FASTP_GPU_H
+#define FASTP_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTP_GPU_ABI_VERSION 1
+
+/* ---- limits ------------------------------------------------------------ */
+#define FASTP_GPU_MAX_READ_LEN 512    /* padded read length the kernels tile in LDS */
+#define FASTP_GPU_MAX_ADAPTER_LEN 128 /* -a / --adapter_sequence_r2 */
+
+/* ---- error codes ------------------------------------------------------- */
+#define FASTP_GPU_OK 0
+#define FASTP_GPU_E_INVALID (-1)     /* bad argument / inconsistent params       */
+#define FASTP_GPU_E_NO_DEVICE (-2)   /* no HIP device / kernels not loadable     */
+#define FASTP_GPU_E_HIP (-3)         /* a HIP runtime call failed                */
+#define FASTP_GPU_E_ALPHABET (-4)    /* base byte outside {A,C,G,T,N} in pack    */
+#define FASTP_GPU_E_TOO_LONG (-5)    /* read longer than params.max_len          */
+#define FASTP_GPU_E_UNSUPPORTED (-6) /* option outside the device path's scope   */
+#define FASTP_GPU_E_OVERFLOW (-7)    /* correction list capacity exceeded        */
+#define FASTP_GPU_E_NOMEM (-8)
+
+/* ---- filter result codes (src/common.h:43-51) --------------------------- */
+#define FASTP_PASS_FILTER 0
+#define FASTP_FAIL_POLY_X 4
+#define FASTP_FAIL_OVERLAP 8
+#define FASTP_FAIL_N_BASE 12
+#define FASTP_FAIL_LENGTH 16
+#define FASTP_FAIL_TOO_LONG 17
+#define FASTP_FAIL_QUALITY 20
+#define FASTP_FAIL_COMPLEXITY 24
+#define FASTP_FAIL_ADAPTER_DIMER 28
+#define FASTP_FILTER_RESULT_TYPES 32
+
+/* ---- parameter block ----------------------------------------------------
+ * Flattened copy of the hot-path subset of `Options` (src/options.h); values
+ * are the ones main.cpp:176-427 + Options::validate (options.cpp:85-446)
+ * derive, i.e. AFTER defaulting (front2 follows front1, merge forces
+ * correction, ...).  Field comments give the Options member.
+ */
+typedef struct fastp_gpu_params {
+    int32_t abi_version; /* FASTP_GPU_ABI_VERSION */
+    int32_t paired;      /* Options::isPaired()                                  */
+    int32_t max_len;     /* longest read any batch may carry (cycles capacity)   */
+
+    /* TrimmingOptions options.h:223-246 */
+    int32_t trim_front1, trim_tail1, trim_front2, trim_tail2;
+    int32_t max_len1, max_len2;
+
+    /* QualityCutOptions options.h:132-170 */
+    int32_t cut_front, cut_tail, cut_right;
+    int32_t cut_front_window, cut_front_quality;
+    int32_t cut_tail_window, cut_tail_quality;
+    int32_t cut_right_window, cut_right_quality;
+
+    /* PolyGTrimmerOptions / PolyXTrimmerOptions options.h:82-102 */
+    int32_t poly_g, poly_g_min_len;
+    int32_t poly_x, poly_x_min_len;
+
+    /* AdapterOptions options.h:197-221.  adapter_seq_rN == NULL or "" means
+     * hasSeqRN == false.  Sequences must be over {A,C,G,T} (options.cpp:369-399). */
+    int32_t adapter_enabled;
+    int32_t allow_gap_overlap_trimming;
+    int32_t dimer_max_len;
+    const char* adapter_seq_r1;
+    const char* adapter_seq_r2;
+
+    /* CorrectionOptions / MergeOptions, overlap knobs options.h:376-379 */
+    int32_t correction;
+    int32_t merge, merge_include_unmerged;
+    int32_t overlap_require, overlap_diff_limit, overlap_diff_percent_limit;
+
+    /* QualityFilteringOptions options.h:248-268 (qualified_qual is the PHRED
+     * number, e.g. 15; the engine applies num2qual itself, util.h:260) */
+    int32_t qual_filter;
+    int32_t qualified_qual, unqualified_percent_limit, n_base_limit, avg_qual_req;
+
+    /* ReadLengthFilteringOptions / LowComplexityFilterOptions */
+    int32_t length_filter, length_required, length_limit;
+    int32_t complexity_filter;
+    double complexity_threshold; /* 0..1, as Options stores it (main.cpp:342) */
+
+    /* DuplicationOptions options.h:32-45 */
+    int32_t dup_enabled, dedup, dup_accuracy_level;
+
+    /* insertSizeMax options.cpp:23 (histogram has insert_size_max+1 bins) */
+    int32_t insert_size_max;
+
+    /* UMI taken from the read itself (umiprocessor.cpp:19-49): number of UMI
+     * bases per mate (0 = that mate carries none) and the skip after it.  The
+     * name edit stays on the host; the engine only reproduces
+     * Read::trimFront (read.cpp:69-73). */
+    int32_t umi_len1, umi_len2, umi_skip;
+
+    int32_t reserved[8];
+} fastp_gpu_params;
+
+/* fills *p with the values an un-flagged `fastp -i R1 [-I R2]` run uses
+ * (main.cpp defaults). */
+void fastp_gpu_default_params(fastp_gpu_params* p, int paired, int max_len);
+
+/* ---- batch layout in memory (host or device) ----------------------------
+ * SoA, one row per read, rows padded to a fixed stride:
+ *   seq : 2 bits/base, base j of a read in bits [2*(j%4), 2*(j%4)+1] of byte
+ *         j/4 of its row; code A=0 C=1 G=2 T=3 ('N' is stored as code 0 and
+ *         flagged in qual).  Row stride = fastp_gpu_seq_stride(max_len).
+ *   qual: 1 byte/base, bits 0..6 = the phred33 ASCII character (33..126),
+ *         bit 7 = 1 iff the base is 'N'.  Row stride = fastp_gpu_qual_stride.
+ *   len : uint16 read length (0..max_len).
+ * Bytes past a read's length inside its row must be zero (the packer does it).
+ */
+size_t fastp_gpu_seq_stride(int max_len);  /* bytes: ceil(max_len/4) rounded up to 8 */
+size_t fastp_gpu_qual_stride(int max_len); /* bytes: max_len rounded up to 8          */
+
+typedef struct fastp_gpu_batch {
+    int32_t n;                  /* reads (SE) or pairs (PE) in this batch         */
+    uint32_t flags;             /* FASTP_GPU_BATCH_*                              */
+    const uint8_t* seq1;        /* n * seq_stride                                 */
+    const uint8_t* qual1;       /* n * qual_stride                                */
+    const uint16_t* len1;       /* n                                              */
+    const uint8_t* seq2;        /* PE only                                        */
+    const uint8_t* qual2;
+    const uint16_t* len2;
+} fastp_gpu_batch;
+
+/* the reference only samples insert size on worker thread 0
+ * (peprocessor.cpp:449,497); the host sets this flag on the packs that thread
+ * 0 would have received.  With -w 1 (the parity configuration) every pack. */
+#define FASTP_GPU_BATCH_STAT_ISIZE 1u
+
+/* ---- per-read / per-pair results ---------------------------------------- */
+typedef struct fastp_gpu_read_result {
+    uint16_t front;      /* bases removed at the 5' end of the ORIGINAL read      */
+    uint16_t len;        /* final length: output seq = orig[front, front+len)     */
+    uint8_t code;        /* passFilter code after the dimer override (common.h)   */
+    uint8_t flags;       /* FASTP_GPU_RF_*                                        */
+    int16_t adapter_pos; /* where the adapter starts, in coordinates of the read  */
+                         /* as it was just before adapter trimming (may be < 0    */
+                         /* for trimBySequence, adaptertrimmer.cpp:138-145)       */
+    uint16_t adapter_len;/* length of the string handed to addAdapterTrimmed:     */
+                         /* pos>=0: read[pos, pos+adapter_len) (after correction); */
+                         /* pos<0 : adapterseq.substr(0, adapter_len)              */
+    uint16_t reserved;
+} fastp_gpu_read_result; /* 12 bytes */
+
+#define FASTP_GPU_RF_NULL 0x01        /* trimAndCut returned NULL (filter.cpp:68)      */
+#define FASTP_GPU_RF_DUP 0x02         /* Duplicate::check* said duplicate               */
+#define FASTP_GPU_RF_ADAPTER 0x04     /* trimmedN == true (peprocessor.cpp:472-475)     */
+#define FASTP_GPU_RF_ADAPTER_OV 0x08  /* ... by trimByOverlapAnalysis                   */
+#define FASTP_GPU_RF_CORRECTED 0x10   /* BaseCorrector edited this mate                 */
+#define FASTP_GPU_RF_MERGED 0x20      /* pair was merged (merge mode)                   */
+#define FASTP_GPU_RF_POLYX 0x40       /* trimPolyX cut this read                        */
+
+typedef struct fastp_gpu_pair_result {
+    int16_t ov_offset;   /* OverlapResult (overlapanalysis.h:15-22) used for       */
+    uint16_t ov_len;     /* isize/correction/adapter trimming; in merge mode the   */
+    uint16_t ov_diff;    /* recomputed one (peprocessor.cpp:523).  ov_len==0 and   */
+                         /* ov_offset==0 when not overlapped                       */
+    uint16_t flags;      /* bit0 overlapped, bit1 hasGap, bit2 isize evaluated     */
+} fastp_gpu_pair_result; /* 8 bytes */
+
+#define FASTP_GPU_PF_OVERLAPPED 0x1
+#define FASTP_GPU_PF_HAS_GAP 0x2
+#define FASTP_GPU_PF_ISIZE 0x4
+
+/* one base edited by BaseCorrector (basecorrector.cpp:39-57) */
+typedef struct fastp_gpu_correction {
+    uint32_t read;  /* 2*pair + (0 for R1, 1 for R2), index within the batch */
+    uint16_t pos;   /* position in the ORIGINAL read                          */
+    uint8_t base;   /* new base, ASCII                                        */
+    uint8_t qual;   /* new quality, ASCII                                     */
+} fastp_gpu_correction; /* 8 bytes */
+
+typedef struct fastp_gpu_results {
+    fastp_gpu_read_result* r1;      /* n                                       */
+    fastp_gpu_read_result* r2;      /* n (PE)                                  */
+    fastp_gpu_pair_result* pair;    /* n (PE)                                  */
+    fastp_gpu_correction* corrections; /* capacity entries, may be NULL        */
+    int32_t corrections_capacity;
+    int32_t* n_corrections;         /* out: number written                     */
+} fastp_gpu_results;
+
+/* ---- counter block -------------------------------------------------------
+ * All int64.  Mirrors Stats (stats.h:75-99), FilterResult (filterresult.h) and
+ * the insert-size histogram so the host can load it back into those objects
+ * and let the reference's own JsonReporter/HtmlReporter run unchanged.
+ * The per-cycle part of each Stats slot has the exact layout of
+ * Stats::mCycleBuffer with bufLen = cycles (stats.cpp:54-63):
+ *   [Q30[8] | Q20[8] | Content[8] | Qual[8] | TotalBase | TotalQual] x cycles
+ */
+enum {
+    FASTP_GPU_STATS_PRE1 = 0,
+    FASTP_GPU_STATS_POST1 = 1,
+    FASTP_GPU_STATS_PRE2 = 2,
+    FASTP_GPU_STATS_POST2 = 3
+};
+
+typedef struct fastp_gpu_counter_layout {
+    int64_t total;            /* number of int64 in the block                   */
+    int64_t cycles;           /* = fastp_gpu_cycles_for(params)                 */
+    int64_t filter_stats;     /* [32]   FilterResult::mFilterReadStats          */
+    int64_t adapter_reads;    /* [1]    mTrimmedAdapterRead                     */
+    int64_t adapter_bases;    /* [1]    mTrimmedAdapterBases                    */
+    int64_t polyx_reads;      /* [4]    mTrimmedPolyXReads (A,T,C,G)            */
+    int64_t polyx_bases;      /* [4]                                            */
+    int64_t correction;       /* [64]   mCorrectionMatrix                       */
+    int64_t corrected_reads;  /* [1]                                            */
+    int64_t merged_pairs;     /* [1]                                            */
+    int64_t dup_total;        /* [1]    Duplicate::mTotalReads                  */
+    int64_t dup_count;        /* [1]    Duplicate::mDupReads                    */
+    int64_t isize;            /* [insert_size_max+1]                            */
+    int64_t stats[4];         /* base offset of each Stats slot                 */
+    /* offsets inside a Stats slot */
+    int64_t st_reads;         /* [1]    mReads                                  */
+    int64_t st_length_sum;    /* [1]    mLengthSum                              */
+    int64_t st_qual_hist;     /* [128]  mBaseQualHistogram                      */
+    int64_t st_kmer;          /* [1024] mKmer (the used half, stats.cpp:45)     */
+    int64_t st_cycle;         /* [34*cycles]                                    */
+    int64_t st_size;
+} fastp_gpu_counter_layout;
+
+/* per-cycle capacity of the Stats slots: max_len, or 2*max_len in merge mode
+ * (a merged read can be as long as both mates; the reference grows its buffers
+ * on demand, Stats::extendBuffer stats.cpp:65-83) */
+int fastp_gpu_cycles_for(const fastp_gpu_params* params);
+void fastp_gpu_counter_layout_for(int cycles, int insert_size_max, fastp_gpu_counter_layout* out);
+
+/* ---- engine -------------------------------------------------------------- */
+typedef struct fastp_gpu_ctx fastp_gpu_ctx;
+
+/* device = HIP device ordinal.  Allocates the duplicate bitmaps, the counter
+ * block and the per-workgroup counter slabs in HBM. */
+int fastp_gpu_create(const fastp_gpu_params* params, int device, fastp_gpu_ctx** out);
+void fastp_gpu_destroy(fastp_gpu_ctx* ctx);
+const char* fastp_gpu_last_error(const fastp_gpu_ctx* ctx); /* ctx may be NULL */
+
+/* ASCII -> packed SoA rows (host code; the repack a patched worker loop does
+ * on its ReadPack before submit).  seqs[i]/quals[i] need not be 0-terminated.
+ * Returns FASTP_GPU_E_ALPHABET (and the index in *bad_read if non-NULL) when a
+ * base outside {A,C,G,T,N} is met, FASTP_GPU_E_TOO_LONG when lens[i] > max_len. */
+int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
+                         const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out,
+                         uint16_t* len_out, int32_t* bad_read);
+
+/* Process one batch whose buffers (and result buffers) live in HOST memory:
+ * H2D copy, kernels, D2H copy, synchronous. */
+int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, fastp_gpu_results* res);
+
+/* Process one batch whose buffers AND result buffers are DEVICE pointers.
+ * Asynchronous on `hip_stream` (a hipStream_t passed as void*; NULL = the
+ * context's own stream).  res->n_corrections must be a device pointer too. */
+int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch,
+                            fastp_gpu_results* res, void* hip_stream);
+
+/* wait for everything submitted on the context's stream */
+int fastp_gpu_synchronize(fastp_gpu_ctx* ctx);
+
+/* Device pointer to the reduced counter block (layout above) - the buffer a
+ * multi-GPU host all-reduces (RCCL sum, int64) in place of Stats::merge /
+ * FilterResult::merge (stats.cpp:877-955, filterresult.cpp:38-89).
+ * Folds any pending per-workgroup slabs first. */
+int fastp_gpu_counters_device(fastp_gpu_ctx* ctx, int64_t** dev_ptr, int64_t* n, void* hip_stream);
+
+/* copy the counter block to the host (n must equal layout.total) */
+int fastp_gpu_counters(fastp_gpu_ctx* ctx, int64_t* out, int64_t n);
+
+/* time spent inside the fused kernel for the launches since the last call,
+ * measured with HIP events on the launch stream: total milliseconds and
+ * number of launches (used by bench.py for the roofline object). */
+int fastp_gpu_kernel_time(fastp_gpu_ctx* ctx, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTP_GPU_H */

@@ -1,0 +1,83 @@
+"""Parity cases: the CLI flags given to the reference binary and the equivalent
+engine parameter block (main.cpp:176-427 + options.cpp:85-446 derivations)."""
+from fastp_amd import abi
+
+ADAPTER_R1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+ADAPTER_R2 = "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+
+
+def _pe(**kw):
+    def f(max_len):
+        p = abi.default_params(True, max_len)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+    return f
+
+
+def _se(**kw):
+    def f(max_len):
+        p = abi.default_params(False, max_len)
+        p.adapter_seq_r1 = None
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+    return f
+
+
+# name -> (paired, reference flags (besides -i/-I/-o/-O/-j/-h/-w 1), params factory, synth kwargs)
+# -G pins polyG off (the reference would otherwise guess from read names); SE cases pin
+# the adapter with -a or -A because SE auto-detection is Evaluator (host) logic.
+CASES = {
+    "pe_default": (True, ["-G"], _pe(), {}),
+    "pe_cut_right": (True, ["-G", "--cut_right"], _pe(cut_right=1), {}),
+    "pe_cut_front_tail": (True, ["-G", "--cut_front", "--cut_tail", "-W", "5", "-M", "18"],
+                          _pe(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5,
+                              cut_right_window=5, cut_front_quality=18, cut_tail_quality=18,
+                              cut_right_quality=18), {}),
+    "pe_polyg_polyx": (True, ["-g", "-x"], _pe(poly_g=1, poly_x=1),
+                       {"polyg_frac": 0.2, "polyx_frac": 0.2}),
+    "pe_adapter_seq": (True, ["-G", "-a", ADAPTER_R1, "--adapter_sequence_r2", ADAPTER_R2],
+                       _pe(adapter_seq_r1=ADAPTER_R1.encode(), adapter_seq_r2=ADAPTER_R2.encode()),
+                       {"insert_mean": 160.0}),
+    "pe_correction": (True, ["-G", "-c"], _pe(correction=1), {"insert_mean": 200.0}),
+    "pe_trim_fixed": (True, ["-G", "-f", "3", "-t", "2", "-F", "1", "-T", "4", "-b", "120", "-B", "100"],
+                      _pe(trim_front1=3, trim_tail1=2, trim_front2=1, trim_tail2=4, max_len1=120, max_len2=100),
+                      {}),
+    "pe_filters": (True, ["-G", "-q", "20", "-u", "30", "-n", "2", "-e", "25", "-l", "40", "--length_limit",
+                          "140", "-y", "-Y", "40", "--cut_tail"],
+                   _pe(qualified_qual=20, unqualified_percent_limit=30, n_base_limit=2, avg_qual_req=25,
+                       length_required=40, length_limit=140, complexity_filter=1, complexity_threshold=0.40,
+                       cut_tail=1), {}),
+    "pe_noadapter_dedup": (True, ["-G", "-A", "--dedup"],
+                           _pe(adapter_enabled=0, dedup=1, dup_accuracy_level=3), {"dup_frac": 0.3}),
+    "pe_nofilters": (True, ["-G", "-Q", "-L", "--dont_eval_duplication"],
+                     _pe(qual_filter=0, length_filter=0, dup_enabled=0), {}),
+    "pe_merge": (True, ["-G", "-m", "--merged_out", "@TMP@/merged.fq"], _pe(merge=1, correction=1),
+                 {"insert_mean": 220.0}),
+    "pe_merge_unmerged": (True, ["-G", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq"],
+                          _pe(merge=1, correction=1, merge_include_unmerged=1), {"insert_mean": 260.0}),
+    "pe_allow_gap": (True, ["-G", "--allow_gap_overlap_trimming", "-c"],
+                     _pe(allow_gap_overlap_trimming=1, correction=1), {"insert_mean": 150.0}),
+    "pe_umi_per_read": (True, ["-G", "-U", "--umi_loc", "per_read", "--umi_len", "6", "--umi_skip", "2"],
+                        _pe(umi_len1=6, umi_len2=6, umi_skip=2), {}),
+    "pe_overlap_knobs": (True, ["-G", "--overlap_len_require", "20", "--overlap_diff_limit", "8",
+                                "--overlap_diff_percent_limit", "10", "--dimer_max_len", "40"],
+                         _pe(overlap_require=20, overlap_diff_limit=8, overlap_diff_percent_limit=10,
+                             dimer_max_len=40), {"insert_mean": 120.0, "insert_sd": 60.0}),
+    "se_default_noadapter": (False, ["-G", "-A"], _se(adapter_enabled=0), {}),
+    "se_adapter_cut": (False, ["-g", "-a", ADAPTER_R1, "--cut_right", "--cut_front"],
+                       _se(adapter_seq_r1=ADAPTER_R1.encode(), poly_g=1, cut_right=1, cut_front=1),
+                       {"insert_mean": 140.0, "polyg_frac": 0.15}),
+    "se_umi_read1": (False, ["-G", "-A", "-U", "--umi_loc", "read1", "--umi_len", "8"],
+                     _se(adapter_enabled=0, umi_len1=8), {}),
+    "se_polyx_complexity": (False, ["-G", "-A", "-x", "-y", "--poly_x_min_len", "8"],
+                            _se(adapter_enabled=0, poly_x=1, poly_x_min_len=8, complexity_filter=1),
+                            {"polyx_frac": 0.3}),
+}
+
+# host-side UMI name editing that goes with a case (the engine only trims the sequence)
+UMI = {
+    "pe_umi_per_read": ("per_read", 6),
+    "se_umi_read1": ("read1", 8),
+}

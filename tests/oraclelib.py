@@ -1,0 +1,129 @@
+"""ctypes binding of oracle/liboracle.so - the CPU checker (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from fastp_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+class Overlap(C.Structure):
+    _fields_ = [("overlapped", C.c_int), ("offset", C.c_int), ("overlap_len", C.c_int),
+                ("diff", C.c_int), ("has_gap", C.c_int)]
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    src = os.path.join(ORACLE_DIR, "fastp_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"])
+    L = C.CDLL(so)
+    L.fastp_oracle_create.restype = C.c_void_p
+    L.fastp_oracle_create.argtypes = [C.POINTER(abi.Params)]
+    L.fastp_oracle_destroy.argtypes = [C.c_void_p]
+    L.fastp_oracle_process.restype = C.c_int
+    L.fastp_oracle_process.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(abi.Results)]
+    L.fastp_oracle_counters.restype = C.c_int
+    L.fastp_oracle_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fastp_oracle_counter_layout.argtypes = [C.c_int, C.c_int, C.POINTER(abi.CounterLayout)]
+    L.fastp_oracle_analyze.restype = Overlap
+    L.fastp_oracle_analyze.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.c_int]
+    L.fastp_oracle_trim_and_cut.restype = C.c_int
+    L.fastp_oracle_trim_and_cut.argtypes = [C.POINTER(abi.Params), C.c_char_p, C.c_char_p, C.c_int,
+                                            C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fastp_oracle_trim_poly_g.restype = C.c_int
+    L.fastp_oracle_trim_poly_g.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.fastp_oracle_trim_poly_x.restype = C.c_int
+    L.fastp_oracle_trim_poly_x.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fastp_oracle_trim_by_sequence.restype = C.c_int
+    L.fastp_oracle_trim_by_sequence.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                                C.POINTER(C.c_int)]
+    L.fastp_oracle_match_one_insertion.restype = C.c_int
+    L.fastp_oracle_match_one_insertion.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.fastp_oracle_pass_filter.restype = C.c_int
+    L.fastp_oracle_pass_filter.argtypes = [C.POINTER(abi.Params), C.c_char_p, C.c_char_p, C.c_int]
+    L.fastp_oracle_dup_hash.restype = C.c_int
+    L.fastp_oracle_dup_hash.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
+                                        C.POINTER(C.c_uint64)]
+    _LIB = L
+    return L
+
+
+def layout(cycles, insert_size_max):
+    lay = abi.CounterLayout()
+    lib().fastp_oracle_counter_layout(cycles, insert_size_max, C.byref(lay))
+    return lay
+
+
+class Oracle:
+    """One engine instance = one fastp run (Stats x4, FilterResult, Duplicate, isize hist)."""
+
+    def __init__(self, params: abi.Params):
+        self.params = params
+        self.h = lib().fastp_oracle_create(C.byref(params))
+        if not self.h:
+            raise RuntimeError("fastp_oracle_create failed")
+        self.layout = layout(abi.cycles_for(params), params.insert_size_max)
+
+    def close(self):
+        if self.h:
+            lib().fastp_oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process(self, seq1, qual1, len1, seq2=None, qual2=None, len2=None, flags=abi.BATCH_STAT_ISIZE,
+                corr_capacity=None):
+        """ASCII rows [n, stride] uint8 + int32 lens -> (r1, r2, pair, corrections) numpy records."""
+        n = int(len(len1))
+        stride = int(seq1.shape[1]) if n else 8
+        seq1 = np.ascontiguousarray(seq1, dtype=np.uint8)
+        qual1 = np.ascontiguousarray(qual1, dtype=np.uint8)
+        len1 = np.ascontiguousarray(len1, dtype=np.int32)
+        r1 = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
+        paired = seq2 is not None
+        r2 = np.zeros(n if paired else 0, dtype=abi.READ_RESULT_DTYPE)
+        pr = np.zeros(n if paired else 0, dtype=abi.PAIR_RESULT_DTYPE)
+        if corr_capacity is None:
+            corr_capacity = max(1024, n * 32)
+        corr = np.zeros(corr_capacity, dtype=abi.CORRECTION_DTYPE)
+        ncorr = C.c_int32(0)
+        res = abi.Results()
+        res.r1 = r1.ctypes.data
+        res.r2 = r2.ctypes.data if paired else None
+        res.pair = pr.ctypes.data if paired else None
+        res.corrections = corr.ctypes.data
+        res.corrections_capacity = corr_capacity
+        res.n_corrections = C.addressof(ncorr)
+        if paired:
+            seq2 = np.ascontiguousarray(seq2, dtype=np.uint8)
+            qual2 = np.ascontiguousarray(qual2, dtype=np.uint8)
+            len2 = np.ascontiguousarray(len2, dtype=np.int32)
+            assert seq2.shape[1] == stride
+            rc = lib().fastp_oracle_process(self.h, n, flags, stride, seq1.ctypes.data, qual1.ctypes.data,
+                                            len1.ctypes.data, seq2.ctypes.data, qual2.ctypes.data,
+                                            len2.ctypes.data, C.byref(res))
+        else:
+            rc = lib().fastp_oracle_process(self.h, n, flags, stride, seq1.ctypes.data, qual1.ctypes.data,
+                                            len1.ctypes.data, None, None, None, C.byref(res))
+        if rc != 0:
+            raise RuntimeError(f"fastp_oracle_process -> {rc}")
+        return r1, (r2 if paired else None), (pr if paired else None), corr[:ncorr.value].copy()
+
+    def counters(self):
+        out = np.zeros(self.layout.total, dtype=np.int64)
+        rc = lib().fastp_oracle_counters(self.h, out.ctypes.data, out.size)
+        assert rc == 0
+        return out
