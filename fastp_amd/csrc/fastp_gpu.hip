@@ -1,0 +1,452 @@
+// fastp_gpu.hip - C ABI of the engine (include/fastp_gpu.h) on the HIP runtime:
+// context, HBM buffers, kernel launches.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "fq_device.h"
+#include "fq_host.h"
+
+using namespace fq;
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(KernelArgs a) {
+    extern __shared__ u32 fq_lds[];
+    fused_body(a, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
+extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
+extern "C" __global__ void __launch_bounds__(256) fq_dup_resolve_kernel(DupArgs d) { dup_resolve_body(d); }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+struct fastp_gpu_ctx {
+    fastp_gpu_params params;
+    std::string adapter1, adapter2;
+    DevParams dp;
+    HostLuts luts;
+    TileConfig cfg;
+    LdsLayout L;
+    fastp_gpu_counter_layout cl;
+    int device = 0;
+    int cus = 0;
+    int blocks = 0;           // persistent workgroups per launch
+    int max_pairs_per_launch = 0;
+    hipStream_t stream = nullptr;
+    // device buffers
+    int16_t* d_ov_limit = nullptr;
+    u16* d_lowq = nullptr;
+    u16* d_cplx = nullptr;
+    u32* d_primes = nullptr;
+    u64* d_posum = nullptr;
+    int64_t* d_ctr = nullptr;
+    u32* d_slabs = nullptr;
+    int slab_dwords = 0;
+    u32* d_bitmap = nullptr;  // Duplicate::mDupBuf as u32 words
+    u64* d_dup_pos = nullptr; size_t dup_pos_cap = 0;
+    u64* d_table = nullptr; size_t table_cap = 0;
+    u8* d_need = nullptr; size_t need_cap = 0;
+    // staging for submit_host
+    void* d_stage = nullptr; size_t stage_cap = 0;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    double kernel_ms = 0.0;
+    int64_t kernel_launches = 0;
+    std::string err;
+};
+
+#define HIP_TRY(ctx, call)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            if (ctx) (ctx)->err = m_;                                                           \
+            g_last_error = m_;                                                                  \
+            return FASTP_GPU_E_HIP;                                                             \
+        }                                                                                       \
+    } while (0)
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static int fail(fastp_gpu_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+extern "C" const char* fastp_gpu_last_error(const fastp_gpu_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+static void drain_events(fastp_gpu_ctx* ctx) {
+    for (auto& pr : ctx->pending_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            ctx->kernel_ms += ms;
+            ctx->kernel_launches += 1;
+        }
+        ctx->free_events.push_back(pr);
+    }
+    ctx->pending_events.clear();
+}
+
+extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drain_events(ctx);
+    for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_ctr, ctx->d_slabs,
+                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_stage};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fastp_gpu_ctx** out) {
+    if (!params || !out) return fail(nullptr, FASTP_GPU_E_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FASTP_GPU_E_NO_DEVICE, "no HIP device visible - the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, FASTP_GPU_E_NO_DEVICE, "device ordinal out of range");
+    fastp_gpu_ctx* ctx = new fastp_gpu_ctx();
+    ctx->params = *params;
+    if (params->adapter_seq_r1) ctx->adapter1 = params->adapter_seq_r1;
+    if (params->adapter_seq_r2) ctx->adapter2 = params->adapter_seq_r2;
+    ctx->params.adapter_seq_r1 = ctx->adapter1.c_str();
+    ctx->params.adapter_seq_r2 = ctx->adapter2.c_str();
+    ctx->device = device;
+    std::string err;
+    int rc = build_dev_params(ctx->params, ctx->dp, ctx->luts, err);
+    if (rc) { delete ctx; return fail(nullptr, rc, err); }
+    hipError_t he = hipSetDevice(device);
+    if (he != hipSuccess) { delete ctx; return fail(nullptr, FASTP_GPU_E_HIP, "hipSetDevice failed"); }
+    hipDeviceProp_t prop;
+    he = hipGetDeviceProperties(&prop, device);
+    if (he != hipSuccess) { delete ctx; return fail(nullptr, FASTP_GPU_E_HIP, "hipGetDeviceProperties failed"); }
+    ctx->cus = prop.multiProcessorCount;
+    // tile / launch geometry (tunable without a rebuild)
+    const int lds_kb_default = (int)(prop.sharedMemPerBlock / 1024) >= 160 ? 156 : (int)(prop.sharedMemPerBlock / 1024) - 4;
+    ctx->cfg.threads = env_int("FASTP_GPU_THREADS", 512);
+    ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
+    ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", lds_kb_default) * 1024;
+    if (ctx->cfg.threads < 64 || ctx->cfg.threads > 1024 || (ctx->cfg.threads & 63)) {
+        delete ctx;
+        return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024");
+    }
+    rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err);
+    if (rc) { delete ctx; return fail(nullptr, rc, err); }
+    const int blocks_per_cu = env_int("FASTP_GPU_BLOCKS_PER_CU", std::max(1, (int)((160 * 1024) / (ctx->L.total * 4))));
+    ctx->blocks = ctx->cus * std::max(1, blocks_per_cu);
+    // a workgroup's packed per-cycle counters hold CYC_MAX_READS reads per Stats slot
+    const int tiles_per_block = CYC_MAX_READS / ctx->L.P;
+    if (tiles_per_block < 1) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "tile too large for the packed counters"); }
+    long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
+    if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
+    mp = mp / ctx->L.P * ctx->L.P;
+    ctx->max_pairs_per_launch = (int)mp;
+    fastp_gpu_counter_layout_for(ctx->dp.cycles, ctx->dp.isize_max, &ctx->cl);
+    ctx->slab_dwords = ctx->L.acc_end - ctx->L.acc_cyc;
+
+    *out = ctx;  // from here on errors go through destroy
+#define CREATE_TRY(call)                                               \
+    do {                                                               \
+        int r_ = [&]() -> int { HIP_TRY(ctx, call); return 0; }();     \
+        if (r_) { std::string m = ctx->err; fastp_gpu_destroy(ctx); *out = nullptr; return fail(nullptr, r_, m); } \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
+        if (bytes == 0) { *dptr = nullptr; return 0; }
+        HIP_TRY(ctx, hipMalloc(dptr, bytes));
+        HIP_TRY(ctx, hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice));
+        return 0;
+    };
+#define CREATE_RC(expr)                                                                                    \
+    do {                                                                                                   \
+        int r_ = (expr);                                                                                   \
+        if (r_) { std::string m = ctx->err; fastp_gpu_destroy(ctx); *out = nullptr; return fail(nullptr, r_, m); } \
+    } while (0)
+    CREATE_RC(upload((void**)&ctx->d_ov_limit, ctx->luts.ov_limit.data(), ctx->luts.ov_limit.size() * 2));
+    CREATE_RC(upload((void**)&ctx->d_lowq, ctx->luts.lowq_limit.data(), ctx->luts.lowq_limit.size() * 2));
+    CREATE_RC(upload((void**)&ctx->d_cplx, ctx->luts.cplx_min.data(), ctx->luts.cplx_min.size() * 2));
+    CREATE_RC(upload((void**)&ctx->d_primes, ctx->luts.dup_primes.data(), ctx->luts.dup_primes.size() * 4));
+    CREATE_RC(upload((void**)&ctx->d_posum, ctx->luts.dup_posum.data(), ctx->luts.dup_posum.size() * 8));
+    {
+        std::vector<int64_t> zero((size_t)ctx->cl.total, 0);
+        zero[0] = FASTP_GPU_ABI_VERSION;
+        zero[1] = ctx->cl.cycles;
+        zero[2] = ctx->dp.isize_max;
+        CREATE_RC(upload((void**)&ctx->d_ctr, zero.data(), zero.size() * 8));
+    }
+    CREATE_TRY(hipMalloc((void**)&ctx->d_slabs, (size_t)ctx->blocks * ctx->slab_dwords * 4));
+    if (ctx->dp.dup_enabled) {
+        const size_t bytes = (size_t)(ctx->dp.dup_bits >> 3) * ctx->dp.dup_bufnum;
+        CREATE_TRY(hipMalloc((void**)&ctx->d_bitmap, bytes));
+        CREATE_TRY(hipMemsetAsync(ctx->d_bitmap, 0, bytes, ctx->stream));
+    }
+    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+    return FASTP_GPU_OK;
+}
+
+static int ensure(fastp_gpu_ctx* ctx, void** buf, size_t* cap, size_t need) {
+    if (*cap >= need) return 0;
+    if (*buf) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+    size_t want = need + need / 4;
+    HIP_TRY(ctx, hipMalloc(buf, want));
+    *cap = want;
+    return 0;
+}
+
+static int get_events(fastp_gpu_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
+    if (ctx->pending_events.size() >= 64) drain_events(ctx);
+    if (!ctx->free_events.empty()) {
+        *a = ctx->free_events.back().first;
+        *b = ctx->free_events.back().second;
+        ctx->free_events.pop_back();
+        return 0;
+    }
+    HIP_TRY(ctx, hipEventCreate(a));
+    HIP_TRY(ctx, hipEventCreate(b));
+    return 0;
+}
+
+// one launch: at most ctx->max_pairs_per_launch units
+static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first, int n, fastp_gpu_results* res,
+                        hipStream_t st) {
+    KernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = ctx->dp;
+    a.lut.ov_limit = (const u16*)ctx->d_ov_limit;
+    a.lut.lowq_limit = ctx->d_lowq;
+    a.lut.cplx_min = ctx->d_cplx;
+    a.lut.dup_primes = ctx->d_primes;
+    a.lut.dup_posum = ctx->d_posum;
+    a.L = ctx->L;
+    a.magic_sw = magic_for((u32)ctx->L.SW);
+    a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
+    a.n = n;
+    a.batch_flags = b->flags;
+    const size_t swg = ctx->dp.sw_g, qwg = ctx->dp.qw_g;
+    a.seq[0] = (const u32*)b->seq1 + (size_t)first * swg;
+    a.qual[0] = (const u32*)b->qual1 + (size_t)first * qwg;
+    a.len[0] = b->len1 + first;
+    a.res[0] = (u32*)res->r1 + (size_t)first * 3;
+    if (ctx->dp.paired) {
+        a.seq[1] = (const u32*)b->seq2 + (size_t)first * swg;
+        a.qual[1] = (const u32*)b->qual2 + (size_t)first * qwg;
+        a.len[1] = b->len2 + first;
+        a.res[1] = (u32*)res->r2 + (size_t)first * 3;
+        a.pair = (u32*)res->pair + (size_t)first * 2;
+    }
+    a.corrections = (ctx->dp.correction && res->corrections && res->n_corrections) ? (u32*)res->corrections : nullptr;
+    a.corr_capacity = res->corrections_capacity;
+    a.n_corrections = res->n_corrections;
+    if (ctx->dp.dup_enabled) {
+        int rc = ensure(ctx, (void**)&ctx->d_dup_pos, &ctx->dup_pos_cap, (size_t)n * ctx->dp.dup_bufnum * 8);
+        if (rc) return rc;
+        a.dup_pos = ctx->d_dup_pos;
+    }
+    a.slabs = ctx->d_slabs;
+    a.slab_dwords = ctx->slab_dwords;
+    a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
+    const int grid = a.tiles < ctx->blocks ? a.tiles : ctx->blocks;
+    hipEvent_t e0, e1;
+    int rc = get_events(ctx, &e0, &e1);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    ctx->pending_events.push_back({e0, e1});
+
+    ReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.slabs = ctx->d_slabs;
+    r.slab_dwords = ctx->slab_dwords;
+    r.nblocks = grid;
+    r.L = ctx->L;
+    r.isize_max = ctx->dp.isize_max;
+    r.ctr = ctx->d_ctr;
+    const fastp_gpu_counter_layout& cl = ctx->cl;
+    r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
+    r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;
+    r.o_corrected_reads = cl.corrected_reads; r.o_merged = cl.merged_pairs; r.o_isize = cl.isize;
+    for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
+    r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
+    r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
+    const int items = 4 * ctx->L.C + 4 * KMER_BINS + 4 * 128 + MISC_ISIZE + ctx->dp.isize_max + 1;
+    hipLaunchKernelGGL(fq_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, st, r);
+    HIP_TRY(ctx, hipGetLastError());
+
+    if (ctx->dp.dup_enabled) {
+        DupArgs d;
+        memset(&d, 0, sizeof(d));
+        d.dup_pos = ctx->d_dup_pos;
+        d.n = n;
+        d.B = ctx->dp.dup_bufnum;
+        d.bits = ctx->dp.dup_bits;
+        d.bitmap = ctx->d_bitmap;
+        int lg = 10;
+        while ((1ull << lg) < (size_t)n * d.B * 2) lg++;
+        rc = ensure(ctx, (void**)&ctx->d_table, &ctx->table_cap, (size_t)8 << lg);
+        if (rc) return rc;
+        rc = ensure(ctx, (void**)&ctx->d_need, &ctx->need_cap, (size_t)n);
+        if (rc) return rc;
+        d.table = ctx->d_table;
+        d.table_log2 = lg;
+        d.need = ctx->d_need;
+        d.res[0] = a.res[0];
+        d.res[1] = a.res[1];
+        d.paired = ctx->dp.paired;
+        d.ctr_total = ctx->d_ctr + cl.dup_total;
+        d.ctr_dups = ctx->d_ctr + cl.dup_count;
+        HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
+        const int g2 = std::min(ctx->cus * 8, (n + 255) / 256);
+        hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(g2), dim3(256), 0, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res,
+                                       void* hip_stream) {
+    if (!ctx || !b || !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    if (b->n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "negative batch size");
+    if (!b->seq1 || !b->qual1 || !b->len1 || !res->r1) {
+        if (b->n > 0) return fail(ctx, FASTP_GPU_E_INVALID, "missing read-1 buffers");
+    }
+    if (ctx->dp.paired && b->n > 0 && (!b->seq2 || !b->qual2 || !b->len2 || !res->r2 || !res->pair))
+        return fail(ctx, FASTP_GPU_E_INVALID, "paired engine needs read-2 buffers and pair results");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
+    for (int first = 0; first < b->n; first += ctx->max_pairs_per_launch) {
+        const int n = std::min(ctx->max_pairs_per_launch, b->n - first);
+        int rc = launch_chunk(ctx, b, first, n, res, st);
+        if (rc) return rc;
+    }
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_synchronize(fastp_gpu_ctx* ctx) {
+    if (!ctx) return FASTP_GPU_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res) {
+    if (!ctx || !b || !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    if (b->n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "negative batch size");
+    if (b->n == 0) { if (res->n_corrections) *res->n_corrections = 0; return FASTP_GPU_OK; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)b->n;
+    const size_t ss = fastp_gpu_seq_stride(ctx->dp.max_len), qs = fastp_gpu_qual_stride(ctx->dp.max_len);
+    const int mates = ctx->dp.paired ? 2 : 1;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t per_mate_in = al(n * ss) + al(n * qs) + al(n * 2);
+    const size_t per_mate_out = al(n * sizeof(fastp_gpu_read_result));
+    const size_t pair_out = ctx->dp.paired ? al(n * sizeof(fastp_gpu_pair_result)) : 0;
+    const size_t corr_out = (res->corrections && res->corrections_capacity > 0)
+                                ? al((size_t)res->corrections_capacity * sizeof(fastp_gpu_correction)) : 0;
+    const size_t total = mates * (per_mate_in + per_mate_out) + pair_out + corr_out + 256;
+    int rc = ensure(ctx, &ctx->d_stage, &ctx->stage_cap, total);
+    if (rc) return rc;
+    char* base = (char*)ctx->d_stage;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += al(bytes); return p; };
+    fastp_gpu_batch db = *b;
+    fastp_gpu_results dr = *res;
+    hipStream_t st = ctx->stream;
+    const void* hs[2][3] = {{b->seq1, b->qual1, b->len1}, {b->seq2, b->qual2, b->len2}};
+    void* dsq[2][3];
+    for (int m = 0; m < mates; m++) {
+        if (!hs[m][0] || !hs[m][1] || !hs[m][2]) return fail(ctx, FASTP_GPU_E_INVALID, "missing input buffer");
+        dsq[m][0] = take(n * ss);
+        dsq[m][1] = take(n * qs);
+        dsq[m][2] = take(n * 2);
+        HIP_TRY(ctx, hipMemcpyAsync(dsq[m][0], hs[m][0], n * ss, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dsq[m][1], hs[m][1], n * qs, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dsq[m][2], hs[m][2], n * 2, hipMemcpyHostToDevice, st));
+    }
+    db.seq1 = (const uint8_t*)dsq[0][0]; db.qual1 = (const uint8_t*)dsq[0][1]; db.len1 = (const uint16_t*)dsq[0][2];
+    if (mates == 2) {
+        db.seq2 = (const uint8_t*)dsq[1][0]; db.qual2 = (const uint8_t*)dsq[1][1]; db.len2 = (const uint16_t*)dsq[1][2];
+    }
+    dr.r1 = (fastp_gpu_read_result*)take(n * sizeof(fastp_gpu_read_result));
+    if (mates == 2) {
+        dr.r2 = (fastp_gpu_read_result*)take(n * sizeof(fastp_gpu_read_result));
+        dr.pair = (fastp_gpu_pair_result*)take(n * sizeof(fastp_gpu_pair_result));
+    }
+    if (corr_out) dr.corrections = (fastp_gpu_correction*)take((size_t)res->corrections_capacity * sizeof(fastp_gpu_correction));
+    else { dr.corrections = nullptr; dr.corrections_capacity = 0; }
+    dr.n_corrections = (int32_t*)take(sizeof(int32_t));
+    rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(res->r1, dr.r1, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
+    if (mates == 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(res->r2, dr.r2, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(res->pair, dr.pair, n * sizeof(fastp_gpu_pair_result), hipMemcpyDeviceToHost, st));
+    }
+    int32_t ncorr = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&ncorr, dr.n_corrections, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (res->n_corrections) *res->n_corrections = ncorr;
+    if (corr_out && ncorr > 0) {
+        if (ncorr > res->corrections_capacity) {
+            if (res->n_corrections) *res->n_corrections = res->corrections_capacity;
+            HIP_TRY(ctx, hipMemcpy(res->corrections, dr.corrections,
+                                   (size_t)res->corrections_capacity * sizeof(fastp_gpu_correction), hipMemcpyDeviceToHost));
+            return fail(ctx, FASTP_GPU_E_OVERFLOW, "correction list capacity exceeded");
+        }
+        HIP_TRY(ctx, hipMemcpy(res->corrections, dr.corrections, (size_t)ncorr * sizeof(fastp_gpu_correction),
+                               hipMemcpyDeviceToHost));
+    }
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_counters_device(fastp_gpu_ctx* ctx, int64_t** dev_ptr, int64_t* n, void* hip_stream) {
+    if (!ctx || !dev_ptr || !n) return FASTP_GPU_E_INVALID;
+    (void)hip_stream;  // slabs are folded right after every launch, on the launch stream
+    *dev_ptr = ctx->d_ctr;
+    *n = ctx->cl.total;
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_counters(fastp_gpu_ctx* ctx, int64_t* out, int64_t n) {
+    if (!ctx || !out || n != ctx->cl.total) return fail(ctx, FASTP_GPU_E_INVALID, "counter block size mismatch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());  // submits may have used a caller-provided stream
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_ctr, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_kernel_time(fastp_gpu_ctx* ctx, double* total_ms, int64_t* launches) {
+    if (!ctx) return FASTP_GPU_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    drain_events(ctx);
+    if (total_ms) *total_ms = ctx->kernel_ms;
+    if (launches) *launches = ctx->kernel_launches;
+    ctx->kernel_ms = 0.0;
+    ctx->kernel_launches = 0;
+    return FASTP_GPU_OK;
+}

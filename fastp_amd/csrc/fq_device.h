@@ -1,0 +1,1191 @@
+// fq_device.h - the fused per-read kernel of the MI355X FASTQ engine (gfx950).
+//
+// One workgroup owns a TILE of P read pairs (or P single reads) staged in LDS as
+// 2-bit bases + N mask + quality bytes, runs every per-read step of fastp's
+// worker loop on it (reference: src/peprocessor.cpp:383-643,
+// src/seprocessor.cpp:204-296) and accumulates the Stats / FilterResult
+// counters in LDS-privatised histograms that are flushed once per launch.
+//
+// Phases (block_sync between them), each with the lane mapping that suits it:
+//   A  load      : coalesced dword copy HBM -> LDS, build N masks
+//   B  pre-stats : lane = 4 consecutive cycles of one read  (Stats::statRead)
+//   C  trim      : lane = one read   (dup hash, UMI, Filter::trimAndCut, polyG)
+//   D  overlap   : wave = one pair, lane = one candidate offset
+//                  (OverlapAnalysis::analyze, __ballot picks the first accept)
+//   E  decide    : lane = one pair   (isize, BaseCorrector, AdapterTrimmer,
+//                  polyX, max_len, Filter::passFilter, result records)
+//   F  post-stats: as B, on the surviving window of the reads that pass
+//
+// Integer / byte work only: no MFMA.  Every function cites the reference lines
+// whose behaviour it reproduces (paths relative to the reference root).
+#pragma once
+#include "fq_intrin.h"
+
+namespace fq {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+FQ_DEV u32 lowmask32(int nbits) { return nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u); }
+FQ_DEV int imin(int a, int b) { return a < b ? a : b; }
+FQ_DEV int imax(int a, int b) { return a > b ? a : b; }
+
+// 32-bit window (16 bases) of a packed row starting at base position bp >= 0
+FQ_DEV u32 window16(const u32* row, int bp) {
+    const int w = bp >> 4;
+    return alignbit(row[w + 1], row[w], (u32)((bp & 15) * 2));
+}
+// same, bp may be in [-15, -1]: the missing low bases read as zero
+FQ_DEV u32 window16_signed(const u32* row, int bp) {
+    if (bp >= 0) return window16(row, bp);
+    return row[0] << (u32)(-bp * 2);
+}
+// 2-bit groups differ -> bit 2k set
+FQ_DEV u32 fold_diff(u32 x) { return (x | (x >> 1)) & 0x55555555u; }
+// reverse the order of the 16 2-bit groups of a word
+FQ_DEV u32 reverse_groups(u32 x) {
+    const u32 r = brev32(x);
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+// exact division of small non-negative n by d via a host-computed reciprocal
+FQ_DEV u32 fastdiv(u32 n, u32 magic) { return __umulhi(n, magic); }
+
+struct Rows {  // LDS views of one read
+    const u32* s;  // packed bases
+    const u32* n;  // N mask (bit 2k = base k is N)
+    const u8* q;   // quality bytes (bit 7 = N)
+};
+
+FQ_DEV u32* lds_seq(const LdsLayout& L, u32* lds, int R) { return lds + L.seq + R * L.SW; }
+FQ_DEV u32* lds_nmk(const LdsLayout& L, u32* lds, int R) { return lds + L.nmk + R * L.SW; }
+FQ_DEV u32* lds_qual(const LdsLayout& L, u32* lds, int R) { return lds + L.qual + R * L.QW; }
+FQ_DEV int* lds_i(u32* lds, int off) { return (int*)(lds + off); }
+
+FQ_DEV u32 code_at(const u32* srow, int j) { return (srow[j >> 4] >> ((j & 15) * 2)) & 3u; }
+FQ_DEV u32 qchar_at(const u8* q, int j) { return q[j] & 0x7Fu; }
+FQ_DEV bool isn_at(const u8* q, int j) { return (q[j] & 0x80u) != 0; }
+// symbol 0..3 = A,T,C,G ; 4 = N
+FQ_DEV u32 sym_at(const u32* srow, const u8* q, int j) { return isn_at(q, j) ? 4u : code_at(srow, j); }
+// util.h:16-33 on symbols: A<->T, C<->G, N->N
+FQ_DEV u32 sym_complement(u32 s) { return s == 4u ? 4u : (s ^ 1u); }
+
+// ---------------------------------------------------------------------------
+// Phase A: load one tile
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const u32 magic_sw = a.magic_sw, magic_qwg = a.magic_qwg;
+    const LdsLayout& L = a.L;
+    const int mates = a.p.paired ? 2 : 1;
+    const int P = L.P;
+    const int swg = a.p.sw_g, qwg = a.p.qw_g;
+    // per-read state + lengths
+    for (int R = tid; R < L.NR; R += nthreads) {
+        const int m = R >= P ? 1 : 0;
+        const int gp = tile_first + (R - m * P);
+        const int len = gp < a.n ? (int)a.len[m][gp] : 0;
+        lds_i(lds, L.rlen0)[R] = len;
+        lds_i(lds, L.front)[R] = 0;
+        lds_i(lds, L.len)[R] = len;
+        lds_i(lds, L.flags)[R] = 0;
+        lds_i(lds, L.ft)[R] = 0;
+        lds_i(lds, L.apos)[R] = 0;
+        lds_i(lds, L.alen)[R] = 0;
+        lds_i(lds, L.code)[R] = 0;
+        if (R < P) {
+            lds_i(lds, L.ov_off)[R] = 0;
+            lds_i(lds, L.ov_len)[R] = 0;
+            lds_i(lds, L.ov_diff)[R] = 0;
+            lds_i(lds, L.ov_flags)[R] = 0;
+        }
+    }
+    // packed bases (+ zero the N masks and the pad words)
+    for (int m = 0; m < mates; m++) {
+        const u32* g = a.seq[m];
+        const int total = P * L.SW;
+        for (int idx = tid; idx < total; idx += nthreads) {
+            const int row = (int)fastdiv((u32)idx, magic_sw);  // idx / SW
+            const int col = idx - row * L.SW;
+            const int gp = tile_first + row;
+            u32 v = 0;
+            if (col < swg && gp < a.n) v = g[(size_t)gp * swg + col];
+            lds[L.seq + (m * P + row) * L.SW + col] = v;
+            lds[L.nmk + (m * P + row) * L.SW + col] = 0;
+        }
+    }
+    block_sync();
+    // quality bytes; derive the N masks from bit 7
+    for (int m = 0; m < mates; m++) {
+        const u32* g = a.qual[m];
+        const int total = P * qwg;
+        for (int idx = tid; idx < total; idx += nthreads) {
+            const int row = (int)fastdiv((u32)idx, magic_qwg);  // idx / qwg
+            const int col = idx - row * qwg;
+            const int gp = tile_first + row;
+            const int R = m * P + row;
+            u32 v = 0;
+            if (gp < a.n) v = g[(size_t)gp * qwg + col];
+            lds[L.qual + R * L.QW + col] = v;
+            const u32 nb = (v >> 7) & 0x01010101u;
+            if (nb) {
+                const u32 t = (nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u;
+                lds_or_u32(&lds[L.nmk + R * L.SW + (col >> 2)], t << ((col & 3) * 8));
+                lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+            }
+        }
+        // pad column(s) of the LDS quality rows
+        for (int R = tid; R < P; R += nthreads)
+            for (int c = qwg; c < L.QW; c++) lds[L.qual + (m * P + R) * L.QW + c] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Phases B / F: Stats::statRead (stats.cpp:191-291) over a tile.
+// lane = (read R, quality dword c) = cycles 4c..4c+3 of that read.
+// post == false : every read, window [0, rlen0)      -> slots PRE1 / PRE2
+// post == true  : reads flagged RS_STAT_POST, window [front, front+len) -> POST1 / POST2
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, bool post, int n_valid, int tid, int nthreads) {
+    const u32 magic_qwg = a.magic_qwg;
+    const LdsLayout& L = a.L;
+    const int qwg = a.p.qw_g;
+    const int total = L.NR * qwg;
+    const int C = L.C;
+    u64* cyc_all = (u64*)(lds + L.acc_cyc);
+    u32* kmer_all = lds + L.acc_kmer;
+    u32* qh_all = lds + L.acc_qh;
+    u32* misc = lds + L.acc_misc;
+    const int copy = tid & (QH_COPIES - 1);
+    for (int idx = tid; idx < total; idx += nthreads) {
+        const int R = (int)fastdiv((u32)idx, magic_qwg);
+        const int c = idx - R * qwg;
+        const int m = R >= L.P ? 1 : 0;
+        int f = 0, l = lds_i(lds, L.rlen0)[R];
+        if (post) {
+            if (!(lds_i(lds, L.flags)[R] & RS_STAT_POST)) continue;
+            f = lds_i(lds, L.front)[R];
+            l = lds_i(lds, L.len)[R];
+        } else if (R - m * L.P >= n_valid) {
+            continue;  // rows past the end of the batch do not exist
+        }
+        const int slot = m * 2 + (post ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
+        if (c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
+            lds_add_u32(&misc[MISC_STAT_READS + slot], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + slot], (u32)l);
+        }
+        const int j0 = c * 4;
+        if (j0 >= f + l || j0 + 4 <= f) continue;
+        const u32* srow = lds + L.seq + R * L.SW;
+        const u32 qd = lds[L.qual + R * L.QW + c];
+        const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
+        u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
+        if (c > 0) {
+            prev8 = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8)) & 0xFFu;
+            const u32 qp = lds[L.qual + R * L.QW + c - 1];
+            const u32 nb = (qp >> 7) & 0x01010101u;
+            nprev = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;  // bit k = base j0-4+k is N
+        }
+        const u32 nbc = (qd >> 7) & 0x01010101u;
+        const u32 ncur = (nbc | (nbc >> 7) | (nbc >> 14) | (nbc >> 21)) & 0xFu;
+        const u32 codes = prev8 | (cur8 << 8);   // bases j0-4 .. j0+3, 2 bits each
+        const u32 nbits = nprev | (ncur << 4);   // same 8 bases, 1 bit each
+        u64* cyc = cyc_all + (size_t)slot * N_CLS * C;
+        u32* kmer = kmer_all + slot * KMER_BINS;
+        u32* qh = qh_all + slot * 128 * QH_COPIES;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + k;
+            if (j < f || j >= f + l) continue;
+            const int pos = j - f;
+            const u32 q = (qd >> (k * 8)) & 0x7Fu;
+            const u32 isn = (ncur >> k) & 1u;
+            const u32 cls = isn ? (u32)CLS_N : ((codes >> (8 + 2 * k)) & 3u);
+            // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
+            const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
+                            ((u64)(q - 33u) << CYC_QSUM_SHIFT);
+            lds_add_u64(&cyc[cls * C + pos], inc);
+            lds_add_u32(&qh[q * QH_COPIES + copy], 1u);  // mBaseQualHistogram[qual]++ (:207)
+            // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
+            // pos-4..pos all exist in the window and none of them is N
+            if (pos >= 4 && ((nbits >> k) & 0x1Fu) == 0u) {
+                const u32 km = (codes >> (2 * k)) & 0x3FFu;  // earliest base in the low bits
+                lds_add_u32(&kmer[km], 1u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Filter::trimAndCut (filter.cpp:68-207) on one read.  Returns false for NULL.
+// q = quality bytes (bit 7 = N flag) of the read as it is now (after UMI trim).
+// ---------------------------------------------------------------------------
+FQ_DEV bool trim_and_cut(const DevParams& p, const u8* q, int len, int front, int tail, int& out_front,
+                         int& out_len) {
+    out_front = 0;
+    out_len = len;
+    const bool enF = p.cut_front, enT = p.cut_tail, enR = p.cut_right;
+    if (front == 0 && tail == 0 && !enF && !enT && !enR) return true;  // :71-72
+    int rlen = len - front - tail;
+    if (rlen < 0) return false;  // :76-77
+    if (!enF && !enT && !enR) {  // :79-89
+        out_front = front;
+        out_len = rlen;
+        return true;
+    }
+    const int l = len;
+    if (enF) {  // :97-127
+        const int w = p.wF;
+        int s = front;
+        if (l - front - tail - w <= 0) return false;
+        int total = 0;
+        for (int i = 0; i < w - 1; i++) total += (int)(q[s + i] & 0x7F);
+        for (s = front; s + w < l - tail; s++) {
+            total += (int)(q[s + w - 1] & 0x7F);
+            if (s > front) total -= (int)(q[s - 1] & 0x7F);
+            if (total >= p.thrF) break;
+        }
+        if (s > 0) s = s + w - 1;
+        while (s < l && (q[s] & 0x80)) s++;  // seq[s] == 'N'
+        front = s;
+        rlen = l - front - tail;
+    }
+    if (enR) {  // :130-163
+        const int w = p.wR;
+        int s = front;
+        if (l - front - tail - w <= 0) return false;
+        int total = 0;
+        for (int i = 0; i < w - 1; i++) total += (int)(q[s + i] & 0x7F);
+        bool found = false;
+        for (s = front; s + w < l - tail; s++) {
+            total += (int)(q[s + w - 1] & 0x7F);
+            if (s > front) total -= (int)(q[s - 1] & 0x7F);
+            if (total < p.thrR) { found = true; break; }
+        }
+        if (found) {
+            while (s < l - 1 && (int)(q[s] & 0x7F) >= p.qRmin) s++;
+            rlen = s - front;
+        }
+    }
+    if (!enR && enT) {  // :166-194
+        const int w = p.wT;
+        if (l - front - tail - w <= 0) return false;
+        int total = 0;
+        int t = l - tail - 1;
+        for (int i = 0; i < w - 1; i++) total += (int)(q[t - i] & 0x7F);
+        for (t = l - tail - 1; t - w >= front; t--) {
+            total += (int)(q[t - w + 1] & 0x7F);
+            if (t < l - tail - 1) total -= (int)(q[t + 1] & 0x7F);
+            if (total >= p.thrT) break;
+        }
+        if (t < l - 1) t = t - w + 1;
+        while (t >= 0 && (q[t] & 0x80)) t--;
+        rlen = t - front + 1;
+    }
+    if (rlen <= 0 || front >= l - 1) return false;  // :196-197
+    out_front = front;
+    out_len = rlen;
+    return true;
+}
+
+// PolyX::trimPolyG (polyx.cpp:16-42): new length of the read [f, f+rlen)
+FQ_DEV int trim_poly_g(const u32* srow, const u8* q, int f, int rlen, int compareReq) {
+    int mismatch = 0, i = 0, firstGPos = rlen - 1;
+    for (i = 0; i < rlen; i++) {
+        const int j = f + rlen - i - 1;
+        if (sym_at(srow, q, j) != (u32)CODE_G) mismatch++;
+        else firstGPos = rlen - i - 1;
+        const int allowed = (i + 1) / 8;
+        if (mismatch > 5 || (mismatch > allowed && i >= compareReq - 1)) break;
+    }
+    if (i >= compareReq && firstGPos >= 0) return firstGPos;
+    return rlen;
+}
+
+// PolyX::trimPolyX (polyx.cpp:49-116).  poly = -1 when nothing is recorded.
+FQ_DEV int trim_poly_x(const u32* srow, const u8* q, int f, int rlen, int compareReq, int& poly, int& trimmed) {
+    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    int pos = 0;
+    poly = -1;
+    trimmed = 0;
+    for (pos = 0; pos < rlen; pos++) {
+        const u32 s = sym_at(srow, q, f + rlen - pos - 1);
+        cnt0 += (s == 0u) | (s == 4u);  // N counts toward all (:79-85)
+        cnt1 += (s == 1u) | (s == 4u);
+        cnt2 += (s == 2u) | (s == 4u);
+        cnt3 += (s == 3u) | (s == 4u);
+        const int cmp = pos + 1;
+        const int allowed = imin(5, cmp / 8);
+        const bool needToBreak = !((cmp - cnt0 <= allowed) | (cmp - cnt1 <= allowed) | (cmp - cnt2 <= allowed) |
+                                   (cmp - cnt3 <= allowed));
+        if (needToBreak && (pos >= 8 || pos + 1 >= compareReq - 1)) break;
+    }
+    if (pos + 1 >= compareReq) {  // :98-115
+        int best = 0, mx = cnt0;  // first maximum in the order A,T,C,G
+        if (cnt1 > mx) { mx = cnt1; best = 1; }
+        if (cnt2 > mx) { mx = cnt2; best = 2; }
+        if (cnt3 > mx) { mx = cnt3; best = 3; }
+        // :109  while(data[rlen-pos-1] != polyBase && pos>=0) pos--;
+        // index -1 (scan never broke) and index rlen (terminating 0) never equal the poly base
+        for (;;) {
+            const int idx = rlen - pos - 1;
+            const bool is_poly = (idx >= 0 && idx < rlen) && sym_at(srow, q, f + idx) == (u32)best;
+            if (!(!is_poly && pos >= 0)) break;
+            pos--;
+        }
+        poly = best;
+        trimmed = pos + 1;
+        const int newlen = rlen - pos - 1;
+        if (newlen < 0 || newlen > rlen) return rlen;  // Read::resize ignores (read.cpp:62-64)
+        return newlen;
+    }
+    return rlen;
+}
+
+// Duplicate::seq2intvector (duplicate.cpp:111-120), the base-value part:
+//   sum_p prime[((p+off)*B+i) & mask] * val(base_p)       (val: A7 T222 C74 G31 else 13)
+// the position part sum_p prime[...]*(p+off) only depends on the lengths and comes
+// from a host-built prefix table (DevLuts::dup_posum).
+FQ_DEV u64 dup_hash_bases(const u32* srow, const u8* q, int len, int off, int B, int i, const u32* primes) {
+    const u32 mask = (u32)(512 * B - 1);
+    u64 acc = 0;
+    for (int p = 0; p < len; p++) {
+        const u32 s = sym_at(srow, q, p);
+        const u32 val = s == 4u ? 13u : ((0x1F4ADE07u >> (s * 8)) & 0xFFu);  // A7 T222 C74 G31
+        const u32 pr = primes[(((u32)(p + off)) * (u32)B + (u32)i) & mask];
+        acc += (u64)pr * (u64)val;
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------
+// Phase C: lane = one read.  Dup hash on the ORIGINAL read (peprocessor.cpp:398,
+// quirk #11), UMI front trim (umiprocessor.cpp:19-49 / read.cpp:69-73), then
+// Filter::trimAndCut.
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    for (int R = tid; R < L.NR; R += nthreads) {
+        const int m = R >= L.P ? 1 : 0;
+        const int pr = R - m * L.P;
+        const u32* srow = lds_seq(L, lds, R);
+        const u8* q = (const u8*)lds_qual(L, lds, R);
+        int len = lds_i(lds, L.rlen0)[R];
+        if (p.dup_enabled) {
+            const int off = m ? lds_i(lds, L.rlen0)[pr] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
+            u64* h = (u64*)(lds + L.hash) + (size_t)R * p.dup_bufnum;
+            for (int i = 0; i < p.dup_bufnum; i++)
+                h[i] = dup_hash_bases(srow, q, len, off, p.dup_bufnum, i, lds + L.primes);
+        }
+        int front = 0;
+        const int umi = m ? p.umi_len2 : p.umi_len1;
+        if (umi > 0) {  // Read::trimFront(min(len,umi)+skip): len = min(length()-1, len)
+            int t = imin(len, umi) + p.umi_skip;
+            t = imin(len - 1, t);
+            if (t > 0) { front = t; len -= t; }
+        }
+        int f2 = 0, l2 = len;
+        const bool alive = trim_and_cut(p, q + front, len, m ? p.trim_front2 : p.trim_front1,
+                                        m ? p.trim_tail2 : p.trim_tail1, f2, l2);
+        if (alive) {
+            lds_i(lds, L.front)[R] = front + f2;
+            lds_i(lds, L.len)[R] = l2;
+            lds_i(lds, L.ft)[R] = f2;  // frontTrimmed (without the UMI part)
+        } else {
+            lds_i(lds, L.front)[R] = front;
+            lds_i(lds, L.len)[R] = len;
+            lds_or_i32(&lds_i(lds, L.flags)[R], RS_NULL);
+        }
+    }
+}
+
+// polyG needs to know that BOTH mates survived trimAndCut (peprocessor.cpp:428-431)
+FQ_DEV void phase_polyg(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    if (!p.poly_g) return;
+    for (int R = tid; R < L.NR; R += nthreads) {
+        const int m = R >= L.P ? 1 : 0;
+        const int pr = R - m * L.P;
+        int dead = lds_i(lds, L.flags)[pr] & RS_NULL;
+        if (p.paired) dead |= lds_i(lds, L.flags)[L.P + pr] & RS_NULL;
+        if (dead) continue;
+        const int f = lds_i(lds, L.front)[R];
+        const int l = lds_i(lds, L.len)[R];
+        lds_i(lds, L.len)[R] = trim_poly_g(lds_seq(L, lds, R), (const u8*)lds_qual(L, lds, R), f, l, p.poly_g_min);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Phase D: OverlapAnalysis::analyze (overlapanalysis.cpp:17-146, no-gap part).
+// One wavefront per pair; lane = one candidate offset in the reference's scan
+// order (forward offsets 0..len1-require-1, then reverse offsets 0,-1,...).
+// Stage 1 (per lane): mismatches of the first <=16 bases on the 2-bit codes only -
+//   a lower bound of the true count, so it can only over-accept.
+// Stage 2 (whole wave, per surviving candidate in scan order): exact count over
+//   the protected prefix (<=50 bases, :28) and over the full overlap.
+// ---------------------------------------------------------------------------
+FQ_DEV u32 wave_sum(u32 v) {
+    v += shfl_xor(v, 1);
+    v += shfl_xor(v, 2);
+    v += shfl_xor(v, 4);
+    v += shfl_xor(v, 8);
+    v += shfl_xor(v, 16);
+    v += shfl_xor(v, 32);
+    return v;
+}
+
+FQ_DEV void overlap_pair(const KernelArgs& a, u32* lds, int pr, int lane, int wave) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    const int R1 = pr, R2 = L.P + pr;
+    const int f1 = lds_i(lds, L.front)[R1], l1 = lds_i(lds, L.len)[R1];
+    const int f2 = lds_i(lds, L.front)[R2], l2 = lds_i(lds, L.len)[R2];
+    const u32* s1 = lds_seq(L, lds, R1);
+    const u32* n1 = lds_nmk(L, lds, R1);
+    const u32* s2 = lds_seq(L, lds, R2);
+    const u32* n2 = lds_nmk(L, lds, R2);
+    const bool hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
+    u32* rcs = lds + L.wscratch + wave * 2 * L.SW;
+    u32* rcn = rcs + L.SW;
+    // reverse complement of r2' = r2[f2, f2+l2) as packed words (overlapanalysis.cpp:19-22):
+    // rc[k] = comp(r2[f2+l2-1-k]); complement of a 2-bit code is code^1, N stays N.
+    {
+        const int e = f2 + l2;
+        for (int t = lane; t < L.SW; t += 64) {
+            u32 vs = 0, vn = 0;
+            const int nb = l2 - 16 * t;  // rc bases held by word t
+            if (nb > 0) {
+                const int lo = e - 16 * (t + 1);
+                const u32 msk = lowmask32(2 * imin(16, nb));
+                vs = (reverse_groups(window16_signed(s2, lo)) ^ 0x55555555u) & msk;
+                vn = reverse_groups(window16_signed(n2, lo)) & msk;
+                vs &= ~(vn | (vn << 1));  // an N is stored as code 0 on both strands
+            }
+            rcs[t] = vs;
+            rcn[t] = vn;
+        }
+    }
+    wave_sync();
+    const int req = p.overlap_require;
+    const int F = imax(0, l1 - req);   // forward candidates  (:48)
+    const int Rv = imax(0, l2 - req);  // reverse candidates  (:73)
+    const int total = F + Rv;
+    const short* lut = (const short*)(lds + L.lut_ov);
+    int found = 0, r_off = 0, r_ol = 0, r_diff = 0;
+    for (int base = 0; base < total && !found; base += 64) {
+        const int c = base + lane;
+        const bool valid = c < total;
+        const bool fwd = c < F;
+        const int o = fwd ? c : c - F;
+        const int ca = fwd ? o : 0;  // start in r1'
+        const int cb = fwd ? 0 : o;  // start in rc(r2')
+        int ol = fwd ? imin(l1 - o, l2) : imin(l1, l2 - o);
+        if (!valid) ol = 0;
+        const int limit = lut[ol];
+        bool pass1 = false;
+        if (valid) {
+            const int n16 = imin(imin(ol, 50), 16);
+            const u32 d = fold_diff(window16(s1, f1 + ca) ^ window16(rcs, cb)) & lowmask32(2 * n16);
+            pass1 = popc32(d) <= limit;
+        }
+        u64 mask = ballot(pass1);
+        while (mask) {
+            const int src = ffs64(mask) - 1;
+            mask &= mask - 1;
+            const int xa = (int)shfl((u32)ca, src);
+            const int xb = (int)shfl((u32)cb, src);
+            const int xol = (int)shfl((u32)ol, src);
+            const int xlim = (int)shfl((u32)limit, src);
+            const int xo = (int)shfl((u32)(fwd ? o : -o), src);
+            const int pre = imin(xol, 50);  // complete_compare_require (:28)
+            u32 cnt_pre = 0, cnt_full = 0;
+            for (int t = lane; t * 16 < xol; t += 64) {
+                u32 dd = fold_diff(window16(s1, f1 + xa + 16 * t) ^ window16(rcs, xb + 16 * t));
+                if (hasN) dd |= window16(n1, f1 + xa + 16 * t) ^ window16(rcn, xb + 16 * t);
+                const int vf = imin(16, xol - 16 * t);
+                const int vp = imax(0, imin(16, pre - 16 * t));
+                cnt_full += (u32)popc32(dd & lowmask32(2 * vf));
+                cnt_pre += (u32)popc32(dd & lowmask32(2 * vp));
+            }
+            cnt_pre = wave_sum(cnt_pre);
+            cnt_full = wave_sum(cnt_full);
+            if ((int)cnt_pre <= xlim) {  // acceptNoGapOverlap (:34-44)
+                found = 1;
+                r_off = xo;
+                r_ol = xol;
+                r_diff = xol > 50 ? (int)cnt_full : (int)cnt_pre;
+                break;
+            }
+        }
+    }
+    if (lane == 0) {
+        lds_i(lds, L.ov_off)[pr] = found ? r_off : 0;
+        lds_i(lds, L.ov_len)[pr] = found ? r_ol : 0;
+        lds_i(lds, L.ov_diff)[pr] = found ? r_diff : 0;
+        lds_i(lds, L.ov_flags)[pr] = found ? 1 : 0;
+    }
+}
+
+FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    if (!p.paired) return;
+    const bool thread0 = (a.batch_flags & 1u) != 0;  // FASTP_GPU_BATCH_STAT_ISIZE
+    if (!(p.need_overlap || thread0)) return;        // peprocessor.cpp:438
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    for (int pr = wave; pr < L.P; pr += nwaves) {
+        const int dead = (lds_i(lds, L.flags)[pr] | lds_i(lds, L.flags)[L.P + pr]) & RS_NULL;
+        if (dead) continue;  // r1 != NULL && r2 != NULL
+        overlap_pair(a, lds, pr, lane, wave);
+        wave_sync();  // the per-wave scratch is reused by the next pair
+    }
+}
+
+// ---------------------------------------------------------------------------
+// AdapterTrimmer::trimBySequence (adaptertrimmer.cpp:64-157) on the read [f, f+rlen)
+// aw = packed adapter words (ACGT only, options.cpp:369-399), alen <= 64.
+// ---------------------------------------------------------------------------
+FQ_DEV int count_mismatch_words(const u32* srow, const u32* nrow, bool hasN, int rp, const u32* aw, int ap,
+                                int n, int allowed) {
+    int mm = 0;
+    for (int k = 0; k < n; k += 16) {
+        u32 d = fold_diff(window16(srow, rp + k) ^ window16(aw, ap + k));
+        if (hasN) d |= window16(nrow, rp + k);
+        mm += popc32(d & lowmask32(2 * imin(16, n - k)));
+        if (mm > allowed) break;
+    }
+    return mm;
+}
+
+// Matcher::matchWithOneInsertion (matcher.cpp:10-54) for every compare length at once.
+// For fixed strings the function only depends on (cmplen, diffLimit):
+//   matched <=> min_{1<=i<cmplen} (L[i-1] + R[i]) <= diffLimit,
+//   L[j] = #mismatch ins[0..j] vs nor[0..j],  R[i] = #mismatch ins[i+1..cmplen] vs nor[i..cmplen-1]
+// (the early exits of the reference never change that outcome: they fire exactly when
+// no later i can succeed).  With P0/P1 the prefix counts of D0[k]=(ins[k]!=nor[k]) and
+// D1[k]=(ins[k+1]!=nor[k]):  L[i-1]+R[i] = (P0(i)-P1(i)) + P1(cmplen), so one pass
+// gives the answer for all cmplen.  Returns a bit mask: bit (c-1) set <=> matched for
+// cmplen == c with diffLimit == c/8 - 1 (adaptertrimmer.cpp:108,125).
+// ins_is_read: insertion case (ins = read, nor = adapter) else deletion case.
+FQ_DEV u64 one_gap_match_mask(const u32* srow, const u8* q, int f, int rlen, const u32* aw, int alen,
+                              bool ins_is_read, int cmax) {
+    u64 ok = 0;
+    int p0 = 0, p1 = 0;           // P0(i), P1(i)
+    int gmin = 0x7FFFFFFF;        // min_{1<=i'<=i-1}... running min of P0(i)-P1(i) over i in [1, c-1]
+    // walk i = 1..cmax ; at step i we know P0(i), P1(i) (prefix over k < i)
+    for (int i = 1; i <= cmax; i++) {
+        const int k = i - 1;
+        u32 d0, d1;
+        if (ins_is_read) {
+            const u32 a_k = code_at(aw, k);
+            d0 = sym_at(srow, q, f + k) != a_k;
+            d1 = sym_at(srow, q, f + k + 1) != a_k;
+        } else {
+            const u32 r_k = sym_at(srow, q, f + k);
+            d0 = code_at(aw, k) != r_k;
+            d1 = code_at(aw, k + 1) != r_k;
+        }
+        p0 += (int)d0;
+        p1 += (int)d1;
+        // now p0 = P0(i), p1 = P1(i).  cmplen c = i: uses min over i' in [1, c-1] (previous gmin) and P1(c)=p1
+        const int c = i;
+        const int limit = c / 8 - 1;
+        if (c >= 2 && gmin != 0x7FFFFFFF && gmin + p1 <= limit) ok |= 1ull << (c - 1);
+        // extend the running min with i' = i (valid for cmplen > i)
+        const int g = p0 - p1;
+        if (g < gmin) gmin = g;
+    }
+    (void)rlen;
+    (void)alen;
+    return ok;
+}
+
+FQ_DEV bool trim_by_sequence(const u32* srow, const u32* nrow, const u8* q, bool hasN, int f, int rlen,
+                             const u32* aw, int alen, int& out_pos) {
+    const int matchReq = 4;
+    if (alen < matchReq) return false;
+    int start = 0;
+    if (alen >= 16) start = -4;
+    else if (alen >= 12) start = -3;
+    else if (alen >= 8) start = -2;
+    int pos;
+    for (pos = start; pos < rlen - matchReq; pos++) {  // :87-100
+        const int cmplen = imin(rlen - pos, alen);
+        const int allowed = cmplen / 8;
+        const int so = imax(0, -pos);
+        const int mm = count_mismatch_words(srow, nrow, hasN, f + so + pos, aw, so, cmplen - so, allowed);
+        if (mm <= allowed) { out_pos = pos; return true; }
+    }
+    // one insertion in the read (:105-118) - rdata/adata are NOT advanced by pos (quirk #7)
+    if (rlen - matchReq - 1 > 0) {
+        const int cmax = imin(rlen - 1, alen);
+        const u64 ok = one_gap_match_mask(srow, q, f, rlen, aw, alen, true, cmax);
+        if (ok) {
+            for (pos = 0; pos < rlen - matchReq - 1; pos++) {
+                const int c = imin(rlen - pos - 1, alen);
+                if (c >= 1 && ((ok >> (c - 1)) & 1ull)) { out_pos = pos; return true; }
+            }
+        }
+    }
+    // one deletion in the read (:122-135)
+    if (rlen - matchReq > 0) {
+        const int cmax = imin(rlen, alen - 1);
+        const u64 ok = one_gap_match_mask(srow, q, f, rlen, aw, alen, false, cmax);
+        if (ok) {
+            for (pos = 0; pos < rlen - matchReq; pos++) {
+                const int c = imin(rlen - pos, alen - 1);
+                if (c >= 1 && ((ok >> (c - 1)) & 1ull)) { out_pos = pos; return true; }
+            }
+        }
+    }
+    return false;
+}
+
+// apply trimBySequence to read R (state in LDS); returns trimmed?
+FQ_DEV bool apply_trim_by_sequence(const KernelArgs& a, u32* lds, int R, const u32* aw, int alen, u32* misc) {
+    const LdsLayout& L = a.L;
+    const int f = lds_i(lds, L.front)[R];
+    const int rlen = lds_i(lds, L.len)[R];
+    const bool hasN = (lds_i(lds, L.flags)[R] & RS_HAS_N) != 0;
+    int pos = 0;
+    if (!trim_by_sequence(lds_seq(L, lds, R), lds_nmk(L, lds, R), (const u8*)lds_qual(L, lds, R), hasN, f, rlen, aw,
+                          alen, pos))
+        return false;
+    int adapter_len;
+    if (pos < 0) {  // adaptertrimmer.cpp:138-145
+        adapter_len = alen + pos;
+        lds_i(lds, L.len)[R] = 0;
+    } else {
+        adapter_len = rlen - pos;
+        lds_i(lds, L.len)[R] = pos;
+    }
+    if (adapter_len > 0) lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)adapter_len);  // filterresult.cpp:127
+    lds_i(lds, L.apos)[R] = pos;
+    lds_i(lds, L.alen)[R] = adapter_len;
+    return true;
+}
+
+// Filter::passFilter (filter.cpp:15-57) on the read [f, f+rlen); alive == non-NULL
+FQ_DEV int pass_filter(const KernelArgs& a, u32* lds, int R, bool alive) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    const int rlen = lds_i(lds, L.len)[R];
+    if (!alive || rlen == 0) return 16;  // FAIL_LENGTH (:16-18)
+    const int f = lds_i(lds, L.front)[R];
+    const u32* srow = lds_seq(L, lds, R);
+    const u8* q = (const u8*)lds_qual(L, lds, R);
+    int low = 0, nb = 0, tot = 0;
+    if (p.qual_filter || p.length_filter) {  // countQualityMetrics simd.cpp:54-119
+        for (int i = 0; i < rlen; i++) {
+            const u32 b = q[f + i];
+            const u32 qc = b & 0x7Fu;
+            tot += (int)qc - 33;
+            low += qc < (u32)p.qual_thr;
+            nb += (int)(b >> 7);
+        }
+    }
+    if (p.qual_filter) {  // :35-42
+        const u16* lowq = (const u16*)(lds + L.lut_lowq);
+        if (low > (int)lowq[rlen]) return 20;                                   // FAIL_QUALITY
+        else if (p.avg_qual_req > 0 && (tot / rlen) < p.avg_qual_req) return 20;  // FAIL_QUALITY
+        else if (nb > p.n_base_limit) return 12;                                // FAIL_N_BASE
+    }
+    if (p.length_filter) {  // :44-49
+        if (rlen < p.length_required) return 16;
+        if (p.length_limit > 0 && rlen > p.length_limit) return 17;
+    }
+    if (p.complexity_filter) {  // :51-54, 59-66
+        if (rlen <= 1) return 24;
+        int diff = 0;
+        u32 prev = sym_at(srow, q, f);
+        for (int i = 1; i < rlen; i++) {
+            const u32 cur = sym_at(srow, q, f + i);
+            diff += prev != cur;
+            prev = cur;
+        }
+        const u16* cmin = (const u16*)(lds + L.lut_cplx);
+        if (diff < (int)cmin[rlen]) return 24;  // FAIL_COMPLEXITY
+    }
+    return 0;
+}
+
+FQ_DEV void store_base(const KernelArgs& a, u32* lds, int R, int j, u32 sym, u32 qchar) {
+    const LdsLayout& L = a.L;
+    u32* srow = lds_seq(L, lds, R);
+    u32* nrow = lds_nmk(L, lds, R);
+    u8* q = (u8*)lds_qual(L, lds, R);
+    const int w = j >> 4, sh = (j & 15) * 2;
+    const u32 code = sym == 4u ? 0u : sym;
+    srow[w] = (srow[w] & ~(3u << sh)) | (code << sh);
+    nrow[w] = (nrow[w] & ~(1u << sh)) | ((sym == 4u ? 1u : 0u) << sh);
+    q[j] = (u8)(qchar | (sym == 4u ? 0x80u : 0u));
+    if (sym == 4u) lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+}
+
+FQ_DEV void write_read_result(const KernelArgs& a, u32* lds, int m, int R, int gp) {
+    const LdsLayout& L = a.L;
+    // fastp_gpu_read_result: u16 front, u16 len | u8 code, u8 flags, i16 adapter_pos | u16 adapter_len, u16 reserved
+    const u32 front = (u32)lds_i(lds, L.front)[R] & 0xFFFFu;
+    const u32 len = (u32)lds_i(lds, L.len)[R] & 0xFFFFu;
+    const u32 code = (u32)lds_i(lds, L.code)[R] & 0xFFu;
+    const u32 flags = (u32)lds_i(lds, L.flags)[R] & 0xFFu;
+    const u32 apos = (u32)lds_i(lds, L.apos)[R] & 0xFFFFu;
+    const u32 alen = (u32)lds_i(lds, L.alen)[R] & 0xFFFFu;
+    u32* out = a.res[m] + (size_t)gp * 3;
+    out[0] = front | (len << 16);
+    out[1] = code | (flags << 8) | (apos << 16);
+    out[2] = alen;
+}
+
+// ASCII & 7 of a symbol (A=1 T=4 C=3 G=7 N=6): FilterResult::addCorrection filterresult.cpp:99-103
+FQ_DEV u32 sym_bin(u32 s) { return (0x67341u >> (s * 4)) & 0xFu; }
+FQ_DEV u32 sym_ascii(u32 s) { return (u32)("ATCGN"[s]); }
+
+// ---------------------------------------------------------------------------
+// Phase E (paired): lane = one pair.  peprocessor.cpp:443-573.
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    u32* misc = lds + L.acc_misc;
+    const bool thread0 = (a.batch_flags & 1u) != 0;
+    for (int pr = tid; pr < L.P; pr += nthreads) {
+        const int gp = tile_first + pr;
+        if (gp >= a.n) continue;
+        const int R1 = pr, R2 = L.P + pr;
+        int* flags = lds_i(lds, L.flags);
+        int* lenv = lds_i(lds, L.len);
+        const bool a1 = !(flags[R1] & RS_NULL), a2 = !(flags[R2] & RS_NULL);
+        const bool both = a1 && a2;
+        const int ft1 = lds_i(lds, L.ft)[R1], ft2 = lds_i(lds, L.ft)[R2];
+        const int ovl = lds_i(lds, L.ov_flags)[pr] & 1;
+        const int ov_off = lds_i(lds, L.ov_off)[pr], ov_len = lds_i(lds, L.ov_len)[pr];
+        const int ov_diff = lds_i(lds, L.ov_diff)[pr];
+        bool isize_done = false, dimer = false;
+        // statInsertSize (peprocessor.cpp:710-723), thread 0 only (:449, :497)
+        if (both && thread0) {
+            int isize = p.isize_max;
+            if (ovl) {
+                if (ov_off > 0) isize = lenv[R1] + lenv[R2] - ov_len + ft1 + ft2;
+                else isize = ov_len + ft1 + ft2;
+            }
+            if (isize > p.isize_max) isize = p.isize_max;
+            if (isize >= 0) lds_add_u32(&misc[MISC_ISIZE + isize], 1u);
+            isize_done = true;
+        }
+        if (both && p.need_overlap) {
+            // BaseCorrector::correctByOverlapAnalysis (basecorrector.cpp:16-83)
+            if (p.correction && ovl && ov_diff != 0) {
+                const int f1 = lds_i(lds, L.front)[R1], f2 = lds_i(lds, L.front)[R2];
+                const int start1 = imax(0, ov_off);
+                const int start2 = lenv[R2] - imax(0, -ov_off) - 1;
+                const u32* s1 = lds_seq(L, lds, R1);
+                const u32* s2 = lds_seq(L, lds, R2);
+                const u8* q1 = (const u8*)lds_qual(L, lds, R1);
+                const u8* q2 = (const u8*)lds_qual(L, lds, R2);
+                int corrected = 0;
+                bool r1c = false, r2c = false;
+                for (int i = 0; i < ov_len; i++) {
+                    const int j1 = f1 + start1 + i, j2 = f2 + start2 - i;
+                    const u32 b1 = sym_at(s1, q1, j1), b2 = sym_at(s2, q2, j2);
+                    if (b1 != sym_complement(b2)) {
+                        const u32 c1 = qchar_at(q1, j1), c2 = qchar_at(q2, j2);
+                        int which = -1, cpos = 0;
+                        u32 nb = 0, nq = 0, from = 0;
+                        if (c1 >= 63u && c2 <= 47u) {  // GOOD_QUAL = Q30, BAD_QUAL = Q14 (:32-33)
+                            from = b2; nb = sym_complement(b1); nq = c1;
+                            store_base(a, lds, R2, j2, nb, nq);
+                            which = 1; cpos = j2; r2c = true;
+                        } else if (c2 >= 63u && c1 <= 47u) {
+                            from = b1; nb = sym_complement(b2); nq = c2;
+                            store_base(a, lds, R1, j1, nb, nq);
+                            which = 0; cpos = j1; r1c = true;
+                        }
+                        if (which >= 0) {
+                            corrected++;
+                            lds_add_u32(&misc[MISC_CORRECTION + sym_bin(from) * 8 + sym_bin(nb)], 1u);
+                            if (a.corrections) {
+                                const int slot = g_atomic_add_i32(a.n_corrections, 1);
+                                if (slot < a.corr_capacity) {
+                                    a.corrections[2 * slot] = (u32)(2 * gp + which);
+                                    a.corrections[2 * slot + 1] = (u32)cpos | (sym_ascii(nb) << 16) | (nq << 24);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (corrected > 0) {  // :75-80
+                    lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
+                    if (r1c) flags[R1] |= RS_CORRECTED;
+                    if (r2c) flags[R2] |= RS_CORRECTED;
+                }
+            }
+            if (p.adapter_enabled) {
+                bool trimmed = false;
+                if (ovl && ov_off < 0) {  // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
+                    const int len1 = imin(lenv[R1], ov_len + ft2);
+                    const int len2 = imin(lenv[R2], ov_len + ft1);
+                    lds_i(lds, L.apos)[R1] = len1;
+                    lds_i(lds, L.alen)[R1] = lenv[R1] - len1;
+                    lds_i(lds, L.apos)[R2] = len2;
+                    lds_i(lds, L.alen)[R2] = lenv[R2] - len2;
+                    lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)((lenv[R1] - len1) + (lenv[R2] - len2)));
+                    lenv[R1] = len1;
+                    lenv[R2] = len2;
+                    trimmed = true;
+                    flags[R1] |= RS_ADAPTER_OV;
+                    flags[R2] |= RS_ADAPTER_OV;
+                }
+                bool t1 = trimmed, t2 = trimmed;
+                if (!trimmed) {  // peprocessor.cpp:460-466
+                    if (p.has_a1) t1 = apply_trim_by_sequence(a, lds, R1, lds + L.adapt, p.alen1, misc);
+                    if (p.has_a2) t2 = apply_trim_by_sequence(a, lds, R2, lds + L.adapt + ADAPT_WORDS, p.alen2, misc);
+                }
+                if (t1) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R1] |= RS_ADAPTER; }  // :472-475
+                if (t2) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R2] |= RS_ADAPTER; }
+                if ((t1 || t2) && lenv[R1] <= p.dimer_max_len && lenv[R2] <= p.dimer_max_len) dimer = true;  // :480-484
+            }
+        }
+        (void)isize_done;
+        if (both && p.poly_x) {  // :506-509
+            for (int k = 0; k < 2; k++) {
+                const int R = k ? R2 : R1;
+                int poly, trimmed;
+                const int nl = trim_poly_x(lds_seq(L, lds, R), (const u8*)lds_qual(L, lds, R), lds_i(lds, L.front)[R],
+                                           lenv[R], p.poly_x_min, poly, trimmed);
+                if (poly >= 0) {  // addPolyXTrimmed filterresult.cpp:186-189
+                    lds_add_u32(&misc[MISC_POLYX_READS + poly], 1u);
+                    lds_add_u32(&misc[MISC_POLYX_BASES + poly], (u32)trimmed);
+                    flags[R] |= RS_POLYX;
+                }
+                lenv[R] = nl;
+            }
+        }
+        if (both) {  // :511-516
+            if (p.max_len1 > 0 && p.max_len1 < lenv[R1]) lenv[R1] = p.max_len1;
+            if (p.max_len2 > 0 && p.max_len2 < lenv[R2]) lenv[R2] = p.max_len2;
+        }
+        int code1 = pass_filter(a, lds, R1, a1);  // :565-566
+        int code2 = pass_filter(a, lds, R2, a2);
+        if (dimer) { code1 = 28; code2 = 28; }     // :568-571
+        const int worst = imax(code1, code2);
+        lds_add_u32(&misc[MISC_FILTER + worst], 2u);  // addFilterResult(max, 2) :573
+        lds_i(lds, L.code)[R1] = code1;
+        lds_i(lds, L.code)[R2] = code2;
+        // post-filtering Stats only see pairs that are written to out1/out2 (:577-591);
+        // with dedup the duplicate decision is taken by the dup kernels beforehand
+        const bool dedup_out = p.dedup && (flags[R1] & RS_DUP);
+        if (!dedup_out && a1 && a2 && code1 == 0 && code2 == 0) {
+            flags[R1] |= RS_STAT_POST;
+            flags[R2] |= RS_STAT_POST;
+        }
+        // Duplicate::checkPair hash values (duplicate.cpp:136-148) for the dup kernels
+        if (p.dup_enabled && a.dup_pos) {
+            const u64* h1 = (const u64*)(lds + L.hash) + (size_t)R1 * p.dup_bufnum;
+            const u64* h2 = (const u64*)(lds + L.hash) + (size_t)R2 * p.dup_bufnum;
+            const int tl = lds_i(lds, L.rlen0)[R1] + lds_i(lds, L.rlen0)[R2];
+            for (int i = 0; i < p.dup_bufnum; i++)
+                a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h1[i] + h2[i] + a.lut.dup_posum[(size_t)tl * p.dup_bufnum + i];
+        }
+        write_read_result(a, lds, 0, R1, gp);
+        write_read_result(a, lds, 1, R2, gp);
+        // fastp_gpu_pair_result: i16 ov_offset, u16 ov_len | u16 ov_diff, u16 flags
+        a.pair[2 * (size_t)gp] = ((u32)ov_off & 0xFFFFu) | (((u32)ov_len & 0xFFFFu) << 16);
+        a.pair[2 * (size_t)gp + 1] = ((u32)ov_diff & 0xFFFFu) | ((u32)((ovl ? 1 : 0) | (isize_done ? 4 : 0)) << 16);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Phase E (single-end): lane = one read.  seprocessor.cpp:244-290.
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_decide_se(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    u32* misc = lds + L.acc_misc;
+    for (int R = tid; R < L.P; R += nthreads) {
+        const int gp = tile_first + R;
+        if (gp >= a.n) continue;
+        int* flags = lds_i(lds, L.flags);
+        int* lenv = lds_i(lds, L.len);
+        const bool alive = !(flags[R] & RS_NULL);
+        bool dimer = false;
+        if (alive && p.adapter_enabled) {  // :244-261
+            bool trimmed = false;
+            if (p.has_a1) trimmed = apply_trim_by_sequence(a, lds, R, lds + L.adapt, p.alen1, misc);
+            if (trimmed) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R] |= RS_ADAPTER; }
+            if (trimmed && lenv[R] <= p.dimer_max_len) dimer = true;
+        }
+        if (alive && p.poly_x) {  // :263-266
+            int poly, trimmed;
+            const int nl = trim_poly_x(lds_seq(L, lds, R), (const u8*)lds_qual(L, lds, R), lds_i(lds, L.front)[R], lenv[R],
+                                       p.poly_x_min, poly, trimmed);
+            if (poly >= 0) {
+                lds_add_u32(&misc[MISC_POLYX_READS + poly], 1u);
+                lds_add_u32(&misc[MISC_POLYX_BASES + poly], (u32)trimmed);
+                flags[R] |= RS_POLYX;
+            }
+            lenv[R] = nl;
+        }
+        if (alive && p.max_len1 > 0 && p.max_len1 < lenv[R]) lenv[R] = p.max_len1;  // :268-271
+        int code = pass_filter(a, lds, R, alive);  // :273
+        if (dimer) code = 28;
+        lds_add_u32(&misc[MISC_FILTER + code], 1u);  // :278
+        lds_i(lds, L.code)[R] = code;
+        const bool dedup_out = p.dedup && (flags[R] & RS_DUP);
+        if (!dedup_out && alive && code == 0) flags[R] |= RS_STAT_POST;  // :280-286
+        if (p.dup_enabled && a.dup_pos) {  // Duplicate::checkRead duplicate.cpp:122-134
+            const u64* h = (const u64*)(lds + L.hash) + (size_t)R * p.dup_bufnum;
+            const int tl = lds_i(lds, L.rlen0)[R];
+            for (int i = 0; i < p.dup_bufnum; i++)
+                a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h[i] + a.lut.dup_posum[(size_t)tl * p.dup_bufnum + i];
+        }
+        write_read_result(a, lds, 0, R, gp);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// The fused kernel: persistent workgroups, grid-stride over tiles.
+// ---------------------------------------------------------------------------
+FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
+    const LdsLayout& L = a.L;
+    const int tid = thread_id(), nt = block_threads();
+    // one-time per workgroup: clear the accumulators, stage LUTs / primes / adapters
+    for (int i = tid; i < L.acc_end - L.acc_cyc; i += nt) lds[L.acc_cyc + i] = 0;
+    {
+        const int lw = (a.p.max_len + 2) / 2;  // u16 tables of max_len+1 entries, in dwords
+        const u32* g0 = (const u32*)a.lut.ov_limit;
+        const u32* g1 = (const u32*)a.lut.lowq_limit;
+        const u32* g2 = (const u32*)a.lut.cplx_min;
+        for (int i = tid; i < lw; i += nt) {
+            lds[L.lut_ov + i] = g0[i];
+            lds[L.lut_lowq + i] = g1[i];
+            lds[L.lut_cplx + i] = g2[i];
+        }
+        if (a.p.dup_enabled)
+            for (int i = tid; i < 512 * a.p.dup_bufnum; i += nt) lds[L.primes + i] = a.lut.dup_primes[i];
+        for (int i = tid; i < 2 * ADAPT_WORDS; i += nt) {
+            const int which = i >= ADAPT_WORDS ? 1 : 0;
+            const int w = i - which * ADAPT_WORDS;
+            u32 v = 0;
+            if (w < MAX_ADAPTER_WORDS) v = which ? a.p.a2w[w] : a.p.a1w[w];
+            lds[L.adapt + i] = v;
+        }
+    }
+    block_sync();
+    for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
+        const int tile_first = tile * L.P;
+        const int n_valid = imin(L.P, a.n - tile_first);
+        phase_load(a, lds, tile_first, tid, nt);
+        block_sync();
+        phase_stats(a, lds, false, n_valid, tid, nt);  // Stats::statRead on the original reads
+        phase_trim(a, lds, tid, nt);
+        block_sync();
+        phase_polyg(a, lds, tid, nt);
+        block_sync();
+        phase_overlap(a, lds, tid, nt);
+        block_sync();
+        if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
+        else phase_decide_se(a, lds, tile_first, tid, nt);
+        block_sync();
+        phase_stats(a, lds, true, n_valid, tid, nt);   // Stats::statRead on what is written out
+        block_sync();
+    }
+    // flush this workgroup's accumulators to its slab (plain coalesced stores)
+    u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
+    for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];
+}
+
+// ---------------------------------------------------------------------------
+// Slab reduction: the device analogue of Stats::merge / FilterResult::merge
+// (stats.cpp:877-955, filterresult.cpp:38-89) over the workgroups of one launch,
+// unpacking the LDS formats into the int64 counter block of include/fastp_gpu.h.
+// ---------------------------------------------------------------------------
+struct ReduceArgs {
+    const u32* slabs;
+    int slab_dwords, nblocks;
+    LdsLayout L;       // offsets of the accumulator regions (relative to L.acc_cyc)
+    int isize_max;
+    int64_t* ctr;      // counter block
+    // fastp_gpu_counter_layout offsets
+    int64_t o_filter, o_adapter_reads, o_adapter_bases, o_polyx_reads, o_polyx_bases, o_correction,
+        o_corrected_reads, o_merged, o_isize, o_stats[4], st_reads, st_length_sum, st_qual_hist, st_kmer,
+        st_cycle, cycles;
+};
+
+FQ_DEV void reduce_body(const ReduceArgs& r) {
+    const LdsLayout& L = r.L;
+    const int C = L.C;
+    const int n_cyc = 4 * C, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128, n_misc = MISC_ISIZE + r.isize_max + 1;
+    const int total = n_cyc + n_kmer + n_qh + n_misc;
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    for (int item = gid; item < total; item += gstride) {
+        if (item < n_cyc) {
+            const int slot = item / C, c = item - slot * C;
+            int64_t* st = r.ctr + r.o_stats[slot] + r.st_cycle;
+            const int64_t CC = r.cycles;
+            int64_t tb = 0, tq = 0;
+            for (int cls = 0; cls < N_CLS; cls++) {
+                int64_t cnt = 0, q20 = 0, q30 = 0, qs = 0;
+                const int off = (L.acc_cyc - L.acc_cyc) + 2 * ((slot * N_CLS + cls) * C + c);
+                for (int b = 0; b < r.nblocks; b++) {
+                    const u32* s = r.slabs + (size_t)b * r.slab_dwords + off;
+                    const u64 v = (u64)s[0] | ((u64)s[1] << 32);
+                    cnt += (int64_t)(v & 0x3FFFu);
+                    q20 += (int64_t)((v >> CYC_Q20_SHIFT) & 0x3FFFu);
+                    q30 += (int64_t)((v >> CYC_Q30_SHIFT) & 0x3FFFu);
+                    qs += (int64_t)(v >> CYC_QSUM_SHIFT);
+                }
+                const int bin = (int)sym_bin((u32)cls);  // 'A'&7=1 'T'&7=4 'C'&7=3 'G'&7=7 'N'&7=6
+                st[(0 * 8 + bin) * CC + c] += q30;   // mCycleQ30Bases  (stats.cpp:54-63 layout)
+                st[(1 * 8 + bin) * CC + c] += q20;   // mCycleQ20Bases
+                st[(2 * 8 + bin) * CC + c] += cnt;   // mCycleBaseContents
+                st[(3 * 8 + bin) * CC + c] += qs;    // mCycleBaseQual
+                tb += cnt;
+                tq += qs;
+            }
+            st[32 * CC + c] += tb;  // mCycleTotalBase
+            st[33 * CC + c] += tq;  // mCycleTotalQual
+        } else if (item < n_cyc + n_kmer) {
+            const int k = item - n_cyc;
+            const int slot = k / KMER_BINS, km = k - slot * KMER_BINS;
+            int64_t sum = 0;
+            const int off = (L.acc_kmer - L.acc_cyc) + k;
+            for (int b = 0; b < r.nblocks; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off];
+            // LDS index has the earliest base in the low bits; fastp's has it in the high bits
+            const u32 fk = ((km & 3u) << 8) | (((km >> 2) & 3u) << 6) | (((km >> 4) & 3u) << 4) |
+                           (((km >> 6) & 3u) << 2) | ((km >> 8) & 3u);
+            r.ctr[r.o_stats[slot] + r.st_kmer + fk] += sum;
+        } else if (item < n_cyc + n_kmer + n_qh) {
+            const int k = item - n_cyc - n_kmer;
+            const int slot = k / 128, q = k - slot * 128;
+            int64_t sum = 0;
+            const int off = (L.acc_qh - L.acc_cyc) + k * QH_COPIES;
+            for (int b = 0; b < r.nblocks; b++)
+                for (int cpy = 0; cpy < QH_COPIES; cpy++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off + cpy];
+            r.ctr[r.o_stats[slot] + r.st_qual_hist + q] += sum;
+        } else {
+            const int k = item - n_cyc - n_kmer - n_qh;
+            int64_t sum = 0;
+            const int off = (L.acc_misc - L.acc_cyc) + k;
+            for (int b = 0; b < r.nblocks; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off];
+            int64_t dst;
+            if (k < MISC_ADAPTER_READS) dst = r.o_filter + k;
+            else if (k == MISC_ADAPTER_READS) dst = r.o_adapter_reads;
+            else if (k == MISC_ADAPTER_BASES) dst = r.o_adapter_bases;
+            else if (k < MISC_POLYX_BASES) dst = r.o_polyx_reads + (k - MISC_POLYX_READS);
+            else if (k < MISC_CORRECTION) dst = r.o_polyx_bases + (k - MISC_POLYX_BASES);
+            else if (k < MISC_CORRECTED_READS) dst = r.o_correction + (k - MISC_CORRECTION);
+            else if (k == MISC_CORRECTED_READS) dst = r.o_corrected_reads;
+            else if (k == MISC_MERGED) dst = r.o_merged;
+            else if (k < MISC_STAT_LENSUM) dst = r.o_stats[k - MISC_STAT_READS] + r.st_reads;
+            else if (k < MISC_ISIZE) dst = r.o_stats[k - MISC_STAT_LENSUM] + r.st_length_sum;
+            else dst = r.o_isize + (k - MISC_ISIZE);
+            r.ctr[dst] += sum;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Duplicate::applyBloomFilter (duplicate.cpp:150-163) with the reference's
+// SEQUENTIAL semantics, evaluated in parallel:
+//   pair g is a duplicate  <=>  for every buffer i the bit pos_i(g) was set by a
+//   pair with a smaller index (in an earlier batch: "committed", or earlier in
+//   this batch).
+// probe  : read the committed bitmaps; pairs with a missing bit register
+//          (buffer, bit) -> min pair index in an open-addressing table.
+// resolve: a missing bit counts as set iff the table's min index is smaller than
+//          the pair's own; then commit the bits (atomic OR) and count.
+// Bitmaps are u32 words: bit `pos` lives in word pos>>5, bit pos&31 (the same bit
+// identity as the reference's byte array: byte pos>>3, bit pos&7).
+// ---------------------------------------------------------------------------
+struct DupArgs {
+    const u64* dup_pos;   // [n][B] Duplicate::seq2intvector values
+    int n, B;
+    u64 bits;             // mBufLenInBits
+    u32* bitmap;          // [B][bits/32]
+    u64* table;           // open addressing, EMPTY = ~0, entry = key(38 bit) << 25 | pair index
+                          // (bit 63 of a real entry is always 0, so it never equals EMPTY)
+    int table_log2;
+    u8* need;             // [n] mask of buffers whose bit was not committed
+    u32* res[2];          // result records (flags byte gets RS_DUP)
+    int paired;
+    int64_t* ctr_total;
+    int64_t* ctr_dups;
+};
+
+enum { DUP_IDX_BITS = 25 };  // pairs per launch < 2^25
+FQ_DEV u64 dup_key(int i, u64 pos) { return ((u64)i << 35) | pos; }
+FQ_DEV u32 dup_slot(u64 key, int log2) { return (u32)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2)); }
+
+FQ_DEV void dup_probe_body(const DupArgs& d) {
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    const u64 words = d.bits >> 5;
+    const u32 tmask = (1u << d.table_log2) - 1u;
+    for (int g = gid; g < d.n; g += gstride) {
+        u32 need = 0;
+        for (int i = 0; i < d.B; i++) {
+            const u64 pos = d.dup_pos[(size_t)g * d.B + i] % d.bits;
+            const u32 w = d.bitmap[(size_t)i * words + (pos >> 5)];
+            if (!((w >> (pos & 31)) & 1u)) {
+                need |= 1u << i;
+                const u64 key = dup_key(i, pos);
+                const u64 entry = (key << DUP_IDX_BITS) | (u64)g;
+                u32 slot = dup_slot(key, d.table_log2);
+                for (;;) {
+                    u64 cur = g_atomic_cas_u64(&d.table[slot], ~0ull, entry);
+                    if (cur == ~0ull) break;              // claimed an empty slot
+                    if ((cur >> DUP_IDX_BITS) == key) {   // same bit: keep the smallest pair index
+                        g_atomic_min_u64(&d.table[slot], entry);
+                        break;
+                    }
+                    slot = (slot + 1) & tmask;
+                }
+            }
+        }
+        d.need[g] = (u8)need;
+    }
+}
+
+FQ_DEV void dup_resolve_body(const DupArgs& d) {
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    const u64 words = d.bits >> 5;
+    const u32 tmask = (1u << d.table_log2) - 1u;
+    const int rounds = (d.n + gstride - 1) / gstride;
+    for (int it = 0; it < rounds; it++) {
+        const int g = gid + it * gstride;
+        bool is_dup = false;
+        if (g < d.n) {
+            const u32 need = d.need[g];
+            is_dup = true;
+            for (int i = 0; i < d.B; i++) {
+                if (!((need >> i) & 1u)) continue;  // committed by an earlier batch
+                const u64 pos = d.dup_pos[(size_t)g * d.B + i] % d.bits;
+                const u64 key = dup_key(i, pos);
+                u32 slot = dup_slot(key, d.table_log2);
+                u64 cur;
+                for (;;) {
+                    cur = d.table[slot];
+                    if ((cur >> DUP_IDX_BITS) == key) break;
+                    slot = (slot + 1) & tmask;
+                }
+                const int first = (int)(cur & ((1ull << DUP_IDX_BITS) - 1));
+                if (!(first < g)) is_dup = false;  // nobody earlier in this batch set it
+                g_atomic_or_u32(&d.bitmap[(size_t)i * words + (pos >> 5)], 1u << (pos & 31));
+            }
+            if (is_dup) {
+                d.res[0][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+                if (d.paired) d.res[1][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+            }
+        }
+        const u64 m = ballot(is_dup);
+        if (lane_id() == 0 && m) g_atomic_add_i64(d.ctr_dups, (int64_t)popc64(m));
+    }
+    if (gid == 0) g_atomic_add_i64(d.ctr_total, (int64_t)d.n);
+}
+
+}  // namespace fq

@@ -1,0 +1,362 @@
+// fq_host.cpp - see fq_host.h.  Host code only (no HIP runtime, no kernels).
+#include "fq_host.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace fq {
+
+u32 magic_for(u32 d) { return (u32)((0x100000000ull + d - 1) / d); }
+
+void dup_geometry(int level, u64& bytes, int& num) {  // Duplicate::Duplicate duplicate.cpp:13-47
+    bytes = 1ull << 29;
+    num = 2;
+    switch (level) {
+        case 2: bytes *= 2; break;
+        case 3: bytes *= 2; num *= 2; break;
+        case 4: bytes *= 4; num *= 2; break;
+        case 5: bytes *= 8; num *= 2; break;
+        case 6: bytes *= 8; num *= 4; break;
+        default: break;
+    }
+}
+
+void dup_primes(int bufnum, std::vector<u32>& out) {  // Duplicate::initPrimeArrays duplicate.cpp:66-84
+    out.clear();
+    u64 number = 10000;
+    while ((int)out.size() < bufnum * 512) {
+        number++;
+        bool is_prime = true;
+        for (u64 i = 2; (double)i <= sqrt((double)number); i++) {
+            if (number % i == 0) { is_prime = false; break; }
+        }
+        if (is_prime) {
+            out.push_back((u32)number);
+            number += 10000;
+        }
+    }
+}
+
+static int base_code(char c) {
+    switch (c) {
+        case 'A': return CODE_A;
+        case 'T': return CODE_T;
+        case 'C': return CODE_C;
+        case 'G': return CODE_G;
+        default: return -1;
+    }
+}
+
+static int pack_adapter(const char* s, u32* words, int& alen, std::string& err) {
+    alen = 0;
+    for (int i = 0; i < MAX_ADAPTER_WORDS; i++) words[i] = 0;
+    if (!s || !s[0]) return FASTP_GPU_OK;
+    const int n = (int)strlen(s);
+    if (n > FASTP_GPU_MAX_ADAPTER_LEN) {
+        err = "adapter sequence longer than FASTP_GPU_MAX_ADAPTER_LEN";
+        return FASTP_GPU_E_UNSUPPORTED;
+    }
+    for (int i = 0; i < n; i++) {
+        const int c = base_code(s[i]);
+        if (c < 0) {  // options.cpp:375-381: only A/T/C/G are legal
+            err = "adapter sequence may only contain A, T, C, G";
+            return FASTP_GPU_E_INVALID;
+        }
+        words[i >> 4] |= (u32)c << ((i & 15) * 2);
+    }
+    alen = n;
+    return FASTP_GPU_OK;
+}
+
+static char num2qual(int num) {  // util.h:260-268
+    if (num > 127 - 33) num = 127 - 33;
+    if (num < 0) num = 0;
+    return (char)(num + 33);
+}
+
+int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, std::string& err) {
+    memset(&p, 0, sizeof(p));
+    if (in.abi_version != FASTP_GPU_ABI_VERSION) { err = "abi_version mismatch"; return FASTP_GPU_E_INVALID; }
+    if (in.max_len <= 0 || in.max_len > FASTP_GPU_MAX_READ_LEN) {
+        err = "max_len must be in 1..FASTP_GPU_MAX_READ_LEN";
+        return FASTP_GPU_E_TOO_LONG;
+    }
+    // options outside the device path's scope for now: fail loudly, never fall back
+    if (in.merge) { err = "merge mode is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
+    if (in.allow_gap_overlap_trimming) { err = "allow_gap_overlap_trimming is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
+    if (in.dedup) { err = "dedup (dropping duplicates) is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
+    if (in.insert_size_max < 0 || in.insert_size_max > 4096) { err = "insert_size_max out of range"; return FASTP_GPU_E_INVALID; }
+    if (in.overlap_diff_limit < 0 || in.overlap_require < 0) { err = "negative overlap knobs"; return FASTP_GPU_E_INVALID; }
+    p.paired = in.paired ? 1 : 0;
+    p.max_len = in.max_len;
+    p.cycles = fastp_gpu_cycles_for(&in);
+    p.sw_g = (int)(fastp_gpu_seq_stride(in.max_len) / 4);
+    p.qw_g = (int)(fastp_gpu_qual_stride(in.max_len) / 4);
+    p.trim_front1 = in.trim_front1; p.trim_tail1 = in.trim_tail1;
+    p.trim_front2 = in.trim_front2; p.trim_tail2 = in.trim_tail2;
+    p.max_len1 = in.max_len1; p.max_len2 = in.max_len2;
+    if (in.trim_front1 < 0 || in.trim_tail1 < 0 || in.trim_front2 < 0 || in.trim_tail2 < 0) {
+        err = "negative trim"; return FASTP_GPU_E_INVALID;
+    }
+    p.cut_front = in.cut_front != 0; p.cut_tail = in.cut_tail != 0; p.cut_right = in.cut_right != 0;
+    if (p.cut_front || p.cut_tail || p.cut_right) {  // options.cpp:350-367
+        const int ws[3] = {in.cut_front_window, in.cut_tail_window, in.cut_right_window};
+        for (int i = 0; i < 3; i++)
+            if (ws[i] < 1 || ws[i] > 1000) { err = "cut window size must be 1..1000"; return FASTP_GPU_E_INVALID; }
+    }
+    p.wF = in.cut_front_window; p.thrF = in.cut_front_window * (33 + in.cut_front_quality);   // filter.cpp:116
+    p.wT = in.cut_tail_window;  p.thrT = in.cut_tail_window * (33 + in.cut_tail_quality);     // filter.cpp:185
+    p.wR = in.cut_right_window; p.thrR = in.cut_right_window * (33 + in.cut_right_quality);   // filter.cpp:151
+    p.qRmin = 33 + in.cut_right_quality;                                                      // filter.cpp:159
+    p.poly_g = in.poly_g != 0; p.poly_g_min = in.poly_g_min_len;
+    p.poly_x = in.poly_x != 0; p.poly_x_min = in.poly_x_min_len;
+    p.adapter_enabled = in.adapter_enabled != 0;
+    p.dimer_max_len = in.dimer_max_len;
+    int rc = pack_adapter(in.adapter_seq_r1, p.a1w, p.alen1, err);
+    if (rc) return rc;
+    rc = pack_adapter(in.adapter_seq_r2, p.a2w, p.alen2, err);
+    if (rc) return rc;
+    p.has_a1 = p.alen1 > 0;
+    p.has_a2 = p.alen2 > 0;
+    p.correction = (in.correction != 0) && p.paired;  // options.cpp:401-404
+    p.overlap_require = in.overlap_require;
+    p.overlap_diff_limit = in.overlap_diff_limit;
+    p.qual_filter = in.qual_filter != 0;
+    p.qual_thr = (int)(unsigned char)num2qual(in.qualified_qual);
+    p.n_base_limit = in.n_base_limit;
+    p.avg_qual_req = in.avg_qual_req;
+    p.length_filter = in.length_filter != 0;
+    p.length_required = in.length_required;
+    p.length_limit = in.length_limit;
+    p.complexity_filter = in.complexity_filter != 0;
+    p.dup_enabled = in.dup_enabled != 0;
+    p.dedup = 0;
+    p.isize_max = in.insert_size_max;
+    p.umi_len1 = in.umi_len1 > 0 ? in.umi_len1 : 0;
+    p.umi_len2 = (p.paired && in.umi_len2 > 0) ? in.umi_len2 : 0;
+    p.umi_skip = in.umi_skip > 0 ? in.umi_skip : 0;
+    p.need_overlap = p.paired && (p.adapter_enabled || p.correction);
+
+    // ---- LUTs: the reference's floating point thresholds, evaluated on the host ----
+    const int n = in.max_len + 2;
+    luts.ov_limit.assign(n, 0);
+    luts.lowq_limit.assign(n, 0);
+    luts.cplx_min.assign(n, 0);
+    const double diffPercentLimit = in.overlap_diff_percent_limit / 100.0;  // peprocessor.cpp:440
+    for (int ol = 0; ol <= in.max_len; ol++) {
+        int lim = (int)(ol * diffPercentLimit);  // overlapanalysis.cpp:51,76
+        if (in.overlap_diff_limit < lim) lim = in.overlap_diff_limit;
+        luts.ov_limit[ol] = (int16_t)lim;
+        // filter.cpp:36: FAIL iff lowQualNum > (pct * rlen / 100.0)  <=> lowQualNum > floor(x)
+        const double x = in.unqualified_percent_limit * ol / 100.0;
+        double fl = floor(x);
+        if (fl < 0) fl = -1;  // any count (>= 0) exceeds a negative bound
+        if (fl > 65534) fl = 65534;
+        luts.lowq_limit[ol] = (u16)(fl < 0 ? 0xFFFF : (int)fl);
+        // filter.cpp:65: pass iff (double)diff/(double)(len-1) >= threshold
+        int need = ol;  // impossible -> always fails
+        if (ol >= 2) {
+            for (int d = 0; d <= ol - 1; d++) {
+                if ((double)d / (double)(ol - 1) >= in.complexity_threshold) { need = d; break; }
+            }
+        }
+        luts.cplx_min[ol] = (u16)need;
+    }
+    // a negative lowq bound cannot be expressed as "low > lut"; only reachable with a negative
+    // percent limit, which the reference's CLI does not validate either - reject it.
+    if (in.unqualified_percent_limit < 0) { err = "unqualified_percent_limit < 0"; return FASTP_GPU_E_INVALID; }
+
+    if (p.dup_enabled) {
+        u64 bytes;
+        int num;
+        dup_geometry(in.dup_accuracy_level, bytes, num);
+        p.dup_bufnum = num;
+        p.dup_bits = bytes << 3;
+        dup_primes(num, luts.dup_primes);
+        // position part of Duplicate::seq2intvector: sum_{t<n} prime[(t*B+i)&mask] * t
+        const int maxpos = 2 * in.max_len;
+        luts.dup_posum.assign((size_t)(maxpos + 1) * num, 0);
+        const u32 mask = (u32)(512 * num - 1);
+        for (int i = 0; i < num; i++) {
+            u64 acc = 0;
+            luts.dup_posum[i] = 0;
+            for (int t = 0; t < maxpos; t++) {
+                acc += (u64)luts.dup_primes[((u32)t * (u32)num + (u32)i) & mask] * (u64)t;
+                luts.dup_posum[(size_t)(t + 1) * num + i] = acc;
+            }
+        }
+    } else {
+        p.dup_bufnum = 0;
+        p.dup_bits = 0;
+        luts.dup_primes.clear();
+        luts.dup_posum.clear();
+    }
+    return FASTP_GPU_OK;
+}
+
+static int round_odd(int x) { return (x & 1) ? x : x + 1; }
+
+int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err) {
+    const int waves = cfg.threads / 64;
+    const int mates = p.paired ? 2 : 1;
+    auto build = [&](int P, LdsLayout& out) {
+        memset(&out, 0, sizeof(out));
+        out.P = P;
+        out.NR = mates * P;
+        out.SW = round_odd(p.sw_g + 1);  // +1: window reads touch word w+1
+        out.QW = round_odd(p.qw_g);
+        out.C = p.cycles;
+        int o = 0;
+        auto take = [&](int n) { int at = o; o += n; return at; };
+        // accumulators first (u64 part 8-byte aligned at offset 0)
+        out.acc_cyc = take(4 * N_CLS * out.C * 2);
+        out.acc_kmer = take(4 * KMER_BINS);
+        out.acc_qh = take(4 * 128 * QH_COPIES);
+        out.acc_misc = take(MISC_ISIZE + p.isize_max + 1);
+        out.acc_end = o;
+        if (o & 1) o++;
+        out.hash = take(out.NR * (p.dup_bufnum > 0 ? p.dup_bufnum : 0) * 2);
+        out.seq = take(out.NR * out.SW);
+        out.nmk = take(out.NR * out.SW);
+        out.qual = take(out.NR * out.QW);
+        out.rlen0 = take(out.NR);
+        out.front = take(out.NR);
+        out.len = take(out.NR);
+        out.flags = take(out.NR);
+        out.ft = take(out.NR);
+        out.apos = take(out.NR);
+        out.alen = take(out.NR);
+        out.code = take(out.NR);
+        out.ov_off = take(P);
+        out.ov_len = take(P);
+        out.ov_diff = take(P);
+        out.ov_flags = take(P);
+        out.adapt = take(2 * ADAPT_WORDS);
+        out.wscratch = take(waves * 2 * out.SW);
+        const int lw = (p.max_len + 2) / 2;
+        out.lut_ov = take(lw);
+        out.lut_lowq = take(lw);
+        out.lut_cplx = take(lw);
+        out.primes = take(p.dup_bufnum > 0 ? 512 * p.dup_bufnum : 0);
+        out.total = o;
+    };
+    if (cfg.P > 0) {
+        build(cfg.P, L);
+        if (L.total * 4 > cfg.lds_budget) { err = "tile does not fit the LDS budget"; return FASTP_GPU_E_INVALID; }
+        return FASTP_GPU_OK;
+    }
+    // largest P (multiple of 32 once >= 32, else multiple of 4) that fits
+    int best = 0;
+    for (int P = 4; P <= 1024; P += (P >= 32 ? 32 : 4)) {
+        LdsLayout t;
+        build(P, t);
+        if (t.total * 4 <= cfg.lds_budget) best = P;
+        else break;
+    }
+    if (!best) { err = "no tile size fits the LDS budget"; return FASTP_GPU_E_INVALID; }
+    cfg.P = best;
+    build(best, L);
+    return FASTP_GPU_OK;
+}
+
+}  // namespace fq
+
+// ---------------------------------------------------------------------------
+// C ABI functions that need no device
+// ---------------------------------------------------------------------------
+extern "C" {
+
+size_t fastp_gpu_seq_stride(int max_len) { return (size_t)(((max_len + 3) / 4 + 7) / 8 * 8); }
+size_t fastp_gpu_qual_stride(int max_len) { return (size_t)((max_len + 7) / 8 * 8); }
+
+int fastp_gpu_cycles_for(const fastp_gpu_params* p) { return p->merge ? 2 * p->max_len : p->max_len; }
+
+void fastp_gpu_default_params(fastp_gpu_params* p, int paired, int max_len) {
+    memset(p, 0, sizeof(*p));
+    p->abi_version = FASTP_GPU_ABI_VERSION;
+    p->paired = paired ? 1 : 0;
+    p->max_len = max_len;
+    p->cut_front_window = p->cut_tail_window = p->cut_right_window = 4;       // main.cpp:90
+    p->cut_front_quality = p->cut_tail_quality = p->cut_right_quality = 20;   // main.cpp:91
+    p->poly_g_min_len = 10;            // main.cpp:79
+    p->poly_x_min_len = 10;            // main.cpp:84
+    p->adapter_enabled = 1;            // main.cpp:55
+    p->dimer_max_len = 2;              // main.cpp:62
+    p->overlap_require = 30;           // main.cpp:123
+    p->overlap_diff_limit = 5;         // main.cpp:124
+    p->overlap_diff_percent_limit = 20;  // main.cpp:125
+    p->qual_filter = 1;                // main.cpp:101-105
+    p->qualified_qual = 15;
+    p->unqualified_percent_limit = 40;
+    p->n_base_limit = 5;
+    p->length_filter = 1;              // main.cpp:108-110
+    p->length_required = 15;
+    p->complexity_threshold = 0.30;    // main.cpp:114, 342
+    p->dup_enabled = 1;                // main.cpp:201-210
+    p->dup_accuracy_level = 1;
+    p->insert_size_max = 512;          // options.cpp:23
+}
+
+void fastp_gpu_counter_layout_for(int cycles, int insert_size_max, fastp_gpu_counter_layout* L) {
+    int64_t o = 0;
+    memset(L, 0, sizeof(*L));
+    L->cycles = cycles;
+    o += 4;  // header: abi version, cycles, insert_size_max, reserved
+    L->filter_stats = o;    o += FASTP_FILTER_RESULT_TYPES;
+    L->adapter_reads = o;   o += 1;
+    L->adapter_bases = o;   o += 1;
+    L->polyx_reads = o;     o += 4;
+    L->polyx_bases = o;     o += 4;
+    L->correction = o;      o += 64;
+    L->corrected_reads = o; o += 1;
+    L->merged_pairs = o;    o += 1;
+    L->dup_total = o;       o += 1;
+    L->dup_count = o;       o += 1;
+    L->isize = o;           o += (int64_t)insert_size_max + 1;
+    L->st_reads = 0;
+    L->st_length_sum = 1;
+    L->st_qual_hist = 2;
+    L->st_kmer = 2 + 128;
+    L->st_cycle = 2 + 128 + 1024;
+    L->st_size = L->st_cycle + 34 * (int64_t)cycles;
+    for (int s = 0; s < 4; s++) { L->stats[s] = o; o += L->st_size; }
+    L->total = o;
+}
+
+int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
+                         const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
+                         int32_t* bad_read) {
+    if (n < 0 || max_len <= 0 || !seqs || !quals || !lens || !seq_out || !qual_out || !len_out)
+        return FASTP_GPU_E_INVALID;
+    const size_t ss = fastp_gpu_seq_stride(max_len), qs = fastp_gpu_qual_stride(max_len);
+    for (int i = 0; i < n; i++) {
+        const int len = lens[i];
+        if (len < 0 || len > max_len) { if (bad_read) *bad_read = i; return FASTP_GPU_E_TOO_LONG; }
+        uint8_t* so = seq_out + (size_t)i * ss;
+        uint8_t* qo = qual_out + (size_t)i * qs;
+        memset(so, 0, ss);
+        memset(qo, 0, qs);
+        const char* s = seqs[i];
+        const char* q = quals[i];
+        for (int j = 0; j < len; j++) {
+            int code;
+            uint8_t nflag = 0;
+            switch (s[j]) {
+                case 'A': code = fq::CODE_A; break;
+                case 'T': code = fq::CODE_T; break;
+                case 'C': code = fq::CODE_C; break;
+                case 'G': code = fq::CODE_G; break;
+                case 'N': code = 0; nflag = 0x80; break;
+                default: if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET;
+            }
+            const unsigned char qc = (unsigned char)q[j];
+            if (qc > 127) { if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET; }
+            so[j >> 2] |= (uint8_t)(code << ((j & 3) * 2));
+            qo[j] = (uint8_t)(qc | nflag);
+        }
+        len_out[i] = (uint16_t)len;
+    }
+    return FASTP_GPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// fq_intrin.h - the gfx950 primitives the kernels use, behind short names.
+// 64-wide wavefronts throughout (CDNA4): ballot masks are 64 bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fq_types.h"
+
+#define FQ_DEV __device__ __forceinline__
+
+namespace fq {
+
+FQ_DEV int thread_id() { return (int)threadIdx.x; }
+FQ_DEV int block_threads() { return (int)blockDim.x; }
+FQ_DEV int block_id() { return (int)blockIdx.x; }
+FQ_DEV int grid_blocks() { return (int)gridDim.x; }
+FQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+FQ_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+
+FQ_DEV void block_sync() { __syncthreads(); }
+// make this wave's LDS writes visible to its own other lanes (no cross-wave effect)
+FQ_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+FQ_DEV u64 ballot(bool pred) { return __ballot(pred); }
+FQ_DEV u32 shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
+FQ_DEV u32 shfl_xor(u32 v, int mask) { return (u32)__shfl_xor((int)v, mask, 64); }
+FQ_DEV int popc32(u32 v) { return __popc(v); }
+FQ_DEV int popc64(u64 v) { return __popcll(v); }
+FQ_DEV int ffs64(u64 v) { return __ffsll((unsigned long long)v); }  // 1-based, 0 if none
+FQ_DEV u32 brev32(u32 v) { return __brev(v); }
+// low 32 bits of ({hi,lo} >> (s & 31))  -> v_alignbit_b32
+FQ_DEV u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+// sum of the four bytes of a, plus c  -> v_sad_u8 against zero
+FQ_DEV u32 sum_bytes(u32 a, u32 c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
+
+// LDS accumulators: fire-and-forget ds_add / ds_or (no return value used)
+FQ_DEV void lds_add_u32(u32* p, u32 v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+FQ_DEV void lds_add_u64(u64* p, u64 v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+FQ_DEV void lds_or_u32(u32* p, u32 v) {
+    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+FQ_DEV void lds_or_i32(int* p, int v) {
+    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// device-scope atomics on global memory
+FQ_DEV int g_atomic_add_i32(int* p, int v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+FQ_DEV u32 g_atomic_or_u32(u32* p, u32 v) {
+    return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+FQ_DEV u64 g_atomic_min_u64(u64* p, u64 v) {
+    return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+FQ_DEV u64 g_atomic_cas_u64(u64* p, u64 expected, u64 desired) {
+    __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    return expected;
+}
+FQ_DEV void g_atomic_add_i64(int64_t* p, int64_t v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace fq

@@ -1,0 +1,137 @@
+// fq_types.h - plain-old-data shared by the host side of the C ABI and the
+// gfx950 kernels: the device parameter block, the LDS tile layout and the
+// kernel argument block.  No HIP types in here.
+#pragma once
+#include <stdint.h>
+
+namespace fq {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---- 2-bit base code (also the order of fastp's k-mer code, stats.cpp:294-311,
+//      so complement(code) == code ^ 1 and the 5-mer index needs no remapping
+//      of symbols, only of significance order) --------------------------------
+enum { CODE_A = 0, CODE_T = 1, CODE_C = 2, CODE_G = 3 };
+// statistics class of a base: the four codes, then N
+enum { CLS_N = 4, N_CLS = 5 };
+
+// ---- per-cycle accumulator word in LDS ------------------------------------
+// one u64 per (Stats slot, class, cycle): [cnt:14][q20:14][q30:14][qsum:22]
+// -> a workgroup may accumulate at most CYC_MAX_READS reads per Stats slot
+// between two flushes (enforced by the host when it sizes a launch).
+enum { CYC_CNT_BITS = 14, CYC_Q20_SHIFT = 14, CYC_Q30_SHIFT = 28, CYC_QSUM_SHIFT = 42 };
+enum { CYC_MAX_READS = (1 << CYC_CNT_BITS) - 1 };
+
+enum { QH_COPIES = 8 };        // replicated quality histograms (bank spreading)
+enum { KMER_BINS = 1024 };
+enum { MAX_DUP_BUFS = 8 };
+enum { MAX_ADAPTER_WORDS = 4 };  // 64 bases
+enum { ADAPT_WORDS = 6 };        // LDS words per adapter (4 + zero padding for window reads)
+
+// read flags kept in LDS while a tile is processed (low byte == FASTP_GPU_RF_*)
+enum {
+    RS_NULL = 0x01, RS_DUP = 0x02, RS_ADAPTER = 0x04, RS_ADAPTER_OV = 0x08, RS_CORRECTED = 0x10,
+    RS_MERGED = 0x20, RS_POLYX = 0x40,
+    RS_HAS_N = 0x100,   // the read contains at least one 'N'
+    RS_STAT_POST = 0x200 // goes into the post-filtering Stats
+};
+
+struct DevParams {
+    int paired, max_len, cycles;
+    int sw_g, qw_g;         // global row strides in dwords (seq, qual)
+    int trim_front1, trim_tail1, trim_front2, trim_tail2, max_len1, max_len2;
+    int cut_front, cut_tail, cut_right;
+    int wF, thrF;           // window, w*(33+Q)
+    int wT, thrT;
+    int wR, thrR, qRmin;    // qRmin = 33+Q (filter.cpp:159)
+    int poly_g, poly_g_min, poly_x, poly_x_min;
+    int adapter_enabled, dimer_max_len;
+    int has_a1, has_a2, alen1, alen2;
+    u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
+    int correction;
+    int overlap_require, overlap_diff_limit;
+    int qual_filter, qual_thr, n_base_limit, avg_qual_req;
+    int length_filter, length_required, length_limit;
+    int complexity_filter;
+    int dup_enabled, dedup, dup_bufnum;
+    u64 dup_bits;           // Duplicate::mBufLenInBits
+    int isize_max;
+    int umi_len1, umi_len2, umi_skip;
+    int need_overlap;       // adapter_enabled || correction  (peprocessor.cpp:438,443)
+};
+
+// LUTs living in global memory (built on the host with the reference's own
+// double expressions so the device only does integer compares)
+struct DevLuts {
+    const u16* ov_limit;    // [max_len+1]  min(diffLimit, (int)(ol*pct/100.0))  overlapanalysis.cpp:51
+    const u16* lowq_limit;  // [max_len+1]  floor(unqualPct*rlen/100.0)          filter.cpp:36
+    const u16* cplx_min;    // [max_len+1]  least adjacent-diff count that passes filter.cpp:65
+    const u32* dup_primes;  // [bufnum*512]                                      duplicate.cpp:66-84
+    const u64* dup_posum;   // [(2*max_len+1)*bufnum]  sum_{p<n} prime[(p*B+i)&mask]*p
+};
+
+// LDS layout, all offsets in dwords from the start of dynamic LDS
+struct LdsLayout {
+    int P;          // pairs (PE) or reads (SE) per tile
+    int NR;         // rows per tile: 2P (PE) or P (SE)
+    int SW, QW;     // LDS row strides in dwords (odd -> conflict-free row-per-lane access)
+    int C;          // cycles
+    int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
+    int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
+    int ov_off, ov_len, ov_diff, ov_flags;                // [P]
+    int hash;       // [NR][bufnum] u64 (2 dwords each): per-read part of Duplicate::seq2intvector
+    int adapt;      // [2][ADAPT_WORDS] packed adapter words
+    int wscratch;   // [waves][2*SW] dwords: rc(r2) words + rc N-mask words
+    int lut_ov, lut_lowq, lut_cplx;                       // u16 tables, (max_len+1+1)/2 dwords each
+    int primes;     // [bufnum*512]
+    int acc_cyc;    // [4][N_CLS][C] u64  (2 dwords each)
+    int acc_kmer;   // [4][KMER_BINS] u32
+    int acc_qh;     // [4][128][QH_COPIES] u32
+    int acc_misc;   // MISC_* u32 counters
+    int acc_end;    // end of the accumulator region (acc_cyc..acc_end is flushed)
+    int total;      // dwords of dynamic LDS
+};
+
+// misc counter indices (u32 each) inside acc_misc
+enum {
+    MISC_FILTER = 0,            // [32]
+    MISC_ADAPTER_READS = 32,
+    MISC_ADAPTER_BASES = 33,
+    MISC_POLYX_READS = 34,      // [4]
+    MISC_POLYX_BASES = 38,      // [4]
+    MISC_CORRECTION = 42,       // [64]
+    MISC_CORRECTED_READS = 106,
+    MISC_MERGED = 107,
+    MISC_STAT_READS = 108,      // [4]
+    MISC_STAT_LENSUM = 112,     // [4]
+    MISC_ISIZE = 116,           // [isize_max+1]
+};
+
+struct KernelArgs {
+    DevParams p;
+    DevLuts lut;
+    LdsLayout L;
+    u32 magic_sw, magic_qwg;   // ceil(2^32 / L.SW), ceil(2^32 / p.qw_g) for exact small divisions
+    // batch (device pointers)
+    int n;
+    u32 batch_flags;
+    const u32* seq[2];
+    const u32* qual[2];
+    const u16* len[2];
+    // results
+    u32* res[2];        // fastp_gpu_read_result, 3 dwords each
+    u32* pair;          // fastp_gpu_pair_result, 2 dwords each
+    u32* corrections;   // fastp_gpu_correction, 2 dwords each
+    int corr_capacity;
+    int* n_corrections;
+    u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
+    // per-workgroup counter slabs: [gridDim][slab_dwords]
+    u32* slabs;
+    int slab_dwords;
+    int tiles;          // ceil(n / P)
+};
+
+}  // namespace fq

@@ -1,0 +1,183 @@
+"""Python host mirror of the engine: thin ctypes layer over libfastp_gpu.so (the C ABI of
+include/fastp_gpu.h).  No computation happens here, and there is NO CPU fallback: if the HIP
+library is missing or no MI355X is visible, construction fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_PKG, "libfastp_gpu.so")
+_LIBS: dict[str, C.CDLL] = {}
+
+EXPORTS = [
+    "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
+    "fastp_gpu_counter_layout_for", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
+    "fastp_gpu_pack_reads", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
+]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fastp_gpu error {code}: {msg}")
+        self.code = code
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or os.environ.get("FASTP_GPU_LIB") or DEFAULT_LIB
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'`).  fastp_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    L.fastp_gpu_default_params.argtypes = [C.POINTER(abi.Params), C.c_int, C.c_int]
+    L.fastp_gpu_seq_stride.restype = C.c_size_t
+    L.fastp_gpu_seq_stride.argtypes = [C.c_int]
+    L.fastp_gpu_qual_stride.restype = C.c_size_t
+    L.fastp_gpu_qual_stride.argtypes = [C.c_int]
+    L.fastp_gpu_cycles_for.restype = C.c_int
+    L.fastp_gpu_cycles_for.argtypes = [C.POINTER(abi.Params)]
+    L.fastp_gpu_counter_layout_for.argtypes = [C.c_int, C.c_int, C.POINTER(abi.CounterLayout)]
+    L.fastp_gpu_create.restype = C.c_int
+    L.fastp_gpu_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(C.c_void_p)]
+    L.fastp_gpu_destroy.argtypes = [C.c_void_p]
+    L.fastp_gpu_last_error.restype = C.c_char_p
+    L.fastp_gpu_last_error.argtypes = [C.c_void_p]
+    L.fastp_gpu_pack_reads.restype = C.c_int
+    L.fastp_gpu_pack_reads.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.fastp_gpu_submit_host.restype = C.c_int
+    L.fastp_gpu_submit_host.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results)]
+    L.fastp_gpu_submit_device.restype = C.c_int
+    L.fastp_gpu_submit_device.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results), C.c_void_p]
+    L.fastp_gpu_synchronize.restype = C.c_int
+    L.fastp_gpu_synchronize.argtypes = [C.c_void_p]
+    L.fastp_gpu_counters_device.restype = C.c_int
+    L.fastp_gpu_counters_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
+    L.fastp_gpu_counters.restype = C.c_int
+    L.fastp_gpu_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fastp_gpu_kernel_time.restype = C.c_int
+    L.fastp_gpu_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _LIBS[path] = L
+    return L
+
+
+def counter_layout(params: abi.Params, lib=None) -> abi.CounterLayout:
+    L = lib or load_library()
+    lay = abi.CounterLayout()
+    L.fastp_gpu_counter_layout_for(L.fastp_gpu_cycles_for(C.byref(params)), params.insert_size_max, C.byref(lay))
+    return lay
+
+
+def pack_ascii(lib, max_len, seq, qual, lens):
+    """ASCII rows [n, stride] -> packed rows via the library's host packer."""
+    n = int(len(lens))
+    ss, qs = int(lib.fastp_gpu_seq_stride(max_len)), int(lib.fastp_gpu_qual_stride(max_len))
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    lens32 = np.ascontiguousarray(lens, dtype=np.int32)
+    stride = seq.shape[1] if n else 0
+    sp = (seq.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(stride)).astype(np.uint64)
+    qp = (qual.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(stride)).astype(np.uint64)
+    so = np.zeros((n, ss), dtype=np.uint8)
+    qo = np.zeros((n, qs), dtype=np.uint8)
+    lo = np.zeros(n, dtype=np.uint16)
+    bad = C.c_int32(-1)
+    rc = lib.fastp_gpu_pack_reads(max_len, n, sp.ctypes.data, qp.ctypes.data, lens32.ctypes.data, so.ctypes.data,
+                                  qo.ctypes.data, lo.ctypes.data, C.byref(bad))
+    if rc != 0:
+        raise EngineError(rc, f"fastp_gpu_pack_reads failed at read {bad.value}")
+    return so, qo, lo
+
+
+class GpuEngine:
+    """One fastp run on one GPU: Stats x4 + FilterResult + Duplicate + insert-size histogram live in HBM."""
+
+    def __init__(self, params: abi.Params, device: int = 0, lib_path: str | None = None):
+        self.lib = load_library(lib_path)
+        self.params = params
+        h = C.c_void_p()
+        rc = self.lib.fastp_gpu_create(C.byref(params), device, C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, (self.lib.fastp_gpu_last_error(None) or b"").decode())
+        self.h = h
+        self.layout = counter_layout(params, self.lib)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fastp_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(rc, (self.lib.fastp_gpu_last_error(self.h) or b"").decode())
+
+    # -- packed host buffers -> results (H2D + kernels + D2H) ---------------------------------
+    def submit_packed(self, s1, q1, l1, s2=None, q2=None, l2=None, flags=abi.BATCH_STAT_ISIZE, corr_capacity=None):
+        n = int(len(l1))
+        paired = s2 is not None
+        r1 = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
+        r2 = np.zeros(n if paired else 0, dtype=abi.READ_RESULT_DTYPE)
+        pr = np.zeros(n if paired else 0, dtype=abi.PAIR_RESULT_DTYPE)
+        if corr_capacity is None:
+            corr_capacity = max(1024, n * 32)
+        corr = np.zeros(corr_capacity, dtype=abi.CORRECTION_DTYPE)
+        ncorr = C.c_int32(0)
+        b = abi.Batch()
+        b.n, b.flags = n, flags
+        b.seq1, b.qual1, b.len1 = s1.ctypes.data, q1.ctypes.data, l1.ctypes.data
+        if paired:
+            b.seq2, b.qual2, b.len2 = s2.ctypes.data, q2.ctypes.data, l2.ctypes.data
+        res = abi.Results()
+        res.r1 = r1.ctypes.data
+        res.r2 = r2.ctypes.data if paired else None
+        res.pair = pr.ctypes.data if paired else None
+        res.corrections = corr.ctypes.data
+        res.corrections_capacity = corr_capacity
+        res.n_corrections = C.addressof(ncorr)
+        self._check(self.lib.fastp_gpu_submit_host(self.h, C.byref(b), C.byref(res)))
+        return r1, (r2 if paired else None), (pr if paired else None), corr[:ncorr.value].copy()
+
+    # -- ASCII rows (what the FASTQ decoder produces) -> results -------------------------------
+    def process(self, seq1, qual1, len1, seq2=None, qual2=None, len2=None, flags=abi.BATCH_STAT_ISIZE):
+        ml = self.params.max_len
+        s1, q1, l1 = pack_ascii(self.lib, ml, seq1, qual1, len1)
+        if seq2 is not None:
+            s2, q2, l2 = pack_ascii(self.lib, ml, seq2, qual2, len2)
+            return self.submit_packed(s1, q1, l1, s2, q2, l2, flags)
+        return self.submit_packed(s1, q1, l1, flags=flags)
+
+    # -- device-resident batches (bench / multi-GPU hosts) ---------------------------------------
+    def submit_device(self, batch: abi.Batch, results: abi.Results, stream=None):
+        self._check(self.lib.fastp_gpu_submit_device(self.h, C.byref(batch), C.byref(results), stream))
+
+    def synchronize(self):
+        self._check(self.lib.fastp_gpu_synchronize(self.h))
+
+    def counters(self):
+        out = np.zeros(self.layout.total, dtype=np.int64)
+        self._check(self.lib.fastp_gpu_counters(self.h, out.ctypes.data, out.size))
+        return out
+
+    def counters_device(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.fastp_gpu_counters_device(self.h, C.byref(p), C.byref(n), None))
+        return p.value, n.value
+
+    def kernel_time(self):
+        ms, k = C.c_double(), C.c_int64()
+        self._check(self.lib.fastp_gpu_kernel_time(self.h, C.byref(ms), C.byref(k)))
+        return ms.value, k.value

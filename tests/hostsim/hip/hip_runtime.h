@@ -1,0 +1,132 @@
+// FAKE <hip/hip_runtime.h> - TEST INFRASTRUCTURE ONLY (tests/hostsim).
+//
+// Lets g++ compile the PRODUCT sources (fastp_amd/csrc/*.hip, *.h) unchanged into
+// a host library in which every kernel launch is executed by a lock-step SIMT
+// emulator (sim.cpp): one coroutine per GPU thread, 64-lane wavefront collectives
+// (__ballot/__shfl/wave barrier) and __syncthreads implemented as rendezvous
+// points, threads scheduled in a shuffled order between rendezvous points so a
+// missing barrier shows up as a wrong answer.  It exists so the device code can be
+// checked against the CPU oracle in the CPU-only container; it is never shipped,
+// never loaded by fastp_amd, and is NOT a fallback path of the engine.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+#define FASTP_HOSTSIM 1
+
+// ---- function / storage qualifiers -------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace sim {
+struct ThreadState;
+extern ThreadState* cur;
+struct Idx { unsigned x, y, z; };
+const Idx& thread_idx();
+const Idx& block_idx();
+const Idx& block_dim();
+const Idx& grid_dim();
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void syncthreads();
+void wave_barrier();
+unsigned long long ballot(bool pred);
+int shfl(int v, int src_lane);
+int shfl_xor(int v, int mask);
+}  // namespace sim
+
+#define threadIdx (sim::thread_idx())
+#define blockIdx (sim::block_idx())
+#define blockDim (sim::block_dim())
+#define gridDim (sim::grid_dim())
+
+static inline void __syncthreads() { sim::syncthreads(); }
+static inline unsigned long long __ballot(int pred) { return sim::ballot(pred != 0); }
+static inline int __shfl(int v, int src, int width = 64) { (void)width; return sim::shfl(v, src); }
+static inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; return sim::shfl_xor(v, mask); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline unsigned __brev(unsigned v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+// ---- gfx950 builtins used by fq_intrin.h -----------------------------------------
+static inline unsigned sim_alignbit(unsigned hi, unsigned lo, unsigned s) {
+    return (unsigned)((((unsigned long long)hi << 32) | lo) >> (s & 31));
+}
+static inline unsigned sim_sad_u8(unsigned a, unsigned b, unsigned c) {
+    unsigned r = c;
+    for (int i = 0; i < 4; i++) {
+        int x = (a >> (8 * i)) & 0xFF, y = (b >> (8 * i)) & 0xFF;
+        r += (unsigned)(x > y ? x - y : y - x);
+    }
+    return r;
+}
+#define __builtin_amdgcn_alignbit(hi, lo, s) sim_alignbit((hi), (lo), (s))
+#define __builtin_amdgcn_sad_u8(a, b, c) sim_sad_u8((a), (b), (c))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() sim::wave_barrier()
+
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+template <class T, class V> static inline T __hip_atomic_fetch_add(T* p, V v, int, int) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class V> static inline T __hip_atomic_fetch_or(T* p, V v, int, int) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <class T, class V> static inline T __hip_atomic_fetch_min(T* p, V v, int, int) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T> static inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, int, int, int) {
+    if (*p == *expected) { *p = desired; return true; }
+    *expected = *p;
+    return false;
+}
+
+// ---- the sliver of the HIP runtime API that fastp_gpu.hip calls -------------------
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+typedef struct sim_stream* hipStream_t;
+typedef struct sim_event* hipEvent_t;
+enum { hipStreamNonBlocking = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t {
+    int multiProcessorCount;
+    size_t sharedMemPerBlock;
+};
+static inline const char* hipGetErrorString(hipError_t) { return "hostsim error"; }
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int);
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipDeviceSynchronize();
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipFuncSetAttribute(const void* f, hipFuncAttribute a, int v);
+hipError_t hipGetLastError();
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    sim::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
