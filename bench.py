@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py - Mreads/s of the fused per-read path on synthetic 2x150 bp paired-end batches
+resident in HBM (BASELINE.json metric; workload = configs[2]: PE 2x150, auto-adapter via
+overlap + quality-trim), with the kernel's roofline position and the reference's CPU path
+timed beside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs B]
+
+A step = one pass of the hot path (fused kernel + slab fold + duplicate kernels) over one
+batch of B pairs already in HBM.  N > 1: launched by torch.distributed.run, one rank per GPU,
+every rank owns its own batch (weak scaling, no data-path collective) and the counter blocks
+are merged by one RCCL all-reduce at the end, inside the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+L = 150
+
+
+def algorithmic_bytes_per_pair(L):
+    # per read ceil(L/4) packed bases + L quality + 4 length in, 16 result out
+    return 2 * ((L + 3) // 4 + L + 4) + 2 * 16   # 416 at L=150
+
+
+def bench_params():
+    from fastp_amd import abi
+    p = abi.default_params(True, L)      # adapter trimming by overlap, dup evaluation, filters: fastp defaults
+    p.cut_right = 1                      # + sliding-window quality trim (configs[2])
+    return p, ["-G", "--cut_right"]
+
+
+def cpu_baseline(sample_pairs, flags, params):
+    """reference fastp (oracle/_ref/fastp_ref, scalar-SIMD shim build) on the host cores, on a bounded
+    sample of the same workload; falls back to the plain-C oracle port if the binary is absent."""
+    import numpy as np
+    import synth_torch
+    d = synth_torch.synth_pairs_torch(sample_pairs, L=L, seed=4242, device="cpu")
+    ref = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
+    cores = os.cpu_count() or 1
+    if os.path.exists(ref):
+        need = sample_pairs * 4 * (2 * L + 60) * 2
+        base = None
+        for cand in ("/dev/shm", "/tmp"):
+            try:
+                st = os.statvfs(cand)
+                if st.f_bavail * st.f_frsize > need:
+                    base = cand
+                    break
+            except OSError:
+                pass
+        tmp = tempfile.mkdtemp(prefix="fastp_cpu_", dir=base)
+        f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+        with open(f1, "wb") as f:
+            f.write(synth_torch.to_fastq_bytes(d["seq1"], d["qual1"], 1))
+        with open(f2, "wb") as f:
+            f.write(synth_torch.to_fastq_bytes(d["seq2"], d["qual2"], 2))
+        cmd = [ref, "-i", f1, "-I", f2, "-o", os.path.join(tmp, "o1.fq"), "-O", os.path.join(tmp, "o2.fq"),
+               "-j", os.path.join(tmp, "r.json"), "-h", os.path.join(tmp, "r.html"), "-w", str(cores)] + flags
+        times = []
+        for _ in range(2):
+            t0 = time.time()
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            times.append(time.time() - t0)
+        for fn in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, fn))
+        os.rmdir(tmp)
+        wall = min(times)
+        return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": cores,
+                "kind": "reference",
+                "sample": f"{sample_pairs} synthetic 2x{L} pairs, plain FASTQ -> FASTQ on tmpfs, fastp_ref -w {cores} "
+                          f"(scalar shim for Highway SIMD), end-to-end wall incl. FASTQ parse/write, best of 2"}
+    import oraclelib
+    orc = oraclelib.Oracle(params)
+    pad = lambda a: np.pad(a.numpy(), ((0, 0), (0, 2)))
+    t0 = time.time()
+    orc.process(pad(d["seq1"]), pad(d["qual1"]), d["len1"].numpy(), pad(d["seq2"]), pad(d["qual2"]), d["len2"].numpy())
+    wall = time.time() - t0
+    orc.close()
+    return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_pairs} synthetic 2x{L} pairs through the plain-C oracle (per-read loop only, 1 thread)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=4 * 1024 * 1024, help="pairs per step per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=500_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as graft
+    from fastp_amd import abi, engine, multigpu
+    import synth_torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if rank == 0:
+        graft.build()
+    if dist is not None:
+        dist.barrier()
+
+    params, ref_flags = bench_params()
+    eng = engine.GpuEngine(params, device=local)
+    B = args.pairs
+    d = synth_torch.synth_pairs_torch(B, L=L, seed=42 + rank, device=dev)
+    s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], L)
+    s2, q2, l2 = synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], L)
+    del d
+    r1 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
+    r2 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
+    pr = torch.zeros(B * 8, dtype=torch.uint8, device=dev)
+    ncorr = torch.zeros(1, dtype=torch.int32, device=dev)
+    batch = abi.Batch()
+    batch.n, batch.flags = B, abi.BATCH_STAT_ISIZE
+    batch.seq1, batch.qual1, batch.len1 = s1.data_ptr(), q1.data_ptr(), l1.data_ptr()
+    batch.seq2, batch.qual2, batch.len2 = s2.data_ptr(), q2.data_ptr(), l2.data_ptr()
+    res = abi.Results()
+    res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
+    res.corrections, res.corrections_capacity, res.n_corrections = None, 0, ncorr.data_ptr()
+    torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.submit_device(batch, res)
+    eng.synchronize()
+    eng.kernel_time()  # reset the event accumulator
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.submit_device(batch, res)
+    if dist is not None:
+        multigpu.allreduce_counters_device(eng, dist, dev)   # the one collective of the job
+    eng.synchronize()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kms, klaunches = eng.kernel_time()
+    if rank == 0:
+        total_pairs = B * args.steps * world
+        value = 2.0 * total_pairs / elapsed / 1e6
+        per_launch_pairs = B * args.steps / max(1, klaunches)
+        avg_ms = kms / max(1, klaunches)
+        bpp = algorithmic_bytes_per_pair(L)
+        achieved = per_launch_pairs * bpp / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")   # written from the rocprofv3 --pmc passes
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mreads/sec (whole node), 2x150 bp PE, inputs resident in HBM", "value": round(value, 3),
+            "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "PE 2x150 bp synthetic (fragment model), auto-adapter via overlap + --cut_right "
+                                   "quality trim, dup evaluation on, fastp default filters",
+                       "pairs_per_step_per_gpu": B, "read_len": L, "parallelism": f"shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": "fq_fused_kernel", "kernel_avg_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": int(per_launch_pairs)},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,7 +155,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     const int blocks_per_cu = env_int("FASTP_GPU_BLOCKS_PER_CU", std::max(1, (int)((160 * 1024) / (ctx->L.total * 4))));
     ctx->blocks = ctx->cus * std::max(1, blocks_per_cu);
     // a workgroup's packed per-cycle counters hold CYC_MAX_READS reads per Stats slot
-    const int tiles_per_block = CYC_MAX_READS / ctx->L.P;
+    int tiles_per_block = CYC_MAX_READS / ctx->L.P;
+    const int cap_tiles = env_int("FASTP_GPU_MAX_TILES_PER_BLOCK", 0);  // tests: force several launches
+    if (cap_tiles > 0 && cap_tiles < tiles_per_block) tiles_per_block = cap_tiles;
     if (tiles_per_block < 1) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "tile too large for the packed counters"); }
     long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
     if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
@@ -437,6 +439,24 @@ extern "C" int fastp_gpu_counters(fastp_gpu_ctx* ctx, int64_t* out, int64_t n) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipDeviceSynchronize());  // submits may have used a caller-provided stream
     HIP_TRY(ctx, hipMemcpy(out, ctx->d_ctr, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_counters_export(fastp_gpu_ctx* ctx, int64_t* dst_device, int64_t n) {
+    if (!ctx || !dst_device || n != ctx->cl.total) return fail(ctx, FASTP_GPU_E_INVALID, "counter block size mismatch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(dst_device, ctx->d_ctr, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_device, int64_t n) {
+    if (!ctx || !src_device || n != ctx->cl.total) return fail(ctx, FASTP_GPU_E_INVALID, "counter block size mismatch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(ctx->d_ctr, src_device, (size_t)n * 8, hipMemcpyDeviceToDevice));
+    const int64_t hdr[4] = {FASTP_GPU_ABI_VERSION, ctx->cl.cycles, ctx->dp.isize_max, 0};
+    HIP_TRY(ctx, hipMemcpy(ctx->d_ctr, hdr, sizeof(hdr), hipMemcpyHostToDevice));
     return FASTP_GPU_OK;
 }
 

@@ -19,6 +19,7 @@ EXPORTS = [
     "fastp_gpu_counter_layout_for", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
     "fastp_gpu_pack_reads", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
+    "fastp_gpu_counters_export", "fastp_gpu_counters_import",
 ]
 
 
@@ -63,6 +64,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.fastp_gpu_counters_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p]
     L.fastp_gpu_counters.restype = C.c_int
     L.fastp_gpu_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    for fn in (L.fastp_gpu_counters_export, L.fastp_gpu_counters_import):
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fastp_gpu_kernel_time.restype = C.c_int
     L.fastp_gpu_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _LIBS[path] = L
@@ -176,6 +180,12 @@ class GpuEngine:
         p, n = C.c_void_p(), C.c_int64()
         self._check(self.lib.fastp_gpu_counters_device(self.h, C.byref(p), C.byref(n), None))
         return p.value, n.value
+
+    def counters_export(self, dst_device_ptr: int):
+        self._check(self.lib.fastp_gpu_counters_export(self.h, dst_device_ptr, self.layout.total))
+
+    def counters_import(self, src_device_ptr: int):
+        self._check(self.lib.fastp_gpu_counters_import(self.h, src_device_ptr, self.layout.total))
 
     def kernel_time(self):
         ms, k = C.c_double(), C.c_int64()

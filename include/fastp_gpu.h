@@ -131,8 +131,9 @@ void fastp_gpu_default_params(fastp_gpu_params* p, int paired, int max_len);
 /* ---- batch layout in memory (host or device) ----------------------------
  * SoA, one row per read, rows padded to a fixed stride:
  *   seq : 2 bits/base, base j of a read in bits [2*(j%4), 2*(j%4)+1] of byte
- *         j/4 of its row; code A=0 C=1 G=2 T=3 ('N' is stored as code 0 and
- *         flagged in qual).  Row stride = fastp_gpu_seq_stride(max_len).
+ *         j/4 of its row; code A=0 T=1 C=2 G=3 - fastp's own k-mer code
+ *         (stats.cpp:294-311), so complement == code^1 ('N' is stored as code 0
+ *         and flagged in qual).  Row stride = fastp_gpu_seq_stride(max_len).
  *   qual: 1 byte/base, bits 0..6 = the phred33 ASCII character (33..126),
  *         bit 7 = 1 iff the base is 'N'.  Row stride = fastp_gpu_qual_stride.
  *   len : uint16 read length (0..max_len).
@@ -292,6 +293,13 @@ int fastp_gpu_counters_device(fastp_gpu_ctx* ctx, int64_t** dev_ptr, int64_t* n,
 
 /* copy the counter block to the host (n must equal layout.total) */
 int fastp_gpu_counters(fastp_gpu_ctx* ctx, int64_t* out, int64_t n);
+
+/* Multi-GPU merge without aliasing engine memory: export copies the counter block into a
+ * caller-owned DEVICE buffer of layout.total int64 (e.g. a torch tensor the host then
+ * all-reduces with RCCL); import replaces the engine's block with the merged one (the
+ * non-additive header words are restored).  Both are synchronous. */
+int fastp_gpu_counters_export(fastp_gpu_ctx* ctx, int64_t* dst_device, int64_t n);
+int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_device, int64_t n);
 
 /* time spent inside the fused kernel for the launches since the last call,
  * measured with HIP events on the launch stream: total milliseconds and

@@ -82,7 +82,10 @@ class Oracle:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def process(self, seq1, qual1, len1, seq2=None, qual2=None, len2=None, flags=abi.BATCH_STAT_ISIZE,
                 corr_capacity=None):

@@ -1,0 +1,96 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol of
+include/fastp_gpu.h, and its device-free entry points behave (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oraclelib
+from fastp_amd import abi, engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    return engine.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "fastp_gpu.h")).read()
+    declared = set(re.findall(r"\b(fastp_gpu_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(abi.ReadResult) == 12
+    assert C.sizeof(abi.PairResult) == 8
+    assert C.sizeof(abi.Correction) == 8
+
+
+def test_default_params_match_python_mirror(lib):
+    for paired in (0, 1):
+        p = abi.Params()
+        lib.fastp_gpu_default_params(C.byref(p), paired, 150)
+        q = abi.default_params(paired, 150)
+        for name, _ in abi.Params._fields_:
+            if name in ("reserved", "adapter_seq_r1", "adapter_seq_r2"):
+                continue
+            assert getattr(p, name) == getattr(q, name), name
+
+
+def test_counter_layout_matches_oracle(lib):
+    for cycles, isz in ((150, 512), (300, 512), (251, 100)):
+        a = abi.CounterLayout()
+        lib.fastp_gpu_counter_layout_for(cycles, isz, C.byref(a))
+        b = oraclelib.layout(cycles, isz)
+        assert bytes(a) == bytes(b)
+
+
+def test_strides(lib):
+    for ml in (1, 4, 31, 32, 33, 100, 150, 151, 250, 512):
+        assert lib.fastp_gpu_seq_stride(ml) == abi.seq_stride(ml)
+        assert lib.fastp_gpu_qual_stride(ml) == abi.qual_stride(ml)
+        assert lib.fastp_gpu_seq_stride(ml) * 4 >= ml and lib.fastp_gpu_seq_stride(ml) % 8 == 0
+
+
+def _np_pack(seq, qual, lens, max_len):
+    """independent numpy restatement of the packed layout documented in fastp_gpu.h"""
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, c in zip(b"ATCG", range(4)):
+        code[ch] = c
+    n = len(lens)
+    ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
+    so = np.zeros((n, ss), dtype=np.uint8)
+    qo = np.zeros((n, qs), dtype=np.uint8)
+    for i in range(n):
+        L = int(lens[i])
+        s = seq[i, :L]
+        c = code[s].astype(np.uint32)
+        for j in range(L):
+            so[i, j >> 2] |= c[j] << ((j & 3) * 2)
+        qo[i, :L] = qual[i, :L] | np.where(s == ord("N"), 0x80, 0).astype(np.uint8)
+    return so, qo, lens.astype(np.uint16)
+
+
+def test_pack_reads_layout_and_errors(lib):
+    import synth
+    d = synth.synth_pairs(300, L=150, seed=3)
+    so, qo, lo = engine.pack_ascii(lib, 150, d["seq1"], d["qual1"], d["len1"])
+    eso, eqo, elo = _np_pack(d["seq1"], d["qual1"], d["len1"], 150)
+    assert np.array_equal(so, eso) and np.array_equal(qo, eqo) and np.array_equal(lo, elo)
+    bad = d["seq1"].copy()
+    bad[7, 3] = ord("R")
+    with pytest.raises(engine.EngineError) as e:
+        engine.pack_ascii(lib, 150, bad, d["qual1"], d["len1"])
+    assert e.value.code == abi.E_ALPHABET
+    with pytest.raises(engine.EngineError) as e:
+        engine.pack_ascii(lib, 100, d["seq1"], d["qual1"], d["len1"])
+    assert e.value.code == abi.E_TOO_LONG

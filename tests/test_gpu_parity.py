@@ -1,0 +1,256 @@
+"""Parity tests proper: the HIP path on a real MI355X, called through the C ABI, against
+the CPU oracle on the same seeded inputs, against the committed golden vectors of the real
+reference, and - at large sizes - through size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import driver
+import engines
+import golden_util
+import oraclelib
+import synth
+from fastp_amd import abi, engine
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED = [k for k in cases.CASES if k not in ("pe_noadapter_dedup", "pe_merge", "pe_merge_unmerged", "pe_allow_gap")]
+
+
+def _args(d, paired):
+    return (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+
+
+def _compare(name, params, d, paired, n_expect=None):
+    o = oraclelib.Oracle(params)
+    g = engines.gpu_engine(params)
+    ro, rg = o.process(*_args(d, paired)), g.process(*_args(d, paired))
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    for k, what in enumerate(("read1 results", "read2 results", "pair results")):
+        if ro[k] is not None:
+            bad = np.nonzero(ro[k] != rg[k])[0]
+            assert len(bad) == 0, (f"{name}: {what} differ at {len(bad)} of {len(ro[k])} entries, first {bad[:5]}: "
+                                   f"oracle {ro[k][bad[:3]]} gpu {rg[k][bad[:3]]}")
+    so = np.sort(ro[3], order=["read", "pos"])
+    sg = np.sort(rg[3], order=["read", "pos"])
+    assert np.array_equal(so, sg), f"{name}: correction lists differ ({len(so)} vs {len(sg)})"
+    bad = np.nonzero(co != cg)[0]
+    assert len(bad) == 0, f"{name}: {len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_gpu_equals_oracle(name):
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(20000, L=150, seed=77, paired=paired, **skw)
+    _compare(name, pf(150), d, paired)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_util.names()
+                                  if n == "testdata_pe" or n in SUPPORTED])
+def test_gpu_equals_reference_golden(name):
+    """trimmed FASTQ (md5), failed_out and every JSON number the real reference produced"""
+    fq1, fq2, meta = golden_util.load(name)
+    params = golden_util.params_for(name, max_len=152)
+    eng = engines.gpu_engine(params)
+    outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name))
+    eng.close()
+    golden_util.check_against_golden(name, outs, rep, meta)
+
+
+@pytest.mark.parametrize("L", [36, 75, 100, 250, 400])
+def test_gpu_read_lengths(L):
+    p = abi.default_params(True, L)
+    p.cut_right = 1
+    p.cut_front = 1
+    p.correction = 1
+    p.poly_g = 1
+    p.poly_x = 1
+    d = synth.synth_pairs(6000, L=L, seed=L, insert_mean=L * 1.4, insert_sd=L * 0.5, insert_min=10,
+                          insert_max=max(800, 3 * L), polyg_frac=0.1, polyx_frac=0.1)
+    _compare(f"L{L}", p, d, True)
+
+
+def test_gpu_edge_batches():
+    p = abi.default_params(True, 150)
+    p.cut_tail = 1
+    g = engines.gpu_engine(p)
+    o = oraclelib.Oracle(p)
+    stride = 152
+    # empty batch
+    e = np.zeros((0, stride), dtype=np.uint8)
+    r = g.process(e, e, np.zeros(0, dtype=np.int32), e, e, np.zeros(0, dtype=np.int32))
+    assert len(r[0]) == 0
+    # single pair, all-empty reads, all-N reads, mixed
+    rng = np.random.default_rng(1)
+    for kind in ("single", "empty", "allN", "len1", "mixed"):
+        n = 1 if kind == "single" else 257
+        d = synth.synth_pairs(n, L=150, seed=9, ragged_frac=0.5 if kind == "mixed" else 0.0)
+        if kind == "empty":
+            d["len1"][:] = 0
+            d["len2"][:] = 0
+        if kind == "len1":
+            d["len1"][:] = 1
+            d["len2"][:] = 1
+        if kind == "allN":
+            d["seq1"][:, :150] = ord("N")
+            d["seq2"][::2, :150] = ord("N")
+        for k in ("seq1", "qual1", "seq2", "qual2"):
+            ln = d["len1"] if k.endswith("1") else d["len2"]
+            d[k][np.arange(d[k].shape[1])[None, :] >= ln[:, None]] = 0
+        ro, rg = o.process(*_args(d, True)), g.process(*_args(d, True))
+        for k in range(3):
+            assert ro[k].tobytes() == rg[k].tobytes(), (kind, k)
+        assert np.array_equal(o.counters(), g.counters()), kind
+    g.close()
+    o.close()
+
+
+def test_gpu_several_launches_and_tile_shapes(monkeypatch):
+    """results must not depend on how a batch is cut into launches / tiles / workgroups"""
+    paired, flags, pf, skw = cases.CASES["pe_correction"]
+    d = synth.synth_pairs(30000, L=150, seed=31, **skw)
+    p = pf(150)
+    ref = None
+    for threads, tile, cap in ((512, 0, 0), (256, 32, 2), (1024, 96, 1), (64, 8, 0)):
+        monkeypatch.setenv("FASTP_GPU_THREADS", str(threads))
+        if tile:
+            monkeypatch.setenv("FASTP_GPU_TILE", str(tile))
+        else:
+            monkeypatch.delenv("FASTP_GPU_TILE", raising=False)
+        if cap:
+            monkeypatch.setenv("FASTP_GPU_MAX_TILES_PER_BLOCK", str(cap))
+        else:
+            monkeypatch.delenv("FASTP_GPU_MAX_TILES_PER_BLOCK", raising=False)
+        g = engines.gpu_engine(p)
+        r = g.process(*_args(d, True))
+        c = g.counters()
+        g.close()
+        cur = (r[0].tobytes(), r[1].tobytes(), r[2].tobytes(), np.sort(r[3], order=["read", "pos"]).tobytes(), c.tobytes())
+        if ref is None:
+            ref = cur
+        assert cur == ref, (threads, tile, cap)
+
+
+def test_gpu_streamed_batches_equal_one_batch():
+    """the engine is a stream processor: cutting the input into packs changes nothing
+    (Stats are sums; Duplicate keeps the reference's sequential semantics across submits)"""
+    p = abi.default_params(True, 150)
+    d = synth.synth_pairs(24000, L=150, seed=8, dup_frac=0.3)
+    g1 = engines.gpu_engine(p)
+    whole = g1.process(*_args(d, True))
+    c1 = g1.counters()
+    g1.close()
+    g2 = engines.gpu_engine(p)
+    parts = []
+    for a in range(0, 24000, 5000):
+        sl = {k: v[a:a + 5000] for k, v in d.items()}
+        parts.append(g2.process(*_args(sl, True)))
+    c2 = g2.counters()
+    g2.close()
+    for k in range(3):
+        assert whole[k].tobytes() == np.concatenate([p_[k] for p_ in parts]).tobytes(), k
+    assert np.array_equal(c1, c2)
+
+
+def test_gpu_full_size_properties():
+    """size-independent properties on device-resident batches at bench scale (default 8M pairs;
+    FASTP_FULLSIZE_PAIRS=100000000 runs BASELINE.json's configs[2] size):
+      * conservation: every pair lands in exactly one filter bin, pre-stats see every read,
+        post-stats see exactly the passing pairs, dup_total counts every pair
+      * linearity: feeding the same batch twice doubles every additive counter
+      * determinism: result records of the second pass equal the first (except the dup flag)"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(engines.ROOT, "tools"))
+    import synth_torch
+    total = int(os.environ.get("FASTP_FULLSIZE_PAIRS", str(8 * 1024 * 1024)))
+    chunk = 2 * 1024 * 1024
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    g = engines.gpu_engine(p)
+    lay = g.layout
+    dev = torch.device("cuda", 0)
+    done = 0
+    seed = 0
+    passed_pairs = 0
+    while done < total:
+        n = min(chunk, total - done)
+        d = synth_torch.synth_pairs_torch(n, L=150, seed=1000 + seed, device=dev)
+        s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], 150)
+        s2, q2, l2 = synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], 150)
+        del d
+        outs = []
+        for rep in range(2 if done == 0 else 1):
+            r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+            r2 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+            pr = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+            nc = torch.zeros(1, dtype=torch.int32, device=dev)
+            b = abi.Batch()
+            b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+            b.seq1, b.qual1, b.len1 = s1.data_ptr(), q1.data_ptr(), l1.data_ptr()
+            b.seq2, b.qual2, b.len2 = s2.data_ptr(), q2.data_ptr(), l2.data_ptr()
+            res = abi.Results()
+            res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
+            res.corrections, res.corrections_capacity, res.n_corrections = None, 0, nc.data_ptr()
+            if done == 0 and rep == 0:
+                before = g.counters()
+            g.submit_device(b, res)
+            g.synchronize()
+            torch.cuda.synchronize(dev)
+            outs.append((r1.cpu().numpy().view(abi.READ_RESULT_DTYPE), r2.cpu().numpy().view(abi.READ_RESULT_DTYPE),
+                         pr.cpu().numpy().view(abi.PAIR_RESULT_DTYPE)))
+            if done == 0 and rep == 0:
+                first = g.counters() - before
+        if done == 0:
+            second = g.counters() - before - first
+            add = np.ones(lay.total, dtype=bool)
+            add[:4] = False
+            add[lay.dup_count] = False   # the second pass finds every pair already seen
+            assert np.array_equal(first[add], second[add]), "counters are not linear in the input"
+            assert second[lay.dup_count] == n, "second pass of the same batch must be 100% duplicates"
+            a, b2 = outs
+            for k in range(3):
+                x, y = a[k].copy(), b2[k].copy()
+                if k < 2:
+                    x["flags"] &= ~np.uint8(abi.RF_DUP)
+                    y["flags"] &= ~np.uint8(abi.RF_DUP)
+                assert x.tobytes() == y.tobytes(), "results are not deterministic"
+            assert (b2[0]["flags"] & abi.RF_DUP).all()
+            passes = 2
+        else:
+            passes = 1
+        r1h, r2h, _ = outs[-1]
+        ok = (r1h["code"] == 0) & (r2h["code"] == 0)
+        passed_pairs += int(ok.sum()) * passes
+        done += n
+        seed += 1
+    ctr = g.counters()
+    g.close()
+    fed = total + chunk if total >= chunk else 2 * total   # first chunk was fed twice
+    fed = total + min(chunk, total)
+    fs = ctr[lay.filter_stats: lay.filter_stats + 32]
+    assert fs.sum() == 2 * fed
+    assert fs[abi.PASS_FILTER] == 2 * passed_pairs
+    for slot in (abi.STATS_PRE1, abi.STATS_PRE2):
+        assert ctr[lay.stats[slot] + lay.st_reads] == fed
+        assert ctr[lay.stats[slot] + lay.st_length_sum] == fed * 150
+    for slot in (abi.STATS_POST1, abi.STATS_POST2):
+        assert ctr[lay.stats[slot] + lay.st_reads] == passed_pairs
+    assert ctr[lay.dup_total] == fed
+    assert ctr[lay.isize: lay.isize + 513].sum() == fed
+    for slot in range(4):
+        base = lay.stats[slot]
+        cyc = ctr[base + lay.st_cycle: base + lay.st_cycle + 34 * 150].reshape(34, 150)
+        assert np.array_equal(cyc[16:24].sum(0), cyc[32]), "per-base contents must add up to total bases"
+        assert np.array_equal(cyc[24:32].sum(0), cyc[33])
+        assert cyc[32].sum() == ctr[base + lay.st_length_sum]
+        assert ctr[base + lay.st_qual_hist: base + lay.st_qual_hist + 128].sum() == cyc[32].sum()
+
+
+def test_gpu_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        engine.load_library(str(tmp_path / "nope.so"))

@@ -1,0 +1,78 @@
+"""The DEVICE code (fastp_amd/csrc) executed by the lock-step SIMT emulator of
+tests/hostsim and compared with the CPU oracle - lets the kernels be checked in the
+CPU-only container.  The real-GPU parity tests are tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import cases
+import driver
+import engines
+import golden_util
+import oraclelib
+import refjson
+import synth
+from fastp_amd import abi, engine, hostloop
+
+SUPPORTED = [k for k in cases.CASES if k not in ("pe_noadapter_dedup", "pe_merge", "pe_merge_unmerged", "pe_allow_gap")]
+
+
+def _both(params, d, paired):
+    o = oraclelib.Oracle(params)
+    g = engines.sim_engine(params)
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    return ro, rg, co, cg
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_sim_records_and_counters_equal_oracle(name):
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(700, L=150, seed=21, paired=paired, **skw)
+    ro, rg, co, cg = _both(pf(150), d, paired)
+    for k, what in enumerate(("r1", "r2", "pair")):
+        if ro[k] is not None:
+            bad = np.nonzero(ro[k] != rg[k])[0]
+            assert len(bad) == 0, f"{name}: {what} differs at {bad[:5]}: oracle {ro[k][bad[:3]]} device {rg[k][bad[:3]]}"
+    so = np.sort(ro[3], order=["read", "pos"])
+    sg = np.sort(rg[3], order=["read", "pos"])
+    assert np.array_equal(so, sg), f"{name}: correction lists differ"
+    assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
+
+
+@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "se_adapter_cut", "testdata_pe"])
+def test_sim_matches_reference_golden(name):
+    fq1, fq2, meta = golden_util.load(name)
+    params = golden_util.params_for(name, max_len=152)
+    eng = engines.sim_engine(params)
+    outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name))
+    eng.close()
+    golden_util.check_against_golden(name, outs, rep, meta)
+
+
+def test_sim_other_read_lengths_and_tile_shapes(monkeypatch):
+    """2x250 and short reads; a non-default tile / workgroup shape must not change anything"""
+    for L, tile, threads in ((250, 0, 512), (75, 12, 128), (100, 40, 256)):
+        if tile:
+            monkeypatch.setenv("FASTP_GPU_TILE", str(tile))
+        monkeypatch.setenv("FASTP_GPU_THREADS", str(threads))
+        p = abi.default_params(True, L)
+        p.cut_right = 1
+        p.correction = 1
+        p.poly_g = 1
+        d = synth.synth_pairs(300, L=L, seed=5, insert_mean=L * 1.3, insert_sd=L * 0.4, polyg_frac=0.1)
+        ro, rg, co, cg = _both(p, d, True)
+        for k in range(3):
+            assert ro[k].tobytes() == rg[k].tobytes(), (L, k)
+        assert np.array_equal(co, cg)
+
+
+def test_sim_unsupported_options_fail_loudly():
+    for field in ("merge", "allow_gap_overlap_trimming", "dedup"):
+        p = abi.default_params(True, 150)
+        setattr(p, field, 1)
+        with pytest.raises(engine.EngineError) as e:
+            engines.sim_engine(p)
+        assert e.value.code == abi.E_UNSUPPORTED
