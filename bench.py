@@ -48,7 +48,7 @@ def cpu_baseline(sample_pairs, flags, params):
     import synth_torch
     d = synth_torch.synth_pairs_torch(sample_pairs, L=L, seed=4242, device="cpu")
     ref = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)   # the reference stops scaling long before that (reader-thread bound)
     if os.path.exists(ref):
         need = sample_pairs * 4 * (2 * L + 60) * 2
         base = None
@@ -71,7 +71,7 @@ def cpu_baseline(sample_pairs, flags, params):
         times = []
         for _ in range(2):
             t0 = time.time()
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300)
             times.append(time.time() - t0)
         for fn in os.listdir(tmp):
             os.unlink(os.path.join(tmp, fn))
@@ -90,6 +90,11 @@ def cpu_baseline(sample_pairs, flags, params):
     orc.close()
     return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
             "sample": f"{sample_pairs} synthetic 2x{L} pairs through the plain-C oracle (per-read loop only, 1 thread)"}
+
+
+def log(msg):
+    if os.environ.get("BENCH_VERBOSE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -126,7 +131,9 @@ def main():
         dist.barrier()
 
     params, ref_flags = bench_params()
+    log("creating engine")
     eng = engine.GpuEngine(params, device=local)
+    log("generating batch")
     B = args.pairs
     d = synth_torch.synth_pairs_torch(B, L=L, seed=42 + rank, device=dev)
     s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], L)
@@ -144,6 +151,7 @@ def main():
     res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
     res.corrections, res.corrections_capacity, res.n_corrections = None, 0, ncorr.data_ptr()
     torch.cuda.synchronize(dev)
+    log("warmup")
 
     for _ in range(args.warmup):
         eng.submit_device(batch, res)
@@ -169,6 +177,7 @@ def main():
         elapsed = float(t.item())
 
     kms, klaunches = eng.kernel_time()
+    log(f"timed region done: {elapsed:.3f}s, kernel {kms:.2f} ms over {klaunches} launches")
     if rank == 0:
         total_pairs = B * args.steps * world
         value = 2.0 * total_pairs / elapsed / 1e6

@@ -58,6 +58,7 @@ struct fastp_gpu_ctx {
     u8* d_need = nullptr; size_t need_cap = 0;
     // staging for submit_host
     void* d_stage = nullptr; size_t stage_cap = 0;
+    u64* d_phase = nullptr;   // optional per-phase cycle counters (FASTP_GPU_PHASE_TIMING=1)
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -111,7 +112,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     drain_events(ctx);
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_ctr, ctx->d_slabs,
-                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_stage};
+                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_stage, ctx->d_phase};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -203,7 +204,21 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         CREATE_TRY(hipMalloc((void**)&ctx->d_bitmap, bytes));
         CREATE_TRY(hipMemsetAsync(ctx->d_bitmap, 0, bytes, ctx->stream));
     }
+    if (env_int("FASTP_GPU_PHASE_TIMING", 0)) {
+        CREATE_TRY(hipMalloc((void**)&ctx->d_phase, 16 * sizeof(u64)));
+        CREATE_TRY(hipMemsetAsync(ctx->d_phase, 0, 16 * sizeof(u64), ctx->stream));
+    }
     CREATE_TRY(hipStreamSynchronize(ctx->stream));
+    return FASTP_GPU_OK;
+}
+
+// debugging aid (not part of the drop-in surface): cycles spent per phase of the fused kernel,
+// summed over workgroups, when the context was created with FASTP_GPU_PHASE_TIMING=1
+extern "C" int fastp_gpu_debug_phase_cycles(fastp_gpu_ctx* ctx, uint64_t* out16) {
+    if (!ctx || !out16 || !ctx->d_phase) return FASTP_GPU_E_INVALID;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(out16, ctx->d_phase, 16 * sizeof(u64), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemset(ctx->d_phase, 0, 16 * sizeof(u64)));
     return FASTP_GPU_OK;
 }
 
@@ -244,6 +259,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.magic_sw = magic_for((u32)ctx->L.SW);
     a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
     a.n = n;
+    a.first = first;
     a.batch_flags = b->flags;
     const size_t swg = ctx->dp.sw_g, qwg = ctx->dp.qw_g;
     a.seq[0] = (const u32*)b->seq1 + (size_t)first * swg;
@@ -265,6 +281,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (rc) return rc;
         a.dup_pos = ctx->d_dup_pos;
     }
+    a.phase_cycles = ctx->d_phase;
     a.slabs = ctx->d_slabs;
     a.slab_dwords = ctx->slab_dwords;
     a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
@@ -341,8 +358,12 @@ extern "C" int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
-    for (int first = 0; first < b->n; first += ctx->max_pairs_per_launch) {
-        const int n = std::min(ctx->max_pairs_per_launch, b->n - first);
+    // split into equally sized launches (each a multiple of the tile size)
+    const int launches = (b->n + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
+    int per = launches ? (b->n + launches - 1) / launches : 0;
+    per = (per + ctx->L.P - 1) / ctx->L.P * ctx->L.P;
+    for (int first = 0; first < b->n; first += per) {
+        const int n = std::min(per, b->n - first);
         int rc = launch_chunk(ctx, b, first, n, res, st);
         if (rc) return rc;
     }

@@ -807,7 +807,7 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
                             if (a.corrections) {
                                 const int slot = g_atomic_add_i32(a.n_corrections, 1);
                                 if (slot < a.corr_capacity) {
-                                    a.corrections[2 * slot] = (u32)(2 * gp + which);
+                                    a.corrections[2 * slot] = (u32)(2 * (a.first + gp) + which);
                                     a.corrections[2 * slot + 1] = (u32)cpos | (sym_ascii(nb) << 16) | (nq << 24);
                                 }
                             }
@@ -973,24 +973,40 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         }
     }
     block_sync();
+    const bool timing_on = a.phase_cycles != nullptr;  // uniform
+    const bool timing = timing_on && tid == 0;
+    u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
         const int n_valid = imin(L.P, a.n - tile_first);
+        u64 t0 = timing ? cycle_counter() : 0, t1;
+#define FQ_STAMP(k) if (timing) { t1 = cycle_counter(); tacc[k] += t1 - t0; t0 = t1; }
         phase_load(a, lds, tile_first, tid, nt);
         block_sync();
+        FQ_STAMP(0)
         phase_stats(a, lds, false, n_valid, tid, nt);  // Stats::statRead on the original reads
+        if (timing_on) block_sync();
+        FQ_STAMP(1)
         phase_trim(a, lds, tid, nt);
         block_sync();
+        FQ_STAMP(2)
         phase_polyg(a, lds, tid, nt);
         block_sync();
+        FQ_STAMP(3)
         phase_overlap(a, lds, tid, nt);
         block_sync();
+        FQ_STAMP(4)
         if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
         else phase_decide_se(a, lds, tile_first, tid, nt);
         block_sync();
+        FQ_STAMP(5)
         phase_stats(a, lds, true, n_valid, tid, nt);   // Stats::statRead on what is written out
         block_sync();
+        FQ_STAMP(6)
+#undef FQ_STAMP
     }
+    if (timing)
+        for (int k = 0; k < 8; k++) g_atomic_add_u64(&a.phase_cycles[k], tacc[k]);
     // flush this workgroup's accumulators to its slab (plain coalesced stores)
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];

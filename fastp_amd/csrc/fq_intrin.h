@@ -17,6 +17,10 @@ FQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 FQ_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
 
 FQ_DEV void block_sync() { __syncthreads(); }
+FQ_DEV u64 cycle_counter() { return (u64)clock64(); }
+FQ_DEV void g_atomic_add_u64(u64* p, u64 v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // make this wave's LDS writes visible to its own other lanes (no cross-wave effect)
 FQ_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

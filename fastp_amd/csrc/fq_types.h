@@ -117,6 +117,7 @@ struct KernelArgs {
     u32 magic_sw, magic_qwg;   // ceil(2^32 / L.SW), ceil(2^32 / p.qw_g) for exact small divisions
     // batch (device pointers)
     int n;
+    int first;          // index of this launch's first read/pair inside the submitted batch
     u32 batch_flags;
     const u32* seq[2];
     const u32* qual[2];
@@ -128,6 +129,7 @@ struct KernelArgs {
     int corr_capacity;
     int* n_corrections;
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
+    u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)
     // per-workgroup counter slabs: [gridDim][slab_dwords]
     u32* slabs;
     int slab_dwords;

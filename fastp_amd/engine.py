@@ -187,6 +187,15 @@ class GpuEngine:
     def counters_import(self, src_device_ptr: int):
         self._check(self.lib.fastp_gpu_counters_import(self.h, src_device_ptr, self.layout.total))
 
+    def debug_phase_cycles(self):
+        """cycles per phase of the fused kernel (context created with FASTP_GPU_PHASE_TIMING=1)"""
+        out = (C.c_uint64 * 16)()
+        fn = self.lib.fastp_gpu_debug_phase_cycles
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, out))
+        return list(out)
+
     def kernel_time(self):
         ms, k = C.c_double(), C.c_int64()
         self._check(self.lib.fastp_gpu_kernel_time(self.h, C.byref(ms), C.byref(k)))

@@ -65,6 +65,7 @@ static inline unsigned __brev(unsigned v) {
     v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
     return (v >> 16) | (v << 16);
 }
+static inline long long clock64() { return 0; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 // ---- gfx950 builtins used by fq_intrin.h -----------------------------------------
@@ -116,6 +117,7 @@ hipError_t hipFree(void* p);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
+hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
