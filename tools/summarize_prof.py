@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense one GPU-box visit's rocprofv3 output (gpurun_out/prof/<tag>, <tag>_fetch, <tag>_write)
+into profiles/<tag>_*.  HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE
+are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream -> doubled
+(checked here against the known input footprint of the fused kernel); WRITE_SIZE is used as is."""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = list(csv.DictReader(open(os.path.join(src, tag, "trace_kernel_stats.csv"))))
+ours = [r for r in stats if r["Name"].startswith("fq_")]
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
+    w.writeheader()
+    for r in stats:
+        r = dict(r)
+        if len(r["Name"]) > 120:
+            r["Name"] = r["Name"][:117] + "..."
+        w.writerow(r)
+
+trace = list(csv.DictReader(open(os.path.join(src, tag, "trace_kernel_trace.csv"))))
+geom = {}
+for r in trace:
+    if r["Kernel_Name"].startswith("fq_") and r["Kernel_Name"] not in geom:
+        geom[r["Kernel_Name"]] = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
+                                                    "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
+
+pmc = {}
+for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    p = os.path.join(src, f"{tag}_{kind}", "pmc_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if r["Kernel_Name"].startswith("fq_") and r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        pmc.setdefault(k, {})[counter + "_KiB_avg"] = sum(v) / len(v)
+        pmc[k][counter + "_launches"] = len(v)
+
+out = {"tag": tag, "kernels": {}}
+for r in ours:
+    k = r["Name"]
+    e = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6,
+         "max_ms": float(r["MaxNs"]) / 1e6}
+    e.update(geom.get(k, {}))
+    if k in pmc:
+        e.update(pmc[k])
+        fetch = pmc[k].get("FETCH_SIZE_KiB_avg")
+        write = pmc[k].get("WRITE_SIZE_KiB_avg")
+        if fetch is not None and write is not None:
+            e["hbm_read_bytes_per_launch"] = fetch * 1024 * 2      # gfx950: FETCH_SIZE = 1/2 of the bytes
+            e["hbm_write_bytes_per_launch"] = write * 1024
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+    out["kernels"][k] = e
+for extra in ("bench.log", "phase.log"):
+    p = os.path.join(ROOT, "gpurun_out", extra)
+    if os.path.exists(p):
+        lines = [l.rstrip("\n") for l in open(p) if l.startswith("{") or l.startswith("kernel ")]
+        if lines:
+            out[extra] = lines[-1]
+json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
