@@ -144,7 +144,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     ctx->cus = prop.multiProcessorCount;
     // tile / launch geometry (tunable without a rebuild)
     const int lds_kb_default = (int)(prop.sharedMemPerBlock / 1024) >= 160 ? 156 : (int)(prop.sharedMemPerBlock / 1024) - 4;
-    ctx->cfg.threads = env_int("FASTP_GPU_THREADS", 512);
+    ctx->cfg.threads = env_int("FASTP_GPU_THREADS", 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
     ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", lds_kb_default) * 1024;
     if (ctx->cfg.threads < 64 || ctx->cfg.threads > 1024 || (ctx->cfg.threads & 63)) {

@@ -98,6 +98,7 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
             lds_i(lds, L.ov_flags)[R] = 0;
         }
     }
+    for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
     // packed bases (+ zero the N masks and the pad words)
     for (int m = 0; m < mates; m++) {
         const u32* g = a.seq[m];
@@ -138,6 +139,59 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
     }
 }
 
+// total quality (N flag masked off) of the windows [4c+k, 4c+k+w), k = 0..3, of one row:
+// v_alignbit_b32 + v_sad_u8 per 4 bases.  ncols = dwords of the LDS row (pad columns are zero).
+FQ_DEV void window_sums4(const u32* qrow, int c, int ncols, int w, u32 out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    u32 lo = qrow[c] & 0x7F7F7F7Fu;
+    int rem = w;
+    for (int i = c + 1; rem > 0; i++, rem -= 4) {
+        const u32 hi = i < ncols ? (qrow[i] & 0x7F7F7F7Fu) : 0u;
+        const u32 keep = lowmask32(8 * rem);
+        out[0] = sum_bytes(lo & keep, out[0]);
+        out[1] = sum_bytes(alignbit(hi, lo, 8) & keep, out[1]);
+        out[2] = sum_bytes(alignbit(hi, lo, 16) & keep, out[2]);
+        out[3] = sum_bytes(alignbit(hi, lo, 24) & keep, out[3]);
+        lo = hi;
+    }
+}
+
+// The sliding windows of Filter::trimAndCut (filter.cpp:97-194) evaluated for EVERY start
+// position at once: lane (read R, quality dword c) sets bits 4c..4c+3 of the read's predicate
+// masks; trim_and_cut() then only bit-scans them.  A window sum is position-absolute, so the
+// reference's rolling sum at position s equals the mask's window [s, s+w).
+FQ_DEV void build_trim_masks(const DevParams& p, const LdsLayout& L, u32* lds, int R, int c, u32 qd, u32 ncur) {
+    u32* wm = lds + L.wm + R * L.wm_stride;
+    const u32* qrow = lds + L.qual + R * L.QW;
+    const int wi = c >> 3, sh = (c & 7) * 4;
+    u32 s4[4];
+    if (L.wm_badF >= 0 && p.wF <= p.max_len) {
+        window_sums4(qrow, c, L.QW, p.wF, s4);
+        const u32 b = (u32)((int)s4[0] < p.thrF) | ((u32)((int)s4[1] < p.thrF) << 1) | ((u32)((int)s4[2] < p.thrF) << 2) |
+                      ((u32)((int)s4[3] < p.thrF) << 3);
+        if (b) lds_or_u32(&wm[L.wm_badF + wi], b << sh);
+    }
+    if (L.wm_badR >= 0 && p.wR <= p.max_len) {
+        window_sums4(qrow, c, L.QW, p.wR, s4);
+        const u32 b = (u32)((int)s4[0] < p.thrR) | ((u32)((int)s4[1] < p.thrR) << 1) | ((u32)((int)s4[2] < p.thrR) << 2) |
+                      ((u32)((int)s4[3] < p.thrR) << 3);
+        if (b) lds_or_u32(&wm[L.wm_badR + wi], b << sh);
+    }
+    if (L.wm_badT >= 0 && p.wT <= p.max_len) {
+        window_sums4(qrow, c, L.QW, p.wT, s4);
+        const u32 b = (u32)((int)s4[0] < p.thrT) | ((u32)((int)s4[1] < p.thrT) << 1) | ((u32)((int)s4[2] < p.thrT) << 2) |
+                      ((u32)((int)s4[3] < p.thrT) << 3);
+        if (b) lds_or_u32(&wm[L.wm_badT + wi], b << sh);
+    }
+    if (L.wm_lowQ >= 0) {
+        u32 b = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) b |= (u32)((int)((qd >> (8 * k)) & 0x7Fu) < p.qRmin) << k;
+        if (b) lds_or_u32(&wm[L.wm_lowQ + wi], b << sh);
+    }
+    if (L.wm_isN >= 0 && ncur) lds_or_u32(&wm[L.wm_isN + wi], ncur << sh);
+}
+
 // ---------------------------------------------------------------------------
 // Phases B / F: Stats::statRead (stats.cpp:191-291) over a tile.
 // lane = (read R, quality dword c) = cycles 4c..4c+3 of that read.
@@ -176,6 +230,10 @@ FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, bool post, int n_valid, i
         if (j0 >= f + l || j0 + 4 <= f) continue;
         const u32* srow = lds + L.seq + R * L.SW;
         const u32 qd = lds[L.qual + R * L.QW + c];
+        if (!post && L.wm_stride) {
+            const u32 nb0 = (qd >> 7) & 0x01010101u;
+            build_trim_masks(a.p, L, lds, R, c, qd, (nb0 | (nb0 >> 7) | (nb0 >> 14) | (nb0 >> 21)) & 0xFu);
+        }
         const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
         u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
         if (c > 0) {
@@ -215,11 +273,47 @@ FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, bool post, int n_valid, i
 }
 
 // ---------------------------------------------------------------------------
-// Filter::trimAndCut (filter.cpp:68-207) on one read.  Returns false for NULL.
-// q = quality bytes (bit 7 = N flag) of the read as it is now (after UMI trim).
+// bit scans over a position mask (bit j of word j>>5 = predicate at base j)
 // ---------------------------------------------------------------------------
-FQ_DEV bool trim_and_cut(const DevParams& p, const u8* q, int len, int front, int tail, int& out_front,
-                         int& out_len) {
+// first j in [lo, hi) whose bit == want; hi if there is none
+FQ_DEV int scan_first(const u32* m, int lo, int hi, bool want) {
+    if (lo >= hi) return hi;
+    int w = lo >> 5;
+    const int wend = (hi - 1) >> 5;
+    u32 x = (want ? m[w] : ~m[w]) & ~lowmask32(lo & 31);
+    for (;;) {
+        if (x) {
+            const int j = (w << 5) + ffs32(x) - 1;
+            return j < hi ? j : hi;
+        }
+        if (++w > wend) return hi;
+        x = want ? m[w] : ~m[w];
+    }
+}
+// last j in [lo, hi) whose bit == want; lo - 1 if there is none
+FQ_DEV int scan_last(const u32* m, int lo, int hi, bool want) {
+    if (lo >= hi) return lo - 1;
+    int w = (hi - 1) >> 5;
+    const int wbeg = lo >> 5;
+    u32 x = (want ? m[w] : ~m[w]) & lowmask32(((hi - 1) & 31) + 1);
+    for (;;) {
+        if (x) {
+            const int j = (w << 5) + 31 - clz32(x);
+            return j >= lo ? j : lo - 1;
+        }
+        if (--w < wbeg) return lo - 1;
+        x = want ? m[w] : ~m[w];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Filter::trimAndCut (filter.cpp:68-207) on one read.  Returns false for NULL.
+// wm = the read's predicate masks (build_trim_masks), u = row position of the read's
+// first base as trimAndCut sees it (after the UMI front trim), len = its length.
+// Every loop of the reference becomes one bit scan; comments give the loop it replaces.
+// ---------------------------------------------------------------------------
+FQ_DEV bool trim_and_cut(const DevParams& p, const LdsLayout& L, const u32* wm, int u, int len, int front, int tail,
+                         int& out_front, int& out_len) {
     out_front = 0;
     out_len = len;
     const bool enF = p.cut_front, enT = p.cut_tail, enR = p.cut_right;
@@ -234,50 +328,33 @@ FQ_DEV bool trim_and_cut(const DevParams& p, const u8* q, int len, int front, in
     const int l = len;
     if (enF) {  // :97-127
         const int w = p.wF;
-        int s = front;
         if (l - front - tail - w <= 0) return false;
-        int total = 0;
-        for (int i = 0; i < w - 1; i++) total += (int)(q[s + i] & 0x7F);
-        for (s = front; s + w < l - tail; s++) {
-            total += (int)(q[s + w - 1] & 0x7F);
-            if (s > front) total -= (int)(q[s - 1] & 0x7F);
-            if (total >= p.thrF) break;
-        }
+        const int end = l - tail - w;  // for (s = front; s + w < l - tail; s++) ... break at the first good window
+        int s = scan_first(wm + L.wm_badF, u + front, u + end, false) - u;  // no break: s == end
         if (s > 0) s = s + w - 1;
-        while (s < l && (q[s] & 0x80)) s++;  // seq[s] == 'N'
+        s = scan_first(wm + L.wm_isN, u + s, u + l, false) - u;  // while (s < l && seq[s] == 'N') s++
         front = s;
         rlen = l - front - tail;
     }
     if (enR) {  // :130-163
         const int w = p.wR;
-        int s = front;
         if (l - front - tail - w <= 0) return false;
-        int total = 0;
-        for (int i = 0; i < w - 1; i++) total += (int)(q[s + i] & 0x7F);
-        bool found = false;
-        for (s = front; s + w < l - tail; s++) {
-            total += (int)(q[s + w - 1] & 0x7F);
-            if (s > front) total -= (int)(q[s - 1] & 0x7F);
-            if (total < p.thrR) { found = true; break; }
-        }
-        if (found) {
-            while (s < l - 1 && (int)(q[s] & 0x7F) >= p.qRmin) s++;
+        const int end = l - tail - w;
+        int s = scan_first(wm + L.wm_badR, u + front, u + end, true) - u;  // first window below the threshold
+        if (s < end) {  // foundLowQualWindow
+            s = scan_first(wm + L.wm_lowQ, u + s, u + l - 1, true) - u;  // while (s < l-1 && qual[s] >= 33+Q) s++
             rlen = s - front;
         }
     }
     if (!enR && enT) {  // :166-194
         const int w = p.wT;
         if (l - front - tail - w <= 0) return false;
-        int total = 0;
-        int t = l - tail - 1;
-        for (int i = 0; i < w - 1; i++) total += (int)(q[t - i] & 0x7F);
-        for (t = l - tail - 1; t - w >= front; t--) {
-            total += (int)(q[t - w + 1] & 0x7F);
-            if (t < l - tail - 1) total -= (int)(q[t + 1] & 0x7F);
-            if (total >= p.thrT) break;
-        }
+        // for (t = l-tail-1; t - w >= front; t--): window [t-w+1, t]; break at the first good one.
+        // In window-start coordinates s' = t-w+1 runs from l-tail-w down to front+1.
+        const int sp = scan_last(wm + L.wm_badT, u + front + 1, u + l - tail - w + 1, false) - u;  // none: front
+        int t = sp + w - 1;  // no break: t == front + w - 1, the loop's exit value
         if (t < l - 1) t = t - w + 1;
-        while (t >= 0 && (q[t] & 0x80)) t--;
+        t = scan_last(wm + L.wm_isN, u, u + t + 1, false) - u;  // while (t >= 0 && seq[t] == 'N') t--
         rlen = t - front + 1;
     }
     if (rlen <= 0 || front >= l - 1) return false;  // :196-197
@@ -340,42 +417,80 @@ FQ_DEV int trim_poly_x(const u32* srow, const u8* q, int f, int rlen, int compar
     return rlen;
 }
 
-// Duplicate::seq2intvector (duplicate.cpp:111-120), the base-value part:
-//   sum_p prime[((p+off)*B+i) & mask] * val(base_p)       (val: A7 T222 C74 G31 else 13)
-// the position part sum_p prime[...]*(p+off) only depends on the lengths and comes
-// from a host-built prefix table (DevLuts::dup_posum).
-FQ_DEV u64 dup_hash_bases(const u32* srow, const u8* q, int len, int off, int B, int i, const u32* primes) {
+// ---------------------------------------------------------------------------
+// Phase C1: Duplicate::seq2intvector (duplicate.cpp:111-120) on the ORIGINAL reads
+// (peprocessor.cpp:398, quirk #11).  8 lanes per read, each summing a run of quality
+// dwords, two buffers at a time; a 3-step shuffle folds the 8 partial sums.
+//   h_i = sum_p prime[((p+off)*B+i) & mask] * val(base_p)     (val: A7 T222 C74 G31 else 13)
+// the position part sum_p prime[...]*(p+off) only depends on the lengths and comes from a
+// host-built prefix table (DevLuts::dup_posum).
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    if (!p.dup_enabled) return;
+    const int B = p.dup_bufnum;
     const u32 mask = (u32)(512 * B - 1);
-    u64 acc = 0;
-    for (int p = 0; p < len; p++) {
-        const u32 s = sym_at(srow, q, p);
-        const u32 val = s == 4u ? 13u : ((0x1F4ADE07u >> (s * 8)) & 0xFFu);  // A7 T222 C74 G31
-        const u32 pr = primes[(((u32)(p + off)) * (u32)B + (u32)i) & mask];
-        acc += (u64)pr * (u64)val;
+    const u32* primes = lds + L.primes;
+    const int D = (p.qw_g + 7) >> 3;  // quality dwords per lane
+    const int total = L.NR * 8;
+    const int lane = tid & 63;
+    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (shuffles inside)
+        const int t = t0 + lane;
+        const bool valid = t < total;
+        const int R = valid ? (t >> 3) : 0, seg = t & 7;
+        const int m = R >= L.P ? 1 : 0;
+        const int len = valid ? lds_i(lds, L.rlen0)[R] : 0;
+        const int off = m ? lds_i(lds, L.rlen0)[R - L.P] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
+        const u32* srow = lds + L.seq + R * L.SW;
+        const u32* qrow = lds + L.qual + R * L.QW;
+        for (int i0 = 0; i0 < B; i0 += 2) {
+            u64 acc0 = 0, acc1 = 0;
+            for (int d = 0; d < D; d++) {
+                const int c = seg * D + d;
+                if (4 * c >= len) break;
+                const u32 qd = qrow[c];
+                const u32 c8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = 4 * c + k;
+                    if (j < len) {
+                        const u32 code = (c8 >> (2 * k)) & 3u;
+                        const u32 val = ((qd >> (8 * k + 7)) & 1u) ? 13u : ((0x1F4ADE07u >> (code * 8)) & 0xFFu);
+                        const u32 pi = (((u32)(j + off)) * (u32)B + (u32)i0) & mask;
+                        acc0 += (u64)primes[pi] * (u64)val;
+                        acc1 += (u64)primes[pi + 1] * (u64)val;
+                    }
+                }
+            }
+            u32 lo0 = (u32)acc0, hi0 = (u32)(acc0 >> 32), lo1 = (u32)acc1, hi1 = (u32)(acc1 >> 32);
+#pragma unroll
+            for (int sh = 1; sh < 8; sh <<= 1) {
+                const u64 o0 = (u64)shfl_xor(lo0, sh) | ((u64)shfl_xor(hi0, sh) << 32);
+                const u64 o1 = (u64)shfl_xor(lo1, sh) | ((u64)shfl_xor(hi1, sh) << 32);
+                const u64 n0 = (((u64)hi0 << 32) | lo0) + o0, n1 = (((u64)hi1 << 32) | lo1) + o1;
+                lo0 = (u32)n0; hi0 = (u32)(n0 >> 32);
+                lo1 = (u32)n1; hi1 = (u32)(n1 >> 32);
+            }
+            if (valid && seg == 0) {
+                u64* h = (u64*)(lds + L.hash) + (size_t)R * B;
+                h[i0] = ((u64)hi0 << 32) | lo0;
+                h[i0 + 1] = ((u64)hi1 << 32) | lo1;
+            }
+        }
     }
-    return acc;
 }
 
 // ---------------------------------------------------------------------------
-// Phase C: lane = one read.  Dup hash on the ORIGINAL read (peprocessor.cpp:398,
-// quirk #11), UMI front trim (umiprocessor.cpp:19-49 / read.cpp:69-73), then
-// Filter::trimAndCut.
+// Phase C2: lane = one read.  UMI front trim (umiprocessor.cpp:19-49 / read.cpp:69-73),
+// then Filter::trimAndCut on the predicate masks.
 // ---------------------------------------------------------------------------
 FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= L.P ? 1 : 0;
-        const int pr = R - m * L.P;
-        const u32* srow = lds_seq(L, lds, R);
-        const u8* q = (const u8*)lds_qual(L, lds, R);
         int len = lds_i(lds, L.rlen0)[R];
-        if (p.dup_enabled) {
-            const int off = m ? lds_i(lds, L.rlen0)[pr] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
-            u64* h = (u64*)(lds + L.hash) + (size_t)R * p.dup_bufnum;
-            for (int i = 0; i < p.dup_bufnum; i++)
-                h[i] = dup_hash_bases(srow, q, len, off, p.dup_bufnum, i, lds + L.primes);
-        }
         int front = 0;
         const int umi = m ? p.umi_len2 : p.umi_len1;
         if (umi > 0) {  // Read::trimFront(min(len,umi)+skip): len = min(length()-1, len)
@@ -384,7 +499,7 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tid, int nthreads) {
             if (t > 0) { front = t; len -= t; }
         }
         int f2 = 0, l2 = len;
-        const bool alive = trim_and_cut(p, q + front, len, m ? p.trim_front2 : p.trim_front1,
+        const bool alive = trim_and_cut(p, L, lds + L.wm + R * L.wm_stride, front, len, m ? p.trim_front2 : p.trim_front1,
                                         m ? p.trim_tail2 : p.trim_tail1, f2, l2);
         if (alive) {
             lds_i(lds, L.front)[R] = front + f2;
@@ -984,8 +1099,9 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         phase_load(a, lds, tile_first, tid, nt);
         block_sync();
         FQ_STAMP(0)
-        phase_stats(a, lds, false, n_valid, tid, nt);  // Stats::statRead on the original reads
-        if (timing_on) block_sync();
+        phase_stats(a, lds, false, n_valid, tid, nt);  // Stats::statRead on the original reads + trim masks
+        phase_hash(a, lds, tid, nt);
+        block_sync();
         FQ_STAMP(1)
         phase_trim(a, lds, tid, nt);
         block_sync();

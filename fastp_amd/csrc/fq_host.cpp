@@ -216,6 +216,17 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.acc_end = o;
         if (o & 1) o++;
         out.hash = take(out.NR * (p.dup_bufnum > 0 ? p.dup_bufnum : 0) * 2);
+        {   // trimAndCut predicate masks, only those the options need
+            int k = 0;
+            out.wm_words = (p.max_len + 31) / 32;
+            out.wm_badF = p.cut_front ? (k++) * out.wm_words : -1;
+            out.wm_badR = p.cut_right ? (k++) * out.wm_words : -1;
+            out.wm_badT = (p.cut_tail && !p.cut_right) ? (k++) * out.wm_words : -1;   // filter.cpp:166
+            out.wm_lowQ = p.cut_right ? (k++) * out.wm_words : -1;
+            out.wm_isN = (p.cut_front || (p.cut_tail && !p.cut_right)) ? (k++) * out.wm_words : -1;
+            out.wm_stride = k * out.wm_words;
+            out.wm = take(out.NR * out.wm_stride);
+        }
         out.seq = take(out.NR * out.SW);
         out.nmk = take(out.NR * out.SW);
         out.qual = take(out.NR * out.QW);

@@ -34,6 +34,8 @@ FQ_DEV u32 shfl_xor(u32 v, int mask) { return (u32)__shfl_xor((int)v, mask, 64);
 FQ_DEV int popc32(u32 v) { return __popc(v); }
 FQ_DEV int popc64(u64 v) { return __popcll(v); }
 FQ_DEV int ffs64(u64 v) { return __ffsll((unsigned long long)v); }  // 1-based, 0 if none
+FQ_DEV int ffs32(u32 v) { return __ffs((int)v); }                       // 1-based, 0 if none
+FQ_DEV int clz32(u32 v) { return __clz((int)v); }                       // 32 for v == 0
 FQ_DEV u32 brev32(u32 v) { return __brev(v); }
 // low 32 bits of ({hi,lo} >> (s & 31))  -> v_alignbit_b32
 FQ_DEV u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }

@@ -83,6 +83,15 @@ struct LdsLayout {
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
     int ov_off, ov_len, ov_diff, ov_flags;                // [P]
     int hash;       // [NR][bufnum] u64 (2 dwords each): per-read part of Duplicate::seq2intvector
+    // per-read position bit masks (bit j of a mask = predicate at base j of the row), built in
+    // the pre-stats pass and bit-scanned by Filter::trimAndCut's resolver; an offset is -1 when
+    // the option that needs the mask is off.  [NR][wm_stride] dwords, each mask wm_words long.
+    int wm, wm_words, wm_stride;
+    int wm_badF;    // window [j, j+wF) has total quality <  thrF   (filter.cpp:116)
+    int wm_badR;    // window [j, j+wR) has total quality <  thrR   (filter.cpp:151)
+    int wm_badT;    // window [j, j+wT) has total quality <  thrT   (filter.cpp:185)
+    int wm_lowQ;    // quality[j] < qRmin                           (filter.cpp:159)
+    int wm_isN;     // base j is 'N'                                (filter.cpp:123,191)
     int adapt;      // [2][ADAPT_WORDS] packed adapter words
     int wscratch;   // [waves][2*SW] dwords: rc(r2) words + rc N-mask words
     int lut_ov, lut_lowq, lut_cplx;                       // u16 tables, (max_len+1+1)/2 dwords each

@@ -81,3 +81,19 @@ UMI = {
     "pe_umi_per_read": ("per_read", 6),
     "se_umi_read1": ("read1", 8),
 }
+
+
+# Filter::trimAndCut stress: (paired, params overrides) run on synth.noisy_reads
+TRIM_STRESS = [
+    (True, dict(cut_front=1, cut_tail=1, cut_front_window=1, cut_tail_window=1)),
+    (True, dict(cut_front=1, cut_right=1, cut_front_window=3, cut_right_window=7, cut_front_quality=25,
+                cut_right_quality=12)),
+    (True, dict(cut_front=1, cut_tail=1, cut_right=1, cut_front_window=4, cut_tail_window=9, cut_right_window=2,
+                trim_front1=2, trim_tail1=3, trim_front2=5, trim_tail2=1)),
+    (True, dict(cut_tail=1, cut_tail_window=33, cut_tail_quality=15, umi_len1=5, umi_len2=7, umi_skip=1)),
+    (True, dict(cut_front=1, cut_front_window=40, cut_front_quality=10, umi_len1=4, trim_tail1=10, trim_tail2=10)),
+    (False, dict(cut_right=1, cut_right_window=16, cut_right_quality=30, adapter_enabled=0)),
+    (False, dict(cut_front=1, cut_tail=1, cut_front_window=149, cut_tail_window=150, adapter_enabled=0)),
+    (False, dict(cut_front=1, cut_right=1, cut_front_window=1000, cut_right_window=5, adapter_enabled=0)),
+    (True, dict(trim_front1=20, trim_tail1=140, trim_front2=0, trim_tail2=151)),
+]

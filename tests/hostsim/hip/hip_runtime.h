@@ -58,6 +58,8 @@ static inline int __shfl_xor(int v, int mask, int width = 64) { (void)width; ret
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __clz(int v) { return v == 0 ? 32 : __builtin_clz((unsigned)v); }
 static inline unsigned __brev(unsigned v) {
     v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
     v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);

@@ -96,6 +96,37 @@ def synth_pairs(n, L=150, seed=42, insert_mean=300.0, insert_sd=80.0, insert_min
     return outs
 
 
+def noisy_reads(n, L=150, seed=1, paired=True, n_rate=0.06, qlo=2, qhi=41):
+    """adversarial input for the quality-cutting / N-skipping scans: i.i.d. qualities with runs of
+    good and bad bases, frequent N (also at both ends), every length 0..L"""
+    rng = np.random.default_rng(seed)
+    stride = (L + 7) // 8 * 8
+    j = np.arange(L)[None, :]
+    outs = {}
+    for tag in ("1", "2") if paired else ("1",):
+        lens = rng.integers(0, L + 1, size=n).astype(np.int32)
+        lens[rng.random(n) < 0.5] = L
+        # piecewise quality: runs of 1..12 bases share a level, plus single-base noise
+        runs = rng.integers(qlo, qhi, size=(n, L))
+        keep = rng.random((n, L)) < 0.25
+        keep[:, 0] = True
+        idx = np.maximum.accumulate(np.where(keep, j, 0), axis=1)
+        q = np.take_along_axis(runs, idx, axis=1)
+        noise = rng.random((n, L)) < 0.1
+        q = np.where(noise, rng.integers(qlo, qhi, size=(n, L)), q)
+        s = _ACGT[rng.integers(0, 4, size=(n, L))]
+        isn = rng.random((n, L)) < n_rate
+        edge = (rng.random((n, 1)) < 0.3) & ((j < rng.integers(0, 6, size=(n, 1))) | (j >= lens[:, None] - rng.integers(0, 6, size=(n, 1))))
+        s = np.where(isn | edge, ord("N"), s).astype(np.uint8)
+        valid = j < lens[:, None]
+        seq = np.zeros((n, stride), dtype=np.uint8)
+        qual = np.zeros((n, stride), dtype=np.uint8)
+        seq[:, :L] = np.where(valid, s, 0)
+        qual[:, :L] = np.where(valid, q + 33, 0)
+        outs["seq" + tag], outs["qual" + tag], outs["len" + tag] = seq, qual, lens
+    return outs
+
+
 def to_fastq(seq, qual, lens, mate, name_prefix="@SIM:1:FC:1:1101"):
     """FASTQ bytes; names are Illumina-like but do NOT start with a 2-colour prefix
     (@A/@NS/@NB/@VH/@LH), so the reference's polyG auto-enable stays off."""

@@ -61,6 +61,20 @@ def test_gpu_equals_reference_golden(name):
     golden_util.check_against_golden(name, outs, rep, meta)
 
 
+@pytest.mark.parametrize("k", range(len(cases.TRIM_STRESS)))
+def test_gpu_trim_and_cut_stress(k):
+    """Filter::trimAndCut via the predicate-mask bit scans vs the oracle's literal loops, on
+    adversarial qualities / N runs / every read length"""
+    paired, kw = cases.TRIM_STRESS[k]
+    p = abi.default_params(paired, 150)
+    if not paired:
+        p.adapter_seq_r1 = None
+    for key, v in kw.items():
+        setattr(p, key, v)
+    d = synth.noisy_reads(20000, L=150, seed=100 + k, paired=paired)
+    _compare(f"trim_stress{k}", p, d, paired)
+
+
 @pytest.mark.parametrize("L", [36, 75, 100, 250, 400])
 def test_gpu_read_lengths(L):
     p = abi.default_params(True, L)

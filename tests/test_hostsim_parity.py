@@ -76,3 +76,20 @@ def test_sim_unsupported_options_fail_loudly():
         with pytest.raises(engine.EngineError) as e:
             engines.sim_engine(p)
         assert e.value.code == abi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("k", range(len(cases.TRIM_STRESS)))
+def test_sim_trim_and_cut_stress(k):
+    """Filter::trimAndCut via the predicate-mask bit scans vs the oracle's literal loops"""
+    paired, kw = cases.TRIM_STRESS[k]
+    p = abi.default_params(paired, 150)
+    if not paired:
+        p.adapter_seq_r1 = None
+    for key, v in kw.items():
+        setattr(p, key, v)
+    d = synth.noisy_reads(500, L=150, seed=100 + k, paired=paired)
+    ro, rg, co, cg = _both(p, d, paired)
+    for i in range(3 if paired else 1):
+        bad = np.nonzero(ro[i] != rg[i])[0]
+        assert len(bad) == 0, f"stress {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
+    assert np.array_equal(co, cg)

@@ -29,5 +29,5 @@ for it in range(2):
     ms, k = g.kernel_time()
     cyc = g.debug_phase_cycles()
     tot = sum(cyc[:7])
-    names = ["load", "pre-stats", "trim", "polyg", "overlap", "decide", "post-stats"]
+    names = ["load", "pre-stats+masks+hash", "trim", "polyg", "overlap", "decide", "post-stats"]
     print(f"kernel {ms:.3f} ms / {k} launches; phase share:", {nm: f"{100.0 * c / tot:.1f}%" for nm, c in zip(names, cyc)})
