@@ -302,6 +302,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     r.nblocks = grid;
     r.L = ctx->L;
     r.isize_max = ctx->dp.isize_max;
+    r.one_pass = ctx->dp.stats_one_pass;
     r.ctr = ctx->d_ctr;
     const fastp_gpu_counter_layout& cl = ctx->cl;
     r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;

@@ -35,10 +35,10 @@ FQ_DEV u32 window16(const u32* row, int bp) {
     const int w = bp >> 4;
     return alignbit(row[w + 1], row[w], (u32)((bp & 15) * 2));
 }
-// same, bp may be in [-15, -1]: the missing low bases read as zero
+// same for any bp: bases at negative positions read as zero
 FQ_DEV u32 window16_signed(const u32* row, int bp) {
     if (bp >= 0) return window16(row, bp);
-    return row[0] << (u32)(-bp * 2);
+    return bp <= -16 ? 0u : row[0] << (u32)(-bp * 2);
 }
 // 2-bit groups differ -> bit 2k set
 FQ_DEV u32 fold_diff(u32 x) { return (x | (x >> 1)) & 0x55555555u; }
@@ -92,7 +92,7 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
         lds_i(lds, L.alen)[R] = 0;
         lds_i(lds, L.code)[R] = 0;
         if (R < P) {
-            lds_i(lds, L.ov_off)[R] = 0;
+            lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
             lds_i(lds, L.ov_len)[R] = 0;
             lds_i(lds, L.ov_diff)[R] = 0;
             lds_i(lds, L.ov_flags)[R] = 0;
@@ -192,82 +192,134 @@ FQ_DEV void build_trim_masks(const DevParams& p, const LdsLayout& L, u32* lds, i
     if (L.wm_isN >= 0 && ncur) lds_or_u32(&wm[L.wm_isN + wi], ncur << sh);
 }
 
+// lane = (read R, quality dword c): the trimAndCut predicate masks of a tile
+FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    if (!L.wm_stride) return;
+    const int qwg = a.p.qw_g;
+    const int total = L.NR * qwg;
+    for (int idx = tid; idx < total; idx += nthreads) {
+        const int R = (int)fastdiv((u32)idx, a.magic_qwg);
+        const int c = idx - R * qwg;
+        if (4 * c >= lds_i(lds, L.rlen0)[R]) continue;
+        const u32 qd = lds[L.qual + R * L.QW + c];
+        const u32 nb = (qd >> 7) & 0x01010101u;
+        build_trim_masks(a.p, L, lds, R, c, qd, (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu);
+    }
+    (void)n_valid;
+}
+
 // ---------------------------------------------------------------------------
-// Phases B / F: Stats::statRead (stats.cpp:191-291) over a tile.
-// lane = (read R, quality dword c) = cycles 4c..4c+3 of that read.
-// post == false : every read, window [0, rlen0)      -> slots PRE1 / PRE2
-// post == true  : reads flagged RS_STAT_POST, window [front, front+len) -> POST1 / POST2
+// Stats::statRead (stats.cpp:191-291) over a tile.
+// lane = (read R, quality dword c) = cycles 4c..4c+3 of that read; the loop has a wave-uniform
+// trip count (ballots inside).
+//   ST_PRE  : every read, window [0, rlen0)                          -> slots PRE1 / PRE2
+//   ST_POST : reads flagged RS_STAT_POST, window [front, front+len)  -> slots POST1 / POST2
+//   ST_BOTH : one pass doing both, legal when no option can move or edit a base that is kept
+//             (DevParams::stats_one_pass): front == 0 always, so base j of a read that is
+//             written out sits in cycle j before and after filtering.  Base j goes to the
+//             "kept" accumulators (stored in the POST slot) when the read is written out and
+//             j < len, else to the "dropped" ones (stored in the PRE slot); the slab fold
+//             forms PRE = kept + dropped, POST = kept.
 // ---------------------------------------------------------------------------
-FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, bool post, int n_valid, int tid, int nthreads) {
+enum { ST_PRE = 0, ST_POST = 1, ST_BOTH = 2 };
+
+FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int mode, int n_valid, int tid, int nthreads) {
     const u32 magic_qwg = a.magic_qwg;
     const LdsLayout& L = a.L;
     const int qwg = a.p.qw_g;
     const int total = L.NR * qwg;
-    const int C = L.C;
+    const int Cp = L.Cp, C4 = L.Cp >> 2;
     u64* cyc_all = (u64*)(lds + L.acc_cyc);
     u32* kmer_all = lds + L.acc_kmer;
     u32* qh_all = lds + L.acc_qh;
     u32* misc = lds + L.acc_misc;
-    const int copy = tid & (QH_COPIES - 1);
-    for (int idx = tid; idx < total; idx += nthreads) {
-        const int R = (int)fastdiv((u32)idx, magic_qwg);
-        const int c = idx - R * qwg;
+    const int lane = tid & 63;
+    const u32 copy = (u32)(tid & (QH_COPIES - 1));
+    for (int base = tid - lane; base < total; base += nthreads) {
+        const int idx = base + lane;
+        bool act = idx < total;
+        const int R = act ? (int)fastdiv((u32)idx, magic_qwg) : 0;
+        const int c = act ? idx - R * qwg : 0;
         const int m = R >= L.P ? 1 : 0;
-        int f = 0, l = lds_i(lds, L.rlen0)[R];
-        if (post) {
-            if (!(lds_i(lds, L.flags)[R] & RS_STAT_POST)) continue;
+        const int rl0 = lds_i(lds, L.rlen0)[R];
+        const bool out_ok = (lds_i(lds, L.flags)[R] & RS_STAT_POST) != 0;
+        int f = 0, l = rl0, lk = 0;
+        if (mode == ST_POST) {
+            act = act && out_ok;
             f = lds_i(lds, L.front)[R];
             l = lds_i(lds, L.len)[R];
-        } else if (R - m * L.P >= n_valid) {
-            continue;  // rows past the end of the batch do not exist
+        } else {
+            act = act && (R - m * L.P < n_valid);  // rows past the end of the batch do not exist
+            if (mode == ST_BOTH && out_ok) lk = lds_i(lds, L.len)[R];
         }
-        const int slot = m * 2 + (post ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
-        if (c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
-            lds_add_u32(&misc[MISC_STAT_READS + slot], 1u);
-            lds_add_u32(&misc[MISC_STAT_LENSUM + slot], (u32)l);
+        const int slot0 = m * 2 + (mode == ST_POST ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
+        if (act && c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
+            lds_add_u32(&misc[MISC_STAT_READS + slot0], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)l);
+            if (mode == ST_BOTH && out_ok) {
+                lds_add_u32(&misc[MISC_STAT_READS + slot0 + 1], 1u);
+                lds_add_u32(&misc[MISC_STAT_LENSUM + slot0 + 1], (u32)lk);
+            }
         }
         const int j0 = c * 4;
-        if (j0 >= f + l || j0 + 4 <= f) continue;
-        const u32* srow = lds + L.seq + R * L.SW;
-        const u32 qd = lds[L.qual + R * L.QW + c];
-        if (!post && L.wm_stride) {
-            const u32 nb0 = (qd >> 7) & 0x01010101u;
-            build_trim_masks(a.p, L, lds, R, c, qd, (nb0 | (nb0 >> 7) | (nb0 >> 14) | (nb0 >> 21)) & 0xFu);
+        act = act && j0 < f + l && j0 + 4 > f;
+        u32 qd = 0, codes = 0, nbits = 0xFFu;
+        if (act) {
+            const u32* srow = lds + L.seq + R * L.SW;
+            qd = lds[L.qual + R * L.QW + c];
+            const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
+            u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
+            if (c > 0) {
+                prev8 = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8)) & 0xFFu;
+                const u32 nb = (lds[L.qual + R * L.QW + c - 1] >> 7) & 0x01010101u;
+                nprev = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;  // bit k = base j0-4+k is N
+            }
+            const u32 nbc = (qd >> 7) & 0x01010101u;
+            codes = prev8 | (cur8 << 8);  // bases j0-4 .. j0+3, 2 bits each
+            nbits = nprev | (((nbc | (nbc >> 7) | (nbc >> 14) | (nbc >> 21)) & 0xFu) << 4);  // same 8 bases, 1 bit each
         }
-        const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
-        u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
-        if (c > 0) {
-            prev8 = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8)) & 0xFFu;
-            const u32 qp = lds[L.qual + R * L.QW + c - 1];
-            const u32 nb = (qp >> 7) & 0x01010101u;
-            nprev = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;  // bit k = base j0-4+k is N
-        }
-        const u32 nbc = (qd >> 7) & 0x01010101u;
-        const u32 ncur = (nbc | (nbc >> 7) | (nbc >> 14) | (nbc >> 21)) & 0xFu;
-        const u32 codes = prev8 | (cur8 << 8);   // bases j0-4 .. j0+3, 2 bits each
-        const u32 nbits = nprev | (ncur << 4);   // same 8 bases, 1 bit each
-        u64* cyc = cyc_all + (size_t)slot * N_CLS * C;
-        u32* kmer = kmer_all + slot * KMER_BINS;
-        u32* qh = qh_all + slot * 128 * QH_COPIES;
+        // ---- per base: per-cycle counters and 5-mers; collect the quality-histogram keys ----
+        u32 key[4];
+        bool val[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = j0 + k;
-            if (j < f || j >= f + l) continue;
-            const int pos = j - f;
+            val[k] = act && j >= f && j < f + l;
+            const int slot = slot0 + ((mode == ST_BOTH && j < lk) ? 1 : 0);
             const u32 q = (qd >> (k * 8)) & 0x7Fu;
-            const u32 isn = (ncur >> k) & 1u;
-            const u32 cls = isn ? (u32)CLS_N : ((codes >> (8 + 2 * k)) & 3u);
-            // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
-            const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
-                            ((u64)(q - 33u) << CYC_QSUM_SHIFT);
-            lds_add_u64(&cyc[cls * C + pos], inc);
-            lds_add_u32(&qh[q * QH_COPIES + copy], 1u);  // mBaseQualHistogram[qual]++ (:207)
-            // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
-            // pos-4..pos all exist in the window and none of them is N
-            if (pos >= 4 && ((nbits >> k) & 0x1Fu) == 0u) {
-                const u32 km = (codes >> (2 * k)) & 0x3FFu;  // earliest base in the low bits
-                lds_add_u32(&kmer[km], 1u);
+            key[k] = (u32)slot * 128u + q;
+            if (val[k]) {
+                const int pos = j - f;
+                const u32 isn = (nbits >> (4 + k)) & 1u;
+                const u32 cls = isn ? (u32)CLS_N : ((codes >> (8 + 2 * k)) & 3u);
+                // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
+                const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
+                                ((u64)(q - 33u) << CYC_QSUM_SHIFT);
+                lds_add_u64(&cyc_all[((size_t)slot * N_CLS + cls) * Cp + (pos & 3) * C4 + (pos >> 2)], inc);
+                // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
+                // pos-4..pos all exist in the window and none of them is N
+                if (pos >= 4 && ((nbits >> k) & 0x1Fu) == 0u)
+                    lds_add_u32(&kmer_all[slot * KMER_BINS + ((codes >> (2 * k)) & 0x3FFu)], 1u);  // earliest base low
             }
+        }
+        // ---- mBaseQualHistogram[qual]++ (:207).  Qualities cluster on a few values, so the
+        // wave first counts the bases equal to one lane's (slot, quality) key with ballots and
+        // lets that lane add the total; only the other bases pay an LDS atomic each.
+        const bool have = val[0] | val[1] | val[2] | val[3];
+        const u32 mine = val[0] ? key[0] : val[1] ? key[1] : val[2] ? key[2] : key[3];
+        const u64 hv = ballot(have);
+        if (hv) {  // wave-uniform
+            const int src = ffs64(hv) - 1;
+            const u32 modek = shfl(mine, src);
+            u32 cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool mk = val[k] && key[k] == modek;
+                cnt += (u32)popc64(ballot(mk));
+                if (val[k] && !mk) lds_add_u32(&qh_all[key[k] * QH_COPIES + copy], 1u);
+            }
+            if (lane == src) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
         }
     }
 }
@@ -419,8 +471,9 @@ FQ_DEV int trim_poly_x(const u32* srow, const u8* q, int f, int rlen, int compar
 
 // ---------------------------------------------------------------------------
 // Phase C1: Duplicate::seq2intvector (duplicate.cpp:111-120) on the ORIGINAL reads
-// (peprocessor.cpp:398, quirk #11).  8 lanes per read, each summing a run of quality
-// dwords, two buffers at a time; a 3-step shuffle folds the 8 partial sums.
+// (peprocessor.cpp:398, quirk #11).  8 lanes per read, lane s summing quality dwords s, s+8, ...
+// (consecutive lanes -> consecutive primes: conflict-free table reads), two buffers at a
+// time; a 3-step shuffle folds the 8 partial sums.
 //   h_i = sum_p prime[((p+off)*B+i) & mask] * val(base_p)     (val: A7 T222 C74 G31 else 13)
 // the position part sum_p prime[...]*(p+off) only depends on the lengths and comes from a
 // host-built prefix table (DevLuts::dup_posum).
@@ -447,7 +500,7 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
         for (int i0 = 0; i0 < B; i0 += 2) {
             u64 acc0 = 0, acc1 = 0;
             for (int d = 0; d < D; d++) {
-                const int c = seg * D + d;
+                const int c = seg + 8 * d;
                 if (4 * c >= len) break;
                 const u32 qd = qrow[c];
                 const u32 c8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
@@ -531,113 +584,110 @@ FQ_DEV void phase_polyg(const KernelArgs& a, u32* lds, int tid, int nthreads) {
 }
 
 // ---------------------------------------------------------------------------
-// Phase D: OverlapAnalysis::analyze (overlapanalysis.cpp:17-146, no-gap part).
-// One wavefront per pair; lane = one candidate offset in the reference's scan
-// order (forward offsets 0..len1-require-1, then reverse offsets 0,-1,...).
-// Stage 1 (per lane): mismatches of the first <=16 bases on the 2-bit codes only -
-//   a lower bound of the true count, so it can only over-accept.
-// Stage 2 (whole wave, per surviving candidate in scan order): exact count over
-//   the protected prefix (<=50 bases, :28) and over the full overlap.
+// Phase D: OverlapAnalysis::analyze (overlapanalysis.cpp:17-89, the no-gap part).
+//
+// The reference slides rc(r2) along r1: forward offsets o = 0..len1-require-1 compare
+// r1[o+i] with rc2[i], then reverse offsets o = 0..len2-require-1 compare r1[i] with
+// rc2[o+i]; the FIRST offset in that order whose first min(ol,50) bases have at most
+// limit(ol) mismatches wins (:34-44).  Both directions are the same problem "slide X over
+// Y" with (X,Y) = (r1,rc2) / (rc2,r1), so a task is (pair, direction, quarter): 8 lanes per
+// pair, the direction wave-uniform.  A lane takes blocks of 16 consecutive offsets; per
+// offset a 16-base 2-bit XOR/popcount prefilter (a lower bound of the true count on a prefix
+// every legal offset has: it can only over-accept) costs 8 VALU instructions; the rare
+// survivors are verified exactly by the same lane, and the pair's winner is an LDS
+// atomic-min over keys ordered like the reference's scan.
 // ---------------------------------------------------------------------------
-FQ_DEV u32 wave_sum(u32 v) {
-    v += shfl_xor(v, 1);
-    v += shfl_xor(v, 2);
-    v += shfl_xor(v, 4);
-    v += shfl_xor(v, 8);
-    v += shfl_xor(v, 16);
-    v += shfl_xor(v, 32);
-    return v;
+struct PairView {
+    const u32 *s1, *n1, *s2, *n2;  // LDS rows (packed bases, N masks) of the two mates
+    int f1, l1, e2, l2;            // r1' = row1[f1, f1+l1), r2' = row2[e2-l2, e2)
+    bool hasN;
+};
+// 16 bases of r1' starting at t (t >= 0; bases past l1 are whatever the row holds)
+FQ_DEV u32 ov_r1(const PairView& v, int t) { return window16(v.s1, v.f1 + t); }
+FQ_DEV u32 ov_r1n(const PairView& v, int t) { return window16(v.n1, v.f1 + t); }
+// 16 bases of rc(r2') starting at t: rc[k] = comp(r2'[l2-1-k]); complement of a code is code^1,
+// an N keeps code 0 on both strands (the rc of N is N, overlapanalysis.cpp:19-22 / simd.cpp:129)
+FQ_DEV u32 ov_rc2n(const PairView& v, int t) { return reverse_groups(window16_signed(v.n2, v.e2 - 16 - t)); }
+FQ_DEV u32 ov_rc2(const PairView& v, int t) {
+    u32 w = reverse_groups(window16_signed(v.s2, v.e2 - 16 - t)) ^ 0x55555555u;
+    if (v.hasN) {
+        const u32 n = ov_rc2n(v, t);
+        w &= ~(n | (n << 1));
+    }
+    return w;
+}
+template <int DIR> FQ_DEV u32 ov_x(const PairView& v, int t) { return DIR ? ov_rc2(v, t) : ov_r1(v, t); }
+template <int DIR> FQ_DEV u32 ov_y(const PairView& v, int t) { return DIR ? ov_r1(v, t) : ov_rc2(v, t); }
+template <int DIR> FQ_DEV u32 ov_xn(const PairView& v, int t) { return DIR ? ov_rc2n(v, t) : ov_r1n(v, t); }
+template <int DIR> FQ_DEV u32 ov_yn(const PairView& v, int t) { return DIR ? ov_r1n(v, t) : ov_rc2n(v, t); }
+
+// acceptNoGapOverlap (:34-44) for X shifted by o against Y; returns the key payload or -1
+template <int DIR>
+FQ_DEV int ov_verify(const PairView& v, int o, int lenX, int lenY, const short* lut) {
+    const int ol = imin(lenX - o, lenY);
+    const int limit = lut[ol];
+    const int pre = imin(ol, 50);  // complete_compare_require (:28)
+    int cnt_pre = 0, cnt_full = 0;
+    for (int t = 0; t < ol; t += 16) {
+        u32 dd = fold_diff(ov_x<DIR>(v, o + t) ^ ov_y<DIR>(v, t));
+        if (v.hasN) dd |= ov_xn<DIR>(v, o + t) ^ ov_yn<DIR>(v, t);
+        cnt_full += popc32(dd & lowmask32(2 * (ol - t)));
+        if (t < pre) {
+            cnt_pre += popc32(dd & lowmask32(2 * (pre - t)));
+            if (cnt_pre > limit) return -1;
+        }
+    }
+    return ol > 50 ? cnt_full : cnt_pre;
 }
 
-FQ_DEV void overlap_pair(const KernelArgs& a, u32* lds, int pr, int lane, int wave) {
+template <int DIR>
+FQ_DEV void overlap_task(const KernelArgs& a, u32* lds, int pr, int part) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     const int R1 = pr, R2 = L.P + pr;
-    const int f1 = lds_i(lds, L.front)[R1], l1 = lds_i(lds, L.len)[R1];
-    const int f2 = lds_i(lds, L.front)[R2], l2 = lds_i(lds, L.len)[R2];
-    const u32* s1 = lds_seq(L, lds, R1);
-    const u32* n1 = lds_nmk(L, lds, R1);
-    const u32* s2 = lds_seq(L, lds, R2);
-    const u32* n2 = lds_nmk(L, lds, R2);
-    const bool hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
-    u32* rcs = lds + L.wscratch + wave * 2 * L.SW;
-    u32* rcn = rcs + L.SW;
-    // reverse complement of r2' = r2[f2, f2+l2) as packed words (overlapanalysis.cpp:19-22):
-    // rc[k] = comp(r2[f2+l2-1-k]); complement of a 2-bit code is code^1, N stays N.
-    {
-        const int e = f2 + l2;
-        for (int t = lane; t < L.SW; t += 64) {
-            u32 vs = 0, vn = 0;
-            const int nb = l2 - 16 * t;  // rc bases held by word t
-            if (nb > 0) {
-                const int lo = e - 16 * (t + 1);
-                const u32 msk = lowmask32(2 * imin(16, nb));
-                vs = (reverse_groups(window16_signed(s2, lo)) ^ 0x55555555u) & msk;
-                vn = reverse_groups(window16_signed(n2, lo)) & msk;
-                vs &= ~(vn | (vn << 1));  // an N is stored as code 0 on both strands
-            }
-            rcs[t] = vs;
-            rcn[t] = vn;
-        }
-    }
-    wave_sync();
-    const int req = p.overlap_require;
-    const int F = imax(0, l1 - req);   // forward candidates  (:48)
-    const int Rv = imax(0, l2 - req);  // reverse candidates  (:73)
-    const int total = F + Rv;
+    if ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_NULL) return;  // r1 != NULL && r2 != NULL
+    PairView v;
+    v.s1 = lds_seq(L, lds, R1);
+    v.n1 = lds_nmk(L, lds, R1);
+    v.s2 = lds_seq(L, lds, R2);
+    v.n2 = lds_nmk(L, lds, R2);
+    v.f1 = lds_i(lds, L.front)[R1];
+    v.l1 = lds_i(lds, L.len)[R1];
+    v.l2 = lds_i(lds, L.len)[R2];
+    v.e2 = lds_i(lds, L.front)[R2] + v.l2;
+    v.hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
+    const int lenX = DIR ? v.l2 : v.l1, lenY = DIR ? v.l1 : v.l2;
+    const int nvalid = lenX - p.overlap_require;  // offsets 0 .. nvalid-1 (:48, :73)
+    if (nvalid <= 0) return;
     const short* lut = (const short*)(lds + L.lut_ov);
-    int found = 0, r_off = 0, r_ol = 0, r_diff = 0;
-    for (int base = 0; base < total && !found; base += 64) {
-        const int c = base + lane;
-        const bool valid = c < total;
-        const bool fwd = c < F;
-        const int o = fwd ? c : c - F;
-        const int ca = fwd ? o : 0;  // start in r1'
-        const int cb = fwd ? 0 : o;  // start in rc(r2')
-        int ol = fwd ? imin(l1 - o, l2) : imin(l1, l2 - o);
-        if (!valid) ol = 0;
-        const int limit = lut[ol];
-        bool pass1 = false;
-        if (valid) {
-            const int n16 = imin(imin(ol, 50), 16);
-            const u32 d = fold_diff(window16(s1, f1 + ca) ^ window16(rcs, cb)) & lowmask32(2 * n16);
-            pass1 = popc32(d) <= limit;
+    // every legal offset compares at least min(require+1, lenY) bases; prefilter on <= 16 of them
+    const int npre = imin(16, imin(p.overlap_require + 1, lenY));
+    const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+    const u32 y0 = ov_y<DIR>(v, 0);
+    const int lmax = p.ov_limit_max;
+    u32* keyp = (u32*)&lds_i(lds, L.ov_off)[pr];
+    for (int b = part; 16 * b < nvalid; b += 4) {
+        const int o0 = 16 * b;
+        if (*(volatile u32*)keyp < ((u32)DIR << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS) | ((u32)o0 << OV_KEY_DIFF_BITS))) break;  // beaten already
+        const u32 w0 = ov_x<DIR>(v, o0), w1 = ov_x<DIR>(v, o0 + 16);
+        u32 cand = 0;  // bit (15 - t) <=> offset o0 + t survives the prefilter
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const u32 x = t ? alignbit(w1, w0, 2 * t) : w0;
+            const u32 d = x ^ y0;
+            const int cnt = popc32((d | (d >> 1)) & premask);
+            cand = cand + cand + (u32)(cnt <= lmax);
         }
-        u64 mask = ballot(pass1);
-        while (mask) {
-            const int src = ffs64(mask) - 1;
-            mask &= mask - 1;
-            const int xa = (int)shfl((u32)ca, src);
-            const int xb = (int)shfl((u32)cb, src);
-            const int xol = (int)shfl((u32)ol, src);
-            const int xlim = (int)shfl((u32)limit, src);
-            const int xo = (int)shfl((u32)(fwd ? o : -o), src);
-            const int pre = imin(xol, 50);  // complete_compare_require (:28)
-            u32 cnt_pre = 0, cnt_full = 0;
-            for (int t = lane; t * 16 < xol; t += 64) {
-                u32 dd = fold_diff(window16(s1, f1 + xa + 16 * t) ^ window16(rcs, xb + 16 * t));
-                if (hasN) dd |= window16(n1, f1 + xa + 16 * t) ^ window16(rcn, xb + 16 * t);
-                const int vf = imin(16, xol - 16 * t);
-                const int vp = imax(0, imin(16, pre - 16 * t));
-                cnt_full += (u32)popc32(dd & lowmask32(2 * vf));
-                cnt_pre += (u32)popc32(dd & lowmask32(2 * vp));
-            }
-            cnt_pre = wave_sum(cnt_pre);
-            cnt_full = wave_sum(cnt_full);
-            if ((int)cnt_pre <= xlim) {  // acceptNoGapOverlap (:34-44)
-                found = 1;
-                r_off = xo;
-                r_ol = xol;
-                r_diff = xol > 50 ? (int)cnt_full : (int)cnt_pre;
-                break;
+        if (nvalid - o0 < 16) cand &= ~lowmask32(16 - (nvalid - o0));
+        while (cand) {
+            const int t = clz32(cand) - 16;  // smallest surviving offset first
+            cand &= ~(0x8000u >> t);
+            const int diff = ov_verify<DIR>(v, o0 + t, lenX, lenY, lut);
+            if (diff >= 0) {
+                lds_min_u32(keyp, ((u32)DIR << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS)) | ((u32)(o0 + t) << OV_KEY_DIFF_BITS) | (u32)diff);
+                return;
             }
         }
-    }
-    if (lane == 0) {
-        lds_i(lds, L.ov_off)[pr] = found ? r_off : 0;
-        lds_i(lds, L.ov_len)[pr] = found ? r_ol : 0;
-        lds_i(lds, L.ov_diff)[pr] = found ? r_diff : 0;
-        lds_i(lds, L.ov_flags)[pr] = found ? 1 : 0;
     }
 }
 
@@ -647,13 +697,26 @@ FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) 
     if (!p.paired) return;
     const bool thread0 = (a.batch_flags & 1u) != 0;  // FASTP_GPU_BATCH_STAT_ISIZE
     if (!(p.need_overlap || thread0)) return;        // peprocessor.cpp:438
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-    for (int pr = wave; pr < L.P; pr += nwaves) {
-        const int dead = (lds_i(lds, L.flags)[pr] | lds_i(lds, L.flags)[L.P + pr]) & RS_NULL;
-        if (dead) continue;  // r1 != NULL && r2 != NULL
-        overlap_pair(a, lds, pr, lane, wave);
-        wave_sync();  // the per-wave scratch is reused by the next pair
+    // tasks [0, 4P): forward, [4P, 8P): reverse -> the direction is uniform per wavefront when 4P % 64 == 0
+    const int half = 4 * L.P;
+    for (int t = tid; t < 2 * half; t += nthreads) {
+        const int dir = t >= half ? 1 : 0;
+        const int u = t - dir * half;
+        if (dir) overlap_task<1>(a, lds, u >> 2, u & 3);
+        else overlap_task<0>(a, lds, u >> 2, u & 3);
     }
+}
+
+// decode the packed scan key of a pair (lengths = the mates' lengths at analyze time)
+FQ_DEV void decode_overlap(u32 key, int l1, int l2, int& ovl, int& off, int& ol, int& diff) {
+    ovl = key != OV_KEY_NONE;
+    off = ol = diff = 0;
+    if (!ovl) return;
+    const int dir = (int)(key >> (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS));
+    const int o = (int)((key >> OV_KEY_DIFF_BITS) & ((1u << OV_KEY_OFF_BITS) - 1u));
+    diff = (int)(key & ((1u << OV_KEY_DIFF_BITS) - 1u));
+    off = dir ? -o : o;
+    ol = dir ? imin(l1, l2 - o) : imin(l1 - o, l2);
 }
 
 // ---------------------------------------------------------------------------
@@ -873,9 +936,8 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         const bool a1 = !(flags[R1] & RS_NULL), a2 = !(flags[R2] & RS_NULL);
         const bool both = a1 && a2;
         const int ft1 = lds_i(lds, L.ft)[R1], ft2 = lds_i(lds, L.ft)[R2];
-        const int ovl = lds_i(lds, L.ov_flags)[pr] & 1;
-        const int ov_off = lds_i(lds, L.ov_off)[pr], ov_len = lds_i(lds, L.ov_len)[pr];
-        const int ov_diff = lds_i(lds, L.ov_diff)[pr];
+        int ovl, ov_off, ov_len, ov_diff;  // the OverlapResult of the pair as it is now (quirk #6)
+        decode_overlap((u32)lds_i(lds, L.ov_off)[pr], lenv[R1], lenv[R2], ovl, ov_off, ov_len, ov_diff);
         bool isize_done = false, dimer = false;
         // statInsertSize (peprocessor.cpp:710-723), thread 0 only (:449, :497)
         if (both && thread0) {
@@ -1099,7 +1161,8 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         phase_load(a, lds, tile_first, tid, nt);
         block_sync();
         FQ_STAMP(0)
-        phase_stats(a, lds, false, n_valid, tid, nt);  // Stats::statRead on the original reads + trim masks
+        if (!a.p.stats_one_pass) phase_stats(a, lds, ST_PRE, n_valid, tid, nt);  // Stats::statRead on the original reads
+        phase_masks(a, lds, n_valid, tid, nt);
         phase_hash(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(1)
@@ -1116,7 +1179,8 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         else phase_decide_se(a, lds, tile_first, tid, nt);
         block_sync();
         FQ_STAMP(5)
-        phase_stats(a, lds, true, n_valid, tid, nt);   // Stats::statRead on what is written out
+        // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
+        phase_stats(a, lds, a.p.stats_one_pass ? ST_BOTH : ST_POST, n_valid, tid, nt);
         block_sync();
         FQ_STAMP(6)
 #undef FQ_STAMP
@@ -1138,12 +1202,16 @@ struct ReduceArgs {
     int slab_dwords, nblocks;
     LdsLayout L;       // offsets of the accumulator regions (relative to L.acc_cyc)
     int isize_max;
+    int one_pass;      // slabs hold kept (POST slot) / dropped (PRE slot): PRE = kept + dropped
     int64_t* ctr;      // counter block
     // fastp_gpu_counter_layout offsets
     int64_t o_filter, o_adapter_reads, o_adapter_bases, o_polyx_reads, o_polyx_bases, o_correction,
         o_corrected_reads, o_merged, o_isize, o_stats[4], st_reads, st_length_sum, st_qual_hist, st_kmer,
         st_cycle, cycles;
 };
+
+// one-pass Stats mode: slot PRE1 (0) / PRE2 (2) = dropped + kept, where kept sits in slot + 1
+FQ_DEV bool fold_kept(const ReduceArgs& r, int slot) { return r.one_pass && (slot & 1) == 0; }
 
 FQ_DEV void reduce_body(const ReduceArgs& r) {
     const LdsLayout& L = r.L;
@@ -1158,16 +1226,20 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
             int64_t* st = r.ctr + r.o_stats[slot] + r.st_cycle;
             const int64_t CC = r.cycles;
             int64_t tb = 0, tq = 0;
+            const int cs = (c & 3) * (L.Cp >> 2) + (c >> 2);  // phase-major position (LdsLayout::Cp)
             for (int cls = 0; cls < N_CLS; cls++) {
                 int64_t cnt = 0, q20 = 0, q30 = 0, qs = 0;
-                const int off = (L.acc_cyc - L.acc_cyc) + 2 * ((slot * N_CLS + cls) * C + c);
-                for (int b = 0; b < r.nblocks; b++) {
-                    const u32* s = r.slabs + (size_t)b * r.slab_dwords + off;
-                    const u64 v = (u64)s[0] | ((u64)s[1] << 32);
-                    cnt += (int64_t)(v & 0x3FFFu);
-                    q20 += (int64_t)((v >> CYC_Q20_SHIFT) & 0x3FFFu);
-                    q30 += (int64_t)((v >> CYC_Q30_SHIFT) & 0x3FFFu);
-                    qs += (int64_t)(v >> CYC_QSUM_SHIFT);
+                // one-pass mode: the PRE slots also take what the POST (kept) slots hold
+                for (int part = 0; part < (fold_kept(r, slot) ? 2 : 1); part++) {
+                    const int off = 2 * (((slot + part) * N_CLS + cls) * L.Cp + cs);
+                    for (int b = 0; b < r.nblocks; b++) {
+                        const u32* s = r.slabs + (size_t)b * r.slab_dwords + off;
+                        const u64 v = (u64)s[0] | ((u64)s[1] << 32);
+                        cnt += (int64_t)(v & 0x3FFFu);
+                        q20 += (int64_t)((v >> CYC_Q20_SHIFT) & 0x3FFFu);
+                        q30 += (int64_t)((v >> CYC_Q30_SHIFT) & 0x3FFFu);
+                        qs += (int64_t)(v >> CYC_QSUM_SHIFT);
+                    }
                 }
                 const int bin = (int)sym_bin((u32)cls);  // 'A'&7=1 'T'&7=4 'C'&7=3 'G'&7=7 'N'&7=6
                 st[(0 * 8 + bin) * CC + c] += q30;   // mCycleQ30Bases  (stats.cpp:54-63 layout)
@@ -1183,8 +1255,10 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
             const int k = item - n_cyc;
             const int slot = k / KMER_BINS, km = k - slot * KMER_BINS;
             int64_t sum = 0;
-            const int off = (L.acc_kmer - L.acc_cyc) + k;
-            for (int b = 0; b < r.nblocks; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off];
+            for (int part = 0; part < (fold_kept(r, slot) ? 2 : 1); part++) {
+                const int off = (L.acc_kmer - L.acc_cyc) + k + part * KMER_BINS;
+                for (int b = 0; b < r.nblocks; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off];
+            }
             // LDS index has the earliest base in the low bits; fastp's has it in the high bits
             const u32 fk = ((km & 3u) << 8) | (((km >> 2) & 3u) << 6) | (((km >> 4) & 3u) << 4) |
                            (((km >> 6) & 3u) << 2) | ((km >> 8) & 3u);
@@ -1193,9 +1267,11 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
             const int k = item - n_cyc - n_kmer;
             const int slot = k / 128, q = k - slot * 128;
             int64_t sum = 0;
-            const int off = (L.acc_qh - L.acc_cyc) + k * QH_COPIES;
-            for (int b = 0; b < r.nblocks; b++)
-                for (int cpy = 0; cpy < QH_COPIES; cpy++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off + cpy];
+            for (int part = 0; part < (fold_kept(r, slot) ? 2 : 1); part++) {
+                const int off = (L.acc_qh - L.acc_cyc) + (k + part * 128) * QH_COPIES;
+                for (int b = 0; b < r.nblocks; b++)
+                    for (int cpy = 0; cpy < QH_COPIES; cpy++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off + cpy];
+            }
             r.ctr[r.o_stats[slot] + r.st_qual_hist + q] += sum;
         } else {
             const int k = item - n_cyc - n_kmer - n_qh;

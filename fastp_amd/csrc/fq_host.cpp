@@ -136,6 +136,7 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.umi_len2 = (p.paired && in.umi_len2 > 0) ? in.umi_len2 : 0;
     p.umi_skip = in.umi_skip > 0 ? in.umi_skip : 0;
     p.need_overlap = p.paired && (p.adapter_enabled || p.correction);
+    p.stats_one_pass = !p.correction && !p.cut_front && !p.trim_front1 && !p.trim_front2 && !p.umi_len1 && !p.umi_len2;
 
     // ---- LUTs: the reference's floating point thresholds, evaluated on the host ----
     const int n = in.max_len + 2;
@@ -147,6 +148,7 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
         int lim = (int)(ol * diffPercentLimit);  // overlapanalysis.cpp:51,76
         if (in.overlap_diff_limit < lim) lim = in.overlap_diff_limit;
         luts.ov_limit[ol] = (int16_t)lim;
+        if (lim > p.ov_limit_max) p.ov_limit_max = lim;
         // filter.cpp:36: FAIL iff lowQualNum > (pct * rlen / 100.0)  <=> lowQualNum > floor(x)
         const double x = in.unqualified_percent_limit * ol / 100.0;
         double fl = floor(x);
@@ -206,10 +208,11 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.SW = round_odd(p.sw_g + 1);  // +1: window reads touch word w+1
         out.QW = round_odd(p.qw_g);
         out.C = p.cycles;
+        out.Cp = (p.cycles + 3) / 4 * 4;
         int o = 0;
         auto take = [&](int n) { int at = o; o += n; return at; };
         // accumulators first (u64 part 8-byte aligned at offset 0)
-        out.acc_cyc = take(4 * N_CLS * out.C * 2);
+        out.acc_cyc = take(4 * N_CLS * out.Cp * 2);
         out.acc_kmer = take(4 * KMER_BINS);
         out.acc_qh = take(4 * 128 * QH_COPIES);
         out.acc_misc = take(MISC_ISIZE + p.isize_max + 1);

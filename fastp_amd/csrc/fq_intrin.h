@@ -49,6 +49,9 @@ FQ_DEV void lds_add_u32(u32* p, u32 v) {
 FQ_DEV void lds_add_u64(u64* p, u64 v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+FQ_DEV void lds_min_u32(u32* p, u32 v) {
+    __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 FQ_DEV void lds_or_u32(u32* p, u32 v) {
     __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -25,6 +25,11 @@ enum { CLS_N = 4, N_CLS = 5 };
 enum { CYC_CNT_BITS = 14, CYC_Q20_SHIFT = 14, CYC_Q30_SHIFT = 28, CYC_QSUM_SHIFT = 42 };
 enum { CYC_MAX_READS = (1 << CYC_CNT_BITS) - 1 };
 
+// OverlapAnalysis::analyze result of a pair as one u32 whose order is the reference's scan order
+// (all forward offsets ascending, then the reverse ones): [dir:1][offset:10][diff:16]; ~0 = none
+enum { OV_KEY_DIFF_BITS = 16, OV_KEY_OFF_BITS = 10 };
+static const u32 OV_KEY_NONE = 0xFFFFFFFFu;
+
 enum { QH_COPIES = 8 };        // replicated quality histograms (bank spreading)
 enum { KMER_BINS = 1024 };
 enum { MAX_DUP_BUFS = 8 };
@@ -53,6 +58,7 @@ struct DevParams {
     u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
     int correction;
     int overlap_require, overlap_diff_limit;
+    int ov_limit_max;       // largest per-length mismatch limit (the LUT is non-decreasing): prefilter bound
     int qual_filter, qual_thr, n_base_limit, avg_qual_req;
     int length_filter, length_required, length_limit;
     int complexity_filter;
@@ -61,6 +67,8 @@ struct DevParams {
     int isize_max;
     int umi_len1, umi_len2, umi_skip;
     int need_overlap;       // adapter_enabled || correction  (peprocessor.cpp:438,443)
+    int stats_one_pass;     // no option can move or edit a kept base (no front trim, no correction):
+                            // one Stats pass classifies each base as kept / dropped (see phase_stats)
 };
 
 // LUTs living in global memory (built on the host with the reference's own
@@ -79,9 +87,12 @@ struct LdsLayout {
     int NR;         // rows per tile: 2P (PE) or P (SE)
     int SW, QW;     // LDS row strides in dwords (odd -> conflict-free row-per-lane access)
     int C;          // cycles
+    int Cp;         // C rounded up to a multiple of 4: per-cycle accumulators are stored phase-major,
+                    // entry (pos & 3) * (Cp/4) + (pos >> 2), so lanes that own consecutive quality dwords
+                    // update consecutive LDS words
     int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
-    int ov_off, ov_len, ov_diff, ov_flags;                // [P]
+    int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed scan key (OV_KEY_*)
     int hash;       // [NR][bufnum] u64 (2 dwords each): per-read part of Duplicate::seq2intvector
     // per-read position bit masks (bit j of a mask = predicate at base j of the row), built in
     // the pre-stats pass and bit-scanned by Filter::trimAndCut's resolver; an offset is -1 when
@@ -96,7 +107,7 @@ struct LdsLayout {
     int wscratch;   // [waves][2*SW] dwords: rc(r2) words + rc N-mask words
     int lut_ov, lut_lowq, lut_cplx;                       // u16 tables, (max_len+1+1)/2 dwords each
     int primes;     // [bufnum*512]
-    int acc_cyc;    // [4][N_CLS][C] u64  (2 dwords each)
+    int acc_cyc;    // [4][N_CLS][Cp] u64  (2 dwords each)
     int acc_kmer;   // [4][KMER_BINS] u32
     int acc_qh;     // [4][128][QH_COPIES] u32
     int acc_misc;   // MISC_* u32 counters

@@ -97,3 +97,14 @@ TRIM_STRESS = [
     (False, dict(cut_front=1, cut_right=1, cut_front_window=1000, cut_right_window=5, adapter_enabled=0)),
     (True, dict(trim_front1=20, trim_tail1=140, trim_front2=0, trim_tail2=151)),
 ]
+
+# OverlapAnalysis::analyze stress: params overrides run on synth.overlap_pairs (paired)
+OVERLAP_STRESS = [
+    dict(),
+    dict(correction=1),
+    dict(overlap_require=5, overlap_diff_limit=20, overlap_diff_percent_limit=50, correction=1),
+    dict(overlap_require=40, overlap_diff_limit=2, overlap_diff_percent_limit=5),
+    dict(overlap_require=1, overlap_diff_limit=0, overlap_diff_percent_limit=0, adapter_enabled=0),
+    dict(overlap_require=16, overlap_diff_limit=5, overlap_diff_percent_limit=20, cut_front=1, cut_tail=1, poly_g=1),
+    dict(overlap_require=149, overlap_diff_limit=60, overlap_diff_percent_limit=100),
+]

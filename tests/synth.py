@@ -127,6 +127,38 @@ def noisy_reads(n, L=150, seed=1, paired=True, n_rate=0.06, qlo=2, qhi=41):
     return outs
 
 
+def overlap_pairs(n, L=150, seed=1, err=0.03, n_rate=0.02):
+    """adversarial input for OverlapAnalysis::analyze: every insert size from 1 to 2L (read-through
+    on both sides and barely-overlapping pairs), both mates cut to independent random lengths,
+    substitutions at `err`, N on both strands, a burst of mismatches after base 50 in some pairs"""
+    rng = np.random.default_rng(seed)
+    stride = (L + 7) // 8 * 8
+    j = np.arange(L)[None, :]
+    ins = rng.integers(1, 2 * L + 1, size=n)
+    F = rng.integers(0, 4, size=(n, 2 * L + 1), dtype=np.uint8)
+    rnd1 = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    rnd2 = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    c1 = np.where(j < ins[:, None], np.take_along_axis(F, np.minimum(j, 2 * L) + np.zeros((n, 1), dtype=np.int64), axis=1), rnd1)
+    i2 = np.clip(ins[:, None] - 1 - j, 0, 2 * L)
+    c2 = np.where(j < ins[:, None], _COMP_CODE[np.take_along_axis(F, i2, axis=1)], rnd2)
+    outs = {}
+    for tag, c in (("1", c1), ("2", c2)):
+        e = rng.random((n, L)) < err * rng.random((n, 1)) * 2
+        burst = (rng.random((n, 1)) < 0.15) & (j >= 50) & (j < 50 + rng.integers(1, 40, size=(n, 1)))
+        c = np.where(e | (burst & (rng.random((n, L)) < 0.5)), rng.integers(0, 4, size=(n, L)), c)
+        s = _ACGT[c]
+        s = np.where(rng.random((n, L)) < n_rate * (rng.random((n, 1)) < 0.5), ord("N"), s).astype(np.uint8)
+        lens = np.where(rng.random(n) < 0.6, L, rng.integers(0, L + 1, size=n)).astype(np.int32)
+        q = np.where(rng.random((n, L)) < 0.1, rng.integers(2, 15, size=(n, L)), rng.integers(30, 41, size=(n, L)))
+        valid = j < lens[:, None]
+        seq = np.zeros((n, stride), dtype=np.uint8)
+        qual = np.zeros((n, stride), dtype=np.uint8)
+        seq[:, :L] = np.where(valid, s, 0)
+        qual[:, :L] = np.where(valid, q + 33, 0)
+        outs["seq" + tag], outs["qual" + tag], outs["len" + tag] = seq, qual, lens
+    return outs
+
+
 def to_fastq(seq, qual, lens, mate, name_prefix="@SIM:1:FC:1:1101"):
     """FASTQ bytes; names are Illumina-like but do NOT start with a 2-colour prefix
     (@A/@NS/@NB/@VH/@LH), so the reference's polyG auto-enable stays off."""

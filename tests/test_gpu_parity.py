@@ -75,6 +75,17 @@ def test_gpu_trim_and_cut_stress(k):
     _compare(f"trim_stress{k}", p, d, paired)
 
 
+@pytest.mark.parametrize("k", range(len(cases.OVERLAP_STRESS)))
+def test_gpu_overlap_stress(k):
+    """OverlapAnalysis::analyze (prefilter + exact verify + scan-order key) vs the oracle's literal scan:
+    every insert size, ragged mates, N on both strands, mismatch bursts after the protected prefix"""
+    p = abi.default_params(True, 150)
+    for key, v in cases.OVERLAP_STRESS[k].items():
+        setattr(p, key, v)
+    d = synth.overlap_pairs(20000, L=150, seed=300 + k)
+    _compare(f"overlap_stress{k}", p, d, True)
+
+
 @pytest.mark.parametrize("L", [36, 75, 100, 250, 400])
 def test_gpu_read_lengths(L):
     p = abi.default_params(True, L)

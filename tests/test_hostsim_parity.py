@@ -93,3 +93,18 @@ def test_sim_trim_and_cut_stress(k):
         bad = np.nonzero(ro[i] != rg[i])[0]
         assert len(bad) == 0, f"stress {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
     assert np.array_equal(co, cg)
+
+
+@pytest.mark.parametrize("k", range(len(cases.OVERLAP_STRESS)))
+def test_sim_overlap_stress(k):
+    """OverlapAnalysis::analyze (prefilter + exact verify + scan-order key) vs the oracle's literal scan"""
+    p = abi.default_params(True, 150)
+    for key, v in cases.OVERLAP_STRESS[k].items():
+        setattr(p, key, v)
+    d = synth.overlap_pairs(600, L=150, seed=300 + k)
+    ro, rg, co, cg = _both(p, d, True)
+    for i in range(3):
+        bad = np.nonzero(ro[i] != rg[i])[0]
+        assert len(bad) == 0, f"overlap stress {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
+    assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"]))
+    assert np.array_equal(co, cg)
