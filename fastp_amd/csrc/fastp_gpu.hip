@@ -19,7 +19,9 @@ using namespace fq;
 // ---------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(KernelArgs a) {
     extern __shared__ u32 fq_lds[];
-    fused_body(a, fq_lds);
+    // read the argument block through the kernarg segment pointer (scalar loads where a field is
+    // used) instead of holding all ~150 dwords in SGPRs for the whole persistent loop
+    fused_body(*kernel_args(&a), fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }

@@ -843,25 +843,82 @@ FQ_DEV bool apply_trim_by_sequence(const KernelArgs& a, u32* lds, int R, const u
     return true;
 }
 
-// Filter::passFilter (filter.cpp:15-57) on the read [f, f+rlen); alive == non-NULL
+// ---------------------------------------------------------------------------
+// fastp_simd::countQualityMetrics (simd.cpp:54-119) and countAdjacentDiffs (:162-185) on the
+// final window [front, front+len) of every read: 8 lanes per read, lane s takes quality
+// dwords s, s+8, ... with byte-parallel arithmetic, a 3-step shuffle folds the partial sums.
+//   met[R][0] = total(qual-33) | lowQualNum << 16      met[R][1] = nBaseNum | adjacentDiffs << 16
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    const int D = (p.qw_g + 7) >> 3;
+    const int total = L.NR * 8;
+    const int lane = tid & 63;
+    const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
+    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (shuffles inside)
+        const int t = t0 + lane;
+        const bool valid = t < total;
+        const int R = valid ? (t >> 3) : 0, seg = t & 7;
+        const int f = lds_i(lds, L.front)[R];
+        const int e = valid ? f + lds_i(lds, L.len)[R] : f;
+        const u32* qrow = lds + L.qual + R * L.QW;
+        const u32* srow = lds + L.seq + R * L.SW;
+        u32 ma = 0, mb = 0;
+        for (int d = 0; d < D; d++) {
+            const int c = seg + 8 * d;
+            const int j0 = 4 * c;
+            if (j0 >= e) break;
+            if (j0 + 4 <= f) continue;
+            const int lo = imax(f - j0, 0), hi = imin(e - j0, 4);  // bytes [lo, hi) of this dword are in the window
+            const u32 M = lowmask32(8 * hi) & ~lowmask32(8 * lo);
+            const u32 qd = qrow[c];
+            const u32 q7 = qd & 0x7F7F7F7Fu;
+            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;  // bit 7 of a byte: qual >= threshold
+            ma += sum_bytes(q7 & M, 0u) - 33u * (u32)(hi - lo);
+            ma += (u32)popc32(~ge & 0x80808080u & M) << 16;
+            mb += (u32)popc32(qd & 0x80808080u & M);
+            if (p.complexity_filter) {
+                // symbol j differs from symbol j-1 (N is its own symbol; its stored code is 0)
+                const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
+                const u32 nb = (qd >> 7) & 0x01010101u;
+                const u32 ncur = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;
+                u32 pcode = 0, pn = 0;
+                if (c > 0) {
+                    pcode = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8 + 6)) & 3u;
+                    pn = (qrow[c - 1] >> 31) & 1u;
+                }
+                const u32 ecodes = pcode | (cur8 << 2);
+                const u32 dc = ecodes ^ (ecodes >> 2);           // group k: code(j0+k-1) ^ code(j0+k)
+                const u32 df = (dc | (dc >> 1)) & 0x55u;
+                const u32 d4 = (df & 1u) | ((df >> 1) & 2u) | ((df >> 2) & 4u) | ((df >> 3) & 8u);
+                const u32 en = pn | (ncur << 1);
+                const u32 dn = (en ^ (en >> 1)) & 0xFu;          // bit k: N(j0+k-1) ^ N(j0+k)
+                const int lo1 = imax(f + 1 - j0, 0);             // pairs (j-1, j) with j in [f+1, e)
+                const u32 M4 = hi > lo1 ? (lowmask32(hi) & ~lowmask32(lo1)) : 0u;
+                mb += (u32)popc32((d4 | dn) & M4) << 16;
+            }
+        }
+#pragma unroll
+        for (int sh = 1; sh < 8; sh <<= 1) {
+            ma += shfl_xor(ma, sh);
+            mb += shfl_xor(mb, sh);
+        }
+        if (valid && seg == 0) {
+            lds[L.met + 2 * R] = ma;
+            lds[L.met + 2 * R + 1] = mb;
+        }
+    }
+}
+
+// Filter::passFilter (filter.cpp:15-57) on the read [f, f+rlen) from its metrics; alive == non-NULL
 FQ_DEV int pass_filter(const KernelArgs& a, u32* lds, int R, bool alive) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     const int rlen = lds_i(lds, L.len)[R];
     if (!alive || rlen == 0) return 16;  // FAIL_LENGTH (:16-18)
-    const int f = lds_i(lds, L.front)[R];
-    const u32* srow = lds_seq(L, lds, R);
-    const u8* q = (const u8*)lds_qual(L, lds, R);
-    int low = 0, nb = 0, tot = 0;
-    if (p.qual_filter || p.length_filter) {  // countQualityMetrics simd.cpp:54-119
-        for (int i = 0; i < rlen; i++) {
-            const u32 b = q[f + i];
-            const u32 qc = b & 0x7Fu;
-            tot += (int)qc - 33;
-            low += qc < (u32)p.qual_thr;
-            nb += (int)(b >> 7);
-        }
-    }
+    const u32 ma = lds[L.met + 2 * R], mb = lds[L.met + 2 * R + 1];
+    const int tot = (int)(ma & 0xFFFFu), low = (int)(ma >> 16), nb = (int)(mb & 0xFFFFu), diff = (int)(mb >> 16);
     if (p.qual_filter) {  // :35-42
         const u16* lowq = (const u16*)(lds + L.lut_lowq);
         if (low > (int)lowq[rlen]) return 20;                                   // FAIL_QUALITY
@@ -874,13 +931,6 @@ FQ_DEV int pass_filter(const KernelArgs& a, u32* lds, int R, bool alive) {
     }
     if (p.complexity_filter) {  // :51-54, 59-66
         if (rlen <= 1) return 24;
-        int diff = 0;
-        u32 prev = sym_at(srow, q, f);
-        for (int i = 1; i < rlen; i++) {
-            const u32 cur = sym_at(srow, q, f + i);
-            diff += prev != cur;
-            prev = cur;
-        }
         const u16* cmin = (const u16*)(lds + L.lut_cplx);
         if (diff < (int)cmin[rlen]) return 24;  // FAIL_COMPLEXITY
     }
@@ -1042,6 +1092,25 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             if (p.max_len1 > 0 && p.max_len1 < lenv[R1]) lenv[R1] = p.max_len1;
             if (p.max_len2 > 0 && p.max_len2 < lenv[R2]) lenv[R2] = p.max_len2;
         }
+        if (dimer) flags[R1] |= RS_DIMER;
+        // fastp_gpu_pair_result: i16 ov_offset, u16 ov_len | u16 ov_diff, u16 flags
+        a.pair[2 * (size_t)gp] = ((u32)ov_off & 0xFFFFu) | (((u32)ov_len & 0xFFFFu) << 16);
+        a.pair[2 * (size_t)gp + 1] = ((u32)ov_diff & 0xFFFFu) | ((u32)((ovl ? 1 : 0) | (isize_done ? 4 : 0)) << 16);
+    }
+}
+
+// Phase E3 (paired): lane = one pair.  Filter::passFilter and routing, peprocessor.cpp:563-591.
+FQ_DEV void phase_filter_pe(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    u32* misc = lds + L.acc_misc;
+    for (int pr = tid; pr < L.P; pr += nthreads) {
+        const int gp = tile_first + pr;
+        if (gp >= a.n) continue;
+        const int R1 = pr, R2 = L.P + pr;
+        int* flags = lds_i(lds, L.flags);
+        const bool a1 = !(flags[R1] & RS_NULL), a2 = !(flags[R2] & RS_NULL);
+        const bool dimer = (flags[R1] & RS_DIMER) != 0;
         int code1 = pass_filter(a, lds, R1, a1);  // :565-566
         int code2 = pass_filter(a, lds, R2, a2);
         if (dimer) { code1 = 28; code2 = 28; }     // :568-571
@@ -1066,9 +1135,6 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         }
         write_read_result(a, lds, 0, R1, gp);
         write_read_result(a, lds, 1, R2, gp);
-        // fastp_gpu_pair_result: i16 ov_offset, u16 ov_len | u16 ov_diff, u16 flags
-        a.pair[2 * (size_t)gp] = ((u32)ov_off & 0xFFFFu) | (((u32)ov_len & 0xFFFFu) << 16);
-        a.pair[2 * (size_t)gp + 1] = ((u32)ov_diff & 0xFFFFu) | ((u32)((ovl ? 1 : 0) | (isize_done ? 4 : 0)) << 16);
     }
 }
 
@@ -1104,8 +1170,22 @@ FQ_DEV void phase_decide_se(const KernelArgs& a, u32* lds, int tile_first, int t
             lenv[R] = nl;
         }
         if (alive && p.max_len1 > 0 && p.max_len1 < lenv[R]) lenv[R] = p.max_len1;  // :268-271
+        if (dimer) flags[R] |= RS_DIMER;
+    }
+}
+
+// Phase E3 (single-end): lane = one read.  Filter::passFilter and routing, seprocessor.cpp:273-290.
+FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    u32* misc = lds + L.acc_misc;
+    for (int R = tid; R < L.P; R += nthreads) {
+        const int gp = tile_first + R;
+        if (gp >= a.n) continue;
+        int* flags = lds_i(lds, L.flags);
+        const bool alive = !(flags[R] & RS_NULL);
         int code = pass_filter(a, lds, R, alive);  // :273
-        if (dimer) code = 28;
+        if (flags[R] & RS_DIMER) code = 28;
         lds_add_u32(&misc[MISC_FILTER + code], 1u);  // :278
         lds_i(lds, L.code)[R] = code;
         const bool dedup_out = p.dedup && (flags[R] & RS_DUP);
@@ -1178,11 +1258,17 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
         else phase_decide_se(a, lds, tile_first, tid, nt);
         block_sync();
+        phase_metrics(a, lds, tid, nt);
+        block_sync();
+        if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
+        else phase_filter_se(a, lds, tile_first, tid, nt);
+        block_sync();
+        FQ_STAMP(6)
         FQ_STAMP(5)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
         phase_stats(a, lds, a.p.stats_one_pass ? ST_BOTH : ST_POST, n_valid, tid, nt);
         block_sync();
-        FQ_STAMP(6)
+        FQ_STAMP(7)
 #undef FQ_STAMP
     }
     if (timing)

@@ -241,6 +241,7 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.apos = take(out.NR);
         out.alen = take(out.NR);
         out.code = take(out.NR);
+        out.met = take(out.NR * 2);
         out.ov_off = take(P);
         out.ov_len = take(P);
         out.ov_diff = take(P);

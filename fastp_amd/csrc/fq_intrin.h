@@ -16,6 +16,16 @@ FQ_DEV int grid_blocks() { return (int)gridDim.x; }
 FQ_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 FQ_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
 
+// the kernel's by-value argument block as it sits in the kernarg segment (constant memory)
+template <class T> FQ_DEV const T* kernel_args(const T* by_value) {
+#ifdef FQ_HOSTSIM
+    return by_value;
+#else
+    (void)by_value;
+    return (const T*)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
+}
+
 FQ_DEV void block_sync() { __syncthreads(); }
 FQ_DEV u64 cycle_counter() { return (u64)clock64(); }
 FQ_DEV void g_atomic_add_u64(u64* p, u64 v) {

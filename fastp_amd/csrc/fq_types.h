@@ -41,7 +41,8 @@ enum {
     RS_NULL = 0x01, RS_DUP = 0x02, RS_ADAPTER = 0x04, RS_ADAPTER_OV = 0x08, RS_CORRECTED = 0x10,
     RS_MERGED = 0x20, RS_POLYX = 0x40,
     RS_HAS_N = 0x100,   // the read contains at least one 'N'
-    RS_STAT_POST = 0x200 // goes into the post-filtering Stats
+    RS_STAT_POST = 0x200, // goes into the post-filtering Stats
+    RS_DIMER = 0x400     // adapter dimer evidence (peprocessor.cpp:480-484), carried from the trim to the filter step
 };
 
 struct DevParams {
@@ -92,6 +93,7 @@ struct LdsLayout {
                     // update consecutive LDS words
     int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
+    int met;        // [NR][2] countQualityMetrics / countAdjacentDiffs of the final window (phase_metrics)
     int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed scan key (OV_KEY_*)
     int hash;       // [NR][bufnum] u64 (2 dwords each): per-read part of Duplicate::seq2intvector
     // per-read position bit masks (bit j of a mask = predicate at base j of the row), built in

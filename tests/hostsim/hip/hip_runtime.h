@@ -46,6 +46,7 @@ int shfl(int v, int src_lane);
 int shfl_xor(int v, int mask);
 }  // namespace sim
 
+#define FQ_HOSTSIM 1
 #define threadIdx (sim::thread_idx())
 #define blockIdx (sim::block_idx())
 #define blockDim (sim::block_dim())
