@@ -260,6 +260,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.L = ctx->L;
     a.magic_sw = magic_for((u32)ctx->L.SW);
     a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
+    a.magic_swg = magic_for((u32)ctx->dp.sw_g);
+    a.prefetch = ctx->L.NR * ctx->dp.qw_g <= PF_Q * ctx->cfg.threads && ctx->L.NR * ctx->dp.sw_g <= PF_S * ctx->cfg.threads &&
+                 ctx->L.NR <= ctx->cfg.threads && !env_int("FASTP_GPU_NO_PREFETCH", 0);
     a.n = n;
     a.first = first;
     a.batch_flags = b->flags;

@@ -139,6 +139,107 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
     }
 }
 
+// ---------------------------------------------------------------------------
+// Phase A with software prefetch: the global loads of tile i+1 are issued right after tile i
+// has been staged and stay in flight (registers) while tile i is processed, so the HBM latency
+// of a tile is hidden behind the compute of the previous one.
+// ---------------------------------------------------------------------------
+struct TileRegs {
+    u32 q[PF_Q];
+    u32 s[PF_S];
+    u32 len;
+};
+
+FQ_DEV void tile_fetch(const KernelArgs& a, int tile_first, int tid, int nthreads, TileRegs& r) {
+    const LdsLayout& L = a.L;
+    const int P = L.P, qwg = a.p.qw_g, swg = a.p.sw_g;
+    const int nq = L.NR * qwg, ns = L.NR * swg;
+#pragma unroll
+    for (int i = 0; i < PF_Q; i++) {
+        const int idx = tid + i * nthreads;
+        u32 v = 0;
+        if (idx < nq) {
+            const int R = (int)fastdiv((u32)idx, a.magic_qwg);
+            const int m = R >= P ? 1 : 0;
+            const int gp = tile_first + R - m * P;
+            if (gp < a.n) v = a.qual[m][(size_t)gp * qwg + (idx - R * qwg)];
+        }
+        r.q[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PF_S; i++) {
+        const int idx = tid + i * nthreads;
+        u32 v = 0;
+        if (idx < ns) {
+            const int R = (int)fastdiv((u32)idx, a.magic_swg);
+            const int m = R >= P ? 1 : 0;
+            const int gp = tile_first + R - m * P;
+            if (gp < a.n) v = a.seq[m][(size_t)gp * swg + (idx - R * swg)];
+        }
+        r.s[i] = v;
+    }
+    r.len = 0;
+    if (tid < L.NR) {
+        const int m = tid >= P ? 1 : 0;
+        const int gp = tile_first + tid - m * P;
+        if (gp < a.n) r.len = a.len[m][gp];
+    }
+}
+
+FQ_DEV void tile_commit(const KernelArgs& a, u32* lds, int tid, int nthreads, const TileRegs& r) {
+    const LdsLayout& L = a.L;
+    const int P = L.P, qwg = a.p.qw_g, swg = a.p.sw_g;
+    const int nq = L.NR * qwg, ns = L.NR * swg;
+    if (tid < L.NR) {
+        const int R = tid, len = (int)r.len;
+        lds_i(lds, L.rlen0)[R] = len;
+        lds_i(lds, L.front)[R] = 0;
+        lds_i(lds, L.len)[R] = len;
+        lds_i(lds, L.flags)[R] = 0;
+        lds_i(lds, L.ft)[R] = 0;
+        lds_i(lds, L.apos)[R] = 0;
+        lds_i(lds, L.alen)[R] = 0;
+        lds_i(lds, L.code)[R] = 0;
+        if (R < P) lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
+    }
+    for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
+    for (int idx = tid; idx < L.NR * L.SW; idx += nthreads) {  // N masks and the pad words of the base rows
+        lds[L.nmk + idx] = 0;
+        const int R = (int)fastdiv((u32)idx, a.magic_sw);
+        if (idx - R * L.SW >= swg) lds[L.seq + idx] = 0;
+    }
+    for (int idx = tid; idx < L.NR * (L.QW - qwg); idx += nthreads) {  // pad column(s) of the quality rows
+        const int per = L.QW - qwg;
+        const int R = idx / per;
+        lds[L.qual + R * L.QW + qwg + (idx - R * per)] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < PF_S; i++) {
+        const int idx = tid + i * nthreads;
+        if (idx < ns) {
+            const int R = (int)fastdiv((u32)idx, a.magic_swg);
+            lds[L.seq + R * L.SW + (idx - R * swg)] = r.s[i];
+        }
+    }
+    block_sync();
+#pragma unroll
+    for (int i = 0; i < PF_Q; i++) {
+        const int idx = tid + i * nthreads;
+        if (idx < nq) {
+            const int R = (int)fastdiv((u32)idx, a.magic_qwg);
+            const int col = idx - R * qwg;
+            const u32 v = r.q[i];
+            lds[L.qual + R * L.QW + col] = v;
+            const u32 nb = (v >> 7) & 0x01010101u;
+            if (nb) {  // N masks from bit 7 of the quality bytes
+                const u32 t = (nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u;
+                lds_or_u32(&lds[L.nmk + R * L.SW + (col >> 2)], t << ((col & 3) * 8));
+                lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+            }
+        }
+    }
+}
+
 // total quality (N flag masked off) of the windows [4c+k, 4c+k+w), k = 0..3, of one row:
 // v_alignbit_b32 + v_sad_u8 per 4 bases.  ncols = dwords of the LDS row (pad columns are zero).
 FQ_DEV void window_sums4(const u32* qrow, int c, int ncols, int w, u32 out[4]) {
@@ -1233,13 +1334,18 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     const bool timing_on = a.phase_cycles != nullptr;  // uniform
     const bool timing = timing_on && tid == 0;
     u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    TileRegs regs;
+    const bool prefetch = a.prefetch != 0;  // uniform
+    if (prefetch && block_id() < a.tiles) tile_fetch(a, block_id() * L.P, tid, nt, regs);
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
         const int n_valid = imin(L.P, a.n - tile_first);
         u64 t0 = timing ? cycle_counter() : 0, t1;
 #define FQ_STAMP(k) if (timing) { t1 = cycle_counter(); tacc[k] += t1 - t0; t0 = t1; }
-        phase_load(a, lds, tile_first, tid, nt);
+        if (prefetch) tile_commit(a, lds, tid, nt, regs);
+        else phase_load(a, lds, tile_first, tid, nt);
         block_sync();
+        if (prefetch && tile + grid_blocks() < a.tiles) tile_fetch(a, (tile + grid_blocks()) * L.P, tid, nt, regs);
         FQ_STAMP(0)
         if (!a.p.stats_one_pass) phase_stats(a, lds, ST_PRE, n_valid, tid, nt);  // Stats::statRead on the original reads
         phase_masks(a, lds, n_valid, tid, nt);
@@ -1249,8 +1355,10 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         phase_trim(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(2)
-        phase_polyg(a, lds, tid, nt);
-        block_sync();
+        if (a.p.poly_g) {
+            phase_polyg(a, lds, tid, nt);
+            block_sync();
+        }
         FQ_STAMP(3)
         phase_overlap(a, lds, tid, nt);
         block_sync();
@@ -1258,13 +1366,13 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
         else phase_decide_se(a, lds, tile_first, tid, nt);
         block_sync();
+        FQ_STAMP(5)
         phase_metrics(a, lds, tid, nt);
         block_sync();
         if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
         else phase_filter_se(a, lds, tile_first, tid, nt);
         block_sync();
         FQ_STAMP(6)
-        FQ_STAMP(5)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
         phase_stats(a, lds, a.p.stats_one_pass ? ST_BOTH : ST_POST, n_valid, tid, nt);
         block_sync();

@@ -30,6 +30,9 @@ enum { CYC_MAX_READS = (1 << CYC_CNT_BITS) - 1 };
 enum { OV_KEY_DIFF_BITS = 16, OV_KEY_OFF_BITS = 10 };
 static const u32 OV_KEY_NONE = 0xFFFFFFFFu;
 
+// per-lane registers that hold the NEXT tile's input while the current tile is processed
+enum { PF_Q = 12, PF_S = 4 };
+
 enum { QH_COPIES = 8 };        // replicated quality histograms (bank spreading)
 enum { KMER_BINS = 1024 };
 enum { MAX_DUP_BUFS = 8 };
@@ -137,6 +140,8 @@ struct KernelArgs {
     DevLuts lut;
     LdsLayout L;
     u32 magic_sw, magic_qwg;   // ceil(2^32 / L.SW), ceil(2^32 / p.qw_g) for exact small divisions
+    u32 magic_swg;             // ceil(2^32 / p.sw_g)
+    int prefetch;              // a tile's input fits the per-lane prefetch registers (TileRegs)
     // batch (device pointers)
     int n;
     int first;          // index of this launch's first read/pair inside the submitted batch
