@@ -23,6 +23,10 @@ extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(KernelArgs a)
     // used) instead of holding all ~150 dwords in SGPRs for the whole persistent loop
     fused_body(*kernel_args(&a), fq_lds);
 }
+extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) {
+    extern __shared__ u32 fq_lds[];
+    hash_body(*kernel_args(&a), fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_resolve_kernel(DupArgs d) { dup_resolve_body(d); }
@@ -58,6 +62,7 @@ struct fastp_gpu_ctx {
     u64* d_dup_pos = nullptr; size_t dup_pos_cap = 0;
     u64* d_table = nullptr; size_t table_cap = 0;
     u8* d_need = nullptr; size_t need_cap = 0;
+    u8* d_dupflag = nullptr; size_t dupflag_cap = 0;   // --dedup: per-unit duplicate decision
     // staging for submit_host
     void* d_stage = nullptr; size_t stage_cap = 0;
     u64* d_phase = nullptr;   // optional per-phase cycle counters (FASTP_GPU_PHASE_TIMING=1)
@@ -114,7 +119,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     drain_events(ctx);
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_ctr, ctx->d_slabs,
-                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_stage, ctx->d_phase};
+                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -177,6 +182,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
         if (bytes == 0) { *dptr = nullptr; return 0; }
         HIP_TRY(ctx, hipMalloc(dptr, bytes));
@@ -291,8 +297,56 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.slab_dwords = ctx->slab_dwords;
     a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
     const int grid = a.tiles < ctx->blocks ? a.tiles : ctx->blocks;
+    const fastp_gpu_counter_layout& cl = ctx->cl;
+    int rc;
+
+    // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
+    auto launch_dup = [&](u8* dupflag) -> int {
+        DupArgs d;
+        memset(&d, 0, sizeof(d));
+        d.dup_pos = ctx->d_dup_pos;
+        d.n = n;
+        d.B = ctx->dp.dup_bufnum;
+        d.bits = ctx->dp.dup_bits;
+        d.bitmap = ctx->d_bitmap;
+        int lg = 10;
+        while ((1ull << lg) < (size_t)n * d.B * 2) lg++;
+        int r2 = ensure(ctx, (void**)&ctx->d_table, &ctx->table_cap, (size_t)8 << lg);
+        if (r2) return r2;
+        r2 = ensure(ctx, (void**)&ctx->d_need, &ctx->need_cap, (size_t)n);
+        if (r2) return r2;
+        d.table = ctx->d_table;
+        d.table_log2 = lg;
+        d.need = ctx->d_need;
+        d.res[0] = a.res[0];
+        d.res[1] = a.res[1];
+        d.dupflag = dupflag;
+        d.paired = ctx->dp.paired;
+        d.ctr_total = ctx->d_ctr + cl.dup_total;
+        d.ctr_dups = ctx->d_ctr + cl.dup_count;
+        HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
+        const int g2 = std::min(ctx->cus * 8, (n + 255) / 256);
+        hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(g2), dim3(256), 0, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
+
+    if (ctx->dp.dedup) {
+        // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
+        rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        rc = launch_dup(ctx->d_dupflag);
+        if (rc) return rc;
+        a.dup_pos = nullptr;
+        a.dupflag = ctx->d_dupflag;
+    }
+
     hipEvent_t e0, e1;
-    int rc = get_events(ctx, &e0, &e1);
+    rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(e0, st));
     hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
@@ -309,7 +363,6 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     r.isize_max = ctx->dp.isize_max;
     r.one_pass = ctx->dp.stats_one_pass;
     r.ctr = ctx->d_ctr;
-    const fastp_gpu_counter_layout& cl = ctx->cl;
     r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
     r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;
     r.o_corrected_reads = cl.corrected_reads; r.o_merged = cl.merged_pairs; r.o_isize = cl.isize;
@@ -320,34 +373,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     hipLaunchKernelGGL(fq_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, st, r);
     HIP_TRY(ctx, hipGetLastError());
 
-    if (ctx->dp.dup_enabled) {
-        DupArgs d;
-        memset(&d, 0, sizeof(d));
-        d.dup_pos = ctx->d_dup_pos;
-        d.n = n;
-        d.B = ctx->dp.dup_bufnum;
-        d.bits = ctx->dp.dup_bits;
-        d.bitmap = ctx->d_bitmap;
-        int lg = 10;
-        while ((1ull << lg) < (size_t)n * d.B * 2) lg++;
-        rc = ensure(ctx, (void**)&ctx->d_table, &ctx->table_cap, (size_t)8 << lg);
+    if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
+        rc = launch_dup(nullptr);
         if (rc) return rc;
-        rc = ensure(ctx, (void**)&ctx->d_need, &ctx->need_cap, (size_t)n);
-        if (rc) return rc;
-        d.table = ctx->d_table;
-        d.table_log2 = lg;
-        d.need = ctx->d_need;
-        d.res[0] = a.res[0];
-        d.res[1] = a.res[1];
-        d.paired = ctx->dp.paired;
-        d.ctr_total = ctx->d_ctr + cl.dup_total;
-        d.ctr_dups = ctx->d_ctr + cl.dup_count;
-        HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
-        const int g2 = std::min(ctx->cus * 8, (n + 255) / 256);
-        hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
-        HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(g2), dim3(256), 0, st, d);
-        HIP_TRY(ctx, hipGetLastError());
     }
     return FASTP_GPU_OK;
 }

@@ -93,7 +93,7 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
         lds_i(lds, L.code)[R] = 0;
         if (R < P) {
             lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
-            lds_i(lds, L.ov_len)[R] = 0;
+            lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
             lds_i(lds, L.ov_diff)[R] = 0;
             lds_i(lds, L.ov_flags)[R] = 0;
         }
@@ -200,7 +200,10 @@ FQ_DEV void tile_commit(const KernelArgs& a, u32* lds, int tid, int nthreads, co
         lds_i(lds, L.apos)[R] = 0;
         lds_i(lds, L.alen)[R] = 0;
         lds_i(lds, L.code)[R] = 0;
-        if (R < P) lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
+        if (R < P) {
+            lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
+            lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
+        }
     }
     for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
     for (int idx = tid; idx < L.NR * L.SW; idx += nthreads) {  // N masks and the pad words of the base rows
@@ -582,7 +585,7 @@ FQ_DEV int trim_poly_x(const u32* srow, const u8* q, int f, int rlen, int compar
 FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
-    if (!p.dup_enabled) return;
+    if (!p.dup_enabled || !a.dup_pos) return;
     const int B = p.dup_bufnum;
     const u32 mask = (u32)(512 * B - 1);
     const u32* primes = lds + L.primes;
@@ -639,11 +642,15 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
 // Phase C2: lane = one read.  UMI front trim (umiprocessor.cpp:19-49 / read.cpp:69-73),
 // then Filter::trimAndCut on the predicate masks.
 // ---------------------------------------------------------------------------
-FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= L.P ? 1 : 0;
+        if (a.dupflag) {  // --dedup: Duplicate::checkPair/checkRead already ran for this batch
+            const int gp = tile_first + R - m * L.P;
+            if (gp < a.n && a.dupflag[gp]) lds_or_i32(&lds_i(lds, L.flags)[R], RS_DUP);
+        }
         int len = lds_i(lds, L.rlen0)[R];
         int front = 0;
         const int umi = m ? p.umi_len2 : p.umi_len1;
@@ -789,6 +796,124 @@ FQ_DEV void overlap_task(const KernelArgs& a, u32* lds, int pr, int part) {
                 return;
             }
         }
+    }
+}
+
+// ---- the one-gap pass (overlapanalysis.cpp:91-139), only for pairs the no-gap scan left
+// without a result.  Matcher::diffWithOneInsertion (matcher.cpp:56-100) in closed form: with
+//   D0[k] = ins[k] != nor[k],  D1[k] = ins[k+1] != nor[k],  P0/P1 their prefix counts, c = cmplen:
+//   result = -1                              if P0(c-1) + D1[c-1] > limit   (the final loop's exit,
+//                                            taken even when an earlier split was good)
+//          = min_{1<=i<c} P0(i) - P1(i) + P1(c)   otherwise; the capped entries of
+//            accMismatchFromRight are all > limit and cannot be that minimum when it is accepted.
+// ins_is_x: ins = X shifted by o, nor = Y;  else ins = Y, nor = X shifted by o.
+template <int DIR>
+FQ_DEV int ov_gap_diff(const PairView& v, int o, int c, int limit, bool ins_is_x) {
+    if (c <= 1) return 100000000;  // the loops never run (matcher.cpp:88)
+    int p0 = 0, p1 = 0, p0_cm1 = 0, d1_last = 0;
+    for (int t = 0; t < c; t += 16) {
+        const u32 x = ov_x<DIR>(v, o + t), y = ov_y<DIR>(v, t);
+        u32 d0 = fold_diff(x ^ y);
+        u32 d1 = ins_is_x ? fold_diff(ov_x<DIR>(v, o + t + 1) ^ y) : fold_diff(ov_y<DIR>(v, t + 1) ^ x);
+        if (v.hasN) {
+            const u32 xn = ov_xn<DIR>(v, o + t), yn = ov_yn<DIR>(v, t);
+            d0 |= xn ^ yn;
+            d1 |= ins_is_x ? (ov_xn<DIR>(v, o + t + 1) ^ yn) : (ov_yn<DIR>(v, t + 1) ^ xn);
+        }
+        p0 += popc32(d0 & lowmask32(2 * (c - t)));
+        p0_cm1 += popc32(d0 & lowmask32(2 * imax(0, c - 1 - t)));
+        p1 += popc32(d1 & lowmask32(2 * (c - t)));
+        if (c - 1 >= t && c - 1 < t + 16) d1_last = (int)((d1 >> (2 * (c - 1 - t))) & 1u);
+    }
+    if (p0_cm1 + d1_last > limit) return -1;
+    // min over i in [1, c) of P0(i) - P1(i)
+    int g = 0, gmin = 0x7FFFFFFF;
+    for (int t = 0; t < c - 1; t += 16) {
+        const u32 x = ov_x<DIR>(v, o + t), y = ov_y<DIR>(v, t);
+        u32 d0 = fold_diff(x ^ y);
+        u32 d1 = ins_is_x ? fold_diff(ov_x<DIR>(v, o + t + 1) ^ y) : fold_diff(ov_y<DIR>(v, t + 1) ^ x);
+        if (v.hasN) {
+            const u32 xn = ov_xn<DIR>(v, o + t), yn = ov_yn<DIR>(v, t);
+            d0 |= xn ^ yn;
+            d1 |= ins_is_x ? (ov_xn<DIR>(v, o + t + 1) ^ yn) : (ov_yn<DIR>(v, t + 1) ^ xn);
+        }
+        const int nb = imin(16, c - 1 - t);  // positions k = t .. t+nb-1 give i = k+1 in [1, c)
+        for (int k = 0; k < nb; k++) {
+            g += (int)((d0 >> (2 * k)) & 1u) - (int)((d1 >> (2 * k)) & 1u);
+            gmin = imin(gmin, g);
+        }
+    }
+    return gmin + p1;
+    (void)p0;
+}
+
+template <int DIR>
+FQ_DEV void overlap_gap_task(const KernelArgs& a, u32* lds, int pr, int part) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    const int R1 = pr, R2 = L.P + pr;
+    if ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_NULL) return;
+    if ((u32)lds_i(lds, L.ov_off)[pr] != OV_KEY_NONE) return;  // the no-gap passes return first (:48-89)
+    PairView v;
+    v.s1 = lds_seq(L, lds, R1);
+    v.n1 = lds_nmk(L, lds, R1);
+    v.s2 = lds_seq(L, lds, R2);
+    v.n2 = lds_nmk(L, lds, R2);
+    v.f1 = lds_i(lds, L.front)[R1];
+    v.l1 = lds_i(lds, L.len)[R1];
+    v.l2 = lds_i(lds, L.len)[R2];
+    v.e2 = lds_i(lds, L.front)[R2] + v.l2;
+    v.hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
+    const int lenX = DIR ? v.l2 : v.l1, lenY = DIR ? v.l1 : v.l2;
+    const int nvalid = lenX - p.overlap_require;
+    if (nvalid <= 0) return;
+    const short* lut = (const short*)(lds + L.lut_ov);
+    // acceptance needs P0(c-1) <= limit: the ungapped mismatches of the first ol-2 positions
+    const int npre = imax(0, imin(16, imin(p.overlap_require - 1, lenY - 2)));
+    const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+    const u32 y0 = ov_y<DIR>(v, 0);
+    const int lmax = p.ov_limit_max;
+    u32* keyp = (u32*)&lds_i(lds, L.ov_len)[pr];
+    for (int b = part; 16 * b < nvalid; b += 4) {
+        const int o0 = 16 * b;
+        if (*(volatile u32*)keyp < ((u32)DIR << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS) | ((u32)o0 << OV_KEY_DIFF_BITS))) break;
+        const u32 w0 = ov_x<DIR>(v, o0), w1 = ov_x<DIR>(v, o0 + 16);
+        u32 cand = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const u32 x = t ? alignbit(w1, w0, 2 * t) : w0;
+            const u32 d = x ^ y0;
+            const int cnt = popc32((d | (d >> 1)) & premask);
+            cand = cand + cand + (u32)(cnt <= lmax);
+        }
+        if (nvalid - o0 < 16) cand &= ~lowmask32(16 - (nvalid - o0));
+        while (cand) {
+            const int t = clz32(cand) - 16;
+            cand &= ~(0x8000u >> t);
+            const int o = o0 + t;
+            const int ol = imin(lenX - o, lenY);
+            const int limit = lut[ol];
+            // forward: diff(str1+o, str2) then diff(str2, str1+o); reverse: diff(str1, str2+o) then diff(str2+o, str1)
+            int d = ov_gap_diff<DIR>(v, o, ol - 1, limit, DIR == 0);
+            if (d < 0 || d > limit) d = ov_gap_diff<DIR>(v, o, ol - 1, limit, DIR != 0);
+            if (d <= limit && d >= 0) {
+                lds_min_u32(keyp, ((u32)DIR << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS)) | ((u32)o << OV_KEY_DIFF_BITS) | (u32)d);
+                return;
+            }
+        }
+    }
+}
+
+FQ_DEV void phase_overlap_gap(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    if (!p.paired || !p.allow_gap || !p.need_overlap) return;  // peprocessor.cpp:443-447
+    const int half = 4 * L.P;
+    for (int t = tid; t < 2 * half; t += nthreads) {
+        const int dir = t >= half ? 1 : 0;
+        const int u = t - dir * half;
+        if (dir) overlap_gap_task<1>(a, lds, u >> 2, u & 3);
+        else overlap_gap_task<0>(a, lds, u >> 2, u & 3);
     }
 }
 
@@ -1089,6 +1214,13 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         const int ft1 = lds_i(lds, L.ft)[R1], ft2 = lds_i(lds, L.ft)[R2];
         int ovl, ov_off, ov_len, ov_diff;  // the OverlapResult of the pair as it is now (quirk #6)
         decode_overlap((u32)lds_i(lds, L.ov_off)[pr], lenv[R1], lenv[R2], ovl, ov_off, ov_len, ov_diff);
+        // ovForAdapter (peprocessor.cpp:445-447): with allow_gap, the one-gap result where no-gap found nothing
+        int aovl = ovl, aoff = ov_off, aol = ov_len, adiff = ov_diff;
+        bool agap = false;
+        if (p.allow_gap && !ovl) {
+            decode_overlap((u32)lds_i(lds, L.ov_len)[pr], lenv[R1], lenv[R2], aovl, aoff, aol, adiff);
+            agap = aovl != 0;
+        }
         bool isize_done = false, dimer = false;
         // statInsertSize (peprocessor.cpp:710-723), thread 0 only (:449, :497)
         if (both && thread0) {
@@ -1103,17 +1235,17 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         }
         if (both && p.need_overlap) {
             // BaseCorrector::correctByOverlapAnalysis (basecorrector.cpp:16-83)
-            if (p.correction && ovl && ov_diff != 0) {
+            if (p.correction && aovl && !agap && adiff != 0) {
                 const int f1 = lds_i(lds, L.front)[R1], f2 = lds_i(lds, L.front)[R2];
-                const int start1 = imax(0, ov_off);
-                const int start2 = lenv[R2] - imax(0, -ov_off) - 1;
+                const int start1 = imax(0, aoff);
+                const int start2 = lenv[R2] - imax(0, -aoff) - 1;
                 const u32* s1 = lds_seq(L, lds, R1);
                 const u32* s2 = lds_seq(L, lds, R2);
                 const u8* q1 = (const u8*)lds_qual(L, lds, R1);
                 const u8* q2 = (const u8*)lds_qual(L, lds, R2);
                 int corrected = 0;
                 bool r1c = false, r2c = false;
-                for (int i = 0; i < ov_len; i++) {
+                for (int i = 0; i < aol; i++) {
                     const int j1 = f1 + start1 + i, j2 = f2 + start2 - i;
                     const u32 b1 = sym_at(s1, q1, j1), b2 = sym_at(s2, q2, j2);
                     if (b1 != sym_complement(b2)) {
@@ -1150,9 +1282,9 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             }
             if (p.adapter_enabled) {
                 bool trimmed = false;
-                if (ovl && ov_off < 0) {  // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
-                    const int len1 = imin(lenv[R1], ov_len + ft2);
-                    const int len2 = imin(lenv[R2], ov_len + ft1);
+                if (aovl && aoff < 0) {  // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
+                    const int len1 = imin(lenv[R1], aol + ft2);
+                    const int len2 = imin(lenv[R2], aol + ft1);
                     lds_i(lds, L.apos)[R1] = len1;
                     lds_i(lds, L.alen)[R1] = lenv[R1] - len1;
                     lds_i(lds, L.apos)[R2] = len2;
@@ -1200,6 +1332,22 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
     }
 }
 
+// Duplicate::checkPair / checkRead hash values (duplicate.cpp:122-148) of unit u (pair or single
+// read) for the dup kernels: per-read base parts + the host-built position part
+FQ_DEV void write_dup_pos(const KernelArgs& a, u32* lds, int u, int gp) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    if (!p.dup_enabled || !a.dup_pos) return;
+    const u64* h1 = (const u64*)(lds + L.hash) + (size_t)u * p.dup_bufnum;
+    int tl = lds_i(lds, L.rlen0)[u];
+    if (p.paired) tl += lds_i(lds, L.rlen0)[L.P + u];
+    for (int i = 0; i < p.dup_bufnum; i++) {
+        u64 h = h1[i] + a.lut.dup_posum[(size_t)tl * p.dup_bufnum + i];
+        if (p.paired) h += ((const u64*)(lds + L.hash) + (size_t)(L.P + u) * p.dup_bufnum)[i];
+        a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h;
+    }
+}
+
 // Phase E3 (paired): lane = one pair.  Filter::passFilter and routing, peprocessor.cpp:563-591.
 FQ_DEV void phase_filter_pe(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
     const LdsLayout& L = a.L;
@@ -1226,14 +1374,7 @@ FQ_DEV void phase_filter_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             flags[R1] |= RS_STAT_POST;
             flags[R2] |= RS_STAT_POST;
         }
-        // Duplicate::checkPair hash values (duplicate.cpp:136-148) for the dup kernels
-        if (p.dup_enabled && a.dup_pos) {
-            const u64* h1 = (const u64*)(lds + L.hash) + (size_t)R1 * p.dup_bufnum;
-            const u64* h2 = (const u64*)(lds + L.hash) + (size_t)R2 * p.dup_bufnum;
-            const int tl = lds_i(lds, L.rlen0)[R1] + lds_i(lds, L.rlen0)[R2];
-            for (int i = 0; i < p.dup_bufnum; i++)
-                a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h1[i] + h2[i] + a.lut.dup_posum[(size_t)tl * p.dup_bufnum + i];
-        }
+        write_dup_pos(a, lds, pr, gp);
         write_read_result(a, lds, 0, R1, gp);
         write_read_result(a, lds, 1, R2, gp);
     }
@@ -1291,12 +1432,7 @@ FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int t
         lds_i(lds, L.code)[R] = code;
         const bool dedup_out = p.dedup && (flags[R] & RS_DUP);
         if (!dedup_out && alive && code == 0) flags[R] |= RS_STAT_POST;  // :280-286
-        if (p.dup_enabled && a.dup_pos) {  // Duplicate::checkRead duplicate.cpp:122-134
-            const u64* h = (const u64*)(lds + L.hash) + (size_t)R * p.dup_bufnum;
-            const int tl = lds_i(lds, L.rlen0)[R];
-            for (int i = 0; i < p.dup_bufnum; i++)
-                a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h[i] + a.lut.dup_posum[(size_t)tl * p.dup_bufnum + i];
-        }
+        write_dup_pos(a, lds, R, gp);
         write_read_result(a, lds, 0, R, gp);
     }
 }
@@ -1352,7 +1488,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         phase_hash(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(1)
-        phase_trim(a, lds, tid, nt);
+        phase_trim(a, lds, tile_first, tid, nt);
         block_sync();
         FQ_STAMP(2)
         if (a.p.poly_g) {
@@ -1362,6 +1498,10 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         FQ_STAMP(3)
         phase_overlap(a, lds, tid, nt);
         block_sync();
+        if (a.p.allow_gap) {
+            phase_overlap_gap(a, lds, tid, nt);
+            block_sync();
+        }
         FQ_STAMP(4)
         if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
         else phase_decide_se(a, lds, tile_first, tid, nt);
@@ -1384,6 +1524,29 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     // flush this workgroup's accumulators to its slab (plain coalesced stores)
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];
+}
+
+// ---------------------------------------------------------------------------
+// --dedup needs the duplicate decision BEFORE routing (peprocessor.cpp:396-402, 575): a light
+// first pass stages each tile, hashes the original reads and writes the hash values; the dup
+// kernels then decide, and the fused kernel reads the decision (KernelArgs::dupflag).
+// ---------------------------------------------------------------------------
+FQ_DEV void hash_body(const KernelArgs& a, u32* lds) {
+    const LdsLayout& L = a.L;
+    const int tid = thread_id(), nt = block_threads();
+    if (a.p.dup_enabled)
+        for (int i = tid; i < 512 * a.p.dup_bufnum; i += nt) lds[L.primes + i] = a.lut.dup_primes[i];
+    block_sync();
+    for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
+        const int tile_first = tile * L.P;
+        phase_load(a, lds, tile_first, tid, nt);
+        block_sync();
+        phase_hash(a, lds, tid, nt);
+        block_sync();
+        for (int u = tid; u < L.P; u += nt)
+            if (tile_first + u < a.n) write_dup_pos(a, lds, u, tile_first + u);
+        block_sync();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1512,7 +1675,8 @@ struct DupArgs {
                           // (bit 63 of a real entry is always 0, so it never equals EMPTY)
     int table_log2;
     u8* need;             // [n] mask of buffers whose bit was not committed
-    u32* res[2];          // result records (flags byte gets RS_DUP)
+    u32* res[2];          // result records (flags byte gets RS_DUP) - used when dupflag == nullptr
+    u8* dupflag;          // [n] --dedup: the decision goes here instead (the records do not exist yet)
     int paired;
     int64_t* ctr_total;
     int64_t* ctr_dups;
@@ -1579,7 +1743,9 @@ FQ_DEV void dup_resolve_body(const DupArgs& d) {
                 if (!(first < g)) is_dup = false;  // nobody earlier in this batch set it
                 g_atomic_or_u32(&d.bitmap[(size_t)i * words + (pos >> 5)], 1u << (pos & 31));
             }
-            if (is_dup) {
+            if (d.dupflag) {
+                d.dupflag[g] = is_dup ? 1 : 0;
+            } else if (is_dup) {
                 d.res[0][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
                 if (d.paired) d.res[1][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
             }

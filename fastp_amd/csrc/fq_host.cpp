@@ -83,8 +83,6 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     }
     // options outside the device path's scope for now: fail loudly, never fall back
     if (in.merge) { err = "merge mode is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
-    if (in.allow_gap_overlap_trimming) { err = "allow_gap_overlap_trimming is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
-    if (in.dedup) { err = "dedup (dropping duplicates) is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
     if (in.insert_size_max < 0 || in.insert_size_max > 4096) { err = "insert_size_max out of range"; return FASTP_GPU_E_INVALID; }
     if (in.overlap_diff_limit < 0 || in.overlap_require < 0) { err = "negative overlap knobs"; return FASTP_GPU_E_INVALID; }
     p.paired = in.paired ? 1 : 0;
@@ -119,6 +117,7 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.has_a1 = p.alen1 > 0;
     p.has_a2 = p.alen2 > 0;
     p.correction = (in.correction != 0) && p.paired;  // options.cpp:401-404
+    p.allow_gap = (in.allow_gap_overlap_trimming != 0) && p.paired;
     p.overlap_require = in.overlap_require;
     p.overlap_diff_limit = in.overlap_diff_limit;
     p.qual_filter = in.qual_filter != 0;
@@ -130,7 +129,7 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.length_limit = in.length_limit;
     p.complexity_filter = in.complexity_filter != 0;
     p.dup_enabled = in.dup_enabled != 0;
-    p.dedup = 0;
+    p.dedup = (in.dedup != 0) && p.dup_enabled;
     p.isize_max = in.insert_size_max;
     p.umi_len1 = in.umi_len1 > 0 ? in.umi_len1 : 0;
     p.umi_len2 = (p.paired && in.umi_len2 > 0) ? in.umi_len2 : 0;

@@ -61,6 +61,7 @@ struct DevParams {
     int has_a1, has_a2, alen1, alen2;
     u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
     int correction;
+    int allow_gap;          // AdapterOptions::allowGapOverlapTrimming (overlapanalysis.cpp:91-139)
     int overlap_require, overlap_diff_limit;
     int ov_limit_max;       // largest per-length mismatch limit (the LUT is non-decreasing): prefilter bound
     int qual_filter, qual_thr, n_base_limit, avg_qual_req;
@@ -97,7 +98,8 @@ struct LdsLayout {
     int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
     int met;        // [NR][2] countQualityMetrics / countAdjacentDiffs of the final window (phase_metrics)
-    int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed scan key (OV_KEY_*)
+    int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed no-gap scan key (OV_KEY_*),
+                                                          // ov_len the key of the one-gap pass (allow_gap)
     int hash;       // [NR][bufnum] u64 (2 dwords each): per-read part of Duplicate::seq2intvector
     // per-read position bit masks (bit j of a mask = predicate at base j of the row), built in
     // the pre-stats pass and bit-scanned by Filter::trimAndCut's resolver; an offset is -1 when
@@ -156,6 +158,7 @@ struct KernelArgs {
     int corr_capacity;
     int* n_corrections;
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
+    const u8* dupflag;  // [n] --dedup: the duplicate decision, taken by the dup kernels BEFORE this launch
     u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)
     // per-workgroup counter slabs: [gridDim][slab_dwords]
     u32* slabs;

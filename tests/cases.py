@@ -107,4 +107,7 @@ OVERLAP_STRESS = [
     dict(overlap_require=1, overlap_diff_limit=0, overlap_diff_percent_limit=0, adapter_enabled=0),
     dict(overlap_require=16, overlap_diff_limit=5, overlap_diff_percent_limit=20, cut_front=1, cut_tail=1, poly_g=1),
     dict(overlap_require=149, overlap_diff_limit=60, overlap_diff_percent_limit=100),
+    dict(allow_gap_overlap_trimming=1, correction=1),
+    dict(allow_gap_overlap_trimming=1, correction=1, overlap_require=10, overlap_diff_limit=10, overlap_diff_percent_limit=40),
+    dict(allow_gap_overlap_trimming=1, overlap_require=5, overlap_diff_limit=20, overlap_diff_percent_limit=50),
 ]

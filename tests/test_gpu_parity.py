@@ -16,7 +16,7 @@ from fastp_amd import abi, engine
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [k for k in cases.CASES if k not in ("pe_noadapter_dedup", "pe_merge", "pe_merge_unmerged", "pe_allow_gap")]
+SUPPORTED = [k for k in cases.CASES if k not in ("pe_merge", "pe_merge_unmerged")]
 
 
 def _args(d, paired):

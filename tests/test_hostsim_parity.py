@@ -13,7 +13,7 @@ import refjson
 import synth
 from fastp_amd import abi, engine, hostloop
 
-SUPPORTED = [k for k in cases.CASES if k not in ("pe_noadapter_dedup", "pe_merge", "pe_merge_unmerged", "pe_allow_gap")]
+SUPPORTED = [k for k in cases.CASES if k not in ("pe_merge", "pe_merge_unmerged")]
 
 
 def _both(params, d, paired):
@@ -70,7 +70,7 @@ def test_sim_other_read_lengths_and_tile_shapes(monkeypatch):
 
 
 def test_sim_unsupported_options_fail_loudly():
-    for field in ("merge", "allow_gap_overlap_trimming", "dedup"):
+    for field in ("merge",):
         p = abi.default_params(True, 150)
         setattr(p, field, 1)
         with pytest.raises(engine.EngineError) as e:
