@@ -328,7 +328,8 @@ FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int
 // ---------------------------------------------------------------------------
 enum { ST_PRE = 0, ST_POST = 1, ST_BOTH = 2 };
 
-FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int mode, int n_valid, int tid, int nthreads) {
+template <int mode, bool MERGE>
+FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
     const u32 magic_qwg = a.magic_qwg;
     const LdsLayout& L = a.L;
     const int qwg = a.p.qw_g;
@@ -347,19 +348,23 @@ FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int mode, int n_valid, in
         const int c = act ? idx - R * qwg : 0;
         const int m = R >= L.P ? 1 : 0;
         const int rl0 = lds_i(lds, L.rlen0)[R];
-        const bool out_ok = (lds_i(lds, L.flags)[R] & RS_STAT_POST) != 0;
-        int f = 0, l = rl0, lk = 0;
+        const int rflags = lds_i(lds, L.flags)[R];
+        const bool out_ok = (rflags & RS_STAT_POST) != 0;
+        const bool rc = MERGE && mode == ST_POST && (rflags & RS_POST_RC) != 0;  // tail of a merged read
+        int f = 0, l = rl0, lk = 0, rc_base = 0;
         if (mode == ST_POST) {
             act = act && out_ok;
             f = lds_i(lds, L.front)[R];
-            l = lds_i(lds, L.len)[R];
+            l = lds_i(lds, MERGE ? L.mlen : L.len)[R];
+            if (rc) rc_base = lds_i(lds, L.mlen)[R - L.P] + l - 1;  // merged position of r2'[i] = len1 + len2 - 1 - i
         } else {
             act = act && (R - m * L.P < n_valid);  // rows past the end of the batch do not exist
             if (mode == ST_BOTH && out_ok) lk = lds_i(lds, L.len)[R];
         }
-        const int slot0 = m * 2 + (mode == ST_POST ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
+        int slot0 = m * 2 + (mode == ST_POST ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
+        if (MERGE && mode == ST_POST && (rflags & RS_POST_TO1)) slot0 = 1;
         if (act && c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
-            lds_add_u32(&misc[MISC_STAT_READS + slot0], 1u);
+            lds_add_u32(&misc[MISC_STAT_READS + slot0], rc ? 0u : 1u);  // a merged read is ONE read
             lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)l);
             if (mode == ST_BOTH && out_ok) {
                 lds_add_u32(&misc[MISC_STAT_READS + slot0 + 1], 1u);
@@ -394,17 +399,21 @@ FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int mode, int n_valid, in
             const u32 q = (qd >> (k * 8)) & 0x7Fu;
             key[k] = (u32)slot * 128u + q;
             if (val[k]) {
-                const int pos = j - f;
+                const int wpos = j - f;                      // index inside the window
+                const int pos = rc ? rc_base - wpos : wpos;  // cycle
                 const u32 isn = (nbits >> (4 + k)) & 1u;
-                const u32 cls = isn ? (u32)CLS_N : ((codes >> (8 + 2 * k)) & 3u);
+                const u32 cls = isn ? (u32)CLS_N : (((codes >> (8 + 2 * k)) & 3u) ^ (rc ? 1u : 0u));
                 // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
                 const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
                                 ((u64)(q - 33u) << CYC_QSUM_SHIFT);
                 lds_add_u64(&cyc_all[((size_t)slot * N_CLS + cls) * Cp + (pos & 3) * C4 + (pos >> 2)], inc);
                 // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
                 // pos-4..pos all exist in the window and none of them is N
-                if (pos >= 4 && ((nbits >> k) & 0x1Fu) == 0u)
-                    lds_add_u32(&kmer_all[slot * KMER_BINS + ((codes >> (2 * k)) & 0x3FFu)], 1u);  // earliest base low
+                if (wpos >= 4 && ((nbits >> k) & 0x1Fu) == 0u) {
+                    u32 km = (codes >> (2 * k)) & 0x3FFu;  // earliest base in the low bits
+                    if (rc) km = (reverse_groups(km) >> 22) ^ 0x155u;  // the same five bases on the merged strand
+                    lds_add_u32(&kmer_all[slot * KMER_BINS + km], 1u);
+                }
             }
         }
         // ---- mBaseQualHistogram[qual]++ (:207).  Qualities cluster on a few values, so the
@@ -922,7 +931,7 @@ FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) 
     const DevParams& p = a.p;
     if (!p.paired) return;
     const bool thread0 = (a.batch_flags & 1u) != 0;  // FASTP_GPU_BATCH_STAT_ISIZE
-    if (!(p.need_overlap || thread0)) return;        // peprocessor.cpp:438
+    if (!(p.need_overlap || thread0 || p.merge)) return;  // peprocessor.cpp:438
     // tasks [0, 4P): forward, [4P, 8P): reverse -> the direction is uniform per wavefront when 4P % 64 == 0
     const int half = 4 * L.P;
     for (int t = tid; t < 2 * half; t += nthreads) {
@@ -1087,7 +1096,7 @@ FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) 
         const bool valid = t < total;
         const int R = valid ? (t >> 3) : 0, seg = t & 7;
         const int f = lds_i(lds, L.front)[R];
-        const int e = valid ? f + lds_i(lds, L.len)[R] : f;
+        const int e = valid ? f + lds_i(lds, p.merge ? L.mlen : L.len)[R] : f;
         const u32* qrow = lds + L.qual + R * L.QW;
         const u32* srow = lds + L.seq + R * L.SW;
         u32 ma = 0, mb = 0;
@@ -1138,13 +1147,10 @@ FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) 
 }
 
 // Filter::passFilter (filter.cpp:15-57) on the read [f, f+rlen) from its metrics; alive == non-NULL
-FQ_DEV int pass_filter(const KernelArgs& a, u32* lds, int R, bool alive) {
+FQ_DEV int filter_code(const KernelArgs& a, u32* lds, int rlen, int tot, int low, int nb, int diff) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
-    const int rlen = lds_i(lds, L.len)[R];
-    if (!alive || rlen == 0) return 16;  // FAIL_LENGTH (:16-18)
-    const u32 ma = lds[L.met + 2 * R], mb = lds[L.met + 2 * R + 1];
-    const int tot = (int)(ma & 0xFFFFu), low = (int)(ma >> 16), nb = (int)(mb & 0xFFFFu), diff = (int)(mb >> 16);
+    if (rlen == 0) return 16;  // FAIL_LENGTH (:16-18)
     if (p.qual_filter) {  // :35-42
         const u16* lowq = (const u16*)(lds + L.lut_lowq);
         if (low > (int)lowq[rlen]) return 20;                                   // FAIL_QUALITY
@@ -1161,6 +1167,12 @@ FQ_DEV int pass_filter(const KernelArgs& a, u32* lds, int R, bool alive) {
         if (diff < (int)cmin[rlen]) return 24;  // FAIL_COMPLEXITY
     }
     return 0;
+}
+FQ_DEV int pass_filter(const KernelArgs& a, u32* lds, int R, bool alive) {
+    const LdsLayout& L = a.L;
+    if (!alive) return 16;  // r == NULL (:16-18)
+    const u32 ma = lds[L.met + 2 * R], mb = lds[L.met + 2 * R + 1];
+    return filter_code(a, lds, lds_i(lds, L.len)[R], (int)(ma & 0xFFFFu), (int)(ma >> 16), (int)(mb & 0xFFFFu), (int)(mb >> 16));
 }
 
 FQ_DEV void store_base(const KernelArgs& a, u32* lds, int R, int j, u32 sym, u32 qchar) {
@@ -1185,15 +1197,24 @@ FQ_DEV void write_read_result(const KernelArgs& a, u32* lds, int m, int R, int g
     const u32 flags = (u32)lds_i(lds, L.flags)[R] & 0xFFu;
     const u32 apos = (u32)lds_i(lds, L.apos)[R] & 0xFFFFu;
     const u32 alen = (u32)lds_i(lds, L.alen)[R] & 0xFFFFu;
+    // reserved: merge mode, overlapped pair: bases of this mate in the merged read (the name tag merged_L1_L2)
+    const int pr1 = m ? R - L.P : R;
+    const u32 rsv = (lds_i(lds, L.flags)[pr1] & RS_MERGE_OV) ? ((u32)lds_i(lds, L.mlen)[R] & 0xFFFFu) : 0u;
     u32* out = a.res[m] + (size_t)gp * 3;
     out[0] = front | (len << 16);
     out[1] = code | (flags << 8) | (apos << 16);
-    out[2] = alen;
+    out[2] = alen | (rsv << 16);
 }
 
 // ASCII & 7 of a symbol (A=1 T=4 C=3 G=7 N=6): FilterResult::addCorrection filterresult.cpp:99-103
 FQ_DEV u32 sym_bin(u32 s) { return (0x67341u >> (s * 4)) & 0xFu; }
 FQ_DEV u32 sym_ascii(u32 s) { return (u32)("ATCGN"[s]); }
+
+// fastp_gpu_pair_result: i16 ov_offset, u16 ov_len | u16 ov_diff, u16 flags
+FQ_DEV void write_pair_result(const KernelArgs& a, int gp, int ovl, int off, int ol, int diff, bool isize_done) {
+    a.pair[2 * (size_t)gp] = ((u32)off & 0xFFFFu) | (((u32)ol & 0xFFFFu) << 16);
+    a.pair[2 * (size_t)gp + 1] = ((u32)diff & 0xFFFFu) | ((u32)((ovl ? 1 : 0) | (isize_done ? 4 : 0)) << 16);
+}
 
 // ---------------------------------------------------------------------------
 // Phase E (paired): lane = one pair.  peprocessor.cpp:443-573.
@@ -1326,9 +1347,43 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             if (p.max_len2 > 0 && p.max_len2 < lenv[R2]) lenv[R2] = p.max_len2;
         }
         if (dimer) flags[R1] |= RS_DIMER;
-        // fastp_gpu_pair_result: i16 ov_offset, u16 ov_len | u16 ov_diff, u16 flags
-        a.pair[2 * (size_t)gp] = ((u32)ov_off & 0xFFFFu) | (((u32)ov_len & 0xFFFFu) << 16);
-        a.pair[2 * (size_t)gp + 1] = ((u32)ov_diff & 0xFFFFu) | ((u32)((ovl ? 1 : 0) | (isize_done ? 4 : 0)) << 16);
+        if (isize_done) flags[R1] |= RS_ISIZE;
+        lds_i(lds, L.mlen)[R1] = lenv[R1];
+        lds_i(lds, L.mlen)[R2] = lenv[R2];
+        if (p.merge && both) {
+            // merge mode analyzes the post-trim reads again (peprocessor.cpp:523); phase_merge writes the record
+            lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;
+        } else {
+            write_pair_result(a, gp, ovl, ov_off, ov_len, ov_diff, isize_done);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Merge mode (peprocessor.cpp:518-527, OverlapAnalysis::merge overlapanalysis.cpp:148-179):
+// lane = one pair, after the second overlap analysis.  merged = r1[0, len1) + rc(r2)[ol, ol+len2),
+// i.e. the first len1 bases of r1' followed by the first len2 bases of r2' reversed and
+// complemented; mlen[] records the two part lengths for the metrics / filter / stats steps.
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_merge(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    for (int pr = tid; pr < L.P; pr += nthreads) {
+        const int gp = tile_first + pr;
+        if (gp >= a.n) continue;
+        const int R1 = pr, R2 = L.P + pr;
+        int* flags = lds_i(lds, L.flags);
+        if ((flags[R1] | flags[R2]) & RS_NULL) continue;
+        const int l1 = lds_i(lds, L.len)[R1], l2 = lds_i(lds, L.len)[R2];
+        int ovl, off, ol, diff;
+        decode_overlap((u32)lds_i(lds, L.ov_off)[pr], l1, l2, ovl, off, ol, diff);
+        if (ovl) {
+            const int len1 = ol + imax(0, off);
+            const int len2 = off > 0 ? l2 - ol : 0;
+            lds_i(lds, L.mlen)[R1] = imin(len1, l1);          // substr(0, len1) clamps
+            lds_i(lds, L.mlen)[R2] = imax(0, imin(len2, l2 - ol));
+            flags[R1] |= RS_MERGE_OV;
+        }
+        write_pair_result(a, gp, ovl, off, ol, diff, (flags[R1] & RS_ISIZE) != 0);
     }
 }
 
@@ -1360,20 +1415,69 @@ FQ_DEV void phase_filter_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         int* flags = lds_i(lds, L.flags);
         const bool a1 = !(flags[R1] & RS_NULL), a2 = !(flags[R2] & RS_NULL);
         const bool dimer = (flags[R1] & RS_DIMER) != 0;
-        int code1 = pass_filter(a, lds, R1, a1);  // :565-566
-        int code2 = pass_filter(a, lds, R2, a2);
-        if (dimer) { code1 = 28; code2 = 28; }     // :568-571
-        const int worst = imax(code1, code2);
-        lds_add_u32(&misc[MISC_FILTER + worst], 2u);  // addFilterResult(max, 2) :573
+        const bool dedup_out = p.dedup && (flags[R1] & RS_DUP);
+        int code1, code2;
+        if (p.merge && a1 && a2 && (flags[R1] & RS_MERGE_OV)) {
+            // passFilter(merged) (:526-535): the metrics of the two parts add up; the adjacent-difference
+            // count gets the junction r1[len1-1] | comp(r2'[len2-1])
+            const int m1 = lds_i(lds, L.mlen)[R1], m2 = lds_i(lds, L.mlen)[R2];
+            const u32 ma1 = lds[L.met + 2 * R1], mb1 = lds[L.met + 2 * R1 + 1];
+            const u32 ma2 = lds[L.met + 2 * R2], mb2 = lds[L.met + 2 * R2 + 1];
+            const int f1 = lds_i(lds, L.front)[R1], f2 = lds_i(lds, L.front)[R2];
+            const u32* s1 = lds_seq(L, lds, R1);
+            const u32* s2 = lds_seq(L, lds, R2);
+            const u8* q1 = (const u8*)lds_qual(L, lds, R1);
+            const u8* q2 = (const u8*)lds_qual(L, lds, R2);
+            int diff = (int)(mb1 >> 16) + (int)(mb2 >> 16);
+            if (m1 > 0 && m2 > 0 && sym_at(s1, q1, f1 + m1 - 1) != sym_complement(sym_at(s2, q2, f2 + m2 - 1))) diff++;
+            const int result = filter_code(a, lds, m1 + m2, (int)(ma1 & 0xFFFFu) + (int)(ma2 & 0xFFFFu),
+                                           (int)(ma1 >> 16) + (int)(ma2 >> 16), (int)(mb1 & 0xFFFFu) + (int)(mb2 & 0xFFFFu), diff);
+            lds_add_u32(&misc[MISC_FILTER + result], 2u);
+            code1 = code2 = result;
+            if (result == 0) {
+                flags[R1] |= RS_MERGED | RS_STAT_POST;                               // postStats1->statRead(merged)
+                flags[R2] |= RS_MERGED | RS_STAT_POST | RS_POST_TO1 | RS_POST_RC;
+                lds_add_u32(&misc[MISC_MERGED], 1u);                                 // mergedCount++
+                // 5-mers that straddle the junction (merged positions len1 .. len1+3); the stats pass
+                // counts the ones inside either part
+                u32* kmer1 = lds + L.acc_kmer + 1 * KMER_BINS;  // slot POST1
+                for (int qj = 0; qj < 4 && qj < m2; qj++) {
+                    const int pe = m1 + qj;
+                    if (pe < 4) continue;
+                    u32 km = 0;
+                    bool ok = true;
+                    for (int t = 0; t < 5; t++) {
+                        const int x = pe - 4 + t;
+                        const u32 sy = x < m1 ? sym_at(s1, q1, f1 + x) : sym_complement(sym_at(s2, q2, f2 + (m1 + m2 - 1 - x)));
+                        if (sy == 4u) ok = false;
+                        km |= (sy & 3u) << (2 * t);
+                    }
+                    if (ok && m1 > pe - 4) lds_add_u32(&kmer1[km], 1u);
+                }
+            }
+        } else if (p.merge && a1 && a2 && p.merge_include_unmerged) {  // :536-559
+            code1 = pass_filter(a, lds, R1, a1);
+            code2 = pass_filter(a, lds, R2, a2);
+            if (dimer) { code1 = 28; code2 = 28; }
+            lds_add_u32(&misc[MISC_FILTER + code1], 1u);
+            lds_add_u32(&misc[MISC_FILTER + code2], 1u);
+            if (code1 == 0 && !dedup_out) flags[R1] |= RS_STAT_POST;
+            if (code2 == 0 && !dedup_out) flags[R2] |= RS_STAT_POST | RS_POST_TO1;
+        } else {
+            code1 = pass_filter(a, lds, R1, a1);  // :565-566
+            code2 = pass_filter(a, lds, R2, a2);
+            if (dimer) { code1 = 28; code2 = 28; }     // :568-571
+            const int worst = imax(code1, code2);
+            lds_add_u32(&misc[MISC_FILTER + worst], 2u);  // addFilterResult(max, 2) :573
+            // post-filtering Stats only see pairs that are written to out1/out2 (:577-591), and not
+            // in merge mode (:588); with dedup the duplicate decision was taken beforehand
+            if (!p.merge && !dedup_out && a1 && a2 && code1 == 0 && code2 == 0) {
+                flags[R1] |= RS_STAT_POST;
+                flags[R2] |= RS_STAT_POST;
+            }
+        }
         lds_i(lds, L.code)[R1] = code1;
         lds_i(lds, L.code)[R2] = code2;
-        // post-filtering Stats only see pairs that are written to out1/out2 (:577-591);
-        // with dedup the duplicate decision is taken by the dup kernels beforehand
-        const bool dedup_out = p.dedup && (flags[R1] & RS_DUP);
-        if (!dedup_out && a1 && a2 && code1 == 0 && code2 == 0) {
-            flags[R1] |= RS_STAT_POST;
-            flags[R2] |= RS_STAT_POST;
-        }
         write_dup_pos(a, lds, pr, gp);
         write_read_result(a, lds, 0, R1, gp);
         write_read_result(a, lds, 1, R2, gp);
@@ -1447,7 +1551,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     // one-time per workgroup: clear the accumulators, stage LUTs / primes / adapters
     for (int i = tid; i < L.acc_end - L.acc_cyc; i += nt) lds[L.acc_cyc + i] = 0;
     {
-        const int lw = (a.p.max_len + 2) / 2;  // u16 tables of max_len+1 entries, in dwords
+        const int lw = (a.p.cycles + 2) / 2;  // u16 tables of cycles+1 entries, in dwords
         const u32* g0 = (const u32*)a.lut.ov_limit;
         const u32* g1 = (const u32*)a.lut.lowq_limit;
         const u32* g2 = (const u32*)a.lut.cplx_min;
@@ -1483,7 +1587,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         block_sync();
         if (prefetch && tile + grid_blocks() < a.tiles) tile_fetch(a, (tile + grid_blocks()) * L.P, tid, nt, regs);
         FQ_STAMP(0)
-        if (!a.p.stats_one_pass) phase_stats(a, lds, ST_PRE, n_valid, tid, nt);  // Stats::statRead on the original reads
+        if (!a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
         phase_masks(a, lds, n_valid, tid, nt);
         phase_hash(a, lds, tid, nt);
         block_sync();
@@ -1506,6 +1610,12 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
         else phase_decide_se(a, lds, tile_first, tid, nt);
         block_sync();
+        if (a.p.merge) {
+            phase_overlap(a, lds, tid, nt);
+            block_sync();
+            phase_merge(a, lds, tile_first, tid, nt);
+            block_sync();
+        }
         FQ_STAMP(5)
         phase_metrics(a, lds, tid, nt);
         block_sync();
@@ -1514,7 +1624,9 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         block_sync();
         FQ_STAMP(6)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
-        phase_stats(a, lds, a.p.stats_one_pass ? ST_BOTH : ST_POST, n_valid, tid, nt);
+        if (a.p.stats_one_pass) phase_stats<ST_BOTH, false>(a, lds, n_valid, tid, nt);
+        else if (a.p.merge) phase_stats<ST_POST, true>(a, lds, n_valid, tid, nt);
+        else phase_stats<ST_POST, false>(a, lds, n_valid, tid, nt);
         block_sync();
         FQ_STAMP(7)
 #undef FQ_STAMP

@@ -82,7 +82,6 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
         return FASTP_GPU_E_TOO_LONG;
     }
     // options outside the device path's scope for now: fail loudly, never fall back
-    if (in.merge) { err = "merge mode is not on the device path yet"; return FASTP_GPU_E_UNSUPPORTED; }
     if (in.insert_size_max < 0 || in.insert_size_max > 4096) { err = "insert_size_max out of range"; return FASTP_GPU_E_INVALID; }
     if (in.overlap_diff_limit < 0 || in.overlap_require < 0) { err = "negative overlap knobs"; return FASTP_GPU_E_INVALID; }
     p.paired = in.paired ? 1 : 0;
@@ -118,6 +117,8 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.has_a2 = p.alen2 > 0;
     p.correction = (in.correction != 0) && p.paired;  // options.cpp:401-404
     p.allow_gap = (in.allow_gap_overlap_trimming != 0) && p.paired;
+    p.merge = (in.merge != 0) && p.paired;
+    p.merge_include_unmerged = in.merge_include_unmerged != 0;
     p.overlap_require = in.overlap_require;
     p.overlap_diff_limit = in.overlap_diff_limit;
     p.qual_filter = in.qual_filter != 0;
@@ -135,15 +136,15 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.umi_len2 = (p.paired && in.umi_len2 > 0) ? in.umi_len2 : 0;
     p.umi_skip = in.umi_skip > 0 ? in.umi_skip : 0;
     p.need_overlap = p.paired && (p.adapter_enabled || p.correction);
-    p.stats_one_pass = !p.correction && !p.cut_front && !p.trim_front1 && !p.trim_front2 && !p.umi_len1 && !p.umi_len2;
+    p.stats_one_pass = !p.correction && !p.merge && !p.cut_front && !p.trim_front1 && !p.trim_front2 && !p.umi_len1 && !p.umi_len2;
 
     // ---- LUTs: the reference's floating point thresholds, evaluated on the host ----
-    const int n = in.max_len + 2;
+    const int n = p.cycles + 2;  // a merged read can be as long as both mates (cycles = 2*max_len in merge mode)
     luts.ov_limit.assign(n, 0);
     luts.lowq_limit.assign(n, 0);
     luts.cplx_min.assign(n, 0);
     const double diffPercentLimit = in.overlap_diff_percent_limit / 100.0;  // peprocessor.cpp:440
-    for (int ol = 0; ol <= in.max_len; ol++) {
+    for (int ol = 0; ol <= p.cycles; ol++) {
         int lim = (int)(ol * diffPercentLimit);  // overlapanalysis.cpp:51,76
         if (in.overlap_diff_limit < lim) lim = in.overlap_diff_limit;
         luts.ov_limit[ol] = (int16_t)lim;
@@ -240,6 +241,7 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.apos = take(out.NR);
         out.alen = take(out.NR);
         out.code = take(out.NR);
+        out.mlen = take(out.NR);
         out.met = take(out.NR * 2);
         out.ov_off = take(P);
         out.ov_len = take(P);
@@ -247,7 +249,7 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.ov_flags = take(P);
         out.adapt = take(2 * ADAPT_WORDS);
         out.wscratch = take(waves * 2 * out.SW);
-        const int lw = (p.max_len + 2) / 2;
+        const int lw = (p.cycles + 2) / 2;
         out.lut_ov = take(lw);
         out.lut_lowq = take(lw);
         out.lut_cplx = take(lw);

@@ -45,7 +45,11 @@ enum {
     RS_MERGED = 0x20, RS_POLYX = 0x40,
     RS_HAS_N = 0x100,   // the read contains at least one 'N'
     RS_STAT_POST = 0x200, // goes into the post-filtering Stats
-    RS_DIMER = 0x400     // adapter dimer evidence (peprocessor.cpp:480-484), carried from the trim to the filter step
+    RS_DIMER = 0x400,    // adapter dimer evidence (peprocessor.cpp:480-484), carried from the trim to the filter step
+    RS_ISIZE = 0x800,    // statInsertSize ran for this pair (kept on R1 until the pair record is written)
+    RS_MERGE_OV = 0x1000,// merge mode: the post-trim overlap analysis found an overlap (kept on R1)
+    RS_POST_TO1 = 0x2000,// merge mode: this read's post-filtering stats go to slot POST1 (peprocessor.cpp:529,548,554)
+    RS_POST_RC = 0x4000  // merge mode: this mate is the reverse-complemented tail of the merged read
 };
 
 struct DevParams {
@@ -61,6 +65,7 @@ struct DevParams {
     int has_a1, has_a2, alen1, alen2;
     u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
     int correction;
+    int merge, merge_include_unmerged;  // MergeOptions (peprocessor.cpp:518-561)
     int allow_gap;          // AdapterOptions::allowGapOverlapTrimming (overlapanalysis.cpp:91-139)
     int overlap_require, overlap_diff_limit;
     int ov_limit_max;       // largest per-length mismatch limit (the LUT is non-decreasing): prefilter bound
@@ -97,6 +102,7 @@ struct LdsLayout {
                     // update consecutive LDS words
     int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
+    int mlen;       // [NR] merge mode: bases of this mate that enter the merged read (else = len)
     int met;        // [NR][2] countQualityMetrics / countAdjacentDiffs of the final window (phase_metrics)
     int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed no-gap scan key (OV_KEY_*),
                                                           // ov_len the key of the one-gap pass (allow_gap)

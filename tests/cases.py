@@ -111,3 +111,12 @@ OVERLAP_STRESS = [
     dict(allow_gap_overlap_trimming=1, correction=1, overlap_require=10, overlap_diff_limit=10, overlap_diff_percent_limit=40),
     dict(allow_gap_overlap_trimming=1, overlap_require=5, overlap_diff_limit=20, overlap_diff_percent_limit=50),
 ]
+
+# merge mode stress: params overrides run on synth.overlap_pairs (paired)
+MERGE_STRESS = [
+    dict(merge=1, correction=1),
+    dict(merge=1, correction=1, merge_include_unmerged=1, dedup=1, dup_accuracy_level=3),
+    dict(merge=1, correction=1, complexity_filter=1, complexity_threshold=0.70, n_base_limit=1, length_required=100),
+    dict(merge=1, correction=1, adapter_enabled=0, cut_front=1, cut_tail=1, overlap_require=10, max_len1=120, max_len2=90),
+    dict(merge=1, correction=1, merge_include_unmerged=1, poly_x=1, trim_front1=3, trim_front2=7, avg_qual_req=30),
+]

@@ -16,7 +16,7 @@ from fastp_amd import abi, engine
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [k for k in cases.CASES if k not in ("pe_merge", "pe_merge_unmerged")]
+SUPPORTED = list(cases.CASES)
 
 
 def _args(d, paired):
@@ -84,6 +84,16 @@ def test_gpu_overlap_stress(k):
         setattr(p, key, v)
     d = synth.overlap_pairs(20000, L=150, seed=300 + k)
     _compare(f"overlap_stress{k}", p, d, True)
+
+
+@pytest.mark.parametrize("k", range(len(cases.MERGE_STRESS)))
+def test_gpu_merge_stress(k):
+    """merge mode: second overlap analysis, OverlapAnalysis::merge, passFilter(merged), stats of the merged read"""
+    p = abi.default_params(True, 150)
+    for key, v in cases.MERGE_STRESS[k].items():
+        setattr(p, key, v)
+    d = synth.overlap_pairs(20000, L=150, seed=700 + k, err=0.01, n_rate=0.01)
+    _compare(f"merge_stress{k}", p, d, True)
 
 
 @pytest.mark.parametrize("L", [36, 75, 100, 250, 400])

@@ -13,7 +13,7 @@ import refjson
 import synth
 from fastp_amd import abi, engine, hostloop
 
-SUPPORTED = [k for k in cases.CASES if k not in ("pe_merge", "pe_merge_unmerged")]
+SUPPORTED = list(cases.CASES)
 
 
 def _both(params, d, paired):
@@ -69,13 +69,16 @@ def test_sim_other_read_lengths_and_tile_shapes(monkeypatch):
         assert np.array_equal(co, cg)
 
 
-def test_sim_unsupported_options_fail_loudly():
-    for field in ("merge",):
+def test_sim_out_of_scope_parameters_fail_loudly():
+    """the engine never falls back: parameters outside the device path are errors"""
+    for field, value, code in (("max_len", 513, abi.E_TOO_LONG), ("insert_size_max", 5000, abi.E_INVALID),
+                               ("abi_version", 99, abi.E_INVALID), ("unqualified_percent_limit", -1, abi.E_INVALID),
+                               ("adapter_seq_r1", b"ACGTN", abi.E_INVALID), ("adapter_seq_r1", b"A" * 65, abi.E_UNSUPPORTED)):
         p = abi.default_params(True, 150)
-        setattr(p, field, 1)
+        setattr(p, field, value)
         with pytest.raises(engine.EngineError) as e:
             engines.sim_engine(p)
-        assert e.value.code == abi.E_UNSUPPORTED
+        assert e.value.code == code, field
 
 
 @pytest.mark.parametrize("k", range(len(cases.TRIM_STRESS)))
@@ -108,3 +111,19 @@ def test_sim_overlap_stress(k):
         assert len(bad) == 0, f"overlap stress {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
     assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"]))
     assert np.array_equal(co, cg)
+
+
+@pytest.mark.parametrize("k", range(len(cases.MERGE_STRESS)))
+def test_sim_merge_stress(k):
+    """merge mode: second overlap analysis, OverlapAnalysis::merge, passFilter(merged), stats of the merged read"""
+    p = abi.default_params(True, 150)
+    for key, v in cases.MERGE_STRESS[k].items():
+        setattr(p, key, v)
+    d = synth.overlap_pairs(600, L=150, seed=700 + k, err=0.01, n_rate=0.01)
+    ro, rg, co, cg = _both(p, d, True)
+    for i in range(3):
+        bad = np.nonzero(ro[i] != rg[i])[0]
+        assert len(bad) == 0, f"merge stress {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
+    assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"]))
+    bad = np.nonzero(co != cg)[0]
+    assert len(bad) == 0, f"merge stress {k}: counters differ at {bad[:8]}: oracle {co[bad[:8]]} device {cg[bad[:8]]}"
