@@ -18,13 +18,13 @@ using namespace fq;
 // kernels
 // ---------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(KernelArgs a) {
-    extern __shared__ u32 fq_lds[];
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     // read the argument block through the kernarg segment pointer (scalar loads where a field is
     // used) instead of holding all ~150 dwords in SGPRs for the whole persistent loop
     fused_body(*kernel_args(&a), fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) {
-    extern __shared__ u32 fq_lds[];
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     hash_body(*kernel_args(&a), fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
@@ -267,8 +267,15 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.magic_sw = magic_for((u32)ctx->L.SW);
     a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
     a.magic_swg = magic_for((u32)ctx->dp.sw_g);
-    a.prefetch = ctx->L.NR * ctx->dp.qw_g <= PF_Q * ctx->cfg.threads && ctx->L.NR * ctx->dp.sw_g <= PF_S * ctx->cfg.threads &&
-                 ctx->L.NR <= ctx->cfg.threads && !env_int("FASTP_GPU_NO_PREFETCH", 0);
+    {   // vector (16-byte) tile copies + register prefetch need aligned rows and a tile that fits the registers
+        const size_t qchunks = (size_t)ctx->L.NR * ctx->dp.qw_g / 4, schunks = (size_t)ctx->L.NR * ctx->dp.sw_g / 4;
+        bool ok = (ctx->L.P % 2 == 0) && (first % 2 == 0) && qchunks <= (size_t)PF_Q * ctx->cfg.threads &&
+                  schunks <= (size_t)PF_S * ctx->cfg.threads && ctx->L.NR <= ctx->cfg.threads &&
+                  !env_int("FASTP_GPU_NO_PREFETCH", 0);
+        const void* ptrs[4] = {b->seq1, b->qual1, ctx->dp.paired ? b->seq2 : b->seq1, ctx->dp.paired ? b->qual2 : b->qual1};
+        for (const void* q : ptrs) ok = ok && (((uintptr_t)q & 15u) == 0);
+        a.prefetch = ok ? 1 : 0;
+    }
     a.n = n;
     a.first = first;
     a.batch_flags = b->flags;

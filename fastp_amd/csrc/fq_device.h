@@ -72,172 +72,139 @@ FQ_DEV u32 sym_complement(u32 s) { return s == 4u ? 4u : (s ^ 1u); }
 // ---------------------------------------------------------------------------
 // Phase A: load one tile
 // ---------------------------------------------------------------------------
+// per-read state of a fresh tile
+FQ_DEV void tile_init_read(const LdsLayout& L, u32* lds, int R, int len) {
+    lds_i(lds, L.rlen0)[R] = len;
+    lds_i(lds, L.front)[R] = 0;
+    lds_i(lds, L.len)[R] = len;
+    lds_i(lds, L.flags)[R] = 0;
+    lds_i(lds, L.ft)[R] = 0;
+    lds_i(lds, L.apos)[R] = 0;
+    lds_i(lds, L.alen)[R] = 0;
+    lds_i(lds, L.code)[R] = 0;
+    if (R < L.P) {
+        lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
+        lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
+    }
+}
+// N masks from bit 7 of quality dword d (flat index inside the tile) - the rare path
+FQ_DEV void tile_note_n(const KernelArgs& a, u32* lds, int d, u32 v) {
+    const LdsLayout& L = a.L;
+    const u32 nb = (v >> 7) & 0x01010101u;
+    if (!nb) return;
+    const int R = (int)fastdiv((u32)d, a.magic_qwg);
+    const int col = d - R * L.QW;
+    const u32 t = (nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u;
+    lds_or_u32(&lds[L.nmk + R * L.SW + (col >> 2)], t << ((col & 3) * 8));
+    lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+}
+
+// Phase A, scalar form (any alignment / tile shape).  The LDS rows have the batch's own strides,
+// so each mate's part of a tile is one contiguous run of dwords in both places.
 FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
-    const u32 magic_sw = a.magic_sw, magic_qwg = a.magic_qwg;
     const LdsLayout& L = a.L;
     const int mates = a.p.paired ? 2 : 1;
     const int P = L.P;
-    const int swg = a.p.sw_g, qwg = a.p.qw_g;
-    // per-read state + lengths
+    const int rows = imax(0, imin(P, a.n - tile_first));  // rows that exist
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= P ? 1 : 0;
         const int gp = tile_first + (R - m * P);
-        const int len = gp < a.n ? (int)a.len[m][gp] : 0;
-        lds_i(lds, L.rlen0)[R] = len;
-        lds_i(lds, L.front)[R] = 0;
-        lds_i(lds, L.len)[R] = len;
-        lds_i(lds, L.flags)[R] = 0;
-        lds_i(lds, L.ft)[R] = 0;
-        lds_i(lds, L.apos)[R] = 0;
-        lds_i(lds, L.alen)[R] = 0;
-        lds_i(lds, L.code)[R] = 0;
-        if (R < P) {
-            lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
-            lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
-            lds_i(lds, L.ov_diff)[R] = 0;
-            lds_i(lds, L.ov_flags)[R] = 0;
-        }
+        tile_init_read(L, lds, R, gp < a.n ? (int)a.len[m][gp] : 0);
     }
     for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
-    // packed bases (+ zero the N masks and the pad words)
+    for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
     for (int m = 0; m < mates; m++) {
-        const u32* g = a.seq[m];
-        const int total = P * L.SW;
-        for (int idx = tid; idx < total; idx += nthreads) {
-            const int row = (int)fastdiv((u32)idx, magic_sw);  // idx / SW
-            const int col = idx - row * L.SW;
-            const int gp = tile_first + row;
-            u32 v = 0;
-            if (col < swg && gp < a.n) v = g[(size_t)gp * swg + col];
-            lds[L.seq + (m * P + row) * L.SW + col] = v;
-            lds[L.nmk + (m * P + row) * L.SW + col] = 0;
-        }
+        const u32* g = a.seq[m] + (size_t)tile_first * L.SW;
+        for (int i = tid; i < P * L.SW; i += nthreads) lds[L.seq + m * P * L.SW + i] = i < rows * L.SW ? g[i] : 0u;
     }
     block_sync();
-    // quality bytes; derive the N masks from bit 7
     for (int m = 0; m < mates; m++) {
-        const u32* g = a.qual[m];
-        const int total = P * qwg;
-        for (int idx = tid; idx < total; idx += nthreads) {
-            const int row = (int)fastdiv((u32)idx, magic_qwg);  // idx / qwg
-            const int col = idx - row * qwg;
-            const int gp = tile_first + row;
-            const int R = m * P + row;
-            u32 v = 0;
-            if (gp < a.n) v = g[(size_t)gp * qwg + col];
-            lds[L.qual + R * L.QW + col] = v;
-            const u32 nb = (v >> 7) & 0x01010101u;
-            if (nb) {
-                const u32 t = (nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u;
-                lds_or_u32(&lds[L.nmk + R * L.SW + (col >> 2)], t << ((col & 3) * 8));
-                lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
-            }
+        const u32* g = a.qual[m] + (size_t)tile_first * L.QW;
+        for (int i = tid; i < P * L.QW; i += nthreads) {
+            const u32 v = i < rows * L.QW ? g[i] : 0u;
+            lds[L.qual + m * P * L.QW + i] = v;
+            tile_note_n(a, lds, m * P * L.QW + i, v);
         }
-        // pad column(s) of the LDS quality rows
-        for (int R = tid; R < P; R += nthreads)
-            for (int c = qwg; c < L.QW; c++) lds[L.qual + (m * P + R) * L.QW + c] = 0;
     }
 }
 
 // ---------------------------------------------------------------------------
-// Phase A with software prefetch: the global loads of tile i+1 are issued right after tile i
-// has been staged and stay in flight (registers) while tile i is processed, so the HBM latency
-// of a tile is hidden behind the compute of the previous one.
+// Phase A, vector form with software prefetch: 16-byte chunks; the global loads of tile i+1 are
+// issued right after tile i has been staged and stay in flight (registers) while tile i is
+// processed, so the HBM latency of a tile is hidden behind the compute of the previous one.
 // ---------------------------------------------------------------------------
 struct TileRegs {
-    u32 q[PF_Q];
-    u32 s[PF_S];
+    u32x4 q[PF_Q];
+    u32x4 s[PF_S];
     u32 len;
 };
 
+FQ_DEV u32x4 tile_chunk(const u32* const g[2], int tile_first, int P, int row_dw, int n, int ci) {
+    // chunk ci of the tile's [mate][P rows][row_dw dwords] block; rows past the batch end read as zero
+    const int per_mate = P * row_dw / 4;
+    const int m = ci >= per_mate ? 1 : 0;
+    const int cm = ci - m * per_mate;
+    const int rows = imax(0, imin(P, n - tile_first));
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (4 * cm < rows * row_dw) {
+        const u32* src = g[m] + (size_t)tile_first * row_dw + 4 * cm;
+        if (4 * cm + 4 <= rows * row_dw) {
+            v = *(const u32x4*)src;
+        } else {  // the chunk straddles the last existing row (odd row count)
+            v.x = src[0];
+            if (4 * cm + 1 < rows * row_dw) v.y = src[1];
+            if (4 * cm + 2 < rows * row_dw) v.z = src[2];
+        }
+    }
+    return v;
+}
+
 FQ_DEV void tile_fetch(const KernelArgs& a, int tile_first, int tid, int nthreads, TileRegs& r) {
     const LdsLayout& L = a.L;
-    const int P = L.P, qwg = a.p.qw_g, swg = a.p.sw_g;
-    const int nq = L.NR * qwg, ns = L.NR * swg;
+    const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
 #pragma unroll
     for (int i = 0; i < PF_Q; i++) {
-        const int idx = tid + i * nthreads;
-        u32 v = 0;
-        if (idx < nq) {
-            const int R = (int)fastdiv((u32)idx, a.magic_qwg);
-            const int m = R >= P ? 1 : 0;
-            const int gp = tile_first + R - m * P;
-            if (gp < a.n) v = a.qual[m][(size_t)gp * qwg + (idx - R * qwg)];
-        }
-        r.q[i] = v;
+        const int ci = tid + i * nthreads;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        r.q[i] = ci < nq ? tile_chunk(a.qual, tile_first, L.P, L.QW, a.n, ci) : z;
     }
 #pragma unroll
     for (int i = 0; i < PF_S; i++) {
-        const int idx = tid + i * nthreads;
-        u32 v = 0;
-        if (idx < ns) {
-            const int R = (int)fastdiv((u32)idx, a.magic_swg);
-            const int m = R >= P ? 1 : 0;
-            const int gp = tile_first + R - m * P;
-            if (gp < a.n) v = a.seq[m][(size_t)gp * swg + (idx - R * swg)];
-        }
-        r.s[i] = v;
+        const int ci = tid + i * nthreads;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        r.s[i] = ci < ns ? tile_chunk(a.seq, tile_first, L.P, L.SW, a.n, ci) : z;
     }
     r.len = 0;
     if (tid < L.NR) {
-        const int m = tid >= P ? 1 : 0;
-        const int gp = tile_first + tid - m * P;
+        const int m = tid >= L.P ? 1 : 0;
+        const int gp = tile_first + tid - m * L.P;
         if (gp < a.n) r.len = a.len[m][gp];
     }
 }
 
 FQ_DEV void tile_commit(const KernelArgs& a, u32* lds, int tid, int nthreads, const TileRegs& r) {
     const LdsLayout& L = a.L;
-    const int P = L.P, qwg = a.p.qw_g, swg = a.p.sw_g;
-    const int nq = L.NR * qwg, ns = L.NR * swg;
-    if (tid < L.NR) {
-        const int R = tid, len = (int)r.len;
-        lds_i(lds, L.rlen0)[R] = len;
-        lds_i(lds, L.front)[R] = 0;
-        lds_i(lds, L.len)[R] = len;
-        lds_i(lds, L.flags)[R] = 0;
-        lds_i(lds, L.ft)[R] = 0;
-        lds_i(lds, L.apos)[R] = 0;
-        lds_i(lds, L.alen)[R] = 0;
-        lds_i(lds, L.code)[R] = 0;
-        if (R < P) {
-            lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
-            lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
-        }
-    }
+    const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
+    if (tid < L.NR) tile_init_read(L, lds, tid, (int)r.len);
     for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
-    for (int idx = tid; idx < L.NR * L.SW; idx += nthreads) {  // N masks and the pad words of the base rows
-        lds[L.nmk + idx] = 0;
-        const int R = (int)fastdiv((u32)idx, a.magic_sw);
-        if (idx - R * L.SW >= swg) lds[L.seq + idx] = 0;
-    }
-    for (int idx = tid; idx < L.NR * (L.QW - qwg); idx += nthreads) {  // pad column(s) of the quality rows
-        const int per = L.QW - qwg;
-        const int R = idx / per;
-        lds[L.qual + R * L.QW + qwg + (idx - R * per)] = 0;
-    }
+    for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
 #pragma unroll
     for (int i = 0; i < PF_S; i++) {
-        const int idx = tid + i * nthreads;
-        if (idx < ns) {
-            const int R = (int)fastdiv((u32)idx, a.magic_swg);
-            lds[L.seq + R * L.SW + (idx - R * swg)] = r.s[i];
-        }
+        const int ci = tid + i * nthreads;
+        if (ci < ns) *(u32x4*)(lds + L.seq + 4 * ci) = r.s[i];
     }
     block_sync();
 #pragma unroll
     for (int i = 0; i < PF_Q; i++) {
-        const int idx = tid + i * nthreads;
-        if (idx < nq) {
-            const int R = (int)fastdiv((u32)idx, a.magic_qwg);
-            const int col = idx - R * qwg;
-            const u32 v = r.q[i];
-            lds[L.qual + R * L.QW + col] = v;
-            const u32 nb = (v >> 7) & 0x01010101u;
-            if (nb) {  // N masks from bit 7 of the quality bytes
-                const u32 t = (nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u;
-                lds_or_u32(&lds[L.nmk + R * L.SW + (col >> 2)], t << ((col & 3) * 8));
-                lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+        const int ci = tid + i * nthreads;
+        if (ci < nq) {
+            const u32x4 v = r.q[i];
+            *(u32x4*)(lds + L.qual + 4 * ci) = v;
+            if ((v.x | v.y | v.z | v.w) & 0x80808080u) {  // some base of this chunk is N
+                tile_note_n(a, lds, 4 * ci, v.x);
+                tile_note_n(a, lds, 4 * ci + 1, v.y);
+                tile_note_n(a, lds, 4 * ci + 2, v.z);
+                tile_note_n(a, lds, 4 * ci + 3, v.w);
             }
         }
     }

@@ -205,8 +205,8 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         memset(&out, 0, sizeof(out));
         out.P = P;
         out.NR = mates * P;
-        out.SW = round_odd(p.sw_g + 1);  // +1: window reads touch word w+1
-        out.QW = round_odd(p.qw_g);
+        out.SW = p.sw_g;
+        out.QW = p.qw_g;
         out.C = p.cycles;
         out.Cp = (p.cycles + 3) / 4 * 4;
         int o = 0;
@@ -230,8 +230,11 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
             out.wm_stride = k * out.wm_words;
             out.wm = take(out.NR * out.wm_stride);
         }
+        o = (o + 3) & ~3;  // 16-byte aligned rows (vector tile copies)
         out.seq = take(out.NR * out.SW);
+        o = (o + 3) & ~3;
         out.nmk = take(out.NR * out.SW);
+        o = (o + 3) & ~3;
         out.qual = take(out.NR * out.QW);
         out.rlen0 = take(out.NR);
         out.front = take(out.NR);

@@ -10,6 +10,7 @@ typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
+struct alignas(16) u32x4 { u32 x, y, z, w; };
 
 // ---- 2-bit base code (also the order of fastp's k-mer code, stats.cpp:294-311,
 //      so complement(code) == code ^ 1 and the 5-mer index needs no remapping
@@ -31,7 +32,7 @@ enum { OV_KEY_DIFF_BITS = 16, OV_KEY_OFF_BITS = 10 };
 static const u32 OV_KEY_NONE = 0xFFFFFFFFu;
 
 // per-lane registers that hold the NEXT tile's input while the current tile is processed
-enum { PF_Q = 12, PF_S = 4 };
+enum { PF_Q = 3, PF_S = 1 };   // in 16-byte chunks
 
 enum { QH_COPIES = 8 };        // replicated quality histograms (bank spreading)
 enum { KMER_BINS = 1024 };
@@ -95,7 +96,8 @@ struct DevLuts {
 struct LdsLayout {
     int P;          // pairs (PE) or reads (SE) per tile
     int NR;         // rows per tile: 2P (PE) or P (SE)
-    int SW, QW;     // LDS row strides in dwords (odd -> conflict-free row-per-lane access)
+    int SW, QW;     // LDS row strides in dwords = the global row strides: a tile in LDS is a flat copy of
+                    // the batch rows (bases past a read's length are masked by every consumer)
     int C;          // cycles
     int Cp;         // C rounded up to a multiple of 4: per-cycle accumulators are stored phase-major,
                     // entry (pos & 3) * (Cp/4) + (pos >> 2), so lanes that own consecutive quality dwords
@@ -149,7 +151,8 @@ struct KernelArgs {
     LdsLayout L;
     u32 magic_sw, magic_qwg;   // ceil(2^32 / L.SW), ceil(2^32 / p.qw_g) for exact small divisions
     u32 magic_swg;             // ceil(2^32 / p.sw_g)
-    int prefetch;              // a tile's input fits the per-lane prefetch registers (TileRegs)
+    int prefetch;              // a tile's input fits the per-lane prefetch registers (TileRegs) and the
+                               // batch buffers are 16-byte aligned (vector loads)
     // batch (device pointers)
     int n;
     int first;          // index of this launch's first read/pair inside the submitted batch

@@ -12,7 +12,7 @@
 #include "hip/hip_runtime.h"
 
 // the dynamic LDS of the block being emulated (`extern __shared__ u32 fq_lds[]` in the kernel)
-uint32_t fq_lds[(160 * 1024) / 4 + 64];
+alignas(16) uint32_t fq_lds[(160 * 1024) / 4 + 64];
 
 namespace sim {
 
