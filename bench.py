@@ -189,7 +189,9 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")   # written from the rocprofv3 --pmc passes
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                if tj.get("pairs_per_launch") in (None, int(per_launch_pairs)):
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

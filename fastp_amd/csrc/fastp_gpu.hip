@@ -376,8 +376,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
     r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
     r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
-    const int items = 4 * ctx->L.C + 4 * KMER_BINS + 4 * 128 + MISC_ISIZE + ctx->dp.isize_max + 1;
-    hipLaunchKernelGGL(fq_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, st, r);
+    const int items = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128 * QH_COPIES + MISC_ISIZE + ctx->dp.isize_max + 1;
+    const int rgroups = (grid + REDUCE_GROUP - 1) / REDUCE_GROUP;
+    hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
     HIP_TRY(ctx, hipGetLastError());
 
     if (ctx->dp.dup_enabled && !ctx->dp.dedup) {

@@ -1646,88 +1646,86 @@ struct ReduceArgs {
         st_cycle, cycles;
 };
 
-// one-pass Stats mode: slot PRE1 (0) / PRE2 (2) = dropped + kept, where kept sits in slot + 1
-FQ_DEV bool fold_kept(const ReduceArgs& r, int slot) { return r.one_pass && (slot & 1) == 0; }
+// Work item = (slab element, group of REDUCE_GROUP workgroup slabs): consecutive lanes read
+// consecutive slab dwords (coalesced), sum them over the group's slabs and add the partial
+// sums to the int64 counters with device atomics.
+// One-pass Stats mode: the POST slots hold "kept", the PRE slots "dropped": a kept element is
+// added to its own (POST) Stats and to the PRE Stats of the same mate.
+enum { REDUCE_GROUP = 16 };
 
 FQ_DEV void reduce_body(const ReduceArgs& r) {
     const LdsLayout& L = r.L;
-    const int C = L.C;
-    const int n_cyc = 4 * C, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128, n_misc = MISC_ISIZE + r.isize_max + 1;
+    const int C = L.C, Cp = L.Cp, C4 = L.Cp >> 2;
+    const int n_cyc = 4 * N_CLS * Cp, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128 * QH_COPIES;
+    const int n_misc = MISC_ISIZE + r.isize_max + 1;
     const int total = n_cyc + n_kmer + n_qh + n_misc;
-    const int gid = block_id() * block_threads() + thread_id();
-    const int gstride = grid_blocks() * block_threads();
-    for (int item = gid; item < total; item += gstride) {
-        if (item < n_cyc) {
-            const int slot = item / C, c = item - slot * C;
-            int64_t* st = r.ctr + r.o_stats[slot] + r.st_cycle;
-            const int64_t CC = r.cycles;
-            int64_t tb = 0, tq = 0;
-            const int cs = (c & 3) * (L.Cp >> 2) + (c >> 2);  // phase-major position (LdsLayout::Cp)
-            for (int cls = 0; cls < N_CLS; cls++) {
-                int64_t cnt = 0, q20 = 0, q30 = 0, qs = 0;
-                // one-pass mode: the PRE slots also take what the POST (kept) slots hold
-                for (int part = 0; part < (fold_kept(r, slot) ? 2 : 1); part++) {
-                    const int off = 2 * (((slot + part) * N_CLS + cls) * L.Cp + cs);
-                    for (int b = 0; b < r.nblocks; b++) {
-                        const u32* s = r.slabs + (size_t)b * r.slab_dwords + off;
-                        const u64 v = (u64)s[0] | ((u64)s[1] << 32);
-                        cnt += (int64_t)(v & 0x3FFFu);
-                        q20 += (int64_t)((v >> CYC_Q20_SHIFT) & 0x3FFFu);
-                        q30 += (int64_t)((v >> CYC_Q30_SHIFT) & 0x3FFFu);
-                        qs += (int64_t)(v >> CYC_QSUM_SHIFT);
-                    }
-                }
-                const int bin = (int)sym_bin((u32)cls);  // 'A'&7=1 'T'&7=4 'C'&7=3 'G'&7=7 'N'&7=6
-                st[(0 * 8 + bin) * CC + c] += q30;   // mCycleQ30Bases  (stats.cpp:54-63 layout)
-                st[(1 * 8 + bin) * CC + c] += q20;   // mCycleQ20Bases
-                st[(2 * 8 + bin) * CC + c] += cnt;   // mCycleBaseContents
-                st[(3 * 8 + bin) * CC + c] += qs;    // mCycleBaseQual
-                tb += cnt;
-                tq += qs;
-            }
-            st[32 * CC + c] += tb;  // mCycleTotalBase
-            st[33 * CC + c] += tq;  // mCycleTotalQual
-        } else if (item < n_cyc + n_kmer) {
-            const int k = item - n_cyc;
-            const int slot = k / KMER_BINS, km = k - slot * KMER_BINS;
-            int64_t sum = 0;
-            for (int part = 0; part < (fold_kept(r, slot) ? 2 : 1); part++) {
-                const int off = (L.acc_kmer - L.acc_cyc) + k + part * KMER_BINS;
-                for (int b = 0; b < r.nblocks; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off];
-            }
-            // LDS index has the earliest base in the low bits; fastp's has it in the high bits
-            const u32 fk = ((km & 3u) << 8) | (((km >> 2) & 3u) << 6) | (((km >> 4) & 3u) << 4) |
-                           (((km >> 6) & 3u) << 2) | ((km >> 8) & 3u);
-            r.ctr[r.o_stats[slot] + r.st_kmer + fk] += sum;
-        } else if (item < n_cyc + n_kmer + n_qh) {
-            const int k = item - n_cyc - n_kmer;
-            const int slot = k / 128, q = k - slot * 128;
-            int64_t sum = 0;
-            for (int part = 0; part < (fold_kept(r, slot) ? 2 : 1); part++) {
-                const int off = (L.acc_qh - L.acc_cyc) + (k + part * 128) * QH_COPIES;
-                for (int b = 0; b < r.nblocks; b++)
-                    for (int cpy = 0; cpy < QH_COPIES; cpy++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off + cpy];
-            }
-            r.ctr[r.o_stats[slot] + r.st_qual_hist + q] += sum;
-        } else {
-            const int k = item - n_cyc - n_kmer - n_qh;
-            int64_t sum = 0;
-            const int off = (L.acc_misc - L.acc_cyc) + k;
-            for (int b = 0; b < r.nblocks; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + off];
-            int64_t dst;
-            if (k < MISC_ADAPTER_READS) dst = r.o_filter + k;
-            else if (k == MISC_ADAPTER_READS) dst = r.o_adapter_reads;
-            else if (k == MISC_ADAPTER_BASES) dst = r.o_adapter_bases;
-            else if (k < MISC_POLYX_BASES) dst = r.o_polyx_reads + (k - MISC_POLYX_READS);
-            else if (k < MISC_CORRECTION) dst = r.o_polyx_bases + (k - MISC_POLYX_BASES);
-            else if (k < MISC_CORRECTED_READS) dst = r.o_correction + (k - MISC_CORRECTION);
-            else if (k == MISC_CORRECTED_READS) dst = r.o_corrected_reads;
-            else if (k == MISC_MERGED) dst = r.o_merged;
-            else if (k < MISC_STAT_LENSUM) dst = r.o_stats[k - MISC_STAT_READS] + r.st_reads;
-            else if (k < MISC_ISIZE) dst = r.o_stats[k - MISC_STAT_LENSUM] + r.st_length_sum;
-            else dst = r.o_isize + (k - MISC_ISIZE);
-            r.ctr[dst] += sum;
+    const int chunks = (total + block_threads() - 1) / block_threads();  // workgroups per slab group
+    const int g = block_id() / chunks;
+    const int item = (block_id() - g * chunks) * block_threads() + thread_id();
+    if (item >= total) return;
+    const int b0 = g * REDUCE_GROUP, b1 = imin(r.nblocks, b0 + REDUCE_GROUP);
+    if (b0 >= b1) return;
+    const int64_t CC = r.cycles;
+    if (item < n_cyc) {
+        const int slot = item / (N_CLS * Cp);
+        const int rem = item - slot * N_CLS * Cp;
+        const int cls = rem / Cp, cs = rem - cls * Cp;
+        const int c = (cs % C4) * 4 + cs / C4;  // phase-major position -> cycle (LdsLayout::Cp)
+        if (c >= C) return;
+        int64_t cnt = 0, q20 = 0, q30 = 0, qs = 0;
+        for (int b = b0; b < b1; b++) {
+            const u32* s = r.slabs + (size_t)b * r.slab_dwords + 2 * item;
+            const u64 v = (u64)s[0] | ((u64)s[1] << 32);
+            cnt += (int64_t)(v & 0x3FFFu);
+            q20 += (int64_t)((v >> CYC_Q20_SHIFT) & 0x3FFFu);
+            q30 += (int64_t)((v >> CYC_Q30_SHIFT) & 0x3FFFu);
+            qs += (int64_t)(v >> CYC_QSUM_SHIFT);
         }
+        if (!(cnt | qs)) return;
+        const int bin = (int)sym_bin((u32)cls);  // 'A'&7=1 'T'&7=4 'C'&7=3 'G'&7=7 'N'&7=6
+        for (int tgt = slot; tgt >= 0; tgt -= 1) {
+            int64_t* st = r.ctr + r.o_stats[tgt] + r.st_cycle;  // Stats::mCycleBuffer layout (stats.cpp:54-63)
+            if (q30) g_atomic_add_i64(&st[(0 * 8 + bin) * CC + c], q30);  // mCycleQ30Bases
+            if (q20) g_atomic_add_i64(&st[(1 * 8 + bin) * CC + c], q20);  // mCycleQ20Bases
+            g_atomic_add_i64(&st[(2 * 8 + bin) * CC + c], cnt);           // mCycleBaseContents
+            g_atomic_add_i64(&st[(3 * 8 + bin) * CC + c], qs);            // mCycleBaseQual
+            g_atomic_add_i64(&st[32 * CC + c], cnt);                      // mCycleTotalBase
+            g_atomic_add_i64(&st[33 * CC + c], qs);                       // mCycleTotalQual
+            if (!(r.one_pass && (tgt & 1))) break;  // kept -> also the PRE Stats of the mate
+        }
+        return;
+    }
+    int64_t sum = 0;
+    for (int b = b0; b < b1; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + (L.acc_kmer - L.acc_cyc) + (item - n_cyc)];
+    if (!sum) return;
+    if (item < n_cyc + n_kmer) {
+        const int k = item - n_cyc;
+        const int slot = k / KMER_BINS, km = k - slot * KMER_BINS;
+        // LDS index has the earliest base in the low bits; fastp's has it in the high bits
+        const u32 fk = ((km & 3u) << 8) | (((km >> 2) & 3u) << 6) | (((km >> 4) & 3u) << 4) | (((km >> 6) & 3u) << 2) |
+                       ((km >> 8) & 3u);
+        g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_kmer + fk], sum);
+        if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_kmer + fk], sum);
+    } else if (item < n_cyc + n_kmer + n_qh) {
+        const int k = (item - n_cyc - n_kmer) / QH_COPIES;
+        const int slot = k / 128, q = k - slot * 128;
+        g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_qual_hist + q], sum);
+        if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_qual_hist + q], sum);
+    } else {
+        const int k = item - n_cyc - n_kmer - n_qh;
+        int64_t dst;
+        if (k < MISC_ADAPTER_READS) dst = r.o_filter + k;
+        else if (k == MISC_ADAPTER_READS) dst = r.o_adapter_reads;
+        else if (k == MISC_ADAPTER_BASES) dst = r.o_adapter_bases;
+        else if (k < MISC_POLYX_BASES) dst = r.o_polyx_reads + (k - MISC_POLYX_READS);
+        else if (k < MISC_CORRECTION) dst = r.o_polyx_bases + (k - MISC_POLYX_BASES);
+        else if (k < MISC_CORRECTED_READS) dst = r.o_correction + (k - MISC_CORRECTION);
+        else if (k == MISC_CORRECTED_READS) dst = r.o_corrected_reads;
+        else if (k == MISC_MERGED) dst = r.o_merged;
+        else if (k < MISC_STAT_LENSUM) dst = r.o_stats[k - MISC_STAT_READS] + r.st_reads;
+        else if (k < MISC_ISIZE) dst = r.o_stats[k - MISC_STAT_LENSUM] + r.st_length_sum;
+        else dst = r.o_isize + (k - MISC_ISIZE);
+        g_atomic_add_i64(&r.ctr[dst], sum);
     }
 }
 

@@ -68,4 +68,18 @@ for extra in ("bench.log", "phase.log"):
         if lines:
             out[extra] = lines[-1]
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+# what bench.py reports as roofline.traffic (HBM bytes per launch of the dominant kernel, PMC-derived)
+fk = out["kernels"].get("fq_fused_kernel", {})
+if "hbm_bytes_per_launch" in fk:
+    ppl = None
+    try:
+        ppl = json.loads(out.get("bench.log", "{}"))["roofline"]["pairs_per_launch"]
+    except Exception:
+        pass
+    json.dump({"tag": tag, "kernel": "fq_fused_kernel", "pairs_per_launch": ppl,
+               "hbm_read_bytes_per_launch": fk["hbm_read_bytes_per_launch"],
+               "hbm_write_bytes_per_launch": fk["hbm_write_bytes_per_launch"],
+               "hbm_bytes_per_launch": fk["hbm_bytes_per_launch"],
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE x2 (gfx950 halves wide reads)"},
+              open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
