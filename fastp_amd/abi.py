@@ -5,7 +5,7 @@ Only declarations live here - no computation.  Used by the Python host mirror
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_READ_LEN = 512
 MAX_ADAPTER_LEN = 64
 
@@ -59,7 +59,8 @@ class Params(C.Structure):
         ("dup_enabled", C.c_int32), ("dedup", C.c_int32), ("dup_accuracy_level", C.c_int32),
         ("insert_size_max", C.c_int32),
         ("umi_len1", C.c_int32), ("umi_len2", C.c_int32), ("umi_skip", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("n_adapter_fasta", C.c_int32), ("adapter_fasta", C.POINTER(C.c_char_p)),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -117,12 +118,32 @@ class Correction(C.Structure):
     _fields_ = [("read", C.c_uint32), ("pos", C.c_uint16), ("base", C.c_uint8), ("qual", C.c_uint8)]
 
 
+class AdapterEvent(C.Structure):
+    _fields_ = [("read", C.c_uint32), ("pos", C.c_int16), ("len", C.c_uint16), ("adapter", C.c_uint16),
+                ("reserved", C.c_uint16)]
+
+
 class Results(C.Structure):
     _fields_ = [
         ("r1", C.c_void_p), ("r2", C.c_void_p), ("pair", C.c_void_p),
         ("corrections", C.c_void_p), ("corrections_capacity", C.c_int32),
         ("n_corrections", C.c_void_p),
+        ("adapter_events", C.c_void_p), ("adapter_events_capacity", C.c_int32),
+        ("n_adapter_events", C.c_void_p),
     ]
+
+
+def set_adapter_fasta(params, seqs):
+    """attach the --adapter_fasta list (bytes objects) to a Params; the array is kept alive on it"""
+    arr = (C.c_char_p * max(1, len(seqs)))(*seqs)
+    params._fasta_keepalive = (arr, list(seqs))
+    params.adapter_fasta = C.cast(arr, C.POINTER(C.c_char_p))
+    params.n_adapter_fasta = len(seqs)
+    return params
+
+
+def adapter_fasta_list(params):
+    return [params.adapter_fasta[i] for i in range(params.n_adapter_fasta)]
 
 
 class CounterLayout(C.Structure):
@@ -146,6 +167,9 @@ READ_RESULT_DTYPE = _np.dtype([("front", "<u2"), ("len", "<u2"), ("code", "u1"),
 PAIR_RESULT_DTYPE = _np.dtype([("ov_offset", "<i2"), ("ov_len", "<u2"), ("ov_diff", "<u2"),
                                ("flags", "<u2")])
 CORRECTION_DTYPE = _np.dtype([("read", "<u4"), ("pos", "<u2"), ("base", "u1"), ("qual", "u1")])
+ADAPTER_EVENT_DTYPE = _np.dtype([("read", "<u4"), ("pos", "<i2"), ("len", "<u2"), ("adapter", "<u2"),
+                                 ("reserved", "<u2")])
+assert ADAPTER_EVENT_DTYPE.itemsize == C.sizeof(AdapterEvent) == 12
 assert READ_RESULT_DTYPE.itemsize == C.sizeof(ReadResult) == 12
 assert PAIR_RESULT_DTYPE.itemsize == C.sizeof(PairResult) == 8
 assert CORRECTION_DTYPE.itemsize == C.sizeof(Correction) == 8

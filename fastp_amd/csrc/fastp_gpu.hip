@@ -55,6 +55,10 @@ struct fastp_gpu_ctx {
     u16* d_cplx = nullptr;
     u32* d_primes = nullptr;
     u64* d_posum = nullptr;
+    u32* d_fasta_words = nullptr;
+    int* d_fasta_len = nullptr;
+    std::vector<std::string> fasta_strings;
+    std::vector<const char*> fasta_ptrs;
     int64_t* d_ctr = nullptr;
     u32* d_slabs = nullptr;
     int slab_dwords = 0;
@@ -118,7 +122,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_events(ctx);
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_ctr, ctx->d_slabs,
+    void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -139,6 +143,11 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (params->adapter_seq_r2) ctx->adapter2 = params->adapter_seq_r2;
     ctx->params.adapter_seq_r1 = ctx->adapter1.c_str();
     ctx->params.adapter_seq_r2 = ctx->adapter2.c_str();
+    if (params->n_adapter_fasta > 0 && params->adapter_fasta) {  // own copies: the caller's strings may go away
+        for (int i = 0; i < params->n_adapter_fasta; i++) ctx->fasta_strings.push_back(params->adapter_fasta[i] ? params->adapter_fasta[i] : "");
+        for (auto& f : ctx->fasta_strings) ctx->fasta_ptrs.push_back(f.c_str());
+        ctx->params.adapter_fasta = ctx->fasta_ptrs.data();
+    }
     ctx->device = device;
     std::string err;
     int rc = build_dev_params(ctx->params, ctx->dp, ctx->luts, err);
@@ -199,6 +208,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_RC(upload((void**)&ctx->d_cplx, ctx->luts.cplx_min.data(), ctx->luts.cplx_min.size() * 2));
     CREATE_RC(upload((void**)&ctx->d_primes, ctx->luts.dup_primes.data(), ctx->luts.dup_primes.size() * 4));
     CREATE_RC(upload((void**)&ctx->d_posum, ctx->luts.dup_posum.data(), ctx->luts.dup_posum.size() * 8));
+    CREATE_RC(upload((void**)&ctx->d_fasta_words, ctx->luts.fasta_words.data(), ctx->luts.fasta_words.size() * 4));
+    CREATE_RC(upload((void**)&ctx->d_fasta_len, ctx->luts.fasta_len.data(), ctx->luts.fasta_len.size() * 4));
     {
         std::vector<int64_t> zero((size_t)ctx->cl.total, 0);
         zero[0] = FASTP_GPU_ABI_VERSION;
@@ -263,6 +274,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.lut.cplx_min = ctx->d_cplx;
     a.lut.dup_primes = ctx->d_primes;
     a.lut.dup_posum = ctx->d_posum;
+    a.lut.fasta_words = ctx->d_fasta_words;
+    a.lut.fasta_len = ctx->d_fasta_len;
     a.L = ctx->L;
     a.magic_sw = magic_for((u32)ctx->L.SW);
     a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
@@ -294,6 +307,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.corrections = (ctx->dp.correction && res->corrections && res->n_corrections) ? (u32*)res->corrections : nullptr;
     a.corr_capacity = res->corrections_capacity;
     a.n_corrections = res->n_corrections;
+    a.adapter_events = (ctx->dp.n_fasta && res->adapter_events && res->n_adapter_events) ? (u32*)res->adapter_events : nullptr;
+    a.adapter_events_capacity = res->adapter_events_capacity;
+    a.n_adapter_events = res->n_adapter_events;
     if (ctx->dp.dup_enabled) {
         int rc = ensure(ctx, (void**)&ctx->d_dup_pos, &ctx->dup_pos_cap, (size_t)n * ctx->dp.dup_bufnum * 8);
         if (rc) return rc;
@@ -400,6 +416,9 @@ extern "C" int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
+    if (ctx->dp.n_fasta && b->n > 0 && (!res->adapter_events || !res->n_adapter_events))
+        return fail(ctx, FASTP_GPU_E_INVALID, "adapter_fasta needs an adapter event list in the results");
+    if (res->n_adapter_events) HIP_TRY(ctx, hipMemsetAsync(res->n_adapter_events, 0, sizeof(int32_t), st));
     // split into equally sized launches (each a multiple of the tile size)
     const int launches = (b->n + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
     int per = launches ? (b->n + launches - 1) / launches : 0;
@@ -433,7 +452,9 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     const size_t pair_out = ctx->dp.paired ? al(n * sizeof(fastp_gpu_pair_result)) : 0;
     const size_t corr_out = (res->corrections && res->corrections_capacity > 0)
                                 ? al((size_t)res->corrections_capacity * sizeof(fastp_gpu_correction)) : 0;
-    const size_t total = mates * (per_mate_in + per_mate_out) + pair_out + corr_out + 256;
+    const size_t ev_out = (res->adapter_events && res->adapter_events_capacity > 0)
+                              ? al((size_t)res->adapter_events_capacity * sizeof(fastp_gpu_adapter_event)) : 0;
+    const size_t total = mates * (per_mate_in + per_mate_out) + pair_out + corr_out + ev_out + 512;
     int rc = ensure(ctx, &ctx->d_stage, &ctx->stage_cap, total);
     if (rc) return rc;
     char* base = (char*)ctx->d_stage;
@@ -465,6 +486,9 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     if (corr_out) dr.corrections = (fastp_gpu_correction*)take((size_t)res->corrections_capacity * sizeof(fastp_gpu_correction));
     else { dr.corrections = nullptr; dr.corrections_capacity = 0; }
     dr.n_corrections = (int32_t*)take(sizeof(int32_t));
+    if (ev_out) dr.adapter_events = (fastp_gpu_adapter_event*)take((size_t)res->adapter_events_capacity * sizeof(fastp_gpu_adapter_event));
+    else { dr.adapter_events = nullptr; dr.adapter_events_capacity = 0; }
+    dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
     rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(res->r1, dr.r1, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
@@ -474,7 +498,16 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     }
     int32_t ncorr = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&ncorr, dr.n_corrections, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t nev = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nev, dr.n_adapter_events, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (res->n_adapter_events) *res->n_adapter_events = nev < res->adapter_events_capacity ? nev : res->adapter_events_capacity;
+    if (ev_out && nev > 0) {
+        const int32_t take_n = nev < res->adapter_events_capacity ? nev : res->adapter_events_capacity;
+        HIP_TRY(ctx, hipMemcpy(res->adapter_events, dr.adapter_events, (size_t)take_n * sizeof(fastp_gpu_adapter_event),
+                               hipMemcpyDeviceToHost));
+        if (nev > res->adapter_events_capacity) return fail(ctx, FASTP_GPU_E_OVERFLOW, "adapter event list capacity exceeded");
+    }
     if (res->n_corrections) *res->n_corrections = ncorr;
     if (corr_out && ncorr > 0) {
         if (ncorr > res->corrections_capacity) {

@@ -981,8 +981,7 @@ FQ_DEV u64 one_gap_match_mask(const u32* srow, const u8* q, int f, int rlen, con
 }
 
 FQ_DEV bool trim_by_sequence(const u32* srow, const u32* nrow, const u8* q, bool hasN, int f, int rlen,
-                             const u32* aw, int alen, int& out_pos) {
-    const int matchReq = 4;
+                             const u32* aw, int alen, int matchReq, int& out_pos) {
     if (alen < matchReq) return false;
     int start = 0;
     if (alen >= 16) start = -4;
@@ -1029,7 +1028,7 @@ FQ_DEV bool apply_trim_by_sequence(const KernelArgs& a, u32* lds, int R, const u
     const bool hasN = (lds_i(lds, L.flags)[R] & RS_HAS_N) != 0;
     int pos = 0;
     if (!trim_by_sequence(lds_seq(L, lds, R), lds_nmk(L, lds, R), (const u8*)lds_qual(L, lds, R), hasN, f, rlen, aw,
-                          alen, pos))
+                          alen, 4, pos))
         return false;
     int adapter_len;
     if (pos < 0) {  // adaptertrimmer.cpp:138-145
@@ -1043,6 +1042,43 @@ FQ_DEV bool apply_trim_by_sequence(const KernelArgs& a, u32* lds, int R, const u
     lds_i(lds, L.apos)[R] = pos;
     lds_i(lds, L.alen)[R] = adapter_len;
     return true;
+}
+
+// AdapterTrimmer::trimByMultiSequences (adaptertrimmer.cpp:48-62) on read R: every --adapter_fasta
+// sequence in turn on the (shrinking) read; each cut is reported as a fastp_gpu_adapter_event
+FQ_DEV bool apply_fasta_trims(const KernelArgs& a, u32* lds, int R, u32 read_index, u32* misc) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    const int f = lds_i(lds, L.front)[R];
+    bool trimmed = false;
+    for (int i = 0; i < p.n_fasta; i++) {
+        const int rlen = lds_i(lds, L.len)[R];
+        const int alen = a.lut.fasta_len[i];
+        const bool hasN = (lds_i(lds, L.flags)[R] & RS_HAS_N) != 0;
+        int pos = 0;
+        if (!trim_by_sequence(lds_seq(L, lds, R), lds_nmk(L, lds, R), (const u8*)lds_qual(L, lds, R), hasN, f, rlen,
+                              a.lut.fasta_words + (size_t)i * ADAPT_WORDS, alen, p.fasta_match_req, pos))
+            continue;
+        trimmed = true;
+        int adapter_len;
+        if (pos < 0) {  // adaptertrimmer.cpp:138-145
+            adapter_len = alen + pos;
+            lds_i(lds, L.len)[R] = 0;
+        } else {
+            adapter_len = rlen - pos;
+            lds_i(lds, L.len)[R] = pos;
+        }
+        if (adapter_len > 0) lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)adapter_len);  // filterresult.cpp:127
+        if (a.adapter_events) {
+            const int slot = g_atomic_add_i32(a.n_adapter_events, 1);
+            if (slot < a.adapter_events_capacity) {
+                a.adapter_events[3 * slot] = read_index;
+                a.adapter_events[3 * slot + 1] = ((u32)pos & 0xFFFFu) | (((u32)adapter_len & 0xFFFFu) << 16);
+                a.adapter_events[3 * slot + 2] = (u32)i;
+            }
+        }
+    }
+    return trimmed;
 }
 
 // ---------------------------------------------------------------------------
@@ -1289,6 +1325,10 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
                     if (p.has_a1) t1 = apply_trim_by_sequence(a, lds, R1, lds + L.adapt, p.alen1, misc);
                     if (p.has_a2) t2 = apply_trim_by_sequence(a, lds, R2, lds + L.adapt + ADAPT_WORDS, p.alen2, misc);
                 }
+                if (p.n_fasta) {  // :467-470
+                    t1 |= apply_fasta_trims(a, lds, R1, 2u * (u32)(a.first + gp), misc);
+                    t2 |= apply_fasta_trims(a, lds, R2, 2u * (u32)(a.first + gp) + 1u, misc);
+                }
                 if (t1) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R1] |= RS_ADAPTER; }  // :472-475
                 if (t2) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R2] |= RS_ADAPTER; }
                 if ((t1 || t2) && lenv[R1] <= p.dimer_max_len && lenv[R2] <= p.dimer_max_len) dimer = true;  // :480-484
@@ -1468,6 +1508,7 @@ FQ_DEV void phase_decide_se(const KernelArgs& a, u32* lds, int tile_first, int t
         if (alive && p.adapter_enabled) {  // :244-261
             bool trimmed = false;
             if (p.has_a1) trimmed = apply_trim_by_sequence(a, lds, R, lds + L.adapt, p.alen1, misc);
+            if (p.n_fasta) trimmed |= apply_fasta_trims(a, lds, R, (u32)(a.first + gp), misc);  // seprocessor.cpp:249-251
             if (trimmed) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R] |= RS_ADAPTER; }
             if (trimmed && lenv[R] <= p.dimer_max_len) dimer = true;
         }

@@ -115,6 +115,20 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     if (rc) return rc;
     p.has_a1 = p.alen1 > 0;
     p.has_a2 = p.alen2 > 0;
+    luts.fasta_words.clear();
+    luts.fasta_len.clear();
+    if (in.n_adapter_fasta < 0 || (in.n_adapter_fasta > 0 && !in.adapter_fasta)) { err = "adapter_fasta list missing"; return FASTP_GPU_E_INVALID; }
+    if (in.n_adapter_fasta > 65535) { err = "more than 65535 adapter_fasta sequences"; return FASTP_GPU_E_UNSUPPORTED; }
+    for (int i = 0; i < in.n_adapter_fasta; i++) {
+        u32 w[MAX_ADAPTER_WORDS];
+        int alen = 0;
+        rc = pack_adapter(in.adapter_fasta[i], w, alen, err);
+        if (rc) return rc;
+        for (int k = 0; k < ADAPT_WORDS; k++) luts.fasta_words.push_back(k < MAX_ADAPTER_WORDS ? w[k] : 0u);
+        luts.fasta_len.push_back(alen);
+    }
+    p.n_fasta = in.n_adapter_fasta;
+    p.fasta_match_req = p.n_fasta > 256 ? 6 : (p.n_fasta > 16 ? 5 : 4);  // adaptertrimmer.cpp:49-53
     p.correction = (in.correction != 0) && p.paired;  // options.cpp:401-404
     p.allow_gap = (in.allow_gap_overlap_trimming != 0) && p.paired;
     p.merge = (in.merge != 0) && p.paired;

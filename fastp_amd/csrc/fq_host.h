@@ -16,6 +16,8 @@ struct HostLuts {
     std::vector<u16> cplx_min;       // [max_len+2]
     std::vector<u32> dup_primes;     // [bufnum*512]
     std::vector<u64> dup_posum;      // [(2*max_len+1)*bufnum]
+    std::vector<u32> fasta_words;    // [n_fasta][ADAPT_WORDS]
+    std::vector<int> fasta_len;      // [n_fasta]
 };
 
 // device geometry the layout is sized for

@@ -64,6 +64,7 @@ struct DevParams {
     int poly_g, poly_g_min, poly_x, poly_x_min;
     int adapter_enabled, dimer_max_len;
     int has_a1, has_a2, alen1, alen2;
+    int n_fasta, fasta_match_req;   // --adapter_fasta list (adaptertrimmer.cpp:48-55)
     u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
     int correction;
     int merge, merge_include_unmerged;  // MergeOptions (peprocessor.cpp:518-561)
@@ -90,6 +91,8 @@ struct DevLuts {
     const u16* cplx_min;    // [max_len+1]  least adjacent-diff count that passes filter.cpp:65
     const u32* dup_primes;  // [bufnum*512]                                      duplicate.cpp:66-84
     const u64* dup_posum;   // [(2*max_len+1)*bufnum]  sum_{p<n} prime[(p*B+i)&mask]*p
+    const u32* fasta_words; // [n_fasta][ADAPT_WORDS] packed --adapter_fasta sequences (zero padded)
+    const int* fasta_len;   // [n_fasta]
 };
 
 // LDS layout, all offsets in dwords from the start of dynamic LDS
@@ -166,6 +169,9 @@ struct KernelArgs {
     u32* corrections;   // fastp_gpu_correction, 2 dwords each
     int corr_capacity;
     int* n_corrections;
+    u32* adapter_events;   // fastp_gpu_adapter_event, 3 dwords each
+    int adapter_events_capacity;
+    int* n_adapter_events;
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
     const u8* dupflag;  // [n] --dedup: the duplicate decision, taken by the dup kernels BEFORE this launch
     u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)

@@ -152,7 +152,16 @@ class GpuEngine:
         res.corrections = corr.ctypes.data
         res.corrections_capacity = corr_capacity
         res.n_corrections = C.addressof(ncorr)
+        nfasta = int(self.params.n_adapter_fasta)
+        ev = np.zeros(max(16, n * 2 * min(nfasta, 8)) if nfasta else 0, dtype=abi.ADAPTER_EVENT_DTYPE)
+        nev = C.c_int32(0)
+        if nfasta:
+            res.adapter_events = ev.ctypes.data
+            res.adapter_events_capacity = len(ev)
+            res.n_adapter_events = C.addressof(nev)
         self._check(self.lib.fastp_gpu_submit_host(self.h, C.byref(b), C.byref(res)))
+        # --adapter_fasta trims of this batch, per read in adapter order (the device emits them unordered)
+        self.last_adapter_events = np.sort(ev[:nev.value].copy(), order=["read", "adapter"])
         return r1, (r2 if paired else None), (pr if paired else None), corr[:ncorr.value].copy()
 
     # -- ASCII rows (what the FASTQ decoder produces) -> results -------------------------------

@@ -182,7 +182,7 @@ class UmiNameEditor:
 
 
 def apply_results(params: abi.Params, b1: FastqBatch, b2: FastqBatch | None, r1, r2, pair, corrections,
-                  outputs: Outputs, amaps: AdapterMaps, umi: UmiNameEditor | None = None):
+                  outputs: Outputs, amaps: AdapterMaps, umi: UmiNameEditor | None = None, adapter_events=None):
     """Turn engine results for one pack into output records + adapter-map updates."""
     paired = b2 is not None
     if umi is not None:  # names are edited before anything is routed (peprocessor.cpp:419-420)
@@ -203,6 +203,11 @@ def apply_results(params: abi.Params, b1: FastqBatch, b2: FastqBatch | None, r1,
             corr_by_read.setdefault(int(c["read"]), []).append((int(c["pos"]), int(c["base"]), int(c["qual"])))
     a1seq = params.adapter_seq_r1 or b""
     a2seq = params.adapter_seq_r2 or b""
+    fasta = abi.adapter_fasta_list(params) if params.n_adapter_fasta else []
+    ev_by_read: dict[int, list] = {}
+    if adapter_events is not None:
+        for e in adapter_events:  # already ordered per read by adapter index
+            ev_by_read.setdefault(int(e["read"]), []).append((int(e["pos"]), int(e["len"]), int(e["adapter"])))
     for i in range(b1.n):
         rr1 = r1[i]
         s1, q1 = _final_read(b1, i, rr1, corr_by_read.get(2 * i if paired else i, ()))
@@ -217,19 +222,27 @@ def apply_results(params: abi.Params, b1: FastqBatch, b2: FastqBatch | None, r1,
             f = int(rr["front"])
             return bytes(s[f + pos:f + pos + alen])
 
+        def replay_fasta(read_key, rr, s, is_r2):  # trimByMultiSequences adaptertrimmer.cpp:48-62
+            f = int(rr["front"])
+            for pos, alen, ai in ev_by_read.get(read_key, ()):
+                amaps.add_single(bytes(fasta[ai][:alen]) if pos < 0 else bytes(s[f + pos:f + pos + alen]), is_r2)
+
         # --- adapter string map, in input order -------------------------------
         if paired:
             ov_trim = (rr1["flags"] & abi.RF_ADAPTER_OV) != 0
             if ov_trim:  # adaptertrimmer.cpp:27-42
                 amaps.add_pair(adapter_string(rr1, s1, a1seq), adapter_string(rr2, s2, a2seq))
-            else:
-                if rr1["flags"] & abi.RF_ADAPTER:
+            else:  # adapter_len == 0: the flag comes from an --adapter_fasta trim only
+                if (rr1["flags"] & abi.RF_ADAPTER) and rr1["adapter_len"]:
                     amaps.add_single(adapter_string(rr1, s1, a1seq), False)
-                if rr2["flags"] & abi.RF_ADAPTER:
+                if (rr2["flags"] & abi.RF_ADAPTER) and rr2["adapter_len"]:
                     amaps.add_single(adapter_string(rr2, s2, a2seq), True)
+            replay_fasta(2 * i, rr1, s1, False)      # peprocessor.cpp:467-470
+            replay_fasta(2 * i + 1, rr2, s2, True)
         else:
-            if rr1["flags"] & abi.RF_ADAPTER:
+            if (rr1["flags"] & abi.RF_ADAPTER) and rr1["adapter_len"]:
                 amaps.add_single(adapter_string(rr1, s1, a1seq), False)
+            replay_fasta(i, rr1, s1, False)          # seprocessor.cpp:249-251
 
         def cut(rr, s, q):
             f, L = int(rr["front"]), int(rr["len"])

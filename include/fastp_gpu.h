@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FASTP_GPU_ABI_VERSION 1
+#define FASTP_GPU_ABI_VERSION 2
 
 /* ---- limits ------------------------------------------------------------ */
 #define FASTP_GPU_MAX_READ_LEN 512    /* padded read length the kernels tile in LDS */
@@ -46,7 +46,7 @@ extern "C" {
 #define FASTP_GPU_E_ALPHABET (-4)    /* base byte outside {A,C,G,T,N} in pack    */
 #define FASTP_GPU_E_TOO_LONG (-5)    /* read longer than params.max_len          */
 #define FASTP_GPU_E_UNSUPPORTED (-6) /* option outside the device path's scope   */
-#define FASTP_GPU_E_OVERFLOW (-7)    /* correction list capacity exceeded        */
+#define FASTP_GPU_E_OVERFLOW (-7)    /* correction / adapter-event list capacity exceeded */
 #define FASTP_GPU_E_NOMEM (-8)
 
 /* ---- filter result codes (src/common.h:43-51) --------------------------- */
@@ -121,7 +121,15 @@ typedef struct fastp_gpu_params {
      * Read::trimFront (read.cpp:69-73). */
     int32_t umi_len1, umi_len2, umi_skip;
 
-    int32_t reserved[8];
+    /* --adapter_fasta (AdapterOptions::seqsInFasta, options.cpp:50-83): the sequences in the
+     * order Options::loadFastaAdapters leaves them (sorted by contig name, >= 6 bp, duplicates
+     * removed).  A..T only, each at most FASTP_GPU_MAX_ADAPTER_LEN long.  Applied to both mates
+     * after the other adapter trimming (AdapterTrimmer::trimByMultiSequences,
+     * adaptertrimmer.cpp:48-62; call sites peprocessor.cpp:467-470, seprocessor.cpp:249-251). */
+    int32_t n_adapter_fasta;
+    const char* const* adapter_fasta;
+
+    int32_t reserved[4];
 } fastp_gpu_params;
 
 /* fills *p with the values an un-flagged `fastp -i R1 [-I R2]` run uses
@@ -201,6 +209,16 @@ typedef struct fastp_gpu_correction {
     uint8_t qual;   /* new quality, ASCII                                     */
 } fastp_gpu_correction; /* 8 bytes */
 
+/* one trim by an --adapter_fasta sequence (a read can be cut by several of them in turn; the
+ * host replays FilterResult::addAdapterTrimmed for each, per read in `adapter` order) */
+typedef struct fastp_gpu_adapter_event {
+    uint32_t read;      /* 2*unit + (0 for R1, 1 for R2) for PE, the read index for SE        */
+    int16_t pos;        /* as fastp_gpu_read_result::adapter_pos                              */
+    uint16_t len;       /* as fastp_gpu_read_result::adapter_len                              */
+    uint16_t adapter;   /* index into params.adapter_fasta                                    */
+    uint16_t reserved;
+} fastp_gpu_adapter_event; /* 12 bytes */
+
 typedef struct fastp_gpu_results {
     fastp_gpu_read_result* r1;      /* n                                       */
     fastp_gpu_read_result* r2;      /* n (PE)                                  */
@@ -208,6 +226,9 @@ typedef struct fastp_gpu_results {
     fastp_gpu_correction* corrections; /* capacity entries, may be NULL        */
     int32_t corrections_capacity;
     int32_t* n_corrections;         /* out: number written                     */
+    fastp_gpu_adapter_event* adapter_events; /* capacity entries; needed with adapter_fasta */
+    int32_t adapter_events_capacity;
+    int32_t* n_adapter_events;      /* out: number written (unordered)         */
 } fastp_gpu_results;
 
 /* ---- counter block -------------------------------------------------------

@@ -596,6 +596,9 @@ struct fastp_oracle {
     char adapter1[FASTP_GPU_MAX_ADAPTER_LEN + 1];
     char adapter2[FASTP_GPU_MAX_ADAPTER_LEN + 1];
     int has_seq_r1, has_seq_r2, alen1, alen2;
+    int n_fasta;          /* AdapterOptions::seqsInFasta (options.h:213) */
+    char** fasta;
+    int* fasta_len;
     fastp_gpu_counter_layout L;
     int64_t* ctr;
     orc_dup* dup;
@@ -619,6 +622,17 @@ fastp_oracle* fastp_oracle_create(const fastp_gpu_params* params) {
     }
     o->p.adapter_seq_r1 = o->adapter1;
     o->p.adapter_seq_r2 = o->adapter2;
+    if (params->n_adapter_fasta > 0 && params->adapter_fasta) {
+        o->n_fasta = params->n_adapter_fasta;
+        o->fasta = (char**)calloc((size_t)o->n_fasta, sizeof(char*));
+        o->fasta_len = (int*)calloc((size_t)o->n_fasta, sizeof(int));
+        for (int i = 0; i < o->n_fasta; i++) {
+            o->fasta_len[i] = (int)strlen(params->adapter_fasta[i]);
+            o->fasta[i] = (char*)malloc((size_t)o->fasta_len[i] + 1);
+            memcpy(o->fasta[i], params->adapter_fasta[i], (size_t)o->fasta_len[i] + 1);
+        }
+    }
+    o->p.adapter_fasta = (const char* const*)o->fasta;
     fastp_oracle_counter_layout(fastp_oracle_cycles_for(params), params->insert_size_max, &o->L);
     o->ctr = (int64_t*)calloc((size_t)o->L.total, sizeof(int64_t));
     o->ctr[0] = FASTP_GPU_ABI_VERSION;
@@ -635,6 +649,9 @@ void fastp_oracle_destroy(fastp_oracle* o) {
     if (!o) return;
     if (o->dup) { free(o->dup->buf); free(o->dup->primes); free(o->dup); }
     free(o->ctr);
+    for (int i = 0; i < o->n_fasta; i++) free(o->fasta[i]);
+    free(o->fasta);
+    free(o->fasta_len);
     free(o);
 }
 
@@ -685,6 +702,52 @@ static int orc_apply_trim_and_cut(fastp_oracle* o, orc_read* r, int front, int t
 }
 
 /* trimBySequence on a mutable read + bookkeeping for the result record */
+static int orc_apply_trim_by_sequence_req(fastp_oracle* o, orc_read* r, const char* adapter, int alen, int matchReq,
+                                          int* out_pos, int* out_len) {
+    int pos = 0;
+    if (!fastp_oracle_trim_by_sequence(r->seq, r->len, adapter, alen, matchReq, &pos)) return 0;
+    int adapter_len;
+    if (pos < 0) { /* adaptertrimmer.cpp:138-145 */
+        adapter_len = alen + pos;
+        r->len = 0;
+    } else {
+        adapter_len = r->len - pos;
+        orc_resize(r, pos);
+    }
+    /* FilterResult::addAdapterTrimmed(string,bool) filterresult.cpp:124-152 */
+    if (adapter_len > 0) o->ctr[o->L.adapter_bases] += adapter_len;
+    *out_pos = pos;
+    *out_len = adapter_len;
+    return 1;
+}
+
+/* AdapterTrimmer::trimByMultiSequences (adaptertrimmer.cpp:48-62): every --adapter_fasta sequence in
+ * turn on the (shrinking) read; one event per cut for the host's adapter-string replay */
+static int orc_trim_by_multi_sequences(fastp_oracle* o, orc_read* r, uint32_t read_index, fastp_gpu_results* res, int* err) {
+    int matchReq = 4;
+    if (o->n_fasta > 16) matchReq = 5;
+    if (o->n_fasta > 256) matchReq = 6;
+    int trimmed = 0;
+    for (int i = 0; i < o->n_fasta; i++) {
+        int pos, alen;
+        if (!orc_apply_trim_by_sequence_req(o, r, o->fasta[i], o->fasta_len[i], matchReq, &pos, &alen)) continue;
+        trimmed = 1;
+        if (res->adapter_events && res->n_adapter_events) {
+            int k = *res->n_adapter_events;
+            if (k < res->adapter_events_capacity) {
+                fastp_gpu_adapter_event* e = &res->adapter_events[k];
+                e->read = read_index; e->pos = (int16_t)pos; e->len = (uint16_t)alen; e->adapter = (uint16_t)i; e->reserved = 0;
+                *res->n_adapter_events = k + 1;
+            } else {
+                *err = FASTP_GPU_E_OVERFLOW;
+            }
+        } else {
+            *err = FASTP_GPU_E_INVALID; /* adapter_fasta needs an event list */
+        }
+    }
+    return trimmed;
+}
+
 static int orc_apply_trim_by_sequence(fastp_oracle* o, orc_read* r, const char* adapter, int alen,
                                       fastp_gpu_read_result* rr) {
     int pos = 0;
@@ -724,7 +787,8 @@ static void orc_finish_result(fastp_gpu_read_result* rr, const orc_read* r, int 
 }
 
 /* ---- single-end loop body: seprocessor.cpp:204-296 ---------------------- */
-static void orc_process_se(fastp_oracle* o, char* seq, char* qual, int len, fastp_gpu_read_result* rr) {
+static void orc_process_se(fastp_oracle* o, int read_index, char* seq, char* qual, int len, fastp_gpu_read_result* rr,
+                           fastp_gpu_results* res, int* err) {
     const fastp_gpu_params* p = &o->p;
     memset(rr, 0, sizeof(*rr));
     orc_read or1 = {seq, qual, len, 0};
@@ -747,6 +811,7 @@ static void orc_process_se(fastp_oracle* o, char* seq, char* qual, int len, fast
     if (alive && p->adapter_enabled) { /* :244-261 */
         int trimmed = 0;
         if (o->has_seq_r1) trimmed = orc_apply_trim_by_sequence(o, &or1, o->adapter1, o->alen1, rr);
+        if (o->n_fasta) trimmed |= orc_trim_by_multi_sequences(o, &or1, (uint32_t)read_index, res, err); /* :249-251 */
         if (trimmed) { o->ctr[o->L.adapter_reads] += 1; rr->flags |= FASTP_GPU_RF_ADAPTER; }
         if (trimmed && or1.len <= p->dimer_max_len) isAdapterDimer = 1;
     }
@@ -897,6 +962,10 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
                 if (o->has_seq_r1) t1 = orc_apply_trim_by_sequence(o, &or1, o->adapter1, o->alen1, rr1);
                 if (o->has_seq_r2) t2 = orc_apply_trim_by_sequence(o, &or2, o->adapter2, o->alen2, rr2);
             }
+            if (o->n_fasta) { /* :467-470 */
+                t1 |= orc_trim_by_multi_sequences(o, &or1, 2u * (uint32_t)pair_index, res, err);
+                t2 |= orc_trim_by_multi_sequences(o, &or2, 2u * (uint32_t)pair_index + 1u, res, err);
+            }
             if (t1) { o->ctr[o->L.adapter_reads] += 1; rr1->flags |= FASTP_GPU_RF_ADAPTER; } /* :472-475 */
             if (t2) { o->ctr[o->L.adapter_reads] += 1; rr2->flags |= FASTP_GPU_RF_ADAPTER; }
             if ((t1 || t2) && or1.len <= p->dimer_max_len && or2.len <= p->dimer_max_len) /* :480-484 */
@@ -996,6 +1065,7 @@ int fastp_oracle_process(fastp_oracle* o, int n, uint32_t batch_flags, int row_s
     if (paired && (!seq2 || !qual2 || !len2 || !res->r2 || !res->pair)) return FASTP_GPU_E_INVALID;
     int err = FASTP_GPU_OK;
     if (res->n_corrections) *res->n_corrections = 0;
+    if (res->n_adapter_events) *res->n_adapter_events = 0;
     const int cap = o->p.max_len + 1;
     char* buf = (char*)malloc((size_t)cap * 4);
     for (int i = 0; i < n; i++) {
@@ -1005,7 +1075,7 @@ int fastp_oracle_process(fastp_oracle* o, int n, uint32_t batch_flags, int row_s
         memcpy(s1, seq1 + (size_t)i * row_stride, (size_t)l1); s1[l1] = 0;
         memcpy(q1, qual1 + (size_t)i * row_stride, (size_t)l1); q1[l1] = 0;
         if (!paired) {
-            orc_process_se(o, s1, q1, l1, &res->r1[i]);
+            orc_process_se(o, i, s1, q1, l1, &res->r1[i], res, &err);
         } else {
             int l2 = len2[i];
             if (l2 < 0 || l2 > o->p.max_len || l2 > row_stride) { err = FASTP_GPU_E_TOO_LONG; break; }

@@ -76,6 +76,27 @@ CASES = {
                             {"polyx_frac": 0.3}),
 }
 
+# --adapter_fasta: contigs as the FASTA file lists them; Options::loadFastaAdapters keeps them in
+# contig-name order (std::map), >= 6 bp, de-duplicated (options.cpp:50-83)
+FASTA_CONTIGS = [("a_truseq_r2", ADAPTER_R2), ("b_truseq_r1", ADAPTER_R1), ("c_nextera", "CTGTCTCTTATACACATCT"),
+                 ("d_short", "AGATCGGA"), ("e_polya", "AAAAAAAAAAAAAAAA")]
+FASTA_LIST = [seq.encode() for _, seq in sorted(FASTA_CONTIGS)]
+FASTA_FILE = "".join(f">{n}\n{q}\n" for n, q in FASTA_CONTIGS).encode()
+
+
+def _with_fasta(factory):
+    def f(max_len):
+        return abi.set_adapter_fasta(factory(max_len), FASTA_LIST)
+    return f
+
+
+CASES["pe_adapter_fasta"] = (True, ["-G", "--adapter_fasta", "@TMP@/adapters.fa"], _with_fasta(_pe()),
+                             {"insert_mean": 150.0, "polyx_frac": 0.2})
+CASES["se_adapter_fasta"] = (False, ["-G", "-a", ADAPTER_R1, "--adapter_fasta", "@TMP@/adapters.fa"],
+                             _with_fasta(_se(adapter_seq_r1=ADAPTER_R1.encode())), {"insert_mean": 120.0, "polyx_frac": 0.3})
+# files a case's reference run needs next to its inputs
+FILES = {"pe_adapter_fasta": {"adapters.fa": FASTA_FILE}, "se_adapter_fasta": {"adapters.fa": FASTA_FILE}}
+
 # host-side UMI name editing that goes with a case (the engine only trims the sequence)
 UMI = {
     "pe_umi_per_read": ("per_read", 6),

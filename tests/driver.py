@@ -37,18 +37,23 @@ def run_engine(engine, params, fq1: bytes, fq2: bytes | None, pack=1000, want_fa
         if b2 is not None:
             p2 = b2.slice(a, e)
             r1, r2, pr, corr = engine.process(p1.seq, p1.qual, p1.lens, p2.seq, p2.qual, p2.lens)
-            hostloop.apply_results(params, p1, p2, r1, r2, pr, corr, outs, amaps, umi)
+            hostloop.apply_results(params, p1, p2, r1, r2, pr, corr, outs, amaps, umi,
+                                   adapter_events=getattr(engine, "last_adapter_events", None))
         else:
             r1, _, _, corr = engine.process(p1.seq, p1.qual, p1.lens)
-            hostloop.apply_results(params, p1, None, r1, None, None, corr, outs, amaps, umi)
+            hostloop.apply_results(params, p1, None, r1, None, None, corr, outs, amaps, umi,
+                                   adapter_events=getattr(engine, "last_adapter_events", None))
     ctr = engine.counters()
     rep = refjson.build(ctr, engine.layout, params, amaps)
     return outs, ctr, rep
 
 
-def run_reference(flags, fq1: bytes, fq2: bytes | None, want_failed=True, workdir=None):
+def run_reference(flags, fq1: bytes, fq2: bytes | None, want_failed=True, workdir=None, extra_files=None):
     """fastp_ref -w 1 on the same text.  Returns dict(out1,out2,failed: bytes, json: dict)."""
     tmp = workdir or tempfile.mkdtemp(prefix="fastp_ref_")
+    for fn, content in (extra_files or {}).items():
+        with open(os.path.join(tmp, fn), "wb") as f:
+            f.write(content)
     i1 = os.path.join(tmp, "in1.fq")
     with open(i1, "wb") as f:
         f.write(fq1)

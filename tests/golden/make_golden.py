@@ -32,7 +32,7 @@ N_PAIRS = 500
 
 
 def one(name, flags, fq1, fq2):
-    ref = driver.run_reference(flags, fq1, fq2)
+    ref = driver.run_reference(flags, fq1, fq2, extra_files=cases.FILES.get(name))
     rec = {"fq1": np.frombuffer(fq1, dtype=np.uint8)}
     if fq2 is not None:
         rec["fq2"] = np.frombuffer(fq2, dtype=np.uint8)
@@ -48,13 +48,16 @@ def one(name, flags, fq1, fq2):
 
 
 def main():
+    only = set(sys.argv[1:])
     for name, (paired, flags, pf, skw) in cases.CASES.items():
+        if only and name not in only:
+            continue
         d = synth.synth_pairs(N_PAIRS, L=150, seed=1234, paired=paired, **skw)
         fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
         fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
         one(name, flags, fq1, fq2)
     td = "/root/reference/testdata"
-    if os.path.exists(td):
+    if os.path.exists(td) and (not only or "testdata_pe" in only):
         one("testdata_pe", [], open(os.path.join(td, "R1.fq"), "rb").read(),
             open(os.path.join(td, "R2.fq"), "rb").read())
 

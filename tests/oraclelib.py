@@ -110,6 +110,13 @@ class Oracle:
         res.corrections = corr.ctypes.data
         res.corrections_capacity = corr_capacity
         res.n_corrections = C.addressof(ncorr)
+        nfasta = int(self.params.n_adapter_fasta)
+        ev = np.zeros(max(16, n * 2 * min(nfasta, 8)) if nfasta else 0, dtype=abi.ADAPTER_EVENT_DTYPE)
+        nev = C.c_int32(0)
+        if nfasta:
+            res.adapter_events = ev.ctypes.data
+            res.adapter_events_capacity = len(ev)
+            res.n_adapter_events = C.addressof(nev)
         if paired:
             seq2 = np.ascontiguousarray(seq2, dtype=np.uint8)
             qual2 = np.ascontiguousarray(qual2, dtype=np.uint8)
@@ -123,6 +130,7 @@ class Oracle:
                                             len1.ctypes.data, None, None, None, C.byref(res))
         if rc != 0:
             raise RuntimeError(f"fastp_oracle_process -> {rc}")
+        self.last_adapter_events = np.sort(ev[:nev.value].copy(), order=["read", "adapter"])
         return r1, (r2 if paired else None), (pr if paired else None), corr[:ncorr.value].copy()
 
     def counters(self):

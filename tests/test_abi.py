@@ -33,6 +33,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(abi.ReadResult) == 12
     assert C.sizeof(abi.PairResult) == 8
     assert C.sizeof(abi.Correction) == 8
+    assert C.sizeof(abi.AdapterEvent) == 12
 
 
 def test_default_params_match_python_mirror(lib):
@@ -41,7 +42,7 @@ def test_default_params_match_python_mirror(lib):
         lib.fastp_gpu_default_params(C.byref(p), paired, 150)
         q = abi.default_params(paired, 150)
         for name, _ in abi.Params._fields_:
-            if name in ("reserved", "adapter_seq_r1", "adapter_seq_r2"):
+            if name in ("reserved", "adapter_seq_r1", "adapter_seq_r2", "adapter_fasta"):
                 continue
             assert getattr(p, name) == getattr(q, name), name
 
