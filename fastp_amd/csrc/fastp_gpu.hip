@@ -159,7 +159,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (he != hipSuccess) { delete ctx; return fail(nullptr, FASTP_GPU_E_HIP, "hipGetDeviceProperties failed"); }
     ctx->cus = prop.multiProcessorCount;
     // tile / launch geometry (tunable without a rebuild)
-    const int lds_kb_default = (int)(prop.sharedMemPerBlock / 1024) >= 160 ? 156 : (int)(prop.sharedMemPerBlock / 1024) - 4;
+    const int lds_kb_default = (int)(prop.sharedMemPerBlock / 1024) >= 160 ? 160 : (int)(prop.sharedMemPerBlock / 1024);
     ctx->cfg.threads = env_int("FASTP_GPU_THREADS", 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
     ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", lds_kb_default) * 1024;
@@ -181,6 +181,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     mp = mp / ctx->L.P * ctx->L.P;
     ctx->max_pairs_per_launch = (int)mp;
     fastp_gpu_counter_layout_for(ctx->dp.cycles, ctx->dp.isize_max, &ctx->cl);
+    if (env_int("FASTP_GPU_VERBOSE", 0))
+        fprintf(stderr, "fastp_gpu: tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch\n", ctx->L.P,
+                ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks, ctx->max_pairs_per_launch);
     ctx->slab_dwords = ctx->L.acc_end - ctx->L.acc_cyc;
 
     *out = ctx;  // from here on errors go through destroy

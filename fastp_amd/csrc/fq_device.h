@@ -86,6 +86,7 @@ FQ_DEV void tile_init_read(const LdsLayout& L, u32* lds, int R, int len) {
         lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
         lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
     }
+    if (R == 0) lds[L.wl] = 0;
 }
 // N masks from bit 7 of quality dword d (flat index inside the tile) - the rare path
 FQ_DEV void tile_note_n(const KernelArgs& a, u32* lds, int d, u32 v) {
@@ -111,7 +112,6 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
         const int gp = tile_first + (R - m * P);
         tile_init_read(L, lds, R, gp < a.n ? (int)a.len[m][gp] : 0);
     }
-    for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
     for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
     for (int m = 0; m < mates; m++) {
         const u32* g = a.seq[m] + (size_t)tile_first * L.SW;
@@ -186,7 +186,6 @@ FQ_DEV void tile_commit(const KernelArgs& a, u32* lds, int tid, int nthreads, co
     const LdsLayout& L = a.L;
     const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
     if (tid < L.NR) tile_init_read(L, lds, tid, (int)r.len);
-    for (int i = tid; i < L.NR * L.wm_stride; i += nthreads) lds[L.wm + i] = 0;
     for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
 #pragma unroll
     for (int i = 0; i < PF_S; i++) {
@@ -228,54 +227,67 @@ FQ_DEV void window_sums4(const u32* qrow, int c, int ncols, int w, u32 out[4]) {
 }
 
 // The sliding windows of Filter::trimAndCut (filter.cpp:97-194) evaluated for EVERY start
-// position at once: lane (read R, quality dword c) sets bits 4c..4c+3 of the read's predicate
-// masks; trim_and_cut() then only bit-scans them.  A window sum is position-absolute, so the
-// reference's rolling sum at position s equals the mask's window [s, s+w).
-FQ_DEV void build_trim_masks(const DevParams& p, const LdsLayout& L, u32* lds, int R, int c, u32 qd, u32 ncur) {
-    u32* wm = lds + L.wm + R * L.wm_stride;
-    const u32* qrow = lds + L.qual + R * L.QW;
-    const int wi = c >> 3, sh = (c & 7) * 4;
-    u32 s4[4];
-    if (L.wm_badF >= 0 && p.wF <= p.max_len) {
-        window_sums4(qrow, c, L.QW, p.wF, s4);
-        const u32 b = (u32)((int)s4[0] < p.thrF) | ((u32)((int)s4[1] < p.thrF) << 1) | ((u32)((int)s4[2] < p.thrF) << 2) |
-                      ((u32)((int)s4[3] < p.thrF) << 3);
-        if (b) lds_or_u32(&wm[L.wm_badF + wi], b << sh);
-    }
-    if (L.wm_badR >= 0 && p.wR <= p.max_len) {
-        window_sums4(qrow, c, L.QW, p.wR, s4);
-        const u32 b = (u32)((int)s4[0] < p.thrR) | ((u32)((int)s4[1] < p.thrR) << 1) | ((u32)((int)s4[2] < p.thrR) << 2) |
-                      ((u32)((int)s4[3] < p.thrR) << 3);
-        if (b) lds_or_u32(&wm[L.wm_badR + wi], b << sh);
-    }
-    if (L.wm_badT >= 0 && p.wT <= p.max_len) {
-        window_sums4(qrow, c, L.QW, p.wT, s4);
-        const u32 b = (u32)((int)s4[0] < p.thrT) | ((u32)((int)s4[1] < p.thrT) << 1) | ((u32)((int)s4[2] < p.thrT) << 2) |
-                      ((u32)((int)s4[3] < p.thrT) << 3);
-        if (b) lds_or_u32(&wm[L.wm_badT + wi], b << sh);
-    }
-    if (L.wm_lowQ >= 0) {
-        u32 b = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) b |= (u32)((int)((qd >> (8 * k)) & 0x7Fu) < p.qRmin) << k;
-        if (b) lds_or_u32(&wm[L.wm_lowQ + wi], b << sh);
-    }
-    if (L.wm_isN >= 0 && ncur) lds_or_u32(&wm[L.wm_isN + wi], ncur << sh);
-}
-
-// lane = (read R, quality dword c): the trimAndCut predicate masks of a tile
+// position at once, as per-read bit masks that trim_and_cut() then only bit-scans.  A window sum
+// is position-absolute, so the reference's rolling sum at position s equals the mask's window
+// [s, s+w).  Item = (mask word w, read R): one lane builds bits 32w..32w+31 of every mask of its
+// read from 8 quality dwords (+ the look-ahead the windows need) and stores the words - no
+// atomics, and nothing to clear beforehand.  The read index runs fastest across lanes.
 FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     if (!L.wm_stride) return;
-    const int qwg = a.p.qw_g;
-    const int total = L.NR * qwg;
-    for (int idx = tid; idx < total; idx += nthreads) {
-        const int R = (int)fastdiv((u32)idx, a.magic_qwg);
-        const int c = idx - R * qwg;
-        if (4 * c >= lds_i(lds, L.rlen0)[R]) continue;
-        const u32 qd = lds[L.qual + R * L.QW + c];
-        const u32 nb = (qd >> 7) & 0x01010101u;
-        build_trim_masks(a.p, L, lds, R, c, qd, (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu);
+    const DevParams& p = a.p;
+    // argument-block fields fetched once, not at every use inside the loops
+    const int NR = L.NR, QW = L.QW, WW = L.wm_words, wm_stride = L.wm_stride;
+    const int oF = L.wm_badF, oR = L.wm_badR, oT = L.wm_badT, oQ = L.wm_lowQ, oN = L.wm_isN;
+    const int wF = p.wF, wR = p.wR, wT = p.wT, thrF = p.thrF, thrR = p.thrR, thrT = p.thrT, qRmin = p.qRmin;
+    const int max_len = p.max_len;
+    const int* rlen0_v = lds_i(lds, L.rlen0);
+    const u32* qual_v = lds + L.qual;
+    u32* wm_v = lds + L.wm;
+    const u32 qmin4 = (u32)imin(imax(qRmin, 0), 127) * 0x01010101u;
+    const int total = NR * WW;
+    const int dW = nthreads / NR, dR = nthreads - dW * NR;
+    int w = tid / NR, R = tid - w * NR;
+    for (int i = tid; i < total; i += nthreads) {
+        const u32* qrow = qual_v + R * QW;
+        const int rl0 = rlen0_v[R];
+        u32 mF = 0, mR = 0, mT = 0, mQ = 0, mN = 0;
+        for (int d = 0; d < 8; d++) {
+            const int c = 8 * w + d;
+            if (c >= QW || 4 * c >= rl0) break;
+            const u32 qd = qrow[c];
+            u32 s4[4];
+            if (oF >= 0 && wF <= max_len) {
+                window_sums4(qrow, c, QW, wF, s4);
+                mF |= ((u32)((int)s4[0] < thrF) | ((u32)((int)s4[1] < thrF) << 1) | ((u32)((int)s4[2] < thrF) << 2) |
+                       ((u32)((int)s4[3] < thrF) << 3)) << (4 * d);
+            }
+            if (oR >= 0 && wR <= max_len) {
+                window_sums4(qrow, c, QW, wR, s4);
+                mR |= ((u32)((int)s4[0] < thrR) | ((u32)((int)s4[1] < thrR) << 1) | ((u32)((int)s4[2] < thrR) << 2) |
+                       ((u32)((int)s4[3] < thrR) << 3)) << (4 * d);
+            }
+            if (oT >= 0 && wT <= max_len) {
+                window_sums4(qrow, c, QW, wT, s4);
+                mT |= ((u32)((int)s4[0] < thrT) | ((u32)((int)s4[1] < thrT) << 1) | ((u32)((int)s4[2] < thrT) << 2) |
+                       ((u32)((int)s4[3] < thrT) << 3)) << (4 * d);
+            }
+            if (oQ >= 0) {  // quality < qRmin, four bytes at once: bit 7 of (q|0x80) - qRmin survives iff q >= qRmin
+                const u32 lt = (~(((qd & 0x7F7F7F7Fu) | 0x80808080u) - qmin4) >> 7) & 0x01010101u;
+                mQ |= ((lt | (lt >> 7) | (lt >> 14) | (lt >> 21)) & 0xFu) << (4 * d);
+            }
+            const u32 nb = (qd >> 7) & 0x01010101u;
+            mN |= ((nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu) << (4 * d);
+        }
+        u32* wm = wm_v + R * wm_stride + w;
+        if (oF >= 0) wm[oF] = mF;
+        if (oR >= 0) wm[oR] = mR;
+        if (oT >= 0) wm[oT] = mT;
+        if (oQ >= 0) wm[oQ] = mQ;
+        if (oN >= 0) wm[oN] = mN;
+        w += dW;
+        R += dR;
+        if (R >= NR) { R -= NR; w++; }
     }
     (void)n_valid;
 }
@@ -295,112 +307,244 @@ FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int
 // ---------------------------------------------------------------------------
 enum { ST_PRE = 0, ST_POST = 1, ST_BOTH = 2 };
 
+// one (read R, quality dword c) item of Stats::statRead; BALLOT: aggregate the quality histogram
+// over the wavefront (every lane of the wave must call this, `act` says whether it has an item)
+template <int mode, bool MERGE, bool BALLOT>
+FQ_DEV void stats_item(const KernelArgs& a, u32* lds, bool act, int R, int c, int n_valid, int lane, u32 copy,
+                       bool count_read = true) {
+    const LdsLayout& L = a.L;
+    const int Cp = L.Cp, C4 = L.Cp >> 2;
+    u64* cyc_all = (u64*)(lds + L.acc_cyc);
+    u32* kmer_all = lds + L.acc_kmer;
+    u32* qh_all = lds + L.acc_qh;
+    u32* misc = lds + L.acc_misc;
+    const int m = R >= L.P ? 1 : 0;
+    const int rl0 = lds_i(lds, L.rlen0)[R];
+    const int rflags = lds_i(lds, L.flags)[R];
+    const bool out_ok = (rflags & RS_STAT_POST) != 0;
+    const bool rc = MERGE && mode == ST_POST && (rflags & RS_POST_RC) != 0;  // tail of a merged read
+    int f = 0, l = rl0, lk = 0, rc_base = 0;
+    if (mode == ST_POST) {
+        act = act && out_ok;
+        f = lds_i(lds, L.front)[R];
+        l = lds_i(lds, MERGE ? L.mlen : L.len)[R];
+        if (rc) rc_base = lds_i(lds, L.mlen)[R - L.P] + l - 1;  // merged position of r2'[i] = len1 + len2 - 1 - i
+    } else {
+        act = act && (R - m * L.P < n_valid);  // rows past the end of the batch do not exist
+        if (mode == ST_BOTH && out_ok) lk = lds_i(lds, L.len)[R];
+    }
+    int slot0 = m * 2 + (mode == ST_POST ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
+    if (MERGE && mode == ST_POST && (rflags & RS_POST_TO1)) slot0 = 1;
+    if (act && c == 0 && count_read) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
+        lds_add_u32(&misc[MISC_STAT_READS + slot0], rc ? 0u : 1u);  // a merged read is ONE read
+        lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)l);
+        if (mode == ST_BOTH && out_ok) {
+            lds_add_u32(&misc[MISC_STAT_READS + slot0 + 1], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + slot0 + 1], (u32)lk);
+        }
+    }
+    const int j0 = c * 4;
+    act = act && j0 < f + l && j0 + 4 > f;
+    u32 qd = 0, codes = 0, nbits = 0xFFu;
+    if (act) {
+        const u32* srow = lds + L.seq + R * L.SW;
+        qd = lds[L.qual + R * L.QW + c];
+        const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
+        u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
+        if (c > 0) {
+            prev8 = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8)) & 0xFFu;
+            const u32 nb = (lds[L.qual + R * L.QW + c - 1] >> 7) & 0x01010101u;
+            nprev = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;  // bit k = base j0-4+k is N
+        }
+        const u32 nbc = (qd >> 7) & 0x01010101u;
+        codes = prev8 | (cur8 << 8);  // bases j0-4 .. j0+3, 2 bits each
+        nbits = nprev | (((nbc | (nbc >> 7) | (nbc >> 14) | (nbc >> 21)) & 0xFu) << 4);  // same 8 bases, 1 bit each
+    }
+    // ---- per base: per-cycle counters and 5-mers; collect the quality-histogram keys ----
+    u32 key[4];
+    bool val[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = j0 + k;
+        val[k] = act && j >= f && j < f + l;
+        const int slot = slot0 + ((mode == ST_BOTH && j < lk) ? 1 : 0);
+        const u32 q = (qd >> (k * 8)) & 0x7Fu;
+        key[k] = (u32)slot * 128u + q;
+        if (val[k]) {
+            const int wpos = j - f;                      // index inside the window
+            const int pos = rc ? rc_base - wpos : wpos;  // cycle
+            const u32 isn = (nbits >> (4 + k)) & 1u;
+            const u32 cls = isn ? (u32)CLS_N : (((codes >> (8 + 2 * k)) & 3u) ^ (rc ? 1u : 0u));
+            // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
+            const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
+                            ((u64)(q - 33u) << CYC_QSUM_SHIFT);
+            lds_add_u64(&cyc_all[((size_t)slot * N_CLS + cls) * Cp + (pos & 3) * C4 + (pos >> 2)], inc);
+            // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
+            // pos-4..pos all exist in the window and none of them is N
+            if (wpos >= 4 && ((nbits >> k) & 0x1Fu) == 0u) {
+                u32 km = (codes >> (2 * k)) & 0x3FFu;  // earliest base in the low bits
+                if (rc) km = (reverse_groups(km) >> 22) ^ 0x155u;  // the same five bases on the merged strand
+                lds_add_u32(&kmer_all[slot * KMER_BINS + km], 1u);
+            }
+        }
+    }
+    // ---- mBaseQualHistogram[qual]++ (:207).  Qualities cluster on a few values, so the
+    // wave first counts the bases equal to one lane's (slot, quality) key with ballots and
+    // lets that lane add the total; only the other bases pay an LDS atomic each.
+    if (!BALLOT) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (val[k]) lds_add_u32(&qh_all[key[k] * QH_COPIES + copy], 1u);
+        return;
+    }
+    const bool have = val[0] | val[1] | val[2] | val[3];
+    const u32 mine = val[0] ? key[0] : val[1] ? key[1] : val[2] ? key[2] : key[3];
+    const u64 hv = ballot(have);
+    if (hv) {  // wave-uniform
+        const int src = ffs64(hv) - 1;
+        const u32 modek = shfl(mine, src);
+        u32 cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool mk = val[k] && key[k] == modek;
+            cnt += (u32)popc64(ballot(mk));
+            if (val[k] && !mk) lds_add_u32(&qh_all[key[k] * QH_COPIES + copy], 1u);
+        }
+        if (lane == src) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
+    }
+}
+
 template <int mode, bool MERGE>
 FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
-    const u32 magic_qwg = a.magic_qwg;
     const LdsLayout& L = a.L;
     const int qwg = a.p.qw_g;
+    const int total = L.NR * qwg;
+    const int lane = tid & 63;
+    const u32 copy = (u32)(tid & (QH_COPIES - 1));
+    for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count (ballots inside)
+        const int idx = base + lane;
+        const bool act = idx < total;
+        const int R = act ? (int)fastdiv((u32)idx, a.magic_qwg) : 0;
+        const int c = act ? idx - R * qwg : 0;
+        stats_item<mode, MERGE, true>(a, lds, act, R, c, n_valid, lane, copy);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One-pass Stats, fast form.  Almost every (read, quality dword) item is "plain": four existing
+// bases, no N among them or the four before, all kept or all dropped.  Plain items take a
+// branch-free path (increment from a 128-entry table, no per-base validity, one shared
+// kept/dropped offset); the others - a read's last partial dword, the dword its kept length
+// cuts, dwords with N - are queued in an LDS work list and run through stats_item afterwards,
+// so that no wavefront pays for both paths.
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const int qwg = L.QW;
     const int total = L.NR * qwg;
     const int Cp = L.Cp, C4 = L.Cp >> 2;
     u64* cyc_all = (u64*)(lds + L.acc_cyc);
     u32* kmer_all = lds + L.acc_kmer;
     u32* qh_all = lds + L.acc_qh;
     u32* misc = lds + L.acc_misc;
+    const u64* inc_lut = (const u64*)(lds + L.inc_lut);
+    u32* wl_count = lds + L.wl;
+    u16* wl_items = (u16*)(lds + L.wl + 1);
+    const u8* seq_bytes = (const u8*)(lds + L.seq);
     const int lane = tid & 63;
     const u32 copy = (u32)(tid & (QH_COPIES - 1));
-    for (int base = tid - lane; base < total; base += nthreads) {
+    // every argument-block field the loop needs, fetched once (they would otherwise be re-read
+    // from the kernarg segment at each use, with a wait on the scalar cache in the loop)
+    const int P = L.P, SW4 = L.SW * 4, wl_cap = L.wl_cap;
+    const int* rlen0_v = lds_i(lds, L.rlen0);
+    const int* flags_v = lds_i(lds, L.flags);
+    const int* len_v = lds_i(lds, L.len);
+    const u32* qual_v = lds + L.qual;
+    // (R, c) of this lane's items advance by a fixed (dR, dc) per trip: no division in the loop
+    int R = (int)fastdiv((u32)tid, a.magic_qwg);
+    int c = tid - R * qwg;
+    const int dR = (int)fastdiv((u32)nthreads, a.magic_qwg), dc = nthreads - dR * qwg;
+    for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count
         const int idx = base + lane;
-        bool act = idx < total;
-        const int R = act ? (int)fastdiv((u32)idx, magic_qwg) : 0;
-        const int c = act ? idx - R * qwg : 0;
-        const int m = R >= L.P ? 1 : 0;
-        const int rl0 = lds_i(lds, L.rlen0)[R];
-        const int rflags = lds_i(lds, L.flags)[R];
-        const bool out_ok = (rflags & RS_STAT_POST) != 0;
-        const bool rc = MERGE && mode == ST_POST && (rflags & RS_POST_RC) != 0;  // tail of a merged read
-        int f = 0, l = rl0, lk = 0, rc_base = 0;
-        if (mode == ST_POST) {
-            act = act && out_ok;
-            f = lds_i(lds, L.front)[R];
-            l = lds_i(lds, MERGE ? L.mlen : L.len)[R];
-            if (rc) rc_base = lds_i(lds, L.mlen)[R - L.P] + l - 1;  // merged position of r2'[i] = len1 + len2 - 1 - i
-        } else {
-            act = act && (R - m * L.P < n_valid);  // rows past the end of the batch do not exist
-            if (mode == ST_BOTH && out_ok) lk = lds_i(lds, L.len)[R];
+        const int m = R >= P ? 1 : 0;
+        bool act = idx < total && (R - m * P < n_valid);
+        int rl0 = 0, lk = 0, rfl = 0;
+        if (act) {
+            rl0 = rlen0_v[R];
+            rfl = flags_v[R];
+            if (rfl & RS_STAT_POST) lk = len_v[R];
         }
-        int slot0 = m * 2 + (mode == ST_POST ? 1 : 0);  // PRE1=0 POST1=1 PRE2=2 POST2=3
-        if (MERGE && mode == ST_POST && (rflags & RS_POST_TO1)) slot0 = 1;
+        const int slot0 = m * 2;
         if (act && c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
-            lds_add_u32(&misc[MISC_STAT_READS + slot0], rc ? 0u : 1u);  // a merged read is ONE read
-            lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)l);
-            if (mode == ST_BOTH && out_ok) {
+            lds_add_u32(&misc[MISC_STAT_READS + slot0], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)rl0);
+            if (rfl & RS_STAT_POST) {
                 lds_add_u32(&misc[MISC_STAT_READS + slot0 + 1], 1u);
                 lds_add_u32(&misc[MISC_STAT_LENSUM + slot0 + 1], (u32)lk);
             }
         }
-        const int j0 = c * 4;
-        act = act && j0 < f + l && j0 + 4 > f;
-        u32 qd = 0, codes = 0, nbits = 0xFFu;
+        const int j0 = 4 * c;
+        act = act && j0 < rl0;
+        bool plain = false;
+        u32 qd = 0, nany = 0;
         if (act) {
-            const u32* srow = lds + L.seq + R * L.SW;
-            qd = lds[L.qual + R * L.QW + c];
-            const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
-            u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
-            if (c > 0) {
-                prev8 = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8)) & 0xFFu;
-                const u32 nb = (lds[L.qual + R * L.QW + c - 1] >> 7) & 0x01010101u;
-                nprev = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;  // bit k = base j0-4+k is N
+            qd = qual_v[idx];  // LDS rows have the batch strides: the item index IS the dword offset
+            nany = qd & 0x80808080u;
+            if (c > 0) nany |= qual_v[idx - 1] & 0x80808080u;
+            plain = j0 + 4 <= rl0 && nany == 0u && (j0 + 4 <= lk || j0 >= lk);
+            if (!plain) {
+                const u32 slot = lds_add_ret_u32(wl_count, 1u);
+                if (slot < (u32)wl_cap) wl_items[slot] = (u16)idx;
+                else stats_item<ST_BOTH, false, false>(a, lds, true, R, c, n_valid, lane, copy, false);  // list full: do it here
             }
-            const u32 nbc = (qd >> 7) & 0x01010101u;
-            codes = prev8 | (cur8 << 8);  // bases j0-4 .. j0+3, 2 bits each
-            nbits = nprev | (((nbc | (nbc >> 7) | (nbc >> 14) | (nbc >> 21)) & 0xFu) << 4);  // same 8 bases, 1 bit each
         }
-        // ---- per base: per-cycle counters and 5-mers; collect the quality-histogram keys ----
-        u32 key[4];
-        bool val[4];
+        u32 key0 = 0;
+        if (plain) {
+            const int slot = slot0 + (j0 < lk ? 1 : 0);
+            const u32 cur8 = seq_bytes[R * SW4 + c];
+            u64* cyc = cyc_all + ((size_t)slot * N_CLS) * Cp + c;  // position 4c+k lives at k*C4 + c (phase-major)
+            key0 = (u32)slot * 128u;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = j0 + k;
-            val[k] = act && j >= f && j < f + l;
-            const int slot = slot0 + ((mode == ST_BOTH && j < lk) ? 1 : 0);
-            const u32 q = (qd >> (k * 8)) & 0x7Fu;
-            key[k] = (u32)slot * 128u + q;
-            if (val[k]) {
-                const int wpos = j - f;                      // index inside the window
-                const int pos = rc ? rc_base - wpos : wpos;  // cycle
-                const u32 isn = (nbits >> (4 + k)) & 1u;
-                const u32 cls = isn ? (u32)CLS_N : (((codes >> (8 + 2 * k)) & 3u) ^ (rc ? 1u : 0u));
-                // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
-                const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
-                                ((u64)(q - 33u) << CYC_QSUM_SHIFT);
-                lds_add_u64(&cyc_all[((size_t)slot * N_CLS + cls) * Cp + (pos & 3) * C4 + (pos >> 2)], inc);
-                // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
-                // pos-4..pos all exist in the window and none of them is N
-                if (wpos >= 4 && ((nbits >> k) & 0x1Fu) == 0u) {
-                    u32 km = (codes >> (2 * k)) & 0x3FFu;  // earliest base in the low bits
-                    if (rc) km = (reverse_groups(km) >> 22) ^ 0x155u;  // the same five bases on the merged strand
-                    lds_add_u32(&kmer_all[slot * KMER_BINS + km], 1u);
-                }
+            for (int k = 0; k < 4; k++) {
+                const u32 q = (qd >> (8 * k)) & 0x7Fu;
+                const u32 cls = (cur8 >> (2 * k)) & 3u;
+                lds_add_u64(&cyc[cls * Cp + k * C4], inc_lut[q]);
+            }
+            if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N)
+                const u32 codes = (u32)seq_bytes[R * SW4 + c - 1] | (cur8 << 8);
+                u32* kmer = kmer_all + slot * KMER_BINS;
+#pragma unroll
+                for (int k = 0; k < 4; k++) lds_add_u32(&kmer[(codes >> (2 * k)) & 0x3FFu], 1u);
             }
         }
-        // ---- mBaseQualHistogram[qual]++ (:207).  Qualities cluster on a few values, so the
-        // wave first counts the bases equal to one lane's (slot, quality) key with ballots and
-        // lets that lane add the total; only the other bases pay an LDS atomic each.
-        const bool have = val[0] | val[1] | val[2] | val[3];
-        const u32 mine = val[0] ? key[0] : val[1] ? key[1] : val[2] ? key[2] : key[3];
-        const u64 hv = ballot(have);
+        // quality histogram of the plain items: ballot-aggregate the commonest key
+        const u64 hv = ballot(plain);
         if (hv) {  // wave-uniform
             const int src = ffs64(hv) - 1;
-            const u32 modek = shfl(mine, src);
+            const u32 modek = shfl(key0 + (qd & 0x7Fu), src);
             u32 cnt = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const bool mk = val[k] && key[k] == modek;
+                const u32 kk = key0 + ((qd >> (8 * k)) & 0x7Fu);
+                const bool mk = plain && kk == modek;
                 cnt += (u32)popc64(ballot(mk));
-                if (val[k] && !mk) lds_add_u32(&qh_all[key[k] * QH_COPIES + copy], 1u);
+                if (plain && !mk) lds_add_u32(&qh_all[kk * QH_COPIES + copy], 1u);
             }
             if (lane == src) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
         }
+        c += dc;
+        R += dR;
+        if (c >= qwg) { c -= qwg; R++; }
+    }
+    block_sync();
+    // the queued items, all through the general path
+    const int nw = (int)imin((int)*wl_count, L.wl_cap);
+    for (int base = tid - lane; base < nw; base += nthreads) {
+        const int i = base + lane;
+        const bool act = i < nw;
+        const int idx = act ? (int)wl_items[i] : 0;
+        const int Rw = (int)fastdiv((u32)idx, a.magic_qwg);
+        stats_item<ST_BOTH, false, true>(a, lds, act, Rw, idx - Rw * qwg, n_valid, lane, copy, false);  // reads were counted above
     }
 }
 
@@ -440,7 +584,7 @@ FQ_DEV int scan_last(const u32* m, int lo, int hi, bool want) {
 
 // ---------------------------------------------------------------------------
 // Filter::trimAndCut (filter.cpp:68-207) on one read.  Returns false for NULL.
-// wm = the read's predicate masks (build_trim_masks), u = row position of the read's
+// wm = the read's predicate masks (phase_masks), u = row position of the read's
 // first base as trimAndCut sees it (after the UMI front trim), len = its length.
 // Every loop of the reference becomes one bit scan; comments give the loop it replaces.
 // ---------------------------------------------------------------------------
@@ -562,9 +706,15 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     if (!p.dup_enabled || !a.dup_pos) return;
-    const int B = p.dup_bufnum;
+    // argument-block fields fetched once, not at every use inside the loops
+    const int B = p.dup_bufnum, P = L.P, SW4 = L.SW * 4, QW = L.QW;
     const u32 mask = (u32)(512 * B - 1);
     const u32* primes = lds + L.primes;
+    const u32* val4 = lds + L.val4_lut;
+    const int* rlen0_v = lds_i(lds, L.rlen0);
+    const u8* seq_bytes = (const u8*)(lds + L.seq);
+    const u32* qual_v = lds + L.qual;
+    u64* hash_v = (u64*)(lds + L.hash);
     const int D = (p.qw_g + 7) >> 3;  // quality dwords per lane
     const int total = L.NR * 8;
     const int lane = tid & 63;
@@ -572,28 +722,28 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
         const int t = t0 + lane;
         const bool valid = t < total;
         const int R = valid ? (t >> 3) : 0, seg = t & 7;
-        const int m = R >= L.P ? 1 : 0;
-        const int len = valid ? lds_i(lds, L.rlen0)[R] : 0;
-        const int off = m ? lds_i(lds, L.rlen0)[R - L.P] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
-        const u32* srow = lds + L.seq + R * L.SW;
-        const u32* qrow = lds + L.qual + R * L.QW;
+        const int len = valid ? rlen0_v[R] : 0;
+        const int off = R >= P ? rlen0_v[R - P] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
         for (int i0 = 0; i0 < B; i0 += 2) {
             u64 acc0 = 0, acc1 = 0;
             for (int d = 0; d < D; d++) {
                 const int c = seg + 8 * d;
-                if (4 * c >= len) break;
-                const u32 qd = qrow[c];
-                const u32 c8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
+                const int rem = len - 4 * c;  // bases of this dword that exist
+                if (rem <= 0) break;
+                const u32 qd = qual_v[R * QW + c];
+                u32 vals = val4[seq_bytes[R * SW4 + c]];  // the four base values, one byte each
+                if (qd & 0x80808080u) {                  // N -> 13
+                    const u32 mN = ((qd >> 7) & 0x01010101u) * 0xFFu;
+                    vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
+                }
+                vals &= lowmask32(8 * rem);              // bases past the read end contribute 0
+                const u32 pi0 = ((u32)(4 * c + off)) * (u32)B + (u32)i0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int j = 4 * c + k;
-                    if (j < len) {
-                        const u32 code = (c8 >> (2 * k)) & 3u;
-                        const u32 val = ((qd >> (8 * k + 7)) & 1u) ? 13u : ((0x1F4ADE07u >> (code * 8)) & 0xFFu);
-                        const u32 pi = (((u32)(j + off)) * (u32)B + (u32)i0) & mask;
-                        acc0 += (u64)primes[pi] * (u64)val;
-                        acc1 += (u64)primes[pi + 1] * (u64)val;
-                    }
+                    const u32 v = (vals >> (8 * k)) & 0xFFu;
+                    const u32 pi = (pi0 + (u32)(k * B)) & mask;
+                    acc0 += (u64)mul24(primes[pi], v);      // prime < 2^24, value < 2^8: exact in 32 bits
+                    acc1 += (u64)mul24(primes[pi + 1], v);
                 }
             }
             u32 lo0 = (u32)acc0, hi0 = (u32)(acc0 >> 32), lo1 = (u32)acc1, hi1 = (u32)(acc1 >> 32);
@@ -606,7 +756,7 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
                 lo1 = (u32)n1; hi1 = (u32)(n1 >> 32);
             }
             if (valid && seg == 0) {
-                u64* h = (u64*)(lds + L.hash) + (size_t)R * B;
+                u64* h = hash_v + (size_t)R * B;
                 h[i0] = ((u64)hi0 << 32) | lo0;
                 h[i0 + 1] = ((u64)hi1 << 32) | lo1;
             }
@@ -1090,7 +1240,14 @@ FQ_DEV bool apply_fasta_trims(const KernelArgs& a, u32* lds, int R, u32 read_ind
 FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
-    const int D = (p.qw_g + 7) >> 3;
+    // argument-block fields fetched once, not at every use inside the loops
+    const int D = (p.qw_g + 7) >> 3, QW = L.QW, SW = L.SW;
+    const bool cplx = p.complexity_filter != 0;
+    const int* front_v = lds_i(lds, L.front);
+    const int* wlen_v = lds_i(lds, p.merge ? L.mlen : L.len);
+    const u32* qual_v = lds + L.qual;
+    const u32* seq_v = lds + L.seq;
+    u32* met_v = lds + L.met;
     const int total = L.NR * 8;
     const int lane = tid & 63;
     const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
@@ -1098,25 +1255,32 @@ FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) 
         const int t = t0 + lane;
         const bool valid = t < total;
         const int R = valid ? (t >> 3) : 0, seg = t & 7;
-        const int f = lds_i(lds, L.front)[R];
-        const int e = valid ? f + lds_i(lds, p.merge ? L.mlen : L.len)[R] : f;
-        const u32* qrow = lds + L.qual + R * L.QW;
-        const u32* srow = lds + L.seq + R * L.SW;
+        const int f = front_v[R];
+        const int e = valid ? f + wlen_v[R] : f;
+        const u32* qrow = qual_v + R * QW;
+        const u32* srow = seq_v + R * SW;
         u32 ma = 0, mb = 0;
         for (int d = 0; d < D; d++) {
             const int c = seg + 8 * d;
             const int j0 = 4 * c;
             if (j0 >= e) break;
             if (j0 + 4 <= f) continue;
-            const int lo = imax(f - j0, 0), hi = imin(e - j0, 4);  // bytes [lo, hi) of this dword are in the window
-            const u32 M = lowmask32(8 * hi) & ~lowmask32(8 * lo);
             const u32 qd = qrow[c];
             const u32 q7 = qd & 0x7F7F7F7Fu;
             const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;  // bit 7 of a byte: qual >= threshold
-            ma += sum_bytes(q7 & M, 0u) - 33u * (u32)(hi - lo);
-            ma += (u32)popc32(~ge & 0x80808080u & M) << 16;
-            mb += (u32)popc32(qd & 0x80808080u & M);
-            if (p.complexity_filter) {
+            int lo = 0, hi = 4;
+            if (j0 >= f && j0 + 4 <= e) {  // the whole dword is inside the window (the common case)
+                ma += sum_bytes(q7, 0u) - 132u + ((u32)popc32(ge ^ 0x80808080u) << 16);
+                mb += (u32)popc32(qd & 0x80808080u);
+            } else {
+                lo = imax(f - j0, 0);
+                hi = imin(e - j0, 4);  // bytes [lo, hi) of this dword are in the window
+                const u32 M = lowmask32(8 * hi) & ~lowmask32(8 * lo);
+                ma += sum_bytes(q7 & M, 0u) - 33u * (u32)(hi - lo);
+                ma += (u32)popc32(~ge & 0x80808080u & M) << 16;
+                mb += (u32)popc32(qd & 0x80808080u & M);
+            }
+            if (cplx) {
                 // symbol j differs from symbol j-1 (N is its own symbol; its stored code is 0)
                 const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
                 const u32 nb = (qd >> 7) & 0x01010101u;
@@ -1143,8 +1307,8 @@ FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) 
             mb += shfl_xor(mb, sh);
         }
         if (valid && seg == 0) {
-            lds[L.met + 2 * R] = ma;
-            lds[L.met + 2 * R + 1] = mb;
+            met_v[2 * R] = ma;
+            met_v[2 * R + 1] = mb;
         }
     }
 }
@@ -1578,10 +1742,21 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             lds[L.adapt + i] = v;
         }
     }
+    if (a.p.dup_enabled)
+        for (int i = tid; i < 256; i += nt) {  // duplicate.cpp:92-109: A=7 T=222 C=74 G=31 (codes A0 T1 C2 G3)
+            u32 v = 0;
+            for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
+            lds[L.val4_lut + i] = v;
+        }
+    for (int q = tid; q < 128; q += nt) {  // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
+        const u64 inc = 1ull | ((u64)(q >= 53) << CYC_Q20_SHIFT) | ((u64)(q >= 63) << CYC_Q30_SHIFT) |
+                        ((u64)(u32)(q - 33) << CYC_QSUM_SHIFT);
+        ((u64*)(lds + L.inc_lut))[q] = inc;
+    }
     block_sync();
     const bool timing_on = a.phase_cycles != nullptr;  // uniform
     const bool timing = timing_on && tid == 0;
-    u64 tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     TileRegs regs;
     const bool prefetch = a.prefetch != 0;  // uniform
     if (prefetch && block_id() < a.tiles) tile_fetch(a, block_id() * L.P, tid, nt, regs);
@@ -1597,6 +1772,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         FQ_STAMP(0)
         if (!a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
         phase_masks(a, lds, n_valid, tid, nt);
+        if (timing_on) { block_sync(); FQ_STAMP(8) }
         phase_hash(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(1)
@@ -1632,7 +1808,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         block_sync();
         FQ_STAMP(6)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
-        if (a.p.stats_one_pass) phase_stats<ST_BOTH, false>(a, lds, n_valid, tid, nt);
+        if (a.p.stats_one_pass) phase_stats_both(a, lds, n_valid, tid, nt);
         else if (a.p.merge) phase_stats<ST_POST, true>(a, lds, n_valid, tid, nt);
         else phase_stats<ST_POST, false>(a, lds, n_valid, tid, nt);
         block_sync();
@@ -1640,7 +1816,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
 #undef FQ_STAMP
     }
     if (timing)
-        for (int k = 0; k < 8; k++) g_atomic_add_u64(&a.phase_cycles[k], tacc[k]);
+        for (int k = 0; k < 10; k++) g_atomic_add_u64(&a.phase_cycles[k], tacc[k]);
     // flush this workgroup's accumulators to its slab (plain coalesced stores)
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];
@@ -1654,6 +1830,12 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
 FQ_DEV void hash_body(const KernelArgs& a, u32* lds) {
     const LdsLayout& L = a.L;
     const int tid = thread_id(), nt = block_threads();
+    if (a.p.dup_enabled)
+        for (int i = tid; i < 256; i += nt) {  // duplicate.cpp:92-109: A=7 T=222 C=74 G=31 (codes A0 T1 C2 G3)
+            u32 v = 0;
+            for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
+            lds[L.val4_lut + i] = v;
+        }
     if (a.p.dup_enabled)
         for (int i = tid; i < 512 * a.p.dup_bufnum; i += nt) lds[L.primes + i] = a.lut.dup_primes[i];
     block_sync();

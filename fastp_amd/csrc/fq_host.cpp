@@ -213,7 +213,6 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
 static int round_odd(int x) { return (x & 1) ? x : x + 1; }
 
 int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err) {
-    const int waves = cfg.threads / 64;
     const int mates = p.paired ? 2 : 1;
     auto build = [&](int P, LdsLayout& out) {
         memset(&out, 0, sizeof(out));
@@ -259,13 +258,17 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.alen = take(out.NR);
         out.code = take(out.NR);
         out.mlen = take(out.NR);
+        if (o & 1) o++;
+        out.inc_lut = take(256);
+        out.val4_lut = take(p.dup_bufnum > 0 ? 256 : 0);
+        out.wl_cap = 2046;
+        out.wl = take(1 + out.wl_cap / 2);
         out.met = take(out.NR * 2);
         out.ov_off = take(P);
         out.ov_len = take(P);
         out.ov_diff = take(P);
         out.ov_flags = take(P);
         out.adapt = take(2 * ADAPT_WORDS);
-        out.wscratch = take(waves * 2 * out.SW);
         const int lw = (p.cycles + 2) / 2;
         out.lut_ov = take(lw);
         out.lut_lowq = take(lw);

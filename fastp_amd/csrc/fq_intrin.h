@@ -50,11 +50,16 @@ FQ_DEV u32 brev32(u32 v) { return __brev(v); }
 // low 32 bits of ({hi,lo} >> (s & 31))  -> v_alignbit_b32
 FQ_DEV u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 // sum of the four bytes of a, plus c  -> v_sad_u8 against zero
+// 24-bit x 24-bit -> low 32 bits (full-rate v_mul_u32_u24)
+FQ_DEV u32 mul24(u32 a, u32 b) { return __umul24(a, b); }
 FQ_DEV u32 sum_bytes(u32 a, u32 c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
 
 // LDS accumulators: fire-and-forget ds_add / ds_or (no return value used)
 FQ_DEV void lds_add_u32(u32* p, u32 v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+FQ_DEV u32 lds_add_ret_u32(u32* p, u32 v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 FQ_DEV void lds_add_u64(u64* p, u64 v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

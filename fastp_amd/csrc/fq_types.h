@@ -34,7 +34,7 @@ static const u32 OV_KEY_NONE = 0xFFFFFFFFu;
 // per-lane registers that hold the NEXT tile's input while the current tile is processed
 enum { PF_Q = 3, PF_S = 1 };   // in 16-byte chunks
 
-enum { QH_COPIES = 8 };        // replicated quality histograms (bank spreading)
+enum { QH_COPIES = 4 };        // replicated quality histograms (bank spreading)
 enum { KMER_BINS = 1024 };
 enum { MAX_DUP_BUFS = 8 };
 enum { MAX_ADAPTER_WORDS = 4 };  // 64 bases
@@ -122,9 +122,13 @@ struct LdsLayout {
     int wm_lowQ;    // quality[j] < qRmin                           (filter.cpp:159)
     int wm_isN;     // base j is 'N'                                (filter.cpp:123,191)
     int adapt;      // [2][ADAPT_WORDS] packed adapter words
-    int wscratch;   // [waves][2*SW] dwords: rc(r2) words + rc N-mask words
     int lut_ov, lut_lowq, lut_cplx;                       // u16 tables, (max_len+1+1)/2 dwords each
     int primes;     // [bufnum*512]
+    int val4_lut;   // [256] u32: Duplicate's base values (A7 T222 C74 G31, duplicate.cpp:92-109) of the four
+                    // bases a packed byte holds, one byte each
+    int inc_lut;    // [128] u64: the packed per-cycle increment of every quality character
+    int wl, wl_cap; // work list of (read, quality dword) items the fast Stats path hands to the general one:
+                    // [0] = count, then wl_cap u16 entries
     int acc_cyc;    // [4][N_CLS][Cp] u64  (2 dwords each)
     int acc_kmer;   // [4][KMER_BINS] u32
     int acc_qh;     // [4][128][QH_COPIES] u32

@@ -69,6 +69,7 @@ static inline unsigned __brev(unsigned v) {
     return (v >> 16) | (v << 16);
 }
 static inline long long clock64() { return 0; }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 // ---- gfx950 builtins used by fq_intrin.h -----------------------------------------

@@ -96,6 +96,15 @@ def test_gpu_merge_stress(k):
     _compare(f"merge_stress{k}", p, d, True)
 
 
+def test_gpu_stats_work_list_overflow():
+    """one-pass Stats: so many N-containing quality dwords that the LDS work list overflows"""
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.n_base_limit = 100
+    d = synth.noisy_reads(20000, L=150, seed=77, paired=True, n_rate=0.35)
+    _compare("stats_overflow", p, d, True)
+
+
 @pytest.mark.parametrize("L", [36, 75, 100, 250, 400])
 def test_gpu_read_lengths(L):
     p = abi.default_params(True, L)

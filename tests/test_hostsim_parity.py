@@ -127,3 +127,16 @@ def test_sim_merge_stress(k):
     assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"]))
     bad = np.nonzero(co != cg)[0]
     assert len(bad) == 0, f"merge stress {k}: counters differ at {bad[:8]}: oracle {co[bad[:8]]} device {cg[bad[:8]]}"
+
+
+def test_sim_stats_work_list_overflow():
+    """one-pass Stats: so many N-containing quality dwords that the LDS work list overflows and the
+    fast path has to run the general code in place"""
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.n_base_limit = 100
+    d = synth.noisy_reads(400, L=150, seed=77, paired=True, n_rate=0.35)
+    ro, rg, co, cg = _both(p, d, True)
+    for i in range(3):
+        assert ro[i].tobytes() == rg[i].tobytes()
+    assert np.array_equal(co, cg)

@@ -28,6 +28,6 @@ for it in range(2):
     g.submit_device(b, res); g.synchronize()
     ms, k = g.kernel_time()
     cyc = g.debug_phase_cycles()
-    tot = sum(cyc[:8])
-    names = ["load", "masks+hash", "trim", "polyg", "overlap", "decide", "metrics+filter", "stats"]
+    tot = sum(cyc[:10])
+    names = ["load", "hash", "trim", "polyg", "overlap", "decide", "metrics+filter", "stats", "masks"]
     print(f"kernel {ms:.3f} ms / {k} launches; phase share:", {nm: f"{100.0 * c / tot:.1f}%" for nm, c in zip(names, cyc)})
