@@ -29,7 +29,10 @@ extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) 
 }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
-extern "C" __global__ void __launch_bounds__(256) fq_dup_resolve_kernel(DupArgs d) { dup_resolve_body(d); }
+extern "C" __global__ void __launch_bounds__(1024) fq_dup_resolve_kernel(DupArgs d) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];  // 1 dword: the workgroup's duplicate count
+    dup_resolve_body(d, fq_lds);
+}
 
 // ---------------------------------------------------------------------------
 // context
@@ -351,10 +354,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         d.ctr_total = ctx->d_ctr + cl.dup_total;
         d.ctr_dups = ctx->d_ctr + cl.dup_count;
         HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
-        const int g2 = std::min(ctx->cus * 8, (n + 255) / 256);
+        const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
         hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(g2), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };

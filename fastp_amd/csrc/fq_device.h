@@ -1994,7 +1994,7 @@ FQ_DEV void dup_probe_body(const DupArgs& d) {
     for (int g = gid; g < d.n; g += gstride) {
         u32 need = 0;
         for (int i = 0; i < d.B; i++) {
-            const u64 pos = d.dup_pos[(size_t)g * d.B + i] % d.bits;
+            const u64 pos = d.dup_pos[(size_t)g * d.B + i] & (d.bits - 1)  /* mBufLenInBits is a power of two (duplicate.cpp:13-47) */;
             const u32 w = d.bitmap[(size_t)i * words + (pos >> 5)];
             if (!((w >> (pos & 31)) & 1u)) {
                 need |= 1u << i;
@@ -2016,7 +2016,9 @@ FQ_DEV void dup_probe_body(const DupArgs& d) {
     }
 }
 
-FQ_DEV void dup_resolve_body(const DupArgs& d) {
+FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
+    if (thread_id() == 0) *block_count = 0;
+    block_sync();
     const int gid = block_id() * block_threads() + thread_id();
     const int gstride = grid_blocks() * block_threads();
     const u64 words = d.bits >> 5;
@@ -2030,7 +2032,7 @@ FQ_DEV void dup_resolve_body(const DupArgs& d) {
             is_dup = true;
             for (int i = 0; i < d.B; i++) {
                 if (!((need >> i) & 1u)) continue;  // committed by an earlier batch
-                const u64 pos = d.dup_pos[(size_t)g * d.B + i] % d.bits;
+                const u64 pos = d.dup_pos[(size_t)g * d.B + i] & (d.bits - 1)  /* mBufLenInBits is a power of two (duplicate.cpp:13-47) */;
                 const u64 key = dup_key(i, pos);
                 u32 slot = dup_slot(key, d.table_log2);
                 u64 cur;
@@ -2050,9 +2052,13 @@ FQ_DEV void dup_resolve_body(const DupArgs& d) {
                 if (d.paired) d.res[1][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
             }
         }
+        // one same-address device atomic per WORKGROUP (they serialize at ~10 ns each): lanes -> ballot,
+        // waves -> LDS counter, workgroup -> global
         const u64 m = ballot(is_dup);
-        if (lane_id() == 0 && m) g_atomic_add_i64(d.ctr_dups, (int64_t)popc64(m));
+        if (lane_id() == 0 && m) lds_add_u32(block_count, (u32)popc64(m));
     }
+    block_sync();
+    if (thread_id() == 0 && *block_count) g_atomic_add_i64(d.ctr_dups, (int64_t)*block_count);
     if (gid == 0) g_atomic_add_i64(d.ctr_total, (int64_t)d.n);
 }
 
