@@ -60,6 +60,10 @@ class Params(C.Structure):
         ("insert_size_max", C.c_int32),
         ("umi_len1", C.c_int32), ("umi_len2", C.c_int32), ("umi_skip", C.c_int32),
         ("n_adapter_fasta", C.c_int32), ("adapter_fasta", C.POINTER(C.c_char_p)),
+        ("overrep_enabled", C.c_int32), ("overrep_sampling", C.c_int32),
+        ("eval_seq_len1", C.c_int32), ("eval_seq_len2", C.c_int32),
+        ("n_overrep_seqs1", C.c_int32), ("n_overrep_seqs2", C.c_int32),
+        ("overrep_seqs1", C.POINTER(C.c_char_p)), ("overrep_seqs2", C.POINTER(C.c_char_p)),
         ("reserved", C.c_int32 * 4),
     ]
 
@@ -142,6 +146,25 @@ def set_adapter_fasta(params, seqs):
     return params
 
 
+def set_overrep(params, seqs1, seqs2, eval_len1, eval_len2, sampling=20):
+    """attach the overrepresentation-analysis seeds (Options::overRepSeqs1/2, sorted) to a Params"""
+    a1 = (C.c_char_p * max(1, len(seqs1)))(*seqs1)
+    a2 = (C.c_char_p * max(1, len(seqs2)))(*seqs2)
+    params._overrep_keepalive = (a1, a2, list(seqs1), list(seqs2))
+    params.overrep_enabled = 1
+    params.overrep_sampling = sampling
+    params.eval_seq_len1, params.eval_seq_len2 = eval_len1, eval_len2
+    params.n_overrep_seqs1, params.n_overrep_seqs2 = len(seqs1), len(seqs2)
+    params.overrep_seqs1 = C.cast(a1, C.POINTER(C.c_char_p))
+    params.overrep_seqs2 = C.cast(a2, C.POINTER(C.c_char_p))
+    return params
+
+
+def overrep_lists(params):
+    return ([params.overrep_seqs1[i] for i in range(params.n_overrep_seqs1)],
+            [params.overrep_seqs2[i] for i in range(params.n_overrep_seqs2)])
+
+
 def adapter_fasta_list(params):
     return [params.adapter_fasta[i] for i in range(params.n_adapter_fasta)]
 
@@ -156,6 +179,8 @@ class CounterLayout(C.Structure):
         ("stats", C.c_int64 * 4),
         ("st_reads", C.c_int64), ("st_length_sum", C.c_int64), ("st_qual_hist", C.c_int64),
         ("st_kmer", C.c_int64), ("st_cycle", C.c_int64), ("st_size", C.c_int64),
+        ("n_overrep", C.c_int64 * 4), ("eval_len", C.c_int64 * 4),
+        ("overrep_count", C.c_int64 * 4), ("overrep_dist", C.c_int64 * 4),
     ]
 
 

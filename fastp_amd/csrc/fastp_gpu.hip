@@ -27,6 +27,16 @@ extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) 
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     hash_body(*kernel_args(&a), fq_lds);
 }
+extern "C" __global__ void __launch_bounds__(256) fq_ovr_pass_kernel(OvrArgs o) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    ovr_pass_body(o, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(64) fq_ovr_scan_kernel(OvrArgs o, int nblocks) { ovr_scan_body(o, nblocks); }
+extern "C" __global__ void __launch_bounds__(256) fq_ovr_tasks_kernel(OvrArgs o) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    ovr_tasks_body(o, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_ovr_count_kernel(OvrArgs o) { ovr_count_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(1024) fq_dup_resolve_kernel(DupArgs d) {
@@ -70,6 +80,15 @@ struct fastp_gpu_ctx {
     u64* d_table = nullptr; size_t table_cap = 0;
     u8* d_need = nullptr; size_t need_cap = 0;
     u8* d_dupflag = nullptr; size_t dupflag_cap = 0;   // --dedup: per-unit duplicate decision
+    // overrepresentation analysis
+    u32* d_ovr_table[2] = {nullptr, nullptr};
+    u8* d_ovr_sym[2] = {nullptr, nullptr};
+    int* d_ovr_len[2] = {nullptr, nullptr};
+    u64* d_post_seen = nullptr;
+    u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
+    uint64_t units_seen = 0;                               // units submitted so far (the pre-filtering Stats' mReads)
+    std::vector<std::string> ovr_strings[2];
+    std::vector<const char*> ovr_ptrs[2];
     // staging for submit_host
     void* d_stage = nullptr; size_t stage_cap = 0;
     u64* d_phase = nullptr;   // optional per-phase cycle counters (FASTP_GPU_PHASE_TIMING=1)
@@ -126,7 +145,9 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     drain_events(ctx);
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
-                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase};
+                    ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
+                    ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -150,6 +171,16 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         for (int i = 0; i < params->n_adapter_fasta; i++) ctx->fasta_strings.push_back(params->adapter_fasta[i] ? params->adapter_fasta[i] : "");
         for (auto& f : ctx->fasta_strings) ctx->fasta_ptrs.push_back(f.c_str());
         ctx->params.adapter_fasta = ctx->fasta_ptrs.data();
+    }
+    if (params->overrep_enabled) {  // own copies of the seed strings
+        const char* const* lists[2] = {params->overrep_seqs1, params->overrep_seqs2};
+        const int ns[2] = {params->n_overrep_seqs1, params->n_overrep_seqs2};
+        for (int m = 0; m < 2; m++) {
+            for (int i = 0; i < ns[m] && lists[m]; i++) ctx->ovr_strings[m].push_back(lists[m][i] ? lists[m][i] : "");
+            for (auto& q : ctx->ovr_strings[m]) ctx->ovr_ptrs[m].push_back(q.c_str());
+        }
+        ctx->params.overrep_seqs1 = ctx->ovr_ptrs[0].data();
+        ctx->params.overrep_seqs2 = ctx->ovr_ptrs[1].data();
     }
     ctx->device = device;
     std::string err;
@@ -183,7 +214,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
     mp = mp / ctx->L.P * ctx->L.P;
     ctx->max_pairs_per_launch = (int)mp;
-    fastp_gpu_counter_layout_for(ctx->dp.cycles, ctx->dp.isize_max, &ctx->cl);
+    fastp_gpu_counter_layout_for_params(&ctx->params, &ctx->cl);
     if (env_int("FASTP_GPU_VERBOSE", 0))
         fprintf(stderr, "fastp_gpu: tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch\n", ctx->L.P,
                 ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks, ctx->max_pairs_per_launch);
@@ -216,6 +247,15 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_RC(upload((void**)&ctx->d_posum, ctx->luts.dup_posum.data(), ctx->luts.dup_posum.size() * 8));
     CREATE_RC(upload((void**)&ctx->d_fasta_words, ctx->luts.fasta_words.data(), ctx->luts.fasta_words.size() * 4));
     CREATE_RC(upload((void**)&ctx->d_fasta_len, ctx->luts.fasta_len.data(), ctx->luts.fasta_len.size() * 4));
+    if (ctx->dp.overrep) {
+        for (int m = 0; m < 2; m++) {
+            CREATE_RC(upload((void**)&ctx->d_ovr_table[m], ctx->luts.ovr_table[m].data(), ctx->luts.ovr_table[m].size() * 4));
+            CREATE_RC(upload((void**)&ctx->d_ovr_sym[m], ctx->luts.ovr_sym[m].data(), ctx->luts.ovr_sym[m].size()));
+            CREATE_RC(upload((void**)&ctx->d_ovr_len[m], ctx->luts.ovr_len[m].data(), ctx->luts.ovr_len[m].size() * 4));
+        }
+        const uint64_t zero = 0;
+        CREATE_RC(upload((void**)&ctx->d_post_seen, &zero, sizeof(zero)));
+    }
     {
         std::vector<int64_t> zero((size_t)ctx->cl.total, 0);
         zero[0] = FASTP_GPU_ABI_VERSION;
@@ -407,6 +447,51 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         rc = launch_dup(nullptr);
         if (rc) return rc;
     }
+
+    if (ctx->dp.overrep) {  // Stats::statRead's overrepresentation analysis (stats.cpp:270-288)
+        OvrArgs o;
+        memset(&o, 0, sizeof(o));
+        o.n = n;
+        o.paired = ctx->dp.paired;
+        o.dedup = ctx->dp.dedup;
+        o.sampling = ctx->dp.overrep_sampling;
+        o.pre_mod = (u32)(ctx->units_seen % (uint64_t)o.sampling);
+        o.sw_g = ctx->dp.sw_g;
+        o.qw_g = ctx->dp.qw_g;
+        for (int m = 0; m < 2; m++) { o.seq[m] = a.seq[m]; o.qual[m] = a.qual[m]; o.len[m] = a.len[m]; o.res[m] = a.res[m]; }
+        const int nb = (n + 255) / 256;
+        const int task_cap = 4 * (n / o.sampling + 2);
+        rc = ensure(ctx, (void**)&ctx->d_ovr_work, &ctx->ovr_work_cap, ((size_t)2 * nb + 1 + task_cap) * 4);
+        if (rc) return rc;
+        o.blocksum = ctx->d_ovr_work;
+        o.blockbase = ctx->d_ovr_work + nb;
+        o.n_tasks = ctx->d_ovr_work + 2 * nb;
+        o.tasks = ctx->d_ovr_work + 2 * nb + 1;
+        o.task_cap = task_cap;
+        o.post_seen = ctx->d_post_seen;
+        for (int m = 0; m < 2; m++) {
+            OvrMate& M = o.mate[m];
+            M.n_seeds = m == 0 ? ctx->params.n_overrep_seqs1 : (ctx->dp.paired ? ctx->params.n_overrep_seqs2 : 0);
+            M.eval_len = m == 0 ? ctx->params.eval_seq_len1 : ctx->params.eval_seq_len2;
+            for (int k = 0; k < OVR_STEPS; k++) { M.steps[k] = ctx->luts.ovr_steps[m][k]; M.pw[k] = ctx->luts.ovr_pw[m][k]; }
+            M.table = ctx->d_ovr_table[m];
+            M.table_mask = (u32)(ctx->luts.ovr_table[m].size() / 2 - 1);
+            M.seed_sym = ctx->d_ovr_sym[m];
+            M.seed_len = ctx->d_ovr_len[m];
+        }
+        o.ctr = ctx->d_ctr;
+        for (int k = 0; k < 4; k++) { o.o_count[k] = cl.overrep_count[k]; o.o_dist[k] = cl.overrep_dist[k]; }
+        HIP_TRY(ctx, hipMemsetAsync(o.n_tasks, 0, 4, st));
+        hipLaunchKernelGGL(fq_ovr_pass_kernel, dim3(nb), dim3(256), 16, st, o);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_ovr_scan_kernel, dim3(1), dim3(64), 0, st, o, nb);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_ovr_tasks_kernel, dim3(nb), dim3(256), 64, st, o);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_ovr_count_kernel, dim3((task_cap + 255) / 256), dim3(256), 0, st, o);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->units_seen += (uint64_t)n;
     return FASTP_GPU_OK;
 }
 

@@ -2062,4 +2062,142 @@ FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
     if (gid == 0) g_atomic_add_i64(d.ctr_total, (int64_t)d.n);
 }
 
+
+// ---------------------------------------------------------------------------
+// Overrepresentation analysis (Stats::statRead stats.cpp:270-288), after the fused kernel.
+// Every `sampling`-th read a Stats object sees is analysed; "sees" is a position in the run's
+// read stream: the unit index for the pre-filtering Stats, the rank among the units that are
+// written out for the post-filtering ones.  Four small kernels:
+//   ovr_pass  : which units reach the post-filtering Stats (from the result records) -> count per
+//               256-unit block
+//   ovr_scan  : running rank at the start of every block, continued across launches
+//   ovr_tasks : the sampled (unit, mate, pre/post) reads, appended to a dense task list
+//   ovr_count : one lane per task: the five step lengths slide over the read with a rolling
+//               hash; a window whose key is in the seed table (and compares equal) is a hit
+// ---------------------------------------------------------------------------
+FQ_DEV bool ovr_unit_passes(const OvrArgs& o, int g) {
+    // the unit is routed to out1[/out2] and statRead by the post-filtering Stats
+    // (peprocessor.cpp:575-591, seprocessor.cpp:280-286)
+    const u32 w1 = o.res[0][(size_t)g * 3 + 1];
+    u32 code = w1 & 0xFFu, flags = (w1 >> 8) & 0xFFu;
+    if (o.paired) {
+        const u32 w2 = o.res[1][(size_t)g * 3 + 1];
+        code |= w2 & 0xFFu;
+        flags |= (w2 >> 8) & (u32)RS_NULL;
+    }
+    if (flags & RS_NULL) return false;
+    if (o.dedup && (flags & RS_DUP)) return false;
+    return code == 0u;
+}
+
+FQ_DEV void ovr_pass_body(const OvrArgs& o, u32* lds) {
+    if (thread_id() == 0) lds[0] = 0;
+    block_sync();
+    const int g = block_id() * block_threads() + thread_id();
+    const bool pass = g < o.n && ovr_unit_passes(o, g);
+    const u64 m = ballot(pass);
+    if (lane_id() == 0 && m) lds_add_u32(&lds[0], (u32)popc64(m));
+    block_sync();
+    if (thread_id() == 0) o.blocksum[block_id()] = lds[0];
+}
+
+FQ_DEV void ovr_scan_body(const OvrArgs& o, int nblocks) {
+    if (block_id() != 0 || thread_id() != 0) return;
+    u64 run = *o.post_seen;
+    for (int b = 0; b < nblocks; b++) {
+        o.blockbase[b] = (u32)(run % (u64)o.sampling);
+        run += o.blocksum[b];
+    }
+    *o.post_seen = run;
+}
+
+FQ_DEV void ovr_tasks_body(const OvrArgs& o, u32* lds) {
+    const int g = block_id() * block_threads() + thread_id();
+    const bool pass = g < o.n && ovr_unit_passes(o, g);
+    // rank of this unit among the passing ones: block base + waves before + lanes before
+    const u64 m = ballot(pass);
+    const int wave = wave_id(), nw = block_threads() >> 6;
+    if (lane_id() == 0) lds[wave] = (u32)popc64(m);
+    block_sync();
+    u32 before = 0;
+    for (int w = 0; w < nw; w++)
+        if (w < wave) before += lds[w];
+    before += (u32)popc64(m & ((1ull << lane_id()) - 1ull));
+    if (g >= o.n) return;
+    const int mates = o.paired ? 2 : 1;
+    const bool pre = (o.pre_mod + (u32)g) % (u32)o.sampling == 0u;             // mReads % sampling == 0 (:272)
+    const bool post = pass && (o.blockbase[block_id()] + before) % (u32)o.sampling == 0u;
+    const int k = ((pre ? 1 : 0) + (post ? 1 : 0)) * mates;
+    if (!k) return;
+    u32 slot = g_atomic_add_u32(o.n_tasks, (u32)k);
+    for (int which = 0; which < 2; which++) {
+        if (!(which ? post : pre)) continue;
+        for (int mt = 0; mt < mates; mt++) {
+            if (slot < (u32)o.task_cap) o.tasks[slot] = ((u32)g << 2) | ((u32)mt << 1) | (u32)which;
+            slot++;
+        }
+    }
+}
+
+FQ_DEV u32 ovr_sym(const u32* srow, const u8* qrow, int j) {  // 0..3 = A,T,C,G ; 4 = N
+    return (qrow[j] & 0x80u) ? 4u : ((srow[j >> 4] >> ((j & 15) * 2)) & 3u);
+}
+
+FQ_DEV void ovr_count_body(const OvrArgs& o) {
+    const int t = block_id() * block_threads() + thread_id();
+    const int nt = (int)imin((int)*o.n_tasks, o.task_cap);
+    if (t >= nt) return;
+    const u32 task = o.tasks[t];
+    const int g = (int)(task >> 2), mt = (int)((task >> 1) & 1u), post = (int)(task & 1u);
+    const OvrMate& M = o.mate[mt];
+    if (M.n_seeds == 0) return;
+    int f = 0, len = (int)o.len[mt][g];
+    if (post) {  // the read as it is written out: [front, front + len)
+        const u32 w0 = o.res[mt][(size_t)g * 3];
+        f = (int)(w0 & 0xFFFFu);
+        len = (int)(w0 >> 16);
+    }
+    const u32* srow = o.seq[mt] + (size_t)g * o.sw_g;
+    const u8* qrow = (const u8*)(o.qual[mt] + (size_t)g * o.qw_g);
+    const int slot = mt * 2 + post;  // PRE1=0 POST1=1 PRE2=2 POST2=3
+    int64_t* cnt = o.ctr + o.o_count[slot];
+    int64_t* dist = o.ctr + o.o_dist[slot];
+    for (int s = 0; s < OVR_STEPS; s++) {
+        const int L = M.steps[s];
+        if (L <= 0 || len - L <= 0) continue;
+        const u32 salt = (u32)L * OVR_SALT_MUL, pw = M.pw[s];
+        int i = 0;
+        u32 h = 0;
+        bool fresh = true;  // h has to be computed from scratch for the window at i
+        while (i < len - L) {  // for (i = 0; i < len - step; i++) (:276)
+            if (fresh) {
+                h = 0;
+                for (int k = 0; k < L; k++) h = h * OVR_HASH_MUL + ovr_sym(srow, qrow, f + i + k) + 1u;
+                fresh = false;
+            }
+            const u32 key = h ^ salt;
+            int hit = -1;
+            for (u32 sl = (key * OVR_SALT_MUL) & M.table_mask;; sl = (sl + 1) & M.table_mask) {
+                const u32 id1 = M.table[2 * sl + 1];
+                if (id1 == 0u) break;
+                if (M.table[2 * sl] == key && M.seed_len[id1 - 1] == L) {
+                    const u8* sd = M.seed_sym + (size_t)(id1 - 1) * OVR_SEED_STRIDE;
+                    bool same = true;
+                    for (int k = 0; k < L && same; k++) same = sd[k] == (u8)ovr_sym(srow, qrow, f + i + k);
+                    if (same) { hit = (int)id1 - 1; break; }
+                }
+            }
+            if (hit >= 0) {  // mOverRepSeq[seq]++, the covered positions of mOverRepSeqDist, i += step (:279-284)
+                g_atomic_add_i64(&cnt[hit], 1);
+                for (int pp = i; pp < i + L && pp < M.eval_len; pp++) g_atomic_add_i64(&dist[(size_t)hit * M.eval_len + pp], 1);
+                i += L + 1;
+                fresh = true;
+            } else {  // slide the window by one base
+                h = (h - (ovr_sym(srow, qrow, f + i) + 1u) * pw) * OVR_HASH_MUL + ovr_sym(srow, qrow, f + i + L) + 1u;
+                i++;
+            }
+        }
+    }
+}
+
 }  // namespace fq

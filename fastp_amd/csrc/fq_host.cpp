@@ -4,6 +4,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace fq {
 
 u32 magic_for(u32 d) { return (u32)((0x100000000ull + d - 1) / d); }
@@ -151,6 +153,51 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.umi_skip = in.umi_skip > 0 ? in.umi_skip : 0;
     p.need_overlap = p.paired && (p.adapter_enabled || p.correction);
     p.stats_one_pass = !p.correction && !p.merge && !p.cut_front && !p.trim_front1 && !p.trim_front2 && !p.umi_len1 && !p.umi_len2;
+
+    // ---- overrepresentation analysis seeds -> hash tables ----
+    p.overrep = in.overrep_enabled != 0;
+    p.overrep_sampling = in.overrep_sampling;
+    for (int m = 0; m < 2; m++) { luts.ovr_table[m].clear(); luts.ovr_sym[m].clear(); luts.ovr_len[m].clear(); }
+    if (p.overrep) {
+        if (in.merge || in.correction) { err = "overrepresentation analysis together with merge / correction is not on the device path"; return FASTP_GPU_E_UNSUPPORTED; }
+        if (in.overrep_sampling <= 0) { err = "overrep_sampling must be positive"; return FASTP_GPU_E_INVALID; }
+        const char* const* lists[2] = {in.overrep_seqs1, in.overrep_seqs2};
+        const int ns[2] = {in.n_overrep_seqs1, p.paired ? in.n_overrep_seqs2 : 0};
+        const int evl[2] = {in.eval_seq_len1, in.eval_seq_len2};
+        for (int m = 0; m < 2; m++) {
+            if (ns[m] < 0 || (ns[m] > 0 && !lists[m])) { err = "overrep seed list missing"; return FASTP_GPU_E_INVALID; }
+            const int steps[OVR_STEPS] = {10, 20, 40, 100, std::min(150, evl[m] - 2)};  // stats.cpp:273
+            for (int s2 = 0; s2 < OVR_STEPS; s2++) {
+                luts.ovr_steps[m][s2] = steps[s2];
+                u32 pw = 1;
+                for (int k = 1; k < steps[s2]; k++) pw *= OVR_HASH_MUL;
+                luts.ovr_pw[m][s2] = pw;
+            }
+            u32 slots = 16;
+            while (slots < (u32)ns[m] * 4u) slots <<= 1;
+            luts.ovr_table[m].assign((size_t)slots * 2, 0u);
+            luts.ovr_sym[m].assign((size_t)std::max(ns[m], 1) * OVR_SEED_STRIDE, 0);
+            luts.ovr_len[m].assign((size_t)std::max(ns[m], 1), 0);
+            for (int i = 0; i < ns[m]; i++) {
+                const char* q = lists[m][i];
+                const int L = (int)strlen(q);
+                if (L <= 0 || L > 150) { err = "overrep seed length out of range"; return FASTP_GPU_E_INVALID; }
+                u32 h = 0;
+                for (int k = 0; k < L; k++) {
+                    int sy = base_code(q[k]);
+                    if (sy < 0) { if (q[k] == 'N') sy = 4; else { err = "overrep seed with a letter outside ACGTN"; return FASTP_GPU_E_INVALID; } }
+                    luts.ovr_sym[m][(size_t)i * OVR_SEED_STRIDE + k] = (u8)sy;
+                    h = h * OVR_HASH_MUL + (u32)(sy + 1);
+                }
+                luts.ovr_len[m][i] = L;
+                const u32 key = h ^ ((u32)L * OVR_SALT_MUL);
+                u32 slot = (key * OVR_SALT_MUL) & (slots - 1);
+                while (luts.ovr_table[m][2 * slot + 1] != 0) slot = (slot + 1) & (slots - 1);
+                luts.ovr_table[m][2 * slot] = key;
+                luts.ovr_table[m][2 * slot + 1] = (u32)i + 1;
+            }
+        }
+    }
 
     // ---- LUTs: the reference's floating point thresholds, evaluated on the host ----
     const int n = p.cycles + 2;  // a merged read can be as long as both mates (cycles = 2*max_len in merge mode)
@@ -356,6 +403,24 @@ void fastp_gpu_counter_layout_for(int cycles, int insert_size_max, fastp_gpu_cou
     L->st_cycle = 2 + 128 + 1024;
     L->st_size = L->st_cycle + 34 * (int64_t)cycles;
     for (int s = 0; s < 4; s++) { L->stats[s] = o; o += L->st_size; }
+    for (int s = 0; s < 4; s++) { L->overrep_count[s] = o; L->overrep_dist[s] = o; }
+    L->total = o;
+}
+
+void fastp_gpu_counter_layout_for_params(const fastp_gpu_params* p, fastp_gpu_counter_layout* L) {
+    fastp_gpu_counter_layout_for(fastp_gpu_cycles_for(p), p->insert_size_max, L);
+    if (!p->overrep_enabled) return;
+    int64_t o = L->total;
+    for (int s = 0; s < 4; s++) {  // PRE1, POST1 use read-1 seeds; PRE2, POST2 read-2 seeds (stats.cpp:956-971)
+        const bool r2 = s >= 2;
+        L->n_overrep[s] = r2 ? p->n_overrep_seqs2 : p->n_overrep_seqs1;
+        L->eval_len[s] = r2 ? p->eval_seq_len2 : p->eval_seq_len1;
+        if (!p->paired && r2) { L->n_overrep[s] = 0; L->eval_len[s] = 0; }
+        L->overrep_count[s] = o;
+        o += L->n_overrep[s];
+        L->overrep_dist[s] = o;
+        o += L->n_overrep[s] * L->eval_len[s];
+    }
     L->total = o;
 }
 

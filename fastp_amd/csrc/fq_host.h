@@ -18,6 +18,12 @@ struct HostLuts {
     std::vector<u64> dup_posum;      // [(2*max_len+1)*bufnum]
     std::vector<u32> fasta_words;    // [n_fasta][ADAPT_WORDS]
     std::vector<int> fasta_len;      // [n_fasta]
+    // overrepresentation analysis seeds, per mate
+    std::vector<u32> ovr_table[2];   // pairs {key, index + 1}
+    std::vector<u8> ovr_sym[2];      // [n][OVR_SEED_STRIDE]
+    std::vector<int> ovr_len[2];
+    int ovr_steps[2][OVR_STEPS];
+    u32 ovr_pw[2][OVR_STEPS];
 };
 
 // device geometry the layout is sized for

@@ -79,6 +79,7 @@ struct DevParams {
     int isize_max;
     int umi_len1, umi_len2, umi_skip;
     int need_overlap;       // adapter_enabled || correction  (peprocessor.cpp:438,443)
+    int overrep, overrep_sampling;  // OverrepresentedSequenceAnasysOptions (-p, -P)
     int stats_one_pass;     // no option can move or edit a kept base (no front trim, no correction):
                             // one Stats pass classifies each base as kept / dropped (see phase_stats)
 };
@@ -150,6 +151,41 @@ enum {
     MISC_STAT_READS = 108,      // [4]
     MISC_STAT_LENSUM = 112,     // [4]
     MISC_ISIZE = 116,           // [isize_max+1]
+};
+
+// ---- overrepresentation analysis (Stats::statRead stats.cpp:270-288), kernels fq_ovr_* ----
+enum { OVR_STEPS = 5, OVR_SEED_STRIDE = 152 };
+static const u32 OVR_HASH_MUL = 0x01000193u;   // odd: the rolling hash is a polynomial mod 2^32
+static const u32 OVR_SALT_MUL = 0x9E3779B1u;   // key = hash ^ (length * OVR_SALT_MUL)
+
+struct OvrMate {                 // one mate's seed set (Options::overRepSeqs1 / overRepSeqs2)
+    int n_seeds;
+    int eval_len;                // Stats::mEvaluatedSeqLen
+    int steps[OVR_STEPS];        // {10, 20, 40, 100, min(150, eval_len - 2)}
+    u32 pw[OVR_STEPS];           // OVR_HASH_MUL ^ (step - 1)
+    const u32* table;            // open addressing, pairs {key, seed index + 1}; index 0 = empty
+    u32 table_mask;              // slots - 1
+    const u8* seed_sym;          // [n_seeds][OVR_SEED_STRIDE] symbols 0..4 (A T C G N)
+    const int* seed_len;
+};
+
+struct OvrArgs {
+    int n, paired, dedup, sampling;
+    u32 pre_mod;                 // (reads this Stats object saw before this launch) % sampling
+    int sw_g, qw_g;              // batch row strides in dwords
+    const u32* seq[2];
+    const u32* qual[2];
+    const u16* len[2];
+    const u32* res[2];           // result records of this launch (3 dwords each)
+    u32* blocksum;               // [ceil(n/256)] units of the block that reach the post-filtering Stats
+    u32* blockbase;              // [ceil(n/256)] (units that reached them before the block) % sampling
+    u64* post_seen;              // running total across launches
+    u32* tasks;                  // [(unit << 2) | mate << 1 | post]
+    u32* n_tasks;
+    int task_cap;
+    OvrMate mate[2];
+    int64_t* ctr;
+    int64_t o_count[4], o_dist[4];   // fastp_gpu_counter_layout::overrep_count / overrep_dist
 };
 
 struct KernelArgs {

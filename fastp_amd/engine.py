@@ -16,7 +16,7 @@ _LIBS: dict[str, C.CDLL] = {}
 
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
-    "fastp_gpu_counter_layout_for", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
+    "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
     "fastp_gpu_pack_reads", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
@@ -46,6 +46,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.fastp_gpu_cycles_for.restype = C.c_int
     L.fastp_gpu_cycles_for.argtypes = [C.POINTER(abi.Params)]
     L.fastp_gpu_counter_layout_for.argtypes = [C.c_int, C.c_int, C.POINTER(abi.CounterLayout)]
+    L.fastp_gpu_counter_layout_for_params.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.CounterLayout)]
+    L.fastp_gpu_counter_layout_for_params.restype = None
     L.fastp_gpu_create.restype = C.c_int
     L.fastp_gpu_create.argtypes = [C.POINTER(abi.Params), C.c_int, C.POINTER(C.c_void_p)]
     L.fastp_gpu_destroy.argtypes = [C.c_void_p]
@@ -76,7 +78,7 @@ def load_library(path: str | None = None) -> C.CDLL:
 def counter_layout(params: abi.Params, lib=None) -> abi.CounterLayout:
     L = lib or load_library()
     lay = abi.CounterLayout()
-    L.fastp_gpu_counter_layout_for(L.fastp_gpu_cycles_for(C.byref(params)), params.insert_size_max, C.byref(lay))
+    L.fastp_gpu_counter_layout_for_params(C.byref(params), C.byref(lay))
     return lay
 
 

@@ -129,6 +129,17 @@ typedef struct fastp_gpu_params {
     int32_t n_adapter_fasta;
     const char* const* adapter_fasta;
 
+    /* OverrepresentedSequenceAnasysOptions (-p / -P, options.h:363-365; Stats::statRead
+     * stats.cpp:270-288).  The seed sequences are what Evaluator::computeOverRepSeq left in
+     * Options::overRepSeqs1/2 (host logic), in std::map order; eval_seq_lenN = Options::seqLenN
+     * (Evaluator::computeSeqLen).  Letters A,C,G,T,N.  Not available together with merge or
+     * correction (FASTP_GPU_E_UNSUPPORTED). */
+    int32_t overrep_enabled, overrep_sampling;
+    int32_t eval_seq_len1, eval_seq_len2;
+    int32_t n_overrep_seqs1, n_overrep_seqs2;
+    const char* const* overrep_seqs1;
+    const char* const* overrep_seqs2;
+
     int32_t reserved[4];
 } fastp_gpu_params;
 
@@ -268,6 +279,13 @@ typedef struct fastp_gpu_counter_layout {
     int64_t st_kmer;          /* [1024] mKmer (the used half, stats.cpp:45)     */
     int64_t st_cycle;         /* [34*cycles]                                    */
     int64_t st_size;
+    /* overrepresentation analysis (absolute offsets, one pair per Stats slot):
+     * mOverRepSeq counts [n_overrep[slot]] and mOverRepSeqDist [n_overrep[slot]][eval_len[slot]]
+     * in the seed order of the parameter block; all zero-sized without overrep_enabled */
+    int64_t n_overrep[4];
+    int64_t eval_len[4];
+    int64_t overrep_count[4];
+    int64_t overrep_dist[4];
 } fastp_gpu_counter_layout;
 
 /* per-cycle capacity of the Stats slots: max_len, or 2*max_len in merge mode
@@ -275,6 +293,8 @@ typedef struct fastp_gpu_counter_layout {
  * on demand, Stats::extendBuffer stats.cpp:65-83) */
 int fastp_gpu_cycles_for(const fastp_gpu_params* params);
 void fastp_gpu_counter_layout_for(int cycles, int insert_size_max, fastp_gpu_counter_layout* out);
+/* the layout an engine created from `params` uses (adds the overrepresentation arrays) */
+void fastp_gpu_counter_layout_for_params(const fastp_gpu_params* params, fastp_gpu_counter_layout* out);
 
 /* ---- engine -------------------------------------------------------------- */
 typedef struct fastp_gpu_ctx fastp_gpu_ctx;

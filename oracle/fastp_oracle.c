@@ -43,6 +43,22 @@ void fastp_oracle_counter_layout(int cycles, int insert_size_max, fastp_gpu_coun
     L->st_cycle = 2 + 128 + 1024;
     L->st_size = L->st_cycle + 34 * (int64_t)max_len;
     for (int s = 0; s < 4; s++) { L->stats[s] = o; o += L->st_size; }
+    for (int s = 0; s < 4; s++) { L->overrep_count[s] = o; L->overrep_dist[s] = o; }
+    L->total = o;
+}
+
+void fastp_oracle_counter_layout_params(const fastp_gpu_params* p, fastp_gpu_counter_layout* L) {
+    fastp_oracle_counter_layout(fastp_oracle_cycles_for(p), p->insert_size_max, L);
+    if (!p->overrep_enabled) return;
+    int64_t o = L->total;
+    for (int s = 0; s < 4; s++) { /* Stats::initOverRepSeq stats.cpp:956-971: read-2 Stats use overRepSeqs2 */
+        const int r2 = s >= 2;
+        L->n_overrep[s] = r2 ? p->n_overrep_seqs2 : p->n_overrep_seqs1;
+        L->eval_len[s] = r2 ? p->eval_seq_len2 : p->eval_seq_len1;
+        if (!p->paired && r2) { L->n_overrep[s] = 0; L->eval_len[s] = 0; }
+        L->overrep_count[s] = o; o += L->n_overrep[s];
+        L->overrep_dist[s] = o;  o += L->n_overrep[s] * L->eval_len[s];
+    }
     L->total = o;
 }
 
@@ -591,6 +607,9 @@ static void orc_stat_read(const fastp_gpu_counter_layout* L, int64_t* st, const 
 /* ------------------------------------------------------------------------ */
 /* the engine object                                                         */
 /* ------------------------------------------------------------------------ */
+struct fastp_oracle;
+static void orc_stat_read_slot(struct fastp_oracle* o, int slot, const char* seqstr, const char* qualstr, int len);
+
 struct fastp_oracle {
     fastp_gpu_params p;
     char adapter1[FASTP_GPU_MAX_ADAPTER_LEN + 1];
@@ -599,6 +618,9 @@ struct fastp_oracle {
     int n_fasta;          /* AdapterOptions::seqsInFasta (options.h:213) */
     char** fasta;
     int* fasta_len;
+    int n_ovr[2];         /* Options::overRepSeqs1/2 (options.h:364-365), map order */
+    char** ovr[2];
+    int* ovr_len[2];
     fastp_gpu_counter_layout L;
     int64_t* ctr;
     orc_dup* dup;
@@ -633,7 +655,21 @@ fastp_oracle* fastp_oracle_create(const fastp_gpu_params* params) {
         }
     }
     o->p.adapter_fasta = (const char* const*)o->fasta;
-    fastp_oracle_counter_layout(fastp_oracle_cycles_for(params), params->insert_size_max, &o->L);
+    if (params->overrep_enabled) {
+        const char* const* lists[2] = {params->overrep_seqs1, params->overrep_seqs2};
+        const int ns[2] = {params->n_overrep_seqs1, params->paired ? params->n_overrep_seqs2 : 0};
+        for (int m = 0; m < 2; m++) {
+            o->n_ovr[m] = ns[m];
+            o->ovr[m] = (char**)calloc((size_t)ns[m] + 1, sizeof(char*));
+            o->ovr_len[m] = (int*)calloc((size_t)ns[m] + 1, sizeof(int));
+            for (int i = 0; i < ns[m]; i++) {
+                o->ovr_len[m][i] = (int)strlen(lists[m][i]);
+                o->ovr[m][i] = (char*)malloc((size_t)o->ovr_len[m][i] + 1);
+                memcpy(o->ovr[m][i], lists[m][i], (size_t)o->ovr_len[m][i] + 1);
+            }
+        }
+    }
+    fastp_oracle_counter_layout_params(params, &o->L);
     o->ctr = (int64_t*)calloc((size_t)o->L.total, sizeof(int64_t));
     o->ctr[0] = FASTP_GPU_ABI_VERSION;
     o->ctr[1] = o->L.cycles;
@@ -649,6 +685,11 @@ void fastp_oracle_destroy(fastp_oracle* o) {
     if (!o) return;
     if (o->dup) { free(o->dup->buf); free(o->dup->primes); free(o->dup); }
     free(o->ctr);
+    for (int m = 0; m < 2; m++) {
+        for (int i = 0; i < o->n_ovr[m]; i++) free(o->ovr[m][i]);
+        free(o->ovr[m]);
+        free(o->ovr_len[m]);
+    }
     for (int i = 0; i < o->n_fasta; i++) free(o->fasta[i]);
     free(o->fasta);
     free(o->fasta_len);
@@ -778,12 +819,40 @@ static void orc_trim_poly_x(fastp_oracle* o, orc_read* r, fastp_gpu_read_result*
     r->len = nl;
 }
 
-static int64_t* orc_stats(fastp_oracle* o, int which) { return o->ctr + o->L.stats[which]; }
 
 static void orc_finish_result(fastp_gpu_read_result* rr, const orc_read* r, int code) {
     rr->front = (uint16_t)r->front;
     rr->len = (uint16_t)r->len;
     rr->code = (uint8_t)code;
+}
+
+/* Stats::statRead incl. the overrepresentation analysis (stats.cpp:270-288): for every
+ * `sampling`-th read THIS Stats object sees, slide the five step lengths over the read and count
+ * the substrings that are seed sequences, skipping `step` bases after a hit */
+static void orc_stat_read_slot(fastp_oracle* o, int slot, const char* seqstr, const char* qualstr, int len) {
+    int64_t* st = o->ctr + o->L.stats[slot];
+    if (o->p.overrep_enabled && o->p.overrep_sampling > 0 && st[o->L.st_reads] % o->p.overrep_sampling == 0) {
+        const int m = slot >= 2 ? 1 : 0;
+        const int evalLen = (int)o->L.eval_len[slot];
+        const int steps[5] = {10, 20, 40, 100, ORC_MIN(150, evalLen - 2)};
+        int64_t* cnt = o->ctr + o->L.overrep_count[slot];
+        int64_t* dist = o->ctr + o->L.overrep_dist[slot];
+        for (int s = 0; s < 5; s++) {
+            const int step = steps[s];
+            if (step <= 0) continue; /* substr(i, 0) is empty and never a seed; negative lengths are not modelled */
+            for (int i = 0; i < len - step; i++) {
+                int hit = -1;
+                for (int k = 0; k < o->n_ovr[m]; k++)
+                    if (o->ovr_len[m][k] == step && memcmp(o->ovr[m][k], seqstr + i, (size_t)step) == 0) { hit = k; break; }
+                if (hit >= 0) {
+                    cnt[hit]++;
+                    for (int p = i; p < step + i && p < evalLen; p++) dist[(int64_t)hit * evalLen + p]++;
+                    i += step;
+                }
+            }
+        }
+    }
+    orc_stat_read(&o->L, st, seqstr, qualstr, len);
 }
 
 /* ---- single-end loop body: seprocessor.cpp:204-296 ---------------------- */
@@ -792,7 +861,7 @@ static void orc_process_se(fastp_oracle* o, int read_index, char* seq, char* qua
     const fastp_gpu_params* p = &o->p;
     memset(rr, 0, sizeof(*rr));
     orc_read or1 = {seq, qual, len, 0};
-    orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_PRE1), or1.seq, or1.qual, or1.len); /* :210 */
+    orc_stat_read_slot(o, FASTP_GPU_STATS_PRE1, or1.seq, or1.qual, or1.len); /* :210 */
     int dedupOut = 0;
     if (o->dup) { /* :213-218 checkRead duplicate.cpp:122-134 */
         uint64_t pos[8] = {0};
@@ -821,7 +890,7 @@ static void orc_process_se(fastp_oracle* o, int read_index, char* seq, char* qua
     if (isAdapterDimer) result = FASTP_FAIL_ADAPTER_DIMER;
     orc_add_filter_result(o, result, 1); /* :278 */
     if (!dedupOut && alive && result == FASTP_PASS_FILTER) /* :280-290 */
-        orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_POST1), or1.seq, or1.qual, or1.len);
+        orc_stat_read_slot(o, FASTP_GPU_STATS_POST1, or1.seq, or1.qual, or1.len);
     if (!alive) rr->flags |= FASTP_GPU_RF_NULL;
     orc_finish_result(rr, &or1, result);
 }
@@ -907,8 +976,8 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
     const int thread0 = (batch_flags & FASTP_GPU_BATCH_STAT_ISIZE) != 0;
     orc_read or1 = {s1, q1, l1, 0}, or2 = {s2, q2, l2, 0};
 
-    orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_PRE1), or1.seq, or1.qual, or1.len); /* :393 */
-    orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_PRE2), or2.seq, or2.qual, or2.len); /* :394 */
+    orc_stat_read_slot(o, FASTP_GPU_STATS_PRE1, or1.seq, or1.qual, or1.len); /* :393 */
+    orc_stat_read_slot(o, FASTP_GPU_STATS_PRE2, or2.seq, or2.qual, or2.len); /* :394 */
 
     int dedupOut = 0;
     if (o->dup) { /* :397-402, checkPair duplicate.cpp:136-148 */
@@ -1011,7 +1080,7 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
             int result = fastp_oracle_pass_filter(p, ms, mq, mlen);
             orc_add_filter_result(o, result, 2);
             if (result == FASTP_PASS_FILTER) {
-                orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_POST1), ms, mq, mlen);
+                orc_stat_read_slot(o, FASTP_GPU_STATS_POST1, ms, mq, mlen);
                 o->ctr[o->L.merged_pairs] += 1; /* mergedCount -> addMergedPairs :688-690 */
                 rr1->flags |= FASTP_GPU_RF_MERGED; rr2->flags |= FASTP_GPU_RF_MERGED;
             }
@@ -1026,10 +1095,10 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
             if (isAdapterDimer) { code1 = code2 = FASTP_FAIL_ADAPTER_DIMER; }
             orc_add_filter_result(o, code1, 1);
             if (code1 == FASTP_PASS_FILTER && !dedupOut)
-                orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_POST1), or1.seq, or1.qual, or1.len);
+                orc_stat_read_slot(o, FASTP_GPU_STATS_POST1, or1.seq, or1.qual, or1.len);
             orc_add_filter_result(o, code2, 1);
             if (code2 == FASTP_PASS_FILTER && !dedupOut)
-                orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_POST1), or2.seq, or2.qual, or2.len);
+                orc_stat_read_slot(o, FASTP_GPU_STATS_POST1, or2.seq, or2.qual, or2.len);
             mergeProcessed = 1;
         }
     }
@@ -1040,8 +1109,8 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
         orc_add_filter_result(o, ORC_MAX(code1, code2), 2);
         if (!dedupOut && a1 && code1 == FASTP_PASS_FILTER && a2 && code2 == FASTP_PASS_FILTER) {
             if (!p->merge) { /* :588-591 */
-                orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_POST1), or1.seq, or1.qual, or1.len);
-                orc_stat_read(&o->L, orc_stats(o, FASTP_GPU_STATS_POST2), or2.seq, or2.qual, or2.len);
+                orc_stat_read_slot(o, FASTP_GPU_STATS_POST1, or1.seq, or1.qual, or1.len);
+                orc_stat_read_slot(o, FASTP_GPU_STATS_POST2, or2.seq, or2.qual, or2.len);
             }
         }
     }

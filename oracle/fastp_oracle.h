@@ -43,6 +43,7 @@ int fastp_oracle_process(fastp_oracle* o, int n, uint32_t batch_flags, int row_s
 int fastp_oracle_counters(fastp_oracle* o, int64_t* out, int64_t n);
 int fastp_oracle_cycles_for(const fastp_gpu_params* params);
 void fastp_oracle_counter_layout(int cycles, int insert_size_max, fastp_gpu_counter_layout* out);
+void fastp_oracle_counter_layout_params(const fastp_gpu_params* params, fastp_gpu_counter_layout* out);
 
 /* ---- individual functions, exported for the known-answer tests ---------- */
 typedef struct fastp_oracle_overlap {

@@ -94,6 +94,37 @@ CASES["pe_adapter_fasta"] = (True, ["-G", "--adapter_fasta", "@TMP@/adapters.fa"
                              {"insert_mean": 150.0, "polyx_frac": 0.2})
 CASES["se_adapter_fasta"] = (False, ["-G", "-a", ADAPTER_R1, "--adapter_fasta", "@TMP@/adapters.fa"],
                              _with_fasta(_se(adapter_seq_r1=ADAPTER_R1.encode())), {"insert_mean": 120.0, "polyx_frac": 0.3})
+# overrepresentation analysis (-p, -P sampling): the seeds come from the Evaluator pre-pass over the
+# input itself (host logic, fastp_amd.hostloop.evaluate_*), so the parameter block is completed
+# by finalize_params() once the input is known
+CASES["pe_overrep"] = (True, ["-G", "-p", "-P", "3"], _pe(), {"insert_mean": 90.0, "insert_sd": 30.0, "polyx_frac": 0.3})
+CASES["se_overrep"] = (False, ["-G", "-A", "-p", "-P", "2", "--cut_right"], _se(adapter_enabled=0, cut_right=1),
+                       {"insert_mean": 80.0, "insert_sd": 25.0})
+OVERREP = {"pe_overrep": 3, "se_overrep": 2}
+N_PAIRS_OVERRIDE = {"pe_overrep": 1500, "se_overrep": 1500}   # golden input size (default 500)
+
+
+class _ArrayBatch:
+    def __init__(self, seq, lens):
+        self.seq, self.lens, self.n = seq, lens, len(lens)
+
+
+def finalize_params(name, p, seq1, len1, seq2=None, len2=None):
+    """attach what the reference's Evaluator would have derived from this input"""
+    if name not in OVERREP:
+        return p
+    from fastp_amd import hostloop
+    b1 = _ArrayBatch(seq1, len1)
+    e1 = hostloop.evaluate_seq_len(b1)
+    s1 = hostloop.evaluate_overrep_seqs(b1, e1)
+    e2, s2 = 0, []
+    if seq2 is not None:
+        b2 = _ArrayBatch(seq2, len2)
+        e2 = hostloop.evaluate_seq_len(b2)
+        s2 = hostloop.evaluate_overrep_seqs(b2, e2)
+    return abi.set_overrep(p, s1, s2, e1, e2, OVERREP[name])
+
+
 # files a case's reference run needs next to its inputs
 FILES = {"pe_adapter_fasta": {"adapters.fa": FASTA_FILE}, "se_adapter_fasta": {"adapters.fa": FASTA_FILE}}
 

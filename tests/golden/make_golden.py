@@ -52,7 +52,7 @@ def main():
     for name, (paired, flags, pf, skw) in cases.CASES.items():
         if only and name not in only:
             continue
-        d = synth.synth_pairs(N_PAIRS, L=150, seed=1234, paired=paired, **skw)
+        d = synth.synth_pairs(cases.N_PAIRS_OVERRIDE.get(name, N_PAIRS), L=150, seed=1234, paired=paired, **skw)
         fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
         fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
         one(name, flags, fq1, fq2)

@@ -19,14 +19,19 @@ def load(name):
     return fq1, fq2, meta
 
 
-def params_for(name, max_len=152):
+def params_for(name, max_len=152, fq1=None, fq2=None):
     import cases
-    from fastp_amd import abi
+    from fastp_amd import abi, hostloop
     if name == "testdata_pe":
         p = abi.default_params(True, max_len)
         p.poly_g = 1  # reference auto-enables it: read names start with @A (evaluator.cpp:16-45)
         return p
-    return cases.CASES[name][2](max_len)
+    p = cases.CASES[name][2](max_len)
+    if name in cases.OVERREP:  # the Evaluator pre-pass over the input (host logic)
+        b1 = hostloop.parse_fastq(fq1)
+        b2 = hostloop.parse_fastq(fq2) if fq2 is not None else None
+        p = cases.finalize_params(name, p, b1.seq, b1.lens, b2.seq if b2 else None, b2.lens if b2 else None)
+    return p
 
 
 def umi_for(name):

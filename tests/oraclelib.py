@@ -66,6 +66,12 @@ def layout(cycles, insert_size_max):
     return lay
 
 
+def layout_for_params(params):
+    lay = abi.CounterLayout()
+    lib().fastp_oracle_counter_layout_params(C.byref(params), C.byref(lay))
+    return lay
+
+
 class Oracle:
     """One engine instance = one fastp run (Stats x4, FilterResult, Duplicate, isize hist)."""
 
@@ -74,7 +80,7 @@ class Oracle:
         self.h = lib().fastp_oracle_create(C.byref(params))
         if not self.h:
             raise RuntimeError("fastp_oracle_create failed")
-        self.layout = layout(abi.cycles_for(params), params.insert_size_max)
+        self.layout = layout_for_params(params)
 
     def close(self):
         if self.h:

@@ -27,9 +27,20 @@ def _div(a, b):
 class StatsView:
     """Stats::summarize (stats.cpp:102-182) over one Stats slot of the counter block."""
 
-    def __init__(self, ctr, lay, which):
+    def __init__(self, ctr, lay, which, params=None):
         base = lay.stats[which]
         C = int(lay.cycles)
+        # overrepresentation analysis: mOverRepSeq in map (= seed list) order
+        self.overrep = {}
+        n = int(lay.n_overrep[which])
+        if params is not None and params.overrep_enabled and n:
+            seeds = abi.overrep_lists(params)[1 if which >= 2 else 0]
+            cnt = ctr[lay.overrep_count[which]: lay.overrep_count[which] + n]
+            s = int(params.overrep_sampling)
+            thr = {10: 500, 20: 200, 40: 100, 100: 50}          # Stats::overRepPassed stats.cpp:519-533
+            for seq, c in zip(seeds, cnt):
+                if s * int(c) > thr.get(len(seq), 20):
+                    self.overrep[seq.decode()] = int(c)
         self.reads = int(ctr[base + lay.st_reads])
         self.length_sum = int(ctr[base + lay.st_length_sum])
         self.qual_hist = ctr[base + lay.st_qual_hist: base + lay.st_qual_hist + 128]
@@ -78,7 +89,7 @@ class StatsView:
             "total_reads": self.reads, "total_bases": self.bases, "q20_bases": self.q20_total,
             "q30_bases": self.q30_total, "q40_bases": self.q40_total, "total_cycles": c,
             "quality_curves": qc, "content_curves": cc, "kmer_count": kmer,
-            "overrepresented_sequences": {},
+            "overrepresented_sequences": self.overrep,
         }
 
 
@@ -102,10 +113,10 @@ def _adapter_counts(m):  # FilterResult::outputAdaptersJson filterresult.cpp:255
 def build(ctr, lay, params: abi.Params, amaps=None):
     """dict with the same keys/values as the reference JSON (minus 'command')."""
     paired = bool(params.paired)
-    pre1 = StatsView(ctr, lay, abi.STATS_PRE1)
-    post1 = StatsView(ctr, lay, abi.STATS_POST1)
-    pre2 = StatsView(ctr, lay, abi.STATS_PRE2) if paired else None
-    post2 = StatsView(ctr, lay, abi.STATS_POST2) if paired else None
+    pre1 = StatsView(ctr, lay, abi.STATS_PRE1, params)
+    post1 = StatsView(ctr, lay, abi.STATS_POST1, params)
+    pre2 = StatsView(ctr, lay, abi.STATS_PRE2, params) if paired else None
+    post2 = StatsView(ctr, lay, abi.STATS_POST2, params) if paired else None
 
     def summ(s1, s2, with_r2_len):
         reads = s1.reads + (s2.reads if s2 else 0)

@@ -46,7 +46,8 @@ def _compare(name, params, d, paired, n_expect=None):
 def test_gpu_equals_oracle(name):
     paired, flags, pf, skw = cases.CASES[name]
     d = synth.synth_pairs(20000, L=150, seed=77, paired=paired, **skw)
-    _compare(name, pf(150), d, paired)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    _compare(name, params, d, paired)
 
 
 @pytest.mark.parametrize("name", [n for n in golden_util.names()
@@ -54,7 +55,7 @@ def test_gpu_equals_oracle(name):
 def test_gpu_equals_reference_golden(name):
     """trimmed FASTQ (md5), failed_out and every JSON number the real reference produced"""
     fq1, fq2, meta = golden_util.load(name)
-    params = golden_util.params_for(name, max_len=152)
+    params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)
     eng = engines.gpu_engine(params)
     outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name))
     eng.close()

@@ -31,7 +31,8 @@ def _both(params, d, paired):
 def test_sim_records_and_counters_equal_oracle(name):
     paired, flags, pf, skw = cases.CASES[name]
     d = synth.synth_pairs(700, L=150, seed=21, paired=paired, **skw)
-    ro, rg, co, cg = _both(pf(150), d, paired)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    ro, rg, co, cg = _both(params, d, paired)
     for k, what in enumerate(("r1", "r2", "pair")):
         if ro[k] is not None:
             bad = np.nonzero(ro[k] != rg[k])[0]
@@ -45,7 +46,7 @@ def test_sim_records_and_counters_equal_oracle(name):
 @pytest.mark.parametrize("name", ["pe_default", "pe_correction", "se_adapter_cut", "testdata_pe"])
 def test_sim_matches_reference_golden(name):
     fq1, fq2, meta = golden_util.load(name)
-    params = golden_util.params_for(name, max_len=152)
+    params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)
     eng = engines.sim_engine(params)
     outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name))
     eng.close()
@@ -140,3 +141,28 @@ def test_sim_stats_work_list_overflow():
     for i in range(3):
         assert ro[i].tobytes() == rg[i].tobytes()
     assert np.array_equal(co, cg)
+
+
+def test_sim_overrep_streamed_and_split_launches(monkeypatch):
+    """overrepresentation sampling is a position in the run's read stream: feeding the reads in
+    several batches, each split into several launches, must give the oracle's one-stream counts"""
+    monkeypatch.setenv("FASTP_GPU_TILE", "32")
+    monkeypatch.setenv("FASTP_GPU_MAX_TILES_PER_BLOCK", "2")   # 3 "CUs" x 2 tiles x 32 pairs per launch
+    name = "pe_overrep"
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(900, L=150, seed=5, paired=True, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d["seq2"], d["len2"])
+    assert params.n_overrep_seqs1 > 0
+    o = oraclelib.Oracle(params)
+    g = engines.sim_engine(params)
+    o.process(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    for a, b in ((0, 250), (250, 251), (251, 900)):
+        sl = {k: v[a:b] for k, v in d.items()}
+        g.process(sl["seq1"], sl["qual1"], sl["len1"], sl["seq2"], sl["qual2"], sl["len2"])
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    lay = o.layout
+    assert co[lay.overrep_count[0]: lay.overrep_count[0] + lay.n_overrep[0]].sum() > 0
+    bad = np.nonzero(co != cg)[0]
+    assert len(bad) == 0, (bad[:10], co[bad[:10]], cg[bad[:10]])

@@ -11,7 +11,7 @@ import oraclelib
 @pytest.mark.parametrize("name", golden_util.names())
 def test_oracle_matches_reference_golden(name):
     fq1, fq2, meta = golden_util.load(name)
-    params = golden_util.params_for(name)
+    params = golden_util.params_for(name, fq1=fq1, fq2=fq2)
     eng = oraclelib.Oracle(params)
     try:
         outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name))

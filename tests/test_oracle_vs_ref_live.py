@@ -13,13 +13,13 @@ pytestmark = pytest.mark.skipif(not driver.have_reference_binary(), reason="orac
 
 
 @pytest.mark.parametrize("name", ["pe_cut_right", "pe_adapter_seq", "pe_correction", "se_adapter_cut",
-                                  "pe_polyg_polyx", "pe_adapter_fasta", "se_adapter_fasta"])
+                                  "pe_polyg_polyx", "pe_adapter_fasta", "se_adapter_fasta", "pe_overrep", "se_overrep"])
 def test_oracle_equals_reference_live(name, tmp_path):
     paired, flags, pf, skw = cases.CASES[name]
     d = synth.synth_pairs(4000, L=100, seed=99, paired=paired, **skw)   # a different length/seed than golden
     fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
     fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
-    params = pf(104)
+    params = cases.finalize_params(name, pf(104), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
     ref = driver.run_reference(flags, fq1, fq2, workdir=str(tmp_path), extra_files=cases.FILES.get(name))
     eng = oraclelib.Oracle(params)
     umi = hostloop.UmiNameEditor(*cases.UMI[name]) if name in cases.UMI else None
