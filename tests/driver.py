@@ -20,8 +20,12 @@ def have_reference_binary():
 
 
 def run_engine(engine, params, fq1: bytes, fq2: bytes | None, pack=1000, want_failed=True,
-               want_unpaired=False, stride=None, umi=None):
-    """engine: object with .process(ASCII arrays...) / .counters() / .layout"""
+               want_unpaired=False, stride=None, umi=None, cpp_host_lib=None):
+    """engine: object with .process(ASCII arrays...) / .counters() / .layout.
+    cpp_host_lib: run the string side through the C++ glue (include/fastp_gpu_host.h) of that
+    library instead of fastp_amd/hostloop.py"""
+    if cpp_host_lib is not None:
+        return _run_engine_cpp(engine, params, fq1, fq2, pack, want_failed, want_unpaired, stride, umi, cpp_host_lib)
     b1 = hostloop.parse_fastq(fq1, stride)
     b2 = hostloop.parse_fastq(fq2, b1.seq.shape[1] if stride is None else stride) if fq2 is not None else None
     if b2 is not None and b2.seq.shape[1] != b1.seq.shape[1]:
@@ -77,6 +81,37 @@ def run_reference(flags, fq1: bytes, fq2: bytes | None, want_failed=True, workdi
     res["json"] = refjson.load_reference_json(os.path.join(tmp, "r.json"))
     res["stderr"] = p.stderr.decode()
     return res
+
+
+def _run_engine_cpp(engine, params, fq1, fq2, pack, want_failed, want_unpaired, stride, umi, lib):
+    import cpphost
+    b1 = hostloop.parse_fastq(fq1, stride)
+    b2 = hostloop.parse_fastq(fq2, b1.seq.shape[1] if stride is None else stride) if fq2 is not None else None
+    if b2 is not None and b2.seq.shape[1] != b1.seq.shape[1]:
+        st = max(b1.seq.shape[1], b2.seq.shape[1])
+        b1 = hostloop.parse_fastq(fq1, st)
+        b2 = hostloop.parse_fastq(fq2, st)
+    host = cpphost.CppHost(lib, params, want_failed, want_unpaired, umi)
+    n = b1.n if b2 is None else min(b1.n, b2.n)
+    for a in range(0, n, pack):
+        e = min(n, a + pack)
+        p1 = b1.slice(a, e)
+        p2 = b2.slice(a, e) if b2 is not None else None
+        if p2 is not None:
+            r1, r2, pr, corr = engine.process(p1.seq, p1.qual, p1.lens, p2.seq, p2.qual, p2.lens)
+        else:
+            r1, r2, pr, corr = engine.process(p1.seq, p1.qual, p1.lens)
+        host.apply(p1, p2, r1, r2, pr, corr, getattr(engine, "last_adapter_events", None))
+    outs = host.outputs(b2 is not None)
+    if not want_failed:
+        outs.failed = None
+    if not want_unpaired:
+        outs.unpaired1 = outs.unpaired2 = None
+    amaps = host.adapter_maps()
+    host.close()
+    ctr = engine.counters()
+    rep = refjson.build(ctr, engine.layout, params, amaps)
+    return outs, ctr, rep
 
 
 def md5(b):

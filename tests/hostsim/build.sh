@@ -5,6 +5,6 @@ set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)
 SRC=$HERE/../../fastp_amd/csrc
 g++ -std=c++17 -O2 -g -fPIC -shared -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-variable \
-    -I"$HERE" -I"$SRC" -x c++ "$SRC/fastp_gpu.hip" "$SRC/fq_host.cpp" "$HERE/sim.cpp" \
+    -I"$HERE" -I"$SRC" -x c++ "$SRC/fastp_gpu.hip" "$SRC/fq_host.cpp" "$SRC/fq_glue.cpp" "$HERE/sim.cpp" \
     -o "$HERE/libfastp_gpu_sim.so"
 echo "built $HERE/libfastp_gpu_sim.so"

@@ -95,3 +95,13 @@ def test_pack_reads_layout_and_errors(lib):
     with pytest.raises(engine.EngineError) as e:
         engine.pack_ascii(lib, 100, d["seq1"], d["qual1"], d["len1"])
     assert e.value.code == abi.E_TOO_LONG
+
+
+def test_host_glue_library_exports_every_declared_symbol(lib):
+    """include/fastp_gpu_host.h (the C++ string side of the patched worker loop)"""
+    import cpphost
+    hdr = open(os.path.join(ROOT, "include", "fastp_gpu_host.h")).read()
+    declared = set(re.findall(r"\b(fastp_gpu_host_[a-z_]+)\s*\(", hdr))
+    assert declared == set(cpphost.EXPORTS), declared ^ set(cpphost.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported"

@@ -106,6 +106,18 @@ def test_gpu_stats_work_list_overflow():
     _compare("stats_overflow", p, d, True)
 
 
+@pytest.mark.parametrize("name", ["pe_default", "pe_merge", "pe_adapter_fasta", "pe_umi_per_read", "se_adapter_cut",
+                                  "pe_noadapter_dedup"])
+def test_gpu_with_cpp_host_glue_equals_reference_golden(name):
+    """device records -> C++ host glue (include/fastp_gpu_host.h, fq_glue.cpp) -> the reference's FASTQ + JSON"""
+    fq1, fq2, meta = golden_util.load(name)
+    params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)
+    eng = engines.gpu_engine(params)
+    outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name), cpp_host_lib=eng.lib)
+    eng.close()
+    golden_util.check_against_golden(name, outs, rep, meta)
+
+
 @pytest.mark.parametrize("L", [36, 75, 100, 250, 400])
 def test_gpu_read_lengths(L):
     p = abi.default_params(True, L)
