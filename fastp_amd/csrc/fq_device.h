@@ -82,6 +82,7 @@ FQ_DEV void tile_init_read(const LdsLayout& L, u32* lds, int R, int len) {
     lds_i(lds, L.apos)[R] = 0;
     lds_i(lds, L.alen)[R] = 0;
     lds_i(lds, L.code)[R] = 0;
+    lds[L.swin + R] = 0;
     if (R < L.P) {
         lds_i(lds, L.ov_off)[R] = (int)OV_KEY_NONE;
         lds_i(lds, L.ov_len)[R] = (int)OV_KEY_NONE;
@@ -456,9 +457,7 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
     // every argument-block field the loop needs, fetched once (they would otherwise be re-read
     // from the kernarg segment at each use, with a wait on the scalar cache in the loop)
     const int P = L.P, SW4 = L.SW * 4, wl_cap = L.wl_cap;
-    const int* rlen0_v = lds_i(lds, L.rlen0);
-    const int* flags_v = lds_i(lds, L.flags);
-    const int* len_v = lds_i(lds, L.len);
+    const u32* swin_v = lds + L.swin;  // rlen0 | kept length << 16, left by the filter phase
     const u32* qual_v = lds + L.qual;
     // (R, c) of this lane's items advance by a fixed (dR, dc) per trip: no division in the loop
     int R = (int)fastdiv((u32)tid, a.magic_qwg);
@@ -468,17 +467,17 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         const int idx = base + lane;
         const int m = R >= P ? 1 : 0;
         bool act = idx < total && (R - m * P < n_valid);
-        int rl0 = 0, lk = 0, rfl = 0;
+        int rl0 = 0, lk = 0;
         if (act) {
-            rl0 = rlen0_v[R];
-            rfl = flags_v[R];
-            if (rfl & RS_STAT_POST) lk = len_v[R];
+            const u32 sw = swin_v[R];
+            rl0 = (int)(sw & 0xFFFFu);
+            lk = (int)(sw >> 16);  // > 0 exactly for the reads that are written out
         }
         const int slot0 = m * 2;
         if (act && c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
             lds_add_u32(&misc[MISC_STAT_READS + slot0], 1u);
             lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)rl0);
-            if (rfl & RS_STAT_POST) {
+            if (lk) {
                 lds_add_u32(&misc[MISC_STAT_READS + slot0 + 1], 1u);
                 lds_add_u32(&misc[MISC_STAT_LENSUM + slot0 + 1], (u32)lk);
             }
@@ -517,20 +516,21 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
                 for (int k = 0; k < 4; k++) lds_add_u32(&kmer[(codes >> (2 * k)) & 0x3FFu], 1u);
             }
         }
-        // quality histogram of the plain items: ballot-aggregate the commonest key
+        // quality histogram of the plain items.  Qualities cluster: a dword's four values are usually
+        // equal, and equal to most other lanes' - those are counted with ONE ballot and added by one
+        // lane; every other base pays its own LDS atomic.
         const u64 hv = ballot(plain);
         if (hv) {  // wave-uniform
             const int src = ffs64(hv) - 1;
-            const u32 modek = shfl(key0 + (qd & 0x7Fu), src);
-            u32 cnt = 0;
+            const u32 q7 = qd & 0x7F7F7F7Fu;
+            const u32 modek = shfl(key0 + (q7 & 0x7Fu), src);
+            const bool agg = plain && q7 == (q7 & 0x7Fu) * 0x01010101u && key0 + (q7 & 0x7Fu) == modek;
+            const u32 cnt = 4u * (u32)popc64(ballot(agg));
+            if (plain && !agg) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u32 kk = key0 + ((qd >> (8 * k)) & 0x7Fu);
-                const bool mk = plain && kk == modek;
-                cnt += (u32)popc64(ballot(mk));
-                if (plain && !mk) lds_add_u32(&qh_all[kk * QH_COPIES + copy], 1u);
+                for (int k = 0; k < 4; k++) lds_add_u32(&qh_all[(key0 + ((qd >> (8 * k)) & 0x7Fu)) * QH_COPIES + copy], 1u);
             }
-            if (lane == src) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
+            if (lane == src && cnt) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
         }
         c += dc;
         R += dR;
@@ -1649,6 +1649,8 @@ FQ_DEV void phase_filter_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         }
         lds_i(lds, L.code)[R1] = code1;
         lds_i(lds, L.code)[R2] = code2;
+        lds[L.swin + R1] = (u32)lds_i(lds, L.rlen0)[R1] | ((flags[R1] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R1] << 16 : 0u);
+        lds[L.swin + R2] = (u32)lds_i(lds, L.rlen0)[R2] | ((flags[R2] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R2] << 16 : 0u);
         write_dup_pos(a, lds, pr, gp);
         write_read_result(a, lds, 0, R1, gp);
         write_read_result(a, lds, 1, R2, gp);
@@ -1708,6 +1710,7 @@ FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int t
         lds_i(lds, L.code)[R] = code;
         const bool dedup_out = p.dedup && (flags[R] & RS_DUP);
         if (!dedup_out && alive && code == 0) flags[R] |= RS_STAT_POST;  // :280-286
+        lds[L.swin + R] = (u32)lds_i(lds, L.rlen0)[R] | ((flags[R] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R] << 16 : 0u);
         write_dup_pos(a, lds, R, gp);
         write_read_result(a, lds, 0, R, gp);
     }

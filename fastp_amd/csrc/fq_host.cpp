@@ -304,6 +304,7 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.apos = take(out.NR);
         out.alen = take(out.NR);
         out.code = take(out.NR);
+        out.swin = take(out.NR);
         out.mlen = take(out.NR);
         if (o & 1) o++;
         out.inc_lut = take(256);

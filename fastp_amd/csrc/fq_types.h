@@ -108,6 +108,7 @@ struct LdsLayout {
                     // update consecutive LDS words
     int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
+    int swin;       // [NR] one-pass Stats window of a read: rlen0 | kept length << 16 (0 = not written out)
     int mlen;       // [NR] merge mode: bases of this mate that enter the merged read (else = len)
     int met;        // [NR][2] countQualityMetrics / countAdjacentDiffs of the final window (phase_metrics)
     int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed no-gap scan key (OV_KEY_*),
