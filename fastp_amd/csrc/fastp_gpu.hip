@@ -333,7 +333,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
                   !env_int("FASTP_GPU_NO_PREFETCH", 0);
         const void* ptrs[4] = {b->seq1, b->qual1, ctx->dp.paired ? b->seq2 : b->seq1, ctx->dp.paired ? b->qual2 : b->qual1};
         for (const void* q : ptrs) ok = ok && (((uintptr_t)q & 15u) == 0);
-        a.prefetch = ok ? 1 : 0;
+        a.prefetch = ok ? (env_int("FASTP_GPU_PREFETCH_AHEAD", 1) ? 1 : 2) : 0;
     }
     a.n = n;
     a.first = first;

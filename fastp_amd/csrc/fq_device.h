@@ -1761,15 +1761,20 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     const bool timing = timing_on && tid == 0;
     u64 tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     TileRegs regs;
-    const bool prefetch = a.prefetch != 0;  // uniform
+    const bool vec = a.prefetch != 0;       // uniform: 16-byte tile copies
+    const bool prefetch = a.prefetch == 1;  // ... issued one tile ahead
     if (prefetch && block_id() < a.tiles) tile_fetch(a, block_id() * L.P, tid, nt, regs);
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
         const int n_valid = imin(L.P, a.n - tile_first);
         u64 t0 = timing ? cycle_counter() : 0, t1;
 #define FQ_STAMP(k) if (timing) { t1 = cycle_counter(); tacc[k] += t1 - t0; t0 = t1; }
-        if (prefetch) tile_commit(a, lds, tid, nt, regs);
-        else phase_load(a, lds, tile_first, tid, nt);
+        if (vec) {
+            if (!prefetch) tile_fetch(a, tile_first, tid, nt, regs);
+            tile_commit(a, lds, tid, nt, regs);
+        } else {
+            phase_load(a, lds, tile_first, tid, nt);
+        }
         block_sync();
         if (prefetch && tile + grid_blocks() < a.tiles) tile_fetch(a, (tile + grid_blocks()) * L.P, tid, nt, regs);
         FQ_STAMP(0)
