@@ -169,6 +169,10 @@ def adapter_fasta_list(params):
     return [params.adapter_fasta[i] for i in range(params.n_adapter_fasta)]
 
 
+class ParseInfo(C.Structure):
+    _fields_ = [("n_records", C.c_int32), ("first_bad", C.c_int32), ("consumed", C.c_int64), ("n_lines", C.c_int64)]
+
+
 class CounterLayout(C.Structure):
     _fields_ = [
         ("total", C.c_int64), ("cycles", C.c_int64),

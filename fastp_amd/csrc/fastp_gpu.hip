@@ -37,6 +37,17 @@ extern "C" __global__ void __launch_bounds__(256) fq_ovr_tasks_kernel(OvrArgs o)
     ovr_tasks_body(o, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_ovr_count_kernel(OvrArgs o) { ovr_count_body(o); }
+extern "C" __global__ void __launch_bounds__(256) fq_parse_count_kernel(ParseArgs p) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    parse_count_body(p, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(64) fq_parse_scan_kernel(ParseArgs p, int nblocks) { parse_scan_body(p, nblocks); }
+extern "C" __global__ void __launch_bounds__(256) fq_parse_index_kernel(ParseArgs p) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    parse_index_body(p, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(64) fq_parse_finish_kernel(ParseArgs p) { parse_finish_body(p); }
+extern "C" __global__ void __launch_bounds__(256) fq_parse_pack_kernel(ParseArgs p) { parse_pack_body(p); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(1024) fq_dup_resolve_kernel(DupArgs d) {
@@ -86,6 +97,7 @@ struct fastp_gpu_ctx {
     int* d_ovr_len[2] = {nullptr, nullptr};
     u64* d_post_seen = nullptr;
     u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
+    u32* d_parse = nullptr; size_t parse_cap = 0;         // FASTQ parse scratch
     uint64_t units_seen = 0;                               // units submitted so far (the pre-filtering Stats' mReads)
     std::vector<std::string> ovr_strings[2];
     std::vector<const char*> ovr_ptrs[2];
@@ -147,7 +159,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -519,6 +531,66 @@ extern "C" int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch
         int rc = launch_chunk(ctx, b, first, n, res, st);
         if (rc) return rc;
     }
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbytes, int is_last_chunk,
+                                     int32_t max_records, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
+                                     uint32_t* line_off, uint32_t* line_len, fastp_gpu_parse_info* info) {
+    if (!ctx || !info || nbytes < 0 || max_records < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    memset(info, 0, sizeof(*info));
+    info->first_bad = -1;
+    if (nbytes == 0 || max_records == 0) return FASTP_GPU_OK;
+    if (!text || !seq_out || !qual_out || !len_out || !line_off || !line_len) return fail(ctx, FASTP_GPU_E_INVALID, "null buffer");
+    if (((uintptr_t)text & 15u) != 0) return fail(ctx, FASTP_GPU_E_INVALID, "text must be 16-byte aligned (and padded to 16 bytes)");
+    if (nbytes >= (1ll << 32)) return fail(ctx, FASTP_GPU_E_INVALID, "chunk of 4 GiB or more");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ParseArgs p;
+    memset(&p, 0, sizeof(p));
+    p.text = text;
+    p.nbytes = (u32)nbytes;
+    p.is_last = is_last_chunk ? 1 : 0;
+    p.max_lines = 4u * (u32)max_records + 1u;
+    p.max_len = ctx->dp.max_len;
+    p.sw_g = ctx->dp.sw_g;
+    p.qw_g = ctx->dp.qw_g;
+    p.max_records = max_records;
+    p.seq_out = (u32*)seq_out;
+    p.qual_out = (u32*)qual_out;
+    p.len_out = len_out;
+    p.line_off = line_off;
+    p.line_len = line_len;
+    const int per_block = PARSE_BLOCK * PARSE_BYTES_PER_LANE;
+    const int nblocks = (int)((nbytes + per_block - 1) / per_block);
+    const size_t dwords = 8 + (size_t)2 * nblocks + p.max_lines + (p.max_lines + 3) / 4;
+    int rc = ensure(ctx, (void**)&ctx->d_parse, &ctx->parse_cap, dwords * 4);
+    if (rc) return rc;
+    p.totals = ctx->d_parse;
+    p.blockcount = ctx->d_parse + 8;
+    p.blockbase = p.blockcount + nblocks;
+    p.term_pos = p.blockbase + nblocks;
+    p.term_len = (u8*)(p.term_pos + p.max_lines);
+    const u32 init[8] = {0, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(p.totals, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(fq_parse_count_kernel, dim3(nblocks), dim3(PARSE_BLOCK), 16, st, p);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_parse_scan_kernel, dim3(1), dim3(64), 0, st, p, nblocks);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_parse_index_kernel, dim3(nblocks), dim3(PARSE_BLOCK), 64, st, p);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_parse_finish_kernel, dim3(1), dim3(64), 0, st, p);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_parse_pack_kernel, dim3((max_records + 3) / 4), dim3(256), 0, st, p);
+    HIP_TRY(ctx, hipGetLastError());
+    u32 totals[8];
+    HIP_TRY(ctx, hipMemcpyAsync(totals, p.totals, sizeof(totals), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    info->n_records = (int32_t)totals[3];
+    info->consumed = (int64_t)totals[4];
+    info->n_lines = (int64_t)totals[2];
+    info->first_bad = totals[1] == 0xFFFFFFFFu ? -1 : (int32_t)totals[1];
+    if (info->first_bad >= 0) return fail(ctx, FASTP_GPU_E_INVALID, "malformed FASTQ record in the chunk (see first_bad)");
     return FASTP_GPU_OK;
 }
 

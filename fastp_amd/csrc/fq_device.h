@@ -2208,4 +2208,166 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// FASTQ text -> packed batch: FastqReader::getLine / read
+// (fastqreader.cpp:240-368) for a well-formed chunk resident in HBM.
+//   parse_count : line terminators per 4 KiB block.  A terminator STARTS at every '\r' and at every
+//                 '\n' that does not follow a '\r' ("\r\n" is one terminator, :257-259)
+//   parse_scan  : terminators before each block
+//   parse_index : position / length of the terminator that ends line k
+//   parse_pack  : one wavefront per record (4 lines): validate, 2-bit pack, N flags, zero padding
+// ---------------------------------------------------------------------------
+FQ_DEV u32 parse_term_mask(const ParseArgs& p, u32 base) {
+    // bit i: a terminator starts at byte base + i (16 bytes per lane)
+    u32 m = 0;
+    if (base >= p.nbytes) return 0;
+    const u32x4 v = *(const u32x4*)(p.text + base);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    u32 prev = base ? (u32)p.text[base - 1] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const u32 b = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        const bool in = base + (u32)i < p.nbytes;
+        // a '\r' that ends a non-final chunk may be half of a "\r\n": leave its line to the next chunk
+        const bool hanging = b == 13u && base + (u32)i + 1u == p.nbytes && !p.is_last;
+        if (in && !hanging && (b == 13u || (b == 10u && prev != 13u))) m |= 1u << i;
+        prev = b;
+    }
+    return m;
+}
+
+FQ_DEV void parse_count_body(const ParseArgs& p, u32* lds) {
+    if (thread_id() == 0) lds[0] = 0;
+    block_sync();
+    const u32 base = ((u32)block_id() * PARSE_BLOCK + (u32)thread_id()) * PARSE_BYTES_PER_LANE;
+    const u32 c = (u32)popc32(parse_term_mask(p, base));
+    u32 wsum = c;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) wsum += shfl_xor(wsum, sh);
+    if (lane_id() == 0 && wsum) lds_add_u32(&lds[0], wsum);
+    block_sync();
+    if (thread_id() == 0) p.blockcount[block_id()] = lds[0];
+}
+
+FQ_DEV void parse_scan_body(const ParseArgs& p, int nblocks) {
+    if (block_id() != 0 || thread_id() != 0) return;
+    u32 run = 0;
+    for (int b = 0; b < nblocks; b++) {
+        p.blockbase[b] = run;
+        run += p.blockcount[b];
+    }
+    p.totals[0] = run;
+    // an unterminated last line of the file still is a line (getLine's bufferFinished() branch)
+    u32 lines = run;
+    if (p.is_last && p.nbytes > 0) {
+        const u32 last = (u32)p.text[p.nbytes - 1];
+        if (last != 10u && last != 13u) lines++;
+    }
+    p.totals[2] = lines;
+}
+
+FQ_DEV void parse_index_body(const ParseArgs& p, u32* lds) {
+    const u32 base = ((u32)block_id() * PARSE_BLOCK + (u32)thread_id()) * PARSE_BYTES_PER_LANE;
+    u32 m = parse_term_mask(p, base);
+    const u32 c = (u32)popc32(m);
+    // exclusive prefix of c inside the workgroup: lanes via shuffles, waves via LDS
+    u32 incl = c;
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        const u32 o = shfl(incl, lane_id() - sh);
+        if (lane_id() >= sh) incl += o;
+    }
+    const int wave = wave_id(), nw = block_threads() >> 6;
+    if (lane_id() == 63) lds[wave] = incl;
+    block_sync();
+    u32 rank = p.blockbase[block_id()] + incl - c;
+    for (int w = 0; w < nw; w++)
+        if (w < wave) rank += lds[w];
+    while (m) {
+        const int i = ffs32(m) - 1;
+        m &= m - 1;
+        if (rank < p.max_lines) {
+            const u32 pos = base + (u32)i;
+            p.term_pos[rank] = pos;
+            p.term_len[rank] = (u8)((p.text[pos] == 13 && pos + 1 < p.nbytes && p.text[pos + 1] == 10) ? 2 : 1);
+        }
+        rank++;
+    }
+}
+
+// totals[3] = records that will be packed, totals[4] = bytes they cover
+FQ_DEV void parse_finish_body(const ParseArgs& p) {
+    if (block_id() != 0 || thread_id() != 0) return;
+    const u32 lines = p.totals[2], terms = p.totals[0];
+    u32 nrec = lines / 4u;
+    if (nrec > (u32)p.max_records) nrec = (u32)p.max_records;
+    u32 consumed = 0;
+    if (nrec) {
+        const u32 k = 4u * nrec - 1u;  // last line of the last record
+        consumed = k < terms ? p.term_pos[k] + p.term_len[k] : p.nbytes;
+    }
+    p.totals[3] = nrec;
+    p.totals[4] = consumed;
+}
+
+FQ_DEV void parse_pack_body(const ParseArgs& p) {
+    const int r = block_id() * (block_threads() >> 6) + wave_id();  // one wavefront per record
+    const u32 lines = p.totals[2], terms = p.totals[0];
+    int nrec = (int)(lines / 4u);
+    if (nrec > p.max_records) nrec = p.max_records;
+    if (r >= nrec) return;
+    const int lane = lane_id();
+    u32 start[4], len[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32 k = 4u * (u32)r + (u32)j;
+        start[j] = k ? p.term_pos[k - 1] + p.term_len[k - 1] : 0u;
+        const u32 end = k < terms ? p.term_pos[k] : p.nbytes;  // the unterminated last line ends at EOF
+        len[j] = end - start[j];
+    }
+    bool bad = false;
+    if (lane == 0) {  // FastqReader::read's checks (:338-362)
+        bad = len[0] == 0 || p.text[start[0]] != '@' || len[2] == 0 || p.text[start[2]] != '+' || len[1] != len[3] ||
+              len[1] > (u32)p.max_len;
+    }
+    bad = ballot(bad) != 0ull;
+    const u32 L = bad ? 0u : len[1];
+    if (lane < 4) {
+        p.line_off[4 * (size_t)r + lane] = start[lane];
+        p.line_len[4 * (size_t)r + lane] = len[lane];
+    }
+    if (lane == 0) p.len_out[r] = (u16)L;
+    // lane c packs bases 4c .. 4c+3: one quality dword, one byte of the 2-bit row
+    const u8* sp = p.text + start[1];
+    const u8* qp = p.text + start[3];
+    u32* qrow = p.qual_out + (size_t)r * p.qw_g;
+    u8* srow = (u8*)(p.seq_out + (size_t)r * p.sw_g);
+    bool alpha_bad = false;
+    for (int c = lane; c < p.qw_g || c < p.sw_g * 4; c += 64) {
+        u32 qd = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u32 j = 4u * (u32)c + (u32)k;
+            if (j < L) {
+                const u32 ch = sp[j];
+                u32 code = 0, nflag = 0;
+                if (ch == 'A') code = CODE_A;
+                else if (ch == 'T') code = CODE_T;
+                else if (ch == 'C') code = CODE_C;
+                else if (ch == 'G') code = CODE_G;
+                else if (ch == 'N') nflag = 0x80u;
+                else alpha_bad = true;
+                const u32 q = qp[j];
+                if (q > 127u) alpha_bad = true;
+                sb |= code << (2 * k);
+                qd |= ((q & 0x7Fu) | nflag) << (8 * k);
+            }
+        }
+        if (c < p.qw_g) qrow[c] = qd;
+        if (c < p.sw_g * 4) srow[c] = (u8)sb;
+    }
+    if ((ballot(alpha_bad) != 0ull || bad) && lane == 0) g_atomic_min_u32(&p.totals[1], (u32)r);
+}
+
 }  // namespace fq

@@ -189,6 +189,27 @@ struct OvrArgs {
     int64_t o_count[4], o_dist[4];   // fastp_gpu_counter_layout::overrep_count / overrep_dist
 };
 
+// ---- FASTQ text -> packed rows on the device (fq_parse_* kernels) ----
+enum { PARSE_BYTES_PER_LANE = 16, PARSE_BLOCK = 256 };
+struct ParseArgs {
+    const u8* text;       // 16-byte aligned
+    u32 nbytes;           // bytes to scan (a trailing lone '\r' of a non-final chunk is left out)
+    int is_last;          // the chunk ends the file: an unterminated last line counts
+    u32* blockcount;      // [nblocks] line terminators starting in the block
+    u32* blockbase;       // [nblocks] ... before the block
+    u32* term_pos;        // [max_lines] offset of the terminator that ends line k
+    u8* term_len;         // [max_lines] 1 or 2 ("\r\n")
+    u32 max_lines;
+    u32* totals;          // [0] terminators, [1] first bad record (atomic min), [2] lines incl. unterminated tail
+    // packing
+    int max_len, sw_g, qw_g, max_records;
+    u32* seq_out;
+    u32* qual_out;
+    u16* len_out;
+    u32* line_off;
+    u32* line_len;
+};
+
 struct KernelArgs {
     DevParams p;
     DevLuts lut;

@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_parse_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
 ]
@@ -178,6 +178,21 @@ class GpuEngine:
     # -- device-resident batches (bench / multi-GPU hosts) ---------------------------------------
     def submit_device(self, batch: abi.Batch, results: abi.Results, stream=None):
         self._check(self.lib.fastp_gpu_submit_device(self.h, C.byref(batch), C.byref(results), stream))
+
+    def parse_fastq(self, text_ptr: int, nbytes: int, is_last: bool, max_records: int, seq_ptr: int, qual_ptr: int,
+                    len_ptr: int, line_off_ptr: int, line_len_ptr: int, check=True) -> abi.ParseInfo:
+        """FASTQ text resident on the device -> packed rows on the device (fastp_gpu_parse_fastq)"""
+        info = abi.ParseInfo()
+        fn = self.lib.fastp_gpu_parse_fastq
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_void_p, C.c_void_p, C.POINTER(abi.ParseInfo)]
+        rc = fn(self.h, text_ptr, nbytes, int(is_last), max_records, seq_ptr, qual_ptr, len_ptr, line_off_ptr,
+                line_len_ptr, C.byref(info))
+        if check:
+            self._check(rc)
+        info.rc = rc
+        return info
 
     def synchronize(self):
         self._check(self.lib.fastp_gpu_synchronize(self.h))

@@ -313,6 +313,30 @@ int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char
                          const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out,
                          uint16_t* len_out, int32_t* bad_read);
 
+/* ---- FASTQ text -> packed batch ON THE DEVICE -----------------------
+ * The step before the path: FastqReader::getLine / read (src/fastqreader.cpp:240-368) + the
+ * packer above, for a chunk of plain FASTQ text resident in HBM.  A line ends at the first '\r' or
+ * '\n'; "\r\n" is one terminator (:246-262).  Records are four consecutive lines; the chunk must
+ * be well formed the way FastqReader::read expects its input - name lines start with '@' and are
+ * not empty, third lines start with '+', sequence and quality have equal length (:338-362) -
+ * otherwise FASTP_GPU_E_INVALID is returned with info->first_bad set and the host falls back to its
+ * own reader for that chunk (the reference's tolerant resynchronisation on '@' is host logic).
+ * Only complete records are produced; info->consumed tells where the next chunk must start.
+ * All pointers except `info` are DEVICE pointers; synchronous. */
+typedef struct fastp_gpu_parse_info {
+    int32_t n_records;   /* records packed                                              */
+    int32_t first_bad;   /* index of the first malformed / over-long / non-ACGTN record, or -1 */
+    int64_t consumed;    /* bytes of text the records cover (offset of the next record)  */
+    int64_t n_lines;     /* line terminators seen (+1 for an unterminated last line)     */
+} fastp_gpu_parse_info;
+
+int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbytes, int is_last_chunk,
+                          int32_t max_records,
+                          uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out, /* packed rows, strides as above */
+                          uint32_t* line_off,  /* [4*max_records] offset of each record line in `text`      */
+                          uint32_t* line_len,  /* [4*max_records] its length without the terminator        */
+                          fastp_gpu_parse_info* info);
+
 /* Process one batch whose buffers (and result buffers) live in HOST memory:
  * H2D copy, kernels, D2H copy, synchronous. */
 int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, fastp_gpu_results* res);

@@ -350,6 +350,65 @@ def test_gpu_counter_export_import_merge_rehearsal():
     assert c0[lay.dup_count] <= cw[lay.dup_count]
 
 
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+def test_gpu_device_fastq_parse_feeds_the_engine(eol):
+    """FASTQ text in HBM -> fastp_gpu_parse_fastq -> fastp_gpu_submit_device on the parsed rows: same packed
+    rows as FastqReader's line splitting + the host packer, same records and counters as the host-packed path"""
+    import torch
+    import parse_util
+    dev = torch.device("cuda", 0)
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    n = 20000
+    d = synth.synth_pairs(n, L=150, seed=31)
+    ref = engines.gpu_engine(p)
+    want = ref.process(*_args(d, True))
+    cref = ref.counters()
+    ref.close()
+    g = engines.gpu_engine(p)
+    ss, qs = abi.seq_stride(150), abi.qual_stride(150)
+    packed = []
+    for mate in (1, 2):
+        txt = synth.to_fastq(d[f"seq{mate}"], d[f"qual{mate}"], d[f"len{mate}"], mate).replace(b"\n", eol)
+        exp = parse_util.expected(txt, 150, None, True)
+        pad = (-len(txt)) % 16 + 16
+        t = torch.frombuffer(bytearray(txt + b"\0" * pad), dtype=torch.uint8).to(dev)
+        assert t.data_ptr() % 16 == 0
+        seq = torch.full((n, ss), 0xEE, dtype=torch.uint8, device=dev)
+        qual = torch.full((n, qs), 0xEE, dtype=torch.uint8, device=dev)
+        lens = torch.zeros(n, dtype=torch.int16, device=dev)
+        loff = torch.zeros(4 * n, dtype=torch.int32, device=dev)
+        llen = torch.zeros(4 * n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        info = g.parse_fastq(t.data_ptr(), len(txt), True, n, seq.data_ptr(), qual.data_ptr(), lens.data_ptr(),
+                             loff.data_ptr(), llen.data_ptr())
+        assert info.n_records == n and info.first_bad == -1 and info.consumed == len(txt)
+        assert np.array_equal(seq.cpu().numpy(), exp[0]) and np.array_equal(qual.cpu().numpy(), exp[1])
+        assert np.array_equal(lens.cpu().numpy().view(np.uint16), exp[2])
+        assert np.array_equal(loff.cpu().numpy().view(np.uint32), exp[3])
+        assert np.array_equal(llen.cpu().numpy().view(np.uint32), exp[4])
+        packed.append((seq, qual, lens))
+    r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+    r2 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+    pr = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+    nc = torch.zeros(1, dtype=torch.int32, device=dev)
+    b = abi.Batch()
+    b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+    b.seq1, b.qual1, b.len1 = (x.data_ptr() for x in packed[0])
+    b.seq2, b.qual2, b.len2 = (x.data_ptr() for x in packed[1])
+    res = abi.Results()
+    res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
+    res.corrections, res.corrections_capacity, res.n_corrections = None, 0, nc.data_ptr()
+    torch.cuda.synchronize(dev)
+    g.submit_device(b, res)
+    g.synchronize()
+    assert r1.cpu().numpy().view(abi.READ_RESULT_DTYPE).tobytes() == want[0].tobytes()
+    assert r2.cpu().numpy().view(abi.READ_RESULT_DTYPE).tobytes() == want[1].tobytes()
+    assert pr.cpu().numpy().view(abi.PAIR_RESULT_DTYPE).tobytes() == want[2].tobytes()
+    assert np.array_equal(g.counters(), cref)
+    g.close()
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))

@@ -166,3 +166,68 @@ def test_sim_overrep_streamed_and_split_launches(monkeypatch):
     assert co[lay.overrep_count[0]: lay.overrep_count[0] + lay.n_overrep[0]].sum() > 0
     bad = np.nonzero(co != cg)[0]
     assert len(bad) == 0, (bad[:10], co[bad[:10]], cg[bad[:10]])
+
+
+def _fastq_text(n=300, L=150, seed=9, eol=b"\n", trailing=True):
+    d = synth.synth_pairs(n, L=L, seed=seed, paired=False)
+    txt = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    txt = txt.replace(b"\n", eol)
+    if not trailing:
+        txt = txt[:-len(eol)]
+    return txt
+
+
+@pytest.mark.parametrize("eol,trailing", [(b"\n", True), (b"\r\n", True), (b"\r", True), (b"\n", False), (b"\r\n", False)])
+def test_sim_device_fastq_parse_equals_reader_and_packer(eol, trailing):
+    """FASTQ text -> packed rows on the device == FastqReader's line splitting + the host packer"""
+    import parse_util
+    g = engines.sim_engine(abi.default_params(False, 150))
+    txt = _fastq_text(eol=eol, trailing=trailing)
+    exp = parse_util.expected(txt, 150, None, True)
+    info, seq, qual, lens, loff, llen = parse_util.run_numpy(g, txt, 150, 1000, True)
+    assert info.n_records == 300 and info.first_bad == -1 and info.consumed == len(txt)
+    assert np.array_equal(seq, exp[0]) and np.array_equal(qual, exp[1]) and np.array_equal(lens, exp[2])
+    assert np.array_equal(loff, exp[3]) and np.array_equal(llen, exp[4])
+    # the packed rows equal what the C packer makes from the same reads
+    b = hostloop.parse_fastq(txt.replace(eol, b"\n") + (b"" if trailing else b"\n"))
+    s2, q2, l2 = engine.pack_ascii(g.lib, 150, b.seq, b.qual, b.lens)
+    assert np.array_equal(seq, s2) and np.array_equal(qual, q2) and np.array_equal(lens, l2)
+    g.close()
+
+
+def test_sim_device_fastq_parse_chunks_limits_and_errors():
+    import parse_util
+    g = engines.sim_engine(abi.default_params(False, 150))
+    txt = _fastq_text(n=120, eol=b"\r\n")
+    # a chunk cut in the middle of a record (and of a \r\n): only complete records, consumed tells where to resume
+    for cut in (len(txt) // 2, len(txt) // 2 + 1, txt.index(b"\r\n", 5000) + 1, 17, 0):
+        chunk = txt[:cut]
+        exp = parse_util.expected(chunk, 150, None, False)
+        info, seq, qual, lens, loff, llen = parse_util.run_numpy(g, chunk, 150, 1000, False)
+        assert info.n_records == len(exp[2]) and info.consumed == exp[5], (cut, info.n_records, info.consumed, exp[5])
+        assert np.array_equal(seq, exp[0]) and np.array_equal(qual, exp[1]) and np.array_equal(lens, exp[2])
+        rest = txt[info.consumed:]
+        info2, *_ = parse_util.run_numpy(g, rest, 150, 1000, True)
+        assert info.n_records + info2.n_records == 120
+    # max_records caps the batch
+    info, seq, qual, lens, loff, llen = parse_util.run_numpy(g, txt, 150, 7, True)
+    exp = parse_util.expected(txt, 150, 7, True)
+    assert info.n_records == 7 and info.consumed == exp[5] and np.array_equal(qual, exp[1])
+    # malformed chunks are refused, never repaired on the device
+    lines = txt.split(b"\r\n")
+    for mutate in ("name", "plus", "length", "alphabet", "toolong"):
+        ls = list(lines)
+        if mutate == "name":
+            ls[4 * 5] = b"X" + ls[4 * 5][1:]
+        elif mutate == "plus":
+            ls[4 * 5 + 2] = b"-"
+        elif mutate == "length":
+            ls[4 * 5 + 3] = ls[4 * 5 + 3][:-1]
+        elif mutate == "alphabet":
+            ls[4 * 5 + 1] = b"R" + ls[4 * 5 + 1][1:]
+        else:
+            ls[4 * 5 + 1] = ls[4 * 5 + 1] + b"ACGT" * 10
+            ls[4 * 5 + 3] = ls[4 * 5 + 3] + b"IIII" * 10
+        info, *_ = parse_util.run_numpy(g, b"\r\n".join(ls), 150, 1000, True, check=False)
+        assert info.rc == abi.E_INVALID and info.first_bad == 5, (mutate, info.rc, info.first_bad)
+    g.close()
