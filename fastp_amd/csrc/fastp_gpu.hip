@@ -41,7 +41,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_parse_count_kernel(ParseArg
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     parse_count_body(p, fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(64) fq_parse_scan_kernel(ParseArgs p, int nblocks) { parse_scan_body(p, nblocks); }
+extern "C" __global__ void __launch_bounds__(1024) fq_parse_scan_kernel(ParseArgs p, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    parse_scan_body(p, nblocks, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_parse_index_kernel(ParseArgs p) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     parse_index_body(p, fq_lds);
@@ -575,7 +578,7 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     HIP_TRY(ctx, hipMemcpyAsync(p.totals, init, sizeof(init), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(fq_parse_count_kernel, dim3(nblocks), dim3(PARSE_BLOCK), 16, st, p);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(fq_parse_scan_kernel, dim3(1), dim3(64), 0, st, p, nblocks);
+    hipLaunchKernelGGL(fq_parse_scan_kernel, dim3(1), dim3(1024), 1024 * 4, st, p, nblocks);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(fq_parse_index_kernel, dim3(nblocks), dim3(PARSE_BLOCK), 64, st, p);
     HIP_TRY(ctx, hipGetLastError());

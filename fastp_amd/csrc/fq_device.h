@@ -2250,21 +2250,38 @@ FQ_DEV void parse_count_body(const ParseArgs& p, u32* lds) {
     if (thread_id() == 0) p.blockcount[block_id()] = lds[0];
 }
 
-FQ_DEV void parse_scan_body(const ParseArgs& p, int nblocks) {
-    if (block_id() != 0 || thread_id() != 0) return;
-    u32 run = 0;
-    for (int b = 0; b < nblocks; b++) {
+FQ_DEV void parse_scan_body(const ParseArgs& p, int nblocks, u32* lds) {
+    // one workgroup: every lane sums a contiguous run of block counts, the lane totals are
+    // scanned through LDS, then each lane writes the running prefix of its run
+    const int tid = thread_id(), nt = block_threads();
+    const int per = (nblocks + nt - 1) / nt;
+    const int b0 = imin(tid * per, nblocks), b1 = imin(b0 + per, nblocks);
+    u32 sum = 0;
+    for (int b = b0; b < b1; b++) sum += p.blockcount[b];
+    lds[tid] = sum;
+    block_sync();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int i = 0; i < nt; i++) {
+            const u32 v = lds[i];
+            lds[i] = run;
+            run += v;
+        }
+        p.totals[0] = run;
+        // an unterminated last line of the file still is a line (getLine's bufferFinished() branch)
+        u32 lines = run;
+        if (p.is_last && p.nbytes > 0) {
+            const u32 last = (u32)p.text[p.nbytes - 1];
+            if (last != 10u && last != 13u) lines++;
+        }
+        p.totals[2] = lines;
+    }
+    block_sync();
+    u32 run = lds[tid];
+    for (int b = b0; b < b1; b++) {
         p.blockbase[b] = run;
         run += p.blockcount[b];
     }
-    p.totals[0] = run;
-    // an unterminated last line of the file still is a line (getLine's bufferFinished() branch)
-    u32 lines = run;
-    if (p.is_last && p.nbytes > 0) {
-        const u32 last = (u32)p.text[p.nbytes - 1];
-        if (last != 10u && last != 13u) lines++;
-    }
-    p.totals[2] = lines;
 }
 
 FQ_DEV void parse_index_body(const ParseArgs& p, u32* lds) {
