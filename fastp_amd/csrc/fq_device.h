@@ -6,15 +6,22 @@
 // src/seprocessor.cpp:204-296) and accumulates the Stats / FilterResult
 // counters in LDS-privatised histograms that are flushed once per launch.
 //
-// Phases (block_sync between them), each with the lane mapping that suits it:
-//   A  load      : coalesced dword copy HBM -> LDS, build N masks
-//   B  pre-stats : lane = 4 consecutive cycles of one read  (Stats::statRead)
-//   C  trim      : lane = one read   (dup hash, UMI, Filter::trimAndCut, polyG)
-//   D  overlap   : wave = one pair, lane = one candidate offset
-//                  (OverlapAnalysis::analyze, __ballot picks the first accept)
-//   E  decide    : lane = one pair   (isize, BaseCorrector, AdapterTrimmer,
-//                  polyX, max_len, Filter::passFilter, result records)
-//   F  post-stats: as B, on the surviving window of the reads that pass
+// Phases (block_sync between them), each with the lane mapping that keeps all wavefronts busy:
+//   load    : flat 16-byte vector copies HBM -> LDS (registers filled one tile ahead), N masks
+//   masks   : lane = (read, 32-position mask word)   trimAndCut's windows for every start position
+//   hash    : 8 lanes per read                        Duplicate::seq2intvector on the original read
+//   trim    : lane = read                             UMI front trim, trimAndCut as bit scans
+//   polyG   : lane = read (when enabled)
+//   overlap : lane = (pair, direction, quarter)       OverlapAnalysis::analyze, prefilter + verify,
+//             LDS atomic-min over scan-order keys; optional one-gap pass; again after trimming in
+//             merge mode
+//   decide  : lane = pair                             isize, BaseCorrector, AdapterTrimmer, polyX, max_len
+//   metrics : 8 lanes per read                        countQualityMetrics / countAdjacentDiffs
+//   filter  : lane = pair                             Filter::passFilter, merge bookkeeping, records
+//   stats   : lane = (read, 4 cycles)                 Stats::statRead for all four Stats objects - one
+//             kept/dropped pass when no option moves or edits a kept base, else pre + post passes
+// After the fused kernel: slab fold (reduce_body), duplicate probe/resolve in input order, and the
+// overrepresentation analysis (ovr_*).  Before it, for FASTQ text resident in HBM: parse_*.
 //
 // Integer / byte work only: no MFMA.  Every function cites the reference lines
 // whose behaviour it reproduces (paths relative to the reference root).
