@@ -389,6 +389,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         DupArgs d;
         memset(&d, 0, sizeof(d));
         d.dup_pos = ctx->d_dup_pos;
+        d.posum = ctx->d_posum;
+        d.len[0] = a.len[0];
+        d.len[1] = a.len[1];
         d.n = n;
         d.B = ctx->dp.dup_bufnum;
         d.bits = ctx->dp.dup_bits;

@@ -1571,11 +1571,11 @@ FQ_DEV void write_dup_pos(const KernelArgs& a, u32* lds, int u, int gp) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     if (!p.dup_enabled || !a.dup_pos) return;
+    // the base-value part only: the length-dependent position part (DevLuts::dup_posum) is added
+    // by the duplicate kernels, so that this thin phase does not wait for a global table read
     const u64* h1 = (const u64*)(lds + L.hash) + (size_t)u * p.dup_bufnum;
-    int tl = lds_i(lds, L.rlen0)[u];
-    if (p.paired) tl += lds_i(lds, L.rlen0)[L.P + u];
     for (int i = 0; i < p.dup_bufnum; i++) {
-        u64 h = h1[i] + a.lut.dup_posum[(size_t)tl * p.dup_bufnum + i];
+        u64 h = h1[i];
         if (p.paired) h += ((const u64*)(lds + L.hash) + (size_t)(L.P + u) * p.dup_bufnum)[i];
         a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h;
     }
@@ -1982,7 +1982,9 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
 // identity as the reference's byte array: byte pos>>3, bit pos&7).
 // ---------------------------------------------------------------------------
 struct DupArgs {
-    const u64* dup_pos;   // [n][B] Duplicate::seq2intvector values
+    const u64* dup_pos;   // [n][B] Duplicate::seq2intvector values, base-value part (write_dup_pos)
+    const u64* posum;     // [(2*max_len+1)][B] position part by total length (DevLuts::dup_posum)
+    const u16* len[2];    // read lengths of the launch (len[1] only when paired)
     int n, B;
     u64 bits;             // mBufLenInBits
     u32* bitmap;          // [B][bits/32]
@@ -1998,6 +2000,13 @@ struct DupArgs {
 };
 
 enum { DUP_IDX_BITS = 25 };  // pairs per launch < 2^25
+// bit position of unit g in buffer i: (base-value part + position part) mod mBufLenInBits
+FQ_DEV u64 dup_bit(const DupArgs& d, int g, int i) {
+    int tl = (int)d.len[0][g];
+    if (d.paired) tl += (int)d.len[1][g];
+    const u64 h = d.dup_pos[(size_t)g * d.B + i] + d.posum[(size_t)tl * d.B + i];
+    return h & (d.bits - 1);  // mBufLenInBits is a power of two (duplicate.cpp:13-47)
+}
 FQ_DEV u64 dup_key(int i, u64 pos) { return ((u64)i << 35) | pos; }
 FQ_DEV u32 dup_slot(u64 key, int log2) { return (u32)((key * 0x9E3779B97F4A7C15ull) >> (64 - log2)); }
 
@@ -2009,7 +2018,7 @@ FQ_DEV void dup_probe_body(const DupArgs& d) {
     for (int g = gid; g < d.n; g += gstride) {
         u32 need = 0;
         for (int i = 0; i < d.B; i++) {
-            const u64 pos = d.dup_pos[(size_t)g * d.B + i] & (d.bits - 1)  /* mBufLenInBits is a power of two (duplicate.cpp:13-47) */;
+            const u64 pos = dup_bit(d, g, i);
             const u32 w = d.bitmap[(size_t)i * words + (pos >> 5)];
             if (!((w >> (pos & 31)) & 1u)) {
                 need |= 1u << i;
@@ -2047,7 +2056,7 @@ FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
             is_dup = true;
             for (int i = 0; i < d.B; i++) {
                 if (!((need >> i) & 1u)) continue;  // committed by an earlier batch
-                const u64 pos = d.dup_pos[(size_t)g * d.B + i] & (d.bits - 1)  /* mBufLenInBits is a power of two (duplicate.cpp:13-47) */;
+                const u64 pos = dup_bit(d, g, i);
                 const u64 key = dup_key(i, pos);
                 u32 slot = dup_slot(key, d.table_log2);
                 u64 cur;
