@@ -194,6 +194,20 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # what actually bounds the kernel: integer VALU issue.  Instruction count from the
+        # committed PMC pass, duration live; reported next to the HBM roofline BASELINE.json asks for.
+        compute = None
+        vf = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vf) and avg_ms > 0:
+            try:
+                vj = json.load(open(vf))
+                if vj.get("pairs_per_launch") == int(per_launch_pairs):
+                    ach = vj["insts_valu_per_launch"] * 64 / (avg_ms * 1e-3) / 1e12
+                    compute = {"bound": "valu_int", "achieved": round(ach, 2), "peak": vj["peak_T_lane_ops_per_s"],
+                               "unit": "T lane-ops/s", "frac": round(ach / vj["peak_T_lane_ops_per_s"], 4),
+                               "insts_valu_per_pair": round(vj["insts_valu_per_launch"] / per_launch_pairs, 1)}
+            except Exception:
+                compute = None
         out = {
             "metric": "Mreads/sec (whole node), 2x150 bp PE, inputs resident in HBM", "value": round(value, 3),
             "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,6 +221,8 @@ def main():
                          "kernel": "fq_fused_kernel", "kernel_avg_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": int(per_launch_pairs)},
         }
+        if compute is not None:
+            out["compute_roofline"] = compute
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params)
         print(json.dumps(out))
