@@ -63,9 +63,11 @@ struct Rows {  // LDS views of one read
     const u8* q;   // quality bytes (bit 7 = N)
 };
 
-FQ_DEV u32* lds_seq(const LdsLayout& L, u32* lds, int R) { return lds + L.seq + R * L.SW; }
-FQ_DEV u32* lds_nmk(const LdsLayout& L, u32* lds, int R) { return lds + L.nmk + R * L.SW; }
-FQ_DEV u32* lds_qual(const LdsLayout& L, u32* lds, int R) { return lds + L.qual + R * L.QW; }
+// LDS indices are far below 2^24: row offsets use the full-rate 24-bit multiply (v_mul_lo_u32 is half rate)
+FQ_DEV int rowoff(int R, int stride) { return (int)mul24((u32)R, (u32)stride); }
+FQ_DEV u32* lds_seq(const LdsLayout& L, u32* lds, int R) { return lds + L.seq + rowoff(R, L.SW); }
+FQ_DEV u32* lds_nmk(const LdsLayout& L, u32* lds, int R) { return lds + L.nmk + rowoff(R, L.SW); }
+FQ_DEV u32* lds_qual(const LdsLayout& L, u32* lds, int R) { return lds + L.qual + rowoff(R, L.QW); }
 FQ_DEV int* lds_i(u32* lds, int off) { return (int*)(lds + off); }
 
 FQ_DEV u32 code_at(const u32* srow, int j) { return (srow[j >> 4] >> ((j & 15) * 2)) & 3u; }
@@ -257,7 +259,7 @@ FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int
     const int dW = nthreads / NR, dR = nthreads - dW * NR;
     int w = tid / NR, R = tid - w * NR;
     for (int i = tid; i < total; i += nthreads) {
-        const u32* qrow = qual_v + R * QW;
+        const u32* qrow = qual_v + rowoff(R, QW);
         const int rl0 = rlen0_v[R];
         u32 mF = 0, mR = 0, mT = 0, mQ = 0, mN = 0;
         for (int d = 0; d < 8; d++) {
@@ -287,7 +289,7 @@ FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int
             const u32 nb = (qd >> 7) & 0x01010101u;
             mN |= ((nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu) << (4 * d);
         }
-        u32* wm = wm_v + R * wm_stride + w;
+        u32* wm = wm_v + rowoff(R, wm_stride) + w;
         if (oF >= 0) wm[oF] = mF;
         if (oR >= 0) wm[oR] = mR;
         if (oT >= 0) wm[oT] = mT;
@@ -355,13 +357,13 @@ FQ_DEV void stats_item(const KernelArgs& a, u32* lds, bool act, int R, int c, in
     act = act && j0 < f + l && j0 + 4 > f;
     u32 qd = 0, codes = 0, nbits = 0xFFu;
     if (act) {
-        const u32* srow = lds + L.seq + R * L.SW;
-        qd = lds[L.qual + R * L.QW + c];
+        const u32* srow = lds + L.seq + rowoff(R, L.SW);
+        qd = lds[L.qual + rowoff(R, L.QW) + c];
         const u32 cur8 = (srow[c >> 2] >> ((c & 3) * 8)) & 0xFFu;
         u32 prev8 = 0, nprev = 0xFu;  // before the read start: "invalid"
         if (c > 0) {
             prev8 = (srow[(c - 1) >> 2] >> (((c - 1) & 3) * 8)) & 0xFFu;
-            const u32 nb = (lds[L.qual + R * L.QW + c - 1] >> 7) & 0x01010101u;
+            const u32 nb = (lds[L.qual + rowoff(R, L.QW) + c - 1] >> 7) & 0x01010101u;
             nprev = (nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu;  // bit k = base j0-4+k is N
         }
         const u32 nbc = (qd >> 7) & 0x01010101u;
@@ -507,17 +509,18 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         u32 key0 = 0;
         if (plain) {
             const int slot = slot0 + (j0 < lk ? 1 : 0);
-            const u32 cur8 = seq_bytes[R * SW4 + c];
-            u64* cyc = cyc_all + ((size_t)slot * N_CLS) * Cp + c;  // position 4c+k lives at k*C4 + c (phase-major)
+            const int sbyte = rowoff(R, SW4) + c;
+            const u32 cur8 = seq_bytes[sbyte];
+            u64* cyc = cyc_all + rowoff(slot, N_CLS * Cp) + c;  // position 4c+k lives at k*C4 + c (phase-major)
             key0 = (u32)slot * 128u;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const u32 q = (qd >> (8 * k)) & 0x7Fu;
                 const u32 cls = (cur8 >> (2 * k)) & 3u;
-                lds_add_u64(&cyc[cls * Cp + k * C4], inc_lut[q]);
+                lds_add_u64(&cyc[rowoff((int)cls, Cp) + k * C4], inc_lut[q]);
             }
             if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N)
-                const u32 codes = (u32)seq_bytes[R * SW4 + c - 1] | (cur8 << 8);
+                const u32 codes = (u32)seq_bytes[sbyte - 1] | (cur8 << 8);
                 u32* kmer = kmer_all + slot * KMER_BINS;
 #pragma unroll
                 for (int k = 0; k < 4; k++) lds_add_u32(&kmer[(codes >> (2 * k)) & 0x3FFu], 1u);
@@ -731,14 +734,15 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
         const int R = valid ? (t >> 3) : 0, seg = t & 7;
         const int len = valid ? rlen0_v[R] : 0;
         const int off = R >= P ? rlen0_v[R - P] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
+        const int rq = rowoff(R, QW), rs = rowoff(R, SW4);
         for (int i0 = 0; i0 < B; i0 += 2) {
             u64 acc0 = 0, acc1 = 0;
             for (int d = 0; d < D; d++) {
                 const int c = seg + 8 * d;
                 const int rem = len - 4 * c;  // bases of this dword that exist
                 if (rem <= 0) break;
-                const u32 qd = qual_v[R * QW + c];
-                u32 vals = val4[seq_bytes[R * SW4 + c]];  // the four base values, one byte each
+                const u32 qd = qual_v[rq + c];
+                u32 vals = val4[seq_bytes[rs + c]];  // the four base values, one byte each
                 if (qd & 0x80808080u) {                  // N -> 13
                     const u32 mN = ((qd >> 7) & 0x01010101u) * 0xFFu;
                     vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
@@ -793,7 +797,7 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, i
             if (t > 0) { front = t; len -= t; }
         }
         int f2 = 0, l2 = len;
-        const bool alive = trim_and_cut(p, L, lds + L.wm + R * L.wm_stride, front, len, m ? p.trim_front2 : p.trim_front1,
+        const bool alive = trim_and_cut(p, L, lds + L.wm + rowoff(R, L.wm_stride), front, len, m ? p.trim_front2 : p.trim_front1,
                                         m ? p.trim_tail2 : p.trim_tail1, f2, l2);
         if (alive) {
             lds_i(lds, L.front)[R] = front + f2;
@@ -1264,8 +1268,8 @@ FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) 
         const int R = valid ? (t >> 3) : 0, seg = t & 7;
         const int f = front_v[R];
         const int e = valid ? f + wlen_v[R] : f;
-        const u32* qrow = qual_v + R * QW;
-        const u32* srow = seq_v + R * SW;
+        const u32* qrow = qual_v + rowoff(R, QW);
+        const u32* srow = seq_v + rowoff(R, SW);
         u32 ma = 0, mb = 0;
         for (int d = 0; d < D; d++) {
             const int c = seg + 8 * d;
