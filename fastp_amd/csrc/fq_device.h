@@ -748,11 +748,11 @@ FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
                     vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
                 }
                 vals &= lowmask32(8 * rem);              // bases past the read end contribute 0
-                const u32 pi0 = ((u32)(4 * c + off)) * (u32)B + (u32)i0;
+                const u32 pi0 = mul24((u32)(4 * c + off), (u32)B) + (u32)i0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const u32 v = (vals >> (8 * k)) & 0xFFu;
-                    const u32 pi = (pi0 + (u32)(k * B)) & mask;
+                    const u32 pi = (pi0 + (k == 0 ? 0u : k == 1 ? (u32)B : k == 2 ? 2u * (u32)B : 3u * (u32)B)) & mask;
                     acc0 += (u64)mul24(primes[pi], v);      // prime < 2^24, value < 2^8: exact in 32 bits
                     acc1 += (u64)mul24(primes[pi + 1], v);
                 }
