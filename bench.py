@@ -119,10 +119,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm; "gloo" only for rehearsals
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if os.environ.get("BENCH_BACKEND", "nccl") != "nccl":
+        local = local % torch.cuda.device_count()            # rehearsal of the N>1 path on fewer GPUs
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if rank == 0:
