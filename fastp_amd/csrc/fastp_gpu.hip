@@ -51,6 +51,19 @@ extern "C" __global__ void __launch_bounds__(256) fq_parse_index_kernel(ParseArg
 }
 extern "C" __global__ void __launch_bounds__(64) fq_parse_finish_kernel(ParseArgs p) { parse_finish_body(p); }
 extern "C" __global__ void __launch_bounds__(256) fq_parse_pack_kernel(ParseArgs p) { parse_pack_body(p); }
+extern "C" __global__ void __launch_bounds__(256) fq_fmt_len_kernel(FmtArgs f) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    fmt_len_body(f, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(1024) fq_fmt_scan_kernel(FmtArgs f) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    fmt_scan_body(f, (u64*)fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_fmt_write_kernel(FmtArgs f) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    fmt_write_body(f, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_fmt_fix_kernel(FmtArgs f) { fmt_fix_body(f); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(1024) fq_dup_resolve_kernel(DupArgs d) {
@@ -101,6 +114,7 @@ struct fastp_gpu_ctx {
     u64* d_post_seen = nullptr;
     u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
     u32* d_parse = nullptr; size_t parse_cap = 0;         // FASTQ parse scratch
+    u64* d_fmt = nullptr; size_t fmt_cap = 0;             // FASTQ format scratch
     uint64_t units_seen = 0;                               // units submitted so far (the pre-filtering Stats' mReads)
     std::vector<std::string> ovr_strings[2];
     std::vector<const char*> ovr_ptrs[2];
@@ -162,7 +176,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -597,6 +611,70 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     info->n_lines = (int64_t)totals[2];
     info->first_bad = totals[1] == 0xFFFFFFFFu ? -1 : (int32_t)totals[1];
     if (info->first_bad >= 0) return fail(ctx, FASTP_GPU_E_INVALID, "malformed FASTQ record in the chunk (see first_bad)");
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_format_fastq(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_format_in* m1, const fastp_gpu_format_in* m2,
+                                      const fastp_gpu_correction* corrections, const int32_t* n_corrections, uint8_t* out1,
+                                      int64_t out1_capacity, uint8_t* out2, int64_t out2_capacity, int64_t out_len[2]) {
+    if (!ctx || !m1 || !out_len || n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    out_len[0] = out_len[1] = 0;
+    const bool paired = ctx->dp.paired != 0;
+    if (paired != (m2 != nullptr)) return fail(ctx, FASTP_GPU_E_INVALID, "mate 2 must be given exactly for a paired engine");
+    if (ctx->dp.merge) return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "merge mode writes the merged stream on the host");
+    if (ctx->dp.umi_len1 || ctx->dp.umi_len2) return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "UMI name edits are host logic");
+    if (n == 0) return FASTP_GPU_OK;
+    if (!out1 || (paired && !out2) || out1_capacity < 0 || out2_capacity < 0) return fail(ctx, FASTP_GPU_E_INVALID, "null output buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    FmtArgs f;
+    memset(&f, 0, sizeof(f));
+    f.n = n;
+    f.paired = paired ? 1 : 0;
+    f.dedup = ctx->dp.dedup;
+    f.nblocks = (n + FMT_BLOCK - 1) / FMT_BLOCK;
+    const size_t words = (size_t)4 * f.nblocks + 2 + (size_t)2 * n;
+    int rc = ensure(ctx, (void**)&ctx->d_fmt, &ctx->fmt_cap, words * 8);
+    if (rc) return rc;
+    f.blocksum = ctx->d_fmt;
+    f.blockbase = f.blocksum + (size_t)2 * f.nblocks;
+    f.totals = f.blockbase + (size_t)2 * f.nblocks;
+    const fastp_gpu_format_in* ins[2] = {m1, m2};
+    uint8_t* outs[2] = {out1, out2};
+    const int64_t caps[2] = {out1_capacity, out2_capacity};
+    for (int m = 0; m < (paired ? 2 : 1); m++) {
+        if (!ins[m]->text || !ins[m]->line_off || !ins[m]->line_len || !ins[m]->res) return fail(ctx, FASTP_GPU_E_INVALID, "null input");
+        f.m[m].text = ins[m]->text;
+        f.m[m].line_off = ins[m]->line_off;
+        f.m[m].line_len = ins[m]->line_len;
+        f.m[m].res = (const u32*)ins[m]->res;
+        f.m[m].out = outs[m];
+        f.m[m].out_cap = (u64)caps[m];
+        f.m[m].unit_off = f.totals + 2 + (size_t)m * n;
+    }
+    f.corrections = (const u32*)corrections;
+    f.n_corrections = n_corrections;
+    HIP_TRY(ctx, hipMemsetAsync(f.totals, 0, 16, st));
+    hipLaunchKernelGGL(fq_fmt_len_kernel, dim3(f.nblocks), dim3(FMT_BLOCK), 16, st, f);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_fmt_scan_kernel, dim3(paired ? 2 : 1), dim3(1024), 1024 * 8, st, f);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_fmt_write_kernel, dim3(f.nblocks), dim3(FMT_BLOCK), 128, st, f);
+    HIP_TRY(ctx, hipGetLastError());
+    int32_t ncorr = 0;
+    if (corrections && n_corrections) HIP_TRY(ctx, hipMemcpyAsync(&ncorr, n_corrections, 4, hipMemcpyDeviceToHost, st));
+    u64 totals[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(totals, f.totals, 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ncorr > 0) {
+        hipLaunchKernelGGL(fq_fmt_fix_kernel, dim3((ncorr + 255) / 256), dim3(256), 0, st, f);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    out_len[0] = (int64_t)totals[0];
+    out_len[1] = (int64_t)totals[1];
+    if (out_len[0] > out1_capacity || (paired && out_len[1] > out2_capacity))
+        return fail(ctx, FASTP_GPU_E_OVERFLOW, "output buffer too small (see out_len for the needed sizes)");
     return FASTP_GPU_OK;
 }
 

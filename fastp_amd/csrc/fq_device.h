@@ -2407,4 +2407,148 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
     if ((ballot(alpha_bad) != 0ull || bad) && lane == 0) g_atomic_min_u32(&p.totals[1], (u32)r);
 }
 
+
+// ---------------------------------------------------------------------------
+// Result records -> output FASTQ text: Read::appendToString (read.cpp:119-134)
+// for the units routed to out1 [/ out2] (peprocessor.cpp:577-591, seprocessor.cpp:280-286).
+//   fmt_len   : bytes each block's units add to each stream
+//   fmt_scan  : running offsets
+//   fmt_write : one wavefront per unit and mate copies the four lines
+//   fmt_fix   : BaseCorrector's edits patched into the copied text
+// ---------------------------------------------------------------------------
+FQ_DEV bool fmt_unit_out(const FmtArgs& f, int g) {
+    const u32 w1 = f.m[0].res[(size_t)g * 3 + 1];
+    u32 code = w1 & 0xFFu, flags = (w1 >> 8) & 0xFFu;
+    if (f.paired) {
+        const u32 w2 = f.m[1].res[(size_t)g * 3 + 1];
+        code |= w2 & 0xFFu;
+        flags |= (w2 >> 8) & (u32)RS_NULL;
+    }
+    if (flags & RS_NULL) return false;
+    if (f.dedup && (flags & RS_DUP)) return false;
+    return code == 0u;
+}
+// name + '\n' + seq + '\n' + strand + '\n' + qual + '\n'
+FQ_DEV u32 fmt_record_bytes(const FmtMate& M, int g) {
+    const u32 len = M.res[(size_t)g * 3] >> 16;
+    return M.line_len[4 * (size_t)g] + M.line_len[4 * (size_t)g + 2] + 2u * len + 4u;
+}
+
+FQ_DEV void fmt_len_body(const FmtArgs& f, u32* lds) {
+    if (thread_id() < 2) lds[thread_id()] = 0;
+    block_sync();
+    const int g = block_id() * block_threads() + thread_id();
+    const bool out = g < f.n && fmt_unit_out(f, g);
+    for (int mt = 0; mt < (f.paired ? 2 : 1); mt++) {
+        u32 b = out ? fmt_record_bytes(f.m[mt], g) : 0u;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) b += shfl_xor(b, sh);
+        if (lane_id() == 0 && b) lds_add_u32(&lds[mt], b);
+    }
+    block_sync();
+    if (thread_id() < 2) f.blocksum[(size_t)thread_id() * f.nblocks + block_id()] = lds[thread_id()];
+}
+
+FQ_DEV void fmt_scan_body(const FmtArgs& f, u64* lds) {
+    // one workgroup per stream (block_id = stream): lanes sum runs of blocks, scan through LDS
+    const int mt = block_id();
+    const int tid = thread_id(), nt = block_threads();
+    const int per = (f.nblocks + nt - 1) / nt;
+    const int b0 = imin(tid * per, f.nblocks), b1 = imin(b0 + per, f.nblocks);
+    const u64* sums = f.blocksum + (size_t)mt * f.nblocks;
+    u64* base = f.blockbase + (size_t)mt * f.nblocks;
+    u64 sum = 0;
+    for (int b = b0; b < b1; b++) sum += sums[b];
+    lds[tid] = sum;
+    block_sync();
+    if (tid == 0) {
+        u64 run = 0;
+        for (int i = 0; i < nt; i++) {
+            const u64 v = lds[i];
+            lds[i] = run;
+            run += v;
+        }
+        f.totals[mt] = run;
+    }
+    block_sync();
+    u64 run = lds[tid];
+    for (int b = b0; b < b1; b++) {
+        base[b] = run;
+        run += sums[b];
+    }
+}
+
+FQ_DEV void fmt_copy(u8* dst, const u8* src, u32 n, int lane) {
+    for (u32 i = (u32)lane; i < n; i += 64) dst[i] = src[i];
+    if (lane == 0) dst[n] = 10;  // '\n'
+}
+
+FQ_DEV void fmt_write_body(const FmtArgs& f, u32* lds) {
+    // offsets of the block's units: block base + exclusive prefix of the record sizes (per stream)
+    const int tid = thread_id();
+    const int g0 = block_id() * block_threads();
+    const int mates = f.paired ? 2 : 1;
+    const int g = g0 + tid;
+    const bool out = g < f.n && fmt_unit_out(f, g);
+    for (int mt = 0; mt < mates; mt++) {
+        const u32 b = out ? fmt_record_bytes(f.m[mt], g) : 0u;
+        u32 incl = b;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const u32 o = shfl(incl, lane_id() - sh);
+            if (lane_id() >= sh) incl += o;
+        }
+        const int wave = wave_id(), nw = block_threads() >> 6;
+        if (lane_id() == 63) lds[mt * 16 + wave] = incl;
+        block_sync();
+        u64 off = f.blockbase[(size_t)mt * f.nblocks + block_id()] + (incl - b);
+        for (int w = 0; w < nw; w++)
+            if (w < wave) off += lds[mt * 16 + w];
+        if (g < f.n) f.m[mt].unit_off[g] = out ? off : ~0ull;
+        block_sync();
+    }
+    // copy: one wavefront per unit, looping over the block's units
+    const int lane = lane_id(), nw = block_threads() >> 6;
+    for (int u = wave_id(); u < block_threads(); u += nw) {
+        const int gu = g0 + u;
+        if (gu >= f.n) break;
+        for (int mt = 0; mt < mates; mt++) {
+            const FmtMate& M = f.m[mt];
+            const u64 off = M.unit_off[gu];
+            if (off == ~0ull) continue;
+            const u32 w0 = M.res[(size_t)gu * 3];
+            const u32 front = w0 & 0xFFFFu, len = w0 >> 16;
+            const u32 nl = M.line_len[4 * (size_t)gu], sl = M.line_len[4 * (size_t)gu + 2];
+            if (off + nl + sl + 2u * len + 4u > M.out_cap) continue;  // the host sees the needed size in totals
+            u8* o = M.out + off;
+            fmt_copy(o, M.text + M.line_off[4 * (size_t)gu], nl, lane);
+            o += nl + 1;
+            fmt_copy(o, M.text + M.line_off[4 * (size_t)gu + 1] + front, len, lane);
+            o += len + 1;
+            fmt_copy(o, M.text + M.line_off[4 * (size_t)gu + 2], sl, lane);
+            o += sl + 1;
+            fmt_copy(o, M.text + M.line_off[4 * (size_t)gu + 3] + front, len, lane);
+        }
+    }
+}
+
+FQ_DEV void fmt_fix_body(const FmtArgs& f) {
+    const int i = block_id() * block_threads() + thread_id();
+    if (!f.corrections || !f.n_corrections || i >= *f.n_corrections) return;
+    const u32 rd = f.corrections[2 * (size_t)i], w = f.corrections[2 * (size_t)i + 1];
+    const int mt = f.paired ? (int)(rd & 1u) : 0;
+    const int g = (int)(f.paired ? rd >> 1 : rd) - f.corr_first;
+    if (g < 0 || g >= f.n) return;
+    const FmtMate& M = f.m[mt];
+    const u64 off = M.unit_off[g];
+    if (off == ~0ull) return;
+    const u32 w0 = M.res[(size_t)g * 3];
+    const u32 front = w0 & 0xFFFFu, len = w0 >> 16, pos = w & 0xFFFFu;
+    if (pos < front || pos >= front + len) return;  // the edited base was trimmed away
+    const u32 nl = M.line_len[4 * (size_t)g], sl = M.line_len[4 * (size_t)g + 2];
+    if (off + nl + sl + 2u * len + 4u > M.out_cap) return;
+    M.out[off + nl + 1 + (pos - front)] = (u8)((w >> 16) & 0xFFu);
+    M.out[off + nl + 1 + len + 1 + sl + 1 + (pos - front)] = (u8)(w >> 24);
+}
+
 }  // namespace fq

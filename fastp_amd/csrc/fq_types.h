@@ -210,6 +210,29 @@ struct ParseArgs {
     u32* line_len;
 };
 
+// ---- result records -> output FASTQ text on the device (fq_fmt_* kernels) ----
+enum { FMT_BLOCK = 256 };
+struct FmtMate {
+    const u8* text;
+    const u32* line_off;
+    const u32* line_len;
+    const u32* res;      // 3 dwords per record
+    u8* out;
+    u64 out_cap;
+    u64* unit_off;       // [n] offset of the unit's record in `out`
+};
+struct FmtArgs {
+    int n, paired, dedup;
+    FmtMate m[2];
+    u64* blocksum;       // [2][nblocks] bytes the block's units add to each stream
+    u64* blockbase;      // [2][nblocks]
+    u64* totals;         // [2]
+    int nblocks;
+    const u32* corrections;  // fastp_gpu_correction, 2 dwords each
+    const int* n_corrections;
+    int corr_first;      // unit index the correction list's `read` field is relative to
+};
+
 struct KernelArgs {
     DevParams p;
     DevLuts lut;

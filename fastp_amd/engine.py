@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_parse_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
 ]
@@ -193,6 +193,20 @@ class GpuEngine:
             self._check(rc)
         info.rc = rc
         return info
+
+    def format_fastq(self, n, m1: abi.FormatIn, m2, corrections_ptr, n_corrections_ptr, out1_ptr, out1_cap, out2_ptr,
+                     out2_cap, check=True):
+        """result records + parsed text on the device -> out1 / out2 FASTQ text on the device"""
+        fn = self.lib.fastp_gpu_format_fastq
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.FormatIn), C.POINTER(abi.FormatIn), C.c_void_p, C.c_void_p,
+                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lens = (C.c_int64 * 2)()
+        rc = fn(self.h, n, C.byref(m1), C.byref(m2) if m2 is not None else None, corrections_ptr, n_corrections_ptr,
+                out1_ptr, out1_cap, out2_ptr, out2_cap, lens)
+        if check:
+            self._check(rc)
+        return rc, int(lens[0]), int(lens[1])
 
     def synchronize(self):
         self._check(self.lib.fastp_gpu_synchronize(self.h))

@@ -337,6 +337,28 @@ int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbyte
                           uint32_t* line_len,  /* [4*max_records] its length without the terminator        */
                           fastp_gpu_parse_info* info);
 
+/* ---- result records -> output FASTQ text ON THE DEVICE ---------------
+ * The step after the path for the main output streams: Read::appendToString (src/read.cpp:119-134)
+ * for every unit the worker loop routes to out1 [and out2] (peprocessor.cpp:577-591,
+ * seprocessor.cpp:280-286): name line, seq[front, front+len), strand line, qual[front, front+len),
+ * each followed by '\n', in input order, BaseCorrector edits applied.  Inputs are what
+ * fastp_gpu_parse_fastq and fastp_gpu_submit_device left on the device.  failed_out / unpaired /
+ * merged streams and name edits (UMI, fixMGI) stay with the host: merge mode and umi_len* > 0 are
+ * refused (FASTP_GPU_E_UNSUPPORTED).  FASTP_GPU_E_OVERFLOW when an output buffer is too small
+ * (out_len still reports the needed sizes).  All pointers except out_len are DEVICE pointers. */
+typedef struct fastp_gpu_format_in {
+    const uint8_t* text;            /* the FASTQ chunk the records were parsed from      */
+    const uint32_t* line_off;       /* [4n] from fastp_gpu_parse_fastq                    */
+    const uint32_t* line_len;       /* [4n]                                               */
+    const fastp_gpu_read_result* res; /* [n] this mate's result records                   */
+} fastp_gpu_format_in;
+
+int fastp_gpu_format_fastq(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_format_in* mate1,
+                           const fastp_gpu_format_in* mate2 /* NULL for single-end */,
+                           const fastp_gpu_correction* corrections, const int32_t* n_corrections /* may be NULL */,
+                           uint8_t* out1, int64_t out1_capacity, uint8_t* out2, int64_t out2_capacity,
+                           int64_t out_len[2] /* host: bytes written (needed) per stream */);
+
 /* Process one batch whose buffers (and result buffers) live in HOST memory:
  * H2D copy, kernels, D2H copy, synchronous. */
 int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, fastp_gpu_results* res);

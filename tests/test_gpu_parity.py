@@ -409,6 +409,29 @@ def test_gpu_device_fastq_parse_feeds_the_engine(eol):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "pe_filters", "pe_noadapter_dedup", "pe_adapter_fasta",
+                                  "se_adapter_cut", "se_polyx_complexity"])
+def test_gpu_device_fastq_format_equals_host_writer(name):
+    """text in HBM -> parse -> submit_device -> fastp_gpu_format_fastq: out1/out2 text == the host writer's"""
+    import format_util
+    import test_hostsim_parity as hs
+    want = hs._format_case(engines.gpu_engine, format_util.TorchMem(), name, 12000)
+    assert len(want.out1) > 0
+
+
+def test_gpu_device_fastq_format_crlf_and_overflow():
+    import format_util
+    import test_hostsim_parity as hs
+    hs._format_case(engines.gpu_engine, format_util.TorchMem(), "pe_correction", 3000, eol=b"\r\n")
+    d = synth.synth_pairs(1000, L=150, seed=5, paired=False)
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    p = abi.default_params(False, 150)
+    g = engines.gpu_engine(p)
+    rc, o1, _, lens = format_util.run(g, format_util.TorchMem(), p, fq1, None, 150, out_slack=-(len(fq1) // 2))
+    assert rc == abi.E_OVERFLOW and lens[0] > len(o1)
+    g.close()
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))

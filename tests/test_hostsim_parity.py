@@ -231,3 +231,59 @@ def test_sim_device_fastq_parse_chunks_limits_and_errors():
         info, *_ = parse_util.run_numpy(g, b"\r\n".join(ls), 150, 1000, True, check=False)
         assert info.rc == abi.E_INVALID and info.first_bad == 5, (mutate, info.rc, info.first_bad)
     g.close()
+
+
+FORMAT_CASES = ["pe_default", "pe_cut_front_tail", "pe_adapter_seq", "pe_correction", "pe_filters", "pe_noadapter_dedup",
+                "pe_allow_gap", "pe_adapter_fasta", "se_default_noadapter", "se_adapter_cut", "se_polyx_complexity"]
+
+
+def _format_case(mk_engine, mem, name, n, eol=b"\n"):
+    import format_util
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(n, L=150, seed=77, paired=paired, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
+    ref = mk_engine(params)
+    want, _, _ = driver.run_engine(ref, params, fq1, fq2, pack=n, stride=abi.qual_stride(150))
+    ref.close()
+    g = mk_engine(params)
+    rc, o1, o2, lens = format_util.run(g, mem, params, fq1.replace(b"\n", eol), fq2.replace(b"\n", eol) if paired else None, 150)
+    g.close()
+    assert rc == 0
+    assert o1 == bytes(want.out1), f"{name}: out1 differs"
+    if paired:
+        assert o2 == bytes(want.out2), f"{name}: out2 differs"
+    assert lens[0] == len(want.out1)
+    return want
+
+
+@pytest.mark.parametrize("name", FORMAT_CASES)
+def test_sim_device_fastq_format_equals_host_writer(name):
+    """results + parsed text -> out1/out2 text on the device == hostloop.apply_results' out1/out2"""
+    import format_util
+    want = _format_case(engines.sim_engine, format_util.NumpyMem(), name, 600)
+    assert len(want.out1) > 0
+
+
+def test_sim_device_fastq_format_crlf_limits_and_errors():
+    import format_util
+    _format_case(engines.sim_engine, format_util.NumpyMem(), "pe_correction", 300, eol=b"\r\n")
+    # too small an output buffer: E_OVERFLOW, needed sizes reported, nothing written past the capacity
+    paired, flags, pf, skw = cases.CASES["se_default_noadapter"]
+    d = synth.synth_pairs(100, L=150, seed=5, paired=False)
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    p = pf(150)
+    g = engines.sim_engine(p)
+    rc, o1, _, lens = format_util.run(g, format_util.NumpyMem(), p, fq1, None, 150, out_slack=-(len(fq1) // 2))
+    assert rc == abi.E_OVERFLOW and lens[0] > len(o1)
+    g.close()
+    for name in ("pe_merge", "pe_umi_per_read"):
+        paired, flags, pf, skw = cases.CASES[name]
+        d = synth.synth_pairs(50, L=150, seed=5)
+        p = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d["seq2"], d["len2"])
+        g = engines.sim_engine(p)
+        rc, *_ = format_util.run(g, format_util.NumpyMem(), p, synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1),
+                                 synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2), 150)
+        assert rc == abi.E_UNSUPPORTED
+        g.close()
