@@ -159,8 +159,22 @@ def main():
     torch.cuda.synchronize(dev)
     log("warmup")
 
-    for _ in range(args.warmup):
-        eng.submit_device(batch, res)
+    # N>1: the exact sharded protocol - duplicate scan pass, bitmap all-gather, worker loop against
+    # the preceding shards' bitmaps - so that the merged result is that of one stream.  BENCH_SHARD=plain runs the
+    # per-shard submit instead (cross-shard duplicates missed); BENCH_SHARD=force runs the protocol at N=1 too.
+    shard_mode = os.environ.get("BENCH_SHARD", "exact")
+    protocol = shard_mode == "force" or (shard_mode == "exact" and world > 1)
+
+    def run_steps(k):
+        if protocol:
+            multigpu.run_shard(eng, dist, rank, world, [batch] * k, [res] * k, dev, force=True)
+        else:
+            for _ in range(k):
+                eng.submit_device(batch, res)
+
+    run_steps(args.warmup)
+    if dist is not None:
+        multigpu.allreduce_counters_device(eng, dist, dev)   # communicator set-up stays outside the timed region
     eng.synchronize()
     eng.kernel_time()  # reset the event accumulator
 
@@ -168,10 +182,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.submit_device(batch, res)
+    run_steps(args.steps)
     if dist is not None:
-        multigpu.allreduce_counters_device(eng, dist, dev)   # the one collective of the job
+        multigpu.allreduce_counters_device(eng, dist, dev)   # Stats::merge / FilterResult::merge
     eng.synchronize()
     torch.cuda.synchronize(dev)
     if dist is not None:
@@ -221,7 +234,9 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "PE 2x150 bp synthetic (fragment model), auto-adapter via overlap + --cut_right "
                                    "quality trim, dup evaluation on, fastp default filters",
-                       "pairs_per_step_per_gpu": B, "read_len": L, "parallelism": f"shard x{world}"},
+                       "pairs_per_step_per_gpu": B, "read_len": L, "parallelism": f"shard x{world}",
+                       "cross_shard_duplicates": "exact (scan pass + bitmap all-gather)" if protocol else
+                                                 ("n/a" if world == 1 else "per shard")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "fq_fused_kernel", "kernel_avg_ms": round(avg_ms, 4),

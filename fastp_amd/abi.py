@@ -25,6 +25,7 @@ FAIL_ADAPTER_DIMER = 28
 FILTER_RESULT_TYPES = 32
 
 BATCH_STAT_ISIZE = 1
+BATCH_DEFER_OVERREP = 2
 
 RF_NULL, RF_DUP, RF_ADAPTER, RF_ADAPTER_OV, RF_CORRECTED, RF_MERGED, RF_POLYX = (
     0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40)

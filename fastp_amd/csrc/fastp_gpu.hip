@@ -51,6 +51,11 @@ extern "C" __global__ void __launch_bounds__(256) fq_parse_index_kernel(ParseArg
 }
 extern "C" __global__ void __launch_bounds__(64) fq_parse_finish_kernel(ParseArgs p) { parse_finish_body(p); }
 extern "C" __global__ void __launch_bounds__(256) fq_parse_pack_kernel(ParseArgs p) { parse_pack_body(p); }
+extern "C" __global__ void __launch_bounds__(256) fq_dup_final_kernel(DupFinalArgs d) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    dup_final_body(d, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_or_images_kernel(OrArgs o) { or_images_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_fmt_len_kernel(FmtArgs f) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     fmt_len_body(f, fq_lds);
@@ -107,6 +112,8 @@ struct fastp_gpu_ctx {
     u64* d_table = nullptr; size_t table_cap = 0;
     u8* d_need = nullptr; size_t need_cap = 0;
     u8* d_dupflag = nullptr; size_t dupflag_cap = 0;   // --dedup: per-unit duplicate decision
+    u32* d_prefix = nullptr;                           // sharded runs: OR of the preceding shards' bitmaps
+    bool has_prefix = false;
     // overrepresentation analysis
     u32* d_ovr_table[2] = {nullptr, nullptr};
     u8* d_ovr_sym[2] = {nullptr, nullptr};
@@ -176,7 +183,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -339,148 +346,11 @@ static int get_events(fastp_gpu_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
 }
 
 // one launch: at most ctx->max_pairs_per_launch units
-static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first, int n, fastp_gpu_results* res,
-                        hipStream_t st) {
-    KernelArgs a;
-    memset(&a, 0, sizeof(a));
-    a.p = ctx->dp;
-    a.lut.ov_limit = (const u16*)ctx->d_ov_limit;
-    a.lut.lowq_limit = ctx->d_lowq;
-    a.lut.cplx_min = ctx->d_cplx;
-    a.lut.dup_primes = ctx->d_primes;
-    a.lut.dup_posum = ctx->d_posum;
-    a.lut.fasta_words = ctx->d_fasta_words;
-    a.lut.fasta_len = ctx->d_fasta_len;
-    a.L = ctx->L;
-    a.magic_sw = magic_for((u32)ctx->L.SW);
-    a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
-    a.magic_swg = magic_for((u32)ctx->dp.sw_g);
-    {   // vector (16-byte) tile copies + register prefetch need aligned rows and a tile that fits the registers
-        const size_t qchunks = (size_t)ctx->L.NR * ctx->dp.qw_g / 4, schunks = (size_t)ctx->L.NR * ctx->dp.sw_g / 4;
-        bool ok = (ctx->L.P % 2 == 0) && (first % 2 == 0) && qchunks <= (size_t)PF_Q * ctx->cfg.threads &&
-                  schunks <= (size_t)PF_S * ctx->cfg.threads && ctx->L.NR <= ctx->cfg.threads &&
-                  !env_int("FASTP_GPU_NO_PREFETCH", 0);
-        const void* ptrs[4] = {b->seq1, b->qual1, ctx->dp.paired ? b->seq2 : b->seq1, ctx->dp.paired ? b->qual2 : b->qual1};
-        for (const void* q : ptrs) ok = ok && (((uintptr_t)q & 15u) == 0);
-        a.prefetch = ok ? (env_int("FASTP_GPU_PREFETCH_AHEAD", 1) ? 1 : 2) : 0;
-    }
-    a.n = n;
-    a.first = first;
-    a.batch_flags = b->flags;
-    const size_t swg = ctx->dp.sw_g, qwg = ctx->dp.qw_g;
-    a.seq[0] = (const u32*)b->seq1 + (size_t)first * swg;
-    a.qual[0] = (const u32*)b->qual1 + (size_t)first * qwg;
-    a.len[0] = b->len1 + first;
-    a.res[0] = (u32*)res->r1 + (size_t)first * 3;
-    if (ctx->dp.paired) {
-        a.seq[1] = (const u32*)b->seq2 + (size_t)first * swg;
-        a.qual[1] = (const u32*)b->qual2 + (size_t)first * qwg;
-        a.len[1] = b->len2 + first;
-        a.res[1] = (u32*)res->r2 + (size_t)first * 3;
-        a.pair = (u32*)res->pair + (size_t)first * 2;
-    }
-    a.corrections = (ctx->dp.correction && res->corrections && res->n_corrections) ? (u32*)res->corrections : nullptr;
-    a.corr_capacity = res->corrections_capacity;
-    a.n_corrections = res->n_corrections;
-    a.adapter_events = (ctx->dp.n_fasta && res->adapter_events && res->n_adapter_events) ? (u32*)res->adapter_events : nullptr;
-    a.adapter_events_capacity = res->adapter_events_capacity;
-    a.n_adapter_events = res->n_adapter_events;
-    if (ctx->dp.dup_enabled) {
-        int rc = ensure(ctx, (void**)&ctx->d_dup_pos, &ctx->dup_pos_cap, (size_t)n * ctx->dp.dup_bufnum * 8);
-        if (rc) return rc;
-        a.dup_pos = ctx->d_dup_pos;
-    }
-    a.phase_cycles = ctx->d_phase;
-    a.slabs = ctx->d_slabs;
-    a.slab_dwords = ctx->slab_dwords;
-    a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
-    const int grid = a.tiles < ctx->blocks ? a.tiles : ctx->blocks;
+// Stats::statRead's overrepresentation analysis (stats.cpp:270-288) of one launch, after its records exist
+static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStream_t st) {
     const fastp_gpu_counter_layout& cl = ctx->cl;
     int rc;
-
-    // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
-    auto launch_dup = [&](u8* dupflag) -> int {
-        DupArgs d;
-        memset(&d, 0, sizeof(d));
-        d.dup_pos = ctx->d_dup_pos;
-        d.posum = ctx->d_posum;
-        d.len[0] = a.len[0];
-        d.len[1] = a.len[1];
-        d.n = n;
-        d.B = ctx->dp.dup_bufnum;
-        d.bits = ctx->dp.dup_bits;
-        d.bitmap = ctx->d_bitmap;
-        int lg = 10;
-        while ((1ull << lg) < (size_t)n * d.B * 2) lg++;
-        int r2 = ensure(ctx, (void**)&ctx->d_table, &ctx->table_cap, (size_t)8 << lg);
-        if (r2) return r2;
-        r2 = ensure(ctx, (void**)&ctx->d_need, &ctx->need_cap, (size_t)n);
-        if (r2) return r2;
-        d.table = ctx->d_table;
-        d.table_log2 = lg;
-        d.need = ctx->d_need;
-        d.res[0] = a.res[0];
-        d.res[1] = a.res[1];
-        d.dupflag = dupflag;
-        d.paired = ctx->dp.paired;
-        d.ctr_total = ctx->d_ctr + cl.dup_total;
-        d.ctr_dups = ctx->d_ctr + cl.dup_count;
-        HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
-        const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
-        hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
-        HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
-        HIP_TRY(ctx, hipGetLastError());
-        return 0;
-    };
-
-    if (ctx->dp.dedup) {
-        // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
-        rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
-        if (rc) return rc;
-        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
-        HIP_TRY(ctx, hipGetLastError());
-        rc = launch_dup(ctx->d_dupflag);
-        if (rc) return rc;
-        a.dup_pos = nullptr;
-        a.dupflag = ctx->d_dupflag;
-    }
-
-    hipEvent_t e0, e1;
-    rc = get_events(ctx, &e0, &e1);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(e1, st));
-    ctx->pending_events.push_back({e0, e1});
-
-    ReduceArgs r;
-    memset(&r, 0, sizeof(r));
-    r.slabs = ctx->d_slabs;
-    r.slab_dwords = ctx->slab_dwords;
-    r.nblocks = grid;
-    r.L = ctx->L;
-    r.isize_max = ctx->dp.isize_max;
-    r.one_pass = ctx->dp.stats_one_pass;
-    r.ctr = ctx->d_ctr;
-    r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
-    r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;
-    r.o_corrected_reads = cl.corrected_reads; r.o_merged = cl.merged_pairs; r.o_isize = cl.isize;
-    for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
-    r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
-    r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
-    const int items = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128 * QH_COPIES + MISC_ISIZE + ctx->dp.isize_max + 1;
-    const int rgroups = (grid + REDUCE_GROUP - 1) / REDUCE_GROUP;
-    hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
-    HIP_TRY(ctx, hipGetLastError());
-
-    if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
-        rc = launch_dup(nullptr);
-        if (rc) return rc;
-    }
-
-    if (ctx->dp.overrep) {  // Stats::statRead's overrepresentation analysis (stats.cpp:270-288)
+    if (ctx->dp.overrep) {
         OvrArgs o;
         memset(&o, 0, sizeof(o));
         o.n = n;
@@ -527,30 +397,302 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     return FASTP_GPU_OK;
 }
 
-extern "C" int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res,
-                                       void* hip_stream) {
-    if (!ctx || !b || !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+// what a launch does with Duplicate::checkPair/checkRead
+enum ChunkMode {
+    CHUNK_STREAM,    // one stream: decide inside this launch (the normal path)
+    CHUNK_DUP_SCAN,  // sharded run, pass 1: hash + insert + scan state only
+    CHUNK_SCANNED,   // sharded run, pass 2: decide from the scan state and the prefix bitmaps
+    CHUNK_OVERREP,   // the deferred overrepresentation analysis only
+};
+
+static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first, int n, const fastp_gpu_results* res,
+                        hipStream_t st, ChunkMode mode = CHUNK_STREAM, u8* scan_state = nullptr) {
+    KernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = ctx->dp;
+    a.lut.ov_limit = (const u16*)ctx->d_ov_limit;
+    a.lut.lowq_limit = ctx->d_lowq;
+    a.lut.cplx_min = ctx->d_cplx;
+    a.lut.dup_primes = ctx->d_primes;
+    a.lut.dup_posum = ctx->d_posum;
+    a.lut.fasta_words = ctx->d_fasta_words;
+    a.lut.fasta_len = ctx->d_fasta_len;
+    a.L = ctx->L;
+    a.magic_sw = magic_for((u32)ctx->L.SW);
+    a.magic_qwg = magic_for((u32)ctx->dp.qw_g);
+    a.magic_swg = magic_for((u32)ctx->dp.sw_g);
+    {   // vector (16-byte) tile copies + register prefetch need aligned rows and a tile that fits the registers
+        const size_t qchunks = (size_t)ctx->L.NR * ctx->dp.qw_g / 4, schunks = (size_t)ctx->L.NR * ctx->dp.sw_g / 4;
+        bool ok = (ctx->L.P % 2 == 0) && (first % 2 == 0) && qchunks <= (size_t)PF_Q * ctx->cfg.threads &&
+                  schunks <= (size_t)PF_S * ctx->cfg.threads && ctx->L.NR <= ctx->cfg.threads &&
+                  !env_int("FASTP_GPU_NO_PREFETCH", 0);
+        const void* ptrs[4] = {b->seq1, b->qual1, ctx->dp.paired ? b->seq2 : b->seq1, ctx->dp.paired ? b->qual2 : b->qual1};
+        for (const void* q : ptrs) ok = ok && (((uintptr_t)q & 15u) == 0);
+        a.prefetch = ok ? (env_int("FASTP_GPU_PREFETCH_AHEAD", 1) ? 1 : 2) : 0;
+    }
+    a.n = n;
+    a.first = first;
+    a.batch_flags = b->flags;
+    const size_t swg = ctx->dp.sw_g, qwg = ctx->dp.qw_g;
+    a.seq[0] = (const u32*)b->seq1 + (size_t)first * swg;
+    a.qual[0] = (const u32*)b->qual1 + (size_t)first * qwg;
+    a.len[0] = b->len1 + first;
+    if (res) a.res[0] = (u32*)res->r1 + (size_t)first * 3;
+    if (ctx->dp.paired) {
+        a.seq[1] = (const u32*)b->seq2 + (size_t)first * swg;
+        a.qual[1] = (const u32*)b->qual2 + (size_t)first * qwg;
+        a.len[1] = b->len2 + first;
+        if (res) {
+            a.res[1] = (u32*)res->r2 + (size_t)first * 3;
+            a.pair = (u32*)res->pair + (size_t)first * 2;
+        }
+    }
+    if (res) {
+        a.corrections = (ctx->dp.correction && res->corrections && res->n_corrections) ? (u32*)res->corrections : nullptr;
+        a.corr_capacity = res->corrections_capacity;
+        a.n_corrections = res->n_corrections;
+        a.adapter_events = (ctx->dp.n_fasta && res->adapter_events && res->n_adapter_events) ? (u32*)res->adapter_events : nullptr;
+        a.adapter_events_capacity = res->adapter_events_capacity;
+        a.n_adapter_events = res->n_adapter_events;
+    }
+    // scan state of the whole batch: positions [b->n][B] u64, then masks [b->n] u8
+    u64* scan_pos = scan_state ? (u64*)scan_state + (size_t)first * ctx->dp.dup_bufnum : nullptr;
+    u8* scan_mask = scan_state ? scan_state + (size_t)b->n * ctx->dp.dup_bufnum * 8 + first : nullptr;
+    if (ctx->dp.dup_enabled && mode != CHUNK_OVERREP) {
+        int rc = ensure(ctx, (void**)&ctx->d_dup_pos, &ctx->dup_pos_cap, (size_t)n * ctx->dp.dup_bufnum * 8);
+        if (rc) return rc;
+        a.dup_pos = ctx->d_dup_pos;
+    }
+    a.phase_cycles = ctx->d_phase;
+    a.slabs = ctx->d_slabs;
+    a.slab_dwords = ctx->slab_dwords;
+    a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
+    const int grid = a.tiles < ctx->blocks ? a.tiles : ctx->blocks;
+    const fastp_gpu_counter_layout& cl = ctx->cl;
+    int rc;
+
+    // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
+    auto launch_dup = [&](u8* dupflag, bool scan = false) -> int {
+        DupArgs d;
+        memset(&d, 0, sizeof(d));
+        if (scan) { d.scan_pos = scan_pos; d.scan_mask = scan_mask; }
+        d.dup_pos = ctx->d_dup_pos;
+        d.posum = ctx->d_posum;
+        d.len[0] = a.len[0];
+        d.len[1] = a.len[1];
+        d.n = n;
+        d.B = ctx->dp.dup_bufnum;
+        d.bits = ctx->dp.dup_bits;
+        d.bitmap = ctx->d_bitmap;
+        int lg = 10;
+        while ((1ull << lg) < (size_t)n * d.B * 2) lg++;
+        int r2 = ensure(ctx, (void**)&ctx->d_table, &ctx->table_cap, (size_t)8 << lg);
+        if (r2) return r2;
+        r2 = ensure(ctx, (void**)&ctx->d_need, &ctx->need_cap, (size_t)n);
+        if (r2) return r2;
+        d.table = ctx->d_table;
+        d.table_log2 = lg;
+        d.need = ctx->d_need;
+        d.res[0] = a.res[0];
+        d.res[1] = a.res[1];
+        d.dupflag = dupflag;
+        d.paired = ctx->dp.paired;
+        d.ctr_total = ctx->d_ctr + cl.dup_total;
+        d.ctr_dups = ctx->d_ctr + cl.dup_count;
+        HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
+        const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
+        hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
+
+    if (mode == CHUNK_DUP_SCAN) {
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        return launch_dup(nullptr, true);
+    }
+    if (mode == CHUNK_OVERREP) return launch_overrep(ctx, a, n, st);
+    if (mode == CHUNK_SCANNED) {
+        // the decision comes from pass 1's scan state + the preceding shards' bitmaps; nothing is hashed again
+        rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
+        if (rc) return rc;
+        DupFinalArgs d;
+        memset(&d, 0, sizeof(d));
+        d.scan_pos = scan_pos;
+        d.scan_mask = scan_mask;
+        d.prefix = ctx->has_prefix ? ctx->d_prefix : nullptr;
+        d.bits = ctx->dp.dup_bits;
+        d.n = n;
+        d.B = ctx->dp.dup_bufnum;
+        d.dupflag = ctx->d_dupflag;
+        d.ctr_total = ctx->d_ctr + cl.dup_total;
+        d.ctr_dups = ctx->d_ctr + cl.dup_count;
+        hipLaunchKernelGGL(fq_dup_final_kernel, dim3((n + 255) / 256), dim3(256), 16, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        a.dup_pos = nullptr;
+        a.dupflag = ctx->d_dupflag;
+    } else if (ctx->dp.dedup) {
+        // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
+        rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        rc = launch_dup(ctx->d_dupflag);
+        if (rc) return rc;
+        a.dup_pos = nullptr;
+        a.dupflag = ctx->d_dupflag;
+    }
+
+    hipEvent_t e0, e1;
+    rc = get_events(ctx, &e0, &e1);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    ctx->pending_events.push_back({e0, e1});
+
+    ReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.slabs = ctx->d_slabs;
+    r.slab_dwords = ctx->slab_dwords;
+    r.nblocks = grid;
+    r.L = ctx->L;
+    r.isize_max = ctx->dp.isize_max;
+    r.one_pass = ctx->dp.stats_one_pass;
+    r.ctr = ctx->d_ctr;
+    r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
+    r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;
+    r.o_corrected_reads = cl.corrected_reads; r.o_merged = cl.merged_pairs; r.o_isize = cl.isize;
+    for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
+    r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
+    r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
+    const int items = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128 * QH_COPIES + MISC_ISIZE + ctx->dp.isize_max + 1;
+    const int rgroups = (grid + REDUCE_GROUP - 1) / REDUCE_GROUP;
+    hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
+    HIP_TRY(ctx, hipGetLastError());
+
+    if (ctx->dp.dup_enabled && !ctx->dp.dedup && mode != CHUNK_SCANNED) {
+        rc = launch_dup(nullptr);
+        if (rc) return rc;
+    }
+    if (b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) return FASTP_GPU_OK;
+    return launch_overrep(ctx, a, n, st);
+}
+
+
+static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fastp_gpu_results* res, void* hip_stream,
+                         ChunkMode mode, u8* scan_state) {
+    if (!ctx || !b) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    const bool need_res = mode != CHUNK_DUP_SCAN;
+    if (need_res && !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
     if (b->n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "negative batch size");
-    if (!b->seq1 || !b->qual1 || !b->len1 || !res->r1) {
+    if (!b->seq1 || !b->qual1 || !b->len1 || (need_res && !res->r1)) {
         if (b->n > 0) return fail(ctx, FASTP_GPU_E_INVALID, "missing read-1 buffers");
     }
-    if (ctx->dp.paired && b->n > 0 && (!b->seq2 || !b->qual2 || !b->len2 || !res->r2 || !res->pair))
+    if (ctx->dp.paired && b->n > 0 && (!b->seq2 || !b->qual2 || !b->len2 || (need_res && (!res->r2 || !res->pair))))
         return fail(ctx, FASTP_GPU_E_INVALID, "paired engine needs read-2 buffers and pair results");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
-    if (ctx->dp.n_fasta && b->n > 0 && (!res->adapter_events || !res->n_adapter_events))
-        return fail(ctx, FASTP_GPU_E_INVALID, "adapter_fasta needs an adapter event list in the results");
-    if (res->n_adapter_events) HIP_TRY(ctx, hipMemsetAsync(res->n_adapter_events, 0, sizeof(int32_t), st));
+    if (mode == CHUNK_STREAM || mode == CHUNK_SCANNED) {
+        if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
+        if (ctx->dp.n_fasta && b->n > 0 && (!res->adapter_events || !res->n_adapter_events))
+            return fail(ctx, FASTP_GPU_E_INVALID, "adapter_fasta needs an adapter event list in the results");
+        if (res->n_adapter_events) HIP_TRY(ctx, hipMemsetAsync(res->n_adapter_events, 0, sizeof(int32_t), st));
+    }
     // split into equally sized launches (each a multiple of the tile size)
     const int launches = (b->n + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
     int per = launches ? (b->n + launches - 1) / launches : 0;
     per = (per + ctx->L.P - 1) / ctx->L.P * ctx->L.P;
     for (int first = 0; first < b->n; first += per) {
         const int n = std::min(per, b->n - first);
-        int rc = launch_chunk(ctx, b, first, n, res, st);
+        int rc = launch_chunk(ctx, b, first, n, res, st, mode, scan_state);
         if (rc) return rc;
     }
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_submit_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res,
+                                       void* hip_stream) {
+    return submit_chunks(ctx, b, res, hip_stream, CHUNK_STREAM, nullptr);
+}
+
+// ---- sharded runs (include/fastp_gpu.h "Sharded runs") -------------------------------------
+extern "C" int64_t fastp_gpu_dup_scan_bytes(const fastp_gpu_ctx* ctx, int32_t n) {
+    if (!ctx || n < 0) return -1;
+    return (int64_t)n * ctx->dp.dup_bufnum * 8 + (((int64_t)n + 15) & ~(int64_t)15);
+}
+
+extern "C" int fastp_gpu_dup_scan_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, void* scan_state, void* hip_stream) {
+    if (!ctx) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    if (!ctx->dp.dup_enabled) return FASTP_GPU_OK;  // nothing depends on earlier units
+    if (!scan_state || ((uintptr_t)scan_state & 7u)) return fail(ctx, FASTP_GPU_E_INVALID, "scan state must be an 8-byte aligned device buffer");
+    return submit_chunks(ctx, b, nullptr, hip_stream, CHUNK_DUP_SCAN, (u8*)scan_state);
+}
+
+extern "C" int fastp_gpu_submit_scanned_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const void* scan_state,
+                                               fastp_gpu_results* res, void* hip_stream) {
+    if (!ctx) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    if (!ctx->dp.dup_enabled) return submit_chunks(ctx, b, res, hip_stream, CHUNK_STREAM, nullptr);
+    if (!scan_state || ((uintptr_t)scan_state & 7u)) return fail(ctx, FASTP_GPU_E_INVALID, "scan state must be an 8-byte aligned device buffer");
+    return submit_chunks(ctx, b, res, hip_stream, CHUNK_SCANNED, (u8*)scan_state);
+}
+
+extern "C" int fastp_gpu_overrep_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fastp_gpu_results* res,
+                                        void* hip_stream) {
+    return submit_chunks(ctx, b, res, hip_stream, CHUNK_OVERREP, nullptr);
+}
+
+extern "C" int64_t fastp_gpu_dup_bitmap_bytes(const fastp_gpu_ctx* ctx) {
+    if (!ctx) return -1;
+    return ctx->dp.dup_enabled ? (int64_t)ctx->dp.dup_bufnum * (int64_t)(ctx->dp.dup_bits / 8) : 0;
+}
+
+extern "C" int fastp_gpu_dup_bitmap_export(fastp_gpu_ctx* ctx, void* dst_device) {
+    if (!ctx) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    const int64_t bytes = fastp_gpu_dup_bitmap_bytes(ctx);
+    if (bytes == 0) return FASTP_GPU_OK;
+    if (!dst_device) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_device, ctx->d_bitmap, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_device, int32_t n_images) {
+    if (!ctx || n_images < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    const int64_t bytes = fastp_gpu_dup_bitmap_bytes(ctx);
+    if (bytes == 0 || n_images == 0) {
+        ctx->has_prefix = false;
+        return FASTP_GPU_OK;
+    }
+    if (!images_device || ((uintptr_t)images_device & 15u)) return fail(ctx, FASTP_GPU_E_INVALID, "bitmap images must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_prefix) {
+        if (hipMalloc((void**)&ctx->d_prefix, (size_t)bytes) != hipSuccess) return fail(ctx, FASTP_GPU_E_NOMEM, "hipMalloc(prefix bitmaps) failed");
+    }
+    OrArgs o;
+    o.images = (const u32x4*)images_device;
+    o.dst = (u32x4*)ctx->d_prefix;
+    o.chunks = (u64)bytes / 16;
+    o.n_images = n_images;
+    hipLaunchKernelGGL(fq_or_images_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, o);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_prefix = true;
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_stream_set_origin(fastp_gpu_ctx* ctx, int64_t units_before, int64_t post_reads_before) {
+    if (!ctx || units_before < 0 || post_reads_before < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->units_seen = (uint64_t)units_before;
+    const u64 v = (u64)post_reads_before;
+    if (!ctx->d_post_seen) return FASTP_GPU_OK;  // no overrepresentation analysis: nothing else reads positions
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_post_seen, &v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FASTP_GPU_OK;
 }
 

@@ -2001,6 +2001,29 @@ struct DupArgs {
     int paired;
     int64_t* ctr_total;
     int64_t* ctr_dups;
+    // sharded runs, pass 1 (fastp_gpu_dup_scan_device): keep the bit positions and the mask of
+    // buffers an earlier unit of this stream had set; no decision, no counters
+    u64* scan_pos;        // [n][B]
+    u8* scan_mask;        // [n]
+};
+
+// sharded runs, pass 2: the decision from the scan state and the preceding shards' bitmaps
+struct DupFinalArgs {
+    const u64* scan_pos;  // [n][B]
+    const u8* scan_mask;  // [n]
+    const u32* prefix;    // [B][bits/32] OR of the preceding shards' bitmaps, or nullptr
+    u64 bits;
+    int n, B;
+    u8* dupflag;          // [n]
+    int64_t* ctr_total;
+    int64_t* ctr_dups;
+};
+
+struct OrArgs {           // dst = OR of n_images consecutive images of `chunks` 16-byte chunks
+    const u32x4* images;
+    u32x4* dst;
+    u64 chunks;
+    int n_images;
 };
 
 enum { DUP_IDX_BITS = 25 };  // pairs per launch < 2^25
@@ -2058,9 +2081,14 @@ FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
         if (g < d.n) {
             const u32 need = d.need[g];
             is_dup = true;
+            u32 set_before = 0;
             for (int i = 0; i < d.B; i++) {
-                if (!((need >> i) & 1u)) continue;  // committed by an earlier batch
+                const bool committed = !((need >> i) & 1u);  // by an earlier batch
+                if (committed) set_before |= 1u << i;
+                if (committed && !d.scan_pos) continue;
                 const u64 pos = dup_bit(d, g, i);
+                if (d.scan_pos) d.scan_pos[(size_t)g * d.B + i] = pos;
+                if (committed) continue;
                 const u64 key = dup_key(i, pos);
                 u32 slot = dup_slot(key, d.table_log2);
                 u64 cur;
@@ -2070,10 +2098,14 @@ FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
                     slot = (slot + 1) & tmask;
                 }
                 const int first = (int)(cur & ((1ull << DUP_IDX_BITS) - 1));
-                if (!(first < g)) is_dup = false;  // nobody earlier in this batch set it
+                if (first < g) set_before |= 1u << i;
+                else is_dup = false;  // nobody earlier in this batch set it
                 g_atomic_or_u32(&d.bitmap[(size_t)i * words + (pos >> 5)], 1u << (pos & 31));
             }
-            if (d.dupflag) {
+            if (d.scan_mask) {
+                d.scan_mask[g] = (u8)set_before;
+                is_dup = false;  // pass 1 decides nothing
+            } else if (d.dupflag) {
                 d.dupflag[g] = is_dup ? 1 : 0;
             } else if (is_dup) {
                 d.res[0][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
@@ -2086,8 +2118,49 @@ FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
         if (lane_id() == 0 && m) lds_add_u32(block_count, (u32)popc64(m));
     }
     block_sync();
+    if (d.scan_mask) return;
     if (thread_id() == 0 && *block_count) g_atomic_add_i64(d.ctr_dups, (int64_t)*block_count);
     if (gid == 0) g_atomic_add_i64(d.ctr_total, (int64_t)d.n);
+}
+
+// duplicate = AND_i (bit i set earlier in this shard OR set by a preceding shard)   
+FQ_DEV void dup_final_body(const DupFinalArgs& d, u32* block_count) {
+    if (thread_id() == 0) *block_count = 0;
+    block_sync();
+    const int g = block_id() * block_threads() + thread_id();
+    const u64 words = d.bits >> 5;
+    bool is_dup = false;
+    if (g < d.n) {
+        const u32 mask = d.scan_mask[g];
+        is_dup = true;
+        for (int i = 0; i < d.B; i++) {
+            if ((mask >> i) & 1u) continue;
+            bool set = false;
+            if (d.prefix) {
+                const u64 pos = d.scan_pos[(size_t)g * d.B + i];
+                set = ((d.prefix[(size_t)i * words + (pos >> 5)] >> (pos & 31)) & 1u) != 0;
+            }
+            if (!set) { is_dup = false; break; }
+        }
+        d.dupflag[g] = is_dup ? 1 : 0;
+    }
+    const u64 m = ballot(is_dup);
+    if (lane_id() == 0 && m) lds_add_u32(block_count, (u32)popc64(m));
+    block_sync();
+    if (thread_id() == 0 && *block_count) g_atomic_add_i64(d.ctr_dups, (int64_t)*block_count);
+    if (g == 0) g_atomic_add_i64(d.ctr_total, (int64_t)d.n);
+}
+
+FQ_DEV void or_images_body(const OrArgs& o) {
+    const u64 stride = (u64)grid_blocks() * block_threads();
+    for (u64 c = (u64)block_id() * block_threads() + thread_id(); c < o.chunks; c += stride) {
+        u32x4 v = o.images[c];
+        for (int k = 1; k < o.n_images; k++) {
+            const u32x4 w = o.images[(u64)k * o.chunks + c];
+            v.x |= w.x; v.y |= w.y; v.z |= w.z; v.w |= w.w;
+        }
+        o.dst[c] = v;
+    }
 }
 
 

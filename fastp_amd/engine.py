@@ -20,6 +20,8 @@ EXPORTS = [
     "fastp_gpu_pack_reads", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
+    "fastp_gpu_dup_scan_bytes", "fastp_gpu_dup_scan_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
+    "fastp_gpu_dup_prefix_set", "fastp_gpu_submit_scanned_device", "fastp_gpu_stream_set_origin", "fastp_gpu_overrep_device",
 ]
 
 
@@ -178,6 +180,48 @@ class GpuEngine:
     # -- device-resident batches (bench / multi-GPU hosts) ---------------------------------------
     def submit_device(self, batch: abi.Batch, results: abi.Results, stream=None):
         self._check(self.lib.fastp_gpu_submit_device(self.h, C.byref(batch), C.byref(results), stream))
+
+    # ---- sharded runs (include/fastp_gpu.h "Sharded runs") ----
+    def dup_scan_bytes(self, n: int) -> int:
+        fn = self.lib.fastp_gpu_dup_scan_bytes
+        fn.restype, fn.argtypes = C.c_int64, [C.c_void_p, C.c_int32]
+        return int(fn(self.h, n))
+
+    def dup_scan_device(self, batch: abi.Batch, scan_ptr: int, stream=None):
+        fn = self.lib.fastp_gpu_dup_scan_device
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(abi.Batch), C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, C.byref(batch), scan_ptr, stream))
+
+    def dup_bitmap_bytes(self) -> int:
+        fn = self.lib.fastp_gpu_dup_bitmap_bytes
+        fn.restype, fn.argtypes = C.c_int64, [C.c_void_p]
+        return int(fn(self.h))
+
+    def dup_bitmap_export(self, dst_ptr: int):
+        fn = self.lib.fastp_gpu_dup_bitmap_export
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+        self._check(fn(self.h, dst_ptr))
+
+    def dup_prefix_set(self, images_ptr, n_images: int):
+        fn = self.lib.fastp_gpu_dup_prefix_set
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]
+        self._check(fn(self.h, images_ptr, n_images))
+
+    def submit_scanned_device(self, batch: abi.Batch, scan_ptr: int, results: abi.Results, stream=None):
+        fn = self.lib.fastp_gpu_submit_scanned_device
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.c_void_p, C.POINTER(abi.Results), C.c_void_p]
+        self._check(fn(self.h, C.byref(batch), scan_ptr, C.byref(results), stream))
+
+    def stream_set_origin(self, units_before: int, post_reads_before: int):
+        fn = self.lib.fastp_gpu_stream_set_origin
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int64, C.c_int64]
+        self._check(fn(self.h, units_before, post_reads_before))
+
+    def overrep_device(self, batch: abi.Batch, results: abi.Results, stream=None):
+        fn = self.lib.fastp_gpu_overrep_device
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results), C.c_void_p]
+        self._check(fn(self.h, C.byref(batch), C.byref(results), stream))
 
     def parse_fastq(self, text_ptr: int, nbytes: int, is_last: bool, max_records: int, seq_ptr: int, qual_ptr: int,
                     len_ptr: int, line_off_ptr: int, line_len_ptr: int, check=True) -> abi.ParseInfo:

@@ -3,9 +3,16 @@ collective, and ONE all-reduce (RCCL over xGMI; `nccl` backend of torch.distribu
 int64 counter block at the end - the device analogue of Stats::merge / FilterResult::merge
 (stats.cpp:877-955, filterresult.cpp:38-89; call sites peprocessor.cpp:217-234).
 
-Duplicate detection is per shard ("replicas only" for that one feature): every rank keeps
-its own bloom bitmaps, so duplicates whose copies land on different GPUs are not seen; the
-summed dup_total / dup_count give a lower bound of the single-stream rate.
+Two quantities of the worker loop depend on what came EARLIER in the stream - the duplicate
+bloom filter (duplicate.cpp:122-163) and the overrepresentation sampling positions
+(stats.cpp:272) - and `run_shard` reproduces both exactly for a sharded run: a
+duplicate scan pass, one all-gather of the bloom bitmaps (the only bandwidth-bound exchange:
+mBufNum * mBufLenInBytes per rank, 1 GiB at the default accuracy level), the worker loop with
+the decision taken against the OR of the preceding shards' bitmaps, and a tiny all-gather of
+stream positions before the deferred overrepresentation pass.  The merged counters and every
+result record are then those of ONE stream over the concatenated shards (`-w 1` semantics).
+Without that protocol (plain `submit_device` per rank) duplicates whose copies land on different
+GPUs are not seen and the summed dup counters are only a lower bound.
 """
 from __future__ import annotations
 
@@ -36,3 +43,66 @@ def allreduce_counters_device(engine, dist, device) -> None:
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize(device)
     engine.counters_import(buf.data_ptr())
+
+
+def _all_gather_flat(dist, mine, world):
+    """all_gather_into_tensor; a gloo group (CPU tests, single-GPU rehearsals) gets host tensors"""
+    import torch
+    staged = mine.is_cuda and dist.get_backend() != "nccl"
+    src = mine.cpu() if staged else mine
+    out = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(mine.device) if staged else out
+
+
+def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False):
+    """Process this rank's shard (`batches[i]` -> `results[i]`, abi.Batch / abi.Results holding
+    pointers valid on `device`: HBM for the real engine) so that results and counters equal those
+    of one stream over all shards in rank order.  `dist` is torch.distributed (nccl = RCCL on the
+    GPUs; gloo in the CPU tests) or None for a single shard.  The counter all-reduce is separate
+    (allreduce_counters_*).  Returns the per-rank scan buffers' total size in bytes."""
+    import torch
+    from . import abi
+    if not exact or ((world == 1 or dist is None) and not force):
+        for b, r in zip(batches, results):
+            engine.submit_device(b, r)
+        engine.synchronize()
+        return 0
+    # pass 1: hash + insert in input order, keep per-unit positions / "set earlier in this shard" masks
+    scans = []
+    for b in batches:
+        t = torch.empty(max(16, engine.dup_scan_bytes(b.n)), dtype=torch.uint8, device=device)
+        engine.dup_scan_device(b, t.data_ptr())
+        scans.append(t)
+    engine.synchronize()
+    # exchange: every rank's bitmaps -> OR of the preceding ranks' images = exclusive prefix
+    nbytes = engine.dup_bitmap_bytes()
+    if nbytes and world > 1:
+        mine = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        engine.dup_bitmap_export(mine.data_ptr())
+        images = _all_gather_flat(dist, mine, world)
+        if images.is_cuda:
+            torch.cuda.synchronize(device)
+        engine.dup_prefix_set(images.data_ptr(), rank)
+        del images, mine
+    else:
+        engine.dup_prefix_set(None, 0)
+    # pass 2: the worker loop; overrepresentation deferred until the stream positions are known
+    defer = bool(engine.params.overrep_enabled)
+    for b, r, t in zip(batches, results, scans):
+        if defer:
+            b.flags |= abi.BATCH_DEFER_OVERREP
+        engine.submit_scanned_device(b, t.data_ptr(), r)
+    engine.synchronize()
+    if defer:
+        lay = engine.layout
+        ctr = engine.counters()
+        mine = torch.tensor([sum(int(b.n) for b in batches), int(ctr[lay.stats[1] + lay.st_reads])], dtype=torch.int64,
+                            device=device)
+        allpos = _all_gather_flat(dist, mine, world) if world > 1 else mine
+        before = allpos.cpu().view(world, 2)[:rank].sum(dim=0)
+        engine.stream_set_origin(int(before[0]), int(before[1]))
+        for b, r in zip(batches, results):
+            engine.overrep_device(b, r)
+        engine.synchronize()
+    return sum(t.numel() for t in scans)

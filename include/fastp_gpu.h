@@ -176,6 +176,10 @@ typedef struct fastp_gpu_batch {
  * (peprocessor.cpp:449,497); the host sets this flag on the packs that thread
  * 0 would have received.  With -w 1 (the parity configuration) every pack. */
 #define FASTP_GPU_BATCH_STAT_ISIZE 1u
+/* leave Stats::statRead's overrepresentation analysis (stats.cpp:270-288) of this batch to a later
+ * fastp_gpu_overrep_device call - a sharded run needs the stream positions of the preceding
+ * shards first (see "Sharded runs" below) */
+#define FASTP_GPU_BATCH_DEFER_OVERREP 2u
 
 /* ---- per-read / per-pair results ---------------------------------------- */
 typedef struct fastp_gpu_read_result {
@@ -387,6 +391,47 @@ int fastp_gpu_counters(fastp_gpu_ctx* ctx, int64_t* out, int64_t n);
  * non-additive header words are restored).  Both are synchronous. */
 int fastp_gpu_counters_export(fastp_gpu_ctx* ctx, int64_t* dst_device, int64_t n);
 int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_device, int64_t n);
+
+/* ---- Sharded runs: one engine per GPU, results identical to ONE stream -------------
+ * The input is cut into contiguous shards in input order, one engine per shard.  Everything the
+ * worker loop computes is per read except two things that depend on what came EARLIER in the
+ * stream, and both have an exact sharded form:
+ *
+ *  (1) Duplicate::checkPair / checkRead (duplicate.cpp:122-163): a unit is a duplicate iff, in every
+ *      bloom buffer, its bit was already set by an earlier unit.  "Earlier" = earlier in this shard,
+ *      or anywhere in a preceding shard.  Two passes:
+ *        pass 1  fastp_gpu_dup_scan_device on every batch of the shard: hashes the units, inserts
+ *                them into this engine's bitmaps in input order and keeps, per unit, the bit
+ *                positions and the mask of buffers whose bit an earlier unit of THIS shard had set
+ *                (`scan_state`, fastp_gpu_dup_scan_bytes(n) bytes of device memory per batch);
+ *        exchange  fastp_gpu_dup_bitmap_export -> all-gather of the images (RCCL) ->
+ *                fastp_gpu_dup_prefix_set with the images of the PRECEDING shards (their OR is the
+ *                exclusive prefix of SURVEY.md 8e);
+ *        pass 2  fastp_gpu_submit_scanned_device instead of fastp_gpu_submit_device:
+ *                duplicate = AND_i (set earlier in this shard OR set in the prefix), then the
+ *                worker loop as usual (--dedup routing, RF_DUP flags and the dup counters included).
+ *
+ *  (2) the overrepresentation sampling (stats.cpp:272: every `sampling`-th read a Stats object has
+ *      seen): submit with FASTP_GPU_BATCH_DEFER_OVERREP, exchange the per-shard read counts of the
+ *      post-filtering Stats (counter st_reads of slot 1), fastp_gpu_stream_set_origin with the
+ *      sums over the preceding shards, then fastp_gpu_overrep_device on the same batches/results.
+ *
+ * All pointers are DEVICE pointers; calls are asynchronous on the stream like submit_device unless
+ * stated.  fastp_amd/multigpu.py drives this over torch.distributed. */
+int64_t fastp_gpu_dup_scan_bytes(const fastp_gpu_ctx* ctx, int32_t n);
+int fastp_gpu_dup_scan_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, void* scan_state, void* hip_stream);
+/* size of one image of the engine's bloom bitmaps (mBufNum * mBufLenInBytes, duplicate.cpp:13-47) */
+int64_t fastp_gpu_dup_bitmap_bytes(const fastp_gpu_ctx* ctx);
+int fastp_gpu_dup_bitmap_export(fastp_gpu_ctx* ctx, void* dst_device);              /* synchronous */
+/* OR of `n_images` consecutive images becomes this engine's prefix (0 = no preceding shard); synchronous */
+int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_device, int32_t n_images);
+int fastp_gpu_submit_scanned_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, const void* scan_state,
+                                    fastp_gpu_results* res, void* hip_stream);
+/* stream position of the next unit this engine will see: units of the preceding shards, and the
+ * reads their post-filtering Stats saw; synchronous */
+int fastp_gpu_stream_set_origin(fastp_gpu_ctx* ctx, int64_t units_before, int64_t post_reads_before);
+int fastp_gpu_overrep_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, const fastp_gpu_results* res,
+                             void* hip_stream);
 
 /* time spent inside the fused kernel for the launches since the last call,
  * measured with HIP events on the launch stream: total milliseconds and

@@ -432,6 +432,32 @@ def test_gpu_device_fastq_format_crlf_and_overflow():
     g.close()
 
 
+@pytest.mark.parametrize("name,npacks", [("pe_default", 2), ("pe_noadapter_dedup", 3), ("pe_overrep", 2)])
+def test_gpu_two_shard_exact_protocol_equals_one_stream(name, npacks):
+    """two ranks (gloo, both on cuda:0) through multigpu.run_shard: records and counters - duplicates across the
+    shard boundary and overrepresentation sampling positions included - equal ONE stream (the oracle's)"""
+    import os
+    import torch.multiprocessing as mp
+    import oraclelib
+    import shard_util
+    n = 30000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + 13
+    mp.spawn(shard_util.shard_worker, args=(2, port, ret, "gpu", name, n, npacks, 150), nprocs=2, join=True)
+    params, d, paired = shard_util.case_input(name, n, 150)
+    o = oraclelib.Oracle(params)
+    whole = o.process(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    ctr, lay = o.counters(), o.layout
+    o.close()
+    assert np.array_equal(ret[0][0], ret[1][0])
+    assert ctr[lay.dup_count] > 0
+    bad = np.nonzero(ret[0][0] != ctr)[0]
+    assert len(bad) == 0, f"{name}: counters differ at {bad[:8]}"
+    for k in range(3):
+        assert ret[0][k + 1] + ret[1][k + 1] == whole[k].tobytes(), f"{name}: records {k} differ"
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))

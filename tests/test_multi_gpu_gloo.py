@@ -1,6 +1,7 @@
 """The N>1 path on CPU: two processes (gloo), each runs the device code (SIMT emulator) on its
 contiguous shard, then ONE all-reduce merges the counter blocks - the result must equal a
-single engine that saw the whole input (duplicate counters excepted: per-shard by design)."""
+single engine that saw the whole input.  With the plain per-shard submit the duplicate counters are
+the exception (cross-shard copies are not seen); multigpu.run_shard's two-pass protocol removes it."""
 import os
 import sys
 
@@ -67,3 +68,54 @@ def test_two_rank_shards_merge_to_single_engine_counters():
             a["flags"] &= ~np.uint8(abi.RF_DUP)
             b["flags"] &= ~np.uint8(abi.RF_DUP)
         assert a.tobytes() == b.tobytes()
+
+
+import pytest
+
+
+@pytest.mark.parametrize("name,npacks", [("pe_default", 2), ("pe_noadapter_dedup", 3), ("pe_overrep", 2), ("se_overrep", 1)])
+def test_two_rank_exact_protocol_equals_one_stream(name, npacks):
+    """run_shard (dup scan -> bitmap all-gather -> prefix -> worker loop -> deferred overrepresentation):
+    every record and every counter - duplicates and sampled positions included - equals ONE stream"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import engines
+    import oraclelib
+    import shard_util
+    engines.build_sim()
+    n = 1100
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.spawn(shard_util.shard_worker, args=(2, port, ret, "sim", name, n, npacks), nprocs=2, join=True)
+    params, d, paired = shard_util.case_input(name, n)
+    o = oraclelib.Oracle(params)
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    whole = o.process(*args)
+    ctr = o.counters()
+    lay = o.layout
+    o.close()
+    assert np.array_equal(ret[0][0], ret[1][0])
+    assert ctr[lay.dup_count] > 0
+    bad = np.nonzero(ret[0][0] != ctr)[0]
+    assert len(bad) == 0, f"{name}: counters differ at {bad[:8]}"
+    for k in range(3 if paired else 1):
+        assert ret[0][k + 1] + ret[1][k + 1] == whole[k].tobytes(), f"{name}: records {k} differ"
+
+
+def test_two_rank_plain_submit_misses_cross_shard_duplicates():
+    """the input of the exact-protocol test does contain cross-shard duplicates: without the protocol they are missed"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import engines
+    import oraclelib
+    import shard_util
+    engines.build_sim()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + 11
+    mp.spawn(shard_util.shard_worker, args=(2, port, ret, "sim", "pe_default", 1100, 2, 100, False), nprocs=2, join=True)
+    params, d, paired = shard_util.case_input("pe_default", 1100)
+    o = oraclelib.Oracle(params)
+    o.process(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    ctr, lay = o.counters(), o.layout
+    o.close()
+    assert ret[0][0][lay.dup_count] < ctr[lay.dup_count]
