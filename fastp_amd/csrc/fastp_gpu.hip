@@ -400,8 +400,10 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
 // what a launch does with Duplicate::checkPair/checkRead
 enum ChunkMode {
     CHUNK_STREAM,    // one stream: decide inside this launch (the normal path)
-    CHUNK_DUP_SCAN,  // sharded run, pass 1: hash + insert + scan state only
-    CHUNK_SCANNED,   // sharded run, pass 2: decide from the scan state and the prefix bitmaps
+    CHUNK_PASS1,     // sharded run, pass 1: insert + scan state, no decision (--dedup: nothing else; otherwise
+                     // the worker loop runs here, its records just lack the RF_DUP flag)
+    CHUNK_PASS2,     // sharded run, pass 2: decide from the scan state and the prefix bitmaps (--dedup: then the
+                     // worker loop; otherwise the decision is patched into pass 1's records)
     CHUNK_OVERREP,   // the deferred overrepresentation analysis only
 };
 
@@ -508,16 +510,18 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         return 0;
     };
 
-    if (mode == CHUNK_DUP_SCAN) {
+    if (mode == CHUNK_PASS1 && ctx->dp.dedup) {
         hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
         HIP_TRY(ctx, hipGetLastError());
         return launch_dup(nullptr, true);
     }
     if (mode == CHUNK_OVERREP) return launch_overrep(ctx, a, n, st);
-    if (mode == CHUNK_SCANNED) {
+    if (mode == CHUNK_PASS2) {
         // the decision comes from pass 1's scan state + the preceding shards' bitmaps; nothing is hashed again
-        rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
-        if (rc) return rc;
+        if (ctx->dp.dedup) {
+            rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
+            if (rc) return rc;
+        }
         DupFinalArgs d;
         memset(&d, 0, sizeof(d));
         d.scan_pos = scan_pos;
@@ -526,11 +530,15 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         d.bits = ctx->dp.dup_bits;
         d.n = n;
         d.B = ctx->dp.dup_bufnum;
-        d.dupflag = ctx->d_dupflag;
+        d.dupflag = ctx->dp.dedup ? ctx->d_dupflag : nullptr;
+        d.res[0] = a.res[0];
+        d.res[1] = a.res[1];
+        d.paired = ctx->dp.paired;
         d.ctr_total = ctx->d_ctr + cl.dup_total;
         d.ctr_dups = ctx->d_ctr + cl.dup_count;
         hipLaunchKernelGGL(fq_dup_final_kernel, dim3((n + 255) / 256), dim3(256), 16, st, d);
         HIP_TRY(ctx, hipGetLastError());
+        if (!ctx->dp.dedup) return FASTP_GPU_OK;  // the records are pass 1's
         a.dup_pos = nullptr;
         a.dupflag = ctx->d_dupflag;
     } else if (ctx->dp.dedup) {
@@ -574,8 +582,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
     HIP_TRY(ctx, hipGetLastError());
 
-    if (ctx->dp.dup_enabled && !ctx->dp.dedup && mode != CHUNK_SCANNED) {
-        rc = launch_dup(nullptr);
+    if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
+        rc = launch_dup(nullptr, mode == CHUNK_PASS1);
         if (rc) return rc;
     }
     if (b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) return FASTP_GPU_OK;
@@ -586,7 +594,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
 static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fastp_gpu_results* res, void* hip_stream,
                          ChunkMode mode, u8* scan_state) {
     if (!ctx || !b) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
-    const bool need_res = mode != CHUNK_DUP_SCAN;
+    const bool need_res = !(mode == CHUNK_PASS1 && ctx->dp.dedup);
     if (need_res && !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
     if (b->n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "negative batch size");
     if (!b->seq1 || !b->qual1 || !b->len1 || (need_res && !res->r1)) {
@@ -596,7 +604,8 @@ static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fas
         return fail(ctx, FASTP_GPU_E_INVALID, "paired engine needs read-2 buffers and pair results");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    if (mode == CHUNK_STREAM || mode == CHUNK_SCANNED) {
+    const bool worker_loop = mode == CHUNK_STREAM || (mode == CHUNK_PASS1 && !ctx->dp.dedup) || (mode == CHUNK_PASS2 && ctx->dp.dedup);
+    if (worker_loop) {
         if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
         if (ctx->dp.n_fasta && b->n > 0 && (!res->adapter_events || !res->n_adapter_events))
             return fail(ctx, FASTP_GPU_E_INVALID, "adapter_fasta needs an adapter event list in the results");
@@ -625,19 +634,20 @@ extern "C" int64_t fastp_gpu_dup_scan_bytes(const fastp_gpu_ctx* ctx, int32_t n)
     return (int64_t)n * ctx->dp.dup_bufnum * 8 + (((int64_t)n + 15) & ~(int64_t)15);
 }
 
-extern "C" int fastp_gpu_dup_scan_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, void* scan_state, void* hip_stream) {
+extern "C" int fastp_gpu_submit_pass1_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, void* scan_state,
+                                             fastp_gpu_results* res, void* hip_stream) {
     if (!ctx) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
-    if (!ctx->dp.dup_enabled) return FASTP_GPU_OK;  // nothing depends on earlier units
+    if (!ctx->dp.dup_enabled) return submit_chunks(ctx, b, res, hip_stream, CHUNK_STREAM, nullptr);  // nothing depends on earlier units
     if (!scan_state || ((uintptr_t)scan_state & 7u)) return fail(ctx, FASTP_GPU_E_INVALID, "scan state must be an 8-byte aligned device buffer");
-    return submit_chunks(ctx, b, nullptr, hip_stream, CHUNK_DUP_SCAN, (u8*)scan_state);
+    return submit_chunks(ctx, b, res, hip_stream, CHUNK_PASS1, (u8*)scan_state);
 }
 
-extern "C" int fastp_gpu_submit_scanned_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const void* scan_state,
-                                               fastp_gpu_results* res, void* hip_stream) {
+extern "C" int fastp_gpu_submit_pass2_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const void* scan_state,
+                                             fastp_gpu_results* res, void* hip_stream) {
     if (!ctx) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
-    if (!ctx->dp.dup_enabled) return submit_chunks(ctx, b, res, hip_stream, CHUNK_STREAM, nullptr);
+    if (!ctx->dp.dup_enabled) return FASTP_GPU_OK;  // pass 1 did everything
     if (!scan_state || ((uintptr_t)scan_state & 7u)) return fail(ctx, FASTP_GPU_E_INVALID, "scan state must be an 8-byte aligned device buffer");
-    return submit_chunks(ctx, b, res, hip_stream, CHUNK_SCANNED, (u8*)scan_state);
+    return submit_chunks(ctx, b, res, hip_stream, CHUNK_PASS2, (u8*)scan_state);
 }
 
 extern "C" int fastp_gpu_overrep_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fastp_gpu_results* res,
@@ -674,7 +684,7 @@ extern "C" int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_d
         if (hipMalloc((void**)&ctx->d_prefix, (size_t)bytes) != hipSuccess) return fail(ctx, FASTP_GPU_E_NOMEM, "hipMalloc(prefix bitmaps) failed");
     }
     OrArgs o;
-    o.images = (const u32x4*)images_device;
+    o.images = (u32x4*)images_device;
     o.dst = (u32x4*)ctx->d_prefix;
     o.chunks = (u64)bytes / 16;
     o.n_images = n_images;
@@ -682,6 +692,22 @@ extern "C" int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_d
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_prefix = true;
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_prefix_or_images(fastp_gpu_ctx* ctx, void* images_device, int32_t n_images, int64_t bytes_each) {
+    if (!ctx || n_images < 0 || bytes_each < 0 || (bytes_each & 15)) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    if (n_images == 0 || bytes_each == 0) return FASTP_GPU_OK;
+    if (!images_device || ((uintptr_t)images_device & 15u)) return fail(ctx, FASTP_GPU_E_INVALID, "images must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    OrArgs o;
+    o.images = (u32x4*)images_device;
+    o.dst = nullptr;
+    o.chunks = (u64)bytes_each / 16;
+    o.n_images = n_images;
+    hipLaunchKernelGGL(fq_or_images_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, o);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FASTP_GPU_OK;
 }
 

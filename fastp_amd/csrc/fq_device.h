@@ -2014,13 +2014,17 @@ struct DupFinalArgs {
     const u32* prefix;    // [B][bits/32] OR of the preceding shards' bitmaps, or nullptr
     u64 bits;
     int n, B;
-    u8* dupflag;          // [n]
+    u8* dupflag;          // [n] --dedup: the fused kernel reads the decision ...
+    u32* res[2];          // ... otherwise the records exist already: their flags byte gets RS_DUP
+    int paired;
     int64_t* ctr_total;
     int64_t* ctr_dups;
 };
 
-struct OrArgs {           // dst = OR of n_images consecutive images of `chunks` 16-byte chunks
-    const u32x4* images;
+// images[k] <- OR of images[j], j < k (exclusive prefix, in place; images[0] <- 0); `chunks` 16-byte chunks each.
+// With dst != nullptr instead: dst <- OR of all n_images (images untouched).
+struct OrArgs {
+    u32x4* images;
     u32x4* dst;
     u64 chunks;
     int n_images;
@@ -2142,7 +2146,12 @@ FQ_DEV void dup_final_body(const DupFinalArgs& d, u32* block_count) {
             }
             if (!set) { is_dup = false; break; }
         }
-        d.dupflag[g] = is_dup ? 1 : 0;
+        if (d.dupflag) {
+            d.dupflag[g] = is_dup ? 1 : 0;
+        } else if (is_dup) {
+            d.res[0][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+            if (d.paired) d.res[1][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+        }
     }
     const u64 m = ballot(is_dup);
     if (lane_id() == 0 && m) lds_add_u32(block_count, (u32)popc64(m));
@@ -2154,12 +2163,15 @@ FQ_DEV void dup_final_body(const DupFinalArgs& d, u32* block_count) {
 FQ_DEV void or_images_body(const OrArgs& o) {
     const u64 stride = (u64)grid_blocks() * block_threads();
     for (u64 c = (u64)block_id() * block_threads() + thread_id(); c < o.chunks; c += stride) {
-        u32x4 v = o.images[c];
-        for (int k = 1; k < o.n_images; k++) {
-            const u32x4 w = o.images[(u64)k * o.chunks + c];
+        u32x4 v;
+        v.x = v.y = v.z = v.w = 0u;
+        for (int k = 0; k < o.n_images; k++) {
+            u32x4* at = o.images + (u64)k * o.chunks + c;
+            const u32x4 w = *at;
+            if (!o.dst) *at = v;
             v.x |= w.x; v.y |= w.y; v.z |= w.z; v.w |= w.w;
         }
-        o.dst[c] = v;
+        if (o.dst) o.dst[c] = v;
     }
 }
 

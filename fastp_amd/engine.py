@@ -20,8 +20,8 @@ EXPORTS = [
     "fastp_gpu_pack_reads", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
-    "fastp_gpu_dup_scan_bytes", "fastp_gpu_dup_scan_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
-    "fastp_gpu_dup_prefix_set", "fastp_gpu_submit_scanned_device", "fastp_gpu_stream_set_origin", "fastp_gpu_overrep_device",
+    "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
+    "fastp_gpu_dup_prefix_set", "fastp_gpu_prefix_or_images", "fastp_gpu_submit_pass2_device", "fastp_gpu_stream_set_origin", "fastp_gpu_overrep_device",
 ]
 
 
@@ -187,10 +187,22 @@ class GpuEngine:
         fn.restype, fn.argtypes = C.c_int64, [C.c_void_p, C.c_int32]
         return int(fn(self.h, n))
 
-    def dup_scan_device(self, batch: abi.Batch, scan_ptr: int, stream=None):
-        fn = self.lib.fastp_gpu_dup_scan_device
-        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(abi.Batch), C.c_void_p, C.c_void_p]
-        self._check(fn(self.h, C.byref(batch), scan_ptr, stream))
+    def submit_pass1_device(self, batch: abi.Batch, scan_ptr: int, results, stream=None):
+        fn = self.lib.fastp_gpu_submit_pass1_device
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.c_void_p, C.POINTER(abi.Results), C.c_void_p]
+        self._check(fn(self.h, C.byref(batch), scan_ptr, C.byref(results) if results is not None else None, stream))
+
+    def submit_pass2_device(self, batch: abi.Batch, scan_ptr: int, results: abi.Results, stream=None):
+        fn = self.lib.fastp_gpu_submit_pass2_device
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.c_void_p, C.POINTER(abi.Results), C.c_void_p]
+        self._check(fn(self.h, C.byref(batch), scan_ptr, C.byref(results), stream))
+
+    def prefix_or_images(self, images_ptr: int, n_images: int, bytes_each: int):
+        fn = self.lib.fastp_gpu_prefix_or_images
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64]
+        self._check(fn(self.h, images_ptr, n_images, bytes_each))
 
     def dup_bitmap_bytes(self) -> int:
         fn = self.lib.fastp_gpu_dup_bitmap_bytes
@@ -206,12 +218,6 @@ class GpuEngine:
         fn = self.lib.fastp_gpu_dup_prefix_set
         fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]
         self._check(fn(self.h, images_ptr, n_images))
-
-    def submit_scanned_device(self, batch: abi.Batch, scan_ptr: int, results: abi.Results, stream=None):
-        fn = self.lib.fastp_gpu_submit_scanned_device
-        fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.c_void_p, C.POINTER(abi.Results), C.c_void_p]
-        self._check(fn(self.h, C.byref(batch), scan_ptr, C.byref(results), stream))
 
     def stream_set_origin(self, units_before: int, post_reads_before: int):
         fn = self.lib.fastp_gpu_stream_set_origin

@@ -16,6 +16,8 @@ GPUs are not seen and the summed dup counters are only a lower bound.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -68,31 +70,52 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
             engine.submit_device(b, r)
         engine.synchronize()
         return 0
-    # pass 1: hash + insert in input order, keep per-unit positions / "set earlier in this shard" masks
+    defer = bool(engine.params.overrep_enabled)
+    if defer:
+        for b in batches:
+            b.flags |= abi.BATCH_DEFER_OVERREP
+    # pass 1: insert in input order, keep per-unit positions / "set earlier in this shard" masks
+    # (without --dedup this already is the whole worker loop, minus the duplicate decision)
     scans = []
-    for b in batches:
+    for b, r in zip(batches, results):
         t = torch.empty(max(16, engine.dup_scan_bytes(b.n)), dtype=torch.uint8, device=device)
-        engine.dup_scan_device(b, t.data_ptr())
+        engine.submit_pass1_device(b, t.data_ptr(), r)
         scans.append(t)
     engine.synchronize()
-    # exchange: every rank's bitmaps -> OR of the preceding ranks' images = exclusive prefix
+    # exchange: exclusive prefix-OR of the bitmaps in rank order
     nbytes = engine.dup_bitmap_bytes()
     if nbytes and world > 1:
         mine = torch.empty(nbytes, dtype=torch.uint8, device=device)
         engine.dup_bitmap_export(mine.data_ptr())
-        images = _all_gather_flat(dist, mine, world)
-        if images.is_cuda:
-            torch.cuda.synchronize(device)
-        engine.dup_prefix_set(images.data_ptr(), rank)
-        del images, mine
+        staged = mine.is_cuda and dist.get_backend() != "nccl"   # gloo rehearsal on a GPU: through host memory
+        if nbytes % (16 * world) == 0 and os.environ.get("FASTP_SHARD_EXCHANGE", "alltoall") != "allgather":
+            # transpose - scan - transpose: rank s owns slice s of every image, scans it over the ranks and sends
+            # each rank its prefix slice back.  2 * (world-1)/world images cross the links per rank, not world-1.
+            src = mine.cpu() if staged else mine
+            slices = torch.empty_like(src)
+            dist.all_to_all_single(slices, src)                 # slices[k] = rank k's image, my slice
+            if staged:
+                slices = slices.to(device)
+            engine.prefix_or_images(slices.data_ptr(), world, nbytes // world)
+            back = slices.cpu() if staged else slices
+            dist.all_to_all_single(src, back)                   # src[s] = my prefix, slice s  -> the whole prefix image
+            prefix = src.to(device) if staged else src
+            if prefix.is_cuda:
+                torch.cuda.synchronize(device)
+            engine.dup_prefix_set(prefix.data_ptr(), 1)
+            del slices, back, prefix, src
+        else:
+            images = _all_gather_flat(dist, mine, world)
+            if images.is_cuda:
+                torch.cuda.synchronize(device)
+            engine.dup_prefix_set(images.data_ptr(), rank)
+            del images
+        del mine
     else:
         engine.dup_prefix_set(None, 0)
-    # pass 2: the worker loop; overrepresentation deferred until the stream positions are known
-    defer = bool(engine.params.overrep_enabled)
+    # pass 2: the decision (and, with --dedup, the worker loop that depends on it)
     for b, r, t in zip(batches, results, scans):
-        if defer:
-            b.flags |= abi.BATCH_DEFER_OVERREP
-        engine.submit_scanned_device(b, t.data_ptr(), r)
+        engine.submit_pass2_device(b, t.data_ptr(), r)
     engine.synchronize()
     if defer:
         lay = engine.layout

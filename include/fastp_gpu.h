@@ -399,34 +399,43 @@ int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_device, int
  *
  *  (1) Duplicate::checkPair / checkRead (duplicate.cpp:122-163): a unit is a duplicate iff, in every
  *      bloom buffer, its bit was already set by an earlier unit.  "Earlier" = earlier in this shard,
- *      or anywhere in a preceding shard.  Two passes:
- *        pass 1  fastp_gpu_dup_scan_device on every batch of the shard: hashes the units, inserts
- *                them into this engine's bitmaps in input order and keeps, per unit, the bit
- *                positions and the mask of buffers whose bit an earlier unit of THIS shard had set
- *                (`scan_state`, fastp_gpu_dup_scan_bytes(n) bytes of device memory per batch);
- *        exchange  fastp_gpu_dup_bitmap_export -> all-gather of the images (RCCL) ->
- *                fastp_gpu_dup_prefix_set with the images of the PRECEDING shards (their OR is the
- *                exclusive prefix of SURVEY.md 8e);
- *        pass 2  fastp_gpu_submit_scanned_device instead of fastp_gpu_submit_device:
- *                duplicate = AND_i (set earlier in this shard OR set in the prefix), then the
- *                worker loop as usual (--dedup routing, RF_DUP flags and the dup counters included).
+ *      or anywhere in a preceding shard.  Two passes over the shard's batches with one exchange:
+ *        pass 1  fastp_gpu_submit_pass1_device: inserts the units into this engine's bitmaps in input
+ *                order and keeps, per unit, the bit positions and the mask of buffers whose bit an
+ *                earlier unit of THIS shard had set (`scan_state`: fastp_gpu_dup_scan_bytes(n) bytes
+ *                of device memory per batch, kept until pass 2).  Without --dedup nothing else
+ *                depends on the decision, so the whole worker loop runs here as in
+ *                fastp_gpu_submit_device (records, counters) - only RF_DUP and the duplicate
+ *                counters are left open.  With --dedup routing depends on it: pass 1 only hashes
+ *                and inserts (res may be NULL).
+ *        exchange  the exclusive prefix-OR of the bitmaps in shard order.  Either
+ *                all-gather the images (fastp_gpu_dup_bitmap_export) and hand the preceding ones to
+ *                fastp_gpu_dup_prefix_set, or - 1/4 of the traffic at 8 shards - all-to-all slices
+ *                of the images, fastp_gpu_prefix_or_images on the slice owner, all-to-all back
+ *                (fastp_amd/multigpu.py does the latter over RCCL).
+ *        pass 2  fastp_gpu_submit_pass2_device: duplicate = AND_i (set earlier in this shard OR set
+ *                in the prefix).  Without --dedup the decision is patched into pass 1's records
+ *                (RF_DUP) and counted; with --dedup the worker loop runs now, with the decision.
  *
  *  (2) the overrepresentation sampling (stats.cpp:272: every `sampling`-th read a Stats object has
- *      seen): submit with FASTP_GPU_BATCH_DEFER_OVERREP, exchange the per-shard read counts of the
- *      post-filtering Stats (counter st_reads of slot 1), fastp_gpu_stream_set_origin with the
- *      sums over the preceding shards, then fastp_gpu_overrep_device on the same batches/results.
+ *      seen): run the worker loop with FASTP_GPU_BATCH_DEFER_OVERREP, exchange the per-shard read
+ *      counts of the post-filtering Stats (counter st_reads of slot 1), fastp_gpu_stream_set_origin
+ *      with the sums over the preceding shards, then fastp_gpu_overrep_device on the same batches.
  *
  * All pointers are DEVICE pointers; calls are asynchronous on the stream like submit_device unless
  * stated.  fastp_amd/multigpu.py drives this over torch.distributed. */
 int64_t fastp_gpu_dup_scan_bytes(const fastp_gpu_ctx* ctx, int32_t n);
-int fastp_gpu_dup_scan_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, void* scan_state, void* hip_stream);
+int fastp_gpu_submit_pass1_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, void* scan_state,
+                                  fastp_gpu_results* res, void* hip_stream);
+int fastp_gpu_submit_pass2_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, const void* scan_state,
+                                  fastp_gpu_results* res, void* hip_stream);
 /* size of one image of the engine's bloom bitmaps (mBufNum * mBufLenInBytes, duplicate.cpp:13-47) */
 int64_t fastp_gpu_dup_bitmap_bytes(const fastp_gpu_ctx* ctx);
 int fastp_gpu_dup_bitmap_export(fastp_gpu_ctx* ctx, void* dst_device);              /* synchronous */
 /* OR of `n_images` consecutive images becomes this engine's prefix (0 = no preceding shard); synchronous */
 int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_device, int32_t n_images);
-int fastp_gpu_submit_scanned_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, const void* scan_state,
-                                    fastp_gpu_results* res, void* hip_stream);
+/* in place: images[k] <- OR of images[j], j < k (images[0] <- 0), each `bytes_each` long; synchronous */
+int fastp_gpu_prefix_or_images(fastp_gpu_ctx* ctx, void* images_device, int32_t n_images, int64_t bytes_each);
 /* stream position of the next unit this engine will see: units of the preceding shards, and the
  * reads their post-filtering Stats saw; synchronous */
 int fastp_gpu_stream_set_origin(fastp_gpu_ctx* ctx, int64_t units_before, int64_t post_reads_before);
