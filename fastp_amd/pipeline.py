@@ -1,0 +1,254 @@
+"""FASTQ files in -> trimmed / filtered FASTQ files out, every per-read step on the device.
+
+The host only moves bytes: it reads raw text chunks (the reference's FastqReader fills 8 MiB blocks,
+fastqreader.cpp:31,88-149), ships them to HBM, and writes the text that comes back (WriterThread,
+writerthread.cpp:118-168).  Line splitting + packing (`fastp_gpu_parse_fastq`), the worker loop
+(`fastp_gpu_submit_device`) and record formatting (`fastp_gpu_format_fastq`) run on the GPU; what the
+reference's processSingleEnd / processPairEnd would have written to out1 / out2 comes out byte for
+byte.  Scope: plain (uncompressed) FASTQ, out1/out2 only, no merge mode / UMI name edits (those keep
+the string-side host path of INTEGRATION.md section 3).  Reader and writer run on their own threads
+so file I/O overlaps the device work of the neighbouring chunks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import queue
+import threading
+import time
+
+import numpy as np
+
+from . import abi, engine
+
+
+class PipelineError(RuntimeError):
+    pass
+
+
+class _Mate:
+    """per-mate buffers of one in-flight chunk"""
+
+    def __init__(self, torch, dev, chunk_bytes, max_records, max_len):
+        ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
+        self.cap = chunk_bytes + 64
+        self.text = torch.zeros(self.cap, dtype=torch.uint8, device=dev)
+        self.seq = torch.empty(max_records * ss, dtype=torch.uint8, device=dev)
+        self.qual = torch.empty(max_records * qs, dtype=torch.uint8, device=dev)
+        self.lens = torch.empty(max_records, dtype=torch.int16, device=dev)
+        self.loff = torch.empty(4 * max_records, dtype=torch.int32, device=dev)
+        self.llen = torch.empty(4 * max_records, dtype=torch.int32, device=dev)
+        self.res = torch.zeros(max_records * 12, dtype=torch.uint8, device=dev)
+        self.out = torch.empty(self.cap, dtype=torch.uint8, device=dev)
+
+
+class FastqPipeline:
+    def __init__(self, params: abi.Params, device: int = 0, chunk_bytes: int = 256 << 20, max_records: int | None = None,
+                 corr_capacity: int = 1 << 22):
+        import torch
+        self.torch = torch
+        self.params = params
+        self.paired = bool(params.paired)
+        self.dev = torch.device("cuda", device)
+        self.eng = engine.GpuEngine(params, device=device)
+        self.chunk = int(chunk_bytes)
+        self.max_records = int(max_records or max(1024, self.chunk // 48))
+        nm = 2 if self.paired else 1
+        self.mates = [_Mate(torch, self.dev, self.chunk, self.max_records, params.max_len) for _ in range(nm)]
+        self.pair = torch.zeros(self.max_records * 8, dtype=torch.uint8, device=self.dev)
+        self.corr_cap = corr_capacity if params.correction else 0
+        self.corr = torch.zeros(max(1, self.corr_cap) * 8, dtype=torch.uint8, device=self.dev)
+        self.nc = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        nf = int(params.n_adapter_fasta)
+        self.ev_cap = self.max_records * 2 * min(nf, 8) if nf else 0
+        self.ev = torch.zeros(max(1, self.ev_cap) * 12, dtype=torch.uint8, device=self.dev)
+        self.nev = torch.zeros(4, dtype=torch.int32, device=self.dev)
+        # two pinned staging sets per direction: the reader fills one while the device works on the other
+        self.stage_in = [[torch.empty(self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
+        self.stage_out = [[torch.empty(self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
+        self.stats = dict(units=0, chunks=0, bytes_in=0, bytes_out=0, t_parse=0.0, t_engine=0.0, t_format=0.0, t_h2d=0.0,
+                          t_d2h=0.0, t_wait_read=0.0, t_wait_write=0.0)
+
+    def close(self):
+        self.eng.close()
+
+    # -- reader thread: (leftover of the previous chunk | fresh bytes) into a pinned staging buffer ------------
+    def _reader(self, files, q_free, q_full, tails):
+        """tails[m] is set by the main thread before it releases a staging set: bytes the device did not consume"""
+        eof = [False] * len(files)
+        try:
+            while True:
+                item = q_free.get()
+                if item is None:
+                    return
+                slot, carry = item
+                fills = []
+                for m, f in enumerate(files):
+                    buf = self.stage_in[slot][m].numpy()
+                    c = carry[m]
+                    k = len(c)
+                    buf[:k] = np.frombuffer(c, dtype=np.uint8) if k else buf[:0]
+                    got = 0
+                    if not eof[m]:
+                        want = self.chunk - k
+                        mv = memoryview(buf)[k:k + want]
+                        while got < want:
+                            r = f.readinto(mv[got:])
+                            if not r:
+                                eof[m] = True
+                                break
+                            got += r
+                    fills.append((k + got, eof[m]))
+                q_full.put((slot, fills))
+        except Exception as e:  # surface in the main thread
+            q_full.put(e)
+
+    def _writer(self, files, q_out, q_done):
+        try:
+            while True:
+                item = q_out.get()
+                if item is None:
+                    return
+                slot, lens = item
+                for m, f in enumerate(files):
+                    f.write(memoryview(self.stage_out[slot][m].numpy())[:lens[m]])
+                q_done.put(slot)
+        except Exception as e:
+            q_done.put(e)
+
+    def run(self, in1: str, in2: str | None, out1: str, out2: str | None) -> dict:
+        torch = self.torch
+        if self.paired != (in2 is not None) or self.paired != (out2 is not None):
+            raise PipelineError("paired engine needs in2/out2, single-end engine must not get them")
+        nm = len(self.mates)
+        fin = [open(p, "rb", buffering=0) for p in ((in1, in2) if self.paired else (in1,))]
+        fout = [open(p, "wb", buffering=0) for p in ((out1, out2) if self.paired else (out1,))]
+        q_free, q_full, q_out, q_done = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+        rd = threading.Thread(target=self._reader, args=(fin, q_free, q_full, None), daemon=True)
+        wr = threading.Thread(target=self._writer, args=(fout, q_out, q_done), daemon=True)
+        rd.start()
+        wr.start()
+        st = self.stats
+        t_start = time.perf_counter()
+        try:
+            q_free.put((0, [b""] * nm))
+            out_free = [0, 1]
+            slot = 0
+            done = False
+            while not done:
+                t0 = time.perf_counter()
+                item = q_full.get()
+                if isinstance(item, Exception):
+                    raise item
+                slot, fills = item
+                st["t_wait_read"] += time.perf_counter() - t0
+                # ---- H2D ----
+                t0 = time.perf_counter()
+                for m in range(nm):
+                    nb = fills[m][0]
+                    self.mates[m].text[:nb].copy_(self.stage_in[slot][m][:nb], non_blocking=True)
+                    self.mates[m].text[nb:nb + 32].zero_()
+                torch.cuda.synchronize(self.dev)
+                st["t_h2d"] += time.perf_counter() - t0
+                st["bytes_in"] += sum(f[0] for f in fills)
+                # ---- parse (both mates to the same record count) ----
+                t0 = time.perf_counter()
+                infos = [self._parse(m, fills[m][0], fills[m][1], self.max_records) for m in range(nm)]
+                n = min(i.n_records for i in infos)
+                for m in range(nm):
+                    if infos[m].n_records != n:
+                        infos[m] = self._parse(m, fills[m][0], fills[m][1], n)
+                st["t_parse"] += time.perf_counter() - t0
+                all_eof = all(f[1] for f in fills)
+                # the unconsumed tails go to the reader with the other staging set; it refills while the device works
+                carry = []
+                for m in range(nm):
+                    a, b = int(infos[m].consumed), fills[m][0]
+                    carry.append(bytes(memoryview(self.stage_in[slot][m].numpy())[a:b]) if b > a else b"")
+                stalled = n == 0 and all(len(carry[m]) == fills[m][0] for m in range(nm))
+                if all_eof and (n == 0 or all(len(c) == 0 for c in carry)):
+                    done = True
+                elif stalled and not all_eof and any(len(c) >= self.chunk for c in carry):
+                    raise PipelineError("a record does not fit the chunk size")
+                elif stalled and all_eof:
+                    done = True   # trailing partial record / mates of different length: the reference stops too
+                if not done:
+                    q_free.put((1 - slot, carry))
+                if n == 0:
+                    continue
+                # ---- worker loop ----
+                t0 = time.perf_counter()
+                b = abi.Batch()
+                b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+                M = self.mates
+                b.seq1, b.qual1, b.len1 = M[0].seq.data_ptr(), M[0].qual.data_ptr(), M[0].lens.data_ptr()
+                if self.paired:
+                    b.seq2, b.qual2, b.len2 = M[1].seq.data_ptr(), M[1].qual.data_ptr(), M[1].lens.data_ptr()
+                r = abi.Results()
+                r.r1 = M[0].res.data_ptr()
+                if self.paired:
+                    r.r2, r.pair = M[1].res.data_ptr(), self.pair.data_ptr()
+                if self.corr_cap:
+                    r.corrections, r.corrections_capacity = self.corr.data_ptr(), self.corr_cap
+                r.n_corrections = self.nc.data_ptr()
+                if self.ev_cap:
+                    r.adapter_events, r.adapter_events_capacity, r.n_adapter_events = self.ev.data_ptr(), self.ev_cap, self.nev.data_ptr()
+                self.eng.submit_device(b, r)
+                self.eng.synchronize()
+                st["t_engine"] += time.perf_counter() - t0
+                # ---- format ----
+                t0 = time.perf_counter()
+                fi = []
+                for m in range(nm):
+                    f = abi.FormatIn()
+                    f.text, f.line_off, f.line_len, f.res = M[m].text.data_ptr(), M[m].loff.data_ptr(), M[m].llen.data_ptr(), M[m].res.data_ptr()
+                    fi.append(f)
+                rc, l1, l2 = self.eng.format_fastq(n, fi[0], fi[1] if self.paired else None,
+                                                   self.corr.data_ptr() if self.corr_cap else None,
+                                                   self.nc.data_ptr() if self.corr_cap else None, M[0].out.data_ptr(), M[0].cap,
+                                                   M[1].out.data_ptr() if self.paired else None, M[1].cap if self.paired else 0)
+                if self.corr_cap and int(self.nc[0].item()) > self.corr_cap:
+                    raise PipelineError("correction list overflow: raise corr_capacity")
+                st["t_format"] += time.perf_counter() - t0
+                lens = (l1, l2)[:nm]
+                # ---- D2H + hand to the writer ----
+                t0 = time.perf_counter()
+                while not out_free:
+                    d = q_done.get()
+                    if isinstance(d, Exception):
+                        raise d
+                    out_free.append(d)
+                st["t_wait_write"] += time.perf_counter() - t0
+                oslot = out_free.pop(0)
+                t0 = time.perf_counter()
+                for m in range(nm):
+                    self.stage_out[oslot][m][:lens[m]].copy_(M[m].out[:lens[m]], non_blocking=True)
+                torch.cuda.synchronize(self.dev)
+                st["t_d2h"] += time.perf_counter() - t0
+                q_out.put((oslot, lens))
+                st["units"] += n
+                st["chunks"] += 1
+                st["bytes_out"] += sum(lens)
+        finally:
+            q_free.put(None)
+            q_out.put(None)
+            wr.join()
+            rd.join(timeout=5)
+            for f in fin + fout:
+                f.close()
+        while not q_done.empty():
+            d = q_done.get()
+            if isinstance(d, Exception):
+                raise d
+        st["wall"] = time.perf_counter() - t_start
+        return dict(st)
+
+    def _parse(self, m, nbytes, is_last, max_records):
+        M = self.mates[m]
+        info = self.eng.parse_fastq(M.text.data_ptr(), nbytes, is_last, max_records, M.seq.data_ptr(), M.qual.data_ptr(),
+                                    M.lens.data_ptr(), M.loff.data_ptr(), M.llen.data_ptr())
+        if info.first_bad >= 0:
+            raise PipelineError(f"malformed FASTQ record {info.first_bad} of a chunk (mate {m + 1}): the device parser does not repair input")
+        return info
+
+    def counters(self):
+        return self.eng.counters()

@@ -458,6 +458,41 @@ def test_gpu_two_shard_exact_protocol_equals_one_stream(name, npacks):
         assert ret[0][k + 1] + ret[1][k + 1] == whole[k].tobytes(), f"{name}: records {k} differ"
 
 
+@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "se_adapter_cut"])
+def test_gpu_file_pipeline_equals_reference_outputs(name, tmp_path):
+    """FASTQ files -> fastp_amd.pipeline (parse, worker loop, format on the device; tiny chunks so that records
+    straddle chunk borders) -> out1/out2 files: byte-identical to the host writer's and, where the reference
+    binary travelled to this box, to reference fastp's own output files; counters == the one-stream engine's"""
+    from fastp_amd import pipeline
+    paired, flags, pf, skw = cases.CASES[name]
+    n = 20000
+    d = synth.synth_pairs(n, L=150, seed=91, paired=paired, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
+    ref = engines.gpu_engine(params)
+    want, ctr, _ = driver.run_engine(ref, params, fq1, fq2, pack=n, stride=abi.qual_stride(150))
+    ref.close()
+    (tmp_path / "r1.fq").write_bytes(fq1)
+    if paired:
+        (tmp_path / "r2.fq").write_bytes(fq2)
+    pl = pipeline.FastqPipeline(params, chunk_bytes=1 << 20, max_records=2500)
+    st = pl.run(str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq") if paired else None, str(tmp_path / "o1.fq"),
+                str(tmp_path / "o2.fq") if paired else None)
+    got_ctr = pl.counters()
+    pl.close()
+    assert st["units"] == n and st["chunks"] > 3
+    assert (tmp_path / "o1.fq").read_bytes() == bytes(want.out1)
+    if paired:
+        assert (tmp_path / "o2.fq").read_bytes() == bytes(want.out2)
+    assert np.array_equal(got_ctr, ctr)
+    if driver.have_reference_binary():
+        r = driver.run_reference(flags, fq1, fq2)
+        assert (tmp_path / "o1.fq").read_bytes() == r["out1"]
+        if paired:
+            assert (tmp_path / "o2.fq").read_bytes() == r["out2"]
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))
