@@ -81,12 +81,15 @@ class FastqPipeline:
                 if item is None:
                     return
                 slot, carry = item
-                fills = []
-                for m, f in enumerate(files):
+                fills = [None] * len(files)
+
+                def fill(m):
+                    f = files[m]
                     buf = self.stage_in[slot][m].numpy()
                     c = carry[m]
                     k = len(c)
-                    buf[:k] = np.frombuffer(c, dtype=np.uint8) if k else buf[:0]
+                    if k:
+                        buf[:k] = np.frombuffer(c, dtype=np.uint8)
                     got = 0
                     if not eof[m]:
                         want = self.chunk - k
@@ -97,7 +100,16 @@ class FastqPipeline:
                                 eof[m] = True
                                 break
                             got += r
-                    fills.append((k + got, eof[m]))
+                    fills[m] = (k + got, eof[m])
+
+                helpers = [threading.Thread(target=fill, args=(m,)) for m in range(1, len(files))]
+                for h in helpers:   # readinto releases the GIL: the mates' files are read concurrently
+                    h.start()
+                fill(0)
+                for h in helpers:
+                    h.join()
+                if any(x is None for x in fills):
+                    raise PipelineError("reader helper failed")
                 q_full.put((slot, fills))
         except Exception as e:  # surface in the main thread
             q_full.put(e)

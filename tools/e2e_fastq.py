@@ -16,12 +16,14 @@ tmp = tempfile.mkdtemp(prefix="fastp_e2e_", dir=base)
 f1, f2 = tmp + "/r1.fq", tmp + "/r2.fq"
 t0 = time.time()
 with open(f1, "wb") as a, open(f2, "wb") as b:
-    left = pairs; seed = 7
-    while left > 0:
-        k = min(left, 500_000)
-        d = synth_torch.synth_pairs_torch(k, L=L, seed=seed, device="cpu")
-        a.write(synth_torch.to_fastq_bytes(d["seq1"], d["qual1"], 1)); b.write(synth_torch.to_fastq_bytes(d["seq2"], d["qual2"], 2))
-        left -= k; seed += 1
+    # one synthetic block of <= 1 M pairs, written as often as needed (repeats only add duplicates)
+    k = min(pairs, 1_000_000)
+    d = synth_torch.synth_pairs_torch(k, L=L, seed=7, device="cpu")
+    t1, t2 = synth_torch.to_fastq_bytes(d["seq1"], d["qual1"], 1), synth_torch.to_fastq_bytes(d["seq2"], d["qual2"], 2)
+    reps = (pairs + k - 1) // k
+    pairs = reps * k
+    for _ in range(reps):
+        a.write(t1); b.write(t2)
 print(f"input: {pairs} pairs, {os.path.getsize(f1) + os.path.getsize(f2)} bytes, generated in {time.time()-t0:.1f}s", flush=True)
 
 p = abi.default_params(True, L); p.cut_right = 1
