@@ -72,58 +72,79 @@ class FastqPipeline:
         self.eng.close()
 
     # -- reader thread: (leftover of the previous chunk | fresh bytes) into a pinned staging buffer ------------
+    IO_THREADS = 8        # positional reads / writes in flight per direction (memcpy-bound on tmpfs / page cache)
+    IO_PIECE = 32 << 20
+
     def _reader(self, files, q_free, q_full, tails):
-        """tails[m] is set by the main thread before it releases a staging set: bytes the device did not consume"""
-        eof = [False] * len(files)
+        """fills a staging set: [bytes the device did not consume last time | fresh bytes], all mates concurrently"""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        fds = [f.fileno() for f in files]
+        sizes = [os.fstat(fd).st_size for fd in fds]
+        pos = [0] * len(files)
+
+        def piece(fd, mv, off):
+            got = 0
+            while got < len(mv):
+                r = os.preadv(fd, [mv[got:]], off + got)
+                if r <= 0:
+                    raise PipelineError("short read")
+                got += r
+
         try:
-            while True:
-                item = q_free.get()
-                if item is None:
-                    return
-                slot, carry = item
-                fills = [None] * len(files)
-
-                def fill(m):
-                    f = files[m]
-                    buf = self.stage_in[slot][m].numpy()
-                    c = carry[m]
-                    k = len(c)
-                    if k:
-                        buf[:k] = np.frombuffer(c, dtype=np.uint8)
-                    got = 0
-                    if not eof[m]:
-                        want = self.chunk - k
+            with ThreadPoolExecutor(self.IO_THREADS) as pool:
+                while True:
+                    item = q_free.get()
+                    if item is None:
+                        return
+                    slot, carry = item
+                    fills, futs = [], []
+                    for m in range(len(files)):
+                        buf = self.stage_in[slot][m].numpy()
+                        k = len(carry[m])
+                        if k:
+                            buf[:k] = np.frombuffer(carry[m], dtype=np.uint8)
+                        want = min(self.chunk - k, sizes[m] - pos[m])
                         mv = memoryview(buf)[k:k + want]
-                        while got < want:
-                            r = f.readinto(mv[got:])
-                            if not r:
-                                eof[m] = True
-                                break
-                            got += r
-                    fills[m] = (k + got, eof[m])
-
-                helpers = [threading.Thread(target=fill, args=(m,)) for m in range(1, len(files))]
-                for h in helpers:   # readinto releases the GIL: the mates' files are read concurrently
-                    h.start()
-                fill(0)
-                for h in helpers:
-                    h.join()
-                if any(x is None for x in fills):
-                    raise PipelineError("reader helper failed")
-                q_full.put((slot, fills))
+                        for a in range(0, want, self.IO_PIECE):
+                            e = min(want, a + self.IO_PIECE)
+                            futs.append(pool.submit(piece, fds[m], mv[a:e], pos[m] + a))
+                        pos[m] += want
+                        fills.append((k + want, pos[m] >= sizes[m]))
+                    for fu in futs:
+                        fu.result()
+                    q_full.put((slot, fills))
         except Exception as e:  # surface in the main thread
             q_full.put(e)
 
     def _writer(self, files, q_out, q_done):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        fds = [f.fileno() for f in files]
+        pos = [0] * len(files)
+
+        def piece(fd, mv, off):
+            done = 0
+            while done < len(mv):
+                done += os.pwritev(fd, [mv[done:]], off + done)
+
         try:
-            while True:
-                item = q_out.get()
-                if item is None:
-                    return
-                slot, lens = item
-                for m, f in enumerate(files):
-                    f.write(memoryview(self.stage_out[slot][m].numpy())[:lens[m]])
-                q_done.put(slot)
+            with ThreadPoolExecutor(self.IO_THREADS) as pool:
+                while True:
+                    item = q_out.get()
+                    if item is None:
+                        return
+                    slot, lens = item
+                    futs = []
+                    for m in range(len(files)):
+                        mv = memoryview(self.stage_out[slot][m].numpy())[:lens[m]]
+                        for a in range(0, lens[m], self.IO_PIECE):
+                            e = min(lens[m], a + self.IO_PIECE)
+                            futs.append(pool.submit(piece, fds[m], mv[a:e], pos[m] + a))
+                        pos[m] += lens[m]
+                    for fu in futs:
+                        fu.result()
+                    q_done.put(slot)
         except Exception as e:
             q_done.put(e)
 
