@@ -122,3 +122,25 @@ def to_fastq_bytes(seq, qual, mate, name_prefix=b"@SIM:1:FC:1:1101"):
     rec[:, p + 4 + L:p + 4 + 2 * L] = qual
     rec[:, p + 4 + 2 * L] = 10
     return rec.tobytes()
+
+
+def to_fastq_tensor(seq, qual, mate, first=0, name_prefix=b"@SIM:1:FC:1:1101"):
+    """to_fastq_bytes on the tensors' device: uint8 [n, record_bytes] (fixed-length reads, 9-digit names from `first`)"""
+    n, L = seq.shape
+    dev = seq.device
+    name0 = name_prefix + b":%09d %d:N:0:ATCG" % (0, mate)
+    p = len(name0)
+    rec = torch.empty((n, p + 1 + L + 3 + L + 1), dtype=torch.uint8, device=dev)
+    rec[:, :p] = torch.tensor(list(name0), dtype=torch.uint8, device=dev)
+    idx = torch.arange(first, first + n, dtype=torch.int64, device=dev)
+    o = len(name_prefix) + 1
+    for k in range(9):
+        rec[:, o + 8 - k] = (48 + (idx // (10 ** k)) % 10).to(torch.uint8)
+    rec[:, p] = 10
+    rec[:, p + 1:p + 1 + L] = seq
+    rec[:, p + 1 + L] = 10
+    rec[:, p + 2 + L] = ord("+")
+    rec[:, p + 3 + L] = 10
+    rec[:, p + 4 + L:p + 4 + 2 * L] = qual
+    rec[:, p + 4 + 2 * L] = 10
+    return rec
