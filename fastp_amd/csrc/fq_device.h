@@ -157,7 +157,11 @@ FQ_DEV u32x4 tile_chunk(const u32* const g[2], int tile_first, int P, int row_dw
     const int rows = imax(0, imin(P, n - tile_first));
     u32x4 v = {0u, 0u, 0u, 0u};
     if (4 * cm < rows * row_dw) {
-        const u32* src = g[m] + (size_t)tile_first * row_dw + 4 * cm;
+        // both mates' base pointers as scalars + a select: g[m] with a per-lane m is a vector load from the
+        // argument block followed by a vmcnt(0) wait, which drains every prefetch load issued before it
+        const u32* g0 = g[0];
+        const u32* g1 = g[1];
+        const u32* src = (m ? g1 : g0) + (size_t)tile_first * row_dw + 4 * cm;
         if (4 * cm + 4 <= rows * row_dw) {
             v = *(const u32x4*)src;
         } else {  // the chunk straddles the last existing row (odd row count)
@@ -188,7 +192,9 @@ FQ_DEV void tile_fetch(const KernelArgs& a, int tile_first, int tid, int nthread
     if (tid < L.NR) {
         const int m = tid >= L.P ? 1 : 0;
         const int gp = tile_first + tid - m * L.P;
-        if (gp < a.n) r.len = a.len[m][gp];
+        const u16* l0 = a.len[0];
+        const u16* l1 = a.len[1];
+        if (gp < a.n) r.len = (m ? l1 : l0)[gp];
     }
 }
 
@@ -510,17 +516,22 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         if (plain) {
             const int slot = slot0 + (j0 < lk ? 1 : 0);
             const int sbyte = rowoff(R, SW4) + c;
+            // every LDS read of the item first, then the atomics back to back: LDS operations return in
+            // order, so a read issued after an atomic would wait for that atomic as well
             const u32 cur8 = seq_bytes[sbyte];
+            const u32 prev8 = c > 0 ? (u32)seq_bytes[sbyte - 1] : 0u;
+            u64 inc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) inc[k] = inc_lut[(qd >> (8 * k)) & 0x7Fu];
             u64* cyc = cyc_all + rowoff(slot, N_CLS * Cp) + c;  // position 4c+k lives at k*C4 + c (phase-major)
             key0 = (u32)slot * 128u;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const u32 q = (qd >> (8 * k)) & 0x7Fu;
                 const u32 cls = (cur8 >> (2 * k)) & 3u;
-                lds_add_u64(&cyc[rowoff((int)cls, Cp) + k * C4], inc_lut[q]);
+                lds_add_u64(&cyc[rowoff((int)cls, Cp) + k * C4], inc[k]);
             }
             if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N)
-                const u32 codes = (u32)seq_bytes[sbyte - 1] | (cur8 << 8);
+                const u32 codes = prev8 | (cur8 << 8);
                 u32* kmer = kmer_all + slot * KMER_BINS;
 #pragma unroll
                 for (int k = 0; k < 4; k++) lds_add_u32(&kmer[(codes >> (2 * k)) & 0x3FFu], 1u);

@@ -268,7 +268,7 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.SW = p.sw_g;
         out.QW = p.qw_g;
         out.C = p.cycles;
-        out.Cp = (p.cycles + 3) / 4 * 4;
+        out.Cp = (p.cycles + 15) / 16 * 16;  // multiple of 16: the class stride does not move a counter to another LDS bank pair
         int o = 0;
         auto take = [&](int n) { int at = o; o += n; return at; };
         // accumulators first (u64 part 8-byte aligned at offset 0)
