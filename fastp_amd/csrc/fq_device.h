@@ -117,10 +117,12 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
     const int mates = a.p.paired ? 2 : 1;
     const int P = L.P;
     const int rows = imax(0, imin(P, a.n - tile_first));  // rows that exist
+    const u16* len0 = a.len[0];
+    const u16* len1 = a.len[1];
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= P ? 1 : 0;
         const int gp = tile_first + (R - m * P);
-        tile_init_read(L, lds, R, gp < a.n ? (int)a.len[m][gp] : 0);
+        tile_init_read(L, lds, R, gp < a.n ? (int)(m ? len1 : len0)[gp] : 0);
     }
     for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
     for (int m = 0; m < mates; m++) {
