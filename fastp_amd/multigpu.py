@@ -54,7 +54,16 @@ def _all_gather_flat(dist, mine, world):
     src = mine.cpu() if staged else mine
     out = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
     dist.all_gather_into_tensor(out, src)
+    _device_sync(out)
     return out.to(mine.device) if staged else out
+
+
+def _device_sync(t):
+    """RCCL work is enqueued on the process group's own stream and the engine launches on ITS own stream:
+    a collective's output must be complete before an engine call reads it"""
+    if t.is_cuda:
+        import torch
+        torch.cuda.synchronize(t.device)
 
 
 def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False):
@@ -94,11 +103,13 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
             src = mine.cpu() if staged else mine
             slices = torch.empty_like(src)
             dist.all_to_all_single(slices, src)                 # slices[k] = rank k's image, my slice
+            _device_sync(slices)
             if staged:
                 slices = slices.to(device)
             engine.prefix_or_images(slices.data_ptr(), world, nbytes // world)
             back = slices.cpu() if staged else slices
             dist.all_to_all_single(src, back)                   # src[s] = my prefix, slice s  -> the whole prefix image
+            _device_sync(src)
             prefix = src.to(device) if staged else src
             if prefix.is_cuda:
                 torch.cuda.synchronize(device)
