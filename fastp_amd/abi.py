@@ -174,6 +174,10 @@ class ParseInfo(C.Structure):
     _fields_ = [("n_records", C.c_int32), ("first_bad", C.c_int32), ("consumed", C.c_int64), ("n_lines", C.c_int64)]
 
 
+class InflateInfo(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("first_bad", C.c_int32), ("consumed", C.c_int64), ("out_bytes", C.c_int64)]
+
+
 class FormatIn(C.Structure):
     _fields_ = [("text", C.c_void_p), ("line_off", C.c_void_p), ("line_len", C.c_void_p), ("res", C.c_void_p)]
 

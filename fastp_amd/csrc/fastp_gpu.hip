@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "fq_device.h"
+#include "fq_inflate.h"
 #include "fq_host.h"
 
 using namespace fq;
@@ -51,6 +52,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_parse_index_kernel(ParseArg
 }
 extern "C" __global__ void __launch_bounds__(64) fq_parse_finish_kernel(ParseArgs p) { parse_finish_body(p); }
 extern "C" __global__ void __launch_bounds__(256) fq_parse_pack_kernel(ParseArgs p) { parse_pack_body(p); }
+extern "C" __global__ void __launch_bounds__(64) fq_inflate_kernel(InflateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    inflate_body(a, (u16*)fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_dup_final_kernel(DupFinalArgs d) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     dup_final_body(d, fq_lds);
@@ -122,6 +127,7 @@ struct fastp_gpu_ctx {
     u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
     u32* d_parse = nullptr; size_t parse_cap = 0;         // FASTQ parse scratch
     u64* d_fmt = nullptr; size_t fmt_cap = 0;             // FASTQ format scratch
+    u8* d_inf = nullptr; size_t inf_cap = 0;              // inflate scratch: code lengths | status | first_bad
     uint64_t units_seen = 0;                               // units submitted so far (the pre-filtering Stats' mReads)
     std::vector<std::string> ovr_strings[2];
     std::vector<const char*> ovr_ptrs[2];
@@ -183,7 +189,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -779,6 +785,98 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     info->n_lines = (int64_t)totals[2];
     info->first_bad = totals[1] == 0xFFFFFFFFu ? -1 : (int32_t)totals[1];
     if (info->first_bad >= 0) return fail(ctx, FASTP_GPU_E_INVALID, "malformed FASTQ record in the chunk (see first_bad)");
+    return FASTP_GPU_OK;
+}
+
+// BgzfMtReader::readerLoop's header walk (src/bgzf.h:29-32, 150-200): gzip member header with the BC extra
+// subfield, BSIZE = member size - 1; deflate payload; CRC32; ISIZE
+extern "C" int fastp_gpu_bgzf_index(const uint8_t* h, int64_t nbytes, int32_t max_blocks, int64_t max_text_bytes,
+                                    uint32_t* pay_off, uint32_t* pay_len, uint32_t* isize, uint32_t* crc, uint64_t* out_off,
+                                    fastp_gpu_inflate_info* info) {
+    if (!info) return FASTP_GPU_E_INVALID;
+    info->n_blocks = 0;
+    info->first_bad = -1;
+    info->consumed = 0;
+    info->out_bytes = 0;
+    if (!h || nbytes < 0 || max_blocks < 0 || !pay_off || !pay_len || !isize || !crc || !out_off) return FASTP_GPU_E_INVALID;
+    int64_t pos = 0, text = 0;
+    int32_t k = 0;
+    while (k < max_blocks && pos + 18 <= nbytes) {
+        const uint8_t* p = h + pos;
+        if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { info->first_bad = k; break; }
+        const uint32_t xlen = (uint32_t)p[10] | ((uint32_t)p[11] << 8);
+        if (pos + 12 + xlen > nbytes) break;  // header not complete yet
+        // find the BC subfield among the extra subfields (bgzip writes it first; others may precede it)
+        int64_t bsize = -1;
+        for (uint32_t o = 0; o + 4 <= xlen;) {
+            const uint8_t* e = p + 12 + o;
+            const uint32_t slen = (uint32_t)e[2] | ((uint32_t)e[3] << 8);
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2 && o + 6 <= xlen) { bsize = ((int64_t)e[4] | ((int64_t)e[5] << 8)) + 1; break; }
+            o += 4 + slen;
+        }
+        if (bsize < 0 || (p[3] & ~4)) { info->first_bad = k; break; }  // not BGZF (or name/comment/hcrc fields: bgzip never writes them)
+        const int64_t hdr = 12 + (int64_t)xlen;
+        if (bsize < hdr + 8) { info->first_bad = k; break; }
+        if (pos + bsize > nbytes) break;  // member not complete yet
+        const uint8_t* t = p + bsize - 8;
+        const uint32_t c = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t n = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (n > 65536u) { info->first_bad = k; break; }
+        if (text + n > max_text_bytes) break;
+        pay_off[k] = (uint32_t)(pos + hdr);
+        pay_len[k] = (uint32_t)(bsize - hdr - 8);
+        isize[k] = n;
+        crc[k] = c;
+        out_off[k] = (uint64_t)text;
+        text += n;
+        pos += bsize;
+        k++;
+    }
+    info->n_blocks = k;
+    info->consumed = pos;
+    info->out_bytes = text;
+    return info->first_bad >= 0 ? FASTP_GPU_E_INVALID : FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, int32_t n_blocks, const uint32_t* pay_off,
+                                      const uint32_t* pay_len, const uint32_t* isize, const uint32_t* crc, const uint64_t* out_off,
+                                      uint8_t* out, int64_t out_capacity, int check_crc, int32_t* first_bad) {
+    if (first_bad) *first_bad = -1;
+    if (!ctx || n_blocks < 0 || out_capacity < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    if (n_blocks == 0) return FASTP_GPU_OK;
+    if (!comp || !pay_off || !pay_len || !isize || !crc || !out_off || !out) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t scratch = (size_t)n_blocks * INF_SCRATCH, status = (size_t)n_blocks * 4;
+    int rc = ensure(ctx, (void**)&ctx->d_inf, &ctx->inf_cap, scratch + status + 16);
+    if (rc) return rc;
+    InflateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.comp = comp;
+    a.pay_off = pay_off; a.pay_len = pay_len; a.isize = isize; a.crc = crc; a.out_off = out_off;
+    a.n = n_blocks;
+    a.out = out;
+    a.out_cap = (u64)out_capacity;
+    a.scratch = ctx->d_inf;
+    a.status = (u32*)(ctx->d_inf + scratch);
+    a.first_bad = (u32*)(ctx->d_inf + scratch + status);
+    a.check_crc = check_crc;
+    HIP_TRY(ctx, hipMemsetAsync(a.first_bad, 0xFF, 4, st));
+    static bool attr_set = false;
+    const int lds_bytes = INF_ENTRIES * INF_LANES * 2;
+    if (!attr_set) {
+        HIP_TRY(ctx, hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fq_inflate_kernel, dim3((n_blocks + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_bytes, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    u32 bad = 0xFFFFFFFFu;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, a.first_bad, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (bad != 0xFFFFFFFFu) {
+        if (first_bad) *first_bad = (int32_t)bad;
+        return fail(ctx, FASTP_GPU_E_INVALID, "a BGZF block failed to inflate (see first_bad)");
+    }
     return FASTP_GPU_OK;
 }
 

@@ -1,0 +1,283 @@
+// fq_inflate.h - DEFLATE (RFC 1951) decoding of BGZF blocks on the device.
+//
+// The step before FASTQ parsing for compressed input: the reference's
+// BgzfMtReader (src/bgzf.h:36-239) cuts a .gz written by bgzip into its independent <= 64 KiB gzip
+// members by the BSIZE field of each header and hands them to a pool of igzip workers.  Here the host
+// does the same header walk (fastp_gpu_bgzf_index, a few bytes per block) and ONE LANE inflates one
+// block: blocks are independent, a lane always sees its own earlier stores (LZ77 copies read back
+// what the same lane wrote), and a text chunk holds thousands of blocks, so the machine fills with
+// lanes rather than with cooperating wavefronts.
+//
+// Per-lane canonical Huffman tables (count per code length + symbols in code order, the textbook
+// decoder of RFC 1951 3.2.2) live in LDS, interleaved by lane ([entry][lane], so that the lanes of a
+// wave reading the same entry hit consecutive halfwords).  The code lengths of a dynamic block pass
+// through a per-lane global scratch row.
+#pragma once
+#include "fq_intrin.h"
+#include "fq_types.h"
+
+namespace fq {
+
+enum {
+    INF_MAXBITS = 15,
+    INF_MAXL = 288,   // literal/length codes
+    INF_MAXD = 32,    // distance codes (30 used)
+    INF_LANES = 64,   // workgroup = one wavefront
+    // per-lane table entries (u16 each): lencnt[16] | lensym[288] | distcnt[16] | distsym[32]
+    INF_O_LCNT = 0,
+    INF_O_LSYM = 16,
+    INF_O_DCNT = 16 + INF_MAXL,
+    INF_O_DSYM = 32 + INF_MAXL,
+    INF_ENTRIES = 32 + INF_MAXL + INF_MAXD,
+    INF_SCRATCH = 320,  // code lengths of a dynamic block (bytes per lane)
+};
+
+// status per block
+enum { INF_OK = 0, INF_E_HEADER = 1, INF_E_BTYPE = 2, INF_E_STORED = 3, INF_E_CODE = 4, INF_E_DIST = 5, INF_E_OVERRUN = 6,
+       INF_E_ISIZE = 7, INF_E_TABLE = 8, INF_E_CRC = 9 };
+
+struct InflateArgs {
+    const u8* comp;        // compressed chunk (padded by >= 8 readable bytes)
+    const u32* pay_off;    // [n] offset of the block's deflate payload in comp
+    const u32* pay_len;    // [n] payload bytes
+    const u32* isize;      // [n] uncompressed size from the member trailer
+    const u32* crc;        // [n] CRC-32 from the member trailer
+    const u64* out_off;    // [n] where the block's text goes in out
+    int n;
+    u8* out;
+    u64 out_cap;
+    u8* scratch;           // [n][INF_SCRATCH]
+    u32* status;           // [n]
+    u32* first_bad;        // atomic min of the failing block indices
+    int check_crc;
+};
+
+struct InfBits {
+    const u8* in;
+    u32 pos, end;   // next byte to fetch, end of payload
+    u64 buf;
+    int cnt;
+};
+
+FQ_DEV void inf_refill(InfBits& b) {
+    if (b.cnt <= 32) {  // four bytes at a time; past-the-end bytes are padding and never consumed by a valid stream
+        const u8* p = b.in + b.pos;
+        const u32 w = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+        b.buf |= (u64)w << b.cnt;
+        b.pos += 4;
+        b.cnt += 32;
+    }
+}
+FQ_DEV u32 inf_bits(InfBits& b, int n) {  // n <= 16
+    inf_refill(b);
+    const u32 v = (u32)b.buf & ((1u << n) - 1u);
+    b.buf >>= n;
+    b.cnt -= n;
+    return v;
+}
+
+// table entry e of this lane
+FQ_DEV u16& inf_t(u16* tab, int e, int lane) { return tab[e * INF_LANES + lane]; }
+
+// canonical Huffman decode: counts at cnt_o[1..15], symbols at sym_o[...]; -1 on an invalid code
+FQ_DEV int inf_decode(InfBits& b, u16* tab, int lane, int cnt_o, int sym_o) {
+    inf_refill(b);
+    int code = 0, first = 0, index = 0;
+    u32 bits = (u32)b.buf;
+    for (int len = 1; len <= INF_MAXBITS; len++) {
+        code |= (int)(bits & 1u);
+        bits >>= 1;
+        const int count = (int)inf_t(tab, cnt_o + len, lane);
+        if (code - count < first) {
+            b.buf >>= len;
+            b.cnt -= len;
+            return (int)inf_t(tab, sym_o + index + (code - first), lane);
+        }
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+// build count[] / symbol[] from n code lengths (read through `len_at`); returns false for an over-subscribed set
+template <class F>
+FQ_DEV bool inf_construct(u16* tab, int lane, int cnt_o, int sym_o, int n, F len_at, bool allow_incomplete) {
+    for (int l = 0; l <= INF_MAXBITS; l++) inf_t(tab, cnt_o + l, lane) = 0;
+    for (int s = 0; s < n; s++) inf_t(tab, cnt_o + (int)len_at(s), lane)++;
+    int left = 1;
+    for (int l = 1; l <= INF_MAXBITS; l++) {
+        left <<= 1;
+        left -= (int)inf_t(tab, cnt_o + l, lane);
+        if (left < 0) return false;
+    }
+    // offsets of each length in the symbol table: kept in registers as a running sum while filling,
+    // one pass per code length (n <= 288, 15 lengths: 4320 steps worst case, once per deflate block)
+    int offs = 0;
+    for (int l = 1; l <= INF_MAXBITS; l++) {
+        const int c = (int)inf_t(tab, cnt_o + l, lane);
+        if (!c) continue;
+        int k = 0;
+        for (int s = 0; s < n && k < c; s++)
+            if ((int)len_at(s) == l) inf_t(tab, sym_o + offs + k++, lane) = (u16)s;
+        offs += c;
+    }
+    const bool complete = left == 0;
+    // an incomplete code is only legal for a distance code with a single symbol (RFC 1951 3.2.7)
+    return complete || allow_incomplete;
+}
+
+// length / distance base values and extra bits (RFC 1951 3.2.5), computed rather than tabulated
+FQ_DEV void inf_len_base(int sym, int& base, int& extra) {  // sym = 257..285
+    const int i = sym - 257;
+    if (i < 8) { base = 3 + i; extra = 0; return; }
+    if (i == 28) { base = 258; extra = 0; return; }
+    extra = (i - 4) >> 2;
+    base = 3 + ((4 + (i & 3)) << extra);
+}
+FQ_DEV void inf_dist_base(int sym, int& base, int& extra) {  // sym = 0..29
+    if (sym < 4) { base = 1 + sym; extra = 0; return; }
+    extra = (sym - 2) >> 1;
+    base = 1 + ((2 + (sym & 1)) << extra);
+}
+
+FQ_DEV u32 inf_crc32_update(u32 crc, u32 byte) {  // bitwise, reflected 0xEDB88320: no table, no memory traffic
+    crc ^= byte;
+#pragma unroll
+    for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    return crc;
+}
+
+FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
+    InfBits b;
+    b.in = a.comp + a.pay_off[g];
+    b.pos = 0;
+    b.end = a.pay_len[g];
+    b.buf = 0;
+    b.cnt = 0;
+    u8* out = a.out + a.out_off[g];
+    const u32 cap = a.isize[g];
+    if (a.out_off[g] + cap > a.out_cap) return INF_E_ISIZE;
+    u32 opos = 0;
+    u8* lens = a.scratch + (size_t)g * INF_SCRATCH;
+    int last;
+    do {
+        last = (int)inf_bits(b, 1);
+        const int type = (int)inf_bits(b, 2);
+        if (type == 0) {  // stored: to the byte boundary, LEN, NLEN, bytes
+            const int drop = b.cnt & 7;
+            b.buf >>= drop;
+            b.cnt -= drop;
+            const u32 len = inf_bits(b, 16);
+            const u32 nlen = inf_bits(b, 16);
+            if ((len ^ 0xFFFFu) != nlen) return INF_E_STORED;
+            if (opos + len > cap) return INF_E_ISIZE;
+            // the bit buffer holds whole bytes now: hand them back, then copy from the stream
+            b.pos -= (u32)(b.cnt >> 3);
+            b.buf = 0;
+            b.cnt = 0;
+            if (b.pos + len > b.end) return INF_E_OVERRUN;
+            for (u32 i = 0; i < len; i++) out[opos + i] = b.in[b.pos + i];
+            b.pos += len;
+            opos += len;
+            continue;
+        }
+        if (type == 3) return INF_E_BTYPE;
+        if (type == 1) {  // fixed codes (3.2.6)
+            auto ll = [](int s) -> u32 { return s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u; };
+            inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, 288, ll, false);
+            auto dl = [](int) -> u32 { return 5u; };
+            inf_construct(tab, lane, INF_O_DCNT, INF_O_DSYM, 30, dl, true);
+        } else {  // dynamic codes (3.2.7)
+            const int nlen = (int)inf_bits(b, 5) + 257;
+            const int ndist = (int)inf_bits(b, 5) + 1;
+            const int ncode = (int)inf_bits(b, 4) + 4;
+            if (nlen > 286 || ndist > 30) return INF_E_TABLE;
+            for (int i = 0; i < 19; i++) lens[i] = 0;
+            for (int i = 0; i < ncode; i++) {
+                // order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15, five bits per entry in two constants
+                const u64 lo = 0x022CAA324E804A30ull;  // entries 0..11
+                const u64 hi = 0x00000003C2E1346Cull;  // entries 12..18
+                const int idx = i < 12 ? (int)((lo >> (5 * i)) & 31u) : (int)((hi >> (5 * (i - 12))) & 31u);
+                lens[idx] = (u8)inf_bits(b, 3);
+            }
+            auto cl = [&](int s) -> u32 { return (u32)lens[s]; };
+            if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, 19, cl, false)) return INF_E_TABLE;
+            int idx = 0;
+            while (idx < nlen + ndist) {
+                int sym = inf_decode(b, tab, lane, INF_O_LCNT, INF_O_LSYM);
+                if (sym < 0) return INF_E_CODE;
+                if (sym < 16) {
+                    lens[idx++] = (u8)sym;
+                } else {
+                    int rep, val = 0;
+                    if (sym == 16) {
+                        if (idx == 0) return INF_E_TABLE;
+                        val = lens[idx - 1];
+                        rep = 3 + (int)inf_bits(b, 2);
+                    } else if (sym == 17) {
+                        rep = 3 + (int)inf_bits(b, 3);
+                    } else {
+                        rep = 11 + (int)inf_bits(b, 7);
+                    }
+                    if (idx + rep > nlen + ndist) return INF_E_TABLE;
+                    while (rep--) lens[idx++] = (u8)val;
+                }
+            }
+            if (lens[256] == 0) return INF_E_TABLE;  // no end-of-block code
+            // the distance lengths first (they sit behind the literal/length ones in the scratch row and the
+            // literal/length table is about to be overwritten by its own construction - it is the same LDS rows
+            // the code-length code used)
+            auto dl = [&](int s) -> u32 { return (u32)lens[nlen + s]; };
+            if (!inf_construct(tab, lane, INF_O_DCNT, INF_O_DSYM, ndist, dl, true)) return INF_E_TABLE;
+            auto ll = [&](int s) -> u32 { return (u32)lens[s]; };
+            if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, nlen, ll, true)) return INF_E_TABLE;
+        }
+        // ---- the symbols of this block ----
+        for (;;) {
+            int sym = inf_decode(b, tab, lane, INF_O_LCNT, INF_O_LSYM);
+            if (sym < 0) return INF_E_CODE;
+            if (sym < 256) {
+                if (opos >= cap) return INF_E_ISIZE;
+                out[opos++] = (u8)sym;
+                continue;
+            }
+            if (sym == 256) break;
+            if (sym > 285) return INF_E_CODE;
+            int base, extra;
+            inf_len_base(sym, base, extra);
+            const int len = base + (int)inf_bits(b, extra);
+            const int ds = inf_decode(b, tab, lane, INF_O_DCNT, INF_O_DSYM);
+            if (ds < 0 || ds > 29) return INF_E_DIST;
+            inf_dist_base(ds, base, extra);
+            // up to 13 extra bits: within inf_bits' 16
+            const u32 dist = (u32)base + inf_bits(b, extra);
+            if (dist > opos) return INF_E_DIST;
+            if (opos + (u32)len > cap) return INF_E_ISIZE;
+            const u8* src = out + opos - dist;
+            u8* dst = out + opos;
+            for (int i = 0; i < len; i++) dst[i] = src[i];  // overlapping copies repeat the pattern, byte by byte
+            opos += (u32)len;
+        }
+        if (b.pos - (u32)(b.cnt >> 3) > b.end) return INF_E_OVERRUN;
+    } while (!last);
+    if (opos != cap) return INF_E_ISIZE;
+    if (a.check_crc) {
+        u32 crc = 0xFFFFFFFFu;
+        for (u32 i = 0; i < cap; i++) crc = inf_crc32_update(crc, out[i]);
+        if ((crc ^ 0xFFFFFFFFu) != a.crc[g]) return INF_E_CRC;
+    }
+    return INF_OK;
+}
+
+FQ_DEV void inflate_body(const InflateArgs& a, u16* tab) {
+    const int lane = lane_id();
+    const int g = block_id() * block_threads() + thread_id();
+    if (g >= a.n) return;
+    const u32 st = inflate_block(a, tab, lane, g);
+    a.status[g] = st;
+    if (st != INF_OK) g_atomic_min_u32(a.first_bad, (u32)g);
+}
+
+}  // namespace fq

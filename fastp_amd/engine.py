@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
@@ -228,6 +228,32 @@ class GpuEngine:
         fn = self.lib.fastp_gpu_overrep_device
         fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results), C.c_void_p]
         self._check(fn(self.h, C.byref(batch), C.byref(results), stream))
+
+    # ---- BGZF input (include/fastp_gpu.h) ----
+    def bgzf_index(self, host_bytes: np.ndarray, max_blocks: int, max_text_bytes: int, check=True):
+        """header walk over HOST bytes -> (info, pay_off, pay_len, isize, crc, out_off) numpy arrays"""
+        fn = self.lib.fastp_gpu_bgzf_index
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64] + [C.c_void_p] * 5 + [C.POINTER(abi.InflateInfo)]
+        arrs = [np.zeros(max(1, max_blocks), dtype=np.uint32) for _ in range(4)] + [np.zeros(max(1, max_blocks), dtype=np.uint64)]
+        info = abi.InflateInfo()
+        rc = fn(host_bytes.ctypes.data, host_bytes.size, max_blocks, max_text_bytes, *[a.ctypes.data for a in arrs], C.byref(info))
+        if check and rc != 0:
+            raise EngineError(rc, f"not a BGZF member at block {info.first_bad}")
+        info.rc = rc
+        return (info,) + tuple(a[:info.n_blocks] for a in arrs)
+
+    def inflate_bgzf(self, comp_ptr, n_blocks, pay_off_ptr, pay_len_ptr, isize_ptr, crc_ptr, out_off_ptr, out_ptr, out_cap,
+                     check_crc=True, check=True):
+        fn = self.lib.fastp_gpu_inflate_bgzf
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32] + [C.c_void_p] * 5 + [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int32)]
+        bad = C.c_int32(-1)
+        rc = fn(self.h, comp_ptr, n_blocks, pay_off_ptr, pay_len_ptr, isize_ptr, crc_ptr, out_off_ptr, out_ptr, out_cap,
+                int(check_crc), C.byref(bad))
+        if check:
+            self._check(rc)
+        return rc, int(bad.value)
 
     def parse_fastq(self, text_ptr: int, nbytes: int, is_last: bool, max_records: int, seq_ptr: int, qual_ptr: int,
                     len_ptr: int, line_off_ptr: int, line_len_ptr: int, check=True) -> abi.ParseInfo:

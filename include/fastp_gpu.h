@@ -341,6 +341,40 @@ int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbyte
                           uint32_t* line_len,  /* [4*max_records] its length without the terminator        */
                           fastp_gpu_parse_info* info);
 
+/* ---- BGZF-compressed FASTQ -> text ON THE DEVICE ----------------------
+ * The reference reads a bgzip-written .gz with BgzfMtReader (src/bgzf.h:36-239): a reader thread
+ * cuts the file into its independent <= 64 KiB gzip members by the BSIZE field of each header
+ * (bgzf.h:29-32) and a pool of igzip workers inflates them.  Same split here: the header walk stays
+ * on the host (fastp_gpu_bgzf_index: HOST memory in, a few bytes per block out), the inflation runs
+ * on the GPU, one lane per block (fastp_gpu_inflate_bgzf).  A plain (single-member) gzip stream has
+ * no block structure to exploit and stays on the host, as in the reference (fastqreader.cpp:88-149).
+ *
+ * fastp_gpu_bgzf_index walks the complete members of bytes[0, nbytes) (at most max_blocks of them,
+ * and only while their text fits max_text_bytes): for block k, pay_off/pay_len locate the raw
+ * deflate payload inside the chunk, isize/crc come from the member trailer, out_off is the running
+ * sum of isize (where its text goes).  info->consumed = bytes of whole members walked (the rest is
+ * carried into the next chunk), info->out_bytes their total text size.  FASTP_GPU_E_INVALID when the
+ * bytes at a member boundary are not a BGZF header (info->first_bad = that block's index). */
+typedef struct fastp_gpu_inflate_info {
+    int32_t n_blocks;
+    int32_t first_bad;   /* index of the first malformed block, or -1 */
+    int64_t consumed;
+    int64_t out_bytes;
+} fastp_gpu_inflate_info;
+
+int fastp_gpu_bgzf_index(const uint8_t* host_bytes, int64_t nbytes, int32_t max_blocks, int64_t max_text_bytes,
+                         uint32_t* pay_off, uint32_t* pay_len, uint32_t* isize, uint32_t* crc, uint64_t* out_off,
+                         fastp_gpu_inflate_info* info);
+
+/* Inflate n_blocks indexed blocks of the compressed chunk `comp` (DEVICE memory, readable for 8 bytes
+ * past the last payload) into `out` (DEVICE).  The five index arrays are DEVICE copies of what
+ * fastp_gpu_bgzf_index produced.  Every block's size is checked against its trailer, and its CRC-32
+ * when check_crc != 0 (the reference's igzip does both).  first_bad (HOST, may be NULL) receives the
+ * first failing block or -1; FASTP_GPU_E_INVALID if any block failed.  Synchronous. */
+int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, int32_t n_blocks, const uint32_t* pay_off,
+                           const uint32_t* pay_len, const uint32_t* isize, const uint32_t* crc, const uint64_t* out_off,
+                           uint8_t* out, int64_t out_capacity, int check_crc, int32_t* first_bad);
+
 /* ---- result records -> output FASTQ text ON THE DEVICE ---------------
  * The step after the path for the main output streams: Read::appendToString (src/read.cpp:119-134)
  * for every unit the worker loop routes to out1 [and out2] (peprocessor.cpp:577-591,

@@ -493,6 +493,27 @@ def test_gpu_file_pipeline_equals_reference_outputs(name, tmp_path):
             assert (tmp_path / "o2.fq").read_bytes() == r["out2"]
 
 
+@pytest.mark.parametrize("level,strategy", [(6, "default"), (1, "default"), (0, "default"), (6, "fixed")])
+def test_gpu_bgzf_inflate_equals_zlib(level, strategy):
+    """BGZF blocks inflated on the device (one lane per block) == the text zlib compressed; then parsed and packed"""
+    import zlib
+    import bgzf_util
+    import format_util
+    import test_hostsim_parity as hs
+    strat = {"default": zlib.Z_DEFAULT_STRATEGY, "fixed": zlib.Z_FIXED}[strategy]
+    text = hs._fastq_text(30000, 8)
+    comp = bgzf_util.compress(text, level=level, strategy=strat)
+    g = engines.gpu_engine(abi.default_params(False, 150))
+    info, rc, bad, got = hs._inflate(g, format_util.TorchMem(), comp)
+    assert rc == 0 and bad == -1 and info.consumed == len(comp) and info.n_blocks == len(text) // 0xff00 + 2
+    assert got == text
+    bad_comp = bytearray(comp)
+    bad_comp[18 + 3000] ^= 0x10
+    _, rc, bad, _ = hs._inflate(g, format_util.TorchMem(), bytes(bad_comp), check=False)
+    assert rc == abi.E_INVALID and bad == 0
+    g.close()
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))

@@ -287,3 +287,75 @@ def test_sim_device_fastq_format_crlf_limits_and_errors():
                                  synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2), 150)
         assert rc == abi.E_UNSUPPORTED
         g.close()
+
+
+def _inflate(eng, mem, comp: bytes, check_crc=True, max_blocks=100000, check=True):
+    """BGZF bytes -> text through fastp_gpu_bgzf_index (host) + fastp_gpu_inflate_bgzf (device)"""
+    host = np.frombuffer(comp, dtype=np.uint8)
+    info, poff, plen, isz, crc, ooff = eng.bgzf_index(host, max_blocks, 1 << 40, check=check)
+    d_comp = mem.upload(comp, 16)
+    dev = [mem.upload(a.tobytes(), 16) for a in (poff, plen, isz, crc, ooff)]
+    out = mem.alloc(max(16, int(info.out_bytes)), 0xEE)
+    mem.sync()
+    rc, bad = eng.inflate_bgzf(mem.ptr(d_comp), info.n_blocks, *[mem.ptr(x) for x in dev], mem.ptr(out), int(info.out_bytes),
+                               check_crc, check=check)
+    return info, rc, bad, mem.download(out, int(info.out_bytes))
+
+
+def _fastq_text(n, seed):
+    d = synth.synth_pairs(n, L=150, seed=seed, paired=False)
+    return synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+
+
+@pytest.mark.parametrize("level,strategy", [(6, "default"), (1, "default"), (9, "default"), (0, "default"), (6, "fixed"),
+                                            (6, "huffman"), (6, "rle")])
+def test_sim_bgzf_inflate_equals_zlib(level, strategy):
+    """every DEFLATE block type (stored, fixed, dynamic) and match style, against the text zlib compressed"""
+    import zlib
+    import bgzf_util
+    import format_util
+    strat = {"default": zlib.Z_DEFAULT_STRATEGY, "fixed": zlib.Z_FIXED, "huffman": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE}[strategy]
+    text = _fastq_text(700, 3)
+    comp = bgzf_util.compress(text, block_bytes=20000, level=level, strategy=strat)
+    g = engines.sim_engine(abi.default_params(False, 150))
+    info, rc, bad, got = _inflate(g, format_util.NumpyMem(), comp)
+    g.close()
+    assert rc == 0 and bad == -1 and info.consumed == len(comp) and info.out_bytes == len(text)
+    assert got == text
+
+
+def test_sim_bgzf_index_chunks_and_errors():
+    import bgzf_util
+    import format_util
+    text = _fastq_text(300, 4) + bytes(range(256)) * 40 + b"A" * 70000   # binary bytes, a long run (distance 1 copies)
+    comp = bgzf_util.compress(text, block_bytes=0xff00)
+    g = engines.sim_engine(abi.default_params(False, 150))
+    mem = format_util.NumpyMem()
+    # a chunk that ends inside a member: only the whole members are walked
+    cut = len(comp) - 37
+    info, *_ = g.bgzf_index(np.frombuffer(comp[:cut], dtype=np.uint8), 1000, 1 << 40)
+    assert 0 < info.consumed < cut and comp[info.consumed:info.consumed + 2] == bytes([0x1f, 0x8b])
+    # limits: blocks, text bytes
+    info2, *_ = g.bgzf_index(np.frombuffer(comp, dtype=np.uint8), 1, 1 << 40)
+    assert info2.n_blocks == 1 and info2.out_bytes == 0xff00
+    info3, *_ = g.bgzf_index(np.frombuffer(comp, dtype=np.uint8), 1000, 0xff00 + 5)
+    assert info3.n_blocks == 1
+    info4, rc, bad, got = _inflate(g, mem, comp)
+    assert rc == 0 and got == text
+    # not BGZF: a plain gzip member
+    import gzip
+    info5, *_ = g.bgzf_index(np.frombuffer(gzip.compress(text[:1000]), dtype=np.uint8), 10, 1 << 40, check=False)
+    assert info5.rc == abi.E_INVALID and info5.first_bad == 0
+    # a corrupted payload byte is caught (CRC or stream error), a corrupted CRC field too
+    bad_comp = bytearray(comp)
+    bad_comp[18 + 200] ^= 0x55
+    _, rc, bad, _ = _inflate(g, mem, bytes(bad_comp), check=False)
+    assert rc == abi.E_INVALID and bad == 0
+    first_len = int.from_bytes(comp[16:18], "little") + 1
+    bad_comp = bytearray(comp)
+    bad_comp[first_len - 8] ^= 1                                # CRC field of block 0
+    _, rc, bad, _ = _inflate(g, mem, bytes(bad_comp), check=False)
+    assert rc == abi.E_INVALID and bad == 0
+    _, rc, bad, got = _inflate(g, mem, bytes(bad_comp), check_crc=False)
+    assert rc == 0 and got == text
+    g.close()
