@@ -37,7 +37,7 @@ enum { INF_OK = 0, INF_E_HEADER = 1, INF_E_BTYPE = 2, INF_E_STORED = 3, INF_E_CO
        INF_E_ISIZE = 7, INF_E_TABLE = 8, INF_E_CRC = 9 };
 
 struct InflateArgs {
-    const u8* comp;        // compressed chunk (padded by >= 8 readable bytes)
+    const u8* comp;        // compressed chunk (readable for 16 bytes past the last member)
     const u32* pay_off;    // [n] offset of the block's deflate payload in comp
     const u32* pay_len;    // [n] payload bytes
     const u32* isize;      // [n] uncompressed size from the member trailer
@@ -52,20 +52,57 @@ struct InflateArgs {
     int check_crc;
 };
 
+// unaligned 8-byte global accesses (gfx9+ global memory handles any alignment)
+FQ_DEV u64 inf_ld8(const u8* p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+FQ_DEV void inf_st8(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
+
+// LSB-first bit reader.  The stream is fetched eight bytes at a time, one fetch AHEAD of its use: `cur`
+// is being consumed four bytes per refill, `nxt` was requested when `cur` was installed, so a refill
+// never waits for memory.  pos = stream offset of the first byte not yet moved into `buf`.
 struct InfBits {
     const u8* in;
-    u32 pos, end;   // next byte to fetch, end of payload
+    u32 pos, end;
     u64 buf;
     int cnt;
+    u64 cur, nxt;
+    int cur_left;   // bytes of `cur` not yet moved into buf (0, 4 or 8)
 };
 
+FQ_DEV void inf_start(InfBits& b, const u8* in, u32 end) {
+    b.in = in;
+    b.pos = 0;
+    b.end = end;
+    b.buf = 0;
+    b.cnt = 0;
+    b.cur = inf_ld8(in);
+    b.nxt = inf_ld8(in + 8);
+    b.cur_left = 8;
+}
+// restart the fetch pipeline at byte offset `pos` (after a stored block)
+FQ_DEV void inf_seek(InfBits& b, u32 pos) {
+    b.pos = pos;
+    b.buf = 0;
+    b.cnt = 0;
+    b.cur = inf_ld8(b.in + pos);
+    b.nxt = inf_ld8(b.in + pos + 8);
+    b.cur_left = 8;
+}
 FQ_DEV void inf_refill(InfBits& b) {
-    if (b.cnt <= 32) {  // four bytes at a time; past-the-end bytes are padding and never consumed by a valid stream
-        const u8* p = b.in + b.pos;
-        const u32 w = (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
-        b.buf |= (u64)w << b.cnt;
-        b.pos += 4;
+    if (b.cnt <= 32) {  // past-the-end bytes are padding / the next member and are never consumed by a valid stream
+        b.buf |= (b.cur & 0xFFFFFFFFull) << b.cnt;
+        b.cur >>= 32;
         b.cnt += 32;
+        b.pos += 4;
+        b.cur_left -= 4;
+        if (b.cur_left == 0) {
+            b.cur = b.nxt;
+            b.cur_left = 8;
+            b.nxt = inf_ld8(b.in + b.pos + 8);
+        }
     }
 }
 FQ_DEV u32 inf_bits(InfBits& b, int n) {  // n <= 16
@@ -79,15 +116,28 @@ FQ_DEV u32 inf_bits(InfBits& b, int n) {  // n <= 16
 // table entry e of this lane
 FQ_DEV u16& inf_t(u16* tab, int e, int lane) { return tab[e * INF_LANES + lane]; }
 
-// canonical Huffman decode: counts at cnt_o[1..15], symbols at sym_o[...]; -1 on an invalid code
-FQ_DEV int inf_decode(InfBits& b, u16* tab, int lane, int cnt_o, int sym_o) {
+// The per-length code counts of one Huffman code in registers (15 counts <= 288, ten bits each): the decode
+// loop walks the code lengths with constant indices, so it touches no memory until the symbol itself.
+struct InfCounts {
+    u32 r[5];
+};
+FQ_DEV void inf_load_counts(InfCounts& c, u16* tab, int lane, int cnt_o) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) c.r[k] = 0;
+#pragma unroll
+    for (int l = 1; l <= INF_MAXBITS; l++) c.r[(l - 1) / 3] |= (u32)inf_t(tab, cnt_o + l, lane) << (10 * ((l - 1) % 3));
+}
+
+// canonical Huffman decode (RFC 1951 3.2.2): symbols at sym_o[...] in code order; -1 on an invalid code
+FQ_DEV int inf_decode(InfBits& b, const InfCounts& c, u16* tab, int lane, int sym_o) {
     inf_refill(b);
     int code = 0, first = 0, index = 0;
     u32 bits = (u32)b.buf;
+#pragma unroll
     for (int len = 1; len <= INF_MAXBITS; len++) {
         code |= (int)(bits & 1u);
         bits >>= 1;
-        const int count = (int)inf_t(tab, cnt_o + len, lane);
+        const int count = (int)((c.r[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 0x3FFu);
         if (code - count < first) {
             b.buf >>= len;
             b.cnt -= len;
@@ -142,6 +192,60 @@ FQ_DEV void inf_dist_base(int sym, int& base, int& extra) {  // sym = 0..29
     base = 1 + ((2 + (sym & 1)) << extra);
 }
 
+// store the low n (< 8) bytes of v
+FQ_DEV void inf_st_tail(u8* p, u64 v, int n) {
+    for (int i = 0; i < n; i++) {
+        p[i] = (u8)v;
+        v >>= 8;
+    }
+}
+
+// LZ77 copy of len bytes from dst - dist to dst (the regions may overlap: the pattern repeats).  A byte loop
+// would pay one memory round trip per byte (every load may alias the store before it); here
+//   dist >= 8 : eight bytes per step, the loads of a 32-byte group issued before its stores when dist >= 32
+//   dist <  8 : the dist-byte pattern is read ONCE, widened to a periodic 8-byte word, and only stored
+// Stores never go past dst + len (the next block's text belongs to another lane).
+FQ_DEV void inf_copy(u8* dst, u32 dist, int len) {
+    const u8* src = dst - dist;
+    if (dist >= 32u) {
+        int i = 0;
+        for (; i + 32 <= len; i += 32) {
+            const u64 a = inf_ld8(src + i), b = inf_ld8(src + i + 8), c = inf_ld8(src + i + 16), d = inf_ld8(src + i + 24);
+            inf_st8(dst + i, a);
+            inf_st8(dst + i + 8, b);
+            inf_st8(dst + i + 16, c);
+            inf_st8(dst + i + 24, d);
+        }
+        if (i < len) {  // < 32 bytes left: reads may run past src + len (still inside the lane's own text), stores are exact
+            const u64 a = inf_ld8(src + i), b = inf_ld8(src + i + 8), c = inf_ld8(src + i + 16), d = inf_ld8(src + i + 24);
+            const u64 w[4] = {a, b, c, d};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int left = len - i - 8 * k;
+                if (left >= 8) inf_st8(dst + i + 8 * k, w[k]);
+                else if (left > 0) inf_st_tail(dst + i + 8 * k, w[k], left);
+            }
+        }
+        return;
+    }
+    if (dist >= 8u) {
+        int i = 0;
+        for (; i + 8 <= len; i += 8) inf_st8(dst + i, inf_ld8(src + i));
+        if (i < len) inf_st_tail(dst + i, inf_ld8(src + i), len - i);
+        return;
+    }
+    // dist 1..7: periodic word.  step = the largest multiple of dist that fits in 8 bytes
+    u64 pat = 0;   // byte loads: independent of each other (one round trip), and nothing past dst is touched
+    for (u32 k = 0; k < dist; k++) pat |= (u64)src[k] << (8 * k);
+    u64 word = pat;
+    for (u32 filled = dist; filled < 8u; filled += dist) word |= pat << (8 * filled);
+    const int step = (int)((8u / dist) * dist);
+    int i = 0;
+    for (; i + 8 <= len; i += step) inf_st8(dst + i, word);
+    // the word starts a period at every multiple of step, so the tail is its low bytes
+    if (i < len) inf_st_tail(dst + i, word, len - i);
+}
+
 FQ_DEV u32 inf_crc32_update(u32 crc, u32 byte) {  // bitwise, reflected 0xEDB88320: no table, no memory traffic
     crc ^= byte;
 #pragma unroll
@@ -151,11 +255,7 @@ FQ_DEV u32 inf_crc32_update(u32 crc, u32 byte) {  // bitwise, reflected 0xEDB883
 
 FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
     InfBits b;
-    b.in = a.comp + a.pay_off[g];
-    b.pos = 0;
-    b.end = a.pay_len[g];
-    b.buf = 0;
-    b.cnt = 0;
+    inf_start(b, a.comp + a.pay_off[g], a.pay_len[g]);
     u8* out = a.out + a.out_off[g];
     const u32 cap = a.isize[g];
     if (a.out_off[g] + cap > a.out_cap) return INF_E_ISIZE;
@@ -174,13 +274,13 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             if ((len ^ 0xFFFFu) != nlen) return INF_E_STORED;
             if (opos + len > cap) return INF_E_ISIZE;
             // the bit buffer holds whole bytes now: hand them back, then copy from the stream
-            b.pos -= (u32)(b.cnt >> 3);
-            b.buf = 0;
-            b.cnt = 0;
-            if (b.pos + len > b.end) return INF_E_OVERRUN;
-            for (u32 i = 0; i < len; i++) out[opos + i] = b.in[b.pos + i];
-            b.pos += len;
+            const u32 at = b.pos - (u32)(b.cnt >> 3);
+            if (at + len > b.end) return INF_E_OVERRUN;
+            u32 i = 0;
+            for (; i + 8 <= len; i += 8) inf_st8(out + opos + i, inf_ld8(b.in + at + i));
+            for (; i < len; i++) out[opos + i] = b.in[at + i];
             opos += len;
+            inf_seek(b, at + len);
             continue;
         }
         if (type == 3) return INF_E_BTYPE;
@@ -204,9 +304,11 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             }
             auto cl = [&](int s) -> u32 { return (u32)lens[s]; };
             if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, 19, cl, false)) return INF_E_TABLE;
+            InfCounts cc;
+            inf_load_counts(cc, tab, lane, INF_O_LCNT);
             int idx = 0;
             while (idx < nlen + ndist) {
-                int sym = inf_decode(b, tab, lane, INF_O_LCNT, INF_O_LSYM);
+                int sym = inf_decode(b, cc, tab, lane, INF_O_LSYM);
                 if (sym < 0) return INF_E_CODE;
                 if (sym < 16) {
                     lens[idx++] = (u8)sym;
@@ -235,8 +337,11 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, nlen, ll, true)) return INF_E_TABLE;
         }
         // ---- the symbols of this block ----
+        InfCounts lc, dc;
+        inf_load_counts(lc, tab, lane, INF_O_LCNT);
+        inf_load_counts(dc, tab, lane, INF_O_DCNT);
         for (;;) {
-            int sym = inf_decode(b, tab, lane, INF_O_LCNT, INF_O_LSYM);
+            int sym = inf_decode(b, lc, tab, lane, INF_O_LSYM);
             if (sym < 0) return INF_E_CODE;
             if (sym < 256) {
                 if (opos >= cap) return INF_E_ISIZE;
@@ -248,16 +353,14 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             int base, extra;
             inf_len_base(sym, base, extra);
             const int len = base + (int)inf_bits(b, extra);
-            const int ds = inf_decode(b, tab, lane, INF_O_DCNT, INF_O_DSYM);
+            const int ds = inf_decode(b, dc, tab, lane, INF_O_DSYM);
             if (ds < 0 || ds > 29) return INF_E_DIST;
             inf_dist_base(ds, base, extra);
             // up to 13 extra bits: within inf_bits' 16
             const u32 dist = (u32)base + inf_bits(b, extra);
             if (dist > opos) return INF_E_DIST;
             if (opos + (u32)len > cap) return INF_E_ISIZE;
-            const u8* src = out + opos - dist;
-            u8* dst = out + opos;
-            for (int i = 0; i < len; i++) dst[i] = src[i];  // overlapping copies repeat the pattern, byte by byte
+            inf_copy(out + opos, dist, len);
             opos += (u32)len;
         }
         if (b.pos - (u32)(b.cnt >> 3) > b.end) return INF_E_OVERRUN;

@@ -366,8 +366,8 @@ int fastp_gpu_bgzf_index(const uint8_t* host_bytes, int64_t nbytes, int32_t max_
                          uint32_t* pay_off, uint32_t* pay_len, uint32_t* isize, uint32_t* crc, uint64_t* out_off,
                          fastp_gpu_inflate_info* info);
 
-/* Inflate n_blocks indexed blocks of the compressed chunk `comp` (DEVICE memory, readable for 8 bytes
- * past the last payload) into `out` (DEVICE).  The five index arrays are DEVICE copies of what
+/* Inflate n_blocks indexed blocks of the compressed chunk `comp` (DEVICE memory, readable for 16 bytes
+ * past the last member) into `out` (DEVICE).  The five index arrays are DEVICE copies of what
  * fastp_gpu_bgzf_index produced.  Every block's size is checked against its trailer, and its CRC-32
  * when check_crc != 0 (the reference's igzip does both).  first_bad (HOST, may be NULL) receives the
  * first failing block or -1; FASTP_GPU_E_INVALID if any block failed.  Synchronous. */
