@@ -5,7 +5,9 @@ fastqreader.cpp:31,88-149), ships them to HBM, and writes the text that comes ba
 writerthread.cpp:118-168).  Line splitting + packing (`fastp_gpu_parse_fastq`), the worker loop
 (`fastp_gpu_submit_device`) and record formatting (`fastp_gpu_format_fastq`) run on the GPU; what the
 reference's processSingleEnd / processPairEnd would have written to out1 / out2 comes out byte for
-byte.  Scope: plain (uncompressed) FASTQ, out1/out2 only, no merge mode / UMI name edits (those keep
+byte.  Input files may be plain FASTQ or BGZF (.gz written by bgzip: the reference's BgzfMtReader path,
+src/bgzf.h) - those are shipped compressed and inflated on the device (`fastp_gpu_inflate_bgzf`).
+Scope: out1/out2 only, no merge mode / UMI name edits (those keep
 the string-side host path of INTEGRATION.md section 3).  Reader and writer run on their own threads
 so file I/O overlaps the device work of the neighbouring chunks.
 """
@@ -30,8 +32,10 @@ class _Mate:
 
     def __init__(self, torch, dev, chunk_bytes, max_records, max_len):
         ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
-        self.cap = chunk_bytes + 64
+        self.cap = 2 * chunk_bytes + 64          # [text carried from the previous chunk | this chunk's text]
         self.text = torch.zeros(self.cap, dtype=torch.uint8, device=dev)
+        self.comp = None                          # BGZF input: the compressed chunk + its block index on the device
+        self.idx = None
         self.seq = torch.empty(max_records * ss, dtype=torch.uint8, device=dev)
         self.qual = torch.empty(max_records * qs, dtype=torch.uint8, device=dev)
         self.lens = torch.empty(max_records, dtype=torch.int16, device=dev)
@@ -51,7 +55,7 @@ class FastqPipeline:
         self.dev = torch.device("cuda", device)
         self.eng = engine.GpuEngine(params, device=device)
         self.chunk = int(chunk_bytes)
-        self.max_records = int(max_records or max(1024, self.chunk // 48))
+        self.max_records = int(max_records or max(1024, (2 * self.chunk) // 48))
         nm = 2 if self.paired else 1
         self.mates = [_Mate(torch, self.dev, self.chunk, self.max_records, params.max_len) for _ in range(nm)]
         self.pair = torch.zeros(self.max_records * 8, dtype=torch.uint8, device=self.dev)
@@ -64,7 +68,9 @@ class FastqPipeline:
         self.nev = torch.zeros(4, dtype=torch.int32, device=self.dev)
         # two pinned staging sets per direction: the reader fills one while the device works on the other
         self.stage_in = [[torch.empty(self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
-        self.stage_out = [[torch.empty(self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
+        self.stage_out = [[torch.empty(2 * self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
+        self.max_blocks = (2 * self.chunk) // 8192 + 64     # BGZF members per chunk (bgzip: ~64 KiB of text each)
+        self.check_crc = True
         self.stats = dict(units=0, chunks=0, bytes_in=0, bytes_out=0, t_parse=0.0, t_engine=0.0, t_format=0.0, t_h2d=0.0,
                           t_d2h=0.0, t_wait_read=0.0, t_wait_write=0.0)
 
@@ -76,7 +82,8 @@ class FastqPipeline:
     IO_PIECE = 32 << 20
 
     def _reader(self, files, q_free, q_full, tails):
-        """fills a staging set: [bytes the device did not consume last time | fresh bytes], all mates concurrently"""
+        """fills a staging set: [file bytes the last trip left over | fresh bytes], all mates concurrently;
+        tails[m] = bytes per trip for file m"""
         import os
         from concurrent.futures import ThreadPoolExecutor
         fds = [f.fileno() for f in files]
@@ -104,7 +111,7 @@ class FastqPipeline:
                         k = len(carry[m])
                         if k:
                             buf[:k] = np.frombuffer(carry[m], dtype=np.uint8)
-                        want = min(self.chunk - k, sizes[m] - pos[m])
+                        want = max(0, min(tails[m] - k, sizes[m] - pos[m]))
                         mv = memoryview(buf)[k:k + want]
                         for a in range(0, want, self.IO_PIECE):
                             e = min(want, a + self.IO_PIECE)
@@ -148,24 +155,70 @@ class FastqPipeline:
         except Exception as e:
             q_done.put(e)
 
+    @staticmethod
+    def is_bgzf(path: str) -> bool:
+        """isBgzf (src/bgzf.h:17-27): gzip magic, FEXTRA, BC subfield of length 2 first"""
+        with open(path, "rb") as f:
+            h = f.read(18)
+        return (len(h) == 18 and h[0] == 0x1f and h[1] == 0x8b and h[2] == 8 and (h[3] & 4) and h[12] == 0x42 and h[13] == 0x43
+                and (h[14] | (h[15] << 8)) == 2)
+
+    def _inflate_into(self, m, slot, nb, tcarry, eof_file):
+        """BGZF bytes in the staging buffer -> text on the device behind the carried text.  Returns (text bytes
+        added, compressed bytes consumed)."""
+        torch = self.torch
+        M = self.mates[m]
+        host = self.stage_in[slot][m].numpy()[:nb]
+        if M.comp is None:
+            M.comp = torch.zeros(self.chunk + 64, dtype=torch.uint8, device=self.dev)
+            M.idx = torch.zeros(self.max_blocks * 24 + 64, dtype=torch.uint8, device=self.dev)
+        room = M.cap - 64 - tcarry
+        info, poff, plen, isz, crc, ooff = self.eng.bgzf_index(host, self.max_blocks, room)
+        nblk, used = int(info.n_blocks), int(info.consumed)
+        if nblk == 0:
+            if eof_file and nb > 0:
+                raise PipelineError(f"truncated BGZF member at the end of mate {m + 1}'s file")
+            return 0, 0
+        M.comp[:used].copy_(self.stage_in[slot][m][:used], non_blocking=True)
+        M.comp[used:used + 32].zero_()
+        packed = np.concatenate([a.view(np.uint8) for a in (poff, plen, isz, crc, ooff)])   # 4+4+4+4+8 bytes per block
+        M.idx[:packed.size].copy_(torch.from_numpy(packed), non_blocking=False)
+        base = M.idx.data_ptr()
+        o = [0, 4 * nblk, 8 * nblk, 12 * nblk, 16 * nblk]
+        torch.cuda.synchronize(self.dev)
+        self.eng.inflate_bgzf(M.comp.data_ptr(), nblk, base + o[0], base + o[1], base + o[2], base + o[3], base + o[4],
+                              M.text.data_ptr() + tcarry, int(info.out_bytes), self.check_crc)
+        return int(info.out_bytes), used
+
     def run(self, in1: str, in2: str | None, out1: str, out2: str | None) -> dict:
         torch = self.torch
         if self.paired != (in2 is not None) or self.paired != (out2 is not None):
             raise PipelineError("paired engine needs in2/out2, single-end engine must not get them")
         nm = len(self.mates)
-        fin = [open(p, "rb", buffering=0) for p in ((in1, in2) if self.paired else (in1,))]
+        paths = (in1, in2) if self.paired else (in1,)
+        gz = [self.is_bgzf(p) for p in paths]
+        for p, g in zip(paths, gz):
+            if not g:
+                with open(p, "rb") as f:
+                    if f.read(2) == b"\x1f\x8b":
+                        raise PipelineError(f"{p}: gzip but not BGZF - a single deflate stream has no independent blocks; "
+                                            "decompress on the host (as the reference does) or recompress with bgzip")
+        fin = [open(p, "rb", buffering=0) for p in paths]
         fout = [open(p, "wb", buffering=0) for p in ((out1, out2) if self.paired else (out1,))]
         q_free, q_full, q_out, q_done = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
-        rd = threading.Thread(target=self._reader, args=(fin, q_free, q_full, None), daemon=True)
+        # a compressed chunk expands ~4-5x: read a quarter of the text budget per trip
+        want = [self.chunk // 4 if g else self.chunk for g in gz]
+        rd = threading.Thread(target=self._reader, args=(fin, q_free, q_full, want), daemon=True)
         wr = threading.Thread(target=self._writer, args=(fout, q_out, q_done), daemon=True)
         rd.start()
         wr.start()
         st = self.stats
+        st.setdefault("t_inflate", 0.0)
         t_start = time.perf_counter()
+        tcarry = [0] * nm          # text bytes already at the front of mates[m].text (device-side carry)
         try:
             q_free.put((0, [b""] * nm))
             out_free = [0, 1]
-            slot = 0
             done = False
             while not done:
                 t0 = time.perf_counter()
@@ -174,93 +227,75 @@ class FastqPipeline:
                     raise item
                 slot, fills = item
                 st["t_wait_read"] += time.perf_counter() - t0
-                # ---- H2D ----
-                t0 = time.perf_counter()
-                for m in range(nm):
-                    nb = fills[m][0]
-                    self.mates[m].text[:nb].copy_(self.stage_in[slot][m][:nb], non_blocking=True)
-                    self.mates[m].text[nb:nb + 32].zero_()
-                torch.cuda.synchronize(self.dev)
-                st["t_h2d"] += time.perf_counter() - t0
                 st["bytes_in"] += sum(f[0] for f in fills)
+                total, fcarry, eof = [0] * nm, [b""] * nm, [False] * nm
+                for m in range(nm):
+                    nb, eof_file = fills[m]
+                    M = self.mates[m]
+                    if gz[m]:
+                        t0 = time.perf_counter()
+                        added, used = self._inflate_into(m, slot, nb, tcarry[m], eof_file)
+                        st["t_inflate"] += time.perf_counter() - t0
+                        if nb > used:
+                            fcarry[m] = bytes(memoryview(self.stage_in[slot][m].numpy())[used:nb])
+                        if added == 0 and not eof_file and len(fcarry[m]) >= want[m]:
+                            raise PipelineError("the text buffer cannot take another BGZF block: raise chunk_bytes")
+                        total[m] = tcarry[m] + added
+                        eof[m] = eof_file and not fcarry[m]
+                    else:
+                        t0 = time.perf_counter()
+                        if tcarry[m] + nb > M.cap - 64:
+                            raise PipelineError("a record does not fit the chunk size")
+                        M.text[tcarry[m]:tcarry[m] + nb].copy_(self.stage_in[slot][m][:nb], non_blocking=True)
+                        torch.cuda.synchronize(self.dev)
+                        st["t_h2d"] += time.perf_counter() - t0
+                        total[m] = tcarry[m] + nb
+                        eof[m] = eof_file
+                    M.text[total[m]:total[m] + 32].zero_()
+                # the reader refills the other staging set while the device works on this chunk
+                all_eof = all(eof)
+                if not all_eof:
+                    q_free.put((1 - slot, fcarry))
                 # ---- parse (both mates to the same record count) ----
                 t0 = time.perf_counter()
-                infos = [self._parse(m, fills[m][0], fills[m][1], self.max_records) for m in range(nm)]
+                infos = [self._parse(m, total[m], eof[m], self.max_records) for m in range(nm)]
                 n = min(i.n_records for i in infos)
                 for m in range(nm):
                     if infos[m].n_records != n:
-                        infos[m] = self._parse(m, fills[m][0], fills[m][1], n)
+                        infos[m] = self._parse(m, total[m], eof[m], n)
                 st["t_parse"] += time.perf_counter() - t0
-                all_eof = all(f[1] for f in fills)
-                # the unconsumed tails go to the reader with the other staging set; it refills while the device works
-                carry = []
-                for m in range(nm):
-                    a, b = int(infos[m].consumed), fills[m][0]
-                    carry.append(bytes(memoryview(self.stage_in[slot][m].numpy())[a:b]) if b > a else b"")
-                stalled = n == 0 and all(len(carry[m]) == fills[m][0] for m in range(nm))
-                if all_eof and (n == 0 or all(len(c) == 0 for c in carry)):
-                    done = True
-                elif stalled and not all_eof and any(len(c) >= self.chunk for c in carry):
+                left = [total[m] - int(infos[m].consumed) for m in range(nm)]
+                if all_eof:
+                    done = True    # what is left is a trailing partial record / the longer mate's surplus: the reference stops too
+                elif n == 0 and any(left[m] >= self.chunk for m in range(nm)):
                     raise PipelineError("a record does not fit the chunk size")
-                elif stalled and all_eof:
-                    done = True   # trailing partial record / mates of different length: the reference stops too
-                if not done:
-                    q_free.put((1 - slot, carry))
-                if n == 0:
-                    continue
-                # ---- worker loop ----
-                t0 = time.perf_counter()
-                b = abi.Batch()
-                b.n, b.flags = n, abi.BATCH_STAT_ISIZE
-                M = self.mates
-                b.seq1, b.qual1, b.len1 = M[0].seq.data_ptr(), M[0].qual.data_ptr(), M[0].lens.data_ptr()
-                if self.paired:
-                    b.seq2, b.qual2, b.len2 = M[1].seq.data_ptr(), M[1].qual.data_ptr(), M[1].lens.data_ptr()
-                r = abi.Results()
-                r.r1 = M[0].res.data_ptr()
-                if self.paired:
-                    r.r2, r.pair = M[1].res.data_ptr(), self.pair.data_ptr()
-                if self.corr_cap:
-                    r.corrections, r.corrections_capacity = self.corr.data_ptr(), self.corr_cap
-                r.n_corrections = self.nc.data_ptr()
-                if self.ev_cap:
-                    r.adapter_events, r.adapter_events_capacity, r.n_adapter_events = self.ev.data_ptr(), self.ev_cap, self.nev.data_ptr()
-                self.eng.submit_device(b, r)
-                self.eng.synchronize()
-                st["t_engine"] += time.perf_counter() - t0
-                # ---- format ----
-                t0 = time.perf_counter()
-                fi = []
+                if n > 0:
+                    lens = self._process_and_format(n, st)
+                    # ---- D2H + hand to the writer ----
+                    t0 = time.perf_counter()
+                    while not out_free:
+                        d = q_done.get()
+                        if isinstance(d, Exception):
+                            raise d
+                        out_free.append(d)
+                    st["t_wait_write"] += time.perf_counter() - t0
+                    oslot = out_free.pop(0)
+                    t0 = time.perf_counter()
+                    for m in range(nm):
+                        self.stage_out[oslot][m][:lens[m]].copy_(self.mates[m].out[:lens[m]], non_blocking=True)
+                    torch.cuda.synchronize(self.dev)
+                    st["t_d2h"] += time.perf_counter() - t0
+                    q_out.put((oslot, lens))
+                    st["units"] += n
+                    st["chunks"] += 1
+                    st["bytes_out"] += sum(lens)
+                # ---- the unconsumed text tail moves to the front (after formatting: the records point into the text) ----
                 for m in range(nm):
-                    f = abi.FormatIn()
-                    f.text, f.line_off, f.line_len, f.res = M[m].text.data_ptr(), M[m].loff.data_ptr(), M[m].llen.data_ptr(), M[m].res.data_ptr()
-                    fi.append(f)
-                rc, l1, l2 = self.eng.format_fastq(n, fi[0], fi[1] if self.paired else None,
-                                                   self.corr.data_ptr() if self.corr_cap else None,
-                                                   self.nc.data_ptr() if self.corr_cap else None, M[0].out.data_ptr(), M[0].cap,
-                                                   M[1].out.data_ptr() if self.paired else None, M[1].cap if self.paired else 0)
-                if self.corr_cap and int(self.nc[0].item()) > self.corr_cap:
-                    raise PipelineError("correction list overflow: raise corr_capacity")
-                st["t_format"] += time.perf_counter() - t0
-                lens = (l1, l2)[:nm]
-                # ---- D2H + hand to the writer ----
-                t0 = time.perf_counter()
-                while not out_free:
-                    d = q_done.get()
-                    if isinstance(d, Exception):
-                        raise d
-                    out_free.append(d)
-                st["t_wait_write"] += time.perf_counter() - t0
-                oslot = out_free.pop(0)
-                t0 = time.perf_counter()
-                for m in range(nm):
-                    self.stage_out[oslot][m][:lens[m]].copy_(M[m].out[:lens[m]], non_blocking=True)
-                torch.cuda.synchronize(self.dev)
-                st["t_d2h"] += time.perf_counter() - t0
-                q_out.put((oslot, lens))
-                st["units"] += n
-                st["chunks"] += 1
-                st["bytes_out"] += sum(lens)
+                    a = int(infos[m].consumed)
+                    if left[m] and a:
+                        tail = self.mates[m].text[a:total[m]].clone()
+                        self.mates[m].text[:left[m]].copy_(tail)
+                    tcarry[m] = left[m]
         finally:
             q_free.put(None)
             q_out.put(None)
@@ -274,6 +309,43 @@ class FastqPipeline:
                 raise d
         st["wall"] = time.perf_counter() - t_start
         return dict(st)
+
+    def _process_and_format(self, n, st):
+        """worker loop + record formatting of the parsed chunk; returns the output byte counts per stream"""
+        nm = len(self.mates)
+        t0 = time.perf_counter()
+        b = abi.Batch()
+        b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+        M = self.mates
+        b.seq1, b.qual1, b.len1 = M[0].seq.data_ptr(), M[0].qual.data_ptr(), M[0].lens.data_ptr()
+        if self.paired:
+            b.seq2, b.qual2, b.len2 = M[1].seq.data_ptr(), M[1].qual.data_ptr(), M[1].lens.data_ptr()
+        r = abi.Results()
+        r.r1 = M[0].res.data_ptr()
+        if self.paired:
+            r.r2, r.pair = M[1].res.data_ptr(), self.pair.data_ptr()
+        if self.corr_cap:
+            r.corrections, r.corrections_capacity = self.corr.data_ptr(), self.corr_cap
+        r.n_corrections = self.nc.data_ptr()
+        if self.ev_cap:
+            r.adapter_events, r.adapter_events_capacity, r.n_adapter_events = self.ev.data_ptr(), self.ev_cap, self.nev.data_ptr()
+        self.eng.submit_device(b, r)
+        self.eng.synchronize()
+        st["t_engine"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        fi = []
+        for m in range(nm):
+            f = abi.FormatIn()
+            f.text, f.line_off, f.line_len, f.res = M[m].text.data_ptr(), M[m].loff.data_ptr(), M[m].llen.data_ptr(), M[m].res.data_ptr()
+            fi.append(f)
+        rc, l1, l2 = self.eng.format_fastq(n, fi[0], fi[1] if self.paired else None,
+                                           self.corr.data_ptr() if self.corr_cap else None,
+                                           self.nc.data_ptr() if self.corr_cap else None, M[0].out.data_ptr(), M[0].cap,
+                                           M[1].out.data_ptr() if self.paired else None, M[1].cap if self.paired else 0)
+        if self.corr_cap and int(self.nc[0].item()) > self.corr_cap:
+            raise PipelineError("correction list overflow: raise corr_capacity")
+        st["t_format"] += time.perf_counter() - t0
+        return (l1, l2)[:nm]
 
     def _parse(self, m, nbytes, is_last, max_records):
         M = self.mates[m]

@@ -514,6 +514,39 @@ def test_gpu_bgzf_inflate_equals_zlib(level, strategy):
     g.close()
 
 
+def test_gpu_file_pipeline_reads_bgzf(tmp_path):
+    """the same pipeline fed BGZF-compressed inputs (inflated on the device): same output files, same counters"""
+    import bgzf_util
+    from fastp_amd import pipeline
+    name = "pe_correction"
+    paired, flags, pf, skw = cases.CASES[name]
+    n = 20000
+    d = synth.synth_pairs(n, L=150, seed=92, paired=True, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d["seq2"], d["len2"])
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
+    ref = engines.gpu_engine(params)
+    want, ctr, _ = driver.run_engine(ref, params, fq1, fq2, pack=n, stride=abi.qual_stride(150))
+    ref.close()
+    (tmp_path / "r1.fq.gz").write_bytes(bgzf_util.compress(fq1))
+    (tmp_path / "r2.fq").write_bytes(fq2)                      # one compressed, one plain
+    assert pipeline.FastqPipeline.is_bgzf(str(tmp_path / "r1.fq.gz")) and not pipeline.FastqPipeline.is_bgzf(str(tmp_path / "r2.fq"))
+    pl = pipeline.FastqPipeline(params, chunk_bytes=1 << 20)
+    st = pl.run(str(tmp_path / "r1.fq.gz"), str(tmp_path / "r2.fq"), str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq"))
+    got_ctr = pl.counters()
+    pl.close()
+    assert st["units"] == n and st["chunks"] > 3
+    assert (tmp_path / "o1.fq").read_bytes() == bytes(want.out1)
+    assert (tmp_path / "o2.fq").read_bytes() == bytes(want.out2)
+    assert np.array_equal(got_ctr, ctr)
+    import gzip
+    (tmp_path / "plain.gz").write_bytes(gzip.compress(fq1[:5000]))
+    pl = pipeline.FastqPipeline(params, chunk_bytes=1 << 20)
+    with pytest.raises(pipeline.PipelineError):
+        pl.run(str(tmp_path / "plain.gz"), str(tmp_path / "r2.fq"), str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq"))
+    pl.close()
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))
