@@ -104,14 +104,14 @@ class FastqPipeline:
                     item = q_free.get()
                     if item is None:
                         return
-                    slot, carry = item
+                    slot, carry, budget = item
                     fills, futs = [], []
                     for m in range(len(files)):
                         buf = self.stage_in[slot][m].numpy()
                         k = len(carry[m])
                         if k:
                             buf[:k] = np.frombuffer(carry[m], dtype=np.uint8)
-                        want = max(0, min(tails[m] - k, sizes[m] - pos[m]))
+                        want = max(0, min(budget[m] - k, sizes[m] - pos[m]))
                         mv = memoryview(buf)[k:k + want]
                         for a in range(0, want, self.IO_PIECE):
                             e = min(want, a + self.IO_PIECE)
@@ -217,7 +217,7 @@ class FastqPipeline:
         t_start = time.perf_counter()
         tcarry = [0] * nm          # text bytes already at the front of mates[m].text (device-side carry)
         try:
-            q_free.put((0, [b""] * nm))
+            q_free.put((0, [b""] * nm, list(want)))
             out_free = [0, 1]
             done = False
             while not done:
@@ -252,10 +252,7 @@ class FastqPipeline:
                         total[m] = tcarry[m] + nb
                         eof[m] = eof_file
                     M.text[total[m]:total[m] + 32].zero_()
-                # the reader refills the other staging set while the device works on this chunk
                 all_eof = all(eof)
-                if not all_eof:
-                    q_free.put((1 - slot, fcarry))
                 # ---- parse (both mates to the same record count) ----
                 t0 = time.perf_counter()
                 infos = [self._parse(m, total[m], eof[m], self.max_records) for m in range(nm)]
@@ -265,6 +262,10 @@ class FastqPipeline:
                         infos[m] = self._parse(m, total[m], eof[m], n)
                 st["t_parse"] += time.perf_counter() - t0
                 left = [total[m] - int(infos[m].consumed) for m in range(nm)]
+                # the reader refills the other staging set while the device works on this chunk; a plain-text mate
+                # whose tail stays on the device gets that much less this trip
+                if not all_eof:
+                    q_free.put((1 - slot, fcarry, [want[m] if gz[m] else max(0, want[m] - left[m]) for m in range(nm)]))
                 if all_eof:
                     done = True    # what is left is a trailing partial record / the longer mate's surplus: the reference stops too
                 elif n == 0 and any(left[m] >= self.chunk for m in range(nm)):
