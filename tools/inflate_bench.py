@@ -8,11 +8,13 @@ import synth_torch, bgzf_util
 from concurrent.futures import ThreadPoolExecutor
 dev = torch.device('cuda', 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+strategy = {"default": zlib.Z_DEFAULT_STRATEGY, "huffman": zlib.Z_HUFFMAN_ONLY, "fixed": zlib.Z_FIXED, "rle": zlib.Z_RLE}[sys.argv[2] if len(sys.argv) > 2 else "default"]
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 d = synth_torch.synth_pairs_torch(200_000, L=150, seed=3, device=dev)
 text = synth_torch.to_fastq_tensor(d["seq1"], d["qual1"], 1).cpu().numpy().tobytes()
 t0 = time.time()
 with ThreadPoolExecutor(32) as pool:   # zlib releases the GIL
-    blocks = list(pool.map(lambda i: bgzf_util.block(text[i:i + 0xff00]), range(0, len(text), 0xff00)))
+    blocks = list(pool.map(lambda i: bgzf_util.block(text[i:i + 0xff00], level, strategy), range(0, len(text), 0xff00)))
 one = b"".join(blocks)
 print(f"{len(text)/1e6:.1f} MB text -> {len(one)/1e6:.1f} MB BGZF ({len(blocks)} blocks, ratio {len(text)/len(one):.2f}) in {time.time()-t0:.1f}s", flush=True)
 g = engine.GpuEngine(abi.default_params(False, 150))
