@@ -863,7 +863,7 @@ extern "C" int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, i
     a.check_crc = check_crc;
     HIP_TRY(ctx, hipMemsetAsync(a.first_bad, 0xFF, 4, st));
     static bool attr_set = false;
-    const int lds_bytes = INF_ENTRIES * INF_LANES * 2;
+    const int lds_bytes = INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4;
     if (!attr_set) {
         HIP_TRY(ctx, hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;

@@ -30,6 +30,7 @@ enum {
     INF_O_DSYM = 32 + INF_MAXL,
     INF_ENTRIES = 32 + INF_MAXL + INF_MAXD,
     INF_SCRATCH = 320,  // code lengths of a dynamic block (bytes per lane)
+    INF_SBUF = 64,      // dwords of compressed stream staged in LDS per lane
 };
 
 // status per block
@@ -60,49 +61,77 @@ FQ_DEV u64 inf_ld8(const u8* p) {
 }
 FQ_DEV void inf_st8(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
 
-// LSB-first bit reader.  The stream is fetched eight bytes at a time, one fetch AHEAD of its use: `cur`
-// is being consumed four bytes per refill, `nxt` was requested when `cur` was installed, so a refill
-// never waits for memory.  pos = stream offset of the first byte not yet moved into `buf`.
+// LSB-first bit reader.  The compressed stream is staged through a per-lane LDS buffer ([dword][lane], INF_SBUF
+// dwords = 256 bytes per lane): one burst of independent 16-byte global loads per 256 bytes of stream instead of
+// a dependent global load every few symbols.  All stream offsets are relative to `base`, the 4-byte aligned
+// address at or below the payload start (`skew` = the payload's offset inside its first dword).
 struct InfBits {
-    const u8* in;
-    u32 pos, end;
+    const u8* base;   // aligned stream origin
+    u32 skew;         // payload start - base (0..3)
+    u32 end;          // payload length in bytes
+    u32 limit;        // dwords of stream that may be fetched (payload + trailer, the chunk is padded beyond)
+    u32 next_dw;      // stream dword index of sbuf slot 0's successor batch (= first dword NOT yet staged)
+    u32 rd;           // next staged dword to consume (index into the lane's buffer)
     u64 buf;
     int cnt;
-    u64 cur, nxt;
-    int cur_left;   // bytes of `cur` not yet moved into buf (0, 4 or 8)
+    u32 taken;        // dwords moved into buf so far since the last seek (+ seek origin) - for position accounting
+    u32* sbuf;
+    int lane;
 };
 
-FQ_DEV void inf_start(InfBits& b, const u8* in, u32 end) {
-    b.in = in;
-    b.pos = 0;
-    b.end = end;
-    b.buf = 0;
-    b.cnt = 0;
-    b.cur = inf_ld8(in);
-    b.nxt = inf_ld8(in + 8);
-    b.cur_left = 8;
+struct InfQuad {  // four dwords at a dword-aligned (not 16-byte aligned) address
+    u32 x, y, z, w;
+};
+FQ_DEV void inf_stage(InfBits& b) {  // fetch the next INF_SBUF dwords of the lane's stream into LDS
+    const InfQuad* src = (const InfQuad*)(b.base + 4 * (size_t)b.next_dw);
+    InfQuad v[INF_SBUF / 4];
+#pragma unroll
+    for (int j = 0; j < INF_SBUF / 4; j++) {
+        const InfQuad z = {0u, 0u, 0u, 0u};
+        v[j] = (b.next_dw + 4u * j < b.limit) ? src[j] : z;
+    }
+#pragma unroll
+    for (int j = 0; j < INF_SBUF / 4; j++) {
+        b.sbuf[(4 * j + 0) * INF_LANES + b.lane] = v[j].x;
+        b.sbuf[(4 * j + 1) * INF_LANES + b.lane] = v[j].y;
+        b.sbuf[(4 * j + 2) * INF_LANES + b.lane] = v[j].z;
+        b.sbuf[(4 * j + 3) * INF_LANES + b.lane] = v[j].w;
+    }
+    b.next_dw += INF_SBUF;
+    b.rd = 0;
 }
-// restart the fetch pipeline at byte offset `pos` (after a stored block)
+// (re)start reading at payload byte offset `pos`
 FQ_DEV void inf_seek(InfBits& b, u32 pos) {
-    b.pos = pos;
-    b.buf = 0;
-    b.cnt = 0;
-    b.cur = inf_ld8(b.in + pos);
-    b.nxt = inf_ld8(b.in + pos + 8);
-    b.cur_left = 8;
+    const u32 abs = b.skew + pos;      // byte offset from base
+    b.next_dw = abs >> 2;
+    b.taken = abs >> 2;
+    inf_stage(b);
+    const u32 drop = abs & 3u;         // bytes of the first dword that precede pos
+    b.buf = (u64)(b.sbuf[b.lane] >> (8 * drop));
+    b.cnt = 32 - 8 * (int)drop;
+    b.rd = 1;
+    b.taken++;
 }
+FQ_DEV void inf_start(InfBits& b, const u8* in, u32 end, u32* sbuf, int lane) {
+    const size_t addr = (size_t)in;
+    b.base = in - (addr & 3u);
+    b.skew = (u32)(addr & 3u);
+    b.end = end;
+    b.limit = ((b.skew + end + 3u) >> 2) + 4u;   // the payload and up to 16 bytes behind it (trailer / padding)
+    b.sbuf = sbuf;
+    b.lane = lane;
+    inf_seek(b, 0);
+}
+// payload bytes consumed so far (whole bytes still in the bit buffer count as not consumed)
+FQ_DEV u32 inf_pos(const InfBits& b) { return b.taken * 4u - b.skew - (u32)(b.cnt >> 3); }
+
 FQ_DEV void inf_refill(InfBits& b) {
-    if (b.cnt <= 32) {  // past-the-end bytes are padding / the next member and are never consumed by a valid stream
-        b.buf |= (b.cur & 0xFFFFFFFFull) << b.cnt;
-        b.cur >>= 32;
+    if (b.cnt <= 32) {  // past-the-end dwords read as zero / padding and are never consumed by a valid stream
+        if (b.rd == (u32)INF_SBUF) inf_stage(b);
+        b.buf |= (u64)b.sbuf[b.rd * INF_LANES + b.lane] << b.cnt;
+        b.rd++;
+        b.taken++;
         b.cnt += 32;
-        b.pos += 4;
-        b.cur_left -= 4;
-        if (b.cur_left == 0) {
-            b.cur = b.nxt;
-            b.cur_left = 8;
-            b.nxt = inf_ld8(b.in + b.pos + 8);
-        }
     }
 }
 FQ_DEV u32 inf_bits(InfBits& b, int n) {  // n <= 16
@@ -255,7 +284,7 @@ FQ_DEV u32 inf_crc32_update(u32 crc, u32 byte) {  // bitwise, reflected 0xEDB883
 
 FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
     InfBits b;
-    inf_start(b, a.comp + a.pay_off[g], a.pay_len[g]);
+    inf_start(b, a.comp + a.pay_off[g], a.pay_len[g], (u32*)(tab + INF_ENTRIES * INF_LANES), lane);
     u8* out = a.out + a.out_off[g];
     const u32 cap = a.isize[g];
     if (a.out_off[g] + cap > a.out_cap) return INF_E_ISIZE;
@@ -274,11 +303,12 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             if ((len ^ 0xFFFFu) != nlen) return INF_E_STORED;
             if (opos + len > cap) return INF_E_ISIZE;
             // the bit buffer holds whole bytes now: hand them back, then copy from the stream
-            const u32 at = b.pos - (u32)(b.cnt >> 3);
+            const u32 at = inf_pos(b);
             if (at + len > b.end) return INF_E_OVERRUN;
+            const u8* in = b.base + b.skew;
             u32 i = 0;
-            for (; i + 8 <= len; i += 8) inf_st8(out + opos + i, inf_ld8(b.in + at + i));
-            for (; i < len; i++) out[opos + i] = b.in[at + i];
+            for (; i + 8 <= len; i += 8) inf_st8(out + opos + i, inf_ld8(in + at + i));
+            for (; i < len; i++) out[opos + i] = in[at + i];
             opos += len;
             inf_seek(b, at + len);
             continue;
@@ -363,7 +393,7 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             inf_copy(out + opos, dist, len);
             opos += (u32)len;
         }
-        if (b.pos - (u32)(b.cnt >> 3) > b.end) return INF_E_OVERRUN;
+        if (inf_pos(b) > b.end) return INF_E_OVERRUN;
     } while (!last);
     if (opos != cap) return INF_E_ISIZE;
     if (a.check_crc) {
