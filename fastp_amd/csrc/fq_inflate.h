@@ -28,9 +28,16 @@ enum {
     INF_O_LSYM = 16,
     INF_O_DCNT = 16 + INF_MAXL,
     INF_O_DSYM = 32 + INF_MAXL,
-    INF_ENTRIES = 32 + INF_MAXL + INF_MAXD,
+    INF_CANON = 32 + INF_MAXL + INF_MAXD,
+    // direct-lookup tables over the next INF_LBITS / INF_DBITS stream bits: entry = symbol << 4 | code length
+    // (0 = the code is longer than the index: canonical walk)
+    INF_LBITS = 9,
+    INF_DBITS = 7,
+    INF_O_LFAST = INF_CANON,
+    INF_O_DFAST = INF_CANON + (1 << INF_LBITS),
+    INF_ENTRIES = INF_CANON + (1 << INF_LBITS) + (1 << INF_DBITS),
     INF_SCRATCH = 320,  // code lengths of a dynamic block (bytes per lane)
-    INF_SBUF = 64,      // dwords of compressed stream staged in LDS per lane
+    INF_SBUF = 32,      // dwords of compressed stream staged in LDS per lane
 };
 
 // status per block
@@ -178,6 +185,39 @@ FQ_DEV int inf_decode(InfBits& b, const InfCounts& c, u16* tab, int lane, int sy
         code <<= 1;
     }
     return -1;
+}
+
+// direct lookup with the canonical walk as the fallback for long codes
+FQ_DEV int inf_decode_fast(InfBits& b, const InfCounts& c, u16* tab, int lane, int fast_o, int fast_bits, int sym_o) {
+    inf_refill(b);
+    const u32 e = (u32)inf_t(tab, fast_o + (int)((u32)b.buf & ((1u << fast_bits) - 1u)), lane);
+    const int l = (int)(e & 15u);
+    if (l) {
+        b.buf >>= l;
+        b.cnt -= l;
+        return (int)(e >> 4);
+    }
+    return inf_decode(b, c, tab, lane, sym_o);
+}
+
+// fill the direct-lookup table of a constructed code: the stream delivers a code LSB first, so the entry index
+// is the bit-reversed code, repeated for every value of the index bits behind it
+FQ_DEV void inf_build_fast(u16* tab, int lane, int cnt_o, int sym_o, int fast_o, int fast_bits) {
+    const int size = 1 << fast_bits;
+    for (int e = 0; e < size; e++) inf_t(tab, fast_o + e, lane) = 0;
+    u32 code = 0;
+    int index = 0;
+    for (int l = 1; l <= fast_bits; l++) {
+        const int count = (int)inf_t(tab, cnt_o + l, lane);
+        for (int j = 0; j < count; j++) {
+            const u32 sym = (u32)inf_t(tab, sym_o + index + j, lane);
+            const u32 rev = __brev(code + (u32)j) >> (32 - l);
+            const u16 entry = (u16)((sym << 4) | (u32)l);
+            for (u32 k = rev; k < (u32)size; k += 1u << l) inf_t(tab, fast_o + (int)k, lane) = entry;
+        }
+        index += count;
+        code = (code + (u32)count) << 1;
+    }
 }
 
 // build count[] / symbol[] from n code lengths (read through `len_at`); returns false for an over-subscribed set
@@ -370,8 +410,10 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
         InfCounts lc, dc;
         inf_load_counts(lc, tab, lane, INF_O_LCNT);
         inf_load_counts(dc, tab, lane, INF_O_DCNT);
+        inf_build_fast(tab, lane, INF_O_LCNT, INF_O_LSYM, INF_O_LFAST, INF_LBITS);
+        inf_build_fast(tab, lane, INF_O_DCNT, INF_O_DSYM, INF_O_DFAST, INF_DBITS);
         for (;;) {
-            int sym = inf_decode(b, lc, tab, lane, INF_O_LSYM);
+            int sym = inf_decode_fast(b, lc, tab, lane, INF_O_LFAST, INF_LBITS, INF_O_LSYM);
             if (sym < 0) return INF_E_CODE;
             if (sym < 256) {
                 if (opos >= cap) return INF_E_ISIZE;
@@ -383,7 +425,7 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             int base, extra;
             inf_len_base(sym, base, extra);
             const int len = base + (int)inf_bits(b, extra);
-            const int ds = inf_decode(b, dc, tab, lane, INF_O_DSYM);
+            const int ds = inf_decode_fast(b, dc, tab, lane, INF_O_DFAST, INF_DBITS, INF_O_DSYM);
             if (ds < 0 || ds > 29) return INF_E_DIST;
             inf_dist_base(ds, base, extra);
             // up to 13 extra bits: within inf_bits' 16
