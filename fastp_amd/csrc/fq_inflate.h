@@ -18,6 +18,9 @@
 
 namespace fq {
 
+// rare paths stay out of line: the symbol loop has to fit the instruction cache
+#define FQ_COLD __device__ __attribute__((noinline))
+
 enum {
     INF_MAXBITS = 15,
     INF_MAXL = 288,   // literal/length codes
@@ -89,21 +92,25 @@ struct InfBits {
 struct InfQuad {  // four dwords at a dword-aligned (not 16-byte aligned) address
     u32 x, y, z, w;
 };
-FQ_DEV void inf_stage(InfBits& b) {  // fetch the next INF_SBUF dwords of the lane's stream into LDS
-    const InfQuad* src = (const InfQuad*)(b.base + 4 * (size_t)b.next_dw);
+// every argument by value: a state struct whose address escapes into a call would live in scratch memory
+FQ_COLD void inf_stage_at(const u8* base, u32 next_dw, u32 limit, u32* sbuf, int lane) {
+    const InfQuad* src = (const InfQuad*)(base + 4 * (size_t)next_dw);
     InfQuad v[INF_SBUF / 4];
 #pragma unroll
     for (int j = 0; j < INF_SBUF / 4; j++) {
         const InfQuad z = {0u, 0u, 0u, 0u};
-        v[j] = (b.next_dw + 4u * j < b.limit) ? src[j] : z;
+        v[j] = (next_dw + 4u * j < limit) ? src[j] : z;
     }
 #pragma unroll
     for (int j = 0; j < INF_SBUF / 4; j++) {
-        b.sbuf[(4 * j + 0) * INF_LANES + b.lane] = v[j].x;
-        b.sbuf[(4 * j + 1) * INF_LANES + b.lane] = v[j].y;
-        b.sbuf[(4 * j + 2) * INF_LANES + b.lane] = v[j].z;
-        b.sbuf[(4 * j + 3) * INF_LANES + b.lane] = v[j].w;
+        sbuf[(4 * j + 0) * INF_LANES + lane] = v[j].x;
+        sbuf[(4 * j + 1) * INF_LANES + lane] = v[j].y;
+        sbuf[(4 * j + 2) * INF_LANES + lane] = v[j].z;
+        sbuf[(4 * j + 3) * INF_LANES + lane] = v[j].w;
     }
+}
+FQ_DEV void inf_stage(InfBits& b) {  // fetch the next INF_SBUF dwords of the lane's stream into LDS
+    inf_stage_at(b.base, b.next_dw, b.limit, b.sbuf, b.lane);
     b.next_dw += INF_SBUF;
     b.rd = 0;
 }
@@ -164,27 +171,31 @@ FQ_DEV void inf_load_counts(InfCounts& c, u16* tab, int lane, int cnt_o) {
     for (int l = 1; l <= INF_MAXBITS; l++) c.r[(l - 1) / 3] |= (u32)inf_t(tab, cnt_o + l, lane) << (10 * ((l - 1) % 3));
 }
 
-// canonical Huffman decode (RFC 1951 3.2.2): symbols at sym_o[...] in code order; -1 on an invalid code
-FQ_DEV int inf_decode(InfBits& b, const InfCounts& c, u16* tab, int lane, int sym_o) {
-    inf_refill(b);
+// canonical Huffman decode (RFC 1951 3.2.2) of the code at the low end of `bits`: symbols at sym_o[...] in code
+// order; returns symbol | code length << 16, or -1 for an invalid code.  Out of line, everything by value.
+FQ_COLD int inf_walk(u32 bits, InfCounts c, u16* tab, int lane, int sym_o) {
     int code = 0, first = 0, index = 0;
-    u32 bits = (u32)b.buf;
 #pragma unroll
     for (int len = 1; len <= INF_MAXBITS; len++) {
         code |= (int)(bits & 1u);
         bits >>= 1;
         const int count = (int)((c.r[(len - 1) / 3] >> (10 * ((len - 1) % 3))) & 0x3FFu);
-        if (code - count < first) {
-            b.buf >>= len;
-            b.cnt -= len;
-            return (int)inf_t(tab, sym_o + index + (code - first), lane);
-        }
+        if (code - count < first) return (int)inf_t(tab, sym_o + index + (code - first), lane) | (len << 16);
         index += count;
         first += count;
         first <<= 1;
         code <<= 1;
     }
     return -1;
+}
+FQ_DEV int inf_decode(InfBits& b, const InfCounts& c, u16* tab, int lane, int sym_o) {
+    inf_refill(b);
+    const int r = inf_walk((u32)b.buf, c, tab, lane, sym_o);
+    if (r < 0) return -1;
+    const int len = r >> 16;
+    b.buf >>= len;
+    b.cnt -= len;
+    return r & 0xFFFF;
 }
 
 // direct lookup with the canonical walk as the fallback for long codes
@@ -202,7 +213,7 @@ FQ_DEV int inf_decode_fast(InfBits& b, const InfCounts& c, u16* tab, int lane, i
 
 // fill the direct-lookup table of a constructed code: the stream delivers a code LSB first, so the entry index
 // is the bit-reversed code, repeated for every value of the index bits behind it
-FQ_DEV void inf_build_fast(u16* tab, int lane, int cnt_o, int sym_o, int fast_o, int fast_bits) {
+FQ_COLD void inf_build_fast(u16* tab, int lane, int cnt_o, int sym_o, int fast_o, int fast_bits) {
     const int size = 1 << fast_bits;
     for (int e = 0; e < size; e++) inf_t(tab, fast_o + e, lane) = 0;
     u32 code = 0;
@@ -222,7 +233,7 @@ FQ_DEV void inf_build_fast(u16* tab, int lane, int cnt_o, int sym_o, int fast_o,
 
 // build count[] / symbol[] from n code lengths (read through `len_at`); returns false for an over-subscribed set
 template <class F>
-FQ_DEV bool inf_construct(u16* tab, int lane, int cnt_o, int sym_o, int n, F len_at, bool allow_incomplete) {
+FQ_COLD bool inf_construct(u16* tab, int lane, int cnt_o, int sym_o, int n, F len_at, bool allow_incomplete) {
     for (int l = 0; l <= INF_MAXBITS; l++) inf_t(tab, cnt_o + l, lane) = 0;
     for (int s = 0; s < n; s++) inf_t(tab, cnt_o + (int)len_at(s), lane)++;
     int left = 1;
@@ -372,7 +383,7 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
                 const int idx = i < 12 ? (int)((lo >> (5 * i)) & 31u) : (int)((hi >> (5 * (i - 12))) & 31u);
                 lens[idx] = (u8)inf_bits(b, 3);
             }
-            auto cl = [&](int s) -> u32 { return (u32)lens[s]; };
+            auto cl = [=](int s) -> u32 { return (u32)lens[s]; };
             if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, 19, cl, false)) return INF_E_TABLE;
             InfCounts cc;
             inf_load_counts(cc, tab, lane, INF_O_LCNT);
@@ -401,9 +412,9 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             // the distance lengths first (they sit behind the literal/length ones in the scratch row and the
             // literal/length table is about to be overwritten by its own construction - it is the same LDS rows
             // the code-length code used)
-            auto dl = [&](int s) -> u32 { return (u32)lens[nlen + s]; };
+            auto dl = [=](int s) -> u32 { return (u32)lens[nlen + s]; };
             if (!inf_construct(tab, lane, INF_O_DCNT, INF_O_DSYM, ndist, dl, true)) return INF_E_TABLE;
-            auto ll = [&](int s) -> u32 { return (u32)lens[s]; };
+            auto ll = [=](int s) -> u32 { return (u32)lens[s]; };
             if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, nlen, ll, true)) return INF_E_TABLE;
         }
         // ---- the symbols of this block ----
