@@ -8,9 +8,12 @@
 // what the same lane wrote), and a text chunk holds thousands of blocks, so the machine fills with
 // lanes rather than with cooperating wavefronts.
 //
-// Per-lane canonical Huffman tables (count per code length + symbols in code order, the textbook
-// decoder of RFC 1951 3.2.2) live in LDS, interleaved by lane ([entry][lane], so that the lanes of a
-// wave reading the same entry hit consecutive halfwords).  The code lengths of a dynamic block pass
+// Per-lane canonical Huffman tables (symbols in code order, the textbook decoder of RFC 1951 3.2.2; the
+// per-length code counts sit in registers) live in LDS, interleaved by lane ([entry][lane], so that the
+// bank of an access depends on the lane only).  51 KB of LDS per wavefront-workgroup: three of them per CU.
+// Direct-lookup tables were tried and removed: a lane's speed is set by the dependent-instruction latency of a
+// single wavefront per SIMD, not by the decoder's instruction count, and their LDS footprint (one workgroup
+// per CU) halved the number of blocks in flight.  The code lengths of a dynamic block pass
 // through a per-lane global scratch row.
 #pragma once
 #include "fq_intrin.h"
@@ -26,19 +29,11 @@ enum {
     INF_MAXL = 288,   // literal/length codes
     INF_MAXD = 32,    // distance codes (30 used)
     INF_LANES = 64,   // workgroup = one wavefront
-    // per-lane table entries (u16 each): lencnt[16] | lensym[288] | distcnt[16] | distsym[32]
-    INF_O_LCNT = 0,
+    // per-lane table entries (u16 each): cnt[16] (construction scratch, then held in registers) | lensym[288] | distsym[32]
+    INF_O_CNT = 0,
     INF_O_LSYM = 16,
-    INF_O_DCNT = 16 + INF_MAXL,
-    INF_O_DSYM = 32 + INF_MAXL,
-    INF_CANON = 32 + INF_MAXL + INF_MAXD,
-    // direct-lookup tables over the next INF_LBITS / INF_DBITS stream bits: entry = symbol << 4 | code length
-    // (0 = the code is longer than the index: canonical walk)
-    INF_LBITS = 9,
-    INF_DBITS = 7,
-    INF_O_LFAST = INF_CANON,
-    INF_O_DFAST = INF_CANON + (1 << INF_LBITS),
-    INF_ENTRIES = INF_CANON + (1 << INF_LBITS) + (1 << INF_DBITS),
+    INF_O_DSYM = 16 + INF_MAXL,
+    INF_ENTRIES = 16 + INF_MAXL + INF_MAXD,
     INF_SCRATCH = 320,  // code lengths of a dynamic block (bytes per lane)
     INF_SBUF = 32,      // dwords of compressed stream staged in LDS per lane
 };
@@ -93,7 +88,7 @@ struct InfQuad {  // four dwords at a dword-aligned (not 16-byte aligned) addres
     u32 x, y, z, w;
 };
 // every argument by value: a state struct whose address escapes into a call would live in scratch memory
-FQ_COLD void inf_stage_at(const u8* base, u32 next_dw, u32 limit, u32* sbuf, int lane) {
+FQ_DEV void inf_stage_at(const u8* base, u32 next_dw, u32 limit, u32* sbuf, int lane) {
     const InfQuad* src = (const InfQuad*)(base + 4 * (size_t)next_dw);
     InfQuad v[INF_SBUF / 4];
 #pragma unroll
@@ -173,7 +168,7 @@ FQ_DEV void inf_load_counts(InfCounts& c, u16* tab, int lane, int cnt_o) {
 
 // canonical Huffman decode (RFC 1951 3.2.2) of the code at the low end of `bits`: symbols at sym_o[...] in code
 // order; returns symbol | code length << 16, or -1 for an invalid code.  Out of line, everything by value.
-FQ_COLD int inf_walk(u32 bits, InfCounts c, u16* tab, int lane, int sym_o) {
+FQ_DEV int inf_walk(u32 bits, InfCounts c, u16* tab, int lane, int sym_o) {
     int code = 0, first = 0, index = 0;
 #pragma unroll
     for (int len = 1; len <= INF_MAXBITS; len++) {
@@ -196,39 +191,6 @@ FQ_DEV int inf_decode(InfBits& b, const InfCounts& c, u16* tab, int lane, int sy
     b.buf >>= len;
     b.cnt -= len;
     return r & 0xFFFF;
-}
-
-// direct lookup with the canonical walk as the fallback for long codes
-FQ_DEV int inf_decode_fast(InfBits& b, const InfCounts& c, u16* tab, int lane, int fast_o, int fast_bits, int sym_o) {
-    inf_refill(b);
-    const u32 e = (u32)inf_t(tab, fast_o + (int)((u32)b.buf & ((1u << fast_bits) - 1u)), lane);
-    const int l = (int)(e & 15u);
-    if (l) {
-        b.buf >>= l;
-        b.cnt -= l;
-        return (int)(e >> 4);
-    }
-    return inf_decode(b, c, tab, lane, sym_o);
-}
-
-// fill the direct-lookup table of a constructed code: the stream delivers a code LSB first, so the entry index
-// is the bit-reversed code, repeated for every value of the index bits behind it
-FQ_COLD void inf_build_fast(u16* tab, int lane, int cnt_o, int sym_o, int fast_o, int fast_bits) {
-    const int size = 1 << fast_bits;
-    for (int e = 0; e < size; e++) inf_t(tab, fast_o + e, lane) = 0;
-    u32 code = 0;
-    int index = 0;
-    for (int l = 1; l <= fast_bits; l++) {
-        const int count = (int)inf_t(tab, cnt_o + l, lane);
-        for (int j = 0; j < count; j++) {
-            const u32 sym = (u32)inf_t(tab, sym_o + index + j, lane);
-            const u32 rev = __brev(code + (u32)j) >> (32 - l);
-            const u16 entry = (u16)((sym << 4) | (u32)l);
-            for (u32 k = rev; k < (u32)size; k += 1u << l) inf_t(tab, fast_o + (int)k, lane) = entry;
-        }
-        index += count;
-        code = (code + (u32)count) << 1;
-    }
 }
 
 // build count[] / symbol[] from n code lengths (read through `len_at`); returns false for an over-subscribed set
@@ -365,11 +327,14 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             continue;
         }
         if (type == 3) return INF_E_BTYPE;
+        InfCounts lc, dc;
         if (type == 1) {  // fixed codes (3.2.6)
-            auto ll = [](int s) -> u32 { return s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u; };
-            inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, 288, ll, false);
             auto dl = [](int) -> u32 { return 5u; };
-            inf_construct(tab, lane, INF_O_DCNT, INF_O_DSYM, 30, dl, true);
+            inf_construct(tab, lane, INF_O_CNT, INF_O_DSYM, 30, dl, true);
+            inf_load_counts(dc, tab, lane, INF_O_CNT);
+            auto ll = [](int s) -> u32 { return s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u; };
+            inf_construct(tab, lane, INF_O_CNT, INF_O_LSYM, 288, ll, false);
+            inf_load_counts(lc, tab, lane, INF_O_CNT);
         } else {  // dynamic codes (3.2.7)
             const int nlen = (int)inf_bits(b, 5) + 257;
             const int ndist = (int)inf_bits(b, 5) + 1;
@@ -384,9 +349,9 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
                 lens[idx] = (u8)inf_bits(b, 3);
             }
             auto cl = [=](int s) -> u32 { return (u32)lens[s]; };
-            if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, 19, cl, false)) return INF_E_TABLE;
+            if (!inf_construct(tab, lane, INF_O_CNT, INF_O_LSYM, 19, cl, false)) return INF_E_TABLE;
             InfCounts cc;
-            inf_load_counts(cc, tab, lane, INF_O_LCNT);
+            inf_load_counts(cc, tab, lane, INF_O_CNT);
             int idx = 0;
             while (idx < nlen + ndist) {
                 int sym = inf_decode(b, cc, tab, lane, INF_O_LSYM);
@@ -409,22 +374,17 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
                 }
             }
             if (lens[256] == 0) return INF_E_TABLE;  // no end-of-block code
-            // the distance lengths first (they sit behind the literal/length ones in the scratch row and the
-            // literal/length table is about to be overwritten by its own construction - it is the same LDS rows
-            // the code-length code used)
+            // the count rows are shared construction scratch: each code's counts move to registers before the next is built
             auto dl = [=](int s) -> u32 { return (u32)lens[nlen + s]; };
-            if (!inf_construct(tab, lane, INF_O_DCNT, INF_O_DSYM, ndist, dl, true)) return INF_E_TABLE;
+            if (!inf_construct(tab, lane, INF_O_CNT, INF_O_DSYM, ndist, dl, true)) return INF_E_TABLE;
+            inf_load_counts(dc, tab, lane, INF_O_CNT);
             auto ll = [=](int s) -> u32 { return (u32)lens[s]; };
-            if (!inf_construct(tab, lane, INF_O_LCNT, INF_O_LSYM, nlen, ll, true)) return INF_E_TABLE;
+            if (!inf_construct(tab, lane, INF_O_CNT, INF_O_LSYM, nlen, ll, true)) return INF_E_TABLE;
+            inf_load_counts(lc, tab, lane, INF_O_CNT);
         }
         // ---- the symbols of this block ----
-        InfCounts lc, dc;
-        inf_load_counts(lc, tab, lane, INF_O_LCNT);
-        inf_load_counts(dc, tab, lane, INF_O_DCNT);
-        inf_build_fast(tab, lane, INF_O_LCNT, INF_O_LSYM, INF_O_LFAST, INF_LBITS);
-        inf_build_fast(tab, lane, INF_O_DCNT, INF_O_DSYM, INF_O_DFAST, INF_DBITS);
         for (;;) {
-            int sym = inf_decode_fast(b, lc, tab, lane, INF_O_LFAST, INF_LBITS, INF_O_LSYM);
+            int sym = inf_decode(b, lc, tab, lane, INF_O_LSYM);
             if (sym < 0) return INF_E_CODE;
             if (sym < 256) {
                 if (opos >= cap) return INF_E_ISIZE;
@@ -436,7 +396,7 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             int base, extra;
             inf_len_base(sym, base, extra);
             const int len = base + (int)inf_bits(b, extra);
-            const int ds = inf_decode_fast(b, dc, tab, lane, INF_O_DFAST, INF_DBITS, INF_O_DSYM);
+            const int ds = inf_decode(b, dc, tab, lane, INF_O_DSYM);
             if (ds < 0 || ds > 29) return INF_E_DIST;
             inf_dist_base(ds, base, extra);
             // up to 13 extra bits: within inf_bits' 16
