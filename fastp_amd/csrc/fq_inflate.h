@@ -195,7 +195,7 @@ FQ_DEV int inf_decode(InfBits& b, const InfCounts& c, u16* tab, int lane, int sy
 
 // build count[] / symbol[] from n code lengths (read through `len_at`); returns false for an over-subscribed set
 template <class F>
-FQ_COLD bool inf_construct(u16* tab, int lane, int cnt_o, int sym_o, int n, F len_at, bool allow_incomplete) {
+FQ_DEV bool inf_construct(u16* tab, int lane, int cnt_o, int sym_o, int n, F len_at, bool allow_incomplete) {
     for (int l = 0; l <= INF_MAXBITS; l++) inf_t(tab, cnt_o + l, lane) = 0;
     for (int s = 0; s < n; s++) inf_t(tab, cnt_o + (int)len_at(s), lane)++;
     int left = 1;
