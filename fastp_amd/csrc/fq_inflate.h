@@ -383,13 +383,29 @@ FQ_DEV u32 inflate_block(const InflateArgs& a, u16* tab, int lane, int g) {
             inf_load_counts(lc, tab, lane, INF_O_CNT);
         }
         // ---- the symbols of this block ----
+        // literals collect in a register and leave eight at a time (one store instead of eight); they are flushed
+        // before anything that reads or orders against them: a match, the end of the block
+        u64 lit = 0;
+        int nlit = 0;
         for (;;) {
             int sym = inf_decode(b, lc, tab, lane, INF_O_LSYM);
             if (sym < 0) return INF_E_CODE;
             if (sym < 256) {
                 if (opos >= cap) return INF_E_ISIZE;
-                out[opos++] = (u8)sym;
+                lit |= (u64)(u32)sym << (8 * nlit);
+                nlit++;
+                opos++;
+                if (nlit == 8) {
+                    inf_st8(out + opos - 8, lit);
+                    lit = 0;
+                    nlit = 0;
+                }
                 continue;
+            }
+            if (nlit) {
+                inf_st_tail(out + opos - (u32)nlit, lit, nlit);
+                lit = 0;
+                nlit = 0;
             }
             if (sym == 256) break;
             if (sym > 285) return INF_E_CODE;

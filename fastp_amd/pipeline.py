@@ -30,12 +30,10 @@ class PipelineError(RuntimeError):
 class _Mate:
     """per-mate buffers of one in-flight chunk"""
 
-    def __init__(self, torch, dev, chunk_bytes, max_records, max_len):
+    def __init__(self, torch, dev, text, max_records, max_len):
         ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
-        self.cap = 2 * chunk_bytes + 64          # [text carried from the previous chunk | this chunk's text]
-        self.text = torch.zeros(self.cap, dtype=torch.uint8, device=dev)
-        self.comp = None                          # BGZF input: the compressed chunk + its block index on the device
-        self.idx = None
+        self.cap = text.numel()                   # [text carried from the previous chunk | this chunk's text]
+        self.text = text
         self.seq = torch.empty(max_records * ss, dtype=torch.uint8, device=dev)
         self.qual = torch.empty(max_records * qs, dtype=torch.uint8, device=dev)
         self.lens = torch.empty(max_records, dtype=torch.int16, device=dev)
@@ -57,7 +55,15 @@ class FastqPipeline:
         self.chunk = int(chunk_bytes)
         self.max_records = int(max_records or max(1024, (2 * self.chunk) // 48))
         nm = 2 if self.paired else 1
-        self.mates = [_Mate(torch, self.dev, self.chunk, self.max_records, params.max_len) for _ in range(nm)]
+        # one allocation for both mates' text (and, for BGZF input, one for their compressed chunks): a single
+        # inflate launch then covers the blocks of both files
+        self.text_cap = (2 * self.chunk + 64 + 255) // 256 * 256
+        self.text_all = torch.zeros(nm * self.text_cap, dtype=torch.uint8, device=self.dev)
+        self.comp_cap = (self.chunk + 64 + 255) // 256 * 256
+        self.comp_all = None
+        self.idx_all = None
+        self.mates = [_Mate(torch, self.dev, self.text_all[m * self.text_cap:(m + 1) * self.text_cap], self.max_records,
+                            params.max_len) for m in range(nm)]
         self.pair = torch.zeros(self.max_records * 8, dtype=torch.uint8, device=self.dev)
         self.corr_cap = corr_capacity if params.correction else 0
         self.corr = torch.zeros(max(1, self.corr_cap) * 8, dtype=torch.uint8, device=self.dev)
@@ -163,32 +169,47 @@ class FastqPipeline:
         return (len(h) == 18 and h[0] == 0x1f and h[1] == 0x8b and h[2] == 8 and (h[3] & 4) and h[12] == 0x42 and h[13] == 0x43
                 and (h[14] | (h[15] << 8)) == 2)
 
-    def _inflate_into(self, m, slot, nb, tcarry, eof_file):
-        """BGZF bytes in the staging buffer -> text on the device behind the carried text.  Returns (text bytes
-        added, compressed bytes consumed)."""
+    def _inflate_all(self, slot, fills, tcarry, gz):
+        """BGZF bytes in the staging buffers -> text on the device behind each mate's carried text, ONE launch for
+        the blocks of all compressed mates.  Returns per mate (text bytes added, compressed bytes consumed)."""
         torch = self.torch
-        M = self.mates[m]
-        host = self.stage_in[slot][m].numpy()[:nb]
-        if M.comp is None:
-            M.comp = torch.zeros(self.chunk + 64, dtype=torch.uint8, device=self.dev)
-            M.idx = torch.zeros(self.max_blocks * 24 + 64, dtype=torch.uint8, device=self.dev)
-        room = M.cap - 64 - tcarry
-        info, poff, plen, isz, crc, ooff = self.eng.bgzf_index(host, self.max_blocks, room)
-        nblk, used = int(info.n_blocks), int(info.consumed)
-        if nblk == 0:
-            if eof_file and nb > 0:
-                raise PipelineError(f"truncated BGZF member at the end of mate {m + 1}'s file")
-            return 0, 0
-        M.comp[:used].copy_(self.stage_in[slot][m][:used], non_blocking=True)
-        M.comp[used:used + 32].zero_()
-        packed = np.concatenate([a.view(np.uint8) for a in (poff, plen, isz, crc, ooff)])   # 4+4+4+4+8 bytes per block
-        M.idx[:packed.size].copy_(torch.from_numpy(packed), non_blocking=False)
-        base = M.idx.data_ptr()
-        o = [0, 4 * nblk, 8 * nblk, 12 * nblk, 16 * nblk]
+        nm = len(self.mates)
+        if self.comp_all is None:
+            self.comp_all = torch.zeros(nm * self.comp_cap, dtype=torch.uint8, device=self.dev)
+            self.idx_all = torch.zeros(nm * self.max_blocks * 24 + 64, dtype=torch.uint8, device=self.dev)
+        res = [(0, 0)] * nm
+        parts = [[] for _ in range(5)]
+        for m in range(nm):
+            if not gz[m]:
+                continue
+            nb, eof_file = fills[m]
+            host = self.stage_in[slot][m].numpy()[:nb]
+            room = self.mates[m].cap - 64 - tcarry[m]
+            info, poff, plen, isz, crc, ooff = self.eng.bgzf_index(host, self.max_blocks, room)
+            nblk, used = int(info.n_blocks), int(info.consumed)
+            if nblk == 0:
+                if eof_file and nb > 0:
+                    raise PipelineError(f"truncated BGZF member at the end of mate {m + 1}'s file")
+                continue
+            c0 = m * self.comp_cap
+            self.comp_all[c0:c0 + used].copy_(self.stage_in[slot][m][:used], non_blocking=True)
+            self.comp_all[c0 + used:c0 + used + 32].zero_()
+            parts[0].append(poff + np.uint32(c0))
+            parts[1].append(plen)
+            parts[2].append(isz)
+            parts[3].append(crc)
+            parts[4].append(ooff + np.uint64(m * self.text_cap + tcarry[m]))
+            res[m] = (int(info.out_bytes), used)
+        n = sum(len(a) for a in parts[0])
+        if n == 0:
+            return res
+        packed = np.concatenate([np.concatenate(p).view(np.uint8) for p in parts])   # 4+4+4+4+8 bytes per block
+        self.idx_all[:packed.size].copy_(torch.from_numpy(packed), non_blocking=False)
+        base = self.idx_all.data_ptr()
         torch.cuda.synchronize(self.dev)
-        self.eng.inflate_bgzf(M.comp.data_ptr(), nblk, base + o[0], base + o[1], base + o[2], base + o[3], base + o[4],
-                              M.text.data_ptr() + tcarry, int(info.out_bytes), self.check_crc)
-        return int(info.out_bytes), used
+        self.eng.inflate_bgzf(self.comp_all.data_ptr(), n, base, base + 4 * n, base + 8 * n, base + 12 * n, base + 16 * n,
+                              self.text_all.data_ptr(), self.text_all.numel(), self.check_crc)
+        return res
 
     def run(self, in1: str, in2: str | None, out1: str, out2: str | None) -> dict:
         torch = self.torch
@@ -229,13 +250,15 @@ class FastqPipeline:
                 st["t_wait_read"] += time.perf_counter() - t0
                 st["bytes_in"] += sum(f[0] for f in fills)
                 total, fcarry, eof = [0] * nm, [b""] * nm, [False] * nm
+                if any(gz):
+                    t0 = time.perf_counter()
+                    inflated = self._inflate_all(slot, fills, tcarry, gz)
+                    st["t_inflate"] += time.perf_counter() - t0
                 for m in range(nm):
                     nb, eof_file = fills[m]
                     M = self.mates[m]
                     if gz[m]:
-                        t0 = time.perf_counter()
-                        added, used = self._inflate_into(m, slot, nb, tcarry[m], eof_file)
-                        st["t_inflate"] += time.perf_counter() - t0
+                        added, used = inflated[m]
                         if nb > used:
                             fcarry[m] = bytes(memoryview(self.stage_in[slot][m].numpy())[used:nb])
                         if added == 0 and not eof_file and len(fcarry[m]) >= want[m]:
