@@ -501,7 +501,7 @@ def test_gpu_bgzf_inflate_equals_zlib(level, strategy):
     import format_util
     import test_hostsim_parity as hs
     strat = {"default": zlib.Z_DEFAULT_STRATEGY, "fixed": zlib.Z_FIXED}[strategy]
-    text = hs._fastq_text(30000, 8)
+    text = hs._se_fastq_text(30000, 8)
     comp = bgzf_util.compress(text, level=level, strategy=strat)
     g = engines.gpu_engine(abi.default_params(False, 150))
     info, rc, bad, got = hs._inflate(g, format_util.TorchMem(), comp)

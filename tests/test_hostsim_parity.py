@@ -302,7 +302,7 @@ def _inflate(eng, mem, comp: bytes, check_crc=True, max_blocks=100000, check=Tru
     return info, rc, bad, mem.download(out, int(info.out_bytes))
 
 
-def _fastq_text(n, seed):
+def _se_fastq_text(n, seed):
     d = synth.synth_pairs(n, L=150, seed=seed, paired=False)
     return synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
 
@@ -315,7 +315,7 @@ def test_sim_bgzf_inflate_equals_zlib(level, strategy):
     import bgzf_util
     import format_util
     strat = {"default": zlib.Z_DEFAULT_STRATEGY, "fixed": zlib.Z_FIXED, "huffman": zlib.Z_HUFFMAN_ONLY, "rle": zlib.Z_RLE}[strategy]
-    text = _fastq_text(700, 3)
+    text = _se_fastq_text(700, 3)
     comp = bgzf_util.compress(text, block_bytes=20000, level=level, strategy=strat)
     g = engines.sim_engine(abi.default_params(False, 150))
     info, rc, bad, got = _inflate(g, format_util.NumpyMem(), comp)
@@ -327,7 +327,7 @@ def test_sim_bgzf_inflate_equals_zlib(level, strategy):
 def test_sim_bgzf_index_chunks_and_errors():
     import bgzf_util
     import format_util
-    text = _fastq_text(300, 4) + bytes(range(256)) * 40 + b"A" * 70000   # binary bytes, a long run (distance 1 copies)
+    text = _se_fastq_text(300, 4) + bytes(range(256)) * 40 + b"A" * 70000   # binary bytes, a long run (distance 1 copies)
     comp = bgzf_util.compress(text, block_bytes=0xff00)
     g = engines.sim_engine(abi.default_params(False, 150))
     mem = format_util.NumpyMem()
