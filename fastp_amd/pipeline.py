@@ -14,6 +14,7 @@ so file I/O overlaps the device work of the neighbouring chunks.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import queue
 import threading
 import time
@@ -84,7 +85,7 @@ class FastqPipeline:
         self.eng.close()
 
     # -- reader thread: (leftover of the previous chunk | fresh bytes) into a pinned staging buffer ------------
-    IO_THREADS = 8        # positional reads / writes in flight per direction (memcpy-bound on tmpfs / page cache)
+    IO_THREADS = int(os.environ.get("FASTP_PIPELINE_IO_THREADS", "8"))   # positional reads / writes in flight per direction
     IO_PIECE = 32 << 20
 
     def _reader(self, files, q_free, q_full, tails):
