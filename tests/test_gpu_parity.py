@@ -131,6 +131,23 @@ def test_gpu_read_lengths(L):
     _compare(f"L{L}", p, d, True)
 
 
+def test_gpu_config5_shape_2x250_dedup_overrep():
+    """BASELINE configs[4]'s option set on one GPU: PE 2x250, --dedup (accuracy level 3: four bloom buffers) and the
+    overrepresentation analysis, against the oracle"""
+    from fastp_amd import hostloop
+    L = 250
+    p = abi.default_params(True, L)
+    p.cut_right = 1
+    p.dedup = 1
+    p.dup_accuracy_level = 3
+    d = synth.synth_pairs(12000, L=L, seed=77, insert_mean=260.0, insert_sd=90.0, insert_min=30, insert_max=900,
+                          dup_frac=0.25, polyx_frac=0.2)
+    b1, b2 = cases._ArrayBatch(d["seq1"], d["len1"]), cases._ArrayBatch(d["seq2"], d["len2"])
+    e1, e2 = hostloop.evaluate_seq_len(b1), hostloop.evaluate_seq_len(b2)
+    abi.set_overrep(p, hostloop.evaluate_overrep_seqs(b1, e1), hostloop.evaluate_overrep_seqs(b2, e2), e1, e2, 5)
+    _compare("config5", p, d, True)
+
+
 def test_gpu_edge_batches():
     p = abi.default_params(True, 150)
     p.cut_tail = 1

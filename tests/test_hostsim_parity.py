@@ -359,3 +359,21 @@ def test_sim_bgzf_index_chunks_and_errors():
     _, rc, bad, got = _inflate(g, mem, bytes(bad_comp), check_crc=False)
     assert rc == 0 and got == text
     g.close()
+
+
+def test_sim_config5_shape_2x250_dedup_overrep():
+    """BASELINE configs[4]'s option set: PE 2x250, --dedup at accuracy level 3 (four bloom buffers), overrepresentation"""
+    L = 250
+    p = abi.default_params(True, L)
+    p.cut_right = 1
+    p.dedup = 1
+    p.dup_accuracy_level = 3
+    d = synth.synth_pairs(600, L=L, seed=77, insert_mean=260.0, insert_sd=90.0, insert_min=30, insert_max=900,
+                          dup_frac=0.25, polyx_frac=0.2)
+    b1, b2 = cases._ArrayBatch(d["seq1"], d["len1"]), cases._ArrayBatch(d["seq2"], d["len2"])
+    e1, e2 = hostloop.evaluate_seq_len(b1), hostloop.evaluate_seq_len(b2)
+    abi.set_overrep(p, hostloop.evaluate_overrep_seqs(b1, e1), hostloop.evaluate_overrep_seqs(b2, e2), e1, e2, 5)
+    ro, rg, co, cg = _both(p, d, True)
+    for k in range(3):
+        assert np.array_equal(ro[k], rg[k])
+    assert np.array_equal(co, cg)
