@@ -38,6 +38,7 @@ extern "C" __global__ void __launch_bounds__(256) fq_ovr_tasks_kernel(OvrArgs o)
     ovr_tasks_body(o, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_ovr_count_kernel(OvrArgs o) { ovr_count_body(o); }
+extern "C" __global__ void __launch_bounds__(256) fq_ovr_corr_link_kernel(OvrArgs o) { ovr_corr_link_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_parse_count_kernel(ParseArgs p) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     parse_count_body(p, fq_lds);
@@ -125,6 +126,7 @@ struct fastp_gpu_ctx {
     int* d_ovr_len[2] = {nullptr, nullptr};
     u64* d_post_seen = nullptr;
     u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
+    u32* d_ovr_corr = nullptr; size_t ovr_corr_cap = 0;   // correction chains: head[reads] | next[capacity]
     u32* d_parse = nullptr; size_t parse_cap = 0;         // FASTQ parse scratch
     u64* d_fmt = nullptr; size_t fmt_cap = 0;             // FASTQ format scratch
     u8* d_inf = nullptr; size_t inf_cap = 0;              // inflate scratch: code lengths | status | first_bad
@@ -189,7 +191,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -389,6 +391,22 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         }
         o.ctr = ctx->d_ctr;
         for (int k = 0; k < 4; k++) { o.o_count[k] = cl.overrep_count[k]; o.o_dist[k] = cl.overrep_dist[k]; }
+        if (ctx->dp.correction && !(a.corrections && a.corr_capacity > 0))
+            return fail(ctx, FASTP_GPU_E_INVALID, "overrepresentation analysis with correction needs the correction list in the results");
+        if (a.corrections && a.corr_capacity > 0) {  // the post-filtering Stats analyse the corrected reads
+            const size_t reads = (size_t)(ctx->dp.paired ? 2 : 1) * n;
+            rc = ensure(ctx, (void**)&ctx->d_ovr_corr, &ctx->ovr_corr_cap, (reads + (size_t)a.corr_capacity) * 4);
+            if (rc) return rc;
+            o.corr = a.corrections;
+            o.n_corr = a.n_corrections;
+            o.corr_cap = a.corr_capacity;
+            o.first = a.first;
+            o.corr_head = ctx->d_ovr_corr;
+            o.corr_next = ctx->d_ovr_corr + reads;
+            HIP_TRY(ctx, hipMemsetAsync(o.corr_head, 0, reads * 4, st));
+            hipLaunchKernelGGL(fq_ovr_corr_link_kernel, dim3((a.corr_capacity + 255) / 256), dim3(256), 0, st, o);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         HIP_TRY(ctx, hipMemsetAsync(o.n_tasks, 0, 4, st));
         hipLaunchKernelGGL(fq_ovr_pass_kernel, dim3(nb), dim3(256), 16, st, o);
         HIP_TRY(ctx, hipGetLastError());

@@ -2269,6 +2269,31 @@ FQ_DEV u32 ovr_sym(const u32* srow, const u8* qrow, int j) {  // 0..3 = A,T,C,G 
     return (qrow[j] & 0x80u) ? 4u : ((srow[j >> 4] >> ((j & 15) * 2)) & 3u);
 }
 
+// thread the correction entries that belong to this launch's reads into per-read chains
+FQ_DEV void ovr_corr_link_body(const OvrArgs& o) {
+    const int e = block_id() * block_threads() + thread_id();
+    const int ne = (int)imin(*o.n_corr, o.corr_cap);
+    if (e >= ne) return;
+    const u32 read = o.corr[2 * (size_t)e];          // pair * 2 + mate (PE) / read (SE), from the batch start
+    const int unit = (int)(o.paired ? read >> 1 : read) - o.first;
+    if (unit < 0 || unit >= o.n) return;
+    const u32 key = o.paired ? (u32)unit * 2u + (read & 1u) : (u32)unit;
+    o.corr_next[e] = g_atomic_exch_u32(&o.corr_head[key], (u32)e + 1u);
+}
+
+// symbol j of a read as the post-filtering Stats see it: BaseCorrector's edits applied (basecorrector.cpp:45-63)
+FQ_DEV u32 ovr_sym_corrected(const OvrArgs& o, const u32* srow, const u8* qrow, int j, u32 head) {
+    u32 s = ovr_sym(srow, qrow, j);
+    for (u32 e = head; e; e = o.corr_next[e - 1]) {
+        const u32 w1 = o.corr[2 * (size_t)(e - 1) + 1];  // u16 pos | u8 base | u8 qual
+        if ((int)(w1 & 0xFFFFu) == j) {
+            const u32 b = (w1 >> 16) & 0xFFu;            // ASCII; engine code order A0 T1 C2 G3
+            s = b == 'A' ? 0u : b == 'T' ? 1u : b == 'C' ? 2u : b == 'G' ? 3u : 4u;
+        }
+    }
+    return s;
+}
+
 FQ_DEV void ovr_count_body(const OvrArgs& o) {
     const int t = block_id() * block_threads() + thread_id();
     const int nt = (int)imin((int)*o.n_tasks, o.task_cap);
@@ -2285,6 +2310,9 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
     }
     const u32* srow = o.seq[mt] + (size_t)g * o.sw_g;
     const u8* qrow = (const u8*)(o.qual[mt] + (size_t)g * o.qw_g);
+    // the pre-filtering Stats saw the read before BaseCorrector touched it (peprocessor.cpp:419-432 vs :447-460)
+    const u32 chain = (post && o.corr) ? o.corr_head[o.paired ? (u32)g * 2u + (u32)mt : (u32)g] : 0u;
+#define OVR_SYM(j) (chain ? ovr_sym_corrected(o, srow, qrow, (j), chain) : ovr_sym(srow, qrow, (j)))
     const int slot = mt * 2 + post;  // PRE1=0 POST1=1 PRE2=2 POST2=3
     int64_t* cnt = o.ctr + o.o_count[slot];
     int64_t* dist = o.ctr + o.o_dist[slot];
@@ -2298,7 +2326,7 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
         while (i < len - L) {  // for (i = 0; i < len - step; i++) (:276)
             if (fresh) {
                 h = 0;
-                for (int k = 0; k < L; k++) h = h * OVR_HASH_MUL + ovr_sym(srow, qrow, f + i + k) + 1u;
+                for (int k = 0; k < L; k++) h = h * OVR_HASH_MUL + OVR_SYM(f + i + k) + 1u;
                 fresh = false;
             }
             const u32 key = h ^ salt;
@@ -2309,7 +2337,7 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
                 if (M.table[2 * sl] == key && M.seed_len[id1 - 1] == L) {
                     const u8* sd = M.seed_sym + (size_t)(id1 - 1) * OVR_SEED_STRIDE;
                     bool same = true;
-                    for (int k = 0; k < L && same; k++) same = sd[k] == (u8)ovr_sym(srow, qrow, f + i + k);
+                    for (int k = 0; k < L && same; k++) same = sd[k] == (u8)OVR_SYM(f + i + k);
                     if (same) { hit = (int)id1 - 1; break; }
                 }
             }
@@ -2319,12 +2347,13 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
                 i += L + 1;
                 fresh = true;
             } else {  // slide the window by one base
-                h = (h - (ovr_sym(srow, qrow, f + i) + 1u) * pw) * OVR_HASH_MUL + ovr_sym(srow, qrow, f + i + L) + 1u;
+                h = (h - (OVR_SYM(f + i) + 1u) * pw) * OVR_HASH_MUL + OVR_SYM(f + i + L) + 1u;
                 i++;
             }
         }
     }
 }
+#undef OVR_SYM
 
 
 // ---------------------------------------------------------------------------

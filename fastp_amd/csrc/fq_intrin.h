@@ -80,6 +80,9 @@ FQ_DEV int g_atomic_add_i32(int* p, int v) {
 FQ_DEV u32 g_atomic_add_u32(u32* p, u32 v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+FQ_DEV u32 g_atomic_exch_u32(u32* p, u32 v) {
+    return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 FQ_DEV u32 g_atomic_min_u32(u32* p, u32 v) {
     return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

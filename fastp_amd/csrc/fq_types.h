@@ -187,6 +187,14 @@ struct OvrArgs {
     OvrMate mate[2];
     int64_t* ctr;
     int64_t o_count[4], o_dist[4];   // fastp_gpu_counter_layout::overrep_count / overrep_dist
+    // --correction: the post-filtering Stats see the corrected bases.  The batch's correction list is threaded
+    // into one chain per read (corr_head[read key] -> entry index + 1, corr_next[entry]) before the counting.
+    const u32* corr;             // fastp_gpu_correction entries, 2 dwords each (nullptr: no correction)
+    const int32_t* n_corr;
+    int corr_cap;
+    int first;                   // index of this launch's first unit inside the batch (the entries' read field counts from the batch start)
+    u32* corr_head;              // [(paired ? 2 : 1) * n]
+    u32* corr_next;              // [corr_cap]
 };
 
 // ---- FASTQ text -> packed rows on the device (fq_parse_* kernels) ----

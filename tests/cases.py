@@ -100,8 +100,10 @@ CASES["se_adapter_fasta"] = (False, ["-G", "-a", ADAPTER_R1, "--adapter_fasta", 
 CASES["pe_overrep"] = (True, ["-G", "-p", "-P", "3"], _pe(), {"insert_mean": 90.0, "insert_sd": 30.0, "polyx_frac": 0.3})
 CASES["se_overrep"] = (False, ["-G", "-A", "-p", "-P", "2", "--cut_right"], _se(adapter_enabled=0, cut_right=1),
                        {"insert_mean": 80.0, "insert_sd": 25.0})
-OVERREP = {"pe_overrep": 3, "se_overrep": 2}
-N_PAIRS_OVERRIDE = {"pe_overrep": 1500, "se_overrep": 1500}   # golden input size (default 500)
+CASES["pe_overrep_correction"] = (True, ["-G", "-p", "-P", "3", "-c"], _pe(correction=1),
+                                  {"insert_mean": 110.0, "insert_sd": 30.0, "polyx_frac": 0.3, "lowq_site_rate": 0.08})
+OVERREP = {"pe_overrep": 3, "se_overrep": 2, "pe_overrep_correction": 3}
+N_PAIRS_OVERRIDE = {"pe_overrep": 1500, "se_overrep": 1500, "pe_overrep_correction": 1500}   # golden input size (default 500)
 
 
 class _ArrayBatch:
