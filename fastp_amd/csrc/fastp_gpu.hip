@@ -368,6 +368,9 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         o.pre_mod = (u32)(ctx->units_seen % (uint64_t)o.sampling);
         o.sw_g = ctx->dp.sw_g;
         o.qw_g = ctx->dp.qw_g;
+        o.merge = ctx->dp.merge;
+        o.merge_include_unmerged = ctx->dp.merge_include_unmerged;
+        o.pair = a.pair;
         for (int m = 0; m < 2; m++) { o.seq[m] = a.seq[m]; o.qual[m] = a.qual[m]; o.len[m] = a.len[m]; o.res[m] = a.res[m]; }
         const int nb = (n + 255) / 256;
         const int task_cap = 4 * (n / o.sampling + 2);

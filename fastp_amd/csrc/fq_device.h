@@ -2216,13 +2216,41 @@ FQ_DEV bool ovr_unit_passes(const OvrArgs& o, int g) {
     return code == 0u;
 }
 
+// what a post-filtering task reads
+enum { OVR_SRC_MATE = 0, OVR_SRC_MERGED = 1, OVR_SRC_R1 = 2, OVR_SRC_R2 = 3 };
+
+// the reads of unit g that reach the post-filtering Stats, in statRead order: 0..2 of them.  Outside merge
+// mode both mates of a passing unit are analysed at the same stream position (one each for the two Stats).
+FQ_DEV int ovr_post_reads(const OvrArgs& o, int g, u32 src[2]) {
+    if (!o.merge) {
+        src[0] = OVR_SRC_MATE;
+        return ovr_unit_passes(o, g) ? 1 : 0;
+    }
+    const u32 w1 = o.res[0][(size_t)g * 3 + 1], w2 = o.res[1][(size_t)g * 3 + 1];
+    const u32 code1 = w1 & 0xFFu, code2 = w2 & 0xFFu;
+    const u32 flags1 = (w1 >> 8) & 0xFFu, flags2 = (w2 >> 8) & 0xFFu;
+    if ((flags1 | flags2) & RS_NULL) return 0;  // merge.enabled && r1 && r2 (:521); otherwise no post-filtering Stats in merge mode (:584)
+    const bool dedup_out = o.dedup && (flags1 & RS_DUP);
+    const u32 pflags = o.pair[(size_t)g * 2 + 1] >> 16;
+    if (pflags & 1u) {  // FASTP_GPU_PF_OVERLAPPED: the merged read, if it passes (:525-537)
+        src[0] = OVR_SRC_MERGED;
+        return code1 == 0u ? 1 : 0;
+    }
+    if (!o.merge_include_unmerged) return 0;
+    int k = 0;  // :538-560
+    if (code1 == 0u && !dedup_out) src[k++] = OVR_SRC_R1;
+    if (code2 == 0u && !dedup_out) src[k++] = OVR_SRC_R2;
+    return k;
+}
+
 FQ_DEV void ovr_pass_body(const OvrArgs& o, u32* lds) {
     if (thread_id() == 0) lds[0] = 0;
     block_sync();
     const int g = block_id() * block_threads() + thread_id();
-    const bool pass = g < o.n && ovr_unit_passes(o, g);
-    const u64 m = ballot(pass);
-    if (lane_id() == 0 && m) lds_add_u32(&lds[0], (u32)popc64(m));
+    u32 src[2];
+    const int k = g < o.n ? ovr_post_reads(o, g, src) : 0;
+    const u32 c = (u32)popc64(ballot(k >= 1)) + (u32)popc64(ballot(k == 2));
+    if (lane_id() == 0 && c) lds_add_u32(&lds[0], c);
     block_sync();
     if (thread_id() == 0) o.blocksum[block_id()] = lds[0];
 }
@@ -2237,31 +2265,44 @@ FQ_DEV void ovr_scan_body(const OvrArgs& o, int nblocks) {
     *o.post_seen = run;
 }
 
+// task = unit << 4 | source << 2 | Stats slot (PRE1=0 POST1=1 PRE2=2 POST2=3)
 FQ_DEV void ovr_tasks_body(const OvrArgs& o, u32* lds) {
     const int g = block_id() * block_threads() + thread_id();
-    const bool pass = g < o.n && ovr_unit_passes(o, g);
-    // rank of this unit among the passing ones: block base + waves before + lanes before
-    const u64 m = ballot(pass);
+    u32 src[2] = {0u, 0u};
+    const int k = g < o.n ? ovr_post_reads(o, g, src) : 0;
+    // stream position of this unit's first post-filtering read: block base + waves before + lanes before
+    const u64 m1 = ballot(k >= 1), m2 = ballot(k == 2);
     const int wave = wave_id(), nw = block_threads() >> 6;
-    if (lane_id() == 0) lds[wave] = (u32)popc64(m);
+    if (lane_id() == 0) lds[wave] = (u32)popc64(m1) + (u32)popc64(m2);
     block_sync();
     u32 before = 0;
     for (int w = 0; w < nw; w++)
         if (w < wave) before += lds[w];
-    before += (u32)popc64(m & ((1ull << lane_id()) - 1ull));
+    const u64 lower = (1ull << lane_id()) - 1ull;
+    before += (u32)popc64(m1 & lower) + (u32)popc64(m2 & lower);
     if (g >= o.n) return;
     const int mates = o.paired ? 2 : 1;
-    const bool pre = (o.pre_mod + (u32)g) % (u32)o.sampling == 0u;             // mReads % sampling == 0 (:272)
-    const bool post = pass && (o.blockbase[block_id()] + before) % (u32)o.sampling == 0u;
-    const int k = ((pre ? 1 : 0) + (post ? 1 : 0)) * mates;
-    if (!k) return;
-    u32 slot = g_atomic_add_u32(o.n_tasks, (u32)k);
-    for (int which = 0; which < 2; which++) {
-        if (!(which ? post : pre)) continue;
-        for (int mt = 0; mt < mates; mt++) {
-            if (slot < (u32)o.task_cap) o.tasks[slot] = ((u32)g << 2) | ((u32)mt << 1) | (u32)which;
-            slot++;
-        }
+    const bool pre = (o.pre_mod + (u32)g) % (u32)o.sampling == 0u;  // mReads % sampling == 0 (:272)
+    bool post[2];
+    int npost = 0;
+    for (int j = 0; j < 2; j++) {
+        post[j] = j < k && (o.blockbase[block_id()] + before + (u32)j) % (u32)o.sampling == 0u;
+        npost += post[j] ? 1 : 0;
+    }
+    const int total = (pre ? mates : 0) + (o.merge ? npost : npost * mates);
+    if (!total) return;
+    u32 slot = g_atomic_add_u32(o.n_tasks, (u32)total);
+    auto put = [&](u32 t) {
+        if (slot < (u32)o.task_cap) o.tasks[slot] = t;
+        slot++;
+    };
+    if (pre)
+        for (int mt = 0; mt < mates; mt++) put(((u32)g << 4) | ((u32)mt << 1));
+    for (int j = 0; j < 2; j++) {
+        if (!post[j]) continue;
+        if (o.merge) put(((u32)g << 4) | (src[j] << 2) | 1u);
+        else
+            for (int mt = 0; mt < mates; mt++) put(((u32)g << 4) | ((u32)mt << 1) | 1u);
     }
 }
 
@@ -2294,26 +2335,70 @@ FQ_DEV u32 ovr_sym_corrected(const OvrArgs& o, const u32* srow, const u8* qrow, 
     return s;
 }
 
+// a read as one of the Stats objects sees it
+struct OvrRead {
+    const u32* srow[2];
+    const u8* qrow[2];
+    u32 chain[2];   // correction chains of the two mates (0 = none)
+    int f[2];       // merged: front of r1 / index of r2'[last] ; plain: f[0] = front
+    int m1;         // merged: bases taken from r1
+    int ol;         // merged: overlap length
+    int len;
+    int src;
+    int mt;         // plain: which mate
+};
+FQ_DEV u32 ovr_fetch(const OvrArgs& o, const OvrRead& r, int j) {
+    if (r.src != OVR_SRC_MERGED || j < r.m1) {
+        const int mt = r.src == OVR_SRC_MERGED ? 0 : r.mt;
+        const int at = r.f[0] + j;
+        return r.chain[mt] ? ovr_sym_corrected(o, r.srow[mt], r.qrow[mt], at, r.chain[mt]) : ovr_sym(r.srow[mt], r.qrow[mt], at);
+    }
+    // merged tail: rc(r2')[ol + k], k = j - m1  =  complement of r2'[len2 - 1 - ol - k]   (overlapanalysis.cpp:148-179)
+    const int at = r.f[1] - r.ol - (j - r.m1);
+    const u32 s = r.chain[1] ? ovr_sym_corrected(o, r.srow[1], r.qrow[1], at, r.chain[1]) : ovr_sym(r.srow[1], r.qrow[1], at);
+    return s < 4u ? (s ^ 1u) : s;  // A0<->T1, C2<->G3
+}
+
 FQ_DEV void ovr_count_body(const OvrArgs& o) {
     const int t = block_id() * block_threads() + thread_id();
     const int nt = (int)imin((int)*o.n_tasks, o.task_cap);
     if (t >= nt) return;
     const u32 task = o.tasks[t];
-    const int g = (int)(task >> 2), mt = (int)((task >> 1) & 1u), post = (int)(task & 1u);
-    const OvrMate& M = o.mate[mt];
+    const int g = (int)(task >> 4), src = (int)((task >> 2) & 3u), slot = (int)(task & 3u);
+    const int post = slot & 1;
+    const int mt = src == OVR_SRC_R1 ? 0 : src == OVR_SRC_R2 ? 1 : (slot >> 1);
+    const OvrMate& M = o.mate[slot >> 1];   // the seed list belongs to the Stats object, not to the read
     if (M.n_seeds == 0) return;
-    int f = 0, len = (int)o.len[mt][g];
-    if (post) {  // the read as it is written out: [front, front + len)
+    OvrRead r;
+    r.src = src;
+    r.mt = mt;
+    for (int m = 0; m < (o.paired ? 2 : 1); m++) {
+        r.srow[m] = o.seq[m] + (size_t)g * o.sw_g;
+        r.qrow[m] = (const u8*)(o.qual[m] + (size_t)g * o.qw_g);
+        // the pre-filtering Stats saw the read before BaseCorrector touched it (peprocessor.cpp:419-432 vs :447-460)
+        r.chain[m] = (post && o.corr) ? o.corr_head[o.paired ? (u32)g * 2u + (u32)m : (u32)g] : 0u;
+    }
+    if (!o.paired) { r.srow[1] = r.srow[0]; r.qrow[1] = r.qrow[0]; r.chain[1] = 0u; }
+    r.m1 = 0;
+    r.ol = 0;
+    r.f[0] = r.f[1] = 0;
+    int len = (int)o.len[mt][g];
+    if (src == OVR_SRC_MERGED) {
+        const u32 a0 = o.res[0][(size_t)g * 3], b0 = o.res[1][(size_t)g * 3];
+        const int m1 = (int)(o.res[0][(size_t)g * 3 + 2] >> 16), m2 = (int)(o.res[1][(size_t)g * 3 + 2] >> 16);
+        r.f[0] = (int)(a0 & 0xFFFFu);
+        r.f[1] = (int)(b0 & 0xFFFFu) + (int)(b0 >> 16) - 1;  // r2'[last]
+        r.m1 = m1;
+        r.ol = (int)(o.pair[(size_t)g * 2] >> 16);
+        len = m1 + m2;
+    } else if (post) {  // the read as it is written out: [front, front + len)
         const u32 w0 = o.res[mt][(size_t)g * 3];
-        f = (int)(w0 & 0xFFFFu);
+        r.f[0] = (int)(w0 & 0xFFFFu);
         len = (int)(w0 >> 16);
     }
-    const u32* srow = o.seq[mt] + (size_t)g * o.sw_g;
-    const u8* qrow = (const u8*)(o.qual[mt] + (size_t)g * o.qw_g);
-    // the pre-filtering Stats saw the read before BaseCorrector touched it (peprocessor.cpp:419-432 vs :447-460)
-    const u32 chain = (post && o.corr) ? o.corr_head[o.paired ? (u32)g * 2u + (u32)mt : (u32)g] : 0u;
-#define OVR_SYM(j) (chain ? ovr_sym_corrected(o, srow, qrow, (j), chain) : ovr_sym(srow, qrow, (j)))
-    const int slot = mt * 2 + post;  // PRE1=0 POST1=1 PRE2=2 POST2=3
+    r.len = len;
+#define OVR_SYM(j) ovr_fetch(o, r, (j))
+    const int f = 0;
     int64_t* cnt = o.ctr + o.o_count[slot];
     int64_t* dist = o.ctr + o.o_dist[slot];
     for (int s = 0; s < OVR_STEPS; s++) {

@@ -159,7 +159,6 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.overrep_sampling = in.overrep_sampling;
     for (int m = 0; m < 2; m++) { luts.ovr_table[m].clear(); luts.ovr_sym[m].clear(); luts.ovr_len[m].clear(); }
     if (p.overrep) {
-        if (in.merge) { err = "overrepresentation analysis together with merge is not on the device path"; return FASTP_GPU_E_UNSUPPORTED; }
         if (in.overrep_sampling <= 0) { err = "overrep_sampling must be positive"; return FASTP_GPU_E_INVALID; }
         const char* const* lists[2] = {in.overrep_seqs1, in.overrep_seqs2};
         const int ns[2] = {in.n_overrep_seqs1, p.paired ? in.n_overrep_seqs2 : 0};

@@ -187,6 +187,10 @@ struct OvrArgs {
     OvrMate mate[2];
     int64_t* ctr;
     int64_t o_count[4], o_dist[4];   // fastp_gpu_counter_layout::overrep_count / overrep_dist
+    // merge mode (peprocessor.cpp:518-561): every post-filtering read goes to the read-1 Stats - the merged read,
+    // or with --include_unmerged r1 then r2 of a pair that did not overlap
+    int merge, merge_include_unmerged;
+    const u32* pair;             // pair records of this launch (2 dwords each)
     // --correction: the post-filtering Stats see the corrected bases.  The batch's correction list is threaded
     // into one chain per read (corr_head[read key] -> entry index + 1, corr_next[entry]) before the counting.
     const u32* corr;             // fastp_gpu_correction entries, 2 dwords each (nullptr: no correction)

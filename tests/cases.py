@@ -102,8 +102,14 @@ CASES["se_overrep"] = (False, ["-G", "-A", "-p", "-P", "2", "--cut_right"], _se(
                        {"insert_mean": 80.0, "insert_sd": 25.0})
 CASES["pe_overrep_correction"] = (True, ["-G", "-p", "-P", "3", "-c"], _pe(correction=1),
                                   {"insert_mean": 110.0, "insert_sd": 30.0, "polyx_frac": 0.3, "lowq_site_rate": 0.08})
-OVERREP = {"pe_overrep": 3, "se_overrep": 2, "pe_overrep_correction": 3}
-N_PAIRS_OVERRIDE = {"pe_overrep": 1500, "se_overrep": 1500, "pe_overrep_correction": 1500}   # golden input size (default 500)
+CASES["pe_overrep_merge"] = (True, ["-G", "-p", "-P", "2", "-m", "--merged_out", "@TMP@/merged.fq"], _pe(merge=1, correction=1),
+                             {"insert_mean": 170.0, "insert_sd": 60.0, "polyx_frac": 0.3, "lowq_site_rate": 0.06})
+CASES["pe_overrep_merge_unmerged"] = (True, ["-G", "-p", "-P", "2", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq", "--dedup"],
+                                      _pe(merge=1, correction=1, merge_include_unmerged=1, dedup=1),
+                                      {"insert_mean": 260.0, "insert_sd": 90.0, "polyx_frac": 0.3, "dup_frac": 0.3})
+OVERREP = {"pe_overrep": 3, "se_overrep": 2, "pe_overrep_correction": 3, "pe_overrep_merge": 2, "pe_overrep_merge_unmerged": 2}
+N_PAIRS_OVERRIDE = {"pe_overrep": 1500, "se_overrep": 1500, "pe_overrep_correction": 1500, "pe_overrep_merge": 1500,
+                    "pe_overrep_merge_unmerged": 1500}   # golden input size (default 500)
 
 
 class _ArrayBatch:
