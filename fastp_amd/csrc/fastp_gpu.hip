@@ -796,7 +796,7 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(fq_parse_finish_kernel, dim3(1), dim3(64), 0, st, p);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(fq_parse_pack_kernel, dim3((max_records + 3) / 4), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(fq_parse_pack_kernel, dim3((max_records + 15) / 16), dim3(256), 0, st, p);  // 4 records per wavefront
     HIP_TRY(ctx, hipGetLastError());
     u32 totals[8];
     HIP_TRY(ctx, hipMemcpyAsync(totals, p.totals, sizeof(totals), hipMemcpyDeviceToHost, st));

@@ -2560,63 +2560,82 @@ FQ_DEV void parse_finish_body(const ParseArgs& p) {
     p.totals[4] = consumed;
 }
 
+// 0x80 in every byte of v that is zero (exact, no borrow across bytes)
+FQ_DEV u32 zero_bytes(u32 v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
+
+enum { PACK_GROUP = 16 };  // lanes per record: four records per wavefront
+
 FQ_DEV void parse_pack_body(const ParseArgs& p) {
-    const int r = block_id() * (block_threads() >> 6) + wave_id();  // one wavefront per record
+    // 16 lanes per record; lane c packs bases 4c .. 4c+3 from ONE dword of the sequence line and one of the
+    // quality line (four letters at a time, byte-parallel), three trips for a 150-base read
+    const int lane = lane_id();
+    const int grp = lane >> 4, gl = lane & (PACK_GROUP - 1);
+    const int r = (block_id() * (block_threads() >> 6) + wave_id()) * 4 + grp;
     const u32 lines = p.totals[2], terms = p.totals[0];
     int nrec = (int)(lines / 4u);
     if (nrec > p.max_records) nrec = p.max_records;
-    if (r >= nrec) return;
-    const int lane = lane_id();
+    const bool have = r < nrec;
+    const int rr = have ? r : 0;
     u32 start[4], len[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const u32 k = 4u * (u32)r + (u32)j;
-        start[j] = k ? p.term_pos[k - 1] + p.term_len[k - 1] : 0u;
-        const u32 end = k < terms ? p.term_pos[k] : p.nbytes;  // the unterminated last line ends at EOF
-        len[j] = end - start[j];
+        const u32 k = 4u * (u32)rr + (u32)j;
+        start[j] = (have && k) ? p.term_pos[k - 1] + p.term_len[k - 1] : 0u;
+        const u32 end = (have && k < terms) ? p.term_pos[k] : p.nbytes;  // the unterminated last line ends at EOF
+        len[j] = have ? end - start[j] : 0u;
     }
     bool bad = false;
-    if (lane == 0) {  // FastqReader::read's checks (:338-362)
+    if (have && gl == 0) {  // FastqReader::read's checks (:338-362)
         bad = len[0] == 0 || p.text[start[0]] != '@' || len[2] == 0 || p.text[start[2]] != '+' || len[1] != len[3] ||
               len[1] > (u32)p.max_len;
     }
-    bad = ballot(bad) != 0ull;
+    const u32 gmask_shift = 16u * (u32)grp;
+    bad = ((ballot(bad) >> gmask_shift) & 0xFFFFull) != 0ull;
     const u32 L = bad ? 0u : len[1];
-    if (lane < 4) {
-        p.line_off[4 * (size_t)r + lane] = start[lane];
-        p.line_len[4 * (size_t)r + lane] = len[lane];
+    if (have && gl < 4) {
+        const u32 st = gl == 0 ? start[0] : gl == 1 ? start[1] : gl == 2 ? start[2] : start[3];
+        const u32 ln = gl == 0 ? len[0] : gl == 1 ? len[1] : gl == 2 ? len[2] : len[3];
+        p.line_off[4 * (size_t)rr + gl] = st;
+        p.line_len[4 * (size_t)rr + gl] = ln;
     }
-    if (lane == 0) p.len_out[r] = (u16)L;
-    // lane c packs bases 4c .. 4c+3: one quality dword, one byte of the 2-bit row
+    if (have && gl == 0) p.len_out[rr] = (u16)L;
     const u8* sp = p.text + start[1];
     const u8* qp = p.text + start[3];
-    u32* qrow = p.qual_out + (size_t)r * p.qw_g;
-    u8* srow = (u8*)(p.seq_out + (size_t)r * p.sw_g);
+    u32* qrow = p.qual_out + (size_t)rr * p.qw_g;
+    u8* srow = (u8*)(p.seq_out + (size_t)rr * p.sw_g);
     bool alpha_bad = false;
-    for (int c = lane; c < p.qw_g || c < p.sw_g * 4; c += 64) {
+    const int ncol = p.qw_g > p.sw_g * 4 ? p.qw_g : p.sw_g * 4;
+    for (int c = gl; c < ncol; c += PACK_GROUP) {
         u32 qd = 0, sb = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const u32 j = 4u * (u32)c + (u32)k;
-            if (j < L) {
-                const u32 ch = sp[j];
-                u32 code = 0, nflag = 0;
-                if (ch == 'A') code = CODE_A;
-                else if (ch == 'T') code = CODE_T;
-                else if (ch == 'C') code = CODE_C;
-                else if (ch == 'G') code = CODE_G;
-                else if (ch == 'N') nflag = 0x80u;
-                else alpha_bad = true;
-                const u32 q = qp[j];
-                if (q > 127u) alpha_bad = true;
-                sb |= code << (2 * k);
-                qd |= ((q & 0x7Fu) | nflag) << (8 * k);
-            }
+        const int rem = (int)L - 4 * c;  // letters of this dword that exist
+        if (have && rem > 0) {
+            // unaligned dword reads; the up to three bytes behind the line are its terminator / the next line (the
+            // text is padded behind its end) and are masked off
+            u32 w, qw;
+            __builtin_memcpy(&w, sp + 4 * c, 4);
+            __builtin_memcpy(&qw, qp + 4 * c, 4);
+            const u32 keep = lowmask32(8 * rem);
+            w &= keep;
+            qw &= keep;
+            // ASCII bits 2:1 tell the letters apart: A 00, C 01, T 10, G 11 (N also 11); engine codes A0 T1 C2 G3 swap them
+            const u32 x = (w >> 1) & 0x03030303u;
+            const u32 code = ((x & 0x01010101u) << 1) | ((x >> 1) & 0x01010101u);
+            // the letter each code stands for, to compare with: 'A' + {0, 0x13, 0x02, 0x06}
+            const u32 c0 = code & 0x01010101u, c1 = (code >> 1) & 0x01010101u, both = c0 & c1;
+            const u32 expect = 0x41414141u + (c1 << 1) + (c0 << 4) + (c0 << 1) + c0 - ((both << 4) - both);
+            const u32 is_letter = zero_bytes(w ^ expect);
+            const u32 is_n = zero_bytes(w ^ 0x4E4E4E4Eu);
+            const u32 live = (0x80808080u & keep);
+            if ((~(is_letter | is_n) & live) | (qw & 0x80808080u)) alpha_bad = true;
+            const u32 codes = code & ~(is_n >> 7) & ~(is_n >> 6);  // N packs as code 0
+            sb = (codes & 3u) | ((codes >> 6) & 0xCu) | ((codes >> 12) & 0x30u) | ((codes >> 18) & 0xC0u);
+            qd = (qw & 0x7F7F7F7Fu) | is_n;
         }
-        if (c < p.qw_g) qrow[c] = qd;
-        if (c < p.sw_g * 4) srow[c] = (u8)sb;
+        if (have && c < p.qw_g) qrow[c] = qd;
+        if (have && c < p.sw_g * 4) srow[c] = (u8)sb;
     }
-    if ((ballot(alpha_bad) != 0ull || bad) && lane == 0) g_atomic_min_u32(&p.totals[1], (u32)r);
+    const bool any_bad = ((ballot(alpha_bad) >> gmask_shift) & 0xFFFFull) != 0ull || bad;
+    if (have && any_bad && gl == 0) g_atomic_min_u32(&p.totals[1], (u32)r);
 }
 
 
@@ -2690,9 +2709,18 @@ FQ_DEV void fmt_scan_body(const FmtArgs& f, u64* lds) {
     }
 }
 
-FQ_DEV void fmt_copy(u8* dst, const u8* src, u32 n, int lane) {
-    for (u32 i = (u32)lane; i < n; i += 64) dst[i] = src[i];
-    if (lane == 0) dst[n] = 10;  // '\n'
+// one line of a record by a 16-lane group: four bytes per lane and trip (source and destination sit at arbitrary
+// byte offsets: global memory takes unaligned dwords), the 0-3 byte tail and the '\n' by the group's first lane
+FQ_DEV void fmt_copy(u8* dst, const u8* src, u32 n, int gl) {
+    for (u32 i = 4u * (u32)gl; i + 4u <= n; i += 4u * 16u) {
+        u32 w;
+        __builtin_memcpy(&w, src + i, 4);
+        __builtin_memcpy(dst + i, &w, 4);
+    }
+    if (gl == 0) {
+        for (u32 i = n & ~3u; i < n; i++) dst[i] = src[i];
+        dst[n] = 10;  // '\n'
+    }
 }
 
 FQ_DEV void fmt_write_body(const FmtArgs& f, u32* lds) {
@@ -2719,12 +2747,14 @@ FQ_DEV void fmt_write_body(const FmtArgs& f, u32* lds) {
         if (g < f.n) f.m[mt].unit_off[g] = out ? off : ~0ull;
         block_sync();
     }
-    // copy: one wavefront per unit, looping over the block's units
-    const int lane = lane_id(), nw = block_threads() >> 6;
-    for (int u = wave_id(); u < block_threads(); u += nw) {
+    // copy: a 16-lane group per (unit, mate), looping over the block's units
+    const int lane = lane_id() & 15, ngroups = block_threads() >> 4;
+    for (int t = tid >> 4; t < block_threads() * mates; t += ngroups) {
+        const int u = f.paired ? t >> 1 : t;
         const int gu = g0 + u;
         if (gu >= f.n) break;
-        for (int mt = 0; mt < mates; mt++) {
+        {
+            const int mt = f.paired ? t & 1 : 0;
             const FmtMate& M = f.m[mt];
             const u64 off = M.unit_off[gu];
             if (off == ~0ull) continue;
