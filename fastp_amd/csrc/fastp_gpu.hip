@@ -273,6 +273,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4));
     auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
         if (bytes == 0) { *dptr = nullptr; return 0; }
         HIP_TRY(ctx, hipMalloc(dptr, bytes));
@@ -883,12 +885,7 @@ extern "C" int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, i
     a.first_bad = (u32*)(ctx->d_inf + scratch + status);
     a.check_crc = check_crc;
     HIP_TRY(ctx, hipMemsetAsync(a.first_bad, 0xFF, 4, st));
-    static bool attr_set = false;
     const int lds_bytes = INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4;
-    if (!attr_set) {
-        HIP_TRY(ctx, hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(fq_inflate_kernel, dim3((n_blocks + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_bytes, st, a);
     HIP_TRY(ctx, hipGetLastError());
     u32 bad = 0xFFFFFFFFu;
