@@ -778,7 +778,7 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     p.len_out = len_out;
     p.line_off = line_off;
     p.line_len = line_len;
-    const int per_block = PARSE_BLOCK * PARSE_BYTES_PER_LANE;
+    const int per_block = PARSE_BLOCK * PARSE_BYTES_PER_LANE * PARSE_SUB;
     const int nblocks = (int)((nbytes + per_block - 1) / per_block);
     const size_t dwords = 8 + (size_t)2 * nblocks + p.max_lines + (p.max_lines + 3) / 4;
     int rc = ensure(ctx, (void**)&ctx->d_parse, &ctx->parse_cap, dwords * 4);

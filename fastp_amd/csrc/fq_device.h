@@ -2450,31 +2450,55 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
 //   parse_index : position / length of the terminator that ends line k
 //   parse_pack  : one wavefront per record (4 lines): validate, 2-bit pack, N flags, zero padding
 // ---------------------------------------------------------------------------
-FQ_DEV u32 parse_term_mask(const ParseArgs& p, u32 base) {
-    // bit i: a terminator starts at byte base + i (16 bytes per lane)
-    u32 m = 0;
+// 0x80 in every byte of v that is zero (exact, no borrow across bytes)
+FQ_DEV u32 zero_bytes(u32 v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
+
+// bit i: a line terminator starts at byte base + i of the 16 bytes v (prev = the byte before them).  Byte-parallel:
+// '\r' always starts one, '\n' does unless the byte before it is '\r' (FastqReader::getLine, fastqreader.cpp:240-268)
+FQ_DEV u32 parse_term_mask16(const ParseArgs& p, u32 base, const u32x4& v, u32 prev) {
     if (base >= p.nbytes) return 0;
-    const u32x4 v = *(const u32x4*)(p.text + base);
     const u32 w[4] = {v.x, v.y, v.z, v.w};
-    u32 prev = base ? (u32)p.text[base - 1] : 0u;
+    u32 m = 0;
+    u32 carry = prev == 13u ? 0x80u : 0u;  // "the byte before this dword is '\r'", positioned for its first byte
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const u32 b = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-        const bool in = base + (u32)i < p.nbytes;
-        // a '\r' that ends a non-final chunk may be half of a "\r\n": leave its line to the next chunk
-        const bool hanging = b == 13u && base + (u32)i + 1u == p.nbytes && !p.is_last;
-        if (in && !hanging && (b == 13u || (b == 10u && prev != 13u))) m |= 1u << i;
-        prev = b;
+    for (int j = 0; j < 4; j++) {
+        const u32 cr = zero_bytes(w[j] ^ 0x0D0D0D0Du), lf = zero_bytes(w[j] ^ 0x0A0A0A0Au);
+        const u32 t = (cr | (lf & ~((cr << 8) | carry))) >> 7;  // bits 0, 8, 16, 24
+        m |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * j);
+        carry = cr >> 24;
     }
+    const u32 left = p.nbytes - base;  // bytes of this chunk that exist
+    if (left < 16u) m &= (1u << left) - 1u;
+    // a '\r' that ends a non-final chunk may be half of a "\r\n": leave its line to the next chunk
+    if (!p.is_last && left <= 16u && ((m >> (left - 1u)) & 1u) && p.text[p.nbytes - 1] == 13) m &= ~(1u << (left - 1u));
     return m;
+}
+
+// the workgroup's PARSE_SUB sub-blocks: lane t of sub-block k owns bytes (block * PARSE_SUB + k) * 4096 + 16 t .. +15.
+// All loads are issued before any mask is built (four independent 16-byte loads in flight per lane).
+FQ_DEV void parse_masks(const ParseArgs& p, u32 m[PARSE_SUB], u32 bases[PARSE_SUB]) {
+    u32x4 v[PARSE_SUB];
+    u32 prev[PARSE_SUB];
+#pragma unroll
+    for (int k = 0; k < PARSE_SUB; k++) {
+        bases[k] = (((u32)block_id() * PARSE_SUB + (u32)k) * PARSE_BLOCK + (u32)thread_id()) * PARSE_BYTES_PER_LANE;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const bool in = bases[k] < p.nbytes;
+        v[k] = in ? *(const u32x4*)(p.text + bases[k]) : z;
+        prev[k] = (in && bases[k]) ? (u32)p.text[bases[k] - 1] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < PARSE_SUB; k++) m[k] = parse_term_mask16(p, bases[k], v[k], prev[k]);
 }
 
 FQ_DEV void parse_count_body(const ParseArgs& p, u32* lds) {
     if (thread_id() == 0) lds[0] = 0;
     block_sync();
-    const u32 base = ((u32)block_id() * PARSE_BLOCK + (u32)thread_id()) * PARSE_BYTES_PER_LANE;
-    const u32 c = (u32)popc32(parse_term_mask(p, base));
-    u32 wsum = c;
+    u32 m[PARSE_SUB], bases[PARSE_SUB];
+    parse_masks(p, m, bases);
+    u32 wsum = 0;
+#pragma unroll
+    for (int k = 0; k < PARSE_SUB; k++) wsum += (u32)popc32(m[k]);
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) wsum += shfl_xor(wsum, sh);
     if (lane_id() == 0 && wsum) lds_add_u32(&lds[0], wsum);
@@ -2517,31 +2541,39 @@ FQ_DEV void parse_scan_body(const ParseArgs& p, int nblocks, u32* lds) {
 }
 
 FQ_DEV void parse_index_body(const ParseArgs& p, u32* lds) {
-    const u32 base = ((u32)block_id() * PARSE_BLOCK + (u32)thread_id()) * PARSE_BYTES_PER_LANE;
-    u32 m = parse_term_mask(p, base);
-    const u32 c = (u32)popc32(m);
-    // exclusive prefix of c inside the workgroup: lanes via shuffles, waves via LDS
-    u32 incl = c;
-#pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) {
-        const u32 o = shfl(incl, lane_id() - sh);
-        if (lane_id() >= sh) incl += o;
-    }
+    u32 m[PARSE_SUB], bases[PARSE_SUB];
+    parse_masks(p, m, bases);
     const int wave = wave_id(), nw = block_threads() >> 6;
-    if (lane_id() == 63) lds[wave] = incl;
-    block_sync();
-    u32 rank = p.blockbase[block_id()] + incl - c;
-    for (int w = 0; w < nw; w++)
-        if (w < wave) rank += lds[w];
-    while (m) {
-        const int i = ffs32(m) - 1;
-        m &= m - 1;
-        if (rank < p.max_lines) {
-            const u32 pos = base + (u32)i;
-            p.term_pos[rank] = pos;
-            p.term_len[rank] = (u8)((p.text[pos] == 13 && pos + 1 < p.nbytes && p.text[pos + 1] == 10) ? 2 : 1);
+    u32 run = p.blockbase[block_id()];  // terminators before this workgroup's first sub-block
+    for (int k = 0; k < PARSE_SUB; k++) {
+        u32 mk = m[k];
+        const u32 c = (u32)popc32(mk);
+        // exclusive prefix of c inside the sub-block: lanes via shuffles, waves via LDS
+        u32 incl = c;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const u32 o = shfl(incl, lane_id() - sh);
+            if (lane_id() >= sh) incl += o;
         }
-        rank++;
+        if (lane_id() == 63) lds[wave] = incl;
+        block_sync();
+        u32 rank = run + incl - c, total = 0;
+        for (int w = 0; w < nw; w++) {
+            if (w < wave) rank += lds[w];
+            total += lds[w];
+        }
+        block_sync();
+        run += total;
+        while (mk) {
+            const int i = ffs32(mk) - 1;
+            mk &= mk - 1;
+            if (rank < p.max_lines) {
+                const u32 pos = bases[k] + (u32)i;
+                p.term_pos[rank] = pos;
+                p.term_len[rank] = (u8)((p.text[pos] == 13 && pos + 1 < p.nbytes && p.text[pos + 1] == 10) ? 2 : 1);
+            }
+            rank++;
+        }
     }
 }
 
@@ -2559,9 +2591,6 @@ FQ_DEV void parse_finish_body(const ParseArgs& p) {
     p.totals[3] = nrec;
     p.totals[4] = consumed;
 }
-
-// 0x80 in every byte of v that is zero (exact, no borrow across bytes)
-FQ_DEV u32 zero_bytes(u32 v) { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu); }
 
 enum { PACK_GROUP = 16 };  // lanes per record: four records per wavefront
 

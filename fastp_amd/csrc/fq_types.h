@@ -202,7 +202,7 @@ struct OvrArgs {
 };
 
 // ---- FASTQ text -> packed rows on the device (fq_parse_* kernels) ----
-enum { PARSE_BYTES_PER_LANE = 16, PARSE_BLOCK = 256 };
+enum { PARSE_BYTES_PER_LANE = 16, PARSE_BLOCK = 256, PARSE_SUB = 4 };  // a workgroup scans PARSE_SUB consecutive 4 KiB sub-blocks
 struct ParseArgs {
     const u8* text;       // 16-byte aligned
     u32 nbytes;           // bytes to scan (a trailing lone '\r' of a non-final chunk is left out)
