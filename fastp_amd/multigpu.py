@@ -66,12 +66,13 @@ def _device_sync(t):
         torch.cuda.synchronize(t.device)
 
 
-def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False):
+def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False, scans=None):
     """Process this rank's shard (`batches[i]` -> `results[i]`, abi.Batch / abi.Results holding
     pointers valid on `device`: HBM for the real engine) so that results and counters equal those
     of one stream over all shards in rank order.  `dist` is torch.distributed (nccl = RCCL on the
     GPUs; gloo in the CPU tests) or None for a single shard.  The counter all-reduce is separate
-    (allreduce_counters_*).  Returns the per-rank scan buffers' total size in bytes."""
+    (allreduce_counters_*).  `scans`: optional preallocated uint8 tensors, one per batch, of at least
+    engine.dup_scan_bytes(batch.n) bytes each (otherwise allocated here).  Returns their total size in bytes."""
     import torch
     from . import abi
     if not exact or ((world == 1 or dist is None) and not force):
@@ -85,11 +86,10 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
             b.flags |= abi.BATCH_DEFER_OVERREP
     # pass 1: insert in input order, keep per-unit positions / "set earlier in this shard" masks
     # (without --dedup this already is the whole worker loop, minus the duplicate decision)
-    scans = []
-    for b, r in zip(batches, results):
-        t = torch.empty(max(16, engine.dup_scan_bytes(b.n)), dtype=torch.uint8, device=device)
+    if scans is None:
+        scans = [torch.empty(max(16, engine.dup_scan_bytes(b.n)), dtype=torch.uint8, device=device) for b in batches]
+    for b, r, t in zip(batches, results, scans):
         engine.submit_pass1_device(b, t.data_ptr(), r)
-        scans.append(t)
     engine.synchronize()
     # exchange: exclusive prefix-OR of the bitmaps in rank order
     nbytes = engine.dup_bitmap_bytes()
