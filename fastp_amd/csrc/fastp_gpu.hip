@@ -37,7 +37,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_ovr_tasks_kernel(OvrArgs o)
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     ovr_tasks_body(o, fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(256) fq_ovr_count_kernel(OvrArgs o) { ovr_count_body(o); }
+extern "C" __global__ void __launch_bounds__(OVR_BLOCK) fq_ovr_count_kernel(OvrArgs o) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    ovr_count_body(o, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_ovr_corr_link_kernel(OvrArgs o) { ovr_corr_link_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_parse_count_kernel(ParseArgs p) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -273,6 +276,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4));
     auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
@@ -419,7 +423,21 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(fq_ovr_tasks_kernel, dim3(nb), dim3(256), 64, st, o);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fq_ovr_count_kernel, dim3((task_cap + 255) / 256), dim3(256), 0, st, o);
+        {   // LDS plan of the counting kernel: symbols of one task per lane, then the seed tables that still fit
+            const int longest = ctx->dp.max_len * (ctx->dp.merge ? 2 : 1);
+            int lds_bytes = ((longest * OVR_BLOCK + 15) / 16) * 16;
+            o.sym_cap = longest;
+            if (lds_bytes > 120 * 1024) { o.sym_cap = 0; lds_bytes = 0; }   // reads too long to stage: the global path
+            for (int m = 0; m < 2; m++) {
+                const size_t tb = ctx->luts.ovr_table[m].size() * 4;
+                o.table_lds[m] = -1;
+                if (o.mate[m].n_seeds > 0 && tb > 0 && lds_bytes + (int)tb <= 150 * 1024) {
+                    o.table_lds[m] = lds_bytes / 4;
+                    lds_bytes += (int)tb;
+                }
+            }
+            hipLaunchKernelGGL(fq_ovr_count_kernel, dim3((task_cap + OVR_BLOCK - 1) / OVR_BLOCK), dim3(OVR_BLOCK), (size_t)lds_bytes, st, o);
+        }
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->units_seen += (uint64_t)n;

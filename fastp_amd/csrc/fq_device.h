@@ -2359,8 +2359,14 @@ FQ_DEV u32 ovr_fetch(const OvrArgs& o, const OvrRead& r, int j) {
     return s < 4u ? (s ^ 1u) : s;  // A0<->T1, C2<->G3
 }
 
-FQ_DEV void ovr_count_body(const OvrArgs& o) {
-    const int t = block_id() * block_threads() + thread_id();
+FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
+    // the seed hash tables into LDS (every lane probes them at every window position)
+    const int tid = thread_id();
+    for (int m = 0; m < 2; m++)
+        if (o.table_lds[m] >= 0)
+            for (u32 i = (u32)tid; i < 2u * (o.mate[m].table_mask + 1u); i += (u32)block_threads()) lds[o.table_lds[m] + (int)i] = o.mate[m].table[i];
+    block_sync();
+    const int t = block_id() * block_threads() + tid;
     const int nt = (int)imin((int)*o.n_tasks, o.task_cap);
     if (t >= nt) return;
     const u32 task = o.tasks[t];
@@ -2397,7 +2403,14 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
         len = (int)(w0 >> 16);
     }
     r.len = len;
-#define OVR_SYM(j) ovr_fetch(o, r, (j))
+    // the read's symbols once into LDS, [position][lane]: the five window lengths below then slide over LDS bytes
+    // instead of re-reading (and re-correcting / re-complementing) global memory twice per position
+    u8* symv = (u8*)lds + tid;
+    const bool staged = len <= o.sym_cap;
+    if (staged)
+        for (int j = 0; j < len; j++) symv[(size_t)j * OVR_BLOCK] = (u8)ovr_fetch(o, r, j);
+#define OVR_SYM(j) (staged ? (u32)symv[(size_t)(j) * OVR_BLOCK] : ovr_fetch(o, r, (j)))
+    const u32* tab = o.table_lds[slot >> 1] >= 0 ? lds + o.table_lds[slot >> 1] : M.table;
     const int f = 0;
     int64_t* cnt = o.ctr + o.o_count[slot];
     int64_t* dist = o.ctr + o.o_dist[slot];
@@ -2417,9 +2430,9 @@ FQ_DEV void ovr_count_body(const OvrArgs& o) {
             const u32 key = h ^ salt;
             int hit = -1;
             for (u32 sl = (key * OVR_SALT_MUL) & M.table_mask;; sl = (sl + 1) & M.table_mask) {
-                const u32 id1 = M.table[2 * sl + 1];
+                const u32 id1 = tab[2 * sl + 1];
                 if (id1 == 0u) break;
-                if (M.table[2 * sl] == key && M.seed_len[id1 - 1] == L) {
+                if (tab[2 * sl] == key && M.seed_len[id1 - 1] == L) {
                     const u8* sd = M.seed_sym + (size_t)(id1 - 1) * OVR_SEED_STRIDE;
                     bool same = true;
                     for (int k = 0; k < L && same; k++) same = sd[k] == (u8)OVR_SYM(f + i + k);

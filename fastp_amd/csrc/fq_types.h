@@ -187,6 +187,10 @@ struct OvrArgs {
     OvrMate mate[2];
     int64_t* ctr;
     int64_t o_count[4], o_dist[4];   // fastp_gpu_counter_layout::overrep_count / overrep_dist
+    // LDS staging of the counting kernel: the task's symbols ([position][lane] bytes, sym_cap positions) and, when
+    // they fit, the seed hash tables (table_lds[m] = dword offset in LDS, or -1: probe the global copy)
+    int sym_cap;
+    int table_lds[2];
     // merge mode (peprocessor.cpp:518-561): every post-filtering read goes to the read-1 Stats - the merged read,
     // or with --include_unmerged r1 then r2 of a pair that did not overlap
     int merge, merge_include_unmerged;
@@ -224,6 +228,7 @@ struct ParseArgs {
 
 // ---- result records -> output FASTQ text on the device (fq_fmt_* kernels) ----
 enum { FMT_BLOCK = 256 };
+enum { OVR_BLOCK = 128 };  // threads of the overrepresentation counting kernel (one task per lane)
 struct FmtMate {
     const u8* text;
     const u32* line_off;
