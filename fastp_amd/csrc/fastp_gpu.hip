@@ -32,7 +32,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_ovr_pass_kernel(OvrArgs o) 
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     ovr_pass_body(o, fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(64) fq_ovr_scan_kernel(OvrArgs o, int nblocks) { ovr_scan_body(o, nblocks); }
+extern "C" __global__ void __launch_bounds__(1024) fq_ovr_scan_kernel(OvrArgs o, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    ovr_scan_body(o, nblocks, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_ovr_tasks_kernel(OvrArgs o) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     ovr_tasks_body(o, fq_lds);
@@ -419,7 +422,7 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         HIP_TRY(ctx, hipMemsetAsync(o.n_tasks, 0, 4, st));
         hipLaunchKernelGGL(fq_ovr_pass_kernel, dim3(nb), dim3(256), 16, st, o);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fq_ovr_scan_kernel, dim3(1), dim3(64), 0, st, o, nb);
+        hipLaunchKernelGGL(fq_ovr_scan_kernel, dim3(1), dim3(1024), 1024 * 4, st, o, nb);
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(fq_ovr_tasks_kernel, dim3(nb), dim3(256), 64, st, o);
         HIP_TRY(ctx, hipGetLastError());

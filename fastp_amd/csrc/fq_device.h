@@ -2255,14 +2255,34 @@ FQ_DEV void ovr_pass_body(const OvrArgs& o, u32* lds) {
     if (thread_id() == 0) o.blocksum[block_id()] = lds[0];
 }
 
-FQ_DEV void ovr_scan_body(const OvrArgs& o, int nblocks) {
-    if (block_id() != 0 || thread_id() != 0) return;
-    u64 run = *o.post_seen;
-    for (int b = 0; b < nblocks; b++) {
+FQ_DEV void ovr_scan_body(const OvrArgs& o, int nblocks, u32* lds) {
+    // one workgroup: every lane sums a contiguous run of block counts, the lane totals are scanned through LDS,
+    // then each lane writes the running stream position (mod sampling) at the start of each of its blocks
+    if (block_id() != 0) return;
+    const int tid = thread_id(), nt = block_threads();
+    const int per = (nblocks + nt - 1) / nt;
+    const int b0 = imin(tid * per, nblocks), b1 = imin(b0 + per, nblocks);
+    u32 sum = 0;
+    for (int b = b0; b < b1; b++) sum += o.blocksum[b];
+    lds[tid] = sum;
+    block_sync();
+    const u64 seen = *o.post_seen;
+    block_sync();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int i = 0; i < nt; i++) {
+            const u32 v = lds[i];
+            lds[i] = run;
+            run += v;
+        }
+        *o.post_seen = seen + run;
+    }
+    block_sync();
+    u64 run = seen + lds[tid];
+    for (int b = b0; b < b1; b++) {
         o.blockbase[b] = (u32)(run % (u64)o.sampling);
         run += o.blocksum[b];
     }
-    *o.post_seen = run;
 }
 
 // task = unit << 4 | source << 2 | Stats slot (PRE1=0 POST1=1 PRE2=2 POST2=3)
