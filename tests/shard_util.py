@@ -71,6 +71,7 @@ def shard_worker(rank, world, port, ret, kind, name, n, npacks, L=100, exact=Tru
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     params, d, paired = case_input(name, n, L)
+    n = len(d["len1"])
     device = torch.device("cpu") if kind == "sim" else torch.device("cuda", 0)
     eng = engines.sim_engine(params) if kind == "sim" else engines.gpu_engine(params)
     lo, hi = multigpu.shard_bounds(n, world, rank)
@@ -86,6 +87,11 @@ def shard_worker(rank, world, port, ret, kind, name, n, npacks, L=100, exact=Tru
 def case_input(name, n, L=100):
     import cases
     import synth
+    if name.startswith("fuzz:"):   # a random option set of tests/test_option_fuzz.py (n and L come with it)
+        import test_option_fuzz
+        p, d, paired = test_option_fuzz.random_case(int(name[5:]))
+        p.dup_accuracy_level = 1
+        return p, d, paired
     paired, flags, pf, skw = cases.CASES[name]
     skw = dict(skw)
     skw.setdefault("dup_frac", 0.3)

@@ -124,3 +124,27 @@ def test_two_rank_plain_submit_misses_cross_shard_duplicates():
     ctr, lay = o.counters(), o.layout
     o.close()
     assert ret[0][0][lay.dup_count] < ctr[lay.dup_count]
+
+
+@pytest.mark.parametrize("seed", [204, 207, 209, 214])
+def test_two_rank_exact_protocol_on_random_option_sets(seed):
+    """the protocol on random option sets (merge, merge + overrepresentation + correction, --dedup + overrepresentation,
+    single end): still ONE stream"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import engines
+    import oraclelib
+    import shard_util
+    engines.build_sim()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + 17 + seed % 50
+    mp.spawn(shard_util.shard_worker, args=(2, port, ret, "sim", f"fuzz:{seed}", 0, 2), nprocs=2, join=True)
+    params, d, paired = shard_util.case_input(f"fuzz:{seed}", 0)
+    o = oraclelib.Oracle(params)
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    whole = o.process(*args)
+    ctr = o.counters()
+    o.close()
+    assert np.array_equal(ret[0][0], ctr), f"seed {seed}: counters differ at {np.nonzero(ret[0][0] != ctr)[0][:8]}"
+    for k in range(3 if paired else 1):
+        assert ret[0][k + 1] + ret[1][k + 1] == whole[k].tobytes(), f"seed {seed}: records {k} differ"
