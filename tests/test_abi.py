@@ -105,3 +105,15 @@ def test_host_glue_library_exports_every_declared_symbol(lib):
     assert declared == set(cpphost.EXPORTS), declared ^ set(cpphost.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_headers_compile_as_plain_c_and_cpp(tmp_path):
+    """include/fastp_gpu.h is a C header (the boundary is a C ABI); fastp_gpu_host.h is the C++ glue header"""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "t.c"
+    c.write_text('#include "fastp_gpu.h"\nint main(void){fastp_gpu_params p; fastp_gpu_default_params(&p,1,150); return 0;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(c)])
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include "fastp_gpu_host.h"\nint main(){return 0;}\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", inc, "-fsyntax-only", str(cpp)])
