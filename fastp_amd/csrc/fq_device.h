@@ -1835,6 +1835,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         FQ_STAMP(5)
         phase_metrics(a, lds, tid, nt);
         block_sync();
+        FQ_STAMP(9)
         if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
         else phase_filter_se(a, lds, tile_first, tid, nt);
         block_sync();

@@ -29,5 +29,5 @@ for it in range(2):
     ms, k = g.kernel_time()
     cyc = g.debug_phase_cycles()
     tot = sum(cyc[:10])
-    names = ["load", "hash", "trim", "polyg", "overlap", "decide", "metrics+filter", "stats", "masks"]
+    names = ["load", "hash", "trim", "polyg", "overlap", "decide", "filter", "stats", "masks", "metrics"]
     print(f"kernel {ms:.3f} ms / {k} launches; phase share:", {nm: f"{100.0 * c / tot:.1f}%" for nm, c in zip(names, cyc)})
