@@ -2689,7 +2689,11 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
             const u32 is_letter = zero_bytes(w ^ expect);
             const u32 is_n = zero_bytes(w ^ 0x4E4E4E4Eu);
             const u32 live = (0x80808080u & keep);
-            if ((~(is_letter | is_n) & live) | (qw & 0x80808080u)) alpha_bad = true;
+            // quality characters outside '!'..'~' are refused like foreign letters: the kernels take (q - 33) as an
+            // unsigned field of a packed counter, the reference adds a negative long (stats.cpp:223,226)
+            const u32 q_lt33 = ~(((qw & 0x7F7F7F7Fu) | 0x80808080u) - 0x21212121u) & 0x80808080u;
+            const u32 q_127 = zero_bytes(qw ^ 0x7F7F7F7Fu);
+            if ((~(is_letter | is_n) & live) | (qw & 0x80808080u) | ((q_lt33 | q_127) & live)) alpha_bad = true;
             const u32 codes = code & ~(is_n >> 7) & ~(is_n >> 6);  // N packs as code 0
             sb = (codes & 3u) | ((codes >> 6) & 0xCu) | ((codes >> 12) & 0x30u) | ((codes >> 18) & 0xC0u);
             qd = (qw & 0x7F7F7F7Fu) | is_n;

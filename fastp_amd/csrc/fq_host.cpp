@@ -451,7 +451,9 @@ int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char
                 default: if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET;
             }
             const unsigned char qc = (unsigned char)q[j];
-            if (qc > 127) { if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET; }
+            // outside '!'..'~': the kernels take (q - 33) as an unsigned field of a packed counter where the
+            // reference adds a negative long (stats.cpp:223,226) - refused like a foreign letter
+            if (qc < 33 || qc > 126) { if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET; }
             so[j >> 2] |= (uint8_t)(code << ((j & 3) * 2));
             qo[j] = (uint8_t)(qc | nflag);
         }

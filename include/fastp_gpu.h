@@ -43,7 +43,7 @@ extern "C" {
 #define FASTP_GPU_E_INVALID (-1)     /* bad argument / inconsistent params       */
 #define FASTP_GPU_E_NO_DEVICE (-2)   /* no HIP device / kernels not loadable     */
 #define FASTP_GPU_E_HIP (-3)         /* a HIP runtime call failed                */
-#define FASTP_GPU_E_ALPHABET (-4)    /* base byte outside {A,C,G,T,N} in pack    */
+#define FASTP_GPU_E_ALPHABET (-4)    /* base outside {A,C,G,T,N} or quality outside '!'..'~' in pack */
 #define FASTP_GPU_E_TOO_LONG (-5)    /* read longer than params.max_len          */
 #define FASTP_GPU_E_UNSUPPORTED (-6) /* option outside the device path's scope   */
 #define FASTP_GPU_E_OVERFLOW (-7)    /* correction / adapter-event list capacity exceeded */
@@ -312,7 +312,8 @@ const char* fastp_gpu_last_error(const fastp_gpu_ctx* ctx); /* ctx may be NULL *
 /* ASCII -> packed SoA rows (host code; the repack a patched worker loop does
  * on its ReadPack before submit).  seqs[i]/quals[i] need not be 0-terminated.
  * Returns FASTP_GPU_E_ALPHABET (and the index in *bad_read if non-NULL) when a
- * base outside {A,C,G,T,N} is met, FASTP_GPU_E_TOO_LONG when lens[i] > max_len. */
+ * base outside {A,C,G,T,N} or a quality character outside '!'..'~' (33..126) is met - the host
+ * routes such packs to its own loop -, FASTP_GPU_E_TOO_LONG when lens[i] > max_len. */
 int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
                          const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out,
                          uint16_t* len_out, int32_t* bad_read);
@@ -329,7 +330,7 @@ int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char
  * All pointers except `info` are DEVICE pointers; synchronous. */
 typedef struct fastp_gpu_parse_info {
     int32_t n_records;   /* records packed                                              */
-    int32_t first_bad;   /* index of the first malformed / over-long / non-ACGTN record, or -1 */
+    int32_t first_bad;   /* index of the first malformed / over-long / non-ACGTN / quality outside '!'..'~' record, or -1 */
     int64_t consumed;    /* bytes of text the records cover (offset of the next record)  */
     int64_t n_lines;     /* line terminators seen (+1 for an unterminated last line)     */
 } fastp_gpu_parse_info;

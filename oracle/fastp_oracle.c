@@ -520,6 +520,25 @@ int fastp_oracle_dup_hash(int level, const char* s1, int l1, const char* s2, int
     return num;
 }
 
+/* the bit positions (hash mod mBufLenInBits) of n pairs / reads: out[n][bufNum].  The stateless half of
+ * Duplicate::checkPair / checkRead, callable from several threads - lets a test at BASELINE scale run the
+ * per-read part of the oracle on chunks in parallel and still check the (stream-ordered) duplicate decisions. */
+int fastp_oracle_dup_bits_batch(int level, int n, int row_stride, const char* seq1, const int32_t* len1,
+                                const char* seq2, const int32_t* len2, uint64_t* out) {
+    uint64_t bytes; int num;
+    orc_dup_geometry(level, &bytes, &num);
+    uint64_t* primes = orc_dup_primes(num);
+    const uint64_t mask = (uint64_t)ORC_PRIME_ARRAY_LEN * num - 1, bits = bytes << 3;
+    for (int g = 0; g < n; g++) {
+        uint64_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        orc_seq2intvector(primes, num, mask, seq1 + (size_t)g * row_stride, len1[g], h, 0);
+        if (seq2) orc_seq2intvector(primes, num, mask, seq2 + (size_t)g * row_stride, len2[g], h, len1[g]);
+        for (int i = 0; i < num; i++) out[(size_t)g * num + i] = h[i] % bits;
+    }
+    free(primes);
+    return num;
+}
+
 static orc_dup* orc_dup_create(int level) {
     orc_dup* d = (orc_dup*)calloc(1, sizeof(orc_dup));
     orc_dup_geometry(level, &d->bufLenInBytes, &d->bufNum);

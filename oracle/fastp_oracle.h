@@ -72,6 +72,10 @@ int fastp_oracle_pass_filter(const fastp_gpu_params* p, const char* seq, const c
 int fastp_oracle_dup_hash(int accuracy_level, const char* s1, int l1, const char* s2, int l2,
                           uint64_t* out);
 
+/* bit positions of n units in every bloom buffer, out[n][bufnum] (stateless; returns bufnum) */
+int fastp_oracle_dup_bits_batch(int accuracy_level, int n, int row_stride, const char* seq1, const int32_t* len1,
+                                const char* seq2, const int32_t* len2, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,22 @@ CASES = {
                             {"polyx_frac": 0.3}),
 }
 
+# inputs on which the reference's one-gap code ACCEPTS (synth.indel_overlap_pairs / adapter_indel_reads): the
+# closed-form device versions of Matcher::diffWithOneInsertion / matchWithOneInsertion take their positive branch
+CASES["pe_allow_gap_indel"] = (True, ["-G", "--allow_gap_overlap_trimming"], _pe(allow_gap_overlap_trimming=1),
+                               {"gen": "indel_overlap"})
+CASES["pe_allow_gap_indel_corr"] = (True, ["-G", "--allow_gap_overlap_trimming", "-c", "--overlap_len_require", "20",
+                                           "--overlap_diff_limit", "7", "--overlap_diff_percent_limit", "30"],
+                                    _pe(allow_gap_overlap_trimming=1, correction=1, overlap_require=20, overlap_diff_limit=7,
+                                        overlap_diff_percent_limit=30), {"gen": "indel_overlap"})
+CASES["se_adapter_indel"] = (False, ["-G", "-a", ADAPTER_R1], _se(adapter_seq_r1=ADAPTER_R1.encode()),
+                             {"gen": "adapter_indel"})
+CASES["pe_adapter_indel"] = (True, ["-G", "-a", ADAPTER_R1, "--adapter_sequence_r2", ADAPTER_R2],
+                             _pe(adapter_seq_r1=ADAPTER_R1.encode(), adapter_seq_r2=ADAPTER_R2.encode()),
+                             {"gen": "adapter_indel"})
+# least number of one-gap ACCEPTS the oracle must report on 20 000 units of these inputs (tests assert it)
+GAP_CASES = ("pe_allow_gap_indel", "pe_allow_gap_indel_corr", "se_adapter_indel", "pe_adapter_indel")
+
 # --adapter_fasta: contigs as the FASTA file lists them; Options::loadFastaAdapters keeps them in
 # contig-name order (std::map), >= 6 bp, de-duplicated (options.cpp:50-83)
 FASTA_CONTIGS = [("a_truseq_r2", ADAPTER_R2), ("b_truseq_r1", ADAPTER_R1), ("c_nextera", "CTGTCTCTTATACACATCT"),
@@ -109,7 +125,9 @@ CASES["pe_overrep_merge_unmerged"] = (True, ["-G", "-p", "-P", "2", "-m", "--inc
                                       {"insert_mean": 260.0, "insert_sd": 90.0, "polyx_frac": 0.3, "dup_frac": 0.3})
 OVERREP = {"pe_overrep": 3, "se_overrep": 2, "pe_overrep_correction": 3, "pe_overrep_merge": 2, "pe_overrep_merge_unmerged": 2}
 N_PAIRS_OVERRIDE = {"pe_overrep": 1500, "se_overrep": 1500, "pe_overrep_correction": 1500, "pe_overrep_merge": 1500,
-                    "pe_overrep_merge_unmerged": 1500}   # golden input size (default 500)
+                    "pe_overrep_merge_unmerged": 1500,
+                    "pe_allow_gap_indel": 1500, "pe_allow_gap_indel_corr": 1500, "se_adapter_indel": 1500,
+                    "pe_adapter_indel": 1500}   # golden input size (default 500)
 
 
 class _ArrayBatch:

@@ -56,8 +56,35 @@ def lib():
     L.fastp_oracle_dup_hash.restype = C.c_int
     L.fastp_oracle_dup_hash.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int,
                                         C.POINTER(C.c_uint64)]
+    L.fastp_oracle_dup_bits_batch.restype = C.c_int
+    L.fastp_oracle_dup_bits_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
     _LIB = L
     return L
+
+
+def sequential_duplicates(level, seq1, len1, seq2=None, len2=None):
+    """Duplicate::checkPair + applyBloomFilter (duplicate.cpp:122-163) over a whole stream at once: unit g is a
+    duplicate iff in EVERY buffer its bit was set by an earlier unit, i.e. some earlier unit has the same bit
+    position.  Bit positions from the oracle's hash; the stream order by first occurrence (numpy)."""
+    n = len(len1)
+    bufnum = {1: 2, 2: 2, 3: 4, 4: 4, 5: 4, 6: 8}.get(int(level), 2)
+    seq1 = np.ascontiguousarray(seq1, dtype=np.uint8)
+    len1 = np.ascontiguousarray(len1, dtype=np.int32)
+    pos = np.zeros((n, bufnum), dtype=np.uint64)
+    if seq2 is not None:
+        seq2 = np.ascontiguousarray(seq2, dtype=np.uint8)
+        len2 = np.ascontiguousarray(len2, dtype=np.int32)
+    got = lib().fastp_oracle_dup_bits_batch(int(level), n, int(seq1.shape[1]), seq1.ctypes.data, len1.ctypes.data,
+                                            seq2.ctypes.data if seq2 is not None else None,
+                                            len2.ctypes.data if seq2 is not None else None, pos.ctypes.data)
+    assert got == bufnum
+    dup = np.ones(n, dtype=bool)
+    idx = np.arange(n)
+    for i in range(bufnum):
+        _, first, inv = np.unique(pos[:, i], return_index=True, return_inverse=True)
+        dup &= first[inv] < idx
+    return dup
 
 
 def layout(cycles, insert_size_max):

@@ -20,8 +20,12 @@ def _adapter_pad(adapter, L):
 
 def synth_pairs(n, L=150, seed=42, insert_mean=300.0, insert_sd=80.0, insert_min=20, insert_max=800,
                 polyg_frac=0.0, polyx_frac=0.0, dup_frac=0.10, ragged_frac=0.02, n_rate=0.5,
-                lowq_site_rate=0.03, paired=True):
+                lowq_site_rate=0.03, paired=True, gen=None):
     """returns dict(seq1,qual1,len1[,seq2,qual2,len2]) as ASCII uint8 [n, stride] + int32 lens"""
+    if gen == "indel_overlap":   # parity cases that need single-base indels (the one-gap ACCEPT paths)
+        return indel_overlap_pairs(n, L=L, seed=seed)
+    if gen == "adapter_indel":
+        return adapter_indel_reads(n, L=L, seed=seed, paired=paired)
     rng = np.random.default_rng(seed)
     stride = (L + 7) // 8 * 8
     ins = np.clip(np.rint(rng.normal(insert_mean, insert_sd, n)), insert_min, insert_max).astype(np.int64)
@@ -156,6 +160,127 @@ def overlap_pairs(n, L=150, seed=1, err=0.03, n_rate=0.02):
         seq[:, :L] = np.where(valid, s, 0)
         qual[:, :L] = np.where(valid, q + 33, 0)
         outs["seq" + tag], outs["qual" + tag], outs["len" + tag] = seq, qual, lens
+    return outs
+
+
+def _finish(c, lens, q, L):
+    """ACGT codes [n, L] + lengths + phred qualities -> padded ASCII rows"""
+    n = len(lens)
+    stride = (L + 7) // 8 * 8
+    j = np.arange(L)[None, :]
+    valid = j < lens[:, None]
+    seq = np.zeros((n, stride), dtype=np.uint8)
+    qual = np.zeros((n, stride), dtype=np.uint8)
+    seq[:, :L] = np.where(valid, _ACGT[c], 0)
+    qual[:, :L] = np.where(valid, q + 33, 0)
+    return seq, qual, lens.astype(np.int32)
+
+
+def _indel_rows(c, kind, pos, rng):
+    """one-base insertion (kind 1: a random base enters at pos, the tail moves right and loses its last base) or
+    deletion (kind 2: base pos leaves, the tail moves left, a random base fills the end) per row; kind 0: untouched"""
+    n, L = c.shape
+    j = np.arange(L)[None, :]
+    p = pos[:, None]
+    src_ins = np.where(j > p, j - 1, j)
+    src_del = np.where(j >= p, np.minimum(j + 1, L - 1), j)
+    ins = np.take_along_axis(c, src_ins, axis=1)
+    ins = np.where(j == p, rng.integers(0, 4, size=(n, 1)), ins)
+    dele = np.take_along_axis(c, src_del, axis=1)
+    dele[:, L - 1] = rng.integers(0, 4, size=n)
+    k = kind[:, None]
+    return np.where(k == 1, ins, np.where(k == 2, dele, c)).astype(np.uint8)
+
+
+def indel_overlap_pairs(n, L=150, seed=1, gap_limit=5):
+    """pairs on which OverlapAnalysis::analyze's one-gap pass (overlapanalysis.cpp:91-139) ACCEPTS.
+    Matcher::diffWithOneInsertion (matcher.cpp:56-100) returns -1 as soon as the UNGAPPED mismatch count of a
+    prefix plus the last shifted position exceeds the limit - also after a good split was seen - so the pass only
+    accepts where the ungapped count over the first overlap_len-2 positions is within the limit while the
+    ungapped scan (first min(overlap_len, 50) positions, :34-44) was over it: short overlaps (<= 51) whose last two
+    positions mismatch.  Built here: overlap lengths around 30..51 on both sides (read-through = negative offset,
+    where the accepted result trims adapters, and barely-overlapping = positive offset), k substitutions in the body
+    of the overlap with k around gap_limit, 0..2 substitutions on the last two overlap positions, in either mate;
+    plus single-base insertions / deletions and clean pairs as controls."""
+    rng = np.random.default_rng(seed)
+    j = np.arange(L)[None, :]
+    ol = rng.integers(20, 60, size=n)
+    ins = np.where(rng.random(n) < 0.6, ol, 2 * L - ol)     # fragment length: overlap = min(ins, L) - max(0, ins - L)
+    F = rng.integers(0, 4, size=(n, 2 * L + 1), dtype=np.uint8)
+    rnd1 = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    rnd2 = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    c1 = np.where(j < ins[:, None], np.take_along_axis(F, np.minimum(j, 2 * L) + np.zeros((n, 1), dtype=np.int64), axis=1), rnd1)
+    i2 = np.clip(ins[:, None] - 1 - j, 0, 2 * L)
+    c2 = np.where(j < ins[:, None], _COMP_CODE[np.take_along_axis(F, i2, axis=1)], rnd2)
+    # the overlap is r1[a, a+ol) against rc(r2[a, a+ol)): overlap position t sits at r1[a+t] and at r2[a+ol-1-t]
+    a = np.maximum(0, ins - L)
+    t = j - a[:, None]                                      # overlap coordinate of r1[j]
+    k = np.clip(gap_limit + rng.integers(-3, 3, size=n), 0, None)
+    body = (t >= 0) & (t < (ol - 2)[:, None])
+    score = np.where(body, rng.random((n, L)), 2.0)
+    kth = np.sort(score, axis=1)[np.arange(n), np.minimum(k, L - 1)]
+    sub_body = body & (score < kth[:, None]) & (k[:, None] > 0)
+    tail = ((t == (ol - 2)[:, None]) & (rng.random((n, 1)) < 0.75)) | ((t == (ol - 1)[:, None]) & (rng.random((n, 1)) < 0.75))
+    sub = sub_body | tail                                   # in overlap coordinates, stored on r1's row index
+    bump = rng.integers(1, 4, size=(n, L)).astype(np.uint8)  # a substitution always changes the base
+    in_r1 = rng.random((n, L)) < 0.5
+    c1 = np.where(sub & in_r1, (c1 + bump) & 3, c1).astype(np.uint8)
+    # the same overlap positions on r2: r2 index a + ol - 1 - t
+    j2 = a[:, None] + ol[:, None] - 1 - t
+    sub2 = np.zeros((n, L), dtype=bool)
+    rows = np.repeat(np.arange(n)[:, None], L, axis=1)
+    ok = sub & ~in_r1 & (j2 >= 0) & (j2 < L)
+    sub2[rows[ok], j2[ok]] = True
+    c2 = np.where(sub2, (c2 + bump) & 3, c2).astype(np.uint8)
+    # controls: 10 % carry a real single-base indel in the body instead
+    ind = rng.random(n) < 0.10
+    kind = np.where(ind, rng.integers(1, 3, size=n), 0)
+    mate = rng.integers(0, 2, size=n)
+    ti = (rng.random(n) * np.maximum(1, ol - 4)).astype(np.int64) + 2
+    c1 = _indel_rows(c1, np.where(mate == 0, kind, 0), np.clip(a + ti, 0, L - 2), rng)
+    c2 = _indel_rows(c2, np.where(mate == 1, kind, 0), np.clip(a + ol - 1 - ti, 0, L - 2), rng)
+    outs = {}
+    for tag, c in (("1", c1), ("2", c2)):
+        lens = np.where(rng.random(n) < 0.9, L, rng.integers(L - 20, L + 1, size=n)).astype(np.int32)
+        q = np.where(rng.random((n, L)) < 0.05, rng.integers(2, 15, size=(n, L)), rng.integers(30, 41, size=(n, L)))
+        outs["seq" + tag], outs["qual" + tag], outs["len" + tag] = _finish(c, lens, q, L)
+    return outs
+
+
+def adapter_indel_reads(n, L=150, seed=1, paired=True):
+    """reads that BEGIN with the adapter carrying one inserted / one deleted base: AdapterTrimmer::trimBySequence's
+    one-gap loops compare the read from position 0 whatever `pos` is (adaptertrimmer.cpp:105-135, quirk #7), so
+    these are the inputs on which Matcher::matchWithOneInsertion accepts.  The adapter prefix length varies
+    (the compare length shrinks with pos, so a short clean prefix matches late in the loop), some reads are
+    shorter than the adapter, and controls carry the exact adapter at 0 / at -1..-4 / further inside."""
+    rng = np.random.default_rng(seed)
+    j = np.arange(L)[None, :]
+    outs = {}
+    for tag, adapter in (("1", ADAPTER_R1), ("2", ADAPTER_R2)) if paired else (("1", ADAPTER_R1),):
+        acode = np.array([b"ACGT".index(ch) for ch in adapter], dtype=np.uint8)
+        alen = len(acode)
+        c = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+        what = rng.random(n)
+        m = rng.integers(10, alen + 1, size=n)                     # adapter bases placed at the read start
+        apad = np.concatenate([acode, rng.integers(0, 4, size=L, dtype=np.uint8)])
+        head = (what < 0.85)
+        c = np.where(head[:, None] & (j < m[:, None]), apad[np.minimum(j, len(apad) - 1)], c)
+        kind = np.where(what < 0.35, 1, np.where(what < 0.7, 2, 0))  # 35 % insertion, 35 % deletion, 15 % exact, rest random
+        pos = 2 + (rng.random(n) * np.maximum(1, m - 5)).astype(np.int64)
+        c = _indel_rows(c, kind, pos, rng)
+        # a few exact adapters shifted left by 1..4 (the Hamming scan's negative start) or placed inside the read
+        shl = (what >= 0.7) & (what < 0.76)
+        sh = rng.integers(1, 5, size=n)
+        c = np.where(shl[:, None], np.take_along_axis(c, np.minimum(j + sh[:, None], L - 1), axis=1), c)
+        inner = what >= 0.9
+        at = rng.integers(20, L - 10, size=n)
+        c = np.where(inner[:, None] & (j >= at[:, None]), apad[np.clip(j - at[:, None], 0, len(apad) - 1)], c)
+        e = rng.random((n, L)) < 0.01 * rng.random((n, 1))
+        c = np.where(e, rng.integers(0, 4, size=(n, L)), c).astype(np.uint8)
+        r = rng.random(n)
+        lens = np.where(r < 0.6, L, np.where(r < 0.8, rng.integers(0, alen + 8, size=n), rng.integers(0, L + 1, size=n))).astype(np.int32)
+        q = np.where(rng.random((n, L)) < 0.05, rng.integers(2, 15, size=(n, L)), rng.integers(30, 41, size=(n, L)))
+        outs["seq" + tag], outs["qual" + tag], outs["len" + tag] = _finish(c, lens, q, L)
     return outs
 
 

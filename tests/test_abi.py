@@ -92,6 +92,13 @@ def test_pack_reads_layout_and_errors(lib):
     with pytest.raises(engine.EngineError) as e:
         engine.pack_ascii(lib, 150, bad, d["qual1"], d["len1"])
     assert e.value.code == abi.E_ALPHABET
+    # quality characters outside '!'..'~' are refused too (the kernels take q - 33 as an unsigned counter field)
+    for qbad in (32, 10, 127, 200):
+        badq = d["qual1"].copy()
+        badq[11, 5] = qbad
+        with pytest.raises(engine.EngineError) as e:
+            engine.pack_ascii(lib, 150, d["seq1"], badq, d["len1"])
+        assert e.value.code == abi.E_ALPHABET, qbad
     with pytest.raises(engine.EngineError) as e:
         engine.pack_ascii(lib, 100, d["seq1"], d["qual1"], d["len1"])
     assert e.value.code == abi.E_TOO_LONG

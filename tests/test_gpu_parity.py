@@ -9,6 +9,7 @@ import pytest
 import cases
 import driver
 import engines
+import gap_util
 import golden_util
 import oraclelib
 import synth
@@ -327,6 +328,106 @@ def test_gpu_full_size_properties():
         assert np.array_equal(cyc[24:32].sum(0), cyc[33])
         assert cyc[32].sum() == ctr[base + lay.st_length_sum]
         assert ctr[base + lay.st_qual_hist: base + lay.st_qual_hist + 128].sum() == cyc[32].sum()
+
+
+@pytest.mark.parametrize("name", cases.GAP_CASES)
+def test_gpu_one_gap_accept_paths(name):
+    """Matcher::diffWithOneInsertion / matchWithOneInsertion ACCEPT on these inputs: the oracle's positives are
+    counted first (so the comparison cannot pass on "both said no"), then every record and counter is compared"""
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(20000, L=150, seed=177, paired=paired, **skw)
+    params = pf(150)
+    o = oraclelib.Oracle(params)
+    ro = o.process(*_args(d, paired))
+    o.close()
+    if "allow_gap" in name:
+        tot, neg = gap_util.gap_overlap_pairs(d, params, limit=6000)
+        assert tot > 100 and neg > 100, f"{name}: only {tot} one-gap overlaps ({neg} with a negative offset) in 6000 pairs"
+        assert gap_util.gap_trimmed_pairs(ro[0], ro[2]) > 100
+    else:
+        assert gap_util.gap_adapter_trims(d["seq1"], d["len1"], ro[0], cases.ADAPTER_R1.encode()) > 1000
+        if paired:
+            assert gap_util.gap_adapter_trims(d["seq2"], d["len2"], ro[1], cases.ADAPTER_R2.encode()) > 1000
+    _compare(name, params, d, paired)
+
+
+def test_gpu_equals_oracle_at_baseline_scale():
+    """BASELINE configs[2] options (auto-adapter by overlap + --cut_right, duplicate evaluation, default filters)
+    on >= 4 M synthetic 2x150 pairs against the ORACLE - every record, every counter, every duplicate decision -
+    so that the driver-run suite carries parity at bench scale, not only properties.  The per-read part of the
+    oracle runs on contiguous chunks in parallel threads (its counters add); the stream-ordered duplicate decisions
+    are checked against oraclelib.sequential_duplicates over the whole stream."""
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    sys.path.insert(0, os.path.join(engines.ROOT, "tools"))
+    import synth_torch
+    total = int(os.environ.get("FASTP_SCALE_PAIRS", str(4 * 1024 * 1024)))
+    chunk = 256 * 1024
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    dev = torch.device("cuda", 0)
+    g = engines.gpu_engine(p)
+    parts, recs = [], []
+    for k, start in enumerate(range(0, total, 1024 * 1024)):
+        n = min(1024 * 1024, total - start)
+        d = synth_torch.synth_pairs_torch(n, L=150, seed=7000 + k, device=dev)
+        s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], 150)
+        s2, q2, l2 = synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], 150)
+        torch.cuda.synchronize(dev)
+        r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        r2 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        pr = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+        nc = torch.zeros(1, dtype=torch.int32, device=dev)
+        b = abi.Batch()
+        b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+        b.seq1, b.qual1, b.len1 = s1.data_ptr(), q1.data_ptr(), l1.data_ptr()
+        b.seq2, b.qual2, b.len2 = s2.data_ptr(), q2.data_ptr(), l2.data_ptr()
+        res = abi.Results()
+        res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
+        res.corrections, res.corrections_capacity, res.n_corrections = None, 0, nc.data_ptr()
+        g.submit_device(b, res)
+        g.synchronize()
+        torch.cuda.synchronize(dev)
+        recs.append((r1.cpu().numpy().view(abi.READ_RESULT_DTYPE), r2.cpu().numpy().view(abi.READ_RESULT_DTYPE),
+                     pr.cpu().numpy().view(abi.PAIR_RESULT_DTYPE)))
+        pad = lambda a: np.pad(a.cpu().numpy(), ((0, 0), (0, 2)))
+        parts.append({kk: (pad(d[kk]) if kk[0] in "sq" else d[kk].cpu().numpy().astype(np.int32)) for kk in
+                      ("seq1", "qual1", "len1", "seq2", "qual2", "len2")})
+        del d, s1, q1, l1, s2, q2, l2
+    cg = g.counters()
+    lay = g.layout
+    g.close()
+    rg = [np.concatenate([r[k] for r in recs]) for k in range(3)]
+    full = {kk: np.concatenate([pt[kk] for pt in parts]) for kk in parts[0]}
+    del parts, recs
+
+    def oracle_chunk(lo):
+        hi = min(total, lo + chunk)
+        o = oraclelib.Oracle(p)
+        r = o.process(full["seq1"][lo:hi], full["qual1"][lo:hi], full["len1"][lo:hi], full["seq2"][lo:hi],
+                      full["qual2"][lo:hi], full["len2"][lo:hi], corr_capacity=16)
+        c = o.counters()
+        o.close()
+        return r[:3], c
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        outs = list(ex.map(oracle_chunk, range(0, total, chunk)))
+    co = np.zeros_like(cg)
+    for _, c in outs:
+        co += c
+    co[:4] = outs[0][1][:4]          # header words (ABI version, cycles, ...) are not additive
+    dup = oraclelib.sequential_duplicates(p.dup_accuracy_level, full["seq1"], full["len1"], full["seq2"], full["len2"])
+    for k, what in enumerate(("read1 results", "read2 results", "pair results")):
+        ro = np.concatenate([o[0][k] for o in outs])
+        if k < 2:   # the chunk oracles each started with an empty bloom filter: take the stream's decision
+            ro["flags"] = (ro["flags"] & ~np.uint8(abi.RF_DUP)) | np.where(dup, abi.RF_DUP, 0).astype(np.uint8)
+        bad = np.nonzero(ro != rg[k])[0]
+        assert len(bad) == 0, f"{what} differ at {len(bad)} of {total}, first {bad[:5]}: oracle {ro[bad[:3]]} gpu {rg[k][bad[:3]]}"
+    co[lay.dup_count] = int(dup.sum())
+    bad = np.nonzero(co != cg)[0]
+    assert len(bad) == 0, f"{len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
+    assert cg[lay.dup_total] == total and dup.sum() > total // 50
 
 
 def test_gpu_counter_export_import_merge_rehearsal():

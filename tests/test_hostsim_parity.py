@@ -7,6 +7,7 @@ import pytest
 import cases
 import driver
 import engines
+import gap_util
 import golden_util
 import oraclelib
 import refjson
@@ -40,6 +41,31 @@ def test_sim_records_and_counters_equal_oracle(name):
     so = np.sort(ro[3], order=["read", "pos"])
     sg = np.sort(rg[3], order=["read", "pos"])
     assert np.array_equal(so, sg), f"{name}: correction lists differ"
+    assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
+
+
+@pytest.mark.parametrize("name", cases.GAP_CASES)
+def test_sim_one_gap_accept_paths(name):
+    """the oracle must ACCEPT one-gap overlaps / one-gap adapter matches on these inputs (counted), then the
+    device code's closed-form versions are compared on them"""
+    paired, flags, pf, skw = cases.CASES[name]
+    n = 3000
+    d = synth.synth_pairs(n, L=150, seed=31, paired=paired, **skw)
+    params = pf(150)
+    ro, rg, co, cg = _both(params, d, paired)
+    if "allow_gap" in name:
+        tot, neg = gap_util.gap_overlap_pairs(d, params)
+        assert tot > 100 and neg > 40, f"{name}: only {tot} one-gap overlaps ({neg} with a negative offset)"
+        assert gap_util.gap_trimmed_pairs(ro[0], ro[2]) > 40
+    else:
+        assert gap_util.gap_adapter_trims(d["seq1"], d["len1"], ro[0], cases.ADAPTER_R1.encode()) > 500
+        if paired:
+            assert gap_util.gap_adapter_trims(d["seq2"], d["len2"], ro[1], cases.ADAPTER_R2.encode()) > 500
+    for k, what in enumerate(("r1", "r2", "pair")):
+        if ro[k] is not None:
+            bad = np.nonzero(ro[k] != rg[k])[0]
+            assert len(bad) == 0, f"{name}: {what} differs at {bad[:5]}: oracle {ro[k][bad[:3]]} device {rg[k][bad[:3]]}"
+    assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"]))
     assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
 
 
@@ -215,7 +241,7 @@ def test_sim_device_fastq_parse_chunks_limits_and_errors():
     assert info.n_records == 7 and info.consumed == exp[5] and np.array_equal(qual, exp[1])
     # malformed chunks are refused, never repaired on the device
     lines = txt.split(b"\r\n")
-    for mutate in ("name", "plus", "length", "alphabet", "toolong"):
+    for mutate in ("name", "plus", "length", "alphabet", "toolong", "qual_low", "qual_del"):
         ls = list(lines)
         if mutate == "name":
             ls[4 * 5] = b"X" + ls[4 * 5][1:]
@@ -225,6 +251,10 @@ def test_sim_device_fastq_parse_chunks_limits_and_errors():
             ls[4 * 5 + 3] = ls[4 * 5 + 3][:-1]
         elif mutate == "alphabet":
             ls[4 * 5 + 1] = b"R" + ls[4 * 5 + 1][1:]
+        elif mutate == "qual_low":    # below '!'
+            ls[4 * 5 + 3] = ls[4 * 5 + 3][:6] + b" " + ls[4 * 5 + 3][7:]
+        elif mutate == "qual_del":    # above '~'
+            ls[4 * 5 + 3] = ls[4 * 5 + 3][:9] + b"\x7f" + ls[4 * 5 + 3][10:]
         else:
             ls[4 * 5 + 1] = ls[4 * 5 + 1] + b"ACGT" * 10
             ls[4 * 5 + 3] = ls[4 * 5 + 3] + b"IIII" * 10
