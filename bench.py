@@ -41,12 +41,13 @@ def bench_params():
     return p, ["-G", "--cut_right"]
 
 
-def cpu_baseline(sample_pairs, flags, params):
+def cpu_baseline(sample_pairs, flags, params, dev):
     """reference fastp (oracle/_ref/fastp_ref, scalar-SIMD shim build) on the host cores, on a bounded
-    sample of the same workload; falls back to the plain-C oracle port if the binary is absent."""
+    sample of the same workload (generated on the GPU, written to tmpfs as plain FASTQ); falls back to the
+    plain-C oracle port on a smaller sample if the binary is absent."""
     import numpy as np
+    import torch
     import synth_torch
-    d = synth_torch.synth_pairs_torch(sample_pairs, L=L, seed=4242, device="cpu")
     ref = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
     cores = min(os.cpu_count() or 1, 16)   # the reference stops scaling long before that (reader-thread bound)
     if os.path.exists(ref):
@@ -62,16 +63,22 @@ def cpu_baseline(sample_pairs, flags, params):
                 pass
         tmp = tempfile.mkdtemp(prefix="fastp_cpu_", dir=base)
         f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
-        with open(f1, "wb") as f:
-            f.write(synth_torch.to_fastq_bytes(d["seq1"], d["qual1"], 1))
-        with open(f2, "wb") as f:
-            f.write(synth_torch.to_fastq_bytes(d["seq2"], d["qual2"], 2))
+        block = 1_000_000
+        with open(f1, "wb", buffering=0) as a, open(f2, "wb", buffering=0) as b:
+            for done in range(0, sample_pairs, block):
+                k = min(block, sample_pairs - done)
+                d = synth_torch.synth_pairs_torch(k, L=L, seed=4242 + done // block, device=dev)
+                for mate, fh in ((1, a), (2, b)):
+                    rec = synth_torch.to_fastq_tensor(d[f"seq{mate}"], d[f"qual{mate}"], mate, first=done).cpu().numpy()
+                    fh.write(memoryview(rec).cast("B"))
+                del d
+        torch.cuda.empty_cache()
         cmd = [ref, "-i", f1, "-I", f2, "-o", os.path.join(tmp, "o1.fq"), "-O", os.path.join(tmp, "o2.fq"),
                "-j", os.path.join(tmp, "r.json"), "-h", os.path.join(tmp, "r.html"), "-w", str(cores)] + flags
         times = []
         for _ in range(2):
             t0 = time.time()
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300)
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
             times.append(time.time() - t0)
         for fn in os.listdir(tmp):
             os.unlink(os.path.join(tmp, fn))
@@ -80,12 +87,15 @@ def cpu_baseline(sample_pairs, flags, params):
         return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": cores,
                 "kind": "reference",
                 "sample": f"{sample_pairs} synthetic 2x{L} pairs, plain FASTQ -> FASTQ on tmpfs, fastp_ref -w {cores} "
-                          f"(scalar shim for Highway SIMD), end-to-end wall incl. FASTQ parse/write, best of 2"}
+                          f"(scalar shim for Highway SIMD), end-to-end wall incl. FASTQ parse/write and the "
+                          f"reference's start-up (bloom allocation, pre-pass), best of 2"}
     import oraclelib
+    sample_pairs = min(sample_pairs, 500_000)
+    d = synth_torch.synth_pairs_torch(sample_pairs, L=L, seed=4242, device=dev)
     orc = oraclelib.Oracle(params)
-    pad = lambda a: np.pad(a.numpy(), ((0, 0), (0, 2)))
+    pad = lambda a: np.pad(a.cpu().numpy(), ((0, 0), (0, 2)))
     t0 = time.time()
-    orc.process(pad(d["seq1"]), pad(d["qual1"]), d["len1"].numpy(), pad(d["seq2"]), pad(d["qual2"]), d["len2"].numpy())
+    orc.process(pad(d["seq1"]), pad(d["qual1"]), d["len1"].cpu().numpy(), pad(d["seq2"]), pad(d["qual2"]), d["len2"].cpu().numpy())
     wall = time.time() - t0
     orc.close()
     return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
@@ -97,29 +107,67 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def respawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvp(cmd[0], cmd)
+
+
+class ResidentBatch:
+    """one batch of B pairs in HBM: packed rows + the abi.Batch that points at them"""
+
+    def __init__(self, B, seed, dev):
+        import torch
+        import synth_torch
+        from fastp_amd import abi
+        d = synth_torch.synth_pairs_torch(B, L=L, seed=seed, device=dev)
+        self.t = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], L) + synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], L)
+        del d
+        b = abi.Batch()
+        b.n, b.flags = B, abi.BATCH_STAT_ISIZE
+        b.seq1, b.qual1, b.len1 = (x.data_ptr() for x in self.t[:3])
+        b.seq2, b.qual2, b.len2 = (x.data_ptr() for x in self.t[3:])
+        self.batch = b
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=720, help="timed steps; a step = one batch through the hot path")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=4 * 1024 * 1024, help="pairs per step per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=500_000)
+    ap.add_argument("--batches", type=int, default=24,
+                    help="distinct batches resident per GPU = one run (24 x 4 Mi = 100.7 M pairs: BASELINE configs[2]); steps "
+                         "cycle through them and the engine starts a new run (fresh bloom filter, counters) after each cycle")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        respawn_ranks(args.gpus)           # does not return
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
     import torch
     import __graft_entry__ as graft
     from fastp_amd import abi, engine, multigpu
     import synth_torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm; "gloo" only for rehearsals
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm; "gloo" only for rehearsals
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -127,7 +175,7 @@ def main():
             dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    if os.environ.get("BENCH_BACKEND", "nccl") != "nccl":
+    if backend != "nccl":
         local = local % torch.cuda.device_count()            # rehearsal of the N>1 path on fewer GPUs
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -139,55 +187,98 @@ def main():
     params, ref_flags = bench_params()
     log("creating engine")
     eng = engine.GpuEngine(params, device=local)
-    log("generating batch")
     B = args.pairs
-    d = synth_torch.synth_pairs_torch(B, L=L, seed=42 + rank, device=dev)
-    s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], L)
-    s2, q2, l2 = synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], L)
-    del d
+    NB = max(1, min(args.batches, max(args.steps, args.warmup)))
+    log(f"generating {NB} resident batches of {B} pairs")
+    resident = [ResidentBatch(B, 42 + 1000 * rank + k, dev) for k in range(NB)]
     r1 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
     r2 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
     pr = torch.zeros(B * 8, dtype=torch.uint8, device=dev)
     ncorr = torch.zeros(1, dtype=torch.int32, device=dev)
-    batch = abi.Batch()
-    batch.n, batch.flags = B, abi.BATCH_STAT_ISIZE
-    batch.seq1, batch.qual1, batch.len1 = s1.data_ptr(), q1.data_ptr(), l1.data_ptr()
-    batch.seq2, batch.qual2, batch.len2 = s2.data_ptr(), q2.data_ptr(), l2.data_ptr()
     res = abi.Results()
     res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
     res.corrections, res.corrections_capacity, res.n_corrections = None, 0, ncorr.data_ptr()
     torch.cuda.synchronize(dev)
     log("warmup")
 
-    # N>1: the exact sharded protocol - duplicate scan pass, bitmap all-gather, worker loop against
-    # the preceding shards' bitmaps - so that the merged result is that of one stream.  BENCH_SHARD=plain runs the
-    # per-shard submit instead (cross-shard duplicates missed); BENCH_SHARD=force runs the protocol at N=1 too.
+    # N>1: the exact sharded protocol - duplicate scan pass, bitmap prefix exchange, decision pass -
+    # so that the merged result is that of one stream.  BENCH_SHARD=plain runs the per-shard submit instead
+    # (cross-shard duplicates missed); BENCH_SHARD=force runs the protocol at N=1 too.
     shard_mode = os.environ.get("BENCH_SHARD", "exact")
     protocol = shard_mode == "force" or (shard_mode == "exact" and world > 1)
 
     # per-step duplicate scan state (17 B/pair), allocated once outside the timed region
-    scan_bufs = [torch.empty(max(16, eng.dup_scan_bytes(B)), dtype=torch.uint8, device=dev)
-                 for _ in range(max(args.steps, args.warmup))] if protocol else []
+    scan_bufs = [torch.empty(max(16, eng.dup_scan_bytes(B)), dtype=torch.uint8, device=dev) for _ in range(NB)] if protocol else []
 
     def run_steps(k):
-        if protocol:
-            multigpu.run_shard(eng, dist, rank, world, [batch] * k, [res] * k, dev, force=True, scans=scan_bufs[:k])
-        else:
-            for _ in range(k):
-                eng.submit_device(batch, res)
+        """k steps = k batches, cycling through the resident set; a cycle is one run of the engine"""
+        done = 0
+        while done < k:
+            m = min(NB, k - done)
+            if protocol:
+                multigpu.run_shard(eng, dist, rank, world, [rb.batch for rb in resident[:m]], [res] * m, dev, force=True,
+                                   scans=scan_bufs[:m])
+            else:
+                for rb in resident[:m]:
+                    eng.submit_device(rb.batch, res)
+            done += m
+            if done < k:
+                eng.reset()     # next run: fresh Duplicate bitmaps / Stats / FilterResult (inside the timed region)
 
+    def agree(failed):
+        """all ranks take the same branch after a failure on any of them"""
+        if dist is None:
+            return failed
+        t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    err = None
     try:
         run_steps(args.warmup)
     except Exception as e:   # e.g. a collective the installed RCCL build refuses: keep measuring, say so in the JSON line
         if not protocol:
             raise
-        print(f"[bench] exact sharded protocol failed on rank {rank} ({e!r}); falling back to per-shard submit", file=sys.stderr, flush=True)
+        err = e
+    if protocol and agree(err is not None):
+        print(f"[bench] exact sharded protocol failed on rank {rank} ({err!r}); falling back to per-shard submit", file=sys.stderr, flush=True)
         protocol = False
-        shard_mode = "plain (exact protocol failed: %s)" % type(e).__name__
+        shard_mode = "plain (exact protocol failed: %s)" % (type(err).__name__ if err else "on another rank")
+        eng.reset()
         run_steps(args.warmup)
+
+    # Stats::merge / FilterResult::merge across the GPUs: the C ABI's own RCCL all-reduce (fastp_gpu_allreduce);
+    # the communicator id travels over the launcher's process group.  BENCH_ALLREDUCE=torch takes the
+    # torch.distributed path (the only one for gloo rehearsals).
+    merge_how = "n/a"
     if dist is not None:
-        multigpu.allreduce_counters_device(eng, dist, dev)   # communicator set-up stays outside the timed region
+        use_cabi = backend == "nccl" and os.environ.get("BENCH_ALLREDUCE", "cabi") == "cabi"
+        cerr = None
+        if use_cabi:
+            try:
+                ids = [eng.comm_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                eng.comm_init(ids[0], world, rank)
+                eng.allreduce()                      # communicator set-up stays outside the timed region
+            except Exception as e:
+                cerr = e
+            if agree(cerr is not None):
+                print(f"[bench] fastp_gpu_allreduce unavailable on rank {rank} ({cerr!r}); using torch.distributed", file=sys.stderr, flush=True)
+                use_cabi = False
+        if not use_cabi:
+            multigpu.allreduce_counters_device(eng, dist, dev)
+        merge_how = "fastp_gpu_allreduce (RCCL, C ABI)" if use_cabi else f"torch.distributed all_reduce ({backend})"
+
+    def merge_counters():
+        if dist is None:
+            return
+        if use_cabi:
+            eng.allreduce()
+        else:
+            multigpu.allreduce_counters_device(eng, dist, dev)
+
     eng.synchronize()
+    eng.reset()
     eng.kernel_time()  # reset the event accumulator
 
     if dist is not None:
@@ -195,15 +286,14 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     run_steps(args.steps)
-    if dist is not None:
-        multigpu.allreduce_counters_device(eng, dist, dev)   # Stats::merge / FilterResult::merge
+    merge_counters()                                      # Stats::merge / FilterResult::merge
     eng.synchronize()
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -239,14 +329,18 @@ def main():
                                "insts_valu_per_pair": round(vj["insts_valu_per_launch"] / per_launch_pairs, 1)}
             except Exception:
                 compute = None
+        runs = args.steps / NB
         out = {
             "metric": "Mreads/sec (whole node), 2x150 bp PE, inputs resident in HBM", "value": round(value, 3),
             "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "PE 2x150 bp synthetic (fragment model), auto-adapter via overlap + --cut_right "
-                                   "quality trim, dup evaluation on, fastp default filters",
-                       "pairs_per_step_per_gpu": B, "read_len": L, "parallelism": f"shard x{world}",
+            "config": {"workload": f"BASELINE configs[2]: PE 2x150 bp synthetic (fragment model), {NB * B / 1e6:.1f} M distinct pairs per GPU "
+                                   f"per run ({NB} resident batches of {B}), auto-adapter via overlap + --cut_right quality trim, dup "
+                                   f"evaluation on, fastp default filters; {runs:.2f} runs timed back to back (fresh bloom filter and "
+                                   f"counters per run)",
+                       "pairs_per_run_per_gpu": NB * B, "pairs_per_step_per_gpu": B, "timed_pairs_total": total_pairs,
+                       "read_len": L, "parallelism": f"shard x{world}", "counter_merge": merge_how,
                        "cross_shard_duplicates": "exact (scan pass + bitmap prefix exchange + decision pass)" if protocol else
                                                  ("n/a" if world == 1 else "per shard: " + shard_mode)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -257,7 +351,9 @@ def main():
         if compute is not None:
             out["compute_roofline"] = compute
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params)
+            del resident
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params, dev)
         print(json.dumps(out))
     eng.close()
     if dist is not None:

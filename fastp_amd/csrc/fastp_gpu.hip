@@ -188,8 +188,12 @@ static void drain_events(fastp_gpu_ctx* ctx) {
     ctx->pending_events.clear();
 }
 
+// set by fq_comm.cpp once a communicator exists: lets fastp_gpu_destroy drop the context's rank
+extern "C" { void (*fastp_gpu_comm_destroy_hook)(fastp_gpu_ctx*) = nullptr; }
+
 extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     if (!ctx) return;
+    if (fastp_gpu_comm_destroy_hook) fastp_gpu_comm_destroy_hook(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_events(ctx);
@@ -862,6 +866,7 @@ extern "C" int fastp_gpu_bgzf_index(const uint8_t* h, int64_t nbytes, int32_t ma
         const int64_t hdr = 12 + (int64_t)xlen;
         if (bsize < hdr + 8) { info->first_bad = k; break; }
         if (pos + bsize > nbytes) break;  // member not complete yet
+        if (pos + bsize > 0xFFFFFFFFll) break;  // payload offsets are 32 bit: the caller indexes the rest from `consumed`
         const uint8_t* t = p + bsize - 8;
         const uint32_t c = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         const uint32_t n = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
@@ -1105,6 +1110,24 @@ extern "C" int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_
     HIP_TRY(ctx, hipMemcpy(ctx->d_ctr, src_device, (size_t)n * 8, hipMemcpyDeviceToDevice));
     const int64_t hdr[4] = {FASTP_GPU_ABI_VERSION, ctx->cl.cycles, ctx->dp.isize_max, 0};
     HIP_TRY(ctx, hipMemcpy(ctx->d_ctr, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_device(const fastp_gpu_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+extern "C" int fastp_gpu_reset(fastp_gpu_ctx* ctx) {
+    if (!ctx) return FASTP_GPU_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipDeviceSynchronize());  // submits may have used a caller-provided stream
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, (size_t)ctx->cl.total * 8, ctx->stream));
+    const int64_t hdr[4] = {FASTP_GPU_ABI_VERSION, ctx->cl.cycles, ctx->dp.isize_max, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ctr, hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->d_bitmap)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_bitmap, 0, (size_t)(ctx->dp.dup_bits >> 3) * ctx->dp.dup_bufnum, ctx->stream));
+    if (ctx->d_post_seen) HIP_TRY(ctx, hipMemsetAsync(ctx->d_post_seen, 0, sizeof(u64), ctx->stream));
+    ctx->units_seen = 0;
+    ctx->has_prefix = false;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return FASTP_GPU_OK;
 }
 

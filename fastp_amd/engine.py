@@ -22,6 +22,9 @@ EXPORTS = [
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
     "fastp_gpu_dup_prefix_set", "fastp_gpu_prefix_or_images", "fastp_gpu_submit_pass2_device", "fastp_gpu_stream_set_origin", "fastp_gpu_overrep_device",
+    "fastp_gpu_device", "fastp_gpu_reset",
+    "fastp_gpu_comm_id", "fastp_gpu_comm_init", "fastp_gpu_comm_init_local", "fastp_gpu_comm_destroy", "fastp_gpu_allreduce",
+    "fastp_gpu_exchange_dup_prefix", "fastp_gpu_comm_last_error",
 ]
 
 
@@ -286,6 +289,39 @@ class GpuEngine:
 
     def synchronize(self):
         self._check(self.lib.fastp_gpu_synchronize(self.h))
+
+    def reset(self):
+        """a new run on the same context (fresh Stats / FilterResult / Duplicate)"""
+        self._check(self.lib.fastp_gpu_reset(self.h))
+
+    # ---- collectives behind the C ABI (RCCL; csrc/fq_comm.cpp) ----
+    def _comm_check(self, rc):
+        if rc != 0:
+            self.lib.fastp_gpu_comm_last_error.restype = C.c_char_p
+            raise EngineError(rc, (self.lib.fastp_gpu_comm_last_error() or b"").decode())
+
+    def comm_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._comm_check(self.lib.fastp_gpu_comm_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, nranks: int, rank: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(comm_id)
+        self.lib.fastp_gpu_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self._comm_check(self.lib.fastp_gpu_comm_init(self.h, buf, nranks, rank))
+
+    def _ctx_array(self):
+        arr = (C.c_void_p * 1)(self.h)
+        return arr
+
+    def allreduce(self):
+        """Stats::merge / FilterResult::merge over the communicator (this process owns one rank)"""
+        self.lib.fastp_gpu_allreduce.argtypes = [C.c_void_p, C.c_int]
+        self._comm_check(self.lib.fastp_gpu_allreduce(self._ctx_array(), 1))
+
+    def exchange_dup_prefix(self):
+        self.lib.fastp_gpu_exchange_dup_prefix.argtypes = [C.c_void_p, C.c_int]
+        self._comm_check(self.lib.fastp_gpu_exchange_dup_prefix(self._ctx_array(), 1))
 
     def counters(self):
         out = np.zeros(self.layout.total, dtype=np.int64)

@@ -81,9 +81,12 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
         engine.synchronize()
         return 0
     defer = bool(engine.params.overrep_enabled)
+    post_before = 0
     if defer:
         for b in batches:
             b.flags |= abi.BATCH_DEFER_OVERREP
+        lay = engine.layout   # the engine's POST1 read counter is cumulative: this call's share is the difference
+        post_before = int(engine.counters()[lay.stats[1] + lay.st_reads])
     # pass 1: insert in input order, keep per-unit positions / "set earlier in this shard" masks
     # (without --dedup this already is the whole worker loop, minus the duplicate decision)
     if scans is None:
@@ -131,11 +134,15 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
     if defer:
         lay = engine.layout
         ctr = engine.counters()
-        mine = torch.tensor([sum(int(b.n) for b in batches), int(ctr[lay.stats[1] + lay.st_reads])], dtype=torch.int64,
+        mine = torch.tensor([sum(int(b.n) for b in batches), int(ctr[lay.stats[1] + lay.st_reads]) - post_before], dtype=torch.int64,
                             device=device)
         allpos = _all_gather_flat(dist, mine, world) if world > 1 else mine
-        before = allpos.cpu().view(world, 2)[:rank].sum(dim=0)
-        engine.stream_set_origin(int(before[0]), int(before[1]))
+        per_rank = allpos.cpu().view(world, 2)
+        before = per_rank[:rank].sum(dim=0)
+        # a later call on the same engines continues the stream after everything the earlier calls fed to ALL ranks
+        done_u, done_p = getattr(engine, "_shard_stream_done", (0, 0))
+        engine.stream_set_origin(done_u + int(before[0]), done_p + int(before[1]))
+        engine._shard_stream_done = (done_u + int(per_rank[:, 0].sum()), done_p + int(per_rank[:, 1].sum()))
         for b, r in zip(batches, results):
             engine.overrep_device(b, r)
         engine.synchronize()

@@ -242,13 +242,18 @@ class FastqPipeline:
             q_free.put((0, [b""] * nm, list(want)))
             out_free = [0, 1]
             done = False
+            drain = False              # every file is at EOF but the device still holds complete records
+            slot = 0
             while not done:
-                t0 = time.perf_counter()
-                item = q_full.get()
-                if isinstance(item, Exception):
-                    raise item
-                slot, fills = item
-                st["t_wait_read"] += time.perf_counter() - t0
+                if drain:
+                    fills = [(0, True)] * nm   # nothing new from the files: parse what was carried over
+                else:
+                    t0 = time.perf_counter()
+                    item = q_full.get()
+                    if isinstance(item, Exception):
+                        raise item
+                    slot, fills = item
+                    st["t_wait_read"] += time.perf_counter() - t0
                 st["bytes_in"] += sum(f[0] for f in fills)
                 total, fcarry, eof = [0] * nm, [b""] * nm, [False] * nm
                 if any(gz):
@@ -291,7 +296,11 @@ class FastqPipeline:
                 if not all_eof:
                     q_free.put((1 - slot, fcarry, [want[m] if gz[m] else max(0, want[m] - left[m]) for m in range(nm)]))
                 if all_eof:
-                    done = True    # what is left is a trailing partial record / the longer mate's surplus: the reference stops too
+                    # a trip takes at most max_records records: when the cap was hit, complete records may remain in
+                    # the carried text - keep parsing without refilling until a trip comes back short.  What is left
+                    # then is a trailing partial record / the longer mate's surplus: the reference stops too
+                    drain = n > 0 and n >= self.max_records and any(left)
+                    done = not drain
                 elif n == 0 and any(left[m] >= self.chunk for m in range(nm)):
                     raise PipelineError("a record does not fit the chunk size")
                 if n > 0:

@@ -477,6 +477,41 @@ int fastp_gpu_stream_set_origin(fastp_gpu_ctx* ctx, int64_t units_before, int64_
 int fastp_gpu_overrep_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, const fastp_gpu_results* res,
                              void* hip_stream);
 
+/* ---- Collectives: RCCL over xGMI behind the C ABI ------------------------------------------------
+ * What a C++ host calls where reference fastp merges its worker threads at the end of a run:
+ * PairEndProcessor::process src/peprocessor.cpp:217-234 (SingleEndProcessor::process
+ * src/seprocessor.cpp:104-116) -> Stats::merge src/stats.cpp:877-955 + FilterResult::merge
+ * src/filterresult.cpp:38-89: an int64 sum over per-worker counter arrays = ONE ncclAllReduce(ncclInt64,
+ * ncclSum) of the counter block (~0.25 MB: latency bound).  And the exchange step of the sharded duplicate
+ * protocol above (the shared Duplicate bitmaps, src/duplicate.h:34-37).
+ *
+ * One communicator rank per context (= per GPU).  Either one process per GPU - rank 0 calls
+ * fastp_gpu_comm_id, the host program hands the 128 bytes to the other processes (MPI, a file, a socket:
+ * its own business), every process calls fastp_gpu_comm_init - or one process that owns n contexts on n
+ * different GPUs calls fastp_gpu_comm_init_local (rank = position in the array).  Both collectives take the
+ * contexts the CALLING PROCESS owns (n = 1 with one process per GPU) and are synchronous; every rank of the
+ * communicator must make the same call.  librccl is loaded at the first use (FASTP_GPU_E_UNSUPPORTED if it
+ * cannot be); errors of this section are reported by fastp_gpu_comm_last_error (thread local). */
+#define FASTP_GPU_COMM_ID_BYTES 128
+int fastp_gpu_comm_id(uint8_t id[FASTP_GPU_COMM_ID_BYTES]);
+int fastp_gpu_comm_init(fastp_gpu_ctx* ctx, const uint8_t id[FASTP_GPU_COMM_ID_BYTES], int nranks, int rank);
+int fastp_gpu_comm_init_local(fastp_gpu_ctx* const* ctxs, int n);
+void fastp_gpu_comm_destroy(fastp_gpu_ctx* ctx);   /* also done by fastp_gpu_destroy */
+/* Stats::merge / FilterResult::merge: every rank's counter block <- the sum over all ranks */
+int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n);
+/* between pass 1 and pass 2 of a sharded run: rank r's prefix <- OR of the bitmaps of ranks 0..r-1
+ * (slices all-to-all, fastp_gpu_prefix_or_images on the slice owner, all-to-all back, fastp_gpu_dup_prefix_set) */
+int fastp_gpu_exchange_dup_prefix(fastp_gpu_ctx* const* ctxs, int n);
+const char* fastp_gpu_comm_last_error(void);
+
+/* HIP device ordinal the context lives on */
+int fastp_gpu_device(const fastp_gpu_ctx* ctx);
+
+/* Start a new run on the same context: counter block, duplicate bitmaps and stream positions as right after
+ * fastp_gpu_create - what constructing fresh Stats / FilterResult / Duplicate objects is for the reference
+ * (src/peprocessor.cpp:26-60).  Synchronous. */
+int fastp_gpu_reset(fastp_gpu_ctx* ctx);
+
 /* time spent inside the fused kernel for the launches since the last call,
  * measured with HIP events on the launch stream: total milliseconds and
  * number of launches (used by bench.py for the roofline object). */

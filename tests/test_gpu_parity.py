@@ -430,6 +430,47 @@ def test_gpu_equals_oracle_at_baseline_scale():
     assert cg[lay.dup_total] == total and dup.sum() > total // 50
 
 
+def test_gpu_reset_starts_a_new_run():
+    """fastp_gpu_reset: counters, bloom bitmaps and stream positions as after create"""
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    d = synth.synth_pairs(9000, L=150, seed=12, dup_frac=0.3)
+    g = engines.gpu_engine(p)
+    first = g.process(*_args(d, True))
+    c1 = g.counters()
+    g.reset()
+    z = g.counters()
+    assert not z[4:].any() and np.array_equal(z[:4], c1[:4])
+    again = g.process(*_args(d, True))
+    c2 = g.counters()
+    g.close()
+    assert np.array_equal(c1, c2)
+    for a, b in zip(first[:3], again[:3]):
+        assert a.tobytes() == b.tobytes()      # incl. RF_DUP: the bloom filter started empty again
+
+
+def test_gpu_cabi_rccl_allreduce_single_rank():
+    """fastp_gpu_comm_id / comm_init / allreduce / exchange_dup_prefix through librccl with a one-rank
+    communicator (this box has one GPU; RCCL refuses two ranks on one device): the sum over one rank is the
+    block itself, header words intact, and the engine keeps working afterwards"""
+    p = abi.default_params(True, 150)
+    d = synth.synth_pairs(5000, L=150, seed=13)
+    g = engines.gpu_engine(p)
+    g.process(*_args(d, True))
+    before = g.counters()
+    g.comm_init(g.comm_id(), 1, 0)
+    g.allreduce()
+    assert np.array_equal(g.counters(), before)
+    g.exchange_dup_prefix()
+    g.allreduce()
+    assert np.array_equal(g.counters(), before)
+    g.process(*_args(d, True))
+    after = g.counters()
+    lay = g.layout
+    assert after[lay.dup_total] == 2 * before[lay.dup_total]
+    g.close()
+
+
 def test_gpu_counter_export_import_merge_rehearsal():
     """the device side of the multi-GPU merge on one GPU: two engines take the two shards, their
     counter blocks are exported into torch tensors, summed (what the RCCL all-reduce does) and
@@ -583,7 +624,7 @@ def test_gpu_file_pipeline_equals_reference_outputs(name, tmp_path):
     binary travelled to this box, to reference fastp's own output files; counters == the one-stream engine's"""
     from fastp_amd import pipeline
     paired, flags, pf, skw = cases.CASES[name]
-    n = 20000
+    n = 20500     # not a multiple of max_records: the last trip is a short one
     d = synth.synth_pairs(n, L=150, seed=91, paired=paired, **skw)
     params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
     fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
@@ -609,6 +650,30 @@ def test_gpu_file_pipeline_equals_reference_outputs(name, tmp_path):
         assert (tmp_path / "o1.fq").read_bytes() == r["out1"]
         if paired:
             assert (tmp_path / "o2.fq").read_bytes() == r["out2"]
+
+
+def test_gpu_file_pipeline_drains_records_left_at_eof(tmp_path):
+    """the whole file fits ONE chunk but holds several times max_records records: after EOF the pipeline must keep
+    parsing the carried text (no refill) instead of stopping after the first max_records"""
+    from fastp_amd import pipeline
+    n = 2300
+    p = abi.default_params(True, 150)
+    d = synth.synth_pairs(n, L=150, seed=92)
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
+    ref = engines.gpu_engine(p)
+    want, ctr, _ = driver.run_engine(ref, p, fq1, fq2, pack=n, stride=abi.qual_stride(150))
+    ref.close()
+    (tmp_path / "r1.fq").write_bytes(fq1)
+    (tmp_path / "r2.fq").write_bytes(fq2)
+    pl = pipeline.FastqPipeline(p, chunk_bytes=4 << 20, max_records=700)
+    st = pl.run(str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), str(tmp_path / "o1.fq"), str(tmp_path / "o2.fq"))
+    got_ctr = pl.counters()
+    pl.close()
+    assert st["units"] == n and st["chunks"] == 4
+    assert (tmp_path / "o1.fq").read_bytes() == bytes(want.out1)
+    assert (tmp_path / "o2.fq").read_bytes() == bytes(want.out2)
+    assert np.array_equal(got_ctr, ctr)
 
 
 @pytest.mark.parametrize("level,strategy", [(6, "default"), (1, "default"), (0, "default"), (6, "fixed")])
