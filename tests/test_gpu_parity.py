@@ -427,7 +427,7 @@ def test_gpu_equals_oracle_at_baseline_scale():
     co[lay.dup_count] = int(dup.sum())
     bad = np.nonzero(co != cg)[0]
     assert len(bad) == 0, f"{len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
-    assert cg[lay.dup_total] == total and dup.sum() > total // 50
+    assert cg[lay.dup_total] == total and dup.sum() > 1000   # exact copies only (most synthetic duplicates differ by an error)
 
 
 def test_gpu_reset_starts_a_new_run():
