@@ -111,6 +111,7 @@ struct fastp_gpu_ctx {
     u16* d_lowq = nullptr;
     u16* d_cplx = nullptr;
     u32* d_primes = nullptr;
+    u32* d_planes = nullptr;  // byte planes of the primes (DevLuts::dup_planes)
     u64* d_posum = nullptr;
     u32* d_fasta_words = nullptr;
     int* d_fasta_len = nullptr;
@@ -198,7 +199,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_events(ctx);
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
+    void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr};
@@ -255,7 +256,11 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         delete ctx;
         return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024");
     }
-    rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err);
+    if (env_int("FASTP_GPU_HASH_GENERIC", 0)) {  // tests: the multiply form of the duplicate hash (what B = 8 uses)
+        ctx->luts.dup_planes.clear();
+        ctx->luts.dup_nq = 0;
+    }
+    rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
     if (rc) { delete ctx; return fail(nullptr, rc, err); }
     const int blocks_per_cu = env_int("FASTP_GPU_BLOCKS_PER_CU", std::max(1, (int)((160 * 1024) / (ctx->L.total * 4))));
     ctx->blocks = ctx->cus * std::max(1, blocks_per_cu);
@@ -301,6 +306,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_RC(upload((void**)&ctx->d_lowq, ctx->luts.lowq_limit.data(), ctx->luts.lowq_limit.size() * 2));
     CREATE_RC(upload((void**)&ctx->d_cplx, ctx->luts.cplx_min.data(), ctx->luts.cplx_min.size() * 2));
     CREATE_RC(upload((void**)&ctx->d_primes, ctx->luts.dup_primes.data(), ctx->luts.dup_primes.size() * 4));
+    CREATE_RC(upload((void**)&ctx->d_planes, ctx->luts.dup_planes.data(), ctx->luts.dup_planes.size() * 4));
     CREATE_RC(upload((void**)&ctx->d_posum, ctx->luts.dup_posum.data(), ctx->luts.dup_posum.size() * 8));
     CREATE_RC(upload((void**)&ctx->d_fasta_words, ctx->luts.fasta_words.data(), ctx->luts.fasta_words.size() * 4));
     CREATE_RC(upload((void**)&ctx->d_fasta_len, ctx->luts.fasta_len.data(), ctx->luts.fasta_len.size() * 4));
@@ -470,6 +476,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.lut.lowq_limit = ctx->d_lowq;
     a.lut.cplx_min = ctx->d_cplx;
     a.lut.dup_primes = ctx->d_primes;
+    a.lut.dup_planes = ctx->d_planes;
     a.lut.dup_posum = ctx->d_posum;
     a.lut.fasta_words = ctx->d_fasta_words;
     a.lut.fasta_len = ctx->d_fasta_len;
@@ -631,7 +638,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
     r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
     r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
-    const int items = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128 * QH_COPIES + MISC_ISIZE + ctx->dp.isize_max + 1;
+    const int items = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128 * QT_DWORDS + MISC_ISIZE + ctx->dp.isize_max + 1;
     const int rgroups = (grid + REDUCE_GROUP - 1) / REDUCE_GROUP;
     hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
     HIP_TRY(ctx, hipGetLastError());

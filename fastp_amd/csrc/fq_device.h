@@ -244,65 +244,103 @@ FQ_DEV void window_sums4(const u32* qrow, int c, int ncols, int w, u32 out[4]) {
     }
 }
 
+// bit j (j = 0..31) <=> the window [32*word + j, 32*word + j + w) of the row has total quality < thr, for the
+// positions below `limit` (bits at or past it are unspecified: no scan of trim_and_cut looks at a window that
+// leaves the read).  Windows of up to 8 bases - the default is 4 - take three instructions per start position:
+// v_alignbit (the window's bytes), v_sad_u8 with -thr as the addend (sum - thr), v_alignbit again to shift the
+// sign into the mask; a wider window goes through window_sums4.
+FQ_DEV u32 bad_window_word(const u32* qrow, int word, int QW, int limit, int w, int thr) {
+    u32 m = 0;
+    if (w == 4) {  // the default window: the four bytes at a position ARE the window
+        const u32 nthr = (u32)(-thr);
+        const int c0 = 8 * word;
+        u32 q[9];
+#pragma unroll
+        for (int d = 0; d < 9; d++) q[d] = (c0 + d < QW && 4 * (c0 + d) < limit + 4) ? (qrow[c0 + d] & 0x7F7F7F7Fu) : 0u;
+#pragma unroll
+        for (int d = 7; d >= 0; d--) {
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const u32 x = k ? alignbit(q[d + 1], q[d], 8 * k) : q[d];
+                m = alignbit(m, sum_bytes(x, nthr), 31);  // m = m << 1 | (sum < thr)
+            }
+        }
+        return m;
+    }
+    if (w <= 8) {
+        const u32 nthr = (u32)(-thr);
+        const u32 keep_lo = lowmask32(8 * imin(w, 4)), keep_hi = w > 4 ? lowmask32(8 * (w - 4)) : 0u;
+        // quality dwords 8*word .. 8*word + 9 (two of look-ahead), high to low so that the mask fills from bit 31 down
+        const int c0 = 8 * word;
+        u32 q[10];
+#pragma unroll
+        for (int d = 0; d < 10; d++) q[d] = (c0 + d < QW && 4 * (c0 + d) < limit + 8) ? (qrow[c0 + d] & 0x7F7F7F7Fu) : 0u;
+#pragma unroll
+        for (int d = 7; d >= 0; d--) {
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const u32 x = k ? alignbit(q[d + 1], q[d], 8 * k) : q[d];
+                u32 sdiff = sum_bytes(x & keep_lo, nthr);
+                if (w > 4) {
+                    const u32 y = k ? alignbit(q[d + 2], q[d + 1], 8 * k) : q[d + 1];
+                    sdiff = sum_bytes(y & keep_hi, sdiff);
+                }
+                m = alignbit(m, sdiff, 31);  // m = m << 1 | (sum < thr)
+            }
+        }
+        return m;
+    }
+    for (int d = 0; d < 8; d++) {
+        const int c = 8 * word + d;
+        if (c >= QW || 4 * c >= limit) break;
+        u32 s4[4];
+        window_sums4(qrow, c, QW, w, s4);
+        m |= ((u32)((int)s4[0] < thr) | ((u32)((int)s4[1] < thr) << 1) | ((u32)((int)s4[2] < thr) << 2) |
+              ((u32)((int)s4[3] < thr) << 3)) << (4 * d);
+    }
+    return m;
+}
+
 // The sliding windows of Filter::trimAndCut (filter.cpp:97-194) evaluated for EVERY start
 // position at once, as per-read bit masks that trim_and_cut() then only bit-scans.  A window sum
 // is position-absolute, so the reference's rolling sum at position s equals the mask's window
 // [s, s+w).  Item = (mask word w, read R): one lane builds bits 32w..32w+31 of every mask of its
 // read from 8 quality dwords (+ the look-ahead the windows need) and stores the words - no
 // atomics, and nothing to clear beforehand.  The read index runs fastest across lanes.
+// (cut_right's per-base test "quality < 33+Q", filter.cpp:159, is not a mask: the scan it belongs to starts at
+// the window found and ends within a few bases, so trim_and_cut reads the quality bytes themselves.)
 FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     if (!L.wm_stride) return;
     const DevParams& p = a.p;
     // argument-block fields fetched once, not at every use inside the loops
     const int NR = L.NR, QW = L.QW, WW = L.wm_words, wm_stride = L.wm_stride;
-    const int oF = L.wm_badF, oR = L.wm_badR, oT = L.wm_badT, oQ = L.wm_lowQ, oN = L.wm_isN;
-    const int wF = p.wF, wR = p.wR, wT = p.wT, thrF = p.thrF, thrR = p.thrR, thrT = p.thrT, qRmin = p.qRmin;
+    const int oF = L.wm_badF, oR = L.wm_badR, oT = L.wm_badT, oN = L.wm_isN;
+    const int wF = p.wF, wR = p.wR, wT = p.wT, thrF = p.thrF, thrR = p.thrR, thrT = p.thrT;
     const int max_len = p.max_len;
     const int* rlen0_v = lds_i(lds, L.rlen0);
     const u32* qual_v = lds + L.qual;
     u32* wm_v = lds + L.wm;
-    const u32 qmin4 = (u32)imin(imax(qRmin, 0), 127) * 0x01010101u;
     const int total = NR * WW;
     const int dW = nthreads / NR, dR = nthreads - dW * NR;
     int w = tid / NR, R = tid - w * NR;
     for (int i = tid; i < total; i += nthreads) {
         const u32* qrow = qual_v + rowoff(R, QW);
         const int rl0 = rlen0_v[R];
-        u32 mF = 0, mR = 0, mT = 0, mQ = 0, mN = 0;
-        for (int d = 0; d < 8; d++) {
-            const int c = 8 * w + d;
-            if (c >= QW || 4 * c >= rl0) break;
-            const u32 qd = qrow[c];
-            u32 s4[4];
-            if (oF >= 0 && wF <= max_len) {
-                window_sums4(qrow, c, QW, wF, s4);
-                mF |= ((u32)((int)s4[0] < thrF) | ((u32)((int)s4[1] < thrF) << 1) | ((u32)((int)s4[2] < thrF) << 2) |
-                       ((u32)((int)s4[3] < thrF) << 3)) << (4 * d);
-            }
-            if (oR >= 0 && wR <= max_len) {
-                window_sums4(qrow, c, QW, wR, s4);
-                mR |= ((u32)((int)s4[0] < thrR) | ((u32)((int)s4[1] < thrR) << 1) | ((u32)((int)s4[2] < thrR) << 2) |
-                       ((u32)((int)s4[3] < thrR) << 3)) << (4 * d);
-            }
-            if (oT >= 0 && wT <= max_len) {
-                window_sums4(qrow, c, QW, wT, s4);
-                mT |= ((u32)((int)s4[0] < thrT) | ((u32)((int)s4[1] < thrT) << 1) | ((u32)((int)s4[2] < thrT) << 2) |
-                       ((u32)((int)s4[3] < thrT) << 3)) << (4 * d);
-            }
-            if (oQ >= 0) {  // quality < qRmin, four bytes at once: bit 7 of (q|0x80) - qRmin survives iff q >= qRmin
-                const u32 lt = (~(((qd & 0x7F7F7F7Fu) | 0x80808080u) - qmin4) >> 7) & 0x01010101u;
-                mQ |= ((lt | (lt >> 7) | (lt >> 14) | (lt >> 21)) & 0xFu) << (4 * d);
-            }
-            const u32 nb = (qd >> 7) & 0x01010101u;
-            mN |= ((nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu) << (4 * d);
-        }
         u32* wm = wm_v + rowoff(R, wm_stride) + w;
-        if (oF >= 0) wm[oF] = mF;
-        if (oR >= 0) wm[oR] = mR;
-        if (oT >= 0) wm[oT] = mT;
-        if (oQ >= 0) wm[oQ] = mQ;
-        if (oN >= 0) wm[oN] = mN;
+        if (oF >= 0) wm[oF] = wF <= max_len ? bad_window_word(qrow, w, QW, rl0, wF, thrF) : 0u;
+        if (oR >= 0) wm[oR] = wR <= max_len ? bad_window_word(qrow, w, QW, rl0, wR, thrR) : 0u;
+        if (oT >= 0) wm[oT] = wT <= max_len ? bad_window_word(qrow, w, QW, rl0, wT, thrT) : 0u;
+        if (oN >= 0) {
+            u32 mN = 0;
+            for (int d = 0; d < 8; d++) {
+                const int c = 8 * w + d;
+                if (c >= QW || 4 * c >= rl0) break;
+                const u32 nb = (qrow[c] >> 7) & 0x01010101u;
+                mN |= ((nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu) << (4 * d);
+            }
+            wm[oN] = mN;
+        }
         w += dW;
         R += dR;
         if (R >= NR) { R -= NR; w++; }
@@ -325,17 +363,21 @@ FQ_DEV void phase_masks(const KernelArgs& a, u32* lds, int n_valid, int tid, int
 // ---------------------------------------------------------------------------
 enum { ST_PRE = 0, ST_POST = 1, ST_BOTH = 2 };
 
+// per-cycle accumulator of (Stats slot, class, cycle), in u64 units from LdsLayout::acc_cyc
+FQ_DEV int cyc_index(int Cp, int slot, int cls, int pos) { return (slot * Cp + pos) * N_CLS + cls; }
+
 // one (read R, quality dword c) item of Stats::statRead; BALLOT: aggregate the quality histogram
 // over the wavefront (every lane of the wave must call this, `act` says whether it has an item)
 template <int mode, bool MERGE, bool BALLOT>
 FQ_DEV void stats_item(const KernelArgs& a, u32* lds, bool act, int R, int c, int n_valid, int lane, u32 copy,
                        bool count_read = true) {
     const LdsLayout& L = a.L;
-    const int Cp = L.Cp, C4 = L.Cp >> 2;
+    const int Cp = L.Cp;
     u64* cyc_all = (u64*)(lds + L.acc_cyc);
     u32* kmer_all = lds + L.acc_kmer;
     u32* qh_all = lds + L.acc_qh;
     u32* misc = lds + L.acc_misc;
+    (void)copy;
     const int m = R >= L.P ? 1 : 0;
     const int rl0 = lds_i(lds, L.rlen0)[R];
     const int rflags = lds_i(lds, L.flags)[R];
@@ -396,7 +438,7 @@ FQ_DEV void stats_item(const KernelArgs& a, u32* lds, bool act, int R, int c, in
             // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
             const u64 inc = 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) |
                             ((u64)(q - 33u) << CYC_QSUM_SHIFT);
-            lds_add_u64(&cyc_all[((size_t)slot * N_CLS + cls) * Cp + (pos & 3) * C4 + (pos >> 2)], inc);
+            lds_add_u64(&cyc_all[cyc_index(Cp, slot, (int)cls, pos)], inc);
             // 5-mer ending at this base (stats.cpp:224-266): counted iff the five bases
             // pos-4..pos all exist in the window and none of them is N
             if (wpos >= 4 && ((nbits >> k) & 0x1Fu) == 0u) {
@@ -412,7 +454,7 @@ FQ_DEV void stats_item(const KernelArgs& a, u32* lds, bool act, int R, int c, in
     if (!BALLOT) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (val[k]) lds_add_u32(&qh_all[key[k] * QH_COPIES + copy], 1u);
+            if (val[k]) lds_add_u32(&qh_all[key[k] * QT_DWORDS + QT_COUNT], 1u);
         return;
     }
     const bool have = val[0] | val[1] | val[2] | val[3];
@@ -426,9 +468,9 @@ FQ_DEV void stats_item(const KernelArgs& a, u32* lds, bool act, int R, int c, in
         for (int k = 0; k < 4; k++) {
             const bool mk = val[k] && key[k] == modek;
             cnt += (u32)popc64(ballot(mk));
-            if (val[k] && !mk) lds_add_u32(&qh_all[key[k] * QH_COPIES + copy], 1u);
+            if (val[k] && !mk) lds_add_u32(&qh_all[key[k] * QT_DWORDS + QT_COUNT], 1u);
         }
-        if (lane == src) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
+        if (lane == src) lds_add_u32(&qh_all[modek * QT_DWORDS + QT_COUNT], cnt);
     }
 }
 
@@ -438,7 +480,7 @@ FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int n_valid, int tid, int
     const int qwg = a.p.qw_g;
     const int total = L.NR * qwg;
     const int lane = tid & 63;
-    const u32 copy = (u32)(tid & (QH_COPIES - 1));
+    const u32 copy = 0u;
     for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count (ballots inside)
         const int idx = base + lane;
         const bool act = idx < total;
@@ -449,115 +491,139 @@ FQ_DEV void phase_stats(const KernelArgs& a, u32* lds, int n_valid, int tid, int
 }
 
 // ---------------------------------------------------------------------------
-// One-pass Stats, fast form.  Almost every (read, quality dword) item is "plain": four existing
-// bases, no N among them or the four before, all kept or all dropped.  Plain items take a
-// branch-free path (increment from a 128-entry table, no per-base validity, one shared
-// kept/dropped offset); the others - a read's last partial dword, the dword its kept length
-// cuts, dwords with N - are queued in an LDS work list and run through stats_item afterwards,
-// so that no wavefront pays for both paths.
+// One-pass Stats, fast form.  lane = (read R, quarter of its quality dwords): everything that only depends
+// on the read - its two windows, the kept / dropped accumulator bases, the row addresses - is set up once per
+// lane, then the lane walks its ~QW/4 dwords.  The walk starts at a read-dependent dword and wraps, so the
+// lanes of a wavefront sit on different cycles (no same-address atomics) and their row reads fall into
+// different banks.
+// Almost every (read, quality dword) item is "plain": no N among its four bases or the four before, all of
+// its existing bases kept or all dropped.  A plain item is branch-free:
+//   * the four quality characters index the quality table of the item's Stats slot (one 16-byte entry per
+//     character: packed per-cycle increment, histogram counter, the constant 1); character 0 = a byte past
+//     the read's end (phase_trim zeroes those) has increment 0 and constant 0, so the partial last dword of a
+//     read needs no special case,
+//   * per-cycle counters sit [slot][cycle][class]: the four cycles of the dword are at fixed distances (DS
+//     offset field) and the class adds 8 bytes,
+//   * the histogram counter shares the address of the table entry already computed; dwords whose four
+//     characters all equal the wavefront's mode are counted with one ballot instead.
+// The others - the dword a kept length cuts, dwords with N - are queued in an LDS work list and run through
+// stats_item afterwards, so that no wavefront pays for both paths.
 // ---------------------------------------------------------------------------
+// the work list is full (a tile of reads riddled with N): the item is done in place - out of line, so that this
+// rare case does not drag the general path into the fast loop's code
+__device__ __attribute__((noinline)) void stats_item_overflow(const KernelArgs* a, u32* lds, int R, int c, int n_valid) {
+    stats_item<ST_BOTH, false, false>(*a, lds, true, R, c, n_valid, 0, 0u, false);
+}
+
 FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid, int nthreads) {
     const LdsLayout& L = a.L;
-    const int qwg = L.QW;
-    const int total = L.NR * qwg;
-    const int Cp = L.Cp, C4 = L.Cp >> 2;
-    u64* cyc_all = (u64*)(lds + L.acc_cyc);
-    u32* kmer_all = lds + L.acc_kmer;
-    u32* qh_all = lds + L.acc_qh;
+    const int QW = L.QW, NR = L.NR, P = L.P, SW4 = L.SW * 4, Cp = L.Cp;
+    const int S = (QW + 3) >> 2;                // dwords per lane
+    const int rot_mask = S >= 8 ? 7 : (S >= 4 ? 3 : 0);
     u32* misc = lds + L.acc_misc;
-    const u64* inc_lut = (const u64*)(lds + L.inc_lut);
     u32* wl_count = lds + L.wl;
     u16* wl_items = (u16*)(lds + L.wl + 1);
-    const u8* seq_bytes = (const u8*)(lds + L.seq);
+    const int wl_cap = L.wl_cap;
+    const u32* swin_v = lds + L.swin;           // rlen0 | kept length << 16, left by the filter phase
+    const u8* lds_b = (const u8*)lds;
+    const u32 cyc_b = (u32)L.acc_cyc * 4u, kmer_b = (u32)L.acc_kmer * 4u, qt_b = (u32)L.acc_qh * 4u;
+    const u32 qual_b = (u32)L.qual * 4u, seq_b = (u32)L.seq * 4u;
     const int lane = tid & 63;
-    const u32 copy = (u32)(tid & (QH_COPIES - 1));
-    // every argument-block field the loop needs, fetched once (they would otherwise be re-read
-    // from the kernarg segment at each use, with a wait on the scalar cache in the loop)
-    const int P = L.P, SW4 = L.SW * 4, wl_cap = L.wl_cap;
-    const u32* swin_v = lds + L.swin;  // rlen0 | kept length << 16, left by the filter phase
-    const u32* qual_v = lds + L.qual;
-    // (R, c) of this lane's items advance by a fixed (dR, dc) per trip: no division in the loop
-    int R = (int)fastdiv((u32)tid, a.magic_qwg);
-    int c = tid - R * qwg;
-    const int dR = (int)fastdiv((u32)nthreads, a.magic_qwg), dc = nthreads - dR * qwg;
-    for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count
-        const int idx = base + lane;
+    const int total = NR * 4;
+    for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count (ballots inside)
+        const int task = base + lane;
+        const bool tv = task < total;
+        const int R = tv ? (task >> 2) : 0, seg = task & 3;
         const int m = R >= P ? 1 : 0;
-        bool act = idx < total && (R - m * P < n_valid);
-        int rl0 = 0, lk = 0;
-        if (act) {
-            const u32 sw = swin_v[R];
-            rl0 = (int)(sw & 0xFFFFu);
-            lk = (int)(sw >> 16);  // > 0 exactly for the reads that are written out
-        }
-        const int slot0 = m * 2;
-        if (act && c == 0) {  // mReads++, mLengthSum += len (stats.cpp:194, 290)
-            lds_add_u32(&misc[MISC_STAT_READS + slot0], 1u);
-            lds_add_u32(&misc[MISC_STAT_LENSUM + slot0], (u32)rl0);
+        const bool rv = tv && (R - m * P < n_valid);
+        const u32 sw = rv ? swin_v[R] : 0u;
+        const int rl0 = (int)(sw & 0xFFFFu);
+        const int lk = (int)(sw >> 16);         // > 0 exactly for the reads that are written out
+        const int slot_d = 2 * m;               // dropped bases -> the PRE slot, kept ones -> the POST slot
+        if (rv && seg == 0) {                   // mReads++, mLengthSum += len (stats.cpp:194, 290)
+            lds_add_u32(&misc[MISC_STAT_READS + slot_d], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + slot_d], (u32)rl0);
             if (lk) {
-                lds_add_u32(&misc[MISC_STAT_READS + slot0 + 1], 1u);
-                lds_add_u32(&misc[MISC_STAT_LENSUM + slot0 + 1], (u32)lk);
+                lds_add_u32(&misc[MISC_STAT_READS + slot_d + 1], 1u);
+                lds_add_u32(&misc[MISC_STAT_LENSUM + slot_d + 1], (u32)lk);
             }
         }
-        const int j0 = 4 * c;
-        act = act && j0 < rl0;
-        bool plain = false;
-        u32 qd = 0, nany = 0;
-        if (act) {
-            qd = qual_v[idx];  // LDS rows have the batch strides: the item index IS the dword offset
-            nany = qd & 0x80808080u;
-            if (c > 0) nany |= qual_v[idx - 1] & 0x80808080u;
-            plain = j0 + 4 <= rl0 && nany == 0u && (j0 + 4 <= lk || j0 >= lk);
-            if (!plain) {
+        const int cany = (rl0 + 3) >> 2;        // dwords holding at least one base
+        const int ck = lk >= rl0 ? cany : (lk >> 2);   // dwords below ck: every existing base is kept
+        const int cd = (lk + 3) >> 2;           // dwords from cd on: every base is dropped
+        const int cbeg = seg * S;
+        const int cmax = imin(imin(cbeg + S, QW), cany);
+        // this read's rows and the two accumulator sets (kept / dropped) as LDS pointers, set up once per lane
+        const u8* qrow_p = lds_b + qual_b + (u32)rowoff(R, QW * 4);
+        const u8* srow_p = lds_b + seq_b + (u32)rowoff(R, SW4);
+        u8* ldsw = (u8*)lds;
+        u8* cyc_d = ldsw + cyc_b + (u32)(slot_d * Cp) * (N_CLS * 8u);
+        u8* cyc_k = cyc_d + (u32)Cp * (N_CLS * 8u);
+        u8* kmer_d = ldsw + kmer_b + (u32)slot_d * (KMER_BINS * 4u);
+        u8* kmer_k = kmer_d + KMER_BINS * 4u;
+        u8* qt_d = ldsw + qt_b + (u32)slot_d * (128u * QT_DWORDS * 4u);
+        u8* qt_k = qt_d + 128u * QT_DWORDS * 4u;
+        int cc = R & rot_mask;
+        u32 mode4 = 0xFFFFFFFFu, agg_cnt = 0;   // wave-uniform: the mode's four characters, dwords counted by ballot
+        int mode_m = 0;
+        for (int t = 0; t < S; t++) {
+            const int c = cbeg + cc;
+            const bool act = rv && c < cmax;
+            const int cr = act ? c : 0;
+            const int cp = cr > 0 ? cr - 1 : 0;
+            const u32 qd = *(const u32*)(qrow_p + 4 * cr);
+            const u32 qp = *(const u32*)(qrow_p + 4 * cp);
+            const u32 cur8 = srow_p[cr];
+            const u32 prev8 = srow_p[cp];
+            const bool kept = c < ck;
+            const bool plain = act && ((qd | qp) & 0x80808080u) == 0u && (kept || c >= cd);
+            if (act && !plain) {                // rare: hand it to the general path
                 const u32 slot = lds_add_ret_u32(wl_count, 1u);
-                if (slot < (u32)wl_cap) wl_items[slot] = (u16)idx;
-                else stats_item<ST_BOTH, false, false>(a, lds, true, R, c, n_valid, lane, copy, false);  // list full: do it here
+                if (slot < (u32)wl_cap) wl_items[slot] = (u16)(R * QW + c);
+                else stats_item_overflow(&a, lds, R, c, n_valid);  // list full: do it here
             }
-        }
-        u32 key0 = 0;
-        if (plain) {
-            const int slot = slot0 + (j0 < lk ? 1 : 0);
-            const int sbyte = rowoff(R, SW4) + c;
-            // every LDS read of the item first, then the atomics back to back: LDS operations return in
-            // order, so a read issued after an atomic would wait for that atomic as well
-            const u32 cur8 = seq_bytes[sbyte];
-            const u32 prev8 = c > 0 ? (u32)seq_bytes[sbyte - 1] : 0u;
-            u64 inc[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) inc[k] = inc_lut[(qd >> (8 * k)) & 0x7Fu];
-            u64* cyc = cyc_all + rowoff(slot, N_CLS * Cp) + c;  // position 4c+k lives at k*C4 + c (phase-major)
-            key0 = (u32)slot * 128u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u32 cls = (cur8 >> (2 * k)) & 3u;
-                lds_add_u64(&cyc[rowoff((int)cls, Cp) + k * C4], inc[k]);
-            }
-            if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N)
-                const u32 codes = prev8 | (cur8 << 8);
-                u32* kmer = kmer_all + slot * KMER_BINS;
-#pragma unroll
-                for (int k = 0; k < 4; k++) lds_add_u32(&kmer[(codes >> (2 * k)) & 0x3FFu], 1u);
-            }
-        }
-        // quality histogram of the plain items.  Qualities cluster: a dword's four values are usually
-        // equal, and equal to most other lanes' - those are counted with ONE ballot and added by one
-        // lane; every other base pays its own LDS atomic.
-        const u64 hv = ballot(plain);
-        if (hv) {  // wave-uniform
-            const int src = ffs64(hv) - 1;
+            // the wavefront's mode = the first plain kept item's first character, fixed at its first appearance
             const u32 q7 = qd & 0x7F7F7F7Fu;
-            const u32 modek = shfl(key0 + (q7 & 0x7Fu), src);
-            const bool agg = plain && q7 == (q7 & 0x7Fu) * 0x01010101u && key0 + (q7 & 0x7Fu) == modek;
-            const u32 cnt = 4u * (u32)popc64(ballot(agg));
-            if (plain && !agg) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) lds_add_u32(&qh_all[(key0 + ((qd >> (8 * k)) & 0x7Fu)) * QH_COPIES + copy], 1u);
+            if (mode4 == 0xFFFFFFFFu) {         // wave-uniform
+                const u64 cand = ballot(plain && kept);
+                if (cand) {
+                    const int src = ffs64(cand) - 1;
+                    mode4 = (shfl(q7, src) & 0x7Fu) * 0x01010101u;
+                    mode_m = (int)shfl((u32)m, src);
+                }
             }
-            if (lane == src && cnt) lds_add_u32(&qh_all[modek * QH_COPIES + copy], cnt);
+            const bool agg = plain && kept && q7 == mode4 && m == mode_m;
+            agg_cnt += (u32)popc64(ballot(agg));
+            if (plain) {
+                u8* qt = kept ? qt_k : qt_d;
+                u8* cyc = (kept ? cyc_k : cyc_d) + mul24((u32)c, 4u * N_CLS * 8u);
+                u8* kmer = kept ? kmer_k : kmer_d;
+                u8* ta[4];
+                u64 inc[4];
+                u32 one[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {   // table entry of each character: {increment u64, counter, 1 or 0}
+                    ta[k] = qt + (bfe(qd, 8 * k, 7) << 4);
+                    inc[k] = *(const u64*)ta[k];
+                    one[k] = *(const u32*)(ta[k] + QT_ONE * 4);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    lds_add_u64((u64*)(cyc + (bfe(cur8, 2 * k, 2) << 3) + k * (N_CLS * 8)), inc[k]);
+                if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N); a base past the read's end adds 0
+                    const u32 codes = prev8 | (cur8 << 8);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) lds_add_u32((u32*)(kmer + (bfe(codes, 2 * k, 10) << 2)), one[k]);
+                }
+                if (!agg) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) lds_add_u32((u32*)(ta[k] + QT_COUNT * 4), one[k]);
+                }
+            }
+            cc = cc + 1 == S ? 0 : cc + 1;
         }
-        c += dc;
-        R += dR;
-        if (c >= qwg) { c -= qwg; R++; }
+        if (lane == 0 && agg_cnt)
+            lds_add_u32(lds + L.acc_qh + ((2 * mode_m + 1) * 128 + (int)(mode4 & 0x7Fu)) * QT_DWORDS + QT_COUNT, 4u * agg_cnt);
     }
     block_sync();
     // the queued items, all through the general path
@@ -567,7 +633,7 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         const bool act = i < nw;
         const int idx = act ? (int)wl_items[i] : 0;
         const int Rw = (int)fastdiv((u32)idx, a.magic_qwg);
-        stats_item<ST_BOTH, false, true>(a, lds, act, Rw, idx - Rw * qwg, n_valid, lane, copy, false);  // reads were counted above
+        stats_item<ST_BOTH, false, true>(a, lds, act, Rw, idx - Rw * QW, n_valid, lane, 0u, false);  // reads were counted above
     }
 }
 
@@ -611,7 +677,24 @@ FQ_DEV int scan_last(const u32* m, int lo, int hi, bool want) {
 // first base as trimAndCut sees it (after the UMI front trim), len = its length.
 // Every loop of the reference becomes one bit scan; comments give the loop it replaces.
 // ---------------------------------------------------------------------------
-FQ_DEV bool trim_and_cut(const DevParams& p, const LdsLayout& L, const u32* wm, int u, int len, int front, int tail,
+// first j in [lo, hi) whose quality character (row position j) is below qmin; hi if there is none.
+// qmin4 = qmin in every byte (0..127); four characters per step: bit 7 of (q|0x80) - qmin survives iff q >= qmin
+FQ_DEV int scan_first_lowq(const u32* qrow, int lo, int hi, u32 qmin4) {
+    if (lo >= hi) return hi;
+    int w = lo >> 2;
+    const int wend = (hi - 1) >> 2;
+    u32 x = ~(((qrow[w] & 0x7F7F7F7Fu) | 0x80808080u) - qmin4) & 0x80808080u & ~lowmask32(8 * (lo & 3));
+    for (;;) {
+        if (x) {
+            const int j = 4 * w + ((ffs32(x) - 1) >> 3);
+            return j < hi ? j : hi;
+        }
+        if (++w > wend) return hi;
+        x = ~(((qrow[w] & 0x7F7F7F7Fu) | 0x80808080u) - qmin4) & 0x80808080u;
+    }
+}
+
+FQ_DEV bool trim_and_cut(const DevParams& p, const LdsLayout& L, const u32* wm, const u32* qrow, int u, int len, int front, int tail,
                          int& out_front, int& out_len) {
     out_front = 0;
     out_len = len;
@@ -641,7 +724,8 @@ FQ_DEV bool trim_and_cut(const DevParams& p, const LdsLayout& L, const u32* wm, 
         const int end = l - tail - w;
         int s = scan_first(wm + L.wm_badR, u + front, u + end, true) - u;  // first window below the threshold
         if (s < end) {  // foundLowQualWindow
-            s = scan_first(wm + L.wm_lowQ, u + s, u + l - 1, true) - u;  // while (s < l-1 && qual[s] >= 33+Q) s++
+            const u32 qmin4 = (u32)imin(imax(p.qRmin, 0), 127) * 0x01010101u;
+            s = scan_first_lowq(qrow, u + s, u + l - 1, qmin4) - u;  // while (s < l-1 && qual[s] >= 33+Q) s++
             rlen = s - front;
         }
     }
@@ -725,10 +809,97 @@ FQ_DEV int trim_poly_x(const u32* srow, const u8* q, int f, int rlen, int compar
 // the position part sum_p prime[...]*(p+off) only depends on the lengths and comes from a
 // host-built prefix table (DevLuts::dup_posum).
 // ---------------------------------------------------------------------------
-FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+// Duplicate's primes into LDS: the byte-plane table of the dot-product hash, or the plain list (generic path)
+FQ_DEV void stage_primes(const KernelArgs& a, u32* lds, int tid, int nt) {
     const LdsLayout& L = a.L;
+    if (!a.p.dup_enabled) return;
+    if (L.hp >= 0) {
+        const int n = 4 * L.hp_nq * a.p.dup_bufnum * a.p.dup_npl;
+        for (int i = tid; i < n; i += nt) lds[L.hp + i] = a.lut.dup_planes[i];
+    } else {
+        for (int i = tid; i < 512 * a.p.dup_bufnum; i += nt) lds[L.primes + i] = a.lut.dup_primes[i];
+    }
+}
+
+// The same sum as byte-plane dot products.  prime * val = sum_b 2^(8b) * byte_b(prime) * val, so for the four bases
+// of one packed byte the contribution to h_i is sum_b 2^(8b) * dot4(vals, plane_b) with vals = the four base
+// values (one byte each, from the 256-entry LUT) and plane_b = the b-th bytes of the four primes - ONE
+// v_dot4_u32_u8 per (buffer, plane) and 4 bases instead of a multiply and a 64-bit add per (buffer, base).  The
+// planes come from a host-built table indexed by stream position (DevLuts::dup_planes), which absorbs read 2's
+// start offset (duplicate.cpp:139) for any read-1 length.  4 lanes per read, base dwords interleaved; the partial
+// dot products of a read stay far below 2^32 (150 * 4 * 255 * 222).
+template <int B, int NPL>
+FQ_DEV void phase_hash_dot(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const int P = L.P, SW4 = L.SW * 4, QW = L.QW, NQ = L.hp_nq;
+    const u32* hp = lds + L.hp;
+    const u32* val4 = lds + L.val4_lut;
+    const int* rlen0_v = lds_i(lds, L.rlen0);
+    const int* flags_v = lds_i(lds, L.flags);
+    const u8* seq_bytes = (const u8*)(lds + L.seq);
+    const u32* qual_v = lds + L.qual;
+    u64* hash_v = (u64*)(lds + L.hash);
+    const int total = L.NR * 4;
+    const int lane = tid & 63;
+    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (shuffles inside)
+        const int t = t0 + lane;
+        const bool valid = t < total;
+        const int R = valid ? (t >> 2) : 0, seg = t & 3;
+        const int len = valid ? rlen0_v[R] : 0;
+        const int off = R >= P ? rlen0_v[R - P] : 0;  // r2 continues at r1->length() (duplicate.cpp:139)
+        const bool hasN = (flags_v[R] & RS_HAS_N) != 0;
+        const int rq = rowoff(R, QW), rs = rowoff(R, SW4);
+        const u32* tb = hp + ((off & 3) * NQ + (off >> 2)) * (B * NPL);
+        u32 acc[B * NPL];
+#pragma unroll
+        for (int k = 0; k < B * NPL; k++) acc[k] = 0;
+        for (int c = seg; 4 * c < len; c += 4) {
+            u32 vals = val4[seq_bytes[rs + c]];  // the four base values, one byte each
+            if (hasN) {
+                const u32 qd = qual_v[rq + c];
+                const u32 mN = ((qd >> 7) & 0x01010101u) * 0xFFu;  // N -> 13 (duplicate.cpp:92-109)
+                vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
+            }
+            const int rem = len - 4 * c;
+            if (rem < 4) vals &= lowmask32(8 * rem);  // bases past the read end contribute 0
+            const u32* e = tb + c * (B * NPL);
+#pragma unroll
+            for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, e[k], acc[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            u64 h = (u64)acc[i * NPL] + ((u64)acc[i * NPL + 1] << 8) + ((u64)acc[i * NPL + 2] << 16);
+            if (NPL > 3) h += (u64)acc[i * NPL + 3] << 24;
+            u32 lo = (u32)h, hi = (u32)(h >> 32);
+#pragma unroll
+            for (int sh = 1; sh < 4; sh <<= 1) {
+                const u64 o = (u64)shfl_xor(lo, sh) | ((u64)shfl_xor(hi, sh) << 32);
+                const u64 n = (((u64)hi << 32) | lo) + o;
+                lo = (u32)n;
+                hi = (u32)(n >> 32);
+            }
+            if (valid && seg == 0) hash_v[(size_t)R * B + i] = ((u64)hi << 32) | lo;
+        }
+    }
+}
+
+FQ_DEV void phase_hash_generic(const KernelArgs& a, u32* lds, int tid, int nthreads);
+
+FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const DevParams& p = a.p;
     if (!p.dup_enabled || !a.dup_pos) return;
+    if (a.L.hp >= 0) {
+        if (p.dup_bufnum == 2 && p.dup_npl == 3) return phase_hash_dot<2, 3>(a, lds, tid, nthreads);
+        if (p.dup_bufnum == 4 && p.dup_npl == 3) return phase_hash_dot<4, 3>(a, lds, tid, nthreads);
+        if (p.dup_bufnum == 2 && p.dup_npl == 4) return phase_hash_dot<2, 4>(a, lds, tid, nthreads);
+        if (p.dup_bufnum == 4 && p.dup_npl == 4) return phase_hash_dot<4, 4>(a, lds, tid, nthreads);
+    }
+    phase_hash_generic(a, lds, tid, nthreads);
+}
+
+FQ_DEV void phase_hash_generic(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
     // argument-block fields fetched once, not at every use inside the loops
     const int B = p.dup_bufnum, P = L.P, SW4 = L.SW * 4, QW = L.QW;
     const u32 mask = (u32)(512 * B - 1);
@@ -797,6 +968,18 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, i
     const DevParams& p = a.p;
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= L.P ? 1 : 0;
+        if (p.stats_one_pass) {
+            // the one-pass Stats path reads quality character 0 as "no base here": make sure that is what the
+            // row holds behind the read's end, whatever the caller's buffer had there
+            const int rl0 = lds_i(lds, L.rlen0)[R];
+            u32* qrow = lds_qual(L, lds, R);
+            int c0 = rl0 >> 2;
+            if (rl0 & 3) {
+                qrow[c0] &= lowmask32(8 * (rl0 & 3));
+                c0++;
+            }
+            for (int c = c0; c < L.QW; c++) qrow[c] = 0;
+        }
         if (a.dupflag) {  // --dedup: Duplicate::checkPair/checkRead already ran for this batch
             const int gp = tile_first + R - m * L.P;
             if (gp < a.n && a.dupflag[gp]) lds_or_i32(&lds_i(lds, L.flags)[R], RS_DUP);
@@ -810,7 +993,7 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, i
             if (t > 0) { front = t; len -= t; }
         }
         int f2 = 0, l2 = len;
-        const bool alive = trim_and_cut(p, L, lds + L.wm + rowoff(R, L.wm_stride), front, len, m ? p.trim_front2 : p.trim_front1,
+        const bool alive = trim_and_cut(p, L, lds + L.wm + rowoff(R, L.wm_stride), lds_qual(L, lds, R), front, len, m ? p.trim_front2 : p.trim_front1,
                                         m ? p.trim_tail2 : p.trim_tail1, f2, l2);
         if (alive) {
             lds_i(lds, L.front)[R] = front + f2;
@@ -1759,8 +1942,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             lds[L.lut_lowq + i] = g1[i];
             lds[L.lut_cplx + i] = g2[i];
         }
-        if (a.p.dup_enabled)
-            for (int i = tid; i < 512 * a.p.dup_bufnum; i += nt) lds[L.primes + i] = a.lut.dup_primes[i];
+        stage_primes(a, lds, tid, nt);
         for (int i = tid; i < 2 * ADAPT_WORDS; i += nt) {
             const int which = i >= ADAPT_WORDS ? 1 : 0;
             const int w = i - which * ADAPT_WORDS;
@@ -1775,10 +1957,17 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
             lds[L.val4_lut + i] = v;
         }
-    for (int q = tid; q < 128; q += nt) {  // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
-        const u64 inc = 1ull | ((u64)(q >= 53) << CYC_Q20_SHIFT) | ((u64)(q >= 63) << CYC_Q30_SHIFT) |
-                        ((u64)(u32)(q - 33) << CYC_QSUM_SHIFT);
-        ((u64*)(lds + L.inc_lut))[q] = inc;
+    block_sync();
+    for (int i = tid; i < 4 * 128; i += nt) {  // quality table constants (the counters in between stay zero)
+        const int q = i & 127;
+        // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20.  Character 0 = no base.
+        const u64 inc = q == 0 ? 0ull
+                               : (1ull | ((u64)(q >= 53) << CYC_Q20_SHIFT) | ((u64)(q >= 63) << CYC_Q30_SHIFT) |
+                                  ((u64)(u32)(q - 33) << CYC_QSUM_SHIFT));
+        u32* e = lds + L.acc_qh + i * QT_DWORDS;
+        e[QT_INC] = (u32)inc;
+        e[QT_INC + 1] = (u32)(inc >> 32);
+        e[QT_ONE] = q == 0 ? 0u : 1u;
     }
     block_sync();
     const bool timing_on = a.phase_cycles != nullptr;  // uniform
@@ -1869,8 +2058,7 @@ FQ_DEV void hash_body(const KernelArgs& a, u32* lds) {
             for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
             lds[L.val4_lut + i] = v;
         }
-    if (a.p.dup_enabled)
-        for (int i = tid; i < 512 * a.p.dup_bufnum; i += nt) lds[L.primes + i] = a.lut.dup_primes[i];
+    stage_primes(a, lds, tid, nt);
     block_sync();
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
@@ -1911,8 +2099,8 @@ enum { REDUCE_GROUP = 16 };
 
 FQ_DEV void reduce_body(const ReduceArgs& r) {
     const LdsLayout& L = r.L;
-    const int C = L.C, Cp = L.Cp, C4 = L.Cp >> 2;
-    const int n_cyc = 4 * N_CLS * Cp, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128 * QH_COPIES;
+    const int C = L.C, Cp = L.Cp;
+    const int n_cyc = 4 * N_CLS * Cp, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128 * QT_DWORDS;
     const int n_misc = MISC_ISIZE + r.isize_max + 1;
     const int total = n_cyc + n_kmer + n_qh + n_misc;
     const int chunks = (total + block_threads() - 1) / block_threads();  // workgroups per slab group
@@ -1923,10 +2111,9 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
     if (b0 >= b1) return;
     const int64_t CC = r.cycles;
     if (item < n_cyc) {
-        const int slot = item / (N_CLS * Cp);
+        const int slot = item / (N_CLS * Cp);   // cyc_index: [slot][cycle][class]
         const int rem = item - slot * N_CLS * Cp;
-        const int cls = rem / Cp, cs = rem - cls * Cp;
-        const int c = (cs % C4) * 4 + cs / C4;  // phase-major position -> cycle (LdsLayout::Cp)
+        const int c = rem / N_CLS, cls = rem - c * N_CLS;
         if (c >= C) return;
         int64_t cnt = 0, q20 = 0, q30 = 0, qs = 0;
         for (int b = b0; b < b1; b++) {
@@ -1963,8 +2150,10 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
         g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_kmer + fk], sum);
         if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_kmer + fk], sum);
     } else if (item < n_cyc + n_kmer + n_qh) {
-        const int k = (item - n_cyc - n_kmer) / QH_COPIES;
+        const int k = (item - n_cyc - n_kmer) / QT_DWORDS;
+        if ((item - n_cyc - n_kmer) - k * QT_DWORDS != QT_COUNT) return;  // the entry's constants are not counters
         const int slot = k / 128, q = k - slot * 128;
+        if (q == 0) return;  // character 0 = "no base" (bytes past a read's end): never a real quality (>= '!')
         g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_qual_hist + q], sum);
         if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_qual_hist + q], sum);
     } else {

@@ -247,18 +247,48 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
                 luts.dup_posum[(size_t)(t + 1) * num + i] = acc;
             }
         }
+        // phase_hash_dot: the value part sum_p prime[...] * val(base_p) as byte-plane dot products (v_dot4_u32_u8).
+        // Entry (r, q) holds, for every buffer i and byte plane b, the b-th bytes of the primes of the four
+        // consecutive stream positions 4q + r .. 4q + r + 3.  A read whose first base sits at stream position
+        // `off` (0 for read 1, read 1's length for read 2, duplicate.cpp:139) reads entry (off & 3, (off >> 2) + c)
+        // for its base dword c.  Only built for the geometries where it fits LDS comfortably.
+        luts.dup_planes.clear();
+        luts.dup_nq = 0;
+        p.dup_npl = 3;
+        if (num <= 4) {
+            const int nq = (maxpos + 3) / 4 + 2;
+            u32 pmax = 0;
+            for (int t = 0; t < 4 * nq + 3; t++)
+                for (int i = 0; i < num; i++) pmax = std::max(pmax, luts.dup_primes[((u32)t * (u32)num + (u32)i) & mask]);
+            p.dup_npl = pmax < (1u << 24) ? 3 : 4;
+            luts.dup_nq = nq;
+            luts.dup_planes.assign((size_t)4 * nq * num * p.dup_npl, 0u);
+            for (int r = 0; r < 4; r++)
+                for (int q = 0; q < nq; q++)
+                    for (int i = 0; i < num; i++)
+                        for (int b = 0; b < p.dup_npl; b++) {
+                            u32 w = 0;
+                            for (int k = 0; k < 4; k++) {
+                                const u32 pr = luts.dup_primes[((u32)(4 * q + r + k) * (u32)num + (u32)i) & mask];
+                                w |= ((pr >> (8 * b)) & 0xFFu) << (8 * k);
+                            }
+                            luts.dup_planes[(((size_t)r * nq + q) * num + i) * p.dup_npl + b] = w;
+                        }
+        }
     } else {
         p.dup_bufnum = 0;
         p.dup_bits = 0;
         luts.dup_primes.clear();
         luts.dup_posum.clear();
+        luts.dup_planes.clear();
+        luts.dup_nq = 0;
     }
     return FASTP_GPU_OK;
 }
 
 static int round_odd(int x) { return (x & 1) ? x : x + 1; }
 
-int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err) {
+int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err, int hp_nq) {
     const int mates = p.paired ? 2 : 1;
     auto build = [&](int P, LdsLayout& out) {
         memset(&out, 0, sizeof(out));
@@ -267,13 +297,13 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.SW = p.sw_g;
         out.QW = p.qw_g;
         out.C = p.cycles;
-        out.Cp = (p.cycles + 15) / 16 * 16;  // multiple of 16: the class stride does not move a counter to another LDS bank pair
+        out.Cp = (p.cycles + 3) / 4 * 4;
         int o = 0;
         auto take = [&](int n) { int at = o; o += n; return at; };
         // accumulators first (u64 part 8-byte aligned at offset 0)
         out.acc_cyc = take(4 * N_CLS * out.Cp * 2);
         out.acc_kmer = take(4 * KMER_BINS);
-        out.acc_qh = take(4 * 128 * QH_COPIES);
+        out.acc_qh = take(4 * 128 * QT_DWORDS);
         out.acc_misc = take(MISC_ISIZE + p.isize_max + 1);
         out.acc_end = o;
         if (o & 1) o++;
@@ -284,7 +314,6 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
             out.wm_badF = p.cut_front ? (k++) * out.wm_words : -1;
             out.wm_badR = p.cut_right ? (k++) * out.wm_words : -1;
             out.wm_badT = (p.cut_tail && !p.cut_right) ? (k++) * out.wm_words : -1;   // filter.cpp:166
-            out.wm_lowQ = p.cut_right ? (k++) * out.wm_words : -1;
             out.wm_isN = (p.cut_front || (p.cut_tail && !p.cut_right)) ? (k++) * out.wm_words : -1;
             out.wm_stride = k * out.wm_words;
             out.wm = take(out.NR * out.wm_stride);
@@ -306,7 +335,6 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.swin = take(out.NR);
         out.mlen = take(out.NR);
         if (o & 1) o++;
-        out.inc_lut = take(256);
         out.val4_lut = take(p.dup_bufnum > 0 ? 256 : 0);
         out.wl_cap = 2046;
         out.wl = take(1 + out.wl_cap / 2);
@@ -320,7 +348,17 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.lut_ov = take(lw);
         out.lut_lowq = take(lw);
         out.lut_cplx = take(lw);
-        out.primes = take(p.dup_bufnum > 0 ? 512 * p.dup_bufnum : 0);
+        // Duplicate's primes: as byte planes for the dot-product hash when that table was built, else the plain list
+        out.hp = -1;
+        out.hp_nq = 0;
+        out.primes = 0;
+        if (p.dup_bufnum > 0 && hp_nq > 0) {
+            if (o & 1) o++;
+            out.hp_nq = hp_nq;
+            out.hp = take(4 * hp_nq * p.dup_bufnum * p.dup_npl);
+        } else {
+            out.primes = take(p.dup_bufnum > 0 ? 512 * p.dup_bufnum : 0);
+        }
         out.total = o;
     };
     if (cfg.P > 0) {

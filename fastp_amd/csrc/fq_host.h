@@ -16,6 +16,8 @@ struct HostLuts {
     std::vector<u16> cplx_min;       // [max_len+2]
     std::vector<u32> dup_primes;     // [bufnum*512]
     std::vector<u64> dup_posum;      // [(2*max_len+1)*bufnum]
+    std::vector<u32> dup_planes;     // [4][dup_nq][bufnum][dup_npl], empty when the table would not pay (see build_dev_params)
+    int dup_nq = 0;
     std::vector<u32> fasta_words;    // [n_fasta][ADAPT_WORDS]
     std::vector<int> fasta_len;      // [n_fasta]
     // overrepresentation analysis seeds, per mate
@@ -37,7 +39,8 @@ struct TileConfig {
 int build_dev_params(const fastp_gpu_params& in, DevParams& out, HostLuts& luts, std::string& err);
 
 // picks P (if cfg.P == 0) so that the tile fits cfg.lds_budget; fills L
-int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err);
+// hp_nq = HostLuts::dup_nq (0: no byte-plane prime table, the generic hash path is used)
+int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err, int hp_nq = 0);
 
 u32 magic_for(u32 d);  // ceil(2^32 / d)
 

@@ -53,6 +53,10 @@ FQ_DEV u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi
 // 24-bit x 24-bit -> low 32 bits (full-rate v_mul_u32_u24)
 FQ_DEV u32 mul24(u32 a, u32 b) { return __umul24(a, b); }
 FQ_DEV u32 sum_bytes(u32 a, u32 c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
+// (v >> off) & ((1 << width) - 1)  -> v_bfe_u32 (kept as one instruction next to the shift-add that uses it)
+FQ_DEV u32 bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe(v, off, width); }
+// c + sum of the four byte products a.b[k] * b.b[k]  -> v_dot4_u32_u8
+FQ_DEV u32 dot4_u8(u32 a, u32 b, u32 c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
 // LDS accumulators: fire-and-forget ds_add / ds_or (no return value used)
 FQ_DEV void lds_add_u32(u32* p, u32 v) {

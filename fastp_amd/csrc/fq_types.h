@@ -34,7 +34,10 @@ static const u32 OV_KEY_NONE = 0xFFFFFFFFu;
 // per-lane registers that hold the NEXT tile's input while the current tile is processed
 enum { PF_Q = 3, PF_S = 1 };   // in 16-byte chunks
 
-enum { QH_COPIES = 4 };        // replicated quality histograms (bank spreading)
+// quality table entry (one per Stats slot and quality character): the packed per-cycle increment of that
+// character (u64), its histogram counter, and the constant 1 (0 for character 0 = "no base here") that the
+// one-pass Stats path adds to the k-mer / histogram counters so that bases past a read's end count nothing
+enum { QT_INC = 0, QT_COUNT = 2, QT_ONE = 3, QT_DWORDS = 4 };
 enum { KMER_BINS = 1024 };
 enum { MAX_DUP_BUFS = 8 };
 enum { MAX_ADAPTER_WORDS = 4 };  // 64 bases
@@ -75,6 +78,7 @@ struct DevParams {
     int length_filter, length_required, length_limit;
     int complexity_filter;
     int dup_enabled, dedup, dup_bufnum;
+    int dup_npl;            // byte planes a prime of the hash needs (3: all primes a position can select are < 2^24; else 4)
     u64 dup_bits;           // Duplicate::mBufLenInBits
     int isize_max;
     int umi_len1, umi_len2, umi_skip;
@@ -92,6 +96,8 @@ struct DevLuts {
     const u16* cplx_min;    // [max_len+1]  least adjacent-diff count that passes filter.cpp:65
     const u32* dup_primes;  // [bufnum*512]                                      duplicate.cpp:66-84
     const u64* dup_posum;   // [(2*max_len+1)*bufnum]  sum_{p<n} prime[(p*B+i)&mask]*p
+    const u32* dup_planes;  // [4][hp_nq][bufnum][dup_npl] the primes of four consecutive positions, one byte plane per
+                            // dword (phase_hash_dot); entry (r, q) starts at position 4q + r.  nullptr: not built
     const u32* fasta_words; // [n_fasta][ADAPT_WORDS] packed --adapter_fasta sequences (zero padded)
     const int* fasta_len;   // [n_fasta]
 };
@@ -103,9 +109,9 @@ struct LdsLayout {
     int SW, QW;     // LDS row strides in dwords = the global row strides: a tile in LDS is a flat copy of
                     // the batch rows (bases past a read's length are masked by every consumer)
     int C;          // cycles
-    int Cp;         // C rounded up to a multiple of 4: per-cycle accumulators are stored phase-major,
-                    // entry (pos & 3) * (Cp/4) + (pos >> 2), so lanes that own consecutive quality dwords
-                    // update consecutive LDS words
+    int Cp;         // C rounded up to a multiple of 4: per-cycle accumulators are stored [slot][cycle][class]
+                    // (cyc_index), so the four cycles of a quality dword sit at constant distances and the
+                    // class only adds 8 bytes
     int seq, nmk, qual;            // [NR][SW], [NR][SW], [NR][QW]
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
     int swin;       // [NR] one-pass Stats window of a read: rlen0 | kept length << 16 (0 = not written out)
@@ -121,19 +127,18 @@ struct LdsLayout {
     int wm_badF;    // window [j, j+wF) has total quality <  thrF   (filter.cpp:116)
     int wm_badR;    // window [j, j+wR) has total quality <  thrR   (filter.cpp:151)
     int wm_badT;    // window [j, j+wT) has total quality <  thrT   (filter.cpp:185)
-    int wm_lowQ;    // quality[j] < qRmin                           (filter.cpp:159)
     int wm_isN;     // base j is 'N'                                (filter.cpp:123,191)
     int adapt;      // [2][ADAPT_WORDS] packed adapter words
     int lut_ov, lut_lowq, lut_cplx;                       // u16 tables, (max_len+1+1)/2 dwords each
-    int primes;     // [bufnum*512]
+    int primes;     // [bufnum*512] (generic hash path only)
+    int hp, hp_nq;  // [4][hp_nq][bufnum][dup_npl] byte planes of the primes (DevLuts::dup_planes); hp = -1: generic path
     int val4_lut;   // [256] u32: Duplicate's base values (A7 T222 C74 G31, duplicate.cpp:92-109) of the four
                     // bases a packed byte holds, one byte each
-    int inc_lut;    // [128] u64: the packed per-cycle increment of every quality character
     int wl, wl_cap; // work list of (read, quality dword) items the fast Stats path hands to the general one:
                     // [0] = count, then wl_cap u16 entries
-    int acc_cyc;    // [4][N_CLS][Cp] u64  (2 dwords each)
+    int acc_cyc;    // [4][Cp][N_CLS] u64  (2 dwords each)
     int acc_kmer;   // [4][KMER_BINS] u32
-    int acc_qh;     // [4][128][QH_COPIES] u32
+    int acc_qh;     // [4][128][QT_DWORDS] u32: quality table = mBaseQualHistogram counters next to the constants
     int acc_misc;   // MISC_* u32 counters
     int acc_end;    // end of the accumulator region (acc_cyc..acc_end is flushed)
     int total;      // dwords of dynamic LDS

@@ -84,6 +84,16 @@ static inline unsigned sim_sad_u8(unsigned a, unsigned b, unsigned c) {
     }
     return r;
 }
+static inline unsigned sim_udot4(unsigned a, unsigned b, unsigned c) {
+    for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    return c;
+}
+#define __builtin_amdgcn_udot4(a, b, c, clamp) sim_udot4((a), (b), (c))
+static inline unsigned sim_ubfe(unsigned v, unsigned off, unsigned width) {
+    off &= 31; width &= 31;
+    return width == 0 ? 0u : ((v >> off) & ((1u << width) - 1u));
+}
+#define __builtin_amdgcn_ubfe(v, off, width) sim_ubfe((v), (off), (width))
 #define __builtin_amdgcn_alignbit(hi, lo, s) sim_alignbit((hi), (lo), (s))
 #define __builtin_amdgcn_sad_u8(a, b, c) sim_sad_u8((a), (b), (c))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)

@@ -100,3 +100,32 @@ def case_input(name, n, L=100):
     p.dup_accuracy_level = 1   # 2 x 512 MiB bitmaps: the exchange buffers of two ranks must fit the test box
     params = cases.finalize_params(name, p, d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
     return params, d, paired
+
+
+def device_bit_positions(eng, d, device):
+    """Duplicate::seq2intvector mod mBufLenInBits of every unit as the DEVICE computed it: the scan state the
+    sharded protocol's pass 1 leaves behind ([n][bufnum] u64 first)"""
+    import torch
+    n = len(d["len1"])
+    batches, results, keep = device_batches(eng, d, 0, n, 1, device)
+    scan = torch.zeros(max(16, eng.dup_scan_bytes(n)), dtype=torch.uint8, device=device)
+    eng.submit_pass1_device(batches[0], scan.data_ptr(), results[0])
+    eng.synchronize()
+    B = {1: 2, 2: 2, 3: 4, 4: 4, 5: 4, 6: 8}[int(eng.params.dup_accuracy_level)]
+    return scan[:n * B * 8].cpu().numpy().view(np.uint64).reshape(n, B).copy()
+
+
+def oracle_bit_positions(level, d):
+    import oraclelib
+    n = len(d["len1"])
+    B = {1: 2, 2: 2, 3: 4, 4: 4, 5: 4, 6: 8}[int(level)]
+    pos = np.zeros((n, B), dtype=np.uint64)
+    paired = "seq2" in d
+    s1 = np.ascontiguousarray(d["seq1"], dtype=np.uint8)
+    l1 = np.ascontiguousarray(d["len1"], dtype=np.int32)
+    s2 = np.ascontiguousarray(d["seq2"], dtype=np.uint8) if paired else None
+    l2 = np.ascontiguousarray(d["len2"], dtype=np.int32) if paired else None
+    oraclelib.lib().fastp_oracle_dup_bits_batch(int(level), n, int(s1.shape[1]), s1.ctypes.data, l1.ctypes.data,
+                                                s2.ctypes.data if paired else None, l2.ctypes.data if paired else None,
+                                                pos.ctypes.data)
+    return pos

@@ -430,6 +430,23 @@ def test_gpu_equals_oracle_at_baseline_scale():
     assert cg[lay.dup_total] == total and dup.sum() > 1000   # exact copies only (most synthetic duplicates differ by an error)
 
 
+@pytest.mark.parametrize("level,L,paired", [(1, 150, True), (3, 150, True), (1, 37, True), (1, 250, True), (1, 150, False), (4, 100, True), (6, 100, True)])
+def test_gpu_duplicate_hash_bit_positions_equal_oracle(level, L, paired):
+    """the hash itself (Duplicate::seq2intvector mod mBufLenInBits), not only the decisions it leads to"""
+    import torch
+    import shard_util
+    p = abi.default_params(paired, L)
+    p.dup_accuracy_level = level
+    if not paired:
+        p.adapter_seq_r1 = None
+    d = synth.synth_pairs(20000, L=L, seed=3 + level, paired=paired, ragged_frac=0.6, insert_mean=L * 1.2, insert_sd=L * 0.4)
+    g = engines.gpu_engine(p)
+    got = shard_util.device_bit_positions(g, d, torch.device("cuda", 0))
+    g.close()
+    want = shard_util.oracle_bit_positions(level, d)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} bit positions differ"
+
+
 def test_gpu_reset_starts_a_new_run():
     """fastp_gpu_reset: counters, bloom bitmaps and stream positions as after create"""
     p = abi.default_params(True, 150)

@@ -44,6 +44,27 @@ def test_sim_records_and_counters_equal_oracle(name):
     assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
 
 
+@pytest.mark.parametrize("level,L,paired", [(1, 150, True), (3, 150, True), (1, 37, True), (1, 250, True), (1, 150, False), (-3, 100, True)])
+def test_sim_duplicate_hash_bit_positions_equal_oracle(level, L, paired, monkeypatch):
+    """the hash itself (Duplicate::seq2intvector mod mBufLenInBits), not only the decisions it leads to: every
+    length incl. ragged read-1 lengths (read 2 continues the position index there), N bases, every buffer"""
+    import torch
+    import shard_util
+    if level < 0:   # the multiply form of the hash (the path of accuracy level 6, whose 32 GiB of bitmaps the emulator cannot afford)
+        monkeypatch.setenv("FASTP_GPU_HASH_GENERIC", "1")
+        level = -level
+    p = abi.default_params(paired, L)
+    p.dup_accuracy_level = level
+    if not paired:
+        p.adapter_seq_r1 = None
+    d = synth.synth_pairs(500, L=L, seed=3 + level, paired=paired, ragged_frac=0.6, insert_mean=L * 1.2, insert_sd=L * 0.4)
+    g = engines.sim_engine(p)
+    got = shard_util.device_bit_positions(g, d, torch.device("cpu"))
+    g.close()
+    want = shard_util.oracle_bit_positions(level, d)
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} bit positions differ"
+
+
 @pytest.mark.parametrize("name", cases.GAP_CASES)
 def test_sim_one_gap_accept_paths(name):
     """the oracle must ACCEPT one-gap overlaps / one-gap adapter matches on these inputs (counted), then the
