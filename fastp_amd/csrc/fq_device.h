@@ -569,14 +569,19 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         for (int t = 0; t < S; t++) {
             const int c = cbeg + cc;
             const bool act = rv && c < cmax;
-            const int cr = act ? c : 0;
-            const int cp = cr > 0 ? cr - 1 : 0;
-            const u32 qd = *(const u32*)(qrow_p + 4 * cr);
-            const u32 qp = *(const u32*)(qrow_p + 4 * cp);
-            const u32 cur8 = srow_p[cr];
-            const u32 prev8 = srow_p[cp];
+            const int cr = act ? c : 1;
+            // one DS instruction per row: the quality dword and the one before it (ds_read2_b32), and the two base
+            // dwords that hold base bytes cr - 1 and cr.  (For cr == 0 "the one before" is whatever precedes the row:
+            // read, never used.)  The LDS pipe takes one wave-instruction per ~4.5 cycles per CU whatever its width,
+            // so the number of DS instructions is what this loop pays for.
+            const u32* qw = (const u32*)(qrow_p + 4 * cr);
+            const u32 qp = qw[-1], qd = qw[0];
+            const u32* sw2 = (const u32*)(srow_p + ((cr - 1) & ~3));
+            const u32 pc16 = alignbit(sw2[1], sw2[0], (u32)((cr - 1) & 3) * 8u);
+            const u32 prev8 = pc16 & 0xFFu, cur8 = (pc16 >> 8) & 0xFFu;
             const bool kept = c < ck;
-            const bool plain = act && ((qd | qp) & 0x80808080u) == 0u && (kept || c >= cd);
+            const u32 nany = (qd | (c > 0 ? qp : 0u)) & 0x80808080u;   // an N among the four bases or the four before
+            const bool plain = (int)act & (int)(nany == 0u) & ((int)kept | (int)(c >= cd));
             if (act && !plain) {                // rare: hand it to the general path
                 const u32 slot = lds_add_ret_u32(wl_count, 1u);
                 if (slot < (u32)wl_cap) wl_items[slot] = (u16)(R * QW + c);
@@ -602,16 +607,16 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
                 u64 inc[4];
                 u32 one[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {   // table entry of each character: {increment u64, counter, 1 or 0}
+                for (int k = 0; k < 4; k++) {   // table entry of each character: {increment u64, counter}
                     ta[k] = qt + (bfe(qd, 8 * k, 7) << 4);
                     inc[k] = *(const u64*)ta[k];
-                    one[k] = *(const u32*)(ta[k] + QT_ONE * 4);
+                    one[k] = (u32)inc[k] & 1u;  // the count field's increment: 1 for a base, 0 for character 0
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     lds_add_u64((u64*)(cyc + (bfe(cur8, 2 * k, 2) << 3) + k * (N_CLS * 8)), inc[k]);
                 if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N); a base past the read's end adds 0
-                    const u32 codes = prev8 | (cur8 << 8);
+                    const u32 codes = pc16 & 0xFFFFu;
 #pragma unroll
                     for (int k = 0; k < 4; k++) lds_add_u32((u32*)(kmer + (bfe(codes, 2 * k, 10) << 2)), one[k]);
                 }
@@ -841,7 +846,7 @@ FQ_DEV void phase_hash_dot(const KernelArgs& a, u32* lds, int tid, int nthreads)
     u64* hash_v = (u64*)(lds + L.hash);
     const int total = L.NR * 4;
     const int lane = tid & 63;
-    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (shuffles inside)
+    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (lane exchanges inside)
         const int t = t0 + lane;
         const bool valid = t < total;
         const int R = valid ? (t >> 2) : 0, seg = t & 3;
@@ -870,15 +875,8 @@ FQ_DEV void phase_hash_dot(const KernelArgs& a, u32* lds, int tid, int nthreads)
         for (int i = 0; i < B; i++) {
             u64 h = (u64)acc[i * NPL] + ((u64)acc[i * NPL + 1] << 8) + ((u64)acc[i * NPL + 2] << 16);
             if (NPL > 3) h += (u64)acc[i * NPL + 3] << 24;
-            u32 lo = (u32)h, hi = (u32)(h >> 32);
-#pragma unroll
-            for (int sh = 1; sh < 4; sh <<= 1) {
-                const u64 o = (u64)shfl_xor(lo, sh) | ((u64)shfl_xor(hi, sh) << 32);
-                const u64 n = (((u64)hi << 32) | lo) + o;
-                lo = (u32)n;
-                hi = (u32)(n >> 32);
-            }
-            if (valid && seg == 0) hash_v[(size_t)R * B + i] = ((u64)hi << 32) | lo;
+            h = sum4_u64(h);
+            if (valid && seg == 0) hash_v[(size_t)R * B + i] = h;
         }
     }
 }
@@ -1440,38 +1438,35 @@ FQ_DEV bool apply_fasta_trims(const KernelArgs& a, u32* lds, int R, u32 read_ind
 
 // ---------------------------------------------------------------------------
 // fastp_simd::countQualityMetrics (simd.cpp:54-119) and countAdjacentDiffs (:162-185) on the
-// final window [front, front+len) of every read: 8 lanes per read, lane s takes quality
-// dwords s, s+8, ... with byte-parallel arithmetic, a 3-step shuffle folds the partial sums.
+// final window [front, front+len) of every read: 4 lanes per read, lane s takes the window's quality
+// dwords s, s+4, ... with byte-parallel arithmetic, two DPP steps fold the partial sums.
 //   met[R][0] = total(qual-33) | lowQualNum << 16      met[R][1] = nBaseNum | adjacentDiffs << 16
 // ---------------------------------------------------------------------------
 FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     // argument-block fields fetched once, not at every use inside the loops
-    const int D = (p.qw_g + 7) >> 3, QW = L.QW, SW = L.SW;
+    const int QW = L.QW, SW = L.SW;
     const bool cplx = p.complexity_filter != 0;
     const int* front_v = lds_i(lds, L.front);
     const int* wlen_v = lds_i(lds, p.merge ? L.mlen : L.len);
     const u32* qual_v = lds + L.qual;
     const u32* seq_v = lds + L.seq;
     u32* met_v = lds + L.met;
-    const int total = L.NR * 8;
+    const int total = L.NR * 4;   // 4 lanes per read, quality dwords interleaved
     const int lane = tid & 63;
     const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
-    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (shuffles inside)
+    for (int t0 = tid - lane; t0 < total; t0 += nthreads) {  // wave-uniform trip count (lane exchanges inside)
         const int t = t0 + lane;
         const bool valid = t < total;
-        const int R = valid ? (t >> 3) : 0, seg = t & 7;
+        const int R = valid ? (t >> 2) : 0, seg = t & 3;
         const int f = front_v[R];
         const int e = valid ? f + wlen_v[R] : f;
         const u32* qrow = qual_v + rowoff(R, QW);
         const u32* srow = seq_v + rowoff(R, SW);
         u32 ma = 0, mb = 0;
-        for (int d = 0; d < D; d++) {
-            const int c = seg + 8 * d;
+        for (int c = (f >> 2) + seg; 4 * c < e; c += 4) {  // only the dwords that touch the window
             const int j0 = 4 * c;
-            if (j0 >= e) break;
-            if (j0 + 4 <= f) continue;
             const u32 qd = qrow[c];
             const u32 q7 = qd & 0x7F7F7F7Fu;
             const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;  // bit 7 of a byte: qual >= threshold
@@ -1508,11 +1503,8 @@ FQ_DEV void phase_metrics(const KernelArgs& a, u32* lds, int tid, int nthreads) 
                 mb += (u32)popc32((d4 | dn) & M4) << 16;
             }
         }
-#pragma unroll
-        for (int sh = 1; sh < 8; sh <<= 1) {
-            ma += shfl_xor(ma, sh);
-            mb += shfl_xor(mb, sh);
-        }
+        ma = sum4(ma);
+        mb = sum4(mb);
         if (valid && seg == 0) {
             met_v[2 * R] = ma;
             met_v[2 * R + 1] = mb;

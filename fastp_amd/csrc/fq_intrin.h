@@ -41,6 +41,23 @@ FQ_DEV void wave_sync() {
 FQ_DEV u64 ballot(bool pred) { return __ballot(pred); }
 FQ_DEV u32 shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
 FQ_DEV u32 shfl_xor(u32 v, int mask) { return (u32)__shfl_xor((int)v, mask, 64); }
+// lane exchanges inside a row of 16 lanes as DPP modifiers (no LDS round trip like ds_bpermute):
+// the value of lane ^ 1, lane ^ 2 (quad_perm) and of the mirrored lane of the 8-lane half row
+template <int CTRL> FQ_DEV u32 dpp_move(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+FQ_DEV u32 quad_xor1(u32 v) { return dpp_move<0xB1>(v); }    // quad_perm:[1,0,3,2]
+FQ_DEV u32 quad_xor2(u32 v) { return dpp_move<0x4E>(v); }    // quad_perm:[2,3,0,1]
+FQ_DEV u32 half_mirror(u32 v) { return dpp_move<0x141>(v); } // row_half_mirror: lane i <-> 7 - i of each 8 lanes
+// sum over the 4 (8) lanes of an aligned group, left in every lane of the group
+FQ_DEV u32 sum4(u32 v) { v += quad_xor1(v); return v + quad_xor2(v); }
+FQ_DEV u32 sum8(u32 v) { v = sum4(v); return v + half_mirror(v); }
+FQ_DEV u64 sum4_u64(u64 v) {
+    u64 o = (u64)quad_xor1((u32)v) | ((u64)quad_xor1((u32)(v >> 32)) << 32);
+    v += o;
+    o = (u64)quad_xor2((u32)v) | ((u64)quad_xor2((u32)(v >> 32)) << 32);
+    return v + o;
+}
 FQ_DEV int popc32(u32 v) { return __popc(v); }
 FQ_DEV int popc64(u64 v) { return __popcll(v); }
 FQ_DEV int ffs64(u64 v) { return __ffsll((unsigned long long)v); }  // 1-based, 0 if none

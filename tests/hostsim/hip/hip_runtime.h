@@ -94,6 +94,18 @@ static inline unsigned sim_ubfe(unsigned v, unsigned off, unsigned width) {
     return width == 0 ? 0u : ((v >> off) & ((1u << width) - 1u));
 }
 #define __builtin_amdgcn_ubfe(v, off, width) sim_ubfe((v), (off), (width))
+// DPP lane exchanges used by fq_intrin.h: quad_perm (ctrl < 0x100), row_half_mirror (0x141), row_mirror (0x140)
+static inline int sim_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+    const int lane = (int)(sim::thread_idx().x & 63u);
+    int from = lane;
+    if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));
+    else abort();
+    return sim::shfl(src, from);
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) sim_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_alignbit(hi, lo, s) sim_alignbit((hi), (lo), (s))
 #define __builtin_amdgcn_sad_u8(a, b, c) sim_sad_u8((a), (b), (c))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
