@@ -98,16 +98,33 @@ FQ_DEV void tile_init_read(const LdsLayout& L, u32* lds, int R, int len) {
     }
     if (R == 0) lds[L.wl] = 0;
 }
-// N masks from bit 7 of quality dword d (flat index inside the tile) - the rare path
-FQ_DEV void tile_note_n(const KernelArgs& a, u32* lds, int d, u32 v) {
+// N masks (bit 2k of word w = base 16w + k is N) of every read, from bit 7 of its quality bytes, and the read's
+// RS_HAS_N flag: lane = (read, 16-base word).  Every word is written, so nothing has to be cleared beforehand.
+FQ_DEV void phase_nmask(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
-    const u32 nb = (v >> 7) & 0x01010101u;
-    if (!nb) return;
-    const int R = (int)fastdiv((u32)d, a.magic_qwg);
-    const int col = d - R * L.QW;
-    const u32 t = (nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u;
-    lds_or_u32(&lds[L.nmk + R * L.SW + (col >> 2)], t << ((col & 3) * 8));
-    lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+    const int SW = L.SW, QW = L.QW;
+    const int total = L.NR * SW;
+    const u32 magic = a.magic_sw;
+    int* flags = lds_i(lds, L.flags);
+    for (int i = tid; i < total; i += nthreads) {
+        const int R = (int)fastdiv((u32)i, magic), w = i - R * SW;
+        u32 m = 0;
+        if (4 * w < QW) {  // quality dwords 4w .. 4w+3 (rows are 8-byte aligned: QW is even)
+            const u64* q2 = (const u64*)(lds + L.qual + rowoff(R, QW) + 4 * w);
+            const u64 a01 = q2[0];
+            const u64 a23 = 4 * w + 2 < QW ? q2[1] : 0ull;
+            if ((a01 | a23) & 0x8080808080808080ull) {
+                const u32 qd[4] = {(u32)a01, (u32)(a01 >> 32), (u32)a23, (u32)(a23 >> 32)};
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const u32 nb = (qd[d] >> 7) & 0x01010101u;
+                    m |= ((nb | (nb >> 6) | (nb >> 12) | (nb >> 18)) & 0x55u) << (8 * d);
+                }
+                lds_or_i32(&flags[R], RS_HAS_N);
+            }
+        }
+        lds[L.nmk + i] = m;
+    }
 }
 
 // Phase A, scalar form (any alignment / tile shape).  The LDS rows have the batch's own strides,
@@ -124,19 +141,13 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
         const int gp = tile_first + (R - m * P);
         tile_init_read(L, lds, R, gp < a.n ? (int)(m ? len1 : len0)[gp] : 0);
     }
-    for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
     for (int m = 0; m < mates; m++) {
         const u32* g = a.seq[m] + (size_t)tile_first * L.SW;
         for (int i = tid; i < P * L.SW; i += nthreads) lds[L.seq + m * P * L.SW + i] = i < rows * L.SW ? g[i] : 0u;
     }
-    block_sync();
     for (int m = 0; m < mates; m++) {
         const u32* g = a.qual[m] + (size_t)tile_first * L.QW;
-        for (int i = tid; i < P * L.QW; i += nthreads) {
-            const u32 v = i < rows * L.QW ? g[i] : 0u;
-            lds[L.qual + m * P * L.QW + i] = v;
-            tile_note_n(a, lds, m * P * L.QW + i, v);
-        }
+        for (int i = tid; i < P * L.QW; i += nthreads) lds[L.qual + m * P * L.QW + i] = i < rows * L.QW ? g[i] : 0u;
     }
 }
 
@@ -151,26 +162,21 @@ struct TileRegs {
     u32 len;
 };
 
-FQ_DEV u32x4 tile_chunk(const u32* const g[2], int tile_first, int P, int row_dw, int n, int ci) {
-    // chunk ci of the tile's [mate][P rows][row_dw dwords] block; rows past the batch end read as zero
-    const int per_mate = P * row_dw / 4;
+// chunk ci (16 bytes) of the tile's [mate][P rows][row_dw dwords] block; rows past the batch end read as zero.
+// g0 / g1 = the two mates' row arrays (scalars: a per-lane choice between them as POINTERS would be a vector load
+// from the argument block followed by vmcnt(0), which drains every prefetch load issued before it),
+// per_mate = P * row_dw / 4 chunks, have = rows * row_dw dwords of each mate exist.
+FQ_DEV u32x4 tile_chunk(const u32* g0, const u32* g1, int per_mate, int have, int ci) {
     const int m = ci >= per_mate ? 1 : 0;
-    const int cm = ci - m * per_mate;
-    const int rows = imax(0, imin(P, n - tile_first));
+    const int cm = ci - (m ? per_mate : 0);
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (4 * cm < rows * row_dw) {
-        // both mates' base pointers as scalars + a select: g[m] with a per-lane m is a vector load from the
-        // argument block followed by a vmcnt(0) wait, which drains every prefetch load issued before it
-        const u32* g0 = g[0];
-        const u32* g1 = g[1];
-        const u32* src = (m ? g1 : g0) + (size_t)tile_first * row_dw + 4 * cm;
-        if (4 * cm + 4 <= rows * row_dw) {
-            v = *(const u32x4*)src;
-        } else {  // the chunk straddles the last existing row (odd row count)
-            v.x = src[0];
-            if (4 * cm + 1 < rows * row_dw) v.y = src[1];
-            if (4 * cm + 2 < rows * row_dw) v.z = src[2];
-        }
+    const u32* src = (m ? g1 : g0) + 4 * cm;
+    if (4 * cm + 4 <= have) {
+        v = *(const u32x4*)src;
+    } else if (4 * cm < have) {  // the chunk straddles the last existing row (odd row count)
+        v.x = src[0];
+        if (4 * cm + 1 < have) v.y = src[1];
+        if (4 * cm + 2 < have) v.z = src[2];
     }
     return v;
 }
@@ -178,17 +184,23 @@ FQ_DEV u32x4 tile_chunk(const u32* const g[2], int tile_first, int P, int row_dw
 FQ_DEV void tile_fetch(const KernelArgs& a, int tile_first, int tid, int nthreads, TileRegs& r) {
     const LdsLayout& L = a.L;
     const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
+    const int rows = imax(0, imin(L.P, a.n - tile_first));
+    const u32* q0 = a.qual[0] + (size_t)tile_first * L.QW;
+    const u32* q1 = a.qual[1] + (size_t)tile_first * L.QW;
+    const u32* s0 = a.seq[0] + (size_t)tile_first * L.SW;
+    const u32* s1 = a.seq[1] + (size_t)tile_first * L.SW;
+    const int qpm = L.P * L.QW / 4, spm = L.P * L.SW / 4;
 #pragma unroll
     for (int i = 0; i < PF_Q; i++) {
         const int ci = tid + i * nthreads;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        r.q[i] = ci < nq ? tile_chunk(a.qual, tile_first, L.P, L.QW, a.n, ci) : z;
+        r.q[i] = ci < nq ? tile_chunk(q0, q1, qpm, rows * L.QW, ci) : z;
     }
 #pragma unroll
     for (int i = 0; i < PF_S; i++) {
         const int ci = tid + i * nthreads;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        r.s[i] = ci < ns ? tile_chunk(a.seq, tile_first, L.P, L.SW, a.n, ci) : z;
+        r.s[i] = ci < ns ? tile_chunk(s0, s1, spm, rows * L.SW, ci) : z;
     }
     r.len = 0;
     if (tid < L.NR) {
@@ -204,26 +216,15 @@ FQ_DEV void tile_commit(const KernelArgs& a, u32* lds, int tid, int nthreads, co
     const LdsLayout& L = a.L;
     const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
     if (tid < L.NR) tile_init_read(L, lds, tid, (int)r.len);
-    for (int i = tid; i < L.NR * L.SW; i += nthreads) lds[L.nmk + i] = 0;
 #pragma unroll
     for (int i = 0; i < PF_S; i++) {
         const int ci = tid + i * nthreads;
         if (ci < ns) *(u32x4*)(lds + L.seq + 4 * ci) = r.s[i];
     }
-    block_sync();
 #pragma unroll
     for (int i = 0; i < PF_Q; i++) {
         const int ci = tid + i * nthreads;
-        if (ci < nq) {
-            const u32x4 v = r.q[i];
-            *(u32x4*)(lds + L.qual + 4 * ci) = v;
-            if ((v.x | v.y | v.z | v.w) & 0x80808080u) {  // some base of this chunk is N
-                tile_note_n(a, lds, 4 * ci, v.x);
-                tile_note_n(a, lds, 4 * ci + 1, v.y);
-                tile_note_n(a, lds, 4 * ci + 2, v.z);
-                tile_note_n(a, lds, 4 * ci + 3, v.w);
-            }
-        }
+        if (ci < nq) *(u32x4*)(lds + L.qual + 4 * ci) = r.q[i];
     }
 }
 
@@ -1037,24 +1038,30 @@ FQ_DEV void phase_polyg(const KernelArgs& a, u32* lds, int tid, int nthreads) {
 // atomic-min over keys ordered like the reference's scan.
 // ---------------------------------------------------------------------------
 struct PairView {
-    const u32 *s1, *n1, *s2, *n2;  // LDS rows (packed bases, N masks) of the two mates
-    int f1, l1, e2, l2;            // r1' = row1[f1, f1+l1), r2' = row2[e2-l2, e2)
+    const u32 *s1, *n1;   // LDS rows of read 1: packed bases, N mask
+    const u32 *rc, *rcn;  // LDS rows of rc(whole read 2) and its N mask (phase_rc)
+    int f1, l1, z2, l2;   // r1' = row1[f1, f1+l1);  rc(r2') = rc[z2, z2+l2) with z2 = rlen0(r2) - (front2 + len2)
     bool hasN;
 };
+FQ_DEV void pair_view(const LdsLayout& L, u32* lds, int pr, PairView& v) {
+    const int R1 = pr, R2 = L.P + pr;
+    v.s1 = lds_seq(L, lds, R1);
+    v.n1 = lds_nmk(L, lds, R1);
+    v.rc = lds + L.rc + rowoff(pr, L.SW);
+    v.rcn = lds + L.rcn + rowoff(pr, L.SW);
+    v.f1 = lds_i(lds, L.front)[R1];
+    v.l1 = lds_i(lds, L.len)[R1];
+    v.l2 = lds_i(lds, L.len)[R2];
+    v.z2 = lds_i(lds, L.rlen0)[R2] - (lds_i(lds, L.front)[R2] + v.l2);
+    v.hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
+}
 // 16 bases of r1' starting at t (t >= 0; bases past l1 are whatever the row holds)
 FQ_DEV u32 ov_r1(const PairView& v, int t) { return window16(v.s1, v.f1 + t); }
 FQ_DEV u32 ov_r1n(const PairView& v, int t) { return window16(v.n1, v.f1 + t); }
 // 16 bases of rc(r2') starting at t: rc[k] = comp(r2'[l2-1-k]); complement of a code is code^1,
 // an N keeps code 0 on both strands (the rc of N is N, overlapanalysis.cpp:19-22 / simd.cpp:129)
-FQ_DEV u32 ov_rc2n(const PairView& v, int t) { return reverse_groups(window16_signed(v.n2, v.e2 - 16 - t)); }
-FQ_DEV u32 ov_rc2(const PairView& v, int t) {
-    u32 w = reverse_groups(window16_signed(v.s2, v.e2 - 16 - t)) ^ 0x55555555u;
-    if (v.hasN) {
-        const u32 n = ov_rc2n(v, t);
-        w &= ~(n | (n << 1));
-    }
-    return w;
-}
+FQ_DEV u32 ov_rc2(const PairView& v, int t) { return window16(v.rc, v.z2 + t); }
+FQ_DEV u32 ov_rc2n(const PairView& v, int t) { return window16(v.rcn, v.z2 + t); }
 template <int DIR> FQ_DEV u32 ov_x(const PairView& v, int t) { return DIR ? ov_rc2(v, t) : ov_r1(v, t); }
 template <int DIR> FQ_DEV u32 ov_y(const PairView& v, int t) { return DIR ? ov_r1(v, t) : ov_rc2(v, t); }
 template <int DIR> FQ_DEV u32 ov_xn(const PairView& v, int t) { return DIR ? ov_rc2n(v, t) : ov_r1n(v, t); }
@@ -1079,53 +1086,65 @@ FQ_DEV int ov_verify(const PairView& v, int o, int lenX, int lenY, const short* 
     return ol > 50 ? cnt_full : cnt_pre;
 }
 
+// key of (direction, offset, diff) in the reference's scan order
+FQ_DEV u32 ov_key(int dir, int o, int diff) {
+    return ((u32)dir << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS)) | ((u32)o << OV_KEY_DIFF_BITS) | (u32)diff;
+}
+// one offset that passed the prefilter: exact test, winner by atomic-min
 template <int DIR>
-FQ_DEV void overlap_task(const KernelArgs& a, u32* lds, int pr, int part) {
+FQ_DEV void overlap_check(const LdsLayout& L, u32* lds, const PairView& v, int pr, int o) {
+    const int lenX = DIR ? v.l2 : v.l1, lenY = DIR ? v.l1 : v.l2;
+    const int diff = ov_verify<DIR>(v, o, lenX, lenY, (const short*)(lds + L.lut_ov));
+    if (diff >= 0) lds_min_u32((u32*)&lds_i(lds, L.ov_off)[pr], ov_key(DIR, o, diff));
+}
+
+// Pass 1, task = (pair, direction, quarter): the prefilter over blocks of 16 offsets.  Per offset: v_alignbit
+// (X shifted), xor, shift, and-or (2-bit groups that differ), v_bcnt with -(lmax+1) as the addend (negative <=>
+// at most lmax mismatches), v_alignbit to shift that sign into the block's candidate mask - six instructions.
+// Survivors go to the tile's candidate list; pass 2 verifies them with every lane busy instead of one lane per
+// wavefront verifying while 63 wait.
+template <int DIR>
+FQ_DEV void overlap_scan(const KernelArgs& a, u32* lds, int pr, int part) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     const int R1 = pr, R2 = L.P + pr;
     if ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_NULL) return;  // r1 != NULL && r2 != NULL
     PairView v;
-    v.s1 = lds_seq(L, lds, R1);
-    v.n1 = lds_nmk(L, lds, R1);
-    v.s2 = lds_seq(L, lds, R2);
-    v.n2 = lds_nmk(L, lds, R2);
-    v.f1 = lds_i(lds, L.front)[R1];
-    v.l1 = lds_i(lds, L.len)[R1];
-    v.l2 = lds_i(lds, L.len)[R2];
-    v.e2 = lds_i(lds, L.front)[R2] + v.l2;
-    v.hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
+    pair_view(L, lds, pr, v);
     const int lenX = DIR ? v.l2 : v.l1, lenY = DIR ? v.l1 : v.l2;
     const int nvalid = lenX - p.overlap_require;  // offsets 0 .. nvalid-1 (:48, :73)
     if (nvalid <= 0) return;
-    const short* lut = (const short*)(lds + L.lut_ov);
     // every legal offset compares at least min(require+1, lenY) bases; prefilter on <= 16 of them
     const int npre = imin(16, imin(p.overlap_require + 1, lenY));
     const u32 premask = lowmask32(2 * npre) & 0x55555555u;
     const u32 y0 = ov_y<DIR>(v, 0);
-    const int lmax = p.ov_limit_max;
-    u32* keyp = (u32*)&lds_i(lds, L.ov_off)[pr];
+    const u32 nlim = (u32)(-(p.ov_limit_max + 1));
+    const u32* xrow = DIR ? v.rc : v.s1;
+    const int xoff = DIR ? v.z2 : v.f1;
+    u32* cl = lds + L.cand;
     for (int b = part; 16 * b < nvalid; b += 4) {
         const int o0 = 16 * b;
-        if (*(volatile u32*)keyp < ((u32)DIR << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS) | ((u32)o0 << OV_KEY_DIFF_BITS))) break;  // beaten already
-        const u32 w0 = ov_x<DIR>(v, o0), w1 = ov_x<DIR>(v, o0 + 16);
+        const int bp = xoff + o0;
+        const u32* xw = xrow + (bp >> 4);
+        const u32 sh = (u32)(bp & 15) * 2u;
+        const u32 d0 = xw[0], d1 = xw[1], d2 = xw[2];
+        const u32 w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
         u32 cand = 0;  // bit (15 - t) <=> offset o0 + t survives the prefilter
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             const u32 x = t ? alignbit(w1, w0, 2 * t) : w0;
             const u32 d = x ^ y0;
-            const int cnt = popc32((d | (d >> 1)) & premask);
-            cand = cand + cand + (u32)(cnt <= lmax);
+            const u32 sd = (u32)popc32((d | (d >> 1)) & premask) + nlim;  // negative <=> count <= lmax
+            cand = alignbit(cand, sd, 31);
         }
+        cand &= 0xFFFFu;
         if (nvalid - o0 < 16) cand &= ~lowmask32(16 - (nvalid - o0));
         while (cand) {
             const int t = clz32(cand) - 16;  // smallest surviving offset first
             cand &= ~(0x8000u >> t);
-            const int diff = ov_verify<DIR>(v, o0 + t, lenX, lenY, lut);
-            if (diff >= 0) {
-                lds_min_u32(keyp, ((u32)DIR << (OV_KEY_OFF_BITS + OV_KEY_DIFF_BITS)) | ((u32)(o0 + t) << OV_KEY_DIFF_BITS) | (u32)diff);
-                return;
-            }
+            const u32 slot = lds_add_ret_u32(cl, 1u);
+            if (slot < (u32)L.cand_cap) cl[1 + slot] = ((u32)pr << 11) | ((u32)DIR << 10) | (u32)(o0 + t);
+            else overlap_check<DIR>(L, lds, v, pr, o0 + t);  // list full (low-complexity reads): verify here
         }
     }
 }
@@ -1186,15 +1205,7 @@ FQ_DEV void overlap_gap_task(const KernelArgs& a, u32* lds, int pr, int part) {
     if ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_NULL) return;
     if ((u32)lds_i(lds, L.ov_off)[pr] != OV_KEY_NONE) return;  // the no-gap passes return first (:48-89)
     PairView v;
-    v.s1 = lds_seq(L, lds, R1);
-    v.n1 = lds_nmk(L, lds, R1);
-    v.s2 = lds_seq(L, lds, R2);
-    v.n2 = lds_nmk(L, lds, R2);
-    v.f1 = lds_i(lds, L.front)[R1];
-    v.l1 = lds_i(lds, L.len)[R1];
-    v.l2 = lds_i(lds, L.len)[R2];
-    v.e2 = lds_i(lds, L.front)[R2] + v.l2;
-    v.hasN = ((lds_i(lds, L.flags)[R1] | lds_i(lds, L.flags)[R2]) & RS_HAS_N) != 0;
+    pair_view(L, lds, pr, v);
     const int lenX = DIR ? v.l2 : v.l1, lenY = DIR ? v.l1 : v.l2;
     const int nvalid = lenX - p.overlap_require;
     if (nvalid <= 0) return;
@@ -1248,6 +1259,32 @@ FQ_DEV void phase_overlap_gap(const KernelArgs& a, u32* lds, int tid, int nthrea
     }
 }
 
+// rc(whole read 2) and its N mask into the rc rows: lane = (pair, 16-base word).  Runs on the reads as loaded;
+// BaseCorrector's edits of read 2 are mirrored into the rows by store_base.
+FQ_DEV void phase_rc(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    if (!a.p.paired) return;
+    const int SW = L.SW, P = L.P;
+    const int total = P * SW;
+    const u32 magic = a.magic_sw;
+    for (int i = tid; i < total; i += nthreads) {
+        const int pr = (int)fastdiv((u32)i, magic), w = i - pr * SW;
+        const int R2 = P + pr;
+        const int l2 = lds_i(lds, L.rlen0)[R2];
+        // rc[16w + k] = comp(r2[l2 - 1 - 16w - k]): the 16 bases that END at l2 - 16w, reversed
+        const int bp = l2 - 16 - 16 * w;
+        u32 x = reverse_groups(window16_signed(lds_seq(L, lds, R2), bp)) ^ 0x55555555u;
+        u32 n = 0;
+        if (lds_i(lds, L.flags)[R2] & RS_HAS_N) {
+            n = reverse_groups(window16_signed(lds_nmk(L, lds, R2), bp));
+            x &= ~(n | (n << 1));   // N stays code 0 on both strands
+        }
+        lds[L.rc + i] = x;
+        lds[L.rcn + i] = n;
+    }
+    if (tid == 0) lds[L.cand] = 0;
+}
+
 FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
@@ -1259,9 +1296,22 @@ FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) 
     for (int t = tid; t < 2 * half; t += nthreads) {
         const int dir = t >= half ? 1 : 0;
         const int u = t - dir * half;
-        if (dir) overlap_task<1>(a, lds, u >> 2, u & 3);
-        else overlap_task<0>(a, lds, u >> 2, u & 3);
+        if (dir) overlap_scan<1>(a, lds, u >> 2, u & 3);
+        else overlap_scan<0>(a, lds, u >> 2, u & 3);
     }
+    block_sync();
+    // pass 2: lane = candidate
+    const int nc = imin((int)lds[L.cand], L.cand_cap);
+    for (int i = tid; i < nc; i += nthreads) {
+        const u32 e = lds[L.cand + 1 + i];
+        const int pr = (int)(e >> 11), o = (int)(e & 0x3FFu);
+        PairView v;
+        pair_view(L, lds, pr, v);
+        if (e & 0x400u) overlap_check<1>(L, lds, v, pr, o);
+        else overlap_check<0>(L, lds, v, pr, o);
+    }
+    block_sync();
+    if (tid == 0) lds[L.cand] = 0;   // ready for the next use (merge mode analyzes twice per tile)
 }
 
 // decode the packed scan key of a pair (lengths = the mates' lengths at analyze time)
@@ -1552,6 +1602,17 @@ FQ_DEV void store_base(const KernelArgs& a, u32* lds, int R, int j, u32 sym, u32
     nrow[w] = (nrow[w] & ~(1u << sh)) | ((sym == 4u ? 1u : 0u) << sh);
     q[j] = (u8)(qchar | (sym == 4u ? 0x80u : 0u));
     if (sym == 4u) lds_or_i32(&lds_i(lds, L.flags)[R], RS_HAS_N);
+    if (R >= L.P && L.rc >= 0) {  // read 2: the same base in the rc rows (position rlen0 - 1 - j, complemented; N -> 0)
+        const int k = lds_i(lds, L.rlen0)[R] - 1 - j;
+        if (k >= 0) {
+            u32* rc = lds + L.rc + rowoff(R - L.P, L.SW);
+            u32* rcn = lds + L.rcn + rowoff(R - L.P, L.SW);
+            const int w2 = k >> 4, sh2 = (k & 15) * 2;
+            const u32 c2 = sym == 4u ? 0u : (sym ^ 1u);
+            rc[w2] = (rc[w2] & ~(3u << sh2)) | (c2 << sh2);
+            rcn[w2] = (rcn[w2] & ~(1u << sh2)) | ((sym == 4u ? 1u : 0u) << sh2);
+        }
+    }
 }
 
 FQ_DEV void write_read_result(const KernelArgs& a, u32* lds, int m, int R, int gp) {
@@ -1982,9 +2043,12 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         }
         block_sync();
         if (prefetch && tile + grid_blocks() < a.tiles) tile_fetch(a, (tile + grid_blocks()) * L.P, tid, nt, regs);
+        phase_nmask(a, lds, tid, nt);
+        block_sync();
         FQ_STAMP(0)
         if (!a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
         phase_masks(a, lds, n_valid, tid, nt);
+        phase_rc(a, lds, tid, nt);
         if (timing_on) { block_sync(); FQ_STAMP(8) }
         phase_hash(a, lds, tid, nt);
         block_sync();
@@ -1998,7 +2062,6 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         }
         FQ_STAMP(3)
         phase_overlap(a, lds, tid, nt);
-        block_sync();
         if (a.p.allow_gap) {
             phase_overlap_gap(a, lds, tid, nt);
             block_sync();
@@ -2009,7 +2072,6 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         block_sync();
         if (a.p.merge) {
             phase_overlap(a, lds, tid, nt);
-            block_sync();
             phase_merge(a, lds, tile_first, tid, nt);
             block_sync();
         }
@@ -2055,6 +2117,8 @@ FQ_DEV void hash_body(const KernelArgs& a, u32* lds) {
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
         phase_load(a, lds, tile_first, tid, nt);
+        block_sync();
+        phase_nmask(a, lds, tid, nt);
         block_sync();
         phase_hash(a, lds, tid, nt);
         block_sync();

@@ -324,6 +324,14 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.nmk = take(out.NR * out.SW);
         o = (o + 3) & ~3;
         out.qual = take(out.NR * out.QW);
+        out.rc = out.rcn = out.cand = -1;
+        out.cand_cap = 0;
+        if (p.paired) {
+            out.rc = take(P * out.SW + 2);    // + the dword a 16-base window read may touch behind the last row
+            out.rcn = take(P * out.SW + 2);
+            out.cand_cap = 4 * P;
+            out.cand = take(1 + out.cand_cap);
+        }
         out.rlen0 = take(out.NR);
         out.front = take(out.NR);
         out.len = take(out.NR);

@@ -119,6 +119,9 @@ struct LdsLayout {
     int met;        // [NR][2] countQualityMetrics / countAdjacentDiffs of the final window (phase_metrics)
     int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed no-gap scan key (OV_KEY_*),
                                                           // ov_len the key of the one-gap pass (allow_gap)
+    int rc, rcn;    // [P][SW] paired: the reverse complement of the WHOLE read 2 (rc[k] = comp(r2[rlen0-1-k]), N kept as
+                    // code 0) and its N mask - OverlapAnalysis::analyze's rc(r2') is a forward window of this row
+    int cand, cand_cap;  // overlap candidates that passed the prefilter: [0] = count, then cand_cap u32 entries
     int hash;       // [NR][bufnum] u64 (2 dwords each): per-read part of Duplicate::seq2intvector
     // per-read position bit masks (bit j of a mask = predicate at base j of the row), built in
     // the pre-stats pass and bit-scanned by Filter::trimAndCut's resolver; an offset is -1 when
