@@ -156,76 +156,69 @@ FQ_DEV void phase_load(const KernelArgs& a, u32* lds, int tile_first, int tid, i
 // issued right after tile i has been staged and stay in flight (registers) while tile i is
 // processed, so the HBM latency of a tile is hidden behind the compute of the previous one.
 // ---------------------------------------------------------------------------
-struct TileRegs {
-    u32x4 q[PF_Q];
-    u32x4 s[PF_S];
-    u32 len;
-};
 
-// chunk ci (16 bytes) of the tile's [mate][P rows][row_dw dwords] block; rows past the batch end read as zero.
-// g0 / g1 = the two mates' row arrays (scalars: a per-lane choice between them as POINTERS would be a vector load
-// from the argument block followed by vmcnt(0), which drains every prefetch load issued before it),
-// per_mate = P * row_dw / 4 chunks, have = rows * row_dw dwords of each mate exist.
-FQ_DEV u32x4 tile_chunk(const u32* g0, const u32* g1, int per_mate, int have, int ci) {
-    const int m = ci >= per_mate ? 1 : 0;
-    const int cm = ci - (m ? per_mate : 0);
-    u32x4 v = {0u, 0u, 0u, 0u};
-    const u32* src = (m ? g1 : g0) + 4 * cm;
-    if (4 * cm + 4 <= have) {
-        v = *(const u32x4*)src;
-    } else if (4 * cm < have) {  // the chunk straddles the last existing row (odd row count)
-        v.x = src[0];
-        if (4 * cm + 1 < have) v.y = src[1];
-        if (4 * cm + 2 < have) v.z = src[2];
+// Stage a FULL tile (all P rows exist): 16-byte chunks HBM -> registers -> LDS, every chunk's load issued before
+// the first store waits for one.  No bounds logic (a ragged last tile goes through phase_load).  The mates' row
+// arrays are scalars: a per-lane choice between them as POINTERS from the argument block would be a vector load
+// followed by a wait.
+FQ_DEV void tile_stage(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
+    typedef u32 v4u __attribute__((vector_size(16)));   // a native 16-byte vector: stays in registers
+    const v4u* q0 = (const v4u*)(a.qual[0] + (size_t)tile_first * L.QW);
+    const v4u* q1 = (const v4u*)(a.qual[1] + (size_t)tile_first * L.QW);
+    const v4u* s0 = (const v4u*)(a.seq[0] + (size_t)tile_first * L.SW);
+    const v4u* s1 = (const v4u*)(a.seq[1] + (size_t)tile_first * L.SW);
+    const int qpm = L.P * L.QW / 4, spm = L.P * L.SW / 4;   // chunks per mate
+    v4u q[PF_Q], sq[PF_S];
+    u32 len = 0;
+#pragma unroll
+    for (int i = 0; i < PF_Q; i++) {
+        const int ci = imin(tid + i * nthreads, nq - 1);   // no branch around a load: lanes past the end re-read the last chunk
+        q[i] = *(ci >= qpm ? q1 + (ci - qpm) : q0 + ci);
+    }
+#pragma unroll
+    for (int i = 0; i < PF_S; i++) {
+        const int ci = imin(tid + i * nthreads, ns - 1);
+        sq[i] = *(ci >= spm ? s1 + (ci - spm) : s0 + ci);
+    }
+    {
+        const u16* l0 = scalar_ptr(a.len[0]) + tile_first;
+        const u16* l1 = scalar_ptr(a.len[1]) + tile_first;
+        const int rr = imin(tid, L.NR - 1);
+        len = *(rr >= L.P ? l1 + (rr - L.P) : l0 + rr);
+    }
+    if (tid < L.NR) tile_init_read(L, lds, tid, (int)len);
+#pragma unroll
+    for (int i = 0; i < PF_S; i++) {
+        const int ci = tid + i * nthreads;
+        if (ci < ns) *(v4u*)(lds + L.seq + 4 * ci) = sq[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PF_Q; i++) {
+        const int ci = tid + i * nthreads;
+        if (ci < nq) *(v4u*)(lds + L.qual + 4 * ci) = q[i];
+    }
+}
+
+// one dword of every 128-byte line of the tile that starts at unit tile_first (rows that exist only): pulls the
+// tile into L2 / the Infinity Cache while the current one is processed
+FQ_DEV u32 tile_warm(const KernelArgs& a, int tile_first, int tid) {
+    const LdsLayout& L = a.L;
+    const int rows = imax(0, imin(L.P, a.n - tile_first));
+    const int mates = a.p.paired ? 2 : 1;
+    const int ql = (rows * L.QW * 4 + 127) >> 7, sl = (rows * L.SW * 4 + 127) >> 7;   // lines per mate
+    const int per = ql + sl;
+    u32 v = 0;
+    if (tid < per * mates) {
+        const int m = tid >= per ? 1 : 0;
+        const int k = tid - m * per;
+        const u32* q = (m ? a.qual[1] : a.qual[0]) + (size_t)tile_first * L.QW;
+        const u32* sq = (m ? a.seq[1] : a.seq[0]) + (size_t)tile_first * L.SW;
+        const volatile u32* p = k < ql ? q + 32 * k : sq + 32 * (k - ql);
+        v = *p;
     }
     return v;
-}
-
-FQ_DEV void tile_fetch(const KernelArgs& a, int tile_first, int tid, int nthreads, TileRegs& r) {
-    const LdsLayout& L = a.L;
-    const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
-    const int rows = imax(0, imin(L.P, a.n - tile_first));
-    const u32* q0 = a.qual[0] + (size_t)tile_first * L.QW;
-    const u32* q1 = a.qual[1] + (size_t)tile_first * L.QW;
-    const u32* s0 = a.seq[0] + (size_t)tile_first * L.SW;
-    const u32* s1 = a.seq[1] + (size_t)tile_first * L.SW;
-    const int qpm = L.P * L.QW / 4, spm = L.P * L.SW / 4;
-#pragma unroll
-    for (int i = 0; i < PF_Q; i++) {
-        const int ci = tid + i * nthreads;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        r.q[i] = ci < nq ? tile_chunk(q0, q1, qpm, rows * L.QW, ci) : z;
-    }
-#pragma unroll
-    for (int i = 0; i < PF_S; i++) {
-        const int ci = tid + i * nthreads;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        r.s[i] = ci < ns ? tile_chunk(s0, s1, spm, rows * L.SW, ci) : z;
-    }
-    r.len = 0;
-    if (tid < L.NR) {
-        const int m = tid >= L.P ? 1 : 0;
-        const int gp = tile_first + tid - m * L.P;
-        const u16* l0 = a.len[0];
-        const u16* l1 = a.len[1];
-        if (gp < a.n) r.len = (m ? l1 : l0)[gp];
-    }
-}
-
-FQ_DEV void tile_commit(const KernelArgs& a, u32* lds, int tid, int nthreads, const TileRegs& r) {
-    const LdsLayout& L = a.L;
-    const int nq = L.NR * L.QW / 4, ns = L.NR * L.SW / 4;
-    if (tid < L.NR) tile_init_read(L, lds, tid, (int)r.len);
-#pragma unroll
-    for (int i = 0; i < PF_S; i++) {
-        const int ci = tid + i * nthreads;
-        if (ci < ns) *(u32x4*)(lds + L.seq + 4 * ci) = r.s[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PF_Q; i++) {
-        const int ci = tid + i * nthreads;
-        if (ci < nq) *(u32x4*)(lds + L.qual + 4 * ci) = r.q[i];
-    }
 }
 
 // total quality (N flag masked off) of the windows [4c+k, 4c+k+w), k = 0..3, of one row:
@@ -565,8 +558,8 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         u8* qt_d = ldsw + qt_b + (u32)slot_d * (128u * QT_DWORDS * 4u);
         u8* qt_k = qt_d + 128u * QT_DWORDS * 4u;
         int cc = R & rot_mask;
-        u32 mode4 = 0xFFFFFFFFu, agg_cnt = 0;   // wave-uniform: the mode's four characters, dwords counted by ballot
-        int mode_m = 0;
+        u32 mode_ta = 0u;   // wave-uniform: LDS byte offset of the mode's table entry
+        u32 agg_cnt = 0;    // per lane: bases that hit it
         for (int t = 0; t < S; t++) {
             const int c = cbeg + cc;
             const bool act = rv && c < cmax;
@@ -588,18 +581,17 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
                 if (slot < (u32)wl_cap) wl_items[slot] = (u16)(R * QW + c);
                 else stats_item_overflow(&a, lds, R, c, n_valid);  // list full: do it here
             }
-            // the wavefront's mode = the first plain kept item's first character, fixed at its first appearance
-            const u32 q7 = qd & 0x7F7F7F7Fu;
-            if (mode4 == 0xFFFFFFFFu) {         // wave-uniform
+            // The wavefront's mode = the table entry (Stats slot AND character) of the first plain kept item's first
+            // character, fixed at its first appearance.  Bases that hit that entry are counted with a ballot and added
+            // once per wavefront: most of a tile's characters are one value, and as LDS atomics they would all land on
+            // one address and serialise.
+            if (mode_ta == 0u) {                // wave-uniform
                 const u64 cand = ballot(plain && kept);
                 if (cand) {
                     const int src = ffs64(cand) - 1;
-                    mode4 = (shfl(q7, src) & 0x7Fu) * 0x01010101u;
-                    mode_m = (int)shfl((u32)m, src);
+                    mode_ta = shfl((u32)(qt_k - ldsw) + ((qd & 0x7Fu) << 4), src);   // byte offset in LDS, never 0
                 }
             }
-            const bool agg = plain && kept && q7 == mode4 && m == mode_m;
-            agg_cnt += (u32)popc64(ballot(agg));
             if (plain) {
                 u8* qt = kept ? qt_k : qt_d;
                 u8* cyc = (kept ? cyc_k : cyc_d) + mul24((u32)c, 4u * N_CLS * 8u);
@@ -621,15 +613,18 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
 #pragma unroll
                     for (int k = 0; k < 4; k++) lds_add_u32((u32*)(kmer + (bfe(codes, 2 * k, 10) << 2)), one[k]);
                 }
-                if (!agg) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) lds_add_u32((u32*)(ta[k] + QT_COUNT * 4), one[k]);
+                for (int k = 0; k < 4; k++) {
+                    const bool is_mode = (u32)(ta[k] - ldsw) == mode_ta;
+                    agg_cnt += is_mode ? 1u : 0u;   // per lane; folded over the wavefront after the loop
+                    if (!is_mode) lds_add_u32((u32*)(ta[k] + QT_COUNT * 4), one[k]);
                 }
             }
             cc = cc + 1 == S ? 0 : cc + 1;
         }
-        if (lane == 0 && agg_cnt)
-            lds_add_u32(lds + L.acc_qh + ((2 * mode_m + 1) * 128 + (int)(mode4 & 0x7Fu)) * QT_DWORDS + QT_COUNT, 4u * agg_cnt);
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) agg_cnt += shfl_xor(agg_cnt, sh);
+        if (lane == 0 && agg_cnt) lds_add_u32((u32*)(ldsw + mode_ta + QT_COUNT * 4), agg_cnt);
     }
     block_sync();
     // the queued items, all through the general path
@@ -2026,23 +2021,26 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     const bool timing_on = a.phase_cycles != nullptr;  // uniform
     const bool timing = timing_on && tid == 0;
     u64 tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    TileRegs regs;
     const bool vec = a.prefetch != 0;       // uniform: 16-byte tile copies
     const bool prefetch = a.prefetch == 1;  // ... issued one tile ahead
-    if (prefetch && block_id() < a.tiles) tile_fetch(a, block_id() * L.P, tid, nt, regs);
+    // Only full tiles take the vector path.  The tile is fetched (all chunks in flight, one wait) when the loop
+    // reaches it; what runs ahead is a one-dword-per-cache-line touch of the NEXT tile (tile_warm: one live
+    // register instead of the 17 a register-held prefetch needs - under the 128-register cap of a 1024-lane
+    // workgroup those were spilled, and a spill behind a load is a wait for it), so the fetch hits L2 / MALL.
+    u32 warm = 0;
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
         const int n_valid = imin(L.P, a.n - tile_first);
         u64 t0 = timing ? cycle_counter() : 0, t1;
 #define FQ_STAMP(k) if (timing) { t1 = cycle_counter(); tacc[k] += t1 - t0; t0 = t1; }
-        if (vec) {
-            if (!prefetch) tile_fetch(a, tile_first, tid, nt, regs);
-            tile_commit(a, lds, tid, nt, regs);
+        if (vec && n_valid == L.P) {
+            tile_stage(a, lds, tile_first, tid, nt);
         } else {
             phase_load(a, lds, tile_first, tid, nt);
         }
         block_sync();
-        if (prefetch && tile + grid_blocks() < a.tiles) tile_fetch(a, (tile + grid_blocks()) * L.P, tid, nt, regs);
+        const int next = tile + grid_blocks();
+        if (prefetch && next < a.tiles) warm ^= tile_warm(a, next * L.P, tid);
         phase_nmask(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(0)
@@ -2093,6 +2091,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     }
     if (timing)
         for (int k = 0; k < 10; k++) g_atomic_add_u64(&a.phase_cycles[k], tacc[k]);
+    if (warm == 0x9E3779B9u && a.n < 0) lds[L.acc_misc] = warm;  // never true: keeps the touch loads alive
     // flush this workgroup's accumulators to its slab (plain coalesced stores)
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];

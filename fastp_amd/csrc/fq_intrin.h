@@ -26,6 +26,19 @@ template <class T> FQ_DEV const T* kernel_args(const T* by_value) {
 #endif
 }
 
+// a pointer read from the argument block, pinned to scalar registers: without this a per-lane choice between
+// two such pointers becomes ONE vector load of the chosen pointer (a load of a select of addresses) and a wait
+// for it in the middle of the loads that should stay in flight
+template <class T> FQ_DEV const T* scalar_ptr(const T* p) {
+#ifdef FQ_HOSTSIM
+    return p;
+#else
+    const unsigned long long v = (unsigned long long)p;
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+    return (const T*)(((unsigned long long)hi << 32) | lo);
+#endif
+}
+
 FQ_DEV void block_sync() { __syncthreads(); }
 FQ_DEV u64 cycle_counter() { return (u64)clock64(); }
 FQ_DEV void g_atomic_add_u64(u64* p, u64 v) {
