@@ -527,6 +527,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         a.dup_pos = ctx->d_dup_pos;
     }
     a.phase_cycles = ctx->d_phase;
+    a.debug_skip = (u32)env_int("FASTP_GPU_DEBUG_SKIP", 0);
     a.slabs = ctx->d_slabs;
     a.slab_dwords = ctx->slab_dwords;
     a.tiles = (n + ctx->L.P - 1) / ctx->L.P;

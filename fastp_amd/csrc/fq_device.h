@@ -202,23 +202,22 @@ FQ_DEV void tile_stage(const KernelArgs& a, u32* lds, int tile_first, int tid, i
 }
 
 // one dword of every 128-byte line of the tile that starts at unit tile_first (rows that exist only): pulls the
-// tile into L2 / the Infinity Cache while the current one is processed
+// tile into L2 / the Infinity Cache while the current one is processed.  Returns the touch's register (touch_done).
 FQ_DEV u32 tile_warm(const KernelArgs& a, int tile_first, int tid) {
     const LdsLayout& L = a.L;
     const int rows = imax(0, imin(L.P, a.n - tile_first));
-    const int mates = a.p.paired ? 2 : 1;
     const int ql = (rows * L.QW * 4 + 127) >> 7, sl = (rows * L.SW * 4 + 127) >> 7;   // lines per mate
     const int per = ql + sl;
-    u32 v = 0;
-    if (tid < per * mates) {
-        const int m = tid >= per ? 1 : 0;
-        const int k = tid - m * per;
-        const u32* q = (m ? a.qual[1] : a.qual[0]) + (size_t)tile_first * L.QW;
-        const u32* sq = (m ? a.seq[1] : a.seq[0]) + (size_t)tile_first * L.SW;
-        const volatile u32* p = k < ql ? q + 32 * k : sq + 32 * (k - ql);
-        v = *p;
-    }
-    return v;
+    const int lines = a.p.paired ? 2 * per : per;
+    const u32* q0 = scalar_ptr(a.qual[0]) + (size_t)tile_first * L.QW;
+    const u32* s0 = scalar_ptr(a.seq[0]) + (size_t)tile_first * L.SW;
+    const u32* q1 = a.p.paired ? scalar_ptr(a.qual[1]) + (size_t)tile_first * L.QW : q0;
+    const u32* s1 = a.p.paired ? scalar_ptr(a.seq[1]) + (size_t)tile_first * L.SW : s0;
+    const int t = imin(tid, lines - 1);    // lanes past the last line touch it again: no branch around the load
+    const int m = t >= per ? 1 : 0;
+    const int k = t - (m ? per : 0);
+    const u32* p = k < ql ? (m ? q1 : q0) + 32 * k : (m ? s1 : s0) + 32 * (k - ql);
+    return touch_begin(lines > 0 ? p : q0);
 }
 
 // total quality (N flag masked off) of the windows [4c+k, 4c+k+w), k = 0..3, of one row:
@@ -2024,10 +2023,10 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     const bool vec = a.prefetch != 0;       // uniform: 16-byte tile copies
     const bool prefetch = a.prefetch == 1;  // ... issued one tile ahead
     // Only full tiles take the vector path.  The tile is fetched (all chunks in flight, one wait) when the loop
-    // reaches it; what runs ahead is a one-dword-per-cache-line touch of the NEXT tile (tile_warm: one live
-    // register instead of the 17 a register-held prefetch needs - under the 128-register cap of a 1024-lane
-    // workgroup those were spilled, and a spill behind a load is a wait for it), so the fetch hits L2 / MALL.
-    u32 warm = 0;
+    // reaches it; what runs ahead is a one-dword-per-cache-line touch of the NEXT tile (tile_warm: one register for
+    // the length of the N-mask pass instead of the 17 a register-held prefetch keeps for a whole tile - under the
+    // 128-register cap of a 1024-lane workgroup those were spilled, and a spill behind a load is a wait for it),
+    // so the fetch hits L2 / the Infinity Cache.
     for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
         const int tile_first = tile * L.P;
         const int n_valid = imin(L.P, a.n - tile_first);
@@ -2040,18 +2039,24 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         }
         block_sync();
         const int next = tile + grid_blocks();
-        if (prefetch && next < a.tiles) warm ^= tile_warm(a, next * L.P, tid);
+        const bool touch = prefetch && next < a.tiles;   // uniform
+        u32 warm = 0;
+        if (touch) warm = tile_warm(a, next * L.P, tid);
         phase_nmask(a, lds, tid, nt);
+        if (touch) touch_done(warm);
         block_sync();
         FQ_STAMP(0)
+        const u32 skip = a.debug_skip;   // profiling only: 0 in any real run
         if (!a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
-        phase_masks(a, lds, n_valid, tid, nt);
-        phase_rc(a, lds, tid, nt);
+        if (!(skip & 1u)) {
+            phase_masks(a, lds, n_valid, tid, nt);
+            phase_rc(a, lds, tid, nt);
+        }
         if (timing_on) { block_sync(); FQ_STAMP(8) }
-        phase_hash(a, lds, tid, nt);
+        if (!(skip & 2u)) phase_hash(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(1)
-        phase_trim(a, lds, tile_first, tid, nt);
+        if (!(skip & 32u)) phase_trim(a, lds, tile_first, tid, nt);
         block_sync();
         FQ_STAMP(2)
         if (a.p.poly_g) {
@@ -2059,14 +2064,16 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             block_sync();
         }
         FQ_STAMP(3)
-        phase_overlap(a, lds, tid, nt);
+        if (!(skip & 4u)) phase_overlap(a, lds, tid, nt);
         if (a.p.allow_gap) {
             phase_overlap_gap(a, lds, tid, nt);
             block_sync();
         }
         FQ_STAMP(4)
-        if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
-        else phase_decide_se(a, lds, tile_first, tid, nt);
+        if (!(skip & 32u)) {
+            if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
+            else phase_decide_se(a, lds, tile_first, tid, nt);
+        }
         block_sync();
         if (a.p.merge) {
             phase_overlap(a, lds, tid, nt);
@@ -2074,24 +2081,27 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             block_sync();
         }
         FQ_STAMP(5)
-        phase_metrics(a, lds, tid, nt);
+        if (!(skip & 8u)) phase_metrics(a, lds, tid, nt);
         block_sync();
         FQ_STAMP(9)
-        if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
-        else phase_filter_se(a, lds, tile_first, tid, nt);
+        if (!(skip & 32u)) {
+            if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
+            else phase_filter_se(a, lds, tile_first, tid, nt);
+        }
         block_sync();
         FQ_STAMP(6)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
-        if (a.p.stats_one_pass) phase_stats_both(a, lds, n_valid, tid, nt);
-        else if (a.p.merge) phase_stats<ST_POST, true>(a, lds, n_valid, tid, nt);
-        else phase_stats<ST_POST, false>(a, lds, n_valid, tid, nt);
+        if (!(skip & 16u)) {
+            if (a.p.stats_one_pass) phase_stats_both(a, lds, n_valid, tid, nt);
+            else if (a.p.merge) phase_stats<ST_POST, true>(a, lds, n_valid, tid, nt);
+            else phase_stats<ST_POST, false>(a, lds, n_valid, tid, nt);
+        }
         block_sync();
         FQ_STAMP(7)
 #undef FQ_STAMP
     }
     if (timing)
         for (int k = 0; k < 10; k++) g_atomic_add_u64(&a.phase_cycles[k], tacc[k]);
-    if (warm == 0x9E3779B9u && a.n < 0) lds[L.acc_misc] = warm;  // never true: keeps the touch loads alive
     // flush this workgroup's accumulators to its slab (plain coalesced stores)
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];

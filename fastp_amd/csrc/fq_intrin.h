@@ -39,6 +39,26 @@ template <class T> FQ_DEV const T* scalar_ptr(const T* p) {
 #endif
 }
 
+// Touch one dword so that its cache line is pulled into L2 / the Infinity Cache: a load the compiler does not
+// see as one (no wait is scheduled for it).  The destination register belongs to the load until touch_done()
+// has waited for it - call that before the value's register can be given to anything else.
+FQ_DEV u32 touch_begin(const u32* p) {
+#ifdef FQ_HOSTSIM
+    return *p;
+#else
+    u32 v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#endif
+}
+FQ_DEV void touch_done(u32 v) {
+#ifdef FQ_HOSTSIM
+    (void)v;
+#else
+    asm volatile("s_waitcnt vmcnt(0)\n; touched %0" : : "v"(v) : "memory");
+#endif
+}
+
 FQ_DEV void block_sync() { __syncthreads(); }
 FQ_DEV u64 cycle_counter() { return (u64)clock64(); }
 FQ_DEV void g_atomic_add_u64(u64* p, u64 v) {

@@ -285,6 +285,8 @@ struct KernelArgs {
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
     const u8* dupflag;  // [n] --dedup: the duplicate decision, taken by the dup kernels BEFORE this launch
     u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)
+    u32 debug_skip;     // profiling only (FASTP_GPU_DEBUG_SKIP): phases left out, results are then meaningless.
+                        // 1 masks+rc, 2 hash, 4 overlap, 8 metrics, 16 stats, 32 trim/decide/filter
     // per-workgroup counter slabs: [gridDim][slab_dwords]
     u32* slabs;
     int slab_dwords;
