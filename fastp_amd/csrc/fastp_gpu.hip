@@ -18,7 +18,7 @@ using namespace fq;
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(KernelArgs a) {
+extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     // read the argument block through the kernarg segment pointer (scalar loads where a field is
     // used) instead of holding all ~150 dwords in SGPRs for the whole persistent loop
@@ -252,6 +252,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     ctx->cfg.threads = env_int("FASTP_GPU_THREADS", 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
     ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", lds_kb_default) * 1024;
+    // two tiles in flight per workgroup (each half of the waves owns one) when the halves are whole wavefronts
+    ctx->cfg.halves = (env_int("FASTP_GPU_HALVES", 2) == 2 && ctx->cfg.threads % 128 == 0) ? 2 : 1;
     if (ctx->cfg.threads < 64 || ctx->cfg.threads > 1024 || (ctx->cfg.threads & 63)) {
         delete ctx;
         return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024");
@@ -268,6 +270,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     int tiles_per_block = CYC_MAX_READS / ctx->L.P;
     const int cap_tiles = env_int("FASTP_GPU_MAX_TILES_PER_BLOCK", 0);  // tests: force several launches
     if (cap_tiles > 0 && cap_tiles < tiles_per_block) tiles_per_block = cap_tiles;
+    if (ctx->cfg.halves == 2 && tiles_per_block > 1) tiles_per_block &= ~1;  // a workgroup's two halves take tiles in pairs
     if (tiles_per_block < 1) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "tile too large for the packed counters"); }
     long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
     if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
@@ -486,8 +489,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.magic_swg = magic_for((u32)ctx->dp.sw_g);
     {   // vector (16-byte) tile copies + register prefetch need aligned rows and a tile that fits the registers
         const size_t qchunks = (size_t)ctx->L.NR * ctx->dp.qw_g / 4, schunks = (size_t)ctx->L.NR * ctx->dp.sw_g / 4;
-        bool ok = (ctx->L.P % 2 == 0) && (first % 2 == 0) && qchunks <= (size_t)PF_Q * ctx->cfg.threads &&
-                  schunks <= (size_t)PF_S * ctx->cfg.threads && ctx->L.NR <= ctx->cfg.threads &&
+        const size_t tile_threads = (size_t)ctx->cfg.threads / ctx->L.halves;   // the waves that stage one tile
+        bool ok = (ctx->L.P % 2 == 0) && (first % 2 == 0) && qchunks <= (size_t)PF_Q * tile_threads &&
+                  schunks <= (size_t)PF_S * tile_threads && (size_t)ctx->L.NR <= tile_threads &&
                   !env_int("FASTP_GPU_NO_PREFETCH", 0);
         const void* ptrs[4] = {b->seq1, b->qual1, ctx->dp.paired ? b->seq2 : b->seq1, ctx->dp.paired ? b->qual2 : b->qual1};
         for (const void* q : ptrs) ok = ok && (((uintptr_t)q & 15u) == 0);
@@ -531,7 +535,11 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.slabs = ctx->d_slabs;
     a.slab_dwords = ctx->slab_dwords;
     a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
-    const int grid = a.tiles < ctx->blocks ? a.tiles : ctx->blocks;
+    a.half_skew = env_int("FASTP_GPU_HALF_SKEW", 6);
+    const int wg_tiles = (a.tiles + ctx->L.halves - 1) / ctx->L.halves;   // tiles are dealt to workgroups `halves` at a time
+    const int grid = wg_tiles < ctx->blocks ? wg_tiles : ctx->blocks;
+    // the stage + hash pre-pass of --dedup runs the whole workgroup on one tile at a time
+    auto whole = [](KernelArgs k) { k.L.halves = 1; return k; };
     const fastp_gpu_counter_layout& cl = ctx->cl;
     int rc;
 
@@ -573,7 +581,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     };
 
     if (mode == CHUNK_PASS1 && ctx->dp.dedup) {
-        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
         HIP_TRY(ctx, hipGetLastError());
         return launch_dup(nullptr, true);
     }
@@ -607,7 +615,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
         rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
         if (rc) return rc;
-        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
         HIP_TRY(ctx, hipGetLastError());
         rc = launch_dup(ctx->d_dupflag);
         if (rc) return rc;
@@ -619,7 +627,13 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, a);
+    {
+        FusedArgs fa;
+        fa.h[0] = a;
+        fa.h[1] = a;
+        fa.h[1].L = layout_for_half(a.L, 1);
+        hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e1, st));
     ctx->pending_events.push_back({e0, e1});

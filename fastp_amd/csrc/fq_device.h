@@ -70,6 +70,13 @@ FQ_DEV u32* lds_nmk(const LdsLayout& L, u32* lds, int R) { return lds + L.nmk + 
 FQ_DEV u32* lds_qual(const LdsLayout& L, u32* lds, int R) { return lds + L.qual + rowoff(R, L.QW); }
 FQ_DEV int* lds_i(u32* lds, int off) { return (int*)(lds + off); }
 
+// barrier over the wavefronts that work on one tile: the whole workgroup, or - two tiles in flight - the half that
+// owns the tile (`lds` is that half's LDS base, `tid` / `nthreads` its view of itself)
+FQ_DEV void tile_sync(const KernelArgs& a, u32* lds, int nthreads) {
+    if (a.L.halves == 2) half_sync(lds + a.L.bar, thread_id() >= nthreads ? 1 : 0, nthreads);
+    else block_sync();
+}
+
 FQ_DEV u32 code_at(const u32* srow, int j) { return (srow[j >> 4] >> ((j & 15) * 2)) & 3u; }
 FQ_DEV u32 qchar_at(const u8* q, int j) { return q[j] & 0x7Fu; }
 FQ_DEV bool isn_at(const u8* q, int j) { return (q[j] & 0x80u) != 0; }
@@ -519,8 +526,9 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
     const int wl_cap = L.wl_cap;
     const u32* swin_v = lds + L.swin;           // rlen0 | kept length << 16, left by the filter phase
     const u8* lds_b = (const u8*)lds;
-    const u32 cyc_b = (u32)L.acc_cyc * 4u, kmer_b = (u32)L.acc_kmer * 4u, qt_b = (u32)L.acc_qh * 4u;
-    const u32 qual_b = (u32)L.qual * 4u, seq_b = (u32)L.seq * 4u;
+    // byte offsets from this half's LDS base; the shared accumulators sit BELOW the base of the second tile slot
+    const int cyc_b = L.acc_cyc * 4, kmer_b = L.acc_kmer * 4, qt_b = L.acc_qh * 4;
+    const int qual_b = L.qual * 4, seq_b = L.seq * 4;
     const int lane = tid & 63;
     const int total = NR * 4;
     for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count (ballots inside)
@@ -547,17 +555,17 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         const int cbeg = seg * S;
         const int cmax = imin(imin(cbeg + S, QW), cany);
         // this read's rows and the two accumulator sets (kept / dropped) as LDS pointers, set up once per lane
-        const u8* qrow_p = lds_b + qual_b + (u32)rowoff(R, QW * 4);
-        const u8* srow_p = lds_b + seq_b + (u32)rowoff(R, SW4);
+        const u8* qrow_p = lds_b + (qual_b + rowoff(R, QW * 4));
+        const u8* srow_p = lds_b + (seq_b + rowoff(R, SW4));
         u8* ldsw = (u8*)lds;
-        u8* cyc_d = ldsw + cyc_b + (u32)(slot_d * Cp) * (N_CLS * 8u);
-        u8* cyc_k = cyc_d + (u32)Cp * (N_CLS * 8u);
-        u8* kmer_d = ldsw + kmer_b + (u32)slot_d * (KMER_BINS * 4u);
-        u8* kmer_k = kmer_d + KMER_BINS * 4u;
-        u8* qt_d = ldsw + qt_b + (u32)slot_d * (128u * QT_DWORDS * 4u);
-        u8* qt_k = qt_d + 128u * QT_DWORDS * 4u;
+        u8* cyc_d = ldsw + (cyc_b + slot_d * Cp * (N_CLS * 8));
+        u8* cyc_k = cyc_d + Cp * (N_CLS * 8);
+        u8* kmer_d = ldsw + (kmer_b + slot_d * (KMER_BINS * 4));
+        u8* kmer_k = kmer_d + KMER_BINS * 4;
+        u8* qt_d = ldsw + (qt_b + slot_d * (128 * QT_DWORDS * 4));
+        u8* qt_k = qt_d + 128 * QT_DWORDS * 4;
         int cc = R & rot_mask;
-        u32 mode_ta = 0u;   // wave-uniform: LDS byte offset of the mode's table entry
+        u32 mode_ta = 0x7FFFFFFFu;   // wave-uniform: LDS byte offset (from this half's base) of the mode's table entry
         u32 agg_cnt = 0;    // per lane: bases that hit it
         for (int t = 0; t < S; t++) {
             const int c = cbeg + cc;
@@ -584,11 +592,11 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
             // character, fixed at its first appearance.  Bases that hit that entry are counted with a ballot and added
             // once per wavefront: most of a tile's characters are one value, and as LDS atomics they would all land on
             // one address and serialise.
-            if (mode_ta == 0u) {                // wave-uniform
+            if (mode_ta == 0x7FFFFFFFu) {       // wave-uniform
                 const u64 cand = ballot(plain && kept);
                 if (cand) {
                     const int src = ffs64(cand) - 1;
-                    mode_ta = shfl((u32)(qt_k - ldsw) + ((qd & 0x7Fu) << 4), src);   // byte offset in LDS, never 0
+                    mode_ta = shfl((u32)(int)(qt_k - ldsw) + ((qd & 0x7Fu) << 4), src);
                 }
             }
             if (plain) {
@@ -614,7 +622,7 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const bool is_mode = (u32)(ta[k] - ldsw) == mode_ta;
+                    const bool is_mode = (u32)(int)(ta[k] - ldsw) == mode_ta;
                     agg_cnt += is_mode ? 1u : 0u;   // per lane; folded over the wavefront after the loop
                     if (!is_mode) lds_add_u32((u32*)(ta[k] + QT_COUNT * 4), one[k]);
                 }
@@ -623,9 +631,9 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
         }
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) agg_cnt += shfl_xor(agg_cnt, sh);
-        if (lane == 0 && agg_cnt) lds_add_u32((u32*)(ldsw + mode_ta + QT_COUNT * 4), agg_cnt);
+        if (lane == 0 && agg_cnt) lds_add_u32((u32*)(ldsw + (int)mode_ta + QT_COUNT * 4), agg_cnt);
     }
-    block_sync();
+    tile_sync(a, lds, nthreads);
     // the queued items, all through the general path
     const int nw = (int)imin((int)*wl_count, L.wl_cap);
     for (int base = tid - lane; base < nw; base += nthreads) {
@@ -813,7 +821,7 @@ FQ_DEV int trim_poly_x(const u32* srow, const u8* q, int f, int rlen, int compar
 FQ_DEV void stage_primes(const KernelArgs& a, u32* lds, int tid, int nt) {
     const LdsLayout& L = a.L;
     if (!a.p.dup_enabled) return;
-    if (L.hp >= 0) {
+    if (L.has_hp) {
         const int n = 4 * L.hp_nq * a.p.dup_bufnum * a.p.dup_npl;
         for (int i = tid; i < n; i += nt) lds[L.hp + i] = a.lut.dup_planes[i];
     } else {
@@ -881,7 +889,7 @@ FQ_DEV void phase_hash_generic(const KernelArgs& a, u32* lds, int tid, int nthre
 FQ_DEV void phase_hash(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     const DevParams& p = a.p;
     if (!p.dup_enabled || !a.dup_pos) return;
-    if (a.L.hp >= 0) {
+    if (a.L.has_hp) {
         if (p.dup_bufnum == 2 && p.dup_npl == 3) return phase_hash_dot<2, 3>(a, lds, tid, nthreads);
         if (p.dup_bufnum == 4 && p.dup_npl == 3) return phase_hash_dot<4, 3>(a, lds, tid, nthreads);
         if (p.dup_bufnum == 2 && p.dup_npl == 4) return phase_hash_dot<2, 4>(a, lds, tid, nthreads);
@@ -1293,7 +1301,7 @@ FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) 
         if (dir) overlap_scan<1>(a, lds, u >> 2, u & 3);
         else overlap_scan<0>(a, lds, u >> 2, u & 3);
     }
-    block_sync();
+    tile_sync(a, lds, nthreads);
     // pass 2: lane = candidate
     const int nc = imin((int)lds[L.cand], L.cand_cap);
     for (int i = tid; i < nc; i += nthreads) {
@@ -1304,7 +1312,7 @@ FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) 
         if (e & 0x400u) overlap_check<1>(L, lds, v, pr, o);
         else overlap_check<0>(L, lds, v, pr, o);
     }
-    block_sync();
+    tile_sync(a, lds, nthreads);
     if (tid == 0) lds[L.cand] = 0;   // ready for the next use (merge mode analyzes twice per tile)
 }
 
@@ -1974,51 +1982,70 @@ FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int t
 // ---------------------------------------------------------------------------
 // The fused kernel: persistent workgroups, grid-stride over tiles.
 // ---------------------------------------------------------------------------
-FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
-    const LdsLayout& L = a.L;
-    const int tid = thread_id(), nt = block_threads();
-    // one-time per workgroup: clear the accumulators, stage LUTs / primes / adapters
-    for (int i = tid; i < L.acc_end - L.acc_cyc; i += nt) lds[L.acc_cyc + i] = 0;
-    {
-        const int lw = (a.p.cycles + 2) / 2;  // u16 tables of cycles+1 entries, in dwords
-        const u32* g0 = (const u32*)a.lut.ov_limit;
-        const u32* g1 = (const u32*)a.lut.lowq_limit;
-        const u32* g2 = (const u32*)a.lut.cplx_min;
+// Two tiles are in flight per workgroup: waves [0, W/2) own tile slot 0, waves [W/2, W) slot 1, each with its own
+// barrier (tile_sync) and its own copy of the argument block (same but for the LDS layout, LdsLayout::halves).
+// The halves run the same phase sequence half a tile apart (half 1 starts late), so that while one sits in a phase
+// bound by the LDS pipe (Stats), by latency (the per-read / per-pair phases, the barriers) or by memory (staging),
+// the other one's VALU-bound phases (overlap, hash, masks, metrics) have the SIMDs.  The accumulators are shared:
+// both halves add to the same LDS counters.
+FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
+    const int tid0 = thread_id(), nt0 = block_threads();
+    const KernelArgs& a0 = fa.h[0];
+    {   // one-time per workgroup, all waves, slot 0's view: clear the accumulators, stage LUTs / primes / adapters
+        const LdsLayout& L = a0.L;
+        u32* lds = lds0;
+        const int tid = tid0, nt = nt0;
+        for (int i = tid; i < L.acc_end - L.acc_cyc; i += nt) lds[L.acc_cyc + i] = 0;
+        const int lw = (a0.p.cycles + 2) / 2;  // u16 tables of cycles+1 entries, in dwords
+        const u32* g0 = (const u32*)a0.lut.ov_limit;
+        const u32* g1 = (const u32*)a0.lut.lowq_limit;
+        const u32* g2 = (const u32*)a0.lut.cplx_min;
         for (int i = tid; i < lw; i += nt) {
             lds[L.lut_ov + i] = g0[i];
             lds[L.lut_lowq + i] = g1[i];
             lds[L.lut_cplx + i] = g2[i];
         }
-        stage_primes(a, lds, tid, nt);
+        stage_primes(a0, lds, tid, nt);
         for (int i = tid; i < 2 * ADAPT_WORDS; i += nt) {
             const int which = i >= ADAPT_WORDS ? 1 : 0;
             const int w = i - which * ADAPT_WORDS;
             u32 v = 0;
-            if (w < MAX_ADAPTER_WORDS) v = which ? a.p.a2w[w] : a.p.a1w[w];
+            if (w < MAX_ADAPTER_WORDS) v = which ? a0.p.a2w[w] : a0.p.a1w[w];
             lds[L.adapt + i] = v;
         }
-    }
-    if (a.p.dup_enabled)
-        for (int i = tid; i < 256; i += nt) {  // duplicate.cpp:92-109: A=7 T=222 C=74 G=31 (codes A0 T1 C2 G3)
-            u32 v = 0;
-            for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
-            lds[L.val4_lut + i] = v;
+        if (a0.p.dup_enabled)
+            for (int i = tid; i < 256; i += nt) {  // duplicate.cpp:92-109: A=7 T=222 C=74 G=31 (codes A0 T1 C2 G3)
+                u32 v = 0;
+                for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
+                lds[L.val4_lut + i] = v;
+            }
+        if (tid < 2 * L.halves) lds[L.bar + (tid >> 1) * L.tile_stride + (tid & 1)] = 0;   // the halves' barrier words
+        block_sync();
+        for (int i = tid; i < 4 * 128; i += nt) {  // quality table constants (the counters in between stay zero)
+            const int q = i & 127;
+            // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20.  Character 0 = no base.
+            const u64 inc = q == 0 ? 0ull
+                                   : (1ull | ((u64)(q >= 53) << CYC_Q20_SHIFT) | ((u64)(q >= 63) << CYC_Q30_SHIFT) |
+                                      ((u64)(u32)(q - 33) << CYC_QSUM_SHIFT));
+            u32* e = lds + L.acc_qh + i * QT_DWORDS;
+            e[QT_INC] = (u32)inc;
+            e[QT_INC + 1] = (u32)(inc >> 32);
+            e[QT_ONE] = q == 0 ? 0u : 1u;
         }
-    block_sync();
-    for (int i = tid; i < 4 * 128; i += nt) {  // quality table constants (the counters in between stay zero)
-        const int q = i & 127;
-        // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20.  Character 0 = no base.
-        const u64 inc = q == 0 ? 0ull
-                               : (1ull | ((u64)(q >= 53) << CYC_Q20_SHIFT) | ((u64)(q >= 63) << CYC_Q30_SHIFT) |
-                                  ((u64)(u32)(q - 33) << CYC_QSUM_SHIFT));
-        u32* e = lds + L.acc_qh + i * QT_DWORDS;
-        e[QT_INC] = (u32)inc;
-        e[QT_INC + 1] = (u32)(inc >> 32);
-        e[QT_ONE] = q == 0 ? 0u : 1u;
+        block_sync();
     }
-    block_sync();
+    // from here on each half is its own little workgroup
+    const int nh = a0.L.halves;
+    const int nt = nt0 / nh;
+    const int half = nh == 2 ? (int)uniform((u32)(tid0 >= nt ? 1 : 0)) : 0;
+    const int tid = tid0 - half * nt;
+    const KernelArgs& a = fa.h[half];
+    const LdsLayout& L = a.L;
+    u32* lds = lds0 + half * a0.L.tile_stride;
+    const int vblock = block_id() * nh + half, vgrid = grid_blocks() * nh;
+    if (half) for (int i = 0; i < a.half_skew; i++) nap();
     const bool timing_on = a.phase_cycles != nullptr;  // uniform
-    const bool timing = timing_on && tid == 0;
+    const bool timing = timing_on && tid0 == 0;
     u64 tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool vec = a.prefetch != 0;       // uniform: 16-byte tile copies
     const bool prefetch = a.prefetch == 1;  // ... issued one tile ahead
@@ -2027,7 +2054,7 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
     // the length of the N-mask pass instead of the 17 a register-held prefetch keeps for a whole tile - under the
     // 128-register cap of a 1024-lane workgroup those were spilled, and a spill behind a load is a wait for it),
     // so the fetch hits L2 / the Infinity Cache.
-    for (int tile = block_id(); tile < a.tiles; tile += grid_blocks()) {
+    for (int tile = vblock; tile < a.tiles; tile += vgrid) {
         const int tile_first = tile * L.P;
         const int n_valid = imin(L.P, a.n - tile_first);
         u64 t0 = timing ? cycle_counter() : 0, t1;
@@ -2037,14 +2064,14 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
         } else {
             phase_load(a, lds, tile_first, tid, nt);
         }
-        block_sync();
-        const int next = tile + grid_blocks();
+        tile_sync(a, lds, nt);
+        const int next = tile + vgrid;
         const bool touch = prefetch && next < a.tiles;   // uniform
         u32 warm = 0;
         if (touch) warm = tile_warm(a, next * L.P, tid);
         phase_nmask(a, lds, tid, nt);
         if (touch) touch_done(warm);
-        block_sync();
+        tile_sync(a, lds, nt);
         FQ_STAMP(0)
         const u32 skip = a.debug_skip;   // profiling only: 0 in any real run
         if (!a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
@@ -2052,43 +2079,43 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             phase_masks(a, lds, n_valid, tid, nt);
             phase_rc(a, lds, tid, nt);
         }
-        if (timing_on) { block_sync(); FQ_STAMP(8) }
+        if (timing_on) { tile_sync(a, lds, nt); FQ_STAMP(8) }
         if (!(skip & 2u)) phase_hash(a, lds, tid, nt);
-        block_sync();
+        tile_sync(a, lds, nt);
         FQ_STAMP(1)
         if (!(skip & 32u)) phase_trim(a, lds, tile_first, tid, nt);
-        block_sync();
+        tile_sync(a, lds, nt);
         FQ_STAMP(2)
         if (a.p.poly_g) {
             phase_polyg(a, lds, tid, nt);
-            block_sync();
+            tile_sync(a, lds, nt);
         }
         FQ_STAMP(3)
         if (!(skip & 4u)) phase_overlap(a, lds, tid, nt);
         if (a.p.allow_gap) {
             phase_overlap_gap(a, lds, tid, nt);
-            block_sync();
+            tile_sync(a, lds, nt);
         }
         FQ_STAMP(4)
         if (!(skip & 32u)) {
             if (a.p.paired) phase_decide_pe(a, lds, tile_first, tid, nt);
             else phase_decide_se(a, lds, tile_first, tid, nt);
         }
-        block_sync();
+        tile_sync(a, lds, nt);
         if (a.p.merge) {
             phase_overlap(a, lds, tid, nt);
             phase_merge(a, lds, tile_first, tid, nt);
-            block_sync();
+            tile_sync(a, lds, nt);
         }
         FQ_STAMP(5)
         if (!(skip & 8u)) phase_metrics(a, lds, tid, nt);
-        block_sync();
+        tile_sync(a, lds, nt);
         FQ_STAMP(9)
         if (!(skip & 32u)) {
             if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
             else phase_filter_se(a, lds, tile_first, tid, nt);
         }
-        block_sync();
+        tile_sync(a, lds, nt);
         FQ_STAMP(6)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
         if (!(skip & 16u)) {
@@ -2096,15 +2123,16 @@ FQ_DEV void fused_body(const KernelArgs& a, u32* lds) {
             else if (a.p.merge) phase_stats<ST_POST, true>(a, lds, n_valid, tid, nt);
             else phase_stats<ST_POST, false>(a, lds, n_valid, tid, nt);
         }
-        block_sync();
+        tile_sync(a, lds, nt);
         FQ_STAMP(7)
 #undef FQ_STAMP
     }
     if (timing)
         for (int k = 0; k < 10; k++) g_atomic_add_u64(&a.phase_cycles[k], tacc[k]);
-    // flush this workgroup's accumulators to its slab (plain coalesced stores)
-    u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
-    for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[L.acc_cyc + i];
+    // both halves are done: flush this workgroup's accumulators to its slab (plain coalesced stores)
+    block_sync();
+    u32* slab = a0.slabs + (size_t)block_id() * a0.slab_dwords;
+    for (int i = tid0; i < a0.slab_dwords; i += nt0) slab[i] = lds0[a0.L.acc_cyc + i];
 }
 
 // ---------------------------------------------------------------------------

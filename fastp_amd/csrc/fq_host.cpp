@@ -287,11 +287,14 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
 }
 
 static int round_odd(int x) { return (x & 1) ? x : x + 1; }
+static int imin_i(int a, int b) { return a < b ? a : b; }
 
 int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err, int hp_nq) {
     const int mates = p.paired ? 2 : 1;
+    const int halves = cfg.halves == 2 ? 2 : 1;
     auto build = [&](int P, LdsLayout& out) {
         memset(&out, 0, sizeof(out));
+        out.halves = halves;
         out.P = P;
         out.NR = mates * P;
         out.SW = p.sw_g;
@@ -300,12 +303,35 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.Cp = (p.cycles + 3) / 4 * 4;
         int o = 0;
         auto take = [&](int n) { int at = o; o += n; return at; };
-        // accumulators first (u64 part 8-byte aligned at offset 0)
+        // ---- shared by the tiles in flight: accumulators first (u64 part 8-byte aligned at offset 0), tables ----
         out.acc_cyc = take(4 * N_CLS * out.Cp * 2);
         out.acc_kmer = take(4 * KMER_BINS);
         out.acc_qh = take(4 * 128 * QT_DWORDS);
         out.acc_misc = take(MISC_ISIZE + p.isize_max + 1);
         out.acc_end = o;
+        out.val4_lut = take(p.dup_bufnum > 0 ? 256 : 0);
+        out.adapt = take(2 * ADAPT_WORDS);
+        const int lw = (p.cycles + 2) / 2;
+        out.lut_ov = take(lw);
+        out.lut_lowq = take(lw);
+        out.lut_cplx = take(lw);
+        // Duplicate's primes: as byte planes for the dot-product hash when that table was built, else the plain list
+        out.hp = 0;
+        out.has_hp = 0;
+        out.hp_nq = 0;
+        out.primes = 0;
+        if (p.dup_bufnum > 0 && hp_nq > 0) {
+            if (o & 1) o++;
+            out.hp_nq = hp_nq;
+            out.has_hp = 1;
+            out.hp = take(4 * hp_nq * p.dup_bufnum * p.dup_npl);
+        } else {
+            out.primes = take(p.dup_bufnum > 0 ? 512 * p.dup_bufnum : 0);
+        }
+        o = (o + 3) & ~3;
+        out.tile_begin = o;
+        // ---- per tile ----
+        out.bar = take(2);
         if (o & 1) o++;
         out.hash = take(out.NR * (p.dup_bufnum > 0 ? p.dup_bufnum : 0) * 2);
         {   // trimAndCut predicate masks, only those the options need
@@ -342,32 +368,17 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.code = take(out.NR);
         out.swin = take(out.NR);
         out.mlen = take(out.NR);
-        if (o & 1) o++;
-        out.val4_lut = take(p.dup_bufnum > 0 ? 256 : 0);
-        out.wl_cap = 2046;
+        out.wl_cap = imin_i(2046, 8 * out.NR + 62);
+        out.wl_cap -= out.wl_cap & 1;
         out.wl = take(1 + out.wl_cap / 2);
         out.met = take(out.NR * 2);
         out.ov_off = take(P);
         out.ov_len = take(P);
         out.ov_diff = take(P);
         out.ov_flags = take(P);
-        out.adapt = take(2 * ADAPT_WORDS);
-        const int lw = (p.cycles + 2) / 2;
-        out.lut_ov = take(lw);
-        out.lut_lowq = take(lw);
-        out.lut_cplx = take(lw);
-        // Duplicate's primes: as byte planes for the dot-product hash when that table was built, else the plain list
-        out.hp = -1;
-        out.hp_nq = 0;
-        out.primes = 0;
-        if (p.dup_bufnum > 0 && hp_nq > 0) {
-            if (o & 1) o++;
-            out.hp_nq = hp_nq;
-            out.hp = take(4 * hp_nq * p.dup_bufnum * p.dup_npl);
-        } else {
-            out.primes = take(p.dup_bufnum > 0 ? 512 * p.dup_bufnum : 0);
-        }
-        out.total = o;
+        o = (o + 3) & ~3;
+        out.tile_stride = o - out.tile_begin;
+        out.total = out.tile_begin + halves * out.tile_stride;
     };
     if (cfg.P > 0) {
         build(cfg.P, L);
@@ -386,6 +397,16 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
     cfg.P = best;
     build(best, L);
     return FASTP_GPU_OK;
+}
+
+// the layout half h of a workgroup works with: its LDS base sits h * tile_stride dwords higher, so the offsets of
+// everything SHARED between the tiles move down by that much; per-tile offsets stay
+LdsLayout layout_for_half(const LdsLayout& L, int h) {
+    LdsLayout o = L;
+    const int d = h * L.tile_stride;
+    o.acc_cyc -= d; o.acc_kmer -= d; o.acc_qh -= d; o.acc_misc -= d; o.acc_end -= d;
+    o.val4_lut -= d; o.adapt -= d; o.lut_ov -= d; o.lut_lowq -= d; o.lut_cplx -= d; o.hp -= d; o.primes -= d;
+    return o;
 }
 
 }  // namespace fq

@@ -33,6 +33,7 @@ struct TileConfig {
     int threads;      // workgroup size (multiple of 64)
     int P;            // pairs / reads per tile
     int lds_budget;   // bytes of LDS one workgroup may use
+    int halves;       // tiles in flight per workgroup: 2 = each half of the waves owns one (fused_body), 1 = one tile
 };
 
 // returns FASTP_GPU_OK or an error code; err receives a human readable reason
@@ -41,6 +42,8 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& out, HostLuts& luts,
 // picks P (if cfg.P == 0) so that the tile fits cfg.lds_budget; fills L
 // hp_nq = HostLuts::dup_nq (0: no byte-plane prime table, the generic hash path is used)
 int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::string& err, int hp_nq = 0);
+
+LdsLayout layout_for_half(const LdsLayout& L, int h);   // see LdsLayout::halves
 
 u32 magic_for(u32 d);  // ceil(2^32 / d)
 

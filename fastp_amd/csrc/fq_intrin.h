@@ -59,7 +59,44 @@ FQ_DEV void touch_done(u32 v) {
 #endif
 }
 
+// a value that is the same in every lane of the wavefront, moved to a scalar register
+FQ_DEV u32 uniform(u32 v) {
+#ifdef FQ_HOSTSIM
+    return v;
+#else
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
 FQ_DEV void block_sync() { __syncthreads(); }
+// Barrier over ONE HALF of the workgroup's wavefronts (the waves that share a tile): an arrival counter and a
+// generation word in LDS, lane 0 of each wave arrives and then polls the generation with s_sleep between polls.
+// gfx950 has one hardware barrier per workgroup; the two halves must be able to wait independently.
+FQ_DEV void half_sync(u32* bar, int group, int nthreads) {
+#ifdef FQ_HOSTSIM
+    (void)bar;
+    sim::group_barrier(group, nthreads);
+#else
+    (void)group;
+    const u32 nwaves = (u32)nthreads >> 6;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's LDS writes are done before it arrives
+    if ((threadIdx.x & 63) == 0) {
+        const u32 gen = __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 arrived = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (arrived == nwaves - 1u) {   // last one: reset the count, then open the next generation (LDS executes a wave's operations in order)
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == gen) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+FQ_DEV void nap() {   // ~3 us
+#ifndef FQ_HOSTSIM
+    __builtin_amdgcn_s_sleep(127);
+#endif
+}
 FQ_DEV u64 cycle_counter() { return (u64)clock64(); }
 FQ_DEV void g_atomic_add_u64(u64* p, u64 v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -104,6 +104,13 @@ struct DevLuts {
 
 // LDS layout, all offsets in dwords from the start of dynamic LDS
 struct LdsLayout {
+    // Shared part first (accumulators, tables), then the per-tile arrays: a workgroup stages `halves` tiles at a
+    // time, tile h at +h * tile_stride dwords.  Half h of the workgroup works on an LDS base moved up by that much
+    // and on a copy of this layout whose SHARED offsets are moved down by it (KernelArgs per half).
+    int halves;     // 1 or 2 tiles in flight per workgroup (2: each half of the waves owns one, see fused_body)
+    int tile_begin, tile_stride;   // dwords
+    int bar;        // [2] per tile: arrival count and generation of the half-workgroup barrier
+    int has_hp;     // the byte-plane prime table exists (hp itself may be negative in a half's copy)
     int P;          // pairs (PE) or reads (SE) per tile
     int NR;         // rows per tile: 2P (PE) or P (SE)
     int SW, QW;     // LDS row strides in dwords = the global row strides: a tile in LDS is a flat copy of
@@ -134,7 +141,7 @@ struct LdsLayout {
     int adapt;      // [2][ADAPT_WORDS] packed adapter words
     int lut_ov, lut_lowq, lut_cplx;                       // u16 tables, (max_len+1+1)/2 dwords each
     int primes;     // [bufnum*512] (generic hash path only)
-    int hp, hp_nq;  // [4][hp_nq][bufnum][dup_npl] byte planes of the primes (DevLuts::dup_planes); hp = -1: generic path
+    int hp, hp_nq;  // [4][hp_nq][bufnum][dup_npl] byte planes of the primes (DevLuts::dup_planes); see has_hp
     int val4_lut;   // [256] u32: Duplicate's base values (A7 T222 C74 G31, duplicate.cpp:92-109) of the four
                     // bases a packed byte holds, one byte each
     int wl, wl_cap; // work list of (read, quality dword) items the fast Stats path hands to the general one:
@@ -285,12 +292,18 @@ struct KernelArgs {
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
     const u8* dupflag;  // [n] --dedup: the duplicate decision, taken by the dup kernels BEFORE this launch
     u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)
+    int half_skew;      // half 1 starts this many ~3 us sleeps late, so the halves sit in different phases
     u32 debug_skip;     // profiling only (FASTP_GPU_DEBUG_SKIP): phases left out, results are then meaningless.
                         // 1 masks+rc, 2 hash, 4 overlap, 8 metrics, 16 stats, 32 trim/decide/filter
     // per-workgroup counter slabs: [gridDim][slab_dwords]
     u32* slabs;
     int slab_dwords;
     int tiles;          // ceil(n / P)
+};
+
+// argument block of the fused kernel: one KernelArgs per half-workgroup (identical but for the LDS layout)
+struct FusedArgs {
+    KernelArgs h[2];
 };
 
 }  // namespace fq

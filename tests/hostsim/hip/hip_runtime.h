@@ -41,6 +41,7 @@ const Idx& grid_dim();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void syncthreads();
 void wave_barrier();
+void group_barrier(int group, int nthreads);   // barrier over threads [group * nthreads, (group + 1) * nthreads)
 unsigned long long ballot(bool pred);
 int shfl(int v, int src_lane);
 int shfl_xor(int v, int mask);
@@ -113,6 +114,8 @@ static inline int sim_update_dpp(int old, int src, int ctrl, int row_mask, int b
 
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
+template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
+template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
 template <class T, class V> static inline T __hip_atomic_fetch_add(T* p, V v, int, int) { T o = *p; *p = (T)(o + (T)v); return o; }
 template <class T, class V> static inline T __hip_atomic_fetch_or(T* p, V v, int, int) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <class T, class V> static inline T __hip_atomic_exchange(T* p, V v, int, int) { T o = *p; *p = (T)v; return o; }

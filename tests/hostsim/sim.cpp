@@ -16,7 +16,7 @@ alignas(16) uint32_t fq_lds[(160 * 1024) / 4 + 64];
 
 namespace sim {
 
-enum Wait { RUN = 0, AT_BLOCK = 1, AT_WAVE_BARRIER = 2, AT_BALLOT = 3, AT_SHFL = 4, AT_SHFL_XOR = 5, DONE = 6 };
+enum Wait { RUN = 0, AT_BLOCK = 1, AT_WAVE_BARRIER = 2, AT_BALLOT = 3, AT_SHFL = 4, AT_SHFL_XOR = 5, DONE = 6, AT_GROUP = 7 };
 
 struct ThreadState {
     ucontext_t ctx;
@@ -48,6 +48,7 @@ static void yield_to_sched(int why) {
 
 void syncthreads() { yield_to_sched(AT_BLOCK); }
 void wave_barrier() { yield_to_sched(AT_WAVE_BARRIER); }
+void group_barrier(int group, int nthreads) { cur->val = group; cur->arg = nthreads; yield_to_sched(AT_GROUP); }
 unsigned long long ballot(bool pred) { cur->val = pred ? 1 : 0; yield_to_sched(AT_BALLOT); return cur->res64; }
 int shfl(int v, int src) { cur->val = v; cur->arg = src & 63; yield_to_sched(AT_SHFL); return cur->res32; }
 int shfl_xor(int v, int mask) { cur->val = v; cur->arg = mask; yield_to_sched(AT_SHFL_XOR); return cur->res32; }
@@ -127,6 +128,24 @@ static void run_block(std::vector<ThreadState>& th) {
             for (int t = lo; t < hi; t++)
                 if (th[t].wait == kind) th[t].wait = RUN;
             progressed = true;
+        }
+        // group-level rendezvous (half-workgroup barriers): a group is released when all of its live threads wait
+        for (int t0 = 0; t0 < T;) {
+            if (th[t0].wait != AT_GROUP) { t0++; continue; }
+            const int size = th[t0].arg, g = th[t0].val;
+            const int lo = g * size, hi = std::min(T, lo + size);
+            int glive = 0, gat = 0;
+            for (int t = lo; t < hi; t++) {
+                if (th[t].wait == DONE) continue;
+                glive++;
+                if (th[t].wait == AT_GROUP && th[t].val == g && th[t].arg == size) gat++;
+            }
+            if (glive > 0 && gat == glive) {
+                for (int t = lo; t < hi; t++)
+                    if (th[t].wait == AT_GROUP) th[t].wait = RUN;
+                progressed = true;
+            }
+            t0 = hi > t0 ? hi : t0 + 1;
         }
         // block-level rendezvous
         int live = 0, at_block = 0;
