@@ -253,7 +253,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
     ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", lds_kb_default) * 1024;
     // two tiles in flight per workgroup (each half of the waves owns one) when the halves are whole wavefronts
-    ctx->cfg.halves = (env_int("FASTP_GPU_HALVES", 2) == 2 && ctx->cfg.threads % 128 == 0) ? 2 : 1;
+    ctx->cfg.halves = (env_int("FASTP_GPU_HALVES", 1) == 2 && ctx->cfg.threads % 128 == 0) ? 2 : 1;
     if (ctx->cfg.threads < 64 || ctx->cfg.threads > 1024 || (ctx->cfg.threads & 63)) {
         delete ctx;
         return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024");
@@ -263,6 +263,10 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->luts.dup_nq = 0;
     }
     rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
+    if (rc && ctx->cfg.halves == 2 && ctx->cfg.P > 0) {  // an explicit tile size that only fits once: one tile in flight
+        ctx->cfg.halves = 1;
+        rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
+    }
     if (rc) { delete ctx; return fail(nullptr, rc, err); }
     const int blocks_per_cu = env_int("FASTP_GPU_BLOCKS_PER_CU", std::max(1, (int)((160 * 1024) / (ctx->L.total * 4))));
     ctx->blocks = ctx->cus * std::max(1, blocks_per_cu);
@@ -536,6 +540,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     a.slab_dwords = ctx->slab_dwords;
     a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
     a.half_skew = env_int("FASTP_GPU_HALF_SKEW", 6);
+    a.half_naps = env_int("FASTP_GPU_HALF_NAPS", 1);
     const int wg_tiles = (a.tiles + ctx->L.halves - 1) / ctx->L.halves;   // tiles are dealt to workgroups `halves` at a time
     const int grid = wg_tiles < ctx->blocks ? wg_tiles : ctx->blocks;
     // the stage + hash pre-pass of --dedup runs the whole workgroup on one tile at a time

@@ -73,7 +73,7 @@ FQ_DEV int* lds_i(u32* lds, int off) { return (int*)(lds + off); }
 // barrier over the wavefronts that work on one tile: the whole workgroup, or - two tiles in flight - the half that
 // owns the tile (`lds` is that half's LDS base, `tid` / `nthreads` its view of itself)
 FQ_DEV void tile_sync(const KernelArgs& a, u32* lds, int nthreads) {
-    if (a.L.halves == 2) half_sync(lds + a.L.bar, thread_id() >= nthreads ? 1 : 0, nthreads);
+    if (a.L.halves == 2) half_sync(lds + a.L.bar, thread_id() >= nthreads ? 1 : 0, nthreads, a.half_naps);
     else block_sync();
 }
 
@@ -531,6 +531,7 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
     const int qual_b = L.qual * 4, seq_b = L.seq * 4;
     const int lane = tid & 63;
     const int total = NR * 4;
+    const u32 dbg = a.debug_skip;   // profiling only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
     for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count (ballots inside)
         const int task = base + lane;
         const bool tv = task < total;
@@ -612,19 +613,24 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
                     inc[k] = *(const u64*)ta[k];
                     one[k] = (u32)inc[k] & 1u;  // the count field's increment: 1 for a base, 0 for character 0
                 }
+                if (!(dbg & 64u)) {
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     lds_add_u64((u64*)(cyc + (bfe(cur8, 2 * k, 2) << 3) + k * (N_CLS * 8)), inc[k]);
-                if (c > 0) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N); a base past the read's end adds 0
+                }
+                if (c > 0 && !(dbg & 128u)) {  // 5-mers ending at 4c..4c+3 (positions >= 4, no N); a base past the read's end adds 0
                     const u32 codes = pc16 & 0xFFFFu;
 #pragma unroll
                     for (int k = 0; k < 4; k++) lds_add_u32((u32*)(kmer + (bfe(codes, 2 * k, 10) << 2)), one[k]);
                 }
+                // a dword of four equal characters (the tail of a read after its quality dropped, for one) adds 4 once
+                const bool same4 = ta[0] == ta[1] && ta[0] == ta[2] && ta[0] == ta[3];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const bool is_mode = (u32)(int)(ta[k] - ldsw) == mode_ta;
                     agg_cnt += is_mode ? 1u : 0u;   // per lane; folded over the wavefront after the loop
-                    if (!is_mode) lds_add_u32((u32*)(ta[k] + QT_COUNT * 4), one[k]);
+                    if (!is_mode && !(dbg & 256u) && (k == 0 || !same4))
+                        lds_add_u32((u32*)(ta[k] + QT_COUNT * 4), (k == 0 && same4) ? 4u * one[0] : one[k]);
                 }
             }
             cc = cc + 1 == S ? 0 : cc + 1;

@@ -71,9 +71,10 @@ FQ_DEV void block_sync() { __syncthreads(); }
 // Barrier over ONE HALF of the workgroup's wavefronts (the waves that share a tile): an arrival counter and a
 // generation word in LDS, lane 0 of each wave arrives and then polls the generation with s_sleep between polls.
 // gfx950 has one hardware barrier per workgroup; the two halves must be able to wait independently.
-FQ_DEV void half_sync(u32* bar, int group, int nthreads) {
+FQ_DEV void half_sync(u32* bar, int group, int nthreads, int naps) {
 #ifdef FQ_HOSTSIM
     (void)bar;
+    (void)naps;
     sim::group_barrier(group, nthreads);
 #else
     (void)group;
@@ -86,7 +87,13 @@ FQ_DEV void half_sync(u32* bar, int group, int nthreads) {
             __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {
-            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == gen) __builtin_amdgcn_s_sleep(1);
+            // poll rarely: every poll is an LDS instruction and a few VALU ones taken from the other half's phases
+            while (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == gen) {
+                if (naps <= 0) __builtin_amdgcn_s_sleep(1);
+                else if (naps == 1) __builtin_amdgcn_s_sleep(4);
+                else if (naps == 2) __builtin_amdgcn_s_sleep(16);
+                else __builtin_amdgcn_s_sleep(64);
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

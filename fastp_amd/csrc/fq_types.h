@@ -293,6 +293,7 @@ struct KernelArgs {
     const u8* dupflag;  // [n] --dedup: the duplicate decision, taken by the dup kernels BEFORE this launch
     u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)
     int half_skew;      // half 1 starts this many ~3 us sleeps late, so the halves sit in different phases
+    int half_naps;      // poll interval class of the half barrier (0: 64 cycles ... 3: 4096)
     u32 debug_skip;     // profiling only (FASTP_GPU_DEBUG_SKIP): phases left out, results are then meaningless.
                         // 1 masks+rc, 2 hash, 4 overlap, 8 metrics, 16 stats, 32 trim/decide/filter
     // per-workgroup counter slabs: [gridDim][slab_dwords]
