@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Insert the GPU worker hooks into COPIES of two reference sources (TEST INFRASTRUCTURE, see gpu_worker.h).
+
+    apply_gpu_worker.py <reference root> <output dir>
+
+Writes <output dir>/peprocessor.cpp and seprocessor.cpp: the reference's files with four one-line insertions,
+each placed by an anchor (the function signature / the comment that opens the merge of the per-thread results).
+Nothing else of the reference is touched or reproduced here; every other source is compiled where it lies.
+"""
+import os
+import re
+import sys
+
+ref, out = sys.argv[1], sys.argv[2]
+os.makedirs(out, exist_ok=True)
+
+
+def patch(name, inserts):
+    src = open(os.path.join(ref, "src", name)).read()
+    src = '#include "gpu_worker.h"\n' + src
+    for anchor, text, where in inserts:
+        m = re.search(anchor, src)
+        if not m:
+            sys.exit(f"apply_gpu_worker: anchor not found in {name}: {anchor}")
+        pos = m.end() if where == "after" else m.start()
+        src = src[:pos] + text + src[pos:]
+    open(os.path.join(out, name), "w").write(src)
+
+
+patch("peprocessor.cpp", [
+    (r"bool PairEndProcessor::processPairEnd\(ReadPack\* leftPack, ReadPack\* rightPack, ThreadConfig\* config\)\s*\{",
+     "\n    if(fastp_gpu_worker_pe(this, leftPack, rightPack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
+    (r"[ \t]*// merge stats and filter results",
+     "    fastp_gpu_worker_finish_pe(this, configs);   // engine counters -> Stats / FilterResult / Duplicate / insert sizes\n", "before"),
+])
+patch("seprocessor.cpp", [
+    (r"bool SingleEndProcessor::processSingleEnd\(ReadPack\* pack, ThreadConfig\* config\)\s*\{",
+     "\n    if(fastp_gpu_worker_se(this, pack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
+    (r"[ \t]*// merge stats and read filter results",
+     "    fastp_gpu_worker_finish_se(this, configs);   // engine counters -> Stats / FilterResult / Duplicate\n", "before"),
+])
+print("patched peprocessor.cpp, seprocessor.cpp ->", out)

@@ -1,0 +1,30 @@
+// gpu_worker.h - the hooks a GPU-enabled build of reference fastp calls (TEST INFRASTRUCTURE: this is the
+// reference-side binding of include/fastp_gpu.h + include/fastp_gpu_host.h, compiled INTO the reference by
+// oracle/build_ref_gpu.sh so that the drop-in boundary is exercised end to end: fastp's own CLI, reader and writer
+// threads, Stats / FilterResult objects and JSON / HTML reporters around the engine).
+//
+// oracle/patches/apply_gpu_worker.py inserts three one-line calls into copies of the reference's sources:
+//   src/peprocessor.cpp  top of PairEndProcessor::processPairEnd   -> fastp_gpu_worker_pe
+//   src/seprocessor.cpp  top of SingleEndProcessor::processSingleEnd -> fastp_gpu_worker_se
+//   both                 before "merge stats" in ::process()        -> fastp_gpu_worker_finish_pe / _se
+// The engine is used when the environment has FASTP_GPU=1; otherwise the hooks return "not handled" and the
+// reference's own loop runs.
+#ifndef FASTP_GPU_WORKER_H
+#define FASTP_GPU_WORKER_H
+
+class PairEndProcessor;
+class SingleEndProcessor;
+class ThreadConfig;
+struct ReadPack;
+
+// 1 = the pack was processed by the engine (outputs handed to the writers, packs freed); -1 = not handled: run the
+// reference's own loop body on this pack (engine disabled, or a read the packer refuses: letters outside ACGTN,
+// quality characters outside '!'..'~', a read longer than the evaluated read length)
+int fastp_gpu_worker_pe(PairEndProcessor* p, ReadPack* left, ReadPack* right, ThreadConfig* config);
+int fastp_gpu_worker_se(SingleEndProcessor* p, ReadPack* pack, ThreadConfig* config);
+// load the engine's counter block into the worker threads' Stats / FilterResult objects, Duplicate's totals and
+// the insert-size histogram, right before the reference merges them and writes its reports
+void fastp_gpu_worker_finish_pe(PairEndProcessor* p, ThreadConfig** configs);
+void fastp_gpu_worker_finish_se(SingleEndProcessor* p, ThreadConfig** configs);
+
+#endif

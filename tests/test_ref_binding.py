@@ -1,0 +1,139 @@
+"""The drop-in boundary end to end: REAL reference fastp (its CLI, reader / writer threads, Stats / FilterResult
+objects, JSON reporter) with the two worker-loop bodies bound to the engine by oracle/patches/gpu_worker.cpp
+(oracle/build_ref_gpu.sh -> oracle/_ref/fastp_ref_gpu), against the unpatched reference `fastp_ref -w 1` on the same
+files: every output FASTQ byte for byte, and the JSON report fastp ITSELF wrote, value for value.
+
+The CPU suite runs the binding linked against the SIMT-emulator build of the engine (fastp_ref_gpusim, small
+inputs); the `-m gpu` test runs the real library.  Both binaries are built in the build container (they need
+/root/reference) and travel to the GPU box with oracle/_ref/."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import cases
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
+REF_GPU = os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpu")
+REF_SIM = os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpusim")
+
+# case -> extra CLI flags that name the secondary outputs the case exercises
+BINDING_CASES = {
+    "pe_default": [],
+    "pe_cut_right": [],
+    "pe_cut_front_tail": [],
+    "pe_polyg_polyx": [],
+    "pe_adapter_seq": [],
+    "pe_correction": [],
+    "pe_trim_fixed": [],
+    "pe_filters": ["--unpaired1", "@TMP@/u1.fq", "--unpaired2", "@TMP@/u2.fq"],
+    "pe_noadapter_dedup": [],
+    "pe_nofilters": [],
+    "pe_merge": [],
+    "pe_merge_unmerged": [],
+    "pe_allow_gap_indel": [],
+    "pe_umi_per_read": [],
+    "pe_adapter_fasta": [],
+    "pe_overrep": [],
+    "se_default_noadapter": [],
+    "se_adapter_cut": [],
+    "se_umi_read1": [],
+    "se_adapter_indel": [],
+    "se_overrep": [],
+}
+
+
+_BUILT = False
+
+
+def _ensure_built():
+    global _BUILT
+    if not _BUILT and os.path.isdir("/root/reference/src"):
+        import __graft_entry__ as g
+        import engines
+        engines.build_sim()     # the emulator build of the engine, which fastp_ref_gpusim links
+        g.build()               # libfastp_gpu.so, fastp_ref, fastp_ref_gpu (+ fastp_ref_gpusim now that the emulator exists)
+        subprocess.check_call([os.path.join(ROOT, "oracle", "build_ref_gpu.sh")], stdout=subprocess.DEVNULL)
+        _BUILT = True
+    return os.path.exists(REF)
+
+
+def _run(binary, tmp, tag, flags, paired, gpu_env):
+    out = os.path.join(tmp, tag)
+    os.makedirs(out, exist_ok=True)
+    cmd = [binary, "-i", os.path.join(tmp, "in1.fq"), "-o", os.path.join(out, "o1.fq"), "-j", os.path.join(out, "r.json"),
+           "-h", os.path.join(out, "r.html"), "-w", "1", "--failed_out", os.path.join(out, "failed.fq")]
+    if paired:
+        cmd += ["-I", os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2.fq")]
+    cmd += [x.replace("@TMP@", out) for x in flags]
+    env = dict(os.environ)
+    env.pop("FASTP_GPU", None)
+    env.update(gpu_env)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200)
+    assert p.returncode == 0, f"{os.path.basename(binary)} failed: {p.stderr.decode()[-1500:]}"
+    files = {fn: open(os.path.join(out, fn), "rb").read() for fn in sorted(os.listdir(out)) if fn.endswith(".fq")}
+    rep = json.load(open(os.path.join(out, "r.json")))
+    rep.pop("command", None)
+    return files, rep
+
+
+def _diff(x, y, path, out):
+    if isinstance(x, dict) and isinstance(y, dict):
+        for k in sorted(set(x) | set(y)):
+            if k not in x or k not in y:
+                out.append(f"{path}/{k}: only on one side")
+            else:
+                _diff(x[k], y[k], f"{path}/{k}", out)
+    elif isinstance(x, list) and isinstance(y, list):
+        if len(x) != len(y):
+            out.append(f"{path}: {len(x)} vs {len(y)} entries")
+        else:
+            for i, (p, q) in enumerate(zip(x, y)):
+                _diff(p, q, f"{path}[{i}]", out)
+    elif x != y:
+        out.append(f"{path}: reference {x!r} binding {y!r}")
+
+
+def _check(name, binary, n, tmp_path, seed):
+    paired, flags, pf, skw = cases.CASES[name]
+    flags = list(flags) + BINDING_CASES[name]
+    tmp = str(tmp_path)
+    d = synth.synth_pairs(n, L=150, seed=seed, paired=paired, **skw)
+    with open(os.path.join(tmp, "in1.fq"), "wb") as f:
+        f.write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1))
+    if paired:
+        with open(os.path.join(tmp, "in2.fq"), "wb") as f:
+            f.write(synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2))
+    for fn, content in cases.FILES.get(name, {}).items():
+        for tag in ("ref", "gpu"):
+            os.makedirs(os.path.join(tmp, tag), exist_ok=True)
+            with open(os.path.join(tmp, tag, fn), "wb") as f:
+                f.write(content)
+    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {})
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, {"FASTP_GPU": "1"})
+    assert sorted(want_files) == sorted(got_files)
+    for fn in want_files:
+        assert want_files[fn] == got_files[fn], f"{name}: {fn} differs ({len(want_files[fn])} vs {len(got_files[fn])} bytes)"
+    problems = []
+    _diff(want_rep, got_rep, "", problems)
+    assert not problems, f"{name}: fastp's own JSON report differs:\n" + "\n".join(problems[:25])
+    assert want_rep["summary"]["before_filtering"]["total_reads"] == (2 if paired else 1) * n
+
+
+@pytest.mark.parametrize("name", list(BINDING_CASES))
+def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 600, tmp_path, seed=41)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(BINDING_CASES))
+def test_gpu_patched_reference_equals_reference(name, tmp_path):
+    """the same on the real library: fastp_ref_gpu (FASTP_GPU=1) vs fastp_ref, 30 000 units"""
+    if not (os.path.exists(REF) and os.path.exists(REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    _check(name, REF_GPU, 30000, tmp_path, seed=43)
