@@ -182,6 +182,14 @@ class FormatIn(C.Structure):
     _fields_ = [("text", C.c_void_p), ("line_off", C.c_void_p), ("line_len", C.c_void_p), ("res", C.c_void_p)]
 
 
+class FormatOptions(C.Structure):
+    _fields_ = [("want_failed", C.c_int32), ("want_unpaired1", C.c_int32), ("want_unpaired2", C.c_int32),
+                ("umi_loc", C.c_int32), ("umi_len", C.c_int32), ("umi_prefix", C.c_char_p), ("umi_delimiter", C.c_char_p)]
+
+
+N_OUTPUTS = 6  # FASTP_GPU_OUT1, OUT2, FAILED, MERGED, UNPAIRED1, UNPAIRED2
+
+
 class CounterLayout(C.Structure):
     _fields_ = [
         ("total", C.c_int64), ("cycles", C.c_int64),

@@ -81,6 +81,19 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmt_write_kernel(FmtArgs f)
     fmt_write_body(f, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_fmt_fix_kernel(FmtArgs f) { fmt_fix_body(f); }
+extern "C" __global__ void __launch_bounds__(256) fq_fmts_corr_kernel(FmtsArgs f) { fmts_corr_body(f); }
+extern "C" __global__ void __launch_bounds__(256) fq_fmts_len_kernel(FmtsArgs f) {
+    extern __shared__ u32 fq_lds[];
+    fmts_len_body(f, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(1024) fq_fmts_scan_kernel(FmtsArgs f) {
+    extern __shared__ u32 fq_lds[];
+    fmts_scan_body(f, (u64*)fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs f) {
+    extern __shared__ u32 fq_lds[];
+    fmts_write_body(f, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(1024) fq_dup_resolve_kernel(DupArgs d) {
@@ -1012,6 +1025,101 @@ extern "C" int fastp_gpu_format_fastq(fastp_gpu_ctx* ctx, int32_t n, const fastp
     out_len[1] = (int64_t)totals[1];
     if (out_len[0] > out1_capacity || (paired && out_len[1] > out2_capacity))
         return fail(ctx, FASTP_GPU_E_OVERFLOW, "output buffer too small (see out_len for the needed sizes)");
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_format_io* m1, const fastp_gpu_format_io* m2,
+                                        const fastp_gpu_pair_result* pair, const fastp_gpu_correction* corrections,
+                                        const int32_t* n_corrections, const fastp_gpu_format_options* opts,
+                                        uint8_t* const out[FASTP_GPU_N_OUTPUTS], const int64_t out_capacity[FASTP_GPU_N_OUTPUTS],
+                                        int64_t out_len[FASTP_GPU_N_OUTPUTS]) {
+    if (!ctx || !m1 || !out || !out_capacity || !out_len || n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) out_len[q] = 0;
+    const bool paired = ctx->dp.paired != 0;
+    if (paired != (m2 != nullptr)) return fail(ctx, FASTP_GPU_E_INVALID, "mate 2 must be given exactly for a paired engine");
+    if (paired && !pair) return fail(ctx, FASTP_GPU_E_INVALID, "a paired engine needs the pair records");
+    FmtsArgs f;
+    memset(&f, 0, sizeof(f));
+    f.n = n;
+    f.paired = paired ? 1 : 0;
+    f.dedup = ctx->dp.dedup;
+    f.merge = paired ? ctx->dp.merge : 0;
+    f.merge_include_unmerged = ctx->dp.merge_include_unmerged;
+    f.delim[0] = ':';
+    f.delim_len = 1;
+    if (opts) {
+        f.want_failed = opts->want_failed != 0;
+        f.want_u1 = opts->want_unpaired1 != 0;
+        f.want_u2 = opts->want_unpaired2 != 0;
+        if (opts->umi_loc < FASTP_GPU_UMI_NONE || opts->umi_loc > FASTP_GPU_UMI_PER_READ)
+            return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "UMIs taken from the index part of the name are host logic");
+        f.umi_loc = opts->umi_loc;
+        f.umi_len = opts->umi_len;
+        if (opts->umi_delimiter) {
+            const size_t dl = strlen(opts->umi_delimiter);
+            if (dl > sizeof(f.delim)) return fail(ctx, FASTP_GPU_E_INVALID, "UMI delimiter longer than 8 characters");
+            memcpy(f.delim, opts->umi_delimiter, dl);
+            f.delim_len = (u32)dl;
+        }
+        if (opts->umi_prefix) {
+            const size_t pl = strlen(opts->umi_prefix);
+            if (pl > sizeof(f.prefix)) return fail(ctx, FASTP_GPU_E_INVALID, "UMI prefix longer than 32 characters");
+            memcpy(f.prefix, opts->umi_prefix, pl);
+            f.prefix_len = (u32)pl;
+        }
+    }
+    if (n == 0) return FASTP_GPU_OK;
+    // the streams this configuration can write to need a buffer
+    bool need[FMTS_STREAMS] = {true, paired, f.want_failed != 0, f.merge != 0, paired && f.want_u1, paired && f.want_u2};
+    for (int q = 0; q < FMTS_STREAMS; q++) {
+        if (out_capacity[q] < 0 || (need[q] && !out[q])) return fail(ctx, FASTP_GPU_E_INVALID, "null output buffer for a stream the options ask for");
+        f.out[q] = out[q];
+        f.out_cap[q] = out[q] ? (u64)out_capacity[q] : 0;
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    f.nblocks = (n + FMT_BLOCK - 1) / FMT_BLOCK;
+    const size_t words = (size_t)2 * FMTS_STREAMS * f.nblocks + FMTS_STREAMS;
+    int rc = ensure(ctx, (void**)&ctx->d_fmt, &ctx->fmt_cap, words * 8);
+    if (rc) return rc;
+    f.blocksum = ctx->d_fmt;
+    f.blockbase = f.blocksum + (size_t)FMTS_STREAMS * f.nblocks;
+    f.totals = f.blockbase + (size_t)FMTS_STREAMS * f.nblocks;
+    const fastp_gpu_format_io* ins[2] = {m1, m2};
+    for (int m = 0; m < (paired ? 2 : 1); m++) {
+        if (!ins[m]->text || !ins[m]->line_off || !ins[m]->line_len || !ins[m]->res) return fail(ctx, FASTP_GPU_E_INVALID, "null input");
+        f.m[m].text = ins[m]->text;
+        f.m[m].line_off = ins[m]->line_off;
+        f.m[m].line_len = ins[m]->line_len;
+        f.m[m].res = (const u32*)ins[m]->res;
+    }
+    f.pair = (const u32*)pair;
+    f.corrections = (const u32*)corrections;
+    f.n_corrections = n_corrections;
+    int32_t ncorr = 0;
+    if (corrections && n_corrections) {
+        HIP_TRY(ctx, hipMemcpyAsync(&ncorr, n_corrections, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (ncorr > 0) {
+            hipLaunchKernelGGL(fq_fmts_corr_kernel, dim3((ncorr + 255) / 256), dim3(256), 0, st, f);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(fq_fmts_len_kernel, dim3(f.nblocks), dim3(FMT_BLOCK), FMTS_STREAMS * 4, st, f);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_fmts_scan_kernel, dim3(FMTS_STREAMS), dim3(1024), 1024 * 8, st, f);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_fmts_write_kernel, dim3(f.nblocks), dim3(FMT_BLOCK), FMTS_STREAMS * 16 * 4 + FMT_BLOCK * 16, st, f);
+    HIP_TRY(ctx, hipGetLastError());
+    u64 totals[FMTS_STREAMS];
+    HIP_TRY(ctx, hipMemcpyAsync(totals, f.totals, sizeof(totals), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    bool overflow = false;
+    for (int q = 0; q < FMTS_STREAMS; q++) {
+        out_len[q] = (int64_t)totals[q];
+        if (totals[q] > f.out_cap[q]) overflow = true;
+    }
+    if (overflow) return fail(ctx, FASTP_GPU_E_OVERFLOW, "output buffer too small (see out_len for the needed sizes)");
     return FASTP_GPU_OK;
 }
 

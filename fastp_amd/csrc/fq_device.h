@@ -3148,4 +3148,395 @@ FQ_DEV void fmt_fix_body(const FmtArgs& f) {
     M.out[off + nl + 1 + len + 1 + sl + 1 + (pos - front)] = (u8)(w >> 24);
 }
 
+// ---------------------------------------------------------------------------
+// Every output stream on the device (second half): the routing of
+// peprocessor.cpp:518-621 / seprocessor.cpp:280-290 from the result records, Read::appendToString /
+// appendToStringWithTag (read.cpp:119-154), OverlapAnalysis::merge's string assembly
+// (overlapanalysis.cpp:148-179) and UmiProcessor::addUmiToName (umiprocessor.cpp:62-81).
+// A unit (pair / single read) makes at most two records ("emissions"); an emission is
+//   stream | source << 3 | tag kind << 5 | filter code << 8      source: 0 read 1, 1 read 2, 2 the merged read
+//                                                                  tag kind: 0 none, 1 FAILED_TYPES[code], 2 "paired_read_is_failing"
+//   fmts_corr  : BaseCorrector's edits patched into the parsed text (the reference edits reads in place)
+//   fmts_len   : bytes each block's units add to each stream
+//   fmts_scan  : running offsets per stream
+//   fmts_write : a 16-lane group per emission assembles the record
+// ---------------------------------------------------------------------------
+FQ_DEV u32 fmts_em(int stream, int src, int tagkind, u32 code) { return (u32)stream | ((u32)src << 3) | ((u32)tagkind << 5) | (code << 8); }
+
+FQ_DEV void fmts_route(const FmtsArgs& f, int g, u32 e[2]) {
+    e[0] = e[1] = FMTS_NONE;
+    const u32 w1 = f.m[0].res[(size_t)g * 3 + 1];
+    const u32 code1 = w1 & 0xFFu, fl1 = (w1 >> 8) & 0xFFu;
+    const bool alive1 = !(fl1 & RS_NULL);
+    const bool dedup_out = f.dedup && (fl1 & RS_DUP);
+    if (!f.paired) {  // seprocessor.cpp:280-290
+        if (dedup_out) return;
+        if (alive1 && code1 == 0u) e[0] = fmts_em(0, 0, 0, 0);
+        else if (f.want_failed) e[0] = fmts_em(2, 0, 1, code1);
+        return;
+    }
+    const u32 w2 = f.m[1].res[(size_t)g * 3 + 1];
+    const u32 code2 = w2 & 0xFFu, fl2 = (w2 >> 8) & 0xFFu;
+    const bool alive2 = !(fl2 & RS_NULL);
+    if (f.merge && alive1 && alive2) {  // peprocessor.cpp:518-561
+        const u32 pflags = f.pair[2 * (size_t)g + 1] >> 16;
+        if (pflags & 1u) {  // overlapped
+            if (code1 == 0u) e[0] = fmts_em(3, 2, 0, 0);
+            return;
+        }
+        if (f.merge_include_unmerged) {
+            int k = 0;
+            if (code1 == 0u && !dedup_out) e[k++] = fmts_em(3, 0, 0, 0);
+            if (code2 == 0u && !dedup_out) e[k++] = fmts_em(3, 1, 0, 0);
+            return;
+        }
+    }
+    if (dedup_out) return;
+    const bool p1 = alive1 && code1 == 0u, p2 = alive2 && code2 == 0u;
+    const bool wf = f.want_failed != 0;
+    if (p1 && p2) {  // :577-594
+        e[0] = fmts_em(0, 0, 0, 0);
+        e[1] = fmts_em(1, 1, 0, 0);
+    } else if (p1) {  // :595-605
+        if (f.want_u1) {
+            e[0] = fmts_em(4, 0, 0, 0);
+            if (wf) e[1] = fmts_em(2, 1, 1, code2);
+        } else if (wf) {
+            e[0] = fmts_em(2, 0, 2, 0);
+            e[1] = fmts_em(2, 1, 1, code2);
+        }
+    } else if (p2) {  // :606-621
+        if (f.want_u2) {
+            e[0] = fmts_em(5, 1, 0, 0);
+            if (wf) e[1] = fmts_em(2, 0, 1, code1);
+        } else if (f.want_u1) {
+            e[0] = fmts_em(4, 1, 0, 0);
+            if (wf) e[1] = fmts_em(2, 0, 1, code1);
+        } else if (wf) {
+            e[0] = fmts_em(2, 0, 1, code1);
+            e[1] = fmts_em(2, 1, 2, 0);
+        }
+    }
+}
+
+// FAILED_TYPES (common.h:57-66) / "paired_read_is_failing": character i of the tag, its length
+FQ_DEV const char* fmts_tag_text(int kind, u32 code) {
+    if (kind == 2) return "paired_read_is_failing";
+    switch (code) {
+        case 0: return "passed";
+        case 4: return "failed_polyx_filter";
+        case 8: return "failed_bad_overlap";
+        case 12: return "failed_too_many_n_bases";
+        case 16: return "failed_too_short";
+        case 17: return "failed_too_long";
+        case 20: return "failed_quality_filter";
+        case 24: return "failed_low_complexity";
+        case 28: return "failed_adapter_dimer";
+        default: return "";
+    }
+}
+FQ_DEV u32 fmts_strlen(const char* t) {
+    u32 n = 0;
+    while (t[n]) n++;
+    return n;
+}
+FQ_DEV u32 fmts_digits(u32 v) { return v >= 1000u ? 4u : v >= 100u ? 3u : v >= 10u ? 2u : 1u; }
+
+// UmiProcessor::process + addUmiToName: length of the text inserted into the names of this unit (0 = no edit),
+// and the lengths of its two UMI parts
+FQ_DEV u32 fmts_umi(const FmtsArgs& f, int g, u32& u1, u32& u2) {
+    u1 = u2 = 0;
+    if (f.umi_loc == 0) return 0;
+    const u32 ul = (u32)imax(0, f.umi_len);
+    const u32 l1 = f.m[0].line_len[4 * (size_t)g + 1];
+    const u32 l2 = f.paired ? f.m[1].line_len[4 * (size_t)g + 1] : 0u;
+    bool tag = true;
+    if (f.umi_loc == 1) u1 = l1 < ul ? l1 : ul;
+    else if (f.umi_loc == 2) { if (f.paired) u2 = l2 < ul ? l2 : ul; else tag = false; }
+    else { u1 = l1 < ul ? l1 : ul; if (f.paired) u2 = l2 < ul ? l2 : ul; }
+    if (f.umi_loc != 3 && u1 + u2 == 0u) tag = false;
+    if (!tag) return 0;
+    return f.delim_len + (f.prefix_len ? f.prefix_len + 1u : 0u) + u1 + u2 + ((f.umi_loc == 3 && f.paired) ? 1u : 0u);
+}
+
+// geometry of one emission of unit g
+struct FmtsRec {
+    int mt;            // the mate whose name / strand lines are used
+    u32 name_len, strand_len, seq_len, tag_len, umi_len, mtag_len;   // mtag: " merged_L1_L2"
+    u32 m1, m2, ol;    // merged parts
+    bool strand_tagged;
+    u32 bytes;
+};
+FQ_DEV void fmts_rec(const FmtsArgs& f, int g, u32 em, u32 umi_len, FmtsRec& r) {
+    const int src = (int)((em >> 3) & 3u);
+    r.mt = src == 1 ? 1 : 0;
+    const FmtsMate& M = f.m[r.mt];
+    r.name_len = M.line_len[4 * (size_t)g];
+    r.strand_len = M.line_len[4 * (size_t)g + 2];
+    r.umi_len = umi_len;
+    const int tagkind = (int)((em >> 5) & 7u);
+    r.tag_len = tagkind ? fmts_strlen(fmts_tag_text(tagkind, (em >> 8) & 0xFFu)) : 0u;
+    r.mtag_len = 0;
+    r.m1 = r.m2 = r.ol = 0;
+    r.strand_tagged = false;
+    if (src == 2) {
+        r.m1 = f.m[0].res[(size_t)g * 3 + 2] >> 16;   // reserved: bases of this mate in the merged read
+        r.m2 = f.m[1].res[(size_t)g * 3 + 2] >> 16;
+        r.ol = f.pair[2 * (size_t)g] >> 16;
+        r.seq_len = r.m1 + r.m2;
+        r.mtag_len = 8u + fmts_digits(r.m1) + 1u + fmts_digits(r.m2);   // " merged_" L1 "_" L2
+        // the strand line gets the tag too unless it is just "+" (overlapanalysis.cpp:170-173)
+        const u8* st = M.text + M.line_off[4 * (size_t)g + 2];
+        r.strand_tagged = !(r.strand_len == 1u && st[0] == '+');
+    } else {
+        r.seq_len = M.res[(size_t)g * 3] >> 16;
+    }
+    r.bytes = r.name_len + r.umi_len + r.mtag_len + (r.tag_len ? 1u + r.tag_len : 0u) + 1u + r.seq_len + 1u + r.strand_len +
+              (r.strand_tagged ? r.mtag_len : 0u) + 1u + r.seq_len + 1u;
+}
+
+FQ_DEV void fmts_corr_body(const FmtsArgs& f) {
+    const int i = block_id() * block_threads() + thread_id();
+    if (!f.corrections || !f.n_corrections || i >= *f.n_corrections) return;
+    const u32 rd = f.corrections[2 * (size_t)i], w = f.corrections[2 * (size_t)i + 1];
+    const int mt = f.paired ? (int)(rd & 1u) : 0;
+    const int g = (int)(f.paired ? rd >> 1 : rd) - f.corr_first;
+    if (g < 0 || g >= f.n) return;
+    const FmtsMate& M = f.m[mt];
+    const u32 pos = w & 0xFFFFu;
+    if (pos >= M.line_len[4 * (size_t)g + 1]) return;
+    M.text[M.line_off[4 * (size_t)g + 1] + pos] = (u8)((w >> 16) & 0xFFu);
+    M.text[M.line_off[4 * (size_t)g + 3] + pos] = (u8)(w >> 24);
+}
+
+// per-unit byte counts per stream -> LDS block sums -> blocksum
+FQ_DEV void fmts_len_body(const FmtsArgs& f, u32* lds) {
+    if (thread_id() < FMTS_STREAMS) lds[thread_id()] = 0;
+    block_sync();
+    const int g = block_id() * block_threads() + thread_id();
+    u32 bytes[FMTS_STREAMS] = {0, 0, 0, 0, 0, 0};
+    if (g < f.n) {
+        u32 e[2];
+        fmts_route(f, g, e);
+        u32 u1, u2;
+        const u32 ul = (e[0] != FMTS_NONE) ? fmts_umi(f, g, u1, u2) : 0u;
+        for (int k = 0; k < 2; k++) {
+            if (e[k] == FMTS_NONE) continue;
+            FmtsRec r;
+            fmts_rec(f, g, e[k], ul, r);
+            const int st = (int)(e[k] & 7u);
+#pragma unroll
+            for (int q = 0; q < FMTS_STREAMS; q++) bytes[q] += q == st ? r.bytes : 0u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < FMTS_STREAMS; q++) {
+        u32 b = bytes[q];
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) b += shfl_xor(b, sh);
+        if (lane_id() == 0 && b) lds_add_u32(&lds[q], b);
+    }
+    block_sync();
+    if (thread_id() < FMTS_STREAMS) f.blocksum[(size_t)thread_id() * f.nblocks + block_id()] = lds[thread_id()];
+}
+
+FQ_DEV void fmts_scan_body(const FmtsArgs& f, u64* lds) {
+    // one workgroup per stream (block_id = stream): lanes sum runs of blocks, scan through LDS
+    const int q = block_id();
+    const int tid = thread_id(), nt = block_threads();
+    const int per = (f.nblocks + nt - 1) / nt;
+    const int b0 = imin(tid * per, f.nblocks), b1 = imin(b0 + per, f.nblocks);
+    const u64* sums = f.blocksum + (size_t)q * f.nblocks;
+    u64* base = f.blockbase + (size_t)q * f.nblocks;
+    u64 sum = 0;
+    for (int b = b0; b < b1; b++) sum += sums[b];
+    lds[tid] = sum;
+    block_sync();
+    if (tid == 0) {
+        u64 run = 0;
+        for (int i = 0; i < nt; i++) {
+            const u64 v = lds[i];
+            lds[i] = run;
+            run += v;
+        }
+        f.totals[q] = run;
+    }
+    block_sync();
+    u64 run = lds[tid];
+    for (int b = b0; b < b1; b++) {
+        base[b] = run;
+        run += sums[b];
+    }
+}
+
+// n bytes by a 16-lane group (no terminator)
+FQ_DEV void fmts_put(u8* dst, const u8* src, u32 n, int gl) {
+    for (u32 i = 4u * (u32)gl; i + 4u <= n; i += 64u) {  // global memory takes unaligned dwords
+        u32 w;
+        __builtin_memcpy(&w, src + i, 4);
+        __builtin_memcpy(dst + i, &w, 4);
+    }
+    if (gl == 15)
+        for (u32 i = n & ~3u; i < n; i++) dst[i] = src[i];
+}
+FQ_DEV u8 fmts_complement(u8 c) {  // util.h:16-33: anything outside ACGTacgt -> 'N'
+    switch (c) {
+        case 'A': case 'a': return 'T';
+        case 'T': case 't': return 'A';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        default: return 'N';
+    }
+}
+// " merged_L1_L2" by the group's first lane; returns its length
+FQ_DEV u32 fmts_put_mtag(u8* dst, u32 m1, u32 m2, int gl) {
+    const u32 d1 = fmts_digits(m1), d2 = fmts_digits(m2);
+    if (gl == 0) {
+        const char* pre = " merged_";
+        for (int i = 0; i < 8; i++) dst[i] = (u8)pre[i];
+        u32 v = m1;
+        for (u32 i = 0; i < d1; i++) { dst[8 + d1 - 1 - i] = (u8)('0' + v % 10u); v /= 10u; }
+        dst[8 + d1] = '_';
+        v = m2;
+        for (u32 i = 0; i < d2; i++) { dst[9 + d1 + d2 - 1 - i] = (u8)('0' + v % 10u); v /= 10u; }
+    }
+    return 8u + d1 + 1u + d2;
+}
+
+FQ_DEV void fmts_write_body(const FmtsArgs& f, u32* lds) {
+    // lds: [FMTS_STREAMS][16 waves] wave sums, then per unit [2] u64 offsets of its emissions (block_threads * 2 * 2 dwords)
+    const int tid = thread_id(), nw = block_threads() >> 6, wave = wave_id();
+    const int g0 = block_id() * block_threads();
+    const int g = g0 + tid;
+    u32 e[2] = {FMTS_NONE, FMTS_NONE};
+    u32 sz[2] = {0, 0};
+    u32 ul = 0, u1 = 0, u2 = 0;
+    if (g < f.n) {
+        fmts_route(f, g, e);
+        if (e[0] != FMTS_NONE) ul = fmts_umi(f, g, u1, u2);
+        for (int k = 0; k < 2; k++)
+            if (e[k] != FMTS_NONE) {
+                FmtsRec r;
+                fmts_rec(f, g, e[k], ul, r);
+                sz[k] = r.bytes;
+            }
+    }
+    u64* eoff = (u64*)(lds + FMTS_STREAMS * 16);
+    u64 off[2] = {~0ull, ~0ull};
+    u32 excl[FMTS_STREAMS], mine0[FMTS_STREAMS];
+#pragma unroll
+    for (int q = 0; q < FMTS_STREAMS; q++) {
+        const u32 b0 = (e[0] != FMTS_NONE && (int)(e[0] & 7u) == q) ? sz[0] : 0u;
+        const u32 b1 = (e[1] != FMTS_NONE && (int)(e[1] & 7u) == q) ? sz[1] : 0u;
+        const u32 b = b0 + b1;
+        u32 incl = b;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            const u32 o = shfl(incl, lane_id() - sh);
+            if (lane_id() >= sh) incl += o;
+        }
+        if (lane_id() == 63) lds[q * 16 + wave] = incl;
+        excl[q] = incl - b;
+        mine0[q] = b0;
+    }
+    block_sync();
+#pragma unroll
+    for (int q = 0; q < FMTS_STREAMS; q++) {
+        u64 base = f.blockbase[(size_t)q * f.nblocks + block_id()] + excl[q];
+        for (int w = 0; w < nw; w++)
+            if (w < wave) base += lds[q * 16 + w];
+        if (e[0] != FMTS_NONE && (int)(e[0] & 7u) == q) off[0] = base;
+        if (e[1] != FMTS_NONE && (int)(e[1] & 7u) == q) off[1] = base + mine0[q];
+    }
+    eoff[2 * tid] = off[0];
+    eoff[2 * tid + 1] = off[1];
+    block_sync();
+    // a 16-lane group per (unit, emission slot)
+    const int gl = lane_id() & 15, ngroups = block_threads() >> 4;
+    for (int t = tid >> 4; t < block_threads() * 2; t += ngroups) {
+        const int u = t >> 1, k = t & 1;
+        const int gu = g0 + u;
+        if (gu >= f.n) break;
+        const u64 o64 = eoff[2 * u + k];
+        if (o64 == ~0ull) continue;
+        u32 ee[2];
+        fmts_route(f, gu, ee);
+        const u32 em = ee[k];
+        u32 v1, v2;
+        const u32 uml = fmts_umi(f, gu, v1, v2);
+        FmtsRec r;
+        fmts_rec(f, gu, em, uml, r);
+        const int st = (int)(em & 7u), src = (int)((em >> 3) & 3u), tagkind = (int)((em >> 5) & 7u);
+        if (!f.out[st] || o64 + r.bytes > f.out_cap[st]) continue;  // the host sees the needed size in totals
+        const FmtsMate& M = f.m[r.mt];
+        u8* o = f.out[st] + o64;
+        // ---- name line: name [up to its first space] + UMI tag + rest + merged tag + failed tag ----
+        const u8* name = M.text + M.line_off[4 * (size_t)gu];
+        u32 sp = r.name_len;
+        if (uml) {  // position of the first space (one lane scans: names are short)
+            for (u32 i = 0; i < r.name_len; i++)
+                if (name[i] == ' ') { sp = i; break; }
+        }
+        fmts_put(o, name, sp, gl);
+        o += sp;
+        if (uml) {
+            fmts_put(o, f.delim, f.delim_len, gl);
+            o += f.delim_len;
+            if (f.prefix_len) {
+                fmts_put(o, f.prefix, f.prefix_len, gl);
+                if (gl == 0) o[f.prefix_len] = '_';
+                o += f.prefix_len + 1u;
+            }
+            fmts_put(o, f.m[0].text + f.m[0].line_off[4 * (size_t)gu + 1], v1, gl);
+            o += v1;
+            if (f.umi_loc == 3 && f.paired) {
+                if (gl == 0) o[0] = '_';
+                o += 1;
+            }
+            if (v2) fmts_put(o, f.m[1].text + f.m[1].line_off[4 * (size_t)gu + 1], v2, gl);
+            o += v2;
+        }
+        fmts_put(o, name + sp, r.name_len - sp, gl);
+        o += r.name_len - sp;
+        if (src == 2) o += fmts_put_mtag(o, r.m1, r.m2, gl);
+        if (tagkind) {
+            if (gl == 0) o[0] = ' ';
+            fmts_put(o + 1, (const u8*)fmts_tag_text(tagkind, (em >> 8) & 0xFFu), r.tag_len, gl);
+            o += 1u + r.tag_len;
+        }
+        if (gl == 0) o[0] = 10;
+        o += 1;
+        // ---- sequence, strand, quality ----
+        const u32 front = M.res[(size_t)gu * 3] & 0xFFFFu;
+        const u8* seq = M.text + M.line_off[4 * (size_t)gu + 1] + front;
+        const u8* qual = M.text + M.line_off[4 * (size_t)gu + 3] + front;
+        const u8 *seq2 = nullptr, *qual2 = nullptr;
+        u32 t2l = 0;
+        if (src == 2) {  // merged: r1'[0, m1) then rc(r2')[ol + k] = comp(r2'[len2 - 1 - ol - k]), k < m2
+            const FmtsMate& M2 = f.m[1];
+            const u32 w2 = M2.res[(size_t)gu * 3];
+            t2l = w2 >> 16;
+            seq2 = M2.text + M2.line_off[4 * (size_t)gu + 1] + (w2 & 0xFFFFu);
+            qual2 = M2.text + M2.line_off[4 * (size_t)gu + 3] + (w2 & 0xFFFFu);
+        }
+        const u32 n1 = src == 2 ? r.m1 : r.seq_len;
+        fmts_put(o, seq, n1, gl);
+        if (src == 2)
+            for (u32 i = (u32)gl; i < r.m2; i += 16u) o[n1 + i] = fmts_complement(seq2[t2l - 1u - r.ol - i]);
+        o += r.seq_len;
+        if (gl == 0) o[0] = 10;
+        o += 1;
+        fmts_put(o, M.text + M.line_off[4 * (size_t)gu + 2], r.strand_len, gl);
+        o += r.strand_len;
+        if (r.strand_tagged) o += fmts_put_mtag(o, r.m1, r.m2, gl);
+        if (gl == 0) o[0] = 10;
+        o += 1;
+        fmts_put(o, qual, n1, gl);
+        if (src == 2)
+            for (u32 i = (u32)gl; i < r.m2; i += 16u) o[n1 + i] = qual2[t2l - 1u - r.ol - i];
+        o += r.seq_len;
+        if (gl == 0) o[0] = 10;
+    }
+}
+
 }  // namespace fq

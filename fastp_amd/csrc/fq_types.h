@@ -265,6 +265,34 @@ struct FmtArgs {
     int corr_first;      // unit index the correction list's `read` field is relative to
 };
 
+// ---- every output stream on the device (fq_fmts_* kernels, fastp_gpu_format_streams) ----
+enum { FMTS_STREAMS = 6 };
+constexpr u32 FMTS_NONE = 0xFFFFFFFFu;
+struct FmtsMate {
+    u8* text;                // corrections are patched in
+    const u32* line_off;
+    const u32* line_len;
+    const u32* res;          // 3 dwords per record
+};
+struct FmtsArgs {
+    int n, paired, dedup, merge, merge_include_unmerged;
+    int want_failed, want_u1, want_u2;
+    int umi_loc, umi_len;
+    u32 delim_len, prefix_len;
+    u8 delim[8], prefix[32];
+    FmtsMate m[2];
+    const u32* pair;         // 2 dwords per pair record
+    u8* out[FMTS_STREAMS];
+    u64 out_cap[FMTS_STREAMS];
+    u64* blocksum;           // [FMTS_STREAMS][nblocks] bytes the block's units add to each stream
+    u64* blockbase;          // [FMTS_STREAMS][nblocks]
+    u64* totals;             // [FMTS_STREAMS]
+    int nblocks;
+    const u32* corrections;  // fastp_gpu_correction, 2 dwords each
+    const int* n_corrections;
+    int corr_first;
+};
+
 struct KernelArgs {
     DevParams p;
     DevLuts lut;

@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
@@ -286,6 +286,24 @@ class GpuEngine:
         if check:
             self._check(rc)
         return rc, int(lens[0]), int(lens[1])
+
+    def format_streams(self, n, m1: abi.FormatIn, m2, pair_ptr, corrections_ptr, n_corrections_ptr,
+                       opts: abi.FormatOptions | None, out_ptrs, out_caps, check=True):
+        """every output stream of the worker loop on the device (out1, out2, failed, merged, unpaired1, unpaired2);
+        corrections are patched into the mates' text.  Returns (rc, [needed bytes per stream])"""
+        fn = self.lib.fastp_gpu_format_streams
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(abi.FormatIn), C.POINTER(abi.FormatIn), C.c_void_p, C.c_void_p,
+                       C.c_void_p, C.POINTER(abi.FormatOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                       C.POINTER(C.c_int64)]
+        outs = (C.c_void_p * abi.N_OUTPUTS)(*[p or None for p in out_ptrs])
+        caps = (C.c_int64 * abi.N_OUTPUTS)(*out_caps)
+        lens = (C.c_int64 * abi.N_OUTPUTS)()
+        rc = fn(self.h, n, C.byref(m1), C.byref(m2) if m2 is not None else None, pair_ptr, corrections_ptr,
+                n_corrections_ptr, C.byref(opts) if opts is not None else None, outs, caps, lens)
+        if check:
+            self._check(rc)
+        return rc, [int(x) for x in lens]
 
     def synchronize(self):
         self._check(self.lib.fastp_gpu_synchronize(self.h))

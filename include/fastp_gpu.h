@@ -381,9 +381,9 @@ int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, int32_t n_bl
  * for every unit the worker loop routes to out1 [and out2] (peprocessor.cpp:577-591,
  * seprocessor.cpp:280-286): name line, seq[front, front+len), strand line, qual[front, front+len),
  * each followed by '\n', in input order, BaseCorrector edits applied.  Inputs are what
- * fastp_gpu_parse_fastq and fastp_gpu_submit_device left on the device.  failed_out / unpaired /
- * merged streams and name edits (UMI, fixMGI) stay with the host: merge mode and umi_len* > 0 are
- * refused (FASTP_GPU_E_UNSUPPORTED).  FASTP_GPU_E_OVERFLOW when an output buffer is too small
+ * fastp_gpu_parse_fastq and fastp_gpu_submit_device left on the device.  This entry point writes
+ * the two main streams only and refuses merge mode and umi_len* > 0 (FASTP_GPU_E_UNSUPPORTED):
+ * fastp_gpu_format_streams below writes every stream, name edits included.  FASTP_GPU_E_OVERFLOW when an output buffer is too small
  * (out_len still reports the needed sizes).  All pointers except out_len are DEVICE pointers. */
 typedef struct fastp_gpu_format_in {
     const uint8_t* text;            /* the FASTQ chunk the records were parsed from      */
@@ -397,6 +397,48 @@ int fastp_gpu_format_fastq(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_format
                            const fastp_gpu_correction* corrections, const int32_t* n_corrections /* may be NULL */,
                            uint8_t* out1, int64_t out1_capacity, uint8_t* out2, int64_t out2_capacity,
                            int64_t out_len[2] /* host: bytes written (needed) per stream */);
+
+/* The same for EVERY output stream of the worker loop (src/peprocessor.cpp:518-621, src/seprocessor.cpp:280-290):
+ * out1 / out2, --failed_out (Read::appendToStringWithTag src/read.cpp:136-154 with the FAILED_TYPES tag,
+ * src/common.h:57-66), --unpaired1 / --unpaired2, the merged stream (OverlapAnalysis::merge's string assembly
+ * src/overlapanalysis.cpp:148-179: r1 part + reverse complement of the r2 part, " merged_L1_L2" appended to the
+ * name, and to the strand line unless that is "+") and the UMI name edit (UmiProcessor::addUmiToName
+ * src/umiprocessor.cpp:62-81).  Routing decisions all come from the result records.  BaseCorrector's edits are
+ * patched INTO `text` first (the reference edits its reads in place, so every stream prints the corrected bases):
+ * `text` is therefore written to.  Streams the options do not ask for get no bytes (their buffers may be NULL).
+ * Output order inside a stream = input order.  FASTP_GPU_E_OVERFLOW + needed sizes in out_len when a buffer is
+ * too small.  All pointers except opts / out / out_capacity / out_len themselves are DEVICE pointers. */
+enum { FASTP_GPU_OUT1 = 0, FASTP_GPU_OUT2 = 1, FASTP_GPU_FAILED = 2, FASTP_GPU_MERGED = 3,
+       FASTP_GPU_UNPAIRED1 = 4, FASTP_GPU_UNPAIRED2 = 5, FASTP_GPU_N_OUTPUTS = 6 };
+#define FASTP_GPU_UMI_NONE 0
+#define FASTP_GPU_UMI_READ1 1     /* UMI_LOC_READ1    */
+#define FASTP_GPU_UMI_READ2 2     /* UMI_LOC_READ2    */
+#define FASTP_GPU_UMI_PER_READ 3  /* UMI_LOC_PER_READ */
+
+typedef struct fastp_gpu_format_options {
+    int32_t want_failed;      /* --failed_out given   */
+    int32_t want_unpaired1;   /* --unpaired1 given    */
+    int32_t want_unpaired2;   /* --unpaired2 given (and different from --unpaired1) */
+    int32_t umi_loc;          /* FASTP_GPU_UMI_*      */
+    int32_t umi_len;
+    const char* umi_prefix;   /* host string, may be NULL, at most 32 characters */
+    const char* umi_delimiter;/* host string, NULL = ":", at most 8 characters   */
+} fastp_gpu_format_options;
+
+typedef struct fastp_gpu_format_io {
+    uint8_t* text;                  /* the FASTQ chunk the records were parsed from (corrections are patched in) */
+    const uint32_t* line_off;       /* [4n] from fastp_gpu_parse_fastq                    */
+    const uint32_t* line_len;       /* [4n]                                               */
+    const fastp_gpu_read_result* res; /* [n] this mate's result records                   */
+} fastp_gpu_format_io;
+
+int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_format_io* mate1,
+                             const fastp_gpu_format_io* mate2 /* NULL for single-end */,
+                             const fastp_gpu_pair_result* pair /* [n] paired; NULL for single-end */,
+                             const fastp_gpu_correction* corrections, const int32_t* n_corrections /* may be NULL */,
+                             const fastp_gpu_format_options* opts /* NULL = main streams only */,
+                             uint8_t* const out[FASTP_GPU_N_OUTPUTS], const int64_t out_capacity[FASTP_GPU_N_OUTPUTS],
+                             int64_t out_len[FASTP_GPU_N_OUTPUTS] /* host: bytes written (needed) per stream */);
 
 /* Process one batch whose buffers (and result buffers) live in HOST memory:
  * H2D copy, kernels, D2H copy, synchronous. */

@@ -27,10 +27,7 @@ typedef struct fastp_gpu_reads {
     const char* const* strand; const int32_t* strand_len;
 } fastp_gpu_reads;
 
-#define FASTP_GPU_UMI_NONE 0
-#define FASTP_GPU_UMI_READ1 1     /* UMI_LOC_READ1    */
-#define FASTP_GPU_UMI_READ2 2     /* UMI_LOC_READ2    */
-#define FASTP_GPU_UMI_PER_READ 3  /* UMI_LOC_PER_READ */
+/* FASTP_GPU_UMI_* and the FASTP_GPU_OUT1 .. FASTP_GPU_N_OUTPUTS stream indices are declared in fastp_gpu.h */
 
 typedef struct fastp_gpu_host_options {
     int32_t want_failed;      /* --failed_out given   */
@@ -41,9 +38,6 @@ typedef struct fastp_gpu_host_options {
     const char* umi_prefix;   /* may be NULL          */
     const char* umi_delimiter;/* NULL = ":"           */
 } fastp_gpu_host_options;
-
-enum { FASTP_GPU_OUT1 = 0, FASTP_GPU_OUT2 = 1, FASTP_GPU_FAILED = 2, FASTP_GPU_MERGED = 3,
-       FASTP_GPU_UNPAIRED1 = 4, FASTP_GPU_UNPAIRED2 = 5, FASTP_GPU_N_OUTPUTS = 6 };
 
 typedef struct fastp_gpu_host fastp_gpu_host;  /* a worker's output strings + FilterResult's adapter maps */
 

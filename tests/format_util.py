@@ -59,8 +59,8 @@ class TorchMem:
         self.torch.cuda.synchronize(self.dev)
 
 
-def run(eng, mem, params, fq1: bytes, fq2, max_len, out_slack=0, corr_cap=1 << 16):
-    """returns (rc, out1 bytes, out2 bytes | None, (len1, len2)) of the whole text as ONE batch"""
+def _prepare(eng, mem, fq1: bytes, fq2, max_len, corr_cap=1 << 16):
+    """text -> parse -> submit_device; everything stays in `mem`"""
     paired = fq2 is not None
     ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
     mates = []
@@ -94,6 +94,13 @@ def run(eng, mem, params, fq1: bytes, fq2, max_len, out_slack=0, corr_cap=1 << 1
     mem.sync()
     eng.submit_device(b, r)
     eng.synchronize()
+    return dict(n=n, mates=mates, res=res, pair=pr, corr=corr, nc=nc, paired=paired)
+
+
+def run(eng, mem, params, fq1: bytes, fq2, max_len, out_slack=0, corr_cap=1 << 16):
+    """returns (rc, out1 bytes, out2 bytes | None, (len1, len2)) of the whole text as ONE batch"""
+    c = _prepare(eng, mem, fq1, fq2, max_len, corr_cap)
+    n, mates, res, corr, nc, paired = c["n"], c["mates"], c["res"], c["corr"], c["nc"], c["paired"]
     fin = []
     for m in range(2 if paired else 1):
         f = abi.FormatIn()
@@ -108,3 +115,42 @@ def run(eng, mem, params, fq1: bytes, fq2, max_len, out_slack=0, corr_cap=1 << 1
     o1 = mem.download(outs[0], min(l1, caps[0]))
     o2 = mem.download(outs[1], min(l2, caps[1])) if paired else None
     return rc, o1, o2, (l1, l2)
+
+
+STREAMS = ("out1", "out2", "failed", "merged", "unpaired1", "unpaired2")
+
+
+def run_streams(eng, mem, params, fq1: bytes, fq2, max_len, want_failed=True, want_unpaired=False, umi=None,
+                shrink=None):
+    """every output stream through fastp_gpu_format_streams; umi = (loc, len[, prefix, delimiter]) or None.
+    returns (rc, {stream: bytes}, [needed lengths]); shrink = stream index whose buffer is made too small"""
+    c = _prepare(eng, mem, fq1, fq2, max_len)
+    n, mates, res, paired = c["n"], c["mates"], c["res"], c["paired"]
+    ios = []
+    for m in range(2 if paired else 1):
+        f = abi.FormatIn()
+        f.text, f.line_off, f.line_len, f.res = (mem.ptr(mates[m]["text"]), mem.ptr(mates[m]["loff"]),
+                                                 mem.ptr(mates[m]["llen"]), mem.ptr(res[m]))
+        ios.append(f)
+    o = abi.FormatOptions()
+    o.want_failed, o.want_unpaired1, o.want_unpaired2 = int(want_failed), int(want_unpaired), int(want_unpaired)
+    if umi is not None:
+        o.umi_loc = {"read1": 1, "read2": 2, "per_read": 3}[umi[0]]
+        o.umi_len = umi[1]
+        o.umi_prefix = umi[2] if len(umi) > 2 and umi[2] else None
+        o.umi_delimiter = umi[3] if len(umi) > 3 else None
+    total = sum(m["nbytes"] for m in mates)
+    # worst case of one stream: every record of both mates, each with a UMI tag, a merged tag and a failed tag
+    cap = total + n * 2 * 160 + 64
+    caps = [cap] * 6
+    if shrink is not None:
+        caps[shrink] = 100
+    outs = [mem.alloc(max(16, k), 0xEE) for k in caps]
+    mem.sync()
+    rc, lens = eng.format_streams(n, ios[0], ios[1] if paired else None, mem.ptr(c["pair"]) if paired else None,
+                                  mem.ptr(c["corr"]), mem.ptr(c["nc"]), o, [mem.ptr(x) for x in outs], caps, check=False)
+    got = {k: mem.download(outs[i], min(lens[i], caps[i])) for i, k in enumerate(STREAMS)}
+    for i in range(6):  # nothing past the reported length
+        tail = mem.download(outs[i])[min(lens[i], caps[i]):]
+        assert tail.count(b"\xEE") == len(tail), f"stream {STREAMS[i]}: bytes written past its length"
+    return rc, got, lens

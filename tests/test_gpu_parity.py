@@ -595,6 +595,36 @@ def test_gpu_device_fastq_format_equals_host_writer(name):
     assert len(want.out1) > 0
 
 
+@pytest.mark.parametrize("name,want_failed,want_unpaired", [
+    ("pe_filters", True, True), ("pe_filters", True, False), ("pe_merge", True, False), ("pe_merge_unmerged", True, False),
+    ("pe_umi_per_read", True, True), ("se_umi_read1", True, False), ("pe_correction", True, True),
+    ("pe_noadapter_dedup", True, True), ("se_polyx_complexity", True, False)])
+def test_gpu_device_all_streams_equal_host_writer(name, want_failed, want_unpaired):
+    """fastp_gpu_format_streams: out1/out2/failed/merged/unpaired text assembled in HBM == the host writer's"""
+    import format_util
+    import test_hostsim_parity as hs
+    got = hs._streams_case(engines.gpu_engine, format_util.TorchMem(), name, 20000, want_failed, want_unpaired)
+    assert sum(len(v) for v in got.values()) > 0
+    if "merge" in name:
+        assert b" merged_" in got["merged"]
+
+
+def test_gpu_device_all_streams_crlf_prefix_overflow():
+    import format_util
+    import test_hostsim_parity as hs
+    got = hs._streams_case(engines.gpu_engine, format_util.TorchMem(), "pe_umi_per_read", 3000, True, False, umi_extra=(b"UMI", b"-"))
+    assert b"-UMI_" in got["out1"]
+    hs._streams_case(engines.gpu_engine, format_util.TorchMem(), "pe_merge", 3000, True, False, eol=b"\r\n")
+    paired, flags, pf, skw = cases.CASES["pe_filters"]
+    d = synth.synth_pairs(2000, L=150, seed=5)
+    p = cases.finalize_params("pe_filters", pf(150), d["seq1"], d["len1"], d["seq2"], d["len2"])
+    g = engines.gpu_engine(p)
+    rc, got, lens = format_util.run_streams(g, format_util.TorchMem(), p, synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1),
+                                            synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2), 150, shrink=1)
+    assert rc == abi.E_OVERFLOW and lens[1] > 100 and lens[0] == len(got["out1"])
+    g.close()
+
+
 def test_gpu_device_fastq_format_crlf_and_overflow():
     import format_util
     import test_hostsim_parity as hs

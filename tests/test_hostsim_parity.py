@@ -340,6 +340,70 @@ def test_sim_device_fastq_format_crlf_limits_and_errors():
         g.close()
 
 
+STREAM_CASES = [("pe_filters", True, True), ("pe_filters", True, False), ("pe_filters", False, True), ("pe_merge", True, False),
+                ("pe_merge_unmerged", True, False), ("pe_umi_per_read", True, True), ("se_umi_read1", True, False),
+                ("pe_correction", True, True), ("se_adapter_cut", True, False), ("pe_noadapter_dedup", True, True),
+                ("se_polyx_complexity", True, False), ("pe_default", False, False)]
+
+
+def _streams_case(mk_engine, mem, name, n, want_failed, want_unpaired, umi_extra=(), eol=b"\n", seed=77):
+    """fastp_gpu_format_streams' six streams == hostloop.apply_results' (the Python restatement of the worker loop's
+    string side, itself pinned to fastp_ref's files by the golden tests)"""
+    import format_util
+    from fastp_amd import hostloop
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(n, L=150, seed=seed, paired=paired, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
+    umi = cases.UMI.get(name)
+    if umi is not None:
+        umi = tuple(umi) + tuple(umi_extra)
+    editor = hostloop.UmiNameEditor(umi[0], umi[1], *[x for x in umi[2:]]) if umi else None
+    ref = mk_engine(params)
+    want, _, _ = driver.run_engine(ref, params, fq1, fq2, pack=n, stride=abi.qual_stride(150), want_failed=want_failed,
+                                   want_unpaired=want_unpaired, umi=editor)
+    ref.close()
+    g = mk_engine(params)
+    rc, got, lens = format_util.run_streams(g, mem, params, fq1.replace(b"\n", eol), fq2.replace(b"\n", eol) if paired else None,
+                                            150, want_failed, want_unpaired, umi)
+    g.close()
+    assert rc == 0
+    for k in format_util.STREAMS:
+        w = getattr(want, k, None)
+        w = bytes(w) if w is not None else b""
+        assert got[k] == w, f"{name}: stream {k} differs ({len(got[k])} vs {len(w)} bytes)"
+    return got
+
+
+@pytest.mark.parametrize("name,want_failed,want_unpaired", STREAM_CASES)
+def test_sim_device_all_streams_equal_host_writer(name, want_failed, want_unpaired):
+    import format_util
+    got = _streams_case(engines.sim_engine, format_util.NumpyMem(), name, 500, want_failed, want_unpaired)
+    assert sum(len(v) for v in got.values()) > 0
+    if "merge" in name:
+        assert len(got["merged"]) > 0 and b" merged_" in got["merged"]
+    if want_failed and name in ("pe_filters", "se_polyx_complexity"):
+        assert b" failed_" in got["failed"]
+    if want_unpaired and name == "pe_filters":
+        assert len(got["unpaired1"]) > 0 and len(got["unpaired2"]) > 0
+
+
+def test_sim_device_all_streams_umi_prefix_crlf_and_overflow():
+    import format_util
+    got = _streams_case(engines.sim_engine, format_util.NumpyMem(), "pe_umi_per_read", 200, True, False, umi_extra=(b"UMI", b"-"))
+    assert b"-UMI_" in got["out1"]
+    _streams_case(engines.sim_engine, format_util.NumpyMem(), "pe_merge", 200, True, False, eol=b"\r\n")
+    paired, flags, pf, skw = cases.CASES["pe_filters"]
+    d = synth.synth_pairs(200, L=150, seed=5)
+    p = cases.finalize_params("pe_filters", pf(150), d["seq1"], d["len1"], d["seq2"], d["len2"])
+    g = engines.sim_engine(p)
+    rc, got, lens = format_util.run_streams(g, format_util.NumpyMem(), p, synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1),
+                                            synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2), 150, shrink=1)
+    assert rc == abi.E_OVERFLOW and lens[1] > 100 and lens[0] == len(got["out1"])
+    g.close()
+
+
 def _inflate(eng, mem, comp: bytes, check_crc=True, max_blocks=100000, check=True):
     """BGZF bytes -> text through fastp_gpu_bgzf_index (host) + fastp_gpu_inflate_bgzf (device)"""
     host = np.frombuffer(comp, dtype=np.uint8)
