@@ -6,11 +6,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "fq_device.h"
 #include "fq_inflate.h"
+#include "fq_eval.h"
 #include "fq_host.h"
 
 using namespace fq;
@@ -81,6 +83,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmt_write_kernel(FmtArgs f)
     fmt_write_body(f, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_fmt_fix_kernel(FmtArgs f) { fmt_fix_body(f); }
+extern "C" __global__ void __launch_bounds__(256) fq_eval_kmer_kernel(EvalKmerArgs a) { eval_kmer_body(a); }
+extern "C" __global__ void __launch_bounds__(256) fq_eval_census_kernel(EvalCensusArgs a) { eval_census_body(a); }
+extern "C" __global__ void __launch_bounds__(256) fq_eval_harvest_kernel(EvalCensusArgs a) { eval_harvest_body(a); }
+extern "C" __global__ void __launch_bounds__(256) fq_eval_text_kernel(EvalCensusArgs a) { eval_text_body(a); }
 extern "C" __global__ void __launch_bounds__(256) fq_fmts_corr_kernel(FmtsArgs f) { fmts_corr_body(f); }
 extern "C" __global__ void __launch_bounds__(256) fq_fmts_len_kernel(FmtsArgs f) {
     extern __shared__ u32 fq_lds[];
@@ -146,6 +152,7 @@ struct fastp_gpu_ctx {
     int* d_ovr_len[2] = {nullptr, nullptr};
     u64* d_post_seen = nullptr;
     u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
+    u8* d_eval = nullptr; size_t eval_cap = 0;            // Evaluator pre-pass: census table | hot list | text
     u32* d_ovr_corr = nullptr; size_t ovr_corr_cap = 0;   // correction chains: head[reads] | next[capacity]
     u32* d_parse = nullptr; size_t parse_cap = 0;         // FASTQ parse scratch
     u64* d_fmt = nullptr; size_t fmt_cap = 0;             // FASTQ format scratch
@@ -215,7 +222,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1120,6 +1127,169 @@ extern "C" int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fas
         if (totals[q] > f.out_cap[q]) overflow = true;
     }
     if (overflow) return fail(ctx, FASTP_GPU_E_OVERFLOW, "output buffer too small (see out_len for the needed sizes)");
+    return FASTP_GPU_OK;
+}
+
+// ---- Evaluator pre-pass (fq_eval.h) ---------------------------------------------------------------------
+// the reads a reference loading loop `while (records < read_limit && bases < base_limit)` admits
+static int eval_admit(fastp_gpu_ctx* ctx, const uint16_t* len, int32_t n, int64_t read_limit, int64_t base_limit,
+                      std::vector<u16>& lens) {
+    const size_t take = (size_t)std::min<int64_t>(n, read_limit);
+    lens.resize(take);
+    if (take) {
+        HIP_TRY(ctx, hipMemcpyAsync(lens.data(), len, take * 2, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    int64_t bases = 0;
+    size_t used = 0;
+    while (used < take && bases < base_limit) bases += lens[used++];
+    lens.resize(used);
+    return 0;
+}
+
+extern "C" int fastp_gpu_eval_seq_len(fastp_gpu_ctx* ctx, const uint16_t* len, int32_t n, int32_t* seq_len) {
+    if (!ctx || !seq_len || n < 0 || (n > 0 && !len)) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<u16> lens;
+    int rc = eval_admit(ctx, len, n, 1000, INT64_MAX, lens);   // evaluator.cpp:63-74
+    if (rc) return rc;
+    int best = 0;
+    for (u16 v : lens) best = std::max(best, (int)v);
+    *seq_len = best;
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_eval_adapter_kmers(fastp_gpu_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint16_t* len,
+                                            int32_t n, int32_t trim_tail1, uint32_t* counts, int64_t* records) {
+    if (!ctx || !counts || n < 0 || (n > 0 && (!seq || !qual || !len))) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t READ_LIMIT = 256 * 1024, BASE_LIMIT = 151 * READ_LIMIT;   // evaluator.cpp:313-314
+    std::vector<u16> lens;
+    int rc = eval_admit(ctx, len, n, READ_LIMIT, BASE_LIMIT, lens);
+    if (rc) return rc;
+    if (records) *records = (int64_t)lens.size();
+    HIP_TRY(ctx, hipMemsetAsync(counts, 0, sizeof(u32) << 20, st));
+    EvalKmerArgs a;
+    memset(&a, 0, sizeof(a));
+    a.r.seq = seq;
+    a.r.qual = qual;
+    a.r.len = len;
+    a.r.n = (int)lens.size();
+    a.r.seq_stride = (int)fastp_gpu_seq_stride(ctx->dp.max_len);
+    a.r.qual_stride = (int)fastp_gpu_qual_stride(ctx->dp.max_len);
+    a.shift_tail = std::max(1, trim_tail1);
+    a.span = std::max(1, ctx->dp.max_len - 29);   // positions 20 .. len - 10 - shift_tail
+    a.counts = counts;
+    const long long lanes = (long long)a.r.n * a.span;
+    if (lanes > 0) {
+        hipLaunchKernelGGL(fq_eval_kmer_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_eval_overrep(fastp_gpu_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint16_t* len, int32_t n,
+                                      int32_t seq_len, char* text, int64_t text_capacity, int64_t* off, int64_t* count,
+                                      int32_t max_seqs, int32_t* n_seqs) {
+    if (!ctx || !n_seqs || !off || n < 0 || max_seqs < 0 || text_capacity < 0 || (n > 0 && (!seq || !qual || !len)) ||
+        (max_seqs > 0 && (!text || !count)))
+        return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    *n_seqs = 0;
+    off[0] = 0;
+    if (seq_len < 1) return fail(ctx, FASTP_GPU_E_INVALID, "seq_len (Evaluator::computeSeqLen) must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t BASE_LIMIT = 151 * 10000;   // evaluator.cpp:83
+    std::vector<u16> lens;
+    int rc = eval_admit(ctx, len, n, (int64_t)(1 << 24) - 2, BASE_LIMIT, lens);
+    if (rc) return rc;
+    EvalCensusArgs a;
+    memset(&a, 0, sizeof(a));
+    a.r.seq = seq;
+    a.r.qual = qual;
+    a.r.len = len;
+    a.r.n = (int)lens.size();
+    a.r.seq_stride = (int)fastp_gpu_seq_stride(ctx->dp.max_len);
+    a.r.qual_stride = (int)fastp_gpu_qual_stride(ctx->dp.max_len);
+    const int steps[EVAL_STEPS] = {10, 20, 40, 100, std::min(150, seq_len - 2)};   // :97
+    int min_step = 1 << 30;
+    for (int i = 0; i < EVAL_STEPS; i++) {
+        a.step[i] = steps[i];
+        if (steps[i] > 0) min_step = std::min(min_step, steps[i]);
+    }
+    a.span = std::max(1, ctx->dp.max_len - min_step);
+    a.seqlen = seq_len;
+    uint64_t items = 0;
+    for (u16 l : lens)
+        for (int i = 0; i < EVAL_STEPS; i++)
+            if (steps[i] > 0 && (int)l > steps[i]) items += (uint64_t)((int)l - steps[i]);
+    if (items == 0) return FASTP_GPU_OK;
+    uint64_t cap = 1024;
+    while (cap < 2 * items) cap <<= 1;
+    if (cap > (1ull << 31)) return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "substring census larger than 2^30 items");
+    // a substring over its threshold occurs >= 3 times
+    a.hot_cap = (u32)std::min<uint64_t>(items / 3 + 16, 1u << 22);
+    const size_t b_slot = cap * 8, b_count = cap * 4, b_hot = (size_t)a.hot_cap * 8, b_hc = (size_t)a.hot_cap * 4,
+                 b_text = (size_t)a.hot_cap * 152;
+    rc = ensure(ctx, (void**)&ctx->d_eval, &ctx->eval_cap, b_slot + b_count + b_hot + b_hc + 16 + b_text);
+    if (rc) return rc;
+    u8* base = ctx->d_eval;
+    a.slot = (u64*)base;
+    a.count = (u32*)(base + b_slot);
+    a.hot = (u64*)(base + b_slot + b_count);
+    a.hot_count = (u32*)(base + b_slot + b_count + b_hot);
+    a.n_hot = (u32*)(base + b_slot + b_count + b_hot + b_hc);
+    a.text = base + b_slot + b_count + b_hot + b_hc + 16;
+    a.mask = (u32)(cap - 1);
+    HIP_TRY(ctx, hipMemsetAsync(base, 0, b_slot + b_count, st));
+    HIP_TRY(ctx, hipMemsetAsync(a.n_hot, 0, 16, st));
+    const long long lanes = (long long)a.r.n * a.span;
+    hipLaunchKernelGGL(fq_eval_census_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fq_eval_harvest_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, a);
+    HIP_TRY(ctx, hipGetLastError());
+    u32 n_hot = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_hot, a.n_hot, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_hot > a.hot_cap) return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "more than 4 Mi overrepresented substrings");
+    std::map<std::string, long> hot;   // Options::overRepSeqs (evaluator.cpp:112-137)
+    if (n_hot) {
+        hipLaunchKernelGGL(fq_eval_text_kernel, dim3((unsigned)(((size_t)n_hot * 16 + 255) / 256)), dim3(256), 0, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        std::vector<u64> hw(n_hot);
+        std::vector<u32> hc(n_hot);
+        std::vector<u8> ht((size_t)n_hot * 152);
+        HIP_TRY(ctx, hipMemcpyAsync(hw.data(), a.hot, (size_t)n_hot * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hc.data(), a.hot_count, (size_t)n_hot * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ht.data(), a.text, ht.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        for (u32 k = 0; k < n_hot; k++)
+            hot[std::string((const char*)&ht[(size_t)k * 152], (size_t)steps[(hw[k] >> 21) & 7u])] = (long)hc[k];
+    }
+    // "remove substrings" (evaluator.cpp:139-160), erasing while iterating as the reference does
+    for (auto it = hot.begin(); it != hot.end();) {
+        bool is_sub = false;
+        for (auto it2 = hot.begin(); it2 != hot.end(); ++it2)
+            if (it->first != it2->first && it2->first.find(it->first) != std::string::npos && it->second / it2->second < 10) {
+                is_sub = true;
+                break;
+            }
+        if (is_sub) it = hot.erase(it);
+        else ++it;
+    }
+    *n_seqs = (int32_t)hot.size();
+    if ((int64_t)hot.size() > max_seqs) return fail(ctx, FASTP_GPU_E_OVERFLOW, "more sequences than max_seqs");
+    int64_t at = 0;
+    int32_t i = 0;
+    for (const auto& kv : hot) {
+        if (at + (int64_t)kv.first.size() > text_capacity) return fail(ctx, FASTP_GPU_E_OVERFLOW, "text buffer too small");
+        memcpy(text + at, kv.first.data(), kv.first.size());
+        at += (int64_t)kv.first.size();
+        count[i] = kv.second;
+        off[++i] = at;
+    }
     return FASTP_GPU_OK;
 }
 

@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
@@ -304,6 +304,43 @@ class GpuEngine:
         if check:
             self._check(rc)
         return rc, [int(x) for x in lens]
+
+    # ---- the Evaluator pre-pass on the device (csrc/fq_eval.h); device pointers of one mate's packed rows ----
+    def eval_seq_len(self, len_ptr, n):
+        fn = self.lib.fastp_gpu_eval_seq_len
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        out = C.c_int32(0)
+        self._check(fn(self.h, len_ptr, n, C.byref(out)))
+        return int(out.value)
+
+    def eval_adapter_kmers(self, seq_ptr, qual_ptr, len_ptr, n, trim_tail1, counts_ptr):
+        """4^10 ten-mer histogram into DEVICE uint32[1 << 20] at counts_ptr; returns the records used"""
+        fn = self.lib.fastp_gpu_eval_adapter_kmers
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                       C.POINTER(C.c_int64)]
+        rec = C.c_int64(0)
+        self._check(fn(self.h, seq_ptr, qual_ptr, len_ptr, n, trim_tail1, counts_ptr, C.byref(rec)))
+        return int(rec.value)
+
+    def eval_overrep(self, seq_ptr, qual_ptr, len_ptr, n, seq_len, max_seqs=1 << 16, text_capacity=1 << 22, check=True):
+        """Evaluator::computeOverRepSeq: returns (rc, [(sequence bytes, count)] in std::map order)"""
+        fn = self.lib.fastp_gpu_eval_overrep
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
+                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32, C.POINTER(C.c_int32)]
+        text = C.create_string_buffer(max(1, text_capacity))
+        off = (C.c_int64 * (max_seqs + 1))()
+        cnt = (C.c_int64 * max(1, max_seqs))()
+        ns = C.c_int32(0)
+        rc = fn(self.h, seq_ptr, qual_ptr, len_ptr, n, seq_len, text, text_capacity, off, cnt, max_seqs, C.byref(ns))
+        if check:
+            self._check(rc)
+        if rc != 0:
+            return rc, int(ns.value)
+        raw = text.raw
+        return rc, [(raw[off[i]:off[i + 1]], int(cnt[i])) for i in range(ns.value)]
 
     def synchronize(self):
         self._check(self.lib.fastp_gpu_synchronize(self.h))

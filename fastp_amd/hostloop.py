@@ -309,61 +309,3 @@ def apply_results(params: abi.Params, b1: FastqBatch, b2: FastqBatch | None, r1,
             elif outputs.failed is not None:
                 outputs.failed += _record(b1.names[i], t1s, b1.strands[i], t1q, FAILED_TYPES[code1])
                 outputs.failed += _record(b2.names[i], t2s, b2.strands[i], t2q, "paired_read_is_failing")
-
-
-# ---------------------------------------------------------------------------------------------
-# Evaluator pre-pass pieces (HOST logic in the reference, src/evaluator.cpp): what a fastp run
-# feeds into the overrepresentation analysis.  The engine only consumes their results.
-# ---------------------------------------------------------------------------------------------
-def evaluate_seq_len(b: FastqBatch) -> int:  # Evaluator::computeSeqLen evaluator.cpp:54-76
-    n = min(b.n, 1000)
-    return int(b.lens[:n].max()) if n else 0
-
-
-def evaluate_overrep_seqs(b: FastqBatch, seqlen: int) -> list[bytes]:
-    """Evaluator::computeOverRepSeq (evaluator.cpp:78-169): hot substrings of the first ~1.5 Mbases,
-    minus those that are substrings of a hotter/longer one; returned in std::map (sorted) order"""
-    BASE_LIMIT = 151 * 10000
-    counts: dict[bytes, int] = {}
-    bases = 0
-    i = 0
-    steps = [10, 20, 40, 100, min(150, seqlen - 2)]
-    while bases < BASE_LIMIT and i < b.n:
-        rlen = int(b.lens[i])
-        seq = b.seq[i, :rlen].tobytes()
-        bases += rlen
-        for step in steps:
-            if step <= 0:
-                continue
-            for k in range(0, rlen - step):
-                sub = seq[k:k + step]
-                counts[sub] = counts.get(sub, 0) + 1
-        i += 1
-    hot: dict[bytes, int] = {}
-    for seq, c in counts.items():
-        L = len(seq)
-        if L >= seqlen - 1:
-            ok = c >= 3
-        elif L >= 100:
-            ok = c >= 5
-        elif L >= 40:
-            ok = c >= 20
-        elif L >= 20:
-            ok = c >= 100
-        elif L >= 10:
-            ok = c >= 500
-        else:
-            ok = False
-        if ok:
-            hot[seq] = c
-    keys = sorted(hot)
-    removed = set()
-    for seq in keys:  # :140-160: erase while iterating; later comparisons see the shrunken map
-        c = hot[seq]
-        for seq2 in keys:
-            if seq2 in removed or seq2 == seq:
-                continue
-            if seq in seq2 and c // hot[seq2] < 10:
-                removed.add(seq)
-                break
-    return [k for k in keys if k not in removed]

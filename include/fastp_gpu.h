@@ -440,6 +440,34 @@ int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_form
                              uint8_t* const out[FASTP_GPU_N_OUTPUTS], const int64_t out_capacity[FASTP_GPU_N_OUTPUTS],
                              int64_t out_len[FASTP_GPU_N_OUTPUTS] /* host: bytes written (needed) per stream */);
 
+/* ---- the Evaluator pre-pass ON THE DEVICE ------------------------------
+ * The loops of src/evaluator.cpp that scan a prefix of the input before the workers start, run on packed
+ * rows already in HBM (DEVICE pointers seq / qual / len as in fastp_gpu_batch, one mate at a time; n reads
+ * are available - the reference's own read / base limits are applied inside).  What the reference does with
+ * the numbers afterwards (top-10 seeds, NucleotideTree walks, known-adapter names) stays in its Evaluator.
+ *
+ * fastp_gpu_eval_seq_len: Evaluator::computeSeqLen (evaluator.cpp:54-76) - the longest of the first 1000 reads.
+ *
+ * fastp_gpu_eval_adapter_kmers: the 4^10 ten-mer histogram of Evaluator::evalAdapterAndReadNum
+ * (evaluator.cpp:377-402) over the reads its loading loop admits (:326-341: at most 256 Ki reads and while
+ * fewer than 151 * 256 Ki bases were loaded): positions 20 .. len - 10 - max(1, trim_tail1), keys by
+ * Evaluator::seq2int (A=0 T=1 C=2 G=3, first base most significant), windows with an N skipped,
+ * counts[0] ("AAAAAAAAAA") = 0.  counts: DEVICE uint32[1 << 20], overwritten.  *records (HOST) = reads used;
+ * the reference does not evaluate below 10000 of them (:357), the caller applies that.
+ *
+ * fastp_gpu_eval_overrep: Evaluator::computeOverRepSeq (evaluator.cpp:78-169) - every substring of lengths
+ * 10, 20, 40, 100 and min(150, seq_len - 2) of the reads read while fewer than 151 * 10000 bases were seen,
+ * counted exactly, kept when over the threshold of its length class (:115-137), minus the ones contained in a
+ * kept longer one with count / count2 < 10 (:140-160).  Result in HOST memory in std::map order (byte order
+ * of the text): sequence i is text[off[i], off[i+1]), count[i] its occurrences.  FASTP_GPU_E_OVERFLOW when
+ * max_seqs or text_capacity is too small (*n_seqs = the number found). */
+int fastp_gpu_eval_seq_len(fastp_gpu_ctx* ctx, const uint16_t* len, int32_t n, int32_t* seq_len);
+int fastp_gpu_eval_adapter_kmers(fastp_gpu_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint16_t* len,
+                                 int32_t n, int32_t trim_tail1, uint32_t* counts, int64_t* records);
+int fastp_gpu_eval_overrep(fastp_gpu_ctx* ctx, const uint8_t* seq, const uint8_t* qual, const uint16_t* len, int32_t n,
+                           int32_t seq_len, char* text, int64_t text_capacity, int64_t* off /* [max_seqs + 1] */,
+                           int64_t* count /* [max_seqs] */, int32_t max_seqs, int32_t* n_seqs);
+
 /* Process one batch whose buffers (and result buffers) live in HOST memory:
  * H2D copy, kernels, D2H copy, synchronous. */
 int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* batch, fastp_gpu_results* res);

@@ -1,6 +1,8 @@
 """Parity cases: the CLI flags given to the reference binary and the equivalent
 engine parameter block (main.cpp:176-427 + options.cpp:85-446 derivations)."""
 from fastp_amd import abi
+import evalport
+
 
 ADAPTER_R1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
 ADAPTER_R2 = "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
@@ -111,7 +113,7 @@ CASES["pe_adapter_fasta"] = (True, ["-G", "--adapter_fasta", "@TMP@/adapters.fa"
 CASES["se_adapter_fasta"] = (False, ["-G", "-a", ADAPTER_R1, "--adapter_fasta", "@TMP@/adapters.fa"],
                              _with_fasta(_se(adapter_seq_r1=ADAPTER_R1.encode())), {"insert_mean": 120.0, "polyx_frac": 0.3})
 # overrepresentation analysis (-p, -P sampling): the seeds come from the Evaluator pre-pass over the
-# input itself (host logic, fastp_amd.hostloop.evaluate_*), so the parameter block is completed
+# input itself (host logic, tests/evalport.py), so the parameter block is completed
 # by finalize_params() once the input is known
 CASES["pe_overrep"] = (True, ["-G", "-p", "-P", "3"], _pe(), {"insert_mean": 90.0, "insert_sd": 30.0, "polyx_frac": 0.3})
 CASES["se_overrep"] = (False, ["-G", "-A", "-p", "-P", "2", "--cut_right"], _se(adapter_enabled=0, cut_right=1),
@@ -141,13 +143,13 @@ def finalize_params(name, p, seq1, len1, seq2=None, len2=None):
         return p
     from fastp_amd import hostloop
     b1 = _ArrayBatch(seq1, len1)
-    e1 = hostloop.evaluate_seq_len(b1)
-    s1 = hostloop.evaluate_overrep_seqs(b1, e1)
+    e1 = evalport.evaluate_seq_len(b1)
+    s1 = evalport.evaluate_overrep_seqs(b1, e1)
     e2, s2 = 0, []
     if seq2 is not None:
         b2 = _ArrayBatch(seq2, len2)
-        e2 = hostloop.evaluate_seq_len(b2)
-        s2 = hostloop.evaluate_overrep_seqs(b2, e2)
+        e2 = evalport.evaluate_seq_len(b2)
+        s2 = evalport.evaluate_overrep_seqs(b2, e2)
     return abi.set_overrep(p, s1, s2, e1, e2, OVERREP[name])
 
 

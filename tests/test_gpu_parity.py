@@ -9,6 +9,7 @@ import pytest
 import cases
 import driver
 import engines
+import evalport
 import gap_util
 import golden_util
 import oraclelib
@@ -144,8 +145,8 @@ def test_gpu_config5_shape_2x250_dedup_overrep():
     d = synth.synth_pairs(12000, L=L, seed=77, insert_mean=260.0, insert_sd=90.0, insert_min=30, insert_max=900,
                           dup_frac=0.25, polyx_frac=0.2)
     b1, b2 = cases._ArrayBatch(d["seq1"], d["len1"]), cases._ArrayBatch(d["seq2"], d["len2"])
-    e1, e2 = hostloop.evaluate_seq_len(b1), hostloop.evaluate_seq_len(b2)
-    abi.set_overrep(p, hostloop.evaluate_overrep_seqs(b1, e1), hostloop.evaluate_overrep_seqs(b2, e2), e1, e2, 5)
+    e1, e2 = evalport.evaluate_seq_len(b1), evalport.evaluate_seq_len(b2)
+    abi.set_overrep(p, evalport.evaluate_overrep_seqs(b1, e1), evalport.evaluate_overrep_seqs(b2, e2), e1, e2, 5)
     _compare("config5", p, d, True)
 
 
@@ -623,6 +624,16 @@ def test_gpu_device_all_streams_crlf_prefix_overflow():
                                             synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2), 150, shrink=1)
     assert rc == abi.E_OVERFLOW and lens[1] > 100 and lens[0] == len(got["out1"])
     g.close()
+
+
+def test_gpu_evaluator_prepass_equals_port():
+    """the Evaluator's counting loops on the device (fastp_gpu_eval_*) at the reference's own sample sizes: the
+    1.51 Mbase limit of computeOverRepSeq cuts inside the batch; ten-mer histogram over all reads"""
+    import format_util
+    import test_hostsim_parity as hs
+    got, wc = hs._eval_case(engines.gpu_engine, format_util.TorchMem(), 12000, 21)
+    assert len(got) >= 3
+    hs._eval_case(engines.gpu_engine, format_util.TorchMem(), 3000, 22, L=102, trim_tail1=2)
 
 
 def test_gpu_device_fastq_format_crlf_and_overflow():

@@ -7,6 +7,7 @@ import pytest
 import cases
 import driver
 import engines
+import evalport
 import gap_util
 import golden_util
 import oraclelib
@@ -404,6 +405,81 @@ def test_sim_device_all_streams_umi_prefix_crlf_and_overflow():
     g.close()
 
 
+def _eval_rows(mem, eng, fq: bytes, max_len):
+    """text -> fastp_gpu_parse_fastq -> packed rows in `mem` (what the Evaluator entry points read)"""
+    ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
+    cap = fq.count(b"\n") // 4 + 2
+    t = mem.upload(fq, (-len(fq)) % 16 + 16)
+    seq, qual = mem.alloc(cap * ss), mem.alloc(cap * qs)
+    lens, loff, llen = mem.alloc(cap * 2), mem.alloc(cap * 16), mem.alloc(cap * 16)
+    mem.sync()
+    info = eng.parse_fastq(mem.ptr(t), len(fq), True, cap, mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), mem.ptr(loff), mem.ptr(llen))
+    assert info.first_bad == -1
+    return seq, qual, lens, info.n_records
+
+
+def _overrep_reads(n, seed, L=150, n_hot=4, with_n=True):
+    """reads with planted repeats of several lengths (hot substrings of every length class) and some N"""
+    rng = np.random.default_rng(seed)
+    d = synth.synth_pairs(n, L=L, seed=seed, paired=False)
+    seq, lens = d["seq1"].copy(), d["len1"]
+    hot = [rng.integers(0, 4, size=int(k)) for k in (L - 1, 120, 60, 30, 14)[:n_hot + 1]]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(n):
+        r = rng.random()
+        if r < 0.45:
+            h = acgt[hot[int(rng.integers(0, len(hot)))]]
+            if len(h) < lens[i]:
+                at = int(rng.integers(0, lens[i] - len(h) + 1))
+                seq[i, at:at + len(h)] = h
+        if with_n and rng.random() < 0.05:
+            seq[i, int(rng.integers(0, max(1, lens[i])))] = ord("N")
+    return synth.to_fastq(seq, d["qual1"], lens, 1)
+
+
+def _eval_case(mk_engine, mem, n, seed, L=150, trim_tail1=0):
+    from fastp_amd import hostloop
+    fq = _overrep_reads(n, seed, L)
+    p = abi.default_params(False, L)
+    g = mk_engine(p)
+    seq, qual, lens, nrec = _eval_rows(mem, g, fq, L)
+    b = hostloop.parse_fastq(fq, abi.qual_stride(L))
+    # Evaluator::computeSeqLen
+    seqlen = g.eval_seq_len(mem.ptr(lens), nrec)
+    assert seqlen == evalport.evaluate_seq_len(b)
+    # computeOverRepSeq: the same sequences, the same counts, the same (std::map) order
+    rc, got = g.eval_overrep(mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), nrec, seqlen)
+    want = evalport.evaluate_overrep_counts(b, seqlen)
+    assert [s for s, _ in got] == sorted(want), (len(got), len(want))
+    assert dict(got) == want
+    # the ten-mer histogram of evalAdapterAndReadNum
+    counts = mem.alloc(4 << 20, 0x55)
+    mem.sync()
+    rec = g.eval_adapter_kmers(mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), nrec, trim_tail1, mem.ptr(counts))
+    wc, wrec = evalport.adapter_kmer_counts(b, trim_tail1)
+    assert rec == wrec
+    assert np.array_equal(np.frombuffer(mem.download(counts), dtype=np.uint32)[:1 << 20], wc)
+    g.close()
+    return got, wc
+
+
+def test_sim_evaluator_prepass_equals_port():
+    """fastp_gpu_eval_seq_len / eval_overrep / eval_adapter_kmers == the Python restatement of evaluator.cpp"""
+    import format_util
+    got, wc = _eval_case(engines.sim_engine, format_util.NumpyMem(), 1500, 11)
+    assert len(got) >= 3 and {len(s) for s, _ in got} & {148, 100, 40}
+    assert int(wc.sum()) > 100000
+    _eval_case(engines.sim_engine, format_util.NumpyMem(), 400, 12, L=102, trim_tail1=3)   # min(150, seqlen - 2) == 100: that step runs twice
+    # too small a result buffer
+    fq = _overrep_reads(600, 13)
+    g = engines.sim_engine(abi.default_params(False, 150))
+    mem = format_util.NumpyMem()
+    seq, qual, lens, nrec = _eval_rows(mem, g, fq, 150)
+    rc, ns = g.eval_overrep(mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), nrec, 150, max_seqs=1, check=False)
+    assert rc == abi.E_OVERFLOW and ns > 1
+    g.close()
+
+
 def _inflate(eng, mem, comp: bytes, check_crc=True, max_blocks=100000, check=True):
     """BGZF bytes -> text through fastp_gpu_bgzf_index (host) + fastp_gpu_inflate_bgzf (device)"""
     host = np.frombuffer(comp, dtype=np.uint8)
@@ -486,8 +562,8 @@ def test_sim_config5_shape_2x250_dedup_overrep():
     d = synth.synth_pairs(600, L=L, seed=77, insert_mean=260.0, insert_sd=90.0, insert_min=30, insert_max=900,
                           dup_frac=0.25, polyx_frac=0.2)
     b1, b2 = cases._ArrayBatch(d["seq1"], d["len1"]), cases._ArrayBatch(d["seq2"], d["len2"])
-    e1, e2 = hostloop.evaluate_seq_len(b1), hostloop.evaluate_seq_len(b2)
-    abi.set_overrep(p, hostloop.evaluate_overrep_seqs(b1, e1), hostloop.evaluate_overrep_seqs(b2, e2), e1, e2, 5)
+    e1, e2 = evalport.evaluate_seq_len(b1), evalport.evaluate_seq_len(b2)
+    abi.set_overrep(p, evalport.evaluate_overrep_seqs(b1, e1), evalport.evaluate_overrep_seqs(b2, e2), e1, e2, 5)
     ro, rg, co, cg = _both(p, d, True)
     for k in range(3):
         assert np.array_equal(ro[k], rg[k])

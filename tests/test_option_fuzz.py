@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import cases
+import evalport
 import engines
 import oraclelib
 import synth
@@ -75,13 +76,13 @@ def random_case(seed):
                           lowq_site_rate=float(rng.choice([0.01, 0.03, 0.1])))
     if pick(0.3) and not (p.umi_len1 or p.umi_len2):   # overrepresentation analysis with the seeds the pre-pass would find
         b1 = cases._ArrayBatch(d["seq1"], d["len1"])
-        e1 = hostloop.evaluate_seq_len(b1)
-        s1 = hostloop.evaluate_overrep_seqs(b1, e1)
+        e1 = evalport.evaluate_seq_len(b1)
+        s1 = evalport.evaluate_overrep_seqs(b1, e1)
         e2, s2 = 0, []
         if paired:
             b2 = cases._ArrayBatch(d["seq2"], d["len2"])
-            e2 = hostloop.evaluate_seq_len(b2)
-            s2 = hostloop.evaluate_overrep_seqs(b2, e2)
+            e2 = evalport.evaluate_seq_len(b2)
+            s2 = evalport.evaluate_overrep_seqs(b2, e2)
         abi.set_overrep(p, s1, s2, e1, e2, int(rng.choice([1, 2, 7, 20])))
     if pick(0.15) and p.adapter_enabled:
         abi.set_adapter_fasta(p, [b"CTGTCTCTTATACACATCT", b"AGATCGGAAGAGC", b"TGGAATTCTCGGGTGCCAAGG"][:int(rng.integers(1, 4))])

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + '/tests'); sys.path.insert(0
 import numpy as np, torch
 from fastp_amd import abi, engine, hostloop
 import synth_torch, cases
+import evalport
+
 dev = torch.device('cuda', 0)
 
 
@@ -51,6 +53,6 @@ n = 2_000_000
 d = synth_torch.synth_pairs_torch(20000, L=L, seed=5, device="cpu")
 pad = lambda a: np.pad(a.numpy(), ((0, 0), (0, 6)))
 b1 = cases._ArrayBatch(pad(d["seq1"]), d["len1"].numpy()); b2 = cases._ArrayBatch(pad(d["seq2"]), d["len2"].numpy())
-e1, e2 = hostloop.evaluate_seq_len(b1), hostloop.evaluate_seq_len(b2)
-abi.set_overrep(p, hostloop.evaluate_overrep_seqs(b1, e1), hostloop.evaluate_overrep_seqs(b2, e2), e1, e2, 20)
+e1, e2 = evalport.evaluate_seq_len(b1), evalport.evaluate_seq_len(b2)
+abi.set_overrep(p, evalport.evaluate_overrep_seqs(b1, e1), evalport.evaluate_overrep_seqs(b2, e2), e1, e2, 20)
 run(f"configs[4] share: PE 2x250, --dedup, -p ({p.n_overrep_seqs1}+{p.n_overrep_seqs2} seeds)", p, L, n, True)
