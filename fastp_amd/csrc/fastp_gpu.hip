@@ -13,6 +13,7 @@
 #include "fq_device.h"
 #include "fq_inflate.h"
 #include "fq_eval.h"
+#include "fq_deflate.h"
 #include "fq_host.h"
 
 using namespace fq;
@@ -83,6 +84,15 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmt_write_kernel(FmtArgs f)
     fmt_write_body(f, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_fmt_fix_kernel(FmtArgs f) { fmt_fix_body(f); }
+extern "C" __global__ void __launch_bounds__(64) fq_deflate_kernel(DeflateArgs a) {
+    extern __shared__ u32 fq_lds[];
+    deflate_body(a, fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(1024) fq_deflate_scan_kernel(DeflateArgs a) {
+    extern __shared__ u32 fq_lds[];
+    deflate_scan_body(a, (u64*)fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_deflate_gather_kernel(DeflateArgs a) { deflate_gather_body(a); }
 extern "C" __global__ void __launch_bounds__(256) fq_eval_kmer_kernel(EvalKmerArgs a) { eval_kmer_body(a); }
 extern "C" __global__ void __launch_bounds__(256) fq_eval_census_kernel(EvalCensusArgs a) { eval_census_body(a); }
 extern "C" __global__ void __launch_bounds__(256) fq_eval_harvest_kernel(EvalCensusArgs a) { eval_harvest_body(a); }
@@ -152,6 +162,7 @@ struct fastp_gpu_ctx {
     int* d_ovr_len[2] = {nullptr, nullptr};
     u64* d_post_seen = nullptr;
     u32* d_ovr_work = nullptr; size_t ovr_work_cap = 0;   // blocksum | blockbase | n_tasks | tasks
+    u8* d_def = nullptr; size_t def_cap = 0;              // deflate scratch: member slots | tokens | sizes | offsets
     u8* d_eval = nullptr; size_t eval_cap = 0;            // Evaluator pre-pass: census table | hot list | text
     u32* d_ovr_corr = nullptr; size_t ovr_corr_cap = 0;   // correction chains: head[reads] | next[capacity]
     u32* d_parse = nullptr; size_t parse_cap = 0;         // FASTQ parse scratch
@@ -222,7 +233,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1290,6 +1301,61 @@ extern "C" int fastp_gpu_eval_overrep(fastp_gpu_ctx* ctx, const uint8_t* seq, co
         count[i] = kv.second;
         off[++i] = at;
     }
+    return FASTP_GPU_OK;
+}
+
+// ---- output text -> BGZF-framed gzip members (fq_deflate.h) ------------------------------------------------
+extern "C" int fastp_gpu_deflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbytes, int write_eof, uint8_t* out,
+                                      int64_t out_capacity, int64_t* out_len) {
+    if (!ctx || !out_len || nbytes < 0 || out_capacity < 0 || (nbytes > 0 && !text) || (out_capacity > 0 && !out))
+        return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    *out_len = 0;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    static const uint8_t eof_member[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t total_blocks = (nbytes + DEF_BLOCK - 1) / DEF_BLOCK;
+    const int round = (int)std::min<int64_t>(total_blocks, 4096);
+    if (round > 0) {
+        const size_t b_slots = (size_t)round * DEF_SLOT, b_tok = (size_t)round * DEF_BLOCK * 4, b_sizes = (size_t)round * 4 + 8,
+                     b_offs = ((size_t)round + 1) * 8;
+        int rc = ensure(ctx, (void**)&ctx->d_def, &ctx->def_cap, b_slots + b_tok + b_sizes + b_offs);
+        if (rc) return rc;
+    }
+    u64 written = 0;   // bytes needed so far
+    for (int64_t b0 = 0; b0 < total_blocks; b0 += round) {
+        DeflateArgs a;
+        memset(&a, 0, sizeof(a));
+        a.nblocks = (int)std::min<int64_t>(round, total_blocks - b0);
+        a.text = text + (size_t)b0 * DEF_BLOCK;
+        a.nbytes = (u64)std::min<int64_t>(nbytes - b0 * DEF_BLOCK, (int64_t)a.nblocks * DEF_BLOCK);
+        a.slots = ctx->d_def;
+        a.tokens = (u32*)(ctx->d_def + (size_t)round * DEF_SLOT);
+        a.sizes = (u32*)((u8*)a.tokens + (size_t)round * DEF_BLOCK * 4);
+        a.offs = (u64*)((u8*)a.sizes + (size_t)round * 4 + 8);
+        a.out = out;
+        a.out_base = written;
+        a.out_cap = (u64)out_capacity;
+        const int grid = std::min(a.nblocks, ctx->cus * 8);
+        hipLaunchKernelGGL(fq_deflate_kernel, dim3(grid), dim3(64), sizeof(DefLds), st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_deflate_scan_kernel, dim3(1), dim3(1024), 1024 * 8, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_deflate_gather_kernel, dim3(std::min(a.nblocks, ctx->cus * 16)), dim3(256), 0, st, a);
+        HIP_TRY(ctx, hipGetLastError());
+        u64 bytes = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&bytes, a.offs + a.nblocks, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        written += bytes;
+    }
+    if (write_eof) {
+        if (written + sizeof(eof_member) <= (u64)out_capacity) {
+            HIP_TRY(ctx, hipMemcpyAsync(out + written, eof_member, sizeof(eof_member), hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+        written += sizeof(eof_member);
+    }
+    *out_len = (int64_t)written;
+    if (written > (u64)out_capacity) return fail(ctx, FASTP_GPU_E_OVERFLOW, "output buffer too small (see out_len for the needed size)");
     return FASTP_GPU_OK;
 }
 

@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_deflate_bgzf", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
@@ -304,6 +304,17 @@ class GpuEngine:
         if check:
             self._check(rc)
         return rc, [int(x) for x in lens]
+
+    def deflate_bgzf(self, text_ptr, nbytes, out_ptr, out_capacity, write_eof=False, check=True):
+        """device text -> BGZF-framed gzip members on the device; returns (rc, bytes written / needed)"""
+        fn = self.lib.fastp_gpu_deflate_bgzf
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        n = C.c_int64(0)
+        rc = fn(self.h, text_ptr, nbytes, int(write_eof), out_ptr, out_capacity, C.byref(n))
+        if check:
+            self._check(rc)
+        return rc, int(n.value)
 
     # ---- the Evaluator pre-pass on the device (csrc/fq_eval.h); device pointers of one mate's packed rows ----
     def eval_seq_len(self, len_ptr, n):

@@ -440,6 +440,21 @@ int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_form
                              uint8_t* const out[FASTP_GPU_N_OUTPUTS], const int64_t out_capacity[FASTP_GPU_N_OUTPUTS],
                              int64_t out_len[FASTP_GPU_N_OUTPUTS] /* host: bytes written (needed) per stream */);
 
+/* ---- output text -> gzip members ON THE DEVICE (second half) -----------
+ * The reference's .gz outputs: every worker compresses its pack as one independent gzip member
+ * (libdeflate_gzip_compress, src/writer.cpp:110-133) and the members land at ordered offsets
+ * (src/writerthread.cpp:118-168); concatenated members are one valid gzip file (src/common.h:27-30).
+ * Here a stream of text (what fastp_gpu_format_streams wrote) is cut into blocks of 65280 bytes and each
+ * becomes one gzip member with the BGZF extra field (the block's size): any gzip reads the result, and a BGZF
+ * reader - the reference's BgzfMtReader, fastp_gpu_bgzf_index + fastp_gpu_inflate_bgzf - inflates it block by
+ * block.  LZ77 (hash of 4 bytes + distance 1) with dynamic Huffman codes, or a stored block when that is
+ * smaller; one wavefront per block.  DEFLATE has no canonical output: the bytes differ from libdeflate's, the
+ * text they inflate to is identical.  write_eof != 0 appends bgzip's 28-byte end-of-file member (for the last
+ * call of a file).  text / out: DEVICE pointers; *out_len (HOST) = bytes written, or needed when
+ * FASTP_GPU_E_OVERFLOW is returned.  An upper bound for out_capacity: nbytes + 31 * (nbytes / 65280 + 1) + 28. */
+int fastp_gpu_deflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbytes, int write_eof, uint8_t* out,
+                           int64_t out_capacity, int64_t* out_len);
+
 /* ---- the Evaluator pre-pass ON THE DEVICE ------------------------------
  * The loops of src/evaluator.cpp that scan a prefix of the input before the workers start, run on packed
  * rows already in HBM (DEVICE pointers seq / qual / len as in fastp_gpu_batch, one mate at a time; n reads

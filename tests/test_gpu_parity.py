@@ -636,6 +636,14 @@ def test_gpu_evaluator_prepass_equals_port():
     hs._eval_case(engines.gpu_engine, format_util.TorchMem(), 3000, 22, L=102, trim_tail1=2)
 
 
+def test_gpu_deflate_bgzf_members_round_trip():
+    """fastp_gpu_deflate_bgzf on 20 MB of FASTQ text, 3 MB of noise, runs and block-boundary sizes: gzip, and our own
+    BGZF index + inflate with CRC check, return the text"""
+    import format_util
+    import test_hostsim_parity as hs
+    hs._deflate_case(engines.gpu_engine, format_util.TorchMem(), big=True)
+
+
 def test_gpu_device_fastq_format_crlf_and_overflow():
     import format_util
     import test_hostsim_parity as hs

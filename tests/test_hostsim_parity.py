@@ -604,3 +604,61 @@ def test_sim_bgzf_inflate_survives_corruption():
         mem.keep.clear()
     g.close()
     assert errors > 20
+
+
+def _deflate(eng, mem, text: bytes, eof=False, cap=None):
+    t = mem.upload(text, 16)
+    cap = cap if cap is not None else len(text) + 31 * (len(text) // 65280 + 1) + 28
+    out = mem.alloc(max(16, cap), 0xEE)
+    mem.sync()
+    rc, n = eng.deflate_bgzf(mem.ptr(t), len(text), mem.ptr(out), cap, eof, check=False)
+    raw = mem.download(out)
+    assert raw[min(n, cap):].count(b"\xEE") == len(raw) - min(n, cap), "bytes written past the reported length"
+    return rc, raw[:min(n, cap)], n
+
+
+def _deflate_texts(big):
+    """FASTQ text, runs (distance-1 matches up to 258), incompressible bytes (stored blocks), block-boundary sizes"""
+    rng = np.random.default_rng(9)
+    fq = _se_fastq_text(700 if not big else 60000, 5)
+    noise = rng.integers(0, 256, size=70000 if not big else 3 << 20, dtype=np.uint8).tobytes()
+    texts = [fq, b"A" * 70001, noise, fq[:65280], fq[:65281], fq[:65279], b"ACGT" * 20000 + noise[:5000] + b"\n" * 300]
+    texts += [fq[:k] for k in (1, 2, 3, 4, 5, 63, 64, 65, 257, 258, 259, 1000)]
+    return texts
+
+
+def _deflate_case(mk_engine, mem, big=False):
+    import gzip
+    import zlib
+    g = mk_engine(abi.default_params(False, 150))
+    for text in _deflate_texts(big):
+        rc, comp, n = _deflate(g, mem, text, eof=True)
+        assert rc == 0 and n == len(comp)
+        assert gzip.decompress(comp) == text                       # any gzip reader: concatenated members
+        assert comp.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+        # block by block, as a BGZF reader does: our own index + inflate with the CRC check
+        info, rc2, bad, back = _inflate(g, mem, comp)
+        assert rc2 == 0 and bad == -1 and back == text
+        assert info.n_blocks == (len(text) + 65279) // 65280 + 1
+        assert n <= len(text) + 31 * (len(text) // 65280 + 1) + 28
+    # ratios: FASTQ text well under 40 %, a run of one byte under 1 %, noise at most 31 bytes per member over
+    fq = _se_fastq_text(700 if not big else 60000, 5)
+    rc, comp, n = _deflate(g, mem, fq)
+    assert n < 0.4 * len(fq) and n < 1.15 * len(zlib.compress(fq, 1))
+    rc, comp, n = _deflate(g, mem, b"G" * 200000)
+    assert n < 2000
+    # empty input: nothing, or just the end-of-file member
+    rc, comp, n = _deflate(g, mem, b"")
+    assert rc == 0 and n == 0
+    rc, comp, n = _deflate(g, mem, b"", eof=True)
+    assert rc == 0 and n == 28 and gzip.decompress(comp) == b""
+    # too small an output buffer: the needed size comes back, nothing past the capacity is touched
+    rc, comp, n = _deflate(g, mem, fq, cap=1000)
+    assert rc == abi.E_OVERFLOW and n > 1000
+    g.close()
+
+
+def test_sim_deflate_bgzf_members_round_trip():
+    """fastp_gpu_deflate_bgzf: every member inflates (gzip, zlib per block, our own BGZF inflate) to the text"""
+    import format_util
+    _deflate_case(engines.sim_engine, format_util.NumpyMem())
