@@ -135,6 +135,16 @@ struct fastp_gpu_ctx {
     int blocks = 0;           // persistent workgroups per launch
     int max_pairs_per_launch = 0;
     hipStream_t stream = nullptr;
+    // Duplicate's probe + resolve of launch k run beside the fused kernel of launch k + 1 (see launch_chunk): the fused
+    // kernel holds every VGPR of the CUs it sits on, so the pair of streams is confined to disjoint CU sets
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fused[2] = {nullptr, nullptr}, ev_dup[2] = {nullptr, nullptr};
+    bool ev_dup_set[2] = {false, false};
+    bool aux_pending = false;      // the aux stream has work the main stream has not joined yet
+    int aux_last = 0;
+    uint64_t launch_seq = 0;
+    u64* d_dup_pos2[2] = {nullptr, nullptr}; size_t dup_pos2_cap[2] = {0, 0};
+    const void* last_res[2] = {nullptr, nullptr};   // result rows [begin, end) the aux stream's last resolve writes to
     // device buffers
     int16_t* d_ov_limit = nullptr;
     u16* d_lowq = nullptr;
@@ -227,8 +237,15 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     if (!ctx) return;
     if (fastp_gpu_comm_destroy_hook) fastp_gpu_comm_destroy_hook(ctx);
     (void)hipSetDevice(ctx->device);
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     drain_events(ctx);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->ev_fused[k]) (void)hipEventDestroy(ctx->ev_fused[k]);
+        if (ctx->ev_dup[k]) (void)hipEventDestroy(ctx->ev_dup[k]);
+        if (ctx->d_dup_pos2[k]) (void)hipFree(ctx->d_dup_pos2[k]);
+    }
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
@@ -307,10 +324,13 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (cap_tiles > 0 && cap_tiles < tiles_per_block) tiles_per_block = cap_tiles;
     if (ctx->cfg.halves == 2 && tiles_per_block > 1) tiles_per_block &= ~1;  // a workgroup's two halves take tiles in pairs
     if (tiles_per_block < 1) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "tile too large for the packed counters"); }
-    long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
-    if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
-    mp = mp / ctx->L.P * ctx->L.P;
-    ctx->max_pairs_per_launch = (int)mp;
+    auto set_launch_size = [&]() {
+        long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
+        if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
+        mp = mp / ctx->L.P * ctx->L.P;
+        ctx->max_pairs_per_launch = (int)mp;
+    };
+    set_launch_size();
     fastp_gpu_counter_layout_for_params(&ctx->params, &ctx->cl);
     if (env_int("FASTP_GPU_VERBOSE", 0))
         fprintf(stderr, "fastp_gpu: tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch\n", ctx->L.P,
@@ -323,7 +343,60 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         int r_ = [&]() -> int { HIP_TRY(ctx, call); return 0; }();     \
         if (r_) { std::string m = ctx->err; fastp_gpu_destroy(ctx); *out = nullptr; return fail(nullptr, r_, m); } \
     } while (0)
-    CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {
+        // FASTP_GPU_AUX_CUS compute units are set aside for the duplicate kernels (0, the default: one stream, everything
+        // in order).  Measured (profiles/r02k_cu_mask_sweep.txt): only a whole SE-even group of 32 CUs keeps the fused
+        // kernel's workgroups evenly placed; it hides the duplicate kernels (+4.5 % Mreads/s) but the fused kernel then
+        // runs on 224 CUs (-13 % of its own rate), so it stays an option.
+        const int aux_cus = (ctx->dp.dup_enabled && !ctx->dp.dedup) ? env_int("FASTP_GPU_AUX_CUS", 0) : 0;
+        bool split = false;
+        if (aux_cus > 0 && aux_cus * 4 <= ctx->cus && blocks_per_cu == 1) {
+            const int words = (ctx->cus + 31) / 32;
+            std::vector<uint32_t> m_main((size_t)words, 0u), m_aux((size_t)words, 0u);
+            // workgroups are dealt evenly to the XCDs, so every XCD gives up the same number of CUs; bit i of a CU mask
+            // belongs to XCD i % n_xcd (measured: profiles/r02k_cu_mask_sweep.txt)
+            const int n_xcd = env_int("FASTP_GPU_XCDS", ctx->cus % 8 == 0 && ctx->cus >= 64 ? 8 : 1);
+            const int per_xcd = std::max(1, aux_cus / n_xcd), slots = ctx->cus / n_xcd;
+            int n_aux = 0;
+            u64 slot_mask = 0;   // which CU slots of an XCD go to the aux stream
+            if (const char* e = getenv("FASTP_GPU_AUX_SLOTS")) {
+                for (const char* q = e; *q;) {
+                    slot_mask |= 1ull << (strtol(q, (char**)&q, 10) & 63);
+                    if (*q == ',') q++;
+                }
+            } else {
+                for (int j = slots - per_xcd; j < slots; j++) slot_mask |= 1ull << j;
+            }
+            for (int cu = 0; cu < ctx->cus; cu++) {
+                const bool to_aux = (slot_mask >> (cu / n_xcd)) & 1ull;
+                if (to_aux) n_aux++;
+                (to_aux ? m_aux : m_main)[(size_t)cu >> 5] |= 1u << (cu & 31);
+            }
+            if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, m_main.data()) == hipSuccess) {
+                if (hipExtStreamCreateWithCUMask(&ctx->aux, (uint32_t)words, m_aux.data()) == hipSuccess) {
+                    split = true;
+                    ctx->blocks = ctx->cus - n_aux;
+                    set_launch_size();
+                } else {
+                    (void)hipStreamDestroy(ctx->stream);
+                    ctx->stream = nullptr;
+                    ctx->aux = nullptr;
+                }
+            } else {
+                ctx->stream = nullptr;
+            }
+            (void)hipGetLastError();
+        }
+        if (split) {
+            for (int k = 0; k < 2; k++) {
+                CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_fused[k], hipEventDisableTiming));
+                CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_dup[k], hipEventDisableTiming));
+            }
+            if (env_int("FASTP_GPU_VERBOSE", 0)) fprintf(stderr, "fastp_gpu: %d CUs for the fused kernel, %d for Duplicate\n", ctx->blocks, ctx->cus - ctx->blocks);
+        } else {
+            CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        }
+    }
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -388,8 +461,23 @@ extern "C" int fastp_gpu_debug_phase_cycles(fastp_gpu_ctx* ctx, uint64_t* out16)
     return FASTP_GPU_OK;
 }
 
+// make `st` wait for what the aux stream still has in flight (duplicate flags, counters, bitmap)
+static int join_aux(fastp_gpu_ctx* ctx, hipStream_t st) {
+    if (!ctx->aux_pending) return 0;
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_dup[ctx->aux_last], 0));
+    if (st == ctx->stream) ctx->aux_pending = false;
+    return 0;
+}
+static int sync_main(fastp_gpu_ctx* ctx) {
+    int rc = join_aux(ctx, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 static int ensure(fastp_gpu_ctx* ctx, void** buf, size_t* cap, size_t need) {
     if (*cap >= need) return 0;
+    if (*buf && ctx->aux_pending) { int rj = join_aux(ctx, ctx->stream); if (rj) return rj; }
     if (*buf) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
     size_t want = need + need / 4;
     HIP_TRY(ctx, hipMalloc(buf, want));
@@ -560,10 +648,32 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     // scan state of the whole batch: positions [b->n][B] u64, then masks [b->n] u8
     u64* scan_pos = scan_state ? (u64*)scan_state + (size_t)first * ctx->dp.dup_bufnum : nullptr;
     u8* scan_mask = scan_state ? scan_state + (size_t)b->n * ctx->dp.dup_bufnum * 8 + first : nullptr;
+    // the worker loop on the context's own streams: Duplicate's kernels go to the aux stream and overlap the next launch
+    const bool piped = ctx->aux && st == ctx->stream && mode == CHUNK_STREAM && ctx->dp.dup_enabled && !ctx->dp.dedup;
+    const int par = (int)(ctx->launch_seq & 1);
+    if (!piped) {
+        int rj = join_aux(ctx, st);
+        if (rj) return rj;
+    }
+    u64* dup_pos_buf = nullptr;
     if (ctx->dp.dup_enabled && mode != CHUNK_OVERREP) {
-        int rc = ensure(ctx, (void**)&ctx->d_dup_pos, &ctx->dup_pos_cap, (size_t)n * ctx->dp.dup_bufnum * 8);
-        if (rc) return rc;
-        a.dup_pos = ctx->d_dup_pos;
+        if (piped) {
+            // this buffer was last read by the resolve of launch k - 2
+            if (ctx->ev_dup_set[par]) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_dup[par], 0));
+            int rc = ensure(ctx, (void**)&ctx->d_dup_pos2[par], &ctx->dup_pos2_cap[par], (size_t)n * ctx->dp.dup_bufnum * 8);
+            if (rc) return rc;
+            dup_pos_buf = ctx->d_dup_pos2[par];
+            // the resolve of launch k - 1 ORs duplicate flags into its result rows: wait for it if this launch writes the same rows
+            const char* lo = (const char*)a.res[0];
+            const char* hi = lo + (size_t)n * sizeof(fastp_gpu_read_result);
+            if (ctx->aux_pending && ctx->ev_dup_set[par ^ 1] && lo < (const char*)ctx->last_res[1] && (const char*)ctx->last_res[0] < hi)
+                HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_dup[par ^ 1], 0));
+        } else {
+            int rc = ensure(ctx, (void**)&ctx->d_dup_pos, &ctx->dup_pos_cap, (size_t)n * ctx->dp.dup_bufnum * 8);
+            if (rc) return rc;
+            dup_pos_buf = ctx->d_dup_pos;
+        }
+        a.dup_pos = dup_pos_buf;
     }
     a.phase_cycles = ctx->d_phase;
     a.debug_skip = (u32)env_int("FASTP_GPU_DEBUG_SKIP", 0);
@@ -576,15 +686,17 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     const int grid = wg_tiles < ctx->blocks ? wg_tiles : ctx->blocks;
     // the stage + hash pre-pass of --dedup runs the whole workgroup on one tile at a time
     auto whole = [](KernelArgs k) { k.L.halves = 1; return k; };
+    hipStream_t st_main = st;
     const fastp_gpu_counter_layout& cl = ctx->cl;
     int rc;
 
     // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
-    auto launch_dup = [&](u8* dupflag, bool scan = false) -> int {
+    auto launch_dup = [&](u8* dupflag, bool scan = false, hipStream_t st = nullptr) -> int {
+        if (!st) st = st_main;
         DupArgs d;
         memset(&d, 0, sizeof(d));
         if (scan) { d.scan_pos = scan_pos; d.scan_mask = scan_mask; }
-        d.dup_pos = ctx->d_dup_pos;
+        d.dup_pos = dup_pos_buf;
         d.posum = ctx->d_posum;
         d.len[0] = a.len[0];
         d.len[1] = a.len[1];
@@ -694,7 +806,19 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
     HIP_TRY(ctx, hipGetLastError());
 
-    if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
+    if (piped) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[par], st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fused[par], 0));
+        rc = launch_dup(nullptr, false, ctx->aux);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_dup[par], ctx->aux));
+        ctx->ev_dup_set[par] = true;
+        ctx->aux_pending = true;
+        ctx->aux_last = par;
+        ctx->last_res[0] = a.res[0];
+        ctx->last_res[1] = (const char*)a.res[0] + (size_t)n * sizeof(fastp_gpu_read_result);
+        ctx->launch_seq++;
+    } else if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
         rc = launch_dup(nullptr, mode == CHUNK_PASS1);
         if (rc) return rc;
     }
@@ -778,8 +902,9 @@ extern "C" int fastp_gpu_dup_bitmap_export(fastp_gpu_ctx* ctx, void* dst_device)
     if (bytes == 0) return FASTP_GPU_OK;
     if (!dst_device) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rj_ = join_aux(ctx, ctx->stream); if (rj_) return rj_; }
     HIP_TRY(ctx, hipMemcpyAsync(dst_device, ctx->d_bitmap, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     return FASTP_GPU_OK;
 }
 
@@ -802,7 +927,7 @@ extern "C" int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_d
     o.n_images = n_images;
     hipLaunchKernelGGL(fq_or_images_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, o);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     ctx->has_prefix = true;
     return FASTP_GPU_OK;
 }
@@ -819,7 +944,7 @@ extern "C" int fastp_gpu_prefix_or_images(fastp_gpu_ctx* ctx, void* images_devic
     o.n_images = n_images;
     hipLaunchKernelGGL(fq_or_images_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, o);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     return FASTP_GPU_OK;
 }
 
@@ -830,7 +955,7 @@ extern "C" int fastp_gpu_stream_set_origin(fastp_gpu_ctx* ctx, int64_t units_bef
     const u64 v = (u64)post_reads_before;
     if (!ctx->d_post_seen) return FASTP_GPU_OK;  // no overrepresentation analysis: nothing else reads positions
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_post_seen, &v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     return FASTP_GPU_OK;
 }
 
@@ -1149,7 +1274,7 @@ static int eval_admit(fastp_gpu_ctx* ctx, const uint16_t* len, int32_t n, int64_
     lens.resize(take);
     if (take) {
         HIP_TRY(ctx, hipMemcpyAsync(lens.data(), len, take * 2, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     }
     int64_t bases = 0;
     size_t used = 0;
@@ -1362,7 +1487,7 @@ extern "C" int fastp_gpu_deflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* text, i
 extern "C" int fastp_gpu_synchronize(fastp_gpu_ctx* ctx) {
     if (!ctx) return FASTP_GPU_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     return FASTP_GPU_OK;
 }
 
@@ -1418,6 +1543,8 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     else { dr.adapter_events = nullptr; dr.adapter_events_capacity = 0; }
     dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
     rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
+    if (rc) return rc;
+    rc = join_aux(ctx, st);   // the duplicate flags of the last launch
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(res->r1, dr.r1, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
     if (mates == 2) {
@@ -1498,7 +1625,7 @@ extern "C" int fastp_gpu_reset(fastp_gpu_ctx* ctx) {
     if (ctx->d_post_seen) HIP_TRY(ctx, hipMemsetAsync(ctx->d_post_seen, 0, sizeof(u64), ctx->stream));
     ctx->units_seen = 0;
     ctx->has_prefix = false;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     return FASTP_GPU_OK;
 }
 

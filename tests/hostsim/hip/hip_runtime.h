@@ -139,6 +139,7 @@ struct hipDeviceProp_t {
     size_t sharedMemPerBlock;
 };
 static inline const char* hipGetErrorString(hipError_t) { return "hostsim error"; }
+enum { hipEventDisableTiming = 2 };
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
@@ -150,6 +151,9 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t words, const uint32_t* mask);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t* e);
