@@ -14,6 +14,7 @@
 #include "fq_inflate.h"
 #include "fq_eval.h"
 #include "fq_deflate.h"
+#include "fq_inflate_wave.h"
 #include "fq_host.h"
 
 using namespace fq;
@@ -84,6 +85,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmt_write_kernel(FmtArgs f)
     fmt_write_body(f, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_fmt_fix_kernel(FmtArgs f) { fmt_fix_body(f); }
+extern "C" __global__ void __launch_bounds__(64) fq_inflate_wave_kernel(InflateArgs a) {
+    extern __shared__ u32 fq_lds[];
+    inflate_wave_body(a, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(64) fq_deflate_kernel(DeflateArgs a) {
     extern __shared__ u32 fq_lds[];
     deflate_body(a, fq_lds);
@@ -400,6 +405,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IwLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4));
     auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
@@ -1094,8 +1100,15 @@ extern "C" int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, i
     a.first_bad = (u32*)(ctx->d_inf + scratch + status);
     a.check_crc = check_crc;
     HIP_TRY(ctx, hipMemsetAsync(a.first_bad, 0xFF, 4, st));
-    const int lds_bytes = INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4;
-    hipLaunchKernelGGL(fq_inflate_kernel, dim3((n_blocks + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_bytes, st, a);
+    // FASTP_GPU_INFLATE=lane: the first design (fq_inflate.h, one lane per block); default: one wavefront per block
+    const char* how = getenv("FASTP_GPU_INFLATE");
+    if (how && !strcmp(how, "lane")) {
+        const int lds_bytes = INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4;
+        hipLaunchKernelGGL(fq_inflate_kernel, dim3((n_blocks + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_bytes, st, a);
+    } else {
+        const int per_cu = std::max(1, (160 * 1024) / (int)sizeof(IwLds));
+        hipLaunchKernelGGL(fq_inflate_wave_kernel, dim3(std::min(n_blocks, ctx->cus * per_cu)), dim3(64), sizeof(IwLds), st, a);
+    }
     HIP_TRY(ctx, hipGetLastError());
     u32 bad = 0xFFFFFFFFu;
     HIP_TRY(ctx, hipMemcpyAsync(&bad, a.first_bad, 4, hipMemcpyDeviceToHost, st));

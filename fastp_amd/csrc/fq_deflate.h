@@ -41,6 +41,12 @@ struct DeflateArgs {
     u64 out_base, out_cap;
 };
 
+// CRC-32 of up to 64 KiB by one wavefront: the byte table and the operators "append 1024 * 2^k zero bytes"
+struct CrcLds {
+    u32 tab[256];
+    u32 mat[6][32];
+};
+
 struct DefLds {
     u16 head[1 << DEF_HASH_BITS];
     u32 hist_ll[DEF_NLL], hist_d[DEF_ND], hist_cl[DEF_NCL];
@@ -52,8 +58,7 @@ struct DefLds {
     u32 blc[16], nxt[16];
     u8 cl_sym[DEF_NLL + DEF_ND], cl_ext[DEF_NLL + DEF_ND];
     u32 cl_n, hlit, hdist, hclen, dyn_bits;
-    u32 crc_tab[256];
-    u32 mat[6][32], mtmp[32];
+    CrcLds crc;
     u32 win[DEF_WIN];
 };
 
@@ -104,11 +109,11 @@ FQ_DEV u32 def_gf2_times(const u32* mat, u32 vec) {
     return sum;
 }
 // byte table + the operators "append 1024 * 2^k zero bytes" (k = 0..5), built once per workgroup by the wave
-FQ_DEV void def_crc_setup(DefLds& S, int lane) {
+FQ_DEV void def_crc_setup(CrcLds& S, int lane) {
     for (int i = lane; i < 256; i += 64) {
         u32 c = (u32)i;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        S.crc_tab[i] = c;
+        S.tab[i] = c;
     }
     u32* m = S.mat[0];
     if (lane < 32) m[lane] = lane == 0 ? 0xEDB88320u : 1u << (lane - 1);   // one zero bit
@@ -124,7 +129,7 @@ FQ_DEV void def_crc_setup(DefLds& S, int lane) {
         wave_sync();
     }
 }
-FQ_DEV u32 def_crc32(const DefLds& S, const u8* in, u32 n, int lane) {
+FQ_DEV u32 def_crc32(const CrcLds& S, const u8* in, u32 n, int lane) {
     if (n == 0u) return 0u;
     // the text right-aligned in a virtual 64 KiB message of leading zero bytes (which leave a zero register unchanged);
     // the 0xFFFFFFFF preset enters where the text starts
@@ -133,7 +138,7 @@ FQ_DEV u32 def_crc32(const DefLds& S, const u8* in, u32 n, int lane) {
     const u32 v0 = (u32)lane * 1024u;
     for (u32 v = v0 < pad ? pad : v0; v < v0 + 1024u; v++) {
         if (v == pad) reg = 0xFFFFFFFFu;
-        reg = S.crc_tab[(reg ^ in[v - pad]) & 0xFFu] ^ (reg >> 8);
+        reg = S.tab[(reg ^ in[v - pad]) & 0xFFu] ^ (reg >> 8);
     }
     for (int k = 0; k < 6; k++) {
         const u32 right = shfl(reg, lane + (1 << k));
@@ -467,7 +472,7 @@ FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
         }
     }
     // ---- gzip framing with the BGZF extra field (total size - 1), CRC-32 and ISIZE ----
-    const u32 crc = def_crc32(S, in, n, lane);
+    const u32 crc = def_crc32(S.crc, in, n, lane);
     if (lane == 0) {
         const u32 bsize = 18u + dbytes + 8u;
         const u8 hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
@@ -485,7 +490,7 @@ FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
 FQ_DEV void deflate_body(const DeflateArgs& a, u32* ldsw) {
     DefLds& S = *(DefLds*)ldsw;
     const int lane = lane_id();
-    def_crc_setup(S, lane);
+    def_crc_setup(S.crc, lane);
     for (int blk = block_id(); blk < a.nblocks; blk += grid_blocks()) deflate_block(a, S, blk, lane);
 }
 

@@ -115,8 +115,27 @@ FQ_DEV void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// order this wave's LDS accesses for the compiler only: the LDS pipe executes one wave's DS instructions in issue
+// order, so a later read by any lane of the wave sees an earlier write without draining the queue (lgkmcnt) first
+FQ_DEV void wave_order() {
+#ifndef FQ_HOSTSIM
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
 FQ_DEV u64 ballot(bool pred) { return __ballot(pred); }
 FQ_DEV u32 shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
+// the value lane `src` holds, src the same in every lane (v_readlane_b32: no LDS crossbar trip)
+FQ_DEV u32 read_lane(u32 v, u32 src) {
+#ifndef FQ_HOSTSIM
+    return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)src));
+#else
+    return (u32)__shfl((int)v, (int)src, 64);
+#endif
+}
 FQ_DEV u32 shfl_xor(u32 v, int mask) { return (u32)__shfl_xor((int)v, mask, 64); }
 // lane exchanges inside a row of 16 lanes as DPP modifiers (no LDS round trip like ds_bpermute):
 // the value of lane ^ 1, lane ^ 2 (quad_perm) and of the mirrored lane of the 8-lane half row

@@ -515,6 +515,19 @@ def test_sim_bgzf_inflate_equals_zlib(level, strategy):
     assert got == text
 
 
+def test_sim_bgzf_inflate_lane_variant(monkeypatch):
+    """FASTP_GPU_INFLATE=lane: the one-lane-per-block kernel (fq_inflate.h) stays selectable and correct"""
+    import bgzf_util
+    import format_util
+    monkeypatch.setenv("FASTP_GPU_INFLATE", "lane")
+    text = _se_fastq_text(900, 4)
+    comp = bgzf_util.compress(text, block_bytes=20000, level=6)
+    g = engines.sim_engine(abi.default_params(False, 150))
+    info, rc, bad, got = _inflate(g, format_util.NumpyMem(), comp)
+    g.close()
+    assert rc == 0 and bad == -1 and got == text
+
+
 def test_sim_bgzf_index_chunks_and_errors():
     import bgzf_util
     import format_util

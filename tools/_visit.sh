@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-for S in "31" "15,31" "23,31" "7,15,23,31" "3,11,19,27" "30,31" "0,1,2,3"; do
-  echo "AUX_SLOTS=$S"; FASTP_GPU_AUX_SLOTS=$S timeout 600 python bench.py --steps 48 --warmup 8 --no-cpu 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'])"
-done > gpurun_out/aux_sweep2.log 2>&1
-cat gpurun_out/aux_sweep2.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "inflate or bgzf or deflate or pipeline" > gpurun_out/pytest_r02l.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_r02l.log
+timeout 600 python tools/aux_bench.py 400000 > gpurun_out/aux_r02l.log 2>&1; echo "aux rc=$?"; tail -12 gpurun_out/aux_r02l.log
+FASTP_GPU_INFLATE=lane timeout 600 python tools/aux_bench.py 400000 2>&1 | grep inflate
+timeout 600 python tools/aux_bench.py 2000000 2>&1 | grep -i "flate\|ratio"
