@@ -1100,9 +1100,12 @@ extern "C" int fastp_gpu_inflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* comp, i
     a.first_bad = (u32*)(ctx->d_inf + scratch + status);
     a.check_crc = check_crc;
     HIP_TRY(ctx, hipMemsetAsync(a.first_bad, 0xFF, 4, st));
-    // FASTP_GPU_INFLATE=lane: the first design (fq_inflate.h, one lane per block); default: one wavefront per block
+    // one wavefront per block (fq_inflate_wave.h: 4.6 ms per launch whatever the size, 2 blocks per CU in flight) up to
+    // 6144 blocks; beyond that blocks in flight decide and one lane per block (fq_inflate.h: ~50 ms per launch, 64 blocks
+    // per wavefront) overtakes it (profiles/r02l_inflate.txt).  FASTP_GPU_INFLATE=lane|wave forces one.
     const char* how = getenv("FASTP_GPU_INFLATE");
-    if (how && !strcmp(how, "lane")) {
+    const bool lane_kernel = how ? !strcmp(how, "lane") : n_blocks > 6144;
+    if (lane_kernel) {
         const int lds_bytes = INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4;
         hipLaunchKernelGGL(fq_inflate_kernel, dim3((n_blocks + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), lds_bytes, st, a);
     } else {
