@@ -7,9 +7,11 @@ writerthread.cpp:118-168).  Line splitting + packing (`fastp_gpu_parse_fastq`), 
 reference's processSingleEnd / processPairEnd would have written to out1 / out2 comes out byte for
 byte.  Input files may be plain FASTQ or BGZF (.gz written by bgzip: the reference's BgzfMtReader path,
 src/bgzf.h) - those are shipped compressed and inflated on the device (`fastp_gpu_inflate_bgzf`).
-Scope: out1/out2 only, no merge mode / UMI name edits (those keep
-the string-side host path of INTEGRATION.md section 3).  Reader and writer run on their own threads
-so file I/O overlaps the device work of the neighbouring chunks.
+Every output stream of the worker loop is assembled on the device (`fastp_gpu_format_streams`): out1 / out2,
+--failed_out, --unpaired1/2, the merged stream, UMI-renamed records; an output path ending in ".gz" is compressed
+on the device too (`fastp_gpu_deflate_bgzf`: BGZF-framed gzip members, what the reference's WriterThread does per
+pack with libdeflate).  Reader and writer run on their own threads so file I/O overlaps the device work of the
+neighbouring chunks.
 """
 from __future__ import annotations
 
@@ -41,7 +43,6 @@ class _Mate:
         self.loff = torch.empty(4 * max_records, dtype=torch.int32, device=dev)
         self.llen = torch.empty(4 * max_records, dtype=torch.int32, device=dev)
         self.res = torch.zeros(max_records * 12, dtype=torch.uint8, device=dev)
-        self.out = torch.empty(self.cap, dtype=torch.uint8, device=dev)
 
 
 class FastqPipeline:
@@ -75,7 +76,9 @@ class FastqPipeline:
         self.nev = torch.zeros(4, dtype=torch.int32, device=self.dev)
         # two pinned staging sets per direction: the reader fills one while the device works on the other
         self.stage_in = [[torch.empty(self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
-        self.stage_out = [[torch.empty(2 * self.chunk + 64, dtype=torch.uint8).pin_memory() for _ in range(nm)] for _ in range(2)]
+        self.stage_out = None      # [slot][stream]: pinned, sized in run() for the streams that are asked for
+        self.outs = [None] * abi.N_OUTPUTS       # device text per stream
+        self.gzbuf = [None] * abi.N_OUTPUTS      # device gzip members per compressed stream
         self.max_blocks = (2 * self.chunk) // 8192 + 64     # BGZF members per chunk (bgzip: ~64 KiB of text each)
         self.check_crc = True
         self.stats = dict(units=0, chunks=0, bytes_in=0, bytes_out=0, t_parse=0.0, t_engine=0.0, t_format=0.0, t_h2d=0.0,
@@ -134,7 +137,7 @@ class FastqPipeline:
     def _writer(self, files, q_out, q_done):
         import os
         from concurrent.futures import ThreadPoolExecutor
-        fds = [f.fileno() for f in files]
+        fds = [f.fileno() if f is not None else -1 for f in files]
         pos = [0] * len(files)
 
         def piece(fd, mv, off):
@@ -151,6 +154,8 @@ class FastqPipeline:
                     slot, lens = item
                     futs = []
                     for m in range(len(files)):
+                        if files[m] is None or not lens[m]:
+                            continue
                         mv = memoryview(self.stage_out[slot][m].numpy())[:lens[m]]
                         for a in range(0, lens[m], self.IO_PIECE):
                             e = min(lens[m], a + self.IO_PIECE)
@@ -212,10 +217,60 @@ class FastqPipeline:
                               self.text_all.data_ptr(), self.text_all.numel(), self.check_crc)
         return res
 
-    def run(self, in1: str, in2: str | None, out1: str, out2: str | None) -> dict:
+    EOF_MEMBER = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")   # bgzip's empty last member
+
+    def _setup_outputs(self, paths):
+        """device + pinned buffers for the streams that are written; paths[q] per abi stream index"""
+        torch = self.torch
+        nm = len(self.mates)
+        both = nm * self.text_cap + self.max_records * 96          # every record of both mates + tags
+        one = self.text_cap + self.max_records * 64
+        caps = [one, one, both, both, both, both]
+        self.out_cap = [0] * abi.N_OUTPUTS
+        self.gz_out = [bool(p) and p.endswith(".gz") for p in paths]
+        for q in range(abi.N_OUTPUTS):
+            if not paths[q]:
+                continue
+            self.out_cap[q] = caps[q]
+            if self.outs[q] is None or self.outs[q].numel() < caps[q]:
+                self.outs[q] = torch.empty(caps[q], dtype=torch.uint8, device=self.dev)
+            if self.gz_out[q]:
+                gcap = caps[q] + 31 * (caps[q] // 65280 + 1) + 64
+                if self.gzbuf[q] is None or self.gzbuf[q].numel() < gcap:
+                    self.gzbuf[q] = torch.empty(gcap, dtype=torch.uint8, device=self.dev)
+        need = [(self.gzbuf[q].numel() if self.gz_out[q] else caps[q]) if paths[q] else 0 for q in range(abi.N_OUTPUTS)]
+        if self.stage_out is None:
+            self.stage_out = [[None] * abi.N_OUTPUTS for _ in range(2)]
+        for sl in range(2):
+            for q in range(abi.N_OUTPUTS):
+                have = self.stage_out[sl][q]
+                if need[q] and (have is None or have.numel() < need[q]):
+                    self.stage_out[sl][q] = torch.empty(need[q], dtype=torch.uint8).pin_memory()
+
+    def run(self, in1: str, in2: str | None, out1: str, out2: str | None, failed_out: str | None = None,
+            merged_out: str | None = None, unpaired1: str | None = None, unpaired2: str | None = None,
+            umi: tuple | None = None) -> dict:
+        """umi = (location "read1" | "read2" | "per_read", length[, prefix bytes[, delimiter bytes]]): the name edit that goes
+        with params.umi_len1/2 (UmiProcessor::addUmiToName)"""
         torch = self.torch
         if self.paired != (in2 is not None) or self.paired != (out2 is not None):
             raise PipelineError("paired engine needs in2/out2, single-end engine must not get them")
+        if self.params.merge and not merged_out:
+            raise PipelineError("merge mode needs merged_out")
+        if (self.params.umi_len1 or self.params.umi_len2) and umi is None:
+            raise PipelineError("params trim a UMI off the reads: pass umi=(location, length) for the name edit")
+        out_paths = [out1, out2, failed_out, merged_out if self.params.merge else None, unpaired1 if self.paired else None,
+                     unpaired2 if self.paired else None]
+        self._setup_outputs(out_paths)
+        self.fmt_opts = abi.FormatOptions()
+        self.fmt_opts.want_failed = int(bool(failed_out))
+        self.fmt_opts.want_unpaired1 = int(bool(out_paths[4]))
+        self.fmt_opts.want_unpaired2 = int(bool(out_paths[5]))
+        if umi is not None:
+            self.fmt_opts.umi_loc = {"read1": 1, "read2": 2, "per_read": 3}[umi[0]]
+            self.fmt_opts.umi_len = int(umi[1])
+            self.fmt_opts.umi_prefix = umi[2] if len(umi) > 2 and umi[2] else None
+            self.fmt_opts.umi_delimiter = umi[3] if len(umi) > 3 else None
         nm = len(self.mates)
         paths = (in1, in2) if self.paired else (in1,)
         gz = [self.is_bgzf(p) for p in paths]
@@ -226,7 +281,7 @@ class FastqPipeline:
                         raise PipelineError(f"{p}: gzip but not BGZF - a single deflate stream has no independent blocks; "
                                             "decompress on the host (as the reference does) or recompress with bgzip")
         fin = [open(p, "rb", buffering=0) for p in paths]
-        fout = [open(p, "wb", buffering=0) for p in ((out1, out2) if self.paired else (out1,))]
+        fout = [open(p, "wb", buffering=0) if p else None for p in out_paths]
         q_free, q_full, q_out, q_done = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
         # a compressed chunk expands ~4-5x: read a quarter of the text budget per trip
         want = [self.chunk // 4 if g else self.chunk for g in gz]
@@ -315,8 +370,10 @@ class FastqPipeline:
                     st["t_wait_write"] += time.perf_counter() - t0
                     oslot = out_free.pop(0)
                     t0 = time.perf_counter()
-                    for m in range(nm):
-                        self.stage_out[oslot][m][:lens[m]].copy_(self.mates[m].out[:lens[m]], non_blocking=True)
+                    for q in range(abi.N_OUTPUTS):
+                        if fout[q] is not None and lens[q]:
+                            src = self.gzbuf[q] if self.gz_out[q] else self.outs[q]
+                            self.stage_out[oslot][q][:lens[q]].copy_(src[:lens[q]], non_blocking=True)
                     torch.cuda.synchronize(self.dev)
                     st["t_d2h"] += time.perf_counter() - t0
                     q_out.put((oslot, lens))
@@ -335,8 +392,12 @@ class FastqPipeline:
             q_out.put(None)
             wr.join()
             rd.join(timeout=5)
+            for q, f in enumerate(fout):
+                if f is not None and self.gz_out[q]:   # the writer thread has joined: append after its last positional write
+                    os.pwrite(f.fileno(), self.EOF_MEMBER, os.fstat(f.fileno()).st_size)
             for f in fin + fout:
-                f.close()
+                if f is not None:
+                    f.close()
         while not q_done.empty():
             d = q_done.get()
             if isinstance(d, Exception):
@@ -372,14 +433,21 @@ class FastqPipeline:
             f = abi.FormatIn()
             f.text, f.line_off, f.line_len, f.res = M[m].text.data_ptr(), M[m].loff.data_ptr(), M[m].llen.data_ptr(), M[m].res.data_ptr()
             fi.append(f)
-        rc, l1, l2 = self.eng.format_fastq(n, fi[0], fi[1] if self.paired else None,
+        rc, lens = self.eng.format_streams(n, fi[0], fi[1] if self.paired else None, self.pair.data_ptr() if self.paired else None,
                                            self.corr.data_ptr() if self.corr_cap else None,
-                                           self.nc.data_ptr() if self.corr_cap else None, M[0].out.data_ptr(), M[0].cap,
-                                           M[1].out.data_ptr() if self.paired else None, M[1].cap if self.paired else 0)
+                                           self.nc.data_ptr() if self.corr_cap else None, self.fmt_opts,
+                                           [t.data_ptr() if t is not None and self.out_cap[q] else None for q, t in enumerate(self.outs)],
+                                           self.out_cap)
         if self.corr_cap and int(self.nc[0].item()) > self.corr_cap:
             raise PipelineError("correction list overflow: raise corr_capacity")
         st["t_format"] += time.perf_counter() - t0
-        return (l1, l2)[:nm]
+        st["bytes_text"] = st.get("bytes_text", 0) + sum(lens)
+        t0 = time.perf_counter()
+        for q in range(abi.N_OUTPUTS):
+            if self.out_cap[q] and self.gz_out[q]:
+                rc, lens[q] = self.eng.deflate_bgzf(self.outs[q].data_ptr(), lens[q], self.gzbuf[q].data_ptr(), self.gzbuf[q].numel())
+        st["t_deflate"] = st.get("t_deflate", 0.0) + time.perf_counter() - t0
+        return lens
 
     def _parse(self, m, nbytes, is_last, max_records):
         M = self.mates[m]

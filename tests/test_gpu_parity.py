@@ -796,6 +796,58 @@ def test_gpu_file_pipeline_reads_bgzf(tmp_path):
     pl.close()
 
 
+@pytest.mark.parametrize("name", ["pe_filters", "pe_merge", "pe_umi_per_read", "se_umi_read1"])
+def test_gpu_file_pipeline_all_streams_and_gzip_outputs(name, tmp_path):
+    """files in (BGZF) -> every output stream assembled and gzip-compressed on the device -> .gz files: their text ==
+    the host writer's streams (and reference fastp's files where the binary is present); the .gz files are valid BGZF"""
+    import gzip
+    import bgzf_util
+    from fastp_amd import hostloop, pipeline
+    paired, flags, pf, skw = cases.CASES[name]
+    n = 15000
+    d = synth.synth_pairs(n, L=150, seed=93, paired=paired, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    fq1 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    fq2 = synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2) if paired else None
+    umi = cases.UMI.get(name)
+    editor = hostloop.UmiNameEditor(*umi) if umi else None
+    ref = engines.gpu_engine(params)
+    want, ctr, _ = driver.run_engine(ref, params, fq1, fq2, pack=n, stride=abi.qual_stride(150), want_failed=True,
+                                     want_unpaired=paired, umi=editor)
+    ref.close()
+    (tmp_path / "r1.fq.gz").write_bytes(bgzf_util.compress(fq1))
+    if paired:
+        (tmp_path / "r2.fq.gz").write_bytes(bgzf_util.compress(fq2))
+    t = lambda f: str(tmp_path / f)
+    pl = pipeline.FastqPipeline(params, chunk_bytes=1 << 20, max_records=3000)
+    st = pl.run(t("r1.fq.gz"), t("r2.fq.gz") if paired else None, t("o1.fq.gz"), t("o2.fq.gz") if paired else None,
+                failed_out=t("failed.fq.gz"), merged_out=t("merged.fq.gz") if params.merge else None,
+                unpaired1=t("u1.fq") if paired else None, unpaired2=t("u2.fq.gz") if paired else None, umi=umi)
+    got_ctr = pl.counters()
+    pl.close()
+    assert st["units"] == n and st["chunks"] > 3
+    assert np.array_equal(got_ctr, ctr)
+
+    def text(fn):
+        raw = (tmp_path / fn).read_bytes()
+        if fn.endswith(".gz"):
+            assert pipeline.FastqPipeline.is_bgzf(t(fn)) and raw.endswith(pipeline.FastqPipeline.EOF_MEMBER)
+            return gzip.decompress(raw)
+        return raw
+    assert text("o1.fq.gz") == bytes(want.out1)
+    assert text("failed.fq.gz") == bytes(want.failed)
+    if paired:
+        assert text("o2.fq.gz") == bytes(want.out2)
+        assert text("u1.fq") == bytes(want.unpaired1) and text("u2.fq.gz") == bytes(want.unpaired2)
+    if params.merge:
+        assert text("merged.fq.gz") == bytes(want.merged) and len(want.merged) > 0
+    if driver.have_reference_binary() and name != "pe_filters":   # (run_reference does not ask for the unpaired files)
+        r = driver.run_reference(flags, fq1, fq2)
+        assert text("o1.fq.gz") == (r["out1"] or b"")
+        if params.merge:
+            assert text("merged.fq.gz") == r["merged"]
+
+
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))
