@@ -659,17 +659,23 @@ FQ_DEV int scan_first(const u32* m, int lo, int hi, bool want) {
     if (lo >= hi) return hi;
     int w = lo >> 5;
     const int wend = (hi - 1) >> 5;
-    u32 x = (want ? m[w] : ~m[w]) & ~lowmask32(lo & 31);
+    // two words per LDS round trip (the second index clamped: a duplicate of the last word is harmless)
+    u32 r0 = m[w], r1 = m[w < wend ? w + 1 : wend];
+    u32 x = (want ? r0 : ~r0) & ~lowmask32(lo & 31);
     for (;;) {
         if (x) {
             const int j = (w << 5) + ffs32(x) - 1;
             return j < hi ? j : hi;
         }
         if (++w > wend) return hi;
-        x = want ? m[w] : ~m[w];
+        x = want ? r1 : ~r1;
+        if (x) continue;
+        if (++w > wend) return hi;
+        r0 = m[w];
+        r1 = m[w < wend ? w + 1 : wend];
+        x = want ? r0 : ~r0;
     }
 }
-// last j in [lo, hi) whose bit == want; lo - 1 if there is none
 FQ_DEV int scan_last(const u32* m, int lo, int hi, bool want) {
     if (lo >= hi) return lo - 1;
     int w = (hi - 1) >> 5;
@@ -975,10 +981,10 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, i
     const DevParams& p = a.p;
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= L.P ? 1 : 0;
+        const int rl0 = lds_i(lds, L.rlen0)[R];
         if (p.stats_one_pass) {
             // the one-pass Stats path reads quality character 0 as "no base here": make sure that is what the
             // row holds behind the read's end, whatever the caller's buffer had there
-            const int rl0 = lds_i(lds, L.rlen0)[R];
             u32* qrow = lds_qual(L, lds, R);
             int c0 = rl0 >> 2;
             if (rl0 & 3) {
@@ -991,7 +997,7 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, i
             const int gp = tile_first + R - m * L.P;
             if (gp < a.n && a.dupflag[gp]) lds_or_i32(&lds_i(lds, L.flags)[R], RS_DUP);
         }
-        int len = lds_i(lds, L.rlen0)[R];
+        int len = rl0;
         int front = 0;
         const int umi = m ? p.umi_len2 : p.umi_len1;
         if (umi > 0) {  // Read::trimFront(min(len,umi)+skip): len = min(length()-1, len)
@@ -1668,13 +1674,16 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         const bool a1 = !(flags[R1] & RS_NULL), a2 = !(flags[R2] & RS_NULL);
         const bool both = a1 && a2;
         const int ft1 = lds_i(lds, L.ft)[R1], ft2 = lds_i(lds, L.ft)[R2];
+        // the two lengths as they are now, kept in registers (a re-read behind every store is an LDS round trip, and two
+        // wavefronts run this phase while fourteen wait); reloaded after the helpers that edit them in LDS
+        int cur1 = lenv[R1], cur2 = lenv[R2];
         int ovl, ov_off, ov_len, ov_diff;  // the OverlapResult of the pair as it is now (quirk #6)
-        decode_overlap((u32)lds_i(lds, L.ov_off)[pr], lenv[R1], lenv[R2], ovl, ov_off, ov_len, ov_diff);
+        decode_overlap((u32)lds_i(lds, L.ov_off)[pr], cur1, cur2, ovl, ov_off, ov_len, ov_diff);
         // ovForAdapter (peprocessor.cpp:445-447): with allow_gap, the one-gap result where no-gap found nothing
         int aovl = ovl, aoff = ov_off, aol = ov_len, adiff = ov_diff;
         bool agap = false;
         if (p.allow_gap && !ovl) {
-            decode_overlap((u32)lds_i(lds, L.ov_len)[pr], lenv[R1], lenv[R2], aovl, aoff, aol, adiff);
+            decode_overlap((u32)lds_i(lds, L.ov_len)[pr], cur1, cur2, aovl, aoff, aol, adiff);
             agap = aovl != 0;
         }
         bool isize_done = false, dimer = false;
@@ -1682,7 +1691,7 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         if (both && thread0) {
             int isize = p.isize_max;
             if (ovl) {
-                if (ov_off > 0) isize = lenv[R1] + lenv[R2] - ov_len + ft1 + ft2;
+                if (ov_off > 0) isize = cur1 + cur2 - ov_len + ft1 + ft2;
                 else isize = ov_len + ft1 + ft2;
             }
             if (isize > p.isize_max) isize = p.isize_max;
@@ -1694,7 +1703,7 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             if (p.correction && aovl && !agap && adiff != 0) {
                 const int f1 = lds_i(lds, L.front)[R1], f2 = lds_i(lds, L.front)[R2];
                 const int start1 = imax(0, aoff);
-                const int start2 = lenv[R2] - imax(0, -aoff) - 1;
+                const int start2 = cur2 - imax(0, -aoff) - 1;
                 const u32* s1 = lds_seq(L, lds, R1);
                 const u32* s2 = lds_seq(L, lds, R2);
                 const u8* q1 = (const u8*)lds_qual(L, lds, R1);
@@ -1732,38 +1741,40 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
                 }
                 if (corrected > 0) {  // :75-80
                     lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
-                    if (r1c) flags[R1] |= RS_CORRECTED;
-                    if (r2c) flags[R2] |= RS_CORRECTED;
+                    if (r1c) lds_or_i32(&flags[R1], RS_CORRECTED);
+                    if (r2c) lds_or_i32(&flags[R2], RS_CORRECTED);
                 }
             }
             if (p.adapter_enabled) {
                 bool trimmed = false;
                 if (aovl && aoff < 0) {  // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
-                    const int len1 = imin(lenv[R1], aol + ft2);
-                    const int len2 = imin(lenv[R2], aol + ft1);
+                    const int len1 = imin(cur1, aol + ft2);
+                    const int len2 = imin(cur2, aol + ft1);
                     lds_i(lds, L.apos)[R1] = len1;
-                    lds_i(lds, L.alen)[R1] = lenv[R1] - len1;
+                    lds_i(lds, L.alen)[R1] = cur1 - len1;
                     lds_i(lds, L.apos)[R2] = len2;
-                    lds_i(lds, L.alen)[R2] = lenv[R2] - len2;
-                    lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)((lenv[R1] - len1) + (lenv[R2] - len2)));
-                    lenv[R1] = len1;
-                    lenv[R2] = len2;
+                    lds_i(lds, L.alen)[R2] = cur2 - len2;
+                    lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)((cur1 - len1) + (cur2 - len2)));
+                    lenv[R1] = cur1 = len1;
+                    lenv[R2] = cur2 = len2;
                     trimmed = true;
-                    flags[R1] |= RS_ADAPTER_OV;
-                    flags[R2] |= RS_ADAPTER_OV;
+                    lds_or_i32(&flags[R1], RS_ADAPTER_OV);
+                    lds_or_i32(&flags[R2], RS_ADAPTER_OV);
                 }
                 bool t1 = trimmed, t2 = trimmed;
                 if (!trimmed) {  // peprocessor.cpp:460-466
-                    if (p.has_a1) t1 = apply_trim_by_sequence(a, lds, R1, lds + L.adapt, p.alen1, misc);
-                    if (p.has_a2) t2 = apply_trim_by_sequence(a, lds, R2, lds + L.adapt + ADAPT_WORDS, p.alen2, misc);
+                    if (p.has_a1) { t1 = apply_trim_by_sequence(a, lds, R1, lds + L.adapt, p.alen1, misc); cur1 = lenv[R1]; }
+                    if (p.has_a2) { t2 = apply_trim_by_sequence(a, lds, R2, lds + L.adapt + ADAPT_WORDS, p.alen2, misc); cur2 = lenv[R2]; }
                 }
                 if (p.n_fasta) {  // :467-470
                     t1 |= apply_fasta_trims(a, lds, R1, 2u * (u32)(a.first + gp), misc);
                     t2 |= apply_fasta_trims(a, lds, R2, 2u * (u32)(a.first + gp) + 1u, misc);
+                    cur1 = lenv[R1];
+                    cur2 = lenv[R2];
                 }
-                if (t1) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R1] |= RS_ADAPTER; }  // :472-475
-                if (t2) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); flags[R2] |= RS_ADAPTER; }
-                if ((t1 || t2) && lenv[R1] <= p.dimer_max_len && lenv[R2] <= p.dimer_max_len) dimer = true;  // :480-484
+                if (t1) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); lds_or_i32(&flags[R1], RS_ADAPTER); }  // :472-475
+                if (t2) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); lds_or_i32(&flags[R2], RS_ADAPTER); }
+                if ((t1 || t2) && cur1 <= p.dimer_max_len && cur2 <= p.dimer_max_len) dimer = true;  // :480-484
             }
         }
         (void)isize_done;
@@ -1772,23 +1783,23 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
                 const int R = k ? R2 : R1;
                 int poly, trimmed;
                 const int nl = trim_poly_x(lds_seq(L, lds, R), (const u8*)lds_qual(L, lds, R), lds_i(lds, L.front)[R],
-                                           lenv[R], p.poly_x_min, poly, trimmed);
+                                           k ? cur2 : cur1, p.poly_x_min, poly, trimmed);
                 if (poly >= 0) {  // addPolyXTrimmed filterresult.cpp:186-189
                     lds_add_u32(&misc[MISC_POLYX_READS + poly], 1u);
                     lds_add_u32(&misc[MISC_POLYX_BASES + poly], (u32)trimmed);
-                    flags[R] |= RS_POLYX;
+                    lds_or_i32(&flags[R], RS_POLYX);
                 }
                 lenv[R] = nl;
+                if (k) cur2 = nl; else cur1 = nl;
             }
         }
         if (both) {  // :511-516
-            if (p.max_len1 > 0 && p.max_len1 < lenv[R1]) lenv[R1] = p.max_len1;
-            if (p.max_len2 > 0 && p.max_len2 < lenv[R2]) lenv[R2] = p.max_len2;
+            if (p.max_len1 > 0 && p.max_len1 < cur1) lenv[R1] = cur1 = p.max_len1;
+            if (p.max_len2 > 0 && p.max_len2 < cur2) lenv[R2] = cur2 = p.max_len2;
         }
-        if (dimer) flags[R1] |= RS_DIMER;
-        if (isize_done) flags[R1] |= RS_ISIZE;
-        lds_i(lds, L.mlen)[R1] = lenv[R1];
-        lds_i(lds, L.mlen)[R2] = lenv[R2];
+        if (dimer | isize_done) lds_or_i32(&flags[R1], (dimer ? RS_DIMER : 0) | (isize_done ? RS_ISIZE : 0));
+        lds_i(lds, L.mlen)[R1] = cur1;
+        lds_i(lds, L.mlen)[R2] = cur2;
         if (p.merge && both) {
             // merge mode analyzes the post-trim reads again (peprocessor.cpp:523); phase_merge writes the record
             lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;
@@ -1843,6 +1854,76 @@ FQ_DEV void write_dup_pos(const KernelArgs& a, u32* lds, int u, int gp) {
 }
 
 // Phase E3 (paired): lane = one pair.  Filter::passFilter and routing, peprocessor.cpp:563-591.
+// passFilter (filter.cpp:15-66) with the two LUT entries of the read's length already in registers
+FQ_DEV int filter_code_pre(const DevParams& p, int rlen, int tot, int low, int nb, int diff, int lowq_v, int cmin_v) {
+    if (rlen == 0) return 16;
+    if (p.qual_filter) {
+        if (low > lowq_v) return 20;
+        else if (p.avg_qual_req > 0 && (tot / rlen) < p.avg_qual_req) return 20;
+        else if (nb > p.n_base_limit) return 12;
+    }
+    if (p.length_filter) {
+        if (rlen < p.length_required) return 16;
+        if (p.length_limit > 0 && rlen > p.length_limit) return 17;
+    }
+    if (p.complexity_filter) {
+        if (rlen <= 1) return 24;
+        if (diff < cmin_v) return 24;
+    }
+    return 0;
+}
+
+// phase_filter_pe without merge mode, written for latency: two wavefronts run this phase while fourteen wait, and a
+// lane's LDS reads were a chain of ~12 round trips because the stores in between pin their order.  Here everything
+// the pair needs is read first (independent loads: one round trip), then the two LUT rows, then it is all registers.
+FQ_DEV void phase_filter_pe_plain(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    u32* misc = lds + L.acc_misc;
+    for (int pr = tid; pr < L.P; pr += nthreads) {
+        const int gp = tile_first + pr;
+        if (gp >= a.n) continue;
+        const int R1 = pr, R2 = L.P + pr;
+        int* flags = lds_i(lds, L.flags);
+        int f1 = flags[R1], f2 = flags[R2];
+        const u32 ma1 = lds[L.met + 2 * R1], mb1 = lds[L.met + 2 * R1 + 1];
+        const u32 ma2 = lds[L.met + 2 * R2], mb2 = lds[L.met + 2 * R2 + 1];
+        const int len1 = lds_i(lds, L.len)[R1], len2 = lds_i(lds, L.len)[R2];
+        const u32 front1 = (u32)lds_i(lds, L.front)[R1], front2 = (u32)lds_i(lds, L.front)[R2];
+        const u32 rl1 = (u32)lds_i(lds, L.rlen0)[R1], rl2 = (u32)lds_i(lds, L.rlen0)[R2];
+        const u32 apos1 = (u32)lds_i(lds, L.apos)[R1], apos2 = (u32)lds_i(lds, L.apos)[R2];
+        const u32 alen1 = (u32)lds_i(lds, L.alen)[R1], alen2 = (u32)lds_i(lds, L.alen)[R2];
+        write_dup_pos(a, lds, pr, gp);   // LDS reads + global stores only
+        const u16* lowq = (const u16*)(lds + L.lut_lowq);
+        const u16* cmin = (const u16*)(lds + L.lut_cplx);
+        const int lq1 = lowq[len1], lq2 = lowq[len2], cm1 = cmin[len1], cm2 = cmin[len2];
+        const bool a1 = !(f1 & RS_NULL), a2 = !(f2 & RS_NULL);
+        int code1 = a1 ? filter_code_pre(p, len1, (int)(ma1 & 0xFFFFu), (int)(ma1 >> 16), (int)(mb1 & 0xFFFFu), (int)(mb1 >> 16), lq1, cm1) : 16;
+        int code2 = a2 ? filter_code_pre(p, len2, (int)(ma2 & 0xFFFFu), (int)(ma2 >> 16), (int)(mb2 & 0xFFFFu), (int)(mb2 >> 16), lq2, cm2) : 16;
+        if (f1 & RS_DIMER) { code1 = 28; code2 = 28; }     // :568-571
+        lds_add_u32(&misc[MISC_FILTER + imax(code1, code2)], 2u);  // addFilterResult(max, 2) :573
+        const bool dedup_out = p.dedup && (f1 & RS_DUP);
+        if (!dedup_out && a1 && a2 && code1 == 0 && code2 == 0) {   // written to out1 / out2 (:577-591)
+            f1 |= RS_STAT_POST;
+            f2 |= RS_STAT_POST;
+            flags[R1] = f1;
+            flags[R2] = f2;
+        }
+        lds_i(lds, L.code)[R1] = code1;
+        lds_i(lds, L.code)[R2] = code2;
+        lds[L.swin + R1] = rl1 | ((f1 & RS_STAT_POST) ? (u32)len1 << 16 : 0u);
+        lds[L.swin + R2] = rl2 | ((f2 & RS_STAT_POST) ? (u32)len2 << 16 : 0u);
+        u32* o1 = a.res[0] + (size_t)gp * 3;
+        u32* o2 = a.res[1] + (size_t)gp * 3;
+        o1[0] = (front1 & 0xFFFFu) | ((u32)len1 << 16);
+        o1[1] = ((u32)code1 & 0xFFu) | (((u32)f1 & 0xFFu) << 8) | (apos1 << 16);
+        o1[2] = alen1 & 0xFFFFu;
+        o2[0] = (front2 & 0xFFFFu) | ((u32)len2 << 16);
+        o2[1] = ((u32)code2 & 0xFFu) | (((u32)f2 & 0xFFu) << 8) | (apos2 << 16);
+        o2[2] = alen2 & 0xFFFFu;
+    }
+}
+
 FQ_DEV void phase_filter_pe(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
@@ -2118,7 +2199,8 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
         tile_sync(a, lds, nt);
         FQ_STAMP(9)
         if (!(skip & 32u)) {
-            if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
+            if (a.p.paired && !a.p.merge) phase_filter_pe_plain(a, lds, tile_first, tid, nt);
+            else if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
             else phase_filter_se(a, lds, tile_first, tid, nt);
         }
         tile_sync(a, lds, nt);
