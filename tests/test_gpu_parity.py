@@ -763,6 +763,16 @@ def test_gpu_bgzf_inflate_equals_zlib(level, strategy):
     g.close()
 
 
+@pytest.mark.parametrize("variant", ["wave", "lane"])
+def test_gpu_bgzf_inflate_survives_corruption(variant, monkeypatch):
+    """200 corrupted chunks through either inflate kernel: errors or (CRC off) different text, never a write outside
+    the output, never an accept with the CRC check on, and the GPU stays alive"""
+    import format_util
+    import test_hostsim_parity as hs
+    monkeypatch.setenv("FASTP_GPU_INFLATE", variant)
+    hs._corruption_case(engines.gpu_engine, format_util.TorchMem(), 3000, 0xff00, 200, 100)
+
+
 def test_gpu_file_pipeline_reads_bgzf(tmp_path):
     """the same pipeline fed BGZF-compressed inputs (inflated on the device): same output files, same counters"""
     import bgzf_util
