@@ -405,6 +405,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DefLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IwLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4));
@@ -624,7 +625,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
                   !env_int("FASTP_GPU_NO_PREFETCH", 0);
         const void* ptrs[4] = {b->seq1, b->qual1, ctx->dp.paired ? b->seq2 : b->seq1, ctx->dp.paired ? b->qual2 : b->qual1};
         for (const void* q : ptrs) ok = ok && (((uintptr_t)q & 15u) == 0);
-        a.prefetch = ok ? (env_int("FASTP_GPU_PREFETCH_AHEAD", 1) ? 1 : 2) : 0;
+        // the L2 warm-up of the next tile (tile_warm) is off by default: it paid while the tile fetch waited per chunk,
+        // now it costs 2.5 % and makes every line cross HBM 1.35 times (profiles/r02p_prefetch_ab.txt)
+        a.prefetch = ok ? (env_int("FASTP_GPU_PREFETCH_AHEAD", 0) ? 1 : 2) : 0;
     }
     a.n = n;
     a.first = first;
@@ -1476,7 +1479,7 @@ extern "C" int fastp_gpu_deflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* text, i
         a.out = out;
         a.out_base = written;
         a.out_cap = (u64)out_capacity;
-        const int grid = std::min(a.nblocks, ctx->cus * 8);
+        const int grid = std::min(a.nblocks, ctx->cus * std::max(1, (160 * 1024) / (int)sizeof(DefLds)));
         hipLaunchKernelGGL(fq_deflate_kernel, dim3(grid), dim3(64), sizeof(DefLds), st, a);
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(fq_deflate_scan_kernel, dim3(1), dim3(1024), 1024 * 8, st, a);

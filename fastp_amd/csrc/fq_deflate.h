@@ -26,6 +26,7 @@ enum {
     DEF_SLOT = 65536 + 64,        // scratch bytes per member; the member starts at +2 so its DEFLATE stream is dword aligned
     DEF_HASH_BITS = 13,
     DEF_WIN = 256,                // LDS bit window, dwords
+    DEF_PROBE = 36,               // bytes a lane compares for its own candidate
     DEF_NLL = 288, DEF_ND = 32, DEF_NCL = 20
 };
 
@@ -264,6 +265,9 @@ FQ_DEV void def_flush(DefLds& S, u32* stream, u32 old_cur, u32 new_cur, int lane
 FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
     const u64 start = (u64)blk * DEF_BLOCK;
     const u32 n = (u32)(a.nbytes - start < (u64)DEF_BLOCK ? a.nbytes - start : (u64)DEF_BLOCK);
+    // (Staging the block's text in LDS was measured and dropped: 93 KB per block leaves one wavefront per CU, and a
+    // single wavefront's time is set by instruction latency either way - 3.5 ms per block against 4.1 from global memory
+    // with five blocks per CU in flight.)
     const u8* in = a.text + start;
     u8* member = a.slots + (size_t)blk * DEF_SLOT + 2;
     u32* stream = (u32*)(member + 18);
@@ -282,17 +286,24 @@ FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
         const u32 p = base + (u32)lane;
         const u32 cnt = n - base < 64u ? n - base : 64u;
         u32 mlen = 0, mdist = 0, h = 0xFFFFFFFFu;
+        // A lane compares at most DEF_PROBE bytes: in FASTQ text most positions sit inside long matches (names, quality
+        // runs) that an earlier position takes, so full-length compares by all 64 lanes were most of the kernel's time.
+        // The match that is actually chosen is extended by the whole wave below.
+        u32 maxl = 0;
         if ((u32)lane < cnt && p + 4u <= n) {
             h = (def_ld4(in + p) * 2654435761u) >> (32 - DEF_HASH_BITS);
-            const u32 c = S.head[h];
-            const u32 maxl = n - p < 258u ? n - p : 258u;
-            if (c != 0xFFFFu && p - c <= 32768u) {
-                const u32 l = def_match(in + p, in + c, maxl);
-                if (l >= 4u || (l == 3u && p - c < 4096u)) { mlen = l; mdist = p - c; }
-            }
-            if (p >= 1u) {
-                const u32 l = def_match(in + p, in + p - 1, maxl);
-                if (l >= 3u && l >= mlen) { mlen = l; mdist = 1u; }
+            if ((u32)lane >= carry) {   // positions an earlier match covers only feed the hash table
+                const u32 c = S.head[h];
+                maxl = n - p < 258u ? n - p : 258u;
+                const u32 probe = maxl < (u32)DEF_PROBE ? maxl : (u32)DEF_PROBE;
+                if (c != 0xFFFFu && p - c <= 32768u) {
+                    const u32 l = def_match(in + p, in + c, probe);
+                    if (l >= 4u || (l == 3u && p - c < 4096u)) { mlen = l; mdist = p - c; }
+                }
+                if (p >= 1u) {
+                    const u32 l = def_match(in + p, in + p - 1, probe);
+                    if (l >= 3u && l > mlen) { mlen = l; mdist = 1u; }
+                }
             }
         }
         wave_sync();   // every lookup before any insert of this step
@@ -312,7 +323,22 @@ FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
             const u32 j = (u32)ffs64(m) - 1u;
             starts |= (~0ull << pos) & ((2ull << j) - 1ull);   // literals [pos, j) and the match at j
             mstart |= 1ull << j;
-            pos = j + shfl(mlen, (int)j);
+            u32 L = shfl(mlen, (int)j);
+            const u32 mx = shfl(maxl, (int)j);
+            if (L >= (u32)DEF_PROBE && L < mx) {   // the probe was cut short: 64 more bytes per step, all lanes
+                const u32 pj = base + j, dj = shfl(mdist, (int)j);
+                const u8* t = in;
+                while (L < mx) {
+                    const u32 k = L + (u32)lane;
+                    const u64 eq = ballot(k < mx && t[pj + k] == t[pj - dj + k]);
+                    const u32 run = ~eq ? (u32)ffs64(~eq) - 1u : 64u;
+                    L += run;
+                    if (run < 64u) break;
+                }
+                if (L > mx) L = mx;
+                if ((u32)lane == j) mlen = L;
+            }
+            pos = j + L;
         }
         carry = pos >= 64u ? pos - 64u : 0u;
         if ((starts >> lane) & 1ull) {
@@ -417,12 +443,14 @@ FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
         cur = shfl(cur, 0);
         def_flush(S, stream, 0, cur, lane);
         // ---- tokens, 64 per step, then the end-of-block code ----
+        u32 t_next = (u32)lane < ntok ? tok[lane] : 0u;   // the next step's tokens are in flight while this step's bits are placed
         for (u32 t0 = 0; t0 <= ntok; t0 += 64u) {
             const u32 i = t0 + (u32)lane;
             u64 bits = 0;
             u32 nb = 0;
+            const u32 t = t_next;
+            t_next = i + 64u < ntok ? tok[i + 64u] : 0u;
             if (i < ntok) {
-                const u32 t = tok[i];
                 if (!(t & 0x80000000u)) {
                     const u32 c = S.code_ll[t];
                     bits = c & 0xFFFFu;
