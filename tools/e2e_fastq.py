@@ -15,6 +15,7 @@ ap.add_argument("--chunk-mib", type=int, default=256)
 ap.add_argument("--no-ref", action="store_true")
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--bgzf", action="store_true", help="feed the GPU pipeline BGZF-compressed copies of the inputs (inflated on the device)")
+ap.add_argument("--gz-out", action="store_true", help="a second pipeline run that also writes failed_out and compresses every output on the device (.gz)")
 args = ap.parse_args()
 L = 150
 dev = torch.device("cuda", 0)
@@ -61,6 +62,21 @@ ctr, lay = pl.counters(), pl.eng.layout
 pl.close()
 print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()}), flush=True)
 print(f"GPU pipeline: {2*st['units']/st['wall']/1e6:.2f} Mreads/s end to end (wall {st['wall']:.2f}s)", flush=True)
+if args.gz_out:
+    pl = pipeline.FastqPipeline(p, chunk_bytes=args.chunk_mib << 20)
+    st2 = pl.run(g_in[0], g_in[1], tmp + "/z1.fq.gz", tmp + "/z2.fq.gz", failed_out=tmp + "/zf.fq.gz")
+    pl.close()
+    print(json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in st2.items()}), flush=True)
+    zs = [os.path.getsize(tmp + f"/{n}") for n in ("z1.fq.gz", "z2.fq.gz", "zf.fq.gz")]
+    print(f"GPU pipeline, out1/out2/failed_out compressed on the device: {2*st2['units']/st2['wall']/1e6:.2f} Mreads/s end to end "
+          f"(wall {st2['wall']:.2f}s); {st2['bytes_text']} bytes of text -> {sum(zs)} bytes of BGZF (ratio {sum(zs)/st2['bytes_text']:.3f}), "
+          f"device deflate {st2['t_deflate']:.2f}s", flush=True)
+    t0 = time.time()
+    ok = []
+    for m in (1, 2):
+        a = subprocess.run(f"gzip -dc {tmp}/z{m}.fq.gz | cmp -s - {tmp}/g{m}.fq", shell=True)
+        ok.append(a.returncode == 0)
+    print(f"gzip -dc of the device-compressed out1 / out2 == the plain outputs: {ok} (checked in {time.time()-t0:.1f}s)", flush=True)
 ref = ROOT + "/oracle/_ref/fastp_ref"
 if os.path.exists(ref) and not args.no_ref:
     cores = min(os.cpu_count() or 1, args.threads)
