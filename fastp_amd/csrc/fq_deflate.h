@@ -24,7 +24,7 @@ namespace fq {
 enum {
     DEF_BLOCK = 65280,            // text bytes per member (bgzip's own block size: 0xff00)
     DEF_SLOT = 65536 + 64,        // scratch bytes per member; the member starts at +2 so its DEFLATE stream is dword aligned
-    DEF_HASH_BITS = 13,
+    DEF_HASH_BITS = 12,           // 8 KB of LDS: ~19 KB per block in all, eight blocks per CU in flight
     DEF_WIN = 256,                // LDS bit window, dwords
     DEF_PROBE = 36,               // bytes a lane compares for its own candidate
     DEF_NLL = 288, DEF_ND = 32, DEF_NCL = 20
@@ -71,13 +71,18 @@ FQ_DEV u32 def_ld4(const u8* p) {
 FQ_DEV int def_ctz32(u32 v) { return ffs32(v) - 1; }
 FQ_DEV int def_log2(u32 v) { return 31 - clz32(v); }
 
-// bytes two positions have in common, at most maxl (both readable for maxl bytes)
+// bytes two positions have in common, at most maxl (both readable for maxl bytes); eight bytes per dependent step
+FQ_DEV u64 def_ld8(const u8* p) {
+    u64 w;
+    __builtin_memcpy(&w, p, 8);
+    return w;
+}
 FQ_DEV u32 def_match(const u8* a, const u8* b, u32 maxl) {
     u32 l = 0;
-    while (l + 4u <= maxl) {
-        const u32 x = def_ld4(a + l) ^ def_ld4(b + l);
-        if (x) return l + (u32)(def_ctz32(x) >> 3);
-        l += 4u;
+    while (l + 8u <= maxl) {
+        const u64 x = def_ld8(a + l) ^ def_ld8(b + l);
+        if (x) return l + (u32)((ffs64(x) - 1) >> 3);
+        l += 8u;
     }
     while (l < maxl && a[l] == b[l]) l++;
     return l;
@@ -328,12 +333,22 @@ FQ_DEV void deflate_block(const DeflateArgs& a, DefLds& S, int blk, int lane) {
             if (L >= (u32)DEF_PROBE && L < mx) {   // the probe was cut short: 64 more bytes per step, all lanes
                 const u32 pj = base + j, dj = shfl(mdist, (int)j);
                 const u8* t = in;
-                while (L < mx) {
-                    const u32 k = L + (u32)lane;
-                    const u64 eq = ballot(k < mx && t[pj + k] == t[pj - dj + k]);
-                    const u32 run = ~eq ? (u32)ffs64(~eq) - 1u : 64u;
-                    L += run;
-                    if (run < 64u) break;
+                while (L < mx) {   // 4 bytes per lane: one step covers what is left of a 258-byte match
+                    const u32 k = L + 4u * (u32)lane;
+                    u32 same = 0;   // bytes of this lane's dword that match (from its low end), capped by mx
+                    if (k < mx) {
+                        const u32 lim = mx - k < 4u ? mx - k : 4u;
+                        if (lim == 4u) {
+                            const u32 x = def_ld4(t + pj + k) ^ def_ld4(t + pj - dj + k);
+                            same = x ? (u32)(def_ctz32(x) >> 3) : 4u;
+                        } else {
+                            while (same < lim && t[pj + k + same] == t[pj - dj + k + same]) same++;
+                        }
+                    }
+                    const u64 stop = ballot(same < 4u);          // lanes where the match ends (or the limit is)
+                    const u32 f = stop ? (u32)ffs64(stop) - 1u : 64u;
+                    L += 4u * f + (f < 64u ? shfl(same, (int)f) : 0u);
+                    if (f < 64u) break;
                 }
                 if (L > mx) L = mx;
                 if ((u32)lane == j) mlen = L;

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 1500 python tools/e2e_fastq.py --pairs 20000000 --threads 16 --gz-out > gpurun_out/e2e_r02.log 2>&1; echo "e2e rc=$?"; cat gpurun_out/e2e_r02.log | grep -v amdgpu.ids
+timeout 600 python tools/aux_bench.py 400000 2>&1 | grep -i "deflate\|ratio"
+timeout 600 python tools/aux_bench.py 2000000 2>&1 | grep -i "deflate\|ratio"
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "deflate or all_streams_and_gzip" 2>&1 | tail -3
