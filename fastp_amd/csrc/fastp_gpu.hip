@@ -117,6 +117,12 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs 
 }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
+extern "C" __global__ void __launch_bounds__(256) fq_dup_claim_kernel(DupArgs d) { dup_claim_body(d); }
+extern "C" __global__ void __launch_bounds__(256) fq_dup_winners_kernel(DupArgs d) { dup_winners_body(d); }
+extern "C" __global__ void __launch_bounds__(1024) fq_dup_finish_kernel(DupArgs d) {
+    extern __shared__ u32 fq_lds[];
+    dup_finish_body(d, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(1024) fq_dup_resolve_kernel(DupArgs d) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];  // 1 dword: the workgroup's duplicate count
     dup_resolve_body(d, fq_lds);
@@ -168,6 +174,8 @@ struct fastp_gpu_ctx {
     u64* d_dup_pos = nullptr; size_t dup_pos_cap = 0;
     u64* d_table = nullptr; size_t table_cap = 0;
     u8* d_need = nullptr; size_t need_cap = 0;
+    u8* d_setw = nullptr; size_t setw_cap = 0;
+    u32* d_cfilter = nullptr;
     u8* d_dupflag = nullptr; size_t dupflag_cap = 0;   // --dedup: per-unit duplicate decision
     u32* d_prefix = nullptr;                           // sharded runs: OR of the preceding shards' bitmaps
     bool has_prefix = false;
@@ -255,7 +263,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -730,9 +738,24 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         d.ctr_dups = ctx->d_ctr + cl.dup_count;
         HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
         const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
-        hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
+        if (env_int("FASTP_GPU_DUP_TABLE", 0)) {      // the first form: probe (read + table insert for every unit) -> resolve
+            hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
+            HIP_TRY(ctx, hipGetLastError());
+            hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
+            HIP_TRY(ctx, hipGetLastError());
+            return 0;
+        }
+        r2 = ensure(ctx, (void**)&ctx->d_setw, &ctx->setw_cap, (size_t)n);
+        if (r2) return r2;
+        if (!ctx->d_cfilter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cfilter, (size_t)1 << (DUP_CF_LOG2 - 3)));
+        d.setw = ctx->d_setw;
+        d.cfilter = ctx->d_cfilter;
+        HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), st));
+        hipLaunchKernelGGL(fq_dup_claim_kernel, dim3(g2), dim3(256), 0, st, d);
         HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(fq_dup_resolve_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
+        hipLaunchKernelGGL(fq_dup_winners_kernel, dim3(g2), dim3(256), 0, st, d);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(fq_dup_finish_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };

@@ -2389,6 +2389,9 @@ struct DupArgs {
     // buffers an earlier unit of this stream had set; no decision, no counters
     u64* scan_pos;        // [n][B]
     u8* scan_mask;        // [n]
+    // claim / winners / finish form (dup_claim_body ...)
+    u8* setw;             // [n] buffers a unit claimed but that turn out to have had an earlier unit of this launch
+    u32* cfilter;         // 2^DUP_CF_LOG2 bits: keys some unit of this launch lost (a one-hash Bloom filter in front of the table)
 };
 
 // sharded runs, pass 2: the decision from the scan state and the preceding shards' bitmaps
@@ -2502,6 +2505,138 @@ FQ_DEV void dup_resolve_body(const DupArgs& d, u32* block_count) {
         }
         // one same-address device atomic per WORKGROUP (they serialize at ~10 ns each): lanes -> ballot,
         // waves -> LDS counter, workgroup -> global
+        const u64 m = ballot(is_dup);
+        if (lane_id() == 0 && m) lds_add_u32(block_count, (u32)popc64(m));
+    }
+    block_sync();
+    if (d.scan_mask) return;
+    if (thread_id() == 0 && *block_count) g_atomic_add_i64(d.ctr_dups, (int64_t)*block_count);
+    if (gid == 0) g_atomic_add_i64(d.ctr_total, (int64_t)d.n);
+}
+
+// ---------------------------------------------------------------------------
+// The same sequential semantics with one scattered atomic per (unit, buffer) instead of four scattered accesses:
+//   claim   : old = atomic_or(bit).  Exactly one unit of the launch sees a clear bit - it WON the bit (in execution
+//             order, which is not input order).  A unit that lost registers (bit -> its index, min) in the table
+//             and marks the key in a small filter; on fresh data almost nobody loses.
+//   winners : a unit that won looks its key up only when the filter says somebody lost it: if the smallest loser
+//             is earlier in the input than the winner, the winner was not first - it counts the bit as set, and
+//             flags the table entry so that the smallest loser knows it was.
+//   finish  : a lost bit counts as set unless the unit is the smallest loser of a flagged entry (it was first; a
+//             bit set before this launch has no winner, hence no flag).  Then Duplicate's decision as before.
+// Per bit with same-launch units S and input-order first g1: every unit of S \ {g1} ends with "set", g1 with
+// "set" iff the bit was set before the launch - what the sequential loop gives (duplicate.cpp:122-163).
+// ---------------------------------------------------------------------------
+enum { DUP_CF_LOG2 = 23 };
+constexpr u64 DUP_FLAG = 1ull << 63;
+FQ_DEV u32 dup_cf_bit(u64 key) { return (u32)((key * 0xD6E8FEB86659FD93ull) >> (64 - DUP_CF_LOG2)); }
+
+FQ_DEV void dup_claim_body(const DupArgs& d) {
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    const u64 words = d.bits >> 5;
+    const u32 tmask = (1u << d.table_log2) - 1u;
+    for (int g = gid; g < d.n; g += gstride) {
+        u32 won = 0;
+        for (int i = 0; i < d.B; i++) {
+            const u64 pos = dup_bit(d, g, i);
+            if (d.scan_pos) d.scan_pos[(size_t)g * d.B + i] = pos;
+            const u32 bit = 1u << (pos & 31);
+            const u32 old = g_atomic_or_u32(&d.bitmap[(size_t)i * words + (pos >> 5)], bit);
+            if (!(old & bit)) {
+                won |= 1u << i;
+                continue;
+            }
+            const u64 key = dup_key(i, pos);
+            const u32 cf = dup_cf_bit(key);
+            g_atomic_or_u32(&d.cfilter[cf >> 5], 1u << (cf & 31));
+            const u64 entry = (key << DUP_IDX_BITS) | (u64)g;
+            u32 slot = dup_slot(key, d.table_log2);
+            for (;;) {
+                u64 cur = g_atomic_cas_u64(&d.table[slot], ~0ull, entry);
+                if (cur == ~0ull) break;
+                if ((cur >> DUP_IDX_BITS) == key) {
+                    g_atomic_min_u64(&d.table[slot], entry);
+                    break;
+                }
+                slot = (slot + 1) & tmask;
+            }
+        }
+        d.need[g] = (u8)won;
+    }
+}
+
+// the table entry of `key`, or ~0 when nobody lost it
+FQ_DEV u64 dup_find(const DupArgs& d, u64 key, u32& slot_out) {
+    const u32 tmask = (1u << d.table_log2) - 1u;
+    u32 slot = dup_slot(key, d.table_log2);
+    for (;;) {
+        const u64 cur = d.table[slot];
+        if (cur == ~0ull) return ~0ull;
+        if (((cur & ~DUP_FLAG) >> DUP_IDX_BITS) == key) {
+            slot_out = slot;
+            return cur;
+        }
+        slot = (slot + 1) & tmask;
+    }
+}
+
+FQ_DEV void dup_winners_body(const DupArgs& d) {
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    for (int g = gid; g < d.n; g += gstride) {
+        const u32 won = d.need[g];
+        u32 setw = 0;
+        for (int i = 0; i < d.B; i++) {
+            if (!((won >> i) & 1u)) continue;
+            const u64 key = dup_key(i, dup_bit(d, g, i));
+            const u32 cf = dup_cf_bit(key);
+            if (!((d.cfilter[cf >> 5] >> (cf & 31)) & 1u)) continue;   // nobody lost this bit
+            u32 slot = 0;
+            const u64 e = dup_find(d, key, slot);
+            if (e == ~0ull) continue;                                   // a filter collision
+            if ((int)(e & ((1ull << DUP_IDX_BITS) - 1)) < g) {
+                setw |= 1u << i;
+                __hip_atomic_fetch_or(&d.table[slot], DUP_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        d.setw[g] = (u8)setw;
+    }
+}
+
+FQ_DEV void dup_finish_body(const DupArgs& d, u32* block_count) {
+    if (thread_id() == 0) *block_count = 0;
+    block_sync();
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    const int rounds = (d.n + gstride - 1) / gstride;
+    const u32 all = (1u << d.B) - 1u;
+    for (int it = 0; it < rounds; it++) {
+        const int g = gid + it * gstride;
+        bool is_dup = false;
+        if (g < d.n) {
+            const u32 won = d.need[g];
+            u32 set_before = d.setw[g];
+            u32 lost = all & ~won;
+            while (lost) {
+                const int i = ffs32(lost) - 1;
+                lost &= lost - 1u;
+                u32 slot = 0;
+                const u64 e = dup_find(d, dup_key(i, dup_bit(d, g, i)), slot);
+                const bool first = (int)(e & ((1ull << DUP_IDX_BITS) - 1)) == g && (e & DUP_FLAG);
+                if (!first) set_before |= 1u << i;
+            }
+            is_dup = set_before == all;
+            if (d.scan_mask) {
+                d.scan_mask[g] = (u8)set_before;
+                is_dup = false;  // pass 1 decides nothing
+            } else if (d.dupflag) {
+                d.dupflag[g] = is_dup ? 1 : 0;
+            } else if (is_dup) {
+                d.res[0][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+                if (d.paired) d.res[1][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+            }
+        }
         const u64 m = ballot(is_dup);
         if (lane_id() == 0 && m) lds_add_u32(block_count, (u32)popc64(m));
     }

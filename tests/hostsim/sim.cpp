@@ -178,7 +178,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     g_bdim = {block.x, 1, 1};
     g_gdim = {grid.x, 1, 1};
     g_body = &body;
-    for (unsigned b = 0; b < grid.x; b++) {
+    // FASTP_SIM_REVERSE_BLOCKS: workgroups run last to first (execution order != index order, as on a GPU)
+    const bool reverse = getenv("FASTP_SIM_REVERSE_BLOCKS") != nullptr;
+    for (unsigned bi = 0; bi < grid.x; bi++) {
+        const unsigned b = reverse ? grid.x - 1 - bi : bi;
         g_block = {b, 0, 0};
         memset(fq_lds, 0xA5, shmem);  // LDS is NOT zero on entry
         for (int t = 0; t < T; t++) th[t].tid = {(unsigned)t, 0, 0};

@@ -45,6 +45,32 @@ def test_sim_records_and_counters_equal_oracle(name):
     assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
 
 
+@pytest.mark.parametrize("name,table", [("pe_noadapter_dedup", 0), ("pe_default", 0), ("se_default_noadapter", 0), ("pe_noadapter_dedup", 1)])
+def test_sim_duplicates_when_workgroups_run_out_of_order(name, table, monkeypatch):
+    """Duplicate's decision must not depend on which unit reaches a bloom bit first: the emulator runs the workgroups last
+    to first, so the unit that wins a bit is usually NOT the first in input order (the winners / finish kernels have to
+    flip it); many planted duplicates, several launches.  table=1: the first (probe / resolve) form of the kernels."""
+    monkeypatch.setenv("FASTP_SIM_REVERSE_BLOCKS", "1")
+    monkeypatch.setenv("FASTP_GPU_MAX_TILES_PER_BLOCK", "2")
+    if table:
+        monkeypatch.setenv("FASTP_GPU_DUP_TABLE", "1")
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(2400, L=150, seed=31, paired=paired, **skw)
+    rng = np.random.default_rng(32)     # exact copies of earlier units (sequencing noise makes the generator's own rare)
+    dst = rng.choice(np.arange(1, 2400), size=800, replace=False)
+    src = (rng.random(800) * dst).astype(np.int64)
+    for k in d:
+        d[k][dst] = d[k][src]
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    ro, rg, co, cg = _both(params, d, paired)
+    dups = int((ro[0]["flags"] & abi.RF_DUP != 0).sum())
+    assert dups > 100, dups
+    for k in range(3):
+        if ro[k] is not None:
+            assert np.array_equal(ro[k], rg[k]), f"{name}: records {k} differ"
+    assert np.array_equal(co, cg)
+
+
 @pytest.mark.parametrize("level,L,paired", [(1, 150, True), (3, 150, True), (1, 37, True), (1, 250, True), (1, 150, False), (-3, 100, True)])
 def test_sim_duplicate_hash_bit_positions_equal_oracle(level, L, paired, monkeypatch):
     """the hash itself (Duplicate::seq2intvector mod mBufLenInBits), not only the decisions it leads to: every
