@@ -118,6 +118,7 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs 
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_claim_kernel(DupArgs d) { dup_claim_body(d); }
+extern "C" __global__ void __launch_bounds__(256) fq_dup_losers_kernel(DupArgs d) { dup_losers_body(d); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_winners_kernel(DupArgs d) { dup_winners_body(d); }
 extern "C" __global__ void __launch_bounds__(1024) fq_dup_finish_kernel(DupArgs d) {
     extern __shared__ u32 fq_lds[];
@@ -708,7 +709,12 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     int rc;
 
     // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
-    auto launch_dup = [&](u8* dupflag, bool scan = false, hipStream_t st = nullptr) -> int {
+    // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers, the context's own stream order
+    const bool claim_fused = ctx->dp.dup_enabled && !ctx->dp.dedup && mode == CHUNK_STREAM && !piped && ctx->dp.dup_bufnum <= 2 &&
+                             !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1);
+    bool dup_prepared = false;
+    auto launch_dup = [&](u8* dupflag, bool scan = false, hipStream_t st = nullptr, int stage = 0) -> int {
+        // stage 0: everything; 1: only the buffers + clears (before a fused kernel that claims); 2: what follows that kernel
         if (!st) st = st_main;
         DupArgs d;
         memset(&d, 0, sizeof(d));
@@ -736,7 +742,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         d.paired = ctx->dp.paired;
         d.ctr_total = ctx->d_ctr + cl.dup_total;
         d.ctr_dups = ctx->d_ctr + cl.dup_count;
-        HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
+        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
         const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
         if (env_int("FASTP_GPU_DUP_TABLE", 0)) {      // the first form: probe (read + table insert for every unit) -> resolve
             hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
@@ -750,8 +756,16 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (!ctx->d_cfilter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cfilter, (size_t)1 << (DUP_CF_LOG2 - 3)));
         d.setw = ctx->d_setw;
         d.cfilter = ctx->d_cfilter;
-        HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), st));
-        hipLaunchKernelGGL(fq_dup_claim_kernel, dim3(g2), dim3(256), 0, st, d);
+        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), st));
+        if (stage == 1) {
+            a.claim_won = ctx->d_need;
+            a.dup_bitmap = ctx->d_bitmap;
+            a.dup_bits = ctx->dp.dup_bits;
+            dup_prepared = true;
+            return 0;
+        }
+        if (stage == 2) hipLaunchKernelGGL(fq_dup_losers_kernel, dim3(g2), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL(fq_dup_claim_kernel, dim3(g2), dim3(256), 0, st, d);
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(fq_dup_winners_kernel, dim3(g2), dim3(256), 0, st, d);
         HIP_TRY(ctx, hipGetLastError());
@@ -803,6 +817,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         a.dupflag = ctx->d_dupflag;
     }
 
+    if (claim_fused) {
+        rc = launch_dup(nullptr, false, nullptr, 1);
+        if (rc) return rc;
+    }
     hipEvent_t e0, e1;
     rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
@@ -851,7 +869,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         ctx->last_res[1] = (const char*)a.res[0] + (size_t)n * sizeof(fastp_gpu_read_result);
         ctx->launch_seq++;
     } else if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
-        rc = launch_dup(nullptr, mode == CHUNK_PASS1);
+        rc = launch_dup(nullptr, mode == CHUNK_PASS1, nullptr, dup_prepared ? 2 : 0);
         if (rc) return rc;
     }
     if (b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) return FASTP_GPU_OK;

@@ -2075,6 +2075,43 @@ FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int t
 // bound by the LDS pipe (Stats), by latency (the per-read / per-pair phases, the barriers) or by memory (staging),
 // the other one's VALU-bound phases (overlap, hash, masks, metrics) have the SIMDs.  The accumulators are shared:
 // both halves add to the same LDS counters.
+// Duplicate's claim step (see dup_claim_body) issued from inside the fused kernel: the unit's thread fires the
+// atomic_or of its one or two bloom bits at the start of the metrics phase and looks at what they returned only after
+// the filter phase, so the device-scope atomics' latency hides behind two phases of other work.  `raw` keeps the
+// returned words and the bit numbers; nothing is decided here.
+struct ClaimRegs {
+    u32 old0, old1, shifts;   // shifts: bit number of buffer 0 | buffer 1 << 8 | valid << 16
+};
+FQ_DEV void dup_claim_issue(const KernelArgs& a, u32* lds, int tile_first, int tid, ClaimRegs& c) {   // tid = unit of the tile
+    const LdsLayout& L = a.L;
+    const DevParams& p = a.p;
+    c.old0 = c.old1 = c.shifts = 0;
+    const int gp = tile_first + tid;
+    if (tid < 0 || tid >= L.P || gp >= a.n) return;
+    const int B = p.dup_bufnum;   // 1 or 2 here
+    int tl = lds_i(lds, L.rlen0)[tid];
+    if (p.paired) tl += lds_i(lds, L.rlen0)[L.P + tid];
+    const u64* h1 = (const u64*)(lds + L.hash) + (size_t)tid * B;
+    const u64* h2 = (const u64*)(lds + L.hash) + (size_t)(L.P + tid) * B;
+    const u64 words = a.dup_bits >> 5;
+    u64 h = h1[0] + (p.paired ? h2[0] : 0ull) + a.lut.dup_posum[(size_t)tl * B];
+    u64 pos = h & (a.dup_bits - 1);
+    c.shifts = (u32)(pos & 31) | (1u << 16);
+    c.old0 = g_atomic_or_u32(&a.dup_bitmap[pos >> 5], 1u << (pos & 31));
+    if (B > 1) {
+        h = h1[1] + (p.paired ? h2[1] : 0ull) + a.lut.dup_posum[(size_t)tl * B + 1];
+        pos = h & (a.dup_bits - 1);
+        c.shifts |= (u32)(pos & 31) << 8;
+        c.old1 = g_atomic_or_u32(&a.dup_bitmap[words + (pos >> 5)], 1u << (pos & 31));
+    }
+}
+FQ_DEV void dup_claim_collect(const KernelArgs& a, int tile_first, int tid, const ClaimRegs& c) {
+    if (!(c.shifts >> 16)) return;
+    u32 won = ((c.old0 >> (c.shifts & 31u)) & 1u) ^ 1u;
+    if (a.p.dup_bufnum > 1) won |= (((c.old1 >> ((c.shifts >> 8) & 31u)) & 1u) ^ 1u) << 1;
+    a.claim_won[tile_first + tid] = (u8)won;
+}
+
 FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
     const int tid0 = thread_id(), nt0 = block_threads();
     const KernelArgs& a0 = fa.h[0];
@@ -2170,6 +2207,12 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
         if (!(skip & 2u)) phase_hash(a, lds, tid, nt);
         tile_sync(a, lds, nt);
         FQ_STAMP(1)
+        // Duplicate's claim: fired here by threads that idle through the thin phases (trim runs on the first NR lanes), the
+        // hash values are final since the last barrier; collected after the filter phase
+        ClaimRegs claim;
+        claim.shifts = 0;
+        const int claim_unit = tid - (nt >= 2 * L.NR ? nt - L.P : 0);
+        if (a.claim_won) dup_claim_issue(a, lds, tile_first, claim_unit, claim);
         if (!(skip & 32u)) phase_trim(a, lds, tile_first, tid, nt);
         tile_sync(a, lds, nt);
         FQ_STAMP(2)
@@ -2203,6 +2246,7 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
             else if (a.p.paired) phase_filter_pe(a, lds, tile_first, tid, nt);
             else phase_filter_se(a, lds, tile_first, tid, nt);
         }
+        if (a.claim_won) dup_claim_collect(a, tile_first, claim_unit, claim);
         tile_sync(a, lds, nt);
         FQ_STAMP(6)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
@@ -2563,6 +2607,35 @@ FQ_DEV void dup_claim_body(const DupArgs& d) {
             }
         }
         d.need[g] = (u8)won;
+    }
+}
+
+// after a launch whose fused kernel did the claiming: the units that lost a bit register in the table and the filter
+FQ_DEV void dup_losers_body(const DupArgs& d) {
+    const int gid = block_id() * block_threads() + thread_id();
+    const int gstride = grid_blocks() * block_threads();
+    const u32 tmask = (1u << d.table_log2) - 1u;
+    const u32 all = (1u << d.B) - 1u;
+    for (int g = gid; g < d.n; g += gstride) {
+        u32 lost = all & ~(u32)d.need[g];
+        while (lost) {
+            const int i = ffs32(lost) - 1;
+            lost &= lost - 1u;
+            const u64 key = dup_key(i, dup_bit(d, g, i));
+            const u32 cf = dup_cf_bit(key);
+            g_atomic_or_u32(&d.cfilter[cf >> 5], 1u << (cf & 31));
+            const u64 entry = (key << DUP_IDX_BITS) | (u64)g;
+            u32 slot = dup_slot(key, d.table_log2);
+            for (;;) {
+                u64 cur = g_atomic_cas_u64(&d.table[slot], ~0ull, entry);
+                if (cur == ~0ull) break;
+                if ((cur >> DUP_IDX_BITS) == key) {
+                    g_atomic_min_u64(&d.table[slot], entry);
+                    break;
+                }
+                slot = (slot + 1) & tmask;
+            }
+        }
     }
 }
 

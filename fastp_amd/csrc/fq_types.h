@@ -318,6 +318,10 @@ struct KernelArgs {
     int adapter_events_capacity;
     int* n_adapter_events;
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
+    // the claim step of Duplicate inside this kernel (dup_claim_issue; plain stream mode, at most two buffers):
+    u8* claim_won;      // [n] or null: mask of the buffers whose bloom bit this unit found clear and set
+    u32* dup_bitmap;    // [bufnum][dup_bits / 32]
+    u64 dup_bits;       // mBufLenInBits
     const u8* dupflag;  // [n] --dedup: the duplicate decision, taken by the dup kernels BEFORE this launch
     u64* phase_cycles;  // optional [16]: cycles per phase summed over workgroups (debug)
     int half_skew;      // half 1 starts this many ~3 us sleeps late, so the halves sit in different phases
