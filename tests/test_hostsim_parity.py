@@ -431,6 +431,52 @@ def test_sim_device_all_streams_umi_prefix_crlf_and_overflow():
     g.close()
 
 
+def _odd_records(mate, rng, n=160):
+    """hand-made records: names with no / one / several spaces, strand lines that repeat the name, reads of length 0..40
+    (shorter than the UMI, shorter than the filters), N runs"""
+    out = []
+    for i in range(n):
+        L = int(rng.integers(0, 41)) if i % 3 else int(rng.integers(0, 4))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        qual = bytes(rng.integers(35, 75, size=L, dtype=np.uint8))
+        name = [b"@r%d" % i, b"@r%d %d:N:0:ACGT" % (i, mate), b"@r%d  two  spaces %d" % (i, mate), b"@%d/%d" % (i, mate)][i % 4]
+        strand = b"+" if i % 5 else b"+" + name[1:]
+        out.append(name + b"\n" + seq + b"\n" + strand + b"\n" + qual + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("paired,umi", [(True, ("per_read", 6)), (True, ("read2", 3)), (False, ("read1", 5)), (True, None), (False, None)])
+def test_sim_device_all_streams_on_odd_records(paired, umi):
+    """the stream formatter on records a generator does not make: empty reads, names without a space, strand lines that
+    carry the name, UMIs longer than the read - against the host writer (hostloop.apply_results)"""
+    import format_util
+    from fastp_amd import hostloop
+    rng = np.random.default_rng(17)
+    fq1 = _odd_records(1, rng)
+    fq2 = _odd_records(2, rng) if paired else None
+    p = abi.default_params(paired, 48)
+    p.length_required = 8
+    p.cut_right = 1
+    if umi is not None:
+        if umi[0] in ("read1", "per_read"):
+            p.umi_len1 = umi[1]
+        if paired and umi[0] in ("read2", "per_read"):
+            p.umi_len2 = umi[1]
+    editor = hostloop.UmiNameEditor(*umi) if umi else None
+    ref = engines.sim_engine(p)
+    want, _, _ = driver.run_engine(ref, p, fq1, fq2, pack=1000, stride=abi.qual_stride(48), want_failed=True, want_unpaired=paired,
+                                   umi=editor)
+    ref.close()
+    g = engines.sim_engine(p)
+    rc, got, lens = format_util.run_streams(g, format_util.NumpyMem(), p, fq1, fq2, 48, True, paired, umi)
+    g.close()
+    assert rc == 0
+    for k in format_util.STREAMS:
+        w = getattr(want, k, None)
+        assert got[k] == (bytes(w) if w is not None else b""), f"stream {k} differs"
+    assert len(got["failed"]) > 0 and sum(len(v) for v in got.values()) > 2000
+
+
 def _eval_rows(mem, eng, fq: bytes, max_len):
     """text -> fastp_gpu_parse_fastq -> packed rows in `mem` (what the Evaluator entry points read)"""
     ss, qs = abi.seq_stride(max_len), abi.qual_stride(max_len)
