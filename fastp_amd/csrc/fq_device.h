@@ -2320,7 +2320,10 @@ struct ReduceArgs {
 // sums to the int64 counters with device atomics.
 // One-pass Stats mode: the POST slots hold "kept", the PRE slots "dropped": a kept element is
 // added to its own (POST) Stats and to the PRE Stats of the same mate.
-enum { REDUCE_GROUP = 16 };
+#ifndef FQ_REDUCE_GROUP
+#define FQ_REDUCE_GROUP 64   // 16: 0.050 ms per fold of 256 slabs (16-way contention on every counter), 64: see profiles/r02t
+#endif
+enum { REDUCE_GROUP = FQ_REDUCE_GROUP };
 
 FQ_DEV void reduce_body(const ReduceArgs& r) {
     const LdsLayout& L = r.L;
