@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/r02t -o trace -- python bench.py --steps 48 --warmup 4 --no-cpu 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'])"
-grep "^fq_\|^\"fq_" gpurun_out/prof/r02t/trace_kernel_stats.csv | cut -c1-110
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_final.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_final.log
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
+timeout 900 python bench.py > gpurun_out/bench_final.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench_final.log | cut -c1-200
