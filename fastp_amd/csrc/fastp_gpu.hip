@@ -1544,6 +1544,42 @@ extern "C" int fastp_gpu_deflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* text, i
     return FASTP_GPU_OK;
 }
 
+extern "C" int fastp_gpu_device_alloc(fastp_gpu_ctx* ctx, int64_t bytes, void** dev_ptr) {
+    if (!ctx || !dev_ptr || bytes < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    *dev_ptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(dev_ptr, (size_t)std::max<int64_t>(bytes, 16)) != hipSuccess) {
+        *dev_ptr = nullptr;
+        return fail(ctx, FASTP_GPU_E_NOMEM, "hipMalloc failed");
+    }
+    return FASTP_GPU_OK;
+}
+extern "C" int fastp_gpu_device_free(fastp_gpu_ctx* ctx, void* dev_ptr) {
+    if (!ctx) return FASTP_GPU_E_INVALID;
+    if (!dev_ptr) return FASTP_GPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
+    HIP_TRY(ctx, hipFree(dev_ptr));
+    return FASTP_GPU_OK;
+}
+extern "C" int fastp_gpu_device_upload(fastp_gpu_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes > 0 && (!dst_dev || !src_host))) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    if (bytes == 0) return FASTP_GPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
+    return FASTP_GPU_OK;
+}
+extern "C" int fastp_gpu_device_download(fastp_gpu_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    if (bytes == 0) return FASTP_GPU_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rj_ = join_aux(ctx, ctx->stream); if (rj_) return rj_; }
+    HIP_TRY(ctx, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
+    return FASTP_GPU_OK;
+}
+
 extern "C" int fastp_gpu_synchronize(fastp_gpu_ctx* ctx) {
     if (!ctx) return FASTP_GPU_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -440,6 +440,16 @@ int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_form
                              uint8_t* const out[FASTP_GPU_N_OUTPUTS], const int64_t out_capacity[FASTP_GPU_N_OUTPUTS],
                              int64_t out_len[FASTP_GPU_N_OUTPUTS] /* host: bytes written (needed) per stream */);
 
+/* ---- device memory for callers that do not link the HIP runtime themselves ----------------
+ * The entry points that take DEVICE pointers (submit_device, parse / format / deflate / inflate, eval_*)
+ * are meant for hosts that manage HBM with HIP; a host that does not (the reference is plain C++ built
+ * with g++) gets the four calls it needs from the engine.  Synchronous; pointers are hipMalloc'ed memory
+ * on the context's device. */
+int fastp_gpu_device_alloc(fastp_gpu_ctx* ctx, int64_t bytes, void** dev_ptr);
+int fastp_gpu_device_free(fastp_gpu_ctx* ctx, void* dev_ptr);
+int fastp_gpu_device_upload(fastp_gpu_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int fastp_gpu_device_download(fastp_gpu_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+
 /* ---- output text -> gzip members ON THE DEVICE (second half) -----------
  * The reference's .gz outputs: every worker compresses its pack as one independent gzip member
  * (libdeflate_gzip_compress, src/writer.cpp:110-133) and the members land at ordered offsets

@@ -2,8 +2,8 @@
 # Build oracle/_ref/fastp_ref_gpu: the REAL reference (OpenGene/fastp v1.3.6) with its two worker-loop bodies
 # bound to libfastp_gpu.so (TEST INFRASTRUCTURE - the drop-in boundary exercised end to end).
 #
-# Every reference source is compiled where it lies under /root/reference/src, except peprocessor.cpp and
-# seprocessor.cpp, of which patched copies are generated into oracle/_ref/src_gpu/ (git-ignored) by
+# Every reference source is compiled where it lies under /root/reference/src, except peprocessor.cpp,
+# seprocessor.cpp and evaluator.cpp, of which patched copies are generated into oracle/_ref/src_gpu/ (git-ignored) by
 # oracle/patches/apply_gpu_worker.py: four inserted lines that call oracle/patches/gpu_worker.cpp.
 # Same shims as build_ref.sh (scalar simd, ISA-L stub).  Needs fastp_amd/libfastp_gpu.so (__graft_entry__.build()).
 set -euo pipefail
@@ -26,7 +26,7 @@ for f in "$REF"/src/*.cpp; do
     b=$(basename "$f" .cpp)
     [ "$b" = simd ] && continue
     src=$f
-    { [ "$b" = peprocessor ] || [ "$b" = seprocessor ]; } && src=$GEN/$b.cpp
+    { [ "$b" = peprocessor ] || [ "$b" = seprocessor ] || [ "$b" = evaluator ]; } && src=$GEN/$b.cpp
     o=$OBJ/$b.o
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$HERE/patches/gpu_worker.h" -nt "$o" ]; then
         $CXX $CXXFLAGS -c "$src" -o "$o" &

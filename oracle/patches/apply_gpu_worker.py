@@ -3,7 +3,7 @@
 
     apply_gpu_worker.py <reference root> <output dir>
 
-Writes <output dir>/peprocessor.cpp and seprocessor.cpp: the reference's files with four one-line insertions,
+Writes <output dir>/peprocessor.cpp, seprocessor.cpp and evaluator.cpp: the reference's files with five one-line insertions,
 each placed by an anchor (the function signature / the comment that opens the merge of the per-thread results).
 Nothing else of the reference is touched or reproduced here; every other source is compiled where it lies.
 """
@@ -39,4 +39,8 @@ patch("seprocessor.cpp", [
     (r"[ \t]*// merge stats and read filter results",
      "    fastp_gpu_worker_finish_se(this, configs);   // engine counters -> Stats / FilterResult / Duplicate\n", "before"),
 ])
-print("patched peprocessor.cpp, seprocessor.cpp ->", out)
+patch("evaluator.cpp", [
+    (r"void Evaluator::computeOverRepSeq\(string filename, map<string, long>& hotseqs, int seqlen\)\s*\{",
+     "\n    if(fastp_gpu_worker_overrep(filename, hotseqs, seqlen) > 0) return;   // counted on the device (FASTP_GPU=1)\n", "after"),
+])
+print("patched peprocessor.cpp, seprocessor.cpp, evaluator.cpp ->", out)

@@ -43,6 +43,7 @@
 #include "src/options.h"
 #include "src/read.h"
 #include "src/util.h"
+#include "src/fastqreader.h"
 #undef private
 #undef protected
 
@@ -415,4 +416,69 @@ void fastp_gpu_worker_finish_se(SingleEndProcessor* sp, ThreadConfig** configs) 
         sp->mDuplicate->mDupReads += (unsigned long)c[G->lay.dup_count];
     }
     shutdown();
+}
+
+// Evaluator::computeOverRepSeq (evaluator.cpp:78-169) with the counting on the device: the reads are taken from the
+// file with the reference's own FastqReader and its own stopping rule, packed, and handed to fastp_gpu_eval_overrep
+// (thresholds and the "remove substrings" pass are inside it).  A temporary single-end engine provides the context:
+// the run's engine does not exist yet when the Evaluator runs.
+int fastp_gpu_worker_overrep(const std::string& filename, std::map<std::string, long>& hotseqs, int seqlen) {
+    if (!enabled() || seqlen < 1) return -1;
+    std::vector<Read*> reads;
+    {
+        FastqReader reader(filename);
+        const long BASE_LIMIT = 151 * 10000;
+        long bases = 0;
+        while (bases < BASE_LIMIT) {
+            Read* r = reader.read();
+            if (!r) break;
+            bases += r->length();
+            reads.push_back(r);
+        }
+    }
+    auto drop = [&] { for (Read* r : reads) delete r; };
+    const int n = (int)reads.size();
+    int max_len = 1;
+    for (Read* r : reads) max_len = std::max(max_len, r->length());
+    if (n == 0 || max_len > 65535) { drop(); return -1; }
+    const size_t ss = fastp_gpu_seq_stride(max_len), qs = fastp_gpu_qual_stride(max_len);
+    std::vector<uint8_t> seq((size_t)n * ss), qual((size_t)n * qs);
+    std::vector<uint16_t> len((size_t)n);
+    {
+        std::vector<const char*> sp((size_t)n), qp((size_t)n);
+        std::vector<int32_t> ln((size_t)n);
+        for (int i = 0; i < n; i++) { sp[i] = reads[i]->mSeq->data(); qp[i] = reads[i]->mQuality->data(); ln[i] = reads[i]->length(); }
+        int32_t bad = -1;
+        const int rc = fastp_gpu_pack_reads(max_len, n, sp.data(), qp.data(), ln.data(), seq.data(), qual.data(), len.data(), &bad);
+        drop();
+        if (rc != FASTP_GPU_OK) return -1;   // a letter outside ACGTN: the reference's own loop handles the file
+    }
+    fastp_gpu_params prm;
+    fastp_gpu_default_params(&prm, 0, max_len);
+    prm.dup_enabled = 0;   // no bloom bitmaps for this short-lived context
+    fastp_gpu_ctx* ctx = nullptr;
+    if (fastp_gpu_create(&prm, 0, &ctx) != FASTP_GPU_OK) return -1;
+    void *d_seq = nullptr, *d_qual = nullptr, *d_len = nullptr;
+    int rc = fastp_gpu_device_alloc(ctx, (int64_t)seq.size(), &d_seq);
+    if (!rc) rc = fastp_gpu_device_alloc(ctx, (int64_t)qual.size(), &d_qual);
+    if (!rc) rc = fastp_gpu_device_alloc(ctx, (int64_t)len.size() * 2, &d_len);
+    if (!rc) rc = fastp_gpu_device_upload(ctx, d_seq, seq.data(), (int64_t)seq.size());
+    if (!rc) rc = fastp_gpu_device_upload(ctx, d_qual, qual.data(), (int64_t)qual.size());
+    if (!rc) rc = fastp_gpu_device_upload(ctx, d_len, len.data(), (int64_t)len.size() * 2);
+    int32_t n_seqs = 0;
+    const int32_t max_seqs = 1 << 16;
+    std::vector<char> text((size_t)8 << 20);
+    std::vector<int64_t> off((size_t)max_seqs + 1), cnt((size_t)max_seqs);
+    if (!rc)
+        rc = fastp_gpu_eval_overrep(ctx, (const uint8_t*)d_seq, (const uint8_t*)d_qual, (const uint16_t*)d_len, n, seqlen, text.data(),
+                                    (int64_t)text.size(), off.data(), cnt.data(), max_seqs, &n_seqs);
+    fastp_gpu_device_free(ctx, d_seq);
+    fastp_gpu_device_free(ctx, d_qual);
+    fastp_gpu_device_free(ctx, d_len);
+    fastp_gpu_destroy(ctx);
+    if (rc != FASTP_GPU_OK) return -1;
+    hotseqs.clear();
+    for (int i = 0; i < n_seqs; i++) hotseqs[std::string(text.data() + off[i], (size_t)(off[i + 1] - off[i]))] = (long)cnt[i];
+    if (getenv("FASTP_GPU_VERBOSE")) fprintf(stderr, "fastp_gpu: computeOverRepSeq on the device: %d reads, %d sequences\n", n, (int)n_seqs);
+    return 1;
 }

@@ -3,14 +3,17 @@
 // oracle/build_ref_gpu.sh so that the drop-in boundary is exercised end to end: fastp's own CLI, reader and writer
 // threads, Stats / FilterResult objects and JSON / HTML reporters around the engine).
 //
-// oracle/patches/apply_gpu_worker.py inserts three one-line calls into copies of the reference's sources:
+// oracle/patches/apply_gpu_worker.py inserts one-line calls into copies of the reference's sources:
 //   src/peprocessor.cpp  top of PairEndProcessor::processPairEnd   -> fastp_gpu_worker_pe
 //   src/seprocessor.cpp  top of SingleEndProcessor::processSingleEnd -> fastp_gpu_worker_se
 //   both                 before "merge stats" in ::process()        -> fastp_gpu_worker_finish_pe / _se
+//   src/evaluator.cpp    top of Evaluator::computeOverRepSeq         -> fastp_gpu_worker_overrep
 // The engine is used when the environment has FASTP_GPU=1; otherwise the hooks return "not handled" and the
 // reference's own loop runs.
 #ifndef FASTP_GPU_WORKER_H
 #define FASTP_GPU_WORKER_H
+#include <map>
+#include <string>
 
 class PairEndProcessor;
 class SingleEndProcessor;
@@ -26,5 +29,7 @@ int fastp_gpu_worker_se(SingleEndProcessor* p, ReadPack* pack, ThreadConfig* con
 // the insert-size histogram, right before the reference merges them and writes its reports
 void fastp_gpu_worker_finish_pe(PairEndProcessor* p, ThreadConfig** configs);
 void fastp_gpu_worker_finish_se(SingleEndProcessor* p, ThreadConfig** configs);
+// Evaluator::computeOverRepSeq (-p) through fastp_gpu_eval_overrep: 1 = hotseqs filled by the engine, -1 = not handled
+int fastp_gpu_worker_overrep(const std::string& filename, std::map<std::string, long>& hotseqs, int seqlen);
 
 #endif

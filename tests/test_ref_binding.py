@@ -77,6 +77,7 @@ def _run(binary, tmp, tag, flags, paired, gpu_env):
     files = {fn: open(os.path.join(out, fn), "rb").read() for fn in sorted(os.listdir(out)) if fn.endswith(".fq")}
     rep = json.load(open(os.path.join(out, "r.json")))
     rep.pop("command", None)
+    rep["__stderr__"] = p.stderr.decode(errors="replace")
     return files, rep
 
 
@@ -113,7 +114,13 @@ def _check(name, binary, n, tmp_path, seed):
             with open(os.path.join(tmp, tag, fn), "wb") as f:
                 f.write(content)
     want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {})
-    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, {"FASTP_GPU": "1"})
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"})
+    err = got_rep.pop("__stderr__")
+    want_rep.pop("__stderr__")
+    if "overrep" in name:   # -p: the Evaluator's substring census ran on the device too (fastp_gpu_eval_overrep)
+        assert err.count("computeOverRepSeq on the device") == (2 if paired else 1), err[-800:]
+        if n >= 10000:   # (600 reads do not reach the count thresholds: both sides then agree on "none")
+            assert len(want_rep["read1_before_filtering"]["overrepresented_sequences"]) > 0
     assert sorted(want_files) == sorted(got_files)
     for fn in want_files:
         assert want_files[fn] == got_files[fn], f"{name}: {fn} differs ({len(want_files[fn])} vs {len(got_files[fn])} bytes)"

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 400 python tools/dup_forms_check.py 5 4194304 > gpurun_out/dup_forms.log 2>&1; echo "rc=$?"; grep -v amdgpu gpurun_out/dup_forms.log | tail -6
+timeout 600 python -m pytest tests/test_ref_binding.py tests/test_abi.py -m gpu -x -q -k "overrep or abi or pe_default or se_adapter" 2>&1 | tail -4
