@@ -552,6 +552,37 @@ def test_sim_evaluator_prepass_equals_port():
     g.close()
 
 
+def test_sim_evaluator_prepass_short_and_empty_inputs():
+    """reads shorter than the step lengths / than position 20, seq_len so small that min(150, seq_len - 2) <= 0, no reads"""
+    import format_util
+    from fastp_amd import hostloop
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(300):
+        L = int(rng.integers(0, 26))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=L, p=[0.3, 0.3, 0.2, 0.15, 0.05]))
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"I" * L + b"\n")
+    recs += [b"@poly%d\n" % i + b"ACGTACGTACGTAC" + b"\n+\n" + b"I" * 14 + b"\n" for i in range(600)]   # a hot 10-mer family
+    fq = b"".join(recs)
+    g = engines.sim_engine(abi.default_params(False, 32))
+    mem = format_util.NumpyMem()
+    seq, qual, lens, nrec = _eval_rows(mem, g, fq, 32)
+    b = hostloop.parse_fastq(fq, abi.qual_stride(32))
+    for seqlen in (1, 2, 11, 12, 14, 25):
+        rc, got = g.eval_overrep(mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), nrec, seqlen)
+        want = evalport.evaluate_overrep_counts(b, seqlen)
+        assert dict(got) == want and [s for s, _ in got] == sorted(want), seqlen
+    assert any(len(s) == 10 for s, _ in got)
+    counts = mem.alloc(4 << 20, 0x11)
+    rec = g.eval_adapter_kmers(mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), nrec, 0, mem.ptr(counts))
+    wc, wrec = evalport.adapter_kmer_counts(b, 0)
+    assert rec == wrec and np.array_equal(np.frombuffer(mem.download(counts), dtype=np.uint32)[:1 << 20], wc)
+    assert g.eval_seq_len(mem.ptr(lens), 0) == 0
+    rc, got = g.eval_overrep(mem.ptr(seq), mem.ptr(qual), mem.ptr(lens), 0, 25)
+    assert rc == 0 and got == []
+    g.close()
+
+
 def _inflate(eng, mem, comp: bytes, check_crc=True, max_blocks=100000, check=True):
     """BGZF bytes -> text through fastp_gpu_bgzf_index (host) + fastp_gpu_inflate_bgzf (device)"""
     host = np.frombuffer(comp, dtype=np.uint8)
