@@ -631,6 +631,46 @@ def test_sim_bgzf_inflate_lane_variant(monkeypatch):
     assert rc == 0 and bad == -1 and got == text
 
 
+@pytest.mark.parametrize("variant", ["wave", "lane"])
+def test_sim_bgzf_inflate_members_with_several_deflate_blocks(variant, monkeypatch):
+    """a member whose DEFLATE stream is a chain of blocks of every kind: dynamic, fixed (Z_FIXED pieces), stored (level 0
+    pieces), empty stored blocks (sync flushes) - matches that reach back across block borders included"""
+    import struct
+    import zlib
+    import format_util
+    monkeypatch.setenv("FASTP_GPU_INFLATE", variant)
+    text = _se_fastq_text(160, 9)[:50000]
+    members = []
+    for start in range(0, len(text), 25000):
+        data = text[start:start + 25000]
+        payload = b""
+        c = None
+        cuts = [0, 3000, 3001, 9000, 15000, 15002, len(data)]
+        for k in range(len(cuts) - 1):
+            level, strat = [(6, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY),
+                            (1, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY)][k]
+            if c is None:
+                c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strat)
+            piece = data[cuts[k]:cuts[k + 1]]
+            payload += c.compress(piece)
+            payload += c.flush(zlib.Z_SYNC_FLUSH if k % 2 else zlib.Z_FULL_FLUSH)   # ends the block, adds an empty stored one
+            # the next piece continues the same stream (window kept after a sync flush) with other parameters
+            c2 = zlib.compressobj([0, 6, 9, 1, 6, 6][k], zlib.DEFLATED, -15, 9, [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_DEFAULT_STRATEGY,
+                                                                                 zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY, zlib.Z_DEFAULT_STRATEGY][k],
+                                  zdict=data[max(0, cuts[k + 1] - 32768):cuts[k + 1]]) if cuts[k + 1] > 0 and k + 1 < len(cuts) - 1 else None
+            c = c2 if c2 is not None else c
+        payload += c.flush(zlib.Z_FINISH)
+        assert zlib.decompress(payload, -15) == data
+        bsize = 18 + len(payload) + 8
+        hdr = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        members.append(hdr + payload + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+    comp = b"".join(members)
+    g = engines.sim_engine(abi.default_params(False, 150))
+    info, rc, bad, got = _inflate(g, format_util.NumpyMem(), comp)
+    g.close()
+    assert rc == 0 and bad == -1 and got == text and info.n_blocks == 2
+
+
 def test_sim_bgzf_index_chunks_and_errors():
     import bgzf_util
     import format_util
