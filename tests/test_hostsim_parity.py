@@ -764,7 +764,7 @@ def _corruption_case(mk_engine, mem, n_reads, block_bytes, trials, min_errors):
 
 def test_sim_bgzf_inflate_survives_corruption():
     import format_util
-    _corruption_case(engines.sim_engine, format_util.NumpyMem(), 120, 15000, 24, 12)   # the GPU suite runs 200 trials
+    _corruption_case(engines.sim_engine, format_util.NumpyMem(), 120, 15000, 24, 12)   # the GPU suite runs 120 trials on full-size blocks
 
 
 def _deflate(eng, mem, text: bytes, eof=False, cap=None):

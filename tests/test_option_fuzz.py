@@ -121,6 +121,6 @@ def test_sim_random_option_sets_equal_oracle(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(40, 100))
+@pytest.mark.parametrize("seed", range(40, 85))
 def test_gpu_random_option_sets_equal_oracle(seed):
     _check(engines.gpu_engine, seed)
