@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "fq_device.h"
+#include "fq_stats.h"
 #include "fq_inflate.h"
 #include "fq_eval.h"
 #include "fq_deflate.h"
@@ -26,7 +27,16 @@ extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(FusedArgs a) 
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     // read the argument block through the kernarg segment pointer (scalar loads where a field is
     // used) instead of holding all ~150 dwords in SGPRs for the whole persistent loop
-    fused_body(*kernel_args(&a), fq_lds);
+    fused_body<false>(*kernel_args(&a), fq_lds);
+}
+// the per-read kernel of the split plan: 256-lane workgroups, four to a CU (fq_stats_kernel counts afterwards)
+extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    fused_body<true>(*kernel_args(&a), fq_lds);
+}
+extern "C" __global__ void __launch_bounds__(1024) fq_stats_kernel(StatsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    stats_body(a, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -146,6 +156,13 @@ struct fastp_gpu_ctx {
     int cus = 0;
     int blocks = 0;           // persistent workgroups per launch
     int max_pairs_per_launch = 0;
+    // split plan (fq_stats.h): the per-read kernel as small workgroups, Stats::statRead as its own streaming kernel
+    bool split = false;
+    int st_threads = 0, st_blocks = 0;     // the Stats kernel's workgroup size and the most workgroups it is launched with
+    int st_H = 0, st_lds_dwords = 0, st_slab_dwords = 0;
+    int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0;
+    u32* d_st_slabs = nullptr;
+    u32* d_swin[2] = {nullptr, nullptr}; size_t swin_cap = 0;
     hipStream_t stream = nullptr;
     // Duplicate's probe + resolve of launch k run beside the fused kernel of launch k + 1 (see launch_chunk): the fused
     // kernel holds every VGPR of the CUs it sits on, so the pair of streams is confined to disjoint CU sets
@@ -264,7 +281,8 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
-                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter};
+                    ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
+                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -311,14 +329,18 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     ctx->cus = prop.multiProcessorCount;
     // tile / launch geometry (tunable without a rebuild)
     const int lds_kb_default = (int)(prop.sharedMemPerBlock / 1024) >= 160 ? 160 : (int)(prop.sharedMemPerBlock / 1024);
-    ctx->cfg.threads = env_int("FASTP_GPU_THREADS", 1024);
+    // The split plan (per-read kernel as 256-lane workgroups, several per CU, + the streaming Stats kernel) whenever no
+    // option moves or edits a kept base; FASTP_GPU_SPLIT=0 keeps Stats inside the one-workgroup-per-CU fused kernel.
+    ctx->split = ctx->dp.stats_one_pass && env_int("FASTP_GPU_SPLIT", 1) != 0;
+    ctx->cfg.split = ctx->split ? 1 : 0;
+    ctx->cfg.threads = env_int("FASTP_GPU_THREADS", ctx->split ? 256 : 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
-    ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", lds_kb_default) * 1024;
+    ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", ctx->split ? std::min(40, lds_kb_default) : lds_kb_default) * 1024;
     // two tiles in flight per workgroup (each half of the waves owns one) when the halves are whole wavefronts
     ctx->cfg.halves = (env_int("FASTP_GPU_HALVES", 1) == 2 && ctx->cfg.threads % 128 == 0) ? 2 : 1;
-    if (ctx->cfg.threads < 64 || ctx->cfg.threads > 1024 || (ctx->cfg.threads & 63)) {
+    if (ctx->cfg.threads < 64 || ctx->cfg.threads > (ctx->split ? 256 : 1024) || (ctx->cfg.threads & 63)) {
         delete ctx;
-        return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024");
+        return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024 (64..256 in the split plan)");
     }
     if (env_int("FASTP_GPU_HASH_GENERIC", 0)) {  // tests: the multiply form of the duplicate hash (what B = 8 uses)
         ctx->luts.dup_planes.clear();
@@ -329,17 +351,54 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->cfg.halves = 1;
         rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
     }
+    if (rc && ctx->split && ctx->cfg.P == 0 && !getenv("FASTP_GPU_LDS_KB")) {  // long reads: the small budget holds no tile
+        ctx->cfg.lds_budget = lds_kb_default * 1024;
+        rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
+    }
     if (rc) { delete ctx; return fail(nullptr, rc, err); }
-    const int blocks_per_cu = env_int("FASTP_GPU_BLOCKS_PER_CU", std::max(1, (int)((160 * 1024) / (ctx->L.total * 4))));
-    ctx->blocks = ctx->cus * std::max(1, blocks_per_cu);
+    int blocks_per_cu = env_int("FASTP_GPU_BLOCKS_PER_CU", std::max(1, (int)((160 * 1024) / (ctx->L.total * 4))));
+    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 2048 / ctx->cfg.threads));   // 32 wavefronts per CU
+#ifndef FQ_HOSTSIM
+    if (!getenv("FASTP_GPU_BLOCKS_PER_CU")) {
+        // persistent workgroups: the grid must not exceed what is resident at once (registers bound it, not only LDS)
+        int nb = 0;
+        const void* kfn = ctx->split ? (const void*)fq_scan_kernel : (const void*)fq_fused_kernel;
+        (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, ctx->cfg.threads, (size_t)ctx->L.total * 4) == hipSuccess && nb > 0)
+            blocks_per_cu = std::min(blocks_per_cu, nb);
+        (void)hipGetLastError();
+    }
+#endif
+    ctx->blocks = ctx->cus * blocks_per_cu;
     // a workgroup's packed per-cycle counters hold CYC_MAX_READS reads per Stats slot
     int tiles_per_block = CYC_MAX_READS / ctx->L.P;
     const int cap_tiles = env_int("FASTP_GPU_MAX_TILES_PER_BLOCK", 0);  // tests: force several launches
     if (cap_tiles > 0 && cap_tiles < tiles_per_block) tiles_per_block = cap_tiles;
     if (ctx->cfg.halves == 2 && tiles_per_block > 1) tiles_per_block &= ~1;  // a workgroup's two halves take tiles in pairs
     if (tiles_per_block < 1) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "tile too large for the packed counters"); }
+    if (ctx->split) {
+        // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
+        ctx->st_H = ctx->dp.qw_g / 2;
+        int o = 0;
+        ctx->st_l_cyc = o; o += 4 * 8 * N_CLS * ctx->st_H * 2;
+        ctx->st_l_kmer = o; o += 4 * KMER_BINS;
+        ctx->st_l_qh = o; o += 4 * 128;
+        ctx->st_l_lut = o; o += 2 * 128;
+        ctx->st_lds_dwords = o;
+        ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
+        ctx->st_threads = env_int("FASTP_GPU_STATS_THREADS", 512);
+        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63)) ctx->st_threads = 512;
+        if (ctx->st_lds_dwords * 4 > (int)prop.sharedMemPerBlock) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "reads too long for the Stats kernel's LDS"); }
+        int st_per_cu = std::min(2048 / ctx->st_threads, (int)((160 * 1024) / (ctx->st_lds_dwords * 4)));
+        st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));
+        ctx->st_blocks = ctx->cus * std::max(1, st_per_cu);
+    }
     auto set_launch_size = [&]() {
         long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
+        if (ctx->split) {   // the per-read kernel has no packed counters; a Stats workgroup takes <= CYC_MAX_READS units
+            mp = (long long)ctx->st_blocks * CYC_MAX_READS;
+            if (cap_tiles > 0) mp = std::min(mp, (long long)ctx->blocks * cap_tiles * ctx->L.P);
+        }
         if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
         mp = mp / ctx->L.P * ctx->L.P;
         ctx->max_pairs_per_launch = (int)mp;
@@ -347,8 +406,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     set_launch_size();
     fastp_gpu_counter_layout_for_params(&ctx->params, &ctx->cl);
     if (env_int("FASTP_GPU_VERBOSE", 0))
-        fprintf(stderr, "fastp_gpu: tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch\n", ctx->L.P,
-                ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks, ctx->max_pairs_per_launch);
+        fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel %d x %d threads, LDS %d bytes\n",
+                ctx->split ? "split plan" : "fused plan", ctx->L.P, ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks,
+                ctx->max_pairs_per_launch, ctx->st_blocks, ctx->st_threads, ctx->st_lds_dwords * 4);
     ctx->slab_dwords = ctx->L.acc_end - ctx->L.acc_cyc;
 
     *out = ctx;  // from here on errors go through destroy
@@ -411,8 +471,12 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         }
     }
-    CREATE_TRY(hipFuncSetAttribute((const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    CREATE_TRY(hipFuncSetAttribute(ctx->split ? (const void*)fq_scan_kernel : (const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    if (ctx->split) {
+        CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
+        CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_blocks * ctx->st_slab_dwords * 4));
+    }
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DefLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IwLds)));
@@ -693,6 +757,20 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         }
         a.dup_pos = dup_pos_buf;
     }
+    a.split = ctx->split ? 1 : 0;
+    if (ctx->split) {
+        const size_t need = ((size_t)n * 4 + 255) & ~(size_t)255;
+        if (need > ctx->swin_cap) {
+            for (int m = 0; m < 2; m++) {
+                if (ctx->d_swin[m]) HIP_TRY(ctx, hipFree(ctx->d_swin[m]));
+                ctx->d_swin[m] = nullptr;
+                HIP_TRY(ctx, hipMalloc((void**)&ctx->d_swin[m], need + need / 4));
+            }
+            ctx->swin_cap = need + need / 4;
+        }
+        a.swin_out[0] = ctx->d_swin[0];
+        a.swin_out[1] = ctx->d_swin[1];
+    }
     a.phase_cycles = ctx->d_phase;
     a.debug_skip = (u32)env_int("FASTP_GPU_DEBUG_SKIP", 0);
     a.slabs = ctx->d_slabs;
@@ -830,17 +908,46 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         fa.h[0] = a;
         fa.h[1] = a;
         fa.h[1].L = layout_for_half(a.L, 1);
-        hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
+        if (ctx->split) hipLaunchKernelGGL(fq_scan_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
+        else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
     }
     HIP_TRY(ctx, hipGetLastError());
+    int st_grid = 0;
+    if (ctx->split && n > 0) {
+        // Stats::statRead of the launch's units: a workgroup takes a run of consecutive units (at most CYC_MAX_READS:
+        // packed counters; at least 64 so that small launches do not pay a 43 KB slab per handful of reads)
+        StatsArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.n = n;
+        sa.paired = ctx->dp.paired;
+        sa.sw_g = ctx->dp.sw_g;
+        sa.qw_g = ctx->dp.qw_g;
+        sa.H = ctx->st_H;
+        sa.magic_H = magic_for((u32)ctx->st_H);
+        sa.Cp = ctx->L.Cp;
+        int upb = (n + ctx->st_blocks - 1) / ctx->st_blocks;
+        upb = std::max(upb, std::min(n, 64));
+        if (upb > CYC_MAX_READS) return fail(ctx, FASTP_GPU_E_INVALID, "launch too large for the Stats kernel");
+        sa.units_per_block = upb;
+        st_grid = (n + upb - 1) / upb;
+        for (int m = 0; m < 2; m++) { sa.seq[m] = a.seq[m]; sa.qual[m] = a.qual[m]; sa.swin[m] = ctx->d_swin[m]; }
+        sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut;
+        sa.l_total = ctx->st_lds_dwords;
+        sa.slabs = ctx->d_st_slabs;
+        sa.slab_dwords = ctx->st_slab_dwords;
+        sa.debug_skip = a.debug_skip;
+        if (!(a.debug_skip & 16u)) {
+            hipLaunchKernelGGL(fq_stats_kernel, dim3(st_grid), dim3(ctx->st_threads), (size_t)ctx->st_lds_dwords * 4, st, sa);
+            HIP_TRY(ctx, hipGetLastError());
+        } else {
+            st_grid = 0;
+        }
+    }
     HIP_TRY(ctx, hipEventRecord(e1, st));
     ctx->pending_events.push_back({e0, e1});
 
     ReduceArgs r;
     memset(&r, 0, sizeof(r));
-    r.slabs = ctx->d_slabs;
-    r.slab_dwords = ctx->slab_dwords;
-    r.nblocks = grid;
     r.L = ctx->L;
     r.isize_max = ctx->dp.isize_max;
     r.one_pass = ctx->dp.stats_one_pass;
@@ -851,10 +958,44 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
     r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
     r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
-    const int items = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128 * QT_DWORDS + MISC_ISIZE + ctx->dp.isize_max + 1;
-    const int rgroups = (grid + REDUCE_GROUP - 1) / REDUCE_GROUP;
-    hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
-    HIP_TRY(ctx, hipGetLastError());
+    const int n_stats = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128, n_misc = MISC_ISIZE + ctx->dp.isize_max + 1;
+    auto fold = [&](int parts, int nblocks) -> int {
+        if (nblocks <= 0) return 0;
+        r.parts = parts;
+        r.nblocks = nblocks;
+        const int items = ((parts & 1) ? n_stats : 0) + ((parts & 2) ? n_misc : 0);
+        const int rgroups = (nblocks + REDUCE_GROUP - 1) / REDUCE_GROUP;
+        hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
+    if (ctx->split) {
+        // the Stats kernel's slabs: per-cycle u64s, k-mer counters, one histogram counter per (slot, character)
+        r.slabs = ctx->d_st_slabs;
+        r.slab_dwords = ctx->st_slab_dwords;
+        r.off_kmer = 4 * N_CLS * ctx->L.Cp * 2;
+        r.off_qh = r.off_kmer + 4 * KMER_BINS;
+        r.qh_stride = 1;
+        r.qh_count = 0;
+        rc = fold(1, st_grid);
+        if (rc) return rc;
+        // the per-read kernel's slabs: the MISC_* counters only
+        r.slabs = ctx->d_slabs;
+        r.slab_dwords = ctx->slab_dwords;
+        r.off_misc = ctx->L.acc_misc - ctx->L.acc_cyc;
+        rc = fold(2, grid);
+        if (rc) return rc;
+    } else {
+        r.slabs = ctx->d_slabs;
+        r.slab_dwords = ctx->slab_dwords;
+        r.off_kmer = ctx->L.acc_kmer - ctx->L.acc_cyc;
+        r.off_qh = ctx->L.acc_qh - ctx->L.acc_cyc;
+        r.qh_stride = QT_DWORDS;
+        r.qh_count = QT_COUNT;
+        r.off_misc = ctx->L.acc_misc - ctx->L.acc_cyc;
+        rc = fold(3, grid);
+        if (rc) return rc;
+    }
 
     if (piped) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[par], st));

@@ -982,7 +982,7 @@ FQ_DEV void phase_trim(const KernelArgs& a, u32* lds, int tile_first, int tid, i
     for (int R = tid; R < L.NR; R += nthreads) {
         const int m = R >= L.P ? 1 : 0;
         const int rl0 = lds_i(lds, L.rlen0)[R];
-        if (p.stats_one_pass) {
+        if (p.stats_one_pass && !a.split) {
             // the one-pass Stats path reads quality character 0 as "no base here": make sure that is what the
             // row holds behind the read's end, whatever the caller's buffer had there
             u32* qrow = lds_qual(L, lds, R);
@@ -1853,6 +1853,25 @@ FQ_DEV void write_dup_pos(const KernelArgs& a, u32* lds, int u, int gp) {
     }
 }
 
+// split plan: mReads++ / mLengthSum += len of the four Stats objects (stats.cpp:194, 290) for one unit - the one-pass
+// convention of phase_stats_both (every read counts in its PRE slot, a read that is written out also in its POST
+// slot with its kept length) - and the unit's entry of the swin arrays the Stats kernel reads.  The addresses are
+// uniform: the compiler folds each of these into one LDS atomic per wavefront.
+FQ_DEV void split_stat_reads(const KernelArgs& a, u32* misc, int gp, u32 sw1, u32 sw2) {
+    lds_add_u32(&misc[MISC_STAT_READS + 0], 1u);
+    lds_add_u32(&misc[MISC_STAT_LENSUM + 0], sw1 & 0xFFFFu);
+    lds_add_u32(&misc[MISC_STAT_READS + 1], (sw1 >> 16) ? 1u : 0u);
+    lds_add_u32(&misc[MISC_STAT_LENSUM + 1], sw1 >> 16);
+    a.swin_out[0][gp] = sw1;
+    if (a.p.paired) {
+        lds_add_u32(&misc[MISC_STAT_READS + 2], 1u);
+        lds_add_u32(&misc[MISC_STAT_LENSUM + 2], sw2 & 0xFFFFu);
+        lds_add_u32(&misc[MISC_STAT_READS + 3], (sw2 >> 16) ? 1u : 0u);
+        lds_add_u32(&misc[MISC_STAT_LENSUM + 3], sw2 >> 16);
+        a.swin_out[1][gp] = sw2;
+    }
+}
+
 // Phase E3 (paired): lane = one pair.  Filter::passFilter and routing, peprocessor.cpp:563-591.
 // passFilter (filter.cpp:15-66) with the two LUT entries of the read's length already in registers
 FQ_DEV int filter_code_pre(const DevParams& p, int rlen, int tot, int low, int nb, int diff, int lowq_v, int cmin_v) {
@@ -1911,8 +1930,11 @@ FQ_DEV void phase_filter_pe_plain(const KernelArgs& a, u32* lds, int tile_first,
         }
         lds_i(lds, L.code)[R1] = code1;
         lds_i(lds, L.code)[R2] = code2;
-        lds[L.swin + R1] = rl1 | ((f1 & RS_STAT_POST) ? (u32)len1 << 16 : 0u);
-        lds[L.swin + R2] = rl2 | ((f2 & RS_STAT_POST) ? (u32)len2 << 16 : 0u);
+        const u32 sw1 = rl1 | ((f1 & RS_STAT_POST) ? (u32)len1 << 16 : 0u);
+        const u32 sw2 = rl2 | ((f2 & RS_STAT_POST) ? (u32)len2 << 16 : 0u);
+        lds[L.swin + R1] = sw1;
+        lds[L.swin + R2] = sw2;
+        if (a.split) split_stat_reads(a, misc, gp, sw1, sw2);
         u32* o1 = a.res[0] + (size_t)gp * 3;
         u32* o2 = a.res[1] + (size_t)gp * 3;
         o1[0] = (front1 & 0xFFFFu) | ((u32)len1 << 16);
@@ -2059,7 +2081,9 @@ FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int t
         lds_i(lds, L.code)[R] = code;
         const bool dedup_out = p.dedup && (flags[R] & RS_DUP);
         if (!dedup_out && alive && code == 0) flags[R] |= RS_STAT_POST;  // :280-286
-        lds[L.swin + R] = (u32)lds_i(lds, L.rlen0)[R] | ((flags[R] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R] << 16 : 0u);
+        const u32 sw = (u32)lds_i(lds, L.rlen0)[R] | ((flags[R] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R] << 16 : 0u);
+        lds[L.swin + R] = sw;
+        if (a.split) split_stat_reads(a, misc, gp, sw, 0u);
         write_dup_pos(a, lds, R, gp);
         write_read_result(a, lds, 0, R, gp);
     }
@@ -2112,6 +2136,8 @@ FQ_DEV void dup_claim_collect(const KernelArgs& a, int tile_first, int tid, cons
     a.claim_won[tile_first + tid] = (u8)won;
 }
 
+// SPLIT: the per-read kernel of the split plan (KernelArgs::split is set; no Stats code in this instantiation)
+template <bool SPLIT>
 FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
     const int tid0 = thread_id(), nt0 = block_threads();
     const KernelArgs& a0 = fa.h[0];
@@ -2145,7 +2171,7 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
             }
         if (tid < 2 * L.halves) lds[L.bar + (tid >> 1) * L.tile_stride + (tid & 1)] = 0;   // the halves' barrier words
         block_sync();
-        for (int i = tid; i < 4 * 128; i += nt) {  // quality table constants (the counters in between stay zero)
+        for (int i = tid; i < (SPLIT ? 0 : 4 * 128); i += nt) {  // quality table constants (the counters in between stay zero)
             const int q = i & 127;
             // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20.  Character 0 = no base.
             const u64 inc = q == 0 ? 0ull
@@ -2198,7 +2224,7 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
         tile_sync(a, lds, nt);
         FQ_STAMP(0)
         const u32 skip = a.debug_skip;   // profiling only: 0 in any real run
-        if (!a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
+        if (!SPLIT && !a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
         if (!(skip & 1u)) {
             phase_masks(a, lds, n_valid, tid, nt);
             phase_rc(a, lds, tid, nt);
@@ -2250,12 +2276,12 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
         tile_sync(a, lds, nt);
         FQ_STAMP(6)
         // Stats::statRead on what is written out (+ on the original reads in one-pass mode)
-        if (!(skip & 16u)) {
+        if (!SPLIT && !(skip & 16u)) {
             if (a.p.stats_one_pass) phase_stats_both(a, lds, n_valid, tid, nt);
             else if (a.p.merge) phase_stats<ST_POST, true>(a, lds, n_valid, tid, nt);
             else phase_stats<ST_POST, false>(a, lds, n_valid, tid, nt);
         }
-        tile_sync(a, lds, nt);
+        if (!SPLIT) tile_sync(a, lds, nt);   // split: the barrier behind the filter phase already closed the tile
         FQ_STAMP(7)
 #undef FQ_STAMP
     }
@@ -2305,7 +2331,12 @@ FQ_DEV void hash_body(const KernelArgs& a, u32* lds) {
 struct ReduceArgs {
     const u32* slabs;
     int slab_dwords, nblocks;
-    LdsLayout L;       // offsets of the accumulator regions (relative to L.acc_cyc)
+    LdsLayout L;       // Cp / C of the per-cycle accumulators
+    // where the regions sit inside a slab (dwords): per-cycle u64s at 0, then
+    int off_kmer, off_qh, off_misc;
+    int qh_stride, qh_count;   // histogram counter of (slot, character) = slab[off_qh + (slot * 128 + q) * qh_stride + qh_count]
+    // which items this launch folds: 1 = per-cycle + k-mer + histogram, 2 = the MISC_* counters, 3 = both (one slab set)
+    int parts;
     int isize_max;
     int one_pass;      // slabs hold kept (POST slot) / dropped (PRE slot): PRE = kept + dropped
     int64_t* ctr;      // counter block
@@ -2328,13 +2359,16 @@ enum { REDUCE_GROUP = FQ_REDUCE_GROUP };
 FQ_DEV void reduce_body(const ReduceArgs& r) {
     const LdsLayout& L = r.L;
     const int C = L.C, Cp = L.Cp;
-    const int n_cyc = 4 * N_CLS * Cp, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128 * QT_DWORDS;
+    const int n_cyc = 4 * N_CLS * Cp, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128;
     const int n_misc = MISC_ISIZE + r.isize_max + 1;
-    const int total = n_cyc + n_kmer + n_qh + n_misc;
+    const int n_stats = n_cyc + n_kmer + n_qh;
+    const int lo = (r.parts & 1) ? 0 : n_stats;
+    const int total = ((r.parts & 2) ? n_stats + n_misc : n_stats) - lo;
     const int chunks = (total + block_threads() - 1) / block_threads();  // workgroups per slab group
     const int g = block_id() / chunks;
-    const int item = (block_id() - g * chunks) * block_threads() + thread_id();
+    int item = (block_id() - g * chunks) * block_threads() + thread_id();
     if (item >= total) return;
+    item += lo;
     const int b0 = g * REDUCE_GROUP, b1 = imin(r.nblocks, b0 + REDUCE_GROUP);
     if (b0 >= b1) return;
     const int64_t CC = r.cycles;
@@ -2366,8 +2400,12 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
         }
         return;
     }
+    int src;   // dword of the slab that holds the item
+    if (item < n_cyc + n_kmer) src = r.off_kmer + (item - n_cyc);
+    else if (item < n_stats) src = r.off_qh + (item - n_cyc - n_kmer) * r.qh_stride + r.qh_count;
+    else src = r.off_misc + (item - n_stats);
     int64_t sum = 0;
-    for (int b = b0; b < b1; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + (L.acc_kmer - L.acc_cyc) + (item - n_cyc)];
+    for (int b = b0; b < b1; b++) sum += (int64_t)r.slabs[(size_t)b * r.slab_dwords + src];
     if (!sum) return;
     if (item < n_cyc + n_kmer) {
         const int k = item - n_cyc;
@@ -2377,15 +2415,14 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
                        ((km >> 8) & 3u);
         g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_kmer + fk], sum);
         if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_kmer + fk], sum);
-    } else if (item < n_cyc + n_kmer + n_qh) {
-        const int k = (item - n_cyc - n_kmer) / QT_DWORDS;
-        if ((item - n_cyc - n_kmer) - k * QT_DWORDS != QT_COUNT) return;  // the entry's constants are not counters
+    } else if (item < n_stats) {
+        const int k = item - n_cyc - n_kmer;
         const int slot = k / 128, q = k - slot * 128;
         if (q == 0) return;  // character 0 = "no base" (bytes past a read's end): never a real quality (>= '!')
         g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_qual_hist + q], sum);
         if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_qual_hist + q], sum);
     } else {
-        const int k = item - n_cyc - n_kmer - n_qh;
+        const int k = item - n_stats;
         int64_t dst;
         if (k < MISC_ADAPTER_READS) dst = r.o_filter + k;
         else if (k == MISC_ADAPTER_READS) dst = r.o_adapter_reads;

@@ -304,9 +304,9 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         int o = 0;
         auto take = [&](int n) { int at = o; o += n; return at; };
         // ---- shared by the tiles in flight: accumulators first (u64 part 8-byte aligned at offset 0), tables ----
-        out.acc_cyc = take(4 * N_CLS * out.Cp * 2);
-        out.acc_kmer = take(4 * KMER_BINS);
-        out.acc_qh = take(4 * 128 * QT_DWORDS);
+        out.acc_cyc = take(cfg.split ? 0 : 4 * N_CLS * out.Cp * 2);
+        out.acc_kmer = take(cfg.split ? 0 : 4 * KMER_BINS);
+        out.acc_qh = take(cfg.split ? 0 : 4 * 128 * QT_DWORDS);
         out.acc_misc = take(MISC_ISIZE + p.isize_max + 1);
         out.acc_end = o;
         out.val4_lut = take(p.dup_bufnum > 0 ? 256 : 0);

@@ -34,6 +34,7 @@ struct TileConfig {
     int P;            // pairs / reads per tile
     int lds_budget;   // bytes of LDS one workgroup may use
     int halves;       // tiles in flight per workgroup: 2 = each half of the waves owns one (fused_body), 1 = one tile
+    int split;        // split plan: no per-cycle / k-mer / histogram accumulators in this kernel's LDS (fq_stats.h)
 };
 
 // returns FASTP_GPU_OK or an error code; err receives a human readable reason

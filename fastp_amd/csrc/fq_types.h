@@ -332,6 +332,11 @@ struct KernelArgs {
     u32* slabs;
     int slab_dwords;
     int tiles;          // ceil(n / P)
+    // split plan (fq_stats.h): Stats::statRead runs in its own kernel afterwards.  This kernel then has no per-cycle /
+    // k-mer / histogram accumulators (their LDS regions are empty, the slab holds the MISC_* counters only), counts the
+    // reads and lengths of the four Stats objects itself, and leaves every read's original and kept length in swin_out.
+    int split;
+    u32* swin_out[2];   // [n] per mate: rlen0 | kept length << 16
 };
 
 // argument block of the fused kernel: one KernelArgs per half-workgroup (identical but for the LDS layout)
