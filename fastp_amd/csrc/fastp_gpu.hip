@@ -29,12 +29,17 @@ extern "C" __global__ void __launch_bounds__(1024) fq_fused_kernel(FusedArgs a) 
     // used) instead of holding all ~150 dwords in SGPRs for the whole persistent loop
     fused_body<false>(*kernel_args(&a), fq_lds);
 }
+// the per-read kernel of the split plan as one large workgroup per CU (A/B against the small-workgroup form)
+extern "C" __global__ void __launch_bounds__(1024) fq_scan_wide_kernel(FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    fused_body<true>(*kernel_args(&a), fq_lds);
+}
 // the per-read kernel of the split plan: 256-lane workgroups, four to a CU (fq_stats_kernel counts afterwards)
 extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     fused_body<true>(*kernel_args(&a), fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(1024) fq_stats_kernel(StatsArgs a) {
+extern "C" __global__ void __launch_bounds__(1024, 8) fq_stats_kernel(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     stats_body(a, fq_lds);
 }
@@ -160,7 +165,7 @@ struct fastp_gpu_ctx {
     bool split = false;
     int st_threads = 0, st_blocks = 0;     // the Stats kernel's workgroup size and the most workgroups it is launched with
     int st_H = 0, st_lds_dwords = 0, st_slab_dwords = 0;
-    int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0;
+    int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
     u32* d_swin[2] = {nullptr, nullptr}; size_t swin_cap = 0;
     hipStream_t stream = nullptr;
@@ -338,9 +343,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     ctx->cfg.lds_budget = env_int("FASTP_GPU_LDS_KB", ctx->split ? std::min(40, lds_kb_default) : lds_kb_default) * 1024;
     // two tiles in flight per workgroup (each half of the waves owns one) when the halves are whole wavefronts
     ctx->cfg.halves = (env_int("FASTP_GPU_HALVES", 1) == 2 && ctx->cfg.threads % 128 == 0) ? 2 : 1;
-    if (ctx->cfg.threads < 64 || ctx->cfg.threads > (ctx->split ? 256 : 1024) || (ctx->cfg.threads & 63)) {
+    if (ctx->cfg.threads < 64 || ctx->cfg.threads > 1024 || (ctx->cfg.threads & 63)) {
         delete ctx;
-        return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024 (64..256 in the split plan)");
+        return fail(nullptr, FASTP_GPU_E_INVALID, "FASTP_GPU_THREADS must be a multiple of 64 in 64..1024");
     }
     if (env_int("FASTP_GPU_HASH_GENERIC", 0)) {  // tests: the multiply form of the duplicate hash (what B = 8 uses)
         ctx->luts.dup_planes.clear();
@@ -362,7 +367,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (!getenv("FASTP_GPU_BLOCKS_PER_CU")) {
         // persistent workgroups: the grid must not exceed what is resident at once (registers bound it, not only LDS)
         int nb = 0;
-        const void* kfn = ctx->split ? (const void*)fq_scan_kernel : (const void*)fq_fused_kernel;
+        const void* kfn = ctx->split ? (ctx->cfg.threads > 256 ? (const void*)fq_scan_wide_kernel : (const void*)fq_scan_kernel) : (const void*)fq_fused_kernel;
         (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, ctx->cfg.threads, (size_t)ctx->L.total * 4) == hipSuccess && nb > 0)
             blocks_per_cu = std::min(blocks_per_cu, nb);
@@ -382,12 +387,15 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         int o = 0;
         ctx->st_l_cyc = o; o += 4 * 8 * N_CLS * ctx->st_H * 2;
         ctx->st_l_kmer = o; o += 4 * KMER_BINS;
-        ctx->st_l_qh = o; o += 4 * 128;
-        ctx->st_l_lut = o; o += 2 * 128;
+        ctx->st_l_qh = o; o += ST_QH_COPIES * 4 * 128;
+        o = (o + 3) & ~3;
+        ctx->st_l_lut = o; o += 4 * 256;
+        ctx->st_wl_cap = 2047;
+        ctx->st_l_wl = o; o += 1 + ctx->st_wl_cap;
         ctx->st_lds_dwords = o;
         ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
-        ctx->st_threads = env_int("FASTP_GPU_STATS_THREADS", 512);
-        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63)) ctx->st_threads = 512;
+        ctx->st_threads = env_int("FASTP_GPU_STATS_THREADS", 1024);
+        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63)) ctx->st_threads = 1024;
         if (ctx->st_lds_dwords * 4 > (int)prop.sharedMemPerBlock) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "reads too long for the Stats kernel's LDS"); }
         int st_per_cu = std::min(2048 / ctx->st_threads, (int)((160 * 1024) / (ctx->st_lds_dwords * 4)));
         st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));
@@ -471,7 +479,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         }
     }
-    CREATE_TRY(hipFuncSetAttribute(ctx->split ? (const void*)fq_scan_kernel : (const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
+    CREATE_TRY(hipFuncSetAttribute(ctx->split ? (ctx->cfg.threads > 256 ? (const void*)fq_scan_wide_kernel : (const void*)fq_scan_kernel) : (const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
@@ -908,7 +916,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         fa.h[0] = a;
         fa.h[1] = a;
         fa.h[1].L = layout_for_half(a.L, 1);
-        if (ctx->split) hipLaunchKernelGGL(fq_scan_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
+        if (ctx->split && ctx->cfg.threads > 256) hipLaunchKernelGGL(fq_scan_wide_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
+        else if (ctx->split) hipLaunchKernelGGL(fq_scan_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
         else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -932,6 +941,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         st_grid = (n + upb - 1) / upb;
         for (int m = 0; m < 2; m++) { sa.seq[m] = a.seq[m]; sa.qual[m] = a.qual[m]; sa.swin[m] = ctx->d_swin[m]; }
         sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut;
+        sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
         sa.l_total = ctx->st_lds_dwords;
         sa.slabs = ctx->d_st_slabs;
         sa.slab_dwords = ctx->st_slab_dwords;

@@ -35,8 +35,9 @@ struct StatsArgs {
     // LDS layout (dwords)
     int l_cyc;              // [4][8][N_CLS][H] u64
     int l_kmer;             // [4][KMER_BINS] u32
-    int l_qh;               // [4][128] u32
-    int l_lut;              // [128] u64: packed per-cycle increment of a quality character
+    int l_qh;               // [ST_QH_COPIES][4][128] u32: lane l adds to copy l % ST_QH_COPIES (same-address atomics serialise)
+    int l_lut;              // [256] x 4 dwords: character | kept << 7 -> {increment u64, per-cycle byte offset, k-mer byte offset}
+    int l_wl, wl_cap;       // work list of the items with an N among their 12 bases: [0] = count, then wl_cap item numbers
     int l_total;
     // slab (dwords): [cyc canonical: 4 * Cp * N_CLS u64][kmer 4 * KMER_BINS][qh 4 * 128]
     u32* slabs;
@@ -44,121 +45,145 @@ struct StatsArgs {
     u32 debug_skip;         // profiling only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
 };
 
+enum { ST_QH_COPIES = 8 };
+
 FQ_DEV u64 stats_inc_of(u32 q) {   // stats.cpp:209-222: q30 ('?') counts into Q30 and Q20, q20 ('5') into Q20
     return 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) | ((u64)(q - 33u) << CYC_QSUM_SHIFT);
 }
 
-// one base through the general path (N, read end or kept boundary inside the item)
-FQ_DEV void stats_base_general(const StatsArgs& a, u32* lds, int slot, int h, int k, u32 q, u32 cls, bool kmer_ok, u32 km) {
+// what a lane needs of item `it` of the workgroup's unit range
+struct StatsItem {
+    int m, h, rl0, lk;
+    u32 q0, q1, qp, codes, prev8;
+    bool act;
+};
+FQ_DEV void stats_fetch(const StatsArgs& a, int u0, int per_mate, int it, bool tv, StatsItem& s) {
+    const int H = a.H;
+    s.m = (tv && it >= per_mate) ? 1 : 0;
+    const int r = tv ? it - s.m * per_mate : 0;
+    const int ur = (int)fastdiv((u32)r, a.magic_H);
+    s.h = r - ur * H;
+    const int g = u0 + ur;
+    const u32* qrow = (s.m ? a.qual[1] : a.qual[0]) + (size_t)g * a.qw_g;
+    const u8* srow = (const u8*)((s.m ? a.seq[1] : a.seq[0]) + (size_t)g * a.sw_g);
+    const u32 sw = tv ? (s.m ? a.swin[1] : a.swin[0])[g] : 0u;
+    s.rl0 = (int)(sw & 0xFFFFu);
+    s.lk = (int)(sw >> 16);
+    s.act = tv && 8 * s.h < s.rl0;
+    s.q0 = s.q1 = s.qp = s.codes = s.prev8 = 0;
+    if (s.act) {   // the item's 8 quality bytes and 8 bases, the 4 of each before them
+        const u64 qq = *(const u64*)(qrow + 2 * s.h);
+        s.q0 = (u32)qq;
+        s.q1 = (u32)(qq >> 32);
+        s.codes = (u32)*(const u16*)(srow + 2 * s.h);
+        if (s.h > 0) {
+            s.qp = qrow[2 * s.h - 1];
+            s.prev8 = (u32)srow[2 * s.h - 1];
+        }
+    }
+}
+
+// an item with an N among its 8 bases or the 4 before: base by base (dense pass over the work list)
+FQ_DEV void stats_item_general(const StatsArgs& a, u32* lds, const StatsItem& s, int lane) {
     u64* cyc = (u64*)(lds + a.l_cyc);
-    lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + (int)cls) * a.H + h], stats_inc_of(q));
-    lds_add_u32(&lds[a.l_qh + slot * 128 + (int)q], 1u);
-    if (kmer_ok) lds_add_u32(&lds[a.l_kmer + slot * KMER_BINS + (int)km], 1u);
+    const u32 nb0 = (s.q0 >> 7) & 0x01010101u, nb1 = (s.q1 >> 7) & 0x01010101u, nbp = (s.qp >> 7) & 0x01010101u;
+    // bit i = base j0 - 4 + i is N (before the read start: "invalid" as in the reference, which needs 5 bases)
+    u32 n12 = ((nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu) | (((nb0 | (nb0 >> 7) | (nb0 >> 14) | (nb0 >> 21)) & 0xFu) << 4) |
+              (((nb1 | (nb1 >> 7) | (nb1 >> 14) | (nb1 >> 21)) & 0xFu) << 8);
+    if (s.h == 0) n12 |= 0xFu;
+    const u32 c24 = s.prev8 | (s.codes << 8);
+    const int j0 = 8 * s.h;
+    u32* qh = lds + a.l_qh + (lane & (ST_QH_COPIES - 1)) * 512;
+    for (int k = 0; k < 8; k++) {
+        const int j = j0 + k;
+        if (j >= s.rl0) break;
+        const u32 q = ((k < 4 ? s.q0 : s.q1) >> (8 * (k & 3))) & 0x7Fu;
+        const bool isn = ((n12 >> (4 + k)) & 1u) != 0;
+        const int cls = isn ? (int)CLS_N : (int)((s.codes >> (2 * k)) & 3u);
+        const int slot = 2 * s.m + (j < s.lk ? 1 : 0);
+        lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + cls) * a.H + s.h], stats_inc_of(q));
+        lds_add_u32(&qh[slot * 128 + (int)q], 1u);
+        if (((n12 >> k) & 0x1Fu) == 0u) lds_add_u32(&lds[a.l_kmer + slot * KMER_BINS + (int)((c24 >> (2 * k)) & 0x3FFu)], 1u);
+    }
 }
 
 FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
     const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
     const int H = a.H;
-    // ---- clear the accumulators, build the increment table ----
+    const u32 H8 = (u32)H * 8u;               // bytes between the classes of one (slot, k)
+    const u32 K8 = (u32)N_CLS * H8;           // bytes between the k of one slot
+    const u32 S8 = 8u * K8;                   // bytes between slots
+    // ---- clear the accumulators, build the character table ----
     for (int i = tid; i < a.l_total; i += nt) lds[i] = 0;
     block_sync();
-    for (int q = tid; q < 128; q += nt) {
-        const u64 inc = q < 33 ? 0ull : stats_inc_of((u32)q);
-        lds[a.l_lut + 2 * q] = (u32)inc;
-        lds[a.l_lut + 2 * q + 1] = (u32)(inc >> 32);
+    for (int e = tid; e < 256; e += nt) {
+        const u32 q = (u32)e & 0x7Fu, kept = (u32)e >> 7;
+        // characters below '!' never occur in a read (the packers refuse them): 0 stands for "no base here" and adds nothing
+        const u64 inc = q < 33u ? 0ull : stats_inc_of(q);
+        u32* t = lds + a.l_lut + 4 * e;
+        t[0] = (u32)inc;
+        t[1] = (u32)(inc >> 32);
+        t[2] = kept ? S8 : 0u;
+        t[3] = kept ? (u32)(KMER_BINS * 4) : 0u;
     }
     block_sync();
     const int u0 = block_id() * a.units_per_block;
     const int nu = imax(0, imin(a.units_per_block, a.n - u0));
     const int per_mate = nu * H;
     const int total = (a.paired ? 2 : 1) * per_mate;
-    const u8* lds_b = (const u8*)lds;
     u8* ldsw = (u8*)lds;
-    const int cyc_b = a.l_cyc * 4, kmer_b = a.l_kmer * 4, qh_b = a.l_qh * 4, lut_b = a.l_lut * 4;
+    const u32 cyc_b = (u32)a.l_cyc * 4u, kmer_b = (u32)a.l_kmer * 4u, lut_b = (u32)a.l_lut * 4u;
+    const u32 qh_b = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 2048u;
     const u32 dbg = a.debug_skip;
-    const u32 H8 = (u32)H * 8u;               // bytes between the classes of one (slot, k)
-    const u32 K8 = (u32)N_CLS * H8;           // bytes between the k of one slot
-    const u32 S8 = 8u * K8;                   // bytes between slots
-    // The wavefront's mode = the histogram bin (Stats slot AND character) of the first plain item's first base, fixed
-    // at its first appearance: bases that hit it are counted per lane and added once at the end - most characters of a
-    // run are one value, and as LDS atomics they would all land on one address and serialise.
+    u32* wl = lds + a.l_wl;
+    // The wavefront's mode = the histogram bin (Stats slot AND character) of the first item's first base, fixed at its
+    // first appearance: bases that hit it are counted per lane and added once at the end - most characters of a run are
+    // one value, and as LDS atomics they would all land on one address and serialise.
     u32 mode_bin = 0xFFFFFFFFu;
     u32 agg_cnt = 0;
     for (int base = tid - lane; base < total; base += nt) {   // wave-uniform trip count (ballots inside)
         const int it = base + lane;
-        const bool tv = it < total;
-        const int m = (tv && it >= per_mate) ? 1 : 0;
-        const int r = tv ? it - m * per_mate : 0;
-        const int ur = (int)fastdiv((u32)r, a.magic_H);
-        const int h = r - ur * H;
-        const int g = u0 + ur;
-        const u32* qrow = (m ? a.qual[1] : a.qual[0]) + (size_t)g * a.qw_g;
-        const u8* srow = (const u8*)((m ? a.seq[1] : a.seq[0]) + (size_t)g * a.sw_g);
-        const u32 sw = tv ? (m ? a.swin[1] : a.swin[0])[g] : 0u;
-        const int rl0 = (int)(sw & 0xFFFFu), lk = (int)(sw >> 16);
-        const int j0 = 8 * h;
-        const bool act = tv && j0 < rl0;
-        // the item's 8 quality bytes and 8 bases, the 4 bases before them
-        u32 q0 = 0, q1 = 0, qp = 0, codes = 0, prev8 = 0;
-        if (act) {
-            const u64 qq = *(const u64*)(qrow + 2 * h);
-            q0 = (u32)qq;
-            q1 = (u32)(qq >> 32);
-            codes = (u32)*(const u16*)(srow + 2 * h);
-            if (h > 0) {
-                qp = qrow[2 * h - 1];
-                prev8 = (u32)srow[2 * h - 1];
-            }
+        StatsItem s;
+        stats_fetch(a, u0, per_mate, it, it < total, s);
+        const u32 nany = (s.q0 | s.q1 | s.qp) & 0x80808080u;   // an N among the 8 bases or the 4 before
+        const bool plain = s.act && nany == 0u;
+        if (s.act && !plain) {                                  // rare: queued for the base-by-base pass
+            const u32 slot = lds_add_ret_u32(wl, 1u);
+            if (slot < (u32)a.wl_cap) wl[1 + slot] = (u32)it;
+            else stats_item_general(a, lds, s, lane);           // list full (reads riddled with N): here and now
         }
-        const int slot_d = 2 * m;
-        const bool full = j0 + 8 <= rl0;                       // all 8 bases exist
-        const bool kept = j0 + 8 <= lk;                        // ... and are kept
-        const bool drop = j0 >= lk;                            // ... or all dropped
-        const u32 nany = (q0 | q1 | qp) & 0x80808080u;         // an N among the 8 bases or the 4 before
-        const bool plain = (int)act & (int)full & (int)(nany == 0u) & ((int)kept | (int)drop);
-        const u32 c24 = prev8 | (codes << 8);                  // bases j0-4 .. j0+7, 2 bits each
+        // bytes of the item that hold a base, and which of those are kept: bit 7 of a quality byte (free: no N here)
+        // becomes "kept", a byte past the read's end becomes character 0
+        const int j0 = 8 * s.h;
+        const int nv = imin(8, s.rl0 - j0), nk = imax(0, imin(8, s.lk - j0));
+        const u64 vmask = nv >= 8 ? ~0ull : ((1ull << (8 * imax(nv, 0))) - 1ull);
+        const u64 kmask = (nk >= 8 ? ~0ull : ((1ull << (8 * nk)) - 1ull)) & 0x8080808080808080ull;
+        const u64 qq = (((u64)s.q1 << 32) | s.q0) & vmask;
+        const u64 qk = plain ? (qq | kmask) : 0ull;            // not plain: eight "no base" characters - nothing is added below
+        const u32 e0 = (u32)qk, e1 = (u32)(qk >> 32);
+        const u32 slot_d = 2u * (u32)s.m;
         if (mode_bin == 0xFFFFFFFFu) {                         // wave-uniform
             const u64 cand = ballot(plain);
-            if (cand) {
-                const int src = ffs64(cand) - 1;
-                mode_bin = shfl((u32)((kept ? slot_d + 1 : slot_d) * 128) + (q0 & 0x7Fu), src);
-            }
+            if (cand) mode_bin = shfl(slot_d * 128u + (e0 & 0xFFu), ffs64(cand) - 1);
         }
-        if (plain) {
-            const u32 slot = (u32)(kept ? slot_d + 1 : slot_d);
-            u8* cyc = ldsw + (cyc_b + (int)(slot * S8) + h * 8);
-            u8* kmer = ldsw + (kmer_b + (int)(slot * (KMER_BINS * 4)));
-            u8* qh = ldsw + (qh_b + (int)(slot * 512));
-            const u32 bin0 = slot * 128u;
+        const u32 c24 = s.prev8 | (s.codes << 8);              // bases j0-4 .. j0+7, 2 bits each
+        const u32 cyc0 = cyc_b + slot_d * S8 + (u32)s.h * 8u;
+        const u32 kmer0 = kmer_b + slot_d * (KMER_BINS * 4);
+        const u32 qh0 = qh_b + slot_d * 512u;
+        const u32 bin0 = slot_d * 128u;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const u32 q = bfe(k < 4 ? q0 : q1, 8 * (k & 3), 7);
-                if (!(dbg & 64u)) {
-                    const u64 inc = *(const u64*)(lds_b + lut_b + (q << 3));
-                    lds_add_u64((u64*)(cyc + (u32)k * K8 + bfe(codes, 2 * k, 2) * H8), inc);
-                }
-                // 5-mer ending at base j0 + k (stats.cpp:224-266): positions >= 4 only
-                if (!(dbg & 128u) && (k >= 4 || h > 0)) lds_add_u32((u32*)(kmer + (bfe(c24, 2 * k, 10) << 2)), 1u);
-                if (!(dbg & 256u)) {
-                    const bool is_mode = bin0 + q == mode_bin;
-                    agg_cnt += is_mode ? 1u : 0u;
-                    if (!is_mode) lds_add_u32((u32*)(qh + (q << 2)), 1u);
-                }
-            }
-        } else if (act) {                                       // rare: N, the read's last item, the item the kept length cuts
-            const u32 nb0 = (q0 >> 7) & 0x01010101u, nb1 = (q1 >> 7) & 0x01010101u, nbp = (qp >> 7) & 0x01010101u;
-            // bit i = base j0 - 4 + i is N (before the read start: "invalid" as in the reference, which needs 5 bases)
-            u32 n12 = ((nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu) | (((nb0 | (nb0 >> 7) | (nb0 >> 14) | (nb0 >> 21)) & 0xFu) << 4) |
-                      (((nb1 | (nb1 >> 7) | (nb1 >> 14) | (nb1 >> 21)) & 0xFu) << 8);
-            if (h == 0) n12 |= 0xFu;
-            for (int k = 0; k < 8; k++) {
-                const int j = j0 + k;
-                if (j >= rl0) break;
-                const u32 q = ((k < 4 ? q0 : q1) >> (8 * (k & 3))) & 0x7Fu;
-                const bool isn = ((n12 >> (4 + k)) & 1u) != 0;
-                const u32 cls = isn ? (u32)CLS_N : ((codes >> (2 * k)) & 3u);
-                const int slot = slot_d + (j < lk ? 1 : 0);
-                stats_base_general(a, lds, slot, h, k, q, cls, ((n12 >> k) & 0x1Fu) == 0u, (c24 >> (2 * k)) & 0x3FFu);
+        for (int k = 0; k < 8; k++) {
+            const u32 e = bfe(k < 4 ? e0 : e1, 8 * (k & 3), 8);     // character | kept << 7
+            const u32x4 t = *(const u32x4*)(ldsw + lut_b + (e << 4));
+            const u32 one = t.x & 1u;                                // the count field's increment: 0 for "no base"
+            if (!(dbg & 64u))
+                lds_add_u64((u64*)(ldsw + (cyc0 + t.z + (u32)k * K8 + bfe(s.codes, 2 * k, 2) * H8)), (u64)t.x | ((u64)t.y << 32));
+            // 5-mer ending at base j0 + k (stats.cpp:224-266): positions >= 4 only
+            if (!(dbg & 128u) && (k >= 4 || s.h > 0)) lds_add_u32((u32*)(ldsw + (kmer0 + t.w + (bfe(c24, 2 * k, 10) << 2))), one);
+            if (!(dbg & 256u)) {
+                const bool is_mode = bin0 + e == mode_bin;
+                agg_cnt += is_mode ? 1u : 0u;
+                if (!is_mode && one) lds_add_u32((u32*)(ldsw + (qh0 + (e << 2))), 1u);
             }
         }
     }
@@ -166,6 +191,14 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) agg_cnt += shfl_xor(agg_cnt, sh);
         if (lane == 0 && agg_cnt) lds_add_u32(&lds[a.l_qh + (int)mode_bin], agg_cnt);
+    }
+    block_sync();
+    // ---- the queued items, every lane busy ----
+    const int nw = imin((int)wl[0], a.wl_cap);
+    for (int i = tid; i < nw; i += nt) {
+        StatsItem s;
+        stats_fetch(a, u0, per_mate, (int)wl[1 + i], true, s);
+        stats_item_general(a, lds, s, lane);
     }
     block_sync();
     // ---- flush to this workgroup's slab in the canonical order the slab fold reads ([slot][cycle][class]) ----
@@ -186,7 +219,11 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         slab[2 * i + 1] = hi;
     }
     for (int i = tid; i < 4 * KMER_BINS; i += nt) slab[2 * n_cyc + i] = lds[a.l_kmer + i];
-    for (int i = tid; i < 4 * 128; i += nt) slab[2 * n_cyc + 4 * KMER_BINS + i] = lds[a.l_qh + i];
+    for (int i = tid; i < 4 * 128; i += nt) {
+        u32 v = 0;
+        for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + c * 512 + i];
+        slab[2 * n_cyc + 4 * KMER_BINS + i] = v;
+    }
 }
 
 }  // namespace fq
