@@ -184,7 +184,8 @@ class FormatIn(C.Structure):
 
 class FormatOptions(C.Structure):
     _fields_ = [("want_failed", C.c_int32), ("want_unpaired1", C.c_int32), ("want_unpaired2", C.c_int32),
-                ("umi_loc", C.c_int32), ("umi_len", C.c_int32), ("umi_prefix", C.c_char_p), ("umi_delimiter", C.c_char_p)]
+                ("umi_loc", C.c_int32), ("umi_len", C.c_int32), ("umi_prefix", C.c_char_p), ("umi_delimiter", C.c_char_p),
+                ("corrections_capacity", C.c_int32)]
 
 
 N_OUTPUTS = 6  # FASTP_GPU_OUT1, OUT2, FAILED, MERGED, UNPAIRED1, UNPAIRED2

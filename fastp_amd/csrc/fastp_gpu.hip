@@ -12,6 +12,7 @@
 
 #include "fq_device.h"
 #include "fq_stats.h"
+#include "fq_lane.h"
 #include "fq_inflate.h"
 #include "fq_eval.h"
 #include "fq_deflate.h"
@@ -38,6 +39,13 @@ extern "C" __global__ void __launch_bounds__(1024) fq_scan_wide_kernel(FusedArgs
 extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     fused_body<true>(*kernel_args(&a), fq_lds);
+}
+// the per-read path with one lane per pair, reads in registers (fq_lane.h): SWM base words per read (10: up to 160
+// bases, 16: up to 256), B bloom buffers hashed (0: no hashing in this launch), byte planes per prime, paired / single
+template <int SWM, int B, int NPL, bool PAIRED>
+__global__ void __launch_bounds__(256) fq_lane_kernel(LaneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    lane_body<SWM, B, NPL, PAIRED>(*kernel_args(&a), fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(1024, 8) fq_stats_kernel(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -167,6 +175,11 @@ struct fastp_gpu_ctx {
     int st_H = 0, st_lds_dwords = 0, st_slab_dwords = 0;
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
+    // lane plan (fq_lane.h): one lane per pair, reads in registers - the option family lane_plan_supported() admits
+    bool lane = false;
+    int ln_swm = 0, ln_blocks = 0;
+    LaneLds ln_lds;
+    u32* d_ln_slabs = nullptr;
     u32* d_swin[2] = {nullptr, nullptr}; size_t swin_cap = 0;
     hipStream_t stream = nullptr;
     // Duplicate's probe + resolve of launch k run beside the fused kernel of launch k + 1 (see launch_chunk): the fused
@@ -215,6 +228,7 @@ struct fastp_gpu_ctx {
     u64* d_fmt = nullptr; size_t fmt_cap = 0;             // FASTQ format scratch
     u8* d_inf = nullptr; size_t inf_cap = 0;              // inflate scratch: code lengths | status | first_bad
     uint64_t units_seen = 0;                               // units submitted so far (the pre-filtering Stats' mReads)
+    const void* last_corr = nullptr; int32_t last_corr_cap = 0;   // the correction list of the last submit and its capacity
     std::vector<std::string> ovr_strings[2];
     std::vector<const char*> ovr_ptrs[2];
     // staging for submit_host
@@ -287,11 +301,35 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
-                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1]};
+                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// the option family the lane kernel covers: nothing moves or edits a kept base (split plan), no step that needs an
+// unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
+// bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
+static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
+    if (!p.stats_one_pass || p.allow_gap || p.poly_x || p.n_fasta || p.has_a1 || p.has_a2 || p.complexity_filter) return false;
+    if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
+    if (p.cut_right && (p.wR < 1 || p.wR > 8)) return false;
+    if (p.cut_tail && !p.cut_right && (p.wT < 1 || p.wT > 8)) return false;
+    if (p.dup_enabled && !(luts.dup_nq > 0 && (p.dup_bufnum == 2 || p.dup_bufnum == 4) && p.dup_npl == 3)) return false;
+    return true;
+}
+
+typedef void (*lane_kernel_fn)(LaneArgs);
+static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired) {
+    if (swm == 10) {
+        if (B == 0) return paired ? fq_lane_kernel<10, 0, 3, true> : fq_lane_kernel<10, 0, 3, false>;
+        if (B == 2) return paired ? fq_lane_kernel<10, 2, 3, true> : fq_lane_kernel<10, 2, 3, false>;
+        return paired ? fq_lane_kernel<10, 4, 3, true> : fq_lane_kernel<10, 4, 3, false>;
+    }
+    if (B == 0) return paired ? fq_lane_kernel<16, 0, 3, true> : fq_lane_kernel<16, 0, 3, false>;
+    if (B == 2) return paired ? fq_lane_kernel<16, 2, 3, true> : fq_lane_kernel<16, 2, 3, false>;
+    return paired ? fq_lane_kernel<16, 4, 3, true> : fq_lane_kernel<16, 4, 3, false>;
 }
 
 extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fastp_gpu_ctx** out) {
@@ -400,6 +438,30 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         int st_per_cu = std::min(2048 / ctx->st_threads, (int)((160 * 1024) / (ctx->st_lds_dwords * 4)));
         st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));
         ctx->st_blocks = ctx->cus * std::max(1, st_per_cu);
+        ctx->lane = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
+        if (ctx->lane) {
+            ctx->ln_swm = ctx->dp.sw_g <= 10 ? 10 : 16;
+            LaneLds& l = ctx->ln_lds;
+            int o = 0;
+            l.n_misc = MISC_ISIZE + ctx->dp.isize_max + 1;
+            l.misc = o; o += l.n_misc;
+            const int lw = (ctx->dp.cycles + 2) / 2;
+            l.lut_ov = o; o += lw;
+            l.lut_lowq = o; o += lw;
+            l.val4 = o; o += 256;
+            l.total = o;
+            int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);
+#ifndef FQ_HOSTSIM
+            if (per_cu <= 0) {
+                int nb = 0;
+                lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)l.total * 4) == hipSuccess && nb > 0) per_cu = nb;
+                (void)hipGetLastError();
+            }
+#endif
+            if (per_cu <= 0) per_cu = 4;
+            ctx->ln_blocks = ctx->cus * per_cu;
+        }
     }
     auto set_launch_size = [&]() {
         long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
@@ -415,7 +477,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     fastp_gpu_counter_layout_for_params(&ctx->params, &ctx->cl);
     if (env_int("FASTP_GPU_VERBOSE", 0))
         fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel %d x %d threads, LDS %d bytes\n",
-                ctx->split ? "split plan" : "fused plan", ctx->L.P, ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks,
+                ctx->lane ? "lane plan" : (ctx->split ? "split plan" : "fused plan"), ctx->L.P, ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks,
                 ctx->max_pairs_per_launch, ctx->st_blocks, ctx->st_threads, ctx->st_lds_dwords * 4);
     ctx->slab_dwords = ctx->L.acc_end - ctx->L.acc_cyc;
 
@@ -484,6 +546,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_blocks * ctx->st_slab_dwords * 4));
+        if (ctx->lane) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
     }
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DefLds)));
@@ -907,6 +970,13 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         rc = launch_dup(nullptr, false, nullptr, 1);
         if (rc) return rc;
     }
+    // the lane kernel loads rows with 8-byte accesses: a batch whose rows are not 8-byte aligned takes the tile kernel
+    bool use_lane = ctx->lane;
+    {
+        const void* ptrs[4] = {a.seq[0], a.qual[0], ctx->dp.paired ? a.seq[1] : a.seq[0], ctx->dp.paired ? a.qual[1] : a.qual[0]};
+        for (const void* q : ptrs) use_lane = use_lane && (((uintptr_t)q & 7u) == 0);
+    }
+    int ln_grid = 0;
     hipEvent_t e0, e1;
     rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
@@ -916,7 +986,17 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         fa.h[0] = a;
         fa.h[1] = a;
         fa.h[1].L = layout_for_half(a.L, 1);
-        if (ctx->split && ctx->cfg.threads > 256) hipLaunchKernelGGL(fq_scan_wide_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
+        if (use_lane) {
+            LaneArgs la;
+            la.k = a;
+            la.k.slabs = ctx->d_ln_slabs;
+            la.k.slab_dwords = ctx->ln_lds.n_misc;
+            la.l = ctx->ln_lds;
+            const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won)) ? ctx->dp.dup_bufnum : 0;
+            lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0);
+            ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
+            hipLaunchKernelGGL(fn, dim3(ln_grid), dim3(256), (size_t)ctx->ln_lds.total * 4, st, la);
+        } else if (ctx->split && ctx->cfg.threads > 256) hipLaunchKernelGGL(fq_scan_wide_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
         else if (ctx->split) hipLaunchKernelGGL(fq_scan_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
         else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
     }
@@ -990,10 +1070,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         rc = fold(1, st_grid);
         if (rc) return rc;
         // the per-read kernel's slabs: the MISC_* counters only
-        r.slabs = ctx->d_slabs;
-        r.slab_dwords = ctx->slab_dwords;
-        r.off_misc = ctx->L.acc_misc - ctx->L.acc_cyc;
-        rc = fold(2, grid);
+        r.slabs = use_lane ? ctx->d_ln_slabs : ctx->d_slabs;
+        r.slab_dwords = use_lane ? ctx->ln_lds.n_misc : ctx->slab_dwords;
+        r.off_misc = use_lane ? 0 : ctx->L.acc_misc - ctx->L.acc_cyc;
+        rc = fold(2, use_lane ? ln_grid : grid);
         if (rc) return rc;
     } else {
         r.slabs = ctx->d_slabs;
@@ -1043,6 +1123,8 @@ static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fas
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     const bool worker_loop = mode == CHUNK_STREAM || (mode == CHUNK_PASS1 && !ctx->dp.dedup) || (mode == CHUNK_PASS2 && ctx->dp.dedup);
     if (worker_loop) {
+        ctx->last_corr = res->corrections;
+        ctx->last_corr_cap = res->corrections ? res->corrections_capacity : 0;
         if (res->n_corrections) HIP_TRY(ctx, hipMemsetAsync(res->n_corrections, 0, sizeof(int32_t), st));
         if (ctx->dp.n_fasta && b->n > 0 && (!res->adapter_events || !res->n_adapter_events))
             return fail(ctx, FASTP_GPU_E_INVALID, "adapter_fasta needs an adapter event list in the results");
@@ -1454,6 +1536,11 @@ extern "C" int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fas
     if (corrections && n_corrections) {
         HIP_TRY(ctx, hipMemcpyAsync(&ncorr, n_corrections, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
+        // the engine's counter keeps counting past the list's capacity: such a list is incomplete and reading
+        // n_corrections entries would run behind the buffer
+        int32_t cap = (opts && opts->corrections_capacity > 0) ? opts->corrections_capacity
+                                                                : (corrections == ctx->last_corr ? ctx->last_corr_cap : 0);
+        if (cap > 0 && ncorr > cap) return fail(ctx, FASTP_GPU_E_OVERFLOW, "correction list capacity exceeded: the list is incomplete");
         if (ncorr > 0) {
             hipLaunchKernelGGL(fq_fmts_corr_kernel, dim3((ncorr + 255) / 256), dim3(256), 0, st, f);
             HIP_TRY(ctx, hipGetLastError());

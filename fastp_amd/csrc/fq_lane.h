@@ -1,0 +1,606 @@
+// fq_lane.h - the per-read path with one LANE per read pair (or single read), everything in registers (gfx950).
+//
+// The tile kernels (fq_device.h) stage a tile of pairs in LDS and walk it phase by phase behind workgroup barriers;
+// measured (profiles/r03b_*): the wavefronts are parked 70 % of the time, the three lane = read phases run on one
+// wavefront of the workgroup, and a pair costs ~230 VALU + ~145 SALU instructions of which most are index
+// arithmetic, LDS addressing and loop control.  Here a lane owns a pair from the first load to the result record:
+//   * its reads live in VGPRs (2-bit bases: SWM dwords per read; N mask; the sliding-window predicate of
+//     Filter::trimAndCut as a bit mask), loaded once with per-lane 8-byte row loads,
+//   * every scan is a fully unrolled, branch-free instruction stream over STATIC register indices - the overlap
+//     prefilter of OverlapAnalysis::analyze is 6 instructions per offset with no address arithmetic at all,
+//   * a dynamic offset (the surviving overlap candidates, the shift of rc(read 2) by its trimmed tail) is applied
+//     with a log-step word shifter over the register array instead of an indexed memory access,
+//   * no LDS tile, no workgroup barrier in the loop, no phase with idle wavefronts; LDS holds the MISC_* counters,
+//     two threshold tables and the duplicate hash's base-value table only.
+// Stats::statRead runs afterwards in fq_stats.h (split plan).  The kernel covers the option family in which nothing
+// needs an indexed walk along a read that cannot be bounded (see lane_plan_supported in fastp_gpu.hip); everything
+// else stays on the tile kernels.  Reference: src/peprocessor.cpp:383-643, src/seprocessor.cpp:204-296.
+#pragma once
+#include "fq_device.h"
+
+namespace fq {
+
+// LDS of the lane kernel (dwords from the start of dynamic LDS)
+struct LaneLds {
+    int misc;       // MISC_* counters (u32), flushed to the workgroup's slab
+    int n_misc;
+    int lut_ov;     // u16 [cycles + 1] min(diffLimit, ol * pct)          overlapanalysis.cpp:51
+    int lut_lowq;   // u16 [cycles + 1] floor(unqualPct * rlen / 100.0)   filter.cpp:36
+    int val4;       // u32 [256] Duplicate's base values of the four bases of a packed byte
+    int total;
+};
+
+struct LaneArgs {
+    KernelArgs k;   // parameters, batch, result arrays (the LDS layout inside is not used)
+    LaneLds l;
+};
+
+// ---------------------------------------------------------------------------
+// register arrays with static indices
+// ---------------------------------------------------------------------------
+// words [0, N) shifted towards index 0 by a per-lane number of words (0 .. 31): out[w] = in[w + dw], zero behind the end
+template <int N>
+FQ_DEV void word_shift_down(u32 (&x)[N], u32 dw) {
+#pragma unroll
+    for (int b = 1; b <= 16; b <<= 1) {
+        const bool on = (dw & (u32)b) != 0;
+#pragma unroll
+        for (int w = 0; w < N; w++) {
+            const u32 from = w + b < N ? x[w + b] : 0u;
+            x[w] = on ? from : x[w];
+        }
+    }
+    if (dw >= 32u) {
+#pragma unroll
+        for (int w = 0; w < N; w++) x[w] = 0;
+    }
+}
+// the 2-bit row x (N words, word N - 1 followed by zeros) shifted down by `bases` positions
+template <int N>
+FQ_DEV void base_shift_down(u32 (&x)[N], u32 bases) {
+    word_shift_down<N>(x, bases >> 4);
+    const u32 sh = (bases & 15u) * 2u;
+#pragma unroll
+    for (int w = 0; w < N; w++) x[w] = alignbit(w + 1 < N ? x[w + 1] : 0u, x[w], sh);
+}
+
+// first set bit at or above `lo` and below `hi` of a mask held in NW words; hi if there is none
+template <int NW>
+FQ_DEV int mask_first(const u32 (&m)[NW], int lo, int hi, bool want) {
+    int r = hi;
+    if (lo >= hi) return hi;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; w--) {   // descending: the smallest position is what remains
+        u32 x = want ? m[w] : ~m[w];
+        const int base = 32 * w;
+        if (lo > base) x &= lo - base >= 32 ? 0u : ~lowmask32(lo - base);
+        const int j = base + ffs32(x) - 1;
+        if (x && j < hi) r = j;
+    }
+    return r;
+}
+// last position in [lo, hi) whose bit == want; lo - 1 if there is none
+template <int NW>
+FQ_DEV int mask_last(const u32 (&m)[NW], int lo, int hi, bool want) {
+    int r = lo - 1;
+    if (lo >= hi) return r;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {        // ascending: the largest position is what remains
+        u32 x = want ? m[w] : ~m[w];
+        const int base = 32 * w;
+        if (hi - base < 32) x &= hi - base <= 0 ? 0u : lowmask32(hi - base);
+        const int j = base + 31 - clz32(x);
+        if (x && j >= lo) r = j;
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// one read in registers
+// ---------------------------------------------------------------------------
+template <int SWM>
+struct LaneRead {
+    u32 s[SWM];         // packed bases (N = code 0); bits past the read's end are whatever the row held
+    u32 n[SWM];         // N mask, bit 2k of word w = base 16w + k is N (zero unless hasN)
+    u32 bad[SWM / 2];   // Filter::trimAndCut: bit j = the window [j, j + w) has total quality < threshold
+    int rl0, len;       // original length, length after the steps so far
+    u32 flags;          // RS_*
+};
+
+// Load read `g` of one mate: bases, N mask, the window predicate of cut_right / cut_tail (the one that is enabled),
+// and - in the same sweep over the quality row - the read's part of Duplicate::seq2intvector as byte-plane dot
+// products (phase_hash_dot of the tile kernel: duplicate.cpp:111-120, N counts as 13).
+// `off` = stream position of the read's first base (0 for read 1, read 1's length for read 2, duplicate.cpp:139).
+template <int SWM, int B, int NPL>
+FQ_DEV void lane_load_read(const KernelArgs& a, const u32* lds, const LaneLds& ll, const u32* seq, const u32* qual, const u16* lenp,
+                           int g, bool valid, int off, int win, int thr, LaneRead<SWM>& r, u64 (&h)[B > 0 ? B : 1]) {
+    const DevParams& p = a.p;
+    const int swg = p.sw_g, qwg = p.qw_g;
+    r.rl0 = valid ? (int)lenp[g] : 0;
+    r.len = r.rl0;
+    r.flags = 0;
+    const u64* srow = (const u64*)(seq + (size_t)g * swg);
+    const u64* qrow = (const u64*)(qual + (size_t)g * qwg);
+#pragma unroll
+    for (int w = 0; w < SWM; w += 2) {
+        u64 v = 0;
+        if (valid && w < swg) v = srow[w >> 1];
+        r.s[w] = (u32)v;
+        r.s[w + 1] = (u32)(v >> 32);
+        r.n[w] = r.n[w + 1] = 0;
+    }
+    constexpr int QWM = 4 * SWM;   // quality dwords a row of SWM base words can have
+    u32 q[QWM + 2];
+#pragma unroll
+    for (int c = 0; c < QWM; c += 2) {
+        u64 v = 0;
+        if (valid && c < qwg) v = qrow[c >> 1];
+        q[c] = (u32)v;
+        q[c + 1] = (u32)(v >> 32);
+    }
+    q[QWM] = q[QWM + 1] = 0;
+    // ---- N mask (rare: only dwords that hold an N pay for it) ----
+    u32 anyn = 0;
+#pragma unroll
+    for (int c = 0; c < QWM; c++) {
+        const u32 nb = q[c] & 0x80808080u;
+        if (nb) {
+            const u32 b1 = nb >> 7;   // bits 0, 8, 16, 24
+            const u32 m4 = (b1 | (b1 >> 6) | (b1 >> 12) | (b1 >> 18)) & 0x55u;
+            r.n[c >> 2] |= m4 << (8 * (c & 3));
+            anyn = 1;
+        }
+    }
+    if (anyn) r.flags |= RS_HAS_N;
+    // ---- Duplicate's hash of the original read ----
+    if (B > 0) {
+        const u32* val4 = lds + ll.val4;
+        u32 acc[(B > 0 ? B : 1) * NPL];
+#pragma unroll
+        for (int k = 0; k < B * NPL; k++) acc[k] = 0;
+        const int NQ = a.L.hp_nq;
+        // all lanes of a wavefront almost always share `off` (fixed-length reads): then the planes are scalar loads
+        const int off0 = (int)uniform((u32)off);
+        const bool same = ballot(off != off0) == 0ull;
+        if (same) {
+            const u32* tb = a.lut.dup_planes + (size_t)((off0 & 3) * NQ + (off0 >> 2)) * (B * NPL);
+#pragma unroll
+            for (int c = 0; c < QWM; c++) {
+                if (c >= qwg) break;                       // uniform
+                const u32 byte = (r.s[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+                u32 vals = val4[byte];
+                const u32 mN = ((q[c] >> 7) & 0x01010101u) * 0xFFu;   // N -> 13 (duplicate.cpp:92-109)
+                vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
+                const int rem = r.rl0 - 4 * c;
+                vals = rem >= 4 ? vals : (rem <= 0 ? 0u : (vals & lowmask32(8 * rem)));
+#pragma unroll
+                for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[c * (B * NPL) + k], acc[k]);
+            }
+        } else {
+            const u32* tb = a.lut.dup_planes + (size_t)((off & 3) * NQ + (off >> 2)) * (B * NPL);
+#pragma unroll
+            for (int c = 0; c < QWM; c++) {
+                if (c >= qwg) break;
+                const u32 byte = (r.s[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+                u32 vals = val4[byte];
+                const u32 mN = ((q[c] >> 7) & 0x01010101u) * 0xFFu;
+                vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
+                const int rem = r.rl0 - 4 * c;
+                vals = rem >= 4 ? vals : (rem <= 0 ? 0u : (vals & lowmask32(8 * rem)));
+#pragma unroll
+                for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[c * (B * NPL) + k], acc[k]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            u64 v = (u64)acc[i * NPL] + ((u64)acc[i * NPL + 1] << 8) + ((u64)acc[i * NPL + 2] << 16);
+            if (NPL > 3) v += (u64)acc[i * NPL + 3] << 24;
+            h[i] = v;
+        }
+    }
+    // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
+#pragma unroll
+    for (int W = 0; W < SWM / 2; W++) r.bad[W] = 0;
+    if (win > 0) {
+        const u32 nthr = (u32)(-thr);
+        const u32 keep_lo = lowmask32(8 * imin(win, 4)), keep_hi = win > 4 ? lowmask32(8 * (win - 4)) : 0u;
+#pragma unroll
+        for (int W = 0; W < SWM / 2; W++) {
+            u32 m = 0;
+#pragma unroll
+            for (int d = 7; d >= 0; d--) {
+                const int c = 8 * W + d;
+                const u32 q0 = q[c] & 0x7F7F7F7Fu, q1 = q[c + 1] & 0x7F7F7F7Fu, q2 = q[c + 2] & 0x7F7F7F7Fu;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const u32 x = k ? alignbit(q1, q0, 8 * k) : q0;
+                    u32 sdiff = sum_bytes(x & keep_lo, nthr);
+                    if (win > 4) {   // uniform
+                        const u32 y = k ? alignbit(q2, q1, 8 * k) : q1;
+                        sdiff = sum_bytes(y & keep_hi, sdiff);
+                    }
+                    m = alignbit(m, sdiff, 31);   // m = m << 1 | (sum < thr)
+                }
+            }
+            r.bad[W] = m;
+        }
+    }
+}
+
+// quality character (7 bits) / N flag of base j of a row in global memory (indexed walks that end after a few bases)
+FQ_DEV u32 g_qbyte(const u32* qual, int qwg, int g, int j) { return (u32)((const u8*)(qual + (size_t)g * qwg))[j]; }
+FQ_DEV u32 g_code(const u32* seq, int swg, int g, int j) { return (u32)(((const u8*)(seq + (size_t)g * swg))[j >> 2] >> ((j & 3) * 2)) & 3u; }
+
+// Filter::trimAndCut (filter.cpp:68-207) for the option family of this kernel: no front trim, no cut_front; cut_right
+// or cut_tail (windows <= 8) and a fixed tail trim.  Returns false for NULL; `len` in / out.
+template <int SWM>
+FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const u32* qual, int g, int tail, int& len) {
+    const DevParams& p = a.p;
+    const bool enT = p.cut_tail, enR = p.cut_right;
+    const int l = len;
+    if (tail == 0 && !enT && !enR) return true;                 // :71-72
+    int rlen = l - tail;
+    if (rlen < 0) return false;                                 // :76-77
+    if (!enT && !enR) { len = rlen; return true; }              // :79-89
+    if (enR) {                                                  // :130-163
+        const int w = p.wR;
+        if (l - tail - w <= 0) return false;
+        const int end = l - tail - w;
+        int s = mask_first<SWM / 2>(r.bad, 0, end, true);       // first window below the threshold
+        if (s < end) {                                          // foundLowQualWindow: while (s < l-1 && qual[s] >= 33+Q) s++
+            const u32 qmin = (u32)imin(imax(p.qRmin, 0), 127);
+            while (s < l - 1 && (g_qbyte(qual, p.qw_g, g, s) & 0x7Fu) >= qmin) s++;
+            rlen = s;
+        }
+    }
+    if (!enR && enT) {                                          // :166-194
+        const int w = p.wT;
+        if (l - tail - w <= 0) return false;
+        const int sp = mask_last<SWM / 2>(r.bad, 1, l - tail - w + 1, false);   // none: 0 (= front)
+        int t = sp + w - 1;
+        if (t < l - 1) t = t - w + 1;
+        while (t >= 0 && (g_qbyte(qual, p.qw_g, g, t) & 0x80u)) t--;            // while (t >= 0 && seq[t] == 'N') t--
+        rlen = t + 1;
+    }
+    if (rlen <= 0 || 0 >= l - 1) return false;                  // :196-197 (front == 0)
+    len = rlen;
+    return true;
+}
+
+// PolyX::trimPolyG (polyx.cpp:16-42) on [0, rlen): new length
+FQ_DEV int lane_trim_poly_g(const KernelArgs& a, const u32* seq, const u32* qual, int g, int rlen, int compareReq) {
+    int mismatch = 0, i = 0, firstGPos = rlen - 1;
+    for (i = 0; i < rlen; i++) {
+        const int j = rlen - i - 1;
+        const bool isn = (g_qbyte(qual, a.p.qw_g, g, j) & 0x80u) != 0;
+        if (isn || g_code(seq, a.p.sw_g, g, j) != (u32)CODE_G) mismatch++;
+        else firstGPos = rlen - i - 1;
+        const int allowed = (i + 1) / 8;
+        if (mismatch > 5 || (mismatch > allowed && i >= compareReq - 1)) break;
+    }
+    if (i >= compareReq && firstGPos >= 0) return firstGPos;
+    return rlen;
+}
+
+// ---------------------------------------------------------------------------
+// OverlapAnalysis::analyze (overlapanalysis.cpp:17-89), the no-gap part.  X slides over Y: forward X = r1', Y = rc(r2');
+// reverse X = rc(r2'), Y = r1'.  Prefilter: per offset the 2-bit XOR / popcount of 16 bases against Y's first 16 -
+// X's window at a STATIC offset is one v_alignbit of two registers - survivors are verified exactly, smallest
+// offset first; the first one that passes is the reference's answer for the direction.
+// ---------------------------------------------------------------------------
+// candidate offsets of one direction: bit (15 - t) of half-word b of cm = offset 16 b + t survives
+template <int SWM>
+FQ_DEV void lane_scan(const u32 (&X)[SWM], u32 y0, int nvalid, u32 premask, u32 nlim, u32 (&cm)[SWM / 2]) {
+#pragma unroll
+    for (int W = 0; W < SWM / 2; W++) cm[W] = 0;
+#pragma unroll
+    for (int b = 0; b < SWM; b++) {
+        const int o0 = 16 * b;
+        if (ballot(nvalid > o0) == 0ull) break;   // uniform: no lane has offsets this far out
+        const u32 w0 = X[b], w1 = b + 1 < SWM ? X[b + 1] : 0u;
+        u32 cand = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const u32 x = t ? alignbit(w1, w0, 2 * t) : w0;
+            const u32 d = x ^ y0;
+            const u32 sd = (u32)popc32((d | (d >> 1)) & premask) + nlim;   // negative <=> count <= lmax
+            cand = alignbit(cand, sd, 31);
+        }
+        cand &= 0xFFFFu;
+        const int left = nvalid - o0;
+        if (left < 16) cand = left <= 0 ? 0u : (cand & ~lowmask32(16 - left));
+        cm[b >> 1] |= cand << (16 * (b & 1));
+    }
+}
+// smallest candidate offset left in cm (removed from it), or -1
+template <int SWM>
+FQ_DEV int lane_next_candidate(u32 (&cm)[SWM / 2]) {
+    int o = -1;
+#pragma unroll
+    for (int W = SWM / 2 - 1; W >= 0; W--) {
+        const u32 lo = cm[W] & 0xFFFFu, hi = cm[W] >> 16;
+        if (hi) o = 32 * W + 16 + (clz32(hi) - 16);
+        if (lo) o = 32 * W + (clz32(lo) - 16);
+    }
+    if (o >= 0) {
+        const int b = o >> 4, t = o & 15;
+        const u32 bit = (0x8000u >> t) << (16 * (b & 1));
+#pragma unroll
+        for (int W = 0; W < SWM / 2; W++)
+            if (W == (b >> 1)) cm[W] &= ~bit;
+    }
+    return o;
+}
+// acceptNoGapOverlap (:34-44) of X shifted by o against Y; -1 or the reported difference count
+template <int SWM>
+FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM], const u32 (&Y)[SWM], const u32 (&YN)[SWM], bool hasN, int o, int lenX,
+                       int lenY, const u16* lut) {
+    const int ol = imin(lenX - o, lenY);
+    const int limit = (int)lut[ol];
+    const int pre = imin(ol, 50);   // complete_compare_require (:28)
+    u32 xs[SWM], xn[SWM];
+#pragma unroll
+    for (int w = 0; w < SWM; w++) { xs[w] = X[w]; xn[w] = XN[w]; }
+    base_shift_down<SWM>(xs, (u32)o);
+    if (hasN) base_shift_down<SWM>(xn, (u32)o);
+    int cnt_pre = 0, cnt_full = 0;
+#pragma unroll
+    for (int w = 0; w < SWM; w++) {
+        const int t = 16 * w;
+        u32 dd = fold_diff(xs[w] ^ Y[w]);
+        if (hasN) dd |= xn[w] ^ YN[w];
+        const int rem = ol - t, remp = pre - t;
+        cnt_full += popc32(rem >= 16 ? dd : (rem <= 0 ? 0u : (dd & lowmask32(2 * rem))));
+        cnt_pre += popc32(remp >= 16 ? dd : (remp <= 0 ? 0u : (dd & lowmask32(2 * remp))));
+    }
+    if (cnt_pre > limit) return -1;
+    return ol > 50 ? cnt_full : cnt_pre;
+}
+
+// ---------------------------------------------------------------------------
+// fastp_simd::countQualityMetrics (simd.cpp:54-119) of [0, len): total (qual - 33), bases below the qualified quality, N
+// ---------------------------------------------------------------------------
+template <int SWM>
+FQ_DEV void lane_metrics(const KernelArgs& a, const u32* qual, int g, bool valid, int len, int& tot, int& low, int& nb) {
+    const int qwg = a.p.qw_g;
+    const u64* qrow = (const u64*)(qual + (size_t)g * qwg);
+    const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
+    u32 t = 0, lo = 0, n = 0;
+#pragma unroll
+    for (int c = 0; c < 4 * SWM; c += 2) {
+        if (c >= qwg) break;                                     // uniform
+        if (ballot(valid && 4 * c < len) == 0ull) break;         // uniform: nobody's window reaches this far
+        const u64 v = (valid && 4 * c < len) ? qrow[c >> 1] : 0ull;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+            const u32 qd = hlf ? (u32)(v >> 32) : (u32)v;
+            const int rem = len - 4 * (c + hlf);
+            const u32 M = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : lowmask32(8 * rem));
+            const u32 q7 = qd & 0x7F7F7F7Fu & M;
+            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;   // bit 7 of a byte: qual >= threshold
+            t = sum_bytes(q7, t);
+            lo += (u32)popc32(~ge & 0x80808080u & M);
+            n += (u32)popc32(qd & 0x80808080u & M);
+        }
+    }
+    tot = (int)t - 33 * len;
+    low = (int)lo;
+    nb = (int)n;
+}
+
+FQ_DEV void lane_claim(const KernelArgs& a, int gp, int tl, const u64* h, int B, u32& won) {
+    // Duplicate's claim (dup_claim_issue / dup_claim_collect of the tile kernel) for this unit
+    const u64 words = a.dup_bits >> 5;
+    won = 0;
+    for (int i = 0; i < B; i++) {
+        const u64 hh = h[i] + a.lut.dup_posum[(size_t)tl * B + i];
+        const u64 pos = hh & (a.dup_bits - 1);
+        const u32 bit = 1u << (pos & 31);
+        const u32 old = g_atomic_or_u32(&a.dup_bitmap[(size_t)i * words + (pos >> 5)], bit);
+        if (!(old & bit)) won |= 1u << i;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the kernel body: persistent wavefronts, a wavefront takes 64 consecutive units at a time
+// ---------------------------------------------------------------------------
+template <int SWM, int B, int NPL, bool PAIRED>
+FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
+    const KernelArgs& a = la.k;
+    const LaneLds& ll = la.l;
+    const DevParams& p = a.p;
+    const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
+    {   // one-time per workgroup
+        for (int i = tid; i < ll.n_misc; i += nt) lds[ll.misc + i] = 0;
+        const int lw = (p.cycles + 2) / 2;
+        const u32* g0 = (const u32*)a.lut.ov_limit;
+        const u32* g1 = (const u32*)a.lut.lowq_limit;
+        for (int i = tid; i < lw; i += nt) {
+            lds[ll.lut_ov + i] = g0[i];
+            lds[ll.lut_lowq + i] = g1[i];
+        }
+        if (B > 0)
+            for (int i = tid; i < 256; i += nt) {  // duplicate.cpp:92-109: A=7 T=222 C=74 G=31 (codes A0 T1 C2 G3)
+                u32 v = 0;
+                for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
+                lds[ll.val4 + i] = v;
+            }
+        block_sync();
+    }
+    u32* misc = lds + ll.misc;
+    const u16* lut_ov = (const u16*)(lds + ll.lut_ov);
+    const u16* lut_lowq = (const u16*)(lds + ll.lut_lowq);
+    const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
+    const int win = p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0);
+    const int thr = p.cut_right ? p.thrR : p.thrT;
+    const int chunks = (a.n + 63) >> 6;
+    const int wpb = nt >> 6;
+    for (int chunk = block_id() * wpb + (tid >> 6); chunk < chunks; chunk += grid_blocks() * wpb) {   // wave-uniform
+        const int gp = chunk * 64 + lane;
+        const bool valid = gp < a.n;
+        const int g = valid ? gp : 0;
+        LaneRead<SWM> r1, r2;
+        u64 h1[B > 0 ? B : 1], h2[B > 0 ? B : 1];
+        lane_load_read<SWM, B, NPL>(a, lds, ll, a.seq[0], a.qual[0], a.len[0], g, valid, 0, win, thr, r1, h1);
+        if (PAIRED) lane_load_read<SWM, B, NPL>(a, lds, ll, a.seq[1], a.qual[1], a.len[1], g, valid, r1.rl0, win, thr, r2, h2);
+        if (a.dupflag && valid && a.dupflag[g]) {   // --dedup: Duplicate::checkPair/checkRead already ran for this batch
+            r1.flags |= RS_DUP;
+            if (PAIRED) r2.flags |= RS_DUP;
+        }
+        // Duplicate's claim: fired now, looked at when the record is written
+        u32 won = 0;
+        const bool claim = B > 0 && a.claim_won != nullptr;
+        if (B > 0 && valid) {
+            u64 hs[B > 0 ? B : 1];
+#pragma unroll
+            for (int i = 0; i < B; i++) hs[i] = h1[i] + (PAIRED ? h2[i] : 0ull);
+            if (a.dup_pos)
+                for (int i = 0; i < B; i++) a.dup_pos[(size_t)g * B + i] = hs[i];
+            if (claim) lane_claim(a, g, r1.rl0 + (PAIRED ? r2.rl0 : 0), hs, B, won);
+        }
+        // ---- Filter::trimAndCut, PolyX::trimPolyG ----
+        if (valid) {
+            if (!lane_trim_and_cut<SWM>(a, r1, a.qual[0], g, p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
+            if (PAIRED && !lane_trim_and_cut<SWM>(a, r2, a.qual[1], g, p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
+        }
+        const bool a1 = valid && !(r1.flags & RS_NULL), a2 = PAIRED ? (valid && !(r2.flags & RS_NULL)) : a1;
+        const bool both = a1 && a2;
+        if (p.poly_g && both) {   // both mates survived trimAndCut (peprocessor.cpp:428-431)
+            r1.len = lane_trim_poly_g(a, a.seq[0], a.qual[0], g, r1.len, p.poly_g_min);
+            if (PAIRED) r2.len = lane_trim_poly_g(a, a.seq[1], a.qual[1], g, r2.len, p.poly_g_min);
+        }
+        u32 apos1 = 0, alen1 = 0, apos2 = 0, alen2 = 0;
+        bool dimer = false;
+        if (PAIRED) {
+            // ---- OverlapAnalysis::analyze ----
+            u32 key = OV_KEY_NONE;
+            const bool want_ov = p.need_overlap || thread0;   // peprocessor.cpp:438
+            if (want_ov && ballot(both) != 0ull) {
+                const int l1 = r1.len, l2 = r2.len;
+                const bool hasN = ((r1.flags | r2.flags) & RS_HAS_N) != 0;
+                // rc(r2') in registers: reverse the word order and the groups, complement, move the frame's unused head out
+                u32 rc[SWM], rcn[SWM];
+#pragma unroll
+                for (int w = 0; w < SWM; w++) {
+                    rc[w] = reverse_groups(r2.s[SWM - 1 - w]) ^ 0x55555555u;
+                    rcn[w] = reverse_groups(r2.n[SWM - 1 - w]);
+                }
+                const u32 D = (u32)(16 * SWM - l2);
+                base_shift_down<SWM>(rc, D);
+                if (hasN) {
+                    base_shift_down<SWM>(rcn, D);
+#pragma unroll
+                    for (int w = 0; w < SWM; w++) rc[w] &= ~(rcn[w] | (rcn[w] << 1));   // N stays code 0 on both strands
+                } else {
+#pragma unroll
+                    for (int w = 0; w < SWM; w++) rcn[w] = 0;
+                }
+                // bases past l2 of rc are zeros by construction; bases of r1 past l1 are masked by every consumer
+                const u32 nlim = (u32)(-(p.ov_limit_max + 1));
+                u32 cm[SWM / 2];
+                // forward: X = r1', Y = rc(r2')
+                {
+                    const int nvalid = both ? l1 - p.overlap_require : 0;
+                    const int npre = imin(16, imin(p.overlap_require + 1, l2));
+                    const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+                    lane_scan<SWM>(r1.s, rc[0], nvalid, premask, nlim, cm);
+                    for (;;) {
+                        const int o = key == OV_KEY_NONE ? lane_next_candidate<SWM>(cm) : -1;
+                        if (ballot(o >= 0) == 0ull) break;
+                        if (o >= 0) {
+                            const int diff = lane_verify<SWM>(r1.s, r1.n, rc, rcn, hasN, o, l1, l2, lut_ov);
+                            if (diff >= 0) key = ov_key(0, o, diff);
+                        }
+                    }
+                }
+                // reverse: X = rc(r2'), Y = r1'
+                if (ballot(both && key == OV_KEY_NONE) != 0ull) {
+                    const int nvalid = (both && key == OV_KEY_NONE) ? l2 - p.overlap_require : 0;
+                    const int npre = imin(16, imin(p.overlap_require + 1, l1));
+                    const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+                    lane_scan<SWM>(rc, r1.s[0], nvalid, premask, nlim, cm);
+                    for (;;) {
+                        const int o = key == OV_KEY_NONE ? lane_next_candidate<SWM>(cm) : -1;
+                        if (ballot(o >= 0) == 0ull) break;
+                        if (o >= 0) {
+                            const int diff = lane_verify<SWM>(rc, rcn, r1.s, r1.n, hasN, o, l2, l1, lut_ov);
+                            if (diff >= 0) key = ov_key(1, o, diff);
+                        }
+                    }
+                }
+            }
+            // ---- peprocessor.cpp:443-516: insert size, adapter trimming by overlap, max_len ----
+            int cur1 = r1.len, cur2 = r2.len;
+            int ovl, ov_off, ov_len, ov_diff;
+            decode_overlap(key, cur1, cur2, ovl, ov_off, ov_len, ov_diff);
+            bool isize_done = false;
+            if (both && thread0) {   // statInsertSize (peprocessor.cpp:710-723)
+                int isize = p.isize_max;
+                if (ovl) isize = ov_off > 0 ? cur1 + cur2 - ov_len : ov_len;
+                if (isize > p.isize_max) isize = p.isize_max;
+                if (isize >= 0) lds_add_u32(&misc[MISC_ISIZE + isize], 1u);
+                isize_done = true;
+            }
+            if (both && p.need_overlap && p.adapter_enabled) {
+                bool trimmed = false;
+                if (ovl && ov_off < 0) {   // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
+                    const int len1 = imin(cur1, ov_len), len2 = imin(cur2, ov_len);
+                    apos1 = (u32)len1; alen1 = (u32)(cur1 - len1);
+                    apos2 = (u32)len2; alen2 = (u32)(cur2 - len2);
+                    lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)((cur1 - len1) + (cur2 - len2)));
+                    cur1 = len1;
+                    cur2 = len2;
+                    trimmed = true;
+                    r1.flags |= RS_ADAPTER_OV | RS_ADAPTER;
+                    r2.flags |= RS_ADAPTER_OV | RS_ADAPTER;
+                    lds_add_u32(&misc[MISC_ADAPTER_READS], 2u);   // :472-475
+                }
+                if (trimmed && cur1 <= p.dimer_max_len && cur2 <= p.dimer_max_len) dimer = true;   // :480-484
+            }
+            if (both) {   // :511-516
+                if (p.max_len1 > 0 && p.max_len1 < cur1) cur1 = p.max_len1;
+                if (p.max_len2 > 0 && p.max_len2 < cur2) cur2 = p.max_len2;
+            }
+            r1.len = cur1;
+            r2.len = cur2;
+            if (valid) write_pair_result(a, g, ovl, ov_off, ov_len, ov_diff, isize_done);
+        } else {
+            if (a1 && p.max_len1 > 0 && p.max_len1 < r1.len) r1.len = p.max_len1;   // seprocessor.cpp:268-271
+        }
+        // ---- Filter::passFilter (filter.cpp:15-57), routing, records ----
+        int tot1, low1, nb1, tot2 = 0, low2 = 0, nb2 = 0;
+        lane_metrics<SWM>(a, a.qual[0], g, a1, r1.len, tot1, low1, nb1);
+        if (PAIRED) lane_metrics<SWM>(a, a.qual[1], g, a2, r2.len, tot2, low2, nb2);
+        if (valid) {
+            int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, 0, (int)lut_lowq[r1.len], 0) : 16;
+            int code2 = 0;
+            if (PAIRED) {
+                code2 = a2 ? filter_code_pre(p, r2.len, tot2, low2, nb2, 0, (int)lut_lowq[r2.len], 0) : 16;
+                if (dimer) { code1 = 28; code2 = 28; }                          // :568-571
+                lds_add_u32(&misc[MISC_FILTER + imax(code1, code2)], 2u);       // addFilterResult(max, 2) :573
+            } else {
+                lds_add_u32(&misc[MISC_FILTER + code1], 1u);                    // seprocessor.cpp:278
+            }
+            const bool dedup_out = p.dedup && (r1.flags & RS_DUP);
+            const bool post = !dedup_out && a1 && a2 && code1 == 0 && code2 == 0;   // written to out1 / out2 (:577-591)
+            const u32 sw1 = (u32)r1.rl0 | (post ? (u32)r1.len << 16 : 0u);
+            split_stat_reads(a, misc, g, sw1, PAIRED ? ((u32)r2.rl0 | (post ? (u32)r2.len << 16 : 0u)) : 0u);
+            u32* o1 = a.res[0] + (size_t)g * 3;
+            o1[0] = (u32)r1.len << 16;
+            o1[1] = ((u32)code1 & 0xFFu) | ((r1.flags & 0xFFu) << 8) | (apos1 << 16);
+            o1[2] = alen1 & 0xFFFFu;
+            if (PAIRED) {
+                u32* o2 = a.res[1] + (size_t)g * 3;
+                o2[0] = (u32)r2.len << 16;
+                o2[1] = ((u32)code2 & 0xFFu) | ((r2.flags & 0xFFu) << 8) | (apos2 << 16);
+                o2[2] = alen2 & 0xFFFFu;
+            }
+            if (claim) a.claim_won[g] = (u8)won;
+        }
+    }
+    block_sync();
+    u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
+    for (int i = tid; i < a.slab_dwords; i += nt) slab[i] = lds[ll.misc + i];
+}
+
+}  // namespace fq

@@ -35,7 +35,8 @@ struct StatsArgs {
     // LDS layout (dwords)
     int l_cyc;              // [4][8][N_CLS][H] u64
     int l_kmer;             // [4][KMER_BINS] u32
-    int l_qh;               // [ST_QH_COPIES][4][128] u32: lane l adds to copy l % ST_QH_COPIES (same-address atomics serialise)
+    int l_qh;               // [4][128][ST_QH_COPIES] u32: lane l adds to copy l % ST_QH_COPIES of a bin (same-address atomics
+                            // serialise; the copies of a bin sit in consecutive banks)
     int l_lut;              // [256] x 4 dwords: character | kept << 7 -> {increment u64, per-cycle byte offset, k-mer byte offset}
     int l_wl, wl_cap;       // work list of the items with an N among their 12 bases: [0] = count, then wl_cap item numbers
     int l_total;
@@ -93,7 +94,7 @@ FQ_DEV void stats_item_general(const StatsArgs& a, u32* lds, const StatsItem& s,
     if (s.h == 0) n12 |= 0xFu;
     const u32 c24 = s.prev8 | (s.codes << 8);
     const int j0 = 8 * s.h;
-    u32* qh = lds + a.l_qh + (lane & (ST_QH_COPIES - 1)) * 512;
+    u32* qh = lds + a.l_qh + (lane & (ST_QH_COPIES - 1));
     for (int k = 0; k < 8; k++) {
         const int j = j0 + k;
         if (j >= s.rl0) break;
@@ -102,7 +103,7 @@ FQ_DEV void stats_item_general(const StatsArgs& a, u32* lds, const StatsItem& s,
         const int cls = isn ? (int)CLS_N : (int)((s.codes >> (2 * k)) & 3u);
         const int slot = 2 * s.m + (j < s.lk ? 1 : 0);
         lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + cls) * a.H + s.h], stats_inc_of(q));
-        lds_add_u32(&qh[slot * 128 + (int)q], 1u);
+        lds_add_u32(&qh[(slot * 128 + (int)q) * ST_QH_COPIES], 1u);
         if (((n12 >> k) & 0x1Fu) == 0u) lds_add_u32(&lds[a.l_kmer + slot * KMER_BINS + (int)((c24 >> (2 * k)) & 0x3FFu)], 1u);
     }
 }
@@ -133,7 +134,7 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
     const int total = (a.paired ? 2 : 1) * per_mate;
     u8* ldsw = (u8*)lds;
     const u32 cyc_b = (u32)a.l_cyc * 4u, kmer_b = (u32)a.l_kmer * 4u, lut_b = (u32)a.l_lut * 4u;
-    const u32 qh_b = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 2048u;
+    const u32 qh_b = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 4u;
     const u32 dbg = a.debug_skip;
     u32* wl = lds + a.l_wl;
     // The wavefront's mode = the histogram bin (Stats slot AND character) of the first item's first base, fixed at its
@@ -169,7 +170,7 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         const u32 c24 = s.prev8 | (s.codes << 8);              // bases j0-4 .. j0+7, 2 bits each
         const u32 cyc0 = cyc_b + slot_d * S8 + (u32)s.h * 8u;
         const u32 kmer0 = kmer_b + slot_d * (KMER_BINS * 4);
-        const u32 qh0 = qh_b + slot_d * 512u;
+        const u32 qh0 = qh_b + slot_d * (512u * ST_QH_COPIES);
         const u32 bin0 = slot_d * 128u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -183,14 +184,14 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
             if (!(dbg & 256u)) {
                 const bool is_mode = bin0 + e == mode_bin;
                 agg_cnt += is_mode ? 1u : 0u;
-                if (!is_mode && one) lds_add_u32((u32*)(ldsw + (qh0 + (e << 2))), 1u);
+                if (!is_mode && one) lds_add_u32((u32*)(ldsw + (qh0 + e * (4u * ST_QH_COPIES))), 1u);
             }
         }
     }
     if (mode_bin != 0xFFFFFFFFu) {
 #pragma unroll
         for (int sh = 1; sh < 64; sh <<= 1) agg_cnt += shfl_xor(agg_cnt, sh);
-        if (lane == 0 && agg_cnt) lds_add_u32(&lds[a.l_qh + (int)mode_bin], agg_cnt);
+        if (lane == 0 && agg_cnt) lds_add_u32(&lds[a.l_qh + (int)mode_bin * ST_QH_COPIES], agg_cnt);
     }
     block_sync();
     // ---- the queued items, every lane busy ----
@@ -221,7 +222,7 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
     for (int i = tid; i < 4 * KMER_BINS; i += nt) slab[2 * n_cyc + i] = lds[a.l_kmer + i];
     for (int i = tid; i < 4 * 128; i += nt) {
         u32 v = 0;
-        for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + c * 512 + i];
+        for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
         slab[2 * n_cyc + 4 * KMER_BINS + i] = v;
     }
 }

@@ -359,6 +359,7 @@ class GpuEngine:
     def reset(self):
         """a new run on the same context (fresh Stats / FilterResult / Duplicate)"""
         self._check(self.lib.fastp_gpu_reset(self.h))
+        self._shard_stream_done = (0, 0)   # multigpu.run_shard's running stream origin belongs to the run that just ended
 
     # ---- collectives behind the C ABI (RCCL; csrc/fq_comm.cpp) ----
     def _comm_check(self, rc):

@@ -426,6 +426,8 @@ class FastqPipeline:
             r.adapter_events, r.adapter_events_capacity, r.n_adapter_events = self.ev.data_ptr(), self.ev_cap, self.nev.data_ptr()
         self.eng.submit_device(b, r)
         self.eng.synchronize()
+        if self.corr_cap and int(self.nc[0].item()) > self.corr_cap:   # before anything reads the list
+            raise PipelineError("correction list overflow: raise corr_capacity")
         st["t_engine"] += time.perf_counter() - t0
         t0 = time.perf_counter()
         fi = []

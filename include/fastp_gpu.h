@@ -423,6 +423,9 @@ typedef struct fastp_gpu_format_options {
     int32_t umi_len;
     const char* umi_prefix;   /* host string, may be NULL, at most 32 characters */
     const char* umi_delimiter;/* host string, NULL = ":", at most 8 characters   */
+    int32_t corrections_capacity; /* entries the correction list can hold; 0 = the capacity given to the submit that
+                                     filled it on this context.  A list whose counter ran past it is not applied:
+                                     FASTP_GPU_E_OVERFLOW, nothing is read behind the buffer */
 } fastp_gpu_format_options;
 
 typedef struct fastp_gpu_format_io {

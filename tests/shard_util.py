@@ -56,7 +56,7 @@ def fetch_records(keep, paired):
     return r1, r2, pr
 
 
-def shard_worker(rank, world, port, ret, kind, name, n, npacks, L=100, exact=True):
+def shard_worker(rank, world, port, ret, kind, name, n, npacks, L=100, exact=True, runs=1):
     """one rank of a sharded run over gloo; kind = 'sim' (emulator, cpu tensors) or 'gpu' (cuda:0 for every rank)"""
     import os
     import sys
@@ -76,7 +76,10 @@ def shard_worker(rank, world, port, ret, kind, name, n, npacks, L=100, exact=Tru
     eng = engines.sim_engine(params) if kind == "sim" else engines.gpu_engine(params)
     lo, hi = multigpu.shard_bounds(n, world, rank)
     batches, results, keep = device_batches(eng, d, lo, hi, npacks, device)
-    multigpu.run_shard(eng, dist, rank, world, batches, results, device, exact=exact)
+    for k in range(runs):   # runs > 1: the same shard again after GpuEngine.reset() - every run must be a fresh stream
+        if k:
+            eng.reset()
+        multigpu.run_shard(eng, dist, rank, world, batches, results, device, exact=exact)
     merged = multigpu.allreduce_counters_host(eng.counters(), dist)
     recs = fetch_records(keep, paired)
     eng.close()

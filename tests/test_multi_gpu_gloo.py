@@ -107,6 +107,31 @@ def test_two_rank_exact_protocol_equals_one_stream(name, npacks):
         assert ret[0][k + 1] + ret[1][k + 1] == whole[k].tobytes(), f"{name}: records {k} differ"
 
 
+def test_two_rank_exact_protocol_after_reset_is_a_fresh_stream():
+    """two sharded runs on the same engines with GpuEngine.reset() in between (what bench.py does between cycles): the
+    second run's overrepresentation sampling must start at the origin again, i.e. its counters equal ONE fresh stream"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import engines
+    import oraclelib
+    import shard_util
+    engines.build_sim()
+    n = 1100
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + 13
+    mp.spawn(shard_util.shard_worker, args=(2, port, ret, "sim", "pe_overrep", n, 2, 100, True, 2), nprocs=2, join=True)
+    params, d, paired = shard_util.case_input("pe_overrep", n)
+    o = oraclelib.Oracle(params)
+    whole = o.process(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    ctr = o.counters()
+    o.close()
+    assert np.array_equal(ret[0][0], ret[1][0])
+    bad = np.nonzero(ret[0][0] != ctr)[0]
+    assert len(bad) == 0, f"second run after reset: counters differ at {bad[:8]}"
+    for k in range(3):
+        assert ret[0][k + 1] + ret[1][k + 1] == whole[k].tobytes()
+
+
 def test_two_rank_plain_submit_misses_cross_shard_duplicates():
     """the input of the exact-protocol test does contain cross-shard duplicates: without the protocol they are missed"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
