@@ -43,7 +43,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a)
 // the per-read path with one lane per pair, reads in registers (fq_lane.h): SWM base words per read (10: up to 160
 // bases, 16: up to 256), B bloom buffers hashed (0: no hashing in this launch), byte planes per prime, paired / single
 template <int SWM, int B, int NPL, bool PAIRED>
-__global__ void __launch_bounds__(256) fq_lane_kernel(LaneArgs a) {
+__global__ void __launch_bounds__(256, 3) fq_lane_kernel(LaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     lane_body<SWM, B, NPL, PAIRED>(*kernel_args(&a), fq_lds);
 }
@@ -449,12 +449,21 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             l.lut_ov = o; o += lw;
             l.lut_lowq = o; o += lw;
             l.val4 = o; o += 256;
+            o = (o + 1) & ~1;
+            l.planes = o;
+            l.n_planes = ctx->dp.dup_enabled ? (int)ctx->luts.dup_planes.size() : 0;
+            o += l.n_planes;
+            o = (o + 3) & ~3;
+            l.stage = o;
+            l.stage_dwords = (64 * std::max(ctx->dp.qw_g, ctx->dp.sw_g) + 3) & ~3;
+            o += 4 * l.stage_dwords;   // 256-lane workgroups: four wavefronts
             l.total = o;
             int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);
 #ifndef FQ_HOSTSIM
             if (per_cu <= 0) {
                 int nb = 0;
                 lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0);
+                (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, l.total * 4);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)l.total * 4) == hipSuccess && nb > 0) per_cu = nb;
                 (void)hipGetLastError();
             }
@@ -546,7 +555,12 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_blocks * ctx->st_slab_dwords * 4));
-        if (ctx->lane) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
+        if (ctx->lane) {
+            CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
+            for (int Bh : {0, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0})
+                CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, ctx->ln_lds.total * 4));
+        }
     }
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DefLds)));
@@ -970,11 +984,11 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         rc = launch_dup(nullptr, false, nullptr, 1);
         if (rc) return rc;
     }
-    // the lane kernel loads rows with 8-byte accesses: a batch whose rows are not 8-byte aligned takes the tile kernel
+    // the lane kernel copies rows with 16-byte accesses: a batch whose arrays are not 16-byte aligned takes the tile kernel
     bool use_lane = ctx->lane;
     {
         const void* ptrs[4] = {a.seq[0], a.qual[0], ctx->dp.paired ? a.seq[1] : a.seq[0], ctx->dp.paired ? a.qual[1] : a.qual[0]};
-        for (const void* q : ptrs) use_lane = use_lane && (((uintptr_t)q & 7u) == 0);
+        for (const void* q : ptrs) use_lane = use_lane && (((uintptr_t)q & 15u) == 0);
     }
     int ln_grid = 0;
     hipEvent_t e0, e1;
@@ -992,7 +1006,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.k.slabs = ctx->d_ln_slabs;
             la.k.slab_dwords = ctx->ln_lds.n_misc;
             la.l = ctx->ln_lds;
-            const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won)) ? ctx->dp.dup_bufnum : 0;
+            const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
             lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0);
             ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
             hipLaunchKernelGGL(fn, dim3(ln_grid), dim3(256), (size_t)ctx->ln_lds.total * 4, st, la);

@@ -126,6 +126,14 @@ FQ_DEV void wave_order() {
 #endif
 }
 
+// nothing is scheduled across this point (keeps two independent load sweeps from being interleaved, which doubles
+// the registers in flight)
+FQ_DEV void sched_fence() {
+#ifndef FQ_HOSTSIM
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 FQ_DEV u64 ballot(bool pred) { return __ballot(pred); }
 FQ_DEV u32 shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
 // the value lane `src` holds, src the same in every lane (v_readlane_b32: no LDS crossbar trip)

@@ -27,6 +27,10 @@ struct LaneLds {
     int lut_ov;     // u16 [cycles + 1] min(diffLimit, ol * pct)          overlapanalysis.cpp:51
     int lut_lowq;   // u16 [cycles + 1] floor(unqualPct * rlen / 100.0)   filter.cpp:36
     int val4;       // u32 [256] Duplicate's base values of the four bases of a packed byte
+    int planes;     // u32 [4][hp_nq][B][NPL] byte planes of the primes (DevLuts::dup_planes), 8-byte aligned
+    int n_planes;
+    int stage;      // per wavefront: 64 rows of one mate's quality (then base) rows, copied from HBM with coalesced 16-byte
+    int stage_dwords;   // loads and read back one row per lane (16-byte aligned, 64 * qw_g dwords each)
     int total;
 };
 
@@ -63,6 +67,26 @@ FQ_DEV void base_shift_down(u32 (&x)[N], u32 bases) {
 #pragma unroll
     for (int w = 0; w < N; w++) x[w] = alignbit(w + 1 < N ? x[w + 1] : 0u, x[w], sh);
 }
+
+// a 1-bit-per-base row (NW words of 32 bases, zeros behind) shifted down by `bits` positions
+template <int NW>
+FQ_DEV void bit_shift_down(u32 (&x)[NW], u32 bits) {
+    word_shift_down<NW>(x, bits >> 5);
+    const u32 sh = bits & 31u;
+#pragma unroll
+    for (int w = 0; w < NW; w++) x[w] = alignbit(w + 1 < NW ? x[w + 1] : 0u, x[w], sh);
+}
+// bit k of the low 16 bits -> bit 2k
+FQ_DEV u32 spread16(u32 x) {
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    return (x | (x << 1)) & 0x55555555u;
+}
+// the 16 bases of 2-bit word w of a 1-bit-per-base row, spread to bit 2k
+template <int NW>
+FQ_DEV u32 nmask_word(const u32 (&n)[NW], int w) { return spread16(n[w >> 1] >> (16 * (w & 1))); }
 
 // first set bit at or above `lo` and below `hi` of a mask held in NW words; hi if there is none
 template <int NW>
@@ -101,8 +125,9 @@ FQ_DEV int mask_last(const u32 (&m)[NW], int lo, int hi, bool want) {
 template <int SWM>
 struct LaneRead {
     u32 s[SWM];         // packed bases (N = code 0); bits past the read's end are whatever the row held
-    u32 n[SWM];         // N mask, bit 2k of word w = base 16w + k is N (zero unless hasN)
+    u32 n[SWM / 2];     // N mask, bit j = base j is N (zero unless hasN)
     u32 bad[SWM / 2];   // Filter::trimAndCut: bit j = the window [j, j + w) has total quality < threshold
+    u32 met[SWM / 2];   // countQualityMetrics of bases 32 W .. 32 W + 31: sum of the characters | below-threshold << 16 | N << 24
     int rl0, len;       // original length, length after the steps so far
     u32 flags;          // RS_*
 };
@@ -111,106 +136,135 @@ struct LaneRead {
 // and - in the same sweep over the quality row - the read's part of Duplicate::seq2intvector as byte-plane dot
 // products (phase_hash_dot of the tile kernel: duplicate.cpp:111-120, N counts as 13).
 // `off` = stream position of the read's first base (0 for read 1, read 1's length for read 2, duplicate.cpp:139).
+// Duplicate::seq2intvector (duplicate.cpp:111-120) of the original read as byte-plane dot products (phase_hash_dot of
+// the tile kernel; N counts as 13, duplicate.cpp:92-109).  `off` = stream position of the read's first base (0 for
+// read 1, read 1's length for read 2, duplicate.cpp:139); the planes of the primes of the read's positions come from
+// the LDS copy of the table (the lanes of a wavefront mostly share `off`: broadcast reads).
 template <int SWM, int B, int NPL>
-FQ_DEV void lane_load_read(const KernelArgs& a, const u32* lds, const LaneLds& ll, const u32* seq, const u32* qual, const u16* lenp,
-                           int g, bool valid, int off, int win, int thr, LaneRead<SWM>& r, u64 (&h)[B > 0 ? B : 1]) {
+FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, const LaneRead<SWM>& r, int off, u64 (&h)[B]) {
+    const u32* val4 = lds + ll.val4;
+    const int qwg = a.p.qw_g;
+    u32 acc[B * NPL];
+#pragma unroll
+    for (int k = 0; k < B * NPL; k++) acc[k] = 0;
+    const u32* tb = lds + ll.planes + ((off & 3) * a.L.hp_nq + (off >> 2)) * (B * NPL);
+#pragma unroll
+    for (int c = 0; c < 4 * SWM; c++) {
+        if (c < qwg) {   // uniform
+            const u32 byte = (r.s[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+            u32 vals = val4[byte];
+            const u32 nb = (r.n[c >> 3] >> (4 * (c & 7))) & 0xFu;
+            if (nb) {
+                const u32 mN = ((nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21)) * 0xFFu;
+                vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
+            }
+            const int rem = r.rl0 - 4 * c;
+            vals = rem >= 4 ? vals : (rem <= 0 ? 0u : (vals & lowmask32(8 * rem)));
+#pragma unroll
+            for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[c * (B * NPL) + k], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        u64 v = (u64)acc[i * NPL] + ((u64)acc[i * NPL + 1] << 8) + ((u64)acc[i * NPL + 2] << 16);
+        if (NPL > 3) v += (u64)acc[i * NPL + 3] << 24;
+        h[i] = v;
+    }
+}
+
+// Load read `g` of one mate: bases, N mask, and in ONE sweep over the quality row the window predicate of cut_right /
+// cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.
+// 64 consecutive rows of `stride` dwords (the wavefront's chunk of one mate) HBM -> this wavefront's LDS buffer with
+// coalesced 16-byte loads.  A lane reading its own 152-byte row straight from HBM touches a fresh 128-byte line per
+// 8-byte load: the rows of 12 resident wavefronts do not fit the 32 KB L1, so nearly every load refetched its line
+// from L2 (profiles/r03e: the load sweep alone took 1.0 ms per 4 M pairs).  Row r of the buffer starts at dword
+// r * stride: stride / 2 is odd for the common read lengths, so the 64-bit row reads of a half-wave are conflict-free.
+FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int lane) {
+    wave_order();   // the buffer's previous contents have been read
+    const int bytes = rows * stride * 4;
+    const u32x4* s4 = (const u32x4*)src;
+    u32x4* d4 = (u32x4*)buf;
+    const int n16 = bytes >> 4;
+    for (int i = lane; i < n16; i += 64) d4[i] = s4[i];
+    if ((bytes & 8) && lane == 0) ((u64*)buf)[2 * n16] = ((const u64*)src)[2 * n16];
+    wave_order();
+}
+
+// Load read `g` of one mate: bases, N mask, and in ONE sweep over the quality row the window predicate of cut_right /
+// cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.  `stage` = this
+// wavefront's LDS buffer, chunk0 = first unit of its chunk, rows = units the chunk has.
+template <int SWM>
+FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, const u32* qual, const u16* lenp, int chunk0, int rows, int lane,
+                           bool valid, int win, int thr, LaneRead<SWM>& r) {
     const DevParams& p = a.p;
     const int swg = p.sw_g, qwg = p.qw_g;
+    const int g = chunk0 + lane;
     r.rl0 = valid ? (int)lenp[g] : 0;
     r.len = r.rl0;
     r.flags = 0;
-    const u64* srow = (const u64*)(seq + (size_t)g * swg);
-    const u64* qrow = (const u64*)(qual + (size_t)g * qwg);
+    lane_stage_rows(stage, seq + (size_t)chunk0 * swg, rows, swg, lane);
+    {
+        const u64* srow = (const u64*)(stage + lane * swg);
 #pragma unroll
-    for (int w = 0; w < SWM; w += 2) {
-        u64 v = 0;
-        if (valid && w < swg) v = srow[w >> 1];
-        r.s[w] = (u32)v;
-        r.s[w + 1] = (u32)(v >> 32);
-        r.n[w] = r.n[w + 1] = 0;
+        for (int w = 0; w < SWM; w += 2) {
+            u64 v = 0;
+            if (valid && w < swg) v = srow[w >> 1];
+            r.s[w] = (u32)v;
+            r.s[w + 1] = (u32)(v >> 32);
+        }
     }
-    constexpr int QWM = 4 * SWM;   // quality dwords a row of SWM base words can have
-    u32 q[QWM + 2];
+    lane_stage_rows(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
+    const u64* qrow = (const u64*)(stage + lane * qwg);
 #pragma unroll
-    for (int c = 0; c < QWM; c += 2) {
-        u64 v = 0;
-        if (valid && c < qwg) v = qrow[c >> 1];
-        q[c] = (u32)v;
-        q[c + 1] = (u32)(v >> 32);
-    }
-    q[QWM] = q[QWM + 1] = 0;
-    // ---- N mask (rare: only dwords that hold an N pay for it) ----
+    for (int w = 0; w < SWM / 2; w++) r.n[w] = 0;
+    const u32 nthr = (u32)(-thr);
+    const u32 keep_lo = lowmask32(8 * imin(imax(win, 1), 4)), keep_hi = win > 4 ? lowmask32(8 * (win - 4)) : 0u;
+    const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
     u32 anyn = 0;
+    // Eight dwords (one 32-position mask word) at a time from the END of the row: the window predicate of word W looks
+    // two dwords into word W + 1, which the previous step left in nx0 / nx1.
+    u32 nx0 = 0, nx1 = 0;
 #pragma unroll
-    for (int c = 0; c < QWM; c++) {
-        const u32 nb = q[c] & 0x80808080u;
-        if (nb) {
-            const u32 b1 = nb >> 7;   // bits 0, 8, 16, 24
-            const u32 m4 = (b1 | (b1 >> 6) | (b1 >> 12) | (b1 >> 18)) & 0x55u;
-            r.n[c >> 2] |= m4 << (8 * (c & 3));
-            anyn = 1;
+    for (int W = SWM / 2 - 1; W >= 0; W--) {
+        u32 q[10];
+#pragma unroll
+        for (int d = 0; d < 8; d += 2) {
+            const int c = 8 * W + d;
+            u64 v = 0;
+            if (valid && c < qwg) v = qrow[c >> 1];
+            q[d] = (u32)v;
+            q[d + 1] = (u32)(v >> 32);
         }
-    }
-    if (anyn) r.flags |= RS_HAS_N;
-    // ---- Duplicate's hash of the original read ----
-    if (B > 0) {
-        const u32* val4 = lds + ll.val4;
-        u32 acc[(B > 0 ? B : 1) * NPL];
+        q[8] = nx0;
+        q[9] = nx1;
+        nx0 = q[0];
+        nx1 = q[1];
+        u32 mt = 0, mlo = 0, mnb = 0;
 #pragma unroll
-        for (int k = 0; k < B * NPL; k++) acc[k] = 0;
-        const int NQ = a.L.hp_nq;
-        // all lanes of a wavefront almost always share `off` (fixed-length reads): then the planes are scalar loads
-        const int off0 = (int)uniform((u32)off);
-        const bool same = ballot(off != off0) == 0ull;
-        if (same) {
-            const u32* tb = a.lut.dup_planes + (size_t)((off0 & 3) * NQ + (off0 >> 2)) * (B * NPL);
-#pragma unroll
-            for (int c = 0; c < QWM; c++) {
-                if (c >= qwg) break;                       // uniform
-                const u32 byte = (r.s[c >> 2] >> (8 * (c & 3))) & 0xFFu;
-                u32 vals = val4[byte];
-                const u32 mN = ((q[c] >> 7) & 0x01010101u) * 0xFFu;   // N -> 13 (duplicate.cpp:92-109)
-                vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
-                const int rem = r.rl0 - 4 * c;
-                vals = rem >= 4 ? vals : (rem <= 0 ? 0u : (vals & lowmask32(8 * rem)));
-#pragma unroll
-                for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[c * (B * NPL) + k], acc[k]);
+        for (int d = 0; d < 8; d++) {
+            const int c = 8 * W + d;
+            // ---- N mask (rare: only dwords that hold an N pay for it) ----
+            const u32 nb = q[d] & 0x80808080u;
+            if (nb) {
+                const u32 b1 = nb >> 7;   // bits 0, 8, 16, 24
+                const u32 m4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+                r.n[c >> 3] |= m4 << (4 * (c & 7));
+                anyn = 1;
+                mnb += (u32)popc32(nb);
             }
-        } else {
-            const u32* tb = a.lut.dup_planes + (size_t)((off & 3) * NQ + (off >> 2)) * (B * NPL);
-#pragma unroll
-            for (int c = 0; c < QWM; c++) {
-                if (c >= qwg) break;
-                const u32 byte = (r.s[c >> 2] >> (8 * (c & 3))) & 0xFFu;
-                u32 vals = val4[byte];
-                const u32 mN = ((q[c] >> 7) & 0x01010101u) * 0xFFu;
-                vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
-                const int rem = r.rl0 - 4 * c;
-                vals = rem >= 4 ? vals : (rem <= 0 ? 0u : (vals & lowmask32(8 * rem)));
-#pragma unroll
-                for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[c * (B * NPL) + k], acc[k]);
-            }
+            // ---- countQualityMetrics partial sums (simd.cpp:54-119); a word the final window cuts is redone exactly ----
+            const u32 q7 = q[d] & 0x7F7F7F7Fu;
+            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;   // bit 7 of a byte: qual >= threshold
+            mt = sum_bytes(q7, mt);
+            mlo += (u32)popc32(ge ^ 0x80808080u);
         }
-#pragma unroll
-        for (int i = 0; i < B; i++) {
-            u64 v = (u64)acc[i * NPL] + ((u64)acc[i * NPL + 1] << 8) + ((u64)acc[i * NPL + 2] << 16);
-            if (NPL > 3) v += (u64)acc[i * NPL + 3] << 24;
-            h[i] = v;
-        }
-    }
-    // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
-#pragma unroll
-    for (int W = 0; W < SWM / 2; W++) r.bad[W] = 0;
-    if (win > 0) {
-        const u32 nthr = (u32)(-thr);
-        const u32 keep_lo = lowmask32(8 * imin(win, 4)), keep_hi = win > 4 ? lowmask32(8 * (win - 4)) : 0u;
-#pragma unroll
-        for (int W = 0; W < SWM / 2; W++) {
-            u32 m = 0;
+        r.met[W] = mt | (mlo << 16) | (mnb << 24);
+        // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
+        u32 m = 0;
+        if (win > 0) {   // uniform
 #pragma unroll
             for (int d = 7; d >= 0; d--) {
-                const int c = 8 * W + d;
-                const u32 q0 = q[c] & 0x7F7F7F7Fu, q1 = q[c + 1] & 0x7F7F7F7Fu, q2 = q[c + 2] & 0x7F7F7F7Fu;
+                const u32 q0 = q[d] & 0x7F7F7F7Fu, q1 = q[d + 1] & 0x7F7F7F7Fu, q2 = q[d + 2 < 10 ? d + 2 : 9] & 0x7F7F7F7Fu;
 #pragma unroll
                 for (int k = 3; k >= 0; k--) {
                     const u32 x = k ? alignbit(q1, q0, 8 * k) : q0;
@@ -222,9 +276,10 @@ FQ_DEV void lane_load_read(const KernelArgs& a, const u32* lds, const LaneLds& l
                     m = alignbit(m, sdiff, 31);   // m = m << 1 | (sum < thr)
                 }
             }
-            r.bad[W] = m;
         }
+        r.bad[W] = m;
     }
+    if (anyn) r.flags |= RS_HAS_N;
 }
 
 // quality character (7 bits) / N flag of base j of a row in global memory (indexed walks that end after a few bases)
@@ -296,20 +351,21 @@ FQ_DEV void lane_scan(const u32 (&X)[SWM], u32 y0, int nvalid, u32 premask, u32 
 #pragma unroll
     for (int b = 0; b < SWM; b++) {
         const int o0 = 16 * b;
-        if (ballot(nvalid > o0) == 0ull) break;   // uniform: no lane has offsets this far out
-        const u32 w0 = X[b], w1 = b + 1 < SWM ? X[b + 1] : 0u;
-        u32 cand = 0;
+        if (ballot(nvalid > o0) != 0ull) {   // uniform: some lane has offsets this far out
+            const u32 w0 = X[b], w1 = b + 1 < SWM ? X[b + 1] : 0u;
+            u32 cand = 0;
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const u32 x = t ? alignbit(w1, w0, 2 * t) : w0;
-            const u32 d = x ^ y0;
-            const u32 sd = (u32)popc32((d | (d >> 1)) & premask) + nlim;   // negative <=> count <= lmax
-            cand = alignbit(cand, sd, 31);
+            for (int t = 0; t < 16; t++) {
+                const u32 x = t ? alignbit(w1, w0, 2 * t) : w0;
+                const u32 d = x ^ y0;
+                const u32 sd = (u32)popc32((d | (d >> 1)) & premask) + nlim;   // negative <=> count <= lmax
+                cand = alignbit(cand, sd, 31);
+            }
+            cand &= 0xFFFFu;
+            const int left = nvalid - o0;
+            if (left < 16) cand = left <= 0 ? 0u : (cand & ~lowmask32(16 - left));
+            cm[b >> 1] |= cand << (16 * (b & 1));
         }
-        cand &= 0xFFFFu;
-        const int left = nvalid - o0;
-        if (left < 16) cand = left <= 0 ? 0u : (cand & ~lowmask32(16 - left));
-        cm[b >> 1] |= cand << (16 * (b & 1));
     }
 }
 // smallest candidate offset left in cm (removed from it), or -1
@@ -333,22 +389,29 @@ FQ_DEV int lane_next_candidate(u32 (&cm)[SWM / 2]) {
 }
 // acceptNoGapOverlap (:34-44) of X shifted by o against Y; -1 or the reported difference count
 template <int SWM>
-FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM], const u32 (&Y)[SWM], const u32 (&YN)[SWM], bool hasN, int o, int lenX,
-                       int lenY, const u16* lut) {
+FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM / 2], const u32 (&Y)[SWM], const u32 (&YN)[SWM / 2], bool hasN, int o,
+                       int lenX, int lenY, const u16* lut) {
     const int ol = imin(lenX - o, lenY);
     const int limit = (int)lut[ol];
     const int pre = imin(ol, 50);   // complete_compare_require (:28)
-    u32 xs[SWM], xn[SWM];
+    u32 xs[SWM];
 #pragma unroll
-    for (int w = 0; w < SWM; w++) { xs[w] = X[w]; xn[w] = XN[w]; }
+    for (int w = 0; w < SWM; w++) xs[w] = X[w];
     base_shift_down<SWM>(xs, (u32)o);
-    if (hasN) base_shift_down<SWM>(xn, (u32)o);
+    u32 dn[SWM / 2];   // positions where exactly one side is N
+    if (hasN) {
+#pragma unroll
+        for (int w = 0; w < SWM / 2; w++) dn[w] = XN[w];
+        bit_shift_down<SWM / 2>(dn, (u32)o);
+#pragma unroll
+        for (int w = 0; w < SWM / 2; w++) dn[w] ^= YN[w];
+    }
     int cnt_pre = 0, cnt_full = 0;
 #pragma unroll
     for (int w = 0; w < SWM; w++) {
         const int t = 16 * w;
         u32 dd = fold_diff(xs[w] ^ Y[w]);
-        if (hasN) dd |= xn[w] ^ YN[w];
+        if (hasN) dd |= nmask_word<SWM / 2>(dn, w);
         const int rem = ol - t, remp = pre - t;
         cnt_full += popc32(rem >= 16 ? dd : (rem <= 0 ? 0u : (dd & lowmask32(2 * rem))));
         cnt_pre += popc32(remp >= 16 ? dd : (remp <= 0 ? 0u : (dd & lowmask32(2 * remp))));
@@ -358,26 +421,35 @@ FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM], const u32 (&Y)
 }
 
 // ---------------------------------------------------------------------------
-// fastp_simd::countQualityMetrics (simd.cpp:54-119) of [0, len): total (qual - 33), bases below the qualified quality, N
+// fastp_simd::countQualityMetrics (simd.cpp:54-119) of [0, len): total (qual - 33), bases below the qualified quality, N.
+// Whole 32-base words come from the partial sums of the load sweep; the word the window ends in is read again (one
+// batch of four 8-byte loads) and counted under a mask.
 // ---------------------------------------------------------------------------
 template <int SWM>
-FQ_DEV void lane_metrics(const KernelArgs& a, const u32* qual, int g, bool valid, int len, int& tot, int& low, int& nb) {
+FQ_DEV void lane_metrics(const KernelArgs& a, const LaneRead<SWM>& r, const u32* qual, int g, bool valid, int len, int& tot, int& low, int& nb) {
     const int qwg = a.p.qw_g;
-    const u64* qrow = (const u64*)(qual + (size_t)g * qwg);
-    const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
+    const int Wb = len >> 5, rem = len & 31;   // words [0, Wb) whole, `rem` bases of word Wb
     u32 t = 0, lo = 0, n = 0;
 #pragma unroll
-    for (int c = 0; c < 4 * SWM; c += 2) {
-        if (c >= qwg) break;                                     // uniform
-        if (ballot(valid && 4 * c < len) == 0ull) break;         // uniform: nobody's window reaches this far
-        const u64 v = (valid && 4 * c < len) ? qrow[c >> 1] : 0ull;
+    for (int W = 0; W < SWM / 2; W++) {
+        const u32 m = W < Wb ? r.met[W] : 0u;
+        t += m & 0xFFFFu;
+        lo += (m >> 16) & 0xFFu;
+        n += m >> 24;
+    }
+    if (ballot(valid && rem != 0) != 0ull) {   // uniform
+        const u64* qrow = (const u64*)(qual + (size_t)g * qwg) + 4 * Wb;
+        const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
+        u64 v[4];
 #pragma unroll
-        for (int hlf = 0; hlf < 2; hlf++) {
-            const u32 qd = hlf ? (u32)(v >> 32) : (u32)v;
-            const int rem = len - 4 * (c + hlf);
-            const u32 M = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : lowmask32(8 * rem));
+        for (int i = 0; i < 4; i++) v[i] = (valid && rem > 8 * i && 8 * Wb + 2 * i < qwg) ? qrow[i] : 0ull;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const u32 qd = (d & 1) ? (u32)(v[d >> 1] >> 32) : (u32)v[d >> 1];
+            const int left = rem - 4 * d;
+            const u32 M = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : lowmask32(8 * left));
             const u32 q7 = qd & 0x7F7F7F7Fu & M;
-            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;   // bit 7 of a byte: qual >= threshold
+            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;
             t = sum_bytes(q7, t);
             lo += (u32)popc32(~ge & 0x80808080u & M);
             n += (u32)popc32(qd & 0x80808080u & M);
@@ -425,24 +497,35 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 for (int k = 0; k < 4; k++) v |= ((0x1F4ADE07u >> (((i >> (2 * k)) & 3) * 8)) & 0xFFu) << (8 * k);
                 lds[ll.val4 + i] = v;
             }
+        if (B > 0)
+            for (int i = tid; i < ll.n_planes; i += nt) lds[ll.planes + i] = a.lut.dup_planes[i];
         block_sync();
     }
     u32* misc = lds + ll.misc;
     const u16* lut_ov = (const u16*)(lds + ll.lut_ov);
     const u16* lut_lowq = (const u16*)(lds + ll.lut_lowq);
     const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
-    const int win = p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0);
+    const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
+    const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
     const int chunks = (a.n + 63) >> 6;
     const int wpb = nt >> 6;
     for (int chunk = block_id() * wpb + (tid >> 6); chunk < chunks; chunk += grid_blocks() * wpb) {   // wave-uniform
         const int gp = chunk * 64 + lane;
         const bool valid = gp < a.n;
+        const int rows = imin(64, a.n - chunk * 64);
+        u32* stage = lds + ll.stage + (tid >> 6) * ll.stage_dwords;
         const int g = valid ? gp : 0;
         LaneRead<SWM> r1, r2;
-        u64 h1[B > 0 ? B : 1], h2[B > 0 ? B : 1];
-        lane_load_read<SWM, B, NPL>(a, lds, ll, a.seq[0], a.qual[0], a.len[0], g, valid, 0, win, thr, r1, h1);
-        if (PAIRED) lane_load_read<SWM, B, NPL>(a, lds, ll, a.seq[1], a.qual[1], a.len[1], g, valid, r1.rl0, win, thr, r2, h2);
+        // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
+        lane_load_read<SWM>(a, stage, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, r1);
+        if (valid && !lane_trim_and_cut<SWM>(a, r1, a.qual[0], g, p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
+        sched_fence();
+        if (PAIRED) {
+            lane_load_read<SWM>(a, stage, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, r2);
+            if (valid && !lane_trim_and_cut<SWM>(a, r2, a.qual[1], g, p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
+            sched_fence();
+        }
         if (a.dupflag && valid && a.dupflag[g]) {   // --dedup: Duplicate::checkPair/checkRead already ran for this batch
             r1.flags |= RS_DUP;
             if (PAIRED) r2.flags |= RS_DUP;
@@ -450,19 +533,21 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         // Duplicate's claim: fired now, looked at when the record is written
         u32 won = 0;
         const bool claim = B > 0 && a.claim_won != nullptr;
-        if (B > 0 && valid) {
-            u64 hs[B > 0 ? B : 1];
+        if constexpr (B > 0) {
+            u64 hs[B], h2[B];
+            lane_hash<SWM, B, NPL>(a, lds, ll, r1, 0, hs);
+            if (PAIRED) {
+                lane_hash<SWM, B, NPL>(a, lds, ll, r2, r1.rl0, h2);
 #pragma unroll
-            for (int i = 0; i < B; i++) hs[i] = h1[i] + (PAIRED ? h2[i] : 0ull);
-            if (a.dup_pos)
-                for (int i = 0; i < B; i++) a.dup_pos[(size_t)g * B + i] = hs[i];
-            if (claim) lane_claim(a, g, r1.rl0 + (PAIRED ? r2.rl0 : 0), hs, B, won);
+                for (int i = 0; i < B; i++) hs[i] += h2[i];
+            }
+            if (valid) {
+                if (a.dup_pos)
+                    for (int i = 0; i < B; i++) a.dup_pos[(size_t)g * B + i] = hs[i];
+                if (claim) lane_claim(a, g, r1.rl0 + (PAIRED ? r2.rl0 : 0), hs, B, won);
+            }
         }
-        // ---- Filter::trimAndCut, PolyX::trimPolyG ----
-        if (valid) {
-            if (!lane_trim_and_cut<SWM>(a, r1, a.qual[0], g, p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
-            if (PAIRED && !lane_trim_and_cut<SWM>(a, r2, a.qual[1], g, p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
-        }
+        // ---- PolyX::trimPolyG ----
         const bool a1 = valid && !(r1.flags & RS_NULL), a2 = PAIRED ? (valid && !(r2.flags & RS_NULL)) : a1;
         const bool both = a1 && a2;
         if (p.poly_g && both) {   // both mates survived trimAndCut (peprocessor.cpp:428-431)
@@ -474,26 +559,27 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         if (PAIRED) {
             // ---- OverlapAnalysis::analyze ----
             u32 key = OV_KEY_NONE;
-            const bool want_ov = p.need_overlap || thread0;   // peprocessor.cpp:438
+            const bool want_ov = (p.need_overlap || thread0) && !(skip & 4u);   // peprocessor.cpp:438
             if (want_ov && ballot(both) != 0ull) {
                 const int l1 = r1.len, l2 = r2.len;
                 const bool hasN = ((r1.flags | r2.flags) & RS_HAS_N) != 0;
                 // rc(r2') in registers: reverse the word order and the groups, complement, move the frame's unused head out
-                u32 rc[SWM], rcn[SWM];
+                u32 rc[SWM], rcn[SWM / 2];
 #pragma unroll
-                for (int w = 0; w < SWM; w++) {
-                    rc[w] = reverse_groups(r2.s[SWM - 1 - w]) ^ 0x55555555u;
-                    rcn[w] = reverse_groups(r2.n[SWM - 1 - w]);
-                }
+                for (int w = 0; w < SWM; w++) rc[w] = reverse_groups(r2.s[SWM - 1 - w]) ^ 0x55555555u;
+#pragma unroll
+                for (int w = 0; w < SWM / 2; w++) rcn[w] = 0;
                 const u32 D = (u32)(16 * SWM - l2);
                 base_shift_down<SWM>(rc, D);
                 if (hasN) {
-                    base_shift_down<SWM>(rcn, D);
 #pragma unroll
-                    for (int w = 0; w < SWM; w++) rc[w] &= ~(rcn[w] | (rcn[w] << 1));   // N stays code 0 on both strands
-                } else {
+                    for (int w = 0; w < SWM / 2; w++) rcn[w] = brev32(r2.n[SWM / 2 - 1 - w]);
+                    bit_shift_down<SWM / 2>(rcn, D);
 #pragma unroll
-                    for (int w = 0; w < SWM; w++) rcn[w] = 0;
+                    for (int w = 0; w < SWM; w++) {   // N stays code 0 on both strands
+                        const u32 sp = nmask_word<SWM / 2>(rcn, w);
+                        rc[w] &= ~(sp | (sp << 1));
+                    }
                 }
                 // bases past l2 of rc are zeros by construction; bases of r1 past l1 are masked by every consumer
                 const u32 nlim = (u32)(-(p.ov_limit_max + 1));
@@ -568,9 +654,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             if (a1 && p.max_len1 > 0 && p.max_len1 < r1.len) r1.len = p.max_len1;   // seprocessor.cpp:268-271
         }
         // ---- Filter::passFilter (filter.cpp:15-57), routing, records ----
-        int tot1, low1, nb1, tot2 = 0, low2 = 0, nb2 = 0;
-        lane_metrics<SWM>(a, a.qual[0], g, a1, r1.len, tot1, low1, nb1);
-        if (PAIRED) lane_metrics<SWM>(a, a.qual[1], g, a2, r2.len, tot2, low2, nb2);
+        int tot1 = 0, low1 = 0, nb1 = 0, tot2 = 0, low2 = 0, nb2 = 0;
+        if (!(skip & 8u)) {
+            lane_metrics<SWM>(a, r1, a.qual[0], g, a1, r1.len, tot1, low1, nb1);
+            if (PAIRED) lane_metrics<SWM>(a, r2, a.qual[1], g, a2, r2.len, tot2, low2, nb2);
+        }
         if (valid) {
             int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, 0, (int)lut_lowq[r1.len], 0) : 16;
             int code2 = 0;
