@@ -42,8 +42,11 @@ extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a)
 }
 // the per-read path with one lane per pair, reads in registers (fq_lane.h): SWM base words per read (10: up to 160
 // bases, 16: up to 256), B bloom buffers hashed (0: no hashing in this launch), byte planes per prime, paired / single
+#ifndef FQ_LANE_WAVES
+#define FQ_LANE_WAVES 3   // wavefronts per SIMD the lane kernel is compiled for (168 VGPRs: no spills; 4 = 128 VGPRs spills ~26 dwords)
+#endif
 template <int SWM, int B, int NPL, bool PAIRED>
-__global__ void __launch_bounds__(256, 3) fq_lane_kernel(LaneArgs a) {
+__global__ void __launch_bounds__(256, FQ_LANE_WAVES) fq_lane_kernel(LaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     lane_body<SWM, B, NPL, PAIRED>(*kernel_args(&a), fq_lds);
 }
@@ -455,7 +458,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             o += l.n_planes;
             o = (o + 3) & ~3;
             l.stage = o;
-            l.stage_dwords = (64 * std::max(ctx->dp.qw_g, ctx->dp.sw_g) + 3) & ~3;
+            l.stage_dwords = (64 * std::max(ctx->dp.qw_g, ctx->dp.sw_g) + 4 * ctx->ln_swm + 3) & ~3;   // + the over-read of the last row
             o += 4 * l.stage_dwords;   // 256-lane workgroups: four wavefronts
             l.total = o;
             int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);

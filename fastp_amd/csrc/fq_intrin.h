@@ -133,6 +133,12 @@ FQ_DEV void sched_fence() {
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// no load or store moves across this point (compiler only): bounds how many table reads an unrolled loop keeps in flight
+FQ_DEV void memory_fence_compiler() {
+#ifndef FQ_HOSTSIM
+    asm volatile("" ::: "memory");
+#endif
+}
 
 FQ_DEV u64 ballot(bool pred) { return __ballot(pred); }
 FQ_DEV u32 shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }

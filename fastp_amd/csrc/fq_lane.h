@@ -127,7 +127,6 @@ struct LaneRead {
     u32 s[SWM];         // packed bases (N = code 0); bits past the read's end are whatever the row held
     u32 n[SWM / 2];     // N mask, bit j = base j is N (zero unless hasN)
     u32 bad[SWM / 2];   // Filter::trimAndCut: bit j = the window [j, j + w) has total quality < threshold
-    u32 met[SWM / 2];   // countQualityMetrics of bases 32 W .. 32 W + 31: sum of the characters | below-threshold << 16 | N << 24
     int rl0, len;       // original length, length after the steps so far
     u32 flags;          // RS_*
 };
@@ -143,26 +142,41 @@ struct LaneRead {
 template <int SWM, int B, int NPL>
 FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, const LaneRead<SWM>& r, int off, u64 (&h)[B]) {
     const u32* val4 = lds + ll.val4;
-    const int qwg = a.p.qw_g;
     u32 acc[B * NPL];
 #pragma unroll
     for (int k = 0; k < B * NPL; k++) acc[k] = 0;
     const u32* tb = lds + ll.planes + ((off & 3) * a.L.hp_nq + (off >> 2)) * (B * NPL);
+    // A ROLLED loop over the read's 32-base groups (8 packed bytes, 48 table words each): fully unrolled, the
+    // compiler issued all 240 table reads of a read before the first dot product and the kernel needed 256 VGPRs.
+    // The base words rotate through sw[0..1] and the N words through nw[0] so that every register index stays static.
+    u32 sw[SWM], nw[SWM / 2];
 #pragma unroll
-    for (int c = 0; c < 4 * SWM; c++) {
-        if (c < qwg) {   // uniform
-            const u32 byte = (r.s[c >> 2] >> (8 * (c & 3))) & 0xFFu;
+    for (int w = 0; w < SWM; w++) sw[w] = r.s[w];
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) nw[w] = r.n[w];
+    int rem = r.rl0;
+#pragma unroll 1
+    for (int grp = 0; grp < SWM / 2; grp++) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const u32 byte = (sw[d >> 2] >> (8 * (d & 3))) & 0xFFu;
             u32 vals = val4[byte];
-            const u32 nb = (r.n[c >> 3] >> (4 * (c & 7))) & 0xFu;
-            if (nb) {
+            const u32 nb = (nw[0] >> (4 * d)) & 0xFu;
+            if (nb) {   // N -> 13
                 const u32 mN = ((nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21)) * 0xFFu;
                 vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
             }
-            const int rem = r.rl0 - 4 * c;
-            vals = rem >= 4 ? vals : (rem <= 0 ? 0u : (vals & lowmask32(8 * rem)));
+            const int left = rem - 4 * d;
+            vals = left >= 4 ? vals : (left <= 0 ? 0u : (vals & lowmask32(8 * left)));   // bases past the read's end add nothing
 #pragma unroll
-            for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[c * (B * NPL) + k], acc[k]);
+            for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[d * (B * NPL) + k], acc[k]);
         }
+        tb += 8 * (B * NPL);
+        rem -= 32;
+#pragma unroll
+        for (int w = 0; w + 2 < SWM; w++) sw[w] = sw[w + 2];
+#pragma unroll
+        for (int w = 0; w + 1 < SWM / 2; w++) nw[w] = nw[w + 1];
     }
 #pragma unroll
     for (int i = 0; i < B; i++) {
@@ -172,8 +186,6 @@ FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, co
     }
 }
 
-// Load read `g` of one mate: bases, N mask, and in ONE sweep over the quality row the window predicate of cut_right /
-// cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.
 // 64 consecutive rows of `stride` dwords (the wavefront's chunk of one mate) HBM -> this wavefront's LDS buffer with
 // coalesced 16-byte loads.  A lane reading its own 152-byte row straight from HBM touches a fresh 128-byte line per
 // 8-byte load: the rows of 12 resident wavefronts do not fit the 32 KB L1, so nearly every load refetched its line
@@ -207,19 +219,16 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
         const u64* srow = (const u64*)(stage + lane * swg);
 #pragma unroll
         for (int w = 0; w < SWM; w += 2) {
-            u64 v = 0;
-            if (valid && w < swg) v = srow[w >> 1];
+            // (a word past the row's stride holds the next row's bases: every consumer masks by the read's length)
+            const u64 v = srow[w >> 1];
             r.s[w] = (u32)v;
             r.s[w + 1] = (u32)(v >> 32);
         }
     }
     lane_stage_rows(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
     const u64* qrow = (const u64*)(stage + lane * qwg);
-#pragma unroll
-    for (int w = 0; w < SWM / 2; w++) r.n[w] = 0;
     const u32 nthr = (u32)(-thr);
     const u32 keep_lo = lowmask32(8 * imin(imax(win, 1), 4)), keep_hi = win > 4 ? lowmask32(8 * (win - 4)) : 0u;
-    const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
     u32 anyn = 0;
     // Eight dwords (one 32-position mask word) at a time from the END of the row: the window predicate of word W looks
     // two dwords into word W + 1, which the previous step left in nx0 / nx1.
@@ -230,8 +239,7 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
 #pragma unroll
         for (int d = 0; d < 8; d += 2) {
             const int c = 8 * W + d;
-            u64 v = 0;
-            if (valid && c < qwg) v = qrow[c >> 1];
+            const u64 v = qrow[c >> 1];
             q[d] = (u32)v;
             q[d + 1] = (u32)(v >> 32);
         }
@@ -239,26 +247,16 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
         q[9] = nx1;
         nx0 = q[0];
         nx1 = q[1];
-        u32 mt = 0, mlo = 0, mnb = 0;
+        // ---- N mask of the word's 32 bases (bit 7 of the quality bytes), branch-free ----
+        u32 nw = 0;
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const int c = 8 * W + d;
-            // ---- N mask (rare: only dwords that hold an N pay for it) ----
-            const u32 nb = q[d] & 0x80808080u;
-            if (nb) {
-                const u32 b1 = nb >> 7;   // bits 0, 8, 16, 24
-                const u32 m4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-                r.n[c >> 3] |= m4 << (4 * (c & 7));
-                anyn = 1;
-                mnb += (u32)popc32(nb);
-            }
-            // ---- countQualityMetrics partial sums (simd.cpp:54-119); a word the final window cuts is redone exactly ----
-            const u32 q7 = q[d] & 0x7F7F7F7Fu;
-            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;   // bit 7 of a byte: qual >= threshold
-            mt = sum_bytes(q7, mt);
-            mlo += (u32)popc32(ge ^ 0x80808080u);
+        for (int d = 7; d >= 0; d--) {
+            const u32 b1 = (q[d] >> 7) & 0x01010101u;   // bits 0, 8, 16, 24
+            const u32 m4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
+            nw = (nw << 4) | m4;
         }
-        r.met[W] = mt | (mlo << 16) | (mnb << 24);
+        r.n[W] = nw;
+        anyn |= nw;
         // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
         u32 m = 0;
         if (win > 0) {   // uniform
@@ -278,6 +276,7 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
             }
         }
         r.bad[W] = m;
+        sched_fence();   // one mask word at a time: the scheduler would otherwise keep every word's dwords in flight
     }
     if (anyn) r.flags |= RS_HAS_N;
 }
@@ -366,6 +365,7 @@ FQ_DEV void lane_scan(const u32 (&X)[SWM], u32 y0, int nvalid, u32 premask, u32 
             if (left < 16) cand = left <= 0 ? 0u : (cand & ~lowmask32(16 - left));
             cm[b >> 1] |= cand << (16 * (b & 1));
         }
+        sched_fence();
     }
 }
 // smallest candidate offset left in cm (removed from it), or -1
@@ -422,37 +422,32 @@ FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM / 2], const u32 
 
 // ---------------------------------------------------------------------------
 // fastp_simd::countQualityMetrics (simd.cpp:54-119) of [0, len): total (qual - 33), bases below the qualified quality, N.
-// Whole 32-base words come from the partial sums of the load sweep; the word the window ends in is read again (one
-// batch of four 8-byte loads) and counted under a mask.
+// The mate's quality rows are staged once more (the final window is only known now; the copy is coalesced and the
+// rows come from L2) and each lane sums its own row under the window's mask.
 // ---------------------------------------------------------------------------
 template <int SWM>
-FQ_DEV void lane_metrics(const KernelArgs& a, const LaneRead<SWM>& r, const u32* qual, int g, bool valid, int len, int& tot, int& low, int& nb) {
+FQ_DEV void lane_metrics(const KernelArgs& a, u32* stage, const u32* qual, int chunk0, int rows, int lane, bool valid, int len, int& tot,
+                         int& low, int& nb) {
     const int qwg = a.p.qw_g;
-    const int Wb = len >> 5, rem = len & 31;   // words [0, Wb) whole, `rem` bases of word Wb
+    lane_stage_rows(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
+    const u64* qrow = (const u64*)(stage + lane * qwg);
+    const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
     u32 t = 0, lo = 0, n = 0;
 #pragma unroll
-    for (int W = 0; W < SWM / 2; W++) {
-        const u32 m = W < Wb ? r.met[W] : 0u;
-        t += m & 0xFFFFu;
-        lo += (m >> 16) & 0xFFu;
-        n += m >> 24;
-    }
-    if (ballot(valid && rem != 0) != 0ull) {   // uniform
-        const u64* qrow = (const u64*)(qual + (size_t)g * qwg) + 4 * Wb;
-        const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
-        u64 v[4];
+    for (int c = 0; c < 4 * SWM; c += 2) {
+        {
+            const u64 v = qrow[c >> 1];   // dwords past the window (or the row) count nothing: M below
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = (valid && rem > 8 * i && 8 * Wb + 2 * i < qwg) ? qrow[i] : 0ull;
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const u32 qd = (d & 1) ? (u32)(v[d >> 1] >> 32) : (u32)v[d >> 1];
-            const int left = rem - 4 * d;
-            const u32 M = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : lowmask32(8 * left));
-            const u32 q7 = qd & 0x7F7F7F7Fu & M;
-            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;
-            t = sum_bytes(q7, t);
-            lo += (u32)popc32(~ge & 0x80808080u & M);
-            n += (u32)popc32(qd & 0x80808080u & M);
+            for (int hlf = 0; hlf < 2; hlf++) {
+                const u32 qd = hlf ? (u32)(v >> 32) : (u32)v;
+                const int rem = len - 4 * (c + hlf);
+                const u32 M = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : lowmask32(8 * rem));
+                const u32 q7 = qd & 0x7F7F7F7Fu & M;
+                const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;   // bit 7 of a byte: qual >= threshold
+                t = sum_bytes(q7, t);
+                lo += (u32)popc32(~ge & 0x80808080u & M);
+                n += (u32)popc32(qd & 0x80808080u & M);
+            }
         }
     }
     tot = (int)t - 33 * len;
@@ -656,8 +651,8 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         // ---- Filter::passFilter (filter.cpp:15-57), routing, records ----
         int tot1 = 0, low1 = 0, nb1 = 0, tot2 = 0, low2 = 0, nb2 = 0;
         if (!(skip & 8u)) {
-            lane_metrics<SWM>(a, r1, a.qual[0], g, a1, r1.len, tot1, low1, nb1);
-            if (PAIRED) lane_metrics<SWM>(a, r2, a.qual[1], g, a2, r2.len, tot2, low2, nb2);
+            lane_metrics<SWM>(a, stage, a.qual[0], chunk * 64, rows, lane, a1, r1.len, tot1, low1, nb1);
+            if (PAIRED) lane_metrics<SWM>(a, stage, a.qual[1], chunk * 64, rows, lane, a2, r2.len, tot2, low2, nb2);
         }
         if (valid) {
             int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, 0, (int)lut_lowq[r1.len], 0) : 16;

@@ -42,3 +42,9 @@ for P in "$P1" "$P2" "$P3"; do
 done
 for K in "void fq_lane" fq_stats; do echo "== SQ counters, $K (one launch of 4194304 pairs)" >> $OUT; python tools/pmc_parse.py $TAG "$K" >> $OUT; done
 cat $OUT
+# variant: the lane kernel compiled for 4 wavefronts per SIMD (128 VGPRs)
+if [ -f fastp_amd/libfastp_gpu_w4.so ]; then
+  run() { NAME=$1; shift; env "$@" timeout 300 python bench.py --steps 32 --warmup 8 --batches 8 --no-cpu > gpurun_out/ab_${TAG}_$NAME.log 2>&1; tail -1 gpurun_out/ab_${TAG}_$NAME.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$NAME', j['value'], 'Mreads/s kernels', r['kernel_avg_ms'], 'ms per', r['pairs_per_launch'])" | tee -a $OUT; }
+  run w4_default FASTP_GPU_LIB=$PWD/fastp_amd/libfastp_gpu_w4.so
+  run w4_nostats FASTP_GPU_LIB=$PWD/fastp_amd/libfastp_gpu_w4.so FASTP_GPU_DEBUG_SKIP=16
+fi
