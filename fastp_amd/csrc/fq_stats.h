@@ -52,57 +52,56 @@ FQ_DEV u64 stats_inc_of(u32 q) {   // stats.cpp:209-222: q30 ('?') counts into Q
     return 1ull | ((u64)(q >= 53u) << CYC_Q20_SHIFT) | ((u64)(q >= 63u) << CYC_Q30_SHIFT) | ((u64)(q - 33u) << CYC_QSUM_SHIFT);
 }
 
-// what a lane needs of item `it` of the workgroup's unit range
+// what a lane needs of item `it` (of one mate) of the workgroup's unit range
 struct StatsItem {
-    int m, h, rl0, lk;
+    int h, rl0, lk;
     u32 q0, q1, qp, codes, prev8;
     bool act;
 };
-FQ_DEV void stats_fetch(const StatsArgs& a, int u0, int per_mate, int it, bool tv, StatsItem& s) {
-    const int H = a.H;
-    s.m = (tv && it >= per_mate) ? 1 : 0;
-    const int r = tv ? it - s.m * per_mate : 0;
-    const int ur = (int)fastdiv((u32)r, a.magic_H);
-    s.h = r - ur * H;
-    const int g = u0 + ur;
-    const u32* qrow = (s.m ? a.qual[1] : a.qual[0]) + (size_t)g * a.qw_g;
-    const u8* srow = (const u8*)((s.m ? a.seq[1] : a.seq[0]) + (size_t)g * a.sw_g);
-    const u32 sw = tv ? (s.m ? a.swin[1] : a.swin[0])[g] : 0u;
+// qual / seq / swin: the mate's arrays at the workgroup's first unit.  A row has H 8-byte quality items, so item `it`
+// of the range is simply the it-th 8-byte word behind `qual`.
+FQ_DEV void stats_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, int it, bool tv, StatsItem& s) {
+    const u32 ur = fastdiv((u32)(tv ? it : 0), a.magic_H);
+    s.h = (tv ? it : 0) - (int)ur * a.H;
+    const u32 sw = tv ? swin[ur] : 0u;
     s.rl0 = (int)(sw & 0xFFFFu);
     s.lk = (int)(sw >> 16);
     s.act = tv && 8 * s.h < s.rl0;
     s.q0 = s.q1 = s.qp = s.codes = s.prev8 = 0;
     if (s.act) {   // the item's 8 quality bytes and 8 bases, the 4 of each before them
-        const u64 qq = *(const u64*)(qrow + 2 * s.h);
+        const u64 qq = ((const u64*)qual)[(u32)it];
         s.q0 = (u32)qq;
         s.q1 = (u32)(qq >> 32);
-        s.codes = (u32)*(const u16*)(srow + 2 * s.h);
+        const u32 sb = ur * (u32)(a.sw_g * 4) + 2u * (u32)s.h;   // byte of the row's packed bases
+        s.codes = (u32)*(const u16*)((const u8*)seq + sb);
         if (s.h > 0) {
-            s.qp = qrow[2 * s.h - 1];
-            s.prev8 = (u32)srow[2 * s.h - 1];
+            s.qp = qual[2u * (u32)it - 1u];
+            s.prev8 = (u32)((const u8*)seq)[sb - 1u];
         }
     }
 }
 
 // an item with an N among its 8 bases or the 4 before: base by base (dense pass over the work list)
-FQ_DEV void stats_item_general(const StatsArgs& a, u32* lds, const StatsItem& s, int lane) {
+FQ_DEV void stats_item_general(const StatsArgs* ap, u32* lds, int m, int h, int rl0, int lk, u32 q0, u32 q1, u32 qp, u32 codes, u32 prev8,
+                               int lane) {
+    const StatsArgs& a = *ap;
     u64* cyc = (u64*)(lds + a.l_cyc);
-    const u32 nb0 = (s.q0 >> 7) & 0x01010101u, nb1 = (s.q1 >> 7) & 0x01010101u, nbp = (s.qp >> 7) & 0x01010101u;
+    const u32 nb0 = (q0 >> 7) & 0x01010101u, nb1 = (q1 >> 7) & 0x01010101u, nbp = (qp >> 7) & 0x01010101u;
     // bit i = base j0 - 4 + i is N (before the read start: "invalid" as in the reference, which needs 5 bases)
     u32 n12 = ((nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu) | (((nb0 | (nb0 >> 7) | (nb0 >> 14) | (nb0 >> 21)) & 0xFu) << 4) |
               (((nb1 | (nb1 >> 7) | (nb1 >> 14) | (nb1 >> 21)) & 0xFu) << 8);
-    if (s.h == 0) n12 |= 0xFu;
-    const u32 c24 = s.prev8 | (s.codes << 8);
-    const int j0 = 8 * s.h;
+    if (h == 0) n12 |= 0xFu;
+    const u32 c24 = prev8 | (codes << 8);
+    const int j0 = 8 * h;
     u32* qh = lds + a.l_qh + (lane & (ST_QH_COPIES - 1));
     for (int k = 0; k < 8; k++) {
         const int j = j0 + k;
-        if (j >= s.rl0) break;
-        const u32 q = ((k < 4 ? s.q0 : s.q1) >> (8 * (k & 3))) & 0x7Fu;
+        if (j >= rl0) break;
+        const u32 q = ((k < 4 ? q0 : q1) >> (8 * (k & 3))) & 0x7Fu;
         const bool isn = ((n12 >> (4 + k)) & 1u) != 0;
-        const int cls = isn ? (int)CLS_N : (int)((s.codes >> (2 * k)) & 3u);
-        const int slot = 2 * s.m + (j < s.lk ? 1 : 0);
-        lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + cls) * a.H + s.h], stats_inc_of(q));
+        const int cls = isn ? (int)CLS_N : (int)((codes >> (2 * k)) & 3u);
+        const int slot = 2 * m + (j < lk ? 1 : 0);
+        lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + cls) * a.H + h], stats_inc_of(q));
         lds_add_u32(&qh[(slot * 128 + (int)q) * ST_QH_COPIES], 1u);
         if (((n12 >> k) & 0x1Fu) == 0u) lds_add_u32(&lds[a.l_kmer + slot * KMER_BINS + (int)((c24 >> (2 * k)) & 0x3FFu)], 1u);
     }
@@ -125,81 +124,80 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         t[0] = (u32)inc;
         t[1] = (u32)(inc >> 32);
         t[2] = kept ? S8 : 0u;
-        t[3] = kept ? (u32)(KMER_BINS * 4) : 0u;
+        t[3] = (kept ? (u32)(KMER_BINS * 4) : 0u) | (q < 33u ? 0u : 1u);   // k-mer slot offset | the count 1 (0: no base)
     }
     block_sync();
     const int u0 = block_id() * a.units_per_block;
     const int nu = imax(0, imin(a.units_per_block, a.n - u0));
     const int per_mate = nu * H;
-    const int total = (a.paired ? 2 : 1) * per_mate;
     u8* ldsw = (u8*)lds;
-    const u32 cyc_b = (u32)a.l_cyc * 4u, kmer_b = (u32)a.l_kmer * 4u, lut_b = (u32)a.l_lut * 4u;
-    const u32 qh_b = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 4u;
-    const u32 dbg = a.debug_skip;
+    const u32x4* lut = (const u32x4*)__builtin_assume_aligned(lds + a.l_lut, 16);
     u32* wl = lds + a.l_wl;
-    // The wavefront's mode = the histogram bin (Stats slot AND character) of the first item's first base, fixed at its
-    // first appearance: bases that hit it are counted per lane and added once at the end - most characters of a run are
-    // one value, and as LDS atomics they would all land on one address and serialise.
-    u32 mode_bin = 0xFFFFFFFFu;
-    u32 agg_cnt = 0;
-    for (int base = tid - lane; base < total; base += nt) {   // wave-uniform trip count (ballots inside)
-        const int it = base + lane;
-        StatsItem s;
-        stats_fetch(a, u0, per_mate, it, it < total, s);
-        const u32 nany = (s.q0 | s.q1 | s.qp) & 0x80808080u;   // an N among the 8 bases or the 4 before
-        const bool plain = s.act && nany == 0u;
-        if (s.act && !plain) {                                  // rare: queued for the base-by-base pass
-            const u32 slot = lds_add_ret_u32(wl, 1u);
-            if (slot < (u32)a.wl_cap) wl[1 + slot] = (u32)it;
-            else stats_item_general(a, lds, s, lane);           // list full (reads riddled with N): here and now
-        }
-        // bytes of the item that hold a base, and which of those are kept: bit 7 of a quality byte (free: no N here)
-        // becomes "kept", a byte past the read's end becomes character 0
-        const int j0 = 8 * s.h;
-        const int nv = imin(8, s.rl0 - j0), nk = imax(0, imin(8, s.lk - j0));
-        const u64 vmask = nv >= 8 ? ~0ull : ((1ull << (8 * imax(nv, 0))) - 1ull);
-        const u64 kmask = (nk >= 8 ? ~0ull : ((1ull << (8 * nk)) - 1ull)) & 0x8080808080808080ull;
-        const u64 qq = (((u64)s.q1 << 32) | s.q0) & vmask;
-        const u64 qk = plain ? (qq | kmask) : 0ull;            // not plain: eight "no base" characters - nothing is added below
-        const u32 e0 = (u32)qk, e1 = (u32)(qk >> 32);
-        const u32 slot_d = 2u * (u32)s.m;
-        if (mode_bin == 0xFFFFFFFFu) {                         // wave-uniform
-            const u64 cand = ballot(plain);
-            if (cand) mode_bin = shfl(slot_d * 128u + (e0 & 0xFFu), ffs64(cand) - 1);
-        }
-        const u32 c24 = s.prev8 | (s.codes << 8);              // bases j0-4 .. j0+7, 2 bits each
-        const u32 cyc0 = cyc_b + slot_d * S8 + (u32)s.h * 8u;
-        const u32 kmer0 = kmer_b + slot_d * (KMER_BINS * 4);
-        const u32 qh0 = qh_b + slot_d * (512u * ST_QH_COPIES);
-        const u32 bin0 = slot_d * 128u;
+    for (int m = 0; m < (a.paired ? 2 : 1); m++) {   // uniform: a mate's arrays and accumulator bases sit in scalar registers
+        const u32* qual = a.qual[m] + (size_t)u0 * a.qw_g;
+        const u32* seq = a.seq[m] + (size_t)u0 * a.sw_g;
+        const u32* swin = a.swin[m] + u0;
+        const u32 slot_d = 2u * (u32)m;       // dropped bases -> the PRE slot, kept ones -> the POST slot (+1)
+        const u32 cyc_m = (u32)a.l_cyc * 4u + slot_d * S8;
+        const u32 kmer_m = (u32)a.l_kmer * 4u + slot_d * (KMER_BINS * 4);
+        const u32 qh_m = (u32)a.l_qh * 4u + slot_d * (512u * ST_QH_COPIES) + (u32)(lane & (ST_QH_COPIES - 1)) * 4u;
+        // The wavefront's mode = the character (with its kept bit) of the first item's first base, fixed at its first
+        // appearance: bases that hit it are counted per lane and added once at the end - most characters of a run are
+        // one value, and as LDS atomics they would all land on one address and serialise.
+        u32 mode_e = 0xFFFFFFFFu;
+        u32 agg_cnt = 0;
+        for (int base = tid - lane; base < per_mate; base += nt) {   // wave-uniform trip count (ballots inside)
+            const int it = base + lane;
+            StatsItem s;
+            stats_fetch(a, qual, seq, swin, it, it < per_mate, s);
+            const u32 nany = (s.q0 | s.q1 | s.qp) & 0x80808080u;   // an N among the 8 bases or the 4 before
+            const bool plain = s.act && nany == 0u;
+            if (s.act && !plain) {                                  // rare: queued for the base-by-base pass
+                const u32 slot = lds_add_ret_u32(wl, 1u);
+                if (slot < (u32)a.wl_cap) wl[1 + slot] = (u32)it | ((u32)m << 31);
+                else stats_item_general(&a, lds, m, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);   // list full: here and now
+            }
+            // bytes of the item that hold a base, and which of those are kept: bit 7 of a quality byte (free: no N
+            // here) becomes "kept", a byte past the read's end becomes character 0 = "no base": it adds nothing
+            const int j0 = 8 * s.h;
+            const int nv = plain ? s.rl0 - j0 : 0, nk = s.lk - j0;   // not plain: eight "no base" characters
+            const u32 v0 = lowmask32(8 * imax(0, imin(nv, 4))), v1 = lowmask32(8 * imax(0, imin(nv - 4, 4)));
+            const u32 k0 = lowmask32(8 * imax(0, imin(nk, 4))) & 0x80808080u, k1 = lowmask32(8 * imax(0, imin(nk - 4, 4))) & 0x80808080u;
+            const u32 e0 = (s.q0 | k0) & v0, e1 = (s.q1 | k1) & v1;
+            if (mode_e == 0xFFFFFFFFu) {                           // wave-uniform
+                const u64 cand = ballot(plain);
+                if (cand) mode_e = shfl(e0 & 0xFFu, ffs64(cand) - 1);
+            }
+            const u32 c24 = s.prev8 | (s.codes << 8);              // bases j0-4 .. j0+7, 2 bits each
+            const u32 cyc0 = cyc_m + (u32)s.h * 8u;
+            const u32 hpos = s.h > 0 ? 1u : 0u;                    // 5-mers need positions >= 4 (stats.cpp:224-266)
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const u32 e = bfe(k < 4 ? e0 : e1, 8 * (k & 3), 8);     // character | kept << 7
-            const u32x4 t = *(const u32x4*)(ldsw + lut_b + (e << 4));
-            const u32 one = t.x & 1u;                                // the count field's increment: 0 for "no base"
-            if (!(dbg & 64u))
-                lds_add_u64((u64*)(ldsw + (cyc0 + t.z + (u32)k * K8 + bfe(s.codes, 2 * k, 2) * H8)), (u64)t.x | ((u64)t.y << 32));
-            // 5-mer ending at base j0 + k (stats.cpp:224-266): positions >= 4 only
-            if (!(dbg & 128u) && (k >= 4 || s.h > 0)) lds_add_u32((u32*)(ldsw + (kmer0 + t.w + (bfe(c24, 2 * k, 10) << 2))), one);
-            if (!(dbg & 256u)) {
-                const bool is_mode = bin0 + e == mode_bin;
+            for (int k = 0; k < 8; k++) {
+                const u32 e = bfe(k < 4 ? e0 : e1, 8 * (k & 3), 8);     // character | kept << 7
+                const u32x4 t = lut[e];
+                lds_add_u64((u64*)(ldsw + mul24(bfe(s.codes, 2 * k, 2), H8) + (cyc0 + t.z + (u32)k * K8)), (u64)t.x | ((u64)t.y << 32));
+                const u32 one = k < 4 ? (t.w & hpos) : (t.w & 1u);
+                lds_add_u32((u32*)(ldsw + ((kmer_m + (t.w & ~1u)) + (bfe(c24, 2 * k, 10) << 2))), one);
+                const bool is_mode = e == mode_e;
                 agg_cnt += is_mode ? 1u : 0u;
-                if (!is_mode && one) lds_add_u32((u32*)(ldsw + (qh0 + e * (4u * ST_QH_COPIES))), 1u);
+                if (!is_mode && (t.w & 1u)) lds_add_u32((u32*)(ldsw + (qh_m + e * (4u * ST_QH_COPIES))), 1u);
             }
         }
-    }
-    if (mode_bin != 0xFFFFFFFFu) {
+        if (mode_e != 0xFFFFFFFFu) {
 #pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) agg_cnt += shfl_xor(agg_cnt, sh);
-        if (lane == 0 && agg_cnt) lds_add_u32(&lds[a.l_qh + (int)mode_bin * ST_QH_COPIES], agg_cnt);
+            for (int sh = 1; sh < 64; sh <<= 1) agg_cnt += shfl_xor(agg_cnt, sh);
+            if (lane == 0 && agg_cnt) lds_add_u32(&lds[a.l_qh + (int)(slot_d * 128u + mode_e) * ST_QH_COPIES], agg_cnt);
+        }
     }
     block_sync();
     // ---- the queued items, every lane busy ----
     const int nw = imin((int)wl[0], a.wl_cap);
     for (int i = tid; i < nw; i += nt) {
+        const u32 w = wl[1 + i];
+        const int m = (int)(w >> 31);
         StatsItem s;
-        stats_fetch(a, u0, per_mate, (int)wl[1 + i], true, s);
-        stats_item_general(a, lds, s, lane);
+        stats_fetch(a, a.qual[m] + (size_t)u0 * a.qw_g, a.seq[m] + (size_t)u0 * a.sw_g, a.swin[m] + u0, (int)(w & 0x7FFFFFFFu), true, s);
+        stats_item_general(&a, lds, m, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);
     }
     block_sync();
     // ---- flush to this workgroup's slab in the canonical order the slab fold reads ([slot][cycle][class]) ----
