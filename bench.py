@@ -26,6 +26,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy
+# the kernels whose summed duration per launch is `roofline.kernel_avg_ms` (one HIP-event pair around them)
+KERNELS = {"fused": "fq_fused_kernel",
+           "split": "fq_scan_kernel + fq_stats_kernel (the fused kernel's work as two launches)",
+           "lane": "fq_lane_kernel + fq_stats_kernel (the fused kernel's work as two launches)"}
 L = 150
 
 
@@ -41,54 +45,67 @@ def bench_params():
     return p, ["-G", "--cut_right"]
 
 
-def cpu_baseline(sample_pairs, flags, params, dev):
+def write_sample_files(sample_pairs, dev):
+    """the bounded sample of the workload as plain FASTQ on tmpfs (generated on the GPU)"""
+    import torch
+    import synth_torch
+    need = sample_pairs * 4 * (2 * L + 60) * 2
+    base = None
+    for cand in ("/dev/shm", "/tmp"):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > need:
+                base = cand
+                break
+        except OSError:
+            pass
+    tmp = tempfile.mkdtemp(prefix="fastp_cpu_", dir=base)
+    f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+    block = 1_000_000
+    with open(f1, "wb", buffering=0) as a, open(f2, "wb", buffering=0) as b:
+        for done in range(0, sample_pairs, block):
+            k = min(block, sample_pairs - done)
+            d = synth_torch.synth_pairs_torch(k, L=L, seed=4242 + done // block, device=dev)
+            for mate, fh in ((1, a), (2, b)):
+                rec = synth_torch.to_fastq_tensor(d[f"seq{mate}"], d[f"qual{mate}"], mate, first=done).cpu().numpy()
+                fh.write(memoryview(rec).cast("B"))
+            del d
+    torch.cuda.empty_cache()
+    return tmp, f1, f2
+
+
+def host_cores():
+    return min(os.cpu_count() or 1, 16)   # the reference stops scaling long before that (reader-thread bound)
+
+
+def timed_ref(binary, tmp, f1, f2, flags, cores, env=None, tag="o"):
+    cmd = [binary, "-i", f1, "-I", f2, "-o", os.path.join(tmp, tag + "1.fq"), "-O", os.path.join(tmp, tag + "2.fq"),
+           "-j", os.path.join(tmp, tag + ".json"), "-h", os.path.join(tmp, tag + ".html"), "-w", str(cores)] + flags
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900,
+                       env=dict(os.environ, **(env or {})))
+        times.append(time.time() - t0)
+    return min(times)
+
+
+def cpu_baseline(sample_pairs, flags, params, dev, files=None):
     """reference fastp (oracle/_ref/fastp_ref, scalar-SIMD shim build) on the host cores, on a bounded
     sample of the same workload (generated on the GPU, written to tmpfs as plain FASTQ); falls back to the
     plain-C oracle port on a smaller sample if the binary is absent."""
     import numpy as np
-    import torch
     import synth_torch
     ref = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
-    cores = min(os.cpu_count() or 1, 16)   # the reference stops scaling long before that (reader-thread bound)
-    if os.path.exists(ref):
-        need = sample_pairs * 4 * (2 * L + 60) * 2
-        base = None
-        for cand in ("/dev/shm", "/tmp"):
-            try:
-                st = os.statvfs(cand)
-                if st.f_bavail * st.f_frsize > need:
-                    base = cand
-                    break
-            except OSError:
-                pass
-        tmp = tempfile.mkdtemp(prefix="fastp_cpu_", dir=base)
-        f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
-        block = 1_000_000
-        with open(f1, "wb", buffering=0) as a, open(f2, "wb", buffering=0) as b:
-            for done in range(0, sample_pairs, block):
-                k = min(block, sample_pairs - done)
-                d = synth_torch.synth_pairs_torch(k, L=L, seed=4242 + done // block, device=dev)
-                for mate, fh in ((1, a), (2, b)):
-                    rec = synth_torch.to_fastq_tensor(d[f"seq{mate}"], d[f"qual{mate}"], mate, first=done).cpu().numpy()
-                    fh.write(memoryview(rec).cast("B"))
-                del d
-        torch.cuda.empty_cache()
-        cmd = [ref, "-i", f1, "-I", f2, "-o", os.path.join(tmp, "o1.fq"), "-O", os.path.join(tmp, "o2.fq"),
-               "-j", os.path.join(tmp, "r.json"), "-h", os.path.join(tmp, "r.html"), "-w", str(cores)] + flags
-        times = []
-        for _ in range(2):
-            t0 = time.time()
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=600)
-            times.append(time.time() - t0)
-        for fn in os.listdir(tmp):
-            os.unlink(os.path.join(tmp, fn))
-        os.rmdir(tmp)
-        wall = min(times)
+    cores = host_cores()
+    if os.path.exists(ref) and files is not None:
+        tmp, f1, f2 = files
+        wall = timed_ref(ref, tmp, f1, f2, flags, cores)
         return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": cores,
                 "kind": "reference",
                 "sample": f"{sample_pairs} synthetic 2x{L} pairs, plain FASTQ -> FASTQ on tmpfs, fastp_ref -w {cores} "
-                          f"(scalar shim for Highway SIMD), end-to-end wall incl. FASTQ parse/write and the "
-                          f"reference's start-up (bloom allocation, pre-pass), best of 2"}
+                          f"(scalar shim for Highway SIMD; the box has {os.cpu_count()} logical cores), end-to-end wall incl. "
+                          f"FASTQ parse/write and the reference's start-up (bloom allocation, pre-pass), best of 2"}
     import oraclelib
     sample_pairs = min(sample_pairs, 500_000)
     d = synth_torch.synth_pairs_torch(sample_pairs, L=L, seed=4242, device=dev)
@@ -100,6 +117,124 @@ def cpu_baseline(sample_pairs, flags, params, dev):
     orc.close()
     return {"value": round(2 * sample_pairs / wall / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
             "sample": f"{sample_pairs} synthetic 2x{L} pairs through the plain-C oracle (per-read loop only, 1 thread)"}
+
+
+def e2e_legs(sample_pairs, flags, params, files, cpu_value):
+    """the same files end to end through the GPU path, two ways (never the headline `value`):
+    e2e_gpu    : fastp_amd.pipeline - raw text to HBM, parse / worker loop / format on the device, text back, file I/O
+    e2e_dropin : the real reference with its worker loops bound to the engine (oracle/_ref/fastp_ref_gpu, FASTP_GPU=1)
+                 - the reference's own reader / writer threads around the C ABI - next to fastp_ref on the same files"""
+    out = {}
+    tmp, f1, f2 = files
+    try:
+        from fastp_amd import pipeline
+        pl = pipeline.FastqPipeline(params, chunk_bytes=256 << 20)
+        best = None
+        for _ in range(2):
+            t0 = time.time()
+            pl.run(f1, f2, os.path.join(tmp, "g1.fq"), os.path.join(tmp, "g2.fq"))
+            dt = time.time() - t0
+            best = dt if best is None else min(best, dt)
+        pl.close()
+        out["e2e_gpu"] = {"value": round(2 * sample_pairs / best / 1e6, 3), "unit": "Mreads/s",
+                          "what": "fastp_amd.pipeline FASTQ -> FASTQ on tmpfs, parse + worker loop + format on the device, best of 2"}
+    except Exception as e:   # the kernel line must not depend on the file pipeline
+        out["e2e_gpu"] = {"value": None, "error": repr(e)[:200]}
+    refgpu = os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpu")
+    if os.path.exists(refgpu):
+        cores = host_cores()
+        try:
+            wall = timed_ref(refgpu, tmp, f1, f2, flags, cores, env={"FASTP_GPU": "1"}, tag="d")
+            same = None
+            o1, d1 = os.path.join(tmp, "o1.fq"), os.path.join(tmp, "d1.fq")
+            if os.path.exists(o1) and os.path.exists(d1):
+                import hashlib
+
+                def md5(pth):
+                    hsh = hashlib.md5()
+                    with open(pth, "rb") as fh:
+                        for blk in iter(lambda: fh.read(1 << 24), b""):
+                            hsh.update(blk)
+                    return hsh.hexdigest()
+                same = md5(o1) == md5(d1) and md5(os.path.join(tmp, "o2.fq")) == md5(os.path.join(tmp, "d2.fq"))
+            out["e2e_dropin"] = {"gpu": round(2 * sample_pairs / wall / 1e6, 3), "cpu": cpu_value, "unit": "Mreads/s", "cores": cores,
+                                 "outputs_identical": same,
+                                 "what": f"FASTP_GPU=1 fastp_ref_gpu -w {cores} vs fastp_ref -w {cores}, same files, best of 2"}
+        except Exception as e:
+            out["e2e_dropin"] = {"gpu": None, "error": repr(e)[:200]}
+    return out
+
+
+def other_configs(dev):
+    """the other single-GPU BASELINE.json configurations, inputs resident in HBM (not bench lines: reported beside it)"""
+    import numpy as np
+    import torch
+    import synth_torch
+    from fastp_amd import abi, engine
+    res = []
+
+    def run(name, params, Lr, n, paired, steps=4):
+        d = synth_torch.synth_pairs_torch(n, L=Lr, seed=5, device=dev)
+        bufs = {}
+        for m in ("1", "2") if paired else ("1",):
+            bufs[m] = synth_torch.pack_torch(d["seq" + m], d["qual" + m], d["len" + m], Lr)
+        del d
+        eng = engine.GpuEngine(params, device=dev.index or 0)
+        r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        r2 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        pr = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+        nc = torch.zeros(1, dtype=torch.int32, device=dev)
+        b = abi.Batch()
+        b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+        b.seq1, b.qual1, b.len1 = (x.data_ptr() for x in bufs["1"])
+        if paired:
+            b.seq2, b.qual2, b.len2 = (x.data_ptr() for x in bufs["2"])
+        r = abi.Results()
+        r.r1 = r1.data_ptr()
+        if paired:
+            r.r2, r.pair = r2.data_ptr(), pr.data_ptr()
+        r.n_corrections = nc.data_ptr()
+        torch.cuda.synchronize()
+        eng.submit_device(b, r)
+        eng.synchronize()
+        eng.reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.submit_device(b, r)
+            eng.reset()
+        eng.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        reads = n * (2 if paired else 1)
+        res.append({"config": name, "units_per_step": n, "ms_per_step": round(dt * 1e3, 3),
+                    "Mreads_per_s": round(reads / dt / 1e6, 1), "plan": eng.plan()})
+        eng.close()
+        del bufs, r1, r2, pr
+        torch.cuda.empty_cache()
+
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.poly_g = 1
+    p.cut_right = 1
+    run("configs[1]: SE 1x150, 10 M reads, -A -g --cut_right", p, 150, 10_000_000, False)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import cases
+        import evalport
+        Lr = 250
+        p = abi.default_params(True, Lr)
+        p.cut_right = 1
+        p.dedup = 1
+        d = synth_torch.synth_pairs_torch(20000, L=Lr, seed=5, device="cpu")
+        pad = lambda a: np.pad(a.numpy(), ((0, 0), (0, 6)))
+        b1 = cases._ArrayBatch(pad(d["seq1"]), d["len1"].numpy())
+        b2 = cases._ArrayBatch(pad(d["seq2"]), d["len2"].numpy())
+        e1, e2 = evalport.evaluate_seq_len(b1), evalport.evaluate_seq_len(b2)
+        abi.set_overrep(p, evalport.evaluate_overrep_seqs(b1, e1), evalport.evaluate_overrep_seqs(b2, e2), e1, e2, 20)
+        run(f"configs[4] per-GPU share: PE 2x250, 2 M pairs, --dedup -p ({p.n_overrep_seqs1}+{p.n_overrep_seqs2} seeds)", p, Lr, 2_000_000, True)
+    except Exception as e:
+        res.append({"config": "configs[4] per-GPU share", "error": repr(e)[:200]})
+    return res
 
 
 def log(msg):
@@ -141,10 +276,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=720, help="timed steps; a step = one batch through the hot path")
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--pairs", type=int, default=4 * 1024 * 1024, help="pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=0,
+                    help="pairs per step per GPU; 0 = 4 Mi, or - fewer steps than batches - what makes ONE run of `steps` steps "
+                         "hold 100.7 M pairs (BASELINE configs[2] at its full size)")
     ap.add_argument("--batches", type=int, default=24,
                     help="distinct batches resident per GPU = one run (24 x 4 Mi = 100.7 M pairs: BASELINE configs[2]); steps "
                          "cycle through them and the engine starts a new run (fresh bloom filter, counters) after each cycle")
+    ap.add_argument("--no-extras", action="store_true", help="skip the end-to-end legs and the other configurations")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -187,8 +325,14 @@ def main():
     params, ref_flags = bench_params()
     log("creating engine")
     eng = engine.GpuEngine(params, device=local)
-    B = args.pairs
     NB = max(1, min(args.batches, max(args.steps, args.warmup)))
+    FULL = 24 * 4 * 1024 * 1024      # BASELINE configs[2]: 100 M pairs (here 100,663,296) in one run
+    if args.pairs > 0:
+        B = args.pairs
+    elif NB < args.batches:          # a short run (the driver's --steps 20): fewer, larger batches - still 100.7 M pairs per run
+        B = -(-FULL // NB // 64) * 64
+    else:
+        B = 4 * 1024 * 1024
     log(f"generating {NB} resident batches of {B} pairs")
     resident = [ResidentBatch(B, 42 + 1000 * rank + k, dev) for k in range(NB)]
     r1 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
@@ -299,6 +443,7 @@ def main():
         elapsed = float(t.item())
 
     kms, klaunches = eng.kernel_time()
+    plan = eng.plan()
     log(f"timed region done: {elapsed:.3f}s, kernel {kms:.2f} ms over {klaunches} launches")
     if rank == 0:
         total_pairs = B * args.steps * world
@@ -346,15 +491,28 @@ def main():
                                                  ("n/a" if world == 1 else "per shard: " + shard_mode)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "fq_fused_kernel", "kernel_avg_ms": round(avg_ms, 4),
+                         "kernel": KERNELS.get(plan, "fq_fused_kernel"), "kernel_avg_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": int(per_launch_pairs)},
         }
         if compute is not None:
             out["compute_roofline"] = compute
+        out["config"]["kernel_plan"] = plan
         if world == 1 and not args.no_cpu:
             del resident
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params, dev)
+            have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "fastp_ref"))
+            files = write_sample_files(args.cpu_sample, dev) if have_ref else None
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params, dev, files)
+            if files is not None and not args.no_extras:
+                out.update(e2e_legs(args.cpu_sample, ref_flags, params, files, out["cpu_baseline"]["value"]))
+            if files is not None:
+                import shutil
+                shutil.rmtree(files[0], ignore_errors=True)
+            if not args.no_extras:
+                try:
+                    out["other_configs"] = other_configs(dev)
+                except Exception as e:
+                    out["other_configs"] = [{"error": repr(e)[:200]}]
         print(json.dumps(out))
     eng.close()
     if dist is not None:

@@ -236,6 +236,14 @@ struct fastp_gpu_ctx {
     std::vector<const char*> ovr_ptrs[2];
     // staging for submit_host
     void* d_stage = nullptr; size_t stage_cap = 0;
+    // fastp_gpu_submit_host_async: device staging, completion event and what to finish per slot
+    struct AsyncSlot {
+        void* d_stage = nullptr; size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+        int32_t* counts = nullptr;            // pinned: n_corrections, n_adapter_events as the device left them
+        fastp_gpu_results res;                // the caller's result block (host pointers)
+    } aslot[FASTP_GPU_ASYNC_SLOTS];
     u64* d_phase = nullptr;   // optional per-phase cycle counters (FASTP_GPU_PHASE_TIMING=1)
     // timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -299,6 +307,11 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
         if (ctx->d_dup_pos2[k]) (void)hipFree(ctx->d_dup_pos2[k]);
     }
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    for (auto& sl : ctx->aslot) {
+        if (sl.d_stage) (void)hipFree(sl.d_stage);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.counts) (void)hipHostFree(sl.counts);
+    }
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     void* bufs[] = {ctx->d_ov_limit, ctx->d_lowq, ctx->d_cplx, ctx->d_primes, ctx->d_planes, ctx->d_posum, ctx->d_fasta_words, ctx->d_fasta_len, ctx->d_ctr, ctx->d_slabs,
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
@@ -1928,6 +1941,120 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     return FASTP_GPU_OK;
 }
 
+
+// ---- asynchronous host submits (include/fastp_gpu.h "Pipelined host submits") ----
+extern "C" int fastp_gpu_host_alloc(fastp_gpu_ctx* ctx, int64_t bytes, void** ptr) {
+    if (!ctx || !ptr || bytes < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(ptr, (size_t)std::max<int64_t>(bytes, 16)));
+    return FASTP_GPU_OK;
+}
+extern "C" int fastp_gpu_host_free(fastp_gpu_ctx* ctx, void* ptr) {
+    if (!ctx) return FASTP_GPU_E_INVALID;
+    if (ptr) HIP_TRY(ctx, hipHostFree(ptr));
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res, int slot) {
+    if (!ctx || !b || !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    if (slot < 0 || slot >= FASTP_GPU_ASYNC_SLOTS) return fail(ctx, FASTP_GPU_E_INVALID, "slot out of range");
+    if (b->n <= 0) return fail(ctx, FASTP_GPU_E_INVALID, "empty batch");
+    fastp_gpu_ctx::AsyncSlot& sl = ctx->aslot[slot];
+    if (sl.busy) return fail(ctx, FASTP_GPU_E_INVALID, "slot still in flight: fastp_gpu_wait it first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!sl.done) HIP_TRY(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (!sl.counts) HIP_TRY(ctx, hipHostMalloc((void**)&sl.counts, 64));
+    const size_t n = (size_t)b->n;
+    const size_t ss = fastp_gpu_seq_stride(ctx->dp.max_len), qs = fastp_gpu_qual_stride(ctx->dp.max_len);
+    const int mates = ctx->dp.paired ? 2 : 1;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t corr_cap = (res->corrections && res->corrections_capacity > 0) ? (size_t)res->corrections_capacity : 0;
+    const size_t ev_cap = (res->adapter_events && res->adapter_events_capacity > 0) ? (size_t)res->adapter_events_capacity : 0;
+    const size_t total = mates * (al(n * ss) + al(n * qs) + al(n * 2) + al(n * sizeof(fastp_gpu_read_result))) +
+                         al(n * sizeof(fastp_gpu_pair_result)) + al(corr_cap * sizeof(fastp_gpu_correction)) +
+                         al(ev_cap * sizeof(fastp_gpu_adapter_event)) + 1024;
+    int rc = ensure(ctx, &sl.d_stage, &sl.cap, total);
+    if (rc) return rc;
+    char* base = (char*)sl.d_stage;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += al(bytes); return p; };
+    hipStream_t st = ctx->stream;
+    fastp_gpu_batch db = *b;
+    fastp_gpu_results dr;
+    memset(&dr, 0, sizeof(dr));
+    const void* hs[2][3] = {{b->seq1, b->qual1, b->len1}, {b->seq2, b->qual2, b->len2}};
+    void* dsq[2][3];
+    for (int m = 0; m < mates; m++) {
+        if (!hs[m][0] || !hs[m][1] || !hs[m][2]) return fail(ctx, FASTP_GPU_E_INVALID, "missing input buffer");
+        dsq[m][0] = take(n * ss);
+        dsq[m][1] = take(n * qs);
+        dsq[m][2] = take(n * 2);
+        HIP_TRY(ctx, hipMemcpyAsync(dsq[m][0], hs[m][0], n * ss, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dsq[m][1], hs[m][1], n * qs, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(dsq[m][2], hs[m][2], n * 2, hipMemcpyHostToDevice, st));
+    }
+    db.seq1 = (const uint8_t*)dsq[0][0]; db.qual1 = (const uint8_t*)dsq[0][1]; db.len1 = (const uint16_t*)dsq[0][2];
+    if (mates == 2) {
+        db.seq2 = (const uint8_t*)dsq[1][0]; db.qual2 = (const uint8_t*)dsq[1][1]; db.len2 = (const uint16_t*)dsq[1][2];
+    }
+    dr.r1 = (fastp_gpu_read_result*)take(n * sizeof(fastp_gpu_read_result));
+    if (mates == 2) {
+        dr.r2 = (fastp_gpu_read_result*)take(n * sizeof(fastp_gpu_read_result));
+        dr.pair = (fastp_gpu_pair_result*)take(n * sizeof(fastp_gpu_pair_result));
+    }
+    if (corr_cap) { dr.corrections = (fastp_gpu_correction*)take(corr_cap * sizeof(fastp_gpu_correction)); dr.corrections_capacity = (int32_t)corr_cap; }
+    dr.n_corrections = (int32_t*)take(sizeof(int32_t));
+    if (ev_cap) { dr.adapter_events = (fastp_gpu_adapter_event*)take(ev_cap * sizeof(fastp_gpu_adapter_event)); dr.adapter_events_capacity = (int32_t)ev_cap; }
+    dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
+    rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
+    if (rc) return rc;
+    rc = join_aux(ctx, st);   // the duplicate flags of the last launch
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(res->r1, dr.r1, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
+    if (mates == 2) {
+        HIP_TRY(ctx, hipMemcpyAsync(res->r2, dr.r2, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(res->pair, dr.pair, n * sizeof(fastp_gpu_pair_result), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(&sl.counts[0], dr.n_corrections, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&sl.counts[1], dr.n_adapter_events, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // the sparse lists are copied whole (their fill is only known on the device): they exist only with --correction / --adapter_fasta
+    if (corr_cap) HIP_TRY(ctx, hipMemcpyAsync(res->corrections, dr.corrections, corr_cap * sizeof(fastp_gpu_correction), hipMemcpyDeviceToHost, st));
+    if (ev_cap) HIP_TRY(ctx, hipMemcpyAsync(res->adapter_events, dr.adapter_events, ev_cap * sizeof(fastp_gpu_adapter_event), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(sl.done, st));
+    sl.res = *res;
+    sl.busy = true;
+    return FASTP_GPU_OK;
+}
+
+static int finish_slot(fastp_gpu_ctx* ctx, fastp_gpu_ctx::AsyncSlot& sl) {
+    sl.busy = false;
+    const int32_t ncorr = sl.counts[0], nev = sl.counts[1];
+    if (sl.res.n_corrections) *sl.res.n_corrections = std::min(ncorr, sl.res.corrections ? sl.res.corrections_capacity : 0);
+    if (sl.res.n_adapter_events) *sl.res.n_adapter_events = std::min(nev, sl.res.adapter_events ? sl.res.adapter_events_capacity : 0);
+    if (sl.res.corrections && ncorr > sl.res.corrections_capacity) return fail(ctx, FASTP_GPU_E_OVERFLOW, "correction list capacity exceeded");
+    if (sl.res.adapter_events && nev > sl.res.adapter_events_capacity) return fail(ctx, FASTP_GPU_E_OVERFLOW, "adapter event list capacity exceeded");
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_wait(fastp_gpu_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= FASTP_GPU_ASYNC_SLOTS) return fail(ctx, FASTP_GPU_E_INVALID, "slot out of range");
+    fastp_gpu_ctx::AsyncSlot& sl = ctx->aslot[slot];
+    if (!sl.busy) return FASTP_GPU_OK;
+    HIP_TRY(ctx, hipEventSynchronize(sl.done));
+    return finish_slot(ctx, sl);
+}
+
+extern "C" int fastp_gpu_poll(fastp_gpu_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= FASTP_GPU_ASYNC_SLOTS) return fail(ctx, FASTP_GPU_E_INVALID, "slot out of range");
+    fastp_gpu_ctx::AsyncSlot& sl = ctx->aslot[slot];
+    if (!sl.busy) return 1;
+    const hipError_t e = hipEventQuery(sl.done);
+    if (e == hipErrorNotReady) return 0;
+    if (e != hipSuccess) { HIP_TRY(ctx, e); }
+    const int rc = finish_slot(ctx, sl);
+    return rc ? rc : 1;
+}
+
 extern "C" int fastp_gpu_counters_device(fastp_gpu_ctx* ctx, int64_t** dev_ptr, int64_t* n, void* hip_stream) {
     if (!ctx || !dev_ptr || !n) return FASTP_GPU_E_INVALID;
     (void)hip_stream;  // slabs are folded right after every launch, on the launch stream
@@ -1963,6 +2090,10 @@ extern "C" int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_
 }
 
 extern "C" int fastp_gpu_device(const fastp_gpu_ctx* ctx) { return ctx ? ctx->device : -1; }
+extern "C" int fastp_gpu_plan(const fastp_gpu_ctx* ctx) {
+    if (!ctx) return -1;
+    return ctx->lane ? FASTP_GPU_PLAN_LANE : (ctx->split ? FASTP_GPU_PLAN_SPLIT : FASTP_GPU_PLAN_FUSED);
+}
 
 extern "C" int fastp_gpu_reset(fastp_gpu_ctx* ctx) {
     if (!ctx) return FASTP_GPU_E_INVALID;

@@ -69,18 +69,31 @@ struct fastp_gpu_host {
     std::vector<std::map<std::string, long>::const_iterator> index[2];  // for adapter_entry()
     bool index_valid[2] = {false, false};
 
-    void record(int which, const std::string& name, const char* seq, const char* qual, int len, const std::string& strand,
+    // a string as (pointer, length): the pack's own buffers are routed without an intermediate copy
+    struct View {
+        const char* p;
+        size_t n;
+    };
+    void record(int which, View name, const char* seq, const char* qual, int len, View strand,
                 const char* tag = nullptr) {  // Read::appendToString / appendToStringWithTag read.cpp:119-154
         std::string& s = out[which];
-        s.append(name);
-        if (tag) { s.push_back(' '); s.append(tag); }
-        s.push_back('\n');
-        s.append(seq, (size_t)len);
-        s.push_back('\n');
-        s.append(strand);
-        s.push_back('\n');
-        s.append(qual, (size_t)len);
-        s.push_back('\n');
+        const size_t tl = tag ? strlen(tag) + 1 : 0;
+        const size_t at = s.size();
+        s.resize(at + name.n + tl + strand.n + 2 * (size_t)len + 4);
+        char* w = &s[at];
+        memcpy(w, name.p, name.n); w += name.n;
+        if (tag) { *w++ = ' '; memcpy(w, tag, tl - 1); w += tl - 1; }
+        *w++ = '\n';
+        memcpy(w, seq, (size_t)len); w += len;
+        *w++ = '\n';
+        memcpy(w, strand.p, strand.n); w += strand.n;
+        *w++ = '\n';
+        memcpy(w, qual, (size_t)len); w += len;
+        *w++ = '\n';
+    }
+    void record(int which, const std::string& name, const char* seq, const char* qual, int len, const std::string& strand,
+                const char* tag = nullptr) {
+        record(which, View{name.data(), name.size()}, seq, qual, len, View{strand.data(), strand.size()}, tag);
     }
     std::string umi_tagged(const std::string& name, const std::string& umi) const {  // addUmiToName umiprocessor.cpp:62-81
         std::string tag = umi_delim + (umi_prefix.empty() ? std::string() : umi_prefix + "_") + umi;
@@ -166,16 +179,66 @@ int fastp_gpu_host_apply(fastp_gpu_host* h, const fastp_gpu_reads* b1, const fas
             std::sort(kv.second.begin(), kv.second.end(),
                       [](const fastp_gpu_adapter_event* x, const fastp_gpu_adapter_event* y) { return x->adapter < y->adapter; });
     }
+    // The common pack - no UMI, no base correction, no adapter string to replay, no merge - is routed straight from
+    // the pack's buffers (pointer + length views, one memcpy per field into the writer's string); everything else
+    // takes the general path below on copies it may edit.
+    const bool simple_opts = h->o.umi_loc == FASTP_GPU_UMI_NONE && corr.empty() && events.empty() && !h->p.merge;
     std::string s1, q1, s2, q2, name1, name2, strand1, strand2;
+    typedef fastp_gpu_host::View View;
     for (int i = 0; i < n; i++) {
         const fastp_gpu_read_result& rr1 = res->r1[i];
+        const fastp_gpu_read_result* prr2 = paired ? &res->r2[i] : nullptr;
+        if (simple_opts && !((rr1.flags | (paired ? prr2->flags : 0)) & (FASTP_GPU_RF_ADAPTER | FASTP_GPU_RF_ADAPTER_OV))) {
+            const View n1{b1->name[i], (size_t)b1->name_len[i]}, st1{b1->strand[i], (size_t)b1->strand_len[i]};
+            const char* t1s = b1->seq[i] + rr1.front; const char* t1q = b1->qual[i] + rr1.front;
+            const int t1l = rr1.len, code1 = rr1.code;
+            const bool dedup_out = h->p.dedup && (rr1.flags & FASTP_GPU_RF_DUP);
+            const bool alive1 = !(rr1.flags & FASTP_GPU_RF_NULL);
+            if (!paired) {  // seprocessor.cpp:280-290
+                if (!dedup_out) {
+                    if (alive1 && code1 == FASTP_PASS_FILTER) h->record(FASTP_GPU_OUT1, n1, t1s, t1q, t1l, st1);
+                    else if (h->want[FASTP_GPU_FAILED]) h->record(FASTP_GPU_FAILED, n1, t1s, t1q, t1l, st1, failed_type(code1));
+                }
+                continue;
+            }
+            if (dedup_out) continue;
+            const fastp_gpu_read_result& rr2 = *prr2;
+            const View n2{b2->name[i], (size_t)b2->name_len[i]}, st2{b2->strand[i], (size_t)b2->strand_len[i]};
+            const char* t2s = b2->seq[i] + rr2.front; const char* t2q = b2->qual[i] + rr2.front;
+            const int t2l = rr2.len, code2 = rr2.code;
+            const bool alive2 = !(rr2.flags & FASTP_GPU_RF_NULL);
+            const bool p1 = alive1 && code1 == FASTP_PASS_FILTER, p2 = alive2 && code2 == FASTP_PASS_FILTER;
+            const bool wf = h->want[FASTP_GPU_FAILED];
+            if (p1 && p2) {  // peprocessor.cpp:577-594
+                h->record(FASTP_GPU_OUT1, n1, t1s, t1q, t1l, st1);
+                h->record(FASTP_GPU_OUT2, n2, t2s, t2q, t2l, st2);
+            } else if (p1) {  // :595-605
+                if (h->want[FASTP_GPU_UNPAIRED1]) {
+                    h->record(FASTP_GPU_UNPAIRED1, n1, t1s, t1q, t1l, st1);
+                    if (wf) h->record(FASTP_GPU_FAILED, n2, t2s, t2q, t2l, st2, failed_type(code2));
+                } else if (wf) {
+                    h->record(FASTP_GPU_FAILED, n1, t1s, t1q, t1l, st1, "paired_read_is_failing");
+                    h->record(FASTP_GPU_FAILED, n2, t2s, t2q, t2l, st2, failed_type(code2));
+                }
+            } else if (p2) {  // :606-621
+                if (h->want[FASTP_GPU_UNPAIRED2]) {
+                    h->record(FASTP_GPU_UNPAIRED2, n2, t2s, t2q, t2l, st2);
+                    if (wf) h->record(FASTP_GPU_FAILED, n1, t1s, t1q, t1l, st1, failed_type(code1));
+                } else if (h->want[FASTP_GPU_UNPAIRED1]) {
+                    h->record(FASTP_GPU_UNPAIRED1, n2, t2s, t2q, t2l, st2);
+                    if (wf) h->record(FASTP_GPU_FAILED, n1, t1s, t1q, t1l, st1, failed_type(code1));
+                } else if (wf) {
+                    h->record(FASTP_GPU_FAILED, n1, t1s, t1q, t1l, st1, failed_type(code1));
+                    h->record(FASTP_GPU_FAILED, n2, t2s, t2q, t2l, st2, "paired_read_is_failing");
+                }
+            }
+            continue;
+        }
         name1.assign(b1->name[i], (size_t)b1->name_len[i]);
         strand1.assign(b1->strand[i], (size_t)b1->strand_len[i]);
         s1.assign(b1->seq[i], (size_t)b1->len[i]);
         q1.assign(b1->qual[i], (size_t)b1->len[i]);
-        const fastp_gpu_read_result* prr2 = nullptr;
         if (paired) {
-            prr2 = &res->r2[i];
             name2.assign(b2->name[i], (size_t)b2->name_len[i]);
             strand2.assign(b2->strand[i], (size_t)b2->strand_len[i]);
             s2.assign(b2->seq[i], (size_t)b2->len[i]);

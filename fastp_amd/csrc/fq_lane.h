@@ -202,6 +202,29 @@ FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int 
     wave_order();
 }
 
+// bit j of the result = the window that starts at base j of this 32-base word (q[0..7] its quality dwords, q[8..9] the
+// two behind them) has total quality < threshold: v_alignbit (the window's bytes), v_sad_u8 with -threshold as the
+// addend, v_alignbit to shift the sign into the mask.  WIDE: windows of 5..8 bases need a second v_sad_u8.
+template <bool WIDE>
+FQ_DEV u32 lane_window_word(const u32 (&q)[10], u32 keep_lo, u32 keep_hi, u32 nthr) {
+    u32 m = 0;
+#pragma unroll
+    for (int d = 7; d >= 0; d--) {
+        const u32 q0 = q[d] & 0x7F7F7F7Fu, q1 = q[d + 1] & 0x7F7F7F7Fu, q2 = q[d + 2 < 10 ? d + 2 : 9] & 0x7F7F7F7Fu;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const u32 x = k ? alignbit(q1, q0, 8 * k) : q0;
+            u32 sdiff = sum_bytes(x & keep_lo, nthr);
+            if (WIDE) {
+                const u32 y = k ? alignbit(q2, q1, 8 * k) : q1;
+                sdiff = sum_bytes(y & keep_hi, sdiff);
+            }
+            m = alignbit(m, sdiff, 31);   // m = m << 1 | (sum < thr)
+        }
+    }
+    return m;
+}
+
 // Load read `g` of one mate: bases, N mask, and in ONE sweep over the quality row the window predicate of cut_right /
 // cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.  `stage` = this
 // wavefront's LDS buffer, chunk0 = first unit of its chunk, rows = units the chunk has.
@@ -259,22 +282,8 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
         anyn |= nw;
         // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
         u32 m = 0;
-        if (win > 0) {   // uniform
-#pragma unroll
-            for (int d = 7; d >= 0; d--) {
-                const u32 q0 = q[d] & 0x7F7F7F7Fu, q1 = q[d + 1] & 0x7F7F7F7Fu, q2 = q[d + 2 < 10 ? d + 2 : 9] & 0x7F7F7F7Fu;
-#pragma unroll
-                for (int k = 3; k >= 0; k--) {
-                    const u32 x = k ? alignbit(q1, q0, 8 * k) : q0;
-                    u32 sdiff = sum_bytes(x & keep_lo, nthr);
-                    if (win > 4) {   // uniform
-                        const u32 y = k ? alignbit(q2, q1, 8 * k) : q1;
-                        sdiff = sum_bytes(y & keep_hi, sdiff);
-                    }
-                    m = alignbit(m, sdiff, 31);   // m = m << 1 | (sum < thr)
-                }
-            }
-        }
+        if (win > 4) m = lane_window_word<true>(q, keep_lo, keep_hi, nthr);        // uniform
+        else if (win > 0) m = lane_window_word<false>(q, keep_lo, keep_hi, nthr);
         r.bad[W] = m;
         sched_fence();   // one mask word at a time: the scheduler would otherwise keep every word's dwords in flight
     }

@@ -22,7 +22,8 @@ EXPORTS = [
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
     "fastp_gpu_dup_prefix_set", "fastp_gpu_prefix_or_images", "fastp_gpu_submit_pass2_device", "fastp_gpu_stream_set_origin", "fastp_gpu_overrep_device",
-    "fastp_gpu_device", "fastp_gpu_reset",
+    "fastp_gpu_device", "fastp_gpu_reset", "fastp_gpu_plan",
+    "fastp_gpu_host_alloc", "fastp_gpu_host_free", "fastp_gpu_submit_host_async", "fastp_gpu_wait", "fastp_gpu_poll",
     "fastp_gpu_comm_id", "fastp_gpu_comm_init", "fastp_gpu_comm_init_local", "fastp_gpu_comm_destroy", "fastp_gpu_allreduce",
     "fastp_gpu_exchange_dup_prefix", "fastp_gpu_comm_last_error",
 ]
@@ -414,6 +415,11 @@ class GpuEngine:
         fn.argtypes = [C.c_void_p, C.c_void_p]
         self._check(fn(self.h, out))
         return list(out)
+
+    def plan(self) -> str:
+        """which kernels run the worker loop for this context's options"""
+        self.lib.fastp_gpu_plan.argtypes = [C.c_void_p]
+        return {0: "fused", 1: "split", 2: "lane"}.get(int(self.lib.fastp_gpu_plan(self.h)), "?")
 
     def kernel_time(self):
         ms, k = C.c_double(), C.c_int64()

@@ -602,6 +602,23 @@ int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n);
 int fastp_gpu_exchange_dup_prefix(fastp_gpu_ctx* const* ctxs, int n);
 const char* fastp_gpu_comm_last_error(void);
 
+/* ---- Pipelined host submits -------------------------------------------------
+ * What a patched fastp does instead of calling the worker-loop body once per 1000-read pack
+ * (src/peprocessor.cpp:1021-1033 processorTask -> processPairEnd): its worker threads pack their packs, in input
+ * order, into one large batch in page-locked memory (fastp_gpu_host_alloc), one thread submits the batch - copies,
+ * kernels and result copies are queued on the context's stream and the call returns - and the threads go on packing
+ * the next batch while it runs; fastp_gpu_wait / fastp_gpu_poll say when a batch's records have arrived.
+ * Batches run in submission order (one stream): Duplicate's and the overrepresentation sampling's stream order is
+ * the submission order.  A slot owns the device staging of one batch in flight. */
+#define FASTP_GPU_ASYNC_SLOTS 4
+int fastp_gpu_host_alloc(fastp_gpu_ctx* ctx, int64_t bytes, void** ptr);   /* page-locked host memory */
+int fastp_gpu_host_free(fastp_gpu_ctx* ctx, void* ptr);
+/* `b` and the arrays of `res` (r1, r2, pair, corrections, adapter_events) must stay valid and untouched until the slot
+ * has been waited for; n_corrections / n_adapter_events are written by fastp_gpu_wait / fastp_gpu_poll. */
+int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res, int slot);
+int fastp_gpu_wait(fastp_gpu_ctx* ctx, int slot);   /* blocks; FASTP_GPU_OK, or the error of the batch (list overflow) */
+int fastp_gpu_poll(fastp_gpu_ctx* ctx, int slot);   /* 1 = arrived (slot free), 0 = still running, < 0 = error */
+
 /* HIP device ordinal the context lives on */
 int fastp_gpu_device(const fastp_gpu_ctx* ctx);
 
@@ -610,10 +627,19 @@ int fastp_gpu_device(const fastp_gpu_ctx* ctx);
  * (src/peprocessor.cpp:26-60).  Synchronous. */
 int fastp_gpu_reset(fastp_gpu_ctx* ctx);
 
-/* time spent inside the fused kernel for the launches since the last call,
- * measured with HIP events on the launch stream: total milliseconds and
- * number of launches (used by bench.py for the roofline object). */
+/* time spent inside the kernels of the per-read path (the fused kernel, or - split / lane plan - the per-read kernel
+ * plus the Stats kernel) for the launches since the last call, measured with HIP events on the launch stream: total
+ * milliseconds and number of launches (used by bench.py for the roofline object). */
 int fastp_gpu_kernel_time(fastp_gpu_ctx* ctx, double* total_ms, int64_t* launches);
+
+/* which kernels run the worker loop for this context's options (diagnostic; the results do not depend on it):
+ * 0 = fq_fused_kernel (one 1024-lane workgroup per CU, Stats::statRead inside),
+ * 1 = fq_scan_kernel + fq_stats_kernel (tile kernel as 256-lane workgroups, streaming Stats kernel),
+ * 2 = fq_lane_kernel + fq_stats_kernel (one lane per pair, reads in registers). */
+#define FASTP_GPU_PLAN_FUSED 0
+#define FASTP_GPU_PLAN_SPLIT 1
+#define FASTP_GPU_PLAN_LANE 2
+int fastp_gpu_plan(const fastp_gpu_ctx* ctx);
 
 #ifdef __cplusplus
 }

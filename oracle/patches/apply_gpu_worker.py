@@ -3,7 +3,7 @@
 
     apply_gpu_worker.py <reference root> <output dir>
 
-Writes <output dir>/peprocessor.cpp, seprocessor.cpp and evaluator.cpp: the reference's files with five one-line insertions,
+Writes <output dir>/peprocessor.cpp, seprocessor.cpp and evaluator.cpp: the reference's files with nine one-line insertions,
 each placed by an anchor (the function signature / the comment that opens the merge of the per-thread results).
 Nothing else of the reference is touched or reproduced here; every other source is compiled where it lies.
 """
@@ -32,12 +32,20 @@ patch("peprocessor.cpp", [
      "\n    if(fastp_gpu_worker_pe(this, leftPack, rightPack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
     (r"[ \t]*// merge stats and filter results",
      "    fastp_gpu_worker_finish_pe(this, configs);   // engine counters -> Stats / FilterResult / Duplicate / insert sizes\n", "before"),
+    (r"[ \t]*inputLeft->setConsumerFinished\(\);\s*inputRight->setConsumerFinished\(\);",
+     "    fastp_gpu_worker_drain_pe(this, config);   // packs still in flight on the engine\n", "before"),
+    (r"\} else \{(?=\s*std::unique_lock<std::mutex> lk\(mBackpressureMtx\);\s*mBackpressureCV\.wait_for\(lk, std::chrono::milliseconds\(1\)\);\s*\}\s*\}\s*fastp_gpu_worker_drain_pe)",
+     "\n            fastp_gpu_worker_idle_pe(this, config);   // nothing to consume: hand out what has come back meanwhile", "after"),
 ])
 patch("seprocessor.cpp", [
     (r"bool SingleEndProcessor::processSingleEnd\(ReadPack\* pack, ThreadConfig\* config\)\s*\{",
      "\n    if(fastp_gpu_worker_se(this, pack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
     (r"[ \t]*// merge stats and read filter results",
      "    fastp_gpu_worker_finish_se(this, configs);   // engine counters -> Stats / FilterResult / Duplicate\n", "before"),
+    (r"[ \t]*input->setConsumerFinished\(\);",
+     "    fastp_gpu_worker_drain_se(this, config);   // packs still in flight on the engine\n", "before"),
+    (r"\} else \{(?=\s*std::unique_lock<std::mutex> lk\(mBackpressureMtx\);\s*mBackpressureCV\.wait_for\(lk, std::chrono::milliseconds\(1\)\);\s*\}\s*\}\s*fastp_gpu_worker_drain_se)",
+     "\n            fastp_gpu_worker_idle_se(this, config);   // nothing to consume: hand out what has come back meanwhile", "after"),
 ])
 patch("evaluator.cpp", [
     (r"void Evaluator::computeOverRepSeq\(string filename, map<string, long>& hotseqs, int seqlen\)\s*\{",

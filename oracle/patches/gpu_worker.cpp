@@ -10,6 +10,7 @@
 #include <sys/stat.h>
 #include <algorithm>
 #include <atomic>
+#include <deque>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -61,18 +62,62 @@
 
 namespace {
 
+// ---------------------------------------------------------------------------------------------------------------
+// The reference deals its 1000-read packs round-robin to W worker threads (pack k -> thread k % W,
+// src/peprocessor.cpp:787-792) and each thread runs the loop body once per pack.  Here the threads do what is left
+// of the body on the host - packing a pack's strings into the engine's rows, and later turning the records into the
+// output strings - while the engine sees WINDOWS of K consecutive packs as one batch:
+//   * window j = packs [jK, (j+1)K).  A thread writes its pack straight into the window's page-locked rows at
+//     (pack - jK) * PACK_SIZE, so the rows of a window are the input stream in input order whatever the threads'
+//     timing: Duplicate and the overrepresentation sampling see exactly the `-w 1` stream.
+//   * the thread that fills the last missing pack of the oldest unsubmitted window submits it
+//     (fastp_gpu_submit_host_async: copies + kernels + result copies queued on one stream, returns at once).
+//   * NSLOT windows are in flight: while window j runs, the threads fill j+1 .. j+NSLOT-1.
+//   * a thread keeps its packs in a FIFO; whenever it comes by (next pack, or the drain at the end of processorTask)
+//     it applies the records of its packs whose window has arrived - fastp_gpu_host_apply into the strings the
+//     WriterThreads take (per-thread order = pack order, as WriterThread::input expects) - and recycles the reads.
+// The reader's backpressure counter (mPackProcessedCounter) is advanced when a pack is ACCEPTED: the windows are the
+// bound on memory now (NSLOT * K packs), and the reader must be allowed to run K packs ahead.
+// ---------------------------------------------------------------------------------------------------------------
+enum { NSLOT = 3 };
+
+struct Window {
+    // page-locked rows of K * PACK_SIZE units
+    uint8_t *pseq[2] = {nullptr, nullptr}, *pqual[2] = {nullptr, nullptr};
+    uint16_t* plen[2] = {nullptr, nullptr};
+    fastp_gpu_read_result* rr[2] = {nullptr, nullptr};
+    fastp_gpu_pair_result* pr = nullptr;
+    fastp_gpu_correction* corr = nullptr;
+    fastp_gpu_adapter_event* ev = nullptr;
+    int32_t corr_cap = 0, ev_cap = 0;
+    int32_t ncorr = 0, nev = 0;
+    std::vector<int32_t> count;            // reads of pack i of the window (PACK_SIZE but for the stream's last pack)
+    std::atomic<int> filled{0};            // packs packed so far
+    std::atomic<int> applied{0};           // packs whose records have been turned into output
+    std::atomic<long> index{-1};           // which window of the stream the slot holds (-1: free)
+    std::atomic<int> state{0};             // 0 filling, 1 submitted, 2 arrived
+    int packs = 0;                         // packs in the submitted batch
+    fastp_gpu_batch batch;
+    fastp_gpu_results res;
+};
+
 struct State {
-    std::mutex mu;               // one engine, packs submitted one at a time (stream order = submission order)
+    std::mutex mu;               // submission order = window order; also guards fastp_gpu_* calls that touch the stream
     fastp_gpu_ctx* ctx = nullptr;
     fastp_gpu_params params;
     fastp_gpu_counter_layout lay;
     bool paired = false;
     int max_len = 0;
+    int W = 1, K = 256;
+    size_t ss = 0, qs = 0;
+    Window win[NSLOT];
+    long next_submit = 0;                  // (under mu) the oldest window not yet submitted
+    std::atomic<long> total_packs{-1};     // known once the reader has finished
     std::vector<fastp_gpu_host*> hosts;              // per worker thread: output strings + adapter maps
     std::vector<std::string> seeds[2], fasta;        // own copies of the strings the parameter block points at
     std::vector<const char*> seedp[2], fastap;
     std::string a1, a2, umi_prefix;
-    bool warned_fallback = false;
+    std::atomic<bool> warned_fallback{false};
 };
 State* G = nullptr;
 std::once_flag g_once;
@@ -172,17 +217,45 @@ void make_state(Options* o, bool paired) {
         if (fastp_gpu_host_create(&p, &ho, &h) != FASTP_GPU_OK) error_exit("fastp_gpu_host_create failed");
         s->hosts.push_back(h);
     }
+    // the windows: K packs each (FASTP_GPU_PACKS, default 256 = 256 K units: the copy of a window takes ~2 ms, its kernels
+    // well under 1 ms; a window is complete after K / W packs per thread)
+    s->W = std::max(1, o->thread);
+    s->K = 256;
+    if (const char* v = getenv("FASTP_GPU_PACKS")) s->K = std::max(1, atoi(v));
+    s->ss = fastp_gpu_seq_stride(s->max_len);
+    s->qs = fastp_gpu_qual_stride(s->max_len);
+    const size_t units = (size_t)s->K * PACK_SIZE;
+    auto pinned = [&](size_t bytes) {
+        void* q = nullptr;
+        if (fastp_gpu_host_alloc(s->ctx, (int64_t)bytes, &q) != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_host_alloc: ") + fastp_gpu_last_error(s->ctx));
+        return q;
+    };
+    for (Window& w : s->win) {
+        for (int m = 0; m < (paired ? 2 : 1); m++) {
+            w.pseq[m] = (uint8_t*)pinned(units * s->ss);
+            w.pqual[m] = (uint8_t*)pinned(units * s->qs);
+            w.plen[m] = (uint16_t*)pinned(units * 2);
+            w.rr[m] = (fastp_gpu_read_result*)pinned(units * sizeof(fastp_gpu_read_result));
+        }
+        if (paired) w.pr = (fastp_gpu_pair_result*)pinned(units * sizeof(fastp_gpu_pair_result));
+        if (p.correction) { w.corr_cap = (int32_t)std::min<size_t>(units * 8 + 1024, (size_t)1 << 26); w.corr = (fastp_gpu_correction*)pinned((size_t)w.corr_cap * sizeof(fastp_gpu_correction)); }
+        if (p.n_adapter_fasta) { w.ev_cap = (int32_t)(units * 2 * std::min(p.n_adapter_fasta, 8) + 16); w.ev = (fastp_gpu_adapter_event*)pinned((size_t)w.ev_cap * sizeof(fastp_gpu_adapter_event)); }
+        w.count.assign((size_t)s->K, 0);
+    }
     G = s;
 }
 
-// per worker thread scratch: the packed pack, the records
+// a worker thread's packs that the engine has not answered yet
+struct Pending {
+    long seq;                    // pack number in the stream
+    ReadPack *left, *right;      // right == NULL for single-end
+    int n;
+};
 struct Scratch {
     std::vector<const char*> name[2], seq[2], qual[2], strand[2];
     std::vector<int32_t> name_len[2], len[2], strand_len[2];
-    std::vector<uint8_t> pseq[2], pqual[2];
-    std::vector<uint16_t> plen[2];
-    std::vector<fastp_gpu_read_result> rr[2];
-    std::vector<fastp_gpu_pair_result> pr;
+    std::deque<Pending> pending;
+    long npacks = 0;             // packs this thread has accepted
     std::vector<fastp_gpu_correction> corr;
     std::vector<fastp_gpu_adapter_event> ev;
 };
@@ -200,14 +273,6 @@ void gather(Read** data, int n, int m) {
     }
 }
 
-bool pack(int n, int m) {
-    const size_t ss = fastp_gpu_seq_stride(G->max_len), qs = fastp_gpu_qual_stride(G->max_len);
-    T.pseq[m].resize((size_t)n * ss); T.pqual[m].resize((size_t)n * qs); T.plen[m].resize(n);
-    int32_t bad = -1;
-    return fastp_gpu_pack_reads(G->max_len, n, T.seq[m].data(), T.qual[m].data(), T.len[m].data(), T.pseq[m].data(),
-                                T.pqual[m].data(), T.plen[m].data(), &bad) == FASTP_GPU_OK;
-}
-
 fastp_gpu_reads reads_of(int n, int m) {
     fastp_gpu_reads r;
     r.n = n;
@@ -217,53 +282,162 @@ fastp_gpu_reads reads_of(int n, int m) {
     return r;
 }
 
-// submit one pack and apply its records; false = not handled
-bool run_pack(int tid, int n, bool paired, bool thread0) {
-    for (int m = 0; m < (paired ? 2 : 1); m++)
-        if (!pack(n, m)) {
-            if (!G->warned_fallback) {
-                G->warned_fallback = true;
-                fprintf(stderr, "FASTP_GPU: a pack holds reads the engine refuses (alphabet / length); such packs run through the CPU loop\n");
-            }
-            return false;
-        }
-    for (int m = 0; m < (paired ? 2 : 1); m++) T.rr[m].assign(n, fastp_gpu_read_result());
-    T.pr.assign(paired ? n : 0, fastp_gpu_pair_result());
-    T.corr.resize(G->params.correction ? (size_t)n * 64 + 16 : 0);
-    T.ev.resize(G->params.n_adapter_fasta ? (size_t)n * 2 * std::min(G->params.n_adapter_fasta, 8) + 16 : 0);
-    int32_t ncorr = 0, nev = 0;
-    fastp_gpu_batch b;
-    memset(&b, 0, sizeof(b));
-    b.n = n;
-    b.flags = thread0 ? FASTP_GPU_BATCH_STAT_ISIZE : 0u;   // statInsertSize runs on worker thread 0 only (peprocessor.cpp:449)
-    b.seq1 = T.pseq[0].data(); b.qual1 = T.pqual[0].data(); b.len1 = T.plen[0].data();
-    if (paired) { b.seq2 = T.pseq[1].data(); b.qual2 = T.pqual[1].data(); b.len2 = T.plen[1].data(); }
-    fastp_gpu_results res;
-    memset(&res, 0, sizeof(res));
-    res.r1 = T.rr[0].data();
-    if (paired) { res.r2 = T.rr[1].data(); res.pair = T.pr.data(); }
-    res.corrections = T.corr.empty() ? NULL : T.corr.data();
-    res.corrections_capacity = (int32_t)T.corr.size();
-    res.n_corrections = &ncorr;
-    res.adapter_events = T.ev.empty() ? NULL : T.ev.data();
-    res.adapter_events_capacity = (int32_t)T.ev.size();
-    res.n_adapter_events = &nev;
-    {
-        std::lock_guard<std::mutex> lk(G->mu);
-        const int rc = fastp_gpu_submit_host(G->ctx, &b, &res);
-        if (rc != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_submit_host: ") + fastp_gpu_last_error(G->ctx));
-    }
-    fastp_gpu_reads r1 = reads_of(n, 0), r2;
-    if (paired) r2 = reads_of(n, 1);
-    fastp_gpu_host_clear_outputs(G->hosts[tid]);
-    if (fastp_gpu_host_apply(G->hosts[tid], &r1, paired ? &r2 : NULL, &res) != FASTP_GPU_OK) error_exit("fastp_gpu_host_apply failed");
-    return true;
-}
-
 std::string* take(int tid, int which) {
     size_t len = 0;
     const char* s = fastp_gpu_host_output(G->hosts[tid], which, &len);
     return new std::string(s ? s : "", s ? len : 0);
+}
+
+long packs_expected(long j) {   // packs window j will hold, or -1 while the stream's length is unknown and the window may be its last
+    const long total = G->total_packs.load(std::memory_order_acquire);
+    if (total < 0) return -1;
+    return std::max<long>(0, std::min<long>(G->K, total - j * G->K));
+}
+
+// submit every complete window at the head of the stream, in order; poll the ones in flight
+void pump() {
+    std::unique_lock<std::mutex> lk(G->mu, std::try_to_lock);
+    if (!lk.owns_lock()) return;          // somebody else is pumping
+    for (;;) {
+        Window& w = G->win[G->next_submit % NSLOT];
+        if (w.index.load(std::memory_order_acquire) != G->next_submit || w.state.load(std::memory_order_acquire) != 0) break;
+        const long exp = packs_expected(G->next_submit);
+        const int have = w.filled.load(std::memory_order_acquire);
+        if (!(have == G->K || (exp >= 0 && have == exp)) || have == 0) {
+            if (exp == 0 && have == 0) { /* the stream ended on a window boundary: nothing to submit */ }
+            break;
+        }
+        // rows are contiguous when every pack but the last is full; the reader only leaves the stream's last pack short
+        long n = 0;
+        bool contiguous = true;
+        for (int i = 0; i < have; i++) {
+            if (i + 1 < have && w.count[(size_t)i] != PACK_SIZE) contiguous = false;
+            n = (long)i * PACK_SIZE + w.count[(size_t)i];
+        }
+        if (!contiguous) error_exit("FASTP_GPU=1: a short pack in the middle of the stream (unexpected reader behaviour)");
+        memset(&w.batch, 0, sizeof(w.batch));
+        w.batch.n = (int32_t)n;
+        w.batch.flags = FASTP_GPU_BATCH_STAT_ISIZE;   // the `-w 1` semantics: every pair's insert size (the reference samples thread 0's packs)
+        w.batch.seq1 = w.pseq[0]; w.batch.qual1 = w.pqual[0]; w.batch.len1 = w.plen[0];
+        if (G->paired) { w.batch.seq2 = w.pseq[1]; w.batch.qual2 = w.pqual[1]; w.batch.len2 = w.plen[1]; }
+        memset(&w.res, 0, sizeof(w.res));
+        w.res.r1 = w.rr[0];
+        if (G->paired) { w.res.r2 = w.rr[1]; w.res.pair = w.pr; }
+        w.res.corrections = w.corr; w.res.corrections_capacity = w.corr_cap; w.res.n_corrections = &w.ncorr;
+        w.res.adapter_events = w.ev; w.res.adapter_events_capacity = w.ev_cap; w.res.n_adapter_events = &w.nev;
+        w.packs = have;
+        if (n > 0) {
+            const int rc = fastp_gpu_submit_host_async(G->ctx, &w.batch, &w.res, (int)(G->next_submit % NSLOT));
+            if (rc != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_submit_host_async: ") + fastp_gpu_last_error(G->ctx));
+            w.state.store(1, std::memory_order_release);
+        } else {
+            w.state.store(2, std::memory_order_release);
+        }
+        G->next_submit++;
+    }
+    for (int s = 0; s < NSLOT; s++) {
+        Window& w = G->win[s];
+        if (w.state.load(std::memory_order_acquire) == 1) {
+            const int r = fastp_gpu_poll(G->ctx, s);
+            if (r < 0) error_exit(std::string("fastp_gpu_poll: ") + fastp_gpu_last_error(G->ctx));
+            if (r == 1) w.state.store(2, std::memory_order_release);
+        }
+    }
+}
+
+// the slot of window j, once it is this window's turn to use it
+Window* window_for(long j) {
+    Window& w = G->win[j % NSLOT];
+    for (;;) {
+        long idx = w.index.load(std::memory_order_acquire);
+        if (idx == j) return &w;
+        if (idx == -1) {   // free: claim it for window j (several threads may try; one wins, the others see idx == j)
+            long expect = -1;
+            if (w.index.compare_exchange_strong(expect, j, std::memory_order_acq_rel)) return &w;
+            continue;
+        }
+        return nullptr;    // still holds window j - NSLOT
+    }
+}
+
+template <class Proc>
+void emit_pe(Proc* pp, int tid) {
+    if (pp->mMergedWriter) pp->mMergedWriter->input(tid, take(tid, FASTP_GPU_MERGED));
+    if (pp->mFailedWriter) pp->mFailedWriter->input(tid, take(tid, FASTP_GPU_FAILED));
+    if (pp->mRightWriter && pp->mLeftWriter) {
+        pp->mLeftWriter->input(tid, take(tid, FASTP_GPU_OUT1));
+        pp->mRightWriter->input(tid, take(tid, FASTP_GPU_OUT2));
+    } else if (pp->mLeftWriter) {
+        pp->mLeftWriter->input(tid, new std::string());   // the interleaved-to-one-stream form needs --stdout (refused above)
+    }
+    if (pp->mUnpairedLeftWriter && pp->mUnpairedRightWriter) {
+        pp->mUnpairedLeftWriter->input(tid, take(tid, FASTP_GPU_UNPAIRED1));
+        pp->mUnpairedRightWriter->input(tid, take(tid, FASTP_GPU_UNPAIRED2));
+    } else if (pp->mUnpairedLeftWriter) {
+        pp->mUnpairedLeftWriter->input(tid, take(tid, FASTP_GPU_UNPAIRED1));
+    }
+}
+
+// apply the records of this thread's packs whose window has arrived (in pack order); returns packs applied
+template <class Emit, class Recycle>
+int drain_ready(int tid, Emit emit, Recycle recycle) {
+    int done = 0;
+    while (!T.pending.empty()) {
+        Pending& pd = T.pending.front();
+        const long j = pd.seq / G->K;
+        Window& w = G->win[j % NSLOT];
+        if (w.index.load(std::memory_order_acquire) != j || w.state.load(std::memory_order_acquire) != 2) break;
+        const int n = pd.n;
+        const size_t row = (size_t)(pd.seq - j * G->K) * PACK_SIZE;
+        gather(pd.left->data, n, 0);
+        if (pd.right) gather(pd.right->data, n, 1);
+        fastp_gpu_results res;
+        memset(&res, 0, sizeof(res));
+        res.r1 = w.rr[0] + row;
+        if (pd.right) { res.r2 = w.rr[1] + row; res.pair = w.pr + row; }
+        // the sparse lists of the window, narrowed to this pack and re-based to it
+        int32_t ncorr = 0, nev = 0;
+        const uint32_t lo = (uint32_t)row * (pd.right ? 2u : 1u), hi = (uint32_t)(row + (size_t)n) * (pd.right ? 2u : 1u);
+        if (w.corr && w.ncorr > 0) {
+            T.corr.clear();
+            for (int32_t i = 0; i < w.ncorr; i++)
+                if (w.corr[i].read >= lo && w.corr[i].read < hi) { T.corr.push_back(w.corr[i]); T.corr.back().read -= lo; }
+            res.corrections = T.corr.data(); ncorr = (int32_t)T.corr.size(); res.corrections_capacity = ncorr; res.n_corrections = &ncorr;
+        }
+        if (w.ev && w.nev > 0) {
+            T.ev.clear();
+            for (int32_t i = 0; i < w.nev; i++)
+                if (w.ev[i].read >= lo && w.ev[i].read < hi) { T.ev.push_back(w.ev[i]); T.ev.back().read -= lo; }
+            res.adapter_events = T.ev.data(); nev = (int32_t)T.ev.size(); res.adapter_events_capacity = nev; res.n_adapter_events = &nev;
+        }
+        fastp_gpu_reads r1 = reads_of(n, 0), r2;
+        if (pd.right) r2 = reads_of(n, 1);
+        fastp_gpu_host_clear_outputs(G->hosts[tid]);
+        if (fastp_gpu_host_apply(G->hosts[tid], &r1, pd.right ? &r2 : NULL, &res) != FASTP_GPU_OK) error_exit("fastp_gpu_host_apply failed");
+        emit(tid);
+        recycle(pd);
+        // the last pack of a window to be applied frees the slot
+        if (w.applied.fetch_add(1, std::memory_order_acq_rel) + 1 == w.packs) {
+            w.applied.store(0, std::memory_order_relaxed);
+            w.filled.store(0, std::memory_order_relaxed);
+            w.state.store(0, std::memory_order_relaxed);
+            w.index.store(-1, std::memory_order_release);
+        }
+        T.pending.pop_front();
+        done++;
+    }
+    return done;
+}
+
+// pack the reads of one ReadPack pair into its rows of its window; false = the engine refuses a read of it
+bool pack_into(Window& w, size_t row, int n, bool paired) {
+    for (int m = 0; m < (paired ? 2 : 1); m++) {
+        int32_t bad = -1;
+        if (fastp_gpu_pack_reads(G->max_len, n, T.seq[m].data(), T.qual[m].data(), T.len[m].data(), w.pseq[m] + row * G->ss,
+                                 w.pqual[m] + row * G->qs, w.plen[m] + row, &bad) != FASTP_GPU_OK)
+            return false;
+    }
+    return true;
 }
 
 // the engine's counter block added onto one Stats object (the per-cycle part has Stats::mCycleBuffer's layout)
@@ -318,6 +492,10 @@ std::vector<int64_t> fetch_counters() {
 }
 
 void shutdown() {
+    for (Window& w : G->win) {
+        void* bufs[] = {w.pseq[0], w.pseq[1], w.pqual[0], w.pqual[1], w.plen[0], w.plen[1], w.rr[0], w.rr[1], w.pr, w.corr, w.ev};
+        for (void* b : bufs) if (b) fastp_gpu_host_free(G->ctx, b);
+    }
     for (auto* h : G->hosts) fastp_gpu_host_destroy(h);
     fastp_gpu_destroy(G->ctx);
     delete G;
@@ -325,6 +503,22 @@ void shutdown() {
 }
 
 }  // namespace
+
+// the stream's length is known once the reader has handed out its last pack (a thread sees that on its own input list)
+template <class Proc, class List>
+void note_total(Proc* pp, List* in) {
+    if (G->total_packs.load(std::memory_order_acquire) >= 0) return;
+    if (in->isProducerFinished()) G->total_packs.store((long)pp->mLeftPackReadCounter, std::memory_order_release);
+}
+void note_total_se(SingleEndProcessor* sp, SingleProducerSingleConsumerList<ReadPack*>* in) {
+    if (G->total_packs.load(std::memory_order_acquire) >= 0) return;
+    if (in->isProducerFinished()) G->total_packs.store((long)sp->mPackReadCounter, std::memory_order_release);
+}
+
+void refuse_pack() {
+    error_exit("FASTP_GPU=1: a pack holds reads the engine refuses (letters outside ACGTN, quality characters outside '!'..'~', or a read "
+               "longer than the evaluated read length); rerun without FASTP_GPU=1");
+}
 
 int fastp_gpu_worker_pe(PairEndProcessor* pp, ReadPack* left, ReadPack* right, ThreadConfig* config) {
     if (!enabled()) return -1;
@@ -338,34 +532,77 @@ int fastp_gpu_worker_pe(PairEndProcessor* pp, ReadPack* left, ReadPack* right, T
     }
     const int tid = config->getThreadId();
     const int n = std::min(left->count, right->count);
+    auto emit = [&](int t) { emit_pe(pp, t); };
+    auto recycle = [&](Pending& pd) {
+        for (int i = 0; i < pd.left->count; i++) pp->recycleToPool1(tid, pd.left->data[i]);
+        for (int i = 0; i < pd.right->count; i++) pp->recycleToPool2(tid, pd.right->data[i]);
+        delete[] pd.left->data;
+        delete[] pd.right->data;
+        delete pd.left;
+        delete pd.right;
+    };
+    const long seq = T.npacks * G->W + tid;   // pack k goes to thread k % W and a thread's packs arrive in order (peprocessor.cpp:787-792)
+    T.npacks++;
+    const long j = seq / G->K;
+    Window* w;
+    while (!(w = window_for(j))) {            // the slot still holds window j - NSLOT: help it along
+        note_total(pp, config->getLeftInput());
+        pump();
+        if (!drain_ready(tid, emit, recycle)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    const size_t slot = (size_t)(seq - j * G->K);
     gather(left->data, n, 0);
     gather(right->data, n, 1);
-    if (!run_pack(tid, n, true, tid == 0)) return -1;
-    // hand the strings to the writer threads exactly as peprocessor.cpp:644-686 does
-    if (pp->mMergedWriter) pp->mMergedWriter->input(tid, take(tid, FASTP_GPU_MERGED));
-    if (pp->mFailedWriter) pp->mFailedWriter->input(tid, take(tid, FASTP_GPU_FAILED));
-    if (pp->mRightWriter && pp->mLeftWriter) {
-        pp->mLeftWriter->input(tid, take(tid, FASTP_GPU_OUT1));
-        pp->mRightWriter->input(tid, take(tid, FASTP_GPU_OUT2));
-    } else if (pp->mLeftWriter) {
-        pp->mLeftWriter->input(tid, new std::string());   // the interleaved-to-one-stream form needs --stdout (refused above)
-    }
-    if (pp->mUnpairedLeftWriter && pp->mUnpairedRightWriter) {
-        pp->mUnpairedLeftWriter->input(tid, take(tid, FASTP_GPU_UNPAIRED1));
-        pp->mUnpairedRightWriter->input(tid, take(tid, FASTP_GPU_UNPAIRED2));
-    } else if (pp->mUnpairedLeftWriter) {
-        pp->mUnpairedLeftWriter->input(tid, take(tid, FASTP_GPU_UNPAIRED1));
-    }
-    for (int i = 0; i < left->count; i++) pp->recycleToPool1(tid, left->data[i]);
-    for (int i = 0; i < right->count; i++) pp->recycleToPool2(tid, right->data[i]);
+    if (!pack_into(*w, slot * PACK_SIZE, n, true)) refuse_pack();
+    w->count[slot] = n;
+    w->filled.fetch_add(1, std::memory_order_acq_rel);
+    T.pending.push_back(Pending{seq, left, right, n});
     config->markProcessed(left->count);
-    delete[] left->data;
-    delete[] right->data;
-    delete left;
-    delete right;
-    pp->mPackProcessedCounter.fetch_add(1, std::memory_order_release);
+    pp->mPackProcessedCounter.fetch_add(1, std::memory_order_release);   // accepted: the windows bound the memory now
     pp->mBackpressureCV.notify_all();
+    note_total(pp, config->getLeftInput());
+    pump();
+    drain_ready(tid, emit, recycle);
     return 1;
+}
+
+// end of processorTask: everything this thread still holds goes out before the writers are told the input is complete
+void fastp_gpu_worker_drain_pe(PairEndProcessor* pp, ThreadConfig* config) {
+    if (!G) return;
+    const int tid = config->getThreadId();
+    auto emit = [&](int t) { emit_pe(pp, t); };
+    auto recycle = [&](Pending& pd) {
+        for (int i = 0; i < pd.left->count; i++) pp->recycleToPool1(tid, pd.left->data[i]);
+        for (int i = 0; i < pd.right->count; i++) pp->recycleToPool2(tid, pd.right->data[i]);
+        delete[] pd.left->data;
+        delete[] pd.right->data;
+        delete pd.left;
+        delete pd.right;
+    };
+    // this thread's loop ended, so the reader is done: the stream's length is final
+    G->total_packs.store((long)pp->mLeftPackReadCounter, std::memory_order_release);
+    while (!T.pending.empty()) {
+        pump();
+        if (!drain_ready(tid, emit, recycle)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    pump();
+}
+
+void fastp_gpu_worker_idle_pe(PairEndProcessor* pp, ThreadConfig* config) {
+    if (!G || T.pending.empty()) return;
+    const int tid = config->getThreadId();
+    auto emit = [&](int t) { emit_pe(pp, t); };
+    auto recycle = [&](Pending& pd) {
+        for (int i = 0; i < pd.left->count; i++) pp->recycleToPool1(tid, pd.left->data[i]);
+        for (int i = 0; i < pd.right->count; i++) pp->recycleToPool2(tid, pd.right->data[i]);
+        delete[] pd.left->data;
+        delete[] pd.right->data;
+        delete pd.left;
+        delete pd.right;
+    };
+    note_total(pp, config->getLeftInput());
+    pump();
+    drain_ready(tid, emit, recycle);
 }
 
 int fastp_gpu_worker_se(SingleEndProcessor* sp, ReadPack* pack, ThreadConfig* config) {
@@ -374,17 +611,74 @@ int fastp_gpu_worker_se(SingleEndProcessor* sp, ReadPack* pack, ThreadConfig* co
     std::call_once(g_once, [&] { make_state(o, false); });
     const int tid = config->getThreadId();
     const int n = pack->count;
+    auto emit = [&](int t) {
+        if (sp->mLeftWriter) sp->mLeftWriter->input(t, take(t, FASTP_GPU_OUT1));     // seprocessor.cpp:299-304
+        if (sp->mFailedWriter) sp->mFailedWriter->input(t, take(t, FASTP_GPU_FAILED));
+    };
+    auto recycle = [&](Pending& pd) {
+        for (int i = 0; i < pd.left->count; i++) sp->recycleToPool(tid, pd.left->data[i]);
+        delete[] pd.left->data;
+        delete pd.left;
+    };
+    const long seq = T.npacks * G->W + tid;
+    T.npacks++;
+    const long j = seq / G->K;
+    Window* w;
+    while (!(w = window_for(j))) {
+        note_total_se(sp, config->getLeftInput());
+        pump();
+        if (!drain_ready(tid, emit, recycle)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    const size_t slot = (size_t)(seq - j * G->K);
     gather(pack->data, n, 0);
-    if (!run_pack(tid, n, false, false)) return -1;
-    if (sp->mLeftWriter) sp->mLeftWriter->input(tid, take(tid, FASTP_GPU_OUT1));     // seprocessor.cpp:299-304
-    if (sp->mFailedWriter) sp->mFailedWriter->input(tid, take(tid, FASTP_GPU_FAILED));
-    for (int i = 0; i < n; i++) sp->recycleToPool(tid, pack->data[i]);
+    if (!pack_into(*w, slot * PACK_SIZE, n, false)) refuse_pack();
+    w->count[slot] = n;
+    w->filled.fetch_add(1, std::memory_order_acq_rel);
+    T.pending.push_back(Pending{seq, pack, nullptr, n});
     config->markProcessed(pack->count);
-    delete pack->data;
-    delete pack;
     sp->mPackProcessedCounter.fetch_add(1, std::memory_order_release);
     sp->mBackpressureCV.notify_all();
+    note_total_se(sp, config->getLeftInput());
+    pump();
+    drain_ready(tid, emit, recycle);
     return 1;
+}
+
+void fastp_gpu_worker_drain_se(SingleEndProcessor* sp, ThreadConfig* config) {
+    if (!G) return;
+    const int tid = config->getThreadId();
+    auto emit = [&](int t) {
+        if (sp->mLeftWriter) sp->mLeftWriter->input(t, take(t, FASTP_GPU_OUT1));
+        if (sp->mFailedWriter) sp->mFailedWriter->input(t, take(t, FASTP_GPU_FAILED));
+    };
+    auto recycle = [&](Pending& pd) {
+        for (int i = 0; i < pd.left->count; i++) sp->recycleToPool(tid, pd.left->data[i]);
+        delete[] pd.left->data;
+        delete pd.left;
+    };
+    G->total_packs.store((long)sp->mPackReadCounter, std::memory_order_release);
+    while (!T.pending.empty()) {
+        pump();
+        if (!drain_ready(tid, emit, recycle)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    pump();
+}
+
+void fastp_gpu_worker_idle_se(SingleEndProcessor* sp, ThreadConfig* config) {
+    if (!G || T.pending.empty()) return;
+    const int tid = config->getThreadId();
+    auto emit = [&](int t) {
+        if (sp->mLeftWriter) sp->mLeftWriter->input(t, take(t, FASTP_GPU_OUT1));
+        if (sp->mFailedWriter) sp->mFailedWriter->input(t, take(t, FASTP_GPU_FAILED));
+    };
+    auto recycle = [&](Pending& pd) {
+        for (int i = 0; i < pd.left->count; i++) sp->recycleToPool(tid, pd.left->data[i]);
+        delete[] pd.left->data;
+        delete pd.left;
+    };
+    note_total_se(sp, config->getLeftInput());
+    pump();
+    drain_ready(tid, emit, recycle);
 }
 
 void fastp_gpu_worker_finish_pe(PairEndProcessor* pp, ThreadConfig** configs) {

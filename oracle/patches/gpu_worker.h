@@ -6,6 +6,7 @@
 // oracle/patches/apply_gpu_worker.py inserts one-line calls into copies of the reference's sources:
 //   src/peprocessor.cpp  top of PairEndProcessor::processPairEnd   -> fastp_gpu_worker_pe
 //   src/seprocessor.cpp  top of SingleEndProcessor::processSingleEnd -> fastp_gpu_worker_se
+//   both                 end of ::processorTask (before setConsumerFinished) -> fastp_gpu_worker_drain_pe / _se
 //   both                 before "merge stats" in ::process()        -> fastp_gpu_worker_finish_pe / _se
 //   src/evaluator.cpp    top of Evaluator::computeOverRepSeq         -> fastp_gpu_worker_overrep
 // The engine is used when the environment has FASTP_GPU=1; otherwise the hooks return "not handled" and the
@@ -20,11 +21,20 @@ class SingleEndProcessor;
 class ThreadConfig;
 struct ReadPack;
 
-// 1 = the pack was processed by the engine (outputs handed to the writers, packs freed); -1 = not handled: run the
-// reference's own loop body on this pack (engine disabled, or a read the packer refuses: letters outside ACGTN,
-// quality characters outside '!'..'~', a read longer than the evaluated read length)
+// 1 = the pack was taken by the engine (packed into the current window of packs; its outputs reach the writers when the
+// window's records arrive - gpu_worker.cpp); -1 = engine disabled: run the reference's own loop body on this pack.
+// A read the packer refuses (letters outside ACGTN, quality characters outside '!'..'~', longer than the evaluated
+// read length) stops the run with a message.
 int fastp_gpu_worker_pe(PairEndProcessor* p, ReadPack* left, ReadPack* right, ThreadConfig* config);
 int fastp_gpu_worker_se(SingleEndProcessor* p, ReadPack* pack, ThreadConfig* config);
+// at the end of processorTask (before the consumer side of the input lists is closed and, for the last thread, the
+// writers are told the input is complete): the packs this thread has handed to the engine and not yet got back
+void fastp_gpu_worker_drain_pe(PairEndProcessor* p, ThreadConfig* config);
+void fastp_gpu_worker_drain_se(SingleEndProcessor* p, ThreadConfig* config);
+// in processorTask's idle branch (no pack to consume): a thread with nothing to do still hands out the packs whose
+// records have arrived - the window slots are freed by the LAST thread to do so
+void fastp_gpu_worker_idle_pe(PairEndProcessor* p, ThreadConfig* config);
+void fastp_gpu_worker_idle_se(SingleEndProcessor* p, ThreadConfig* config);
 // load the engine's counter block into the worker threads' Stats / FilterResult objects, Duplicate's totals and
 // the insert-size histogram, right before the reference merges them and writes its reports
 void fastp_gpu_worker_finish_pe(PairEndProcessor* p, ThreadConfig** configs);

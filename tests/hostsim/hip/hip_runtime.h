@@ -128,7 +128,7 @@ template <class T> static inline bool __hip_atomic_compare_exchange_strong(T* p,
 
 // ---- the sliver of the HIP runtime API that fastp_gpu.hip calls -------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef struct sim_stream* hipStream_t;
 typedef struct sim_event* hipEvent_t;
 enum { hipStreamNonBlocking = 1 };
@@ -145,6 +145,9 @@ hipError_t hipSetDevice(int);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t bytes);
+hipError_t hipHostFree(void* p);
+hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);

@@ -61,11 +61,11 @@ def _ensure_built():
     return os.path.exists(REF)
 
 
-def _run(binary, tmp, tag, flags, paired, gpu_env):
+def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1):
     out = os.path.join(tmp, tag)
     os.makedirs(out, exist_ok=True)
     cmd = [binary, "-i", os.path.join(tmp, "in1.fq"), "-o", os.path.join(out, "o1.fq"), "-j", os.path.join(out, "r.json"),
-           "-h", os.path.join(out, "r.html"), "-w", "1", "--failed_out", os.path.join(out, "failed.fq")]
+           "-h", os.path.join(out, "r.html"), "-w", str(threads), "--failed_out", os.path.join(out, "failed.fq")]
     if paired:
         cmd += ["-I", os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2.fq")]
     cmd += [x.replace("@TMP@", out) for x in flags]
@@ -98,7 +98,7 @@ def _diff(x, y, path, out):
         out.append(f"{path}: reference {x!r} binding {y!r}")
 
 
-def _check(name, binary, n, tmp_path, seed):
+def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None):
     paired, flags, pf, skw = cases.CASES[name]
     flags = list(flags) + BINDING_CASES[name]
     tmp = str(tmp_path)
@@ -114,7 +114,8 @@ def _check(name, binary, n, tmp_path, seed):
             with open(os.path.join(tmp, tag, fn), "wb") as f:
                 f.write(content)
     want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {})
-    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"})
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, dict({"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}, **(extra_env or {})),
+                              threads=threads)
     err = got_rep.pop("__stderr__")
     want_rep.pop("__stderr__")
     if "overrep" in name:   # -p: the Evaluator's substring census ran on the device too (fastp_gpu_eval_overrep)
@@ -135,6 +136,16 @@ def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
     _check(name, REF_SIM, 600, tmp_path, seed=41)
+
+
+@pytest.mark.parametrize("name,threads,packs", [("pe_default", 3, 2), ("se_default_noadapter", 2, 1), ("pe_correction", 2, 3)])
+def test_patched_reference_pipelines_windows_of_packs(name, threads, packs, tmp_path):
+    """several worker threads, windows of FASTP_GPU_PACKS packs, more windows than slots in flight: the binding packs
+    the threads' packs into windows in STREAM order, so the outputs and the whole report equal `fastp_ref -w 1`
+    whatever the thread count (duplicates and insert sizes included)"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 9300, tmp_path, seed=43, threads=threads, extra_env={"FASTP_GPU_PACKS": str(packs)})
 
 
 @pytest.mark.gpu

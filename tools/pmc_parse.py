@@ -7,7 +7,7 @@ agg = collections.defaultdict(list)
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof", tag + "_sq*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith(prefix):
+            if r["Kernel_Name"].startswith(prefix) or (prefix in r["Kernel_Name"]):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     v = agg[k]

@@ -16,7 +16,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 stats = list(csv.DictReader(open(os.path.join(src, tag, "trace_kernel_stats.csv"))))
-ours = [r for r in stats if r["Name"].startswith("fq_")]
+ours = [r for r in stats if r["Name"].startswith("fq_") or "fq_lane_kernel" in r["Name"]]
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(stats[0].keys()))
     w.writeheader()
@@ -29,7 +29,7 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
 trace = list(csv.DictReader(open(os.path.join(src, tag, "trace_kernel_trace.csv"))))
 geom = {}
 for r in trace:
-    if r["Kernel_Name"].startswith("fq_") and r["Kernel_Name"] not in geom:
+    if (r["Kernel_Name"].startswith("fq_") or "fq_lane_kernel" in r["Kernel_Name"]) and r["Kernel_Name"] not in geom:
         geom[r["Kernel_Name"]] = {k: r[k] for k in ("LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count",
                                                     "SGPR_Count", "Workgroup_Size_X", "Grid_Size_X")}
 
@@ -40,7 +40,7 @@ for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if r["Kernel_Name"].startswith("fq_") and r["Counter_Name"] == counter:
+        if (r["Kernel_Name"].startswith("fq_") or "fq_lane_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         pmc.setdefault(k, {})[counter + "_KiB_avg"] = sum(v) / len(v)
@@ -68,18 +68,19 @@ for extra in ("bench.log", "phase.log"):
         if lines:
             out[extra] = lines[-1]
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-# what bench.py reports as roofline.traffic (HBM bytes per launch of the dominant kernel, PMC-derived)
-fk = out["kernels"].get("fq_fused_kernel", {})
-if "hbm_bytes_per_launch" in fk:
+# what bench.py reports as roofline.traffic: HBM bytes per launch of the kernels that run the worker loop (the fused
+# kernel, or the per-read kernel + the Stats kernel of the split / lane plan), PMC-derived
+main = [k for k in out["kernels"] if k == "fq_fused_kernel" or k.startswith("fq_scan") or "fq_lane_kernel" in k or k == "fq_stats_kernel"]
+main = [k for k in main if "hbm_bytes_per_launch" in out["kernels"][k]]
+if main:
     ppl = None
     try:
         ppl = json.loads(out.get("bench.log", "{}"))["roofline"]["pairs_per_launch"]
     except Exception:
         pass
-    json.dump({"tag": tag, "kernel": "fq_fused_kernel", "pairs_per_launch": ppl,
-               "hbm_read_bytes_per_launch": fk["hbm_read_bytes_per_launch"],
-               "hbm_write_bytes_per_launch": fk["hbm_write_bytes_per_launch"],
-               "hbm_bytes_per_launch": fk["hbm_bytes_per_launch"],
+    tot = {f: sum(out["kernels"][k][f] for k in main) for f in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch")}
+    json.dump({"tag": tag, "kernel": " + ".join(main), "pairs_per_launch": ppl, **tot,
+               "per_kernel": {k: {f: out["kernels"][k][f] for f in tot} for k in main},
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE x2 (gfx950 halves wide reads)"},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
