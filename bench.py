@@ -394,25 +394,40 @@ def main():
     # Stats::merge / FilterResult::merge across the GPUs: one all-reduce of the counter block (RCCL either way)
     merge_how = "n/a"
     if dist is not None:
-        # default: torch.distributed (the path the two-rank tests cover).  BENCH_ALLREDUCE=cabi takes the C ABI's own
-        # fastp_gpu_allreduce: exercised on one rank only by the builder (no multi-GPU box), so it is opt-in - a native
-        # collective that hangs cannot be recovered from inside a timed run
-        use_cabi = backend == "nccl" and os.environ.get("BENCH_ALLREDUCE", "torch") == "cabi"
+        # default: the C ABI's own collective (fastp_gpu_comm_init + fastp_gpu_allreduce: RCCL behind the drop-in boundary,
+        # what a patched fastp would call), set up and rehearsed OUTSIDE the timed region under a watchdog - a native
+        # collective that hangs cannot be interrupted, so the rehearsal runs on a helper thread and every rank votes;
+        # any failure or timeout on any rank -> all ranks use torch.distributed's all_reduce (RCCL as well) instead.
+        # BENCH_ALLREDUCE=torch skips the attempt.
+        use_cabi = backend == "nccl" and os.environ.get("BENCH_ALLREDUCE", "cabi") == "cabi"
         cerr = None
         if use_cabi:
-            try:
-                ids = [eng.comm_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                eng.comm_init(ids[0], world, rank)
-                eng.allreduce()                      # communicator set-up stays outside the timed region
-            except Exception as e:
-                cerr = e
+            import threading
+            box = {}
+
+            def rehearse():
+                try:
+                    ids = [eng.comm_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    eng.comm_init(ids[0], world, rank)
+                    eng.allreduce()
+                    box["ok"] = True
+                except Exception as e:   # noqa: BLE001
+                    box["err"] = e
+            th = threading.Thread(target=rehearse, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("BENCH_CABI_TIMEOUT", "90")))
+            if th.is_alive():
+                cerr = TimeoutError("fastp_gpu_allreduce rehearsal did not return")
+            elif "err" in box:
+                cerr = box["err"]
             if agree(cerr is not None):
                 print(f"[bench] fastp_gpu_allreduce unavailable on rank {rank} ({cerr!r}); using torch.distributed", file=sys.stderr, flush=True)
                 use_cabi = False
         if not use_cabi:
             multigpu.allreduce_counters_device(eng, dist, dev)
-        merge_how = "fastp_gpu_allreduce (RCCL, C ABI)" if use_cabi else f"torch.distributed all_reduce ({backend})"
+        merge_how = "fastp_gpu_allreduce (RCCL, C ABI)" if use_cabi else \
+                    f"torch.distributed all_reduce ({backend})" + (f"; C ABI attempt failed: {type(cerr).__name__}" if cerr else "")
 
     def merge_counters():
         if dist is None:

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -44,8 +45,10 @@ thread_local std::string t_err;
 
 bool load_rccl() {
     if (g_rccl.handle) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // FASTP_GPU_RCCL_LIB names the library explicitly (a site's own build; the test suite's in-process stand-in)
+    const char* names[] = {getenv("FASTP_GPU_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
+        if (!n || !*n) continue;
         g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.handle) break;
     }
@@ -91,6 +94,15 @@ int fail(int code, const std::string& msg) {
         hipError_t e_ = (call);                                                                          \
         if (e_ != hipSuccess) return fail(FASTP_GPU_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// ncclGroupStart ... ncclGroupEnd with the end guaranteed on every exit path (an open group would swallow the
+// process's next collective)
+struct Group {
+    bool open = false;
+    ncclResult_t start() { const ncclResult_t r = g_rccl.GroupStart(); open = r == ncclSuccess; return r; }
+    ncclResult_t end() { open = false; return g_rccl.GroupEnd(); }
+    ~Group() { if (open) (void)g_rccl.GroupEnd(); }
+};
 
 void drop_comm(fastp_gpu_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -142,7 +154,10 @@ int fastp_gpu_comm_init(fastp_gpu_ctx* ctx, const uint8_t id[FASTP_GPU_COMM_ID_B
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     NCCL_TRY(g_rccl.CommInitRank(&c.comm, nranks, u, rank));
-    HIPC_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)g_rccl.CommDestroy(c.comm);
+        return fail(FASTP_GPU_E_HIP, "hipStreamCreateWithFlags failed");
+    }
     g_comms[ctx] = c;
     fastp_gpu_comm_destroy_hook = drop_comm;
     return FASTP_GPU_OK;
@@ -182,13 +197,20 @@ void fastp_gpu_comm_destroy(fastp_gpu_ctx* ctx) { drop_comm(ctx); }
 // words are restored).  ctxs = the contexts THIS process owns (1 with one process per GPU).
 int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n) {
     if (!ctxs || n < 1) return fail(FASTP_GPU_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(g_mu);
+    // g_mu guards the context -> communicator map only: the collectives below block on the other ranks, and a process
+    // that drives its ranks from separate threads (each calling with n = 1) must not serialise them behind one mutex.
+    // A context's communicator is used by one call at a time (the caller's contract, as for every fastp_gpu_* call).
     std::vector<Comm*> cs(n);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (int i = 0; i < n; i++) {
+            cs[i] = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
+            if (!cs[i]) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
+        }
+    }
     std::vector<int64_t*> ptr(n);
     std::vector<int64_t> cnt(n);
     for (int i = 0; i < n; i++) {
-        cs[i] = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
-        if (!cs[i]) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
         int rc = fastp_gpu_synchronize(ctxs[i]);   // every launch and slab fold of this context is complete
         if (rc) return fail(rc, fastp_gpu_last_error(ctxs[i]));
         rc = fastp_gpu_counters_device(ctxs[i], &ptr[i], &cnt[i], nullptr);
@@ -199,12 +221,15 @@ int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n) {
     int64_t hdr[4];
     HIPC_TRY(hipSetDevice(cs[0]->device));
     HIPC_TRY(hipMemcpy(hdr, ptr[0], sizeof(hdr), hipMemcpyDeviceToHost));
-    if (n > 1) NCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < n; i++) {
-        HIPC_TRY(hipSetDevice(cs[i]->device));
-        NCCL_TRY(g_rccl.AllReduce(ptr[i], ptr[i], (size_t)cnt[i], ncclInt64, ncclSum, cs[i]->comm, cs[i]->stream));
+    {
+        Group grp;
+        if (n > 1) NCCL_TRY(grp.start());
+        for (int i = 0; i < n; i++) {
+            HIPC_TRY(hipSetDevice(cs[i]->device));
+            NCCL_TRY(g_rccl.AllReduce(ptr[i], ptr[i], (size_t)cnt[i], ncclInt64, ncclSum, cs[i]->comm, cs[i]->stream));
+        }
+        if (n > 1) NCCL_TRY(grp.end());
     }
-    if (n > 1) NCCL_TRY(g_rccl.GroupEnd());
     for (int i = 0; i < n; i++) {
         HIPC_TRY(hipSetDevice(cs[i]->device));
         HIPC_TRY(hipMemcpyAsync(ptr[i], hdr, sizeof(hdr), hipMemcpyHostToDevice, cs[i]->stream));
@@ -220,12 +245,16 @@ int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n) {
 // the links per rank instead of the N-1 of an all-gather.
 int fastp_gpu_exchange_dup_prefix(fastp_gpu_ctx* const* ctxs, int n) {
     if (!ctxs || n < 1) return fail(FASTP_GPU_E_INVALID, "bad argument");
-    std::lock_guard<std::mutex> lk(g_mu);
     std::vector<Comm*> cs(n);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (int i = 0; i < n; i++) {
+            cs[i] = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
+            if (!cs[i]) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
+        }
+    }
     int64_t bytes = 0;
     for (int i = 0; i < n; i++) {
-        cs[i] = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
-        if (!cs[i]) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
         const int64_t b = fastp_gpu_dup_bitmap_bytes(ctxs[i]);
         if (i && b != bytes) return fail(FASTP_GPU_E_INVALID, "contexts with different duplicate geometry");
         bytes = b;
@@ -255,18 +284,21 @@ int fastp_gpu_exchange_dup_prefix(fastp_gpu_ctx* const* ctxs, int n) {
         if (rc) return fail(rc, fastp_gpu_last_error(ctxs[i]));
     }
     auto all_to_all = [&](bool back) -> int {
-        NCCL_TRY(g_rccl.GroupStart());
-        for (int i = 0; i < n; i++) {
-            Comm& c = *cs[i];
-            HIPC_TRY(hipSetDevice(c.device));
-            const char* src = (const char*)(back ? c.slices : c.images);
-            char* dst = (char*)(back ? c.images : c.slices);
-            for (int peer = 0; peer < W; peer++) {
-                NCCL_TRY(g_rccl.Send(src + (size_t)peer * slice, (size_t)slice, ncclUint8, peer, c.comm, c.stream));
-                NCCL_TRY(g_rccl.Recv(dst + (size_t)peer * slice, (size_t)slice, ncclUint8, peer, c.comm, c.stream));
+        {
+            Group grp;
+            NCCL_TRY(grp.start());
+            for (int i = 0; i < n; i++) {
+                Comm& c = *cs[i];
+                HIPC_TRY(hipSetDevice(c.device));
+                const char* src = (const char*)(back ? c.slices : c.images);
+                char* dst = (char*)(back ? c.images : c.slices);
+                for (int peer = 0; peer < W; peer++) {
+                    NCCL_TRY(g_rccl.Send(src + (size_t)peer * slice, (size_t)slice, ncclUint8, peer, c.comm, c.stream));
+                    NCCL_TRY(g_rccl.Recv(dst + (size_t)peer * slice, (size_t)slice, ncclUint8, peer, c.comm, c.stream));
+                }
             }
+            NCCL_TRY(grp.end());
         }
-        NCCL_TRY(g_rccl.GroupEnd());
         for (int i = 0; i < n; i++) {
             HIPC_TRY(hipSetDevice(cs[i]->device));
             HIPC_TRY(hipStreamSynchronize(cs[i]->stream));

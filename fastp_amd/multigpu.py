@@ -43,7 +43,7 @@ def allreduce_counters_device(engine, dist, device) -> None:
     buf = torch.empty(engine.layout.total, dtype=torch.int64, device=device)
     engine.counters_export(buf.data_ptr())
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    torch.cuda.synchronize(device)
+    _device_sync(buf)
     engine.counters_import(buf.data_ptr())
 
 
@@ -59,11 +59,12 @@ def _all_gather_flat(dist, mine, world):
 
 
 def _device_sync(t):
-    """RCCL work is enqueued on the process group's own stream and the engine launches on ITS own stream:
-    a collective's output must be complete before an engine call reads it"""
+    """RCCL work is enqueued on the process group's own stream, which torch's current stream is made to wait for, and the
+    engine launches on ITS own stream: a collective's output must be complete before an engine call reads it.  Waiting
+    for torch's current stream (an event behind the collective) is enough - no device-wide synchronisation."""
     if t.is_cuda:
         import torch
-        torch.cuda.synchronize(t.device)
+        torch.cuda.current_stream(t.device).synchronize()
 
 
 def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False, scans=None):
@@ -114,14 +115,12 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
             dist.all_to_all_single(src, back)                   # src[s] = my prefix, slice s  -> the whole prefix image
             _device_sync(src)
             prefix = src.to(device) if staged else src
-            if prefix.is_cuda:
-                torch.cuda.synchronize(device)
+            _device_sync(prefix)
             engine.dup_prefix_set(prefix.data_ptr(), 1)
             del slices, back, prefix, src
         else:
             images = _all_gather_flat(dist, mine, world)
-            if images.is_cuda:
-                torch.cuda.synchronize(device)
+            _device_sync(images)
             engine.dup_prefix_set(images.data_ptr(), rank)
             del images
         del mine

@@ -217,10 +217,13 @@ void make_state(Options* o, bool paired) {
         if (fastp_gpu_host_create(&p, &ho, &h) != FASTP_GPU_OK) error_exit("fastp_gpu_host_create failed");
         s->hosts.push_back(h);
     }
-    // the windows: K packs each (FASTP_GPU_PACKS, default 256 = 256 K units: the copy of a window takes ~2 ms, its kernels
-    // well under 1 ms; a window is complete after K / W packs per thread)
+    // the windows: K packs each (FASTP_GPU_PACKS).  K = PACK_IN_MEM_LIMIT / 2 (16): the reader thread pauses whenever a
+    // WriterThread holds more than that many strings (peprocessor.cpp:842-849), and a window's outputs reach the writers
+    // in one burst - with 256-pack windows the reader sat out the writer's drain after every window and the run was
+    // slower than the CPU loop (profiles/r03_dropin_first.txt); 16 beat 32 and 64 at every thread count (r03_dropin.txt).
+    // 16 K pairs per batch still take the engine ~0.1 ms.
     s->W = std::max(1, o->thread);
-    s->K = 256;
+    s->K = PACK_IN_MEM_LIMIT / 2;
     if (const char* v = getenv("FASTP_GPU_PACKS")) s->K = std::max(1, atoi(v));
     s->ss = fastp_gpu_seq_stride(s->max_len);
     s->qs = fastp_gpu_qual_stride(s->max_len);

@@ -861,3 +861,146 @@ def test_gpu_file_pipeline_all_streams_and_gzip_outputs(name, tmp_path):
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))
+@pytest.mark.gpu
+def test_gpu_equals_oracle_at_scale_config1_single_end():
+    """BASELINE configs[1] (SE 1x150, sliding-window quality trim + polyG only: `-A -g --cut_right`) on 2 Mi synthetic
+    reads against the ORACLE: every record, every counter, every duplicate decision (chunked oracle for the per-read
+    part, oraclelib.sequential_duplicates for the stream-ordered part - the harness of the configs[2] test)."""
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    sys.path.insert(0, os.path.join(engines.ROOT, "tools"))
+    import synth_torch
+    total = int(os.environ.get("FASTP_SCALE_READS", str(2 * 1024 * 1024)))
+    chunk = 256 * 1024
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.poly_g = 1
+    p.cut_right = 1
+    dev = torch.device("cuda", 0)
+    g = engines.gpu_engine(p)
+    parts, recs = [], []
+    for k, start in enumerate(range(0, total, 1024 * 1024)):
+        n = min(1024 * 1024, total - start)
+        d = synth_torch.synth_pairs_torch(n, L=150, seed=7100 + k, device=dev)
+        s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], 150)
+        r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        nc = torch.zeros(1, dtype=torch.int32, device=dev)
+        b = abi.Batch()
+        b.n, b.flags = n, 0
+        b.seq1, b.qual1, b.len1 = s1.data_ptr(), q1.data_ptr(), l1.data_ptr()
+        res = abi.Results()
+        res.r1 = r1.data_ptr()
+        res.corrections, res.corrections_capacity, res.n_corrections = None, 0, nc.data_ptr()
+        torch.cuda.synchronize(dev)
+        g.submit_device(b, res)
+        g.synchronize()
+        recs.append(r1.cpu().numpy().view(abi.READ_RESULT_DTYPE))
+        pad = lambda a: np.pad(a.cpu().numpy(), ((0, 0), (0, 2)))
+        parts.append({"seq1": pad(d["seq1"]), "qual1": pad(d["qual1"]), "len1": d["len1"].cpu().numpy().astype(np.int32)})
+        del d, s1, q1, l1
+    assert g.plan() == "lane"
+    cg = g.counters()
+    lay = g.layout
+    g.close()
+    rg = np.concatenate(recs)
+    full = {kk: np.concatenate([pt[kk] for pt in parts]) for kk in parts[0]}
+    del parts, recs
+
+    def oracle_chunk(lo):
+        hi = min(total, lo + chunk)
+        o = oraclelib.Oracle(p)
+        r = o.process(full["seq1"][lo:hi], full["qual1"][lo:hi], full["len1"][lo:hi], corr_capacity=16)
+        c = o.counters()
+        o.close()
+        return r[0], c
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        outs = list(ex.map(oracle_chunk, range(0, total, chunk)))
+    co = np.zeros_like(cg)
+    for _, c in outs:
+        co += c
+    co[:4] = outs[0][1][:4]
+    dup = oraclelib.sequential_duplicates(p.dup_accuracy_level, full["seq1"], full["len1"], None, None)
+    ro = np.concatenate([o[0] for o in outs])
+    ro["flags"] = (ro["flags"] & ~np.uint8(abi.RF_DUP)) | np.where(dup, abi.RF_DUP, 0).astype(np.uint8)
+    bad = np.nonzero(ro != rg)[0]
+    assert len(bad) == 0, f"records differ at {len(bad)} of {total}, first {bad[:5]}: oracle {ro[bad[:3]]} gpu {rg[bad[:3]]}"
+    assert int((rg["flags"] & abi.RF_POLYX).sum()) == 0 and int((ro["len"] < full["len1"]).sum()) > total // 10   # the trims do happen
+    co[lay.dup_count] = int(dup.sum())
+    bad = np.nonzero(co != cg)[0]
+    assert len(bad) == 0, f"{len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_at_scale_config4_dedup_overrep():
+    """BASELINE configs[4]'s options (PE 2x250, --dedup, overrepresentation analysis with the Evaluator's seeds) on 1 Mi
+    synthetic pairs against the ORACLE run over the whole stream on one thread (the duplicate decision feeds the
+    routing and the sampling positions are stream positions: nothing here can be chunked): records + every counter."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(engines.ROOT, "tools"))
+    import synth_torch
+    import evalport
+    total = int(os.environ.get("FASTP_SCALE_PAIRS4", str(1024 * 1024)))
+    L = 250
+    p = abi.default_params(True, L)
+    p.cut_right = 1
+    p.dedup = 1
+    dsmall = synth_torch.synth_pairs_torch(20000, L=L, seed=5, device="cpu")
+    pad6 = lambda a: np.pad(a.numpy(), ((0, 0), (0, 6)))
+    b1 = cases._ArrayBatch(pad6(dsmall["seq1"]), dsmall["len1"].numpy())
+    b2 = cases._ArrayBatch(pad6(dsmall["seq2"]), dsmall["len2"].numpy())
+    e1, e2 = evalport.evaluate_seq_len(b1), evalport.evaluate_seq_len(b2)
+    abi.set_overrep(p, evalport.evaluate_overrep_seqs(b1, e1), evalport.evaluate_overrep_seqs(b2, e2), e1, e2, 20)
+    assert p.n_overrep_seqs1 > 0
+    dev = torch.device("cuda", 0)
+    g = engines.gpu_engine(p)
+    parts, recs = [], []
+    step = 256 * 1024
+    for k, start in enumerate(range(0, total, step)):
+        n = min(step, total - start)
+        d = synth_torch.synth_pairs_torch(n, L=L, seed=7200 + k, device=dev, dup_frac=0.2) if "dup_frac" in synth_torch.synth_pairs_torch.__code__.co_varnames \
+            else synth_torch.synth_pairs_torch(n, L=L, seed=7200 + (k % 3), device=dev)   # repeated seeds: duplicates across batches
+        s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], L)
+        s2, q2, l2 = synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], L)
+        r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        r2 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
+        pr = torch.zeros(n * 8, dtype=torch.uint8, device=dev)
+        nc = torch.zeros(1, dtype=torch.int32, device=dev)
+        b = abi.Batch()
+        b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+        b.seq1, b.qual1, b.len1 = s1.data_ptr(), q1.data_ptr(), l1.data_ptr()
+        b.seq2, b.qual2, b.len2 = s2.data_ptr(), q2.data_ptr(), l2.data_ptr()
+        res = abi.Results()
+        res.r1, res.r2, res.pair = r1.data_ptr(), r2.data_ptr(), pr.data_ptr()
+        res.corrections, res.corrections_capacity, res.n_corrections = None, 0, nc.data_ptr()
+        torch.cuda.synchronize(dev)
+        g.submit_device(b, res)
+        g.synchronize()
+        recs.append((r1.cpu().numpy().view(abi.READ_RESULT_DTYPE), r2.cpu().numpy().view(abi.READ_RESULT_DTYPE),
+                     pr.cpu().numpy().view(abi.PAIR_RESULT_DTYPE)))
+        pad = lambda a: np.pad(a.cpu().numpy(), ((0, 0), (0, 6)))
+        parts.append({kk: (pad(d[kk]) if kk[0] in "sq" else d[kk].cpu().numpy().astype(np.int32)) for kk in
+                      ("seq1", "qual1", "len1", "seq2", "qual2", "len2")})
+        del d, s1, q1, l1, s2, q2, l2
+    cg = g.counters()
+    g.close()
+    rg = [np.concatenate([r[k] for r in recs]) for k in range(3)]
+    full = {kk: np.concatenate([pt[kk] for pt in parts]) for kk in parts[0]}
+    del parts, recs
+    o = oraclelib.Oracle(p)
+    ro = o.process(full["seq1"], full["qual1"], full["len1"], full["seq2"], full["qual2"], full["len2"], corr_capacity=16)
+    co = o.counters()
+    lay = o.layout
+    o.close()
+    assert int((ro[0]["flags"] & abi.RF_DUP != 0).sum()) > total // 100, "the input must hold duplicates for --dedup to matter"
+    for k, what in enumerate(("read1 results", "read2 results", "pair results")):
+        bad = np.nonzero(ro[k] != rg[k])[0]
+        assert len(bad) == 0, f"{what} differ at {len(bad)} of {total}, first {bad[:5]}: oracle {ro[k][bad[:3]]} gpu {rg[k][bad[:3]]}"
+    bad = np.nonzero(co != cg)[0]
+    assert len(bad) == 0, f"{len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
+    assert int(co[lay.overrep_count[0]:lay.overrep_count[0] + lay.n_overrep[0]].sum()) > 0, "the overrepresentation counters must move"
+
+
