@@ -3,7 +3,7 @@
 
     apply_gpu_worker.py <reference root> <output dir>
 
-Writes <output dir>/peprocessor.cpp, seprocessor.cpp and evaluator.cpp: the reference's files with nine one-line insertions,
+Writes <output dir>/peprocessor.cpp, seprocessor.cpp and evaluator.cpp: the reference's files with ten one-line insertions,
 each placed by an anchor (the function signature / the comment that opens the merge of the per-thread results).
 Nothing else of the reference is touched or reproduced here; every other source is compiled where it lies.
 """
@@ -50,5 +50,7 @@ patch("seprocessor.cpp", [
 patch("evaluator.cpp", [
     (r"void Evaluator::computeOverRepSeq\(string filename, map<string, long>& hotseqs, int seqlen\)\s*\{",
      "\n    if(fastp_gpu_worker_overrep(filename, hotseqs, seqlen) > 0) return;   // counted on the device (FASTP_GPU=1)\n", "after"),
+    (r"for\(int i=0; i<records; i\+\+\) \{\s*Read\* r = loadedReads\[i\];\s*const char\* data = r->mSeq->c_str\(\);\s*int key = -1;",
+     "if(fastp_gpu_worker_adapter_kmers(this, loadedReads, records, shiftTail, counts) < 0)   // else: counted on the device (FASTP_GPU=1)\n    ", "before"),
 ])
 print("patched peprocessor.cpp, seprocessor.cpp, evaluator.cpp ->", out)

@@ -45,6 +45,7 @@
 #include "src/read.h"
 #include "src/util.h"
 #include "src/fastqreader.h"
+#include "src/evaluator.h"
 #undef private
 #undef protected
 
@@ -777,5 +778,70 @@ int fastp_gpu_worker_overrep(const std::string& filename, std::map<std::string, 
     hotseqs.clear();
     for (int i = 0; i < n_seqs; i++) hotseqs[std::string(text.data() + off[i], (size_t)(off[i + 1] - off[i]))] = (long)cnt[i];
     if (getenv("FASTP_GPU_VERBOSE")) fprintf(stderr, "fastp_gpu: computeOverRepSeq on the device: %d reads, %d sequences\n", n, (int)n_seqs);
+    return 1;
+}
+
+// The 4^10 ten-mer histogram of Evaluator::evalAdapterAndReadNum (evaluator.cpp:384-396) through
+// fastp_gpu_eval_adapter_kmers: the reads are the ones the reference's own loading loop admitted (:326-341), the
+// top-10 selection and the NucleotideTree walks that follow stay the reference's.  1 = counts filled, -1 = not handled
+// (engine disabled, or a letter outside ACGTN: the reference's loop counts then).
+int fastp_gpu_worker_adapter_kmers(Evaluator* ev, Read** reads, long records, int shiftTail, unsigned int* counts) {
+    if (!enabled() || records <= 0 || records > (1 << 30)) return -1;
+    const int n = (int)records;
+    int max_len = 1;
+    for (int i = 0; i < n; i++) max_len = std::max(max_len, reads[i]->length());
+    if (max_len > 65535) return -1;
+    const size_t ss = fastp_gpu_seq_stride(max_len), qs = fastp_gpu_qual_stride(max_len);
+    std::vector<uint8_t> seq((size_t)n * ss), qual((size_t)n * qs);
+    std::vector<uint16_t> len((size_t)n);
+    {
+        std::vector<const char*> sp((size_t)n), qp((size_t)n);
+        std::vector<int32_t> ln((size_t)n);
+        for (int i = 0; i < n; i++) { sp[i] = reads[i]->mSeq->data(); qp[i] = reads[i]->mQuality->data(); ln[i] = reads[i]->length(); }
+        int32_t bad = -1;
+        if (fastp_gpu_pack_reads(max_len, n, sp.data(), qp.data(), ln.data(), seq.data(), qual.data(), len.data(), &bad) != FASTP_GPU_OK) return -1;
+    }
+    fastp_gpu_params prm;
+    fastp_gpu_default_params(&prm, 0, max_len);
+    prm.dup_enabled = 0;   // no bloom bitmaps for this short-lived context
+    fastp_gpu_ctx* ctx = nullptr;
+    if (fastp_gpu_create(&prm, 0, &ctx) != FASTP_GPU_OK) return -1;
+    void *d_seq = nullptr, *d_qual = nullptr, *d_len = nullptr, *d_cnt = nullptr;
+    const int64_t cnt_bytes = (int64_t)4 << 20;
+    int rc = fastp_gpu_device_alloc(ctx, (int64_t)seq.size(), &d_seq);
+    if (!rc) rc = fastp_gpu_device_alloc(ctx, (int64_t)qual.size(), &d_qual);
+    if (!rc) rc = fastp_gpu_device_alloc(ctx, (int64_t)len.size() * 2, &d_len);
+    if (!rc) rc = fastp_gpu_device_alloc(ctx, cnt_bytes, &d_cnt);
+    if (!rc) rc = fastp_gpu_device_upload(ctx, d_seq, seq.data(), (int64_t)seq.size());
+    if (!rc) rc = fastp_gpu_device_upload(ctx, d_qual, qual.data(), (int64_t)qual.size());
+    if (!rc) rc = fastp_gpu_device_upload(ctx, d_len, len.data(), (int64_t)len.size() * 2);
+    int64_t used = 0;
+    if (!rc) rc = fastp_gpu_eval_adapter_kmers(ctx, (const uint8_t*)d_seq, (const uint8_t*)d_qual, (const uint16_t*)d_len, n, shiftTail,
+                                               (uint32_t*)d_cnt, &used);
+    if (!rc && used != records) rc = FASTP_GPU_E_INVALID;   // the device admits exactly the reads the reference loaded
+    if (!rc) rc = fastp_gpu_device_download(ctx, counts, d_cnt, cnt_bytes);
+    fastp_gpu_device_free(ctx, d_seq);
+    fastp_gpu_device_free(ctx, d_qual);
+    fastp_gpu_device_free(ctx, d_len);
+    fastp_gpu_device_free(ctx, d_cnt);
+    fastp_gpu_destroy(ctx);
+    if (rc != FASTP_GPU_OK) return -1;
+    if (getenv("FASTP_GPU_VERBOSE")) fprintf(stderr, "fastp_gpu: evalAdapterAndReadNum's ten-mer histogram on the device: %d reads\n", n);
+    if (getenv("FASTP_GPU_EVAL_CHECK")) {   // tests: the reference's own counting loop (Evaluator::seq2int) beside it
+        std::vector<unsigned int> want((size_t)1 << 20, 0u);
+        for (int i = 0; i < n; i++) {
+            Read* r = reads[i];
+            int key = -1;
+            for (int pos = 20; pos <= r->length() - 10 - shiftTail; pos++) {
+                key = ev->seq2int(r->mSeq, pos, 10, key);
+                if (key >= 0) want[(size_t)key]++;
+            }
+        }
+        want[0] = 0;
+        size_t bad = 0, nonzero = 0;
+        for (size_t k = 0; k < want.size(); k++) { bad += want[k] != counts[k]; nonzero += want[k] != 0; }
+        fprintf(stderr, "fastp_gpu: ten-mer histogram check vs Evaluator::seq2int: %zu of %zu bins differ (%zu non-zero)\n", bad, want.size(), nonzero);
+        if (bad) error_exit("FASTP_GPU_EVAL_CHECK: the device histogram differs from the reference's counting loop");
+    }
     return 1;
 }

@@ -9,6 +9,7 @@
 //   both                 end of ::processorTask (before setConsumerFinished) -> fastp_gpu_worker_drain_pe / _se
 //   both                 before "merge stats" in ::process()        -> fastp_gpu_worker_finish_pe / _se
 //   src/evaluator.cpp    top of Evaluator::computeOverRepSeq         -> fastp_gpu_worker_overrep
+//   src/evaluator.cpp    in front of evalAdapterAndReadNum's counting loop -> fastp_gpu_worker_adapter_kmers
 // The engine is used when the environment has FASTP_GPU=1; otherwise the hooks return "not handled" and the
 // reference's own loop runs.
 #ifndef FASTP_GPU_WORKER_H
@@ -41,5 +42,11 @@ void fastp_gpu_worker_finish_pe(PairEndProcessor* p, ThreadConfig** configs);
 void fastp_gpu_worker_finish_se(SingleEndProcessor* p, ThreadConfig** configs);
 // Evaluator::computeOverRepSeq (-p) through fastp_gpu_eval_overrep: 1 = hotseqs filled by the engine, -1 = not handled
 int fastp_gpu_worker_overrep(const std::string& filename, std::map<std::string, long>& hotseqs, int seqlen);
+
+// Evaluator::evalAdapterAndReadNum's ten-mer histogram (evaluator.cpp:384-396) through fastp_gpu_eval_adapter_kmers:
+// 1 = counts filled by the engine, -1 = not handled (the reference's own counting loop runs)
+class Read;
+class Evaluator;
+int fastp_gpu_worker_adapter_kmers(Evaluator* ev, Read** reads, long records, int shiftTail, unsigned int* counts);
 
 #endif

@@ -995,7 +995,7 @@ def test_gpu_equals_oracle_at_scale_config4_dedup_overrep():
     co = o.counters()
     lay = o.layout
     o.close()
-    assert int((ro[0]["flags"] & abi.RF_DUP != 0).sum()) > total // 100, "the input must hold duplicates for --dedup to matter"
+    assert int(((ro[0]["flags"] & abi.RF_DUP) != 0).sum()) > total // 100, "the input must hold duplicates for --dedup to matter"
     for k, what in enumerate(("read1 results", "read2 results", "pair results")):
         bad = np.nonzero(ro[k] != rg[k])[0]
         assert len(bad) == 0, f"{what} differ at {len(bad)} of {total}, first {bad[:5]}: oracle {ro[k][bad[:3]]} gpu {rg[k][bad[:3]]}"

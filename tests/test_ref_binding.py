@@ -138,6 +138,51 @@ def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
     _check(name, REF_SIM, 600, tmp_path, seed=41)
 
 
+def _auto_adapter_check(binary, n, tmp_path):
+    """SE run with adapter auto-detection on reads that carry an adapter fastp does not know (so checkKnownAdapters does
+    not short-cut the k-mer path): the Evaluator's ten-mer histogram (evaluator.cpp:384-396) comes from
+    fastp_gpu_eval_adapter_kmers; it is compared bin by bin with the reference's own counting loop inside the binding
+    (FASTP_GPU_EVAL_CHECK), and the whole run that follows must equal the unpatched reference's"""
+    tmp = str(tmp_path)
+    custom = b"CTGACCTAGTCAAGGTCCATGCTAGGATCCATGCAAT"
+    old = synth.ADAPTER_R1
+    synth.ADAPTER_R1 = custom
+    try:
+        d = synth.synth_pairs(n, L=150, seed=47, paired=False, insert_mean=110.0, insert_sd=25.0, dup_frac=0.0)
+    finally:
+        synth.ADAPTER_R1 = old
+    with open(os.path.join(tmp, "in1.fq"), "wb") as f:
+        f.write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1))
+    flags = ["-G"]
+    want_files, want_rep = _run(REF, tmp, "ref", flags, False, {})
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, False, {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1", "FASTP_GPU_EVAL_CHECK": "1"})
+    err = got_rep.pop("__stderr__")
+    want_rep.pop("__stderr__")
+    assert "ten-mer histogram on the device" in err, err[-600:]
+    # FASTP_GPU_EVAL_CHECK: the binding also ran the reference's own counting loop (Evaluator::seq2int) and compared all 4^10 bins
+    import re
+    m = re.search(r"ten-mer histogram check vs Evaluator::seq2int: (\d+) of 1048576 bins differ \((\d+) non-zero\)", err)
+    assert m and int(m.group(1)) == 0 and int(m.group(2)) > 1000, err[-600:]
+    for fn in want_files:
+        assert want_files[fn] == got_files[fn], f"{fn} differs"
+    problems = []
+    _diff(want_rep, got_rep, "", problems)
+    assert not problems, "fastp's own JSON report differs:\n" + "\n".join(problems[:25])
+
+
+def test_patched_reference_auto_adapter_on_emulator(tmp_path):
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _auto_adapter_check(REF_SIM, 11000, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_patched_reference_auto_adapter(tmp_path):
+    if not (os.path.exists(REF) and os.path.exists(REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    _auto_adapter_check(REF_GPU, 60000, tmp_path)
+
+
 @pytest.mark.parametrize("name,threads,packs", [("pe_default", 3, 2), ("se_default_noadapter", 2, 1), ("pe_correction", 2, 3)])
 def test_patched_reference_pipelines_windows_of_packs(name, threads, packs, tmp_path):
     """several worker threads, windows of FASTP_GPU_PACKS packs, more windows than slots in flight: the binding packs
