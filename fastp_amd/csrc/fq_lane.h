@@ -18,6 +18,12 @@
 #pragma once
 #include "fq_device.h"
 
+#ifdef FQ_LANE_NO_FENCE      // A/B switch (tools/gpu_lane_ab3.sh)
+#define FQ_LANE_FENCE() ((void)0)
+#else
+#define FQ_LANE_FENCE() sched_fence()
+#endif
+
 namespace fq {
 
 // LDS of the lane kernel (dwords from the start of dynamic LDS)
@@ -285,7 +291,7 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
         if (win > 4) m = lane_window_word<true>(q, keep_lo, keep_hi, nthr);        // uniform
         else if (win > 0) m = lane_window_word<false>(q, keep_lo, keep_hi, nthr);
         r.bad[W] = m;
-        sched_fence();   // one mask word at a time: the scheduler would otherwise keep every word's dwords in flight
+        FQ_LANE_FENCE();   // one mask word at a time: the scheduler would otherwise keep every word's dwords in flight
     }
     if (anyn) r.flags |= RS_HAS_N;
 }
@@ -374,7 +380,7 @@ FQ_DEV void lane_scan(const u32 (&X)[SWM], u32 y0, int nvalid, u32 premask, u32 
             if (left < 16) cand = left <= 0 ? 0u : (cand & ~lowmask32(16 - left));
             cm[b >> 1] |= cand << (16 * (b & 1));
         }
-        sched_fence();
+        FQ_LANE_FENCE();
     }
 }
 // smallest candidate offset left in cm (removed from it), or -1

@@ -961,8 +961,15 @@ def test_gpu_equals_oracle_at_scale_config4_dedup_overrep():
     step = 256 * 1024
     for k, start in enumerate(range(0, total, step)):
         n = min(step, total - start)
-        d = synth_torch.synth_pairs_torch(n, L=L, seed=7200 + k, device=dev, dup_frac=0.2) if "dup_frac" in synth_torch.synth_pairs_torch.__code__.co_varnames \
-            else synth_torch.synth_pairs_torch(n, L=L, seed=7200 + (k % 3), device=dev)   # repeated seeds: duplicates across batches
+        d = synth_torch.synth_pairs_torch(n, L=L, seed=7200 + k, device=dev)
+        # exact duplicates (the synthesizer's share a fragment but not their sequencing errors): a fifth of the rows
+        # become copies of other rows of the batch
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(99 + k)
+        dst = torch.randperm(n, generator=gen, device=dev)[:n // 5]
+        src = torch.randint(0, n, (n // 5,), generator=gen, device=dev)
+        for kk in ("seq1", "qual1", "seq2", "qual2"):
+            d[kk][dst] = d[kk][src]
         s1, q1, l1 = synth_torch.pack_torch(d["seq1"], d["qual1"], d["len1"], L)
         s2, q2, l2 = synth_torch.pack_torch(d["seq2"], d["qual2"], d["len2"], L)
         r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
