@@ -65,7 +65,7 @@ class Params(C.Structure):
         ("eval_seq_len1", C.c_int32), ("eval_seq_len2", C.c_int32),
         ("n_overrep_seqs1", C.c_int32), ("n_overrep_seqs2", C.c_int32),
         ("overrep_seqs1", C.POINTER(C.c_char_p)), ("overrep_seqs2", C.POINTER(C.c_char_p)),
-        ("reserved", C.c_int32 * 4),
+        ("overlapped_out", C.c_int32), ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -189,6 +189,8 @@ class FormatOptions(C.Structure):
 
 
 N_OUTPUTS = 6  # FASTP_GPU_OUT1, OUT2, FAILED, MERGED, UNPAIRED1, UNPAIRED2
+OUT_OVERLAPPED = 6   # host glue only (FASTP_GPU_OVERLAPPED)
+OVOUT_HIT = 0x8000   # fastp_gpu_read_result.reserved of read 1 with overlapped_out
 
 
 class CounterLayout(C.Structure):

@@ -328,7 +328,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
-    if (!p.stats_one_pass || p.allow_gap || p.poly_x || p.n_fasta || p.has_a1 || p.has_a2 || p.complexity_filter) return false;
+    if (!p.stats_one_pass || p.allow_gap || p.poly_x || p.n_fasta || p.has_a1 || p.has_a2 || p.complexity_filter || p.overlapped_out) return false;
     if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
     if (p.cut_right && (p.wR < 1 || p.wR > 8)) return false;
     if (p.cut_tail && !p.cut_right && (p.wT < 1 || p.wT > 8)) return false;
@@ -1504,6 +1504,7 @@ extern "C" int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fas
     const bool paired = ctx->dp.paired != 0;
     if (paired != (m2 != nullptr)) return fail(ctx, FASTP_GPU_E_INVALID, "mate 2 must be given exactly for a paired engine");
     if (paired && !pair) return fail(ctx, FASTP_GPU_E_INVALID, "a paired engine needs the pair records");
+    if (ctx->dp.overlapped_out) return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "--overlapped_out's stream is written by the host glue (fastp_gpu_host.h)");
     FmtsArgs f;
     memset(&f, 0, sizeof(f));
     f.n = n;

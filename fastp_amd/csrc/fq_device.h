@@ -1085,7 +1085,7 @@ template <int DIR> FQ_DEV u32 ov_yn(const PairView& v, int t) { return DIR ? ov_
 template <int DIR>
 FQ_DEV int ov_verify(const PairView& v, int o, int lenX, int lenY, const short* lut) {
     const int ol = imin(lenX - o, lenY);
-    const int limit = lut[ol];
+    const int limit = lut ? lut[ol] : 0;   // no table: diffPercentLimit 0 (--overlapped_out's analysis, peprocessor.cpp:489)
     const int pre = imin(ol, 50);  // complete_compare_require (:28)
     int cnt_pre = 0, cnt_full = 0;
     for (int t = 0; t < ol; t += 16) {
@@ -1106,9 +1106,9 @@ FQ_DEV u32 ov_key(int dir, int o, int diff) {
 }
 // one offset that passed the prefilter: exact test, winner by atomic-min
 template <int DIR>
-FQ_DEV void overlap_check(const LdsLayout& L, u32* lds, const PairView& v, int pr, int o) {
+FQ_DEV void overlap_check(const LdsLayout& L, u32* lds, const PairView& v, int pr, int o, bool exact) {
     const int lenX = DIR ? v.l2 : v.l1, lenY = DIR ? v.l1 : v.l2;
-    const int diff = ov_verify<DIR>(v, o, lenX, lenY, (const short*)(lds + L.lut_ov));
+    const int diff = ov_verify<DIR>(v, o, lenX, lenY, exact ? nullptr : (const short*)(lds + L.lut_ov));
     if (diff >= 0) lds_min_u32((u32*)&lds_i(lds, L.ov_off)[pr], ov_key(DIR, o, diff));
 }
 
@@ -1118,7 +1118,7 @@ FQ_DEV void overlap_check(const LdsLayout& L, u32* lds, const PairView& v, int p
 // Survivors go to the tile's candidate list; pass 2 verifies them with every lane busy instead of one lane per
 // wavefront verifying while 63 wait.
 template <int DIR>
-FQ_DEV void overlap_scan(const KernelArgs& a, u32* lds, int pr, int part) {
+FQ_DEV void overlap_scan(const KernelArgs& a, u32* lds, int pr, int part, bool exact) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     const int R1 = pr, R2 = L.P + pr;
@@ -1132,7 +1132,7 @@ FQ_DEV void overlap_scan(const KernelArgs& a, u32* lds, int pr, int part) {
     const int npre = imin(16, imin(p.overlap_require + 1, lenY));
     const u32 premask = lowmask32(2 * npre) & 0x55555555u;
     const u32 y0 = ov_y<DIR>(v, 0);
-    const u32 nlim = (u32)(-(p.ov_limit_max + 1));
+    const u32 nlim = (u32)(-((exact ? 0 : p.ov_limit_max) + 1));
     const u32* xrow = DIR ? v.rc : v.s1;
     const int xoff = DIR ? v.z2 : v.f1;
     u32* cl = lds + L.cand;
@@ -1158,7 +1158,7 @@ FQ_DEV void overlap_scan(const KernelArgs& a, u32* lds, int pr, int part) {
             cand &= ~(0x8000u >> t);
             const u32 slot = lds_add_ret_u32(cl, 1u);
             if (slot < (u32)L.cand_cap) cl[1 + slot] = ((u32)pr << 11) | ((u32)DIR << 10) | (u32)(o0 + t);
-            else overlap_check<DIR>(L, lds, v, pr, o0 + t);  // list full (low-complexity reads): verify here
+            else overlap_check<DIR>(L, lds, v, pr, o0 + t, exact);  // list full (low-complexity reads): verify here
         }
     }
 }
@@ -1299,19 +1299,19 @@ FQ_DEV void phase_rc(const KernelArgs& a, u32* lds, int tid, int nthreads) {
     if (tid == 0) lds[L.cand] = 0;
 }
 
-FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) {
+FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads, bool exact = false) {
     const LdsLayout& L = a.L;
     const DevParams& p = a.p;
     if (!p.paired) return;
     const bool thread0 = (a.batch_flags & 1u) != 0;  // FASTP_GPU_BATCH_STAT_ISIZE
-    if (!(p.need_overlap || thread0 || p.merge)) return;  // peprocessor.cpp:438
+    if (!(p.need_overlap || thread0 || p.merge || exact)) return;  // peprocessor.cpp:438
     // tasks [0, 4P): forward, [4P, 8P): reverse -> the direction is uniform per wavefront when 4P % 64 == 0
     const int half = 4 * L.P;
     for (int t = tid; t < 2 * half; t += nthreads) {
         const int dir = t >= half ? 1 : 0;
         const int u = t - dir * half;
-        if (dir) overlap_scan<1>(a, lds, u >> 2, u & 3);
-        else overlap_scan<0>(a, lds, u >> 2, u & 3);
+        if (dir) overlap_scan<1>(a, lds, u >> 2, u & 3, exact);
+        else overlap_scan<0>(a, lds, u >> 2, u & 3, exact);
     }
     tile_sync(a, lds, nthreads);
     // pass 2: lane = candidate
@@ -1321,8 +1321,8 @@ FQ_DEV void phase_overlap(const KernelArgs& a, u32* lds, int tid, int nthreads) 
         const int pr = (int)(e >> 11), o = (int)(e & 0x3FFu);
         PairView v;
         pair_view(L, lds, pr, v);
-        if (e & 0x400u) overlap_check<1>(L, lds, v, pr, o);
-        else overlap_check<0>(L, lds, v, pr, o);
+        if (e & 0x400u) overlap_check<1>(L, lds, v, pr, o, exact);
+        else overlap_check<0>(L, lds, v, pr, o, exact);
     }
     tile_sync(a, lds, nthreads);
     if (tid == 0) lds[L.cand] = 0;   // ready for the next use (merge mode analyzes twice per tile)
@@ -1640,7 +1640,8 @@ FQ_DEV void write_read_result(const KernelArgs& a, u32* lds, int m, int R, int g
     const u32 alen = (u32)lds_i(lds, L.alen)[R] & 0xFFFFu;
     // reserved: merge mode, overlapped pair: bases of this mate in the merged read (the name tag merged_L1_L2)
     const int pr1 = m ? R - L.P : R;
-    const u32 rsv = (lds_i(lds, L.flags)[pr1] & RS_MERGE_OV) ? ((u32)lds_i(lds, L.mlen)[R] & 0xFFFFu) : 0u;
+    // --overlapped_out: read 1 carries 0x8000 | first printed position, read 2 the number of printed bases
+    const u32 rsv = ((lds_i(lds, L.flags)[pr1] & RS_MERGE_OV) || a.p.overlapped_out) ? ((u32)lds_i(lds, L.mlen)[R] & 0xFFFFu) : 0u;
     u32* out = a.res[m] + (size_t)gp * 3;
     out[0] = front | (len << 16);
     out[1] = code | (flags << 8) | (apos << 16);
@@ -1778,6 +1779,10 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             }
         }
         (void)isize_done;
+        if (p.overlapped_out) {  // the reads as --overlapped_out's analysis sees them (:488, before polyX and max_len)
+            lds_i(lds, L.mlen)[R1] = cur1;
+            lds_i(lds, L.mlen)[R2] = cur2;
+        }
         if (both && p.poly_x) {  // :506-509
             for (int k = 0; k < 2; k++) {
                 const int R = k ? R2 : R1;
@@ -1798,14 +1803,54 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             if (p.max_len2 > 0 && p.max_len2 < cur2) lenv[R2] = cur2 = p.max_len2;
         }
         if (dimer | isize_done) lds_or_i32(&flags[R1], (dimer ? RS_DIMER : 0) | (isize_done ? RS_ISIZE : 0));
-        lds_i(lds, L.mlen)[R1] = cur1;
-        lds_i(lds, L.mlen)[R2] = cur2;
+        if (!p.overlapped_out) {
+            lds_i(lds, L.mlen)[R1] = cur1;
+            lds_i(lds, L.mlen)[R2] = cur2;
+        }
         if (p.merge && both) {
             // merge mode analyzes the post-trim reads again (peprocessor.cpp:523); phase_merge writes the record
             lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;
         } else {
             write_pair_result(a, gp, ovl, ov_off, ov_len, ov_diff, isize_done);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// --overlapped_out (peprocessor.cpp:488-495): a third OverlapAnalysis::analyze with diffPercentLimit 0 on the reads
+// as they are right after adapter trimming.  What the reference prints for an overlapped pair is
+//   string(r1->mSeq->substr(max(0, offset)), overlap_len)   (:491)
+// - std::string's (str, pos) constructor, i.e. the bases of read 1 BEHIND the overlapped region,
+// r1'[max(0, offset) + overlap_len, len1').  phase_decide_pe left the post-adapter lengths in mlen[] (unused outside
+// merge mode, which excludes this option); the analysis runs on them, then the record's `reserved` fields take
+//   mlen[R1] = 0x8000 | pos (overlapped; pos = max(0, offset) + overlap_len) or 0, mlen[R2] = len1' - pos.
+// ---------------------------------------------------------------------------
+FQ_DEV void phase_ovout_begin(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    for (int pr = tid; pr < L.P; pr += nthreads) {
+        if (tile_first + pr >= a.n) continue;
+        for (int k = 0; k < 2; k++) {
+            const int R = k ? L.P + pr : pr;
+            const int fin = lds_i(lds, L.len)[R];
+            lds_i(lds, L.len)[R] = lds_i(lds, L.mlen)[R];
+            lds_i(lds, L.mlen)[R] = fin;
+        }
+        lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;
+    }
+}
+FQ_DEV void phase_ovout_end(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
+    const LdsLayout& L = a.L;
+    for (int pr = tid; pr < L.P; pr += nthreads) {
+        if (tile_first + pr >= a.n) continue;
+        const int R1 = pr, R2 = L.P + pr;
+        int ovl, off, ol, diff;
+        const int l1 = lds_i(lds, L.len)[R1];
+        decode_overlap((u32)lds_i(lds, L.ov_off)[pr], l1, lds_i(lds, L.len)[R2], ovl, off, ol, diff);
+        lds_i(lds, L.len)[R1] = lds_i(lds, L.mlen)[R1];
+        lds_i(lds, L.len)[R2] = lds_i(lds, L.mlen)[R2];
+        const int pos = imax(0, off) + ol;   // <= l1: string(substr(start), overlap_len) never throws
+        lds_i(lds, L.mlen)[R1] = ovl ? (0x8000 | pos) : 0;
+        lds_i(lds, L.mlen)[R2] = ovl ? l1 - pos : 0;
     }
 }
 
@@ -1912,6 +1957,8 @@ FQ_DEV void phase_filter_pe_plain(const KernelArgs& a, u32* lds, int tile_first,
         const u32 rl1 = (u32)lds_i(lds, L.rlen0)[R1], rl2 = (u32)lds_i(lds, L.rlen0)[R2];
         const u32 apos1 = (u32)lds_i(lds, L.apos)[R1], apos2 = (u32)lds_i(lds, L.apos)[R2];
         const u32 alen1 = (u32)lds_i(lds, L.alen)[R1], alen2 = (u32)lds_i(lds, L.alen)[R2];
+        const u32 rsv1 = p.overlapped_out ? (u32)lds_i(lds, L.mlen)[R1] & 0xFFFFu : 0u;   // phase_ovout_end
+        const u32 rsv2 = p.overlapped_out ? (u32)lds_i(lds, L.mlen)[R2] & 0xFFFFu : 0u;
         write_dup_pos(a, lds, pr, gp);   // LDS reads + global stores only
         const u16* lowq = (const u16*)(lds + L.lut_lowq);
         const u16* cmin = (const u16*)(lds + L.lut_cplx);
@@ -1939,10 +1986,10 @@ FQ_DEV void phase_filter_pe_plain(const KernelArgs& a, u32* lds, int tile_first,
         u32* o2 = a.res[1] + (size_t)gp * 3;
         o1[0] = (front1 & 0xFFFFu) | ((u32)len1 << 16);
         o1[1] = ((u32)code1 & 0xFFu) | (((u32)f1 & 0xFFu) << 8) | (apos1 << 16);
-        o1[2] = alen1 & 0xFFFFu;
+        o1[2] = (alen1 & 0xFFFFu) | (rsv1 << 16);
         o2[0] = (front2 & 0xFFFFu) | ((u32)len2 << 16);
         o2[1] = ((u32)code2 & 0xFFu) | (((u32)f2 & 0xFFu) << 8) | (apos2 << 16);
-        o2[2] = alen2 & 0xFFFFu;
+        o2[2] = (alen2 & 0xFFFFu) | (rsv2 << 16);
     }
 }
 
@@ -2261,6 +2308,13 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
         if (a.p.merge) {
             phase_overlap(a, lds, tid, nt);
             phase_merge(a, lds, tile_first, tid, nt);
+            tile_sync(a, lds, nt);
+        }
+        if (a.p.overlapped_out) {
+            phase_ovout_begin(a, lds, tile_first, tid, nt);
+            tile_sync(a, lds, nt);
+            phase_overlap(a, lds, tid, nt, true);
+            phase_ovout_end(a, lds, tile_first, tid, nt);
             tile_sync(a, lds, nt);
         }
         FQ_STAMP(5)

@@ -63,8 +63,8 @@ struct fastp_gpu_host {
     fastp_gpu_host_options o;
     std::string a1seq, a2seq, umi_prefix, umi_delim;
     std::vector<std::string> fasta;
-    std::string out[FASTP_GPU_N_OUTPUTS];
-    bool want[FASTP_GPU_N_OUTPUTS];
+    std::string out[FASTP_GPU_N_HOST_OUTPUTS];
+    bool want[FASTP_GPU_N_HOST_OUTPUTS];
     AdapterMap amap[2];
     std::vector<std::map<std::string, long>::const_iterator> index[2];  // for adapter_entry()
     bool index_valid[2] = {false, false};
@@ -124,6 +124,7 @@ int fastp_gpu_host_create(const fastp_gpu_params* params, const fastp_gpu_host_o
     h->want[FASTP_GPU_MERGED] = params->merge != 0;
     h->want[FASTP_GPU_UNPAIRED1] = opts && opts->want_unpaired1;
     h->want[FASTP_GPU_UNPAIRED2] = opts && opts->want_unpaired2;
+    h->want[FASTP_GPU_OVERLAPPED] = params->paired && params->overlapped_out;
     *out = h;
     return FASTP_GPU_OK;
 }
@@ -131,7 +132,7 @@ int fastp_gpu_host_create(const fastp_gpu_params* params, const fastp_gpu_host_o
 void fastp_gpu_host_destroy(fastp_gpu_host* h) { delete h; }
 
 const char* fastp_gpu_host_output(fastp_gpu_host* h, int which, size_t* len) {
-    if (!h || which < 0 || which >= FASTP_GPU_N_OUTPUTS || !h->want[which]) { if (len) *len = 0; return nullptr; }
+    if (!h || which < 0 || which >= FASTP_GPU_N_HOST_OUTPUTS || !h->want[which]) { if (len) *len = 0; return nullptr; }
     if (len) *len = h->out[which].size();
     return h->out[which].data();
 }
@@ -182,7 +183,7 @@ int fastp_gpu_host_apply(fastp_gpu_host* h, const fastp_gpu_reads* b1, const fas
     // The common pack - no UMI, no base correction, no adapter string to replay, no merge - is routed straight from
     // the pack's buffers (pointer + length views, one memcpy per field into the writer's string); everything else
     // takes the general path below on copies it may edit.
-    const bool simple_opts = h->o.umi_loc == FASTP_GPU_UMI_NONE && corr.empty() && events.empty() && !h->p.merge;
+    const bool simple_opts = h->o.umi_loc == FASTP_GPU_UMI_NONE && corr.empty() && events.empty() && !h->p.merge && !h->p.overlapped_out;
     std::string s1, q1, s2, q2, name1, name2, strand1, strand2;
     typedef fastp_gpu_host::View View;
     for (int i = 0; i < n; i++) {
@@ -313,6 +314,13 @@ int fastp_gpu_host_apply(fastp_gpu_host* h, const fastp_gpu_reads* b1, const fas
         const int t2l = rr2.len;
         const int code2 = rr2.code;
         const bool alive2 = !(rr2.flags & FASTP_GPU_RF_NULL);
+        if (h->want[FASTP_GPU_OVERLAPPED] && (rr1.reserved & FASTP_GPU_OVOUT_HIT)) {  // peprocessor.cpp:488-495
+            // string(substr(max(0, offset)), overlap_len) is std::string's (str, pos) constructor: the reference prints
+            // the bases of read 1 BEHIND the overlapped region.  The engine analysed the pair as it was right after
+            // adapter trimming; the later polyX / max_len cuts do not shorten what is printed here.
+            const int pos = rr1.reserved & 0x7FFF, cnt = rr2.reserved;
+            h->record(FASTP_GPU_OVERLAPPED, name1, t1s + pos, t1q + pos, cnt, strand1);
+        }
         if (h->p.merge && alive1 && alive2) {  // peprocessor.cpp:518-561
             if (res->pair[i].flags & FASTP_GPU_PF_OVERLAPPED) {
                 if (code1 == FASTP_PASS_FILTER) {  // OverlapAnalysis::merge overlapanalysis.cpp:148-179

@@ -135,6 +135,8 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.allow_gap = (in.allow_gap_overlap_trimming != 0) && p.paired;
     p.merge = (in.merge != 0) && p.paired;
     p.merge_include_unmerged = in.merge_include_unmerged != 0;
+    p.overlapped_out = (in.overlapped_out != 0) && p.paired;   // mOverlappedWriter exists for paired input only (peprocessor.cpp:94-97)
+    if (p.overlapped_out && p.merge) { err = "overlapped_out together with merge (both use the records' reserved fields)"; return FASTP_GPU_E_UNSUPPORTED; }
     p.overlap_require = in.overlap_require;
     p.overlap_diff_limit = in.overlap_diff_limit;
     p.qual_filter = in.qual_filter != 0;

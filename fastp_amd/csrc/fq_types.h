@@ -71,6 +71,7 @@ struct DevParams {
     u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
     int correction;
     int merge, merge_include_unmerged;  // MergeOptions (peprocessor.cpp:518-561)
+    int overlapped_out;     // --overlapped_out: the diffPercentLimit-0 analysis after adapter trimming (peprocessor.cpp:488-495)
     int allow_gap;          // AdapterOptions::allowGapOverlapTrimming (overlapanalysis.cpp:91-139)
     int overlap_require, overlap_diff_limit;
     int ov_limit_max;       // largest per-length mismatch limit (the LUT is non-decreasing): prefilter bound

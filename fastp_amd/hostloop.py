@@ -131,6 +131,7 @@ class Outputs:
         self.unpaired1 = bytearray() if want_unpaired1 else None
         self.unpaired2 = bytearray() if want_unpaired2 else None
         self.merged = bytearray()
+        self.overlapped = bytearray()   # --overlapped_out (peprocessor.cpp:488-495)
 
 
 def _record(name, seq, strand, qual, tag=None):  # Read::appendToString read.cpp:119-154
@@ -263,6 +264,12 @@ def apply_results(params: abi.Params, b1: FastqBatch, b2: FastqBatch | None, r1,
         t2s, t2q = cut(rr2, s2, q2)
         code2 = int(rr2["code"])
         alive2 = not (rr2["flags"] & abi.RF_NULL)
+        if params.overlapped_out and (int(rr1["reserved"]) & abi.OVOUT_HIT):  # peprocessor.cpp:488-495
+            # string(substr(max(0, offset)), overlap_len) at :491 is std::string's (str, pos) constructor: what is
+            # printed are the bases of read 1 BEHIND the region the exact (diffPercentLimit 0) analysis found
+            # overlapped, of the read as it was right after adapter trimming (later polyX / max_len cuts do not apply)
+            f, st, cnt = int(rr1["front"]), int(rr1["reserved"]) & 0x7FFF, int(rr2["reserved"])
+            outputs.overlapped += _record(b1.names[i], bytes(s1[f + st:f + st + cnt]), b1.strands[i], bytes(q1[f + st:f + st + cnt]))
         if params.merge and alive1 and alive2:  # peprocessor.cpp:518-561
             if pair[i]["flags"] & abi.PF_OVERLAPPED:
                 if code1 == abi.PASS_FILTER:

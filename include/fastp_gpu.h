@@ -140,7 +140,11 @@ typedef struct fastp_gpu_params {
     const char* const* overrep_seqs1;
     const char* const* overrep_seqs2;
 
-    int32_t reserved[4];
+    /* --overlapped_out given (paired input; Options::overlappedOut, peprocessor.cpp:488-495): the engine runs the
+     * third OverlapAnalysis::analyze (diffPercentLimit 0, on the pair right after adapter trimming) and reports the
+     * overlapped part of read 1 in the records' `reserved` fields.  Not together with merge (FASTP_GPU_E_UNSUPPORTED). */
+    int32_t overlapped_out;
+    int32_t reserved[3];
 } fastp_gpu_params;
 
 /* fills *p with the values an un-flagged `fastp -i R1 [-I R2]` run uses
@@ -193,8 +197,13 @@ typedef struct fastp_gpu_read_result {
     uint16_t adapter_len;/* length of the string handed to addAdapterTrimmed:     */
                          /* pos>=0: read[pos, pos+adapter_len) (after correction); */
                          /* pos<0 : adapterseq.substr(0, adapter_len)              */
-    uint16_t reserved;
+    uint16_t reserved;   /* merge mode, merged pair: bases of this mate in the merged read.               */
+                         /* overlapped_out: read 1 = FASTP_GPU_OVOUT_HIT | pos, read 2 = count: the extra  */
+                         /* stream gets orig_r1[front + pos, front + pos + count) - the bases BEHIND the   */
+                         /* overlapped region, pos = max(0, offset) + overlap_len, as peprocessor.cpp:491  */
+                         /* builds it with std::string's (str, pos) constructor                           */
 } fastp_gpu_read_result; /* 12 bytes */
+#define FASTP_GPU_OVOUT_HIT 0x8000u
 
 #define FASTP_GPU_RF_NULL 0x01        /* trimAndCut returned NULL (filter.cpp:68)      */
 #define FASTP_GPU_RF_DUP 0x02         /* Duplicate::check* said duplicate               */
@@ -409,7 +418,9 @@ int fastp_gpu_format_fastq(fastp_gpu_ctx* ctx, int32_t n, const fastp_gpu_format
  * Output order inside a stream = input order.  FASTP_GPU_E_OVERFLOW + needed sizes in out_len when a buffer is
  * too small.  All pointers except opts / out / out_capacity / out_len themselves are DEVICE pointers. */
 enum { FASTP_GPU_OUT1 = 0, FASTP_GPU_OUT2 = 1, FASTP_GPU_FAILED = 2, FASTP_GPU_MERGED = 3,
-       FASTP_GPU_UNPAIRED1 = 4, FASTP_GPU_UNPAIRED2 = 5, FASTP_GPU_N_OUTPUTS = 6 };
+       FASTP_GPU_UNPAIRED1 = 4, FASTP_GPU_UNPAIRED2 = 5, FASTP_GPU_N_OUTPUTS = 6,
+       /* host glue only (fastp_gpu_host.h): --overlapped_out's stream; fastp_gpu_format_streams refuses that option */
+       FASTP_GPU_OVERLAPPED = 6, FASTP_GPU_N_HOST_OUTPUTS = 7 };
 #define FASTP_GPU_UMI_NONE 0
 #define FASTP_GPU_UMI_READ1 1     /* UMI_LOC_READ1    */
 #define FASTP_GPU_UMI_READ2 2     /* UMI_LOC_READ2    */

@@ -1060,6 +1060,17 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
                 isAdapterDimer = 1;
         }
     }
+    if (p->overlapped_out && both) { /* :488-495, mOverlappedWriter: analyze(r1, r2, diffLimit, require, 0) */
+        fastp_oracle_overlap ovx = fastp_oracle_analyze(or1.seq, or1.len, or2.seq, or2.len, p->overlap_diff_limit,
+                                                        p->overlap_require, 0.0, 0);
+        if (ovx.overlapped) {
+            /* :491 new string(r1->mSeq->substr(max(0, offset)), overlap_len): the (str, pos) constructor, so the
+             * stream gets what FOLLOWS the overlapped region of read 1, r1[start + overlap_len, len1) */
+            int pos = ORC_MAX(0, ovx.offset) + ovx.overlap_len;
+            rr1->reserved = (uint16_t)(FASTP_GPU_OVOUT_HIT | (unsigned)pos);
+            rr2->reserved = (uint16_t)(or1.len - pos);
+        }
+    }
     if (thread0 && !isizeEvaluated && both) { /* :497-504 */
         if (!ovComputed) { ov = orc_analyze_reads(o, &or1, &or2, 0); ovComputed = 1; }
         orc_stat_isize(o, or1.len, or2.len, &ov, ft1, ft2);

@@ -137,7 +137,6 @@ void make_state(Options* o, bool paired) {
     if (o->indexFilter.enabled) refuse("--filter_by_index");
     if (o->fixMGI) refuse("--fix_mgi_id");
     if (o->split.enabled) refuse("--split");
-    if (!o->overlappedOut.empty()) refuse("--overlapped_out");
     if (o->outputToSTDOUT) refuse("--stdout");
     s->max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);
     if (s->max_len <= 0) s->max_len = 151;
@@ -168,6 +167,7 @@ void make_state(Options* o, bool paired) {
     p.allow_gap_overlap_trimming = o->adapter.allowGapOverlapTrimming;
     p.dimer_max_len = o->adapter.dimerMaxLen;
     p.correction = o->correction.enabled;  p.merge = o->merge.enabled;
+    p.overlapped_out = (paired && !o->overlappedOut.empty()) ? 1 : 0;   // mOverlappedWriter (peprocessor.cpp:94-97)
     p.merge_include_unmerged = o->merge.includeUnmerged;
     p.overlap_require = o->overlapRequire;  p.overlap_diff_limit = o->overlapDiffLimit;
     p.overlap_diff_percent_limit = o->overlapDiffPercentLimit;
@@ -368,6 +368,7 @@ template <class Proc>
 void emit_pe(Proc* pp, int tid) {
     if (pp->mMergedWriter) pp->mMergedWriter->input(tid, take(tid, FASTP_GPU_MERGED));
     if (pp->mFailedWriter) pp->mFailedWriter->input(tid, take(tid, FASTP_GPU_FAILED));
+    if (pp->mOverlappedWriter) pp->mOverlappedWriter->input(tid, take(tid, FASTP_GPU_OVERLAPPED));   // :662-664
     if (pp->mRightWriter && pp->mLeftWriter) {
         pp->mLeftWriter->input(tid, take(tid, FASTP_GPU_OUT1));
         pp->mRightWriter->input(tid, take(tid, FASTP_GPU_OUT2));

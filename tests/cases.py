@@ -78,6 +78,17 @@ CASES = {
                             {"polyx_frac": 0.3}),
 }
 
+# --overlapped_out (peprocessor.cpp:488-495): the third, exact analysis after adapter trimming
+CASES["pe_overlapped_out"] = (True, ["-G", "--overlapped_out", "@TMP@/overlapped.fq"], _pe(overlapped_out=1),
+                              {"insert_mean": 200.0})
+CASES["pe_overlapped_out_trims"] = (True, ["-G", "-c", "-x", "-b", "120", "-B", "100", "--cut_front", "-f", "2",
+                                           "--overlapped_out", "@TMP@/overlapped.fq"],
+                                    _pe(overlapped_out=1, correction=1, poly_x=1, max_len1=120, max_len2=100, cut_front=1,
+                                        trim_front1=2, trim_front2=2),
+                                    {"insert_mean": 170.0, "polyx_frac": 0.2})
+CASES["pe_overlapped_out_noadapter"] = (True, ["-G", "-A", "--overlapped_out", "@TMP@/overlapped.fq"],
+                                        _pe(overlapped_out=1, adapter_enabled=0), {"insert_mean": 150.0, "insert_sd": 60.0})
+
 # inputs on which the reference's one-gap code ACCEPTS (synth.indel_overlap_pairs / adapter_indel_reads): the
 # closed-form device versions of Matcher::diffWithOneInsertion / matchWithOneInsertion take their positive branch
 CASES["pe_allow_gap_indel"] = (True, ["-G", "--allow_gap_overlap_trimming"], _pe(allow_gap_overlap_trimming=1),

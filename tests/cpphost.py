@@ -103,6 +103,7 @@ class CppHost:
         o.failed = self.output(2)
         o.merged = self.output(3) or b""
         o.unpaired1, o.unpaired2 = self.output(4), self.output(5)
+        o.overlapped = self.output(abi.OUT_OVERLAPPED) or b""
         return o
 
     def adapter_maps(self):

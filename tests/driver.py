@@ -75,7 +75,8 @@ def run_reference(flags, fq1: bytes, fq2: bytes | None, want_failed=True, workdi
     if p.returncode != 0:
         raise RuntimeError("fastp_ref failed: " + p.stderr.decode()[-2000:])
     res = {}
-    for k, fn in (("out1", "o1.fq"), ("out2", "o2.fq"), ("failed", "failed.fq"), ("merged", "merged.fq")):
+    for k, fn in (("out1", "o1.fq"), ("out2", "o2.fq"), ("failed", "failed.fq"), ("merged", "merged.fq"),
+                  ("overlapped", "overlapped.fq")):
         path = os.path.join(tmp, fn)
         res[k] = open(path, "rb").read() if os.path.exists(path) else None
     res["json"] = refjson.load_reference_json(os.path.join(tmp, "r.json"))

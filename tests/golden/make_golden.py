@@ -9,7 +9,7 @@ Run in the build container (needs oracle/_ref/fastp_ref, built from
 For every case of tests/cases.py it writes tests/golden/<case>.npz holding
   * the input FASTQ text (R1[,R2]) - synthetic (tests/synth.py, fixed seed), and
     for case "testdata_pe" the reference's own testdata/R1.fq + R2.fq,
-  * md5 + size of every FASTQ the reference wrote (-w 1: out1,out2,failed,merged),
+  * md5 + size of every FASTQ the reference wrote (-w 1: out1,out2,failed,merged,overlapped),
   * the reference's JSON report with "command" removed.
 The GPU box has no /root/reference; the parity tests read only these files.
 """
@@ -37,7 +37,7 @@ def one(name, flags, fq1, fq2):
     if fq2 is not None:
         rec["fq2"] = np.frombuffer(fq2, dtype=np.uint8)
     meta = {"flags": flags, "outputs": {}}
-    for k in ("out1", "out2", "failed", "merged"):
+    for k in ("out1", "out2", "failed", "merged", "overlapped"):
         b = ref.get(k)
         if b is not None:
             meta["outputs"][k] = {"md5": hashlib.md5(b).hexdigest(), "size": len(b)}

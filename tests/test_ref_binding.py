@@ -38,6 +38,8 @@ BINDING_CASES = {
     "pe_umi_per_read": [],
     "pe_adapter_fasta": [],
     "pe_overrep": [],
+    "pe_overlapped_out_trims": [],
+    "pe_overlapped_out_noadapter": [],
     "se_default_noadapter": [],
     "se_adapter_cut": [],
     "se_umi_read1": [],
