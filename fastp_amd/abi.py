@@ -7,7 +7,7 @@ import ctypes as C
 
 ABI_VERSION = 2
 MAX_READ_LEN = 512
-MAX_ADAPTER_LEN = 64
+MAX_ADAPTER_LEN = 256
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_ALPHABET, E_TOO_LONG, E_UNSUPPORTED, E_OVERFLOW, E_NOMEM = (

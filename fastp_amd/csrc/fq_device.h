@@ -1342,7 +1342,7 @@ FQ_DEV void decode_overlap(u32 key, int l1, int l2, int& ovl, int& off, int& ol,
 
 // ---------------------------------------------------------------------------
 // AdapterTrimmer::trimBySequence (adaptertrimmer.cpp:64-157) on the read [f, f+rlen)
-// aw = packed adapter words (ACGT only, options.cpp:369-399), alen <= 64.
+// aw = packed adapter words (ACGT only, options.cpp:369-399), alen <= FASTP_GPU_MAX_ADAPTER_LEN (16 words).
 // ---------------------------------------------------------------------------
 FQ_DEV int count_mismatch_words(const u32* srow, const u32* nrow, bool hasN, int rp, const u32* aw, int ap,
                                 int n, int allowed) {
@@ -1366,9 +1366,33 @@ FQ_DEV int count_mismatch_words(const u32* srow, const u32* nrow, bool hasN, int
 // gives the answer for all cmplen.  Returns a bit mask: bit (c-1) set <=> matched for
 // cmplen == c with diffLimit == c/8 - 1 (adaptertrimmer.cpp:108,125).
 // ins_is_read: insertion case (ins = read, nor = adapter) else deletion case.
-FQ_DEV u64 one_gap_match_mask(const u32* srow, const u8* q, int f, int rlen, const u32* aw, int alen,
-                              bool ins_is_read, int cmax) {
-    u64 ok = 0;
+struct GapMask {   // one bit per compare length 1 .. 64 * MAX_ADAPTER_WORDS / 4; words picked by compares, not by address
+    u64 w[MAX_ADAPTER_WORDS / 4];
+    FQ_DEV void clear() {
+#pragma unroll
+        for (int i = 0; i < MAX_ADAPTER_WORDS / 4; i++) w[i] = 0;
+    }
+    FQ_DEV void set(int b) {
+#pragma unroll
+        for (int i = 0; i < MAX_ADAPTER_WORDS / 4; i++) w[i] |= (b >> 6) == i ? 1ull << (b & 63) : 0ull;
+    }
+    FQ_DEV bool test(int b) const {
+        u64 x = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_ADAPTER_WORDS / 4; i++) x |= (b >> 6) == i ? w[i] : 0ull;
+        return ((x >> (b & 63)) & 1ull) != 0;
+    }
+    FQ_DEV bool any() const {
+        u64 x = 0;
+#pragma unroll
+        for (int i = 0; i < MAX_ADAPTER_WORDS / 4; i++) x |= w[i];
+        return x != 0;
+    }
+};
+FQ_DEV GapMask one_gap_match_mask(const u32* srow, const u8* q, int f, int rlen, const u32* aw, int alen,
+                                  bool ins_is_read, int cmax) {
+    GapMask ok;
+    ok.clear();
     int p0 = 0, p1 = 0;           // P0(i), P1(i)
     int gmin = 0x7FFFFFFF;        // min_{1<=i'<=i-1}... running min of P0(i)-P1(i) over i in [1, c-1]
     // walk i = 1..cmax ; at step i we know P0(i), P1(i) (prefix over k < i)
@@ -1389,7 +1413,7 @@ FQ_DEV u64 one_gap_match_mask(const u32* srow, const u8* q, int f, int rlen, con
         // now p0 = P0(i), p1 = P1(i).  cmplen c = i: uses min over i' in [1, c-1] (previous gmin) and P1(c)=p1
         const int c = i;
         const int limit = c / 8 - 1;
-        if (c >= 2 && gmin != 0x7FFFFFFF && gmin + p1 <= limit) ok |= 1ull << (c - 1);
+        if (c >= 2 && gmin != 0x7FFFFFFF && gmin + p1 <= limit) ok.set(c - 1);
         // extend the running min with i' = i (valid for cmplen > i)
         const int g = p0 - p1;
         if (g < gmin) gmin = g;
@@ -1417,22 +1441,22 @@ FQ_DEV bool trim_by_sequence(const u32* srow, const u32* nrow, const u8* q, bool
     // one insertion in the read (:105-118) - rdata/adata are NOT advanced by pos (quirk #7)
     if (rlen - matchReq - 1 > 0) {
         const int cmax = imin(rlen - 1, alen);
-        const u64 ok = one_gap_match_mask(srow, q, f, rlen, aw, alen, true, cmax);
-        if (ok) {
+        const GapMask ok = one_gap_match_mask(srow, q, f, rlen, aw, alen, true, cmax);
+        if (ok.any()) {
             for (pos = 0; pos < rlen - matchReq - 1; pos++) {
                 const int c = imin(rlen - pos - 1, alen);
-                if (c >= 1 && ((ok >> (c - 1)) & 1ull)) { out_pos = pos; return true; }
+                if (c >= 1 && ok.test(c - 1)) { out_pos = pos; return true; }
             }
         }
     }
     // one deletion in the read (:122-135)
     if (rlen - matchReq > 0) {
         const int cmax = imin(rlen, alen - 1);
-        const u64 ok = one_gap_match_mask(srow, q, f, rlen, aw, alen, false, cmax);
-        if (ok) {
+        const GapMask ok = one_gap_match_mask(srow, q, f, rlen, aw, alen, false, cmax);
+        if (ok.any()) {
             for (pos = 0; pos < rlen - matchReq; pos++) {
                 const int c = imin(rlen - pos, alen - 1);
-                if (c >= 1 && ((ok >> (c - 1)) & 1ull)) { out_pos = pos; return true; }
+                if (c >= 1 && ok.test(c - 1)) { out_pos = pos; return true; }
             }
         }
     }

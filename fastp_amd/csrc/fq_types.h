@@ -40,8 +40,8 @@ enum { PF_Q = 3, PF_S = 1 };   // in 16-byte chunks
 enum { QT_INC = 0, QT_COUNT = 2, QT_ONE = 3, QT_DWORDS = 4 };
 enum { KMER_BINS = 1024 };
 enum { MAX_DUP_BUFS = 8 };
-enum { MAX_ADAPTER_WORDS = 4 };  // 64 bases
-enum { ADAPT_WORDS = 6 };        // LDS words per adapter (4 + zero padding for window reads)
+enum { MAX_ADAPTER_WORDS = 16 }; // 256 bases = FASTP_GPU_MAX_ADAPTER_LEN
+enum { ADAPT_WORDS = 18 };       // LDS words per adapter (16 + zero padding for window reads)
 
 // read flags kept in LDS while a tile is processed (low byte == FASTP_GPU_RF_*)
 enum {

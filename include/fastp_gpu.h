@@ -36,7 +36,7 @@ extern "C" {
 
 /* ---- limits ------------------------------------------------------------ */
 #define FASTP_GPU_MAX_READ_LEN 512    /* padded read length the kernels tile in LDS */
-#define FASTP_GPU_MAX_ADAPTER_LEN 64  /* -a / --adapter_sequence_r2 (fastp truncates detected ones to 60) */
+#define FASTP_GPU_MAX_ADAPTER_LEN 256 /* -a / --adapter_sequence_r2 / --adapter_fasta entries (detected ones are <= 60) */
 
 /* ---- error codes ------------------------------------------------------- */
 #define FASTP_GPU_OK 0

@@ -89,6 +89,19 @@ CASES["pe_overlapped_out_trims"] = (True, ["-G", "-c", "-x", "-b", "120", "-B", 
 CASES["pe_overlapped_out_noadapter"] = (True, ["-G", "-A", "--overlapped_out", "@TMP@/overlapped.fq"],
                                         _pe(overlapped_out=1, adapter_enabled=0), {"insert_mean": 150.0, "insert_sd": 60.0})
 
+# adapters longer than 64 bases (the engine's cap is FASTP_GPU_MAX_ADAPTER_LEN = 256): the read-through of the
+# synthetic reads is adapter + poly-A, so these match over their whole length
+LONG_R1 = ADAPTER_R1 + "A" * 70      # 103 bases
+LONG_R2 = ADAPTER_R2 + "A" * 100     # 133 bases
+CASES["se_adapter_long"] = (False, ["-G", "-a", LONG_R1], _se(adapter_seq_r1=LONG_R1.encode()), {"insert_mean": 90.0})
+CASES["pe_adapter_long"] = (True, ["-G", "-a", LONG_R1, "--adapter_sequence_r2", LONG_R2],
+                            _pe(adapter_seq_r1=LONG_R1.encode(), adapter_seq_r2=LONG_R2.encode()),
+                            {"insert_mean": 100.0, "insert_sd": 50.0})
+# a long adapter without the poly-A run (one-gap matches need the indel to matter), indel-bearing reads that start with it
+LONG_MIXED = ADAPTER_R1 + "CTGACCTCAAGTCTGCACACGAGAAGGCTAGATCGTAGCTAGCTAGGATCCATCGATTTACGGCAAT" + ADAPTER_R2[::-1]   # 131 bases
+CASES["se_adapter_long_indel"] = (False, ["-G", "-a", LONG_MIXED], _se(adapter_seq_r1=LONG_MIXED.encode()),
+                                  {"gen": "adapter_indel", "adapters": (LONG_MIXED, LONG_MIXED)})
+
 # inputs on which the reference's one-gap code ACCEPTS (synth.indel_overlap_pairs / adapter_indel_reads): the
 # closed-form device versions of Matcher::diffWithOneInsertion / matchWithOneInsertion take their positive branch
 CASES["pe_allow_gap_indel"] = (True, ["-G", "--allow_gap_overlap_trimming"], _pe(allow_gap_overlap_trimming=1),
@@ -103,7 +116,7 @@ CASES["pe_adapter_indel"] = (True, ["-G", "-a", ADAPTER_R1, "--adapter_sequence_
                              _pe(adapter_seq_r1=ADAPTER_R1.encode(), adapter_seq_r2=ADAPTER_R2.encode()),
                              {"gen": "adapter_indel"})
 # least number of one-gap ACCEPTS the oracle must report on 20 000 units of these inputs (tests assert it)
-GAP_CASES = ("pe_allow_gap_indel", "pe_allow_gap_indel_corr", "se_adapter_indel", "pe_adapter_indel")
+GAP_CASES = ("pe_allow_gap_indel", "pe_allow_gap_indel_corr", "se_adapter_indel", "pe_adapter_indel", "se_adapter_long_indel")
 
 # --adapter_fasta: contigs as the FASTA file lists them; Options::loadFastaAdapters keeps them in
 # contig-name order (std::map), >= 6 bp, de-duplicated (options.cpp:50-83)

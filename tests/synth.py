@@ -20,12 +20,12 @@ def _adapter_pad(adapter, L):
 
 def synth_pairs(n, L=150, seed=42, insert_mean=300.0, insert_sd=80.0, insert_min=20, insert_max=800,
                 polyg_frac=0.0, polyx_frac=0.0, dup_frac=0.10, ragged_frac=0.02, n_rate=0.5,
-                lowq_site_rate=0.03, paired=True, gen=None):
+                lowq_site_rate=0.03, paired=True, gen=None, adapters=None):
     """returns dict(seq1,qual1,len1[,seq2,qual2,len2]) as ASCII uint8 [n, stride] + int32 lens"""
     if gen == "indel_overlap":   # parity cases that need single-base indels (the one-gap ACCEPT paths)
         return indel_overlap_pairs(n, L=L, seed=seed)
     if gen == "adapter_indel":
-        return adapter_indel_reads(n, L=L, seed=seed, paired=paired)
+        return adapter_indel_reads(n, L=L, seed=seed, paired=paired, adapters=adapters)
     rng = np.random.default_rng(seed)
     stride = (L + 7) // 8 * 8
     ins = np.clip(np.rint(rng.normal(insert_mean, insert_sd, n)), insert_min, insert_max).astype(np.int64)
@@ -247,7 +247,7 @@ def indel_overlap_pairs(n, L=150, seed=1, gap_limit=5):
     return outs
 
 
-def adapter_indel_reads(n, L=150, seed=1, paired=True):
+def adapter_indel_reads(n, L=150, seed=1, paired=True, adapters=None):
     """reads that BEGIN with the adapter carrying one inserted / one deleted base: AdapterTrimmer::trimBySequence's
     one-gap loops compare the read from position 0 whatever `pos` is (adaptertrimmer.cpp:105-135, quirk #7), so
     these are the inputs on which Matcher::matchWithOneInsertion accepts.  The adapter prefix length varies
@@ -256,7 +256,10 @@ def adapter_indel_reads(n, L=150, seed=1, paired=True):
     rng = np.random.default_rng(seed)
     j = np.arange(L)[None, :]
     outs = {}
-    for tag, adapter in (("1", ADAPTER_R1), ("2", ADAPTER_R2)) if paired else (("1", ADAPTER_R1),):
+    ad1, ad2 = adapters if adapters else (ADAPTER_R1, ADAPTER_R2)
+    for tag, adapter in (("1", ad1), ("2", ad2)) if paired else (("1", ad1),):
+        if isinstance(adapter, str):
+            adapter = adapter.encode()
         acode = np.array([b"ACGT".index(ch) for ch in adapter], dtype=np.uint8)
         alen = len(acode)
         c = rng.integers(0, 4, size=(n, L), dtype=np.uint8)

@@ -346,9 +346,9 @@ def test_gpu_one_gap_accept_paths(name):
         assert tot > 100 and neg > 100, f"{name}: only {tot} one-gap overlaps ({neg} with a negative offset) in 6000 pairs"
         assert gap_util.gap_trimmed_pairs(ro[0], ro[2]) > 100
     else:
-        assert gap_util.gap_adapter_trims(d["seq1"], d["len1"], ro[0], cases.ADAPTER_R1.encode()) > 1000
+        assert gap_util.gap_adapter_trims(d["seq1"], d["len1"], ro[0], bytes(params.adapter_seq_r1)) > 1000
         if paired:
-            assert gap_util.gap_adapter_trims(d["seq2"], d["len2"], ro[1], cases.ADAPTER_R2.encode()) > 1000
+            assert gap_util.gap_adapter_trims(d["seq2"], d["len2"], ro[1], bytes(params.adapter_seq_r2)) > 1000
     _compare(name, params, d, paired)
 
 

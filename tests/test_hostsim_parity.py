@@ -106,9 +106,9 @@ def test_sim_one_gap_accept_paths(name):
         assert tot > 100 and neg > 40, f"{name}: only {tot} one-gap overlaps ({neg} with a negative offset)"
         assert gap_util.gap_trimmed_pairs(ro[0], ro[2]) > 40
     else:
-        assert gap_util.gap_adapter_trims(d["seq1"], d["len1"], ro[0], cases.ADAPTER_R1.encode()) > 500
+        assert gap_util.gap_adapter_trims(d["seq1"], d["len1"], ro[0], bytes(params.adapter_seq_r1)) > 500
         if paired:
-            assert gap_util.gap_adapter_trims(d["seq2"], d["len2"], ro[1], cases.ADAPTER_R2.encode()) > 500
+            assert gap_util.gap_adapter_trims(d["seq2"], d["len2"], ro[1], bytes(params.adapter_seq_r2)) > 500
     for k, what in enumerate(("r1", "r2", "pair")):
         if ro[k] is not None:
             bad = np.nonzero(ro[k] != rg[k])[0]
@@ -148,7 +148,7 @@ def test_sim_out_of_scope_parameters_fail_loudly():
     """the engine never falls back: parameters outside the device path are errors"""
     for field, value, code in (("max_len", 513, abi.E_TOO_LONG), ("insert_size_max", 5000, abi.E_INVALID),
                                ("abi_version", 99, abi.E_INVALID), ("unqualified_percent_limit", -1, abi.E_INVALID),
-                               ("adapter_seq_r1", b"ACGTN", abi.E_INVALID), ("adapter_seq_r1", b"A" * 65, abi.E_UNSUPPORTED)):
+                               ("adapter_seq_r1", b"ACGTN", abi.E_INVALID), ("adapter_seq_r1", b"A" * (abi.MAX_ADAPTER_LEN + 1), abi.E_UNSUPPORTED)):
         p = abi.default_params(True, 150)
         setattr(p, field, value)
         with pytest.raises(engine.EngineError) as e:

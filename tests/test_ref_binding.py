@@ -45,6 +45,8 @@ BINDING_CASES = {
     "se_umi_read1": [],
     "se_adapter_indel": [],
     "se_overrep": [],
+    "pe_adapter_long": [],
+    "se_adapter_long_indel": [],
 }
 
 
