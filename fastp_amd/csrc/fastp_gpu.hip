@@ -175,7 +175,7 @@ struct fastp_gpu_ctx {
     // split plan (fq_stats.h): the per-read kernel as small workgroups, Stats::statRead as its own streaming kernel
     bool split = false;
     int st_threads = 0, st_blocks = 0;     // the Stats kernel's workgroup size and the most workgroups it is launched with
-    int st_H = 0, st_lds_dwords = 0, st_slab_dwords = 0;
+    int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
     // lane plan (fq_lane.h): one lane per pair, reads in registers - the option family lane_plan_supported() admits
@@ -438,13 +438,22 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
         ctx->st_H = ctx->dp.qw_g / 2;
+        // class stride of the per-cycle table: 32 items (= all 64 banks) where two workgroups per CU still fit
+        ctx->st_Hs = ctx->st_H;
+        if (env_int("FASTP_GPU_STATS_PAD", 1) && ctx->st_H < 32) ctx->st_Hs = 32;
+        ctx->st_wl_cap = ctx->st_Hs > ctx->st_H ? 511 : 2047;
+        for (;;) {
+            const int bytes = (4 * 8 * N_CLS * ctx->st_Hs * 2 + 4 * KMER_BINS + ST_QH_COPIES * 4 * 128 + 4 * 256 + 1 + ctx->st_wl_cap + 3) * 4;
+            if (ctx->st_Hs == ctx->st_H || 2 * bytes <= 160 * 1024) break;
+            ctx->st_Hs = ctx->st_H;
+            ctx->st_wl_cap = 2047;
+        }
         int o = 0;
-        ctx->st_l_cyc = o; o += 4 * 8 * N_CLS * ctx->st_H * 2;
+        ctx->st_l_cyc = o; o += 4 * 8 * N_CLS * ctx->st_Hs * 2;
         ctx->st_l_kmer = o; o += 4 * KMER_BINS;
         ctx->st_l_qh = o; o += ST_QH_COPIES * 4 * 128;
         o = (o + 3) & ~3;
         ctx->st_l_lut = o; o += 4 * 256;
-        ctx->st_wl_cap = 2047;
         ctx->st_l_wl = o; o += 1 + ctx->st_wl_cap;
         ctx->st_lds_dwords = o;
         ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
@@ -1041,7 +1050,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.paired = ctx->dp.paired;
         sa.sw_g = ctx->dp.sw_g;
         sa.qw_g = ctx->dp.qw_g;
-        sa.H = ctx->st_H;
+        sa.H = ctx->st_H; sa.Hs = ctx->st_Hs;
         sa.magic_H = magic_for((u32)ctx->st_H);
         sa.Cp = ctx->L.Cp;
         int upb = (n + ctx->st_blocks - 1) / ctx->st_blocks;

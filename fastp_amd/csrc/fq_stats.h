@@ -26,6 +26,8 @@ struct StatsArgs {
     int paired;
     int sw_g, qw_g;         // batch row strides in dwords
     int H;                  // 8-base items per row = qw_g / 2
+    int Hs;                 // items between two classes of the per-cycle table (>= H; 32 = one full set of banks: lanes
+                            // that differ in class then never meet in a bank unless they share the item column)
     u32 magic_H;            // ceil(2^32 / H)
     int Cp;                 // cycles rounded up to a multiple of 4 (canonical slab layout, cyc_index)
     int units_per_block;    // a workgroup takes this many consecutive units (<= CYC_MAX_READS: packed counters)
@@ -33,11 +35,12 @@ struct StatsArgs {
     const u32* qual[2];
     const u32* swin[2];     // per read: original length | kept length << 16 (0 kept = not written out), left by the scan kernel
     // LDS layout (dwords)
-    int l_cyc;              // [4][8][N_CLS][H] u64
+    int l_cyc;              // [4][8][N_CLS][Hs] u64
     int l_kmer;             // [4][KMER_BINS] u32
     int l_qh;               // [4][128][ST_QH_COPIES] u32: lane l adds to copy l % ST_QH_COPIES of a bin (same-address atomics
                             // serialise; the copies of a bin sit in consecutive banks)
-    int l_lut;              // [256] x 4 dwords: character | kept << 7 -> {increment u64, per-cycle byte offset, k-mer byte offset}
+    int l_lut;              // [256] x 4 dwords: character | kept << 7 -> {increment u64 (bit 0 = "a base"), per-cycle byte offset,
+                            // k-mer byte offset}
     int l_wl, wl_cap;       // work list of the items with an N among their 12 bases: [0] = count, then wl_cap item numbers
     int l_total;
     // slab (dwords): [cyc canonical: 4 * Cp * N_CLS u64][kmer 4 * KMER_BINS][qh 4 * 128]
@@ -101,7 +104,7 @@ FQ_DEV void stats_item_general(const StatsArgs* ap, u32* lds, int m, int h, int 
         const bool isn = ((n12 >> (4 + k)) & 1u) != 0;
         const int cls = isn ? (int)CLS_N : (int)((codes >> (2 * k)) & 3u);
         const int slot = 2 * m + (j < lk ? 1 : 0);
-        lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + cls) * a.H + h], stats_inc_of(q));
+        lds_add_u64(&cyc[((slot * 8 + k) * N_CLS + cls) * a.Hs + h], stats_inc_of(q));
         lds_add_u32(&qh[(slot * 128 + (int)q) * ST_QH_COPIES], 1u);
         if (((n12 >> k) & 0x1Fu) == 0u) lds_add_u32(&lds[a.l_kmer + slot * KMER_BINS + (int)((c24 >> (2 * k)) & 0x3FFu)], 1u);
     }
@@ -110,7 +113,7 @@ FQ_DEV void stats_item_general(const StatsArgs* ap, u32* lds, int m, int h, int 
 FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
     const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
     const int H = a.H;
-    const u32 H8 = (u32)H * 8u;               // bytes between the classes of one (slot, k)
+    const u32 H8 = (u32)a.Hs * 8u;            // bytes between the classes of one (slot, k)
     const u32 K8 = (u32)N_CLS * H8;           // bytes between the k of one slot
     const u32 S8 = 8u * K8;                   // bytes between slots
     // ---- clear the accumulators, build the character table ----
@@ -124,7 +127,7 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         t[0] = (u32)inc;
         t[1] = (u32)(inc >> 32);
         t[2] = kept ? S8 : 0u;
-        t[3] = (kept ? (u32)(KMER_BINS * 4) : 0u) | (q < 33u ? 0u : 1u);   // k-mer slot offset | the count 1 (0: no base)
+        t[3] = kept ? (u32)(KMER_BINS * 4) : 0u;   // k-mer slot offset; "this is a base" = bit 0 of the increment (its count field)
     }
     block_sync();
     const int u0 = block_id() * a.units_per_block;
@@ -171,16 +174,26 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
             const u32 c24 = s.prev8 | (s.codes << 8);              // bases j0-4 .. j0+7, 2 bits each
             const u32 cyc0 = cyc_m + (u32)s.h * 8u;
             const u32 hpos = s.h > 0 ? 1u : 0u;                    // 5-mers need positions >= 4 (stats.cpp:224-266)
+            // the eight table rows first (independent reads, one round trip), then the adds: an add in between would pin
+            // every later read behind it (the compiler cannot tell the table from the counters)
+            // (four at a time: the workgroup's 64 VGPRs per lane do not hold eight rows)
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const u32 e = bfe(k < 4 ? e0 : e1, 8 * (k & 3), 8);     // character | kept << 7
-                const u32x4 t = lut[e];
-                lds_add_u64((u64*)(ldsw + mul24(bfe(s.codes, 2 * k, 2), H8) + (cyc0 + t.z + (u32)k * K8)), (u64)t.x | ((u64)t.y << 32));
-                const u32 one = k < 4 ? (t.w & hpos) : (t.w & 1u);
-                lds_add_u32((u32*)(ldsw + ((kmer_m + (t.w & ~1u)) + (bfe(c24, 2 * k, 10) << 2))), one);
-                const bool is_mode = e == mode_e;
-                agg_cnt += is_mode ? 1u : 0u;
-                if (!is_mode && (t.w & 1u)) lds_add_u32((u32*)(ldsw + (qh_m + e * (4u * ST_QH_COPIES))), 1u);
+            for (int kb = 0; kb < 8; kb += 4) {
+                u32x4 t[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = lut[bfe(kb ? e1 : e0, 8 * i, 8)];   // character | kept << 7
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = kb + i;
+                    const u32 e = bfe(kb ? e1 : e0, 8 * i, 8);
+                    lds_add_u64((u64*)(ldsw + mul24(bfe(s.codes, 2 * k, 2), H8) + (cyc0 + t[i].z + (u32)k * K8)), (u64)t[i].x | ((u64)t[i].y << 32));
+                    const u32 one = k < 4 ? (t[i].x & hpos) : (t[i].x & 1u);
+                    lds_add_u32((u32*)(ldsw + ((kmer_m + t[i].w) + (bfe(c24, 2 * k, 10) << 2))), one);
+                    const bool is_mode = e == mode_e;
+                    agg_cnt += is_mode ? 1u : 0u;
+                    // character 0 ("no base") lands in bin 0 of the dropped slot, which the flush leaves out
+                    if (!is_mode) lds_add_u32((u32*)(ldsw + (qh_m + e * (4u * ST_QH_COPIES))), 1u);
+                }
             }
         }
         if (mode_e != 0xFFFFFFFFu) {
@@ -210,7 +223,7 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         const int h = pos >> 3, k = pos & 7;
         u32 lo = 0, hi = 0;
         if (h < H) {
-            const int w = a.l_cyc + 2 * (((slot * 8 + k) * N_CLS + cls) * H + h);
+            const int w = a.l_cyc + 2 * (((slot * 8 + k) * N_CLS + cls) * a.Hs + h);
             lo = lds[w];
             hi = lds[w + 1];
         }
@@ -220,7 +233,8 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
     for (int i = tid; i < 4 * KMER_BINS; i += nt) slab[2 * n_cyc + i] = lds[a.l_kmer + i];
     for (int i = tid; i < 4 * 128; i += nt) {
         u32 v = 0;
-        for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
+        if (i & 127)   // bin 0 of a slot collects the "no base" characters of the fast path
+            for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
         slab[2 * n_cyc + 4 * KMER_BINS + i] = v;
     }
 }
