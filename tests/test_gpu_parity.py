@@ -1010,4 +1010,36 @@ def test_gpu_equals_oracle_at_scale_config4_dedup_overrep():
     assert len(bad) == 0, f"{len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
     assert int(co[lay.overrep_count[0]:lay.overrep_count[0] + lay.n_overrep[0]].sum()) > 0, "the overrepresentation counters must move"
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired,L", [(True, 150), (False, 150), (True, 250)])
+def test_gpu_plans_agree(paired, L, monkeypatch):
+    """the benchmark's option family through each kernel plan (lane + stats / scan + stats / fused): the oracle's
+    records and counters from all three"""
+    p = abi.default_params(paired, L)
+    p.cut_right = 1
+    p.poly_g = 1
+    if not paired:
+        p.adapter_seq_r1 = None
+        p.adapter_enabled = 0
+    d = synth.synth_pairs(30000, L=L, seed=61, paired=paired, insert_mean=L * 1.4, insert_sd=L * 0.5, polyg_frac=0.1, dup_frac=0.2)
+    o = oraclelib.Oracle(p)
+    ro, co = o.process(*_args(d, paired)), o.counters()
+    o.close()
+    for env, want in (({}, "lane"), ({"FASTP_GPU_LANE": "0"}, "split"), ({"FASTP_GPU_LANE": "0", "FASTP_GPU_SPLIT": "0"}, "fused")):
+        for k in ("FASTP_GPU_LANE", "FASTP_GPU_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = engines.gpu_engine(p)
+        assert g.plan() == want
+        rg, cg = g.process(*_args(d, paired)), g.counters()
+        g.close()
+        for k in range(3):
+            if ro[k] is not None:
+                bad = np.nonzero(ro[k] != rg[k])[0]
+                assert len(bad) == 0, f"{want}: result {k} differs at {len(bad)} entries, first {bad[:5]}"
+        bad = np.nonzero(co != cg)[0]
+        assert len(bad) == 0, f"{want}: {len(bad)} counters differ, first at {bad[:8]}"
+
+
 

@@ -144,6 +144,36 @@ def test_sim_other_read_lengths_and_tile_shapes(monkeypatch):
         assert np.array_equal(co, cg)
 
 
+@pytest.mark.parametrize("paired,L", [(True, 150), (False, 150), (True, 100)])
+def test_sim_three_kernel_plans_agree(paired, L, monkeypatch):
+    """the benchmark's option family through each plan (lane + stats kernels / scan + stats kernels / fused kernel):
+    the same records and counters as the oracle from all three"""
+    p = abi.default_params(paired, L)
+    p.cut_right = 1
+    p.poly_g = 1
+    if not paired:
+        p.adapter_seq_r1 = None
+        p.adapter_enabled = 0
+    d = synth.synth_pairs(900, L=L, seed=61, paired=paired, insert_mean=L * 1.4, insert_sd=L * 0.5, polyg_frac=0.1, dup_frac=0.2)
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    o = oraclelib.Oracle(p)
+    ro, co = o.process(*args), o.counters()
+    o.close()
+    for env, want in (({}, "lane"), ({"FASTP_GPU_LANE": "0"}, "split"), ({"FASTP_GPU_LANE": "0", "FASTP_GPU_SPLIT": "0"}, "fused")):
+        for k in ("FASTP_GPU_LANE", "FASTP_GPU_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = engines.sim_engine(p)
+        assert g.plan() == want
+        rg, cg = g.process(*args), g.counters()
+        g.close()
+        for k in range(3):
+            if ro[k] is not None:
+                assert ro[k].tobytes() == rg[k].tobytes(), (want, k)
+        assert np.array_equal(co, cg), (want, int((co != cg).sum()))
+
+
 def test_sim_out_of_scope_parameters_fail_loudly():
     """the engine never falls back: parameters outside the device path are errors"""
     for field, value, code in (("max_len", 513, abi.E_TOO_LONG), ("insert_size_max", 5000, abi.E_INVALID),
