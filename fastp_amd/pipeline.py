@@ -219,12 +219,18 @@ class FastqPipeline:
 
     EOF_MEMBER = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")   # bgzip's empty last member
 
-    def _setup_outputs(self, paths):
+    def _setup_outputs(self, paths, umi=None):
         """device + pinned buffers for the streams that are written; paths[q] per abi stream index"""
         torch = self.torch
         nm = len(self.mates)
-        both = nm * self.text_cap + self.max_records * 96          # every record of both mates + tags
-        one = self.text_cap + self.max_records * 64
+        # what a record can grow by over its input text: the UMI name tag (addUmiToName: delimiter + prefix + '_' + the
+        # UMI of one or both mates joined by '_'), the failed / merged tags on the name and the strand line
+        grow = 0
+        if umi:
+            grow = len(umi[3] if len(umi) > 3 and umi[3] else b":") + (len(umi[2]) + 1 if len(umi) > 2 and umi[2] else 0) + \
+                2 * int(umi[1]) + 1
+        both = nm * self.text_cap + self.max_records * (96 + 2 * grow)          # every record of both mates + tags
+        one = self.text_cap + self.max_records * (64 + grow)
         caps = [one, one, both, both, both, both]
         self.out_cap = [0] * abi.N_OUTPUTS
         self.gz_out = [bool(p) and p.endswith(".gz") for p in paths]
@@ -261,7 +267,7 @@ class FastqPipeline:
             raise PipelineError("params trim a UMI off the reads: pass umi=(location, length) for the name edit")
         out_paths = [out1, out2, failed_out, merged_out if self.params.merge else None, unpaired1 if self.paired else None,
                      unpaired2 if self.paired else None]
-        self._setup_outputs(out_paths)
+        self._setup_outputs(out_paths, umi)
         self.fmt_opts = abi.FormatOptions()
         self.fmt_opts.want_failed = int(bool(failed_out))
         self.fmt_opts.want_unpaired1 = int(bool(out_paths[4]))
