@@ -176,13 +176,14 @@ struct fastp_gpu_ctx {
     bool split = false;
     int st_threads = 0, st_blocks = 0;     // the Stats kernel's workgroup size and the most workgroups it is launched with
     int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
-    int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_wl = 0, st_wl_cap = 0;
+    int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
     // lane plan (fq_lane.h): one lane per pair, reads in registers - the option family lane_plan_supported() admits
     bool lane = false;
     int ln_swm = 0, ln_blocks = 0;
     LaneLds ln_lds;
     u32* d_ln_slabs = nullptr;
+    int* d_ln_ctr = nullptr;       // the lane kernel's chunk counter
     u32* d_swin[2] = {nullptr, nullptr}; size_t swin_cap = 0;
     hipStream_t stream = nullptr;
     // Duplicate's probe + resolve of launch k run beside the fused kernel of launch k + 1 (see launch_chunk): the fused
@@ -317,7 +318,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
-                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs};
+                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -443,7 +444,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         if (env_int("FASTP_GPU_STATS_PAD", 1) && ctx->st_H < 32) ctx->st_Hs = 32;
         ctx->st_wl_cap = ctx->st_Hs > ctx->st_H ? 511 : 2047;
         for (;;) {
-            const int bytes = (4 * 8 * N_CLS * ctx->st_Hs * 2 + 4 * KMER_BINS + ST_QH_COPIES * 4 * 128 + 4 * 256 + 1 + ctx->st_wl_cap + 3) * 4;
+            const int bytes = (4 * 8 * N_CLS * ctx->st_Hs * 2 + 4 * KMER_BINS + ST_QH_COPIES * 4 * 128 + 4 * 256 + 20 + 1 + ctx->st_wl_cap + 3) * 4;
             if (ctx->st_Hs == ctx->st_H || 2 * bytes <= 160 * 1024) break;
             ctx->st_Hs = ctx->st_H;
             ctx->st_wl_cap = 2047;
@@ -454,6 +455,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->st_l_qh = o; o += ST_QH_COPIES * 4 * 128;
         o = (o + 3) & ~3;
         ctx->st_l_lut = o; o += 4 * 256;
+        ctx->st_l_mt = o; o += 18 + 2;
         ctx->st_l_wl = o; o += 1 + ctx->st_wl_cap;
         ctx->st_lds_dwords = o;
         ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
@@ -582,6 +584,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_blocks * ctx->st_slab_dwords * 4));
         if (ctx->lane) {
             CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
+            if (env_int("FASTP_GPU_LANE_DYNAMIC", 1)) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_ctr, sizeof(int)));
             for (int Bh : {0, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0})
                 CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, ctx->ln_lds.total * 4));
@@ -1031,6 +1034,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.k.slabs = ctx->d_ln_slabs;
             la.k.slab_dwords = ctx->ln_lds.n_misc;
             la.l = ctx->ln_lds;
+            la.chunk_ctr = ctx->d_ln_ctr;
+            if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
             lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0);
             ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
@@ -1059,7 +1064,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.units_per_block = upb;
         st_grid = (n + upb - 1) / upb;
         for (int m = 0; m < 2; m++) { sa.seq[m] = a.seq[m]; sa.qual[m] = a.qual[m]; sa.swin[m] = ctx->d_swin[m]; }
-        sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut;
+        sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut; sa.l_mt = ctx->st_l_mt;
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
         sa.l_total = ctx->st_lds_dwords;
         sa.slabs = ctx->d_st_slabs;

@@ -180,6 +180,9 @@ FQ_DEV u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi
 // 24-bit x 24-bit -> low 32 bits (full-rate v_mul_u32_u24)
 FQ_DEV u32 mul24(u32 a, u32 b) { return __umul24(a, b); }
 FQ_DEV u32 sum_bytes(u32 a, u32 c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
+// four sliding 4-byte sums at once: 16-bit field i = bytes i .. i+3 of the 64-bit value {hi, lo} summed, plus field i of acc
+// -> v_qsad_pk_u16_u8 against zero
+FQ_DEV u64 sum_bytes_sliding4(u32 lo, u32 hi, u64 acc) { return __builtin_amdgcn_qsad_pk_u16_u8((u64)lo | ((u64)hi << 32), 0u, acc); }
 // (v >> off) & ((1 << width) - 1)  -> v_bfe_u32 (kept as one instruction next to the shift-add that uses it)
 FQ_DEV u32 bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe(v, off, width); }
 // c + sum of the four byte products a.b[k] * b.b[k]  -> v_dot4_u32_u8

@@ -43,6 +43,8 @@ struct LaneLds {
 struct LaneArgs {
     KernelArgs k;   // parameters, batch, result arrays (the LDS layout inside is not used)
     LaneLds l;
+    int* chunk_ctr; // zero at launch: chunks beyond every wave's first are handed out by this counter (a static stride
+                    // leaves a third of the waves one chunk short at 21.3 chunks per wave); nullptr = static stride
 };
 
 // ---------------------------------------------------------------------------
@@ -211,6 +213,21 @@ FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int 
 // bit j of the result = the window that starts at base j of this 32-base word (q[0..7] its quality dwords, q[8..9] the
 // two behind them) has total quality < threshold: v_alignbit (the window's bytes), v_sad_u8 with -threshold as the
 // addend, v_alignbit to shift the sign into the mask.  WIDE: windows of 5..8 bases need a second v_sad_u8.
+// windows of exactly four bases (the default --cut_right_window_size): v_qsad_pk_u16_u8 sums four consecutive windows per
+// instruction; nthr4 = the negated threshold in each 16-bit field, so a field's sign bit says "window sum < threshold"
+FQ_DEV u32 lane_window_word4(const u32 (&q)[10], u64 nthr4) {
+    u32 m = 0;
+#pragma unroll
+    for (int d = 7; d >= 0; d--) {
+        const u64 s = sum_bytes_sliding4(q[d] & 0x7F7F7F7Fu, q[d + 1] & 0x7F7F7F7Fu, nthr4);
+        const u32 lo = (u32)s, hi = (u32)(s >> 32);
+        m = alignbit(m, hi, 31);         // window 4d + 3
+        m = alignbit(m, hi << 16, 31);   //        4d + 2
+        m = alignbit(m, lo, 31);         //        4d + 1
+        m = alignbit(m, lo << 16, 31);   //        4d
+    }
+    return m;
+}
 template <bool WIDE>
 FQ_DEV u32 lane_window_word(const u32 (&q)[10], u32 keep_lo, u32 keep_hi, u32 nthr) {
     u32 m = 0;
@@ -257,6 +274,7 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
     lane_stage_rows(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
     const u64* qrow = (const u64*)(stage + lane * qwg);
     const u32 nthr = (u32)(-thr);
+    const u64 nthr4 = 0x0001000100010001ull * (u64)(nthr & 0xFFFFu);
     const u32 keep_lo = lowmask32(8 * imin(imax(win, 1), 4)), keep_hi = win > 4 ? lowmask32(8 * (win - 4)) : 0u;
     u32 anyn = 0;
     // Eight dwords (one 32-position mask word) at a time from the END of the row: the window predicate of word W looks
@@ -281,14 +299,14 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
 #pragma unroll
         for (int d = 7; d >= 0; d--) {
             const u32 b1 = (q[d] >> 7) & 0x01010101u;   // bits 0, 8, 16, 24
-            const u32 m4 = (b1 | (b1 >> 7) | (b1 >> 14) | (b1 >> 21)) & 0xFu;
-            nw = (nw << 4) | m4;
+            nw = dot4_u8(b1, 0x08040201u, nw << 4);     // the four flags as a nibble behind the ones gathered so far
         }
         r.n[W] = nw;
         anyn |= nw;
         // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
         u32 m = 0;
-        if (win > 4) m = lane_window_word<true>(q, keep_lo, keep_hi, nthr);        // uniform
+        if (win == 4) m = lane_window_word4(q, nthr4);                             // uniform
+        else if (win > 4) m = lane_window_word<true>(q, keep_lo, keep_hi, nthr);
         else if (win > 0) m = lane_window_word<false>(q, keep_lo, keep_hi, nthr);
         r.bad[W] = m;
         FQ_LANE_FENCE();   // one mask word at a time: the scheduler would otherwise keep every word's dwords in flight
@@ -520,7 +538,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const int thr = p.cut_right ? p.thrR : p.thrT;
     const int chunks = (a.n + 63) >> 6;
     const int wpb = nt >> 6;
-    for (int chunk = block_id() * wpb + (tid >> 6); chunk < chunks; chunk += grid_blocks() * wpb) {   // wave-uniform
+    const int nstatic = grid_blocks() * wpb;
+    int nx = 0;
+    for (int chunk = block_id() * wpb + (tid >> 6); chunk < chunks;
+         chunk = la.chunk_ctr ? nstatic + (int)shfl((u32)nx, 0) : chunk + nstatic) {   // wave-uniform
+        if (la.chunk_ctr && lane == 0) nx = g_atomic_add_i32(la.chunk_ctr, 1);   // the next chunk's number, looked at in the loop header
         const int gp = chunk * 64 + lane;
         const bool valid = gp < a.n;
         const int rows = imin(64, a.n - chunk * 64);

@@ -41,6 +41,7 @@ struct StatsArgs {
                             // serialise; the copies of a bin sit in consecutive banks)
     int l_lut;              // [256] x 4 dwords: character | kept << 7 -> {increment u64 (bit 0 = "a base"), per-cycle byte offset,
                             // k-mer byte offset}
+    int l_mt;               // [9] x 2 dwords: the byte masks "first i of 8 bytes"
     int l_wl, wl_cap;       // work list of the items with an N among their 12 bases: [0] = count, then wl_cap item numbers
     int l_total;
     // slab (dwords): [cyc canonical: 4 * Cp * N_CLS u64][kmer 4 * KMER_BINS][qh 4 * 128]
@@ -66,12 +67,11 @@ struct StatsItem {
 FQ_DEV void stats_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, int it, bool tv, StatsItem& s) {
     const u32 ur = fastdiv((u32)(tv ? it : 0), a.magic_H);
     s.h = (tv ? it : 0) - (int)ur * a.H;
-    const u32 sw = tv ? swin[ur] : 0u;
-    s.rl0 = (int)(sw & 0xFFFFu);
-    s.lk = (int)(sw >> 16);
-    s.act = tv && 8 * s.h < s.rl0;
+    u32 sw = 0;
     s.q0 = s.q1 = s.qp = s.codes = s.prev8 = 0;
-    if (s.act) {   // the item's 8 quality bytes and 8 bases, the 4 of each before them
+    if (tv) {   // the item's 8 quality bytes and 8 bases, the 4 of each before them - all loads independent of each other:
+                // the bytes of a row behind its read are zeros (fastp_gpu.h), i.e. "no base" characters, whatever swin says
+        sw = swin[ur];
         const u64 qq = ((const u64*)qual)[(u32)it];
         s.q0 = (u32)qq;
         s.q1 = (u32)(qq >> 32);
@@ -82,6 +82,9 @@ FQ_DEV void stats_fetch(const StatsArgs& a, const u32* qual, const u32* seq, con
             s.prev8 = (u32)((const u8*)seq)[sb - 1u];
         }
     }
+    s.rl0 = (int)(sw & 0xFFFFu);
+    s.lk = (int)(sw >> 16);
+    s.act = tv && 8 * s.h < s.rl0;
 }
 
 // an item with an N among its 8 bases or the 4 before: base by base (dense pass over the work list)
@@ -129,6 +132,10 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         t[2] = kept ? S8 : 0u;
         t[3] = kept ? (u32)(KMER_BINS * 4) : 0u;   // k-mer slot offset; "this is a base" = bit 0 of the increment (its count field)
     }
+    for (int i = tid; i < 9; i += nt) {
+        lds[a.l_mt + 2 * i] = lowmask32(8 * imin(i, 4));
+        lds[a.l_mt + 2 * i + 1] = lowmask32(8 * imax(0, i - 4));
+    }
     block_sync();
     const int u0 = block_id() * a.units_per_block;
     const int nu = imax(0, imin(a.units_per_block, a.n - u0));
@@ -136,6 +143,7 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
     u8* ldsw = (u8*)lds;
     const u32x4* lut = (const u32x4*)__builtin_assume_aligned(lds + a.l_lut, 16);
     u32* wl = lds + a.l_wl;
+    const u32x2* mt = (const u32x2*)__builtin_assume_aligned(lds + a.l_mt, 8);
     for (int m = 0; m < (a.paired ? 2 : 1); m++) {   // uniform: a mate's arrays and accumulator bases sit in scalar registers
         const u32* qual = a.qual[m] + (size_t)u0 * a.qw_g;
         const u32* seq = a.seq[m] + (size_t)u0 * a.sw_g;
@@ -164,8 +172,8 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
             // here) becomes "kept", a byte past the read's end becomes character 0 = "no base": it adds nothing
             const int j0 = 8 * s.h;
             const int nv = plain ? s.rl0 - j0 : 0, nk = s.lk - j0;   // not plain: eight "no base" characters
-            const u32 v0 = lowmask32(8 * imax(0, imin(nv, 4))), v1 = lowmask32(8 * imax(0, imin(nv - 4, 4)));
-            const u32 k0 = lowmask32(8 * imax(0, imin(nk, 4))) & 0x80808080u, k1 = lowmask32(8 * imax(0, imin(nk - 4, 4))) & 0x80808080u;
+            const u32x2 vm = mt[imax(0, imin(nv, 8))], km = mt[imax(0, imin(nk, 8))];   // byte masks from a 9-row table
+            const u32 v0 = vm.x, v1 = vm.y, k0 = km.x & 0x80808080u, k1 = km.y & 0x80808080u;
             const u32 e0 = (s.q0 | k0) & v0, e1 = (s.q1 | k1) & v1;
             if (mode_e == 0xFFFFFFFFu) {                           // wave-uniform
                 const u64 cand = ballot(plain);

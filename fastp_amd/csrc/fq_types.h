@@ -11,6 +11,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 struct alignas(16) u32x4 { u32 x, y, z, w; };
+struct alignas(8) u32x2 { u32 x, y; };
 
 // ---- 2-bit base code (also the order of fastp's k-mer code, stats.cpp:294-311,
 //      so complement(code) == code ^ 1 and the 5-mer index needs no remapping

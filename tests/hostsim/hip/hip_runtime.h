@@ -109,6 +109,20 @@ static inline int sim_update_dpp(int old, int src, int ctrl, int row_mask, int b
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) sim_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_alignbit(hi, lo, s) sim_alignbit((hi), (lo), (s))
 #define __builtin_amdgcn_sad_u8(a, b, c) sim_sad_u8((a), (b), (c))
+// v_qsad_pk_u16_u8: field i (16 bits) = SAD of the four bytes of s0 >> 8i against the bytes of s1, plus field i of acc
+static inline unsigned long long sim_qsad_pk_u16_u8(unsigned long long s0, unsigned int s1, unsigned long long acc) {
+    unsigned long long out = 0;
+    for (int i = 0; i < 4; i++) {
+        unsigned int sad = 0;
+        for (int k = 0; k < 4; k++) {
+            const int a = (int)((s0 >> (8 * (i + k))) & 0xFFu), b = (int)((s1 >> (8 * k)) & 0xFFu);
+            sad += (unsigned int)(a > b ? a - b : b - a);
+        }
+        out |= (unsigned long long)((sad + (unsigned int)((acc >> (16 * i)) & 0xFFFFu)) & 0xFFFFu) << (16 * i);
+    }
+    return out;
+}
+#define __builtin_amdgcn_qsad_pk_u16_u8(s0, s1, acc) sim_qsad_pk_u16_u8((s0), (s1), (acc))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() sim::wave_barrier()
 
