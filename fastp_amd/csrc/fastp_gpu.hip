@@ -184,6 +184,9 @@ struct fastp_gpu_ctx {
     LaneLds ln_lds;
     u32* d_ln_slabs = nullptr;
     int* d_ln_ctr = nullptr;       // the lane kernel's chunk counter
+    // split plans: Duplicate's losers / winners / finish kernels of a launch run on this stream beside its Stats kernel
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_k1 = nullptr, ev_tail = nullptr;
     u32* d_swin[2] = {nullptr, nullptr}; size_t swin_cap = 0;
     hipStream_t stream = nullptr;
     // Duplicate's probe + resolve of launch k run beside the fused kernel of launch k + 1 (see launch_chunk): the fused
@@ -321,6 +324,9 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -582,6 +588,11 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_blocks * ctx->st_slab_dwords * 4));
+        if (env_int("FASTP_GPU_DUP_OVERLAP", 1)) {
+            CREATE_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
+            CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
+        }
         if (ctx->lane) {
             CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
             if (env_int("FASTP_GPU_LANE_DYNAMIC", 1)) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_ctr, sizeof(int)));
@@ -1045,6 +1056,17 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
     }
     HIP_TRY(ctx, hipGetLastError());
+    // the claim ran inside that kernel: what is left of Duplicate (losers / winners / finish) needs nothing of the Stats
+    // kernel and runs beside it on its own stream; the launch stream joins it before anything else touches the records
+    bool dup_tail_launched = false;
+    if (ctx->split && ctx->tail && dup_prepared && n > 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
+        rc = launch_dup(nullptr, mode == CHUNK_PASS1, ctx->tail, 2);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
+        dup_tail_launched = true;
+    }
     int st_grid = 0;
     if (ctx->split && n > 0) {
         // Stats::statRead of the launch's units: a workgroup takes a run of consecutive units (at most CYC_MAX_READS:
@@ -1093,7 +1115,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
     r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
     const int n_stats = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128, n_misc = MISC_ISIZE + ctx->dp.isize_max + 1;
-    auto fold = [&](int parts, int nblocks) -> int {
+    auto fold = [&](int parts, int nblocks, hipStream_t st) -> int {
         if (nblocks <= 0) return 0;
         r.parts = parts;
         r.nblocks = nblocks;
@@ -1111,14 +1133,16 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         r.off_qh = r.off_kmer + 4 * KMER_BINS;
         r.qh_stride = 1;
         r.qh_count = 0;
-        rc = fold(1, st_grid);
+        rc = fold(1, st_grid, st);
         if (rc) return rc;
         // the per-read kernel's slabs: the MISC_* counters only
         r.slabs = use_lane ? ctx->d_ln_slabs : ctx->d_slabs;
         r.slab_dwords = use_lane ? ctx->ln_lds.n_misc : ctx->slab_dwords;
         r.off_misc = use_lane ? 0 : ctx->L.acc_misc - ctx->L.acc_cyc;
-        rc = fold(2, use_lane ? ln_grid : grid);
+        // (needs nothing of the Stats kernel either: beside it, behind Duplicate's tail, when that stream is in use)
+        rc = fold(2, use_lane ? ln_grid : grid, dup_tail_launched ? ctx->tail : st);
         if (rc) return rc;
+        if (dup_tail_launched) HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
     } else {
         r.slabs = ctx->d_slabs;
         r.slab_dwords = ctx->slab_dwords;
@@ -1127,7 +1151,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         r.qh_stride = QT_DWORDS;
         r.qh_count = QT_COUNT;
         r.off_misc = ctx->L.acc_misc - ctx->L.acc_cyc;
-        rc = fold(3, grid);
+        rc = fold(3, grid, st);
         if (rc) return rc;
     }
 
@@ -1143,6 +1167,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         ctx->last_res[0] = a.res[0];
         ctx->last_res[1] = (const char*)a.res[0] + (size_t)n * sizeof(fastp_gpu_read_result);
         ctx->launch_seq++;
+    } else if (dup_tail_launched) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_tail, 0));
     } else if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
         rc = launch_dup(nullptr, mode == CHUNK_PASS1, nullptr, dup_prepared ? 2 : 0);
         if (rc) return rc;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Duplicate's tail kernels beside the Stats kernel (second stream) on/off
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:-ab6}
+OUT=gpurun_out/ab_$TAG.txt
+: > $OUT
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "equals_oracle or plans_agree or dup or stream or baseline_scale" > gpurun_out/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/pytest_$TAG.log
+run() { NAME=$1; shift; env "$@" timeout 300 python bench.py --steps 48 --warmup 8 --batches 8 --no-cpu --no-extras > gpurun_out/ab_${TAG}_$NAME.log 2>&1; tail -1 gpurun_out/ab_${TAG}_$NAME.log | python -c "import sys,json; j=json.loads(sys.stdin.read()); r=j['roofline']; print('$NAME', j['value'], 'Mreads/s step', j['ms_per_step'], 'kernels', r['kernel_avg_ms'], 'ms per', r['pairs_per_launch'])" | tee -a $OUT; }
+for rep in 1 2; do
+run overlap_default
+run overlap_off FASTP_GPU_DUP_OVERLAP=0
+done
