@@ -86,6 +86,13 @@ def random_case(seed):
         abi.set_overrep(p, s1, s2, e1, e2, int(rng.choice([1, 2, 7, 20])))
     if pick(0.15) and p.adapter_enabled:
         abi.set_adapter_fasta(p, [b"CTGTCTCTTATACACATCT", b"AGATCGGAAGAGC", b"TGGAATTCTCGGGTGCCAAGG"][:int(rng.integers(1, 4))])
+    # (drawn last so that the earlier seeds keep their cases) --overlapped_out; adapters longer than 64 bases
+    if paired and not p.merge and pick(0.2):
+        p.overlapped_out = 1
+    if p.adapter_enabled and p.adapter_seq_r1 and pick(0.15):
+        p.adapter_seq_r1 = cases.LONG_R1.encode()
+        if paired:
+            p.adapter_seq_r2 = cases.LONG_R2.encode()
     return p, d, paired
 
 
