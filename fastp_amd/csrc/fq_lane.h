@@ -18,6 +18,9 @@
 #pragma once
 #include "fq_device.h"
 
+#ifndef FQ_LANE_STAGE_BATCH
+#define FQ_LANE_STAGE_BATCH 10
+#endif
 #ifdef FQ_LANE_NO_FENCE      // A/B switch (tools/gpu_lane_ab3.sh)
 #define FQ_LANE_FENCE() ((void)0)
 #else
@@ -202,10 +205,21 @@ FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, co
 FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int lane) {
     wave_order();   // the buffer's previous contents have been read
     const int bytes = rows * stride * 4;
-    const u32x4* s4 = (const u32x4*)src;
-    u32x4* d4 = (u32x4*)buf;
+    typedef u32 vec16 __attribute__((vector_size(16)));   // (a register value: an array of the u32x4 struct stays in scratch)
+    const vec16* s4 = (const vec16*)src;
+    vec16* d4 = (vec16*)buf;
     const int n16 = bytes >> 4;
-    for (int i = lane; i < n16; i += 64) d4[i] = s4[i];
+    // FQ_LANE_STAGE_BATCH vectors per lane are in flight before the first is stored (clamped indices instead of
+    // branches): as a plain copy loop every 1 KB piece waited for its own round trip to memory - ten per quality stage
+    for (int base = lane; base - lane < n16; base += 64 * FQ_LANE_STAGE_BATCH) {
+        vec16 v[FQ_LANE_STAGE_BATCH];
+#pragma unroll
+        for (int k = 0; k < FQ_LANE_STAGE_BATCH; k++) v[k] = s4[imin(base + 64 * k, n16 - 1)];
+        sched_fence();   // (the scheduler sinks each load to its store otherwise)
+#pragma unroll
+        for (int k = 0; k < FQ_LANE_STAGE_BATCH; k++)
+            if (base + 64 * k < n16) d4[base + 64 * k] = v[k];
+    }
     if ((bytes & 8) && lane == 0) ((u64*)buf)[2 * n16] = ((const u64*)src)[2 * n16];
     wave_order();
 }
