@@ -202,6 +202,7 @@ FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, co
 // 8-byte load: the rows of 12 resident wavefronts do not fit the 32 KB L1, so nearly every load refetched its line
 // from L2 (profiles/r03e: the load sweep alone took 1.0 ms per 4 M pairs).  Row r of the buffer starts at dword
 // r * stride: stride / 2 is odd for the common read lengths, so the 64-bit row reads of a half-wave are conflict-free.
+template <int NB>   // vectors per lane in flight: what one stage of the caller's rows needs, so that it is one round trip
 FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int lane) {
     wave_order();   // the buffer's previous contents have been read
     const int bytes = rows * stride * 4;
@@ -209,15 +210,15 @@ FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int 
     const vec16* s4 = (const vec16*)src;
     vec16* d4 = (vec16*)buf;
     const int n16 = bytes >> 4;
-    // FQ_LANE_STAGE_BATCH vectors per lane are in flight before the first is stored (clamped indices instead of
+    // NB vectors per lane are in flight before the first is stored (clamped indices instead of
     // branches): as a plain copy loop every 1 KB piece waited for its own round trip to memory - ten per quality stage
-    for (int base = lane; base - lane < n16; base += 64 * FQ_LANE_STAGE_BATCH) {
-        vec16 v[FQ_LANE_STAGE_BATCH];
+    for (int base = lane; base - lane < n16; base += 64 * NB) {
+        vec16 v[NB];
 #pragma unroll
-        for (int k = 0; k < FQ_LANE_STAGE_BATCH; k++) v[k] = s4[imin(base + 64 * k, n16 - 1)];
+        for (int k = 0; k < NB; k++) v[k] = s4[imin(base + 64 * k, n16 - 1)];
         sched_fence();   // (the scheduler sinks each load to its store otherwise)
 #pragma unroll
-        for (int k = 0; k < FQ_LANE_STAGE_BATCH; k++)
+        for (int k = 0; k < NB; k++)
             if (base + 64 * k < n16) d4[base + 64 * k] = v[k];
     }
     if ((bytes & 8) && lane == 0) ((u64*)buf)[2 * n16] = ((const u64*)src)[2 * n16];
@@ -274,7 +275,7 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
     r.rl0 = valid ? (int)lenp[g] : 0;
     r.len = r.rl0;
     r.flags = 0;
-    lane_stage_rows(stage, seq + (size_t)chunk0 * swg, rows, swg, lane);
+    lane_stage_rows<(SWM + 3) / 4>(stage, seq + (size_t)chunk0 * swg, rows, swg, lane);
     {
         const u64* srow = (const u64*)(stage + lane * swg);
 #pragma unroll
@@ -285,7 +286,7 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
             r.s[w + 1] = (u32)(v >> 32);
         }
     }
-    lane_stage_rows(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
+    lane_stage_rows<FQ_LANE_STAGE_BATCH>(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
     const u64* qrow = (const u64*)(stage + lane * qwg);
     const u32 nthr = (u32)(-thr);
     const u64 nthr4 = 0x0001000100010001ull * (u64)(nthr & 0xFFFFu);
@@ -334,8 +335,10 @@ FQ_DEV u32 g_code(const u32* seq, int swg, int g, int j) { return (u32)(((const 
 
 // Filter::trimAndCut (filter.cpp:68-207) for the option family of this kernel: no front trim, no cut_front; cut_right
 // or cut_tail (windows <= 8) and a fixed tail trim.  Returns false for NULL; `len` in / out.
+// qrow: the lane's quality row in the wave's LDS stage (lane_load_read leaves it there) - the two short walks below
+// are chains of dependent byte reads, a round trip to memory each when they went to the global row
 template <int SWM>
-FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const u32* qual, int g, int tail, int& len) {
+FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const u8* qrow, int tail, int& len) {
     const DevParams& p = a.p;
     const bool enT = p.cut_tail, enR = p.cut_right;
     const int l = len;
@@ -350,7 +353,7 @@ FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const
         int s = mask_first<SWM / 2>(r.bad, 0, end, true);       // first window below the threshold
         if (s < end) {                                          // foundLowQualWindow: while (s < l-1 && qual[s] >= 33+Q) s++
             const u32 qmin = (u32)imin(imax(p.qRmin, 0), 127);
-            while (s < l - 1 && (g_qbyte(qual, p.qw_g, g, s) & 0x7Fu) >= qmin) s++;
+            while (s < l - 1 && ((u32)qrow[s] & 0x7Fu) >= qmin) s++;
             rlen = s;
         }
     }
@@ -360,7 +363,7 @@ FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const
         const int sp = mask_last<SWM / 2>(r.bad, 1, l - tail - w + 1, false);   // none: 0 (= front)
         int t = sp + w - 1;
         if (t < l - 1) t = t - w + 1;
-        while (t >= 0 && (g_qbyte(qual, p.qw_g, g, t) & 0x80u)) t--;            // while (t >= 0 && seq[t] == 'N') t--
+        while (t >= 0 && ((u32)qrow[t] & 0x80u)) t--;                           // while (t >= 0 && seq[t] == 'N') t--
         rlen = t + 1;
     }
     if (rlen <= 0 || 0 >= l - 1) return false;                  // :196-197 (front == 0)
@@ -368,17 +371,52 @@ FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const
     return true;
 }
 
-// PolyX::trimPolyG (polyx.cpp:16-42) on [0, rlen): new length
-FQ_DEV int lane_trim_poly_g(const KernelArgs& a, const u32* seq, const u32* qual, int g, int rlen, int compareReq) {
+// word idx of a register array, idx per lane (0 outside the array): a compare + select per word
+template <int N>
+FQ_DEV u32 lane_word_at(const u32 (&a)[N], int idx) {
+    u32 v = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) v = idx == k ? a[k] : v;
+    return v;
+}
+// the 32 bases [end - 32, end) of the read in registers as "is a G" flags: bit 2 * (31 - t) <=> base end - 1 - t is a G
+// (bases before the read's start: 0)
+template <int SWM>
+FQ_DEV u64 lane_g_window(const LaneRead<SWM>& r, int end) {
+    const int b0 = end - 32;
+    const int w0 = b0 >> 4;                        // floor: negative for windows that start before the read
+    const u32 sh = (u32)(b0 & 15) * 2u;
+    const u32 A = lane_word_at<SWM>(r.s, w0), B = lane_word_at<SWM>(r.s, w0 + 1), C = lane_word_at<SWM>(r.s, w0 + 2);
+    const u32 lo = alignbit(B, A, sh), hi = alignbit(C, B, sh);
+    // G = code 3 = both bits of the group; an N is stored as code 0 (fastp_gpu.h), so its group never shows a G
+    const u32 glo = lo & (lo >> 1) & 0x55555555u, ghi = hi & (hi >> 1) & 0x55555555u;
+    return (u64)glo | ((u64)ghi << 32);
+}
+// PolyX::trimPolyG (polyx.cpp:16-42) on [0, rlen): new length.  The walk from the tail runs on 32-base windows taken
+// from the read's registers (as a walk over the global rows it was a round trip to memory per base, ten at least)
+template <int SWM>
+FQ_DEV int lane_trim_poly_g(const LaneRead<SWM>& r, bool active, int rlen, int compareReq) {
     int mismatch = 0, i = 0, firstGPos = rlen - 1;
-    for (i = 0; i < rlen; i++) {
-        const int j = rlen - i - 1;
-        const bool isn = (g_qbyte(qual, a.p.qw_g, g, j) & 0x80u) != 0;
-        if (isn || g_code(seq, a.p.sw_g, g, j) != (u32)CODE_G) mismatch++;
-        else firstGPos = rlen - i - 1;
-        const int allowed = (i + 1) / 8;
-        if (mismatch > 5 || (mismatch > allowed && i >= compareReq - 1)) break;
+    bool done = !active || rlen <= 0;
+    for (int k = 0; ballot(!done) != 0ull; k++) {   // wave-uniform
+        const u64 gw = lane_g_window<SWM>(r, rlen - 32 * k);
+        for (int t = 0; t < 32; t++) {
+            if (ballot(!done) == 0ull) break;
+            if (!done) {
+                if (i >= rlen) {
+                    done = true;                     // the loop ran out: i == rlen
+                } else {
+                    const bool isg = ((gw >> (62 - 2 * t)) & 1ull) != 0ull;
+                    if (!isg) mismatch++;
+                    else firstGPos = rlen - i - 1;
+                    const int allowed = (i + 1) / 8;
+                    if (mismatch > 5 || (mismatch > allowed && i >= compareReq - 1)) done = true;   // break: i stays
+                    else i++;
+                }
+            }
+        }
     }
+    if (!active) return rlen;
     if (i >= compareReq && firstGPos >= 0) return firstGPos;
     return rlen;
 }
@@ -476,7 +514,7 @@ template <int SWM>
 FQ_DEV void lane_metrics(const KernelArgs& a, u32* stage, const u32* qual, int chunk0, int rows, int lane, bool valid, int len, int& tot,
                          int& low, int& nb) {
     const int qwg = a.p.qw_g;
-    lane_stage_rows(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
+    lane_stage_rows<FQ_LANE_STAGE_BATCH>(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
     const u64* qrow = (const u64*)(stage + lane * qwg);
     const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
     u32 t = 0, lo = 0, n = 0;
@@ -565,11 +603,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         LaneRead<SWM> r1, r2;
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
         lane_load_read<SWM>(a, stage, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, r1);
-        if (valid && !lane_trim_and_cut<SWM>(a, r1, a.qual[0], g, p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
+        if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
         if (PAIRED) {
             lane_load_read<SWM>(a, stage, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, r2);
-            if (valid && !lane_trim_and_cut<SWM>(a, r2, a.qual[1], g, p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
+            if (valid && !lane_trim_and_cut<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
             sched_fence();
         }
         if (a.dupflag && valid && a.dupflag[g]) {   // --dedup: Duplicate::checkPair/checkRead already ran for this batch
@@ -596,9 +634,9 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         // ---- PolyX::trimPolyG ----
         const bool a1 = valid && !(r1.flags & RS_NULL), a2 = PAIRED ? (valid && !(r2.flags & RS_NULL)) : a1;
         const bool both = a1 && a2;
-        if (p.poly_g && both) {   // both mates survived trimAndCut (peprocessor.cpp:428-431)
-            r1.len = lane_trim_poly_g(a, a.seq[0], a.qual[0], g, r1.len, p.poly_g_min);
-            if (PAIRED) r2.len = lane_trim_poly_g(a, a.seq[1], a.qual[1], g, r2.len, p.poly_g_min);
+        if (p.poly_g) {   // (uniform) a pair's mates are trimmed when both survived trimAndCut (peprocessor.cpp:428-431)
+            r1.len = lane_trim_poly_g<SWM>(r1, both, r1.len, p.poly_g_min);
+            if (PAIRED) r2.len = lane_trim_poly_g<SWM>(r2, both, r2.len, p.poly_g_min);
         }
         u32 apos1 = 0, alen1 = 0, apos2 = 0, alen2 = 0;
         bool dimer = false;

@@ -1011,6 +1011,35 @@ def test_gpu_equals_oracle_at_scale_config4_dedup_overrep():
     assert int(co[lay.overrep_count[0]:lay.overrep_count[0] + lay.n_overrep[0]].sum()) > 0, "the overrepresentation counters must move"
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("paired,L,minlen", [(False, 150, 10), (True, 150, 10), (True, 100, 5), (False, 250, 14)])
+def test_gpu_polyg_tails_of_every_length(paired, L, minlen):
+    """trimPolyG on G runs from 0 to the whole read (the lane kernel walks 32-base windows of the read's registers)"""
+    from test_hostsim_parity import _polyg_tail_reads
+    p = abi.default_params(paired, L)
+    p.poly_g, p.poly_g_min_len = 1, minlen
+    p.adapter_enabled = 0
+    if not paired:
+        p.adapter_seq_r1 = None
+    s1, q1, l1 = _polyg_tail_reads(20000, L, 71)
+    args = (s1, q1, l1)
+    if paired:
+        args += _polyg_tail_reads(20000, L, 72)
+    o = oraclelib.Oracle(p)
+    g = engines.gpu_engine(p)
+    assert g.plan() == "lane"
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    assert int((l1 - ro[0]["len"] > 40).sum()) > 1000
+    for k in range(3):
+        if ro[k] is not None:
+            bad = np.nonzero(ro[k] != rg[k])[0]
+            assert len(bad) == 0, f"result {k} differs at {len(bad)} entries, first {bad[:5]}"
+    assert np.array_equal(co, cg)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("paired,L", [(True, 150), (False, 150), (True, 250)])
 def test_gpu_plans_agree(paired, L, monkeypatch):
     """the benchmark's option family through each kernel plan (lane + stats / scan + stats / fused): the oracle's

@@ -174,6 +174,55 @@ def test_sim_three_kernel_plans_agree(paired, L, monkeypatch):
         assert np.array_equal(co, cg), (want, int((co != cg).sum()))
 
 
+def _polyg_tail_reads(n, L, seed):
+    """reads that end in G runs of 0 .. L bases with a few other bases sprinkled in (PolyX::trimPolyG's mismatch rules),
+    some entirely G, lengths ragged"""
+    rng = np.random.default_rng(seed)
+    stride = (L + 7) // 8 * 8
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, stride))]
+    run = np.minimum(rng.integers(0, L + 30, size=n), L)
+    run = np.where(rng.random(n) < 0.3, rng.integers(0, 40, size=n), run)
+    lens = np.where(rng.random(n) < 0.3, rng.integers(1, L + 1, size=n), L).astype(np.int32)
+    j = np.arange(stride)[None, :]
+    in_run = (j >= (lens - run)[:, None]) & (j < lens[:, None])
+    noise = rng.random((n, stride)) < rng.choice([0.0, 0.05, 0.12, 0.3], size=(n, 1))
+    seq = np.where(in_run & ~noise, ord("G"), seq).astype(np.uint8)
+    seq = np.where(rng.random((n, stride)) < 0.01, ord("N"), seq).astype(np.uint8)
+    qual = rng.integers(35, 41, size=(n, stride)).astype(np.uint8) + 33
+    seq[j >= lens[:, None]] = 0
+    qual[j >= lens[:, None]] = 0
+    return seq, qual, lens
+
+
+@pytest.mark.parametrize("paired,L,minlen", [(False, 150, 10), (True, 150, 10), (True, 100, 5), (False, 250, 14)])
+def test_sim_polyg_tails_of_every_length(paired, L, minlen):
+    """trimPolyG on G runs from 0 to the whole read, with mismatches inside the run: the lane kernel walks 32-base
+    windows of the read's registers; runs longer than a window take the outer loop"""
+    p = abi.default_params(paired, L)
+    p.poly_g, p.poly_g_min_len = 1, minlen
+    p.adapter_enabled = 0
+    if not paired:
+        p.adapter_seq_r1 = None
+    s1, q1, l1 = _polyg_tail_reads(1500, L, 71)
+    args = (s1, q1, l1)
+    if paired:
+        args += _polyg_tail_reads(1500, L, 72)
+    o = oraclelib.Oracle(p)
+    g = engines.sim_engine(p)
+    assert g.plan() == "lane"
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    assert int((ro[0]["len"] < l1).sum()) > 400, "the inputs must make trimPolyG cut"
+    assert int((l1 - ro[0]["len"] > 40).sum()) > 100, "runs longer than one window must occur"
+    for k in range(3):
+        if ro[k] is not None:
+            bad = np.nonzero(ro[k] != rg[k])[0]
+            assert len(bad) == 0, f"result {k} differs at {bad[:5]}: oracle {ro[k][bad[:3]]} device {rg[k][bad[:3]]}"
+    assert np.array_equal(co, cg)
+
+
 def test_sim_out_of_scope_parameters_fail_loudly():
     """the engine never falls back: parameters outside the device path are errors"""
     for field, value, code in (("max_len", 513, abi.E_TOO_LONG), ("insert_size_max", 5000, abi.E_INVALID),
