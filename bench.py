@@ -513,7 +513,7 @@ def main():
             out["compute_roofline"] = compute
         out["config"]["kernel_plan"] = plan
         if world == 1 and not args.no_cpu:
-            del resident
+            resident = None
             torch.cuda.empty_cache()
             have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "fastp_ref"))
             files = write_sample_files(args.cpu_sample, dev) if have_ref else None
@@ -523,11 +523,13 @@ def main():
             if files is not None:
                 import shutil
                 shutil.rmtree(files[0], ignore_errors=True)
-            if not args.no_extras:
-                try:
-                    out["other_configs"] = other_configs(dev)
-                except Exception as e:
-                    out["other_configs"] = [{"error": repr(e)[:200]}]
+        if world == 1 and not args.no_extras:
+            resident = None
+            torch.cuda.empty_cache()
+            try:
+                out["other_configs"] = other_configs(dev)
+            except Exception as e:
+                out["other_configs"] = [{"error": repr(e)[:200]}]
         print(json.dumps(out))
     eng.close()
     if dist is not None:

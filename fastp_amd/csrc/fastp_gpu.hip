@@ -45,8 +45,10 @@ extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a)
 #ifndef FQ_LANE_WAVES
 #define FQ_LANE_WAVES 3   // wavefronts per SIMD the lane kernel is compiled for (168 VGPRs: no spills; 4 = 128 VGPRs spills ~26 dwords)
 #endif
+// (reads of up to 256 bases, SWM = 16: the row stage alone is 16 KB per wavefront, two workgroups fit a CU whatever the
+// register count - compiled for two wavefronts per SIMD, no spills)
 template <int SWM, int B, int NPL, bool PAIRED>
-__global__ void __launch_bounds__(256, FQ_LANE_WAVES) fq_lane_kernel(LaneArgs a) {
+__global__ void __launch_bounds__(256, SWM > 10 ? 2 : FQ_LANE_WAVES) fq_lane_kernel(LaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     lane_body<SWM, B, NPL, PAIRED>(*kernel_args(&a), fq_lds);
 }

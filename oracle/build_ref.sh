@@ -34,5 +34,7 @@ done
 $CXX $CXXFLAGS -c "$HERE/shims/simd_scalar.cpp" -o "$OBJ/simd_scalar.o" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref" -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ldeflate -lpthread
+# (linked beside its name, then renamed: a test process may be executing the old binary at this moment)
+$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref.tmp.$$" -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ldeflate -lpthread
+mv -f "$OUT/fastp_ref.tmp.$$" "$OUT/fastp_ref"
 echo "built $OUT/fastp_ref"

@@ -43,13 +43,16 @@ for p in "${pids[@]}"; do wait "$p"; done
 # which the HIP runtime behind libfastp_gpu.so cannot live with)
 DEFLATE=/usr/lib/x86_64-linux-gnu/libdeflate.so.0
 [ -f "$DEFLATE" ] || DEFLATE=/opt/conda/lib/libdeflate.so
-$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpu" "$DEFLATE" -lpthread \
+# (linked beside their names, then renamed: a test process may be executing the old binaries at this moment)
+$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpu.tmp.$$" "$DEFLATE" -lpthread \
     -L"$ROOT/fastp_amd" -Wl,-rpath,'$ORIGIN/../../fastp_amd' -lfastp_gpu
+mv -f "$OUT/fastp_ref_gpu.tmp.$$" "$OUT/fastp_ref_gpu"
 echo "built $OUT/fastp_ref_gpu"
 # the same binding against the SIMT emulator build of the engine (tests/hostsim): lets the CPU-only suite run
 # the patched reference end to end on small inputs
 SIM=$ROOT/tests/hostsim/libfastp_gpu_sim.so
 if [ -f "$SIM" ]; then
-    $CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpusim" "$DEFLATE" -lpthread "$SIM" -Wl,-rpath,"$ROOT/tests/hostsim"
+    $CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpusim.tmp.$$" "$DEFLATE" -lpthread "$SIM" -Wl,-rpath,"$ROOT/tests/hostsim"
+    mv -f "$OUT/fastp_ref_gpusim.tmp.$$" "$OUT/fastp_ref_gpusim"
     echo "built $OUT/fastp_ref_gpusim"
 fi
