@@ -770,7 +770,7 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         HIP_TRY(ctx, hipGetLastError());
         {   // LDS plan of the counting kernel: symbols of one task per lane, then the seed tables that still fit
             const int longest = ctx->dp.max_len * (ctx->dp.merge ? 2 : 1);
-            int lds_bytes = ((longest * OVR_BLOCK + 15) / 16) * 16;
+            int lds_bytes = ((longest * OVR_SYM_STRIDE + 15) / 16) * 16;
             o.sym_cap = longest;
             if (lds_bytes > 120 * 1024) { o.sym_cap = 0; lds_bytes = 0; }   // reads too long to stage: the global path
             for (int m = 0; m < 2; m++) {
@@ -781,7 +781,7 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
                     lds_bytes += (int)tb;
                 }
             }
-            hipLaunchKernelGGL(fq_ovr_count_kernel, dim3((task_cap + OVR_BLOCK - 1) / OVR_BLOCK), dim3(OVR_BLOCK), (size_t)lds_bytes, st, o);
+            hipLaunchKernelGGL(fq_ovr_count_kernel, dim3((task_cap + OVR_TPB - 1) / OVR_TPB), dim3(OVR_BLOCK), (size_t)lds_bytes, st, o);
         }
         HIP_TRY(ctx, hipGetLastError());
     }

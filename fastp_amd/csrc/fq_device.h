@@ -3083,15 +3083,18 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
         if (o.table_lds[m] >= 0)
             for (u32 i = (u32)tid; i < 2u * (o.mate[m].table_mask + 1u); i += (u32)block_threads()) lds[o.table_lds[m] + (int)i] = o.mate[m].table[i];
     block_sync();
-    const int t = block_id() * block_threads() + tid;
+    // lane = (task, window length): the five lengths of a read run side by side on the read's symbols in LDS (one lane
+    // per read walked 5 x len windows in turn with two wavefronts per SIMD to hide its LDS round trips)
+    const int tk = tid / OVR_STEPS, my_step = tid - tk * OVR_STEPS;
+    const int t = block_id() * OVR_TPB + tk;
     const int nt = (int)imin((int)*o.n_tasks, o.task_cap);
-    if (t >= nt) return;
-    const u32 task = o.tasks[t];
+    const bool live = tk < OVR_TPB && t < nt;
+    const u32 task = live ? o.tasks[t] : 0u;
     const int g = (int)(task >> 4), src = (int)((task >> 2) & 3u), slot = (int)(task & 3u);
     const int post = slot & 1;
     const int mt = src == OVR_SRC_R1 ? 0 : src == OVR_SRC_R2 ? 1 : (slot >> 1);
     const OvrMate& M = o.mate[slot >> 1];   // the seed list belongs to the Stats object, not to the read
-    if (M.n_seeds == 0) return;
+    const bool work = live && M.n_seeds != 0;
     OvrRead r;
     r.src = src;
     r.mt = mt;
@@ -3105,8 +3108,9 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
     r.m1 = 0;
     r.ol = 0;
     r.f[0] = r.f[1] = 0;
-    int len = (int)o.len[mt][g];
-    if (src == OVR_SRC_MERGED) {
+    int len = work ? (int)o.len[mt][g] : 0;
+    if (!work) {
+    } else if (src == OVR_SRC_MERGED) {
         const u32 a0 = o.res[0][(size_t)g * 3], b0 = o.res[1][(size_t)g * 3];
         const int m1 = (int)(o.res[0][(size_t)g * 3 + 2] >> 16), m2 = (int)(o.res[1][(size_t)g * 3 + 2] >> 16);
         r.f[0] = (int)(a0 & 0xFFFFu);
@@ -3122,18 +3126,22 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
     r.len = len;
     // the read's symbols once into LDS, [position][lane]: the five window lengths below then slide over LDS bytes
     // instead of re-reading (and re-correcting / re-complementing) global memory twice per position
-    u8* symv = (u8*)lds + tid;
-    const bool staged = len <= o.sym_cap;
-    if (staged)
-        for (int j = 0; j < len; j++) symv[(size_t)j * OVR_BLOCK] = (u8)ovr_fetch(o, r, j);
-#define OVR_SYM(j) (staged ? (u32)symv[(size_t)(j) * OVR_BLOCK] : ovr_fetch(o, r, (j)))
+    u8* symv = (u8*)lds + tk;
+    const bool staged = o.sym_cap > 0;   // (uniform; launch_overrep sizes the rows for the longest read or not at all)
+    if (staged) {
+        for (int j = my_step; j < len; j += OVR_STEPS) symv[(size_t)j * OVR_SYM_STRIDE] = (u8)ovr_fetch(o, r, j);
+        block_sync();
+    }
+    if (!work) return;
+#define OVR_SYM(j) (staged ? (u32)symv[(size_t)(j) * OVR_SYM_STRIDE] : ovr_fetch(o, r, (j)))
     const u32* tab = o.table_lds[slot >> 1] >= 0 ? lds + o.table_lds[slot >> 1] : M.table;
     const int f = 0;
     int64_t* cnt = o.ctr + o.o_count[slot];
     int64_t* dist = o.ctr + o.o_dist[slot];
-    for (int s = 0; s < OVR_STEPS; s++) {
+    {
+        const int s = my_step;
         const int L = M.steps[s];
-        if (L <= 0 || len - L <= 0) continue;
+        if (L <= 0 || len - L <= 0) return;
         const u32 salt = (u32)L * OVR_SALT_MUL, pw = M.pw[s];
         int i = 0;
         u32 h = 0;

@@ -245,7 +245,10 @@ struct ParseArgs {
 
 // ---- result records -> output FASTQ text on the device (fq_fmt_* kernels) ----
 enum { FMT_BLOCK = 256 };
-enum { OVR_BLOCK = 128 };  // threads of the overrepresentation counting kernel (one task per lane)
+enum { OVR_BLOCK = 128 };  // threads of the overrepresentation counting kernel
+// a task (one sampled read) takes OVR_STEPS lanes, one per window length; OVR_TPB tasks per workgroup share its LDS
+// symbol rows ([position][OVR_SYM_STRIDE] bytes)
+enum { OVR_TPB = OVR_BLOCK / 5, OVR_SYM_STRIDE = 32 };
 struct FmtMate {
     const u8* text;
     const u32* line_off;
