@@ -19,6 +19,10 @@ if [ ! -d "$REF/src" ]; then
     exit 0
 fi
 mkdir -p "$OBJ"
+mkdir -p "$OUT"
+# one build at a time: pytest-xdist workers (and the build step of several tests) may call this script concurrently
+exec 9>"$OUT"/.build.lock
+flock 9
 CXX=${CXX:-g++}
 CXXFLAGS="-std=c++11 -pthread -O3 -w -I$REF -I$HERE/shims -I/opt/conda/include"
 pids=()

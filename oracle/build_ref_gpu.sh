@@ -18,6 +18,10 @@ if [ ! -d "$REF/src" ]; then
     exit 0
 fi
 mkdir -p "$OBJ" "$GEN"
+mkdir -p "$OUT"
+# one build at a time: pytest-xdist workers (and the build step of several tests) may call this script concurrently
+exec 9>"$OUT"/.build.lock
+flock 9
 python3 "$HERE/patches/apply_gpu_worker.py" "$REF" "$GEN" > /dev/null
 CXX=${CXX:-g++}
 CXXFLAGS="-std=c++11 -pthread -O3 -w -I$REF -I$REF/src -I$HERE/shims -I/opt/conda/include -I$HERE/patches -I$ROOT/include"

@@ -4,6 +4,9 @@
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)
 SRC=$HERE/../../fastp_amd/csrc
+# one build at a time: pytest-xdist workers (and the build step of several tests) may call this script concurrently
+exec 9>"$HERE"/.build.lock
+flock 9
 g++ -std=c++17 -O2 -g -fPIC -shared -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-variable \
     -I"$HERE" -I"$SRC" -x c++ "$SRC/fastp_gpu.hip" "$SRC/fq_host.cpp" "$SRC/fq_glue.cpp" "$SRC/fq_comm.cpp" "$HERE/sim.cpp" \
     -ldl -o "$HERE/libfastp_gpu_sim.so"

@@ -135,7 +135,15 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None):
     assert want_rep["summary"]["before_filtering"]["total_reads"] == (2 if paired else 1) * n
 
 
-@pytest.mark.parametrize("name", list(BINDING_CASES))
+# on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
+# test_gpu_patched_reference_equals_reference; each costs seconds here because the emulator clears Duplicate's 1 GiB
+EMULATOR_CASES = ["pe_default", "pe_correction", "pe_merge", "pe_filters", "pe_noadapter_dedup", "pe_umi_per_read",
+                  "pe_adapter_fasta", "pe_overrep", "pe_allow_gap_indel", "pe_overlapped_out_trims", "pe_adapter_long",
+                  "se_adapter_cut", "se_overrep", "se_adapter_long_indel"]
+assert all(n in BINDING_CASES for n in EMULATOR_CASES)
+
+
+@pytest.mark.parametrize("name", EMULATOR_CASES)
 def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
