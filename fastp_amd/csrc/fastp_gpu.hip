@@ -1810,7 +1810,9 @@ extern "C" int fastp_gpu_deflate_bgzf(fastp_gpu_ctx* ctx, const uint8_t* text, i
     hipStream_t st = ctx->stream;
     static const uint8_t eof_member[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t total_blocks = (nbytes + DEF_BLOCK - 1) / DEF_BLOCK;
-    const int round = (int)std::min<int64_t>(total_blocks, 4096);
+    // a round = what is in flight at once (a wavefront per block, eight per CU): the scratch is sized by it - 4 bytes of
+    // tokens per input byte + a member slot per block - so a larger round only costs HBM
+    const int round = (int)std::min<int64_t>(total_blocks, (int64_t)ctx->cus * 8);
     if (round > 0) {
         const size_t b_slots = (size_t)round * DEF_SLOT, b_tok = (size_t)round * DEF_BLOCK * 4, b_sizes = (size_t)round * 4 + 8,
                      b_offs = ((size_t)round + 1) * 8;
