@@ -5,13 +5,15 @@
 // wavefront of the workgroup, and a pair costs ~230 VALU + ~145 SALU instructions of which most are index
 // arithmetic, LDS addressing and loop control.  Here a lane owns a pair from the first load to the result record:
 //   * its reads live in VGPRs (2-bit bases: SWM dwords per read; N mask; the sliding-window predicate of
-//     Filter::trimAndCut as a bit mask), loaded once with per-lane 8-byte row loads,
+//     Filter::trimAndCut as a bit mask); the wavefront copies its 64 rows coalesced into a private LDS stage (all the
+//     vectors of a stage in flight at once) and every lane reads its own row back from there,
 //   * every scan is a fully unrolled, branch-free instruction stream over STATIC register indices - the overlap
 //     prefilter of OverlapAnalysis::analyze is 6 instructions per offset with no address arithmetic at all,
 //   * a dynamic offset (the surviving overlap candidates, the shift of rc(read 2) by its trimmed tail) is applied
 //     with a log-step word shifter over the register array instead of an indexed memory access,
-//   * no LDS tile, no workgroup barrier in the loop, no phase with idle wavefronts; LDS holds the MISC_* counters,
-//     two threshold tables and the duplicate hash's base-value table only.
+//   * no LDS tile, no workgroup barrier in the loop, no phase with idle wavefronts; LDS holds the row stages, the
+//     MISC_* counters, two threshold tables and the duplicate hash's tables,
+//   * chunks of 64 pairs are handed to the persistent wavefronts by an atomic counter.
 // Stats::statRead runs afterwards in fq_stats.h (split plan).  The kernel covers the option family in which nothing
 // needs an indexed walk along a read that cannot be bounded (see lane_plan_supported in fastp_gpu.hip); everything
 // else stays on the tile kernels.  Reference: src/peprocessor.cpp:383-643, src/seprocessor.cpp:204-296.
