@@ -100,9 +100,7 @@ FQ_DEV void half_sync(u32* bar, int group, int nthreads, int naps) {
 #endif
 }
 FQ_DEV void nap() {   // ~3 us
-#ifndef FQ_HOSTSIM
     __builtin_amdgcn_s_sleep(127);
-#endif
 }
 FQ_DEV u64 cycle_counter() { return (u64)clock64(); }
 FQ_DEV void g_atomic_add_u64(u64* p, u64 v) {
@@ -118,26 +116,18 @@ FQ_DEV void wave_sync() {
 // order this wave's LDS accesses for the compiler only: the LDS pipe executes one wave's DS instructions in issue
 // order, so a later read by any lane of the wave sees an earlier write without draining the queue (lgkmcnt) first
 FQ_DEV void wave_order() {
-#ifndef FQ_HOSTSIM
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-#else
-    __builtin_amdgcn_wave_barrier();
-#endif
 }
 
 // nothing is scheduled across this point (keeps two independent load sweeps from being interleaved, which doubles
 // the registers in flight)
 FQ_DEV void sched_fence() {
-#ifndef FQ_HOSTSIM
     __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 // no load or store moves across this point (compiler only): bounds how many table reads an unrolled loop keeps in flight
 FQ_DEV void memory_fence_compiler() {
-#ifndef FQ_HOSTSIM
     asm volatile("" ::: "memory");
-#endif
 }
 
 FQ_DEV u64 ballot(bool pred) { return __ballot(pred); }

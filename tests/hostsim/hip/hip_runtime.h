@@ -124,6 +124,8 @@ static inline unsigned long long sim_qsad_pk_u16_u8(unsigned long long s0, unsig
 }
 #define __builtin_amdgcn_qsad_pk_u16_u8(s0, s1, acc) sim_qsad_pk_u16_u8((s0), (s1), (acc))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)   // scheduling hints: nothing to emulate
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_wave_barrier() sim::wave_barrier()
 
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
