@@ -493,6 +493,24 @@ void fastp_gpu_counter_layout_for_params(const fastp_gpu_params* p, fastp_gpu_co
     L->total = o;
 }
 
+// Eight bases / quality characters at a time (the packer runs on the host's worker threads between the reader and the
+// submit: one byte at a time through a switch it was half of what a worker did per pack).
+//   letters:  x = (c >> 1) & 3 is A 0, C 1, T 2, G 3 (and 3 for N); fastp's code A 0, T 1, C 2, G 3 is x with its two
+//             bits swapped; an N becomes code 0 + the flag; anything that is not one of the five letters is refused
+//   quality:  '!'..'~' only (the kernels take q - 33 as an unsigned field, stats.cpp:223,226)
+namespace {
+inline uint64_t load8(const char* p, int n) {   // n <= 8 bytes, zero padded
+    uint64_t v = 0;
+    memcpy(&v, p, (size_t)n);
+    return v;
+}
+inline uint64_t zero_bytes(uint64_t v) {   // 0x80 in every byte of v that is zero (exact: no borrow between bytes)
+    const uint64_t m = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((v & m) + m) | v | m);
+}
+inline uint64_t bytes_equal(uint64_t v, unsigned char c) { return zero_bytes(v ^ (0x0101010101010101ull * c)); }
+}  // namespace
+
 int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
                          const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
                          int32_t* bad_read) {
@@ -504,28 +522,39 @@ int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char
         if (len < 0 || len > max_len) { if (bad_read) *bad_read = i; return FASTP_GPU_E_TOO_LONG; }
         uint8_t* so = seq_out + (size_t)i * ss;
         uint8_t* qo = qual_out + (size_t)i * qs;
-        memset(so, 0, ss);
-        memset(qo, 0, qs);
         const char* s = seqs[i];
         const char* q = quals[i];
-        for (int j = 0; j < len; j++) {
-            int code;
-            uint8_t nflag = 0;
-            switch (s[j]) {
-                case 'A': code = fq::CODE_A; break;
-                case 'T': code = fq::CODE_T; break;
-                case 'C': code = fq::CODE_C; break;
-                case 'G': code = fq::CODE_G; break;
-                case 'N': code = 0; nflag = 0x80; break;
-                default: if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET;
+        int j = 0;
+        for (; j < len; j += 8) {   // both strides are multiples of 8 bytes of quality / 2 bytes of bases: whole groups fit
+            const int m = len - j < 8 ? len - j : 8;
+            const uint64_t live = m == 8 ? ~0ull : ((1ull << (8 * m)) - 1ull);
+            const uint64_t c = load8(s + j, m), qq = load8(q + j, m);
+            const uint64_t isn = bytes_equal(c, 'N');
+            const uint64_t known = bytes_equal(c, 'A') | bytes_equal(c, 'C') | bytes_equal(c, 'G') | bytes_equal(c, 'T') | isn;
+            // quality in '!'..'~': q - 33 does not borrow and q + 1 does not reach bit 7
+            const uint64_t qbad = ((qq | 0x8080808080808080ull) - 0x2121212121212121ull) ^ 0x8080808080808080ull;   // bit 7 set <=> q < 33 (for q < 128)
+            const uint64_t qhigh = (qq | ((qq & 0x7F7F7F7F7F7F7F7Full) + 0x0101010101010101ull)) & 0x8080808080808080ull;   // q >= 127
+            if ((((~known) | (qbad & 0x8080808080808080ull) | qhigh) & 0x8080808080808080ull & live) != 0) {
+                if (bad_read) *bad_read = i;
+                return FASTP_GPU_E_ALPHABET;
             }
-            const unsigned char qc = (unsigned char)q[j];
-            // outside '!'..'~': the kernels take (q - 33) as an unsigned field of a packed counter where the
-            // reference adds a negative long (stats.cpp:223,226) - refused like a foreign letter
-            if (qc < 33 || qc > 126) { if (bad_read) *bad_read = i; return FASTP_GPU_E_ALPHABET; }
-            so[j >> 2] |= (uint8_t)(code << ((j & 3) * 2));
-            qo[j] = (uint8_t)(qc | nflag);
+            uint64_t code = (c >> 1) & 0x0303030303030303ull;
+            code = ((code >> 1) | (code << 1)) & 0x0303030303030303ull;   // swap the two bits: A 0, T 1, C 2, G 3
+            code &= ~((isn >> 7) * 3ull);                                 // an N is code 0
+            code &= live;
+            // gather the eight 2-bit codes into 16 bits
+            code = (code | (code >> 6)) & 0x000F000F000F000Full;
+            code = (code | (code >> 12)) & 0x000000FF000000FFull;
+            code = (code | (code >> 24)) & 0xFFFFull;
+            so[j >> 2] = (uint8_t)code;
+            so[(j >> 2) + 1] = (uint8_t)(code >> 8);
+            const uint64_t qv = (qq | isn) & live;
+            memcpy(qo + j, &qv, 8);
         }
+        // the rest of the row is zero (fastp_gpu.h: bytes past a read's length)
+        const size_t sdone = (size_t)((len + 7) / 8) * 2, qdone = (size_t)((len + 7) / 8) * 8;
+        if (sdone < ss) memset(so + sdone, 0, ss - sdone);
+        if (qdone < qs) memset(qo + qdone, 0, qs - qdone);
         len_out[i] = (uint16_t)len;
     }
     return FASTP_GPU_OK;

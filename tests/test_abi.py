@@ -104,6 +104,56 @@ def test_pack_reads_layout_and_errors(lib):
     assert e.value.code == abi.E_TOO_LONG
 
 
+def _pack_rows(lib, seqs, quals, max_len):
+    n = len(seqs)
+    lib.fastp_gpu_seq_stride.restype = C.c_size_t
+    lib.fastp_gpu_qual_stride.restype = C.c_size_t
+    ss, qs = lib.fastp_gpu_seq_stride(max_len), lib.fastp_gpu_qual_stride(max_len)
+    so = np.full(n * ss, 0xEE, dtype=np.uint8)     # (stale bytes: the packer must write every byte of a row)
+    qo = np.full(n * qs, 0xEE, dtype=np.uint8)
+    lo = np.zeros(n, dtype=np.uint16)
+    sp, qp = (C.c_char_p * n)(*seqs), (C.c_char_p * n)(*quals)
+    lens, bad = (C.c_int32 * n)(*[len(s) for s in seqs]), C.c_int32(-1)
+    rc = lib.fastp_gpu_pack_reads(max_len, n, sp, qp, lens, so.ctypes.data_as(C.c_void_p), qo.ctypes.data_as(C.c_void_p),
+                                  lo.ctypes.data_as(C.c_void_p), C.byref(bad))
+    return rc, bad.value, so.reshape(n, ss), qo.reshape(n, qs), lo
+
+
+def test_pack_reads_eight_at_a_time_equals_byte_by_byte(lib):
+    """the packer works on groups of eight characters: every read length around the group and stride boundaries against a
+    byte-by-byte restatement, and every foreign letter / quality value at every position of a group refused"""
+    rng = np.random.default_rng(3)
+    code = {ord("A"): 0, ord("T"): 1, ord("C"): 2, ord("G"): 3, ord("N"): 0}
+    for max_len in (1, 7, 8, 9, 31, 32, 33, 150, 151, 250, 256):
+        seqs, quals = [], []
+        for _ in range(120):
+            L = int(rng.integers(0, max_len + 1))
+            seqs.append(bytes(rng.choice(list(b"ACGTN"), size=L, p=[.24, .24, .24, .24, .04]).astype(np.uint8)))
+            quals.append(bytes(rng.integers(33, 127, size=L).astype(np.uint8)))
+        rc, bad, so, qo, lo = _pack_rows(lib, seqs, quals, max_len)
+        assert rc == 0, (max_len, rc, bad)
+        es, eq = np.zeros_like(so), np.zeros_like(qo)
+        for i, (s, q) in enumerate(zip(seqs, quals)):
+            for j, (c, qc) in enumerate(zip(s, q)):
+                es[i, j >> 2] |= code[c] << (2 * (j & 3))
+                eq[i, j] = qc | (0x80 if c == ord("N") else 0)
+        assert np.array_equal(so, es) and np.array_equal(qo, eq) and list(lo) == [len(s) for s in seqs], max_len
+    good = b"ACGTNACGTNACGTNACGTNACG"
+    for pos in (0, 1, 6, 7, 8, 9, 15, 16, 22):
+        for c in range(1, 256):
+            if c in b"ACGTN":
+                continue
+            s = bytearray(good)
+            s[pos] = c
+            rc, bad, *_ = _pack_rows(lib, [b"ACGT", bytes(s)], [b"IIII", b"I" * len(s)], 40)
+            assert rc == abi.E_ALPHABET and bad == 1, (pos, c, rc, bad)
+        for qc in list(range(1, 33)) + list(range(127, 256)):
+            q = bytearray(b"I" * len(good))
+            q[pos] = qc
+            rc, bad, *_ = _pack_rows(lib, [good], [bytes(q)], 40)
+            assert rc == abi.E_ALPHABET and bad == 0, (pos, qc, rc)
+
+
 def test_host_glue_library_exports_every_declared_symbol(lib):
     """include/fastp_gpu_host.h (the C++ string side of the patched worker loop)"""
     import cpphost
