@@ -3,7 +3,7 @@
 
     apply_gpu_worker.py <reference root> <output dir>
 
-Writes <output dir>/peprocessor.cpp, seprocessor.cpp and evaluator.cpp: the reference's files with ten one-line insertions,
+Writes <output dir>/peprocessor.cpp, seprocessor.cpp, evaluator.cpp and fastqreader.cpp: the reference's files with twelve one-line insertions,
 each placed by an anchor (the function signature / the comment that opens the merge of the per-thread results).
 Nothing else of the reference is touched or reproduced here; every other source is compiled where it lies.
 """
@@ -19,6 +19,13 @@ def patch(name, inserts):
     src = open(os.path.join(ref, "src", name)).read()
     src = '#include "gpu_worker.h"\n' + src
     for anchor, text, where in inserts:
+        if where == "before_each":   # the same insertion in front of every match
+            ms = list(re.finditer(anchor, src))
+            if not ms:
+                sys.exit(f"apply_gpu_worker: anchor not found in {name}: {anchor}")
+            for m in reversed(ms):
+                src = src[:m.start()] + text + src[m.start():]
+            continue
         m = re.search(anchor, src)
         if not m:
             sys.exit(f"apply_gpu_worker: anchor not found in {name}: {anchor}")
@@ -53,4 +60,9 @@ patch("evaluator.cpp", [
     (r"for\(int i=0; i<records; i\+\+\) \{\s*Read\* r = loadedReads\[i\];\s*const char\* data = r->mSeq->c_str\(\);\s*int key = -1;",
      "if(fastp_gpu_worker_adapter_kmers(this, loadedReads, records, shiftTail, counts) < 0)   // else: counted on the device (FASTP_GPU=1)\n    ", "before"),
 ])
-print("patched peprocessor.cpp, seprocessor.cpp, evaluator.cpp ->", out)
+patch("fastqreader.cpp", [
+    # FastqReader::getLine's two scans for the end of the line (the loop stays and finds it has nothing to do)
+    (r"[ \t]*while\(end < mBufDataLen\) \{\s*if\(mFastqBuf\[end\] != '\\r' && mFastqBuf\[end\] != '\\n'\)\s*end\+\+;",
+     "\tend = fastp_gpu_reader_scan_eol(mFastqBuf, end, mBufDataLen);   // memchr instead of one character at a time (FASTP_GPU=1)\n", "before_each"),
+])
+print("patched peprocessor.cpp, seprocessor.cpp, evaluator.cpp, fastqreader.cpp ->", out)

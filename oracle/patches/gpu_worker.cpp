@@ -786,6 +786,16 @@ int fastp_gpu_worker_overrep(const std::string& filename, std::map<std::string, 
 // fastp_gpu_eval_adapter_kmers: the reads are the ones the reference's own loading loop admitted (:326-341), the
 // top-10 selection and the NucleotideTree walks that follow stay the reference's.  1 = counts filled, -1 = not handled
 // (engine disabled, or a letter outside ACGTN: the reference's loop counts then).
+int fastp_gpu_reader_scan_eol(const char* buf, int from, int to) {
+    if (!enabled() || from >= to) return from;
+    const char* p = buf + from;
+    const size_t n = (size_t)(to - from);
+    const char* lf = (const char*)memchr(p, '\n', n);
+    const char* cr = (const char*)memchr(p, '\r', lf ? (size_t)(lf - p) : n);   // a '\r' only counts in front of that '\n'
+    const char* e = cr ? cr : lf;
+    return e ? (int)(e - buf) : to;
+}
+
 int fastp_gpu_worker_adapter_kmers(Evaluator* ev, Read** reads, long records, int shiftTail, unsigned int* counts) {
     if (!enabled() || records <= 0 || records > (1 << 30)) return -1;
     const int n = (int)records;

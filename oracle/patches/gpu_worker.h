@@ -49,4 +49,10 @@ class Read;
 class Evaluator;
 int fastp_gpu_worker_adapter_kmers(Evaluator* ev, Read** reads, long records, int shiftTail, unsigned int* counts);
 
+// FastqReader::getLine (fastqreader.cpp:240-262): with the engine on, the worker threads are no longer what bounds a run -
+// the reader is, and most of its time goes into looking for the end of a line one character at a time.  The hook sits in
+// front of that loop and returns the position the loop would stop at (the first '\r' or '\n' in [from, to), or `to`),
+// found with memchr; the loop behind it then has nothing left to do.  FASTP_GPU off: returns `from`, the loop runs.
+int fastp_gpu_reader_scan_eol(const char* buf, int from, int to);
+
 #endif

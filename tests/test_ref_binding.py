@@ -102,16 +102,20 @@ def _diff(x, y, path, out):
         out.append(f"{path}: reference {x!r} binding {y!r}")
 
 
-def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None):
+def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n", trailing=True):
     paired, flags, pf, skw = cases.CASES[name]
     flags = list(flags) + BINDING_CASES[name]
     tmp = str(tmp_path)
     d = synth.synth_pairs(n, L=150, seed=seed, paired=paired, **skw)
+
+    def text(seq, qual, lens, mate):   # line ends as the caller wants them (FastqReader::getLine takes \n, \r\n and \r)
+        t = synth.to_fastq(seq, qual, lens, mate).replace(b"\n", eol)
+        return t if trailing else t[:len(t) - len(eol)]
     with open(os.path.join(tmp, "in1.fq"), "wb") as f:
-        f.write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1))
+        f.write(text(d["seq1"], d["qual1"], d["len1"], 1))
     if paired:
         with open(os.path.join(tmp, "in2.fq"), "wb") as f:
-            f.write(synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2))
+            f.write(text(d["seq2"], d["qual2"], d["len2"], 2))
     for fn, content in cases.FILES.get(name, {}).items():
         for tag in ("ref", "gpu"):
             os.makedirs(os.path.join(tmp, tag), exist_ok=True)
@@ -203,6 +207,22 @@ def test_patched_reference_pipelines_windows_of_packs(name, threads, packs, tmp_
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
     _check(name, REF_SIM, 9300, tmp_path, seed=43, threads=threads, extra_env={"FASTP_GPU_PACKS": str(packs)})
+
+
+@pytest.mark.parametrize("eol,trailing", [(b"\r\n", True), (b"\r", True), (b"\n", False), (b"\r\n", False)])
+def test_patched_reference_reader_hook_line_ends(eol, trailing, tmp_path):
+    """the memchr hook in front of FastqReader::getLine's scan (fastp_gpu_reader_scan_eol): the same records from \\r\\n, \\r
+    and unterminated last lines as the reference's own character-by-character scan (whose binary runs without the hook)"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check("pe_cut_right", REF_SIM, 2300, tmp_path, seed=47, threads=2, eol=eol, trailing=trailing)
+
+
+def test_patched_reference_reader_hook_across_buffer_refills(tmp_path):
+    """input files larger than FastqReader's 8 MiB buffer: lines that straddle a refill take getLine's second scan"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check("se_default_noadapter", REF_SIM, 52000, tmp_path, seed=48, threads=2, eol=b"\r\n")
 
 
 @pytest.mark.gpu
