@@ -5,7 +5,7 @@ Only declarations live here - no computation.  Used by the Python host mirror
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_READ_LEN = 512
 MAX_ADAPTER_LEN = 256
 
@@ -171,7 +171,8 @@ def adapter_fasta_list(params):
 
 
 class ParseInfo(C.Structure):
-    _fields_ = [("n_records", C.c_int32), ("first_bad", C.c_int32), ("consumed", C.c_int64), ("n_lines", C.c_int64)]
+    _fields_ = [("n_records", C.c_int32), ("first_bad", C.c_int32), ("consumed", C.c_int64), ("n_lines", C.c_int64),
+                ("bad_kind", C.c_int32), ("max_seq_len", C.c_int32)]
 
 
 class InflateInfo(C.Structure):

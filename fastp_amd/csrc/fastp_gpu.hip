@@ -1263,6 +1263,20 @@ extern "C" int fastp_gpu_dup_bitmap_export(fastp_gpu_ctx* ctx, void* dst_device)
     return FASTP_GPU_OK;
 }
 
+// the counterpart of the export: this engine's bitmaps <- an image (a context that takes over another's stream,
+// fastp_gpu_stream.h's re-plan; Duplicate's state is nothing but these bits, duplicate.h:34-37)
+extern "C" int fastp_gpu_dup_bitmap_import(fastp_gpu_ctx* ctx, const void* src_device) {
+    if (!ctx) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    const int64_t bytes = fastp_gpu_dup_bitmap_bytes(ctx);
+    if (bytes == 0) return FASTP_GPU_OK;
+    if (!src_device) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rj_ = join_aux(ctx, ctx->stream); if (rj_) return rj_; }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bitmap, src_device, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
+    return FASTP_GPU_OK;
+}
+
 extern "C" int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_device, int32_t n_images) {
     if (!ctx || n_images < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
     const int64_t bytes = fastp_gpu_dup_bitmap_bytes(ctx);
@@ -1369,8 +1383,14 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     info->n_records = (int32_t)totals[3];
     info->consumed = (int64_t)totals[4];
     info->n_lines = (int64_t)totals[2];
-    info->first_bad = totals[1] == 0xFFFFFFFFu ? -1 : (int32_t)totals[1];
-    if (info->first_bad >= 0) return fail(ctx, FASTP_GPU_E_INVALID, "malformed FASTQ record in the chunk (see first_bad)");
+    info->first_bad = totals[1] == 0xFFFFFFFFu ? -1 : (int32_t)(totals[1] >> 2);
+    info->bad_kind = totals[1] == 0xFFFFFFFFu ? 0 : (int32_t)(totals[1] & 3u);
+    info->max_seq_len = (int32_t)totals[5];
+    if (info->first_bad >= 0)
+        return fail(ctx, FASTP_GPU_E_INVALID,
+                    info->bad_kind == FASTP_GPU_PARSE_BAD_TOO_LONG ? "a read of the chunk is longer than the context's max_len (see first_bad, max_seq_len)"
+                    : info->bad_kind == FASTP_GPU_PARSE_BAD_ALPHABET ? "a record of the chunk has a letter outside ACGTN or a quality character outside '!'..'~' (see first_bad)"
+                                                                     : "malformed FASTQ record in the chunk (see first_bad)");
     return FASTP_GPU_OK;
 }
 

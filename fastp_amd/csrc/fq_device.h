@@ -3331,6 +3331,7 @@ FQ_DEV void parse_finish_body(const ParseArgs& p) {
 }
 
 enum { PACK_GROUP = 16 };  // lanes per record: four records per wavefront
+enum { PARSE_BAD_MALFORMED = 1, PARSE_BAD_TOO_LONG = 2, PARSE_BAD_ALPHABET = 3 };  // = FASTP_GPU_PARSE_BAD_* (fastp_gpu.h)
 
 FQ_DEV void parse_pack_body(const ParseArgs& p) {
     // 16 lanes per record; lane c packs bases 4c .. 4c+3 from ONE dword of the sequence line and one of the
@@ -3352,9 +3353,13 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
         len[j] = have ? end - start[j] : 0u;
     }
     bool bad = false;
+    u32 kind = 0;  // why the record is refused: PARSE_BAD_* (the smallest bad record's reason reaches the host)
     if (have && gl == 0) {  // FastqReader::read's checks (:338-362)
-        bad = len[0] == 0 || p.text[start[0]] != '@' || len[2] == 0 || p.text[start[2]] != '+' || len[1] != len[3] ||
-              len[1] > (u32)p.max_len;
+        const bool malformed = len[0] == 0 || p.text[start[0]] != '@' || len[2] == 0 || p.text[start[2]] != '+' || len[1] != len[3];
+        const bool too_long = len[1] > (u32)p.max_len;
+        bad = malformed || too_long;
+        kind = malformed ? (u32)PARSE_BAD_MALFORMED : too_long ? (u32)PARSE_BAD_TOO_LONG : 0u;
+        if (!malformed) g_atomic_max_u32(&p.totals[5], len[1]);  // the longest sequence line: what a re-plan sizes max_len from
     }
     const u32 gmask_shift = 16u * (u32)grp;
     bad = ((ballot(bad) >> gmask_shift) & 0xFFFFull) != 0ull;
@@ -3406,7 +3411,7 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
         if (have && c < p.sw_g * 4) srow[c] = (u8)sb;
     }
     const bool any_bad = ((ballot(alpha_bad) >> gmask_shift) & 0xFFFFull) != 0ull || bad;
-    if (have && any_bad && gl == 0) g_atomic_min_u32(&p.totals[1], (u32)r);
+    if (have && any_bad && gl == 0) g_atomic_min_u32(&p.totals[1], ((u32)r << 2) | (kind ? kind : (u32)PARSE_BAD_ALPHABET));
 }
 
 

@@ -162,6 +162,26 @@ int fastp_gpu_host_adapter_entry(fastp_gpu_host* h, int is_r2, int64_t index, co
     return FASTP_GPU_OK;
 }
 
+// FilterResult::addAdapterTrimmed for hosts that cut the adapter strings out of their own text (fastp_gpu_stream.h):
+// the single-read form (filterresult.cpp:124-152) and the pair form, which skips read 2's string when read 1's was
+// refused by a cap (:154-180, quirk #8)
+int fastp_gpu_host_add_adapter(fastp_gpu_host* h, int is_r2, const char* a, int32_t len) {
+    if (!h || len < 0 || (len && !a)) return FASTP_GPU_E_INVALID;
+    if (len == 0) return FASTP_GPU_OK;
+    h->index_valid[0] = h->index_valid[1] = false;
+    h->amap[is_r2 ? 1 : 0].add(std::string(a, (size_t)len));
+    return FASTP_GPU_OK;
+}
+
+int fastp_gpu_host_add_adapter_pair(fastp_gpu_host* h, const char* a1, int32_t len1, const char* a2, int32_t len2) {
+    if (!h || len1 < 0 || len2 < 0 || (len1 && !a1) || (len2 && !a2)) return FASTP_GPU_E_INVALID;
+    h->index_valid[0] = h->index_valid[1] = false;
+    bool go = true;
+    if (len1) go = h->amap[0].add(std::string(a1, (size_t)len1));
+    if (go && len2) h->amap[1].add(std::string(a2, (size_t)len2));
+    return FASTP_GPU_OK;
+}
+
 int fastp_gpu_host_apply(fastp_gpu_host* h, const fastp_gpu_reads* b1, const fastp_gpu_reads* b2, const fastp_gpu_results* res) {
     if (!h || !b1 || !res || !res->r1) return FASTP_GPU_E_INVALID;
     const bool paired = b2 != nullptr;

@@ -210,6 +210,9 @@ FQ_DEV u32 g_atomic_exch_u32(u32* p, u32 v) {
 FQ_DEV u32 g_atomic_min_u32(u32* p, u32 v) {
     return __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+FQ_DEV u32 g_atomic_max_u32(u32* p, u32 v) {
+    return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 FQ_DEV u32 g_atomic_or_u32(u32* p, u32 v) {
     return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

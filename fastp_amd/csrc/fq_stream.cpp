@@ -1,0 +1,948 @@
+// fq_stream.cpp - include/fastp_gpu_stream.h: FASTQ files -> output streams around the engine, one host loop in C++.
+//
+// The loop a GPU-enabled fastp runs in place of its reader threads + worker threads + the string side of its writers
+// (readerTask src/peprocessor.cpp:725-888 / src/seprocessor.cpp:327-442, FastqReader::read src/fastqreader.cpp:240-368,
+// processorTask :1021-1033, the output strings of :652-686, WriterThread::inputPwrite src/writerthread.cpp:118-168).
+// Host code; the per-read work is the device entry points of fastp_gpu.h.  Four threads + two small I/O pools:
+//
+//   reader thread   pread pieces of the next chunk of each file into page-locked memory, H2D copy on its own stream
+//   caller thread   parse -> worker loop -> format (-> deflate) on the context's stream, D2H of the output text
+//   writer thread   pwrite pieces of a chunk's output (or the emit callback), in chunk order
+//   replay thread   FilterResult::addAdapterTrimmed for the reads the records flag, in input order
+//
+// The text of a chunk that the records of the trip do not cover (a partial record at the end, the surplus of the
+// mate whose records are shorter) is copied to the front of the other page-locked slot and the next trip's fresh bytes
+// are read in behind it: a slot always holds the whole text of its trip ([carried | fresh], at most chunk_bytes), which
+// is what the adapter replay cuts its strings from.
+#include <errno.h>
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fastp_gpu_stream.h"
+
+namespace {
+
+thread_local std::string g_stream_error;
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// a few threads that run positional reads / writes; wait() returns when everything submitted so far is done
+class IoPool {
+  public:
+    explicit IoPool(int n) {
+        for (int i = 0; i < std::max(1, n); i++) th_.emplace_back([this] { work(); });
+    }
+    ~IoPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); pending_++; }
+        cv_.notify_one();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            f();
+            { std::lock_guard<std::mutex> lk(mu_); pending_--; }
+            done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::deque<std::function<void()>> q_;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+
+template <class T>
+class Channel {
+  public:
+    void put(T v) {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(v)); }
+        cv_.notify_one();
+    }
+    T get() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !q_.empty(); });
+        T v = std::move(q_.front());
+        q_.pop_front();
+        return v;
+    }
+
+  private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+};
+
+const int IO_PIECE = 8 << 20;
+const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct ReadReq {
+    int slot = -1;                 // -1: stop
+    int64_t carry[2] = {0, 0};     // bytes already at the front of the slot's page-locked text
+    int64_t budget[2] = {0, 0};    // fresh bytes wanted behind them
+};
+struct ReadDone {
+    int slot = 0;
+    int64_t nb[2] = {0, 0};
+    bool eof[2] = {false, false};
+    int err = 0;
+};
+struct WriteJob {
+    int oslot = -1;                // -1: stop
+    int64_t len[FASTP_GPU_N_OUTPUTS] = {0, 0, 0, 0, 0, 0};
+};
+// the adapter strings of one chunk, in input order: entries [kind u8][len1 u16][len2 u16][bytes1][bytes2]
+struct ReplayJob {
+    bool stop = false;
+    std::vector<uint8_t> blob;
+};
+enum { RP_SINGLE_R1 = 0, RP_SINGLE_R2 = 1, RP_PAIR = 2 };
+
+}  // namespace
+
+struct fastp_gpu_stream {
+    fastp_gpu_params p;
+    fastp_gpu_stream_config cfg;
+    std::string in1, in2, a1, a2, umi_prefix, umi_delim;
+    std::vector<std::string> fasta, seeds[2];
+    std::vector<const char*> fastap, seedp[2];
+    fastp_gpu_ctx* ctx = nullptr;
+    bool paired = false;
+    int nm = 1;
+    std::string err;
+    fastp_gpu_stream_stats st;
+    // counter blocks of the contexts a re-plan replaced
+    std::vector<std::pair<fastp_gpu_counter_layout, std::vector<int64_t>>> segments;
+
+    // ---- buffers ------------------------------------------------------------------------------------------
+    int64_t chunk = 0, text_cap = 0;
+    int32_t max_records = 0;
+    uint8_t* d_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [slot][mate]
+    uint8_t* pin_in[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
+    uint16_t* d_len[2] = {nullptr, nullptr};
+    uint32_t *d_loff[2] = {nullptr, nullptr}, *d_llen[2] = {nullptr, nullptr};
+    fastp_gpu_read_result* d_res[2] = {nullptr, nullptr};
+    fastp_gpu_pair_result* d_pair = nullptr;
+    fastp_gpu_correction* d_corr = nullptr;
+    fastp_gpu_adapter_event* d_ev = nullptr;
+    int32_t *d_nc = nullptr, *d_nev = nullptr;
+    int32_t corr_cap = 0, ev_cap = 0;
+    uint8_t* d_zero = nullptr;
+    uint8_t* d_out[FASTP_GPU_N_OUTPUTS] = {};
+    uint8_t* d_gz[FASTP_GPU_N_OUTPUTS] = {};
+    int64_t out_cap[FASTP_GPU_N_OUTPUTS] = {}, gz_cap[FASTP_GPU_N_OUTPUTS] = {};
+    uint8_t* pin_out[2][FASTP_GPU_N_OUTPUTS] = {};
+    // host copies for the adapter replay
+    fastp_gpu_read_result* h_res[2] = {nullptr, nullptr};
+    uint32_t* h_loff[2] = {nullptr, nullptr};
+    fastp_gpu_correction* h_corr = nullptr;
+    fastp_gpu_adapter_event* h_ev = nullptr;
+    int32_t* h_counts = nullptr;   // pinned: n_corrections, n_adapter_events
+    hipStream_t sx = nullptr, cp_in = nullptr;
+    bool any_out = false;
+
+    int fail(int code, const std::string& m) {
+        err = m;
+        g_stream_error = m;
+        return code;
+    }
+    int fail_ctx(int code, const char* what) {
+        return fail(code, std::string(what) + ": " + fastp_gpu_last_error(ctx));
+    }
+};
+
+namespace {
+
+#define S_HIP(s, call)                                                                               \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return (s)->fail(FASTP_GPU_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void free_buffers(fastp_gpu_stream* s) {
+    auto dfree = [](void* p) { if (p) (void)hipFree(p); };
+    auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
+    for (int sl = 0; sl < 2; sl++)
+        for (int m = 0; m < 2; m++) { dfree(s->d_text[sl][m]); s->d_text[sl][m] = nullptr; hfree(s->pin_in[sl][m]); s->pin_in[sl][m] = nullptr; }
+    for (int m = 0; m < 2; m++) {
+        dfree(s->d_seq[m]); dfree(s->d_qual[m]); dfree(s->d_len[m]); dfree(s->d_loff[m]); dfree(s->d_llen[m]); dfree(s->d_res[m]);
+        s->d_seq[m] = s->d_qual[m] = nullptr; s->d_len[m] = nullptr; s->d_loff[m] = s->d_llen[m] = nullptr; s->d_res[m] = nullptr;
+        hfree(s->h_res[m]); hfree(s->h_loff[m]);
+        s->h_res[m] = nullptr; s->h_loff[m] = nullptr;
+    }
+    dfree(s->d_pair); dfree(s->d_corr); dfree(s->d_ev); dfree(s->d_nc); dfree(s->d_nev); dfree(s->d_zero);
+    s->d_pair = nullptr; s->d_corr = nullptr; s->d_ev = nullptr; s->d_nc = s->d_nev = nullptr; s->d_zero = nullptr;
+    hfree(s->h_corr); hfree(s->h_ev); hfree(s->h_counts);
+    s->h_corr = nullptr; s->h_ev = nullptr; s->h_counts = nullptr;
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+        dfree(s->d_out[q]); dfree(s->d_gz[q]);
+        s->d_out[q] = s->d_gz[q] = nullptr;
+        for (int sl = 0; sl < 2; sl++) { hfree(s->pin_out[sl][q]); s->pin_out[sl][q] = nullptr; }
+    }
+    if (s->sx) { (void)hipStreamDestroy(s->sx); s->sx = nullptr; }
+    if (s->cp_in) { (void)hipStreamDestroy(s->cp_in); s->cp_in = nullptr; }
+}
+
+// the packed rows depend on max_len: (re)allocated for every context
+int alloc_rows(fastp_gpu_stream* s) {
+    const size_t ss = fastp_gpu_seq_stride(s->p.max_len), qs = fastp_gpu_qual_stride(s->p.max_len);
+    for (int m = 0; m < s->nm; m++) {
+        if (s->d_seq[m]) (void)hipFree(s->d_seq[m]);
+        if (s->d_qual[m]) (void)hipFree(s->d_qual[m]);
+        s->d_seq[m] = s->d_qual[m] = nullptr;
+        S_HIP(s, hipMalloc((void**)&s->d_seq[m], (size_t)s->max_records * ss));
+        S_HIP(s, hipMalloc((void**)&s->d_qual[m], (size_t)s->max_records * qs));
+    }
+    return FASTP_GPU_OK;
+}
+
+int alloc_buffers(fastp_gpu_stream* s) {
+    S_HIP(s, hipSetDevice(s->cfg.device));
+    S_HIP(s, hipStreamCreateWithFlags(&s->sx, hipStreamNonBlocking));
+    S_HIP(s, hipStreamCreateWithFlags(&s->cp_in, hipStreamNonBlocking));
+    const int nm = s->nm;
+    s->text_cap = (s->chunk + 4096 + 255) / 256 * 256;   // a trip's text never exceeds chunk bytes (see the loop)
+    s->max_records = (int32_t)std::max<int64_t>(1024, s->chunk / 32);
+    for (int sl = 0; sl < 2; sl++)
+        for (int m = 0; m < nm; m++) {
+            S_HIP(s, hipMalloc((void**)&s->d_text[sl][m], (size_t)s->text_cap));
+            S_HIP(s, hipHostMalloc((void**)&s->pin_in[sl][m], (size_t)s->text_cap));
+        }
+    S_HIP(s, hipMalloc((void**)&s->d_zero, 64));
+    S_HIP(s, hipMemsetAsync(s->d_zero, 0, 64, s->sx));
+    for (int m = 0; m < nm; m++) {
+        S_HIP(s, hipMalloc((void**)&s->d_len[m], (size_t)s->max_records * 2));
+        S_HIP(s, hipMalloc((void**)&s->d_loff[m], (size_t)s->max_records * 16));
+        S_HIP(s, hipMalloc((void**)&s->d_llen[m], (size_t)s->max_records * 16));
+        S_HIP(s, hipMalloc((void**)&s->d_res[m], (size_t)s->max_records * sizeof(fastp_gpu_read_result)));
+        S_HIP(s, hipMemsetAsync(s->d_res[m], 0, (size_t)s->max_records * sizeof(fastp_gpu_read_result), s->sx));
+    }
+    int rc = alloc_rows(s);
+    if (rc) return rc;
+    if (s->paired) S_HIP(s, hipMalloc((void**)&s->d_pair, (size_t)s->max_records * sizeof(fastp_gpu_pair_result)));
+    S_HIP(s, hipMalloc((void**)&s->d_nc, 16));
+    S_HIP(s, hipMalloc((void**)&s->d_nev, 16));
+    S_HIP(s, hipMemsetAsync(s->d_nc, 0, 16, s->sx));
+    S_HIP(s, hipMemsetAsync(s->d_nev, 0, 16, s->sx));
+    if (s->p.correction) {
+        s->corr_cap = 1 << 22;
+        S_HIP(s, hipMalloc((void**)&s->d_corr, (size_t)s->corr_cap * sizeof(fastp_gpu_correction)));
+    }
+    if (s->p.n_adapter_fasta) {
+        s->ev_cap = (int32_t)std::min<int64_t>((int64_t)s->max_records * 2 * std::min(s->p.n_adapter_fasta, 8) + 16, (int64_t)1 << 28);
+        S_HIP(s, hipMalloc((void**)&s->d_ev, (size_t)s->ev_cap * sizeof(fastp_gpu_adapter_event)));
+    }
+    // what a record can grow by over its input text: the UMI tag on the name (delimiter + prefix + '_' + the UMI of one or
+    // both mates joined by '_', UmiProcessor::addUmiToName), the failed / merged tags on the name and the strand line
+    int64_t grow = 0;
+    if (s->cfg.format.umi_loc != FASTP_GPU_UMI_NONE)
+        grow = (int64_t)s->umi_delim.size() + (s->umi_prefix.empty() ? 0 : (int64_t)s->umi_prefix.size() + 1) + 2 * (int64_t)s->cfg.format.umi_len + 1;
+    const int64_t both = nm * s->text_cap + (int64_t)s->max_records * (96 + 2 * grow);   // every record of both mates + tags
+    const int64_t one = s->text_cap + (int64_t)s->max_records * grow + 64;              // out1 / out2: records only shrink, but for the UMI tag
+    const int64_t caps[FASTP_GPU_N_OUTPUTS] = {one, one, both, both, both, both};
+    s->any_out = false;
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) s->any_out = s->any_out || s->cfg.want[q];
+    // fastp_gpu_format_streams wants a buffer for every stream the options can route to
+    const bool need[FASTP_GPU_N_OUTPUTS] = {true, s->paired, s->cfg.format.want_failed != 0, s->paired && s->p.merge,
+                                            s->paired && s->cfg.format.want_unpaired1, s->paired && s->cfg.format.want_unpaired2};
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+        if (!s->any_out || !(need[q] || s->cfg.want[q])) continue;
+        s->out_cap[q] = caps[q];
+        S_HIP(s, hipMalloc((void**)&s->d_out[q], (size_t)caps[q]));
+        int64_t host_bytes = caps[q];
+        if (s->cfg.want[q] && s->cfg.compress[q]) {
+            s->gz_cap[q] = caps[q] + 31 * (caps[q] / 65280 + 1) + 64;
+            S_HIP(s, hipMalloc((void**)&s->d_gz[q], (size_t)s->gz_cap[q]));
+            host_bytes = s->gz_cap[q];
+        }
+        if (s->cfg.want[q])
+            for (int sl = 0; sl < 2; sl++) S_HIP(s, hipHostMalloc((void**)&s->pin_out[sl][q], (size_t)host_bytes));
+    }
+    if (s->cfg.host) {
+        for (int m = 0; m < nm; m++) {
+            S_HIP(s, hipHostMalloc((void**)&s->h_res[m], (size_t)s->max_records * sizeof(fastp_gpu_read_result)));
+            S_HIP(s, hipHostMalloc((void**)&s->h_loff[m], (size_t)s->max_records * 16));
+        }
+        if (s->corr_cap) S_HIP(s, hipHostMalloc((void**)&s->h_corr, (size_t)s->corr_cap * sizeof(fastp_gpu_correction)));
+        if (s->ev_cap) S_HIP(s, hipHostMalloc((void**)&s->h_ev, (size_t)s->ev_cap * sizeof(fastp_gpu_adapter_event)));
+    }
+    S_HIP(s, hipHostMalloc((void**)&s->h_counts, 64));
+    S_HIP(s, hipStreamSynchronize(s->sx));
+    return FASTP_GPU_OK;
+}
+
+// dst (layout dl) += src (layout sl): same options, only the per-cycle capacity differs (dl.cycles >= sl.cycles)
+void add_counters(const fastp_gpu_counter_layout& dl, std::vector<int64_t>& dst, const fastp_gpu_counter_layout& sl,
+                  const std::vector<int64_t>& src, int insert_size_max) {
+    auto add = [&](int64_t d, int64_t s0, int64_t n) { for (int64_t i = 0; i < n; i++) dst[(size_t)(d + i)] += src[(size_t)(s0 + i)]; };
+    add(dl.filter_stats, sl.filter_stats, FASTP_FILTER_RESULT_TYPES);
+    add(dl.adapter_reads, sl.adapter_reads, 1);
+    add(dl.adapter_bases, sl.adapter_bases, 1);
+    add(dl.polyx_reads, sl.polyx_reads, 4);
+    add(dl.polyx_bases, sl.polyx_bases, 4);
+    add(dl.correction, sl.correction, 64);
+    add(dl.corrected_reads, sl.corrected_reads, 1);
+    add(dl.merged_pairs, sl.merged_pairs, 1);
+    add(dl.dup_total, sl.dup_total, 1);
+    add(dl.dup_count, sl.dup_count, 1);
+    add(dl.isize, sl.isize, (int64_t)insert_size_max + 1);
+    for (int k = 0; k < 4; k++) {
+        const int64_t d = dl.stats[k], s0 = sl.stats[k];
+        add(d + dl.st_reads, s0 + sl.st_reads, 1);
+        add(d + dl.st_length_sum, s0 + sl.st_length_sum, 1);
+        add(d + dl.st_qual_hist, s0 + sl.st_qual_hist, 128);
+        add(d + dl.st_kmer, s0 + sl.st_kmer, 1024);
+        for (int a = 0; a < 34; a++) add(d + dl.st_cycle + a * dl.cycles, s0 + sl.st_cycle + a * sl.cycles, sl.cycles);
+        add(dl.overrep_count[k], sl.overrep_count[k], sl.n_overrep[k]);
+        add(dl.overrep_dist[k], sl.overrep_dist[k], sl.n_overrep[k] * sl.eval_len[k]);
+    }
+}
+
+int fetch_ctx_counters(fastp_gpu_stream* s, fastp_gpu_counter_layout* lay, std::vector<int64_t>* c) {
+    fastp_gpu_counter_layout_for_params(&s->p, lay);
+    c->assign((size_t)lay->total, 0);
+    if (fastp_gpu_synchronize(s->ctx) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_synchronize");
+    if (fastp_gpu_counters(s->ctx, c->data(), lay->total) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_counters");
+    return FASTP_GPU_OK;
+}
+
+// a read of `needed` bases has turned up: the work so far is kept (counters folded on the host, duplicate bitmaps and
+// stream positions carried over) and the run goes on with a context sized for it
+int replan(fastp_gpu_stream* s, int needed) {
+    if (needed > FASTP_GPU_MAX_READ_LEN)
+        return s->fail(FASTP_GPU_E_TOO_LONG, "a read of " + std::to_string(needed) + " bases is longer than FASTP_GPU_MAX_READ_LEN");
+    int target = std::max(needed, s->p.max_len + s->p.max_len / 4);   // some headroom: re-plans are rare but not free
+    target = std::min<int>(FASTP_GPU_MAX_READ_LEN, (target + 7) / 8 * 8);
+    fastp_gpu_counter_layout lay;
+    std::vector<int64_t> c;
+    int rc = fetch_ctx_counters(s, &lay, &c);
+    if (rc) return rc;
+    const int64_t post_reads = c[(size_t)(lay.stats[FASTP_GPU_STATS_POST1] + lay.st_reads)];
+    s->segments.emplace_back(lay, std::move(c));
+    void* image = nullptr;
+    const int64_t image_bytes = fastp_gpu_dup_bitmap_bytes(s->ctx);
+    if (image_bytes > 0) {
+        S_HIP(s, hipMalloc(&image, (size_t)image_bytes));
+        if (fastp_gpu_dup_bitmap_export(s->ctx, image) != FASTP_GPU_OK) { (void)hipFree(image); return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_dup_bitmap_export"); }
+    }
+    fastp_gpu_destroy(s->ctx);
+    s->ctx = nullptr;
+    s->p.max_len = target;
+    rc = fastp_gpu_create(&s->p, s->cfg.device, &s->ctx);
+    if (rc != FASTP_GPU_OK) { if (image) (void)hipFree(image); return s->fail(rc, std::string("fastp_gpu_create (re-plan): ") + fastp_gpu_last_error(nullptr)); }
+    if (image) {
+        rc = fastp_gpu_dup_bitmap_import(s->ctx, image);
+        (void)hipFree(image);
+        if (rc != FASTP_GPU_OK) return s->fail_ctx(rc, "fastp_gpu_dup_bitmap_import");
+    }
+    if (fastp_gpu_stream_set_origin(s->ctx, s->st.units, post_reads) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_stream_set_origin");
+    s->st.replans++;
+    s->st.max_len = target;
+    return alloc_rows(s);
+}
+
+// ---- FilterResult::addAdapterTrimmed: the strings of one chunk, cut out of the chunk's text on the host ---------------
+struct Extractor {
+    fastp_gpu_stream* s;
+    std::unordered_map<uint32_t, std::vector<const fastp_gpu_correction*>> corr;
+    std::unordered_map<uint32_t, std::vector<const fastp_gpu_adapter_event*>> events;
+    std::string tmp[2];
+
+    // the read as the trimmer saw it: BaseCorrector's edits applied (basecorrector.cpp:39-57)
+    const char* read_text(int m, int i, uint32_t key, const uint8_t* text, int32_t len_hint, int* out_len) {
+        const uint32_t off = s->h_loff[m][4 * (size_t)i + 1];
+        const char* base = (const char*)text + off;
+        *out_len = len_hint;
+        auto it = corr.find(key);
+        if (it == corr.end()) return base;
+        tmp[m].assign(base, (size_t)len_hint);
+        for (const fastp_gpu_correction* c : it->second)
+            if (c->pos < tmp[m].size()) tmp[m][c->pos] = (char)c->base;
+        return tmp[m].data();
+    }
+    static void put(std::vector<uint8_t>& blob, int kind, const char* a, size_t la, const char* b, size_t lb) {
+        const size_t at = blob.size();
+        blob.resize(at + 5 + la + lb);
+        uint8_t* w = blob.data() + at;
+        w[0] = (uint8_t)kind;
+        w[1] = (uint8_t)(la & 0xFF); w[2] = (uint8_t)(la >> 8);
+        w[3] = (uint8_t)(lb & 0xFF); w[4] = (uint8_t)(lb >> 8);
+        if (la) memcpy(w + 5, a, la);
+        if (lb) memcpy(w + 5 + la, b, lb);
+    }
+    // the string handed to addAdapterTrimmed for one record (fastp_gpu_read_result::adapter_pos / adapter_len)
+    static void cut(const fastp_gpu_read_result& rr, const char* read, int read_len, const std::string& aseq, const char** a, size_t* la) {
+        if (rr.adapter_pos < 0) {
+            *a = aseq.data();
+            *la = std::min<size_t>(aseq.size(), rr.adapter_len);
+            return;
+        }
+        const size_t from = (size_t)rr.front + (size_t)rr.adapter_pos;
+        if (from >= (size_t)read_len) { *a = read; *la = 0; return; }
+        *a = read + from;
+        *la = std::min<size_t>(rr.adapter_len, (size_t)read_len - from);
+    }
+
+    void run(int n, const uint8_t* const text[2], int32_t ncorr, int32_t nev, std::vector<uint8_t>& blob) {
+        const bool paired = s->paired;
+        corr.clear();
+        events.clear();
+        for (int32_t i = 0; i < ncorr; i++) corr[s->h_corr[i].read].push_back(&s->h_corr[i]);
+        for (int32_t i = 0; i < nev; i++) events[s->h_ev[i].read].push_back(&s->h_ev[i]);
+        for (auto& kv : events)   // the device emits them unordered; per read they apply in adapter order
+            std::sort(kv.second.begin(), kv.second.end(),
+                      [](const fastp_gpu_adapter_event* x, const fastp_gpu_adapter_event* y) { return x->adapter < y->adapter; });
+        const uint8_t flagmask = FASTP_GPU_RF_ADAPTER | FASTP_GPU_RF_ADAPTER_OV;
+        for (int i = 0; i < n; i++) {
+            const fastp_gpu_read_result& r1 = s->h_res[0][i];
+            const fastp_gpu_read_result* r2 = paired ? &s->h_res[1][i] : nullptr;
+            const uint32_t k1 = paired ? 2u * (uint32_t)i : (uint32_t)i, k2 = 2u * (uint32_t)i + 1u;
+            const bool ev1 = nev && events.count(k1), ev2 = paired && nev && events.count(k2);
+            if (!((r1.flags | (r2 ? r2->flags : 0)) & flagmask) && !ev1 && !ev2) continue;
+            // line lengths are not downloaded: a sequence line reaches to the strand line's offset minus its terminator;
+            // front + len of the record bound what is cut, so the distance to the next line is a safe upper bound
+            int l1 = 0, l2 = 0;
+            const int cap1 = (int)(s->h_loff[0][4 * (size_t)i + 2] - s->h_loff[0][4 * (size_t)i + 1]);
+            const char* t1 = read_text(0, i, k1, text[0], cap1, &l1);
+            const char* t2 = nullptr;
+            if (paired) {
+                const int cap2 = (int)(s->h_loff[1][4 * (size_t)i + 2] - s->h_loff[1][4 * (size_t)i + 1]);
+                t2 = read_text(1, i, k2, text[1], cap2, &l2);
+            }
+            const char *x1 = nullptr, *x2 = nullptr;
+            size_t n1 = 0, n2 = 0;
+            if (paired) {
+                if (r1.flags & FASTP_GPU_RF_ADAPTER_OV) {   // addAdapterTrimmed(a1, a2) filterresult.cpp:154-180
+                    cut(r1, t1, l1, s->a1, &x1, &n1);
+                    cut(*r2, t2, l2, s->a2, &x2, &n2);
+                    put(blob, RP_PAIR, x1, n1, x2, n2);
+                } else {
+                    if ((r1.flags & FASTP_GPU_RF_ADAPTER) && r1.adapter_len) { cut(r1, t1, l1, s->a1, &x1, &n1); if (n1) put(blob, RP_SINGLE_R1, x1, n1, nullptr, 0); }
+                    if ((r2->flags & FASTP_GPU_RF_ADAPTER) && r2->adapter_len) { cut(*r2, t2, l2, s->a2, &x2, &n2); if (n2) put(blob, RP_SINGLE_R2, x2, n2, nullptr, 0); }
+                }
+            } else if ((r1.flags & FASTP_GPU_RF_ADAPTER) && r1.adapter_len) {
+                cut(r1, t1, l1, s->a1, &x1, &n1);
+                if (n1) put(blob, RP_SINGLE_R1, x1, n1, nullptr, 0);
+            }
+            auto fasta_events = [&](uint32_t key, const fastp_gpu_read_result& rr, const char* t, int tl, int is_r2) {   // trimByMultiSequences adaptertrimmer.cpp:48-62
+                auto it = events.find(key);
+                if (it == events.end()) return;
+                for (const fastp_gpu_adapter_event* e : it->second) {
+                    fastp_gpu_read_result q = rr;
+                    q.adapter_pos = e->pos;
+                    q.adapter_len = e->len;
+                    const char* a; size_t la;
+                    cut(q, t, tl, e->adapter < s->fasta.size() ? s->fasta[e->adapter] : std::string(), &a, &la);
+                    if (la) put(blob, is_r2 ? RP_SINGLE_R2 : RP_SINGLE_R1, a, la, nullptr, 0);
+                }
+            };
+            if (ev1) fasta_events(k1, r1, t1, l1, 0);
+            if (ev2) fasta_events(k2, *r2, t2, l2, 1);
+        }
+    }
+};
+
+void replay_blob(fastp_gpu_host* h, const std::vector<uint8_t>& blob) {
+    size_t at = 0;
+    while (at + 5 <= blob.size()) {
+        const uint8_t* w = blob.data() + at;
+        const int kind = w[0];
+        const size_t la = (size_t)w[1] | ((size_t)w[2] << 8), lb = (size_t)w[3] | ((size_t)w[4] << 8);
+        const char* a = (const char*)w + 5;
+        if (kind == RP_PAIR) fastp_gpu_host_add_adapter_pair(h, a, (int32_t)la, a + la, (int32_t)lb);
+        else fastp_gpu_host_add_adapter(h, kind == RP_SINGLE_R2, a, (int32_t)la);
+        at += 5 + la + lb;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fastp_gpu_stream_last_error(const fastp_gpu_stream* s) { return s ? s->err.c_str() : g_stream_error.c_str(); }
+
+int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stream_config* cfg, fastp_gpu_stream** out) {
+    if (!params || !cfg || !out || !cfg->in1) { g_stream_error = "null argument"; return FASTP_GPU_E_INVALID; }
+    std::unique_ptr<fastp_gpu_stream> s(new fastp_gpu_stream());
+    memset(&s->st, 0, sizeof(s->st));
+    s->p = *params;
+    s->cfg = *cfg;
+    s->paired = params->paired != 0;
+    s->nm = s->paired ? 2 : 1;
+    if (s->paired != (cfg->in2 != nullptr)) { g_stream_error = "a paired engine needs two input files, a single-end engine one"; return FASTP_GPU_E_INVALID; }
+    if (params->overlapped_out) { g_stream_error = "--overlapped_out's stream is written by the host glue (fastp_gpu_host.h), not by the device formatter"; return FASTP_GPU_E_UNSUPPORTED; }
+    s->in1 = cfg->in1;
+    if (cfg->in2) s->in2 = cfg->in2;
+    // own copies of every string the parameter block points at: a re-plan creates a context again
+    if (params->adapter_seq_r1) { s->a1 = params->adapter_seq_r1; s->p.adapter_seq_r1 = s->a1.c_str(); }
+    if (params->adapter_seq_r2) { s->a2 = params->adapter_seq_r2; s->p.adapter_seq_r2 = s->a2.c_str(); }
+    for (int i = 0; i < params->n_adapter_fasta && params->adapter_fasta; i++) s->fasta.push_back(params->adapter_fasta[i]);
+    for (auto& f : s->fasta) s->fastap.push_back(f.c_str());
+    s->p.adapter_fasta = s->fastap.empty() ? nullptr : s->fastap.data();
+    for (int i = 0; i < params->n_overrep_seqs1 && params->overrep_seqs1; i++) s->seeds[0].push_back(params->overrep_seqs1[i]);
+    for (int i = 0; i < params->n_overrep_seqs2 && params->overrep_seqs2; i++) s->seeds[1].push_back(params->overrep_seqs2[i]);
+    for (int m = 0; m < 2; m++) for (auto& q : s->seeds[m]) s->seedp[m].push_back(q.c_str());
+    s->p.overrep_seqs1 = s->seedp[0].empty() ? nullptr : s->seedp[0].data();
+    s->p.overrep_seqs2 = s->seedp[1].empty() ? nullptr : s->seedp[1].data();
+    if (cfg->format.umi_prefix) s->umi_prefix = cfg->format.umi_prefix;
+    s->umi_delim = cfg->format.umi_delimiter ? cfg->format.umi_delimiter : ":";
+    s->cfg.format.umi_prefix = s->umi_prefix.empty() ? nullptr : s->umi_prefix.c_str();
+    s->cfg.format.umi_delimiter = s->umi_delim.c_str();
+    s->cfg.in1 = s->in1.c_str();
+    s->cfg.in2 = s->paired ? s->in2.c_str() : nullptr;
+    s->chunk = cfg->chunk_bytes > 0 ? cfg->chunk_bytes : (int64_t)env_int("FASTP_GPU_STREAM_CHUNK_MB", 32) << 20;
+    if (cfg->chunk_bytes <= 0 && getenv("FASTP_GPU_STREAM_CHUNK_BYTES")) s->chunk = atoll(getenv("FASTP_GPU_STREAM_CHUNK_BYTES"));   // tests: many small trips
+    s->chunk = std::max<int64_t>(4096, std::min<int64_t>(s->chunk, (int64_t)1 << 30)) / 256 * 256;
+    if (s->cfg.io_threads <= 0) s->cfg.io_threads = env_int("FASTP_GPU_STREAM_IO_THREADS", 8);
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+        const bool possible = q == FASTP_GPU_OUT1 || (s->paired && q == FASTP_GPU_OUT2) || (q == FASTP_GPU_FAILED && cfg->format.want_failed) ||
+                              (q == FASTP_GPU_MERGED && s->paired && params->merge) || (q == FASTP_GPU_UNPAIRED1 && s->paired && cfg->format.want_unpaired1) ||
+                              (q == FASTP_GPU_UNPAIRED2 && s->paired && cfg->format.want_unpaired2);
+        if (s->cfg.want[q] && !possible) { g_stream_error = "a stream is wanted that the options never write to"; return FASTP_GPU_E_INVALID; }
+        if (s->cfg.want[q] && s->cfg.out_fd[q] < 0 && !s->cfg.emit) { g_stream_error = "a wanted stream has neither a file descriptor nor an emit callback"; return FASTP_GPU_E_INVALID; }
+    }
+    if (params->merge && s->paired && !s->cfg.want[FASTP_GPU_MERGED] && (s->cfg.want[FASTP_GPU_OUT1] || s->cfg.want[FASTP_GPU_OUT2])) {
+        // merge mode without --merged_out: legal for the reference (the merged reads are dropped); nothing to check
+    }
+    const double t0 = now_s();
+    int rc = fastp_gpu_create(&s->p, s->cfg.device, &s->ctx);
+    if (rc != FASTP_GPU_OK) { g_stream_error = std::string("fastp_gpu_create: ") + fastp_gpu_last_error(nullptr); return rc; }
+    s->st.max_len = s->p.max_len;
+    rc = alloc_buffers(s.get());
+    if (rc != FASTP_GPU_OK) {
+        g_stream_error = s->err;
+        free_buffers(s.get());
+        fastp_gpu_destroy(s->ctx);
+        return rc;
+    }
+    s->st.setup_s = now_s() - t0;
+    *out = s.release();
+    return FASTP_GPU_OK;
+}
+
+void fastp_gpu_stream_destroy(fastp_gpu_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    free_buffers(s);
+    if (s->ctx) fastp_gpu_destroy(s->ctx);
+    delete s;
+}
+
+int fastp_gpu_stream_get_stats(const fastp_gpu_stream* s, fastp_gpu_stream_stats* out) {
+    if (!s || !out) return FASTP_GPU_E_INVALID;
+    *out = s->st;
+    return FASTP_GPU_OK;
+}
+
+int fastp_gpu_stream_layout(const fastp_gpu_stream* s, fastp_gpu_counter_layout* out) {
+    if (!s || !out) return FASTP_GPU_E_INVALID;
+    fastp_gpu_counter_layout_for_params(&s->p, out);
+    return FASTP_GPU_OK;
+}
+
+int fastp_gpu_stream_counters(fastp_gpu_stream* s, int64_t* out, int64_t n) {
+    if (!s || !out || !s->ctx) return FASTP_GPU_E_INVALID;
+    fastp_gpu_counter_layout lay;
+    std::vector<int64_t> c;
+    int rc = fetch_ctx_counters(s, &lay, &c);
+    if (rc) return rc;
+    if (n != lay.total) return s->fail(FASTP_GPU_E_INVALID, "counter block size mismatch");
+    for (auto& seg : s->segments) add_counters(lay, c, seg.first, seg.second, s->p.insert_size_max);
+    memcpy(out, c.data(), (size_t)n * 8);
+    return FASTP_GPU_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// everything the threads of one run share
+struct Run {
+    fastp_gpu_stream* s;
+    int fds[2] = {-1, -1};
+    int64_t sizes[2] = {0, 0};
+    std::atomic<int> io_err{0}, emit_err{0};
+    Channel<ReadReq> q_req;
+    Channel<ReadDone> q_done;
+    Channel<WriteJob> q_write;
+    Channel<int> q_ofree;
+    Channel<ReplayJob> q_replay;
+    int64_t out_pos[FASTP_GPU_N_OUTPUTS];
+    explicit Run(fastp_gpu_stream* st) : s(st) {}
+};
+
+void reader_main(Run* R) {
+    fastp_gpu_stream* s = R->s;
+    (void)hipSetDevice(s->cfg.device);
+    IoPool pool(s->cfg.io_threads);
+    int64_t pos[2] = {0, 0};
+    for (;;) {
+        ReadReq rq = R->q_req.get();
+        if (rq.slot < 0) return;
+        ReadDone d;
+        d.slot = rq.slot;
+        for (int m = 0; m < s->nm; m++) {
+            const int64_t want = std::max<int64_t>(0, std::min(rq.budget[m], R->sizes[m] - pos[m]));
+            uint8_t* dst = s->pin_in[rq.slot][m] + rq.carry[m];
+            for (int64_t a = 0; a < want; a += IO_PIECE) {
+                const int64_t e = std::min(want, a + IO_PIECE);
+                const int fd = R->fds[m];
+                const int64_t off = pos[m] + a;
+                std::atomic<int>* err = &R->io_err;
+                pool.submit([fd, dst, a, e, off, err] {
+                    int64_t got = 0;
+                    while (got < e - a) {
+                        const ssize_t r = pread(fd, dst + a + got, (size_t)(e - a - got), (off_t)(off + got));
+                        if (r < 0 && errno == EINTR) continue;
+                        if (r <= 0) { err->store(1); return; }
+                        got += r;
+                    }
+                });
+            }
+            pos[m] += want;
+            d.nb[m] = want;
+            d.eof[m] = pos[m] >= R->sizes[m];
+        }
+        pool.wait();
+        if (R->io_err.load()) d.err = 1;
+        for (int m = 0; m < s->nm && !d.err; m++) {
+            const int64_t total = rq.carry[m] + d.nb[m];
+            memset(s->pin_in[rq.slot][m] + total, 0, 32);   // the parser reads 16-byte vectors past the end
+            if (hipMemcpyAsync(s->d_text[rq.slot][m], s->pin_in[rq.slot][m], (size_t)total + 32, hipMemcpyHostToDevice, s->cp_in) != hipSuccess) d.err = 2;
+        }
+        if (!d.err && hipStreamSynchronize(s->cp_in) != hipSuccess) d.err = 2;
+        R->q_done.put(d);
+    }
+}
+
+void writer_main(Run* R) {
+    fastp_gpu_stream* s = R->s;
+    IoPool pool(s->cfg.io_threads);
+    for (;;) {
+        WriteJob j = R->q_write.get();
+        if (j.oslot < 0) return;
+        const double t0 = now_s();
+        for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+            if (!s->cfg.want[q]) continue;
+            const uint8_t* src = j.oslot >= 2 ? BGZF_EOF : s->pin_out[j.oslot][q];   // oslot 2: the end-of-file members of the compressed streams
+            if (j.oslot >= 2 && !j.len[q]) continue;
+            if (s->cfg.out_fd[q] >= 0) {
+                for (int64_t a = 0; a < j.len[q]; a += IO_PIECE) {
+                    const int64_t e = std::min(j.len[q], a + IO_PIECE);
+                    const int fd = s->cfg.out_fd[q];
+                    const int64_t off = R->out_pos[q] + a;
+                    std::atomic<int>* err = &R->io_err;
+                    pool.submit([fd, src, a, e, off, err] {
+                        int64_t done = 0;
+                        while (done < e - a) {
+                            const ssize_t r = pwrite(fd, src + a + done, (size_t)(e - a - done), (off_t)(off + done));
+                            if (r < 0 && errno == EINTR) continue;
+                            if (r <= 0) { err->store(3); return; }
+                            done += r;
+                        }
+                    });
+                }
+            } else if (!R->emit_err.load()) {
+                if (s->cfg.emit(s->cfg.user, q, (const char*)src, j.len[q]) != 0) R->emit_err.store(1);
+            }
+            R->out_pos[q] += j.len[q];
+            s->st.bytes_out[q] += j.len[q];
+        }
+        pool.wait();
+        s->st.write_s += now_s() - t0;
+        if (j.oslot < 2) R->q_ofree.put(j.oslot);
+    }
+}
+
+void replay_main(Run* R) {
+    for (;;) {
+        ReplayJob j = R->q_replay.get();
+        if (j.stop) return;
+        const double t0 = now_s();
+        replay_blob(R->s->cfg.host, j.blob);
+        R->s->st.replay_s += now_s() - t0;
+    }
+}
+
+// the caller's thread: one trip per chunk
+int run_loop(Run* R) {
+    fastp_gpu_stream* s = R->s;
+    const int nm = s->nm;
+    Extractor ex{s, {}, {}, {}};
+    int64_t carry[2] = {0, 0};
+    int slot = 0;
+    bool done = false, drain = false;
+    {
+        ReadReq rq;
+        rq.slot = 0;
+        for (int m = 0; m < nm; m++) rq.budget[m] = s->chunk;
+        R->q_req.put(rq);
+    }
+    while (!done) {
+        double t0 = now_s();
+        ReadDone d = R->q_done.get();
+        s->st.wait_read_s += now_s() - t0;
+        if (d.err) return s->fail(d.err == 2 ? FASTP_GPU_E_HIP : FASTP_GPU_E_INVALID, d.err == 2 ? "host-to-device copy of a chunk failed" : "reading an input file failed");
+        slot = d.slot;
+        int64_t total[2] = {0, 0};
+        bool all_eof = true;
+        for (int m = 0; m < nm; m++) {
+            total[m] = carry[m] + d.nb[m];
+            s->st.bytes_in[m] += d.nb[m];
+            all_eof = all_eof && d.eof[m];
+        }
+        // ---- parse: both mates to the same number of records ----
+        int32_t cap = s->max_records;
+        if (s->cfg.reads_to_process > 0) cap = (int32_t)std::min<int64_t>(cap, s->cfg.reads_to_process - s->st.units);
+        fastp_gpu_parse_info info[2];
+        memset(info, 0, sizeof(info));
+        int n = 0;
+        bool stop_after = false;
+        t0 = now_s();
+        for (int attempt = 0;; attempt++) {
+            if (cap <= 0) { n = 0; break; }
+            if (attempt > 16) return s->fail(FASTP_GPU_E_INVALID, "the parser does not settle on a record count");
+            bool again = false;
+            int32_t want = cap;
+            for (int pass = 0; pass < 2 && !again; pass++) {
+                for (int m = 0; m < nm && !again; m++) {
+                    if (pass == 1 && info[m].n_records == want) continue;
+                    const int prc = fastp_gpu_parse_fastq(s->ctx, s->d_text[slot][m], total[m], d.eof[m] ? 1 : 0, want, s->d_seq[m], s->d_qual[m], s->d_len[m],
+                                                          s->d_loff[m], s->d_llen[m], &info[m]);
+                    if (prc == FASTP_GPU_OK) continue;
+                    if (prc != FASTP_GPU_E_INVALID || info[m].first_bad < 0) return s->fail_ctx(prc, "fastp_gpu_parse_fastq");
+                    if (info[m].bad_kind == FASTP_GPU_PARSE_BAD_TOO_LONG) {
+                        const int rc = replan(s, info[m].max_seq_len);
+                        if (rc) return rc;
+                        again = true;
+                    } else if (info[m].bad_kind == FASTP_GPU_PARSE_BAD_ALPHABET) {
+                        return s->fail(FASTP_GPU_E_ALPHABET, "record " + std::to_string(s->st.units + info[m].first_bad) + " of file " + std::to_string(m + 1) +
+                                                                 " has a letter outside ACGTN or a quality character outside '!'..'~'");
+                    } else {   // FastqReader::read returns NULL there: the stream ends in front of this record
+                        cap = info[m].first_bad;
+                        s->st.truncated = 1;
+                        stop_after = true;
+                        again = true;
+                    }
+                }
+                if (again) break;
+                want = info[0].n_records;
+                for (int m = 1; m < nm; m++) want = std::min(want, info[m].n_records);
+                if (want == 0) break;
+            }
+            if (again) continue;
+            n = want;
+            break;
+        }
+        s->st.parse_s += now_s() - t0;
+        int64_t left[2] = {0, 0};
+        bool any_left = false;
+        for (int m = 0; m < nm; m++) {
+            left[m] = total[m] - (n > 0 ? info[m].consumed : 0);
+            any_left = any_left || left[m] > 0;
+        }
+        const bool limit_hit = s->cfg.reads_to_process > 0 && s->st.units + n >= s->cfg.reads_to_process;
+        if (stop_after || limit_hit) {
+            done = true;
+        } else if (all_eof) {
+            // a trip takes at most max_records records: when the cap was hit, complete records may remain in the carried
+            // text - keep parsing without reading until a trip comes back short.  What is left then is a trailing partial
+            // record / the longer mate's surplus: the reference stops there too
+            drain = n > 0 && n >= cap && any_left;
+            done = !drain;
+        } else if (n == 0) {
+            for (int m = 0; m < nm; m++)
+                if (left[m] >= s->chunk) return s->fail(FASTP_GPU_E_INVALID, "a record does not fit the chunk size (FASTP_GPU_STREAM_CHUNK_MB)");
+        }
+        // the text the records do not cover moves to the front of the other slot; the reader fills in behind it while
+        // the device works on this trip
+        if (!done) {
+            ReadReq rq;
+            rq.slot = 1 - slot;
+            for (int m = 0; m < nm; m++) {
+                if (left[m] > 0) memcpy(s->pin_in[1 - slot][m], s->pin_in[slot][m] + (total[m] - left[m]), (size_t)left[m]);
+                rq.carry[m] = left[m];
+                rq.budget[m] = drain ? 0 : std::max<int64_t>(0, s->chunk - left[m]);
+            }
+            R->q_req.put(rq);
+        }
+        if (n > 0) {
+            // ---- the worker loop ----
+            t0 = now_s();
+            fastp_gpu_batch b;
+            memset(&b, 0, sizeof(b));
+            b.n = n;
+            b.flags = FASTP_GPU_BATCH_STAT_ISIZE;
+            b.seq1 = s->d_seq[0]; b.qual1 = s->d_qual[0]; b.len1 = s->d_len[0];
+            if (s->paired) { b.seq2 = s->d_seq[1]; b.qual2 = s->d_qual[1]; b.len2 = s->d_len[1]; }
+            fastp_gpu_results r;
+            memset(&r, 0, sizeof(r));
+            r.r1 = s->d_res[0];
+            if (s->paired) { r.r2 = s->d_res[1]; r.pair = s->d_pair; }
+            r.corrections = s->d_corr; r.corrections_capacity = s->corr_cap; r.n_corrections = s->d_nc;
+            r.adapter_events = s->d_ev; r.adapter_events_capacity = s->ev_cap; r.n_adapter_events = s->d_nev;
+            if (fastp_gpu_submit_device(s->ctx, &b, &r, nullptr) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_submit_device");
+            if (fastp_gpu_synchronize(s->ctx) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_synchronize");
+            s->st.engine_s += now_s() - t0;
+            // ---- the sparse lists' fill counts and, for the adapter replay, the records come to the host ----
+            t0 = now_s();
+            S_HIP(s, hipMemcpyAsync(&s->h_counts[0], s->d_nc, 4, hipMemcpyDeviceToHost, s->sx));
+            S_HIP(s, hipMemcpyAsync(&s->h_counts[1], s->d_nev, 4, hipMemcpyDeviceToHost, s->sx));
+            if (s->cfg.host)
+                for (int m = 0; m < nm; m++) {
+                    S_HIP(s, hipMemcpyAsync(s->h_res[m], s->d_res[m], (size_t)n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, s->sx));
+                    S_HIP(s, hipMemcpyAsync(s->h_loff[m], s->d_loff[m], (size_t)n * 16, hipMemcpyDeviceToHost, s->sx));
+                }
+            S_HIP(s, hipStreamSynchronize(s->sx));
+            const int32_t ncorr = s->corr_cap ? s->h_counts[0] : 0, nev = s->ev_cap ? s->h_counts[1] : 0;
+            if (ncorr > s->corr_cap) return s->fail(FASTP_GPU_E_OVERFLOW, "correction list overflow: lower the chunk size");
+            if (nev > s->ev_cap) return s->fail(FASTP_GPU_E_OVERFLOW, "adapter event list overflow: lower the chunk size");
+            if (s->cfg.host) {
+                if (ncorr) S_HIP(s, hipMemcpyAsync(s->h_corr, s->d_corr, (size_t)ncorr * sizeof(fastp_gpu_correction), hipMemcpyDeviceToHost, s->sx));
+                if (nev) S_HIP(s, hipMemcpyAsync(s->h_ev, s->d_ev, (size_t)nev * sizeof(fastp_gpu_adapter_event), hipMemcpyDeviceToHost, s->sx));
+                if (ncorr || nev) S_HIP(s, hipStreamSynchronize(s->sx));
+                ReplayJob job;
+                const uint8_t* text[2] = {s->pin_in[slot][0], nm > 1 ? s->pin_in[slot][1] : nullptr};
+                ex.run(n, text, ncorr, nev, job.blob);
+                if (!job.blob.empty()) R->q_replay.put(std::move(job));
+            }
+            s->st.d2h_s += now_s() - t0;
+            // ---- records -> the text of every output stream (-> gzip members) ----
+            WriteJob wj;
+            if (s->any_out) {
+                t0 = now_s();
+                fastp_gpu_format_io io[2];
+                for (int m = 0; m < nm; m++) { io[m].text = s->d_text[slot][m]; io[m].line_off = s->d_loff[m]; io[m].line_len = s->d_llen[m]; io[m].res = s->d_res[m]; }
+                fastp_gpu_format_options fo = s->cfg.format;
+                fo.corrections_capacity = s->corr_cap;
+                int64_t lens[FASTP_GPU_N_OUTPUTS];
+                if (fastp_gpu_format_streams(s->ctx, n, &io[0], s->paired ? &io[1] : nullptr, s->d_pair, s->d_corr, s->corr_cap ? s->d_nc : nullptr, &fo, s->d_out,
+                                             s->out_cap, lens) != FASTP_GPU_OK)
+                    return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_format_streams");
+                s->st.format_s += now_s() - t0;
+                t0 = now_s();
+                const uint8_t* src[FASTP_GPU_N_OUTPUTS];
+                for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+                    src[q] = s->d_out[q];
+                    if (!s->cfg.want[q]) { lens[q] = 0; continue; }
+                    if (s->cfg.compress[q] && lens[q] > 0) {
+                        int64_t glen = 0;
+                        if (fastp_gpu_deflate_bgzf(s->ctx, s->d_out[q], lens[q], 0, s->d_gz[q], s->gz_cap[q], &glen) != FASTP_GPU_OK)
+                            return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_deflate_bgzf");
+                        lens[q] = glen;
+                        src[q] = s->d_gz[q];
+                    }
+                }
+                s->st.deflate_s += now_s() - t0;
+                t0 = now_s();
+                wj.oslot = R->q_ofree.get();
+                s->st.wait_write_s += now_s() - t0;
+                t0 = now_s();
+                for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+                    wj.len[q] = lens[q];
+                    if (lens[q] > 0) S_HIP(s, hipMemcpyAsync(s->pin_out[wj.oslot][q], src[q], (size_t)lens[q], hipMemcpyDeviceToHost, s->sx));
+                }
+                S_HIP(s, hipStreamSynchronize(s->sx));
+                s->st.d2h_s += now_s() - t0;
+                R->q_write.put(wj);
+            }
+            s->st.units += n;
+            s->st.chunks++;
+        }
+        if (R->io_err.load()) return s->fail(FASTP_GPU_E_INVALID, "writing an output file failed");
+        if (R->emit_err.load()) return s->fail(FASTP_GPU_E_INVALID, "the emit callback stopped the run");
+        for (int m = 0; m < nm; m++) carry[m] = left[m];
+    }
+    return FASTP_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
+    if (!s || !s->ctx) return FASTP_GPU_E_INVALID;
+    const double t_start = now_s();
+    S_HIP(s, hipSetDevice(s->cfg.device));
+    Run R(s);
+    const char* paths[2] = {s->cfg.in1, s->cfg.in2};
+    for (int m = 0; m < s->nm; m++) {
+        R.fds[m] = open(paths[m], O_RDONLY);
+        struct stat sb;
+        if (R.fds[m] < 0 || fstat(R.fds[m], &sb) != 0 || !S_ISREG(sb.st_mode)) {
+            for (int k = 0; k <= m; k++) if (R.fds[k] >= 0) close(R.fds[k]);
+            return s->fail(FASTP_GPU_E_INVALID, std::string("cannot open as a regular file: ") + paths[m]);
+        }
+        R.sizes[m] = (int64_t)sb.st_size;
+    }
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) R.out_pos[q] = s->cfg.out_offset[q];
+    R.q_ofree.put(0);
+    R.q_ofree.put(1);
+    std::thread reader(reader_main, &R), writer(writer_main, &R), replayer(replay_main, &R);
+    int rc = run_loop(&R);
+    if (rc == FASTP_GPU_OK) {   // bgzip's empty last member ends every compressed stream
+        WriteJob eofs;
+        eofs.oslot = 2;
+        bool any = false;
+        for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++)
+            if (s->cfg.want[q] && s->cfg.compress[q]) { eofs.len[q] = (int64_t)sizeof(BGZF_EOF); any = true; }
+        if (any) R.q_write.put(eofs);
+    }
+    ReadReq stop_r;
+    R.q_req.put(stop_r);
+    WriteJob stop_w;
+    R.q_write.put(stop_w);
+    ReplayJob stop_p;
+    stop_p.stop = true;
+    R.q_replay.put(std::move(stop_p));
+    reader.join();
+    writer.join();
+    replayer.join();
+    for (int m = 0; m < s->nm; m++) close(R.fds[m]);
+    if (rc == FASTP_GPU_OK && R.io_err.load()) rc = s->fail(FASTP_GPU_E_INVALID, "file I/O failed");
+    if (rc == FASTP_GPU_OK && R.emit_err.load()) rc = s->fail(FASTP_GPU_E_INVALID, "the emit callback stopped the run");
+    s->st.wall_s = now_s() - t_start;
+    return rc;
+}

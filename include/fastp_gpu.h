@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FASTP_GPU_ABI_VERSION 2
+#define FASTP_GPU_ABI_VERSION 3
 
 /* ---- limits ------------------------------------------------------------ */
 #define FASTP_GPU_MAX_READ_LEN 512    /* padded read length the kernels tile in LDS */
@@ -337,11 +337,16 @@ int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char
  * own reader for that chunk (the reference's tolerant resynchronisation on '@' is host logic).
  * Only complete records are produced; info->consumed tells where the next chunk must start.
  * All pointers except `info` are DEVICE pointers; synchronous. */
+#define FASTP_GPU_PARSE_BAD_MALFORMED 1 /* what FastqReader::read refuses (:338-362): the reference stops reading there      */
+#define FASTP_GPU_PARSE_BAD_TOO_LONG 2  /* well formed, but longer than the context's max_len: re-plan with max_seq_len     */
+#define FASTP_GPU_PARSE_BAD_ALPHABET 3  /* well formed, a letter outside ACGTN / a quality character outside '!'..'~'        */
 typedef struct fastp_gpu_parse_info {
     int32_t n_records;   /* records packed                                              */
     int32_t first_bad;   /* index of the first malformed / over-long / non-ACGTN / quality outside '!'..'~' record, or -1 */
     int64_t consumed;    /* bytes of text the records cover (offset of the next record)  */
     int64_t n_lines;     /* line terminators seen (+1 for an unterminated last line)     */
+    int32_t bad_kind;    /* FASTP_GPU_PARSE_BAD_* of record first_bad, 0 when there is none (ABI v3)                */
+    int32_t max_seq_len; /* the longest sequence line among the well-formed records looked at (ABI v3)              */
 } fastp_gpu_parse_info;
 
 int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbytes, int is_last_chunk,
@@ -576,6 +581,8 @@ int fastp_gpu_submit_pass2_device(fastp_gpu_ctx* ctx, const fastp_gpu_batch* bat
 /* size of one image of the engine's bloom bitmaps (mBufNum * mBufLenInBytes, duplicate.cpp:13-47) */
 int64_t fastp_gpu_dup_bitmap_bytes(const fastp_gpu_ctx* ctx);
 int fastp_gpu_dup_bitmap_export(fastp_gpu_ctx* ctx, void* dst_device);              /* synchronous */
+/* this engine's bitmaps <- an image of the same size (a context that continues another one's stream); synchronous */
+int fastp_gpu_dup_bitmap_import(fastp_gpu_ctx* ctx, const void* src_device);
 /* OR of `n_images` consecutive images becomes this engine's prefix (0 = no preceding shard); synchronous */
 int fastp_gpu_dup_prefix_set(fastp_gpu_ctx* ctx, const void* images_device, int32_t n_images);
 /* in place: images[k] <- OR of images[j], j < k (images[0] <- 0), each `bytes_each` long; synchronous */

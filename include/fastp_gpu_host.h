@@ -57,6 +57,12 @@ int64_t fastp_gpu_host_adapter_entries(fastp_gpu_host* h, int is_r2);
 int fastp_gpu_host_adapter_entry(fastp_gpu_host* h, int is_r2, int64_t index, const char** seq, int32_t* len,
                                  int64_t* count);
 
+/* FilterResult::addAdapterTrimmed (src/filterresult.cpp:124-180) for a host that cuts the adapter strings out of
+ * its own text (fastp_gpu_stream.h): the one-read form, and the pair form of trimByOverlapAnalysis - read 2's string
+ * is not recorded when a cap refused read 1's.  Empty strings are not recorded (:125). */
+int fastp_gpu_host_add_adapter(fastp_gpu_host* h, int is_r2, const char* adapter, int32_t len);
+int fastp_gpu_host_add_adapter_pair(fastp_gpu_host* h, const char* a1, int32_t len1, const char* a2, int32_t len2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,8 @@ def patch(name, inserts):
 
 
 patch("peprocessor.cpp", [
+    (r"void PairEndProcessor::readerTask\(bool isLeft\)\s*\{",
+     "\n    if(fastp_gpu_stream_reader_pe(this, isLeft) > 0) return;   // GPU stream mode: raw chunks -> device parser / engine / formatter -> the writers' files\n", "after"),
     (r"bool PairEndProcessor::processPairEnd\(ReadPack\* leftPack, ReadPack\* rightPack, ThreadConfig\* config\)\s*\{",
      "\n    if(fastp_gpu_worker_pe(this, leftPack, rightPack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
     (r"[ \t]*// merge stats and filter results",
@@ -45,6 +47,8 @@ patch("peprocessor.cpp", [
      "\n            fastp_gpu_worker_idle_pe(this, config);   // nothing to consume: hand out what has come back meanwhile", "after"),
 ])
 patch("seprocessor.cpp", [
+    (r"void SingleEndProcessor::readerTask\(\)\s*\{",
+     "\n    if(fastp_gpu_stream_reader_se(this) > 0) return;   // GPU stream mode\n", "after"),
     (r"bool SingleEndProcessor::processSingleEnd\(ReadPack\* pack, ThreadConfig\* config\)\s*\{",
      "\n    if(fastp_gpu_worker_se(this, pack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
     (r"[ \t]*// merge stats and read filter results",

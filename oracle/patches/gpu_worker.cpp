@@ -59,6 +59,7 @@
 
 #include "fastp_gpu.h"
 #include "fastp_gpu_host.h"
+#include "fastp_gpu_stream.h"
 #include "gpu_worker.h"
 
 namespace {
@@ -96,16 +97,26 @@ struct Window {
     std::atomic<int> filled{0};            // packs packed so far
     std::atomic<int> applied{0};           // packs whose records have been turned into output
     std::atomic<long> index{-1};           // which window of the stream the slot holds (-1: free)
+    std::atomic<long> next{-1};            // the window the slot serves next (slot, slot + NSLOT, ...): set by make_state / the free
     std::atomic<int> state{0};             // 0 filling, 1 submitted, 2 arrived
     int packs = 0;                         // packs in the submitted batch
     fastp_gpu_batch batch;
     fastp_gpu_results res;
 };
 
+// the strings a parameter block points at, and the host-side options that go with it
+struct ParamBlock {
+    fastp_gpu_params params;
+    fastp_gpu_host_options ho;
+    std::vector<std::string> seeds[2], fasta;        // own copies of the strings the parameter block points at
+    std::vector<const char*> seedp[2], fastap;
+    std::string a1, a2, umi_prefix, umi_delim;
+};
+
 struct State {
     std::mutex mu;               // submission order = window order; also guards fastp_gpu_* calls that touch the stream
     fastp_gpu_ctx* ctx = nullptr;
-    fastp_gpu_params params;
+    ParamBlock B;
     fastp_gpu_counter_layout lay;
     bool paired = false;
     int max_len = 0;
@@ -115,10 +126,6 @@ struct State {
     long next_submit = 0;                  // (under mu) the oldest window not yet submitted
     std::atomic<long> total_packs{-1};     // known once the reader has finished
     std::vector<fastp_gpu_host*> hosts;              // per worker thread: output strings + adapter maps
-    std::vector<std::string> seeds[2], fasta;        // own copies of the strings the parameter block points at
-    std::vector<const char*> seedp[2], fastap;
-    std::string a1, a2, umi_prefix;
-    std::atomic<bool> warned_fallback{false};
 };
 State* G = nullptr;
 std::once_flag g_once;
@@ -131,18 +138,14 @@ bool enabled() {
 void refuse(const char* what) { error_exit(std::string("FASTP_GPU=1: ") + what + " is outside the engine's scope"); }
 
 // Options (already validated, Evaluator results applied) -> the engine's flat parameter block
-void make_state(Options* o, bool paired) {
-    State* s = new State();
-    s->paired = paired;
+void fill_params(Options* o, bool paired, int max_len, ParamBlock* s) {
     if (o->indexFilter.enabled) refuse("--filter_by_index");
     if (o->fixMGI) refuse("--fix_mgi_id");
     if (o->split.enabled) refuse("--split");
     if (o->outputToSTDOUT) refuse("--stdout");
-    s->max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);
-    if (s->max_len <= 0) s->max_len = 151;
-    if (s->max_len > FASTP_GPU_MAX_READ_LEN) refuse("reads longer than FASTP_GPU_MAX_READ_LEN");
+    if (max_len > FASTP_GPU_MAX_READ_LEN) refuse("reads longer than FASTP_GPU_MAX_READ_LEN");
     fastp_gpu_params& p = s->params;
-    fastp_gpu_default_params(&p, paired ? 1 : 0, s->max_len);
+    fastp_gpu_default_params(&p, paired ? 1 : 0, max_len);
     p.trim_front1 = o->trim.front1;  p.trim_tail1 = o->trim.tail1;
     p.trim_front2 = o->trim.front2;  p.trim_tail2 = o->trim.tail2;
     p.max_len1 = o->trim.maxLen1;    p.max_len2 = o->trim.maxLen2;
@@ -197,10 +200,7 @@ void make_state(Options* o, bool paired) {
         p.overrep_seqs2 = s->seedp[1].data();  p.n_overrep_seqs2 = paired ? (int)s->seedp[1].size() : 0;
         p.eval_seq_len1 = o->seqLen1;  p.eval_seq_len2 = o->seqLen2;
     }
-    int rc = fastp_gpu_create(&p, 0, &s->ctx);
-    if (rc != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_create: ") + fastp_gpu_last_error(NULL));   // never a silent CPU fallback
-    fastp_gpu_counter_layout_for_params(&p, &s->lay);
-    fastp_gpu_host_options ho;
+    fastp_gpu_host_options& ho = s->ho;
     memset(&ho, 0, sizeof(ho));
     ho.want_failed = !o->failedOut.empty();
     ho.want_unpaired1 = !o->unpaired1.empty();
@@ -210,9 +210,29 @@ void make_state(Options* o, bool paired) {
                    : o->umi.location == UMI_LOC_READ2 ? FASTP_GPU_UMI_READ2 : FASTP_GPU_UMI_PER_READ;
         ho.umi_len = o->umi.length;
         s->umi_prefix = o->umi.prefix;
+        s->umi_delim = o->umi.delimiter;
         ho.umi_prefix = s->umi_prefix.empty() ? NULL : s->umi_prefix.c_str();
-        ho.umi_delimiter = o->umi.delimiter.empty() ? NULL : o->umi.delimiter.c_str();
+        ho.umi_delimiter = s->umi_delim.empty() ? NULL : s->umi_delim.c_str();
     }
+}
+
+void make_state(Options* o, bool paired) {
+    State* s = new State();
+    s->paired = paired;
+    // pack mode is what is left for the option sets the stream binding below does not take (--overlapped_out, phred64,
+    // interleaved / piped input); it is bound by the reference's reader thread, so the rows are sized generously rather
+    // than by the first 1000 reads (Evaluator::computeSeqLen evaluator.cpp:54-76): a longer read later in the file is
+    // what the reference takes in its stride (Stats::extendBuffer stats.cpp:65-83)
+    s->max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);
+    if (s->max_len <= 0) s->max_len = 151;
+    s->max_len = std::min<int>(FASTP_GPU_MAX_READ_LEN, std::max(s->max_len + s->max_len / 2, 256));
+    if (const char* v = getenv("FASTP_GPU_MAX_LEN")) s->max_len = atoi(v);
+    fill_params(o, paired, s->max_len, &s->B);
+    fastp_gpu_params& p = s->B.params;
+    int rc = fastp_gpu_create(&p, 0, &s->ctx);
+    if (rc != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_create: ") + fastp_gpu_last_error(NULL));   // never a silent CPU fallback
+    fastp_gpu_counter_layout_for_params(&p, &s->lay);
+    const fastp_gpu_host_options& ho = s->B.ho;
     for (int t = 0; t < o->thread; t++) {
         fastp_gpu_host* h = NULL;
         if (fastp_gpu_host_create(&p, &ho, &h) != FASTP_GPU_OK) error_exit("fastp_gpu_host_create failed");
@@ -246,6 +266,7 @@ void make_state(Options* o, bool paired) {
         if (p.n_adapter_fasta) { w.ev_cap = (int32_t)(units * 2 * std::min(p.n_adapter_fasta, 8) + 16); w.ev = (fastp_gpu_adapter_event*)pinned((size_t)w.ev_cap * sizeof(fastp_gpu_adapter_event)); }
         w.count.assign((size_t)s->K, 0);
     }
+    for (int k = 0; k < NSLOT; k++) s->win[k].next.store(k);
     G = s;
 }
 
@@ -311,12 +332,16 @@ void pump() {
             if (exp == 0 && have == 0) { /* the stream ended on a window boundary: nothing to submit */ }
             break;
         }
-        // rows are contiguous when every pack but the last is full; the reader only leaves the stream's last pack short
+        // rows are contiguous when every pack in front of the last non-empty one is full: the reader leaves the stream's
+        // last pack short, and --reads_to_process / unequal files put an empty terminal pack behind a short one
+        // (peprocessor.cpp:757-771, :775-778)
         long n = 0;
-        bool contiguous = true;
+        bool contiguous = true, ended = false;
         for (int i = 0; i < have; i++) {
-            if (i + 1 < have && w.count[(size_t)i] != PACK_SIZE) contiguous = false;
-            n = (long)i * PACK_SIZE + w.count[(size_t)i];
+            const int cnt = w.count[(size_t)i];
+            if (ended && cnt != 0) contiguous = false;
+            if (cnt != PACK_SIZE) ended = true;
+            if (cnt > 0) n = (long)i * PACK_SIZE + cnt;
         }
         if (!contiguous) error_exit("FASTP_GPU=1: a short pack in the middle of the stream (unexpected reader behaviour)");
         memset(&w.batch, 0, sizeof(w.batch));
@@ -356,6 +381,9 @@ Window* window_for(long j) {
         long idx = w.index.load(std::memory_order_acquire);
         if (idx == j) return &w;
         if (idx == -1) {   // free: claim it for window j (several threads may try; one wins, the others see idx == j)
+            // ... but only when it is window j's turn: a thread that runs ahead must not take the slot of a window whose
+            // packs have not been picked up yet (window 3 in front of window 0: nobody could ever submit window 0)
+            if (w.next.load(std::memory_order_acquire) != j) return nullptr;
             long expect = -1;
             if (w.index.compare_exchange_strong(expect, j, std::memory_order_acq_rel)) return &w;
             continue;
@@ -426,6 +454,7 @@ int drain_ready(int tid, Emit emit, Recycle recycle) {
             w.applied.store(0, std::memory_order_relaxed);
             w.filled.store(0, std::memory_order_relaxed);
             w.state.store(0, std::memory_order_relaxed);
+            w.next.store(j + NSLOT, std::memory_order_release);
             w.index.store(-1, std::memory_order_release);
         }
         T.pending.pop_front();
@@ -446,8 +475,10 @@ bool pack_into(Window& w, size_t row, int n, bool paired) {
 }
 
 // the engine's counter block added onto one Stats object (the per-cycle part has Stats::mCycleBuffer's layout)
+const fastp_gpu_counter_layout* LAY = nullptr;   // the layout of the block being loaded (pack mode: G->lay, stream mode: the stream's)
+
 void load_stats(Stats* st, const std::vector<int64_t>& c, int slot, const std::vector<std::string>& seeds) {
-    const fastp_gpu_counter_layout& L = G->lay;
+    const fastp_gpu_counter_layout& L = *LAY;
     const int64_t base = L.stats[slot];
     st->mReads += c[base + L.st_reads];
     st->mLengthSum += c[base + L.st_length_sum];
@@ -466,7 +497,7 @@ void load_stats(Stats* st, const std::vector<int64_t>& c, int slot, const std::v
 }
 
 void load_filter_result(FilterResult* fr, const std::vector<int64_t>& c) {
-    const fastp_gpu_counter_layout& L = G->lay;
+    const fastp_gpu_counter_layout& L = *LAY;
     for (int i = 0; i < FILTER_RESULT_TYPES; i++) fr->mFilterReadStats[i] += c[L.filter_stats + i];
     fr->mTrimmedAdapterRead += c[L.adapter_reads];
     fr->mTrimmedAdapterBases += c[L.adapter_bases];
@@ -476,14 +507,14 @@ void load_filter_result(FilterResult* fr, const std::vector<int64_t>& c) {
     fr->mMergedPairs += c[L.merged_pairs];
 }
 
-void load_adapters(ThreadConfig** configs, int threads) {
-    for (int t = 0; t < threads && t < (int)G->hosts.size(); t++)
+void load_adapters(ThreadConfig** configs, const std::vector<fastp_gpu_host*>& hosts, int threads) {
+    for (int t = 0; t < threads && t < (int)hosts.size(); t++)
         for (int m = 0; m < 2; m++) {
-            const int64_t n = fastp_gpu_host_adapter_entries(G->hosts[t], m);
+            const int64_t n = fastp_gpu_host_adapter_entries(hosts[t], m);
             auto& dst = m ? configs[t]->getFilterResult()->mAdapter2 : configs[t]->getFilterResult()->mAdapter1;
             for (int64_t i = 0; i < n; i++) {
                 const char* s; int32_t len; int64_t cnt;
-                fastp_gpu_host_adapter_entry(G->hosts[t], m, i, &s, &len, &cnt);
+                fastp_gpu_host_adapter_entry(hosts[t], m, i, &s, &len, &cnt);
                 dst[std::string(s, (size_t)len)] += cnt;
             }
         }
@@ -510,10 +541,13 @@ void shutdown() {
 }  // namespace
 
 // the stream's length is known once the reader has handed out its last pack (a thread sees that on its own input list)
-template <class Proc, class List>
-void note_total(Proc* pp, List* in) {
+// Paired: a worker's loop can also end because ITS read-2 list is exhausted while the read-1 reader is still producing
+// packs for other threads (processorTask's second exit, peprocessor.cpp:1034-1037) - the pack counters are final only
+// when both readers have closed their lists, and the stream holds min(read-1 packs, read-2 packs) pack pairs.
+void note_total(PairEndProcessor* pp, ThreadConfig* config) {
     if (G->total_packs.load(std::memory_order_acquire) >= 0) return;
-    if (in->isProducerFinished()) G->total_packs.store((long)pp->mLeftPackReadCounter, std::memory_order_release);
+    if (config->getLeftInput()->isProducerFinished() && config->getRightInput()->isProducerFinished())
+        G->total_packs.store(std::min((long)pp->mLeftPackReadCounter, (long)pp->mRightPackReadCounter), std::memory_order_release);
 }
 void note_total_se(SingleEndProcessor* sp, SingleProducerSingleConsumerList<ReadPack*>* in) {
     if (G->total_packs.load(std::memory_order_acquire) >= 0) return;
@@ -551,21 +585,21 @@ int fastp_gpu_worker_pe(PairEndProcessor* pp, ReadPack* left, ReadPack* right, T
     const long j = seq / G->K;
     Window* w;
     while (!(w = window_for(j))) {            // the slot still holds window j - NSLOT: help it along
-        note_total(pp, config->getLeftInput());
+        note_total(pp, config);
         pump();
         if (!drain_ready(tid, emit, recycle)) std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     const size_t slot = (size_t)(seq - j * G->K);
     gather(left->data, n, 0);
     gather(right->data, n, 1);
-    if (!pack_into(*w, slot * PACK_SIZE, n, true)) refuse_pack();
+    if (n > 0 && !pack_into(*w, slot * PACK_SIZE, n, true)) refuse_pack();   // the stream's terminal pack may be empty (reads % 1000 == 0)
     w->count[slot] = n;
     w->filled.fetch_add(1, std::memory_order_acq_rel);
     T.pending.push_back(Pending{seq, left, right, n});
     config->markProcessed(left->count);
     pp->mPackProcessedCounter.fetch_add(1, std::memory_order_release);   // accepted: the windows bound the memory now
     pp->mBackpressureCV.notify_all();
-    note_total(pp, config->getLeftInput());
+    note_total(pp, config);
     pump();
     drain_ready(tid, emit, recycle);
     return 1;
@@ -584,12 +618,19 @@ void fastp_gpu_worker_drain_pe(PairEndProcessor* pp, ThreadConfig* config) {
         delete pd.left;
         delete pd.right;
     };
-    // this thread's loop ended, so the reader is done: the stream's length is final
-    G->total_packs.store((long)pp->mLeftPackReadCounter, std::memory_order_release);
+    // this thread's loop has ended; the stream's length is final once BOTH readers are done (see note_total)
+    long spins = 0;
     while (!T.pending.empty()) {
+        note_total(pp, config);
         pump();
         if (!drain_ready(tid, emit, recycle)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (getenv("FASTP_GPU_DEBUG_BINDING") && ++spins % 20000 == 0) {
+            fprintf(stderr, "drain tid %d: pending front %ld (n=%zu) next_submit %ld total %ld L %ld R %ld lf %d rf %d\n", tid, T.pending.front().seq, T.pending.size(), G->next_submit,
+                    G->total_packs.load(), (long)pp->mLeftPackReadCounter, (long)pp->mRightPackReadCounter, (int)config->getLeftInput()->isProducerFinished(), (int)config->getRightInput()->isProducerFinished());
+            for (int k = 0; k < NSLOT; k++) fprintf(stderr, "   slot %d: index %ld state %d filled %d applied %d packs %d\n", k, G->win[k].index.load(), G->win[k].state.load(), G->win[k].filled.load(), G->win[k].applied.load(), G->win[k].packs);
+        }
     }
+    note_total(pp, config);
     pump();
 }
 
@@ -605,7 +646,7 @@ void fastp_gpu_worker_idle_pe(PairEndProcessor* pp, ThreadConfig* config) {
         delete pd.left;
         delete pd.right;
     };
-    note_total(pp, config->getLeftInput());
+    note_total(pp, config);
     pump();
     drain_ready(tid, emit, recycle);
 }
@@ -636,7 +677,7 @@ int fastp_gpu_worker_se(SingleEndProcessor* sp, ReadPack* pack, ThreadConfig* co
     }
     const size_t slot = (size_t)(seq - j * G->K);
     gather(pack->data, n, 0);
-    if (!pack_into(*w, slot * PACK_SIZE, n, false)) refuse_pack();
+    if (n > 0 && !pack_into(*w, slot * PACK_SIZE, n, false)) refuse_pack();
     w->count[slot] = n;
     w->filled.fetch_add(1, std::memory_order_acq_rel);
     T.pending.push_back(Pending{seq, pack, nullptr, n});
@@ -686,34 +727,221 @@ void fastp_gpu_worker_idle_se(SingleEndProcessor* sp, ThreadConfig* config) {
     drain_ready(tid, emit, recycle);
 }
 
+// the counter block (layout *LAY) into the first worker's Stats / FilterResult objects, Duplicate's totals and the
+// insert-size histogram; the reference's own merge + reporters take it from there
+template <class Proc>
+void load_block(Proc* pp, ThreadConfig** configs, const std::vector<int64_t>& c, const ParamBlock& B, bool paired) {
+    load_stats(configs[0]->getPreStats1(), c, FASTP_GPU_STATS_PRE1, B.seeds[0]);
+    load_stats(configs[0]->getPostStats1(), c, FASTP_GPU_STATS_POST1, B.seeds[0]);
+    if (paired) {
+        load_stats(configs[0]->getPreStats2(), c, FASTP_GPU_STATS_PRE2, B.seeds[1]);
+        load_stats(configs[0]->getPostStats2(), c, FASTP_GPU_STATS_POST2, B.seeds[1]);
+    }
+    load_filter_result(configs[0]->getFilterResult(), c);
+    if (pp->mDuplicate) {
+        pp->mDuplicate->mTotalReads += (unsigned long)c[LAY->dup_total];
+        pp->mDuplicate->mDupReads += (unsigned long)c[LAY->dup_count];
+    }
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// STREAM MODE (the default with FASTP_GPU=1): the reference's reader threads, worker threads and the string side of its
+// writers are bypassed by ONE loop - include/fastp_gpu_stream.h: raw chunks of the input files -> page-locked memory ->
+// fastp_gpu_parse_fastq -> fastp_gpu_submit_device -> fastp_gpu_format_streams (-> fastp_gpu_deflate_bgzf for ".gz") ->
+// the files the reference's own WriterThread objects opened.  The hook sits at the top of readerTask: the read-1 reader
+// thread runs the loop, the read-2 reader thread returns at once, and when the loop is done both sets of input lists
+// are closed - the (idle) worker threads then leave processorTask and the last of them completes the writers, exactly
+// as after a normal run.  Evaluator, Options, WriterThread (file ownership, gz truncation), Stats / FilterResult /
+// Duplicate objects, JSON and HTML reporters stay the reference's.
+//   FASTP_GPU_STREAM=0       pack mode (below) for every option set
+//   FASTP_GPU_WRITER=input   hand the text to WriterThread::input as strings (one per chunk, threads in turn) instead
+//                            of writing it into the writers' file descriptors with positional writes
+// ---------------------------------------------------------------------------------------------------------------
+struct StreamState {
+    ParamBlock B;
+    fastp_gpu_stream* st = nullptr;
+    fastp_gpu_host* host = nullptr;
+    WriterThread* writer[FASTP_GPU_N_OUTPUTS] = {};
+    long fed[FASTP_GPU_N_OUTPUTS] = {};     // strings handed to each writer so far (FASTP_GPU_WRITER=input)
+    int W = 1;
+    bool paired = false, ran = false;
+};
+StreamState* SG = nullptr;
+std::once_flag sg_once;
+
+bool plain_regular_file(const std::string& path) {
+    if (path.empty() || ends_with(path, ".gz")) return false;
+    struct stat sb;
+    return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+}
+
+// the option sets the stream loop takes; everything else goes through pack mode
+bool stream_mode(Options* o, bool paired) {
+    if (!enabled()) return false;
+    if (const char* v = getenv("FASTP_GPU_STREAM")) if (atoi(v) == 0) return false;
+    if (o->interleavedInput || o->phred64 || !o->overlappedOut.empty()) return false;
+    if (!plain_regular_file(o->in1) || (paired && !plain_regular_file(o->in2))) return false;
+    if (paired && !o->out1.empty() && o->out2.empty()) return false;   // two reads into one stream: --stdout's form
+    return true;
+}
+
+int emit_to_writer(void* user, int stream, const char* data, int64_t len) {
+    StreamState* S = (StreamState*)user;
+    WriterThread* w = S->writer[stream];
+    if (!w) return 0;
+    while (w->bufferLength() > PACK_IN_MEM_LIMIT) usleep(200);   // the reader's own backpressure rule (peprocessor.cpp:842-849)
+    w->input((int)(S->fed[stream]++ % S->W), new std::string(data, (size_t)len));
+    return 0;
+}
+
+void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU_N_OUTPUTS]) {
+    StreamState* S = new StreamState();
+    S->paired = paired;
+    S->W = std::max(1, o->thread);
+    int max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);   // Evaluator::computeSeqLen: the first 1000 reads
+    if (max_len <= 0) max_len = 151;
+    if (const char* v = getenv("FASTP_GPU_MAX_LEN")) max_len = atoi(v);
+    fill_params(o, paired, max_len, &S->B);
+    if (fastp_gpu_host_create(&S->B.params, &S->B.ho, &S->host) != FASTP_GPU_OK) error_exit("fastp_gpu_host_create failed");
+    fastp_gpu_stream_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.in1 = o->in1.c_str();
+    cfg.in2 = paired ? o->in2.c_str() : NULL;
+    cfg.reads_to_process = o->readsToProcess;
+    cfg.format.want_failed = S->B.ho.want_failed;
+    cfg.format.want_unpaired1 = S->B.ho.want_unpaired1;
+    cfg.format.want_unpaired2 = S->B.ho.want_unpaired2;
+    cfg.format.umi_loc = S->B.ho.umi_loc;
+    cfg.format.umi_len = S->B.ho.umi_len;
+    cfg.format.umi_prefix = S->B.ho.umi_prefix;
+    cfg.format.umi_delimiter = S->B.ho.umi_delimiter;
+    const char* wm = getenv("FASTP_GPU_WRITER");
+    const bool via_input = wm && std::string(wm) == "input";
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+        WriterThread* w = writers[q];
+        S->writer[q] = w;
+        cfg.out_fd[q] = -1;
+        if (!w) continue;
+        cfg.want[q] = 1;
+        if (via_input) continue;   // text to WriterThread::input, which compresses ".gz" itself
+        cfg.compress[q] = ends_with(w->getFilename(), ".gz") ? 1 : 0;
+        cfg.out_fd[q] = w->mPwriteMode ? w->mFd : fileno(w->mWriter1->mFP);
+    }
+    cfg.emit = emit_to_writer;
+    cfg.user = S;
+    cfg.host = S->host;
+    if (fastp_gpu_stream_create(&S->B.params, &cfg, &S->st) != FASTP_GPU_OK)
+        error_exit(std::string("fastp_gpu_stream_create: ") + fastp_gpu_stream_last_error(NULL));   // never a silent CPU fallback
+    SG = S;
+}
+
+void stream_run() {
+    StreamState* S = SG;
+    if (fastp_gpu_stream_run(S->st) != FASTP_GPU_OK) error_exit(std::string("FASTP_GPU=1: ") + fastp_gpu_stream_last_error(S->st));
+    fastp_gpu_stream_stats st;
+    fastp_gpu_stream_get_stats(S->st, &st);
+    // a pwrite-mode writer (".gz", several threads) cuts its file at the offset the last pack was written to
+    // (WriterThread::setInputCompletedPwrite): tell it where the stream's bytes end
+    for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+        WriterThread* w = S->writer[q];
+        if (!w || !w->mPwriteMode || S->fed[q] > 0) continue;
+        w->mOffsetRing[0].cumulative_offset.store((size_t)st.bytes_out[q], std::memory_order_relaxed);
+        w->mOffsetRing[0].published_seq.store(0, std::memory_order_release);
+        w->mNextSeq[0] = (size_t)S->W;   // "worker 0 wrote pack 0"
+    }
+    if (st.truncated) cerr << "WARNING: the input ended at a malformed FASTQ record; the reads in front of it were processed" << endl;
+    if (getenv("FASTP_GPU_VERBOSE"))
+        fprintf(stderr, "fastp_gpu: stream mode: %lld units in %lld chunks, %.3f s (setup %.3f, wait-read %.3f, parse %.3f, engine %.3f, format %.3f, deflate %.3f, "
+                        "copies %.3f, wait-write %.3f; writer %.3f, adapter replay %.3f), max_len %d, %lld re-plan(s)\n",
+                (long long)st.units, (long long)st.chunks, st.wall_s, st.setup_s, st.wait_read_s, st.parse_s, st.engine_s, st.format_s, st.deflate_s, st.d2h_s,
+                st.wait_write_s, st.write_s, st.replay_s, (int)st.max_len, (long long)st.replans);
+    S->ran = true;
+}
+
+void stream_shutdown() {
+    fastp_gpu_stream_destroy(SG->st);
+    fastp_gpu_host_destroy(SG->host);
+    delete SG;
+    SG = nullptr;
+}
+
+bool stream_finish_pe(PairEndProcessor* pp, ThreadConfig** configs) {
+    if (!SG) return false;
+    fastp_gpu_counter_layout lay;
+    fastp_gpu_stream_layout(SG->st, &lay);
+    std::vector<int64_t> c((size_t)lay.total);
+    if (fastp_gpu_stream_counters(SG->st, c.data(), lay.total) != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_stream_counters: ") + fastp_gpu_stream_last_error(SG->st));
+    LAY = &lay;
+    load_block(pp, configs, c, SG->B, true);
+    load_adapters(configs, std::vector<fastp_gpu_host*>(1, SG->host), 1);
+    for (int i = 0; i <= pp->mOptions->insertSizeMax; i++) pp->mInsertSizeHist[i] += (long)c[lay.isize + i];
+    LAY = nullptr;
+    stream_shutdown();
+    return true;
+}
+
+bool stream_finish_se(SingleEndProcessor* sp, ThreadConfig** configs) {
+    if (!SG) return false;
+    fastp_gpu_counter_layout lay;
+    fastp_gpu_stream_layout(SG->st, &lay);
+    std::vector<int64_t> c((size_t)lay.total);
+    if (fastp_gpu_stream_counters(SG->st, c.data(), lay.total) != FASTP_GPU_OK) error_exit(std::string("fastp_gpu_stream_counters: ") + fastp_gpu_stream_last_error(SG->st));
+    LAY = &lay;
+    load_block(sp, configs, c, SG->B, false);
+    load_adapters(configs, std::vector<fastp_gpu_host*>(1, SG->host), 1);
+    LAY = nullptr;
+    stream_shutdown();
+    return true;
+}
+
+}  // namespace
+
+// the reader-thread hooks (top of readerTask): 1 = stream mode took the run, -1 = the reference's reader runs (pack mode)
+int fastp_gpu_stream_reader_pe(PairEndProcessor* pp, bool isLeft) {
+    if (!stream_mode(pp->mOptions, true)) return -1;
+    if (!isLeft) return 1;   // the read-1 reader thread drives both files
+    WriterThread* const writers[FASTP_GPU_N_OUTPUTS] = {pp->mLeftWriter, pp->mRightWriter, pp->mFailedWriter, pp->mMergedWriter,
+                                                        pp->mUnpairedLeftWriter, pp->mUnpairedRightWriter};
+    stream_setup(pp->mOptions, true, writers);
+    stream_run();
+    for (int t = 0; t < pp->mOptions->thread; t++) {   // what both reader threads do when their file is exhausted (peprocessor.cpp:866-872)
+        pp->mLeftInputLists[t]->setProducerFinished();
+        pp->mRightInputLists[t]->setProducerFinished();
+    }
+    pp->mBackpressureCV.notify_all();
+    return 1;
+}
+
+int fastp_gpu_stream_reader_se(SingleEndProcessor* sp) {
+    if (!stream_mode(sp->mOptions, false)) return -1;
+    WriterThread* const writers[FASTP_GPU_N_OUTPUTS] = {sp->mLeftWriter, NULL, sp->mFailedWriter, NULL, NULL, NULL};
+    stream_setup(sp->mOptions, false, writers);
+    stream_run();
+    for (int t = 0; t < sp->mOptions->thread; t++) sp->mInputLists[t]->setProducerFinished();
+    sp->mBackpressureCV.notify_all();
+    return 1;
+}
+
 void fastp_gpu_worker_finish_pe(PairEndProcessor* pp, ThreadConfig** configs) {
+    if (stream_finish_pe(pp, configs)) return;
     if (!G) return;
     const std::vector<int64_t> c = fetch_counters();
-    load_stats(configs[0]->getPreStats1(), c, FASTP_GPU_STATS_PRE1, G->seeds[0]);
-    load_stats(configs[0]->getPostStats1(), c, FASTP_GPU_STATS_POST1, G->seeds[0]);
-    load_stats(configs[0]->getPreStats2(), c, FASTP_GPU_STATS_PRE2, G->seeds[1]);
-    load_stats(configs[0]->getPostStats2(), c, FASTP_GPU_STATS_POST2, G->seeds[1]);
-    load_filter_result(configs[0]->getFilterResult(), c);
-    load_adapters(configs, pp->mOptions->thread);
-    if (pp->mDuplicate) {
-        pp->mDuplicate->mTotalReads += (unsigned long)c[G->lay.dup_total];
-        pp->mDuplicate->mDupReads += (unsigned long)c[G->lay.dup_count];
-    }
+    LAY = &G->lay;
+    load_block(pp, configs, c, G->B, true);
+    load_adapters(configs, G->hosts, pp->mOptions->thread);
     for (int i = 0; i <= pp->mOptions->insertSizeMax; i++) pp->mInsertSizeHist[i] += (long)c[G->lay.isize + i];
     shutdown();
 }
 
 void fastp_gpu_worker_finish_se(SingleEndProcessor* sp, ThreadConfig** configs) {
+    if (stream_finish_se(sp, configs)) return;
     if (!G) return;
     const std::vector<int64_t> c = fetch_counters();
-    load_stats(configs[0]->getPreStats1(), c, FASTP_GPU_STATS_PRE1, G->seeds[0]);
-    load_stats(configs[0]->getPostStats1(), c, FASTP_GPU_STATS_POST1, G->seeds[0]);
-    load_filter_result(configs[0]->getFilterResult(), c);
-    load_adapters(configs, sp->mOptions->thread);
-    if (sp->mDuplicate) {
-        sp->mDuplicate->mTotalReads += (unsigned long)c[G->lay.dup_total];
-        sp->mDuplicate->mDupReads += (unsigned long)c[G->lay.dup_count];
-    }
+    LAY = &G->lay;
+    load_block(sp, configs, c, G->B, false);
+    load_adapters(configs, G->hosts, sp->mOptions->thread);
     shutdown();
 }
 

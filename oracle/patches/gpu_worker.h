@@ -4,6 +4,8 @@
 // threads, Stats / FilterResult objects and JSON / HTML reporters around the engine).
 //
 // oracle/patches/apply_gpu_worker.py inserts one-line calls into copies of the reference's sources:
+//   src/peprocessor.cpp  top of PairEndProcessor::readerTask       -> fastp_gpu_stream_reader_pe   (stream mode)
+//   src/seprocessor.cpp  top of SingleEndProcessor::readerTask     -> fastp_gpu_stream_reader_se
 //   src/peprocessor.cpp  top of PairEndProcessor::processPairEnd   -> fastp_gpu_worker_pe
 //   src/seprocessor.cpp  top of SingleEndProcessor::processSingleEnd -> fastp_gpu_worker_se
 //   both                 end of ::processorTask (before setConsumerFinished) -> fastp_gpu_worker_drain_pe / _se
@@ -22,7 +24,15 @@ class SingleEndProcessor;
 class ThreadConfig;
 struct ReadPack;
 
-// 1 = the pack was taken by the engine (packed into the current window of packs; its outputs reach the writers when the
+// STREAM MODE - the hook at the top of readerTask (src/peprocessor.cpp:725, src/seprocessor.cpp:327): with FASTP_GPU=1 and
+// plain FASTQ files the read-1 reader thread runs include/fastp_gpu_stream.h's loop over both files (raw chunks -> device
+// parser -> worker loop -> device formatter -> the WriterThreads' files) and closes the input lists when it is done; the
+// worker threads stay idle.  1 = the run was taken, -1 = the reference's reader runs and the worker hooks below see packs.
+int fastp_gpu_stream_reader_pe(PairEndProcessor* p, bool isLeft);
+int fastp_gpu_stream_reader_se(SingleEndProcessor* p);
+
+// PACK MODE (FASTP_GPU_STREAM=0, or an option set the stream loop does not take: --overlapped_out, phred64, interleaved /
+// piped / gz input).  1 = the pack was taken by the engine (packed into the current window of packs; its outputs reach the writers when the
 // window's records arrive - gpu_worker.cpp); -1 = engine disabled: run the reference's own loop body on this pack.
 // A read the packer refuses (letters outside ACGTN, quality characters outside '!'..'~', longer than the evaluated
 // read length) stops the run with a message.

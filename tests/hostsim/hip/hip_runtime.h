@@ -136,6 +136,7 @@ template <class T, class V> static inline T __hip_atomic_fetch_add(T* p, V v, in
 template <class T, class V> static inline T __hip_atomic_fetch_or(T* p, V v, int, int) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <class T, class V> static inline T __hip_atomic_exchange(T* p, V v, int, int) { T o = *p; *p = (T)v; return o; }
 template <class T, class V> static inline T __hip_atomic_fetch_min(T* p, V v, int, int) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class V> static inline T __hip_atomic_fetch_max(T* p, V v, int, int) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
 template <class T> static inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, int, int, int) {
     if (*p == *expected) { *p = desired; return true; }
     *expected = *p;

@@ -65,13 +65,14 @@ def _ensure_built():
     return os.path.exists(REF)
 
 
-def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1):
+def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1, gz=False, in1=None):
     out = os.path.join(tmp, tag)
     os.makedirs(out, exist_ok=True)
-    cmd = [binary, "-i", os.path.join(tmp, "in1.fq"), "-o", os.path.join(out, "o1.fq"), "-j", os.path.join(out, "r.json"),
-           "-h", os.path.join(out, "r.html"), "-w", str(threads), "--failed_out", os.path.join(out, "failed.fq")]
+    ext = ".fq.gz" if gz else ".fq"
+    cmd = [binary, "-i", in1 or os.path.join(tmp, "in1.fq"), "-o", os.path.join(out, "o1" + ext), "-j", os.path.join(out, "r.json"),
+           "-h", os.path.join(out, "r.html"), "-w", str(threads), "--failed_out", os.path.join(out, "failed" + ext)]
     if paired:
-        cmd += ["-I", os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2.fq")]
+        cmd += ["-I", os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2" + ext)]
     cmd += [x.replace("@TMP@", out) for x in flags]
     env = dict(os.environ)
     env.pop("FASTP_GPU", None)
@@ -79,6 +80,10 @@ def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1):
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1200)
     assert p.returncode == 0, f"{os.path.basename(binary)} failed: {p.stderr.decode()[-1500:]}"
     files = {fn: open(os.path.join(out, fn), "rb").read() for fn in sorted(os.listdir(out)) if fn.endswith(".fq")}
+    for fn in sorted(os.listdir(out)):   # ".gz" outputs: concatenated gzip members, compared by what they inflate to
+        if fn.endswith(".fq.gz"):
+            import gzip
+            files[fn] = gzip.decompress(open(os.path.join(out, fn), "rb").read())
     rep = json.load(open(os.path.join(out, "r.json")))
     rep.pop("command", None)
     rep["__stderr__"] = p.stderr.decode(errors="replace")
@@ -102,11 +107,20 @@ def _diff(x, y, path, out):
         out.append(f"{path}: reference {x!r} binding {y!r}")
 
 
-def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n", trailing=True):
+# the emulator runs a launch per kernel lane by lane: small chunks keep its parser launches short AND make every run
+# take several trips (carried partial records, the mates' different record sizes)
+SIM_ENV = {"FASTP_GPU_STREAM_CHUNK_BYTES": "70000"}
+PACK_MODE = {"FASTP_GPU_STREAM": "0"}   # the reference's own reader threads + the worker-loop hooks
+
+
+def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n", trailing=True, gz=False, more_flags=(),
+           mode="stream", mutate=None, expect_units=None):
     paired, flags, pf, skw = cases.CASES[name]
-    flags = list(flags) + BINDING_CASES[name]
+    flags = list(flags) + BINDING_CASES[name] + list(more_flags)
     tmp = str(tmp_path)
     d = synth.synth_pairs(n, L=150, seed=seed, paired=paired, **skw)
+    if mutate:
+        mutate(d)
 
     def text(seq, qual, lens, mate):   # line ends as the caller wants them (FastqReader::getLine takes \n, \r\n and \r)
         t = synth.to_fastq(seq, qual, lens, mate).replace(b"\n", eol)
@@ -121,11 +135,19 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
             os.makedirs(os.path.join(tmp, tag), exist_ok=True)
             with open(os.path.join(tmp, tag, fn), "wb") as f:
                 f.write(content)
-    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {})
-    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, dict({"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}, **(extra_env or {})),
-                              threads=threads)
+    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {}, gz=gz)
+    env = {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}
+    if binary == REF_SIM:
+        env.update(SIM_ENV)
+    if mode == "pack":
+        env.update(PACK_MODE)
+    env.update(extra_env or {})
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, env, threads=threads, gz=gz)
     err = got_rep.pop("__stderr__")
     want_rep.pop("__stderr__")
+    # which binding ran: the stream loop says so; --overlapped_out is pack mode's
+    streamed = "fastp_gpu: stream mode:" in err
+    assert streamed == (mode == "stream" and "overlapped_out" not in name), err[-800:]
     if "overrep" in name:   # -p: the Evaluator's substring census ran on the device too (fastp_gpu_eval_overrep)
         assert err.count("computeOverRepSeq on the device") == (2 if paired else 1), err[-800:]
         if n >= 10000:   # (600 reads do not reach the count thresholds: both sides then agree on "none")
@@ -136,7 +158,8 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     problems = []
     _diff(want_rep, got_rep, "", problems)
     assert not problems, f"{name}: fastp's own JSON report differs:\n" + "\n".join(problems[:25])
-    assert want_rep["summary"]["before_filtering"]["total_reads"] == (2 if paired else 1) * n
+    assert want_rep["summary"]["before_filtering"]["total_reads"] == (2 if paired else 1) * (n if expect_units is None else expect_units)
+    return err
 
 
 # on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
@@ -149,9 +172,87 @@ assert all(n in BINDING_CASES for n in EMULATOR_CASES)
 
 @pytest.mark.parametrize("name", EMULATOR_CASES)
 def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
+    """stream mode (the default): raw chunks -> device parser -> worker loop -> device formatter -> the writers' files"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    _check(name, REF_SIM, 600, tmp_path, seed=41)
+    err = _check(name, REF_SIM, 600, tmp_path, seed=41)
+    if "overlapped_out" not in name:
+        import re
+        m = re.search(r"stream mode: 600 units in (\d+) chunks", err)
+        assert m and int(m.group(1)) >= 2, err[-600:]    # several trips, so partial records were carried
+
+
+@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "pe_adapter_fasta", "pe_merge", "se_adapter_cut", "se_umi_read1"])
+def test_patched_reference_pack_mode_on_emulator(name, tmp_path):
+    """pack mode: the reference's own reader threads, the hook at the top of the worker-loop body"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 600, tmp_path, seed=41, mode="pack")
+
+
+@pytest.mark.parametrize("name,threads,writer", [("pe_default", 3, "input"), ("pe_filters", 2, "input"), ("se_adapter_cut", 4, "input"),
+                                                 ("pe_merge_unmerged", 5, None)])
+def test_patched_reference_stream_threads_and_writer_handoff(name, threads, writer, tmp_path):
+    """the stream's result does not depend on -w; FASTP_GPU_WRITER=input hands the text to WriterThread::input (one string
+    per chunk, the threads' lists in turn) instead of writing into the writers' file descriptors"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 900, tmp_path, seed=52, threads=threads, extra_env={"FASTP_GPU_WRITER": writer} if writer else None)
+
+
+@pytest.mark.parametrize("name,threads,writer", [("pe_default", 1, None), ("pe_default", 3, None), ("se_adapter_cut", 2, None),
+                                                 ("pe_filters", 3, "input")])
+def test_patched_reference_stream_gz_outputs(name, threads, writer, tmp_path):
+    """".gz" outputs: gzip members made on the device (fastp_gpu_deflate_bgzf) written into the WriterThread's file - its
+    pwrite mode with several threads, its Writer with one - and bgzip's end-of-file member; or (writer = input) text
+    compressed by the reference itself.  Compared by content."""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 700, tmp_path, seed=53, threads=threads, gz=True, extra_env={"FASTP_GPU_WRITER": writer} if writer else None)
+
+
+@pytest.mark.parametrize("mode", ["stream", "pack"])
+@pytest.mark.parametrize("name,n,limit,threads", [("pe_default", 3000, 1500, 2), ("pe_default", 3000, 1000, 2), ("se_adapter_cut", 2500, 2000, 4),
+                                                  ("pe_cut_right", 2200, 700, 3)])
+def test_patched_reference_reads_to_process(name, n, limit, threads, mode, tmp_path):
+    """--reads_to_process: the reader stops after N reads (a short pack followed by an empty one in pack mode,
+    a record cap on the trips in stream mode)"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, n, tmp_path, seed=54, threads=threads, more_flags=["--reads_to_process", str(limit)], mode=mode, expect_units=limit)
+
+
+@pytest.mark.parametrize("mode", ["stream", "pack"])
+@pytest.mark.parametrize("name,n,threads", [("pe_default", 3000, 4), ("se_default_noadapter", 3000, 4), ("pe_default", 2000, 3)])
+def test_patched_reference_read_count_multiple_of_pack_size(name, n, threads, mode, tmp_path):
+    """reads % 1000 == 0: the reader ends the stream with an EMPTY pack, which can be a worker's first pack"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, n, tmp_path, seed=55, threads=threads, mode=mode)
+
+
+def _lengthen_late_reads(d):
+    """reads longer than anything among the first 1000 (what Evaluator::computeSeqLen looks at)"""
+    import numpy as np
+    for m in ("1", "2"):
+        if "seq" + m not in d or d["seq" + m] is None:
+            continue
+        seq, qual, lens = d["seq" + m], d["qual" + m], d["len" + m]
+        lens[:1200] = np.minimum(lens[:1200], 100)
+        assert lens[1200:].max() > 100
+
+
+@pytest.mark.parametrize("name", ["pe_default", "se_adapter_cut", "pe_noadapter_dedup", "pe_overrep"])
+def test_patched_reference_stream_replans_for_longer_reads(name, tmp_path):
+    """the first 1000 reads are at most 100 bases, later ones 150: the reference sizes its buffers from the first 1000 and
+    grows them (Stats::extendBuffer); the stream re-plans - counters, Duplicate's bitmaps and the sampling positions of
+    the overrepresentation analysis carried into a context with a larger max_len - and the report is the same"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    err = _check(name, REF_SIM, 2600 if "overrep" not in name else 11000, tmp_path, seed=56, mutate=_lengthen_late_reads)
+    import re
+    m = re.search(r"max_len (\d+), (\d+) re-plan", err)
+    assert m and int(m.group(2)) >= 1 and int(m.group(1)) >= 150, err[-600:]
 
 
 def _auto_adapter_check(binary, n, tmp_path):
@@ -206,23 +307,24 @@ def test_patched_reference_pipelines_windows_of_packs(name, threads, packs, tmp_
     whatever the thread count (duplicates and insert sizes included)"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    _check(name, REF_SIM, 9300, tmp_path, seed=43, threads=threads, extra_env={"FASTP_GPU_PACKS": str(packs)})
+    _check(name, REF_SIM, 9300, tmp_path, seed=43, threads=threads, extra_env={"FASTP_GPU_PACKS": str(packs)}, mode="pack")
 
 
+@pytest.mark.parametrize("mode", ["stream", "pack"])
 @pytest.mark.parametrize("eol,trailing", [(b"\r\n", True), (b"\r", True), (b"\n", False), (b"\r\n", False)])
-def test_patched_reference_reader_hook_line_ends(eol, trailing, tmp_path):
+def test_patched_reference_reader_hook_line_ends(eol, trailing, mode, tmp_path):
     """the memchr hook in front of FastqReader::getLine's scan (fastp_gpu_reader_scan_eol): the same records from \\r\\n, \\r
     and unterminated last lines as the reference's own character-by-character scan (whose binary runs without the hook)"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    _check("pe_cut_right", REF_SIM, 2300, tmp_path, seed=47, threads=2, eol=eol, trailing=trailing)
+    _check("pe_cut_right", REF_SIM, 2300, tmp_path, seed=47, threads=2, eol=eol, trailing=trailing, mode=mode)
 
 
 def test_patched_reference_reader_hook_across_buffer_refills(tmp_path):
     """input files larger than FastqReader's 8 MiB buffer: lines that straddle a refill take getLine's second scan"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    _check("se_default_noadapter", REF_SIM, 52000, tmp_path, seed=48, threads=2, eol=b"\r\n")
+    _check("se_default_noadapter", REF_SIM, 52000, tmp_path, seed=48, threads=2, eol=b"\r\n", mode="pack")
 
 
 @pytest.mark.gpu
@@ -232,3 +334,34 @@ def test_gpu_patched_reference_equals_reference(name, tmp_path):
     if not (os.path.exists(REF) and os.path.exists(REF_GPU)):
         pytest.skip("oracle/_ref binaries did not travel to this box")
     _check(name, REF_GPU, 30000, tmp_path, seed=43)
+
+
+def test_patched_reference_pack_mode_with_a_lagging_read1_reader(tmp_path):
+    """read 1's reader thread is slowed down (an LD_PRELOAD shim delays every fread on in1.fq, tests/slowread): a worker's
+    loop then ends on its exhausted read-2 list while the read-1 reader is still producing packs for other workers
+    (processorTask's second exit).  The stream's length must not be published from the read-1 counter at that moment
+    (the last window was submitted short and its owners waited forever)."""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    tmp = str(tmp_path)
+    shim = os.path.join(tmp, "slowread.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tests", "slowread", "slowread.c"), "-ldl", "-o", shim])
+    n = 9300     # 10 packs per file; FastqReader fills 8 MiB at a time, so the file is a handful of freads
+    d = synth.synth_pairs(n, L=150, seed=61, paired=True)
+    with open(os.path.join(tmp, "in1.fq"), "wb") as f:
+        f.write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1))
+    with open(os.path.join(tmp, "in2.fq"), "wb") as f:
+        f.write(synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2))
+    want_files, want_rep = _run(REF, tmp, "ref", [], True, {})
+    env = {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1", "FASTP_GPU_PACKS": "2", "LD_PRELOAD": shim,
+           "SLOWREAD_PATH": os.path.realpath(os.path.join(tmp, "in1.fq")), "SLOWREAD_US": "1500000"}
+    env.update(PACK_MODE)
+    got_files, got_rep = _run(REF_SIM, tmp, "gpu", [], True, env, threads=4)
+    err = got_rep.pop("__stderr__")
+    want_rep.pop("__stderr__")
+    assert "stream mode" not in err
+    for fn in want_files:
+        assert want_files[fn] == got_files[fn], f"{fn} differs"
+    problems = []
+    _diff(want_rep, got_rep, "", problems)
+    assert not problems, "\n".join(problems[:25])
