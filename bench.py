@@ -361,7 +361,7 @@ def main():
             m = min(NB, k - done)
             if protocol:
                 multigpu.run_shard(eng, dist, rank, world, [rb.batch for rb in resident[:m]], [res] * m, dev, force=True,
-                                   scans=scan_bufs[:m])
+                                   scans=scan_bufs[:m], exchange=exchange["how"], timings=timings)
             else:
                 for rb in resident[:m]:
                     eng.submit_device(rb.batch, res)
@@ -377,36 +377,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(int(t.item()))
 
-    err = None
-    try:
-        run_steps(args.warmup)
-    except Exception as e:   # e.g. a collective the installed RCCL build refuses: keep measuring, say so in the JSON line
-        if not protocol:
-            raise
-        err = e
-    if protocol and agree(err is not None):
-        print(f"[bench] exact sharded protocol failed on rank {rank} ({err!r}); falling back to per-shard submit", file=sys.stderr, flush=True)
-        protocol = False
-        shard_mode = "plain (exact protocol failed: %s)" % (type(err).__name__ if err else "on another rank")
-        eng.reset()
-        run_steps(args.warmup)
-
-    # Stats::merge / FilterResult::merge across the GPUs: one all-reduce of the counter block (RCCL either way)
-    merge_how = "n/a"
+    # The collectives of an N > 1 run - the bitmap prefix exchange between the two passes and the counter all-reduce at the
+    # end (Stats::merge / FilterResult::merge) - are the C ABI's own by default (fastp_gpu_comm_init + fastp_gpu_exchange_dup_prefix
+    # + fastp_gpu_allreduce: RCCL behind the drop-in boundary, what a patched fastp would call).  They are set up and rehearsed
+    # OUTSIDE the timed region under a watchdog: a native collective that hangs cannot be interrupted, so the rehearsal runs on
+    # a helper thread and every rank votes; any failure or timeout on any rank -> all ranks use torch.distributed's
+    # collectives (RCCL as well) instead.  BENCH_ALLREDUCE=torch / BENCH_EXCHANGE=torch skip the attempt.
+    merge_how, exchange_how = "n/a", "n/a"
+    use_cabi = False
+    cerr = None
     if dist is not None:
-        # default: the C ABI's own collective (fastp_gpu_comm_init + fastp_gpu_allreduce: RCCL behind the drop-in boundary,
-        # what a patched fastp would call), set up and rehearsed OUTSIDE the timed region under a watchdog - a native
-        # collective that hangs cannot be interrupted, so the rehearsal runs on a helper thread and every rank votes;
-        # any failure or timeout on any rank -> all ranks use torch.distributed's all_reduce (RCCL as well) instead.
-        # BENCH_ALLREDUCE=torch skips the attempt.
         use_cabi = backend == "nccl" and os.environ.get("BENCH_ALLREDUCE", "cabi") == "cabi"
-        cerr = None
         if use_cabi:
             import threading
             box = {}
 
             def rehearse():
                 try:
+                    torch.cuda.set_device(dev)   # the current device is per thread
                     ids = [eng.comm_id() if rank == 0 else None]
                     dist.broadcast_object_list(ids, src=0)
                     eng.comm_init(ids[0], world, rank)
@@ -424,10 +412,51 @@ def main():
             if agree(cerr is not None):
                 print(f"[bench] fastp_gpu_allreduce unavailable on rank {rank} ({cerr!r}); using torch.distributed", file=sys.stderr, flush=True)
                 use_cabi = False
-        if not use_cabi:
-            multigpu.allreduce_counters_device(eng, dist, dev)
         merge_how = "fastp_gpu_allreduce (RCCL, C ABI)" if use_cabi else \
                     f"torch.distributed all_reduce ({backend})" + (f"; C ABI attempt failed: {type(cerr).__name__}" if cerr else "")
+    exchange = {"how": "cabi" if (use_cabi and os.environ.get("BENCH_EXCHANGE", "cabi") == "cabi") else "torch"}
+    timings = {}
+
+    err = None
+    try:
+        if protocol and exchange["how"] == "cabi":   # the first exchange under the watchdog too
+            import threading
+            box = {}
+
+            def first():
+                try:
+                    torch.cuda.set_device(dev)
+                    run_steps(args.warmup)
+                    box["ok"] = True
+                except Exception as e:   # noqa: BLE001
+                    box["err"] = e
+            th = threading.Thread(target=first, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("BENCH_CABI_TIMEOUT", "90")) + 60.0)
+            xerr = TimeoutError("fastp_gpu_exchange_dup_prefix did not return") if th.is_alive() else box.get("err")
+            if agree(xerr is not None):
+                print(f"[bench] fastp_gpu_exchange_dup_prefix unavailable on rank {rank} ({xerr!r}); exchange through torch.distributed", file=sys.stderr, flush=True)
+                if th.is_alive():
+                    raise SystemExit("bench.py: a native collective hangs; rerun with BENCH_EXCHANGE=torch")
+                exchange["how"] = "torch"
+                eng.reset()
+                run_steps(args.warmup)
+        else:
+            run_steps(args.warmup)
+    except Exception as e:   # e.g. a collective the installed RCCL build refuses: keep measuring, say so in the JSON line
+        if not protocol:
+            raise
+        err = e
+    if protocol and agree(err is not None):
+        print(f"[bench] exact sharded protocol failed on rank {rank} ({err!r}); falling back to per-shard submit", file=sys.stderr, flush=True)
+        protocol = False
+        shard_mode = "plain (exact protocol failed: %s)" % (type(err).__name__ if err else "on another rank")
+        eng.reset()
+        run_steps(args.warmup)
+    if dist is not None and protocol:
+        exchange_how = "fastp_gpu_exchange_dup_prefix (RCCL, C ABI)" if exchange["how"] == "cabi" else f"torch.distributed all_to_all_single ({backend})"
+    if dist is not None and not use_cabi:
+        multigpu.allreduce_counters_device(eng, dist, dev)
 
     def merge_counters():
         if dist is None:
@@ -440,14 +469,18 @@ def main():
     eng.synchronize()
     eng.reset()
     eng.kernel_time()  # reset the event accumulator
+    timings.clear()
 
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     run_steps(args.steps)
+    eng.synchronize()
+    t_merge = time.perf_counter()
     merge_counters()                                      # Stats::merge / FilterResult::merge
     eng.synchronize()
+    timings["merge_s"] = time.perf_counter() - t_merge
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -467,27 +500,30 @@ def main():
         avg_ms = kms / max(1, klaunches)
         bpp = algorithmic_bytes_per_pair(L)
         achieved = per_launch_pairs * bpp / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM-side bytes and VALU instructions come from the committed rocprofv3 --pmc passes (profiles/traffic.json,
+        # profiles/valu.json: figures PER PAIR of the same kernels, so they apply at any batch size), durations are live
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")   # written from the rocprofv3 --pmc passes
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("pairs_per_launch") in (None, int(per_launch_pairs)):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if "hbm_bytes_per_pair" in tj:
+                    traffic = round(tj["hbm_bytes_per_pair"] * per_launch_pairs)
+                elif tj.get("pairs_per_launch"):
+                    traffic = round(tj["hbm_bytes_per_launch"] / tj["pairs_per_launch"] * per_launch_pairs)
             except Exception:
                 traffic = None
-        # what actually bounds the kernel: integer VALU issue.  Instruction count from the
-        # committed PMC pass, duration live; reported next to the HBM roofline BASELINE.json asks for.
+        # what actually bounds the kernels: integer VALU issue, reported next to the HBM roofline BASELINE.json asks for
         compute = None
         vf = os.path.join(ROOT, "profiles", "valu.json")
         if os.path.exists(vf) and avg_ms > 0:
             try:
                 vj = json.load(open(vf))
-                if vj.get("pairs_per_launch") == int(per_launch_pairs):
-                    ach = vj["insts_valu_per_launch"] * 64 / (avg_ms * 1e-3) / 1e12
-                    compute = {"bound": "valu_int", "achieved": round(ach, 2), "peak": vj["peak_T_lane_ops_per_s"],
-                               "unit": "T lane-ops/s", "frac": round(ach / vj["peak_T_lane_ops_per_s"], 4),
-                               "insts_valu_per_pair": round(vj["insts_valu_per_launch"] / per_launch_pairs, 1)}
+                ipp = vj.get("insts_valu_per_pair") or vj["insts_valu_per_launch"] / vj["pairs_per_launch"]
+                ach = ipp * per_launch_pairs * 64 / (avg_ms * 1e-3) / 1e12
+                compute = {"bound": "valu_int", "achieved": round(ach, 2), "peak": vj["peak_T_lane_ops_per_s"],
+                           "unit": "T lane-ops/s", "frac": round(ach / vj["peak_T_lane_ops_per_s"], 4),
+                           "insts_valu_per_pair": round(ipp, 1), "profile": vj.get("tag")}
             except Exception:
                 compute = None
         runs = args.steps / NB
@@ -502,6 +538,11 @@ def main():
                                    f"counters per run)",
                        "pairs_per_run_per_gpu": NB * B, "pairs_per_step_per_gpu": B, "timed_pairs_total": total_pairs,
                        "read_len": L, "parallelism": f"shard x{world}", "counter_merge": merge_how,
+                       # per-run constants of an N > 1 run, inside the timed region but reported apart so that a 1 -> N curve
+                       # can be read: the bitmap prefix exchange (once per run of NB steps) and the counter all-reduce (once)
+                       "bitmap_exchange": exchange_how,
+                       "exchange_ms_per_run": round(timings.get("exchange_s", 0.0) / max(1.0, -(-args.steps // NB)) * 1e3, 3) if protocol else None,
+                       "merge_ms": round(timings.get("merge_s", 0.0) * 1e3, 3) if dist is not None else None,
                        "cross_shard_duplicates": "exact (scan pass + bitmap prefix exchange + decision pass)" if protocol else
                                                  ("n/a" if world == 1 else "per shard: " + shard_mode)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

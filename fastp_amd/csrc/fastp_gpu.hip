@@ -492,6 +492,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             l.stage = o;
             l.stage_dwords = (64 * std::max(ctx->dp.qw_g, ctx->dp.sw_g) + 4 * ctx->ln_swm + 3) & ~3;   // + the over-read of the last row
             o += 4 * l.stage_dwords;   // 256-lane workgroups: four wavefronts
+            l.part = o;
+            l.part_dwords = ctx->ln_swm * 64;   // [2 mates][ln_swm / 2 words][64 lanes]
+            o += 4 * l.part_dwords;
             l.total = o;
             int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);
 #ifndef FQ_HOSTSIM

@@ -42,6 +42,8 @@ struct LaneLds {
     int n_planes;
     int stage;      // per wavefront: 64 rows of one mate's quality (then base) rows, copied from HBM with coalesced 16-byte
     int stage_dwords;   // loads and read back one row per lane (16-byte aligned, 64 * qw_g dwords each)
+    int part;       // per wavefront: countQualityMetrics' per-32-base partial sums [mate][word][lane] (lane-contiguous: conflict-free;
+    int part_dwords;    // registers would not hold them - ten more live VGPRs spill 270 dwords at the cap of 168)
     int total;
 };
 
@@ -170,6 +172,8 @@ FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, co
     int rem = r.rl0;
 #pragma unroll 1
     for (int grp = 0; grp < SWM / 2; grp++) {
+        // a group every lane's read covers whole (four of five for 150-base reads) needs no mask by the read's length
+        const bool cut = ballot(rem < 32) != 0ull;   // wave-uniform
 #pragma unroll
         for (int d = 0; d < 8; d++) {
             const u32 byte = (sw[d >> 2] >> (8 * (d & 3))) & 0xFFu;
@@ -179,8 +183,10 @@ FQ_DEV void lane_hash(const KernelArgs& a, const u32* lds, const LaneLds& ll, co
                 const u32 mN = ((nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21)) * 0xFFu;
                 vals = (vals & ~mN) | (0x0D0D0D0Du & mN);
             }
-            const int left = rem - 4 * d;
-            vals = left >= 4 ? vals : (left <= 0 ? 0u : (vals & lowmask32(8 * left)));   // bases past the read's end add nothing
+            if (cut) {
+                const int left = rem - 4 * d;
+                vals = left >= 4 ? vals : (left <= 0 ? 0u : (vals & lowmask32(8 * left)));   // bases past the read's end add nothing
+            }
 #pragma unroll
             for (int k = 0; k < B * NPL; k++) acc[k] = dot4_u8(vals, tb[d * (B * NPL) + k], acc[k]);
         }
@@ -269,8 +275,8 @@ FQ_DEV u32 lane_window_word(const u32 (&q)[10], u32 keep_lo, u32 keep_hi, u32 nt
 // cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.  `stage` = this
 // wavefront's LDS buffer, chunk0 = first unit of its chunk, rows = units the chunk has.
 template <int SWM>
-FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, const u32* qual, const u16* lenp, int chunk0, int rows, int lane,
-                           bool valid, int win, int thr, LaneRead<SWM>& r) {
+FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32* seq, const u32* qual, const u16* lenp, int chunk0, int rows, int lane,
+                           bool valid, int win, int thr, u32 thr4, LaneRead<SWM>& r) {
     const DevParams& p = a.p;
     const int swg = p.sw_g, qwg = p.qw_g;
     const int g = chunk0 + lane;
@@ -313,13 +319,18 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, const u32* seq, cons
         nx1 = q[1];
         // ---- N mask of the word's 32 bases (bit 7 of the quality bytes), branch-free ----
         u32 nw = 0;
+        // ... and countQualityMetrics' sums over the word's 32 bases (bytes behind the read are zeros: they add nothing)
+        u32 ts = 0, gs = 0;
 #pragma unroll
         for (int d = 7; d >= 0; d--) {
             const u32 b1 = (q[d] >> 7) & 0x01010101u;   // bits 0, 8, 16, 24
             nw = dot4_u8(b1, 0x08040201u, nw << 4);     // the four flags as a nibble behind the ones gathered so far
+            ts = sum_bytes(q[d] & 0x7F7F7F7Fu, ts);
+            gs += (u32)popc32(((q[d] | 0x80808080u) - thr4) & 0x80808080u);
         }
         r.n[W] = nw;
         anyn |= nw;
+        part[W * 64 + lane] = ts | (gs << 16);   // sum of the quality characters | bases at or above the qualified quality << 16
         // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
         u32 m = 0;
         if (win == 4) m = lane_window_word4(q, nthr4);                             // uniform
@@ -509,36 +520,52 @@ FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM / 2], const u32 
 
 // ---------------------------------------------------------------------------
 // fastp_simd::countQualityMetrics (simd.cpp:54-119) of [0, len): total (qual - 33), bases below the qualified quality, N.
-// The mate's quality rows are staged once more (the final window is only known now; the copy is coalesced and the
-// rows come from L2) and each lane sums its own row under the window's mask.
+// The 32-base words the final window covers whole come from the partial sums the load sweep left in registers; only the
+// ONE word the window's end cuts is looked at again - its 32 quality bytes straight from the lane's row (an L2 hit: the
+// row was staged moments ago), both mates' loads in flight together.  (Round 3 staged every quality row a second time
+// through LDS and masked all 38 dwords by the window: two more round trips per chunk and 32 instructions per dword.)
+// The N count comes from the N mask in registers.
 // ---------------------------------------------------------------------------
-template <int SWM>
-FQ_DEV void lane_metrics(const KernelArgs& a, u32* stage, const u32* qual, int chunk0, int rows, int lane, bool valid, int len, int& tot,
-                         int& low, int& nb) {
+struct LaneCutWord {
+    u64 v[4];   // the 32 quality bytes of the word the window's end cuts
+};
+FQ_DEV void lane_cut_fetch(const KernelArgs& a, const u32* qual, int g, bool valid, int len, LaneCutWord& cw) {
     const int qwg = a.p.qw_g;
-    lane_stage_rows<FQ_LANE_STAGE_BATCH>(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
-    const u64* qrow = (const u64*)(stage + lane * qwg);
+    const u64* row = (const u64*)(qual + (size_t)g * qwg);
+    const int w8 = 4 * (len >> 5);   // first u64 of the cut word
+#pragma unroll
+    for (int k = 0; k < 4; k++) cw.v[k] = valid ? row[imin(w8 + k, (qwg >> 1) - 1)] : 0ull;   // (a u64 behind the row is never inside the window)
+}
+template <int SWM>
+FQ_DEV void lane_metrics(const KernelArgs& a, const LaneRead<SWM>& r, const u32* part, int lane, const LaneCutWord& cw, int len, int& tot, int& low,
+                         int& nb) {
     const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
-    u32 t = 0, lo = 0, n = 0;
+    const int wfull = len >> 5, rem = len & 31;
+    u32 acc = 0;   // sum | count << 16, as the partial sums
 #pragma unroll
-    for (int c = 0; c < 4 * SWM; c += 2) {
-        {
-            const u64 v = qrow[c >> 1];   // dwords past the window (or the row) count nothing: M below
-#pragma unroll
-            for (int hlf = 0; hlf < 2; hlf++) {
-                const u32 qd = hlf ? (u32)(v >> 32) : (u32)v;
-                const int rem = len - 4 * (c + hlf);
-                const u32 M = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : lowmask32(8 * rem));
-                const u32 q7 = qd & 0x7F7F7F7Fu & M;
-                const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;   // bit 7 of a byte: qual >= threshold
-                t = sum_bytes(q7, t);
-                lo += (u32)popc32(~ge & 0x80808080u & M);
-                n += (u32)popc32(qd & 0x80808080u & M);
-            }
-        }
+    for (int w = 0; w < SWM / 2; w++) {
+        const u32 pw = part[w * 64 + lane];
+        acc += w < wfull ? pw : 0u;
     }
-    tot = (int)t - 33 * len;
-    low = (int)lo;
+    const int fullb = rem >> 2, partb = rem & 3;
+    const u32 cutmask = lowmask32(8 * partb);   // 0 when the window ends on a dword boundary
+    u32 t = 0, ge = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const u32 qd = (d & 1) ? (u32)(cw.v[d >> 1] >> 32) : (u32)cw.v[d >> 1];
+        const u32 M = d < fullb ? 0xFFFFFFFFu : (d == fullb ? cutmask : 0u);
+        const u32 q7 = qd & 0x7F7F7F7Fu & M;
+        t = sum_bytes(q7, t);
+        ge += (u32)popc32(((q7 | 0x80808080u) - thr4) & 0x80808080u & M);
+    }
+    u32 n = 0;
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) {
+        const int left = len - 32 * w;
+        n += (u32)popc32(left >= 32 ? r.n[w] : (left <= 0 ? 0u : (r.n[w] & lowmask32(left))));
+    }
+    tot = (int)((acc & 0xFFFFu) + t) - 33 * len;
+    low = len - (int)((acc >> 16) + ge);
     nb = (int)n;
 }
 
@@ -590,6 +617,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
+    const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
     const int chunks = (a.n + 63) >> 6;
     const int wpb = nt >> 6;
     const int nstatic = grid_blocks() * wpb;
@@ -601,14 +629,15 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         const bool valid = gp < a.n;
         const int rows = imin(64, a.n - chunk * 64);
         u32* stage = lds + ll.stage + (tid >> 6) * ll.stage_dwords;
+        u32* part = lds + ll.part + (tid >> 6) * ll.part_dwords;
         const int g = valid ? gp : 0;
         LaneRead<SWM> r1, r2;
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
-        lane_load_read<SWM>(a, stage, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, r1);
+        lane_load_read<SWM>(a, stage, part, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, thr4, r1);
         if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
         if (PAIRED) {
-            lane_load_read<SWM>(a, stage, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, r2);
+            lane_load_read<SWM>(a, stage, part + (SWM / 2) * 64, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, thr4, r2);
             if (valid && !lane_trim_and_cut<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
             sched_fence();
         }
@@ -742,8 +771,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         // ---- Filter::passFilter (filter.cpp:15-57), routing, records ----
         int tot1 = 0, low1 = 0, nb1 = 0, tot2 = 0, low2 = 0, nb2 = 0;
         if (!(skip & 8u)) {
-            lane_metrics<SWM>(a, stage, a.qual[0], chunk * 64, rows, lane, a1, r1.len, tot1, low1, nb1);
-            if (PAIRED) lane_metrics<SWM>(a, stage, a.qual[1], chunk * 64, rows, lane, a2, r2.len, tot2, low2, nb2);
+            LaneCutWord c1, c2;
+            lane_cut_fetch(a, a.qual[0], g, a1, r1.len, c1);
+            if (PAIRED) lane_cut_fetch(a, a.qual[1], g, a2, r2.len, c2);
+            lane_metrics<SWM>(a, r1, part, lane, c1, r1.len, tot1, low1, nb1);
+            if (PAIRED) lane_metrics<SWM>(a, r2, part + (SWM / 2) * 64, lane, c2, r2.len, tot2, low2, nb2);
         }
         if (valid) {
             int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, 0, (int)lut_lowq[r1.len], 0) : 16;

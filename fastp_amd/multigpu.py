@@ -67,13 +67,18 @@ def _device_sync(t):
         torch.cuda.current_stream(t.device).synchronize()
 
 
-def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False, scans=None):
+def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, exact=True, force=False, scans=None, exchange="torch",
+              timings=None):
     """Process this rank's shard (`batches[i]` -> `results[i]`, abi.Batch / abi.Results holding
     pointers valid on `device`: HBM for the real engine) so that results and counters equal those
     of one stream over all shards in rank order.  `dist` is torch.distributed (nccl = RCCL on the
     GPUs; gloo in the CPU tests) or None for a single shard.  The counter all-reduce is separate
     (allreduce_counters_*).  `scans`: optional preallocated uint8 tensors, one per batch, of at least
-    engine.dup_scan_bytes(batch.n) bytes each (otherwise allocated here).  Returns their total size in bytes."""
+    engine.dup_scan_bytes(batch.n) bytes each (otherwise allocated here).  Returns their total size in bytes.
+    `exchange`: "cabi" = the bitmap prefix exchange is the engine's own collective (fastp_gpu_exchange_dup_prefix: RCCL
+    send / recv groups behind the C ABI; the engine must have a communicator, GpuEngine.comm_init), "torch" = the same
+    sequence through torch.distributed (RCCL as well on the GPUs; the only choice for gloo).  `timings`: optional dict,
+    gets "exchange_s" added (wall time of the exchange step, synchronised) - a per-run constant, reported apart."""
     import torch
     from . import abi
     if not exact or ((world == 1 or dist is None) and not force):
@@ -97,7 +102,11 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
     engine.synchronize()
     # exchange: exclusive prefix-OR of the bitmaps in rank order
     nbytes = engine.dup_bitmap_bytes()
-    if nbytes and world > 1:
+    import time
+    t_x = time.perf_counter()
+    if nbytes and world > 1 and exchange == "cabi":
+        engine.exchange_dup_prefix()   # slices all-to-all, scan on the slice owner, all-to-all back, prefix set (fq_comm.cpp)
+    elif nbytes and world > 1:
         mine = torch.empty(nbytes, dtype=torch.uint8, device=device)
         engine.dup_bitmap_export(mine.data_ptr())
         staged = mine.is_cuda and dist.get_backend() != "nccl"   # gloo rehearsal on a GPU: through host memory
@@ -126,6 +135,9 @@ def run_shard(engine, dist, rank: int, world: int, batches, results, device, *, 
         del mine
     else:
         engine.dup_prefix_set(None, 0)
+    if timings is not None:
+        engine.synchronize()
+        timings["exchange_s"] = timings.get("exchange_s", 0.0) + time.perf_counter() - t_x
     # pass 2: the decision (and, with --dedup, the worker loop that depends on it)
     for b, r, t in zip(batches, results, scans):
         engine.submit_pass2_device(b, t.data_ptr(), r)

@@ -21,7 +21,8 @@ class HostOptions(C.Structure):
 
 
 EXPORTS = ["fastp_gpu_host_create", "fastp_gpu_host_destroy", "fastp_gpu_host_apply", "fastp_gpu_host_output",
-           "fastp_gpu_host_clear_outputs", "fastp_gpu_host_adapter_entries", "fastp_gpu_host_adapter_entry"]
+           "fastp_gpu_host_clear_outputs", "fastp_gpu_host_adapter_entries", "fastp_gpu_host_adapter_entry",
+           "fastp_gpu_host_add_adapter", "fastp_gpu_host_add_adapter_pair"]
 UMI_LOC = {"read1": 1, "read2": 2, "per_read": 3}
 
 

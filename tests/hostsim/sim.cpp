@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "hip/hip_runtime.h"
@@ -165,6 +166,10 @@ static void run_block(std::vector<ThreadState>& th) {
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    // one launch at a time: the emulator's state (coroutine pool, LDS, indices) is global, and host code may drive two
+    // contexts from two threads (the two ranks of tests/test_comm_stub.py, the stream loop's reader beside its caller)
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> launch_lock(launch_mu);
     if (shmem > sizeof(fq_lds)) die("dynamic LDS request exceeds 160 KiB");
     static std::vector<ThreadState> pool;
     const int T = (int)block.x;

@@ -5,10 +5,19 @@
 // between ncclGroupStart and ncclGroupEnd and carried out at the end of the group, matching the operations of
 // the communicators that share a unique id; outside a group an operation is carried out at once, which needs all
 // ranks of the communicator to be in the same call (how fq_comm.cpp uses n > 1: one group per exchange).
+// The ranks may also be THREADS of the process, one context each (how bench.py's ranks call the C ABI, one rank per
+// process there): a group that ends while ranks of its communicators are still missing waits for the other threads'
+// groups (FASTP_STUB_TIMEOUT_MS, default 3000 ms - a rank that never shows up is an error, as before).
 #include <stdint.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <chrono>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "../hostsim/rccl/rccl.h"
@@ -16,15 +25,41 @@
 namespace {
 struct Comm { int id, nranks, rank; };
 struct Op { int kind; const void* src; void* dst; size_t count; int dtype; int peer; Comm* c; };   // 0 allreduce, 1 send, 2 recv
-std::vector<Op> g_ops;
-int g_depth = 0, g_next_id = 1;
+std::vector<Op> g_ops;                  // the operations of every thread's finished (and not yet carried out) group
+thread_local std::vector<Op> t_ops;     // the calling thread's open group
+thread_local int g_depth = 0;
+int g_next_id = 1;
+std::mutex g_mu;
+std::condition_variable g_cv;
+unsigned long g_generation = 0;         // bumped whenever a flush has carried the pending operations out
+ncclResult_t g_last = ncclSuccess;
 size_t width(int dt) { return dt == ncclInt64 || dt == ncclUint64 ? 8 : (dt == ncclInt32 || dt == ncclUint32 ? 4 : 1); }
 
 ncclResult_t flush_ops();
+bool all_ranks_present() {   // every communicator that has an operation pending has one from each of its ranks
+    std::map<int, std::set<int>> seen;
+    std::map<int, int> want;
+    for (const Op& o : g_ops) { seen[o.c->id].insert(o.c->rank); want[o.c->id] = o.c->nranks; }
+    for (auto& kv : seen) if ((int)kv.second.size() != want[kv.first]) return false;
+    return true;
+}
 ncclResult_t flush() {   // a failed group leaves nothing queued behind
-    const ncclResult_t r = flush_ops();
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_ops.insert(g_ops.end(), t_ops.begin(), t_ops.end());
+    t_ops.clear();
+    if (!all_ranks_present()) {   // the other ranks are other threads: wait for their groups
+        const unsigned long gen = g_generation;
+        const char* v = getenv("FASTP_STUB_TIMEOUT_MS");
+        const auto limit = std::chrono::milliseconds(v ? atoi(v) : 3000);
+        if (g_cv.wait_for(lk, limit, [&] { return g_generation != gen; })) return g_last;
+        g_ops.clear();            // nobody came: the group fails
+        return ncclInvalidArgument;
+    }
+    g_last = flush_ops();
     g_ops.clear();
-    return r;
+    g_generation++;
+    g_cv.notify_all();
+    return g_last;
 }
 ncclResult_t flush_ops() {
     // all-reduce: group by communicator id
@@ -88,15 +123,15 @@ ncclResult_t ncclGroupStart() { g_depth++; return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { if (g_depth <= 0) return ncclInvalidArgument; return --g_depth == 0 ? flush() : ncclSuccess; }
 ncclResult_t ncclAllReduce(const void* s, void* d, size_t n, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c, void*) {
     if (op != ncclSum) return ncclInvalidArgument;
-    g_ops.push_back(Op{0, s, d, n, (int)dt, -1, (Comm*)c});
+    t_ops.push_back(Op{0, s, d, n, (int)dt, -1, (Comm*)c});
     return g_depth ? ncclSuccess : flush();
 }
 ncclResult_t ncclSend(const void* s, size_t n, ncclDataType_t dt, int peer, ncclComm_t c, void*) {
-    g_ops.push_back(Op{1, s, nullptr, n, (int)dt, peer, (Comm*)c});
+    t_ops.push_back(Op{1, s, nullptr, n, (int)dt, peer, (Comm*)c});
     return g_depth ? ncclSuccess : ncclInvalidArgument;
 }
 ncclResult_t ncclRecv(void* d, size_t n, ncclDataType_t dt, int peer, ncclComm_t c, void*) {
-    g_ops.push_back(Op{2, nullptr, d, n, (int)dt, peer, (Comm*)c});
+    t_ops.push_back(Op{2, nullptr, d, n, (int)dt, peer, (Comm*)c});
     return g_depth ? ncclSuccess : ncclInvalidArgument;
 }
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "success" : "stub: invalid argument / unmatched operation"; }

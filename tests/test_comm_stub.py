@@ -103,3 +103,49 @@ def test_cabi_collectives_error_paths():
     c = e.counters()
     assert c[0] == abi.ABI_VERSION if hasattr(abi, "ABI_VERSION") else c[0] > 0
     e.close()
+
+
+def test_run_shard_with_the_cabi_exchange_two_ranks_as_threads():
+    """multigpu.run_shard(exchange="cabi") - what bench.py --gpus N does by default: pass 1, fastp_gpu_exchange_dup_prefix,
+    pass 2 - with the two ranks as two threads of this process (one context each, the stand-in librccl makes them meet);
+    then fastp_gpu_allreduce.  Records and merged counters are the oracle's one stream."""
+    import threading
+    import torch
+    from fastp_amd import multigpu
+    n = 1300
+    params, d, paired = shard_util.case_input("pe_default", n)
+    e0, e1 = _pair_of_engines(params)
+    dev = torch.device("cpu")
+    keeps, errs, timings = [None, None], [], [{}, {}]
+
+    def rank_main(rank, eng):
+        try:
+            lo, hi = multigpu.shard_bounds(n, 2, rank)
+            batches, results, keep = shard_util.device_batches(eng, d, lo, hi, 2, dev)
+            keeps[rank] = (batches, results, keep)
+            multigpu.run_shard(eng, None, rank, 2, batches, results, dev, force=True, exchange="cabi", timings=timings[rank])
+            eng.allreduce()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=rank_main, args=(r, e)) for r, e in enumerate((e0, e1))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not errs, errs
+    assert all("exchange_s" in t for t in timings)
+    merged = [e.counters() for e in (e0, e1)]
+    o = oraclelib.Oracle(params)
+    whole = o.process(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    ctr = o.counters()
+    lay = o.layout
+    o.close()
+    assert ctr[lay.dup_count] > 0
+    assert np.array_equal(merged[0], merged[1])
+    bad = np.nonzero(merged[0] != ctr)[0]
+    assert len(bad) == 0, f"merged counters differ from one stream at {bad[:8]}"
+    recs = [shard_util.fetch_records(k[2], True) for k in keeps]
+    for k in range(3):
+        assert recs[0][k] + recs[1][k] == whole[k].tobytes(), f"records {k} differ"
+    e0.close()
+    e1.close()

@@ -11,6 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+PAIRS = int(sys.argv[2]) if len(sys.argv) > 2 else 4194304   # pairs per launch of the profiled runs (bench.py --batches 2: 4 Mi)
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -73,14 +74,39 @@ json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 main = [k for k in out["kernels"] if k == "fq_fused_kernel" or k.startswith("fq_scan") or "fq_lane_kernel" in k or k == "fq_stats_kernel"]
 main = [k for k in main if "hbm_bytes_per_launch" in out["kernels"][k]]
 if main:
-    ppl = None
-    try:
-        ppl = json.loads(out.get("bench.log", "{}"))["roofline"]["pairs_per_launch"]
-    except Exception:
-        pass
     tot = {f: sum(out["kernels"][k][f] for k in main) for f in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch")}
-    json.dump({"tag": tag, "kernel": " + ".join(main), "pairs_per_launch": ppl, **tot,
-               "per_kernel": {k: {f: out["kernels"][k][f] for f in tot} for k in main},
+    # per PAIR, so that bench.py can attach the figure at whatever batch size it runs (the driver's --steps 20 picks 5.03 M pairs)
+    json.dump({"tag": tag, "kernel": " + ".join(main), "pairs_per_launch": PAIRS, **tot,
+               "hbm_bytes_per_pair": tot["hbm_bytes_per_launch"] / PAIRS,
+               "hbm_read_bytes_per_pair": tot["hbm_read_bytes_per_launch"] / PAIRS,
+               "hbm_write_bytes_per_pair": tot["hbm_write_bytes_per_launch"] / PAIRS,
+               "per_kernel": {k: dict({f: out["kernels"][k][f] for f in tot}, hbm_bytes_per_pair=out["kernels"][k]["hbm_bytes_per_launch"] / PAIRS) for k in main},
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB -> bytes; FETCH_SIZE x2 (gfx950 halves wide reads)"},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+# VALU / LDS wave-instructions per pair of the same kernels from the SQ passes (gpurun_out/prof/<tag>_sq*)
+import glob
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(glob.glob(os.path.join(src, tag + "_sq*"))):
+    for fcsv in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fcsv)):
+            kn = r["Kernel_Name"]
+            if "fq_lane_kernel" in kn or kn in ("fq_stats_kernel", "fq_fused_kernel", "fq_scan_kernel"):
+                sq["fq_lane_kernel" if "fq_lane_kernel" in kn else kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if sq:
+    per = {}
+    for kn, ctrs in sq.items():
+        per[kn] = {c: sum(v) / len(v) for c, v in ctrs.items()}
+    valu = sum(p.get("SQ_INSTS_VALU", 0.0) for p in per.values())
+    lds = sum(p.get("SQ_INSTS_LDS", 0.0) for p in per.values())
+    json.dump({"tag": tag, "kernel": " + ".join(sorted(per)), "pairs_per_launch": PAIRS,
+               "insts_valu_per_launch": valu, "insts_valu_per_pair": valu / PAIRS, "insts_lds_per_pair": lds / PAIRS,
+               "per_kernel": {kn: {"insts_valu_per_pair": p.get("SQ_INSTS_VALU", 0.0) / PAIRS, "insts_lds_per_pair": p.get("SQ_INSTS_LDS", 0.0) / PAIRS,
+                                   "wait_any_frac": (p.get("SQ_WAIT_ANY", 0.0) / p["SQ_WAVE_CYCLES"]) if p.get("SQ_WAVE_CYCLES") else None,
+                                   "lds_bank_conflict_frac": (p.get("SQ_LDS_BANK_CONFLICT", 0.0) / p["SQ_LDS_IDX_ACTIVE"]) if p.get("SQ_LDS_IDX_ACTIVE") else None}
+                              for kn, p in per.items()},
+               "peak_T_lane_ops_per_s": 36.3,
+               "method": "SQ_INSTS_VALU of the plan's kernels from rocprofv3 --pmc (profiles/<tag>_sq_counters.txt), one launch of pairs_per_launch pairs; "
+                         "'peak' = the measured issue rate of the bit-op / v_bcnt / v_sad_u8 / v_alignbit class (profiles/r02c_issue_rate_microbench.txt: ~4.5 "
+                         "cycles per wave64 instruction per SIMD, 1024 SIMDs, 2.4 GHz, x64 lanes); v_add / v_and issue in 2.8 cycles, so the fraction is an upper bound"},
+              open(os.path.join(dst, "valu.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
