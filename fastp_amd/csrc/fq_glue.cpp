@@ -1,5 +1,7 @@
 // fq_glue.cpp - include/fastp_gpu_host.h: the string side of the patched worker loop in C++.
 // Host code only.  Mirrors fastp_amd/hostloop.py (apply_results, AdapterMaps, UmiNameEditor).
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -40,6 +42,10 @@ char complement(char c) {  // util.h:16-33: anything outside ACGTacgt -> 'N'
     }
 }
 
+static FILE* dump_file() {   // debugging aid: FASTP_GPU_DUMP_ADAPTERS=<path> logs every string handed to a map
+    static FILE* f = [] { const char* p = getenv("FASTP_GPU_DUMP_ADAPTERS"); return p ? fopen(p, "w") : (FILE*)nullptr; }();
+    return f;
+}
 struct AdapterMap {
     std::map<std::string, long> m;
     static bool low_complexity(const std::string& a) {  // filterresult.cpp:115-122
@@ -48,6 +54,7 @@ struct AdapterMap {
         return diff < (int)(a.size() / 2);
     }
     bool add(const std::string& a) {  // the per-map body of addAdapterTrimmed (:128-151)
+        if (FILE* f = dump_file()) fprintf(f, "%p %s\n", (void*)this, a.c_str());
         auto it = m.find(a);
         if (it != m.end()) { it->second++; return true; }
         if ((int)m.size() > MAX_ADAPTER_REC || ((int)m.size() > LOW_COMPLEXITY_SKIP && low_complexity(a))) return false;

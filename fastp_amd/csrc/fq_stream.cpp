@@ -476,7 +476,9 @@ struct Extractor {
                     q.adapter_pos = e->pos;
                     q.adapter_len = e->len;
                     const char* a; size_t la;
-                    cut(q, t, tl, e->adapter < s->fasta.size() ? s->fasta[e->adapter] : std::string(), &a, &la);
+                    static const std::string none;
+                    const std::string& aseq = e->adapter < s->fasta.size() ? s->fasta[e->adapter] : none;   // (a reference: cut() keeps a pointer into it)
+                    cut(q, t, tl, aseq, &a, &la);
                     if (la) put(blob, is_r2 ? RP_SINGLE_R2 : RP_SINGLE_R1, a, la, nullptr, 0);
                 }
             };
@@ -741,6 +743,7 @@ int run_loop(Run* R) {
         fastp_gpu_parse_info info[2];
         memset(info, 0, sizeof(info));
         int n = 0;
+        int32_t first_n[2] = {0, 0};   // complete records each file's text of this trip holds (up to cap)
         bool stop_after = false;
         t0 = now_s();
         for (int attempt = 0;; attempt++) {
@@ -753,7 +756,7 @@ int run_loop(Run* R) {
                     if (pass == 1 && info[m].n_records == want) continue;
                     const int prc = fastp_gpu_parse_fastq(s->ctx, s->d_text[slot][m], total[m], d.eof[m] ? 1 : 0, want, s->d_seq[m], s->d_qual[m], s->d_len[m],
                                                           s->d_loff[m], s->d_llen[m], &info[m]);
-                    if (prc == FASTP_GPU_OK) continue;
+                    if (prc == FASTP_GPU_OK) { if (pass == 0) first_n[m] = info[m].n_records; continue; }
                     if (prc != FASTP_GPU_E_INVALID || info[m].first_bad < 0) return s->fail_ctx(prc, "fastp_gpu_parse_fastq");
                     if (info[m].bad_kind == FASTP_GPU_PARSE_BAD_TOO_LONG) {
                         const int rc = replan(s, info[m].max_seq_len);
@@ -778,6 +781,11 @@ int run_loop(Run* R) {
             n = want;
             break;
         }
+        // a file that is at its end and has handed out its last complete record ends the stream, whatever the other file
+        // still holds: the reference pairs packs up and stops at the shorter file (peprocessor.cpp:363-370, :1034-1037)
+        bool exhausted = false;
+        for (int m = 0; m < nm; m++)
+            if (d.eof[m] && cap > 0 && (total[m] == 0 || (info[m].n_records == n && first_n[m] == n && first_n[m] < cap))) exhausted = true;
         s->st.parse_s += now_s() - t0;
         int64_t left[2] = {0, 0};
         bool any_left = false;
@@ -786,7 +794,7 @@ int run_loop(Run* R) {
             any_left = any_left || left[m] > 0;
         }
         const bool limit_hit = s->cfg.reads_to_process > 0 && s->st.units + n >= s->cfg.reads_to_process;
-        if (stop_after || limit_hit) {
+        if (stop_after || limit_hit || (exhausted && nm > 1)) {
             done = true;
         } else if (all_eof) {
             // a trip takes at most max_records records: when the cap was hit, complete records may remain in the carried

@@ -13,7 +13,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=4_000_000)
 ap.add_argument("--big", type=int, default=0, help="a second, larger sample for the stream mode (start-up amortised)")
-ap.add_argument("--ref-threads", default="1,4,16,32,64")
+ap.add_argument("--ref-threads", default="1,16")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 REF = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
@@ -35,7 +35,10 @@ def run(binary, w, tag, tmp, f1, f2, env=None, reps=2, extra=()):
     best, err = None, ""
     for _ in range(reps):
         t0 = time.time()
-        p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})), timeout=2400)
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})), timeout=300)
+        except subprocess.TimeoutExpired:
+            return None, "timeout (300 s)", ""
         if p.returncode != 0:
             return None, p.stderr.decode()[-400:], ""
         dt = time.time() - t0
@@ -95,11 +98,11 @@ def block(pairs, ref_threads, gpu_cfgs):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
-cfgs = [("stream", 16, {}), ("stream", 4, {}), ("stream", 1, {}),
+cfgs = [("stream", 16, {}), ("stream", 4, {}),
         ("stream c64", 16, {"FASTP_GPU_STREAM_CHUNK_MB": "64"}), ("stream c16", 16, {"FASTP_GPU_STREAM_CHUNK_MB": "16"}),
         ("stream io16", 16, {"FASTP_GPU_STREAM_IO_THREADS": "16"}),
         ("stream input", 16, {"FASTP_GPU_WRITER": "input"}),
-        ("pack", 16, {"FASTP_GPU_STREAM": "0"}), ("pack", 4, {"FASTP_GPU_STREAM": "0"})]
+        ("pack", 16, {"FASTP_GPU_STREAM": "0"})]
 block(args.pairs, [int(x) for x in args.ref_threads.split(",")], cfgs)
 if args.big:
     block(args.big, [1, 16], [("stream", 16, {}), ("stream c64", 16, {"FASTP_GPU_STREAM_CHUNK_MB": "64"}), ("stream input", 16, {"FASTP_GPU_WRITER": "input"})])
