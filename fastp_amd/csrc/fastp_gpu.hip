@@ -47,10 +47,10 @@ extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a)
 #endif
 // (reads of up to 256 bases, SWM = 16: the row stage alone is 16 KB per wavefront, two workgroups fit a CU whatever the
 // register count - compiled for two wavefronts per SIMD, no spills)
-template <int SWM, int B, int NPL, bool PAIRED>
+template <int SWM, int B, int NPL, bool PAIRED, bool EXT>
 __global__ void __launch_bounds__(256, SWM > 10 ? 2 : FQ_LANE_WAVES) fq_lane_kernel(LaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
-    lane_body<SWM, B, NPL, PAIRED>(*kernel_args(&a), fq_lds);
+    lane_body<SWM, B, NPL, PAIRED, EXT>(*kernel_args(&a), fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(1024, 8) fq_stats_kernel(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -337,7 +337,8 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
-    if (!p.stats_one_pass || p.allow_gap || p.poly_x || p.n_fasta || p.has_a1 || p.has_a2 || p.complexity_filter || p.overlapped_out) return false;
+    if (!p.stats_one_pass || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
+    if ((p.has_a1 && p.alen1 > 64) || (p.has_a2 && p.alen2 > 64)) return false;   // the lane kernel keeps an adapter in four uniform words
     if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
     if (p.cut_right && (p.wR < 1 || p.wR > 8)) return false;
     if (p.cut_tail && !p.cut_right && (p.wT < 1 || p.wT > 8)) return false;
@@ -346,15 +347,21 @@ static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
 }
 
 typedef void (*lane_kernel_fn)(LaneArgs);
-static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired) {
+template <bool EXT>
+static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
     if (swm == 10) {
-        if (B == 0) return paired ? fq_lane_kernel<10, 0, 3, true> : fq_lane_kernel<10, 0, 3, false>;
-        if (B == 2) return paired ? fq_lane_kernel<10, 2, 3, true> : fq_lane_kernel<10, 2, 3, false>;
-        return paired ? fq_lane_kernel<10, 4, 3, true> : fq_lane_kernel<10, 4, 3, false>;
+        if (B == 0) return paired ? fq_lane_kernel<10, 0, 3, true, EXT> : fq_lane_kernel<10, 0, 3, false, EXT>;
+        if (B == 2) return paired ? fq_lane_kernel<10, 2, 3, true, EXT> : fq_lane_kernel<10, 2, 3, false, EXT>;
+        return paired ? fq_lane_kernel<10, 4, 3, true, EXT> : fq_lane_kernel<10, 4, 3, false, EXT>;
     }
-    if (B == 0) return paired ? fq_lane_kernel<16, 0, 3, true> : fq_lane_kernel<16, 0, 3, false>;
-    if (B == 2) return paired ? fq_lane_kernel<16, 2, 3, true> : fq_lane_kernel<16, 2, 3, false>;
-    return paired ? fq_lane_kernel<16, 4, 3, true> : fq_lane_kernel<16, 4, 3, false>;
+    if (B == 0) return paired ? fq_lane_kernel<16, 0, 3, true, EXT> : fq_lane_kernel<16, 0, 3, false, EXT>;
+    if (B == 2) return paired ? fq_lane_kernel<16, 2, 3, true, EXT> : fq_lane_kernel<16, 2, 3, false, EXT>;
+    return paired ? fq_lane_kernel<16, 4, 3, true, EXT> : fq_lane_kernel<16, 4, 3, false, EXT>;
+}
+// ext: adapter sequences, polyX trimming or the complexity filter are on (the instantiation that carries those steps)
+static bool lane_ext(const DevParams& p) { return p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter; }
+static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, bool ext) {
+    return ext ? lane_kernel_pick<true>(swm, B, paired) : lane_kernel_pick<false>(swm, B, paired);
 }
 
 extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fastp_gpu_ctx** out) {
@@ -483,6 +490,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             const int lw = (ctx->dp.cycles + 2) / 2;
             l.lut_ov = o; o += lw;
             l.lut_lowq = o; o += lw;
+            l.lut_cplx = o; o += lw;
             l.val4 = o; o += 256;
             o = (o + 1) & ~1;
             l.planes = o;
@@ -500,7 +508,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
 #ifndef FQ_HOSTSIM
             if (per_cu <= 0) {
                 int nb = 0;
-                lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0);
+                lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0, lane_ext(ctx->dp));
                 (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, l.total * 4);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)l.total * 4) == hipSuccess && nb > 0) per_cu = nb;
                 (void)hipGetLastError();
@@ -602,7 +610,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
             if (env_int("FASTP_GPU_LANE_DYNAMIC", 1)) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_ctr, sizeof(int)));
             for (int Bh : {0, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0})
-                CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0),
+                CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp)),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, ctx->ln_lds.total * 4));
         }
     }
@@ -1053,7 +1061,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.chunk_ctr = ctx->d_ln_ctr;
             if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
-            lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0);
+            lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp));
             ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
             hipLaunchKernelGGL(fn, dim3(ln_grid), dim3(256), (size_t)ctx->ln_lds.total * 4, st, la);
         } else if (ctx->split && ctx->cfg.threads > 256) hipLaunchKernelGGL(fq_scan_wide_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);

@@ -163,6 +163,7 @@ FQ_DEV int popc64(u64 v) { return __popcll(v); }
 FQ_DEV int ffs64(u64 v) { return __ffsll((unsigned long long)v); }  // 1-based, 0 if none
 FQ_DEV int ffs32(u32 v) { return __ffs((int)v); }                       // 1-based, 0 if none
 FQ_DEV int clz32(u32 v) { return __clz((int)v); }                       // 32 for v == 0
+FQ_DEV int clz64(u64 v) { const u32 hi = (u32)(v >> 32); return hi ? __clz((int)hi) : 32 + __clz((int)(u32)v); }   // 64 for v == 0
 FQ_DEV u32 brev32(u32 v) { return __brev(v); }
 // low 32 bits of ({hi,lo} >> (s & 31))  -> v_alignbit_b32
 FQ_DEV u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }

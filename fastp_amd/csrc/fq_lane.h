@@ -23,6 +23,9 @@
 #ifndef FQ_LANE_STAGE_BATCH
 #define FQ_LANE_STAGE_BATCH 10
 #endif
+#ifndef FQ_LANE_METRICS      // A/B switch: 2 = partial sums from the load sweep + the one cut word (default), 0 = round 3's second staging of the
+#define FQ_LANE_METRICS 2    // quality rows with every dword masked by the window
+#endif
 #ifdef FQ_LANE_NO_FENCE      // A/B switch (tools/gpu_lane_ab3.sh)
 #define FQ_LANE_FENCE() ((void)0)
 #else
@@ -37,6 +40,7 @@ struct LaneLds {
     int n_misc;
     int lut_ov;     // u16 [cycles + 1] min(diffLimit, ol * pct)          overlapanalysis.cpp:51
     int lut_lowq;   // u16 [cycles + 1] floor(unqualPct * rlen / 100.0)   filter.cpp:36
+    int lut_cplx;   // u16 [cycles + 1] least adjacent-difference count that passes filter.cpp:65
     int val4;       // u32 [256] Duplicate's base values of the four bases of a packed byte
     int planes;     // u32 [4][hp_nq][B][NPL] byte planes of the primes (DevLuts::dup_planes), 8-byte aligned
     int n_planes;
@@ -325,12 +329,18 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32
         for (int d = 7; d >= 0; d--) {
             const u32 b1 = (q[d] >> 7) & 0x01010101u;   // bits 0, 8, 16, 24
             nw = dot4_u8(b1, 0x08040201u, nw << 4);     // the four flags as a nibble behind the ones gathered so far
+#if FQ_LANE_METRICS == 2
             ts = sum_bytes(q[d] & 0x7F7F7F7Fu, ts);
             gs += (u32)popc32(((q[d] | 0x80808080u) - thr4) & 0x80808080u);
+#endif
         }
         r.n[W] = nw;
         anyn |= nw;
+#if FQ_LANE_METRICS == 2
         part[W * 64 + lane] = ts | (gs << 16);   // sum of the quality characters | bases at or above the qualified quality << 16
+#else
+        (void)ts; (void)gs; (void)part; (void)thr4;
+#endif
         // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
         u32 m = 0;
         if (win == 4) m = lane_window_word4(q, nthr4);                             // uniform
@@ -569,6 +579,296 @@ FQ_DEV void lane_metrics(const KernelArgs& a, const LaneRead<SWM>& r, const u32*
     nb = (int)n;
 }
 
+// ---------------------------------------------------------------------------
+// AdapterTrimmer::trimBySequence (adaptertrimmer.cpp:64-157) with the read in registers, for adapters of at most 64
+// bases (four uniform words: -a / --adapter_sequence_r2 and the ones the Evaluator detects are <= 60; longer ones keep
+// the tile kernels).  Same three passes as trim_by_sequence() of the tile kernel: the no-gap scan over pos = start ..
+// rlen - matchReq - 1 (here: negative positions by four static compares against the shifted adapter, the positions with
+// 16 bases to look at by the overlap prefilter's 6 instructions per position + an exact check of the survivors in
+// ascending order, the last positions on a 16-base window cut out of the read's tail), then Matcher's one-insertion and
+// one-deletion forms in closed form (one_gap_match_mask: one walk gives the answer for every compare length).
+// ---------------------------------------------------------------------------
+enum { LANE_ADAPTER_WORDS = 4 };
+// 16 bases (and their N flags, spread to bit 2k) of the read starting at base bp (any sign; outside the words: zeros)
+template <int SWM>
+FQ_DEV void lane_window16(const LaneRead<SWM>& r, int bp, u32& codes, u32& nsp) {
+    const int w0 = bp >> 4;   // floor
+    const u32 sh = (u32)(bp & 15) * 2u;
+    const u32 A = lane_word_at<SWM>(r.s, w0), B = lane_word_at<SWM>(r.s, w0 + 1);
+    codes = alignbit(B, A, sh);
+    const int b0 = bp >> 5;
+    const u32 nsh = (u32)(bp & 31);
+    const u32 NA = lane_word_at<SWM / 2>(r.n, b0), NB = lane_word_at<SWM / 2>(r.n, b0 + 1);
+    nsp = spread16(alignbit(NB, NA, nsh));
+}
+// mismatches of n (<= 64) bases: xs (the read moved so that the compare starts at base 0; xn = its N flags, 1 bit per base)
+// against the uniform words aw
+template <int SWM>
+FQ_DEV int lane_adapter_mm(const u32 (&xs)[SWM], const u32 (&xn)[SWM / 2], bool hasN, const u32 (&aw)[LANE_ADAPTER_WORDS], int n) {
+    int mm = 0;
+#pragma unroll
+    for (int w = 0; w < LANE_ADAPTER_WORDS; w++) {
+        u32 d = fold_diff(xs[w] ^ aw[w]);
+        if (hasN) d |= nmask_word<SWM / 2>(xn, w);
+        const int rem = n - 16 * w;
+        mm += popc32(rem >= 16 ? d : (rem <= 0 ? 0u : (d & lowmask32(2 * rem))));
+    }
+    return mm;
+}
+// Matcher::matchWithOneInsertion for every compare length at once (one_gap_match_mask of the tile kernel): D0 / D1 =
+// "position k differs" of the aligned / the shifted comparison, 2 bits per position as fold_diff leaves them; returns
+// bit (c - 1) <=> matched for compare length c (c <= cmax <= 64)
+FQ_DEV u64 lane_gap_mask(const u32 (&D0)[LANE_ADAPTER_WORDS], const u32 (&D1)[LANE_ADAPTER_WORDS], int cmax, int bound) {
+    u32 ok_lo = 0, ok_hi = 0;
+    int p0 = 0, p1 = 0, gmin = 4096;   // 4096 = "no split point yet": never passes a limit
+#pragma unroll
+    for (int k = 0; k < 16 * LANE_ADAPTER_WORDS; k++) {
+        if (k < bound) {   // uniform: the adapter's length
+            const int c = k + 1;
+            p0 += (int)((D0[k >> 4] >> (2 * (k & 15))) & 1u);
+            p1 += (int)((D1[k >> 4] >> (2 * (k & 15))) & 1u);
+            const bool hit = c <= cmax && gmin + p1 <= c / 8 - 1;
+            if (c <= 32) ok_lo |= hit ? (1u << ((c - 1) & 31)) : 0u;
+            else ok_hi |= hit ? (1u << ((c - 1) & 31)) : 0u;
+            gmin = imin(gmin, p0 - p1);
+        }
+    }
+    return (u64)ok_lo | ((u64)ok_hi << 32);
+}
+// the position the reference's loop over pos picks from such a mask: compare length cfirst at pos 0, one less per
+// position once the read's end is nearer than the adapter's (quirk #7: the strings are not advanced by pos); -1 = none
+FQ_DEV int lane_gap_pick(u64 ok, int cfirst, int npos, int rlen_minus) {
+    if (cfirst < 1 || npos <= 0) return -1;
+    const u64 m = cfirst >= 64 ? ok : (ok & ((1ull << cfirst) - 1ull));
+    if (m == 0ull) return -1;
+    if ((m >> (cfirst - 1)) & 1ull) return 0;
+    const int c = 64 - clz64(m);             // the largest compare length that matches
+    const int pos = rlen_minus - c;          // where the loop reaches it
+    return pos < npos ? pos : -1;
+}
+template <int SWM>
+FQ_DEV bool lane_trim_by_sequence(const LaneRead<SWM>& r, int rlen, const u32 (&aw)[LANE_ADAPTER_WORDS], int alen, int matchReq, int& out_pos) {
+    if (alen < matchReq) return false;                      // (uniform)
+    const bool hasN = (r.flags & RS_HAS_N) != 0;
+    const int last = rlen - matchReq;                       // pos runs to last - 1
+    bool found = false;
+    int pos_found = 0;
+    // ---- negative positions: the read's head against the adapter without its first -pos bases (:79-86) ----
+    const int start = alen >= 16 ? -4 : (alen >= 12 ? -3 : (alen >= 8 ? -2 : 0));
+#pragma unroll
+    for (int pos = -4; pos < 0; pos++) {
+        if (pos >= start) {   // uniform
+            const int so = -pos;
+            u32 as[LANE_ADAPTER_WORDS];
+#pragma unroll
+            for (int w = 0; w < LANE_ADAPTER_WORDS; w++) as[w] = alignbit(w + 1 < LANE_ADAPTER_WORDS ? aw[w + 1] : 0u, aw[w], 2u * (u32)so);
+            const int cmplen = imin(rlen - pos, alen);
+            const int mm = lane_adapter_mm<SWM>(r.s, r.n, hasN, as, cmplen - so);
+            if (!found && pos < last && mm <= cmplen / 8) { found = true; pos_found = pos; }
+        }
+    }
+    // ---- positions with npre bases to look at: prefilter + exact check, ascending ----
+    const int npre = imin(16, alen);
+    const int nmain = imin(rlen - npre + 1, last);          // positions [0, nmain)
+    if (ballot(!found && nmain > 0) != 0ull) {
+        u32 cm[SWM / 2];
+        const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+        lane_scan<SWM>(r.s, aw[0], found ? 0 : nmain, premask, (u32)(-(alen / 8 + 1)), cm);
+        for (;;) {
+            const int o = found ? -1 : lane_next_candidate<SWM>(cm);
+            if (ballot(o >= 0) == 0ull) break;
+            if (o >= 0) {
+                u32 xs[SWM], xn[SWM / 2];
+#pragma unroll
+                for (int w = 0; w < SWM; w++) xs[w] = r.s[w];
+                base_shift_down<SWM>(xs, (u32)o);
+#pragma unroll
+                for (int w = 0; w < SWM / 2; w++) xn[w] = r.n[w];
+                if (hasN) bit_shift_down<SWM / 2>(xn, (u32)o);
+                const int cmplen = imin(rlen - o, alen);
+                if (lane_adapter_mm<SWM>(xs, xn, hasN, aw, cmplen) <= cmplen / 8) { found = true; pos_found = o; }
+            }
+        }
+    }
+    // ---- the last positions: fewer than npre bases left (compare length k = rlen - pos, matchReq < k < npre) ----
+    if (ballot(!found && rlen > matchReq) != 0ull) {
+        u32 tc, tn;
+        lane_window16<SWM>(r, rlen - 16, tc, tn);           // bases [rlen - 16, rlen)
+#pragma unroll
+        for (int k = 15; k > 0; k--) {
+            if (k < npre && k > matchReq) {   // uniform
+                const u32 sh = 2u * (u32)(16 - k);
+                u32 d = fold_diff((tc >> sh) ^ aw[0]);
+                if (hasN) d |= tn >> sh;
+                const int mm = popc32(d & lowmask32(2 * k));
+                const int pos = rlen - k;
+                if (!found && pos >= 0 && pos >= nmain && mm <= k / 8) { found = true; pos_found = pos; }
+            }
+        }
+    }
+    // ---- one insertion / one deletion in the read (:105-135), both on the strings as they start (quirk #7) ----
+    if (ballot(!found && rlen - matchReq > 0) != 0ull) {
+        u32 D0[LANE_ADAPTER_WORDS], D1[LANE_ADAPTER_WORDS];
+        u32 n1[SWM / 2];
+#pragma unroll
+        for (int w = 0; w < SWM / 2; w++) n1[w] = alignbit(w + 1 < SWM / 2 ? r.n[w + 1] : 0u, r.n[w], 1);   // N flags of the read moved down one base
+#pragma unroll
+        for (int w = 0; w < LANE_ADAPTER_WORDS; w++) {
+            const u32 s1 = alignbit(r.s[w + 1], r.s[w], 2);                  // read[k + 1]
+            D0[w] = fold_diff(r.s[w] ^ aw[w]);
+            D1[w] = fold_diff(s1 ^ aw[w]);
+            if (hasN) { D0[w] |= nmask_word<SWM / 2>(r.n, w); D1[w] |= nmask_word<SWM / 2>(n1, w); }
+        }
+        if (!found && rlen - matchReq - 1 > 0) {             // insertion: ins = read, nor = adapter
+            const int cmax = imin(rlen - 1, alen);
+            const int pos = lane_gap_pick(lane_gap_mask(D0, D1, cmax, imin(alen, 64)), cmax, rlen - matchReq - 1, rlen - 1);
+            if (pos >= 0) { found = true; pos_found = pos; }
+        } else {
+            (void)lane_gap_mask(D0, D1, 0, 0);
+        }
+        if (ballot(!found && rlen - matchReq > 0) != 0ull) {
+#pragma unroll
+            for (int w = 0; w < LANE_ADAPTER_WORDS; w++) {               // deletion: ins = adapter, nor = read: D1 = adapter[k + 1] != read[k]
+                const u32 a1 = alignbit(w + 1 < LANE_ADAPTER_WORDS ? aw[w + 1] : 0u, aw[w], 2);
+                D1[w] = fold_diff(r.s[w] ^ a1);
+                if (hasN) D1[w] |= nmask_word<SWM / 2>(r.n, w);
+            }
+            if (!found && rlen - matchReq > 0) {
+                const int cmax = imin(rlen, alen - 1);
+                const int pos = lane_gap_pick(lane_gap_mask(D0, D1, cmax, imin(alen - 1, 64)), cmax, rlen - matchReq, rlen);
+                if (pos >= 0) { found = true; pos_found = pos; }
+            }
+        }
+    }
+    out_pos = pos_found;
+    return found;
+}
+// the bookkeeping of AdapterTrimmer::trimBySequence's hit (:138-156): new length, the string handed to addAdapterTrimmed
+FQ_DEV void lane_apply_adapter(u32* misc, int pos, int alen, int& len, u32& apos, u32& alen_out) {
+    int adapter_len;
+    if (pos < 0) { adapter_len = alen + pos; len = 0; }
+    else { adapter_len = len - pos; len = pos; }
+    if (adapter_len > 0) lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)adapter_len);
+    apos = (u32)pos & 0xFFFFu;
+    alen_out = (u32)adapter_len;
+}
+
+// ---------------------------------------------------------------------------
+// PolyX::trimPolyX (polyx.cpp:49-116) on [0, rlen) of a read in registers: the walk from the tail over 32-base windows
+// (codes and N flags cut out of the registers), then the reference's step back to the first base of the winning letter.
+// ---------------------------------------------------------------------------
+template <int SWM>
+FQ_DEV u32 lane_sym_at(const LaneRead<SWM>& r, int j) {   // A0 T1 C2 G3 N4; 5 outside the read's words
+    const u32 w = lane_word_at<SWM>(r.s, j >> 4), nw = lane_word_at<SWM / 2>(r.n, j >> 5);
+    const u32 code = (w >> (2 * (j & 15))) & 3u;
+    return ((nw >> (j & 31)) & 1u) ? 4u : code;
+}
+template <int SWM>
+FQ_DEV int lane_trim_poly_x(const LaneRead<SWM>& r, bool active, int rlen, int compareReq, int& poly, int& trimmed) {
+    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, pos = 0;
+    bool done = !active || rlen <= 0;
+    poly = -1;
+    trimmed = 0;
+    for (int k = 0; ballot(!done) != 0ull; k++) {   // wave-uniform
+        const int end = rlen - 32 * k;              // the window holds bases [end - 32, end)
+        u32 lo, hi, nlo, nhi;
+        lane_window16<SWM>(r, end - 32, lo, nlo);
+        lane_window16<SWM>(r, end - 16, hi, nhi);
+        for (int t = 0; t < 32; t++) {
+            if (ballot(!done) == 0ull) break;
+            if (!done) {
+                if (pos >= rlen) {
+                    done = true;                    // the loop ran out: pos == rlen
+                } else {
+                    const int g = 15 - (t & 15);    // base end - 1 - t
+                    const u32 cw = t < 16 ? hi : lo, nw = t < 16 ? nhi : nlo;
+                    const u32 code = (cw >> (2 * g)) & 3u;
+                    const bool isn = ((nw >> (2 * g)) & 1u) != 0u;
+                    cnt0 += (isn || code == 0u) ? 1 : 0;   // N counts toward all (:79-85)
+                    cnt1 += (isn || code == 1u) ? 1 : 0;
+                    cnt2 += (isn || code == 2u) ? 1 : 0;
+                    cnt3 += (isn || code == 3u) ? 1 : 0;
+                    const int cmp = pos + 1;
+                    const int allowed = imin(5, cmp / 8);
+                    const bool brk = !((cmp - cnt0 <= allowed) | (cmp - cnt1 <= allowed) | (cmp - cnt2 <= allowed) | (cmp - cnt3 <= allowed));
+                    if (brk && (pos >= 8 || pos + 1 >= compareReq - 1)) done = true;   // break: pos stays
+                    else pos++;
+                }
+            }
+        }
+    }
+    const bool hit = active && pos + 1 >= compareReq;        // :98 (no early return: the loop below is a wave collective)
+    int best = 0, mx = cnt0;                                 // first maximum in the order A, T, C, G
+    if (cnt1 > mx) { mx = cnt1; best = 1; }
+    if (cnt2 > mx) { mx = cnt2; best = 2; }
+    if (cnt3 > mx) { mx = cnt3; best = 3; }
+    // :109  while(data[rlen-pos-1] != polyBase && pos>=0) pos--;   index -1 and index rlen never equal the poly base
+    bool walking = hit;
+    while (ballot(walking) != 0ull) {
+        if (walking) {
+            const int idx = rlen - pos - 1;
+            const bool is_poly = idx >= 0 && idx < rlen && lane_sym_at<SWM>(r, idx) == (u32)best;
+            if (!is_poly && pos >= 0) pos--;
+            else walking = false;
+        }
+    }
+    if (!hit) return rlen;
+    poly = best;
+    trimmed = pos + 1;
+    const int newlen = rlen - pos - 1;
+    if (newlen < 0 || newlen > rlen) return rlen;   // Read::resize ignores (read.cpp:62-64)
+    return newlen;
+}
+
+// fastp_simd::countAdjacentDiffs (simd.cpp:121-185) of [0, len): positions j in [1, len) whose symbol differs from the one before
+template <int SWM>
+FQ_DEV int lane_adjacent_diffs(const LaneRead<SWM>& r, int len) {
+    const bool hasN = (r.flags & RS_HAS_N) != 0;
+    u32 nd[SWM / 2];   // bit j: N(j) != N(j - 1)
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) nd[w] = r.n[w] ^ ((r.n[w] << 1) | (w ? r.n[w - 1] >> 31 : 0u));
+    int cnt = 0;
+#pragma unroll
+    for (int w = 0; w < SWM; w++) {
+        const u32 prev = (r.s[w] << 2) | (w ? r.s[w - 1] >> 30 : 0u);
+        u32 d = fold_diff(r.s[w] ^ prev);
+        if (hasN) d |= nmask_word<SWM / 2>(nd, w);
+        const int hi = len - 16 * w;                         // bases [16 w, 16 w + hi) of this word are inside
+        u32 M = hi >= 16 ? 0x55555555u : (hi <= 0 ? 0u : (lowmask32(2 * hi) & 0x55555555u));
+        if (w == 0) M &= ~1u;                                // base 0 has nothing before it
+        cnt += popc32(d & M);
+    }
+    return cnt;
+}
+
+// round 3's form (FQ_LANE_METRICS == 0): the mate's quality rows are staged once more and every dword masked by the window
+template <int SWM>
+FQ_DEV void lane_metrics_staged(const KernelArgs& a, u32* stage, const u32* qual, int chunk0, int rows, int lane, int len, int& tot, int& low, int& nb) {
+    const int qwg = a.p.qw_g;
+    lane_stage_rows<FQ_LANE_STAGE_BATCH>(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
+    const u64* qrow = (const u64*)(stage + lane * qwg);
+    const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
+    u32 t = 0, lo = 0, n = 0;
+#pragma unroll
+    for (int c = 0; c < 4 * SWM; c += 2) {
+        const u64 v = qrow[c >> 1];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+            const u32 qd = hlf ? (u32)(v >> 32) : (u32)v;
+            const int rem = len - 4 * (c + hlf);
+            const u32 M = rem >= 4 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : lowmask32(8 * rem));
+            const u32 q7 = qd & 0x7F7F7F7Fu & M;
+            const u32 ge = ((q7 | 0x80808080u) - thr4) & 0x80808080u;
+            t = sum_bytes(q7, t);
+            lo += (u32)popc32(~ge & 0x80808080u & M);
+            n += (u32)popc32(qd & 0x80808080u & M);
+        }
+    }
+    tot = (int)t - 33 * len;
+    low = (int)lo;
+    nb = (int)n;
+}
+
 FQ_DEV void lane_claim(const KernelArgs& a, int gp, int tl, const u64* h, int B, u32& won) {
     // Duplicate's claim (dup_claim_issue / dup_claim_collect of the tile kernel) for this unit
     const u64 words = a.dup_bits >> 5;
@@ -585,7 +885,9 @@ FQ_DEV void lane_claim(const KernelArgs& a, int gp, int tl, const u64* h, int B,
 // ---------------------------------------------------------------------------
 // the kernel body: persistent wavefronts, a wavefront takes 64 consecutive units at a time
 // ---------------------------------------------------------------------------
-template <int SWM, int B, int NPL, bool PAIRED>
+// EXT: the option family with adapter sequences, polyX trimming or the complexity filter - a second instantiation, so that
+// the registers those steps need (+30) are not taken from the kernel of the options that do not use them
+template <int SWM, int B, int NPL, bool PAIRED, bool EXT>
 FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const KernelArgs& a = la.k;
     const LaneLds& ll = la.l;
@@ -596,9 +898,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         const int lw = (p.cycles + 2) / 2;
         const u32* g0 = (const u32*)a.lut.ov_limit;
         const u32* g1 = (const u32*)a.lut.lowq_limit;
+        const u32* g2 = (const u32*)a.lut.cplx_min;
         for (int i = tid; i < lw; i += nt) {
             lds[ll.lut_ov + i] = g0[i];
             lds[ll.lut_lowq + i] = g1[i];
+            lds[ll.lut_cplx + i] = g2[i];
         }
         if (B > 0)
             for (int i = tid; i < 256; i += nt) {  // duplicate.cpp:92-109: A=7 T=222 C=74 G=31 (codes A0 T1 C2 G3)
@@ -613,6 +917,10 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     u32* misc = lds + ll.misc;
     const u16* lut_ov = (const u16*)(lds + ll.lut_ov);
     const u16* lut_lowq = (const u16*)(lds + ll.lut_lowq);
+    const u16* lut_cplx = (const u16*)(lds + ll.lut_cplx);
+    u32 aw1[LANE_ADAPTER_WORDS], aw2[LANE_ADAPTER_WORDS];   // -a / --adapter_sequence_r2 (uniform)
+#pragma unroll
+    for (int w = 0; w < LANE_ADAPTER_WORDS; w++) { aw1[w] = p.a1w[w]; aw2[w] = p.a2w[w]; }
     const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
     const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
@@ -742,9 +1050,10 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 if (isize >= 0) lds_add_u32(&misc[MISC_ISIZE + isize], 1u);
                 isize_done = true;
             }
-            if (both && p.need_overlap && p.adapter_enabled) {
+            {
+                const bool adapt = both && p.need_overlap && p.adapter_enabled;   // per lane; the sequence scans below are wave collectives
                 bool trimmed = false;
-                if (ovl && ov_off < 0) {   // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
+                if (adapt && ovl && ov_off < 0) {   // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
                     const int len1 = imin(cur1, ov_len), len2 = imin(cur2, ov_len);
                     apos1 = (u32)len1; alen1 = (u32)(cur1 - len1);
                     apos2 = (u32)len2; alen2 = (u32)(cur2 - len2);
@@ -752,11 +1061,40 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                     cur1 = len1;
                     cur2 = len2;
                     trimmed = true;
-                    r1.flags |= RS_ADAPTER_OV | RS_ADAPTER;
-                    r2.flags |= RS_ADAPTER_OV | RS_ADAPTER;
-                    lds_add_u32(&misc[MISC_ADAPTER_READS], 2u);   // :472-475
+                    r1.flags |= RS_ADAPTER_OV;
+                    r2.flags |= RS_ADAPTER_OV;
                 }
-                if (trimmed && cur1 <= p.dimer_max_len && cur2 <= p.dimer_max_len) dimer = true;   // :480-484
+                bool t1 = trimmed, t2 = trimmed;
+                if (EXT && (p.has_a1 | p.has_a2)) {   // (uniform) peprocessor.cpp:460-466: the pairs the overlap did not trim
+                    const bool go = adapt && !trimmed;
+                    int pos = 0;
+                    if (p.has_a1 && ballot(go) != 0ull) {
+                        const bool hit = lane_trim_by_sequence<SWM>(r1, go ? cur1 : 0, aw1, p.alen1, 4, pos);
+                        if (go && hit) { lane_apply_adapter(misc, pos, p.alen1, cur1, apos1, alen1); t1 = true; }
+                    }
+                    if (p.has_a2 && ballot(go) != 0ull) {
+                        const bool hit = lane_trim_by_sequence<SWM>(r2, go ? cur2 : 0, aw2, p.alen2, 4, pos);
+                        if (go && hit) { lane_apply_adapter(misc, pos, p.alen2, cur2, apos2, alen2); t2 = true; }
+                    }
+                }
+                if (t1) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); r1.flags |= RS_ADAPTER; }   // :472-475
+                if (t2) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); r2.flags |= RS_ADAPTER; }
+                if ((t1 || t2) && cur1 <= p.dimer_max_len && cur2 <= p.dimer_max_len) dimer = true;   // :480-484
+            }
+            if (EXT && p.poly_x && ballot(both) != 0ull) {   // :506-509
+                int poly, cut;
+                cur1 = lane_trim_poly_x<SWM>(r1, both, cur1, p.poly_x_min, poly, cut);
+                if (both && poly >= 0) {   // addPolyXTrimmed filterresult.cpp:186-189
+                    lds_add_u32(&misc[MISC_POLYX_READS + poly], 1u);
+                    lds_add_u32(&misc[MISC_POLYX_BASES + poly], (u32)cut);
+                    r1.flags |= RS_POLYX;
+                }
+                cur2 = lane_trim_poly_x<SWM>(r2, both, cur2, p.poly_x_min, poly, cut);
+                if (both && poly >= 0) {
+                    lds_add_u32(&misc[MISC_POLYX_READS + poly], 1u);
+                    lds_add_u32(&misc[MISC_POLYX_BASES + poly], (u32)cut);
+                    r2.flags |= RS_POLYX;
+                }
             }
             if (both) {   // :511-516
                 if (p.max_len1 > 0 && p.max_len1 < cur1) cur1 = p.max_len1;
@@ -766,10 +1104,36 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             r2.len = cur2;
             if (valid) write_pair_result(a, g, ovl, ov_off, ov_len, ov_diff, isize_done);
         } else {
+            if (EXT && p.adapter_enabled && p.has_a1 && ballot(a1) != 0ull) {   // seprocessor.cpp:244-261
+                int pos = 0, cur = r1.len;
+                const bool hit = lane_trim_by_sequence<SWM>(r1, a1 ? cur : 0, aw1, p.alen1, 4, pos);
+                if (a1 && hit) {
+                    lane_apply_adapter(misc, pos, p.alen1, cur, apos1, alen1);
+                    r1.len = cur;
+                    lds_add_u32(&misc[MISC_ADAPTER_READS], 1u);
+                    r1.flags |= RS_ADAPTER;
+                    if (cur <= p.dimer_max_len) dimer = true;
+                }
+            }
+            if (EXT && p.poly_x && ballot(a1) != 0ull) {   // :263-266
+                int poly, cut;
+                r1.len = lane_trim_poly_x<SWM>(r1, a1, r1.len, p.poly_x_min, poly, cut);
+                if (a1 && poly >= 0) {
+                    lds_add_u32(&misc[MISC_POLYX_READS + poly], 1u);
+                    lds_add_u32(&misc[MISC_POLYX_BASES + poly], (u32)cut);
+                    r1.flags |= RS_POLYX;
+                }
+            }
             if (a1 && p.max_len1 > 0 && p.max_len1 < r1.len) r1.len = p.max_len1;   // seprocessor.cpp:268-271
         }
         // ---- Filter::passFilter (filter.cpp:15-57), routing, records ----
         int tot1 = 0, low1 = 0, nb1 = 0, tot2 = 0, low2 = 0, nb2 = 0;
+#if FQ_LANE_METRICS == 0
+        if (!(skip & 8u)) {
+            lane_metrics_staged<SWM>(a, stage, a.qual[0], chunk * 64, rows, lane, r1.len, tot1, low1, nb1);
+            if (PAIRED) lane_metrics_staged<SWM>(a, stage, a.qual[1], chunk * 64, rows, lane, r2.len, tot2, low2, nb2);
+        }
+#else
         if (!(skip & 8u)) {
             LaneCutWord c1, c2;
             lane_cut_fetch(a, a.qual[0], g, a1, r1.len, c1);
@@ -777,14 +1141,21 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             lane_metrics<SWM>(a, r1, part, lane, c1, r1.len, tot1, low1, nb1);
             if (PAIRED) lane_metrics<SWM>(a, r2, part + (SWM / 2) * 64, lane, c2, r2.len, tot2, low2, nb2);
         }
+#endif
+        int dif1 = 0, dif2 = 0;
+        if (EXT && p.complexity_filter) {   // (uniform) filter.cpp:51-54: countAdjacentDiffs of the final window
+            dif1 = lane_adjacent_diffs<SWM>(r1, r1.len);
+            if (PAIRED) dif2 = lane_adjacent_diffs<SWM>(r2, r2.len);
+        }
         if (valid) {
-            int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, 0, (int)lut_lowq[r1.len], 0) : 16;
+            int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, dif1, (int)lut_lowq[r1.len], (int)lut_cplx[r1.len]) : 16;
             int code2 = 0;
             if (PAIRED) {
-                code2 = a2 ? filter_code_pre(p, r2.len, tot2, low2, nb2, 0, (int)lut_lowq[r2.len], 0) : 16;
+                code2 = a2 ? filter_code_pre(p, r2.len, tot2, low2, nb2, dif2, (int)lut_lowq[r2.len], (int)lut_cplx[r2.len]) : 16;
                 if (dimer) { code1 = 28; code2 = 28; }                          // :568-571
                 lds_add_u32(&misc[MISC_FILTER + imax(code1, code2)], 2u);       // addFilterResult(max, 2) :573
             } else {
+                if (dimer) code1 = 28;                                          // seprocessor.cpp:273-277
                 lds_add_u32(&misc[MISC_FILTER + code1], 1u);                    // seprocessor.cpp:278
             }
             const bool dedup_out = p.dedup && (r1.flags & RS_DUP);
