@@ -144,7 +144,19 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value):
     if os.path.exists(refgpu):
         cores = host_cores()
         try:
-            wall = timed_ref(refgpu, tmp, f1, f2, flags, cores, env={"FASTP_GPU": "1"}, tag="d")
+            import re
+            cmd = [refgpu, "-i", f1, "-I", f2, "-o", os.path.join(tmp, "d1.fq"), "-O", os.path.join(tmp, "d2.fq"), "-j", os.path.join(tmp, "d.json"),
+                   "-h", os.path.join(tmp, "d.html"), "-w", str(cores)] + flags
+            best, stream_s, setup_s = None, None, None
+            for _ in range(2):
+                t0 = time.time()
+                pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, timeout=900,
+                                    env=dict(os.environ, FASTP_GPU="1", FASTP_GPU_VERBOSE="1"))
+                dt = time.time() - t0
+                if best is None or dt < best:
+                    best = dt
+                    m = re.search(r"stream mode: \d+ units in \d+ chunks, ([0-9.]+) s \(setup ([0-9.]+)", pr.stderr.decode(errors="replace"))
+                    stream_s, setup_s = (float(m.group(1)), float(m.group(2))) if m else (None, None)
             same = None
             o1, d1 = os.path.join(tmp, "o1.fq"), os.path.join(tmp, "d1.fq")
             if os.path.exists(o1) and os.path.exists(d1):
@@ -157,9 +169,18 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value):
                             hsh.update(blk)
                     return hsh.hexdigest()
                 same = md5(o1) == md5(d1) and md5(os.path.join(tmp, "o2.fq")) == md5(os.path.join(tmp, "d2.fq"))
-            out["e2e_dropin"] = {"gpu": round(2 * sample_pairs / wall / 1e6, 3), "cpu": cpu_value, "unit": "Mreads/s", "cores": cores,
-                                 "outputs_identical": same,
-                                 "what": f"FASTP_GPU=1 fastp_ref_gpu -w {cores} vs fastp_ref -w {cores}, same files, best of 2"}
+            # what a run costs whatever its size: process start, HIP runtime, engine + page-locked buffers (the first 1000 pairs only)
+            t0 = time.time()
+            subprocess.run(cmd + ["--reads_to_process", "1000"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300,
+                           env=dict(os.environ, FASTP_GPU="1"))
+            startup = time.time() - t0
+            out["e2e_dropin"] = {"gpu": round(2 * sample_pairs / best / 1e6, 3), "cpu": cpu_value, "unit": "Mreads/s", "cores": cores,
+                                 "outputs_identical": same, "wall_s": round(best, 3), "startup_s": round(startup, 3),
+                                 "stream_s": stream_s, "stream_setup_s": setup_s,
+                                 "stream_Mreads_per_s": round(2 * sample_pairs / stream_s / 1e6, 2) if stream_s else None,
+                                 "what": f"FASTP_GPU=1 fastp_ref_gpu -w {cores} (stream binding: raw chunks -> device parser / worker loop / formatter -> "
+                                         f"the writers' files) vs fastp_ref -w {cores}, same files on tmpfs, whole-process wall, best of 2; startup_s = the same "
+                                         f"binary on the first 1000 pairs; stream_s = the file loop alone"}
         except Exception as e:
             out["e2e_dropin"] = {"gpu": None, "error": repr(e)[:200]}
     return out
@@ -217,6 +238,17 @@ def other_configs(dev):
     p.poly_g = 1
     p.cut_right = 1
     run("configs[1]: SE 1x150, 10 M reads, -A -g --cut_right", p, 150, 10_000_000, False)
+    # fastp's DEFAULT single-end run: the adapter is auto-detected and trimmed by sequence (seprocessor.cpp:240-252,
+    # AdapterTrimmer::trimBySequence) - the TruSeq adapter the synthetic reads carry, as the Evaluator would report it
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    run("SE 1x150 default (adapter auto-detected -> trimBySequence), 10 M reads", p, 150, 10_000_000, False)
+    p = abi.default_params(True, 150)
+    p.adapter_seq_r1 = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    p.adapter_seq_r2 = b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
+    p.cut_right = 1
+    run("PE 2x150 --adapter_sequence/--adapter_sequence_r2 + --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import cases

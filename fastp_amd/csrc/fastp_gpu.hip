@@ -2165,6 +2165,22 @@ extern "C" int fastp_gpu_counters_import(fastp_gpu_ctx* ctx, const int64_t* src_
     return FASTP_GPU_OK;
 }
 
+// Bring the HIP runtime up on `device` (context creation, the library's code object) without creating an engine: a
+// host program calls it from a helper thread as early as it knows a GPU run is coming, so that the ~0.2 s this takes
+// overlap its own start-up (option parsing, the Evaluator pre-pass) instead of preceding the first batch.
+extern "C" int fastp_gpu_warmup(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(nullptr, FASTP_GPU_E_NO_DEVICE, "no such HIP device");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FASTP_GPU_E_HIP, "hipSetDevice failed");
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return fail(nullptr, FASTP_GPU_E_HIP, "hipMalloc failed");
+    (void)hipFuncSetAttribute((const void*)fq_reduce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 0);   // looks the kernel up: loads the code object
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return FASTP_GPU_OK;
+}
+
 extern "C" int fastp_gpu_device(const fastp_gpu_ctx* ctx) { return ctx ? ctx->device : -1; }
 extern "C" int fastp_gpu_plan(const fastp_gpu_ctx* ctx) {
     if (!ctx) return -1;

@@ -536,7 +536,7 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     s->cfg.format.umi_delimiter = s->umi_delim.c_str();
     s->cfg.in1 = s->in1.c_str();
     s->cfg.in2 = s->paired ? s->in2.c_str() : nullptr;
-    s->chunk = cfg->chunk_bytes > 0 ? cfg->chunk_bytes : (int64_t)env_int("FASTP_GPU_STREAM_CHUNK_MB", 32) << 20;
+    s->chunk = cfg->chunk_bytes > 0 ? cfg->chunk_bytes : (int64_t)env_int("FASTP_GPU_STREAM_CHUNK_MB", 16) << 20;
     if (cfg->chunk_bytes <= 0 && getenv("FASTP_GPU_STREAM_CHUNK_BYTES")) s->chunk = atoll(getenv("FASTP_GPU_STREAM_CHUNK_BYTES"));   // tests: many small trips
     s->chunk = std::max<int64_t>(4096, std::min<int64_t>(s->chunk, (int64_t)1 << 30)) / 256 * 256;
     if (s->cfg.io_threads <= 0) s->cfg.io_threads = env_int("FASTP_GPU_STREAM_IO_THREADS", 8);
@@ -673,8 +673,12 @@ void writer_main(Run* R) {
             const uint8_t* src = j.oslot >= 2 ? BGZF_EOF : s->pin_out[j.oslot][q];   // oslot 2: the end-of-file members of the compressed streams
             if (j.oslot >= 2 && !j.len[q]) continue;
             if (s->cfg.out_fd[q] >= 0) {
-                for (int64_t a = 0; a < j.len[q]; a += IO_PIECE) {
-                    const int64_t e = std::min(j.len[q], a + IO_PIECE);
+                // one positional write per stream and chunk, the streams side by side: on tmpfs eight writers into one file
+                // were slower than one (7.8 vs 10 GB/s, profiles/r04_dropin.txt); FASTP_GPU_STREAM_WRITE_PIECE_MB cuts them up
+                static const int64_t piece = (int64_t)env_int("FASTP_GPU_STREAM_WRITE_PIECE_MB", 0) << 20;
+                const int64_t step = piece > 0 ? piece : std::max<int64_t>(j.len[q], 1);
+                for (int64_t a = 0; a < j.len[q]; a += step) {
+                    const int64_t e = std::min(j.len[q], a + step);
                     const int fd = s->cfg.out_fd[q];
                     const int64_t off = R->out_pos[q] + a;
                     std::atomic<int>* err = &R->io_err;

@@ -25,7 +25,7 @@ EXPORTS = [
     "fastp_gpu_device", "fastp_gpu_reset", "fastp_gpu_plan",
     "fastp_gpu_host_alloc", "fastp_gpu_host_free", "fastp_gpu_submit_host_async", "fastp_gpu_wait", "fastp_gpu_poll",
     "fastp_gpu_comm_id", "fastp_gpu_comm_init", "fastp_gpu_comm_init_local", "fastp_gpu_comm_destroy", "fastp_gpu_allreduce",
-    "fastp_gpu_exchange_dup_prefix", "fastp_gpu_comm_last_error", "fastp_gpu_dup_bitmap_import",
+    "fastp_gpu_exchange_dup_prefix", "fastp_gpu_comm_last_error", "fastp_gpu_dup_bitmap_import", "fastp_gpu_warmup",
     # include/fastp_gpu_host.h
     "fastp_gpu_host_create", "fastp_gpu_host_destroy", "fastp_gpu_host_apply", "fastp_gpu_host_output", "fastp_gpu_host_clear_outputs",
     "fastp_gpu_host_adapter_entries", "fastp_gpu_host_adapter_entry", "fastp_gpu_host_add_adapter", "fastp_gpu_host_add_adapter_pair",

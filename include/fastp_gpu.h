@@ -637,6 +637,11 @@ int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fa
 int fastp_gpu_wait(fastp_gpu_ctx* ctx, int slot);   /* blocks; FASTP_GPU_OK, or the error of the batch (list overflow) */
 int fastp_gpu_poll(fastp_gpu_ctx* ctx, int slot);   /* 1 = arrived (slot free), 0 = still running, < 0 = error */
 
+/* Bring the HIP runtime up on `device` (context, this library's code object) ahead of fastp_gpu_create - for a helper
+ * thread started as soon as the host program knows a GPU run is coming, so that the runtime's start-up overlaps its own
+ * (reference: nothing - the cost has no CPU counterpart). */
+int fastp_gpu_warmup(int device);
+
 /* HIP device ordinal the context lives on */
 int fastp_gpu_device(const fastp_gpu_ctx* ctx);
 

@@ -46,7 +46,7 @@ typedef int (*fastp_gpu_stream_emit_fn)(void* user, int stream, const char* data
 typedef struct fastp_gpu_stream_config {
     const char* in1;            /* plain FASTQ file (a regular file: it is read with pread)               */
     const char* in2;            /* second file of a paired run, NULL for single-end                        */
-    int64_t chunk_bytes;        /* text per file and trip; 0 = 32 MiB (FASTP_GPU_STREAM_CHUNK_MB)          */
+    int64_t chunk_bytes;        /* text per file and trip; 0 = 16 MiB (FASTP_GPU_STREAM_CHUNK_MB)          */
     int32_t io_threads;         /* positional reads / writes in flight; 0 = 8 (FASTP_GPU_STREAM_IO_THREADS) */
     int32_t device;             /* HIP device ordinal                                                      */
     int64_t reads_to_process;   /* --reads_to_process (src/peprocessor.cpp:775-778): 0 = all               */

@@ -30,7 +30,7 @@ for f in "$REF"/src/*.cpp; do
     b=$(basename "$f" .cpp)
     [ "$b" = simd ] && continue
     src=$f
-    { [ "$b" = peprocessor ] || [ "$b" = seprocessor ] || [ "$b" = evaluator ] || [ "$b" = fastqreader ]; } && src=$GEN/$b.cpp
+    { [ "$b" = peprocessor ] || [ "$b" = seprocessor ] || [ "$b" = evaluator ] || [ "$b" = fastqreader ] || [ "$b" = duplicate ]; } && src=$GEN/$b.cpp
     o=$OBJ/$b.o
     if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$HERE/patches/gpu_worker.h" -nt "$o" ]; then
         $CXX $CXXFLAGS -c "$src" -o "$o" &

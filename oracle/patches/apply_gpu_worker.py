@@ -69,4 +69,8 @@ patch("fastqreader.cpp", [
     (r"[ \t]*while\(end < mBufDataLen\) \{\s*if\(mFastqBuf\[end\] != '\\r' && mFastqBuf\[end\] != '\\n'\)\s*end\+\+;",
      "\tend = fastp_gpu_reader_scan_eol(mFastqBuf, end, mBufDataLen);   // memchr instead of one character at a time (FASTP_GPU=1)\n", "before_each"),
 ])
-print("patched peprocessor.cpp, seprocessor.cpp, evaluator.cpp, fastqreader.cpp ->", out)
+patch("duplicate.cpp", [
+    (r"[ \t]*mBufLenInBits = mBufLenInBytes << 3;",
+     "    mBufLenInBytes = fastp_gpu_worker_dup_bytes(mBufLenInBytes);   // FASTP_GPU=1: Duplicate's bitmaps live in HBM, a token buffer here\n", "before"),
+])
+print("patched duplicate.cpp, peprocessor.cpp, seprocessor.cpp, evaluator.cpp, fastqreader.cpp ->", out)

@@ -135,6 +135,12 @@ bool enabled() {
     return e != 0;
 }
 
+// the HIP runtime comes up on a helper thread from the moment the binary is loaded: it overlaps main()'s option parsing
+// and the Evaluator pre-pass instead of preceding the first chunk (fastp_gpu_warmup)
+struct WarmUp {
+    WarmUp() { if (enabled()) std::thread([] { (void)fastp_gpu_warmup(0); }).detach(); }
+} g_warm_up;
+
 void refuse(const char* what) { error_exit(std::string("FASTP_GPU=1: ") + what + " is outside the engine's scope"); }
 
 // Options (already validated, Evaluator results applied) -> the engine's flat parameter block
@@ -1014,6 +1020,10 @@ int fastp_gpu_worker_overrep(const std::string& filename, std::map<std::string, 
 // fastp_gpu_eval_adapter_kmers: the reads are the ones the reference's own loading loop admitted (:326-341), the
 // top-10 selection and the NucleotideTree walks that follow stay the reference's.  1 = counts filled, -1 = not handled
 // (engine disabled, or a letter outside ACGTN: the reference's loop counts then).
+// Duplicate::Duplicate (duplicate.cpp:46-52): with the engine on, Duplicate's bitmaps live in HBM and the reference's own
+// checkPair / checkRead are never called - a token buffer instead of 1 .. 32 GiB allocated and cleared on the host
+long fastp_gpu_worker_dup_bytes(long bytes) { return enabled() ? 64 : bytes; }
+
 int fastp_gpu_reader_scan_eol(const char* buf, int from, int to) {
     if (!enabled() || from >= to) return from;
     const char* p = buf + from;

@@ -65,4 +65,8 @@ int fastp_gpu_worker_adapter_kmers(Evaluator* ev, Read** reads, long records, in
 // found with memchr; the loop behind it then has nothing left to do.  FASTP_GPU off: returns `from`, the loop runs.
 int fastp_gpu_reader_scan_eol(const char* buf, int from, int to);
 
+// Duplicate::Duplicate (src/duplicate.cpp:46-52): the size of the bitmap the reference allocates and clears on the host.  With
+// the engine on, Duplicate's bits live in HBM and the reference's own checkPair / checkRead never run: a token size then.
+long fastp_gpu_worker_dup_bytes(long bytes);
+
 #endif

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=4_000_000)
 ap.add_argument("--big", type=int, default=0, help="a second, larger sample for the stream mode (start-up amortised)")
 ap.add_argument("--ref-threads", default="1,16")
+ap.add_argument("--quick", action="store_true", help="stream mode only (default settings, the string hand-off, more write pieces)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 REF = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
@@ -103,6 +104,10 @@ cfgs = [("stream", 16, {}), ("stream", 4, {}),
         ("stream io16", 16, {"FASTP_GPU_STREAM_IO_THREADS": "16"}),
         ("stream input", 16, {"FASTP_GPU_WRITER": "input"}),
         ("pack", 16, {"FASTP_GPU_STREAM": "0"})]
+if args.quick:
+    cfgs = [("stream", 16, {}), ("stream c32", 16, {"FASTP_GPU_STREAM_CHUNK_MB": "32"}), ("stream wp8", 16, {"FASTP_GPU_STREAM_WRITE_PIECE_MB": "8"}),
+            ("stream input", 16, {"FASTP_GPU_WRITER": "input"})]
 block(args.pairs, [int(x) for x in args.ref_threads.split(",")], cfgs)
 if args.big:
-    block(args.big, [1, 16], [("stream", 16, {}), ("stream c64", 16, {"FASTP_GPU_STREAM_CHUNK_MB": "64"}), ("stream input", 16, {"FASTP_GPU_WRITER": "input"})])
+    block(args.big, [1, 16], [("stream", 16, {}), ("stream c32", 16, {"FASTP_GPU_STREAM_CHUNK_MB": "32"}), ("stream wp8", 16, {"FASTP_GPU_STREAM_WRITE_PIECE_MB": "8"}),
+                              ("stream input", 16, {"FASTP_GPU_WRITER": "input"})])
