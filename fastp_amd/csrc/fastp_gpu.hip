@@ -47,8 +47,13 @@ extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a)
 #endif
 // (reads of up to 256 bases, SWM = 16: the row stage alone is 16 KB per wavefront, two workgroups fit a CU whatever the
 // register count - compiled for two wavefronts per SIMD, no spills)
+// One workgroup per CU that owns the whole LDS: the tables every wavefront reads (hash planes, counters, LUTs: 12 KB) are then
+// held once per CU instead of once per 256-lane workgroup, which is what makes room for twelve wavefronts' row stages PLUS
+// read 1's partial quality sums (three 256-lane workgroups of 51 KB fitted, of 56 KB they do not: two per CU, a third of
+// the wavefronts gone - profiles/r04_lane_metrics_ab.txt).  FQ_LANE_WAVES wavefronts per SIMD: 168 VGPRs.
+template <int SWM> struct LaneGeom { enum { MAX_THREADS = SWM > 10 ? 512 : 256 * FQ_LANE_WAVES }; };
 template <int SWM, int B, int NPL, bool PAIRED, bool EXT>
-__global__ void __launch_bounds__(256, SWM > 10 ? 2 : FQ_LANE_WAVES) fq_lane_kernel(LaneArgs a) {
+__global__ void __launch_bounds__(LaneGeom<SWM>::MAX_THREADS, 1) fq_lane_kernel(LaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     lane_body<SWM, B, NPL, PAIRED, EXT>(*kernel_args(&a), fq_lds);
 }
@@ -182,7 +187,7 @@ struct fastp_gpu_ctx {
     u32* d_st_slabs = nullptr;
     // lane plan (fq_lane.h): one lane per pair, reads in registers - the option family lane_plan_supported() admits
     bool lane = false;
-    int ln_swm = 0, ln_blocks = 0;
+    int ln_swm = 0, ln_blocks = 0, ln_threads = 256;
     LaneLds ln_lds;
     u32* d_ln_slabs = nullptr;
     int* d_ln_ctr = nullptr;       // the lane kernel's chunk counter
@@ -499,10 +504,17 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             o = (o + 3) & ~3;
             l.stage = o;
             l.stage_dwords = (64 * std::max(ctx->dp.qw_g, ctx->dp.sw_g) + 4 * ctx->ln_swm + 3) & ~3;   // + the over-read of the last row
-            o += 4 * l.stage_dwords;   // 256-lane workgroups: four wavefronts
+            l.part_dwords = ctx->dp.paired ? (ctx->ln_swm / 2) * 64 : 0;   // read 1 of a pair: [ln_swm / 2 words][64 lanes]
+            // as many wavefronts per workgroup as the LDS holds (up to three per SIMD for reads <= 160 bases, two above)
+            const int max_waves = (ctx->ln_swm > 10 ? 512 : 256 * FQ_LANE_WAVES) / 64;
+            int waves = (int)(((long long)prop.sharedMemPerBlock / 4 - o) / (l.stage_dwords + l.part_dwords));
+            waves = std::max(1, std::min(waves, max_waves));
+            const int env_threads = env_int("FASTP_GPU_LANE_THREADS", 0);   // A/B: 256 = round 3's geometry (several workgroups per CU)
+            if (env_threads >= 64 && env_threads <= max_waves * 64) waves = env_threads / 64;
+            ctx->ln_threads = waves * 64;
+            o += waves * l.stage_dwords;
             l.part = o;
-            l.part_dwords = ctx->ln_swm * 64;   // [2 mates][ln_swm / 2 words][64 lanes]
-            o += 4 * l.part_dwords;
+            o += waves * l.part_dwords;
             l.total = o;
             int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);
 #ifndef FQ_HOSTSIM
@@ -510,7 +522,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
                 int nb = 0;
                 lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0, lane_ext(ctx->dp));
                 (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, l.total * 4);
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, (size_t)l.total * 4) == hipSuccess && nb > 0) per_cu = nb;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, ctx->ln_threads, (size_t)l.total * 4) == hipSuccess && nb > 0) per_cu = nb;
                 (void)hipGetLastError();
             }
 #endif
@@ -534,6 +546,10 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel %d x %d threads, LDS %d bytes\n",
                 ctx->lane ? "lane plan" : (ctx->split ? "split plan" : "fused plan"), ctx->L.P, ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks,
                 ctx->max_pairs_per_launch, ctx->st_blocks, ctx->st_threads, ctx->st_lds_dwords * 4);
+    if (env_int("FASTP_GPU_VERBOSE", 0) && ctx->lane)
+        fprintf(stderr, "fastp_gpu: lane kernel %d x %d threads (%d per CU), LDS %d bytes per workgroup (stage %d + read-1 sums %d per wavefront), SWM %d, ext %d\n",
+                ctx->ln_blocks, ctx->ln_threads, ctx->ln_blocks / std::max(1, ctx->cus), ctx->ln_lds.total * 4, ctx->ln_lds.stage_dwords * 4,
+                ctx->ln_lds.part_dwords * 4, ctx->ln_swm, (int)lane_ext(ctx->dp));
     ctx->slab_dwords = ctx->L.acc_end - ctx->L.acc_cyc;
 
     *out = ctx;  // from here on errors go through destroy
@@ -1063,7 +1079,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
             lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp));
             ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
-            hipLaunchKernelGGL(fn, dim3(ln_grid), dim3(256), (size_t)ctx->ln_lds.total * 4, st, la);
+            hipLaunchKernelGGL(fn, dim3(ln_grid), dim3(ctx->ln_threads), (size_t)ctx->ln_lds.total * 4, st, la);
         } else if (ctx->split && ctx->cfg.threads > 256) hipLaunchKernelGGL(fq_scan_wide_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
         else if (ctx->split) hipLaunchKernelGGL(fq_scan_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
         else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);

@@ -23,8 +23,8 @@
 #ifndef FQ_LANE_STAGE_BATCH
 #define FQ_LANE_STAGE_BATCH 10
 #endif
-#ifndef FQ_LANE_METRICS      // A/B switch: 2 = partial sums from the load sweep + the one cut word (default), 0 = round 3's second staging of the
-#define FQ_LANE_METRICS 2    // quality rows with every dword masked by the window
+#ifndef FQ_LANE_METRICS      // A/B switch: 2 = read 1 from the load sweep's partial sums + the one cut word, the last-staged read straight from the
+#define FQ_LANE_METRICS 2    // stage (default); 0 = round 3's second staging of the quality rows with every dword masked by the window
 #endif
 #ifdef FQ_LANE_NO_FENCE      // A/B switch (tools/gpu_lane_ab3.sh)
 #define FQ_LANE_FENCE() ((void)0)
@@ -46,8 +46,8 @@ struct LaneLds {
     int n_planes;
     int stage;      // per wavefront: 64 rows of one mate's quality (then base) rows, copied from HBM with coalesced 16-byte
     int stage_dwords;   // loads and read back one row per lane (16-byte aligned, 64 * qw_g dwords each)
-    int part;       // per wavefront: countQualityMetrics' per-32-base partial sums [mate][word][lane] (lane-contiguous: conflict-free;
-    int part_dwords;    // registers would not hold them - ten more live VGPRs spill 270 dwords at the cap of 168)
+    int part;       // per wavefront: countQualityMetrics' per-32-base partial sums of READ 1 of a pair [word][lane] (lane-contiguous:
+    int part_dwords;    // conflict-free; registers do not hold them - ten more live VGPRs spilled 270 dwords at the cap of 168)
     int total;
 };
 
@@ -278,7 +278,7 @@ FQ_DEV u32 lane_window_word(const u32 (&q)[10], u32 keep_lo, u32 keep_hi, u32 nt
 // Load read `g` of one mate: bases, N mask, and in ONE sweep over the quality row the window predicate of cut_right /
 // cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.  `stage` = this
 // wavefront's LDS buffer, chunk0 = first unit of its chunk, rows = units the chunk has.
-template <int SWM>
+template <int SWM, bool KEEP>   // KEEP: leave countQualityMetrics' per-word sums in `part` (read 1 of a pair: its rows leave the stage)
 FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32* seq, const u32* qual, const u16* lenp, int chunk0, int rows, int lane,
                            bool valid, int win, int thr, u32 thr4, LaneRead<SWM>& r) {
     const DevParams& p = a.p;
@@ -329,18 +329,15 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32
         for (int d = 7; d >= 0; d--) {
             const u32 b1 = (q[d] >> 7) & 0x01010101u;   // bits 0, 8, 16, 24
             nw = dot4_u8(b1, 0x08040201u, nw << 4);     // the four flags as a nibble behind the ones gathered so far
-#if FQ_LANE_METRICS == 2
-            ts = sum_bytes(q[d] & 0x7F7F7F7Fu, ts);
-            gs += (u32)popc32(((q[d] | 0x80808080u) - thr4) & 0x80808080u);
-#endif
+            if (KEEP && FQ_LANE_METRICS == 2) {
+                ts = sum_bytes(q[d] & 0x7F7F7F7Fu, ts);
+                gs += (u32)popc32(((q[d] | 0x80808080u) - thr4) & 0x80808080u);
+            }
         }
         r.n[W] = nw;
         anyn |= nw;
-#if FQ_LANE_METRICS == 2
-        part[W * 64 + lane] = ts | (gs << 16);   // sum of the quality characters | bases at or above the qualified quality << 16
-#else
-        (void)ts; (void)gs; (void)part; (void)thr4;
-#endif
+        if (KEEP && FQ_LANE_METRICS == 2) part[W * 64 + lane] = ts | (gs << 16);   // sum of the quality characters | bases at or above the qualified quality << 16
+        else { (void)ts; (void)gs; (void)part; (void)thr4; }
         // ---- window predicate (bad_window_word of the tile kernel, windows of up to 8 bases) ----
         u32 m = 0;
         if (win == 4) m = lane_window_word4(q, nthr4);                             // uniform
@@ -530,12 +527,55 @@ FQ_DEV int lane_verify(const u32 (&X)[SWM], const u32 (&XN)[SWM / 2], const u32 
 
 // ---------------------------------------------------------------------------
 // fastp_simd::countQualityMetrics (simd.cpp:54-119) of [0, len): total (qual - 33), bases below the qualified quality, N.
-// The 32-base words the final window covers whole come from the partial sums the load sweep left in registers; only the
-// ONE word the window's end cuts is looked at again - its 32 quality bytes straight from the lane's row (an L2 hit: the
-// row was staged moments ago), both mates' loads in flight together.  (Round 3 staged every quality row a second time
-// through LDS and masked all 38 dwords by the window: two more round trips per chunk and 32 instructions per dword.)
+// Round 3 staged every quality row a second time through LDS and masked all 38 dwords by the window (two more round trips
+// per chunk, 32 instructions per dword).  Now nothing is staged again:
+//   * the read staged LAST (read 2 of a pair, the read of a single-end run) still has its quality rows in the wavefront's
+//     stage when the final window is known: a dword wholly inside the window is summed as it is and committed by one
+//     select, the one dword the window's end cuts is read by its index and masked (9 instructions per dword);
+//   * read 1 of a pair (its rows are gone by then) gets the 32-base words its window covers whole from the partial sums
+//     the load sweep left in LDS, and the ONE word the window's end cuts from its row in memory (32 bytes per lane, an
+//     L2 hit: the row was staged moments ago).
 // The N count comes from the N mask in registers.
 // ---------------------------------------------------------------------------
+template <int SWM>
+FQ_DEV int lane_count_n(const LaneRead<SWM>& r, int len) {
+    u32 n = 0;
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) {
+        const int left = len - 32 * w;
+        n += (u32)popc32(left >= 32 ? r.n[w] : (left <= 0 ? 0u : (r.n[w] & lowmask32(left))));
+    }
+    return (int)n;
+}
+// the read whose quality rows are still in the stage (row = this lane's row there)
+template <int SWM>
+FQ_DEV void lane_metrics_stage(const KernelArgs& a, const u32* row, const LaneRead<SWM>& r, int len, int& tot, int& low, int& nb) {
+    const int qwg = a.p.qw_g;
+    const u64* qrow = (const u64*)row;
+    const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
+    const int full = len >> 2, part = len & 3;
+    const u32 cutmask = lowmask32(8 * part);   // 0 when the window ends on a dword boundary
+    const u32 qb = row[imin(full, qwg - 1)] & 0x7F7F7F7Fu & cutmask;
+    u32 t = sum_bytes(qb, 0u);
+    u32 ge = (u32)popc32(((qb | 0x80808080u) - thr4) & 0x80808080u & cutmask);
+#pragma unroll
+    for (int c = 0; c < 4 * SWM; c += 2) {
+        const u64 v = qrow[c >> 1];   // (dwords behind the row's stride are never inside the window)
+#pragma unroll
+        for (int hlf = 0; hlf < 2; hlf++) {
+            const u32 q7 = (hlf ? (u32)(v >> 32) : (u32)v) & 0x7F7F7F7Fu;
+            const bool in = c + hlf < full;
+            const u32 t2 = sum_bytes(q7, t);
+            const u32 g2 = ge + (u32)popc32(((q7 | 0x80808080u) - thr4) & 0x80808080u);
+            t = in ? t2 : t;
+            ge = in ? g2 : ge;
+        }
+    }
+    tot = (int)t - 33 * len;
+    low = len - (int)ge;
+    nb = lane_count_n<SWM>(r, len);
+}
+// read 1 of a pair: partial sums + the cut word
 struct LaneCutWord {
     u64 v[4];   // the 32 quality bytes of the word the window's end cuts
 };
@@ -547,8 +587,8 @@ FQ_DEV void lane_cut_fetch(const KernelArgs& a, const u32* qual, int g, bool val
     for (int k = 0; k < 4; k++) cw.v[k] = valid ? row[imin(w8 + k, (qwg >> 1) - 1)] : 0ull;   // (a u64 behind the row is never inside the window)
 }
 template <int SWM>
-FQ_DEV void lane_metrics(const KernelArgs& a, const LaneRead<SWM>& r, const u32* part, int lane, const LaneCutWord& cw, int len, int& tot, int& low,
-                         int& nb) {
+FQ_DEV void lane_metrics_part(const KernelArgs& a, const LaneRead<SWM>& r, const u32* part, int lane, const LaneCutWord& cw, int len, int& tot,
+                              int& low, int& nb) {
     const u32 thr4 = (u32)a.p.qual_thr * 0x01010101u;
     const int wfull = len >> 5, rem = len & 31;
     u32 acc = 0;   // sum | count << 16, as the partial sums
@@ -568,15 +608,9 @@ FQ_DEV void lane_metrics(const KernelArgs& a, const LaneRead<SWM>& r, const u32*
         t = sum_bytes(q7, t);
         ge += (u32)popc32(((q7 | 0x80808080u) - thr4) & 0x80808080u & M);
     }
-    u32 n = 0;
-#pragma unroll
-    for (int w = 0; w < SWM / 2; w++) {
-        const int left = len - 32 * w;
-        n += (u32)popc32(left >= 32 ? r.n[w] : (left <= 0 ? 0u : (r.n[w] & lowmask32(left))));
-    }
     tot = (int)((acc & 0xFFFFu) + t) - 33 * len;
     low = len - (int)((acc >> 16) + ge);
-    nb = (int)n;
+    nb = lane_count_n<SWM>(r, len);
 }
 
 // ---------------------------------------------------------------------------
@@ -941,11 +975,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         const int g = valid ? gp : 0;
         LaneRead<SWM> r1, r2;
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
-        lane_load_read<SWM>(a, stage, part, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, thr4, r1);
+        lane_load_read<SWM, PAIRED>(a, stage, part, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, thr4, r1);
         if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
         if (PAIRED) {
-            lane_load_read<SWM>(a, stage, part + (SWM / 2) * 64, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, thr4, r2);
+            lane_load_read<SWM, false>(a, stage, part, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, thr4, r2);
             if (valid && !lane_trim_and_cut<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
             sched_fence();
         }
@@ -1135,11 +1169,15 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         }
 #else
         if (!(skip & 8u)) {
-            LaneCutWord c1, c2;
-            lane_cut_fetch(a, a.qual[0], g, a1, r1.len, c1);
-            if (PAIRED) lane_cut_fetch(a, a.qual[1], g, a2, r2.len, c2);
-            lane_metrics<SWM>(a, r1, part, lane, c1, r1.len, tot1, low1, nb1);
-            if (PAIRED) lane_metrics<SWM>(a, r2, part + (SWM / 2) * 64, lane, c2, r2.len, tot2, low2, nb2);
+            const u32* row = stage + lane * p.qw_g;   // the quality row of the read that was staged last
+            if (PAIRED) {
+                LaneCutWord c1;
+                lane_cut_fetch(a, a.qual[0], g, a1, r1.len, c1);
+                lane_metrics_stage<SWM>(a, row, r2, r2.len, tot2, low2, nb2);      // (read 1's cut word is on its way meanwhile)
+                lane_metrics_part<SWM>(a, r1, part, lane, c1, r1.len, tot1, low1, nb1);
+            } else {
+                lane_metrics_stage<SWM>(a, row, r1, r1.len, tot1, low1, nb1);
+            }
         }
 #endif
         int dif1 = 0, dif2 = 0;

@@ -861,11 +861,10 @@ def test_gpu_file_pipeline_all_streams_and_gzip_outputs(name, tmp_path):
 def test_gpu_missing_library_fails_loudly(tmp_path):
     with pytest.raises(FileNotFoundError):
         engine.load_library(str(tmp_path / "nope.so"))
-@pytest.mark.gpu
-def test_gpu_equals_oracle_at_scale_config1_single_end():
-    """BASELINE configs[1] (SE 1x150, sliding-window quality trim + polyG only: `-A -g --cut_right`) on 2 Mi synthetic
-    reads against the ORACLE: every record, every counter, every duplicate decision (chunked oracle for the per-read
-    part, oraclelib.sequential_duplicates for the stream-ordered part - the harness of the configs[2] test)."""
+def _se_scale_against_oracle(p, expect_plan, check):
+    """2 Mi synthetic single-end reads against the ORACLE: every record, every counter, every duplicate decision (chunked
+    oracle for the per-read part, oraclelib.sequential_duplicates for the stream-ordered part - the harness of the
+    configs[2] test)."""
     import sys
     from concurrent.futures import ThreadPoolExecutor
     import torch
@@ -873,11 +872,6 @@ def test_gpu_equals_oracle_at_scale_config1_single_end():
     import synth_torch
     total = int(os.environ.get("FASTP_SCALE_READS", str(2 * 1024 * 1024)))
     chunk = 256 * 1024
-    p = abi.default_params(False, 150)
-    p.adapter_seq_r1 = None
-    p.adapter_enabled = 0
-    p.poly_g = 1
-    p.cut_right = 1
     dev = torch.device("cuda", 0)
     g = engines.gpu_engine(p)
     parts, recs = [], []
@@ -900,7 +894,7 @@ def test_gpu_equals_oracle_at_scale_config1_single_end():
         pad = lambda a: np.pad(a.cpu().numpy(), ((0, 0), (0, 2)))
         parts.append({"seq1": pad(d["seq1"]), "qual1": pad(d["qual1"]), "len1": d["len1"].cpu().numpy().astype(np.int32)})
         del d, s1, q1, l1
-    assert g.plan() == "lane"
+    assert g.plan() == expect_plan
     cg = g.counters()
     lay = g.layout
     g.close()
@@ -927,10 +921,40 @@ def test_gpu_equals_oracle_at_scale_config1_single_end():
     ro["flags"] = (ro["flags"] & ~np.uint8(abi.RF_DUP)) | np.where(dup, abi.RF_DUP, 0).astype(np.uint8)
     bad = np.nonzero(ro != rg)[0]
     assert len(bad) == 0, f"records differ at {len(bad)} of {total}, first {bad[:5]}: oracle {ro[bad[:3]]} gpu {rg[bad[:3]]}"
-    assert int((rg["flags"] & abi.RF_POLYX).sum()) == 0 and int((ro["len"] < full["len1"]).sum()) > total // 10   # the trims do happen
+    check(rg, ro, full, total)
     co[lay.dup_count] = int(dup.sum())
     bad = np.nonzero(co != cg)[0]
     assert len(bad) == 0, f"{len(bad)} counters differ, first at {bad[:8]}: oracle {co[bad[:8]]} gpu {cg[bad[:8]]}"
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_at_scale_config1_single_end():
+    """BASELINE configs[1] (SE 1x150, sliding-window quality trim + polyG only: `-A -g --cut_right`)"""
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.poly_g = 1
+    p.cut_right = 1
+
+    def check(rg, ro, full, total):
+        assert int((rg["flags"] & abi.RF_POLYX).sum()) == 0 and int((ro["len"] < full["len1"]).sum()) > total // 10   # the trims do happen
+    _se_scale_against_oracle(p, "lane", check)
+
+
+@pytest.mark.gpu
+def test_gpu_equals_oracle_at_scale_single_end_default_adapter_by_sequence():
+    """fastp's DEFAULT single-end run as the Evaluator leaves it: the detected adapter trimmed by sequence
+    (AdapterTrimmer::trimBySequence, seprocessor.cpp:240-252) - on the lane plan since round 4 - plus polyX trimming and the
+    complexity filter, which ride in the same kernel instantiation"""
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+    p.poly_x = 1
+    p.complexity_filter = 1
+
+    def check(rg, ro, full, total):
+        assert int((rg["flags"] & abi.RF_ADAPTER).sum()) > total // 20        # the adapter is found in a good share of the reads
+        assert int((rg["adapter_pos"] < 0).sum()) >= 0
+    _se_scale_against_oracle(p, "lane", check)
 
 
 @pytest.mark.gpu
