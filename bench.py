@@ -119,7 +119,7 @@ def cpu_baseline(sample_pairs, flags, params, dev, files=None):
             "sample": f"{sample_pairs} synthetic 2x{L} pairs through the plain-C oracle (per-read loop only, 1 thread)"}
 
 
-def e2e_legs(sample_pairs, flags, params, files, cpu_value):
+def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False):
     """the same files end to end through the GPU path, two ways (never the headline `value`):
     e2e_gpu    : fastp_amd.pipeline - raw text to HBM, parse / worker loop / format on the device, text back, file I/O
     e2e_dropin : the real reference with its worker loops bound to the engine (oracle/_ref/fastp_ref_gpu, FASTP_GPU=1)
@@ -127,6 +127,8 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value):
     out = {}
     tmp, f1, f2 = files
     try:
+        if dropin_only:
+            raise StopIteration
         from fastp_amd import pipeline
         pl = pipeline.FastqPipeline(params, chunk_bytes=256 << 20)
         best = None
@@ -138,6 +140,8 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value):
         pl.close()
         out["e2e_gpu"] = {"value": round(2 * sample_pairs / best / 1e6, 3), "unit": "Mreads/s",
                           "what": "fastp_amd.pipeline FASTQ -> FASTQ on tmpfs, parse + worker loop + format on the device, best of 2"}
+    except StopIteration:
+        pass
     except Exception as e:   # the kernel line must not depend on the file pipeline
         out["e2e_gpu"] = {"value": None, "error": repr(e)[:200]}
     refgpu = os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpu")
@@ -596,6 +600,26 @@ def main():
             if files is not None:
                 import shutil
                 shutil.rmtree(files[0], ignore_errors=True)
+            # the same leg on a sample three times the size: a run's start-up (process, HIP runtime, engine, page-locked buffers:
+            # startup_s above) is most of a 4 M-pair run's wall clock, so the larger sample shows the rate a real file sees
+            if files is not None and not args.no_extras and "e2e_dropin" in out and out["e2e_dropin"].get("gpu"):
+                big = None
+                try:
+                    big = write_sample_files(3 * args.cpu_sample, dev)
+                    ref = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
+                    t0 = time.time()
+                    subprocess.run([ref, "-i", big[1], "-I", big[2], "-o", os.path.join(big[0], "o1.fq"), "-O", os.path.join(big[0], "o2.fq"), "-j",
+                                    os.path.join(big[0], "o.json"), "-h", os.path.join(big[0], "o.html"), "-w", str(host_cores())] + ref_flags,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900)
+                    cpu_big = round(2 * 3 * args.cpu_sample / (time.time() - t0) / 1e6, 4)
+                    leg = e2e_legs(3 * args.cpu_sample, ref_flags, params, big, cpu_big, dropin_only=True)
+                    out["e2e_dropin_large"] = dict(leg.get("e2e_dropin", {}), pairs=3 * args.cpu_sample)
+                except Exception as e:   # never at the expense of the kernel line
+                    out["e2e_dropin_large"] = {"gpu": None, "error": repr(e)[:200]}
+                finally:
+                    if big is not None:
+                        import shutil
+                        shutil.rmtree(big[0], ignore_errors=True)
         if world == 1 and not args.no_extras:
             resident = None
             torch.cuda.empty_cache()

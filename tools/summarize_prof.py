@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 PAIRS = int(sys.argv[2]) if len(sys.argv) > 2 else 4194304   # pairs per launch of the profiled runs (bench.py --batches 2: 4 Mi)
 src = os.path.join(ROOT, "gpurun_out", "prof")
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("SUMMARIZE_DST") or os.path.join(ROOT, "profiles")   # (on the GPU box: a directory under gpurun_out/, which is what travels back)
 os.makedirs(dst, exist_ok=True)
 
 stats = list(csv.DictReader(open(os.path.join(src, tag, "trace_kernel_stats.csv"))))
@@ -27,7 +27,8 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
             r["Name"] = r["Name"][:117] + "..."
         w.writerow(r)
 
-trace = list(csv.DictReader(open(os.path.join(src, tag, "trace_kernel_trace.csv"))))
+tp = os.path.join(src, tag, "trace_kernel_trace.csv")
+trace = list(csv.DictReader(open(tp))) if os.path.exists(tp) else []
 geom = {}
 for r in trace:
     if (r["Kernel_Name"].startswith("fq_") or "fq_lane_kernel" in r["Kernel_Name"]) and r["Kernel_Name"] not in geom:
