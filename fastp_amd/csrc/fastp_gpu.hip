@@ -1402,11 +1402,18 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(fq_parse_finish_kernel, dim3(1), dim3(64), 0, st, p);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(fq_parse_pack_kernel, dim3((max_records + 15) / 16), dim3(256), 0, st, p);  // 4 records per wavefront
-    HIP_TRY(ctx, hipGetLastError());
     u32 totals[8];
+    // the record count comes back before the packer is launched: its grid then covers the records that exist, not the
+    // caller's capacity (a 16 MiB chunk of 150-base reads holds 50 K records of the 512 K it may hold)
     HIP_TRY(ctx, hipMemcpyAsync(totals, p.totals, sizeof(totals), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    const u32 nrec = totals[3];
+    if (nrec > 0) {
+        hipLaunchKernelGGL(fq_parse_pack_kernel, dim3((nrec + 15) / 16), dim3(256), 0, st, p);  // 4 records per wavefront
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(totals, p.totals, sizeof(totals), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
     info->n_records = (int32_t)totals[3];
     info->consumed = (int64_t)totals[4];
     info->n_lines = (int64_t)totals[2];

@@ -164,9 +164,8 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
 
 # on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
 # test_gpu_patched_reference_equals_reference; each costs seconds here because the emulator clears Duplicate's 1 GiB
-EMULATOR_CASES = ["pe_default", "pe_correction", "pe_merge", "pe_filters", "pe_noadapter_dedup", "pe_umi_per_read",
-                  "pe_adapter_fasta", "pe_overrep", "pe_allow_gap_indel", "pe_overlapped_out_trims", "pe_adapter_long",
-                  "se_adapter_cut", "se_overrep", "se_adapter_long_indel"]
+EMULATOR_CASES = ["pe_correction", "pe_filters", "pe_noadapter_dedup", "pe_umi_per_read", "pe_adapter_fasta", "pe_overrep", "pe_allow_gap_indel",
+                  "pe_overlapped_out_trims", "se_adapter_cut", "se_adapter_long_indel"]
 assert all(n in BINDING_CASES for n in EMULATOR_CASES)
 
 
@@ -182,7 +181,7 @@ def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
         assert m and int(m.group(1)) >= 2, err[-600:]    # several trips, so partial records were carried
 
 
-@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "pe_adapter_fasta", "pe_merge", "se_adapter_cut", "se_umi_read1"])
+@pytest.mark.parametrize("name", ["pe_correction", "pe_adapter_fasta", "pe_merge", "se_umi_read1"])
 def test_patched_reference_pack_mode_on_emulator(name, tmp_path):
     """pack mode: the reference's own reader threads, the hook at the top of the worker-loop body"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
@@ -190,8 +189,7 @@ def test_patched_reference_pack_mode_on_emulator(name, tmp_path):
     _check(name, REF_SIM, 600, tmp_path, seed=41, mode="pack")
 
 
-@pytest.mark.parametrize("name,threads,writer", [("pe_default", 3, "input"), ("pe_filters", 2, "input"), ("se_adapter_cut", 4, "input"),
-                                                 ("pe_merge_unmerged", 5, None)])
+@pytest.mark.parametrize("name,threads,writer", [("pe_filters", 2, "input"), ("se_adapter_cut", 4, "input"), ("pe_merge_unmerged", 5, None)])
 def test_patched_reference_stream_threads_and_writer_handoff(name, threads, writer, tmp_path):
     """the stream's result does not depend on -w; FASTP_GPU_WRITER=input hands the text to WriterThread::input (one string
     per chunk, the threads' lists in turn) instead of writing into the writers' file descriptors"""
@@ -200,8 +198,7 @@ def test_patched_reference_stream_threads_and_writer_handoff(name, threads, writ
     _check(name, REF_SIM, 900, tmp_path, seed=52, threads=threads, extra_env={"FASTP_GPU_WRITER": writer} if writer else None)
 
 
-@pytest.mark.parametrize("name,threads,writer", [("pe_default", 1, None), ("pe_default", 3, None), ("se_adapter_cut", 2, None),
-                                                 ("pe_filters", 3, "input")])
+@pytest.mark.parametrize("name,threads,writer", [("pe_default", 1, None), ("pe_default", 3, None), ("pe_filters", 3, "input")])
 def test_patched_reference_stream_gz_outputs(name, threads, writer, tmp_path):
     """".gz" outputs: gzip members made on the device (fastp_gpu_deflate_bgzf) written into the WriterThread's file - its
     pwrite mode with several threads, its Writer with one - and bgzip's end-of-file member; or (writer = input) text
@@ -212,8 +209,7 @@ def test_patched_reference_stream_gz_outputs(name, threads, writer, tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["stream", "pack"])
-@pytest.mark.parametrize("name,n,limit,threads", [("pe_default", 3000, 1500, 2), ("pe_default", 3000, 1000, 2), ("se_adapter_cut", 2500, 2000, 4),
-                                                  ("pe_cut_right", 2200, 700, 3)])
+@pytest.mark.parametrize("name,n,limit,threads", [("pe_default", 3000, 1500, 2), ("pe_default", 3000, 1000, 2), ("se_adapter_cut", 2500, 2000, 4)])
 def test_patched_reference_reads_to_process(name, n, limit, threads, mode, tmp_path):
     """--reads_to_process: the reader stops after N reads (a short pack followed by an empty one in pack mode,
     a record cap on the trips in stream mode)"""
@@ -223,7 +219,7 @@ def test_patched_reference_reads_to_process(name, n, limit, threads, mode, tmp_p
 
 
 @pytest.mark.parametrize("mode", ["stream", "pack"])
-@pytest.mark.parametrize("name,n,threads", [("pe_default", 3000, 4), ("se_default_noadapter", 3000, 4), ("pe_default", 2000, 3)])
+@pytest.mark.parametrize("name,n,threads", [("pe_default", 3000, 4), ("se_default_noadapter", 3000, 4)])
 def test_patched_reference_read_count_multiple_of_pack_size(name, n, threads, mode, tmp_path):
     """reads % 1000 == 0: the reader ends the stream with an EMPTY pack, which can be a worker's first pack"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
@@ -242,14 +238,14 @@ def _lengthen_late_reads(d):
         assert lens[1200:].max() > 100
 
 
-@pytest.mark.parametrize("name", ["pe_default", "se_adapter_cut", "pe_noadapter_dedup", "pe_overrep"])
+@pytest.mark.parametrize("name", ["se_adapter_cut", "pe_noadapter_dedup", "pe_overrep"])
 def test_patched_reference_stream_replans_for_longer_reads(name, tmp_path):
     """the first 1000 reads are at most 100 bases, later ones 150: the reference sizes its buffers from the first 1000 and
     grows them (Stats::extendBuffer); the stream re-plans - counters, Duplicate's bitmaps and the sampling positions of
     the overrepresentation analysis carried into a context with a larger max_len - and the report is the same"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    err = _check(name, REF_SIM, 2600 if "overrep" not in name else 11000, tmp_path, seed=56, mutate=_lengthen_late_reads)
+    err = _check(name, REF_SIM, 2600 if "overrep" not in name else 10200, tmp_path, seed=56, mutate=_lengthen_late_reads)
     import re
     m = re.search(r"max_len (\d+), (\d+) re-plan", err)
     assert m and int(m.group(2)) >= 1 and int(m.group(1)) >= 150, err[-600:]
@@ -300,7 +296,7 @@ def test_gpu_patched_reference_auto_adapter(tmp_path):
     _auto_adapter_check(REF_GPU, 60000, tmp_path)
 
 
-@pytest.mark.parametrize("name,threads,packs", [("pe_default", 3, 2), ("se_default_noadapter", 2, 1), ("pe_correction", 2, 3)])
+@pytest.mark.parametrize("name,threads,packs", [("pe_default", 3, 2), ("se_default_noadapter", 2, 1)])
 def test_patched_reference_pipelines_windows_of_packs(name, threads, packs, tmp_path):
     """several worker threads, windows of FASTP_GPU_PACKS packs, more windows than slots in flight: the binding packs
     the threads' packs into windows in STREAM order, so the outputs and the whole report equal `fastp_ref -w 1`
@@ -310,8 +306,8 @@ def test_patched_reference_pipelines_windows_of_packs(name, threads, packs, tmp_
     _check(name, REF_SIM, 9300, tmp_path, seed=43, threads=threads, extra_env={"FASTP_GPU_PACKS": str(packs)}, mode="pack")
 
 
-@pytest.mark.parametrize("mode", ["stream", "pack"])
-@pytest.mark.parametrize("eol,trailing", [(b"\r\n", True), (b"\r", True), (b"\n", False), (b"\r\n", False)])
+@pytest.mark.parametrize("eol,trailing,mode", [(b"\r\n", True, "stream"), (b"\r", True, "stream"), (b"\n", False, "stream"), (b"\r\n", False, "stream"),
+                                               (b"\r\n", True, "pack"), (b"\r", False, "pack")])
 def test_patched_reference_reader_hook_line_ends(eol, trailing, mode, tmp_path):
     """the memchr hook in front of FastqReader::getLine's scan (fastp_gpu_reader_scan_eol): the same records from \\r\\n, \\r
     and unterminated last lines as the reference's own character-by-character scan (whose binary runs without the hook)"""

@@ -14,8 +14,8 @@ import streamlib
 from fastp_amd import abi, engine
 
 STREAM_GOLDENS = [n for n in golden_util.names() if "overlapped_out" not in n]   # --overlapped_out's stream is the host glue's
-SIM_CASES = ["pe_default", "pe_correction", "pe_merge", "pe_merge_unmerged", "pe_filters", "pe_adapter_fasta", "pe_adapter_seq", "pe_umi_per_read",
-             "pe_overrep", "pe_noadapter_dedup", "se_adapter_cut", "se_adapter_fasta", "se_umi_read1", "testdata_pe"]
+SIM_CASES = ["pe_correction", "pe_merge_unmerged", "pe_filters", "pe_adapter_fasta", "pe_umi_per_read", "pe_overrep", "pe_noadapter_dedup",
+             "se_adapter_cut", "se_adapter_fasta", "testdata_pe"]
 
 
 def _files(tmp_path, fq1, fq2):
