@@ -620,7 +620,8 @@ struct Run {
 void reader_main(Run* R) {
     fastp_gpu_stream* s = R->s;
     (void)hipSetDevice(s->cfg.device);
-    IoPool pool(s->cfg.io_threads);
+    // reads scale with threads (page-cache copies into page-locked memory), writes do not (writer_main): twice the pool here
+    IoPool pool(env_int("FASTP_GPU_STREAM_READ_THREADS", 2 * s->cfg.io_threads));
     int64_t pos[2] = {0, 0};
     for (;;) {
         ReadReq rq = R->q_req.get();

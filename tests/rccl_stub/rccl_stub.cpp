@@ -7,7 +7,7 @@
 // ranks of the communicator to be in the same call (how fq_comm.cpp uses n > 1: one group per exchange).
 // The ranks may also be THREADS of the process, one context each (how bench.py's ranks call the C ABI, one rank per
 // process there): a group that ends while ranks of its communicators are still missing waits for the other threads'
-// groups (FASTP_STUB_TIMEOUT_MS, default 3000 ms - a rank that never shows up is an error, as before).
+// groups (FASTP_STUB_TIMEOUT_MS, default 30000 ms - a rank that never shows up is an error, as before).
 #include <stdint.h>
 #include <string.h>
 
@@ -50,7 +50,7 @@ ncclResult_t flush() {   // a failed group leaves nothing queued behind
     if (!all_ranks_present()) {   // the other ranks are other threads: wait for their groups
         const unsigned long gen = g_generation;
         const char* v = getenv("FASTP_STUB_TIMEOUT_MS");
-        const auto limit = std::chrono::milliseconds(v ? atoi(v) : 3000);
+        const auto limit = std::chrono::milliseconds(v ? atoi(v) : 30000);
         if (g_cv.wait_for(lk, limit, [&] { return g_generation != gen; })) return g_last;
         g_ops.clear();            // nobody came: the group fails
         return ncclInvalidArgument;

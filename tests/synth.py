@@ -26,6 +26,13 @@ def synth_pairs(n, L=150, seed=42, insert_mean=300.0, insert_sd=80.0, insert_min
         return indel_overlap_pairs(n, L=L, seed=seed)
     if gen == "adapter_indel":
         return adapter_indel_reads(n, L=L, seed=seed, paired=paired, adapters=adapters)
+    if gen == "late_long":   # nothing longer than 100 bases among the first 1100 units: what Evaluator::computeSeqLen sees (the first 1000 reads)
+        d = synth_pairs(n, L=L, seed=seed, insert_mean=insert_mean, insert_sd=insert_sd, paired=paired)
+        head = min(1100, (2 * n) // 3)   # (inputs of fewer than 1650 units: two thirds of them)
+        for m in ("1", "2") if paired else ("1",):
+            d["len" + m][:head] = np.minimum(d["len" + m][:head], 100)
+        assert n < 2 or int(d["len1"][head:].max()) > 100
+        return d
     rng = np.random.default_rng(seed)
     stride = (L + 7) // 8 * 8
     ins = np.clip(np.rint(rng.normal(insert_mean, insert_sd, n)), insert_min, insert_max).astype(np.int64)

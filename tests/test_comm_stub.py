@@ -91,6 +91,7 @@ def test_cabi_collectives_error_paths():
     p.dup_enabled = 0
     engines.build_sim()
     os.environ["FASTP_GPU_RCCL_LIB"] = STUB
+    os.environ["FASTP_STUB_TIMEOUT_MS"] = "300"   # how long the stand-in waits for a rank that never shows up
     e = engines.sim_engine(p)
     with pytest.raises(Exception):
         e.allreduce()                       # no communicator yet
@@ -103,6 +104,7 @@ def test_cabi_collectives_error_paths():
     c = e.counters()
     assert c[0] == abi.ABI_VERSION if hasattr(abi, "ABI_VERSION") else c[0] > 0
     e.close()
+    os.environ.pop("FASTP_STUB_TIMEOUT_MS", None)
 
 
 def test_run_shard_with_the_cabi_exchange_two_ranks_as_threads():
@@ -114,6 +116,7 @@ def test_run_shard_with_the_cabi_exchange_two_ranks_as_threads():
     from fastp_amd import multigpu
     n = 1300
     params, d, paired = shard_util.case_input("pe_default", n)
+    os.environ["FASTP_STUB_TIMEOUT_MS"] = "240000"   # the emulator runs one launch at a time: a rank may wait for the other's kernels
     e0, e1 = _pair_of_engines(params)
     dev = torch.device("cpu")
     keeps, errs, timings = [None, None], [], [{}, {}]

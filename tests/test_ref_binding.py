@@ -47,6 +47,8 @@ BINDING_CASES = {
     "se_overrep": [],
     "pe_adapter_long": [],
     "se_adapter_long_indel": [],
+    "pe_late_long_reads": [],     # reads longer than the length the Evaluator saw in the first 1000: the stream re-plans
+    "se_late_long_reads": [],
 }
 
 

@@ -34,9 +34,9 @@ def _synthetic(n, seed):
     return synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1), synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
 
 
-def _golden(lib, name, tmp_path, chunk_bytes, **kw):
+def _golden(lib, name, tmp_path, chunk_bytes, max_len=152, **kw):
     fq1, fq2, meta = golden_util.load(name)
-    params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)
+    params = golden_util.params_for(name, max_len=max_len, fq1=fq1, fq2=fq2)
     p1, p2 = _files(tmp_path, fq1, fq2)
     want = [k for k in meta["outputs"] if k != "overlapped"]
     if "out1" not in want:
@@ -52,6 +52,17 @@ def test_sim_stream_equals_reference_golden(name, tmp_path):
     lib = engine.load_library(engines.build_sim())
     st = _golden(lib, name, tmp_path, chunk_bytes=60000)
     assert st.chunks >= 2 or name == "testdata_pe"
+
+
+@pytest.mark.parametrize("name", ["pe_late_long_reads", "se_late_long_reads"])
+def test_sim_stream_replans_like_the_reference_grows_its_buffers(name, tmp_path):
+    """the goldens whose first 1100 units are at most 100 bases long and later ones 150: the REFERENCE sized its buffers from the
+    first 1000 reads (Evaluator::computeSeqLen) and grew them (Stats::extendBuffer); the stream starts with that max_len,
+    re-plans when the first longer read turns up, and must reproduce the reference's files and report (with -p: distance
+    arrays of the evaluated length, sampling positions carried across the re-plan)"""
+    lib = engine.load_library(engines.build_sim())
+    st = _golden(lib, name, tmp_path, chunk_bytes=60000, max_len=100)
+    assert st.replans >= 1 and st.max_len >= 150
 
 
 def test_sim_stream_emit_callback_and_gz(tmp_path):
@@ -129,6 +140,14 @@ def test_sim_stream_unequal_files_and_bad_arguments(tmp_path):
 def test_gpu_stream_equals_reference_golden(name, tmp_path):
     lib = engine.load_library()
     _golden(lib, name, tmp_path, chunk_bytes=1 << 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pe_late_long_reads", "se_late_long_reads"])
+def test_gpu_stream_replans_like_the_reference_grows_its_buffers(name, tmp_path):
+    lib = engine.load_library()
+    st = _golden(lib, name, tmp_path, chunk_bytes=1 << 18, max_len=100)
+    assert st.replans >= 1 and st.max_len >= 150
 
 
 @pytest.mark.gpu
