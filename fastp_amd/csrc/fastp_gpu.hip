@@ -254,6 +254,9 @@ struct fastp_gpu_ctx {
         bool busy = false;
         int32_t* counts = nullptr;            // pinned: n_corrections, n_adapter_events as the device left them
         fastp_gpu_results res;                // the caller's result block (host pointers)
+        const void* d_corr = nullptr;         // the batch's sparse lists in the slot's device staging: copied out when the batch
+        const void* d_ev = nullptr;           // has arrived, as many entries as were written (not their whole capacity per batch)
+        hipStream_t copy = nullptr;
     } aslot[FASTP_GPU_ASYNC_SLOTS];
     u64* d_phase = nullptr;   // optional per-phase cycle counters (FASTP_GPU_PHASE_TIMING=1)
     // timing
@@ -321,6 +324,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
     for (auto& sl : ctx->aslot) {
         if (sl.d_stage) (void)hipFree(sl.d_stage);
         if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.copy) (void)hipStreamDestroy(sl.copy);
         if (sl.counts) (void)hipHostFree(sl.counts);
     }
     for (auto& pr : ctx->free_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -2006,9 +2010,11 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     else { dr.adapter_events = nullptr; dr.adapter_events_capacity = 0; }
     dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
     rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
-    if (rc) return rc;
-    rc = join_aux(ctx, st);   // the duplicate flags of the last launch
-    if (rc) return rc;
+    if (!rc) rc = join_aux(ctx, st);   // the duplicate flags of the last launch
+    if (rc) {   // copies from the caller's pinned buffers are queued: they must have drained before the caller may reuse them
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(res->r1, dr.r1, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
     if (mates == 2) {
         HIP_TRY(ctx, hipMemcpyAsync(res->r2, dr.r2, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
@@ -2106,9 +2112,11 @@ extern "C" int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_b
     if (ev_cap) { dr.adapter_events = (fastp_gpu_adapter_event*)take(ev_cap * sizeof(fastp_gpu_adapter_event)); dr.adapter_events_capacity = (int32_t)ev_cap; }
     dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
     rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
-    if (rc) return rc;
-    rc = join_aux(ctx, st);   // the duplicate flags of the last launch
-    if (rc) return rc;
+    if (!rc) rc = join_aux(ctx, st);   // the duplicate flags of the last launch
+    if (rc) {   // copies from the caller's pinned buffers are queued: they must have drained before the caller may reuse them
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(res->r1, dr.r1, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
     if (mates == 2) {
         HIP_TRY(ctx, hipMemcpyAsync(res->r2, dr.r2, n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, st));
@@ -2116,9 +2124,10 @@ extern "C" int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_b
     }
     HIP_TRY(ctx, hipMemcpyAsync(&sl.counts[0], dr.n_corrections, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(&sl.counts[1], dr.n_adapter_events, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    // the sparse lists are copied whole (their fill is only known on the device): they exist only with --correction / --adapter_fasta
-    if (corr_cap) HIP_TRY(ctx, hipMemcpyAsync(res->corrections, dr.corrections, corr_cap * sizeof(fastp_gpu_correction), hipMemcpyDeviceToHost, st));
-    if (ev_cap) HIP_TRY(ctx, hipMemcpyAsync(res->adapter_events, dr.adapter_events, ev_cap * sizeof(fastp_gpu_adapter_event), hipMemcpyDeviceToHost, st));
+    // the sparse lists (--correction / --adapter_fasta) come out in finish_slot: their fill is only known once the batch has run,
+    // and copying their whole capacity with every batch multiplied the D2H traffic of a window by ten
+    sl.d_corr = corr_cap ? dr.corrections : nullptr;
+    sl.d_ev = ev_cap ? dr.adapter_events : nullptr;
     HIP_TRY(ctx, hipEventRecord(sl.done, st));
     sl.res = *res;
     sl.busy = true;
@@ -2128,6 +2137,14 @@ extern "C" int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_b
 static int finish_slot(fastp_gpu_ctx* ctx, fastp_gpu_ctx::AsyncSlot& sl) {
     sl.busy = false;
     const int32_t ncorr = sl.counts[0], nev = sl.counts[1];
+    // the entries that were written, on the slot's own stream (the launch stream may already hold the next batches)
+    const int32_t ccopy = sl.d_corr ? std::min(ncorr, sl.res.corrections_capacity) : 0, ecopy = sl.d_ev ? std::min(nev, sl.res.adapter_events_capacity) : 0;
+    if (ccopy > 0 || ecopy > 0) {
+        if (!sl.copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking));
+        if (ccopy > 0) HIP_TRY(ctx, hipMemcpyAsync(sl.res.corrections, sl.d_corr, (size_t)ccopy * sizeof(fastp_gpu_correction), hipMemcpyDeviceToHost, sl.copy));
+        if (ecopy > 0) HIP_TRY(ctx, hipMemcpyAsync(sl.res.adapter_events, sl.d_ev, (size_t)ecopy * sizeof(fastp_gpu_adapter_event), hipMemcpyDeviceToHost, sl.copy));
+        HIP_TRY(ctx, hipStreamSynchronize(sl.copy));
+    }
     if (sl.res.n_corrections) *sl.res.n_corrections = std::min(ncorr, sl.res.corrections ? sl.res.corrections_capacity : 0);
     if (sl.res.n_adapter_events) *sl.res.n_adapter_events = std::min(nev, sl.res.adapter_events ? sl.res.adapter_events_capacity : 0);
     if (sl.res.corrections && ncorr > sl.res.corrections_capacity) return fail(ctx, FASTP_GPU_E_OVERFLOW, "correction list capacity exceeded");

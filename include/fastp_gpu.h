@@ -614,6 +614,9 @@ int fastp_gpu_comm_init(fastp_gpu_ctx* ctx, const uint8_t id[FASTP_GPU_COMM_ID_B
 int fastp_gpu_comm_init_local(fastp_gpu_ctx* const* ctxs, int n);
 void fastp_gpu_comm_destroy(fastp_gpu_ctx* ctx);   /* also done by fastp_gpu_destroy */
 /* Stats::merge / FilterResult::merge: every rank's counter block <- the sum over all ranks */
+/* Contract of both collectives: the contexts passed in (and their communicators) must stay alive until the call returns -
+ * fastp_gpu_destroy / fastp_gpu_comm_destroy of one of them from another thread while a collective is in flight is a
+ * use-after-free (the registry lock is NOT held across the RCCL calls, so that two ranks living in one process can meet). */
 int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n);
 /* between pass 1 and pass 2 of a sharded run: rank r's prefix <- OR of the bitmaps of ranks 0..r-1
  * (slices all-to-all, fastp_gpu_prefix_or_images on the slice owner, all-to-all back, fastp_gpu_dup_prefix_set) */

@@ -13,6 +13,7 @@ import synth_torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=100_000_000)
 ap.add_argument("--ref-threads", type=int, default=1)
+ap.add_argument("--no-ref", action="store_true", help="time the drop-in only (several stream settings), no reference run")
 ap.add_argument("--also", type=int, default=16, help="a second, timing-only run of the reference with this many threads (0 = none)")
 args = ap.parse_args()
 L = 150
@@ -48,6 +49,15 @@ def run(binary, tag, w, env=None):
     return dt, rep, p.stderr.decode(errors="replace")
 
 
+if args.no_ref:
+    for label, env in (("default", {}), ("read threads 32", {"FASTP_GPU_STREAM_READ_THREADS": "32"}), ("read threads 8", {"FASTP_GPU_STREAM_READ_THREADS": "8"}),
+                       ("chunks of 32 MiB", {"FASTP_GPU_STREAM_CHUNK_MB": "32"})):
+        tg, rg, err = run(os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpu"), "g", 16, dict({"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}, **env))
+        m = re.search(r"fastp_gpu: stream mode: .*", err)
+        print(f"FASTP_GPU=1 fastp_ref_gpu -w 16, {label}: {tg:.2f} s = {2*args.pairs/tg/1e6:.2f} Mreads/s\n   " + (m.group(0) if m else ""), flush=True)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    raise SystemExit(0)
 tg, rg, err = run(os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpu"), "g", 16, {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"})
 print(f"FASTP_GPU=1 fastp_ref_gpu -w 16 (stream binding): {tg:.2f} s = {2*args.pairs/tg/1e6:.2f} Mreads/s", flush=True)
 m = re.search(r"fastp_gpu: stream mode: .*", err)
