@@ -1665,7 +1665,10 @@ FQ_DEV void write_read_result(const KernelArgs& a, u32* lds, int m, int R, int g
     // reserved: merge mode, overlapped pair: bases of this mate in the merged read (the name tag merged_L1_L2)
     const int pr1 = m ? R - L.P : R;
     // --overlapped_out: read 1 carries 0x8000 | first printed position, read 2 the number of printed bases
-    const u32 rsv = ((lds_i(lds, L.flags)[pr1] & RS_MERGE_OV) || a.p.overlapped_out) ? ((u32)lds_i(lds, L.mlen)[R] & 0xFFFFu) : 0u;
+    // (with merge AS WELL the fields carry the --overlapped_out values: the merged part lengths follow from the pair
+    // record, len1 = ov_len + max(0, ov_offset), len2 = ov_offset > 0 ? len(read 2) - ov_len : 0)
+    const u32 rsv = a.p.overlapped_out ? ((u32)lds_i(lds, L.olen)[R] & 0xFFFFu)
+                    : (lds_i(lds, L.flags)[pr1] & RS_MERGE_OV) ? ((u32)lds_i(lds, L.mlen)[R] & 0xFFFFu) : 0u;
     u32* out = a.res[m] + (size_t)gp * 3;
     out[0] = front | (len << 16);
     out[1] = code | (flags << 8) | (apos << 16);
@@ -1804,8 +1807,8 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
         }
         (void)isize_done;
         if (p.overlapped_out) {  // the reads as --overlapped_out's analysis sees them (:488, before polyX and max_len)
-            lds_i(lds, L.mlen)[R1] = cur1;
-            lds_i(lds, L.mlen)[R2] = cur2;
+            lds_i(lds, L.olen)[R1] = cur1;
+            lds_i(lds, L.olen)[R2] = cur2;
         }
         if (both && p.poly_x) {  // :506-509
             for (int k = 0; k < 2; k++) {
@@ -1827,10 +1830,8 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
             if (p.max_len2 > 0 && p.max_len2 < cur2) lenv[R2] = cur2 = p.max_len2;
         }
         if (dimer | isize_done) lds_or_i32(&flags[R1], (dimer ? RS_DIMER : 0) | (isize_done ? RS_ISIZE : 0));
-        if (!p.overlapped_out) {
-            lds_i(lds, L.mlen)[R1] = cur1;
-            lds_i(lds, L.mlen)[R2] = cur2;
-        }
+        lds_i(lds, L.mlen)[R1] = cur1;
+        lds_i(lds, L.mlen)[R2] = cur2;
         if (p.merge && both) {
             // merge mode analyzes the post-trim reads again (peprocessor.cpp:523); phase_merge writes the record
             lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;
@@ -1845,9 +1846,10 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
 // as they are right after adapter trimming.  What the reference prints for an overlapped pair is
 //   string(r1->mSeq->substr(max(0, offset)), overlap_len)   (:491)
 // - std::string's (str, pos) constructor, i.e. the bases of read 1 BEHIND the overlapped region,
-// r1'[max(0, offset) + overlap_len, len1').  phase_decide_pe left the post-adapter lengths in mlen[] (unused outside
-// merge mode, which excludes this option); the analysis runs on them, then the record's `reserved` fields take
-//   mlen[R1] = 0x8000 | pos (overlapped; pos = max(0, offset) + overlap_len) or 0, mlen[R2] = len1' - pos.
+// r1'[max(0, offset) + overlap_len, len1').  phase_decide_pe left the post-adapter lengths in olen[] (an array of its
+// own: mlen[] belongs to merge mode, which may be on as well and runs AFTER this, :518); the analysis runs on them,
+// then the record's `reserved` fields take
+//   olen[R1] = 0x8000 | pos (overlapped; pos = max(0, offset) + overlap_len) or 0, olen[R2] = len1' - pos.
 // ---------------------------------------------------------------------------
 FQ_DEV void phase_ovout_begin(const KernelArgs& a, u32* lds, int tile_first, int tid, int nthreads) {
     const LdsLayout& L = a.L;
@@ -1856,8 +1858,8 @@ FQ_DEV void phase_ovout_begin(const KernelArgs& a, u32* lds, int tile_first, int
         for (int k = 0; k < 2; k++) {
             const int R = k ? L.P + pr : pr;
             const int fin = lds_i(lds, L.len)[R];
-            lds_i(lds, L.len)[R] = lds_i(lds, L.mlen)[R];
-            lds_i(lds, L.mlen)[R] = fin;
+            lds_i(lds, L.len)[R] = lds_i(lds, L.olen)[R];
+            lds_i(lds, L.olen)[R] = fin;
         }
         lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;
     }
@@ -1870,11 +1872,12 @@ FQ_DEV void phase_ovout_end(const KernelArgs& a, u32* lds, int tile_first, int t
         int ovl, off, ol, diff;
         const int l1 = lds_i(lds, L.len)[R1];
         decode_overlap((u32)lds_i(lds, L.ov_off)[pr], l1, lds_i(lds, L.len)[R2], ovl, off, ol, diff);
-        lds_i(lds, L.len)[R1] = lds_i(lds, L.mlen)[R1];
-        lds_i(lds, L.len)[R2] = lds_i(lds, L.mlen)[R2];
+        lds_i(lds, L.len)[R1] = lds_i(lds, L.olen)[R1];
+        lds_i(lds, L.len)[R2] = lds_i(lds, L.olen)[R2];
         const int pos = imax(0, off) + ol;   // <= l1: string(substr(start), overlap_len) never throws
-        lds_i(lds, L.mlen)[R1] = ovl ? (0x8000 | pos) : 0;
-        lds_i(lds, L.mlen)[R2] = ovl ? l1 - pos : 0;
+        lds_i(lds, L.olen)[R1] = ovl ? (0x8000 | pos) : 0;
+        lds_i(lds, L.olen)[R2] = ovl ? l1 - pos : 0;
+        if (a.p.merge) lds_i(lds, L.ov_off)[pr] = (int)OV_KEY_NONE;   // merge mode's analysis of the final reads comes next
     }
 }
 
@@ -1981,8 +1984,8 @@ FQ_DEV void phase_filter_pe_plain(const KernelArgs& a, u32* lds, int tile_first,
         const u32 rl1 = (u32)lds_i(lds, L.rlen0)[R1], rl2 = (u32)lds_i(lds, L.rlen0)[R2];
         const u32 apos1 = (u32)lds_i(lds, L.apos)[R1], apos2 = (u32)lds_i(lds, L.apos)[R2];
         const u32 alen1 = (u32)lds_i(lds, L.alen)[R1], alen2 = (u32)lds_i(lds, L.alen)[R2];
-        const u32 rsv1 = p.overlapped_out ? (u32)lds_i(lds, L.mlen)[R1] & 0xFFFFu : 0u;   // phase_ovout_end
-        const u32 rsv2 = p.overlapped_out ? (u32)lds_i(lds, L.mlen)[R2] & 0xFFFFu : 0u;
+        const u32 rsv1 = p.overlapped_out ? (u32)lds_i(lds, L.olen)[R1] & 0xFFFFu : 0u;   // phase_ovout_end
+        const u32 rsv2 = p.overlapped_out ? (u32)lds_i(lds, L.olen)[R2] & 0xFFFFu : 0u;
         write_dup_pos(a, lds, pr, gp);   // LDS reads + global stores only
         const u16* lowq = (const u16*)(lds + L.lut_lowq);
         const u16* cmin = (const u16*)(lds + L.lut_cplx);
@@ -2329,16 +2332,16 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
             else phase_decide_se(a, lds, tile_first, tid, nt);
         }
         tile_sync(a, lds, nt);
-        if (a.p.merge) {
-            phase_overlap(a, lds, tid, nt);
-            phase_merge(a, lds, tile_first, tid, nt);
-            tile_sync(a, lds, nt);
-        }
-        if (a.p.overlapped_out) {
+        if (a.p.overlapped_out) {   // :488-495, in front of merge mode's own analysis (:518) as in the reference
             phase_ovout_begin(a, lds, tile_first, tid, nt);
             tile_sync(a, lds, nt);
             phase_overlap(a, lds, tid, nt, true);
             phase_ovout_end(a, lds, tile_first, tid, nt);
+            tile_sync(a, lds, nt);
+        }
+        if (a.p.merge) {
+            phase_overlap(a, lds, tid, nt);
+            phase_merge(a, lds, tile_first, tid, nt);
             tile_sync(a, lds, nt);
         }
         FQ_STAMP(5)

@@ -351,7 +351,12 @@ int fastp_gpu_host_apply(fastp_gpu_host* h, const fastp_gpu_reads* b1, const fas
         if (h->p.merge && alive1 && alive2) {  // peprocessor.cpp:518-561
             if (res->pair[i].flags & FASTP_GPU_PF_OVERLAPPED) {
                 if (code1 == FASTP_PASS_FILTER) {  // OverlapAnalysis::merge overlapanalysis.cpp:148-179
-                    const int m1 = rr1.reserved, m2 = rr2.reserved, ol = res->pair[i].ov_len;
+                    // the part lengths: in the records' reserved fields, unless --overlapped_out occupies them - then
+                    // from the pair record (merge mode's own analysis): len1 = overlap_len + max(0, offset), len2 =
+                    // offset > 0 ? len(r2') - overlap_len : 0 (overlapanalysis.cpp:152-156)
+                    const int ol = res->pair[i].ov_len, off = res->pair[i].ov_offset;
+                    const int m1 = h->p.overlapped_out ? ol + (off > 0 ? off : 0) : rr1.reserved;
+                    const int m2 = h->p.overlapped_out ? (off > 0 ? t2l - ol : 0) : rr2.reserved;
                     std::string ms(t1s, (size_t)m1), mq(t1q, (size_t)m1);
                     for (int k = 0; k < m2; k++) {  // rc(r2')[ol + k] = comp(r2'[len2 - 1 - ol - k])
                         ms.push_back(complement(t2s[t2l - 1 - ol - k]));

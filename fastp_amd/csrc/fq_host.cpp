@@ -136,7 +136,6 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.merge = (in.merge != 0) && p.paired;
     p.merge_include_unmerged = in.merge_include_unmerged != 0;
     p.overlapped_out = (in.overlapped_out != 0) && p.paired;   // mOverlappedWriter exists for paired input only (peprocessor.cpp:94-97)
-    if (p.overlapped_out && p.merge) { err = "overlapped_out together with merge (both use the records' reserved fields)"; return FASTP_GPU_E_UNSUPPORTED; }
     p.overlap_require = in.overlap_require;
     p.overlap_diff_limit = in.overlap_diff_limit;
     p.qual_filter = in.qual_filter != 0;
@@ -370,6 +369,7 @@ int compute_lds_layout(const DevParams& p, TileConfig& cfg, LdsLayout& L, std::s
         out.code = take(out.NR);
         out.swin = take(out.NR);
         out.mlen = take(out.NR);
+        out.olen = p.overlapped_out ? take(out.NR) : -1;
         out.wl_cap = imin_i(2046, 8 * out.NR + 62);
         out.wl_cap -= out.wl_cap & 1;
         out.wl = take(1 + out.wl_cap / 2);

@@ -125,6 +125,7 @@ struct LdsLayout {
     int rlen0, front, len, flags, ft, apos, alen, code;   // [NR] ints
     int swin;       // [NR] one-pass Stats window of a read: rlen0 | kept length << 16 (0 = not written out)
     int mlen;       // [NR] merge mode: bases of this mate that enter the merged read (else = len)
+    int olen;       // [NR] --overlapped_out: post-adapter length, then the record's `reserved` value (phase_ovout_*); else -1
     int met;        // [NR][2] countQualityMetrics / countAdjacentDiffs of the final window (phase_metrics)
     int ov_off, ov_len, ov_diff, ov_flags;                // [P]; ov_off holds the packed no-gap scan key (OV_KEY_*),
                                                           // ov_len the key of the one-gap pass (allow_gap)

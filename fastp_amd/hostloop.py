@@ -274,8 +274,12 @@ def apply_results(params: abi.Params, b1: FastqBatch, b2: FastqBatch | None, r1,
             if pair[i]["flags"] & abi.PF_OVERLAPPED:
                 if code1 == abi.PASS_FILTER:
                     # OverlapAnalysis::merge overlapanalysis.cpp:148-179
-                    m1, m2 = int(rr1["reserved"]), int(rr2["reserved"])
                     ol = int(pair[i]["ov_len"])
+                    if params.overlapped_out:   # the reserved fields are taken: the part lengths follow from the pair record
+                        off = int(pair[i]["ov_offset"])
+                        m1, m2 = ol + max(0, off), (len(t2s) - ol if off > 0 else 0)
+                    else:
+                        m1, m2 = int(rr1["reserved"]), int(rr2["reserved"])
                     rc2 = _complement_bytes(t2s[::-1])
                     rq2 = t2q[::-1]
                     tag = b" merged_%d_%d" % (m1, m2)

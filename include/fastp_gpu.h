@@ -142,7 +142,9 @@ typedef struct fastp_gpu_params {
 
     /* --overlapped_out given (paired input; Options::overlappedOut, peprocessor.cpp:488-495): the engine runs the
      * third OverlapAnalysis::analyze (diffPercentLimit 0, on the pair right after adapter trimming) and reports the
-     * overlapped part of read 1 in the records' `reserved` fields.  Not together with merge (FASTP_GPU_E_UNSUPPORTED). */
+     * overlapped part of read 1 in the records' `reserved` fields.  Together with merge the fields keep THESE values and
+     * the merged part lengths follow from the pair record (merge's own analysis, peprocessor.cpp:523): len1 = ov_len +
+     * max(0, ov_offset), len2 = ov_offset > 0 ? len(read 2) - ov_len : 0 (overlapanalysis.cpp:152-156). */
     int32_t overlapped_out;
     int32_t reserved[3];
 } fastp_gpu_params;
@@ -197,7 +199,7 @@ typedef struct fastp_gpu_read_result {
     uint16_t adapter_len;/* length of the string handed to addAdapterTrimmed:     */
                          /* pos>=0: read[pos, pos+adapter_len) (after correction); */
                          /* pos<0 : adapterseq.substr(0, adapter_len)              */
-    uint16_t reserved;   /* merge mode, merged pair: bases of this mate in the merged read.               */
+    uint16_t reserved;   /* merge mode, merged pair: bases of this mate in the merged read (unless:)      */
                          /* overlapped_out: read 1 = FASTP_GPU_OVOUT_HIT | pos, read 2 = count: the extra  */
                          /* stream gets orig_r1[front + pos, front + pos + count) - the bases BEHIND the   */
                          /* overlapped region, pos = max(0, offset) + overlap_len, as peprocessor.cpp:491  */

@@ -1116,8 +1116,10 @@ static void orc_process_pe(fastp_oracle* o, int pair_index, uint32_t batch_flags
             }
             free(ms); free(mq);
             code1 = code2 = result;
-            rr1->reserved = (uint16_t)m1; /* merged_<len1>_<len2> for the host's name tag */
-            rr2->reserved = (uint16_t)m2;
+            if (!p->overlapped_out) { /* with --overlapped_out the fields keep its values; m1 / m2 follow from the pair record */
+                rr1->reserved = (uint16_t)m1; /* merged_<len1>_<len2> for the host's name tag */
+                rr2->reserved = (uint16_t)m2;
+            }
             mergeProcessed = 1;
         } else if (p->merge_include_unmerged) {
             code1 = fastp_oracle_pass_filter(p, or1.seq, or1.qual, or1.len);

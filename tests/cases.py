@@ -88,6 +88,16 @@ CASES["pe_overlapped_out_trims"] = (True, ["-G", "-c", "-x", "-b", "120", "-B", 
                                     {"insert_mean": 170.0, "polyx_frac": 0.2})
 CASES["pe_overlapped_out_noadapter"] = (True, ["-G", "-A", "--overlapped_out", "@TMP@/overlapped.fq"],
                                         _pe(overlapped_out=1, adapter_enabled=0), {"insert_mean": 150.0, "insert_sd": 60.0})
+# --overlapped_out together with --merge: the exact analysis (:488) comes before the polyX / max_len cuts, merge mode's
+# own analysis (:518) after them; both want the records' reserved fields (the engine gives them to --overlapped_out
+# and the merged part lengths follow from the pair record)
+CASES["pe_merge_overlapped_out"] = (True, ["-G", "-m", "--merged_out", "@TMP@/merged.fq", "--overlapped_out", "@TMP@/overlapped.fq"],
+                                    _pe(merge=1, correction=1, overlapped_out=1), {"insert_mean": 200.0})
+CASES["pe_merge_overlapped_out_trims"] = (True, ["-G", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq", "-x", "-b", "120",
+                                                 "-B", "100", "--cut_front", "-f", "2", "--overlapped_out", "@TMP@/overlapped.fq"],
+                                          _pe(merge=1, correction=1, merge_include_unmerged=1, overlapped_out=1, poly_x=1, max_len1=120,
+                                              max_len2=100, cut_front=1, trim_front1=2, trim_front2=2),
+                                          {"insert_mean": 170.0, "polyx_frac": 0.2})
 
 # adapters longer than 64 bases (the engine's cap is FASTP_GPU_MAX_ADAPTER_LEN = 256): the read-through of the
 # synthetic reads is adapter + poly-A, so these match over their whole length

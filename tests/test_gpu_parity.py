@@ -109,7 +109,8 @@ def test_gpu_stats_work_list_overflow():
 
 
 @pytest.mark.parametrize("name", ["pe_default", "pe_merge", "pe_adapter_fasta", "pe_umi_per_read", "se_adapter_cut",
-                                  "pe_noadapter_dedup", "pe_overlapped_out_trims"])
+                                  "pe_noadapter_dedup", "pe_overlapped_out_trims", "pe_merge_overlapped_out",
+                                  "pe_merge_overlapped_out_trims"])
 def test_gpu_with_cpp_host_glue_equals_reference_golden(name):
     """device records -> C++ host glue (include/fastp_gpu_host.h, fq_glue.cpp) -> the reference's FASTQ + JSON"""
     fq1, fq2, meta = golden_util.load(name)

@@ -117,7 +117,8 @@ def test_sim_one_gap_accept_paths(name):
     assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
 
 
-@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "se_adapter_cut", "testdata_pe", "pe_overlapped_out_trims"])
+@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "se_adapter_cut", "testdata_pe", "pe_overlapped_out_trims",
+                                  "pe_merge_overlapped_out", "pe_merge_overlapped_out_trims"])
 def test_sim_matches_reference_golden(name):
     fq1, fq2, meta = golden_util.load(name)
     params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)

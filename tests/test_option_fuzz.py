@@ -87,7 +87,7 @@ def random_case(seed):
     if pick(0.15) and p.adapter_enabled:
         abi.set_adapter_fasta(p, [b"CTGTCTCTTATACACATCT", b"AGATCGGAAGAGC", b"TGGAATTCTCGGGTGCCAAGG"][:int(rng.integers(1, 4))])
     # (drawn last so that the earlier seeds keep their cases) --overlapped_out; adapters longer than 64 bases
-    if paired and not p.merge and pick(0.2):
+    if paired and pick(0.2):   # with merge as well (the records' reserved fields go to --overlapped_out then)
         p.overlapped_out = 1
     if p.adapter_enabled and p.adapter_seq_r1 and pick(0.15):
         p.adapter_seq_r1 = cases.LONG_R1.encode()

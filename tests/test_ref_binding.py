@@ -40,6 +40,7 @@ BINDING_CASES = {
     "pe_overrep": [],
     "pe_overlapped_out_trims": [],
     "pe_overlapped_out_noadapter": [],
+    "pe_merge_overlapped_out_trims": [],
     "se_default_noadapter": [],
     "se_adapter_cut": [],
     "se_umi_read1": [],
@@ -167,7 +168,7 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
 # on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
 # test_gpu_patched_reference_equals_reference; each costs seconds here because the emulator clears Duplicate's 1 GiB
 EMULATOR_CASES = ["pe_filters", "pe_noadapter_dedup", "pe_umi_per_read", "pe_adapter_fasta", "pe_overrep", "pe_allow_gap_indel",
-                  "pe_overlapped_out_trims", "se_adapter_cut", "se_adapter_long_indel"]
+                  "pe_merge_overlapped_out_trims", "se_adapter_cut", "se_adapter_long_indel"]
 assert all(n in BINDING_CASES for n in EMULATOR_CASES)
 
 
