@@ -5,7 +5,7 @@ Only declarations live here - no computation.  Used by the Python host mirror
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_READ_LEN = 512
 MAX_ADAPTER_LEN = 256
 
@@ -104,6 +104,9 @@ class Batch(C.Structure):
         ("n", C.c_int32), ("flags", C.c_uint32),
         ("seq1", C.c_void_p), ("qual1", C.c_void_p), ("len1", C.c_void_p),
         ("seq2", C.c_void_p), ("qual2", C.c_void_p), ("len2", C.c_void_p),
+        # units with letters outside ACGTN (ABI v4): see include/fastp_gpu.h
+        ("n_exotic", C.c_int32), ("exotic_dense", C.c_int32), ("exotic_unit", C.c_void_p),
+        ("exotic_text", C.c_void_p * 2), ("exotic_off", C.c_void_p * 2), ("exotic_text_bytes", C.c_int64 * 2),
     ]
 
 

@@ -13,6 +13,7 @@
 #include "fq_device.h"
 #include "fq_stats.h"
 #include "fq_lane.h"
+#include "fq_exact.h"
 #include "fq_inflate.h"
 #include "fq_eval.h"
 #include "fq_deflate.h"
@@ -148,6 +149,7 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs 
     extern __shared__ u32 fq_lds[];
     fmts_write_body(f, fq_lds);
 }
+extern "C" __global__ void __launch_bounds__(64) fq_exact_kernel(ExactArgs e) { exact_body(e); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_claim_kernel(DupArgs d) { dup_claim_body(d); }
@@ -245,6 +247,12 @@ struct fastp_gpu_ctx {
     const void* last_corr = nullptr; int32_t last_corr_cap = 0;   // the correction list of the last submit and its capacity
     std::vector<std::string> ovr_strings[2];
     std::vector<const char*> ovr_ptrs[2];
+    // exact plan (fq_exact.h): the worker loop on the text, for units with letters outside ACGTN
+    bool exact_all = false;                                // FASTP_GPU_EXACT=1: every unit takes it (tests)
+    u8* d_x_scratch = nullptr; size_t x_scratch_cap = 0;   // [lanes][lane_bytes]
+    int* d_x_unit = nullptr; size_t x_unit_cap = 0;        // the submitted batch's exotic unit list
+    void* d_x_text[2] = {nullptr, nullptr}; size_t x_text_cap[2] = {0, 0};   // host submits: the raw text + offsets staged in HBM
+    void* d_x_off[2] = {nullptr, nullptr}; size_t x_off_cap[2] = {0, 0};
     // staging for submit_host
     void* d_stage = nullptr; size_t stage_cap = 0;
     // fastp_gpu_submit_host_async: device staging, completion event and what to finish per slot
@@ -332,7 +340,8 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_bitmap, ctx->d_dup_pos, ctx->d_table, ctx->d_need, ctx->d_dupflag, ctx->d_stage, ctx->d_phase,
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
-                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr};
+                    ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr,
+                    ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
@@ -546,6 +555,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     };
     set_launch_size();
     fastp_gpu_counter_layout_for_params(&ctx->params, &ctx->cl);
+    ctx->exact_all = env_int("FASTP_GPU_EXACT", 0) != 0;   // tests: every unit through the text kernel (fq_exact.h)
+    if (ctx->exact_all && env_int("FASTP_GPU_VERBOSE", 0)) fprintf(stderr, "fastp_gpu: FASTP_GPU_EXACT=1, every unit takes the text kernel\n");
     if (env_int("FASTP_GPU_VERBOSE", 0))
         fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel %d x %d threads, LDS %d bytes\n",
                 ctx->lane ? "lane plan" : (ctx->split ? "split plan" : "fused plan"), ctx->L.P, ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks,
@@ -830,8 +841,10 @@ enum ChunkMode {
     CHUNK_OVERREP,   // the deferred overrepresentation analysis only
 };
 
+// `exact`: the units [first, first + n) go through the text kernel (fq_exact.h) instead of the plan's kernels - a segment
+// around units with letters outside ACGTN (submit_chunks cuts the batch), or everything (FASTP_GPU_EXACT=1)
 static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first, int n, const fastp_gpu_results* res,
-                        hipStream_t st, ChunkMode mode = CHUNK_STREAM, u8* scan_state = nullptr) {
+                        hipStream_t st, ChunkMode mode = CHUNK_STREAM, u8* scan_state = nullptr, bool exact = false) {
     KernelArgs a;
     memset(&a, 0, sizeof(a));
     a.p = ctx->dp;
@@ -888,7 +901,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     u64* scan_pos = scan_state ? (u64*)scan_state + (size_t)first * ctx->dp.dup_bufnum : nullptr;
     u8* scan_mask = scan_state ? scan_state + (size_t)b->n * ctx->dp.dup_bufnum * 8 + first : nullptr;
     // the worker loop on the context's own streams: Duplicate's kernels go to the aux stream and overlap the next launch
-    const bool piped = ctx->aux && st == ctx->stream && mode == CHUNK_STREAM && ctx->dp.dup_enabled && !ctx->dp.dedup;
+    const bool piped = ctx->aux && st == ctx->stream && mode == CHUNK_STREAM && ctx->dp.dup_enabled && !ctx->dp.dedup && !exact;
     const int par = (int)(ctx->launch_seq & 1);
     if (!piped) {
         int rj = join_aux(ctx, st);
@@ -946,7 +959,35 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
     // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers, the context's own stream order
     const bool claim_fused = ctx->dp.dup_enabled && !ctx->dp.dedup && mode == CHUNK_STREAM && !piped && ctx->dp.dup_bufnum <= 2 &&
-                             !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1);
+                             !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1) && !exact;
+    // the text kernel: a lane per unit with a private stretch of HBM for its text buffers; counters straight into d_ctr
+    auto launch_exact = [&](int hash_only) -> int {
+        ExactArgs e;
+        memset(&e, 0, sizeof(e));
+        e.k = a;
+        const fastp_gpu_counter_layout& c = ctx->cl;
+        e.c.filter = c.filter_stats; e.c.adapter_reads = c.adapter_reads; e.c.adapter_bases = c.adapter_bases;
+        e.c.polyx_reads = c.polyx_reads; e.c.polyx_bases = c.polyx_bases; e.c.correction = c.correction;
+        e.c.corrected_reads = c.corrected_reads; e.c.merged = c.merged_pairs; e.c.isize = c.isize;
+        for (int k = 0; k < 4; k++) e.c.stats[k] = c.stats[k];
+        e.c.st_reads = c.st_reads; e.c.st_length_sum = c.st_length_sum; e.c.st_qual_hist = c.st_qual_hist;
+        e.c.st_kmer = c.st_kmer; e.c.st_cycle = c.st_cycle; e.c.cycles = c.cycles;
+        e.ctr = ctx->d_ctr;
+        e.x_n = b->n_exotic;
+        e.x_unit = ctx->d_x_unit;
+        e.x_dense = b->exotic_dense;
+        for (int m = 0; m < 2; m++) { e.x_text[m] = b->exotic_text[m]; e.x_off[m] = b->exotic_off[m]; }
+        e.ML = (ctx->dp.max_len + 8 + 7) & ~7;
+        e.lane_bytes = (u32)(EXACT_BUFS * e.ML + EXACT_ADAPTER_BYTES);
+        e.hash_only = hash_only;
+        const int lanes = std::min((n + 63) / 64 * 64, env_int("FASTP_GPU_EXACT_LANES", 16384));
+        int r2 = ensure(ctx, (void**)&ctx->d_x_scratch, &ctx->x_scratch_cap, (size_t)lanes * e.lane_bytes);
+        if (r2) return r2;
+        e.scratch = ctx->d_x_scratch;
+        hipLaunchKernelGGL(fq_exact_kernel, dim3(lanes / 64), dim3(64), 0, st, e);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
     bool dup_prepared = false;
     auto launch_dup = [&](u8* dupflag, bool scan = false, hipStream_t st = nullptr, int stage = 0) -> int {
         // stage 0: everything; 1: only the buffers + clears (before a fused kernel that claims); 2: what follows that kernel
@@ -1010,8 +1051,13 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     };
 
     if (mode == CHUNK_PASS1 && ctx->dp.dedup) {
-        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
-        HIP_TRY(ctx, hipGetLastError());
+        if (exact) {
+            rc = launch_exact(1);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
+            HIP_TRY(ctx, hipGetLastError());
+        }
         return launch_dup(nullptr, true);
     }
     if (mode == CHUNK_OVERREP) return launch_overrep(ctx, a, n, st);
@@ -1044,8 +1090,13 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
         rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
         if (rc) return rc;
-        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
-        HIP_TRY(ctx, hipGetLastError());
+        if (exact) {
+            rc = launch_exact(1);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
+            HIP_TRY(ctx, hipGetLastError());
+        }
         rc = launch_dup(ctx->d_dupflag);
         if (rc) return rc;
         a.dup_pos = nullptr;
@@ -1067,7 +1118,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    {
+    if (exact) {
+        rc = launch_exact(0);
+        if (rc) return rc;
+    } else {
         FusedArgs fa;
         fa.h[0] = a;
         fa.h[1] = a;
@@ -1101,7 +1155,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         dup_tail_launched = true;
     }
     int st_grid = 0;
-    if (ctx->split && n > 0) {
+    if (ctx->split && n > 0 && !exact) {
         // Stats::statRead of the launch's units: a workgroup takes a run of consecutive units (at most CYC_MAX_READS:
         // packed counters; at least 64 so that small launches do not pay a 43 KB slab per handful of reads)
         StatsArgs sa;
@@ -1158,7 +1212,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
-    if (ctx->split) {
+    if (exact) {
+        // the text kernel adds to the counter block itself: nothing to fold
+    } else if (ctx->split) {
         // the Stats kernel's slabs: per-cycle u64s, k-mer counters, one histogram counter per (slot, character)
         r.slabs = ctx->d_st_slabs;
         r.slab_dwords = ctx->st_slab_dwords;
@@ -1234,14 +1290,51 @@ static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fas
         if (res->n_adapter_events) HIP_TRY(ctx, hipMemsetAsync(res->n_adapter_events, 0, sizeof(int32_t), st));
     }
     // split into equally sized launches (each a multiple of the tile size)
-    const int launches = (b->n + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
-    int per = launches ? (b->n + launches - 1) / launches : 0;
-    per = (per + ctx->L.P - 1) / ctx->L.P * ctx->L.P;
-    for (int first = 0; first < b->n; first += per) {
-        const int n = std::min(per, b->n - first);
-        int rc = launch_chunk(ctx, b, first, n, res, st, mode, scan_state);
+    auto run_range = [&](int lo, int hi, bool exact) -> int {
+        const int span = hi - lo;
+        const int launches = (span + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
+        int per = launches ? (span + launches - 1) / launches : 0;
+        per = (per + ctx->L.P - 1) / ctx->L.P * ctx->L.P;
+        for (int first = lo; first < hi; first += per) {
+            const int n = std::min(per, hi - first);
+            int rc = launch_chunk(ctx, b, first, n, res, st, mode, scan_state, exact);
+            if (rc) return rc;
+        }
+        return FASTP_GPU_OK;
+    };
+    if (b->n_exotic <= 0) return run_range(0, b->n, ctx->exact_all);
+    // Units with letters outside ACGTN: the packed rows cannot carry them, the text kernel (fq_exact.h) takes them with
+    // the units around them - groups of four, so that what is left for the plan's kernels starts at 16-byte aligned rows -
+    // and the stretches in between go through the plan's kernels as launches of their own, all in stream order
+    // (Duplicate's bloom semantics and the records' positions are those of one pass over the batch).
+    if (!b->exotic_unit || !b->exotic_text[0] || !b->exotic_off[0] || (ctx->dp.paired && (!b->exotic_text[1] || !b->exotic_off[1])))
+        return fail(ctx, FASTP_GPU_E_INVALID, "n_exotic > 0 needs exotic_unit, exotic_text and exotic_off");
+    if (ctx->dp.overrep) return fail(ctx, FASTP_GPU_E_ALPHABET, "letters outside ACGTN together with the overrepresentation analysis");
+    for (int k = 0; k < b->n_exotic; k++)
+        if (b->exotic_unit[k] < 0 || b->exotic_unit[k] >= b->n || (k && b->exotic_unit[k] <= b->exotic_unit[k - 1]))
+            return fail(ctx, FASTP_GPU_E_INVALID, "exotic_unit must be ascending unit indexes of the batch");
+    {
+        int rc = ensure(ctx, (void**)&ctx->d_x_unit, &ctx->x_unit_cap, (size_t)b->n_exotic * sizeof(int));
         if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_x_unit, b->exotic_unit, (size_t)b->n_exotic * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));   // the list is the caller's (pageable) memory
     }
+    std::vector<std::pair<int, int>> segs;   // [lo, hi) of the text kernel's segments
+    const int join_gap = env_int("FASTP_GPU_EXACT_JOIN", 256);   // stretches shorter than this are not worth launches of their own
+    for (int k = 0; k < b->n_exotic; k++) {
+        const int lo = b->exotic_unit[k] & ~3, hi = std::min(b->n, (b->exotic_unit[k] | 3) + 1);
+        if (!segs.empty() && lo - segs.back().second < join_gap) segs.back().second = std::max(segs.back().second, hi);
+        else segs.push_back({lo, hi});
+    }
+    if (ctx->exact_all || (int)segs.size() > env_int("FASTP_GPU_EXACT_MAX_SEGMENTS", 64)) { segs.clear(); segs.push_back({0, b->n}); }
+    int at = 0;
+    for (const auto& sg : segs) {
+        if (sg.first > at) { int rc = run_range(at, sg.first, false); if (rc) return rc; }
+        int rc = run_range(sg.first, sg.second, true);
+        if (rc) return rc;
+        at = sg.second;
+    }
+    if (at < b->n) return run_range(at, b->n, false);
     return FASTP_GPU_OK;
 }
 
@@ -1958,6 +2051,26 @@ extern "C" int fastp_gpu_synchronize(fastp_gpu_ctx* ctx) {
     return FASTP_GPU_OK;
 }
 
+// host submits: the raw text and offsets of the batch's exotic units (fastp_gpu_batch::exotic_*) go to HBM with it
+static int stage_exotic(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_batch* db, hipStream_t st) {
+    if (b->n_exotic <= 0) return FASTP_GPU_OK;
+    if (b->exotic_dense) return fail(ctx, FASTP_GPU_E_INVALID, "exotic_dense describes text that is already in HBM (fastp_gpu_submit_device)");
+    const int mates = ctx->dp.paired ? 2 : 1;
+    for (int m = 0; m < mates; m++) {
+        if (!b->exotic_text[m] || !b->exotic_off[m] || b->exotic_text_bytes[m] <= 0)
+            return fail(ctx, FASTP_GPU_E_INVALID, "n_exotic > 0 needs exotic_text, exotic_off and exotic_text_bytes");
+        int rc = ensure(ctx, &ctx->d_x_text[m], &ctx->x_text_cap[m], (size_t)b->exotic_text_bytes[m] + 16);
+        if (rc) return rc;
+        rc = ensure(ctx, &ctx->d_x_off[m], &ctx->x_off_cap[m], (size_t)b->n_exotic * 4);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_x_text[m], b->exotic_text[m], (size_t)b->exotic_text_bytes[m], hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_x_off[m], b->exotic_off[m], (size_t)b->n_exotic * 4, hipMemcpyHostToDevice, st));
+        db->exotic_text[m] = (const uint8_t*)ctx->d_x_text[m];
+        db->exotic_off[m] = (const uint32_t*)ctx->d_x_off[m];
+    }
+    return FASTP_GPU_OK;
+}
+
 extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, fastp_gpu_results* res) {
     if (!ctx || !b || !res) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
     if (b->n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "negative batch size");
@@ -2009,7 +2122,8 @@ extern "C" int fastp_gpu_submit_host(fastp_gpu_ctx* ctx, const fastp_gpu_batch* 
     if (ev_out) dr.adapter_events = (fastp_gpu_adapter_event*)take((size_t)res->adapter_events_capacity * sizeof(fastp_gpu_adapter_event));
     else { dr.adapter_events = nullptr; dr.adapter_events_capacity = 0; }
     dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
-    rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
+    rc = stage_exotic(ctx, b, &db, st);
+    if (!rc) rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
     if (!rc) rc = join_aux(ctx, st);   // the duplicate flags of the last launch
     if (rc) {   // copies from the caller's pinned buffers are queued: they must have drained before the caller may reuse them
         (void)hipStreamSynchronize(st);
@@ -2111,7 +2225,8 @@ extern "C" int fastp_gpu_submit_host_async(fastp_gpu_ctx* ctx, const fastp_gpu_b
     dr.n_corrections = (int32_t*)take(sizeof(int32_t));
     if (ev_cap) { dr.adapter_events = (fastp_gpu_adapter_event*)take(ev_cap * sizeof(fastp_gpu_adapter_event)); dr.adapter_events_capacity = (int32_t)ev_cap; }
     dr.n_adapter_events = (int32_t*)take(sizeof(int32_t));
-    rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
+    rc = stage_exotic(ctx, b, &db, st);
+    if (!rc) rc = fastp_gpu_submit_device(ctx, &db, &dr, st);
     if (!rc) rc = join_aux(ctx, st);   // the duplicate flags of the last launch
     if (rc) {   // copies from the caller's pinned buffers are queued: they must have drained before the caller may reuse them
         (void)hipStreamSynchronize(st);

@@ -511,9 +511,26 @@ inline uint64_t zero_bytes(uint64_t v) {   // 0x80 in every byte of v that is ze
 inline uint64_t bytes_equal(uint64_t v, unsigned char c) { return zero_bytes(v ^ (0x0101010101010101ull * c)); }
 }  // namespace
 
+static int pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
+                      const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
+                      int32_t* bad_read, uint8_t* exotic);
+
 int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
                          const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
                          int32_t* bad_read) {
+    return pack_reads(max_len, n, seqs, quals, lens, seq_out, qual_out, len_out, bad_read, nullptr);
+}
+
+int fastp_gpu_pack_reads_x(int max_len, int n, const char* const* seqs, const char* const* quals,
+                           const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
+                           int32_t* bad_read, uint8_t* exotic) {
+    if (!exotic) return FASTP_GPU_E_INVALID;
+    return pack_reads(max_len, n, seqs, quals, lens, seq_out, qual_out, len_out, bad_read, exotic);
+}
+
+static int pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
+                      const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out, uint16_t* len_out,
+                      int32_t* bad_read, uint8_t* exotic) {
     if (n < 0 || max_len <= 0 || !seqs || !quals || !lens || !seq_out || !qual_out || !len_out)
         return FASTP_GPU_E_INVALID;
     const size_t ss = fastp_gpu_seq_stride(max_len), qs = fastp_gpu_qual_stride(max_len);
@@ -534,13 +551,15 @@ int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char
             // quality in '!'..'~': q - 33 does not borrow and q + 1 does not reach bit 7
             const uint64_t qbad = ((qq | 0x8080808080808080ull) - 0x2121212121212121ull) ^ 0x8080808080808080ull;   // bit 7 set <=> q < 33 (for q < 128)
             const uint64_t qhigh = (qq | ((qq & 0x7F7F7F7F7F7F7F7Full) + 0x0101010101010101ull)) & 0x8080808080808080ull;   // q >= 127
-            if ((((~known) | (qbad & 0x8080808080808080ull) | qhigh) & 0x8080808080808080ull & live) != 0) {
+            const uint64_t foreign = ~known & 0x8080808080808080ull & live;
+            if (((((qbad & 0x8080808080808080ull) | qhigh) & 0x8080808080808080ull & live) != 0) || (foreign && !exotic)) {
                 if (bad_read) *bad_read = i;
                 return FASTP_GPU_E_ALPHABET;
             }
+            if (foreign) exotic[i] = 1;   // the unit goes through the text kernel (fq_exact.h); its packed row is a placeholder
             uint64_t code = (c >> 1) & 0x0303030303030303ull;
             code = ((code >> 1) | (code << 1)) & 0x0303030303030303ull;   // swap the two bits: A 0, T 1, C 2, G 3
-            code &= ~((isn >> 7) * 3ull);                                 // an N is code 0
+            code &= ~(((isn | foreign) >> 7) * 3ull);                     // an N (and a foreign letter) is code 0
             code &= live;
             // gather the eight 2-bit codes into 16 bits
             code = (code | (code >> 6)) & 0x000F000F000F000Full;

@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_deflate_bgzf", "fastp_gpu_device_alloc", "fastp_gpu_device_free", "fastp_gpu_device_upload", "fastp_gpu_device_download", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_pack_reads_x", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_deflate_bgzf", "fastp_gpu_device_alloc", "fastp_gpu_device_free", "fastp_gpu_device_upload", "fastp_gpu_device_download", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",
@@ -68,6 +68,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.fastp_gpu_pack_reads.restype = C.c_int
     L.fastp_gpu_pack_reads.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.fastp_gpu_pack_reads_x.restype = C.c_int
+    L.fastp_gpu_pack_reads_x.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
     L.fastp_gpu_submit_host.restype = C.c_int
     L.fastp_gpu_submit_host.argtypes = [C.c_void_p, C.POINTER(abi.Batch), C.POINTER(abi.Results)]
     L.fastp_gpu_submit_device.restype = C.c_int
@@ -94,8 +97,9 @@ def counter_layout(params: abi.Params, lib=None) -> abi.CounterLayout:
     return lay
 
 
-def pack_ascii(lib, max_len, seq, qual, lens):
-    """ASCII rows [n, stride] -> packed rows via the library's host packer."""
+def pack_ascii(lib, max_len, seq, qual, lens, exotic=None):
+    """ASCII rows [n, stride] -> packed rows via the library's host packer.  `exotic`: uint8 [n], gets 1 where a read
+    holds a letter outside ACGTN (fastp_gpu_pack_reads_x); without it such a read is an error."""
     n = int(len(lens))
     ss, qs = int(lib.fastp_gpu_seq_stride(max_len)), int(lib.fastp_gpu_qual_stride(max_len))
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -108,8 +112,12 @@ def pack_ascii(lib, max_len, seq, qual, lens):
     qo = np.zeros((n, qs), dtype=np.uint8)
     lo = np.zeros(n, dtype=np.uint16)
     bad = C.c_int32(-1)
-    rc = lib.fastp_gpu_pack_reads(max_len, n, sp.ctypes.data, qp.ctypes.data, lens32.ctypes.data, so.ctypes.data,
-                                  qo.ctypes.data, lo.ctypes.data, C.byref(bad))
+    if exotic is not None:
+        rc = lib.fastp_gpu_pack_reads_x(max_len, n, sp.ctypes.data, qp.ctypes.data, lens32.ctypes.data, so.ctypes.data,
+                                        qo.ctypes.data, lo.ctypes.data, C.byref(bad), exotic.ctypes.data)
+    else:
+        rc = lib.fastp_gpu_pack_reads(max_len, n, sp.ctypes.data, qp.ctypes.data, lens32.ctypes.data, so.ctypes.data,
+                                      qo.ctypes.data, lo.ctypes.data, C.byref(bad))
     if rc != 0:
         raise EngineError(rc, f"fastp_gpu_pack_reads failed at read {bad.value}")
     return so, qo, lo
@@ -144,7 +152,9 @@ class GpuEngine:
             raise EngineError(rc, (self.lib.fastp_gpu_last_error(self.h) or b"").decode())
 
     # -- packed host buffers -> results (H2D + kernels + D2H) ---------------------------------
-    def submit_packed(self, s1, q1, l1, s2=None, q2=None, l2=None, flags=abi.BATCH_STAT_ISIZE, corr_capacity=None):
+    def submit_packed(self, s1, q1, l1, s2=None, q2=None, l2=None, flags=abi.BATCH_STAT_ISIZE, corr_capacity=None, exotic=None):
+        # exotic: (units int32 ascending, [text1, text2], [off1, off2]) - the raw sequence bytes of the units with letters
+        # outside ACGTN (fastp_gpu_batch.exotic_*)
         n = int(len(l1))
         paired = s2 is not None
         r1 = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
@@ -159,6 +169,14 @@ class GpuEngine:
         b.seq1, b.qual1, b.len1 = s1.ctypes.data, q1.ctypes.data, l1.ctypes.data
         if paired:
             b.seq2, b.qual2, b.len2 = s2.ctypes.data, q2.ctypes.data, l2.ctypes.data
+        if exotic is not None and len(exotic[0]):
+            xu, xt, xo = exotic
+            b.n_exotic = len(xu)
+            b.exotic_unit = xu.ctypes.data
+            for m in range(2 if paired else 1):
+                b.exotic_text[m] = xt[m].ctypes.data
+                b.exotic_off[m] = xo[m].ctypes.data
+                b.exotic_text_bytes[m] = xt[m].nbytes
         res = abi.Results()
         res.r1 = r1.ctypes.data
         res.r2 = r2.ctypes.data if paired else None
@@ -181,11 +199,21 @@ class GpuEngine:
     # -- ASCII rows (what the FASTQ decoder produces) -> results -------------------------------
     def process(self, seq1, qual1, len1, seq2=None, qual2=None, len2=None, flags=abi.BATCH_STAT_ISIZE):
         ml = self.params.max_len
-        s1, q1, l1 = pack_ascii(self.lib, ml, seq1, qual1, len1)
+        n = int(len(len1))
+        mask = np.zeros(n, dtype=np.uint8)
+        s1, q1, l1 = pack_ascii(self.lib, ml, seq1, qual1, len1, mask)
+        s2 = q2 = l2 = None
         if seq2 is not None:
-            s2, q2, l2 = pack_ascii(self.lib, ml, seq2, qual2, len2)
-            return self.submit_packed(s1, q1, l1, s2, q2, l2, flags)
-        return self.submit_packed(s1, q1, l1, flags=flags)
+            s2, q2, l2 = pack_ascii(self.lib, ml, seq2, qual2, len2, mask)
+        exotic = None
+        if mask.any():   # letters outside ACGTN: the units' raw rows travel with the batch
+            xu = np.flatnonzero(mask).astype(np.int32)
+            rows = [np.ascontiguousarray(np.asarray(a, dtype=np.uint8)[xu]) for a in ((seq1, seq2) if seq2 is not None else (seq1,))]
+            offs = [(np.arange(len(xu), dtype=np.uint32) * np.uint32(r.shape[1])) for r in rows]
+            exotic = (xu, rows, offs)
+        if seq2 is not None:
+            return self.submit_packed(s1, q1, l1, s2, q2, l2, flags, exotic=exotic)
+        return self.submit_packed(s1, q1, l1, flags=flags, exotic=exotic)
 
     # -- device-resident batches (bench / multi-GPU hosts) ---------------------------------------
     def submit_device(self, batch: abi.Batch, results: abi.Results, stream=None):

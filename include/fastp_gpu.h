@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FASTP_GPU_ABI_VERSION 3
+#define FASTP_GPU_ABI_VERSION 4
 
 /* ---- limits ------------------------------------------------------------ */
 #define FASTP_GPU_MAX_READ_LEN 512    /* padded read length the kernels tile in LDS */
@@ -176,6 +176,21 @@ typedef struct fastp_gpu_batch {
     const uint8_t* seq2;        /* PE only                                        */
     const uint8_t* qual2;
     const uint16_t* len2;
+    /* ---- units with letters outside ACGTN ("exotic" units; ABI v4) --------------------------------
+     * The packed rows cannot carry such a byte, and the reference treats it differently in nearly every
+     * consumer: `base & 7` bins in Stats::statRead (stats.cpp:206-222), hash value 13 (duplicate.cpp:92-109),
+     * a/c/g/t complement to T/G/C/A and everything else to N (util.h:16-33), raw-byte compares in the overlap
+     * analysis, adapter matching, polyG / polyX and the complexity filter, only a literal 'N' counts as N.
+     * The packer (fastp_gpu_pack_reads_x / fastp_gpu_parse_fastq) stores such a letter as code 0 WITHOUT the N
+     * flag and names the unit; the engine runs the listed units - and a few of their neighbours - through a
+     * kernel that works on the text itself.  All zero / NULL: no such unit (what a zeroed struct says). */
+    int32_t n_exotic;               /* units listed in exotic_unit                                        */
+    int32_t exotic_dense;           /* 1: exotic_off[m] is fastp_gpu_parse_fastq's line_off table of mate m
+                                     * (entry [4 * unit + 1] = the sequence line); 0: one entry per listed unit */
+    const int32_t* exotic_unit;     /* HOST memory (always): n_exotic ascending unit indexes              */
+    const uint8_t* exotic_text[2];  /* same memory space as seq1: text holding the listed units' sequence bytes of mate m */
+    const uint32_t* exotic_off[2];  /* same memory space: byte offset of each listed unit's sequence in exotic_text[m]     */
+    int64_t exotic_text_bytes[2];   /* host submits: size of exotic_text[m] (it is copied to the device)  */
 } fastp_gpu_batch;
 
 /* the reference only samples insert size on worker thread 0
@@ -328,6 +343,12 @@ const char* fastp_gpu_last_error(const fastp_gpu_ctx* ctx); /* ctx may be NULL *
 int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
                          const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out,
                          uint16_t* len_out, int32_t* bad_read);
+/* The same, but a letter outside {A,C,G,T,N} is not an error: the read's entry of exotic[n] (caller-zeroed) is set
+ * to 1, the letter is stored as code 0 without the N flag, and the caller lists the unit in the batch's exotic_* fields
+ * (fastp_gpu_batch) with its raw sequence bytes.  Quality characters outside '!'..'~' stay an error. */
+int fastp_gpu_pack_reads_x(int max_len, int n, const char* const* seqs, const char* const* quals,
+                           const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out,
+                           uint16_t* len_out, int32_t* bad_read, uint8_t* exotic);
 
 /* ---- FASTQ text -> packed batch ON THE DEVICE -----------------------
  * The step before the path: FastqReader::getLine / read (src/fastqreader.cpp:240-368) + the

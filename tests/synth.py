@@ -20,8 +20,13 @@ def _adapter_pad(adapter, L):
 
 def synth_pairs(n, L=150, seed=42, insert_mean=300.0, insert_sd=80.0, insert_min=20, insert_max=800,
                 polyg_frac=0.0, polyx_frac=0.0, dup_frac=0.10, ragged_frac=0.02, n_rate=0.5,
-                lowq_site_rate=0.03, paired=True, gen=None, adapters=None):
+                lowq_site_rate=0.03, paired=True, gen=None, adapters=None, exotic_frac=0.0):
     """returns dict(seq1,qual1,len1[,seq2,qual2,len2]) as ASCII uint8 [n, stride] + int32 lens"""
+    if exotic_frac > 0:   # letters outside ACGTN on top of whatever the other arguments produce
+        d = synth_pairs(n, L=L, seed=seed, insert_mean=insert_mean, insert_sd=insert_sd, insert_min=insert_min, insert_max=insert_max,
+                        polyg_frac=polyg_frac, polyx_frac=polyx_frac, dup_frac=dup_frac, ragged_frac=ragged_frac, n_rate=n_rate,
+                        lowq_site_rate=lowq_site_rate, paired=paired, gen=gen, adapters=adapters)
+        return add_exotic(d, seed=seed, read_frac=exotic_frac, paired=paired)
     if gen == "indel_overlap":   # parity cases that need single-base indels (the one-gap ACCEPT paths)
         return indel_overlap_pairs(n, L=L, seed=seed)
     if gen == "adapter_indel":
@@ -105,6 +110,39 @@ def synth_pairs(n, L=150, seed=42, insert_mean=300.0, insert_sd=80.0, insert_min
         outs["qual" + tag] = qual
         outs["len" + tag] = lens
     return outs
+
+
+def add_exotic(d, seed=1, read_frac=0.12, paired=True):
+    """Letters outside ACGTN in a fraction of the reads (in place): soft-masked (lower-case) stretches and whole reads,
+    IUPAC codes, '.' - what the reference bins by `base & 7` (stats.cpp:206-208), hashes as 13, complements to N ..."""
+    rng = np.random.default_rng(seed + 977)
+    iupac = np.frombuffer(b"RYKMSWBDHVryn.uX-", dtype=np.uint8)
+    for tag in ("1", "2") if paired else ("1",):
+        seq, lens = d["seq" + tag], d["len" + tag]
+        for i in np.flatnonzero(rng.random(len(lens)) < read_frac):
+            L = int(lens[i])
+            if L == 0:
+                continue
+            kind = int(rng.integers(0, 5))
+            if kind == 0:     # a soft-masked stretch
+                a = int(rng.integers(0, L))
+                b = min(L, a + int(rng.integers(1, 60)))
+                seq[i, a:b] |= 0x20
+            elif kind == 1:   # the whole read in lower case
+                seq[i, :L] |= 0x20
+            elif kind == 2:   # a few IUPAC / foreign letters
+                pos = rng.integers(0, L, size=int(rng.integers(1, 6)))
+                seq[i, pos] = iupac[rng.integers(0, len(iupac), size=len(pos))]
+            elif kind == 3:   # '.' for no-calls, also where an N was
+                pos = np.flatnonzero(seq[i, :L] == ord("N"))
+                if len(pos) == 0:
+                    pos = rng.integers(0, L, size=2)
+                seq[i, pos] = ord(".")
+            else:             # a foreign letter at the ends (trimming, polyX, adapter matching look there first)
+                seq[i, L - 1] = iupac[int(rng.integers(0, len(iupac)))]
+                if rng.random() < 0.5:
+                    seq[i, 0] = iupac[int(rng.integers(0, len(iupac)))]
+    return d
 
 
 def noisy_reads(n, L=150, seed=1, paired=True, n_rate=0.06, qlo=2, qhi=41):
