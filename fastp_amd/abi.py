@@ -175,7 +175,7 @@ def adapter_fasta_list(params):
 
 class ParseInfo(C.Structure):
     _fields_ = [("n_records", C.c_int32), ("first_bad", C.c_int32), ("consumed", C.c_int64), ("n_lines", C.c_int64),
-                ("bad_kind", C.c_int32), ("max_seq_len", C.c_int32)]
+                ("bad_kind", C.c_int32), ("max_seq_len", C.c_int32), ("n_exotic", C.c_int32), ("reserved", C.c_int32)]
 
 
 class InflateInfo(C.Structure):

@@ -253,6 +253,7 @@ struct fastp_gpu_ctx {
     int* d_x_unit = nullptr; size_t x_unit_cap = 0;        // the submitted batch's exotic unit list
     void* d_x_text[2] = {nullptr, nullptr}; size_t x_text_cap[2] = {0, 0};   // host submits: the raw text + offsets staged in HBM
     void* d_x_off[2] = {nullptr, nullptr}; size_t x_off_cap[2] = {0, 0};
+    std::vector<int32_t> parse_exotic;                     // records of the last fastp_gpu_parse_fastq call with letters outside ACGTN
     // staging for submit_host
     void* d_stage = nullptr; size_t stage_cap = 0;
     // fastp_gpu_submit_host_async: device staging, completion event and what to finish per slot
@@ -1481,7 +1482,7 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     p.line_len = line_len;
     const int per_block = PARSE_BLOCK * PARSE_BYTES_PER_LANE * PARSE_SUB;
     const int nblocks = (int)((nbytes + per_block - 1) / per_block);
-    const size_t dwords = 8 + (size_t)2 * nblocks + p.max_lines + (p.max_lines + 3) / 4;
+    const size_t dwords = 8 + (size_t)2 * nblocks + p.max_lines + (p.max_lines + 3) / 4 + 4 + (size_t)max_records;
     int rc = ensure(ctx, (void**)&ctx->d_parse, &ctx->parse_cap, dwords * 4);
     if (rc) return rc;
     p.totals = ctx->d_parse;
@@ -1489,6 +1490,9 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     p.blockbase = p.blockcount + nblocks;
     p.term_pos = p.blockbase + nblocks;
     p.term_len = (u8*)(p.term_pos + p.max_lines);
+    p.exotic_list = p.term_pos + p.max_lines + (p.max_lines + 3) / 4 + 1;
+    p.exotic_cap = (u32)max_records;
+    ctx->parse_exotic.clear();
     const u32 init[8] = {0, 0xFFFFFFFFu, 0, 0, 0, 0, 0, 0};
     HIP_TRY(ctx, hipMemcpyAsync(p.totals, init, sizeof(init), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(fq_parse_count_kernel, dim3(nblocks), dim3(PARSE_BLOCK), 16, st, p);
@@ -1517,12 +1521,26 @@ extern "C" int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, in
     info->first_bad = totals[1] == 0xFFFFFFFFu ? -1 : (int32_t)(totals[1] >> 2);
     info->bad_kind = totals[1] == 0xFFFFFFFFu ? 0 : (int32_t)(totals[1] & 3u);
     info->max_seq_len = (int32_t)totals[5];
+    if (totals[6] > 0 && nrec > 0) {   // records with letters outside ACGTN: their indexes, ascending (fastp_gpu_parse_exotic)
+        const u32 cnt = std::min(totals[6], p.exotic_cap);
+        ctx->parse_exotic.resize(cnt);
+        HIP_TRY(ctx, hipMemcpy(ctx->parse_exotic.data(), p.exotic_list, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        std::sort(ctx->parse_exotic.begin(), ctx->parse_exotic.end());
+    }
+    info->n_exotic = (int32_t)ctx->parse_exotic.size();
     if (info->first_bad >= 0)
         return fail(ctx, FASTP_GPU_E_INVALID,
                     info->bad_kind == FASTP_GPU_PARSE_BAD_TOO_LONG ? "a read of the chunk is longer than the context's max_len (see first_bad, max_seq_len)"
-                    : info->bad_kind == FASTP_GPU_PARSE_BAD_ALPHABET ? "a record of the chunk has a letter outside ACGTN or a quality character outside '!'..'~' (see first_bad)"
+                    : info->bad_kind == FASTP_GPU_PARSE_BAD_ALPHABET ? "a record of the chunk has a quality character outside '!'..'~' (see first_bad)"
                                                                      : "malformed FASTQ record in the chunk (see first_bad)");
     return FASTP_GPU_OK;
+}
+
+extern "C" int32_t fastp_gpu_parse_exotic(const fastp_gpu_ctx* ctx, int32_t* units, int32_t capacity) {
+    if (!ctx) return 0;
+    const int32_t n = (int32_t)ctx->parse_exotic.size();
+    for (int32_t k = 0; units && k < n && k < capacity; k++) units[k] = ctx->parse_exotic[k];
+    return n;
 }
 
 // BgzfMtReader::readerLoop's header walk (src/bgzf.h:29-32, 150-200): gzip member header with the BC extra

@@ -3378,7 +3378,7 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
     const u8* qp = p.text + start[3];
     u32* qrow = p.qual_out + (size_t)rr * p.qw_g;
     u8* srow = (u8*)(p.seq_out + (size_t)rr * p.sw_g);
-    bool alpha_bad = false;
+    bool alpha_bad = false, foreign = false;
     const int ncol = p.qw_g > p.sw_g * 4 ? p.qw_g : p.sw_g * 4;
     for (int c = gl; c < ncol; c += PACK_GROUP) {
         u32 qd = 0, sb = 0;
@@ -3405,8 +3405,12 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
             // unsigned field of a packed counter, the reference adds a negative long (stats.cpp:223,226)
             const u32 q_lt33 = ~(((qw & 0x7F7F7F7Fu) | 0x80808080u) - 0x21212121u) & 0x80808080u;
             const u32 q_127 = zero_bytes(qw ^ 0x7F7F7F7Fu);
-            if ((~(is_letter | is_n) & live) | (qw & 0x80808080u) | ((q_lt33 | q_127) & live)) alpha_bad = true;
-            const u32 codes = code & ~(is_n >> 7) & ~(is_n >> 6);  // N packs as code 0
+            if ((qw & 0x80808080u) | ((q_lt33 | q_127) & live)) alpha_bad = true;
+            // a letter outside ACGTN: the record is listed for the text kernel (fq_exact.h) - its packed row is a placeholder
+            const u32 fm = ~(is_letter | is_n) & live;
+            if (fm) foreign = true;
+            const u32 zero = is_n | fm;
+            const u32 codes = code & ~(zero >> 7) & ~(zero >> 6);  // N (and a foreign letter) packs as code 0
             sb = (codes & 3u) | ((codes >> 6) & 0xCu) | ((codes >> 12) & 0x30u) | ((codes >> 18) & 0xC0u);
             qd = (qw & 0x7F7F7F7Fu) | is_n;
         }
@@ -3415,6 +3419,11 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
     }
     const bool any_bad = ((ballot(alpha_bad) >> gmask_shift) & 0xFFFFull) != 0ull || bad;
     if (have && any_bad && gl == 0) g_atomic_min_u32(&p.totals[1], ((u32)r << 2) | (kind ? kind : (u32)PARSE_BAD_ALPHABET));
+    const bool any_foreign = ((ballot(foreign) >> gmask_shift) & 0xFFFFull) != 0ull;
+    if (have && any_foreign && !any_bad && gl == 0) {
+        const u32 slot = g_atomic_add_u32(&p.totals[6], 1u);
+        if (slot < p.exotic_cap) p.exotic_list[slot] = (u32)r;
+    }
 }
 
 

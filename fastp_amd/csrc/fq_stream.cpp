@@ -749,6 +749,7 @@ int run_loop(Run* R) {
         memset(info, 0, sizeof(info));
         int n = 0;
         int32_t first_n[2] = {0, 0};   // complete records each file's text of this trip holds (up to cap)
+        std::vector<int32_t> exotic[2];
         bool stop_after = false;
         t0 = now_s();
         for (int attempt = 0;; attempt++) {
@@ -761,7 +762,12 @@ int run_loop(Run* R) {
                     if (pass == 1 && info[m].n_records == want) continue;
                     const int prc = fastp_gpu_parse_fastq(s->ctx, s->d_text[slot][m], total[m], d.eof[m] ? 1 : 0, want, s->d_seq[m], s->d_qual[m], s->d_len[m],
                                                           s->d_loff[m], s->d_llen[m], &info[m]);
-                    if (prc == FASTP_GPU_OK) { if (pass == 0) first_n[m] = info[m].n_records; continue; }
+                    if (prc == FASTP_GPU_OK) {
+                        if (pass == 0) first_n[m] = info[m].n_records;
+                        exotic[m].resize((size_t)info[m].n_exotic);   // records with letters outside ACGTN, for the text kernel
+                        if (info[m].n_exotic) fastp_gpu_parse_exotic(s->ctx, exotic[m].data(), info[m].n_exotic);
+                        continue;
+                    }
                     if (prc != FASTP_GPU_E_INVALID || info[m].first_bad < 0) return s->fail_ctx(prc, "fastp_gpu_parse_fastq");
                     if (info[m].bad_kind == FASTP_GPU_PARSE_BAD_TOO_LONG) {
                         const int rc = replan(s, info[m].max_seq_len);
@@ -769,7 +775,7 @@ int run_loop(Run* R) {
                         again = true;
                     } else if (info[m].bad_kind == FASTP_GPU_PARSE_BAD_ALPHABET) {
                         return s->fail(FASTP_GPU_E_ALPHABET, "record " + std::to_string(s->st.units + info[m].first_bad) + " of file " + std::to_string(m + 1) +
-                                                                 " has a letter outside ACGTN or a quality character outside '!'..'~'");
+                                                                 " has a quality character outside '!'..'~'");
                     } else {   // FastqReader::read returns NULL there: the stream ends in front of this record
                         cap = info[m].first_bad;
                         s->st.truncated = 1;
@@ -832,13 +838,26 @@ int run_loop(Run* R) {
             b.flags = FASTP_GPU_BATCH_STAT_ISIZE;
             b.seq1 = s->d_seq[0]; b.qual1 = s->d_qual[0]; b.len1 = s->d_len[0];
             if (s->paired) { b.seq2 = s->d_seq[1]; b.qual2 = s->d_qual[1]; b.len2 = s->d_len[1]; }
+            std::vector<int32_t> xunits;   // units with letters outside ACGTN in either mate: the engine reads their text in place
+            for (int m = 0; m < nm; m++)
+                for (int32_t u : exotic[m])
+                    if (u < n) xunits.push_back(u);
+            if (!xunits.empty()) {
+                std::sort(xunits.begin(), xunits.end());
+                xunits.erase(std::unique(xunits.begin(), xunits.end()), xunits.end());
+                b.n_exotic = (int32_t)xunits.size();
+                b.exotic_dense = 1;
+                b.exotic_unit = xunits.data();
+                for (int m = 0; m < nm; m++) { b.exotic_text[m] = s->d_text[slot][m]; b.exotic_off[m] = s->d_loff[m]; }
+            }
             fastp_gpu_results r;
             memset(&r, 0, sizeof(r));
             r.r1 = s->d_res[0];
             if (s->paired) { r.r2 = s->d_res[1]; r.pair = s->d_pair; }
             r.corrections = s->d_corr; r.corrections_capacity = s->corr_cap; r.n_corrections = s->d_nc;
             r.adapter_events = s->d_ev; r.adapter_events_capacity = s->ev_cap; r.n_adapter_events = s->d_nev;
-            if (fastp_gpu_submit_device(s->ctx, &b, &r, nullptr) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_submit_device");
+            const int src = fastp_gpu_submit_device(s->ctx, &b, &r, nullptr);
+            if (src != FASTP_GPU_OK) return s->fail_ctx(src == FASTP_GPU_E_ALPHABET ? src : FASTP_GPU_E_HIP, "fastp_gpu_submit_device");
             if (fastp_gpu_synchronize(s->ctx) != FASTP_GPU_OK) return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_synchronize");
             s->st.engine_s += now_s() - t0;
             // ---- the sparse lists' fill counts and, for the adapter replay, the records come to the host ----

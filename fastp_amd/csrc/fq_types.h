@@ -234,7 +234,10 @@ struct ParseArgs {
     u32* term_pos;        // [max_lines] offset of the terminator that ends line k
     u8* term_len;         // [max_lines] 1 or 2 ("\r\n")
     u32 max_lines;
-    u32* totals;          // [0] terminators, [1] first bad record (atomic min), [2] lines incl. unterminated tail
+    u32* totals;          // [0] terminators, [1] first bad record (atomic min), [2] lines incl. unterminated tail,
+                          // [3] records, [4] bytes consumed, [5] longest sequence line, [6] records with letters outside ACGTN
+    u32* exotic_list;     // [exotic_cap] those records (unordered), for the text kernel (fq_exact.h)
+    u32 exotic_cap;
     // packing
     int max_len, sw_g, qw_g, max_records;
     u32* seq_out;

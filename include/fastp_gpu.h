@@ -362,14 +362,16 @@ int fastp_gpu_pack_reads_x(int max_len, int n, const char* const* seqs, const ch
  * All pointers except `info` are DEVICE pointers; synchronous. */
 #define FASTP_GPU_PARSE_BAD_MALFORMED 1 /* what FastqReader::read refuses (:338-362): the reference stops reading there      */
 #define FASTP_GPU_PARSE_BAD_TOO_LONG 2  /* well formed, but longer than the context's max_len: re-plan with max_seq_len     */
-#define FASTP_GPU_PARSE_BAD_ALPHABET 3  /* well formed, a letter outside ACGTN / a quality character outside '!'..'~'        */
+#define FASTP_GPU_PARSE_BAD_ALPHABET 3  /* well formed, a quality character outside '!'..'~' (a letter outside ACGTN is no error: n_exotic) */
 typedef struct fastp_gpu_parse_info {
     int32_t n_records;   /* records packed                                              */
-    int32_t first_bad;   /* index of the first malformed / over-long / non-ACGTN / quality outside '!'..'~' record, or -1 */
+    int32_t first_bad;   /* index of the first malformed / over-long / quality outside '!'..'~' record, or -1           */
     int64_t consumed;    /* bytes of text the records cover (offset of the next record)  */
     int64_t n_lines;     /* line terminators seen (+1 for an unterminated last line)     */
     int32_t bad_kind;    /* FASTP_GPU_PARSE_BAD_* of record first_bad, 0 when there is none (ABI v3)                */
     int32_t max_seq_len; /* the longest sequence line among the well-formed records looked at (ABI v3)              */
+    int32_t n_exotic;    /* records with a letter outside ACGTN (ABI v4): not an error - fastp_gpu_parse_exotic lists  */
+    int32_t reserved;    /* them, and the batch built from this chunk names them in its exotic_* fields              */
 } fastp_gpu_parse_info;
 
 int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbytes, int is_last_chunk,
@@ -378,6 +380,11 @@ int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbyte
                           uint32_t* line_off,  /* [4*max_records] offset of each record line in `text`      */
                           uint32_t* line_len,  /* [4*max_records] its length without the terminator        */
                           fastp_gpu_parse_info* info);
+/* The records of the LAST fastp_gpu_parse_fastq call on this context that hold a letter outside ACGTN
+ * (info->n_exotic of them): ascending record indexes into units[0, capacity); returns their number.
+ * They go into fastp_gpu_batch::exotic_unit (the union of both mates' lists for paired input), with
+ * exotic_dense = 1, exotic_text[m] = the chunk and exotic_off[m] = its line_off table. */
+int32_t fastp_gpu_parse_exotic(const fastp_gpu_ctx* ctx, int32_t* units, int32_t capacity);
 
 /* ---- BGZF-compressed FASTQ -> text ON THE DEVICE ----------------------
  * The reference reads a bgzip-written .gz with BgzfMtReader (src/bgzf.h:36-239): a reader thread

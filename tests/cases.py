@@ -98,6 +98,22 @@ CASES["pe_merge_overlapped_out_trims"] = (True, ["-G", "-m", "--include_unmerged
                                           _pe(merge=1, correction=1, merge_include_unmerged=1, overlapped_out=1, poly_x=1, max_len1=120,
                                               max_len2=100, cut_front=1, trim_front1=2, trim_front2=2),
                                           {"insert_mean": 170.0, "polyx_frac": 0.2})
+# letters outside ACGTN: soft-masked stretches and reads, IUPAC codes, '.' - the reference
+# bins them by `base & 7`, hashes them as 13, complements a/c/g/t to T/G/C/A and the rest to N, compares raw bytes
+# everywhere else; the engine runs those units through the text kernel (fq_exact.h)
+CASES["pe_exotic_default"] = (True, ["-G", "--cut_right", "--overlapped_out", "@TMP@/overlapped.fq"], _pe(cut_right=1, overlapped_out=1),
+                              {"insert_mean": 190.0, "exotic_frac": 0.12})
+CASES["pe_exotic_merge"] = (True, ["-G", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq", "-x", "-y", "--cut_front", "--cut_tail"],
+                            _pe(merge=1, correction=1, merge_include_unmerged=1, poly_x=1, complexity_filter=1, cut_front=1, cut_tail=1),
+                            {"insert_mean": 200.0, "polyx_frac": 0.15, "exotic_frac": 0.15})
+CASES["pe_exotic_dedup_adapters"] = (True, ["-g", "--dedup", "-c", "--allow_gap_overlap_trimming", "--adapter_sequence", ADAPTER_R1,
+                                            "--adapter_sequence_r2", ADAPTER_R2],
+                                     _pe(dedup=1, dup_accuracy_level=3, correction=1, allow_gap_overlap_trimming=1, poly_g=1,
+                                         adapter_seq_r1=ADAPTER_R1.encode(), adapter_seq_r2=ADAPTER_R2.encode()),
+                                     {"insert_mean": 140.0, "insert_sd": 50.0, "polyg_frac": 0.1, "dup_frac": 0.3, "exotic_frac": 0.12})
+CASES["se_exotic_adapter"] = (False, ["-G", "-a", ADAPTER_R1, "-x", "-y", "--cut_right", "-U", "--umi_loc", "read1", "--umi_len", "6"],
+                              _se(adapter_seq_r1=ADAPTER_R1.encode(), poly_x=1, complexity_filter=1, cut_right=1, umi_len1=6),
+                              {"insert_mean": 120.0, "polyx_frac": 0.2, "exotic_frac": 0.15})
 
 # adapters longer than 64 bases (the engine's cap is FASTP_GPU_MAX_ADAPTER_LEN = 256): the read-through of the
 # synthetic reads is adapter + poly-A, so these match over their whole length
@@ -199,6 +215,7 @@ FILES = {"pe_adapter_fasta": {"adapters.fa": FASTA_FILE}, "se_adapter_fasta": {"
 UMI = {
     "pe_umi_per_read": ("per_read", 6),
     "se_umi_read1": ("read1", 8),
+    "se_exotic_adapter": ("read1", 6),
 }
 
 

@@ -118,7 +118,8 @@ def test_sim_one_gap_accept_paths(name):
 
 
 @pytest.mark.parametrize("name", ["pe_default", "pe_correction", "se_adapter_cut", "testdata_pe", "pe_overlapped_out_trims",
-                                  "pe_merge_overlapped_out", "pe_merge_overlapped_out_trims"])
+                                  "pe_merge_overlapped_out", "pe_merge_overlapped_out_trims",
+                                  "pe_exotic_default", "pe_exotic_merge", "pe_exotic_dedup_adapters", "se_exotic_adapter"])
 def test_sim_matches_reference_golden(name):
     fq1, fq2, meta = golden_util.load(name)
     params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)
