@@ -100,6 +100,11 @@ struct Window {
     std::atomic<long> next{-1};            // the window the slot serves next (slot, slot + NSLOT, ...): set by make_state / the free
     std::atomic<int> state{0};             // 0 filling, 1 submitted, 2 arrived
     int packs = 0;                         // packs in the submitted batch
+    // units with letters outside ACGTN: mask per row (the packing threads set it), their raw sequence bytes at row * max_len
+    std::vector<uint8_t> xmask, xraw[2];
+    std::atomic<int> xany{0};
+    std::vector<int32_t> xunit;
+    std::vector<uint32_t> xoff;
     fastp_gpu_batch batch;
     fastp_gpu_results res;
 };
@@ -115,6 +120,7 @@ struct ParamBlock {
 
 struct State {
     std::mutex mu;               // submission order = window order; also guards fastp_gpu_* calls that touch the stream
+    std::mutex xmu;              // first use of a window's raw-text rows (units with letters outside ACGTN)
     fastp_gpu_ctx* ctx = nullptr;
     ParamBlock B;
     fastp_gpu_counter_layout lay;
@@ -271,6 +277,7 @@ void make_state(Options* o, bool paired) {
         if (p.correction) { w.corr_cap = (int32_t)std::min<size_t>(units * 8 + 1024, (size_t)1 << 26); w.corr = (fastp_gpu_correction*)pinned((size_t)w.corr_cap * sizeof(fastp_gpu_correction)); }
         if (p.n_adapter_fasta) { w.ev_cap = (int32_t)(units * 2 * std::min(p.n_adapter_fasta, 8) + 16); w.ev = (fastp_gpu_adapter_event*)pinned((size_t)w.ev_cap * sizeof(fastp_gpu_adapter_event)); }
         w.count.assign((size_t)s->K, 0);
+        w.xmask.assign(units, 0);
     }
     for (int k = 0; k < NSLOT; k++) s->win[k].next.store(k);
     G = s;
@@ -355,6 +362,21 @@ void pump() {
         w.batch.flags = FASTP_GPU_BATCH_STAT_ISIZE;   // the `-w 1` semantics: every pair's insert size (the reference samples thread 0's packs)
         w.batch.seq1 = w.pseq[0]; w.batch.qual1 = w.pqual[0]; w.batch.len1 = w.plen[0];
         if (G->paired) { w.batch.seq2 = w.pseq[1]; w.batch.qual2 = w.pqual[1]; w.batch.len2 = w.plen[1]; }
+        if (w.xany.load(std::memory_order_acquire)) {
+            w.xunit.clear();
+            w.xoff.clear();
+            for (long u = 0; u < n; u++)
+                if (w.xmask[(size_t)u]) { w.xunit.push_back((int32_t)u); w.xoff.push_back((uint32_t)((size_t)u * (size_t)G->max_len)); }
+            w.batch.n_exotic = (int32_t)w.xunit.size();
+            w.batch.exotic_unit = w.xunit.data();
+            for (int m = 0; m < (G->paired ? 2 : 1); m++) {
+                w.batch.exotic_text[m] = w.xraw[m].data();
+                w.batch.exotic_off[m] = w.xoff.data();
+                w.batch.exotic_text_bytes[m] = (int64_t)w.xraw[m].size();
+            }
+            std::fill(w.xmask.begin(), w.xmask.end(), 0);
+            w.xany.store(0, std::memory_order_relaxed);
+        }
         memset(&w.res, 0, sizeof(w.res));
         w.res.r1 = w.rr[0];
         if (G->paired) { w.res.r2 = w.rr[1]; w.res.pair = w.pr; }
@@ -473,9 +495,21 @@ int drain_ready(int tid, Emit emit, Recycle recycle) {
 bool pack_into(Window& w, size_t row, int n, bool paired) {
     for (int m = 0; m < (paired ? 2 : 1); m++) {
         int32_t bad = -1;
-        if (fastp_gpu_pack_reads(G->max_len, n, T.seq[m].data(), T.qual[m].data(), T.len[m].data(), w.pseq[m] + row * G->ss,
-                                 w.pqual[m] + row * G->qs, w.plen[m] + row, &bad) != FASTP_GPU_OK)
+        if (fastp_gpu_pack_reads_x(G->max_len, n, T.seq[m].data(), T.qual[m].data(), T.len[m].data(), w.pseq[m] + row * G->ss,
+                                   w.pqual[m] + row * G->qs, w.plen[m] + row, &bad, w.xmask.data() + row) != FASTP_GPU_OK)
             return false;
+    }
+    // letters outside ACGTN: the unit's text travels with the batch (fastp_gpu_batch::exotic_*), the engine's text kernel takes it
+    for (int i = 0; i < n; i++) {
+        if (!w.xmask[row + (size_t)i]) continue;
+        for (int m = 0; m < (paired ? 2 : 1); m++) {
+            if (w.xraw[m].empty()) {
+                std::lock_guard<std::mutex> lk(G->xmu);
+                if (w.xraw[m].empty()) w.xraw[m].assign((size_t)G->K * PACK_SIZE * (size_t)G->max_len, 0);
+            }
+            memcpy(w.xraw[m].data() + (row + (size_t)i) * (size_t)G->max_len, T.seq[m][(size_t)i], (size_t)T.len[m][(size_t)i]);
+        }
+        w.xany.store(1, std::memory_order_release);
     }
     return true;
 }
@@ -561,8 +595,8 @@ void note_total_se(SingleEndProcessor* sp, SingleProducerSingleConsumerList<Read
 }
 
 void refuse_pack() {
-    error_exit("FASTP_GPU=1: a pack holds reads the engine refuses (letters outside ACGTN, quality characters outside '!'..'~', or a read "
-               "longer than the evaluated read length); rerun without FASTP_GPU=1");
+    error_exit("FASTP_GPU=1: a pack holds reads the engine refuses (quality characters outside '!'..'~', or a read longer than the rows "
+               "pack mode sized - FASTP_GPU_MAX_LEN); rerun without FASTP_GPU=1");
 }
 
 int fastp_gpu_worker_pe(PairEndProcessor* pp, ReadPack* left, ReadPack* right, ThreadConfig* config) {

@@ -41,6 +41,11 @@ BINDING_CASES = {
     "pe_overlapped_out_trims": [],
     "pe_overlapped_out_noadapter": [],
     "pe_merge_overlapped_out_trims": [],
+    # letters outside ACGTN (soft-masked stretches, IUPAC codes, '.'): the text kernel, through both bindings
+    "pe_exotic_default": [],
+    "pe_exotic_merge": [],
+    "pe_exotic_dedup_adapters": [],
+    "se_exotic_adapter": [],
     "se_default_noadapter": [],
     "se_adapter_cut": [],
     "se_umi_read1": [],
@@ -150,7 +155,7 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     want_rep.pop("__stderr__")
     # which binding ran: the stream loop says so; --overlapped_out is pack mode's
     streamed = "fastp_gpu: stream mode:" in err
-    assert streamed == (mode == "stream" and "overlapped_out" not in name), err[-800:]
+    assert streamed == (mode == "stream" and not _overlapped_out(name)), err[-800:]
     if "overrep" in name:   # -p: the Evaluator's substring census ran on the device too (fastp_gpu_eval_overrep)
         assert err.count("computeOverRepSeq on the device") == (2 if paired else 1), err[-800:]
         if n >= 10000:   # (600 reads do not reach the count thresholds: both sides then agree on "none")
@@ -168,8 +173,12 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
 # on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
 # test_gpu_patched_reference_equals_reference; each costs seconds here because the emulator clears Duplicate's 1 GiB
 EMULATOR_CASES = ["pe_filters", "pe_noadapter_dedup", "pe_umi_per_read", "pe_adapter_fasta", "pe_overrep", "pe_allow_gap_indel",
-                  "pe_merge_overlapped_out_trims", "se_adapter_cut", "se_adapter_long_indel"]
+                  "pe_merge_overlapped_out_trims", "se_adapter_cut", "se_adapter_long_indel", "pe_exotic_merge", "pe_exotic_default"]
 assert all(n in BINDING_CASES for n in EMULATOR_CASES)
+
+
+def _overlapped_out(name):
+    return any("overlapped_out" in f for f in cases.CASES[name][1])
 
 
 @pytest.mark.parametrize("name", EMULATOR_CASES)
@@ -178,13 +187,13 @@ def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
     err = _check(name, REF_SIM, 600, tmp_path, seed=41)
-    if "overlapped_out" not in name:
+    if not _overlapped_out(name):
         import re
         m = re.search(r"stream mode: 600 units in (\d+) chunks", err)
         assert m and int(m.group(1)) >= 2, err[-600:]    # several trips, so partial records were carried
 
 
-@pytest.mark.parametrize("name", ["pe_correction", "pe_adapter_fasta", "pe_merge", "se_umi_read1"])
+@pytest.mark.parametrize("name", ["pe_correction", "pe_adapter_fasta", "pe_merge", "se_umi_read1", "pe_exotic_dedup_adapters", "se_exotic_adapter"])
 def test_patched_reference_pack_mode_on_emulator(name, tmp_path):
     """pack mode: the reference's own reader threads, the hook at the top of the worker-loop body"""
     if not _ensure_built() or not os.path.exists(REF_SIM):

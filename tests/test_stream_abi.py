@@ -111,9 +111,9 @@ def test_sim_stream_replans_and_limits(tmp_path):
     open(p2, "wb").write(b"\n".join(lines))
     d, ctr_d, lay_d, _, st_d = streamlib.run_files(lib, big, p1, p2, str(tmp_path), chunk_bytes=60000)
     assert st_d.truncated == 1 and st_d.units == 1234 and ctr_d[lay_d.stats[0] + lay_d.st_reads] == 1234
-    # a letter outside ACGTN: refused with the record named, nothing silently skipped
+    # a quality character outside '!'..'~': refused with the record named, nothing silently skipped
     lines = fq1.split(b"\n")
-    lines[4 * 50 + 1] = lines[4 * 50 + 1][:10] + b"r" + lines[4 * 50 + 1][11:]
+    lines[4 * 50 + 3] = lines[4 * 50 + 3][:10] + b" " + lines[4 * 50 + 3][11:]
     open(p1, "wb").write(b"\n".join(lines))
     open(p2, "wb").write(fq2)
     with pytest.raises(streamlib.StreamError) as e:
