@@ -150,6 +150,7 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs 
     fmts_write_body(f, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(64) fq_exact_kernel(ExactArgs e) { exact_body(e); }
+extern "C" __global__ void __launch_bounds__(256) fq_exact_mask_kernel(ExactMaskArgs m) { exact_mask_body(m); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_claim_kernel(DupArgs d) { dup_claim_body(d); }
@@ -251,6 +252,7 @@ struct fastp_gpu_ctx {
     bool exact_all = false;                                // FASTP_GPU_EXACT=1: every unit takes it (tests)
     u8* d_x_scratch = nullptr; size_t x_scratch_cap = 0;   // [lanes][lane_bytes]
     int* d_x_unit = nullptr; size_t x_unit_cap = 0;        // the submitted batch's exotic unit list
+    u16* d_x_len = nullptr; size_t x_len_cap = 0;          // the launch's length arrays with the text kernel's units zeroed (what the plan's kernels see)
     void* d_x_text[2] = {nullptr, nullptr}; size_t x_text_cap[2] = {0, 0};   // host submits: the raw text + offsets staged in HBM
     void* d_x_off[2] = {nullptr, nullptr}; size_t x_off_cap[2] = {0, 0};
     std::vector<int32_t> parse_exotic;                     // records of the last fastp_gpu_parse_fastq call with letters outside ACGTN
@@ -342,7 +344,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
                     ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr,
-                    ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
+                    ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
@@ -842,10 +844,8 @@ enum ChunkMode {
     CHUNK_OVERREP,   // the deferred overrepresentation analysis only
 };
 
-// `exact`: the units [first, first + n) go through the text kernel (fq_exact.h) instead of the plan's kernels - a segment
-// around units with letters outside ACGTN (submit_chunks cuts the batch), or everything (FASTP_GPU_EXACT=1)
 static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first, int n, const fastp_gpu_results* res,
-                        hipStream_t st, ChunkMode mode = CHUNK_STREAM, u8* scan_state = nullptr, bool exact = false) {
+                        hipStream_t st, ChunkMode mode = CHUNK_STREAM, u8* scan_state = nullptr) {
     KernelArgs a;
     memset(&a, 0, sizeof(a));
     a.p = ctx->dp;
@@ -897,6 +897,39 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         a.adapter_events = (ctx->dp.n_fasta && res->adapter_events && res->n_adapter_events) ? (u32*)res->adapter_events : nullptr;
         a.adapter_events_capacity = res->adapter_events_capacity;
         a.n_adapter_events = res->n_adapter_events;
+    }
+    // Units with letters outside ACGTN (fastp_gpu_batch::exotic_*; FASTP_GPU_EXACT=1: every unit) take the text kernel
+    // (fq_exact.h).  The plan's kernels still run over the whole launch, on a copy of the length arrays in which those units
+    // are EMPTY; the text kernel then runs once over the listed units: it takes back what an empty unit added to the
+    // counters (the same loop on an empty unit, sign -1), adds the real unit, and overwrites the unit's records and hash
+    // values.  Duplicate's kernels run once over the whole launch afterwards: input order holds across both kinds.
+    int xk0 = 0, xk1 = 0;
+    if (b->n_exotic > 0) {
+        xk0 = (int)(std::lower_bound(b->exotic_unit, b->exotic_unit + b->n_exotic, first) - b->exotic_unit);
+        xk1 = (int)(std::lower_bound(b->exotic_unit, b->exotic_unit + b->n_exotic, first + n) - b->exotic_unit);
+    }
+    const bool exact = n > 0 && (ctx->exact_all || xk1 > xk0);
+    const u16* true_len[2] = {a.len[0], a.len[1]};
+    if (exact) {
+        const int mates = ctx->dp.paired ? 2 : 1;
+        int rx = ensure(ctx, (void**)&ctx->d_x_len, &ctx->x_len_cap, (size_t)2 * n * sizeof(u16));
+        if (rx) return rx;
+        for (int m = 0; m < mates; m++) {
+            u16* copy = ctx->d_x_len + (size_t)m * n;
+            if (ctx->exact_all) HIP_TRY(ctx, hipMemsetAsync(copy, 0, (size_t)n * sizeof(u16), st));
+            else HIP_TRY(ctx, hipMemcpyAsync(copy, a.len[m], (size_t)n * sizeof(u16), hipMemcpyDeviceToDevice, st));
+            a.len[m] = copy;
+        }
+        if (!ctx->exact_all) {
+            ExactMaskArgs mk;
+            mk.units = ctx->d_x_unit + xk0;
+            mk.count = xk1 - xk0;
+            mk.first = first;
+            mk.len[0] = ctx->d_x_len;
+            mk.len[1] = mates == 2 ? ctx->d_x_len + n : nullptr;
+            hipLaunchKernelGGL(fq_exact_mask_kernel, dim3((mk.count + 255) / 256), dim3(256), 0, st, mk);
+            HIP_TRY(ctx, hipGetLastError());
+        }
     }
     // scan state of the whole batch: positions [b->n][B] u64, then masks [b->n] u8
     u64* scan_pos = scan_state ? (u64*)scan_state + (size_t)first * ctx->dp.dup_bufnum : nullptr;
@@ -974,14 +1007,21 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         e.c.st_reads = c.st_reads; e.c.st_length_sum = c.st_length_sum; e.c.st_qual_hist = c.st_qual_hist;
         e.c.st_kmer = c.st_kmer; e.c.st_cycle = c.st_cycle; e.c.cycles = c.cycles;
         e.ctr = ctx->d_ctr;
+        e.k.len[0] = true_len[0];
+        e.k.len[1] = true_len[1];
         e.x_n = b->n_exotic;
         e.x_unit = ctx->d_x_unit;
+        e.x_all = ctx->exact_all ? 1 : 0;
+        e.x_k0 = xk0;
+        e.x_count = ctx->exact_all ? n : xk1 - xk0;
+        e.sign = 1;
+        e.ghost = 0;
         e.x_dense = b->exotic_dense;
         for (int m = 0; m < 2; m++) { e.x_text[m] = b->exotic_text[m]; e.x_off[m] = b->exotic_off[m]; }
         e.ML = (ctx->dp.max_len + 8 + 7) & ~7;
         e.lane_bytes = (u32)(EXACT_BUFS * e.ML + EXACT_ADAPTER_BYTES);
         e.hash_only = hash_only;
-        const int lanes = std::min((n + 63) / 64 * 64, env_int("FASTP_GPU_EXACT_LANES", 16384));
+        const int lanes = std::min((e.x_count + 63) / 64 * 64, env_int("FASTP_GPU_EXACT_LANES", 16384));
         int r2 = ensure(ctx, (void**)&ctx->d_x_scratch, &ctx->x_scratch_cap, (size_t)lanes * e.lane_bytes);
         if (r2) return r2;
         e.scratch = ctx->d_x_scratch;
@@ -1052,16 +1092,23 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     };
 
     if (mode == CHUNK_PASS1 && ctx->dp.dedup) {
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
+        HIP_TRY(ctx, hipGetLastError());
         if (exact) {
             rc = launch_exact(1);
             if (rc) return rc;
-        } else {
-            hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
-            HIP_TRY(ctx, hipGetLastError());
         }
         return launch_dup(nullptr, true);
     }
-    if (mode == CHUNK_OVERREP) return launch_overrep(ctx, a, n, st);
+    // the overrepresentation analysis reads the rows by their TRUE lengths (with listed exotic units the submit was refused:
+    // only FASTP_GPU_EXACT=1 gets here with a masked copy)
+    auto overrep = [&]() -> int {
+        KernelArgs ao = a;
+        ao.len[0] = true_len[0];
+        ao.len[1] = true_len[1];
+        return launch_overrep(ctx, ao, n, st);
+    };
+    if (mode == CHUNK_OVERREP) return overrep();
     if (mode == CHUNK_PASS2) {
         // the decision comes from pass 1's scan state + the preceding shards' bitmaps; nothing is hashed again
         if (ctx->dp.dedup) {
@@ -1091,12 +1138,11 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
         rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
         if (rc) return rc;
+        hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
+        HIP_TRY(ctx, hipGetLastError());
         if (exact) {
             rc = launch_exact(1);
             if (rc) return rc;
-        } else {
-            hipLaunchKernelGGL(fq_hash_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, whole(a));
-            HIP_TRY(ctx, hipGetLastError());
         }
         rc = launch_dup(ctx->d_dupflag);
         if (rc) return rc;
@@ -1119,10 +1165,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(e0, st));
-    if (exact) {
-        rc = launch_exact(0);
-        if (rc) return rc;
-    } else {
+    {
         FusedArgs fa;
         fa.h[0] = a;
         fa.h[1] = a;
@@ -1144,6 +1187,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (exact) {   // behind the plan's kernel: the records and hash values of its units are overwritten
+        rc = launch_exact(0);
+        if (rc) return rc;
+    }
     // the claim ran inside that kernel: what is left of Duplicate (losers / winners / finish) needs nothing of the Stats
     // kernel and runs beside it on its own stream; the launch stream joins it before anything else touches the records
     bool dup_tail_launched = false;
@@ -1156,7 +1203,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         dup_tail_launched = true;
     }
     int st_grid = 0;
-    if (ctx->split && n > 0 && !exact) {
+    if (ctx->split && n > 0) {
         // Stats::statRead of the launch's units: a workgroup takes a run of consecutive units (at most CYC_MAX_READS:
         // packed counters; at least 64 so that small launches do not pay a 43 KB slab per handful of reads)
         StatsArgs sa;
@@ -1213,9 +1260,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
-    if (exact) {
-        // the text kernel adds to the counter block itself: nothing to fold
-    } else if (ctx->split) {
+    if (ctx->split) {
         // the Stats kernel's slabs: per-cycle u64s, k-mer counters, one histogram counter per (slot, character)
         r.slabs = ctx->d_st_slabs;
         r.slab_dwords = ctx->st_slab_dwords;
@@ -1264,7 +1309,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (rc) return rc;
     }
     if (b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) return FASTP_GPU_OK;
-    return launch_overrep(ctx, a, n, st);
+    return overrep();
 }
 
 
@@ -1290,52 +1335,28 @@ static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fas
             return fail(ctx, FASTP_GPU_E_INVALID, "adapter_fasta needs an adapter event list in the results");
         if (res->n_adapter_events) HIP_TRY(ctx, hipMemsetAsync(res->n_adapter_events, 0, sizeof(int32_t), st));
     }
-    // split into equally sized launches (each a multiple of the tile size)
-    auto run_range = [&](int lo, int hi, bool exact) -> int {
-        const int span = hi - lo;
-        const int launches = (span + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
-        int per = launches ? (span + launches - 1) / launches : 0;
-        per = (per + ctx->L.P - 1) / ctx->L.P * ctx->L.P;
-        for (int first = lo; first < hi; first += per) {
-            const int n = std::min(per, hi - first);
-            int rc = launch_chunk(ctx, b, first, n, res, st, mode, scan_state, exact);
-            if (rc) return rc;
-        }
-        return FASTP_GPU_OK;
-    };
-    if (b->n_exotic <= 0) return run_range(0, b->n, ctx->exact_all);
-    // Units with letters outside ACGTN: the packed rows cannot carry them, the text kernel (fq_exact.h) takes them with
-    // the units around them - groups of four, so that what is left for the plan's kernels starts at 16-byte aligned rows -
-    // and the stretches in between go through the plan's kernels as launches of their own, all in stream order
-    // (Duplicate's bloom semantics and the records' positions are those of one pass over the batch).
-    if (!b->exotic_unit || !b->exotic_text[0] || !b->exotic_off[0] || (ctx->dp.paired && (!b->exotic_text[1] || !b->exotic_off[1])))
-        return fail(ctx, FASTP_GPU_E_INVALID, "n_exotic > 0 needs exotic_unit, exotic_text and exotic_off");
-    if (ctx->dp.overrep) return fail(ctx, FASTP_GPU_E_ALPHABET, "letters outside ACGTN together with the overrepresentation analysis");
-    for (int k = 0; k < b->n_exotic; k++)
-        if (b->exotic_unit[k] < 0 || b->exotic_unit[k] >= b->n || (k && b->exotic_unit[k] <= b->exotic_unit[k - 1]))
-            return fail(ctx, FASTP_GPU_E_INVALID, "exotic_unit must be ascending unit indexes of the batch");
-    {
+    if (b->n_exotic > 0) {
+        // units with letters outside ACGTN: the text kernel (fq_exact.h) takes them, launch by launch (launch_chunk)
+        if (!b->exotic_unit || !b->exotic_text[0] || !b->exotic_off[0] || (ctx->dp.paired && (!b->exotic_text[1] || !b->exotic_off[1])))
+            return fail(ctx, FASTP_GPU_E_INVALID, "n_exotic > 0 needs exotic_unit, exotic_text and exotic_off");
+        if (ctx->dp.overrep) return fail(ctx, FASTP_GPU_E_ALPHABET, "letters outside ACGTN together with the overrepresentation analysis");
+        for (int k = 0; k < b->n_exotic; k++)
+            if (b->exotic_unit[k] < 0 || b->exotic_unit[k] >= b->n || (k && b->exotic_unit[k] <= b->exotic_unit[k - 1]))
+                return fail(ctx, FASTP_GPU_E_INVALID, "exotic_unit must be ascending unit indexes of the batch");
         int rc = ensure(ctx, (void**)&ctx->d_x_unit, &ctx->x_unit_cap, (size_t)b->n_exotic * sizeof(int));
         if (rc) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_x_unit, b->exotic_unit, (size_t)b->n_exotic * sizeof(int), hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));   // the list is the caller's (pageable) memory
     }
-    std::vector<std::pair<int, int>> segs;   // [lo, hi) of the text kernel's segments
-    const int join_gap = env_int("FASTP_GPU_EXACT_JOIN", 256);   // stretches shorter than this are not worth launches of their own
-    for (int k = 0; k < b->n_exotic; k++) {
-        const int lo = b->exotic_unit[k] & ~3, hi = std::min(b->n, (b->exotic_unit[k] | 3) + 1);
-        if (!segs.empty() && lo - segs.back().second < join_gap) segs.back().second = std::max(segs.back().second, hi);
-        else segs.push_back({lo, hi});
-    }
-    if (ctx->exact_all || (int)segs.size() > env_int("FASTP_GPU_EXACT_MAX_SEGMENTS", 64)) { segs.clear(); segs.push_back({0, b->n}); }
-    int at = 0;
-    for (const auto& sg : segs) {
-        if (sg.first > at) { int rc = run_range(at, sg.first, false); if (rc) return rc; }
-        int rc = run_range(sg.first, sg.second, true);
+    // split into equally sized launches (each a multiple of the tile size)
+    const int launches = (b->n + ctx->max_pairs_per_launch - 1) / ctx->max_pairs_per_launch;
+    int per = launches ? (b->n + launches - 1) / launches : 0;
+    per = (per + ctx->L.P - 1) / ctx->L.P * ctx->L.P;
+    for (int first = 0; first < b->n; first += per) {
+        const int n = std::min(per, b->n - first);
+        int rc = launch_chunk(ctx, b, first, n, res, st, mode, scan_state);
         if (rc) return rc;
-        at = sg.second;
     }
-    if (at < b->n) return run_range(at, b->n, false);
     return FASTP_GPU_OK;
 }
 

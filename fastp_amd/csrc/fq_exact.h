@@ -8,11 +8,18 @@
 //   (util.h:16-33, simd.cpp:296-310), overlap analysis / adapter matching / polyG / polyX / the complexity filter compare
 //   raw bytes, passFilter and trimAndCut count only a literal 'N'.
 // Units that hold such a byte ("exotic" units, fastp_gpu_batch::exotic_*) therefore go through THIS kernel: a lane owns a
-// unit, rebuilds its text in a private stretch of HBM (exotic units: the raw bytes; their neighbours in the launch:
-// decoded from the packed rows) and runs the loop body as the reference wrote it, byte by byte, counters straight into
-// the context's int64 block with global atomics.  Nothing here is fast and nothing has to be: a launch holds the few
-// units around an exotic one (fastp_gpu.hip cuts a batch into segments), or - FASTP_GPU_EXACT=1, tests - a whole batch.
-// Duplicate's bloom semantics stay with the fq_dup_* kernels: this kernel only leaves the hash values.
+// unit, rebuilds its text in a private stretch of HBM (exotic units: the raw bytes; any other unit: decoded from the
+// packed rows) and runs the loop body as the reference wrote it, byte by byte, counters straight into the context's
+// int64 block with global atomics.  Nothing here is fast and nothing has to be: one launch per batch launch, over the
+// listed units only (FASTP_GPU_EXACT=1, tests: over every unit).
+//
+// How it composes with the plan's kernels (fastp_gpu.hip launch_chunk): those still sweep the whole launch, but on a
+// copy of the length arrays in which the listed units are EMPTY reads.  What an empty unit adds to the counters is
+// exactly what this loop computes for an empty unit - so a lane first runs the loop on an empty unit with sign -1
+// (the "ghost" pass: counters only), then on the real unit with sign +1, and overwrites the unit's records and hash
+// values.  Duplicate's bloom semantics stay with the fq_dup_* kernels, which run once over the whole launch afterwards:
+// this kernel leaves the COMPLETE hash values of its units (the position part included - the dup kernels add the
+// position sum of the length they see, zero).
 //
 // Each function cites the reference lines it follows.
 #pragma once
@@ -30,6 +37,9 @@ struct ExactArgs {
     KernelArgs k;        // parameters, LUTs, the launch's rows / records / lists (pointers already at `first`)
     ExactCtr c;
     int64_t* ctr;
+    // which units: the entries [x_k0, x_k0 + x_count) of the batch's list, or (x_all) the launch's units 0 .. x_count - 1
+    int x_all, x_k0, x_count;
+    int sign, ghost;     // ghost pass: an empty unit, counters only, sign -1 (set per lane, see exact_body)
     // raw sequence bytes of the exotic units
     const int* x_unit;   // [x_n] ascending unit indexes inside the submitted batch
     int x_n;
@@ -51,7 +61,20 @@ struct XRead {
     int front;
 };
 
-FQ_DEV void x_add(const ExactArgs& E, long long off, long long v) { g_atomic_add_i64(E.ctr + off, (int64_t)v); }
+struct ExactMaskArgs {
+    const int* units;   // listed units of this launch (batch indexes)
+    int count, first;
+    u16* len[2];        // the launch's copies of the length arrays
+};
+FQ_DEV void exact_mask_body(const ExactMaskArgs& m) {
+    const int i = block_id() * block_threads() + thread_id();
+    if (i >= m.count) return;
+    const int gp = m.units[i] - m.first;
+    m.len[0][gp] = 0;
+    if (m.len[1]) m.len[1][gp] = 0;
+}
+
+FQ_DEV void x_add(const ExactArgs& E, long long off, long long v) { g_atomic_add_i64(E.ctr + off, (int64_t)(v * E.sign)); }
 
 FQ_DEV u8 x_complement(u8 b) {   // util.h:16-33
     switch (b) {
@@ -97,6 +120,7 @@ FQ_DEV const u8* x_raw(const ExactArgs& E, int gp, int m) {
 }
 
 FQ_DEV int x_load(const ExactArgs& E, int gp, int m, u8* s, u8* q) {
+    if (E.ghost) { s[0] = 0; q[0] = 0; return 0; }
     const int len = (int)E.k.len[m][gp];
     const u8* qrow = (const u8*)(E.k.qual[m] + (size_t)gp * E.k.p.qw_g);
     const u32* srow = E.k.seq[m] + (size_t)gp * E.k.p.sw_g;
@@ -520,12 +544,13 @@ FQ_DEV int x_pass_filter(const KernelArgs& a, const u8* s, const u8* q, int rlen
     return 0;
 }
 
-// ---- Duplicate::seq2intvector (duplicate.cpp:111-120), the base-value part: the dup kernels add the position part ----
+// ---- Duplicate::seq2intvector (duplicate.cpp:111-120), the whole value (the dup kernels add the position sum of the
+// length THEY see for this unit: zero, it is an empty read in their length arrays) ----
 FQ_DEV void x_hash(const KernelArgs& a, const u8* s, int len, int pos_offset, u64* out) {
     const int B = a.p.dup_bufnum;
     const u32 mask = (u32)(512 * B - 1);
     for (int p = 0; p < len; p++) {
-        const u64 v = x_hash_val(s[p]);
+        const u64 v = x_hash_val(s[p]) + (u64)(p + pos_offset);
         for (int i = 0; i < B; i++) out[i] += (u64)a.lut.dup_primes[((u32)((p + pos_offset) * B + i)) & mask] * v;
     }
 }
@@ -625,7 +650,7 @@ FQ_DEV void x_process_se(const ExactArgs& E, int gp, const XBufs& b) {
     const DevParams& p = a.p;
     XRead r = {b.s1, b.q1, x_load(E, gp, 0, b.s1, b.q1), 0};
     XRes x = {0, 0, 0, 0};
-    if (p.dup_enabled && a.dup_pos) {   // :213-218, checkRead duplicate.cpp:122-134
+    if (p.dup_enabled && a.dup_pos && !E.ghost) {   // :213-218, checkRead duplicate.cpp:122-134
         u64 h[MAX_DUP_BUFS] = {0, 0, 0, 0, 0, 0, 0, 0};
         x_hash(a, r.s, r.len, 0, h);
         for (int i = 0; i < p.dup_bufnum; i++) a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h[i];
@@ -663,7 +688,7 @@ FQ_DEV void x_process_se(const ExactArgs& E, int gp, const XBufs& b) {
     x_add(E, E.c.filter + result, 1);   // :278
     if (!dedup_out && alive && result == 0) x_stat_read(E, 1, r.s, r.q, r.len);   // :280-290
     if (!alive) x.flags |= RS_NULL;
-    x_write_read(a, 0, gp, r, result, x);
+    if (!E.ghost) x_write_read(a, 0, gp, r, result, x);
 }
 
 // ---- paired-end loop body: peprocessor.cpp:383-643 ----
@@ -674,7 +699,7 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
     XRead r1 = {b.s1, b.q1, x_load(E, gp, 0, b.s1, b.q1), 0};
     XRead r2 = {b.s2, b.q2, x_load(E, gp, 1, b.s2, b.q2), 0};
     XRes x1 = {0, 0, 0, 0}, x2 = {0, 0, 0, 0};
-    if (p.dup_enabled && a.dup_pos) {   // :397-402, checkPair duplicate.cpp:136-148
+    if (p.dup_enabled && a.dup_pos && !E.ghost) {   // :397-402, checkPair duplicate.cpp:136-148
         u64 h[MAX_DUP_BUFS] = {0, 0, 0, 0, 0, 0, 0, 0};
         x_hash(a, r1.s, r1.len, 0, h);
         x_hash(a, r2.s, r2.len, r1.len, h);
@@ -820,6 +845,7 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
     }
     if (!a1) x1.flags |= RS_NULL;
     if (!a2) x2.flags |= RS_NULL;
+    if (E.ghost) return;
     x_write_read(a, 0, gp, r1, code1, x1);
     x_write_read(a, 1, gp, r2, code2, x2);
     a.pair[2 * (size_t)gp] = ((u32)ov.offset & 0xFFFFu) | (((u32)ov.overlap_len & 0xFFFFu) << 16);
@@ -848,7 +874,15 @@ FQ_DEV void exact_body(const ExactArgs& E) {
         if (E.k.p.has_a1) x_decode_adapter(E.k.p.a1w, E.k.p.alen1, b.ad1);
         if (E.k.p.has_a2) x_decode_adapter(E.k.p.a2w, E.k.p.alen2, b.ad2);
     }
-    for (int gp = lane; gp < E.k.n; gp += lanes) {
+    for (int i = lane; i < E.x_count; i += lanes) {
+        const int gp = E.x_all ? i : E.x_unit[E.x_k0 + i] - E.k.first;
+        if (!E.hash_only) {   // what the plan's kernels counted for the empty unit they saw in this place
+            ExactArgs G = E;
+            G.sign = -1;
+            G.ghost = 1;
+            if (G.k.p.paired) x_process_pe(G, gp, b);
+            else x_process_se(G, gp, b);
+        }
         if (E.k.p.paired) x_process_pe(E, gp, b);
         else x_process_se(E, gp, b);
     }
