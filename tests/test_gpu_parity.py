@@ -64,6 +64,29 @@ def test_gpu_equals_reference_golden(name):
     golden_util.check_against_golden(name, outs, rep, meta)
 
 
+@pytest.mark.parametrize("name", ["pe_default", "pe_correction", "pe_merge_unmerged", "pe_allow_gap_indel_corr", "pe_adapter_fasta",
+                                  "pe_noadapter_dedup", "pe_overrep", "pe_polyg_polyx", "pe_merge_overlapped_out_trims",
+                                  "se_adapter_long_indel", "se_polyx_complexity", "pe_exotic_merge"])
+def test_gpu_text_kernel_on_every_unit_equals_reference_golden(name, monkeypatch):
+    """FASTP_GPU_EXACT=1: the plan's kernels see only empty reads, every unit goes through the text kernel (fq_exact.h) -
+    the kernel that takes the units with letters outside ACGTN - and through its compensation of the empty units"""
+    monkeypatch.setenv("FASTP_GPU_EXACT", "1")
+    fq1, fq2, meta = golden_util.load(name)
+    params = golden_util.params_for(name, max_len=152, fq1=fq1, fq2=fq2)
+    eng = engines.gpu_engine(params)
+    outs, ctr, rep = driver.run_engine(eng, params, fq1, fq2, umi=golden_util.umi_for(name))
+    eng.close()
+    golden_util.check_against_golden(name, outs, rep, meta)
+
+
+def test_gpu_sparse_exotic_units_at_scale():
+    """200 k pairs, one unit in a thousand with letters outside ACGTN: records and counters equal the oracle's"""
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    d = synth.synth_pairs(200000, L=150, seed=91, insert_mean=200.0, exotic_frac=0.0005)
+    _compare("sparse_exotic", p, d, True)
+
+
 @pytest.mark.parametrize("k", range(len(cases.TRIM_STRESS)))
 def test_gpu_trim_and_cut_stress(k):
     """Filter::trimAndCut via the predicate-mask bit scans vs the oracle's literal loops, on
