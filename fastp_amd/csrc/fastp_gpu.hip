@@ -1021,7 +1021,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         e.ML = (ctx->dp.max_len + 8 + 7) & ~7;
         e.lane_bytes = (u32)(EXACT_BUFS * e.ML + EXACT_ADAPTER_BYTES);
         e.hash_only = hash_only;
-        const int lanes = std::min((e.x_count + 63) / 64 * 64, env_int("FASTP_GPU_EXACT_LANES", 16384));
+        const int lanes = std::min((e.x_count + 63) / 64 * 64, env_int("FASTP_GPU_EXACT_LANES", 131072));
         int r2 = ensure(ctx, (void**)&ctx->d_x_scratch, &ctx->x_scratch_cap, (size_t)lanes * e.lane_bytes);
         if (r2) return r2;
         e.scratch = ctx->d_x_scratch;

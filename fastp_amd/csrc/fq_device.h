@@ -3115,7 +3115,12 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
     if (!work) {
     } else if (src == OVR_SRC_MERGED) {
         const u32 a0 = o.res[0][(size_t)g * 3], b0 = o.res[1][(size_t)g * 3];
-        const int m1 = (int)(o.res[0][(size_t)g * 3 + 2] >> 16), m2 = (int)(o.res[1][(size_t)g * 3 + 2] >> 16);
+        // the merged parts from the pair record (merge mode's own analysis): len1 = overlap_len + max(0, offset), len2 =
+        // offset > 0 ? len(r2') - overlap_len : 0 (overlapanalysis.cpp:152-156) - the records' reserved fields hold the same
+        // numbers unless --overlapped_out occupies them
+        const u32 pw = o.pair[(size_t)g * 2];
+        const int pol = (int)(pw >> 16), poff = (int)(int16_t)(pw & 0xFFFFu);
+        const int m1 = pol + imax(0, poff), m2 = poff > 0 ? (int)(b0 >> 16) - pol : 0;
         r.f[0] = (int)(a0 & 0xFFFFu);
         r.f[1] = (int)(b0 & 0xFFFFu) + (int)(b0 >> 16) - 1;  // r2'[last]
         r.m1 = m1;
@@ -3713,9 +3718,12 @@ FQ_DEV void fmts_rec(const FmtsArgs& f, int g, u32 em, u32 umi_len, FmtsRec& r) 
     r.m1 = r.m2 = r.ol = 0;
     r.strand_tagged = false;
     if (src == 2) {
-        r.m1 = f.m[0].res[(size_t)g * 3 + 2] >> 16;   // reserved: bases of this mate in the merged read
-        r.m2 = f.m[1].res[(size_t)g * 3 + 2] >> 16;
-        r.ol = f.pair[2 * (size_t)g] >> 16;
+        // bases of each mate in the merged read, from the pair record (see ovr_count_body)
+        const u32 pw = f.pair[2 * (size_t)g];
+        const int poff = (int)(int16_t)(pw & 0xFFFFu);
+        r.ol = pw >> 16;
+        r.m1 = r.ol + (u32)imax(0, poff);
+        r.m2 = poff > 0 ? (f.m[1].res[(size_t)g * 3] >> 16) - r.ol : 0u;
         r.seq_len = r.m1 + r.m2;
         r.mtag_len = 8u + fmts_digits(r.m1) + 1u + fmts_digits(r.m2);   // " merged_" L1 "_" L2
         // the strand line gets the tag too unless it is just "+" (overlapanalysis.cpp:170-173)
