@@ -149,7 +149,10 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs 
     extern __shared__ u32 fq_lds[];
     fmts_write_body(f, fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(64) fq_exact_kernel(ExactArgs e) { exact_body(e); }
+extern "C" __global__ void __launch_bounds__(512) fq_exact_kernel(ExactArgs e) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    exact_body(e, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_exact_mask_kernel(ExactMaskArgs m) { exact_mask_body(m); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
@@ -649,6 +652,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         }
     }
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DefLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IwLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1021,11 +1025,16 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         e.ML = (ctx->dp.max_len + 8 + 7) & ~7;
         e.lane_bytes = (u32)(EXACT_BUFS * e.ML + EXACT_ADAPTER_BYTES);
         e.hash_only = hash_only;
-        const int lanes = std::min((e.x_count + 63) / 64 * 64, env_int("FASTP_GPU_EXACT_LANES", 131072));
+        // Stats' per-base tables of a workgroup in LDS when four of them fit (not the hash pre-pass, which counts nothing)
+        const int slot_dwords = 34 * (int)c.cycles + 1024 + 128;
+        const bool lds_tables = !hash_only && (size_t)4 * slot_dwords * 4 <= (size_t)150 * 1024 && env_int("FASTP_GPU_EXACT_LDS", 1);
+        e.lds_slot_dwords = lds_tables ? slot_dwords : 0;
+        const int wg = lds_tables ? 512 : 64;   // one 512-lane workgroup per CU owns the tables; without them small workgroups
+        const int lanes = std::min((e.x_count + wg - 1) / wg * wg, env_int("FASTP_GPU_EXACT_LANES", lds_tables ? ctx->cus * 512 : 16384) / wg * wg);
         int r2 = ensure(ctx, (void**)&ctx->d_x_scratch, &ctx->x_scratch_cap, (size_t)lanes * e.lane_bytes);
         if (r2) return r2;
         e.scratch = ctx->d_x_scratch;
-        hipLaunchKernelGGL(fq_exact_kernel, dim3(lanes / 64), dim3(64), 0, st, e);
+        hipLaunchKernelGGL(fq_exact_kernel, dim3(lanes / wg), dim3(wg), (size_t)4 * e.lds_slot_dwords * 4, st, e);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };

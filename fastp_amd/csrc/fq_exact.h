@@ -50,6 +50,10 @@ struct ExactArgs {
     u32 lane_bytes;
     int ML;              // bytes per text buffer of a lane (max_len + slack, multiple of 8)
     int hash_only;       // --dedup's pre-pass: leave the hash values, nothing else
+    // Stats::statRead's per-base counters of the workgroup's units are gathered in LDS (u32: [slot][34 * cycles | 1024 5-mers |
+    // 128 quality characters]) and added to the block once at the end - with every lane of a launch adding to the same few
+    // thousand int64s in HBM the kernel ran at the atomics' rate.  0: the tables do not fit (merge mode of long reads)
+    int lds_slot_dwords;
 };
 
 enum { EXACT_BUFS = 14, EXACT_ADAPTER_BYTES = 3 * 264 };   // text buffers of ML bytes per lane; three decoded adapters
@@ -141,12 +145,18 @@ FQ_DEV void x_decode_adapter(const u32* words, int alen, u8* out) {
 }
 
 // ---- Stats::statRead (stats.cpp:191-291, without the overrepresentation part) ----
-FQ_DEV void x_stat_read(const ExactArgs& E, int slot, const u8* s, const u8* q, int len) {
+FQ_DEV void x_stat_read_lds(const ExactArgs& E, u32* lds, int slot, const u8* s, const u8* q, int len);
+FQ_DEV void x_stat_read(const ExactArgs& E, u32* lds, int slot, const u8* s, const u8* q, int len) {
     const long long st = E.c.stats[slot];
     const long long C = E.c.cycles;
     const long long cyc = st + E.c.st_cycle;
     const long long q30 = cyc, q20 = cyc + 8 * C, cont = cyc + 16 * C, qual = cyc + 24 * C, tot_base = cyc + 32 * C, tot_qual = cyc + 33 * C;
     x_add(E, st + E.c.st_length_sum, len);
+    if (E.lds_slot_dwords && E.sign > 0) {
+        x_stat_read_lds(E, lds, slot, s, q, len);
+        x_add(E, st + E.c.st_reads, 1);
+        return;
+    }
     int kmer = 0;
     bool need_full = true;
     for (int i = 0; i < len; i++) {
@@ -180,6 +190,47 @@ FQ_DEV void x_stat_read(const ExactArgs& E, int slot, const u8* s, const u8* q, 
         }
     }
     x_add(E, st + E.c.st_reads, 1);
+}
+
+// the same walk with the per-base counters in the workgroup's LDS tables (exact_body folds them into the block)
+FQ_DEV void x_stat_read_lds(const ExactArgs& E, u32* lds, int slot, const u8* s, const u8* q, int len) {
+    const int C = (int)E.c.cycles;
+    u32* t = lds + (size_t)slot * E.lds_slot_dwords;
+    u32* q30 = t, *q20 = t + 8 * C, *cont = t + 16 * C, *qual = t + 24 * C, *tot_base = t + 32 * C, *tot_qual = t + 33 * C;
+    u32* kmers = t + 34 * C;
+    u32* hist = kmers + 1024;
+    int kmer = 0;
+    bool need_full = true;
+    for (int i = 0; i < len; i++) {
+        const u8 base = s[i], qc = q[i];
+        const int b = base & 7;
+        lds_add_u32(&hist[qc], 1u);
+        if (qc >= '?') { lds_add_u32(&q30[b * C + i], 1u); lds_add_u32(&q20[b * C + i], 1u); }
+        else if (qc >= '5') lds_add_u32(&q20[b * C + i], 1u);
+        lds_add_u32(&cont[b * C + i], 1u);
+        lds_add_u32(&qual[b * C + i], (u32)((int)qc - 33));
+        lds_add_u32(&tot_base[i], 1u);
+        lds_add_u32(&tot_qual[i], (u32)((int)qc - 33));
+        if (base == 'N') { need_full = true; continue; }
+        if (i < 4) continue;
+        if (!need_full) {
+            const int v = x_base2val(base);
+            if (v < 0) { need_full = true; continue; }
+            kmer = ((kmer << 2) & 0x3FC) | v;
+            lds_add_u32(&kmers[kmer], 1u);
+        } else {
+            bool valid = true;
+            kmer = 0;
+            for (int k = 0; k < 5; k++) {
+                const int v = x_base2val(s[i - 4 + k]);
+                if (v < 0) { valid = false; break; }
+                kmer = ((kmer << 2) & 0x3FC) | v;
+            }
+            if (!valid) { need_full = true; continue; }
+            lds_add_u32(&kmers[kmer], 1u);
+            need_full = false;
+        }
+    }
 }
 
 // ---- Filter::trimAndCut (filter.cpp:68-207); false = NULL ----
@@ -645,7 +696,7 @@ FQ_DEV void x_poly_x(const ExactArgs& E, XRead& r, XRes& x) {
 }
 
 // ---- single-end loop body: seprocessor.cpp:204-296 ----
-FQ_DEV void x_process_se(const ExactArgs& E, int gp, const XBufs& b) {
+FQ_DEV void x_process_se(const ExactArgs& E, u32* lds, int gp, const XBufs& b) {
     const KernelArgs& a = E.k;
     const DevParams& p = a.p;
     XRead r = {b.s1, b.q1, x_load(E, gp, 0, b.s1, b.q1), 0};
@@ -656,7 +707,7 @@ FQ_DEV void x_process_se(const ExactArgs& E, int gp, const XBufs& b) {
         for (int i = 0; i < p.dup_bufnum; i++) a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h[i];
     }
     if (E.hash_only) return;
-    x_stat_read(E, 0, r.s, r.q, r.len);   // :210
+    x_stat_read(E, lds, 0, r.s, r.q, r.len);   // :210
     bool dedup_out = false;
     if (a.dupflag && a.dupflag[gp]) {
         x.flags |= RS_DUP;
@@ -686,13 +737,13 @@ FQ_DEV void x_process_se(const ExactArgs& E, int gp, const XBufs& b) {
     int result = alive ? x_pass_filter(a, r.s, r.q, r.len) : 16;
     if (dimer) result = 28;
     x_add(E, E.c.filter + result, 1);   // :278
-    if (!dedup_out && alive && result == 0) x_stat_read(E, 1, r.s, r.q, r.len);   // :280-290
+    if (!dedup_out && alive && result == 0) x_stat_read(E, lds, 1, r.s, r.q, r.len);   // :280-290
     if (!alive) x.flags |= RS_NULL;
     if (!E.ghost) x_write_read(a, 0, gp, r, result, x);
 }
 
 // ---- paired-end loop body: peprocessor.cpp:383-643 ----
-FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
+FQ_DEV void x_process_pe(const ExactArgs& E, u32* lds, int gp, const XBufs& b) {
     const KernelArgs& a = E.k;
     const DevParams& p = a.p;
     const bool thread0 = (a.batch_flags & 1u) != 0;
@@ -706,8 +757,8 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
         for (int i = 0; i < p.dup_bufnum; i++) a.dup_pos[(size_t)gp * p.dup_bufnum + i] = h[i];
     }
     if (E.hash_only) return;
-    x_stat_read(E, 0, r1.s, r1.q, r1.len);   // :393
-    x_stat_read(E, 2, r2.s, r2.q, r2.len);   // :394
+    x_stat_read(E, lds, 0, r1.s, r1.q, r1.len);   // :393
+    x_stat_read(E, lds, 2, r2.s, r2.q, r2.len);   // :394
     bool dedup_out = false;
     if (a.dupflag && a.dupflag[gp]) {
         x1.flags |= RS_DUP;
@@ -814,7 +865,7 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
             const int result = x_pass_filter(a, b.ms, b.mq, mlen);
             x_add(E, E.c.filter + result, 2);
             if (result == 0) {
-                x_stat_read(E, 1, b.ms, b.mq, mlen);
+                x_stat_read(E, lds, 1, b.ms, b.mq, mlen);
                 x_add(E, E.c.merged, 1);   // :688-690
                 x1.flags |= RS_MERGED;
                 x2.flags |= RS_MERGED;
@@ -827,9 +878,9 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
             code2 = x_pass_filter(a, r2.s, r2.q, r2.len);
             if (dimer) code1 = code2 = 28;
             x_add(E, E.c.filter + code1, 1);
-            if (code1 == 0 && !dedup_out) x_stat_read(E, 1, r1.s, r1.q, r1.len);
+            if (code1 == 0 && !dedup_out) x_stat_read(E, lds, 1, r1.s, r1.q, r1.len);
             x_add(E, E.c.filter + code2, 1);
-            if (code2 == 0 && !dedup_out) x_stat_read(E, 1, r2.s, r2.q, r2.len);
+            if (code2 == 0 && !dedup_out) x_stat_read(E, lds, 1, r2.s, r2.q, r2.len);
             merge_done = true;
         }
     }
@@ -839,8 +890,8 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
         if (dimer) code1 = code2 = 28;
         x_add(E, E.c.filter + imax(code1, code2), 2);
         if (!dedup_out && a1 && code1 == 0 && a2 && code2 == 0 && !p.merge) {   // :588-591
-            x_stat_read(E, 1, r1.s, r1.q, r1.len);
-            x_stat_read(E, 3, r2.s, r2.q, r2.len);
+            x_stat_read(E, lds, 1, r1.s, r1.q, r1.len);
+            x_stat_read(E, lds, 3, r2.s, r2.q, r2.len);
         }
     }
     if (!a1) x1.flags |= RS_NULL;
@@ -852,7 +903,12 @@ FQ_DEV void x_process_pe(const ExactArgs& E, int gp, const XBufs& b) {
     a.pair[2 * (size_t)gp + 1] = ((u32)ov.diff & 0xFFFFu) | ((u32)((ov.overlapped ? 1 : 0) | (ov.has_gap ? 2 : 0) | (isize_done ? 4 : 0)) << 16);
 }
 
-FQ_DEV void exact_body(const ExactArgs& E) {
+FQ_DEV void exact_body(const ExactArgs& E, u32* lds) {
+    const int lds_total = 4 * E.lds_slot_dwords;
+    if (lds_total) {
+        for (int i = thread_id(); i < lds_total; i += block_threads()) lds[i] = 0u;
+        block_sync();
+    }
     const int lane = block_id() * block_threads() + thread_id();
     const int lanes = grid_blocks() * block_threads();
     u8* base = E.scratch + (size_t)lane * E.lane_bytes;
@@ -880,11 +936,23 @@ FQ_DEV void exact_body(const ExactArgs& E) {
             ExactArgs G = E;
             G.sign = -1;
             G.ghost = 1;
-            if (G.k.p.paired) x_process_pe(G, gp, b);
-            else x_process_se(G, gp, b);
+            if (G.k.p.paired) x_process_pe(G, lds, gp, b);
+            else x_process_se(G, lds, gp, b);
         }
-        if (E.k.p.paired) x_process_pe(E, gp, b);
-        else x_process_se(E, gp, b);
+        if (E.k.p.paired) x_process_pe(E, lds, gp, b);
+        else x_process_se(E, lds, gp, b);
+    }
+    if (lds_total) {   // the workgroup's tables into the counter block: [slot][34 * cycles | 5-mers | quality characters]
+        block_sync();
+        const int C34 = 34 * (int)E.c.cycles;
+        for (int i = thread_id(); i < lds_total; i += block_threads()) {
+            const u32 v = lds[i];
+            if (!v) continue;
+            const int slot = i / E.lds_slot_dwords, r = i - slot * E.lds_slot_dwords;
+            const long long st = E.c.stats[slot];
+            const long long off = r < C34 ? st + E.c.st_cycle + r : r < C34 + 1024 ? st + E.c.st_kmer + (r - C34) : st + E.c.st_qual_hist + (r - C34 - 1024);
+            g_atomic_add_i64(E.ctr + off, (int64_t)v);
+        }
     }
 }
 

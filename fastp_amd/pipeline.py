@@ -421,6 +421,12 @@ class FastqPipeline:
         b.seq1, b.qual1, b.len1 = M[0].seq.data_ptr(), M[0].qual.data_ptr(), M[0].lens.data_ptr()
         if self.paired:
             b.seq2, b.qual2, b.len2 = M[1].seq.data_ptr(), M[1].qual.data_ptr(), M[1].lens.data_ptr()
+        xu = np.unique(np.concatenate([getattr(M[m], "exotic", np.zeros(0, dtype=np.int32)) for m in range(nm)])).astype(np.int32)
+        xu = np.ascontiguousarray(xu[xu < n])
+        if len(xu):
+            b.n_exotic, b.exotic_dense, b.exotic_unit = len(xu), 1, xu.ctypes.data
+            for m in range(nm):
+                b.exotic_text[m], b.exotic_off[m] = M[m].text.data_ptr(), M[m].loff.data_ptr()
         r = abi.Results()
         r.r1 = M[0].res.data_ptr()
         if self.paired:
@@ -463,6 +469,8 @@ class FastqPipeline:
                                     M.lens.data_ptr(), M.loff.data_ptr(), M.llen.data_ptr())
         if info.first_bad >= 0:
             raise PipelineError(f"malformed FASTQ record {info.first_bad} of a chunk (mate {m + 1}): the device parser does not repair input")
+        # records with letters outside ACGTN: the engine's text kernel takes those units from the chunk's own text
+        M.exotic = self.eng.parse_exotic() if info.n_exotic else np.zeros(0, dtype=np.int32)
         return info
 
     def counters(self):

@@ -338,8 +338,8 @@ const char* fastp_gpu_last_error(const fastp_gpu_ctx* ctx); /* ctx may be NULL *
 /* ASCII -> packed SoA rows (host code; the repack a patched worker loop does
  * on its ReadPack before submit).  seqs[i]/quals[i] need not be 0-terminated.
  * Returns FASTP_GPU_E_ALPHABET (and the index in *bad_read if non-NULL) when a
- * base outside {A,C,G,T,N} or a quality character outside '!'..'~' (33..126) is met - the host
- * routes such packs to its own loop -, FASTP_GPU_E_TOO_LONG when lens[i] > max_len. */
+ * base outside {A,C,G,T,N} or a quality character outside '!'..'~' (33..126) is met (letters:
+ * see fastp_gpu_pack_reads_x, which lists such reads instead), FASTP_GPU_E_TOO_LONG when lens[i] > max_len. */
 int fastp_gpu_pack_reads(int max_len, int n, const char* const* seqs, const char* const* quals,
                          const int32_t* lens, uint8_t* seq_out, uint8_t* qual_out,
                          uint16_t* len_out, int32_t* bad_read);
