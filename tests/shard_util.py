@@ -19,8 +19,9 @@ def device_batches(eng, d, lo, hi, npacks, device, corr_cap=1 << 16):
         b = abi.Batch()
         b.n, b.flags = n, abi.BATCH_STAT_ISIZE
         tens = {}
+        mask = np.zeros(n, dtype=np.uint8)   # units with letters outside ACGTN: listed in the batch with their raw rows
         for m in ("1", "2") if paired else ("1",):
-            s, q, l = engine.pack_ascii(eng.lib, ml, d["seq" + m][a:e], d["qual" + m][a:e], d["len" + m][a:e])
+            s, q, l = engine.pack_ascii(eng.lib, ml, d["seq" + m][a:e], d["qual" + m][a:e], d["len" + m][a:e], mask)
             for nm, arr in (("seq", s), ("qual", q), ("len", l)):
                 t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).to(device)
                 if t.numel() == 0:
@@ -29,6 +30,15 @@ def device_batches(eng, d, lo, hi, npacks, device, corr_cap=1 << 16):
         b.seq1, b.qual1, b.len1 = tens["seq1"].data_ptr(), tens["qual1"].data_ptr(), tens["len1"].data_ptr()
         if paired:
             b.seq2, b.qual2, b.len2 = tens["seq2"].data_ptr(), tens["qual2"].data_ptr(), tens["len2"].data_ptr()
+        if mask.any():
+            xu = np.flatnonzero(mask).astype(np.int32)
+            tens["xunit"] = xu   # host memory, kept alive with the batch
+            b.n_exotic, b.exotic_unit = len(xu), xu.ctypes.data
+            for k, m in enumerate(("1", "2") if paired else ("1",)):
+                rows = np.ascontiguousarray(np.asarray(d["seq" + m][a:e], dtype=np.uint8)[xu])
+                tens["xtext" + m] = torch.from_numpy(rows.reshape(-1).copy()).to(device)
+                tens["xoff" + m] = torch.from_numpy((np.arange(len(xu), dtype=np.uint32) * np.uint32(rows.shape[1])).view(np.uint8).copy()).to(device)
+                b.exotic_text[k], b.exotic_off[k] = tens["xtext" + m].data_ptr(), tens["xoff" + m].data_ptr()
         r = abi.Results()
         out = dict(r1=torch.zeros(max(1, n) * 12, dtype=torch.uint8, device=device),
                    r2=torch.zeros(max(1, n) * 12, dtype=torch.uint8, device=device),

@@ -73,7 +73,7 @@ def test_two_rank_shards_merge_to_single_engine_counters():
 import pytest
 
 
-@pytest.mark.parametrize("name,npacks", [("pe_noadapter_dedup", 3), ("pe_overrep", 2), ("se_overrep", 1)])
+@pytest.mark.parametrize("name,npacks", [("pe_noadapter_dedup", 3), ("pe_overrep", 2), ("se_overrep", 1), ("pe_exotic_dedup_adapters", 2)])
 def test_two_rank_exact_protocol_equals_one_stream(name, npacks):
     """run_shard (dup scan -> bitmap all-gather -> prefix -> worker loop -> deferred overrepresentation):
     every record and every counter - duplicates and sampled positions included - equals ONE stream"""
