@@ -198,11 +198,21 @@ def other_configs(dev):
     from fastp_amd import abi, engine
     res = []
 
-    def run(name, params, Lr, n, paired, steps=4):
+    def run(name, params, Lr, n, paired, steps=4, soft_masked_every=0):
         d = synth_torch.synth_pairs_torch(n, L=Lr, seed=5, device=dev)
         bufs = {}
         for m in ("1", "2") if paired else ("1",):
             bufs[m] = synth_torch.pack_torch(d["seq" + m], d["qual" + m], d["len" + m], Lr)
+        xkeep = None
+        if soft_masked_every:   # every k-th unit in lower case: letters outside ACGTN, the text kernel (fq_exact.h) takes those units
+            xu = np.arange(0, n, soft_masked_every, dtype=np.int32)
+            xt = torch.from_numpy(xu.astype(np.int64)).to(dev)
+            xkeep = [xu]
+            for m in ("1", "2") if paired else ("1",):
+                rows = d["seq" + m][xt].clone()
+                rows = torch.where(rows > 0, rows | 0x20, rows).contiguous()
+                off = (torch.arange(len(xu), dtype=torch.int64, device=dev) * rows.shape[1]).to(torch.int32)
+                xkeep += [rows, off]
         del d
         eng = engine.GpuEngine(params, device=dev.index or 0)
         r1 = torch.zeros(n * 12, dtype=torch.uint8, device=dev)
@@ -214,6 +224,10 @@ def other_configs(dev):
         b.seq1, b.qual1, b.len1 = (x.data_ptr() for x in bufs["1"])
         if paired:
             b.seq2, b.qual2, b.len2 = (x.data_ptr() for x in bufs["2"])
+        if xkeep:
+            b.n_exotic, b.exotic_unit = len(xkeep[0]), xkeep[0].ctypes.data
+            for k in range(2 if paired else 1):
+                b.exotic_text[k], b.exotic_off[k] = xkeep[1 + 2 * k].data_ptr(), xkeep[2 + 2 * k].data_ptr()
         r = abi.Results()
         r.r1 = r1.data_ptr()
         if paired:
@@ -253,6 +267,11 @@ def other_configs(dev):
     p.adapter_seq_r2 = b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
     p.cut_right = 1
     run("PE 2x150 --adapter_sequence/--adapter_sequence_r2 + --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
+    # letters outside ACGTN (soft-masked reads): one pair in a thousand goes through the text kernel, the rest through the lane plan
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    run("PE 2x150 --cut_right, 4 Mi pairs, 1 pair in 1000 soft-masked (lower case: the text kernel)", p, 150, 4 * 1024 * 1024, True,
+        soft_masked_every=1000)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import cases

@@ -39,6 +39,9 @@ flags = ["-G", "--cut_right"]
 
 def run(binary, tag, w, env=None):
     cmd = [binary, "-i", f1, "-I", f2, "-o", f"{tmp}/{tag}1.fq", "-O", f"{tmp}/{tag}2.fq", "-j", f"{tmp}/{tag}.json", "-h", f"{tmp}/{tag}.html", "-w", str(w)] + flags
+    for k in "12":   # an earlier run's outputs: truncating ~30 GB of tmpfs inside open() would be timed (3 - 4 s of the A/B runs of round 4)
+        if os.path.exists(f"{tmp}/{tag}{k}.fq"):
+            os.unlink(f"{tmp}/{tag}{k}.fq")
     t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})), timeout=1500)
     dt = time.time() - t0
