@@ -1,5 +1,5 @@
-"""more seeds of the differential option fuzz (tests/test_option_fuzz.py) on the GPU than the suite runs:
-python tools/fuzz_more.py FIRST LAST   -> one line per failing seed, a summary at the end"""
+"""more seeds of the differential option fuzz (tests/test_option_fuzz.py) than the suite runs, on the GPU or (FUZZ_ENGINE=sim)
+on the SIMT emulator: python tools/fuzz_more.py FIRST LAST   -> one line per failing seed, a summary at the end"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
@@ -9,11 +9,13 @@ import engines
 import test_option_fuzz as tf
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
+mk = engines.sim_engine if os.environ.get("FUZZ_ENGINE") == "sim" else engines.gpu_engine
+exotic = 0
 t0 = time.time()
 ok = skipped = failed = 0
 for seed in range(first, last):
     try:
-        tf._check(engines.gpu_engine, seed)
+        tf._check(mk, seed)
         ok += 1
     except pytest.skip.Exception:
         skipped += 1
