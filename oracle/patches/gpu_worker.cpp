@@ -120,7 +120,6 @@ struct ParamBlock {
 
 struct State {
     std::mutex mu;               // submission order = window order; also guards fastp_gpu_* calls that touch the stream
-    std::mutex xmu;              // first use of a window's raw-text rows (units with letters outside ACGTN)
     fastp_gpu_ctx* ctx = nullptr;
     ParamBlock B;
     fastp_gpu_counter_layout lay;
@@ -278,6 +277,7 @@ void make_state(Options* o, bool paired) {
         if (p.n_adapter_fasta) { w.ev_cap = (int32_t)(units * 2 * std::min(p.n_adapter_fasta, 8) + 16); w.ev = (fastp_gpu_adapter_event*)pinned((size_t)w.ev_cap * sizeof(fastp_gpu_adapter_event)); }
         w.count.assign((size_t)s->K, 0);
         w.xmask.assign(units, 0);
+        for (int m = 0; m < (paired ? 2 : 1); m++) w.xraw[m].assign(units * (size_t)s->max_len, 0);   // virtual until a unit with such letters turns up
     }
     for (int k = 0; k < NSLOT; k++) s->win[k].next.store(k);
     G = s;
@@ -503,10 +503,6 @@ bool pack_into(Window& w, size_t row, int n, bool paired) {
     for (int i = 0; i < n; i++) {
         if (!w.xmask[row + (size_t)i]) continue;
         for (int m = 0; m < (paired ? 2 : 1); m++) {
-            if (w.xraw[m].empty()) {
-                std::lock_guard<std::mutex> lk(G->xmu);
-                if (w.xraw[m].empty()) w.xraw[m].assign((size_t)G->K * PACK_SIZE * (size_t)G->max_len, 0);
-            }
             memcpy(w.xraw[m].data() + (row + (size_t)i) * (size_t)G->max_len, T.seq[m][(size_t)i], (size_t)T.len[m][(size_t)i]);
         }
         w.xany.store(1, std::memory_order_release);
