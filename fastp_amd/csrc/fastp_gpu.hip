@@ -755,7 +755,7 @@ static int get_events(fastp_gpu_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
 
 // one launch: at most ctx->max_pairs_per_launch units
 // Stats::statRead's overrepresentation analysis (stats.cpp:270-288) of one launch, after its records exist
-static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStream_t st) {
+static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStream_t st, const fastp_gpu_batch* b = nullptr) {
     const fastp_gpu_counter_layout& cl = ctx->cl;
     int rc;
     if (ctx->dp.overrep) {
@@ -772,6 +772,13 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         o.merge_include_unmerged = ctx->dp.merge_include_unmerged;
         o.pair = a.pair;
         for (int m = 0; m < 2; m++) { o.seq[m] = a.seq[m]; o.qual[m] = a.qual[m]; o.len[m] = a.len[m]; o.res[m] = a.res[m]; }
+        if (b && b->n_exotic > 0) {   // units with letters outside ACGTN: the counting kernel reads their symbols from the text
+            o.first = a.first;
+            o.x_unit = ctx->d_x_unit;
+            o.x_n = b->n_exotic;
+            o.x_dense = b->exotic_dense;
+            for (int m = 0; m < 2; m++) { o.x_text[m] = b->exotic_text[m]; o.x_off[m] = b->exotic_off[m]; }
+        }
         const int nb = (n + 255) / 256;
         const int task_cap = 4 * (n / o.sampling + 2);
         rc = ensure(ctx, (void**)&ctx->d_ovr_work, &ctx->ovr_work_cap, ((size_t)2 * nb + 1 + task_cap) * 4);
@@ -1109,13 +1116,12 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         }
         return launch_dup(nullptr, true);
     }
-    // the overrepresentation analysis reads the rows by their TRUE lengths (with listed exotic units the submit was refused:
-    // only FASTP_GPU_EXACT=1 gets here with a masked copy)
+    // the overrepresentation analysis reads the rows by their TRUE lengths, and the listed units' symbols from their text
     auto overrep = [&]() -> int {
         KernelArgs ao = a;
         ao.len[0] = true_len[0];
         ao.len[1] = true_len[1];
-        return launch_overrep(ctx, ao, n, st);
+        return launch_overrep(ctx, ao, n, st, b);
     };
     if (mode == CHUNK_OVERREP) return overrep();
     if (mode == CHUNK_PASS2) {
@@ -1348,7 +1354,6 @@ static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fas
         // units with letters outside ACGTN: the text kernel (fq_exact.h) takes them, launch by launch (launch_chunk)
         if (!b->exotic_unit || !b->exotic_text[0] || !b->exotic_off[0] || (ctx->dp.paired && (!b->exotic_text[1] || !b->exotic_off[1])))
             return fail(ctx, FASTP_GPU_E_INVALID, "n_exotic > 0 needs exotic_unit, exotic_text and exotic_off");
-        if (ctx->dp.overrep) return fail(ctx, FASTP_GPU_E_ALPHABET, "letters outside ACGTN together with the overrepresentation analysis");
         for (int k = 0; k < b->n_exotic; k++)
             if (b->exotic_unit[k] < 0 || b->exotic_unit[k] >= b->n || (k && b->exotic_unit[k] <= b->exotic_unit[k - 1]))
                 return fail(ctx, FASTP_GPU_E_INVALID, "exotic_unit must be ascending unit indexes of the batch");

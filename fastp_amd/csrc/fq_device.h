@@ -3059,6 +3059,7 @@ FQ_DEV u32 ovr_sym_corrected(const OvrArgs& o, const u32* srow, const u8* qrow, 
 struct OvrRead {
     const u32* srow[2];
     const u8* qrow[2];
+    const u8* raw[2];   // the mate's sequence text when the unit holds letters outside ACGTN (else null)
     u32 chain[2];   // correction chains of the two mates (0 = none)
     int f[2];       // merged: front of r1 / index of r2'[last] ; plain: f[0] = front
     int m1;         // merged: bases taken from r1
@@ -3067,14 +3068,49 @@ struct OvrRead {
     int src;
     int mt;         // plain: which mate
 };
+// the text of a unit with letters outside ACGTN: the byte at `at` of mate mt with BaseCorrector's edits applied
+FQ_DEV u32 ovr_raw_byte(const OvrArgs& o, const OvrRead& r, int mt, int at) {
+    u32 b = r.raw[mt][at];
+    for (u32 e = r.chain[mt]; e; e = o.corr_next[e - 1]) {
+        const u32 w1 = o.corr[2 * (size_t)(e - 1) + 1];
+        if ((int)(w1 & 0xFFFFu) == at) b = (w1 >> 16) & 0xFFu;
+    }
+    return b;
+}
+// A T C G N as the packed rows give them (0..4); any other byte is its own symbol, as in the seed tables (fq_host.cpp)
+FQ_DEV u32 ovr_byte_sym(u32 b) { return b == 'A' ? 0u : b == 'T' ? 1u : b == 'C' ? 2u : b == 'G' ? 3u : b == 'N' ? 4u : b; }
+FQ_DEV u32 ovr_byte_complement(u32 b) {   // util.h:16-33
+    switch (b) {
+        case 'A': case 'a': return 'T';
+        case 'T': case 't': return 'A';
+        case 'C': case 'c': return 'G';
+        case 'G': case 'g': return 'C';
+        default: return 'N';
+    }
+}
+// the raw sequence text of unit g's mate m, or null (binary search in the batch's list)
+FQ_DEV const u8* ovr_raw(const OvrArgs& o, int g, int m) {
+    const int unit = o.first + g;
+    int lo = 0, hi = o.x_n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (o.x_unit[mid] < unit) lo = mid + 1;
+        else hi = mid;
+    }
+    if (lo >= o.x_n || o.x_unit[lo] != unit) return nullptr;
+    return o.x_text[m] + (o.x_dense ? o.x_off[m][4 * (size_t)unit + 1] : o.x_off[m][lo]);
+}
+
 FQ_DEV u32 ovr_fetch(const OvrArgs& o, const OvrRead& r, int j) {
     if (r.src != OVR_SRC_MERGED || j < r.m1) {
         const int mt = r.src == OVR_SRC_MERGED ? 0 : r.mt;
         const int at = r.f[0] + j;
+        if (r.raw[mt]) return ovr_byte_sym(ovr_raw_byte(o, r, mt, at));
         return r.chain[mt] ? ovr_sym_corrected(o, r.srow[mt], r.qrow[mt], at, r.chain[mt]) : ovr_sym(r.srow[mt], r.qrow[mt], at);
     }
     // merged tail: rc(r2')[ol + k], k = j - m1  =  complement of r2'[len2 - 1 - ol - k]   (overlapanalysis.cpp:148-179)
     const int at = r.f[1] - r.ol - (j - r.m1);
+    if (r.raw[1]) return ovr_byte_sym(ovr_byte_complement(ovr_raw_byte(o, r, 1, at)));
     const u32 s = r.chain[1] ? ovr_sym_corrected(o, r.srow[1], r.qrow[1], at, r.chain[1]) : ovr_sym(r.srow[1], r.qrow[1], at);
     return s < 4u ? (s ^ 1u) : s;  // A0<->T1, C2<->G3
 }
@@ -3106,8 +3142,9 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
         r.qrow[m] = (const u8*)(o.qual[m] + (size_t)g * o.qw_g);
         // the pre-filtering Stats saw the read before BaseCorrector touched it (peprocessor.cpp:419-432 vs :447-460)
         r.chain[m] = (post && o.corr) ? o.corr_head[o.paired ? (u32)g * 2u + (u32)m : (u32)g] : 0u;
+        r.raw[m] = (work && o.x_n) ? ovr_raw(o, g, m) : nullptr;
     }
-    if (!o.paired) { r.srow[1] = r.srow[0]; r.qrow[1] = r.qrow[0]; r.chain[1] = 0u; }
+    if (!o.paired) { r.srow[1] = r.srow[0]; r.qrow[1] = r.qrow[0]; r.chain[1] = 0u; r.raw[1] = r.raw[0]; }
     r.m1 = 0;
     r.ol = 0;
     r.f[0] = r.f[1] = 0;

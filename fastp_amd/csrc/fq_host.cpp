@@ -185,7 +185,9 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
                 u32 h = 0;
                 for (int k = 0; k < L; k++) {
                     int sy = base_code(q[k]);
-                    if (sy < 0) { if (q[k] == 'N') sy = 4; else { err = "overrep seed with a letter outside ACGTN"; return FASTP_GPU_E_INVALID; } }
+                    // a seed the Evaluator cut from reads with letters outside ACGTN: such a byte is its own symbol (> 4), equal
+                    // only to the same byte of a listed unit's text (ovr_byte_sym); the packed rows never produce it
+                    if (sy < 0) sy = q[k] == 'N' ? 4 : (int)(unsigned char)q[k];
                     luts.ovr_sym[m][(size_t)i * OVR_SEED_STRIDE + k] = (u8)sy;
                     h = h * OVR_HASH_MUL + (u32)(sy + 1);
                 }

@@ -184,7 +184,7 @@ struct OvrMate {                 // one mate's seed set (Options::overRepSeqs1 /
     u32 pw[OVR_STEPS];           // OVR_HASH_MUL ^ (step - 1)
     const u32* table;            // open addressing, pairs {key, seed index + 1}; index 0 = empty
     u32 table_mask;              // slots - 1
-    const u8* seed_sym;          // [n_seeds][OVR_SEED_STRIDE] symbols 0..4 (A T C G N)
+    const u8* seed_sym;          // [n_seeds][OVR_SEED_STRIDE] symbols 0..4 (A T C G N); any other byte stands for itself
     const int* seed_len;
 };
 
@@ -221,6 +221,12 @@ struct OvrArgs {
     int first;                   // index of this launch's first unit inside the batch (the entries' read field counts from the batch start)
     u32* corr_head;              // [(paired ? 2 : 1) * n]
     u32* corr_next;              // [corr_cap]
+    // units with letters outside ACGTN (fastp_gpu_batch::exotic_*): their symbols come from the raw text - a foreign byte
+    // is its own symbol (seeds cut from such reads hold it the same way), its complement follows util.h:16-33
+    const int* x_unit;
+    int x_n, x_dense;
+    const u8* x_text[2];
+    const u32* x_off[2];
 };
 
 // ---- FASTQ text -> packed rows on the device (fq_parse_* kernels) ----

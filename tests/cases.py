@@ -175,14 +175,22 @@ CASES["pe_overrep_merge"] = (True, ["-G", "-p", "-P", "2", "-m", "--merged_out",
 CASES["pe_overrep_merge_unmerged"] = (True, ["-G", "-p", "-P", "2", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq", "--dedup"],
                                       _pe(merge=1, correction=1, merge_include_unmerged=1, dedup=1),
                                       {"insert_mean": 260.0, "insert_sd": 90.0, "polyx_frac": 0.3, "dup_frac": 0.3})
-OVERREP = {"pe_overrep": 3, "se_overrep": 2, "pe_overrep_correction": 3, "pe_overrep_merge": 2, "pe_overrep_merge_unmerged": 2}
+# -p on reads with letters outside ACGTN: the counting kernel takes those units' symbols from their text (a foreign byte equals
+# no seed symbol; in a merged read a/c/g/t complement to real bases, util.h:16-33)
+CASES["pe_exotic_overrep_merge"] = (True, ["-G", "-p", "-P", "2", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq"],
+                                    _pe(merge=1, correction=1, merge_include_unmerged=1),
+                                    {"insert_mean": 200.0, "insert_sd": 80.0, "polyx_frac": 0.3, "lowq_site_rate": 0.06, "exotic_frac": 0.2})
+CASES["se_exotic_overrep"] = (False, ["-G", "-A", "-p", "-P", "2"], _se(adapter_enabled=0),
+                              {"insert_mean": 110.0, "insert_sd": 30.0, "polyx_frac": 0.3, "exotic_frac": 0.2})
+OVERREP = {"pe_overrep": 3, "se_overrep": 2, "pe_overrep_correction": 3, "pe_overrep_merge": 2, "pe_overrep_merge_unmerged": 2,
+           "pe_exotic_overrep_merge": 2, "se_exotic_overrep": 2}
 # reads LONGER than the length the reference evaluates from the first 1000 reads (Evaluator::computeSeqLen evaluator.cpp:54-76; it grows
 # its buffers, Stats::extendBuffer stats.cpp:65-83, quirk ledger: a20): the first 1100 units are at most 100 bases, later ones 150
 CASES["pe_late_long_reads"] = (True, ["-G", "--cut_right"], _pe(cut_right=1), {"gen": "late_long"})
 CASES["se_late_long_reads"] = (False, ["-G", "-A", "-p", "-P", "2"], _se(adapter_enabled=0), {"gen": "late_long", "insert_mean": 80.0, "insert_sd": 25.0})
 OVERREP["se_late_long_reads"] = 2   # the distance arrays are sized by the EVALUATED length (100): stats.cpp:279
 N_PAIRS_OVERRIDE = {"pe_late_long_reads": 1700, "se_late_long_reads": 1700, "pe_overrep": 1500, "se_overrep": 1500, "pe_overrep_correction": 1500, "pe_overrep_merge": 1500,
-                    "pe_overrep_merge_unmerged": 1500,
+                    "pe_overrep_merge_unmerged": 1500, "pe_exotic_overrep_merge": 1500, "se_exotic_overrep": 1500,
                     "pe_allow_gap_indel": 1500, "pe_allow_gap_indel_corr": 1500, "se_adapter_indel": 1500,
                     "pe_adapter_indel": 1500}   # golden input size (default 500)
 

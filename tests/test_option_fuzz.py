@@ -94,7 +94,8 @@ def random_case(seed):
         if paired:
             p.adapter_seq_r2 = cases.LONG_R2.encode()
     # letters outside ACGTN (soft-masked stretches, IUPAC codes, '.'): the text kernel (fq_exact.h) takes those units
-    if not p.overrep_enabled and pick(0.3):
+    # (with -p the seeds were evaluated on the reads as they were before: seeds are ACGTN, fq_host.cpp refuses others)
+    if pick(0.3):
         synth.add_exotic(d, seed=seed, read_frac=float(rng.choice([0.005, 0.05, 0.4])), paired=paired)
     return p, d, paired
 

@@ -15,7 +15,7 @@ from fastp_amd import abi, engine
 
 STREAM_GOLDENS = [n for n in golden_util.names() if "overlapped_out" not in n and n != "pe_exotic_default"]   # --overlapped_out's stream is the host glue's
 SIM_CASES = ["pe_correction", "pe_merge_unmerged", "pe_filters", "pe_adapter_fasta", "pe_umi_per_read", "pe_overrep", "pe_noadapter_dedup",
-             "se_adapter_cut", "se_adapter_fasta", "testdata_pe", "pe_exotic_merge", "pe_exotic_dedup_adapters", "se_exotic_adapter"]
+             "se_adapter_cut", "se_adapter_fasta", "testdata_pe", "pe_exotic_merge", "pe_exotic_dedup_adapters", "se_exotic_adapter", "pe_exotic_overrep_merge"]
 
 
 def _files(tmp_path, fq1, fq2):
