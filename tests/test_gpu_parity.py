@@ -47,7 +47,7 @@ def _compare(name, params, d, paired, n_expect=None):
 @pytest.mark.parametrize("name", SUPPORTED)
 def test_gpu_equals_oracle(name):
     paired, flags, pf, skw = cases.CASES[name]
-    d = synth.synth_pairs(12000, L=150, seed=77, paired=paired, **skw)   # (54 flag sets: the host-side oracle is most of this test's time)
+    d = synth.synth_pairs(12000, L=150, seed=77, paired=paired, **skw)   # (46 flag sets: the host-side oracle is most of this test's time)
     params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
     _compare(name, params, d, paired)
 
