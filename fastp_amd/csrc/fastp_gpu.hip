@@ -1034,14 +1034,16 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         e.hash_only = hash_only;
         // Stats' per-base tables of a workgroup in LDS when four of them fit (not the hash pre-pass, which counts nothing)
         const int slot_dwords = 34 * (int)c.cycles + 1024 + 128;
-        const bool lds_tables = !hash_only && (size_t)4 * slot_dwords * 4 <= (size_t)150 * 1024 && env_int("FASTP_GPU_EXACT_LDS", 1);
+        const int slots = !ctx->dp.paired ? 2 : ctx->dp.merge ? 3 : 4;   // the Stats objects a unit can reach
+        const bool lds_tables = !hash_only && (size_t)slots * slot_dwords * 4 <= (size_t)150 * 1024 && env_int("FASTP_GPU_EXACT_LDS", 1);
         e.lds_slot_dwords = lds_tables ? slot_dwords : 0;
+        e.lds_slots = lds_tables ? slots : 0;
         const int wg = lds_tables ? 512 : 64;   // one 512-lane workgroup per CU owns the tables; without them small workgroups
         const int lanes = std::min((e.x_count + wg - 1) / wg * wg, env_int("FASTP_GPU_EXACT_LANES", lds_tables ? ctx->cus * 512 : 16384) / wg * wg);
         int r2 = ensure(ctx, (void**)&ctx->d_x_scratch, &ctx->x_scratch_cap, (size_t)lanes * e.lane_bytes);
         if (r2) return r2;
         e.scratch = ctx->d_x_scratch;
-        hipLaunchKernelGGL(fq_exact_kernel, dim3(lanes / wg), dim3(wg), (size_t)4 * e.lds_slot_dwords * 4, st, e);
+        hipLaunchKernelGGL(fq_exact_kernel, dim3(lanes / wg), dim3(wg), (size_t)e.lds_slots * e.lds_slot_dwords * 4, st, e);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };

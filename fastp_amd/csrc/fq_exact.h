@@ -54,6 +54,7 @@ struct ExactArgs {
     // 128 quality characters]) and added to the block once at the end - with every lane of a launch adding to the same few
     // thousand int64s in HBM the kernel ran at the atomics' rate.  0: the tables do not fit (merge mode of long reads)
     int lds_slot_dwords;
+    int lds_slots;       // Stats objects that can be touched: 2 single-end, 3 merge mode (nothing reaches POST2), else 4
 };
 
 enum { EXACT_BUFS = 14, EXACT_ADAPTER_BYTES = 3 * 264 };   // text buffers of ML bytes per lane; three decoded adapters
@@ -904,7 +905,7 @@ FQ_DEV void x_process_pe(const ExactArgs& E, u32* lds, int gp, const XBufs& b) {
 }
 
 FQ_DEV void exact_body(const ExactArgs& E, u32* lds) {
-    const int lds_total = 4 * E.lds_slot_dwords;
+    const int lds_total = E.lds_slots * E.lds_slot_dwords;
     if (lds_total) {
         for (int i = thread_id(); i < lds_total; i += block_threads()) lds[i] = 0u;
         block_sync();
