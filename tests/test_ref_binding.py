@@ -338,6 +338,32 @@ def test_patched_reference_reader_hook_across_buffer_refills(tmp_path):
     _check("se_default_noadapter", REF_SIM, 52000, tmp_path, seed=48, threads=2, eol=b"\r\n", mode="pack")
 
 
+@pytest.mark.parametrize("name,kw", [("pe_exotic_merge", dict(eol=b"\r\n", threads=3)), ("se_exotic_adapter", dict(gz=True, threads=4)),
+                                     ("pe_exotic_dedup_adapters", dict(gz=True, threads=2, mode="pack")),
+                                     ("se_exotic_overrep", dict(eol=b"\r", trailing=False, threads=2, more_flags=("--reads_to_process", "700"),
+                                                                expect_units=700))])
+def test_patched_reference_exotic_letters_with_line_ends_gz_and_limits(name, kw, tmp_path):
+    """letters outside ACGTN together with what else the stream has to get right: other line ends, several -w, ".gz" outputs,
+    --reads_to_process, pack mode"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 1500, tmp_path, seed=11, **kw)
+
+
+def test_patched_reference_exotic_letters_in_reads_longer_than_evaluated(tmp_path):
+    """the stream re-plans for a longer read while units with letters outside ACGTN (and -p) are in flight"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    paired, flags, pf, skw = cases.CASES["se_late_long_reads"]
+    cases.CASES["_se_late_long_exotic"] = (False, flags, pf, dict(skw, exotic_frac=0.1))
+    BINDING_CASES["_se_late_long_exotic"] = []
+    try:
+        err = _check("_se_late_long_exotic", REF_SIM, 1700, tmp_path, seed=5)
+        assert "1 re-plan(s)" in err, err[-400:]
+    finally:
+        del cases.CASES["_se_late_long_exotic"], BINDING_CASES["_se_late_long_exotic"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(BINDING_CASES))
 def test_gpu_patched_reference_equals_reference(name, tmp_path):
