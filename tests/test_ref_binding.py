@@ -8,6 +8,7 @@ inputs); the `-m gpu` test runs the real library.  Both binaries are built in th
 /root/reference) and travel to the GPU box with oracle/_ref/."""
 import json
 import os
+import sys
 import subprocess
 
 import pytest
@@ -362,6 +363,18 @@ def test_patched_reference_exotic_letters_in_reads_longer_than_evaluated(tmp_pat
         assert "1 re-plan(s)" in err, err[-400:]
     finally:
         del cases.CASES["_se_late_long_exotic"], BINDING_CASES["_se_late_long_exotic"]
+
+
+@pytest.mark.parametrize("seed", range(2000, 2006))
+def test_patched_reference_random_command_lines(seed):
+    """tools/binding_fuzz.py: a random fastp command line on a random input (line ends, -w, ".gz", stream or pack binding, letters
+    outside ACGTN) - every output file and the JSON report equal to the reference's (1000 more: profiles/r04_binding_fuzz_emulator.txt)"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import binding_fuzz
+    problems, c = binding_fuzz.run(seed, REF_SIM, True)
+    assert not problems, f"{' '.join(c['flags'])} [{c['mode']}, -w {c['threads']}]: " + "; ".join(problems[:6])
 
 
 @pytest.mark.gpu
