@@ -38,6 +38,8 @@ def random_command(seed):
         f += ["-a", ADAPTER_R1]
         if paired and pick(0.7):
             f += ["--adapter_sequence_r2", ADAPTER_R2]
+    if paired and "-A" not in f and "-a" not in f and pick(0.3):
+        f += ["--detect_adapter_for_pe"]   # the Evaluator's adapter detection on both mates (its counting loop runs on the device)
     if paired and pick(0.15):
         f += ["--allow_gap_overlap_trimming"]
     if pick(0.15):
