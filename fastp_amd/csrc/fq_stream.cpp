@@ -6,6 +6,11 @@
 // Host code; the per-read work is the device entry points of fastp_gpu.h.  Four threads + two small I/O pools:
 //
 //   reader thread   pread pieces of the next chunk of each file into page-locked memory, H2D copy on its own stream
+//                   (".gz" inputs, FastqReader::init src/fastqreader.cpp:169-199: a bgzip-written file - isBgzf,
+//                   src/bgzf.h:17-27 - is shipped COMPRESSED, cut at member boundaries by fastp_gpu_bgzf_index, and
+//                   inflated on the device by the caller thread, which stands in for BgzfMtReader src/bgzf.h:36-239;
+//                   any other gzip stream is inflated here with zlib, one pool thread per file, as
+//                   FastqReader::readToBufIgzip src/fastqreader.cpp:88-149 does on the reference's reader thread)
 //   caller thread   parse -> worker loop -> format (-> deflate) on the context's stream, D2H of the output text
 //   writer thread   pwrite pieces of a chunk's output (or the emit callback), in chunk order
 //   replay thread   FilterResult::addAdapterTrimmed for the reads the records flag, in input order
@@ -22,6 +27,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -49,6 +55,19 @@ double now_s() {
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+
+// isBgzf (src/bgzf.h:17-27) on the file's first bytes; FastqReader::init looks at the name first (".gz")
+// 0 plain text, 1 gzip, 2 BGZF (SRC_* below)
+int input_kind(const std::string& path) {
+    if (path.size() < 3 || path.compare(path.size() - 3, 3, ".gz") != 0) return 0;
+    unsigned char h[18];
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return 1;   // the run reports the open error
+    const ssize_t n = pread(fd, h, 18, 0);
+    close(fd);
+    if (n == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 0x42 && h[13] == 0x43 && (h[14] | (h[15] << 8)) == 2) return 2;
+    return 1;
 }
 
 // a few threads that run positional reads / writes; wait() returns when everything submitted so far is done
@@ -126,10 +145,13 @@ struct ReadReq {
 };
 struct ReadDone {
     int slot = 0;
-    int64_t nb[2] = {0, 0};
+    int64_t nb[2] = {0, 0};        // fresh TEXT bytes behind the carried ones (of a BGZF file: what its blocks inflate to)
     bool eof[2] = {false, false};
-    int err = 0;
+    int err = 0;                   // 1 file I/O, 2 host-to-device copy, 4 a gzip stream is damaged, 5 a BGZF file is damaged
+    int32_t n_blocks = 0;          // BGZF members of this trip (both files), indexed in d_idx[slot], bytes in d_comp[slot]
+    int64_t file_bytes[2] = {0, 0};
 };
+enum { SRC_PLAIN = 0, SRC_GZIP = 1, SRC_BGZF = 2 };
 struct WriteJob {
     int oslot = -1;                // -1: stop
     int64_t len[FASTP_GPU_N_OUTPUTS] = {0, 0, 0, 0, 0, 0};
@@ -160,8 +182,17 @@ struct fastp_gpu_stream {
     // ---- buffers ------------------------------------------------------------------------------------------
     int64_t chunk = 0, text_cap = 0;
     int32_t max_records = 0;
-    uint8_t* d_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [slot][mate]
+    uint8_t* d_text[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [slot][mate]; the mates of a slot are one allocation
     uint8_t* pin_in[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // compressed inputs (src_kind per file: SRC_*)
+    int src_kind[2] = {SRC_PLAIN, SRC_PLAIN};
+    bool any_bgzf = false;
+    int64_t comp_cap = 0;                            // compressed bytes of one file per trip (staging + device)
+    int32_t max_blocks = 0;                          // BGZF members of one file per trip
+    uint8_t* pin_comp[2] = {nullptr, nullptr};       // [mate]: the file's bytes not yet handed to the device, from the front
+    uint8_t* d_comp[2] = {nullptr, nullptr};         // [slot]: mate m's members at m * comp_cap
+    uint8_t* pin_idx[2] = {nullptr, nullptr};        // [slot]: pay_off | pay_len | isize | crc (u32 each) | out_off (u64), n entries each
+    uint8_t* d_idx[2] = {nullptr, nullptr};
     uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
     uint16_t* d_len[2] = {nullptr, nullptr};
     uint32_t *d_loff[2] = {nullptr, nullptr}, *d_llen[2] = {nullptr, nullptr};
@@ -207,7 +238,16 @@ void free_buffers(fastp_gpu_stream* s) {
     auto dfree = [](void* p) { if (p) (void)hipFree(p); };
     auto hfree = [](void* p) { if (p) (void)hipHostFree(p); };
     for (int sl = 0; sl < 2; sl++)
-        for (int m = 0; m < 2; m++) { dfree(s->d_text[sl][m]); s->d_text[sl][m] = nullptr; hfree(s->pin_in[sl][m]); s->pin_in[sl][m] = nullptr; }
+        for (int m = 0; m < 2; m++) {
+            if (m == 0) dfree(s->d_text[sl][0]);   // mate 2's text lies behind mate 1's in the same allocation
+            s->d_text[sl][m] = nullptr;
+            hfree(s->pin_in[sl][m]);
+            s->pin_in[sl][m] = nullptr;
+        }
+    for (int k = 0; k < 2; k++) {
+        hfree(s->pin_comp[k]); dfree(s->d_comp[k]); hfree(s->pin_idx[k]); dfree(s->d_idx[k]);
+        s->pin_comp[k] = s->d_comp[k] = s->pin_idx[k] = s->d_idx[k] = nullptr;
+    }
     for (int m = 0; m < 2; m++) {
         dfree(s->d_seq[m]); dfree(s->d_qual[m]); dfree(s->d_len[m]); dfree(s->d_loff[m]); dfree(s->d_llen[m]); dfree(s->d_res[m]);
         s->d_seq[m] = s->d_qual[m] = nullptr; s->d_len[m] = nullptr; s->d_loff[m] = s->d_llen[m] = nullptr; s->d_res[m] = nullptr;
@@ -247,11 +287,29 @@ int alloc_buffers(fastp_gpu_stream* s) {
     const int nm = s->nm;
     s->text_cap = (s->chunk + 4096 + 255) / 256 * 256;   // a trip's text never exceeds chunk bytes (see the loop)
     s->max_records = (int32_t)std::max<int64_t>(1024, s->chunk / 32);
-    for (int sl = 0; sl < 2; sl++)
+    for (int sl = 0; sl < 2; sl++) {
+        // one allocation per slot: a single fastp_gpu_inflate_bgzf launch writes the text of both files
+        S_HIP(s, hipMalloc((void**)&s->d_text[sl][0], (size_t)(nm * s->text_cap)));
         for (int m = 0; m < nm; m++) {
-            S_HIP(s, hipMalloc((void**)&s->d_text[sl][m], (size_t)s->text_cap));
+            s->d_text[sl][m] = s->d_text[sl][0] + (size_t)m * (size_t)s->text_cap;
             S_HIP(s, hipHostMalloc((void**)&s->pin_in[sl][m], (size_t)s->text_cap));
         }
+    }
+    if (s->any_bgzf) {
+        // a member holds at most 64 KiB of text and is at worst a stored block + 26 bytes of framing, so the members
+        // that fill a trip's text are never larger than this; one more member may sit incomplete at the end
+        s->comp_cap = (s->chunk + s->chunk / 512 + (1 << 17) + 255) / 256 * 256;
+        s->max_blocks = (int32_t)std::min<int64_t>(s->chunk / 2048 + 64, 1 << 20);
+        const size_t idx_bytes = (size_t)nm * (size_t)s->max_blocks * 24 + 64;
+        for (int m = 0; m < nm; m++)
+            if (s->src_kind[m] == SRC_BGZF) S_HIP(s, hipHostMalloc((void**)&s->pin_comp[m], (size_t)s->comp_cap + 64));
+        for (int sl = 0; sl < 2; sl++) {
+            S_HIP(s, hipMalloc((void**)&s->d_comp[sl], (size_t)(nm * s->comp_cap) + 64));
+            S_HIP(s, hipMemsetAsync(s->d_comp[sl], 0, (size_t)(nm * s->comp_cap) + 64, s->sx));
+            S_HIP(s, hipHostMalloc((void**)&s->pin_idx[sl], idx_bytes));
+            S_HIP(s, hipMalloc((void**)&s->d_idx[sl], idx_bytes));
+        }
+    }
     S_HIP(s, hipMalloc((void**)&s->d_zero, 64));
     S_HIP(s, hipMemsetAsync(s->d_zero, 0, 64, s->sx));
     for (int m = 0; m < nm; m++) {
@@ -540,6 +598,11 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     if (cfg->chunk_bytes <= 0 && getenv("FASTP_GPU_STREAM_CHUNK_BYTES")) s->chunk = atoll(getenv("FASTP_GPU_STREAM_CHUNK_BYTES"));   // tests: many small trips
     s->chunk = std::max<int64_t>(4096, std::min<int64_t>(s->chunk, (int64_t)1 << 30)) / 256 * 256;
     if (s->cfg.io_threads <= 0) s->cfg.io_threads = env_int("FASTP_GPU_STREAM_IO_THREADS", 8);
+    for (int m = 0; m < s->nm; m++) {
+        s->src_kind[m] = input_kind(m ? s->in2 : s->in1);
+        s->st.input_kind[m] = s->src_kind[m];
+        s->any_bgzf = s->any_bgzf || s->src_kind[m] == SRC_BGZF;
+    }
     for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
         const bool possible = q == FASTP_GPU_OUT1 || (s->paired && q == FASTP_GPU_OUT2) || (q == FASTP_GPU_FAILED && cfg->format.want_failed) ||
                               (q == FASTP_GPU_MERGED && s->paired && params->merge) || (q == FASTP_GPU_UNPAIRED1 && s->paired && cfg->format.want_unpaired1) ||
@@ -617,47 +680,197 @@ struct Run {
     explicit Run(fastp_gpu_stream* st) : s(st) {}
 };
 
+// a gzip stream that is not bgzip's: inflated on the host, member after member, as FastqReader::readToBufIgzip does
+// (src/fastqreader.cpp:88-149: a stream may hold several members; anything but a gzip header behind a member, or a
+// file that ends inside one, is an error there too)
+struct GzSource {
+    z_stream z;
+    bool open = false, in_member = false, at_eof = false;
+    int fd = -1;
+    int64_t fpos = 0, fsize = 0;
+    std::vector<uint8_t> in;
+    size_t in_at = 0, in_len = 0;
+    ~GzSource() { if (open) inflateEnd(&z); }
+    // up to `want` bytes of text to dst; < 0: damaged stream / read error
+    int64_t fill(uint8_t* dst, int64_t want, int* err) {
+        if (!open) {
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, 15 + 16) != Z_OK) { *err = 4; return -1; }
+            open = true;
+            in.resize(4 << 20);
+        }
+        int64_t made = 0;
+        while (made < want && !at_eof) {
+            if (in_at == in_len) {
+                const int64_t ask = std::min<int64_t>((int64_t)in.size(), fsize - fpos);
+                int64_t got = 0;
+                while (got < ask) {
+                    const ssize_t r = pread(fd, in.data() + got, (size_t)(ask - got), (off_t)(fpos + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { *err = 1; return -1; }
+                    got += r;
+                }
+                fpos += got;
+                in_at = 0;
+                in_len = (size_t)got;
+                if (got == 0) {
+                    if (in_member) { *err = 4; return -1; }   // "igzip: unexpected eof"
+                    at_eof = true;
+                    break;
+                }
+            }
+            z.next_in = in.data() + in_at;
+            z.avail_in = (uInt)(in_len - in_at);
+            z.next_out = dst + made;
+            z.avail_out = (uInt)std::min<int64_t>(want - made, 1 << 30);
+            const uInt out0 = z.avail_out;
+            const int rc = inflate(&z, Z_NO_FLUSH);
+            in_at = in_len - z.avail_in;
+            made += (int64_t)(out0 - z.avail_out);
+            if (rc == Z_STREAM_END) {
+                in_member = false;
+                if (inflateReset(&z) != Z_OK) { *err = 4; return -1; }
+            } else if (rc == Z_OK || rc == Z_BUF_ERROR) {
+                in_member = true;
+            } else {
+                *err = 4;
+                return -1;
+            }
+        }
+        if (!at_eof && !in_member && in_at == in_len && fpos >= fsize) at_eof = true;
+        return made;
+    }
+};
+
 void reader_main(Run* R) {
     fastp_gpu_stream* s = R->s;
     (void)hipSetDevice(s->cfg.device);
     // reads scale with threads (page-cache copies into page-locked memory), writes do not (writer_main): twice the pool here
     IoPool pool(env_int("FASTP_GPU_STREAM_READ_THREADS", 2 * s->cfg.io_threads));
     int64_t pos[2] = {0, 0};
+    GzSource gz[2];
+    int64_t comp_have[2] = {0, 0};        // BGZF: bytes at the front of pin_comp[m] that no trip has taken yet
+    bool src_eof[2] = {false, false};
+    std::vector<uint32_t> ix32[4];
+    std::vector<uint64_t> ix64;
+    for (int m = 0; m < s->nm; m++) { gz[m].fd = R->fds[m]; gz[m].fsize = R->sizes[m]; }
+    auto pread_pieces = [&](int fd, uint8_t* dst, int64_t off0, int64_t want) {
+        for (int64_t a = 0; a < want; a += IO_PIECE) {
+            const int64_t e = std::min(want, a + IO_PIECE);
+            const int64_t off = off0 + a;
+            std::atomic<int>* err = &R->io_err;
+            pool.submit([fd, dst, a, e, off, err] {
+                int64_t got = 0;
+                while (got < e - a) {
+                    const ssize_t r = pread(fd, dst + a + got, (size_t)(e - a - got), (off_t)(off + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { err->store(1); return; }
+                    got += r;
+                }
+            });
+        }
+    };
     for (;;) {
         ReadReq rq = R->q_req.get();
         if (rq.slot < 0) return;
         ReadDone d;
         d.slot = rq.slot;
+        int64_t gz_made[2] = {0, 0};
+        int gz_err[2] = {0, 0};
         for (int m = 0; m < s->nm; m++) {
-            const int64_t want = std::max<int64_t>(0, std::min(rq.budget[m], R->sizes[m] - pos[m]));
             uint8_t* dst = s->pin_in[rq.slot][m] + rq.carry[m];
-            for (int64_t a = 0; a < want; a += IO_PIECE) {
-                const int64_t e = std::min(want, a + IO_PIECE);
-                const int fd = R->fds[m];
-                const int64_t off = pos[m] + a;
-                std::atomic<int>* err = &R->io_err;
-                pool.submit([fd, dst, a, e, off, err] {
-                    int64_t got = 0;
-                    while (got < e - a) {
-                        const ssize_t r = pread(fd, dst + a + got, (size_t)(e - a - got), (off_t)(off + got));
-                        if (r < 0 && errno == EINTR) continue;
-                        if (r <= 0) { err->store(1); return; }
-                        got += r;
-                    }
-                });
+            if (s->src_kind[m] == SRC_PLAIN) {
+                const int64_t want = std::max<int64_t>(0, std::min(rq.budget[m], R->sizes[m] - pos[m]));
+                pread_pieces(R->fds[m], dst, pos[m], want);
+                pos[m] += want;
+                d.nb[m] = want;
+                d.file_bytes[m] = want;
+                src_eof[m] = pos[m] >= R->sizes[m];
+            } else if (s->src_kind[m] == SRC_GZIP) {
+                if (rq.budget[m] > 0 && !src_eof[m]) {
+                    GzSource* g = &gz[m];
+                    const int64_t want = rq.budget[m];
+                    int64_t* made = &gz_made[m];
+                    int* err = &gz_err[m];
+                    pool.submit([g, dst, want, made, err] { *made = g->fill(dst, want, err); });
+                }
+            } else if (rq.budget[m] > 0) {   // SRC_BGZF: top the staging buffer up
+                const int64_t want = std::max<int64_t>(0, std::min(s->comp_cap - comp_have[m], R->sizes[m] - pos[m]));
+                pread_pieces(R->fds[m], s->pin_comp[m] + comp_have[m], pos[m], want);
+                pos[m] += want;
+                comp_have[m] += want;
+                d.file_bytes[m] = want;
             }
-            pos[m] += want;
-            d.nb[m] = want;
-            d.eof[m] = pos[m] >= R->sizes[m];
         }
         pool.wait();
         if (R->io_err.load()) d.err = 1;
+        for (int m = 0; m < s->nm && !d.err; m++)
+            if (s->src_kind[m] == SRC_GZIP && rq.budget[m] > 0 && !src_eof[m]) {
+                if (gz_made[m] < 0) { d.err = gz_err[m] ? gz_err[m] : 4; break; }
+                d.nb[m] = gz_made[m];
+                src_eof[m] = gz[m].at_eof;
+                d.file_bytes[m] = gz[m].fpos - pos[m];
+                pos[m] = gz[m].fpos;
+            }
+        // ---- BGZF: the whole members at the front of the staging buffers whose text fits the trip ----
+        int64_t consumed[2] = {0, 0};
+        if (s->any_bgzf && !d.err) {
+            int32_t nblk[2] = {0, 0};
+            for (int k = 0; k < 4; k++) ix32[k].clear();
+            ix64.clear();
+            for (int m = 0; m < s->nm && !d.err; m++) {
+                if (s->src_kind[m] != SRC_BGZF || rq.budget[m] <= 0) continue;
+                const size_t at = ix64.size(), room = (size_t)s->max_blocks;
+                for (int k = 0; k < 4; k++) ix32[k].resize(at + room);
+                ix64.resize(at + room);
+                fastp_gpu_inflate_info info;
+                const int rc = fastp_gpu_bgzf_index(s->pin_comp[m], comp_have[m], s->max_blocks, rq.budget[m], ix32[0].data() + at, ix32[1].data() + at,
+                                                    ix32[2].data() + at, ix32[3].data() + at, ix64.data() + at, &info);
+                if (rc != FASTP_GPU_OK) { d.err = 5; break; }
+                nblk[m] = info.n_blocks;
+                for (int k = 0; k < 4; k++) ix32[k].resize(at + (size_t)info.n_blocks);
+                ix64.resize(at + (size_t)info.n_blocks);
+                for (int32_t k = 0; k < info.n_blocks; k++) {
+                    ix32[0][at + (size_t)k] += (uint32_t)((int64_t)m * s->comp_cap);
+                    ix64[at + (size_t)k] += (uint64_t)((int64_t)m * s->text_cap + rq.carry[m]);
+                }
+                consumed[m] = info.consumed;
+                d.nb[m] = info.out_bytes;
+                src_eof[m] = pos[m] >= R->sizes[m] && info.consumed == comp_have[m];
+                // the file has ended and what is left of it is not a whole member: BgzfMtReader stops there silently
+                // (src/bgzf.h:138-142); a run that drops reads unnoticed is worse
+                if (pos[m] >= R->sizes[m] && info.consumed < comp_have[m]) {
+                    const uint8_t* p = s->pin_comp[m] + info.consumed;
+                    const int64_t rest = comp_have[m] - info.consumed;
+                    if (rest < 18 || (int64_t)((uint32_t)p[16] | ((uint32_t)p[17] << 8)) + 1 > rest) { d.err = 5; break; }
+                }
+            }
+            d.n_blocks = nblk[0] + nblk[1];
+            if (!d.err && d.n_blocks > 0) {
+                const size_t n = (size_t)d.n_blocks;
+                uint8_t* w = s->pin_idx[rq.slot];
+                for (int k = 0; k < 4; k++) memcpy(w + 4 * n * (size_t)k, ix32[k].data(), 4 * n);
+                memcpy(w + 16 * n, ix64.data(), 8 * n);
+                if (hipMemcpyAsync(s->d_idx[rq.slot], w, 24 * n, hipMemcpyHostToDevice, s->cp_in) != hipSuccess) d.err = 2;
+                for (int m = 0; m < s->nm && !d.err; m++)
+                    if (consumed[m] > 0 &&
+                        hipMemcpyAsync(s->d_comp[rq.slot] + (size_t)m * (size_t)s->comp_cap, s->pin_comp[m], (size_t)consumed[m], hipMemcpyHostToDevice, s->cp_in) != hipSuccess)
+                        d.err = 2;
+            }
+        }
         for (int m = 0; m < s->nm && !d.err; m++) {
-            const int64_t total = rq.carry[m] + d.nb[m];
+            d.eof[m] = src_eof[m];
+            // a BGZF file's fresh text is made on the device (run_loop): only the carried text goes up from here
+            const int64_t total = rq.carry[m] + (s->src_kind[m] == SRC_BGZF ? 0 : d.nb[m]);
             memset(s->pin_in[rq.slot][m] + total, 0, 32);   // the parser reads 16-byte vectors past the end
             if (hipMemcpyAsync(s->d_text[rq.slot][m], s->pin_in[rq.slot][m], (size_t)total + 32, hipMemcpyHostToDevice, s->cp_in) != hipSuccess) d.err = 2;
         }
         if (!d.err && hipStreamSynchronize(s->cp_in) != hipSuccess) d.err = 2;
+        for (int m = 0; m < s->nm; m++)
+            if (consumed[m] > 0) {   // (after the copy: the staging buffer is its source)
+                memmove(s->pin_comp[m], s->pin_comp[m] + consumed[m], (size_t)(comp_have[m] - consumed[m]));
+                comp_have[m] -= consumed[m];
+            }
         R->q_done.put(d);
     }
 }
@@ -733,14 +946,42 @@ int run_loop(Run* R) {
         double t0 = now_s();
         ReadDone d = R->q_done.get();
         s->st.wait_read_s += now_s() - t0;
-        if (d.err) return s->fail(d.err == 2 ? FASTP_GPU_E_HIP : FASTP_GPU_E_INVALID, d.err == 2 ? "host-to-device copy of a chunk failed" : "reading an input file failed");
+        if (d.err) {
+            static const char* const what[6] = {"", "reading an input file failed", "host-to-device copy of a chunk failed", "", 
+                                                "a gzip input is damaged or ends inside a member",
+                                                "a BGZF input is damaged: not a whole bgzip member where one must start, or the file ends inside one"};
+            return s->fail(d.err == 2 ? FASTP_GPU_E_HIP : FASTP_GPU_E_INVALID, what[d.err < 6 ? d.err : 1]);
+        }
         slot = d.slot;
+        if (d.n_blocks > 0) {   // BgzfMtReader's pool of inflaters (src/bgzf.h:165-195): one launch for the members of both files
+            t0 = now_s();
+            const size_t nb = (size_t)d.n_blocks;
+            const uint8_t* ix = s->d_idx[slot];
+            int32_t bad = -1;
+            static const int check_crc = env_int("FASTP_GPU_STREAM_CHECK_CRC", 1);
+            if (fastp_gpu_inflate_bgzf(s->ctx, s->d_comp[slot], d.n_blocks, (const uint32_t*)ix, (const uint32_t*)(ix + 4 * nb), (const uint32_t*)(ix + 8 * nb),
+                                       (const uint32_t*)(ix + 12 * nb), (const uint64_t*)(ix + 16 * nb), s->d_text[slot][0], (int64_t)nm * s->text_cap, check_crc,
+                                       &bad) != FASTP_GPU_OK)
+                return s->fail_ctx(FASTP_GPU_E_INVALID, bad >= 0 ? "a BGZF member of an input does not inflate to what its trailer says (damaged file)" : "fastp_gpu_inflate_bgzf");
+            // the text comes to the host as well: the part no record covers is carried from there, the adapter replay cuts
+            // its strings from it
+            for (int m = 0; m < nm; m++) {
+                if (s->src_kind[m] != SRC_BGZF) continue;
+                S_HIP(s, hipMemsetAsync(s->d_text[slot][m] + carry[m] + d.nb[m], 0, 32, s->sx));
+                if (d.nb[m] > 0)
+                    S_HIP(s, hipMemcpyAsync(s->pin_in[slot][m] + carry[m], s->d_text[slot][m] + carry[m], (size_t)d.nb[m], hipMemcpyDeviceToHost, s->sx));
+            }
+            S_HIP(s, hipStreamSynchronize(s->sx));
+            s->st.inflate_s += now_s() - t0;
+        }
         int64_t total[2] = {0, 0};
-        bool all_eof = true;
+        bool all_eof = true, any_fresh = false;
         for (int m = 0; m < nm; m++) {
             total[m] = carry[m] + d.nb[m];
             s->st.bytes_in[m] += d.nb[m];
+            s->st.bytes_file[m] += d.file_bytes[m];
             all_eof = all_eof && d.eof[m];
+            any_fresh = any_fresh || d.nb[m] > 0;
         }
         // ---- parse: both mates to the same number of records ----
         int32_t cap = s->max_records;
@@ -816,6 +1057,9 @@ int run_loop(Run* R) {
         } else if (n == 0) {
             for (int m = 0; m < nm; m++)
                 if (left[m] >= s->chunk) return s->fail(FASTP_GPU_E_INVALID, "a record does not fit the chunk size (FASTP_GPU_STREAM_CHUNK_MB)");
+            // nothing parsed and nothing new arrived: a BGZF member (up to 64 KiB of text) takes whole-member room behind the carried text
+            if (!any_fresh && total[0] + total[1] > 0)
+                return s->fail(FASTP_GPU_E_INVALID, "a record (or a BGZF member) does not fit the chunk size (FASTP_GPU_STREAM_CHUNK_MB)");
         }
         // the text the records do not cover moves to the front of the other slot; the reader fills in behind it while
         // the device works on this trip

@@ -13,6 +13,8 @@
  *   WriterThread::inputPwrite's per-pack gzip members  src/writerthread.cpp:118-168
  *   FilterResult::addAdapterTrimmed  src/filterresult.cpp:124-180 (replayed on the host from the parsed text)
  *
+ *   BgzfMtReader (bgzip-written ".gz" inputs)  src/bgzf.h:36-239  } fastp_gpu_inflate_bgzf on the compressed bytes
+ *
  * What runs where: the host reads raw chunks of the input files into page-locked memory (a small pool of
  * positional reads), copies them to HBM and gets text back; line splitting + packing
  * (fastp_gpu_parse_fastq), the worker loop (fastp_gpu_submit_device), record formatting for every output
@@ -44,7 +46,11 @@ extern "C" {
 typedef int (*fastp_gpu_stream_emit_fn)(void* user, int stream, const char* data, int64_t len);
 
 typedef struct fastp_gpu_stream_config {
-    const char* in1;            /* plain FASTQ file (a regular file: it is read with pread)               */
+    const char* in1;            /* FASTQ file (a regular file: it is read with pread).  A name that ends in ".gz" is a
+                                 * gzip stream, as for FastqReader::init (src/fastqreader.cpp:169-199): a bgzip-written
+                                 * one (isBgzf, src/bgzf.h:17-27) goes to the device compressed and is inflated there
+                                 * (fastp_gpu_bgzf_index + fastp_gpu_inflate_bgzf in place of BgzfMtReader), any other
+                                 * is inflated by zlib on one host thread per file (readToBufIgzip :88-149)          */
     const char* in2;            /* second file of a paired run, NULL for single-end                        */
     int64_t chunk_bytes;        /* text per file and trip; 0 = 16 MiB (FASTP_GPU_STREAM_CHUNK_MB)          */
     int32_t io_threads;         /* positional reads / writes in flight; 0 = 8 (FASTP_GPU_STREAM_IO_THREADS) */
@@ -69,6 +75,9 @@ typedef struct fastp_gpu_stream_stats {
     int64_t bytes_in[2];
     int64_t bytes_out[FASTP_GPU_N_OUTPUTS];   /* as written (compressed size for compressed streams)       */
     double wall_s, setup_s, wait_read_s, parse_s, engine_s, format_s, deflate_s, d2h_s, wait_write_s, write_s, replay_s;
+    double inflate_s;           /* BGZF inputs: the device inflate + the text's copy to the host                */
+    int64_t bytes_file[2];      /* bytes read from each input file (bytes_in counts TEXT)                        */
+    int32_t input_kind[2];      /* 0 plain text, 1 gzip inflated on the host, 2 BGZF inflated on the device      */
 } fastp_gpu_stream_stats;
 
 typedef struct fastp_gpu_stream fastp_gpu_stream;

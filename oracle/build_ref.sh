@@ -7,7 +7,7 @@
 # (nothing is copied into this repo).  Two third-party dependencies of the
 # reference are absent from this image, so two tiny shims of our own are used:
 #   * oracle/shims/simd_scalar.cpp   replaces src/simd.cpp (Google Highway 1.3.0)
-#   * oracle/shims/isa-l/igzip_lib.h stubs ISA-L v2.31.1 (gz *input* unsupported)
+#   * oracle/shims/isa-l/igzip_lib.h provides the ISA-L v2.31.1 inflate calls the reader names, over zlib
 # libdeflate comes from /opt/conda (v1.8).  We do NOT run the reference Makefile.
 set -euo pipefail
 REF=${FASTP_REFERENCE_ROOT:-/root/reference}
@@ -30,7 +30,7 @@ for f in "$REF"/src/*.cpp; do
     b=$(basename "$f" .cpp)
     [ "$b" = simd ] && continue
     o=$OBJ/$b.o
-    if [ ! -f "$o" ] || [ "$f" -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/shims/isa-l/igzip_lib.h" -nt "$o" ]; then
         $CXX $CXXFLAGS -c "$f" -o "$o" &
         pids+=($!)
     fi
@@ -39,6 +39,6 @@ $CXX $CXXFLAGS -c "$HERE/shims/simd_scalar.cpp" -o "$OBJ/simd_scalar.o" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 # (linked beside its name, then renamed: a test process may be executing the old binary at this moment)
-$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref.tmp.$$" -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ldeflate -lpthread
+$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref.tmp.$$" -L/opt/conda/lib -Wl,-rpath,/opt/conda/lib -ldeflate -lz -lpthread
 mv -f "$OUT/fastp_ref.tmp.$$" "$OUT/fastp_ref"
 echo "built $OUT/fastp_ref"

@@ -5,7 +5,7 @@
 # Every reference source is compiled where it lies under /root/reference/src, except peprocessor.cpp,
 # seprocessor.cpp and evaluator.cpp, of which patched copies are generated into oracle/_ref/src_gpu/ (git-ignored) by
 # oracle/patches/apply_gpu_worker.py: four inserted lines that call oracle/patches/gpu_worker.cpp.
-# Same shims as build_ref.sh (scalar simd, ISA-L stub).  Needs fastp_amd/libfastp_gpu.so (__graft_entry__.build()).
+# Same shims as build_ref.sh (scalar simd, ISA-L inflate over zlib).  Needs fastp_amd/libfastp_gpu.so (__graft_entry__.build()).
 set -euo pipefail
 REF=${FASTP_REFERENCE_ROOT:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -32,7 +32,7 @@ for f in "$REF"/src/*.cpp; do
     src=$f
     { [ "$b" = peprocessor ] || [ "$b" = seprocessor ] || [ "$b" = evaluator ] || [ "$b" = fastqreader ] || [ "$b" = duplicate ]; } && src=$GEN/$b.cpp
     o=$OBJ/$b.o
-    if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$HERE/patches/gpu_worker.h" -nt "$o" ]; then
+    if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$HERE/patches/gpu_worker.h" -nt "$o" ] || [ "$HERE/shims/isa-l/igzip_lib.h" -nt "$o" ]; then
         $CXX $CXXFLAGS -c "$src" -o "$o" &
         pids+=($!)
     fi
@@ -48,7 +48,7 @@ for p in "${pids[@]}"; do wait "$p"; done
 DEFLATE=/usr/lib/x86_64-linux-gnu/libdeflate.so.0
 [ -f "$DEFLATE" ] || DEFLATE=/opt/conda/lib/libdeflate.so
 # (linked beside their names, then renamed: a test process may be executing the old binaries at this moment)
-$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpu.tmp.$$" "$DEFLATE" -lpthread \
+$CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpu.tmp.$$" "$DEFLATE" -lz -lpthread \
     -L"$ROOT/fastp_amd" -Wl,-rpath,'$ORIGIN/../../fastp_amd' -lfastp_gpu
 mv -f "$OUT/fastp_ref_gpu.tmp.$$" "$OUT/fastp_ref_gpu"
 echo "built $OUT/fastp_ref_gpu"
@@ -56,7 +56,7 @@ echo "built $OUT/fastp_ref_gpu"
 # the patched reference end to end on small inputs
 SIM=$ROOT/tests/hostsim/libfastp_gpu_sim.so
 if [ -f "$SIM" ]; then
-    $CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpusim.tmp.$$" "$DEFLATE" -lpthread "$SIM" -Wl,-rpath,"$ROOT/tests/hostsim"
+    $CXX -pthread "$OBJ"/*.o -o "$OUT/fastp_ref_gpusim.tmp.$$" "$DEFLATE" -lz -lpthread "$SIM" -Wl,-rpath,"$ROOT/tests/hostsim"
     mv -f "$OUT/fastp_ref_gpusim.tmp.$$" "$OUT/fastp_ref_gpusim"
     echo "built $OUT/fastp_ref_gpusim"
 fi

@@ -807,8 +807,12 @@ struct StreamState {
 StreamState* SG = nullptr;
 std::once_flag sg_once;
 
+// (".gz" inputs included: the stream inflates bgzip-written files on the device and other gzip streams with zlib,
+// fastp_gpu_stream.h; FASTP_GPU_STREAM_GZ=0 sends them through the reference's reader - pack mode - instead)
 bool plain_regular_file(const std::string& path) {
-    if (path.empty() || ends_with(path, ".gz")) return false;
+    if (path.empty()) return false;
+    if (ends_with(path, ".gz"))
+        if (const char* v = getenv("FASTP_GPU_STREAM_GZ")) if (atoi(v) == 0) return false;
     struct stat sb;
     return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
 }
@@ -893,6 +897,12 @@ void stream_run() {
                         "copies %.3f, wait-write %.3f; writer %.3f, adapter replay %.3f), max_len %d, %lld re-plan(s)\n",
                 (long long)st.units, (long long)st.chunks, st.wall_s, st.setup_s, st.wait_read_s, st.parse_s, st.engine_s, st.format_s, st.deflate_s, st.d2h_s,
                 st.wait_write_s, st.write_s, st.replay_s, (int)st.max_len, (long long)st.replans);
+    if (getenv("FASTP_GPU_VERBOSE"))
+        for (int m = 0; m < (S->paired ? 2 : 1); m++)
+            if (st.input_kind[m])
+                fprintf(stderr, "fastp_gpu: stream mode: input %d is %s: %lld bytes of the file -> %lld bytes of text (inflate + its copy to the host %.3f s)\n", m + 1,
+                        st.input_kind[m] == 2 ? "BGZF, inflated on the device" : "gzip, inflated by zlib on the host", (long long)st.bytes_file[m],
+                        (long long)st.bytes_in[m], st.inflate_s);
     S->ran = true;
 }
 

@@ -31,7 +31,8 @@ class StreamStats(C.Structure):
     _fields_ = [("units", C.c_int64), ("chunks", C.c_int64), ("replans", C.c_int64), ("max_len", C.c_int32), ("truncated", C.c_int32),
                 ("bytes_in", C.c_int64 * 2), ("bytes_out", C.c_int64 * N_OUT)] + \
                [(k, C.c_double) for k in ("wall_s", "setup_s", "wait_read_s", "parse_s", "engine_s", "format_s", "deflate_s", "d2h_s",
-                                          "wait_write_s", "write_s", "replay_s")]
+                                          "wait_write_s", "write_s", "replay_s", "inflate_s")] + \
+               [("bytes_file", C.c_int64 * 2), ("input_kind", C.c_int32 * 2)]
 
 
 class StreamError(RuntimeError):

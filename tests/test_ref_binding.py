@@ -76,14 +76,14 @@ def _ensure_built():
     return os.path.exists(REF)
 
 
-def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1, gz=False, in1=None):
+def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1, gz=False, in1=None, in2=None):
     out = os.path.join(tmp, tag)
     os.makedirs(out, exist_ok=True)
     ext = ".fq.gz" if gz else ".fq"
     cmd = [binary, "-i", in1 or os.path.join(tmp, "in1.fq"), "-o", os.path.join(out, "o1" + ext), "-j", os.path.join(out, "r.json"),
            "-h", os.path.join(out, "r.html"), "-w", str(threads), "--failed_out", os.path.join(out, "failed" + ext)]
     if paired:
-        cmd += ["-I", os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2" + ext)]
+        cmd += ["-I", in2 or os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2" + ext)]
     cmd += [x.replace("@TMP@", out) for x in flags]
     env = dict(os.environ)
     env.pop("FASTP_GPU", None)
@@ -125,7 +125,7 @@ PACK_MODE = {"FASTP_GPU_STREAM": "0"}   # the reference's own reader threads + t
 
 
 def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n", trailing=True, gz=False, more_flags=(),
-           mode="stream", mutate=None, expect_units=None):
+           mode="stream", mutate=None, expect_units=None, gz_in=None):
     paired, flags, pf, skw = cases.CASES[name]
     flags = list(flags) + BINDING_CASES[name] + list(more_flags)
     tmp = str(tmp_path)
@@ -146,14 +146,17 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
             os.makedirs(os.path.join(tmp, tag), exist_ok=True)
             with open(os.path.join(tmp, tag, fn), "wb") as f:
                 f.write(content)
-    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {}, gz=gz)
+    in1 = in2 = None
+    if gz_in:   # ".gz" inputs, read by BOTH binaries (the reference here inflates through oracle/shims/isa-l over zlib)
+        in1, in2 = _compress_inputs(tmp, paired, gz_in)
+    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {}, gz=gz, in1=in1, in2=in2)
     env = {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}
     if binary == REF_SIM:
         env.update(SIM_ENV)
     if mode == "pack":
         env.update(PACK_MODE)
     env.update(extra_env or {})
-    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, env, threads=threads, gz=gz)
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, env, threads=threads, gz=gz, in1=in1, in2=in2)
     err = got_rep.pop("__stderr__")
     want_rep.pop("__stderr__")
     # which binding ran: the stream loop says so; --overlapped_out is pack mode's
@@ -172,6 +175,26 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     assert not problems, f"{name}: fastp's own JSON report differs:\n" + "\n".join(problems[:25])
     assert want_rep["summary"]["before_filtering"]["total_reads"] == (2 if paired else 1) * (n if expect_units is None else expect_units)
     return err
+
+
+def _compress_inputs(tmp, paired, how):
+    """in1.fq / in2.fq -> .fq.gz: "bgzf" = bgzip's members (9000 bytes of text each here: many per trip), "gzip" = one member,
+    "members" = a few plain gzip members one behind the other"""
+    import gzip
+    import bgzf_util
+    paths = []
+    for k, h in zip((1, 2) if paired else (1,), how):
+        text = open(os.path.join(tmp, f"in{k}.fq"), "rb").read()
+        if h == "bgzf":
+            blob = bgzf_util.compress(text, block_bytes=9000)
+        elif h == "gzip":
+            blob = gzip.compress(text, 5)
+        else:
+            third = len(text) // 3
+            blob = gzip.compress(text[:third], 1) + gzip.compress(text[third:2 * third + 7], 9) + gzip.compress(text[2 * third + 7:], 4)
+        paths.append(os.path.join(tmp, f"in{k}.fq.gz"))
+        open(paths[-1], "wb").write(blob)
+    return paths[0], (paths[1] if paired else None)
 
 
 # on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
@@ -222,6 +245,22 @@ def test_patched_reference_stream_gz_outputs(name, threads, writer, tmp_path):
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
     _check(name, REF_SIM, 700, tmp_path, seed=53, threads=threads, gz=True, extra_env={"FASTP_GPU_WRITER": writer} if writer else None)
+
+
+@pytest.mark.parametrize("name,how,kw", [("pe_default", ("bgzf", "bgzf"), dict(threads=2)), ("pe_merge_unmerged", ("gzip", "bgzf"), dict(threads=1)),
+                                         ("se_adapter_cut", ("bgzf",), dict(threads=3, gz=True)), ("se_umi_read1", ("members",), dict(threads=1)),
+                                         ("pe_exotic_dedup_adapters", ("members", "gzip"), dict(threads=2)),
+                                         ("pe_filters", ("bgzf", "bgzf"), dict(threads=2, more_flags=("--reads_to_process", "1200"), expect_units=1200)),
+                                         ("pe_correction", ("bgzf", "gzip"), dict(threads=2, mode="pack", extra_env={"FASTP_GPU_STREAM_GZ": "0"}))])
+def test_patched_reference_compressed_inputs(name, how, kw, tmp_path):
+    """".gz" inputs: bgzip-written files go to the device compressed and are inflated there (in place of BgzfMtReader), other
+    gzip streams are inflated by zlib inside the stream; FASTP_GPU_STREAM_GZ=0 leaves them to the reference's reader (pack mode).
+    Both binaries read the same compressed files."""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    err = _check(name, REF_SIM, 1700, tmp_path, seed=57, gz_in=how, **kw)
+    if kw.get("mode") != "pack":
+        assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
 
 
 @pytest.mark.parametrize("mode", ["stream", "pack"])
@@ -375,6 +414,16 @@ def test_patched_reference_random_command_lines(seed):
     import binding_fuzz
     problems, c = binding_fuzz.run(seed, REF_SIM, True)
     assert not problems, f"{' '.join(c['flags'])} [{c['mode']}, -w {c['threads']}]: " + "; ".join(problems[:6])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,how", [("pe_default", ("bgzf", "bgzf")), ("pe_overrep_merge" if "pe_overrep_merge" in BINDING_CASES else "pe_overrep", ("bgzf", "gzip")),
+                                      ("se_adapter_cut", ("bgzf",)), ("se_default_noadapter", ("members",))])
+def test_gpu_patched_reference_compressed_inputs(name, how, tmp_path):
+    if not (os.path.exists(REF) and os.path.exists(REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    err = _check(name, REF_GPU, 30000, tmp_path, seed=44, gz_in=how, threads=4)
+    assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
 
 
 @pytest.mark.gpu

@@ -173,3 +173,176 @@ def test_gpu_stream_large_input_default_chunks(tmp_path):
     gz, ctr3, _, _, _ = streamlib.run_files(lib, params, p1, p2, str(tmp_path), compress=("out1", "out2", "failed"))
     assert gzip.decompress(gz["out1"]) == outs["out1"] and gzip.decompress(gz["failed"]) == outs["failed"]
     assert np.array_equal(ctr, ctr3)
+
+
+# ---- ".gz" inputs: bgzip-written files inflated on the device (in place of BgzfMtReader), other gzip streams by zlib on the host ----
+def _pack(text: bytes, how: str, seed=0) -> bytes:
+    import bgzf_util
+    if how == "bgzf":
+        return bgzf_util.compress(text, block_bytes=9000)
+    if how == "bgzf_big":       # bgzip's own block size; no end-of-file member (htslib warns, readers go on)
+        return bgzf_util.compress(text, block_bytes=0xff00, eof=False)
+    if how == "gzip":
+        return gzip.compress(text, 6)
+    if how == "members":        # several gzip members cut at arbitrary bytes (what fastp's own WriterThread writes per pack)
+        rng = np.random.default_rng(seed)
+        cuts = sorted(set(int(x) for x in rng.integers(1, len(text), size=7))) + [len(text)]
+        out, a = [], 0
+        for b in cuts:
+            out.append(gzip.compress(text[a:b], 1 + (a % 9)))
+            a = b
+        return b"".join(out)
+    raise ValueError(how)
+
+
+def _gz_files(tmp_path, fq1, fq2, how1, how2, tag=""):
+    p1 = os.path.join(str(tmp_path), f"in1{tag}.fq.gz")
+    open(p1, "wb").write(_pack(fq1, how1, 1))
+    p2 = None
+    if fq2 is not None:
+        p2 = os.path.join(str(tmp_path), f"in2{tag}.fq.gz")
+        open(p2, "wb").write(_pack(fq2, how2, 2))
+    return p1, p2
+
+
+def _golden_gz(lib, name, tmp_path, chunk_bytes, how1, how2, max_len=152):
+    fq1, fq2, meta = golden_util.load(name)
+    params = golden_util.params_for(name, max_len=max_len, fq1=fq1, fq2=fq2)
+    p1, p2 = _gz_files(tmp_path, fq1, fq2, how1, how2)
+    want = [k for k in meta["outputs"] if k != "overlapped"]
+    if "out1" not in want:
+        want += ["out1"] + (["out2"] if fq2 is not None else [])
+    outs, ctr, lay, amaps, st = streamlib.run_files(lib, params, p1, p2, str(tmp_path), want=want, chunk_bytes=chunk_bytes, umi=golden_util.umi_for(name))
+    golden_util.check_against_golden(name, streamlib.as_outputs(outs, fq2 is not None), streamlib.report(ctr, lay, params, amaps), meta)
+    kinds = {"bgzf": 2, "bgzf_big": 2, "gzip": 1, "members": 1}
+    assert st.input_kind[0] == kinds[how1] and (fq2 is None or st.input_kind[1] == kinds[how2])
+    assert st.bytes_in[0] == len(fq1) or st.truncated or params.paired      # TEXT bytes; a paired run may stop inside the longer file
+    assert 0 < st.bytes_file[0] <= os.path.getsize(p1)
+    return st
+
+
+GZ_SIM_CASES = [("pe_default", "bgzf", "bgzf"), ("pe_adapter_fasta", "bgzf", "gzip"), ("pe_merge_unmerged", "members", "bgzf"),
+                ("se_adapter_cut", "bgzf", None), ("se_adapter_fasta", "members", None), ("pe_correction", "gzip", "members"),
+                ("pe_exotic_merge", "bgzf", "bgzf"), ("pe_umi_per_read", "bgzf", "bgzf")]
+
+
+@pytest.mark.parametrize("name,how1,how2", GZ_SIM_CASES)
+def test_sim_stream_compressed_inputs_equal_reference_golden(name, how1, how2, tmp_path):
+    """the golden's input files compressed: what the stream writes and counts is what the reference made of the plain files
+    (a decompressor changes nothing downstream), with several BGZF members and several trips per file"""
+    lib = engine.load_library(engines.build_sim())
+    st = _golden_gz(lib, name, tmp_path, 60000, how1, how2)
+    assert st.chunks >= 2
+
+
+def test_sim_stream_bgzf_late_long_reads_replan(tmp_path):
+    lib = engine.load_library(engines.build_sim())
+    st = _golden_gz(lib, "pe_late_long_reads", tmp_path, 60000, "bgzf", "bgzf", max_len=100)
+    assert st.replans >= 1
+
+
+def _run_plain_and(lib, tmp_path, fq1, fq2, packed1, packed2, chunk_bytes=70000, **kw):
+    params = golden_util.params_for("pe_cut_right", max_len=152)
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    a = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=chunk_bytes, **kw)
+    g1, g2 = os.path.join(str(tmp_path), "x1.fq.gz"), os.path.join(str(tmp_path), "x2.fq.gz")
+    open(g1, "wb").write(packed1)
+    open(g2, "wb").write(packed2)
+    b = streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=chunk_bytes, **kw)
+    return params, a, b
+
+
+def test_sim_stream_reads_its_own_compressed_output(tmp_path):
+    """round trip: the ".gz" streams the device deflate writes are bgzip members - fed back as inputs they are inflated on the
+    device and give the run its plain files give; bgzip-sized members (64 KiB of text) with the default trip size class"""
+    import refjson
+    lib = engine.load_library(engines.build_sim())
+    fq1, fq2 = _synthetic(1800, seed=93)
+    params = abi.default_params(True, 152)      # no trimming, no filtering that drops: out1/out2 are the inputs again
+    params.adapter_trimming = 0
+    params.quality_filter = 0
+    params.length_filter = 0
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    first, _, _, _, _ = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=200000, compress=("out1", "out2"))
+    if gzip.decompress(first["out1"]) != fq1:   # the parameter block filters after all: the round trip still holds on what came out
+        fq1, fq2 = gzip.decompress(first["out1"]), gzip.decompress(first["out2"])
+    params2, a, b = _run_plain_and(lib, tmp_path, fq1, fq2, first["out1"], first["out2"], chunk_bytes=200000)
+    assert b[4].input_kind[0] == 2 and b[4].input_kind[1] == 2
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3].a1 == b[3].a1 and a[3].a2 == b[3].a2
+    assert not refjson.diff(streamlib.report(a[1], a[2], params2, a[3]), streamlib.report(b[1], b[2], params2, b[3]))
+
+
+def test_sim_stream_compressed_inputs_limits_and_damage(tmp_path):
+    """--reads_to_process and unequal files on compressed inputs; a file that ends inside a member, a member whose bytes were
+    changed, and bytes that are no gzip header behind a member are errors (the reference: "igzip: unexpected eof" /
+    "igzip: invalid gzip header found", fastqreader.cpp:102-146), never a shorter run"""
+    import bgzf_util
+    lib = engine.load_library(engines.build_sim())
+    fq1, fq2 = _synthetic(1500, seed=94)
+    params = golden_util.params_for("pe_cut_right", max_len=152)
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    plain = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000, reads_to_process=777)
+    for how in ("bgzf", "members"):
+        g1, g2 = _gz_files(tmp_path, fq1, fq2, how, how, tag=how)
+        got = streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=60000, reads_to_process=777)
+        assert got[0] == plain[0] and np.array_equal(got[1], plain[1]) and got[4].units == 777
+    cut = b"\n".join(fq2.split(b"\n")[:4 * 901]) + b"\n"
+    g1, g2 = _gz_files(tmp_path, fq1, cut, "bgzf", "bgzf", tag="u")
+    assert streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=60000)[4].units == 901
+    good = {"bgzf": bgzf_util.compress(fq1, block_bytes=9000), "gzip": gzip.compress(fq1, 6)}
+    g2 = os.path.join(str(tmp_path), "ok2.fq.gz")
+    open(g2, "wb").write(bgzf_util.compress(fq2, block_bytes=9000))
+    bad = os.path.join(str(tmp_path), "bad1.fq.gz")
+    for kind, data in good.items():
+        damaged = {"ends inside a member": data[:len(data) * 2 // 3],
+                   "changed bytes": data[:len(data) // 2] + bytes(b ^ 0x5a for b in data[len(data) // 2:len(data) // 2 + 8]) + data[len(data) // 2 + 8:],
+                   "no header behind a member": (data[:-28] if kind == "bgzf" else data) + b"this is not gzip" * 4}
+        for what, blob in damaged.items():
+            open(bad, "wb").write(blob)
+            try:
+                st = streamlib.run_files(lib, params, bad, g2, str(tmp_path), chunk_bytes=60000)[4]
+            except streamlib.StreamError as e:
+                assert e.code == abi.E_INVALID and ("gzip" in str(e) or "BGZF" in str(e)), (kind, what, str(e))
+                continue
+            # changed bytes inside a plain deflate stream may decode to something: then the text is no FASTQ and the stream
+            # ends in front of the first malformed record, as FastqReader::read does (the member's CRC is never reached)
+            assert kind == "gzip" and what == "changed bytes" and st.truncated == 1 and st.units < 1500, (kind, what)
+    # a BGZF member that does not fit a trip next to the carried text is named, not looped on
+    open(bad, "wb").write(bgzf_util.compress(fq1, block_bytes=0xff00))
+    with pytest.raises(streamlib.StreamError) as e:
+        streamlib.run_files(lib, params, bad, g2, str(tmp_path), chunk_bytes=40000)
+    assert "does not fit the chunk size" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,how1,how2", GZ_SIM_CASES + [("pe_overrep_merge", "bgzf_big", "bgzf_big"), ("pe_noadapter_dedup", "bgzf_big", "gzip")])
+def test_gpu_stream_compressed_inputs_equal_reference_golden(name, how1, how2, tmp_path):
+    lib = engine.load_library()
+    _golden_gz(lib, name, tmp_path, 1 << 20, how1, how2)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_large_bgzf_input_default_chunks(tmp_path):
+    """300 000 pairs as bgzip-sized members through the default chunks (thousands of members per launch: both inflate kernels'
+    ranges), as plain gzip, and the stream's own compressed output fed back: all equal the run on the plain files"""
+    import bgzf_util
+    import synth
+    lib = engine.load_library()
+    d = synth.synth_pairs(300000, L=150, seed=78)
+    fq1, fq2 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1), synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
+    params = abi.default_params(True, 150)
+    params.cut_right = 1
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    a = streamlib.run_files(lib, params, p1, p2, str(tmp_path))
+    z = streamlib.run_files(lib, params, p1, p2, str(tmp_path), compress=("out1", "out2"))
+    for pack1, pack2 in ((bgzf_util.compress(fq1, level=1), bgzf_util.compress(fq2, level=1)), (gzip.compress(fq1, 1), bgzf_util.compress(fq2, level=1))):
+        g1, g2 = os.path.join(str(tmp_path), "big1.fq.gz"), os.path.join(str(tmp_path), "big2.fq.gz")
+        open(g1, "wb").write(pack1)
+        open(g2, "wb").write(pack2)
+        b = streamlib.run_files(lib, params, g1, g2, str(tmp_path))
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3].a1 == b[3].a1
+        assert b[4].bytes_file[0] == len(pack1) and b[4].bytes_in[0] == len(fq1)
+    # the stream's own ".gz" outputs as inputs of a second run == that run on their text
+    t1, t2 = gzip.decompress(z[0]["out1"]), gzip.decompress(z[0]["out2"])
+    _, c, e = _run_plain_and(lib, tmp_path, t1, t2, z[0]["out1"], z[0]["out2"], chunk_bytes=0)
+    assert c[0] == e[0] and np.array_equal(c[1], e[1]) and e[4].input_kind[0] == 2
