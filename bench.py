@@ -190,6 +190,64 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False):
     return out
 
 
+def e2e_compressed_leg(sample_pairs, flags, dev):
+    """".gz" on both sides of the drop-in (never the headline `value`): (a) the patched reference writes its outputs as gzip members
+    made on the device; (b) those files - bgzip members, the format the reference reads with BgzfMtReader - are the INPUT of a second
+    run, which ships them to the device compressed and inflates them there; (c) fastp_ref reads the same ".gz" files on the host
+    cores (its reader inflates through oracle/shims/isa-l over zlib here).  Outputs of (b) and (c) are compared."""
+    import hashlib
+    import json as _json
+    import re
+    import shutil
+    ref = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
+    refgpu = os.path.join(ROOT, "oracle", "_ref", "fastp_ref_gpu")
+    if not (os.path.exists(ref) and os.path.exists(refgpu)):
+        return None
+    cores = host_cores()
+    tmp, f1, f2 = write_sample_files(sample_pairs, dev)
+    try:
+        J = lambda n: os.path.join(tmp, n)
+        genv = dict(os.environ, FASTP_GPU="1", FASTP_GPU_VERBOSE="1")
+
+        def run(binary, i1, i2, tag, ext, env):
+            cmd = [binary, "-i", i1, "-I", i2, "-o", J(tag + "1" + ext), "-O", J(tag + "2" + ext), "-j", J(tag + ".json"), "-h", J(tag + ".html"),
+                   "-w", str(cores)] + flags
+            t0 = time.time()
+            pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, timeout=240, env=env)
+            return time.time() - t0, pr.stderr.decode(errors="replace")
+
+        def md5(pth):
+            hsh = hashlib.md5()
+            with open(pth, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    hsh.update(blk)
+            return hsh.hexdigest()
+        t_a, _ = run(refgpu, f1, f2, "z", ".fq.gz", genv)
+        kept = _json.load(open(J("z.json")))["summary"]["after_filtering"]["total_reads"]
+        os.remove(f1)
+        os.remove(f2)
+        best, err = None, ""
+        for _ in range(2):
+            t_b, e = run(refgpu, J("z1.fq.gz"), J("z2.fq.gz"), "b", ".fq", genv)
+            if best is None or t_b < best:
+                best, err = t_b, e
+        t_c, _ = run(ref, J("z1.fq.gz"), J("z2.fq.gz"), "c", ".fq", dict(os.environ))
+        m = re.search(r"stream mode: \d+ units in (\d+) chunks, ([0-9.]+) s", err)
+        k = re.search(r"inflate \+ its copy to the host ([0-9.]+) s", err)
+        return {"gz_outputs_Mreads_per_s": round(2 * sample_pairs / t_a / 1e6, 3),
+                "gpu": round(kept / best / 1e6, 3), "cpu": round(kept / t_c / 1e6, 3), "unit": "Mreads/s", "cores": cores, "reads": kept,
+                "outputs_identical": md5(J("b1.fq")) == md5(J("c1.fq")) and md5(J("b2.fq")) == md5(J("c2.fq")),
+                "inflated_on_the_device": "BGZF, inflated on the device" in err,
+                "compressed_bytes": os.path.getsize(J("z1.fq.gz")) + os.path.getsize(J("z2.fq.gz")),
+                "wall_s": round(best, 3), "stream_s": float(m.group(2)) if m else None, "chunks": int(m.group(1)) if m else None,
+                "inflate_s": float(k.group(1)) if k else None,
+                "what": f"FASTP_GPU=1 fastp_ref_gpu -w {cores}: {sample_pairs} pairs written as .fq.gz (gzip members made on the device), then those "
+                        f"files as the input of a second run (compressed to HBM, fastp_gpu_inflate_bgzf in place of BgzfMtReader) vs fastp_ref -w {cores} "
+                        f"on the same .gz files (zlib behind the ISA-L shim), whole-process wall, best of 2"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def other_configs(dev):
     """the other single-GPU BASELINE.json configurations, inputs resident in HBM (not bench lines: reported beside it)"""
     import numpy as np
@@ -646,6 +704,13 @@ def main():
                 out["other_configs"] = other_configs(dev)
             except Exception as e:
                 out["other_configs"] = [{"error": repr(e)[:200]}]
+            if not args.no_cpu:   # last: nothing above depends on it
+                try:
+                    leg = e2e_compressed_leg(args.cpu_sample, ref_flags, dev)
+                    if leg is not None:
+                        out["e2e_dropin_bgzf"] = leg
+                except Exception as e:
+                    out["e2e_dropin_bgzf"] = {"gpu": None, "error": repr(e)[:300]}
         print(json.dumps(out))
     eng.close()
     if dist is not None:

@@ -247,8 +247,8 @@ def test_patched_reference_stream_gz_outputs(name, threads, writer, tmp_path):
     _check(name, REF_SIM, 700, tmp_path, seed=53, threads=threads, gz=True, extra_env={"FASTP_GPU_WRITER": writer} if writer else None)
 
 
-@pytest.mark.parametrize("name,how,kw", [("pe_default", ("bgzf", "bgzf"), dict(threads=2)), ("pe_merge_unmerged", ("gzip", "bgzf"), dict(threads=1)),
-                                         ("se_adapter_cut", ("bgzf",), dict(threads=3, gz=True)), ("se_umi_read1", ("members",), dict(threads=1)),
+@pytest.mark.parametrize("name,how,kw", [("pe_merge_unmerged", ("gzip", "bgzf"), dict(threads=1)),
+                                         ("se_adapter_cut", ("bgzf",), dict(threads=3, gz=True)),
                                          ("pe_exotic_dedup_adapters", ("members", "gzip"), dict(threads=2)),
                                          ("pe_filters", ("bgzf", "bgzf"), dict(threads=2, more_flags=("--reads_to_process", "1200"), expect_units=1200)),
                                          ("pe_correction", ("bgzf", "gzip"), dict(threads=2, mode="pack", extra_env={"FASTP_GPU_STREAM_GZ": "0"}))])
@@ -258,7 +258,7 @@ def test_patched_reference_compressed_inputs(name, how, kw, tmp_path):
     Both binaries read the same compressed files."""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    err = _check(name, REF_SIM, 1700, tmp_path, seed=57, gz_in=how, **kw)
+    err = _check(name, REF_SIM, 1500, tmp_path, seed=57, gz_in=how, **kw)
     if kw.get("mode") != "pack":
         assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
 

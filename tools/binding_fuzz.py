@@ -132,7 +132,15 @@ def random_command(seed):
     threads = int(rng.choice([1, 2, 5]))
     gz = pick(0.15)
     mode = "pack" if pick(0.2) else "stream"
-    return dict(paired=paired, flags=f, L=L, n=n, skw=skw, eol=eol, threads=threads, gz=gz, mode=mode, umi=umi)
+    # ".gz" inputs, drawn from a generator of their own so that a seed's command line stays what it was before they existed:
+    # bgzip-written (inflated on the device), one gzip member, several members (zlib inside the stream); pack mode leaves them
+    # to the reference's reader
+    rng2 = np.random.default_rng(seed + 7_000_000)
+    gz_in = None
+    if rng2.random() < 0.3:
+        kinds = ["bgzf", "bgzf", "gzip", "members"]
+        gz_in = tuple(kinds[int(rng2.integers(0, 4))] for _ in range(2 if paired else 1))
+    return dict(paired=paired, flags=f, L=L, n=n, skw=skw, eol=eol, threads=threads, gz=gz, mode=mode, umi=umi, gz_in=gz_in)
 
 
 def run(seed, binary, sim):
@@ -143,13 +151,16 @@ def run(seed, binary, sim):
         open(os.path.join(tmp, "in1.fq"), "wb").write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1).replace(b"\n", c["eol"]))
         if c["paired"]:
             open(os.path.join(tmp, "in2.fq"), "wb").write(synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2).replace(b"\n", c["eol"]))
-        want_files, want_rep = rb._run(rb.REF, tmp, "ref", c["flags"], c["paired"], {}, gz=c["gz"])
+        in1 = in2 = None
+        if c["gz_in"]:
+            in1, in2 = rb._compress_inputs(tmp, c["paired"], c["gz_in"])
+        want_files, want_rep = rb._run(rb.REF, tmp, "ref", c["flags"], c["paired"], {}, gz=c["gz"], in1=in1, in2=in2)
         env = {"FASTP_GPU": "1"}
         if sim:
             env.update(rb.SIM_ENV)
         if c["mode"] == "pack":
             env.update(rb.PACK_MODE)
-        got_files, got_rep = rb._run(binary, tmp, "gpu", c["flags"], c["paired"], env, threads=c["threads"], gz=c["gz"])
+        got_files, got_rep = rb._run(binary, tmp, "gpu", c["flags"], c["paired"], env, threads=c["threads"], gz=c["gz"], in1=in1, in2=in2)
         want_rep.pop("__stderr__")
         got_rep.pop("__stderr__")
         problems = []
@@ -177,7 +188,7 @@ def main():
             problems, c = [f"run failed: {str(e)[-400:]}"], random_command(seed)
         if problems:
             failed += 1
-            print(f"seed {seed}: {' '.join(c['flags'])} [{c['mode']}, -w {c['threads']}, paired={c['paired']}, gz={c['gz']}]: " + "; ".join(problems[:4]), flush=True)
+            print(f"seed {seed}: {' '.join(c['flags'])} [{c['mode']}, -w {c['threads']},  paired={c['paired']}, gz={c['gz']}, gz_in={c['gz_in']}]: " + "; ".join(problems[:4]), flush=True)
         else:
             ok += 1
     print(f"seeds {first}..{last - 1}: {ok} command lines with every output file and the JSON report equal to the reference's, {failed} FAILED, {time.time() - t0:.0f}s")
