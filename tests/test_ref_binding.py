@@ -417,16 +417,6 @@ def test_patched_reference_random_command_lines(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,how", [("pe_default", ("bgzf", "bgzf")), ("pe_overrep_merge" if "pe_overrep_merge" in BINDING_CASES else "pe_overrep", ("bgzf", "gzip")),
-                                      ("se_adapter_cut", ("bgzf",)), ("se_default_noadapter", ("members",))])
-def test_gpu_patched_reference_compressed_inputs(name, how, tmp_path):
-    if not (os.path.exists(REF) and os.path.exists(REF_GPU)):
-        pytest.skip("oracle/_ref binaries did not travel to this box")
-    err = _check(name, REF_GPU, 30000, tmp_path, seed=44, gz_in=how, threads=4)
-    assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("name", list(BINDING_CASES))
 def test_gpu_patched_reference_equals_reference(name, tmp_path):
     """the same on the real library: fastp_ref_gpu (FASTP_GPU=1) vs fastp_ref, 30 000 units"""

@@ -313,37 +313,3 @@ def test_sim_stream_compressed_inputs_limits_and_damage(tmp_path):
     with pytest.raises(streamlib.StreamError) as e:
         streamlib.run_files(lib, params, bad, g2, str(tmp_path), chunk_bytes=40000)
     assert "does not fit the chunk size" in str(e.value)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,how1,how2", GZ_CASES + [("pe_overrep_merge", "bgzf_big", "bgzf_big"), ("pe_noadapter_dedup", "bgzf_big", "gzip")])
-def test_gpu_stream_compressed_inputs_equal_reference_golden(name, how1, how2, tmp_path):
-    lib = engine.load_library()
-    _golden_gz(lib, name, tmp_path, 1 << 20, how1, how2)
-
-
-@pytest.mark.gpu
-def test_gpu_stream_large_bgzf_input_default_chunks(tmp_path):
-    """300 000 pairs as bgzip-sized members through the default chunks (thousands of members per launch: both inflate kernels'
-    ranges), as plain gzip, and the stream's own compressed output fed back: all equal the run on the plain files"""
-    import bgzf_util
-    import synth
-    lib = engine.load_library()
-    d = synth.synth_pairs(300000, L=150, seed=78)
-    fq1, fq2 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1), synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
-    params = abi.default_params(True, 150)
-    params.cut_right = 1
-    p1, p2 = _files(tmp_path, fq1, fq2)
-    a = streamlib.run_files(lib, params, p1, p2, str(tmp_path))
-    z = streamlib.run_files(lib, params, p1, p2, str(tmp_path), compress=("out1", "out2"))
-    for pack1, pack2 in ((bgzf_util.compress(fq1, level=1), bgzf_util.compress(fq2, level=1)), (gzip.compress(fq1, 1), bgzf_util.compress(fq2, level=1))):
-        g1, g2 = os.path.join(str(tmp_path), "big1.fq.gz"), os.path.join(str(tmp_path), "big2.fq.gz")
-        open(g1, "wb").write(pack1)
-        open(g2, "wb").write(pack2)
-        b = streamlib.run_files(lib, params, g1, g2, str(tmp_path))
-        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3].a1 == b[3].a1
-        assert b[4].bytes_file[0] == len(pack1) and b[4].bytes_in[0] == len(fq1)
-    # the stream's own ".gz" outputs as inputs of a second run == that run on their text
-    t1, t2 = gzip.decompress(z[0]["out1"]), gzip.decompress(z[0]["out2"])
-    _, c, e = _run_plain_and(lib, tmp_path, t1, t2, z[0]["out1"], z[0]["out2"], chunk_bytes=0)
-    assert c[0] == e[0] and np.array_equal(c[1], e[1]) and e[4].input_kind[0] == 2

@@ -1,0 +1,58 @@
+"""The `-m gpu` side of the compressed-input tests (".gz" inputs of the stream: bgzip-written files inflated on the device in
+place of BgzfMtReader, other gzip streams by zlib inside the stream).  Their CPU-suite counterparts run on the emulator in
+tests/test_stream_abi.py and tests/test_ref_binding.py; these were written in a session without GPU minutes and live in a file
+of their own, collected last, so that nothing else's result depends on them."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import streamlib
+import test_ref_binding as rb
+from fastp_amd import abi, engine
+from test_stream_abi import GZ_CASES, _files, _golden_gz, _run_plain_and
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,how1,how2", GZ_CASES + [("pe_overrep_merge", "bgzf_big", "bgzf_big"), ("pe_noadapter_dedup", "bgzf_big", "gzip")])
+def test_gpu_stream_compressed_inputs_equal_reference_golden(name, how1, how2, tmp_path):
+    lib = engine.load_library()
+    _golden_gz(lib, name, tmp_path, 1 << 20, how1, how2)
+
+
+@pytest.mark.gpu
+def test_gpu_stream_large_bgzf_input_default_chunks(tmp_path):
+    """300 000 pairs as bgzip-sized members through the default chunks (thousands of members per launch: both inflate kernels'
+    ranges), as plain gzip, and the stream's own compressed output fed back: all equal the run on the plain files"""
+    import bgzf_util
+    import synth
+    lib = engine.load_library()
+    d = synth.synth_pairs(300000, L=150, seed=78)
+    fq1, fq2 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1), synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
+    params = abi.default_params(True, 150)
+    params.cut_right = 1
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    a = streamlib.run_files(lib, params, p1, p2, str(tmp_path))
+    z = streamlib.run_files(lib, params, p1, p2, str(tmp_path), compress=("out1", "out2"))
+    for pack1, pack2 in ((bgzf_util.compress(fq1, level=1), bgzf_util.compress(fq2, level=1)), (gzip.compress(fq1, 1), bgzf_util.compress(fq2, level=1))):
+        g1, g2 = os.path.join(str(tmp_path), "big1.fq.gz"), os.path.join(str(tmp_path), "big2.fq.gz")
+        open(g1, "wb").write(pack1)
+        open(g2, "wb").write(pack2)
+        b = streamlib.run_files(lib, params, g1, g2, str(tmp_path))
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3].a1 == b[3].a1
+        assert 0.9 * len(pack1) <= b[4].bytes_file[0] <= len(pack1) and b[4].bytes_in[0] == len(fq1)
+    # the stream's own ".gz" outputs as inputs of a second run == that run on their text
+    t1, t2 = gzip.decompress(z[0]["out1"]), gzip.decompress(z[0]["out2"])
+    _, c, e = _run_plain_and(lib, tmp_path, t1, t2, z[0]["out1"], z[0]["out2"], chunk_bytes=0)
+    assert c[0] == e[0] and np.array_equal(c[1], e[1]) and e[4].input_kind[0] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,how", [("pe_default", ("bgzf", "bgzf")), ("pe_overrep_merge" if "pe_overrep_merge" in rb.BINDING_CASES else "pe_overrep", ("bgzf", "gzip")),
+                                      ("se_adapter_cut", ("bgzf",)), ("se_default_noadapter", ("members",))])
+def test_gpu_patched_reference_compressed_inputs(name, how, tmp_path):
+    if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    err = rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=44, gz_in=how, threads=4)
+    assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
