@@ -244,6 +244,7 @@ def test_sim_stream_bgzf_late_long_reads_replan(tmp_path):
 
 def _run_plain_and(lib, tmp_path, fq1, fq2, packed1, packed2, chunk_bytes=70000, **kw):
     params = golden_util.params_for("pe_cut_right", max_len=152)
+    params.dup_enabled = 0
     p1, p2 = _files(tmp_path, fq1, fq2)
     a = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=chunk_bytes, **kw)
     g1, g2 = os.path.join(str(tmp_path), "x1.fq.gz"), os.path.join(str(tmp_path), "x2.fq.gz")
@@ -258,11 +259,12 @@ def test_sim_stream_reads_its_own_compressed_output(tmp_path):
     device and give the run its plain files give; bgzip-sized members (64 KiB of text) with the default trip size class"""
     import refjson
     lib = engine.load_library(engines.build_sim())
-    fq1, fq2 = _synthetic(1800, seed=93)
+    fq1, fq2 = _synthetic(1200, seed=93)
     params = abi.default_params(True, 152)      # no trimming, no filtering that drops: out1/out2 are the inputs again
     params.adapter_trimming = 0
     params.quality_filter = 0
     params.length_filter = 0
+    params.dup_enabled = 0
     p1, p2 = _files(tmp_path, fq1, fq2)
     first, _, _, _, _ = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=200000, compress=("out1", "out2"))
     if gzip.decompress(first["out1"]) != fq1:   # the parameter block filters after all: the round trip still holds on what came out
@@ -279,20 +281,20 @@ def test_sim_stream_compressed_inputs_limits_and_damage(tmp_path):
     "igzip: invalid gzip header found", fastqreader.cpp:102-146), never a shorter run"""
     import bgzf_util
     lib = engine.load_library(engines.build_sim())
-    fq1, fq2 = _synthetic(1500, seed=94)
+    fq1, fq2 = _synthetic(800, seed=94)      # (the emulator runs the inflate kernel lane by lane: seconds per 100 KB)
     params = golden_util.params_for("pe_cut_right", max_len=152)
+    params.dup_enabled = 0
     p1, p2 = _files(tmp_path, fq1, fq2)
-    plain = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000, reads_to_process=777)
+    plain = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000, reads_to_process=333)
     for how in ("bgzf", "members"):
         g1, g2 = _gz_files(tmp_path, fq1, fq2, how, how, tag=how)
-        got = streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=60000, reads_to_process=777)
-        assert got[0] == plain[0] and np.array_equal(got[1], plain[1]) and got[4].units == 777
-    cut = b"\n".join(fq2.split(b"\n")[:4 * 901]) + b"\n"
+        got = streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=60000, reads_to_process=333)
+        assert got[0] == plain[0] and np.array_equal(got[1], plain[1]) and got[4].units == 333
+    cut = b"\n".join(fq2.split(b"\n")[:4 * 401]) + b"\n"
     g1, g2 = _gz_files(tmp_path, fq1, cut, "bgzf", "bgzf", tag="u")
-    assert streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=60000)[4].units == 901
+    assert streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=60000)[4].units == 401
     good = {"bgzf": bgzf_util.compress(fq1, block_bytes=9000), "gzip": gzip.compress(fq1, 6)}
-    g2 = os.path.join(str(tmp_path), "ok2.fq.gz")
-    open(g2, "wb").write(bgzf_util.compress(fq2, block_bytes=9000))
+    g2 = p2                     # (the other file plain: a run may mix them)
     bad = os.path.join(str(tmp_path), "bad1.fq.gz")
     for kind, data in good.items():
         damaged = {"ends inside a member": data[:len(data) * 2 // 3],
@@ -307,7 +309,7 @@ def test_sim_stream_compressed_inputs_limits_and_damage(tmp_path):
                 continue
             # changed bytes inside a plain deflate stream may decode to something: then the text is no FASTQ and the stream
             # ends in front of the first malformed record, as FastqReader::read does (the member's CRC is never reached)
-            assert kind == "gzip" and what == "changed bytes" and st.truncated == 1 and st.units < 1500, (kind, what)
+            assert kind == "gzip" and what == "changed bytes" and st.truncated == 1 and st.units < 800, (kind, what)
     # a BGZF member that does not fit a trip next to the carried text is named, not looped on
     open(bad, "wb").write(bgzf_util.compress(fq1, block_bytes=0xff00))
     with pytest.raises(streamlib.StreamError) as e:
