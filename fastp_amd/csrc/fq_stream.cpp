@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/fastp_gpu_stream.h"
+#include "fq_gunzip.h"
 
 namespace {
 
@@ -690,9 +691,22 @@ struct GzSource {
     int64_t fpos = 0, fsize = 0;
     std::vector<uint8_t> in;
     size_t in_at = 0, in_len = 0;
+    std::unique_ptr<fqgz::Gunzip> fast;   // the inflater of fq_gunzip.h (default); FASTP_GPU_STREAM_GUNZIP=zlib: zlib's, for comparison
     ~GzSource() { if (open) inflateEnd(&z); }
     // up to `want` bytes of text to dst; < 0: damaged stream / read error
     int64_t fill(uint8_t* dst, int64_t want, int* err) {
+        static const bool use_zlib = getenv("FASTP_GPU_STREAM_GUNZIP") && !strcmp(getenv("FASTP_GPU_STREAM_GUNZIP"), "zlib");
+        if (!use_zlib) {
+            if (!fast) {
+                fast.reset(new fqgz::Gunzip());
+                fast->fd = fd;
+                fast->fsize = fsize;
+            }
+            const int64_t made = fast->read(dst, want, err);
+            fpos = fast->fpos;
+            at_eof = fast->at_eof;
+            return made;
+        }
         if (!open) {
             memset(&z, 0, sizeof(z));
             if (inflateInit2(&z, 15 + 16) != Z_OK) { *err = 4; return -1; }
@@ -1177,6 +1191,40 @@ int run_loop(Run* R) {
 }
 
 }  // namespace
+
+extern "C" int fastp_gpu_stream_gunzip_file(const char* path, uint8_t* out, int64_t capacity, int64_t piece, int64_t* out_len) {
+    if (!path || !out || !out_len || capacity < 0) return FASTP_GPU_E_INVALID;
+    *out_len = 0;
+    const int fd = open(path, O_RDONLY);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0) {
+        if (fd >= 0) close(fd);
+        g_stream_error = std::string("cannot open ") + path;
+        return FASTP_GPU_E_INVALID;
+    }
+    std::unique_ptr<fqgz::Gunzip> g(new fqgz::Gunzip());
+    g->fd = fd;
+    g->fsize = (int64_t)sb.st_size;
+    if (piece <= 0) piece = 1 << 20;
+    int rc = FASTP_GPU_OK;
+    for (;;) {
+        const int64_t want = std::min(piece, capacity - *out_len);
+        if (want <= 0) {   // full: fine if the stream has ended as well
+            uint8_t probe;
+            int err = 0;
+            const int64_t more = g->read(&probe, 1, &err);
+            if (more != 0) { rc = more < 0 ? FASTP_GPU_E_INVALID : FASTP_GPU_E_OVERFLOW; g_stream_error = more < 0 ? "damaged gzip stream" : "output buffer too small"; }
+            break;
+        }
+        int err = 0;
+        const int64_t made = g->read(out + *out_len, want, &err);
+        if (made < 0) { rc = FASTP_GPU_E_INVALID; g_stream_error = err == 1 ? "reading the file failed" : "damaged gzip stream"; break; }
+        *out_len += made;
+        if (made < want) break;   // fewer than asked: the file has ended
+    }
+    close(fd);
+    return rc;
+}
 
 extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
     if (!s || !s->ctx) return FASTP_GPU_E_INVALID;

@@ -95,6 +95,14 @@ int fastp_gpu_stream_get_stats(const fastp_gpu_stream* s, fastp_gpu_stream_stats
 const char* fastp_gpu_stream_last_error(const fastp_gpu_stream* s);   /* s may be NULL: the creating thread's last error */
 void fastp_gpu_stream_destroy(fastp_gpu_stream* s);
 
+/* The host inflater the stream reads non-bgzip ".gz" inputs with (fastp_amd/csrc/fq_gunzip.h: what ISA-L's igzip is to
+ * FastqReader::readToBufIgzip, src/fastqreader.cpp:88-149), on its own: the text of every member of the gzip file `path`
+ * into out[0, capacity), taken from the inflater `piece` bytes at a time (0 = 1 MiB; the tests vary it to move the
+ * hand-over points).  FASTP_GPU_E_INVALID for a damaged stream (bad code set, distance in front of the member, CRC-32 /
+ * ISIZE mismatch, no gzip header behind a member, end of file inside one), FASTP_GPU_E_OVERFLOW if capacity is too small.
+ * Needs no device. */
+int fastp_gpu_stream_gunzip_file(const char* path, uint8_t* out, int64_t capacity, int64_t piece, int64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,8 +190,15 @@ def _compress_inputs(tmp, paired, how):
         elif h == "gzip":
             blob = gzip.compress(text, 5)
         else:
-            third = len(text) // 3
-            blob = gzip.compress(text[:third], 1) + gzip.compress(text[third:2 * third + 7], 9) + gzip.compress(text[2 * third + 7:], 4)
+            # (member ends become buffer ends in the reference's reader, and its line splitter loses the '\n' of a "\r\n" that
+            # straddles or ends a buffer - fastqreader.cpp:257-259 `end < mBufDataLen-1` - and then stops at a bogus malformed
+            # record; the stream parses the text itself and reads on, DESIGN.md 1.  Not what this test is about: cut elsewhere)
+            def cut_at(c):
+                while text[c - 1:c] == b"\r" or text[c - 2:c] == b"\r\n":
+                    c += 1
+                return c
+            a, b = cut_at(len(text) // 3), cut_at(2 * (len(text) // 3) + 7)
+            blob = gzip.compress(text[:a], 1) + gzip.compress(text[a:b], 9) + gzip.compress(text[b:], 4)
         paths.append(os.path.join(tmp, f"in{k}.fq.gz"))
         open(paths[-1], "wb").write(blob)
     return paths[0], (paths[1] if paired else None)
