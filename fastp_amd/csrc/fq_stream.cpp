@@ -174,7 +174,9 @@ struct fastp_gpu_stream {
     std::vector<const char*> fastap, seedp[2];
     fastp_gpu_ctx* ctx = nullptr;
     bool paired = false;
-    int nm = 1;
+    bool interleaved = false;      // both mates' records alternate in ONE file (--interleaved_in: FastqReaderPair::read src/fastqreader.cpp:470-478)
+    int nm = 1;                    // mates of a unit
+    int nf = 1;                    // input files (= nm unless interleaved)
     std::string err;
     fastp_gpu_stream_stats st;
     // counter blocks of the contexts a re-plan replaced
@@ -197,6 +199,10 @@ struct fastp_gpu_stream {
     uint8_t *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
     uint16_t* d_len[2] = {nullptr, nullptr};
     uint32_t *d_loff[2] = {nullptr, nullptr}, *d_llen[2] = {nullptr, nullptr};
+    // interleaved input: the parser's output for the file's records (2 x max_records), dealt out to the mates' arrays above
+    uint8_t *il_seq = nullptr, *il_qual = nullptr;
+    uint16_t* il_len = nullptr;
+    uint32_t *il_loff = nullptr, *il_llen = nullptr;
     fastp_gpu_read_result* d_res[2] = {nullptr, nullptr};
     fastp_gpu_pair_result* d_pair = nullptr;
     fastp_gpu_correction* d_corr = nullptr;
@@ -255,6 +261,8 @@ void free_buffers(fastp_gpu_stream* s) {
         hfree(s->h_res[m]); hfree(s->h_loff[m]);
         s->h_res[m] = nullptr; s->h_loff[m] = nullptr;
     }
+    dfree(s->il_seq); dfree(s->il_qual); dfree(s->il_len); dfree(s->il_loff); dfree(s->il_llen);
+    s->il_seq = s->il_qual = nullptr; s->il_len = nullptr; s->il_loff = s->il_llen = nullptr;
     dfree(s->d_pair); dfree(s->d_corr); dfree(s->d_ev); dfree(s->d_nc); dfree(s->d_nev); dfree(s->d_zero);
     s->d_pair = nullptr; s->d_corr = nullptr; s->d_ev = nullptr; s->d_nc = s->d_nev = nullptr; s->d_zero = nullptr;
     hfree(s->h_corr); hfree(s->h_ev); hfree(s->h_counts);
@@ -278,6 +286,13 @@ int alloc_rows(fastp_gpu_stream* s) {
         S_HIP(s, hipMalloc((void**)&s->d_seq[m], (size_t)s->max_records * ss));
         S_HIP(s, hipMalloc((void**)&s->d_qual[m], (size_t)s->max_records * qs));
     }
+    if (s->interleaved) {
+        if (s->il_seq) (void)hipFree(s->il_seq);
+        if (s->il_qual) (void)hipFree(s->il_qual);
+        s->il_seq = s->il_qual = nullptr;
+        S_HIP(s, hipMalloc((void**)&s->il_seq, 2 * (size_t)s->max_records * ss));
+        S_HIP(s, hipMalloc((void**)&s->il_qual, 2 * (size_t)s->max_records * qs));
+    }
     return FASTP_GPU_OK;
 }
 
@@ -285,13 +300,14 @@ int alloc_buffers(fastp_gpu_stream* s) {
     S_HIP(s, hipSetDevice(s->cfg.device));
     S_HIP(s, hipStreamCreateWithFlags(&s->sx, hipStreamNonBlocking));
     S_HIP(s, hipStreamCreateWithFlags(&s->cp_in, hipStreamNonBlocking));
-    const int nm = s->nm;
+    const int nm = s->nm, nf = s->nf;
     s->text_cap = (s->chunk + 4096 + 255) / 256 * 256;   // a trip's text never exceeds chunk bytes (see the loop)
     s->max_records = (int32_t)std::max<int64_t>(1024, s->chunk / 32);
+    if (s->interleaved) s->max_records = (s->max_records + 1) / 2;   // units: the file's text holds two records per unit
     for (int sl = 0; sl < 2; sl++) {
         // one allocation per slot: a single fastp_gpu_inflate_bgzf launch writes the text of both files
-        S_HIP(s, hipMalloc((void**)&s->d_text[sl][0], (size_t)(nm * s->text_cap)));
-        for (int m = 0; m < nm; m++) {
+        S_HIP(s, hipMalloc((void**)&s->d_text[sl][0], (size_t)(nf * s->text_cap)));
+        for (int m = 0; m < nf; m++) {
             s->d_text[sl][m] = s->d_text[sl][0] + (size_t)m * (size_t)s->text_cap;
             S_HIP(s, hipHostMalloc((void**)&s->pin_in[sl][m], (size_t)s->text_cap));
         }
@@ -301,12 +317,12 @@ int alloc_buffers(fastp_gpu_stream* s) {
         // that fill a trip's text are never larger than this; one more member may sit incomplete at the end
         s->comp_cap = (s->chunk + s->chunk / 512 + (1 << 17) + 255) / 256 * 256;
         s->max_blocks = (int32_t)std::min<int64_t>(s->chunk / 2048 + 64, 1 << 20);
-        const size_t idx_bytes = (size_t)nm * (size_t)s->max_blocks * 24 + 64;
-        for (int m = 0; m < nm; m++)
+        const size_t idx_bytes = (size_t)nf * (size_t)s->max_blocks * 24 + 64;
+        for (int m = 0; m < nf; m++)
             if (s->src_kind[m] == SRC_BGZF) S_HIP(s, hipHostMalloc((void**)&s->pin_comp[m], (size_t)s->comp_cap + 64));
         for (int sl = 0; sl < 2; sl++) {
-            S_HIP(s, hipMalloc((void**)&s->d_comp[sl], (size_t)(nm * s->comp_cap) + 64));
-            S_HIP(s, hipMemsetAsync(s->d_comp[sl], 0, (size_t)(nm * s->comp_cap) + 64, s->sx));
+            S_HIP(s, hipMalloc((void**)&s->d_comp[sl], (size_t)(nf * s->comp_cap) + 64));
+            S_HIP(s, hipMemsetAsync(s->d_comp[sl], 0, (size_t)(nf * s->comp_cap) + 64, s->sx));
             S_HIP(s, hipHostMalloc((void**)&s->pin_idx[sl], idx_bytes));
             S_HIP(s, hipMalloc((void**)&s->d_idx[sl], idx_bytes));
         }
@@ -319,6 +335,11 @@ int alloc_buffers(fastp_gpu_stream* s) {
         S_HIP(s, hipMalloc((void**)&s->d_llen[m], (size_t)s->max_records * 16));
         S_HIP(s, hipMalloc((void**)&s->d_res[m], (size_t)s->max_records * sizeof(fastp_gpu_read_result)));
         S_HIP(s, hipMemsetAsync(s->d_res[m], 0, (size_t)s->max_records * sizeof(fastp_gpu_read_result), s->sx));
+    }
+    if (s->interleaved) {
+        S_HIP(s, hipMalloc((void**)&s->il_len, 2 * (size_t)s->max_records * 2));
+        S_HIP(s, hipMalloc((void**)&s->il_loff, 2 * (size_t)s->max_records * 16));
+        S_HIP(s, hipMalloc((void**)&s->il_llen, 2 * (size_t)s->max_records * 16));
     }
     int rc = alloc_rows(s);
     if (rc) return rc;
@@ -340,7 +361,7 @@ int alloc_buffers(fastp_gpu_stream* s) {
     int64_t grow = 0;
     if (s->cfg.format.umi_loc != FASTP_GPU_UMI_NONE)
         grow = (int64_t)s->umi_delim.size() + (s->umi_prefix.empty() ? 0 : (int64_t)s->umi_prefix.size() + 1) + 2 * (int64_t)s->cfg.format.umi_len + 1;
-    const int64_t both = nm * s->text_cap + (int64_t)s->max_records * (96 + 2 * grow);   // every record of both mates + tags
+    const int64_t both = nf * s->text_cap + (int64_t)s->max_records * (96 + 2 * grow);   // every record of both mates + tags
     const int64_t one = s->text_cap + (int64_t)s->max_records * grow + 64;              // out1 / out2: records only shrink, but for the UMI tag
     const int64_t caps[FASTP_GPU_N_OUTPUTS] = {one, one, both, both, both, both};
     s->any_out = false;
@@ -574,7 +595,10 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     s->cfg = *cfg;
     s->paired = params->paired != 0;
     s->nm = s->paired ? 2 : 1;
-    if (s->paired != (cfg->in2 != nullptr)) { g_stream_error = "a paired engine needs two input files, a single-end engine one"; return FASTP_GPU_E_INVALID; }
+    s->interleaved = cfg->interleaved != 0;
+    if (s->interleaved && (!s->paired || cfg->in2)) { g_stream_error = "interleaved input is one file of a paired run"; return FASTP_GPU_E_INVALID; }
+    s->nf = s->interleaved ? 1 : s->nm;
+    if (!s->interleaved && s->paired != (cfg->in2 != nullptr)) { g_stream_error = "a paired engine needs two input files (or one interleaved file), a single-end engine one"; return FASTP_GPU_E_INVALID; }
     if (params->overlapped_out) { g_stream_error = "--overlapped_out's stream is written by the host glue (fastp_gpu_host.h), not by the device formatter"; return FASTP_GPU_E_UNSUPPORTED; }
     s->in1 = cfg->in1;
     if (cfg->in2) s->in2 = cfg->in2;
@@ -594,12 +618,12 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     s->cfg.format.umi_prefix = s->umi_prefix.empty() ? nullptr : s->umi_prefix.c_str();
     s->cfg.format.umi_delimiter = s->umi_delim.c_str();
     s->cfg.in1 = s->in1.c_str();
-    s->cfg.in2 = s->paired ? s->in2.c_str() : nullptr;
+    s->cfg.in2 = s->nf > 1 ? s->in2.c_str() : nullptr;
     s->chunk = cfg->chunk_bytes > 0 ? cfg->chunk_bytes : (int64_t)env_int("FASTP_GPU_STREAM_CHUNK_MB", 16) << 20;
     if (cfg->chunk_bytes <= 0 && getenv("FASTP_GPU_STREAM_CHUNK_BYTES")) s->chunk = atoll(getenv("FASTP_GPU_STREAM_CHUNK_BYTES"));   // tests: many small trips
     s->chunk = std::max<int64_t>(4096, std::min<int64_t>(s->chunk, (int64_t)1 << 30)) / 256 * 256;
     if (s->cfg.io_threads <= 0) s->cfg.io_threads = env_int("FASTP_GPU_STREAM_IO_THREADS", 8);
-    for (int m = 0; m < s->nm; m++) {
+    for (int m = 0; m < s->nf; m++) {
         s->src_kind[m] = input_kind(m ? s->in2 : s->in1);
         s->st.input_kind[m] = s->src_kind[m];
         s->any_bgzf = s->any_bgzf || s->src_kind[m] == SRC_BGZF;
@@ -767,7 +791,7 @@ void reader_main(Run* R) {
     bool src_eof[2] = {false, false};
     std::vector<uint32_t> ix32[4];
     std::vector<uint64_t> ix64;
-    for (int m = 0; m < s->nm; m++) { gz[m].fd = R->fds[m]; gz[m].fsize = R->sizes[m]; }
+    for (int m = 0; m < s->nf; m++) { gz[m].fd = R->fds[m]; gz[m].fsize = R->sizes[m]; }
     auto pread_pieces = [&](int fd, uint8_t* dst, int64_t off0, int64_t want) {
         for (int64_t a = 0; a < want; a += IO_PIECE) {
             const int64_t e = std::min(want, a + IO_PIECE);
@@ -791,7 +815,7 @@ void reader_main(Run* R) {
         d.slot = rq.slot;
         int64_t gz_made[2] = {0, 0};
         int gz_err[2] = {0, 0};
-        for (int m = 0; m < s->nm; m++) {
+        for (int m = 0; m < s->nf; m++) {
             uint8_t* dst = s->pin_in[rq.slot][m] + rq.carry[m];
             if (s->src_kind[m] == SRC_PLAIN) {
                 const int64_t want = std::max<int64_t>(0, std::min(rq.budget[m], R->sizes[m] - pos[m]));
@@ -818,7 +842,7 @@ void reader_main(Run* R) {
         }
         pool.wait();
         if (R->io_err.load()) d.err = 1;
-        for (int m = 0; m < s->nm && !d.err; m++)
+        for (int m = 0; m < s->nf && !d.err; m++)
             if (s->src_kind[m] == SRC_GZIP && rq.budget[m] > 0 && !src_eof[m]) {
                 if (gz_made[m] < 0) { d.err = gz_err[m] ? gz_err[m] : 4; break; }
                 d.nb[m] = gz_made[m];
@@ -832,7 +856,7 @@ void reader_main(Run* R) {
             int32_t nblk[2] = {0, 0};
             for (int k = 0; k < 4; k++) ix32[k].clear();
             ix64.clear();
-            for (int m = 0; m < s->nm && !d.err; m++) {
+            for (int m = 0; m < s->nf && !d.err; m++) {
                 if (s->src_kind[m] != SRC_BGZF || rq.budget[m] <= 0) continue;
                 const size_t at = ix64.size(), room = (size_t)s->max_blocks;
                 for (int k = 0; k < 4; k++) ix32[k].resize(at + room);
@@ -866,13 +890,13 @@ void reader_main(Run* R) {
                 for (int k = 0; k < 4; k++) memcpy(w + 4 * n * (size_t)k, ix32[k].data(), 4 * n);
                 memcpy(w + 16 * n, ix64.data(), 8 * n);
                 if (hipMemcpyAsync(s->d_idx[rq.slot], w, 24 * n, hipMemcpyHostToDevice, s->cp_in) != hipSuccess) d.err = 2;
-                for (int m = 0; m < s->nm && !d.err; m++)
+                for (int m = 0; m < s->nf && !d.err; m++)
                     if (consumed[m] > 0 &&
                         hipMemcpyAsync(s->d_comp[rq.slot] + (size_t)m * (size_t)s->comp_cap, s->pin_comp[m], (size_t)consumed[m], hipMemcpyHostToDevice, s->cp_in) != hipSuccess)
                         d.err = 2;
             }
         }
-        for (int m = 0; m < s->nm && !d.err; m++) {
+        for (int m = 0; m < s->nf && !d.err; m++) {
             d.eof[m] = src_eof[m];
             // a BGZF file's fresh text is made on the device (run_loop): only the carried text goes up from here
             const int64_t total = rq.carry[m] + (s->src_kind[m] == SRC_BGZF ? 0 : d.nb[m]);
@@ -880,7 +904,7 @@ void reader_main(Run* R) {
             if (hipMemcpyAsync(s->d_text[rq.slot][m], s->pin_in[rq.slot][m], (size_t)total + 32, hipMemcpyHostToDevice, s->cp_in) != hipSuccess) d.err = 2;
         }
         if (!d.err && hipStreamSynchronize(s->cp_in) != hipSuccess) d.err = 2;
-        for (int m = 0; m < s->nm; m++)
+        for (int m = 0; m < s->nf; m++)
             if (consumed[m] > 0) {   // (after the copy: the staging buffer is its source)
                 memmove(s->pin_comp[m], s->pin_comp[m] + consumed[m], (size_t)(comp_have[m] - consumed[m]));
                 comp_have[m] -= consumed[m];
@@ -945,7 +969,8 @@ void replay_main(Run* R) {
 // the caller's thread: one trip per chunk
 int run_loop(Run* R) {
     fastp_gpu_stream* s = R->s;
-    const int nm = s->nm;
+    const int nm = s->nm, nf = s->nf;
+    const auto file_of = [s](int m) { return s->interleaved ? 0 : m; };   // the file (text) a mate's records lie in
     Extractor ex{s, {}, {}, {}};
     int64_t carry[2] = {0, 0};
     int slot = 0;
@@ -953,7 +978,7 @@ int run_loop(Run* R) {
     {
         ReadReq rq;
         rq.slot = 0;
-        for (int m = 0; m < nm; m++) rq.budget[m] = s->chunk;
+        for (int m = 0; m < nf; m++) rq.budget[m] = s->chunk;
         R->q_req.put(rq);
     }
     while (!done) {
@@ -974,12 +999,12 @@ int run_loop(Run* R) {
             int32_t bad = -1;
             static const int check_crc = env_int("FASTP_GPU_STREAM_CHECK_CRC", 1);
             if (fastp_gpu_inflate_bgzf(s->ctx, s->d_comp[slot], d.n_blocks, (const uint32_t*)ix, (const uint32_t*)(ix + 4 * nb), (const uint32_t*)(ix + 8 * nb),
-                                       (const uint32_t*)(ix + 12 * nb), (const uint64_t*)(ix + 16 * nb), s->d_text[slot][0], (int64_t)nm * s->text_cap, check_crc,
+                                       (const uint32_t*)(ix + 12 * nb), (const uint64_t*)(ix + 16 * nb), s->d_text[slot][0], (int64_t)nf * s->text_cap, check_crc,
                                        &bad) != FASTP_GPU_OK)
                 return s->fail_ctx(FASTP_GPU_E_INVALID, bad >= 0 ? "a BGZF member of an input does not inflate to what its trailer says (damaged file)" : "fastp_gpu_inflate_bgzf");
             // the text comes to the host as well: the part no record covers is carried from there, the adapter replay cuts
             // its strings from it
-            for (int m = 0; m < nm; m++) {
+            for (int m = 0; m < nf; m++) {
                 if (s->src_kind[m] != SRC_BGZF) continue;
                 S_HIP(s, hipMemsetAsync(s->d_text[slot][m] + carry[m] + d.nb[m], 0, 32, s->sx));
                 if (d.nb[m] > 0)
@@ -990,7 +1015,7 @@ int run_loop(Run* R) {
         }
         int64_t total[2] = {0, 0};
         bool all_eof = true, any_fresh = false;
-        for (int m = 0; m < nm; m++) {
+        for (int m = 0; m < nf; m++) {
             total[m] = carry[m] + d.nb[m];
             s->st.bytes_in[m] += d.nb[m];
             s->st.bytes_file[m] += d.file_bytes[m];
@@ -1007,7 +1032,41 @@ int run_loop(Run* R) {
         std::vector<int32_t> exotic[2];
         bool stop_after = false;
         t0 = now_s();
-        for (int attempt = 0;; attempt++) {
+        for (int attempt = 0; s->interleaved; attempt++) {
+            // one file, the mates' records in turn (FastqReaderPair::read, src/fastqreader.cpp:470-478): 2 * cap records at most;
+            // an odd record at the end waits for its mate in the next trip (at the end of the file it has none: the reference's
+            // pair is then incomplete, which is its end of input as well, src/peprocessor.cpp:906-909)
+            if (cap <= 0) { n = 0; break; }
+            if (attempt > 16) return s->fail(FASTP_GPU_E_INVALID, "the parser does not settle on a record count");
+            int32_t want = 2 * cap;
+            int prc = fastp_gpu_parse_fastq(s->ctx, s->d_text[slot][0], total[0], d.eof[0] ? 1 : 0, want, s->il_seq, s->il_qual, s->il_len, s->il_loff, s->il_llen, &info[0]);
+            if (prc == FASTP_GPU_OK && (info[0].n_records & 1)) {
+                want = info[0].n_records - 1;
+                if (want == 0) { n = 0; break; }
+                prc = fastp_gpu_parse_fastq(s->ctx, s->d_text[slot][0], total[0], d.eof[0] ? 1 : 0, want, s->il_seq, s->il_qual, s->il_len, s->il_loff, s->il_llen, &info[0]);
+                if (prc == FASTP_GPU_OK && info[0].n_records != want) return s->fail(FASTP_GPU_E_INVALID, "the parser does not settle on a record count");
+            }
+            if (prc == FASTP_GPU_OK) {
+                n = info[0].n_records / 2;
+                first_n[0] = n;
+                exotic[0].resize((size_t)info[0].n_exotic);
+                if (info[0].n_exotic) fastp_gpu_parse_exotic(s->ctx, exotic[0].data(), info[0].n_exotic);
+                for (int32_t& u : exotic[0]) u >>= 1;   // record -> unit
+                break;
+            }
+            if (prc != FASTP_GPU_E_INVALID || info[0].first_bad < 0) return s->fail_ctx(prc, "fastp_gpu_parse_fastq");
+            if (info[0].bad_kind == FASTP_GPU_PARSE_BAD_TOO_LONG) {
+                const int rc = replan(s, info[0].max_seq_len);
+                if (rc) return rc;
+            } else if (info[0].bad_kind == FASTP_GPU_PARSE_BAD_ALPHABET) {
+                return s->fail(FASTP_GPU_E_ALPHABET, "record " + std::to_string(2 * s->st.units + info[0].first_bad) + " of file 1 has a quality character outside '!'..'~'");
+            } else {   // FastqReader::read returns NULL there, for either mate: the stream ends in front of that pair
+                cap = info[0].first_bad / 2;
+                s->st.truncated = 1;
+                stop_after = true;
+            }
+        }
+        for (int attempt = 0; !s->interleaved; attempt++) {
             if (cap <= 0) { n = 0; break; }
             if (attempt > 16) return s->fail(FASTP_GPU_E_INVALID, "the parser does not settle on a record count");
             bool again = false;
@@ -1050,17 +1109,17 @@ int run_loop(Run* R) {
         // a file that is at its end and has handed out its last complete record ends the stream, whatever the other file
         // still holds: the reference pairs packs up and stops at the shorter file (peprocessor.cpp:363-370, :1034-1037)
         bool exhausted = false;
-        for (int m = 0; m < nm; m++)
+        for (int m = 0; m < nf; m++)
             if (d.eof[m] && cap > 0 && (total[m] == 0 || (info[m].n_records == n && first_n[m] == n && first_n[m] < cap))) exhausted = true;
         s->st.parse_s += now_s() - t0;
         int64_t left[2] = {0, 0};
         bool any_left = false;
-        for (int m = 0; m < nm; m++) {
+        for (int m = 0; m < nf; m++) {
             left[m] = total[m] - (n > 0 ? info[m].consumed : 0);
             any_left = any_left || left[m] > 0;
         }
         const bool limit_hit = s->cfg.reads_to_process > 0 && s->st.units + n >= s->cfg.reads_to_process;
-        if (stop_after || limit_hit || (exhausted && nm > 1)) {
+        if (stop_after || limit_hit || (exhausted && nf > 1)) {
             done = true;
         } else if (all_eof) {
             // a trip takes at most max_records records: when the cap was hit, complete records may remain in the carried
@@ -1069,7 +1128,7 @@ int run_loop(Run* R) {
             drain = n > 0 && n >= cap && any_left;
             done = !drain;
         } else if (n == 0) {
-            for (int m = 0; m < nm; m++)
+            for (int m = 0; m < nf; m++)
                 if (left[m] >= s->chunk) return s->fail(FASTP_GPU_E_INVALID, "a record does not fit the chunk size (FASTP_GPU_STREAM_CHUNK_MB)");
             // nothing parsed and nothing new arrived: a BGZF member (up to 64 KiB of text) takes whole-member room behind the carried text
             if (!any_fresh && total[0] + total[1] > 0)
@@ -1080,12 +1139,25 @@ int run_loop(Run* R) {
         if (!done) {
             ReadReq rq;
             rq.slot = 1 - slot;
-            for (int m = 0; m < nm; m++) {
+            for (int m = 0; m < nf; m++) {
                 if (left[m] > 0) memcpy(s->pin_in[1 - slot][m], s->pin_in[slot][m] + (total[m] - left[m]), (size_t)left[m]);
                 rq.carry[m] = left[m];
                 rq.budget[m] = drain ? 0 : std::max<int64_t>(0, s->chunk - left[m]);
             }
             R->q_req.put(rq);
+        }
+        if (n > 0 && s->interleaved) {   // deal the file's records out: even ones are read 1, odd ones read 2 (strided device copies)
+            t0 = now_s();
+            const size_t ss = fastp_gpu_seq_stride(s->p.max_len), qs = fastp_gpu_qual_stride(s->p.max_len);
+            for (int m = 0; m < 2; m++) {
+                S_HIP(s, hipMemcpy2DAsync(s->d_seq[m], ss, s->il_seq + (size_t)m * ss, 2 * ss, ss, (size_t)n, hipMemcpyDeviceToDevice, s->sx));
+                S_HIP(s, hipMemcpy2DAsync(s->d_qual[m], qs, s->il_qual + (size_t)m * qs, 2 * qs, qs, (size_t)n, hipMemcpyDeviceToDevice, s->sx));
+                S_HIP(s, hipMemcpy2DAsync(s->d_len[m], 2, s->il_len + m, 4, 2, (size_t)n, hipMemcpyDeviceToDevice, s->sx));
+                S_HIP(s, hipMemcpy2DAsync(s->d_loff[m], 16, s->il_loff + 4 * m, 32, 16, (size_t)n, hipMemcpyDeviceToDevice, s->sx));
+                S_HIP(s, hipMemcpy2DAsync(s->d_llen[m], 16, s->il_llen + 4 * m, 32, 16, (size_t)n, hipMemcpyDeviceToDevice, s->sx));
+            }
+            S_HIP(s, hipStreamSynchronize(s->sx));
+            s->st.parse_s += now_s() - t0;
         }
         if (n > 0) {
             // ---- the worker loop ----
@@ -1097,7 +1169,7 @@ int run_loop(Run* R) {
             b.seq1 = s->d_seq[0]; b.qual1 = s->d_qual[0]; b.len1 = s->d_len[0];
             if (s->paired) { b.seq2 = s->d_seq[1]; b.qual2 = s->d_qual[1]; b.len2 = s->d_len[1]; }
             std::vector<int32_t> xunits;   // units with letters outside ACGTN in either mate: the engine reads their text in place
-            for (int m = 0; m < nm; m++)
+            for (int m = 0; m < nf; m++)
                 for (int32_t u : exotic[m])
                     if (u < n) xunits.push_back(u);
             if (!xunits.empty()) {
@@ -1106,7 +1178,7 @@ int run_loop(Run* R) {
                 b.n_exotic = (int32_t)xunits.size();
                 b.exotic_dense = 1;
                 b.exotic_unit = xunits.data();
-                for (int m = 0; m < nm; m++) { b.exotic_text[m] = s->d_text[slot][m]; b.exotic_off[m] = s->d_loff[m]; }
+                for (int m = 0; m < nm; m++) { b.exotic_text[m] = s->d_text[slot][file_of(m)]; b.exotic_off[m] = s->d_loff[m]; }
             }
             fastp_gpu_results r;
             memset(&r, 0, sizeof(r));
@@ -1136,7 +1208,7 @@ int run_loop(Run* R) {
                 if (nev) S_HIP(s, hipMemcpyAsync(s->h_ev, s->d_ev, (size_t)nev * sizeof(fastp_gpu_adapter_event), hipMemcpyDeviceToHost, s->sx));
                 if (ncorr || nev) S_HIP(s, hipStreamSynchronize(s->sx));
                 ReplayJob job;
-                const uint8_t* text[2] = {s->pin_in[slot][0], nm > 1 ? s->pin_in[slot][1] : nullptr};
+                const uint8_t* text[2] = {s->pin_in[slot][0], nm > 1 ? s->pin_in[slot][file_of(1)] : nullptr};
                 ex.run(n, text, ncorr, nev, job.blob);
                 if (!job.blob.empty()) R->q_replay.put(std::move(job));
             }
@@ -1146,7 +1218,7 @@ int run_loop(Run* R) {
             if (s->any_out) {
                 t0 = now_s();
                 fastp_gpu_format_io io[2];
-                for (int m = 0; m < nm; m++) { io[m].text = s->d_text[slot][m]; io[m].line_off = s->d_loff[m]; io[m].line_len = s->d_llen[m]; io[m].res = s->d_res[m]; }
+                for (int m = 0; m < nm; m++) { io[m].text = s->d_text[slot][file_of(m)]; io[m].line_off = s->d_loff[m]; io[m].line_len = s->d_llen[m]; io[m].res = s->d_res[m]; }
                 fastp_gpu_format_options fo = s->cfg.format;
                 fo.corrections_capacity = s->corr_cap;
                 int64_t lens[FASTP_GPU_N_OUTPUTS];
@@ -1185,7 +1257,7 @@ int run_loop(Run* R) {
         }
         if (R->io_err.load()) return s->fail(FASTP_GPU_E_INVALID, "writing an output file failed");
         if (R->emit_err.load()) return s->fail(FASTP_GPU_E_INVALID, "the emit callback stopped the run");
-        for (int m = 0; m < nm; m++) carry[m] = left[m];
+        for (int m = 0; m < nf; m++) carry[m] = left[m];
     }
     return FASTP_GPU_OK;
 }
@@ -1232,7 +1304,7 @@ extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
     S_HIP(s, hipSetDevice(s->cfg.device));
     Run R(s);
     const char* paths[2] = {s->cfg.in1, s->cfg.in2};
-    for (int m = 0; m < s->nm; m++) {
+    for (int m = 0; m < s->nf; m++) {
         R.fds[m] = open(paths[m], O_RDONLY);
         struct stat sb;
         if (R.fds[m] < 0 || fstat(R.fds[m], &sb) != 0 || !S_ISREG(sb.st_mode)) {
@@ -1264,7 +1336,7 @@ extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
     reader.join();
     writer.join();
     replayer.join();
-    for (int m = 0; m < s->nm; m++) close(R.fds[m]);
+    for (int m = 0; m < s->nf; m++) close(R.fds[m]);
     if (rc == FASTP_GPU_OK && R.io_err.load()) rc = s->fail(FASTP_GPU_E_INVALID, "file I/O failed");
     if (rc == FASTP_GPU_OK && R.emit_err.load()) rc = s->fail(FASTP_GPU_E_INVALID, "the emit callback stopped the run");
     s->st.wall_s = now_s() - t_start;

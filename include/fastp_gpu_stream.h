@@ -5,6 +5,7 @@
  * Reference code this stands in for (OpenGene/fastp v1.3.6) when a maintainer binds it into the
  * reference's own reader / writer threads (oracle/patches/gpu_worker.cpp):
  *   PairEndProcessor::readerTask      src/peprocessor.cpp:725-888   } raw file bytes instead of
+ *   PairEndProcessor::interleavedReaderTask  src/peprocessor.cpp:890-1013 (config.interleaved)
  *   SingleEndProcessor::readerTask    src/seprocessor.cpp:327-442   } FastqReader::read
  *   FastqReader::getLine / read       src/fastqreader.cpp:240-368   } (src/fastqreader.cpp:88-149 fills 8 MiB blocks)
  *   processorTask -> processPairEnd / processSingleEnd  src/peprocessor.cpp:1021-1033, :362-708
@@ -64,6 +65,9 @@ typedef struct fastp_gpu_stream_config {
     fastp_gpu_stream_emit_fn emit;
     void* user;
     fastp_gpu_host* host;       /* FilterResult's adapter maps are replayed into this object (may be NULL) */
+    int32_t interleaved;        /* --interleaved_in: a paired run whose mates alternate in in1 (in2 = NULL), as
+                                 * FastqReaderPair::read takes them (src/fastqreader.cpp:470-478) in
+                                 * PairEndProcessor::interleavedReaderTask (src/peprocessor.cpp:890-1013)          */
 } fastp_gpu_stream_config;
 
 typedef struct fastp_gpu_stream_stats {

@@ -3,7 +3,7 @@
 
     apply_gpu_worker.py <reference root> <output dir>
 
-Writes <output dir>/peprocessor.cpp, seprocessor.cpp, evaluator.cpp and fastqreader.cpp: the reference's files with twelve one-line insertions,
+Writes <output dir>/peprocessor.cpp, seprocessor.cpp, evaluator.cpp and fastqreader.cpp: the reference's files with thirteen one-line insertions,
 each placed by an anchor (the function signature / the comment that opens the merge of the per-thread results).
 Nothing else of the reference is touched or reproduced here; every other source is compiled where it lies.
 """
@@ -37,6 +37,8 @@ def patch(name, inserts):
 patch("peprocessor.cpp", [
     (r"void PairEndProcessor::readerTask\(bool isLeft\)\s*\{",
      "\n    if(fastp_gpu_stream_reader_pe(this, isLeft) > 0) return;   // GPU stream mode: raw chunks -> device parser / engine / formatter -> the writers' files\n", "after"),
+    (r"void PairEndProcessor::interleavedReaderTask\(\)\s*\{",
+     "\n    if(fastp_gpu_stream_reader_interleaved(this) > 0) return;   // GPU stream mode on --interleaved_in\n", "after"),
     (r"bool PairEndProcessor::processPairEnd\(ReadPack\* leftPack, ReadPack\* rightPack, ThreadConfig\* config\)\s*\{",
      "\n    if(fastp_gpu_worker_pe(this, leftPack, rightPack, config) > 0) return true;   // GPU engine (FASTP_GPU=1)\n", "after"),
     (r"[ \t]*// merge stats and filter results",

@@ -231,7 +231,7 @@ void make_state(Options* o, bool paired) {
     State* s = new State();
     s->paired = paired;
     // pack mode is what is left for the option sets the stream binding below does not take (--overlapped_out, phred64,
-    // interleaved / piped input); it is bound by the reference's reader thread, so the rows are sized generously rather
+    // piped input); it is bound by the reference's reader thread, so the rows are sized generously rather
     // than by the first 1000 reads (Evaluator::computeSeqLen evaluator.cpp:54-76): a longer read later in the file is
     // what the reference takes in its stride (Stats::extendBuffer stats.cpp:65-83)
     s->max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);
@@ -821,8 +821,11 @@ bool plain_regular_file(const std::string& path) {
 bool stream_mode(Options* o, bool paired) {
     if (!enabled()) return false;
     if (const char* v = getenv("FASTP_GPU_STREAM")) if (atoi(v) == 0) return false;
-    if (o->interleavedInput || o->phred64 || !o->overlappedOut.empty()) return false;
-    if (!plain_regular_file(o->in1) || (paired && !plain_regular_file(o->in2))) return false;
+    if (o->phred64 || !o->overlappedOut.empty()) return false;
+    if (o->interleavedInput) {
+        if (const char* v = getenv("FASTP_GPU_STREAM_INTERLEAVED")) if (atoi(v) == 0) return false;   // (pack mode for comparison)
+    }
+    if (!plain_regular_file(o->in1) || (paired && !o->interleavedInput && !plain_regular_file(o->in2))) return false;
     if (paired && !o->out1.empty() && o->out2.empty()) return false;   // two reads into one stream: --stdout's form
     return true;
 }
@@ -848,7 +851,8 @@ void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU
     fastp_gpu_stream_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.in1 = o->in1.c_str();
-    cfg.in2 = paired ? o->in2.c_str() : NULL;
+    cfg.in2 = paired && !o->interleavedInput ? o->in2.c_str() : NULL;
+    cfg.interleaved = paired && o->interleavedInput ? 1 : 0;
     cfg.reads_to_process = o->readsToProcess;
     cfg.format.want_failed = S->B.ho.want_failed;
     cfg.format.want_unpaired1 = S->B.ho.want_unpaired1;
@@ -901,7 +905,7 @@ void stream_run() {
         for (int m = 0; m < (S->paired ? 2 : 1); m++)
             if (st.input_kind[m])
                 fprintf(stderr, "fastp_gpu: stream mode: input %d is %s: %lld bytes of the file -> %lld bytes of text (inflate + its copy to the host %.3f s)\n", m + 1,
-                        st.input_kind[m] == 2 ? "BGZF, inflated on the device" : "gzip, inflated by zlib on the host", (long long)st.bytes_file[m],
+                        st.input_kind[m] == 2 ? "BGZF, inflated on the device" : "gzip, inflated on a host thread of the stream (fq_gunzip.h)", (long long)st.bytes_file[m],
                         (long long)st.bytes_in[m], st.inflate_s);
     S->ran = true;
 }
@@ -957,6 +961,23 @@ int fastp_gpu_stream_reader_pe(PairEndProcessor* pp, bool isLeft) {
         pp->mRightInputLists[t]->setProducerFinished();
     }
     pp->mBackpressureCV.notify_all();
+    return 1;
+}
+
+// --interleaved_in: one reader thread (PairEndProcessor::interleavedReaderTask, src/peprocessor.cpp:890-1013) feeds both lists
+int fastp_gpu_stream_reader_interleaved(PairEndProcessor* pp) {
+    if (!stream_mode(pp->mOptions, true)) return -1;
+    WriterThread* const writers[FASTP_GPU_N_OUTPUTS] = {pp->mLeftWriter, pp->mRightWriter, pp->mFailedWriter, pp->mMergedWriter,
+                                                        pp->mUnpairedLeftWriter, pp->mUnpairedRightWriter};
+    stream_setup(pp->mOptions, true, writers);
+    stream_run();
+    for (int t = 0; t < pp->mOptions->thread; t++) {   // the task's own tail (:1001-1012)
+        pp->mLeftInputLists[t]->setProducerFinished();
+        pp->mRightInputLists[t]->setProducerFinished();
+    }
+    pp->mBackpressureCV.notify_all();
+    pp->mLeftReaderFinished.store(true, std::memory_order_release);
+    pp->mRightReaderFinished.store(true, std::memory_order_release);
     return 1;
 }
 

@@ -6,6 +6,7 @@
 // oracle/patches/apply_gpu_worker.py inserts one-line calls into copies of the reference's sources:
 //   src/peprocessor.cpp  top of PairEndProcessor::readerTask       -> fastp_gpu_stream_reader_pe   (stream mode)
 //   src/seprocessor.cpp  top of SingleEndProcessor::readerTask     -> fastp_gpu_stream_reader_se
+//   src/peprocessor.cpp  top of PairEndProcessor::interleavedReaderTask -> fastp_gpu_stream_reader_interleaved
 //   src/peprocessor.cpp  top of PairEndProcessor::processPairEnd   -> fastp_gpu_worker_pe
 //   src/seprocessor.cpp  top of SingleEndProcessor::processSingleEnd -> fastp_gpu_worker_se
 //   both                 end of ::processorTask (before setConsumerFinished) -> fastp_gpu_worker_drain_pe / _se
@@ -30,6 +31,7 @@ struct ReadPack;
 // worker threads stay idle.  1 = the run was taken, -1 = the reference's reader runs and the worker hooks below see packs.
 int fastp_gpu_stream_reader_pe(PairEndProcessor* p, bool isLeft);
 int fastp_gpu_stream_reader_se(SingleEndProcessor* p);
+int fastp_gpu_stream_reader_interleaved(PairEndProcessor* p);
 
 // PACK MODE (FASTP_GPU_STREAM=0, or an option set the stream loop does not take: --overlapped_out, phred64, interleaved /
 // piped / gz input).  1 = the pack was taken by the engine (packed into the current window of packs; its outputs reach the writers when the

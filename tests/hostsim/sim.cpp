@@ -222,6 +222,11 @@ hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   // launches run to completion inside hipLaunchKernelGGL
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+    if (width > dpitch || width > spitch) return hipErrorUnknown;
+    for (size_t r = 0; r < height; r++) memcpy((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+    return hipSuccess;
+}
 // Clearing Duplicate's 1 GiB of bitmaps with memset touches every page (a quarter of a million faults per engine that is
 // created or reset: minutes of system time over the suite).  A large zero fill gives the pages back instead: the blocks
 // come from calloc, i.e. private anonymous mappings, which read as zeros again after MADV_DONTNEED.

@@ -76,13 +76,15 @@ def _ensure_built():
     return os.path.exists(REF)
 
 
-def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1, gz=False, in1=None, in2=None):
+def _run(binary, tmp, tag, flags, paired, gpu_env, threads=1, gz=False, in1=None, in2=None, interleaved=False):
     out = os.path.join(tmp, tag)
     os.makedirs(out, exist_ok=True)
     ext = ".fq.gz" if gz else ".fq"
     cmd = [binary, "-i", in1 or os.path.join(tmp, "in1.fq"), "-o", os.path.join(out, "o1" + ext), "-j", os.path.join(out, "r.json"),
            "-h", os.path.join(out, "r.html"), "-w", str(threads), "--failed_out", os.path.join(out, "failed" + ext)]
-    if paired:
+    if paired and interleaved:      # both mates in in1
+        cmd += ["--interleaved_in", "-O", os.path.join(out, "o2" + ext)]
+    elif paired:
         cmd += ["-I", in2 or os.path.join(tmp, "in2.fq"), "-O", os.path.join(out, "o2" + ext)]
     cmd += [x.replace("@TMP@", out) for x in flags]
     env = dict(os.environ)
@@ -125,7 +127,7 @@ PACK_MODE = {"FASTP_GPU_STREAM": "0"}   # the reference's own reader threads + t
 
 
 def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n", trailing=True, gz=False, more_flags=(),
-           mode="stream", mutate=None, expect_units=None, gz_in=None):
+           mode="stream", mutate=None, expect_units=None, gz_in=None, interleaved=False):
     paired, flags, pf, skw = cases.CASES[name]
     flags = list(flags) + BINDING_CASES[name] + list(more_flags)
     tmp = str(tmp_path)
@@ -146,17 +148,26 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
             os.makedirs(os.path.join(tmp, tag), exist_ok=True)
             with open(os.path.join(tmp, tag, fn), "wb") as f:
                 f.write(content)
+    if interleaved:   # --interleaved_in: the two files dealt into one (read 1, read 2, read 1, ...), which takes in1.fq's place
+        a = open(os.path.join(tmp, "in1.fq"), "rb").read().split(eol)
+        b = open(os.path.join(tmp, "in2.fq"), "rb").read().split(eol)
+        recs = []
+        for i in range(0, min(len(a), len(b)) - 3, 4):
+            recs += a[i:i + 4] + b[i:i + 4]
+        with open(os.path.join(tmp, "in1.fq"), "wb") as f:
+            f.write(eol.join(recs) + (eol if trailing else b""))
+        os.remove(os.path.join(tmp, "in2.fq"))
     in1 = in2 = None
     if gz_in:   # ".gz" inputs, read by BOTH binaries (the reference here inflates through oracle/shims/isa-l over zlib)
         in1, in2 = _compress_inputs(tmp, paired, gz_in)
-    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {}, gz=gz, in1=in1, in2=in2)
+    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {}, gz=gz, in1=in1, in2=in2, interleaved=interleaved)
     env = {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}
     if binary == REF_SIM:
         env.update(SIM_ENV)
     if mode == "pack":
         env.update(PACK_MODE)
     env.update(extra_env or {})
-    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, env, threads=threads, gz=gz, in1=in1, in2=in2)
+    got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, env, threads=threads, gz=gz, in1=in1, in2=in2, interleaved=interleaved)
     err = got_rep.pop("__stderr__")
     want_rep.pop("__stderr__")
     # which binding ran: the stream loop says so; --overlapped_out is pack mode's
@@ -177,13 +188,29 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     return err
 
 
+IL_BINDING_CASES = [("pe_default", dict(threads=2)), ("pe_merge_unmerged", dict(threads=1, eol=b"\r\n")),
+                    ("pe_exotic_dedup_adapters", dict(threads=3, gz_in=("bgzf",), gz=True)), ("pe_overrep", dict(threads=4, gz_in=("members",)))]
+
+
+@pytest.mark.parametrize("name,kw", [("pe_merge_unmerged", dict(threads=1, eol=b"\r\n")),
+                                     ("pe_exotic_dedup_adapters", dict(threads=3, gz_in=("bgzf",), gz=True)),
+                                     ("pe_adapter_fasta", dict(threads=2, more_flags=("--reads_to_process", "500"), expect_units=500)),
+                                     ("pe_correction", dict(threads=2, mode="pack", extra_env={"FASTP_GPU_STREAM_INTERLEAVED": "0"}))])
+def test_patched_reference_interleaved_input(name, kw, tmp_path):
+    """--interleaved_in (PairEndProcessor::interleavedReaderTask): the stream deals the one file's records out to the mates on the
+    device; FASTP_GPU_STREAM_INTERLEAVED=0 keeps the reference's own interleaved reader (pack mode)"""
+    if not _ensure_built() or not os.path.exists(REF_SIM):
+        pytest.skip("reference binaries not built (no /root/reference here)")
+    _check(name, REF_SIM, 900, tmp_path, seed=58, interleaved=True, **kw)
+
+
 def _compress_inputs(tmp, paired, how):
     """in1.fq / in2.fq -> .fq.gz: "bgzf" = bgzip's members (9000 bytes of text each here: many per trip), "gzip" = one member,
     "members" = a few plain gzip members one behind the other"""
     import gzip
     import bgzf_util
     paths = []
-    for k, h in zip((1, 2) if paired else (1,), how):
+    for k, h in zip((1, 2) if paired and len(how) > 1 else (1,), how):
         text = open(os.path.join(tmp, f"in{k}.fq"), "rb").read()
         if h == "bgzf":
             blob = bgzf_util.compress(text, block_bytes=9000)
@@ -201,7 +228,7 @@ def _compress_inputs(tmp, paired, how):
             blob = gzip.compress(text[:a], 1) + gzip.compress(text[a:b], 9) + gzip.compress(text[b:], 4)
         paths.append(os.path.join(tmp, f"in{k}.fq.gz"))
         open(paths[-1], "wb").write(blob)
-    return paths[0], (paths[1] if paired else None)
+    return paths[0], (paths[1] if len(paths) > 1 else None)
 
 
 # on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in

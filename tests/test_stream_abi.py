@@ -315,3 +315,78 @@ def test_sim_stream_compressed_inputs_limits_and_damage(tmp_path):
     with pytest.raises(streamlib.StreamError) as e:
         streamlib.run_files(lib, params, bad, g2, str(tmp_path), chunk_bytes=40000)
     assert "does not fit the chunk size" in str(e.value)
+
+
+# ---- --interleaved_in: the mates' records alternate in one file ----
+def _interleave(fq1: bytes, fq2: bytes) -> bytes:
+    a, b = fq1.split(b"\n"), fq2.split(b"\n")
+    out = []
+    for i in range(0, min(len(a), len(b)) - 3, 4):
+        out += a[i:i + 4] + b[i:i + 4]
+    return b"\n".join(out) + b"\n"
+
+
+def _golden_interleaved(lib, name, tmp_path, chunk_bytes, pack=None, max_len=152):
+    fq1, fq2, meta = golden_util.load(name)
+    params = golden_util.params_for(name, max_len=max_len, fq1=fq1, fq2=fq2)
+    text = _interleave(fq1, fq2)
+    p1 = os.path.join(str(tmp_path), "il.fq" + (".gz" if pack else ""))
+    open(p1, "wb").write(_pack(text, pack, 5) if pack else text)
+    want = [k for k in meta["outputs"] if k != "overlapped"]
+    if "out1" not in want:
+        want += ["out1", "out2"]
+    outs, ctr, lay, amaps, st = streamlib.run_files(lib, params, p1, None, str(tmp_path), want=want, chunk_bytes=chunk_bytes, umi=golden_util.umi_for(name),
+                                                     interleaved=True)
+    golden_util.check_against_golden(name, streamlib.as_outputs(outs, True), streamlib.report(ctr, lay, params, amaps), meta)
+    return st
+
+
+IL_CASES = [("pe_default", None), ("pe_correction", None), ("pe_merge_unmerged", "bgzf"), ("pe_adapter_fasta", "gzip"), ("pe_exotic_dedup_adapters", None),
+            ("pe_umi_per_read", None), ("pe_overrep", None), ("pe_filters", "members")]
+
+
+@pytest.mark.parametrize("name,pack", [c for c in IL_CASES if c[0] in ("pe_correction", "pe_merge_unmerged", "pe_exotic_dedup_adapters", "pe_filters")])
+def test_sim_stream_interleaved_input_equals_reference_golden(name, pack, tmp_path):
+    """the paired goldens with their two input files dealt into ONE (read 1, read 2, read 1, ...): FastqReaderPair::read takes
+    them in turn, so the run is the two-file run - outputs, counters, adapter maps; several trips, odd records carried"""
+    lib = engine.load_library(engines.build_sim())
+    st = _golden_interleaved(lib, name, tmp_path, 60000, pack)
+    assert st.chunks >= 3
+
+
+def test_sim_stream_interleaved_limits_odd_tail_and_replan(tmp_path):
+    lib = engine.load_library(engines.build_sim())
+    fq1, fq2 = _synthetic(1300, seed=95)
+    params = golden_util.params_for("pe_cut_right", max_len=152)
+    params.dup_enabled = 0
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    two = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000)
+    il = os.path.join(str(tmp_path), "il.fq")
+    text = _interleave(fq1, fq2)
+    open(il, "wb").write(text)
+    one = streamlib.run_files(lib, params, il, None, str(tmp_path), chunk_bytes=60000, interleaved=True)
+    assert one[0] == two[0] and np.array_equal(one[1], two[1]) and one[3].a1 == two[3].a1 and one[3].a2 == two[3].a2 and one[4].units == 1300
+    # a record without its mate at the end: the reference's last pair is incomplete = its end of input (peprocessor.cpp:906-909)
+    open(il, "wb").write(text + b"\n".join(fq1.split(b"\n")[:4]) + b"\n")
+    odd = streamlib.run_files(lib, params, il, None, str(tmp_path), chunk_bytes=60000, interleaved=True)
+    assert odd[0] == two[0] and np.array_equal(odd[1], two[1])
+    # --reads_to_process counts pairs
+    lim2 = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000, reads_to_process=555)
+    open(il, "wb").write(text)
+    lim1 = streamlib.run_files(lib, params, il, None, str(tmp_path), chunk_bytes=60000, reads_to_process=555, interleaved=True)
+    assert lim1[0] == lim2[0] and np.array_equal(lim1[1], lim2[1]) and lim1[4].units == 555
+    # a malformed record (either mate's) ends the stream in front of its pair
+    lines = text.split(b"\n")
+    k = 4 * (2 * 700 + 1) + 3           # the quality line of read 2 of pair 700
+    lines[k] = lines[k][:-1]
+    open(il, "wb").write(b"\n".join(lines))
+    cut = streamlib.run_files(lib, params, il, None, str(tmp_path), chunk_bytes=60000, interleaved=True)
+    assert cut[4].truncated == 1 and cut[4].units == 700
+    # a longer read later in the file: re-plan with the dealt-out rows reallocated
+    small = golden_util.params_for("pe_cut_right", max_len=64)
+    small.dup_enabled = 0
+    open(il, "wb").write(text)
+    rp = streamlib.run_files(lib, small, il, None, str(tmp_path), chunk_bytes=60000, interleaved=True)
+    assert rp[4].replans >= 1 and rp[0] == two[0]
+    with pytest.raises(streamlib.StreamError):
+        streamlib.run_files(lib, params, il, p2, str(tmp_path), interleaved=True)     # interleaved input is ONE file

@@ -1,4 +1,4 @@
-"""The `-m gpu` side of the compressed-input tests (".gz" inputs of the stream: bgzip-written files inflated on the device in
+"""The `-m gpu` side of the compressed-input and interleaved-input tests (".gz" inputs of the stream: bgzip-written files inflated on the device in
 place of BgzfMtReader, other gzip streams by zlib inside the stream).  Their CPU-suite counterparts run on the emulator in
 tests/test_stream_abi.py and tests/test_ref_binding.py; these were written in a session without GPU minutes and live in a file
 of their own, collected last, so that nothing else's result depends on them."""
@@ -11,7 +11,7 @@ import pytest
 import streamlib
 import test_ref_binding as rb
 from fastp_amd import abi, engine
-from test_stream_abi import GZ_CASES, _files, _golden_gz, _run_plain_and
+from test_stream_abi import GZ_CASES, IL_CASES, _files, _golden_gz, _golden_interleaved, _run_plain_and
 
 
 @pytest.mark.gpu
@@ -56,3 +56,18 @@ def test_gpu_patched_reference_compressed_inputs(name, how, tmp_path):
         pytest.skip("oracle/_ref binaries did not travel to this box")
     err = rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=44, gz_in=how, threads=4)
     assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,pack", IL_CASES)
+def test_gpu_stream_interleaved_input_equals_reference_golden(name, pack, tmp_path):
+    lib = engine.load_library()
+    _golden_interleaved(lib, name, tmp_path, 1 << 20, pack)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", rb.IL_BINDING_CASES)
+def test_gpu_patched_reference_interleaved_input(name, kw, tmp_path):
+    if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=45, interleaved=True, **kw)

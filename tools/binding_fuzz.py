@@ -140,7 +140,10 @@ def random_command(seed):
     if rng2.random() < 0.3:
         kinds = ["bgzf", "bgzf", "gzip", "members"]
         gz_in = tuple(kinds[int(rng2.integers(0, 4))] for _ in range(2 if paired else 1))
-    return dict(paired=paired, flags=f, L=L, n=n, skw=skw, eol=eol, threads=threads, gz=gz, mode=mode, umi=umi, gz_in=gz_in)
+    interleaved = bool(paired and rng2.random() < 0.2)   # --interleaved_in: both mates in one file
+    if interleaved and gz_in:
+        gz_in = gz_in[:1]
+    return dict(paired=paired, flags=f, L=L, n=n, skw=skw, eol=eol, threads=threads, gz=gz, mode=mode, umi=umi, gz_in=gz_in, interleaved=interleaved)
 
 
 def run(seed, binary, sim):
@@ -151,16 +154,24 @@ def run(seed, binary, sim):
         open(os.path.join(tmp, "in1.fq"), "wb").write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1).replace(b"\n", c["eol"]))
         if c["paired"]:
             open(os.path.join(tmp, "in2.fq"), "wb").write(synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2).replace(b"\n", c["eol"]))
+        if c["interleaved"]:
+            a = open(os.path.join(tmp, "in1.fq"), "rb").read().split(c["eol"])
+            b = open(os.path.join(tmp, "in2.fq"), "rb").read().split(c["eol"])
+            recs = []
+            for i in range(0, min(len(a), len(b)) - 3, 4):
+                recs += a[i:i + 4] + b[i:i + 4]
+            open(os.path.join(tmp, "in1.fq"), "wb").write(c["eol"].join(recs) + c["eol"])
+            os.remove(os.path.join(tmp, "in2.fq"))
         in1 = in2 = None
         if c["gz_in"]:
             in1, in2 = rb._compress_inputs(tmp, c["paired"], c["gz_in"])
-        want_files, want_rep = rb._run(rb.REF, tmp, "ref", c["flags"], c["paired"], {}, gz=c["gz"], in1=in1, in2=in2)
+        want_files, want_rep = rb._run(rb.REF, tmp, "ref", c["flags"], c["paired"], {}, gz=c["gz"], in1=in1, in2=in2, interleaved=c["interleaved"])
         env = {"FASTP_GPU": "1"}
         if sim:
             env.update(rb.SIM_ENV)
         if c["mode"] == "pack":
             env.update(rb.PACK_MODE)
-        got_files, got_rep = rb._run(binary, tmp, "gpu", c["flags"], c["paired"], env, threads=c["threads"], gz=c["gz"], in1=in1, in2=in2)
+        got_files, got_rep = rb._run(binary, tmp, "gpu", c["flags"], c["paired"], env, threads=c["threads"], gz=c["gz"], in1=in1, in2=in2, interleaved=c["interleaved"])
         want_rep.pop("__stderr__")
         got_rep.pop("__stderr__")
         problems = []
@@ -188,7 +199,7 @@ def main():
             problems, c = [f"run failed: {str(e)[-400:]}"], random_command(seed)
         if problems:
             failed += 1
-            print(f"seed {seed}: {' '.join(c['flags'])} [{c['mode']}, -w {c['threads']},  paired={c['paired']}, gz={c['gz']}, gz_in={c['gz_in']}]: " + "; ".join(problems[:4]), flush=True)
+            print(f"seed {seed}: {' '.join(c['flags'])} [{c['mode']}, -w {c['threads']},  paired={c['paired']}, gz={c['gz']}, gz_in={c['gz_in']}, interleaved={c['interleaved']}]: " + "; ".join(problems[:4]), flush=True)
         else:
             ok += 1
     print(f"seeds {first}..{last - 1}: {ok} command lines with every output file and the JSON report equal to the reference's, {failed} FAILED, {time.time() - t0:.0f}s")
