@@ -106,6 +106,7 @@ extern "C" __global__ void __launch_bounds__(256) fq_dup_final_kernel(DupFinalAr
     dup_final_body(d, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_or_images_kernel(OrArgs o) { or_images_body(o); }
+extern "C" __global__ void __launch_bounds__(256) fq_phred64_kernel(Phred64Args a) { phred64_body(a); }
 extern "C" __global__ void __launch_bounds__(256) fq_fmt_len_kernel(FmtArgs f) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     fmt_len_body(f, fq_lds);
@@ -1474,6 +1475,25 @@ extern "C" int fastp_gpu_prefix_or_images(fastp_gpu_ctx* ctx, void* images_devic
     o.chunks = (u64)bytes_each / 16;
     o.n_images = n_images;
     hipLaunchKernelGGL(fq_or_images_kernel, dim3(ctx->cus * 8), dim3(256), 0, ctx->stream, o);
+    HIP_TRY(ctx, hipGetLastError());
+    { int rs_ = sync_main(ctx); if (rs_) return rs_; }
+    return FASTP_GPU_OK;
+}
+
+extern "C" int fastp_gpu_phred64_to_33(fastp_gpu_ctx* ctx, int32_t n, uint8_t* text, const uint32_t* line_off, const uint32_t* line_len, uint8_t* qual_rows) {
+    if (!ctx || n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
+    if (n == 0) return FASTP_GPU_OK;
+    if (!text || !line_off || !line_len || !qual_rows) return fail(ctx, FASTP_GPU_E_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Phred64Args a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    a.qs = (int)fastp_gpu_qual_stride(ctx->dp.max_len);
+    a.text = text;
+    a.line_off = line_off;
+    a.line_len = line_len;
+    a.qual = qual_rows;
+    hipLaunchKernelGGL(fq_phred64_kernel, dim3(std::min((n + 3) / 4, ctx->cus * 32)), dim3(256), 0, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
     { int rs_ = sync_main(ctx); if (rs_) return rs_; }
     return FASTP_GPU_OK;

@@ -2582,6 +2582,32 @@ struct OrArgs {
     int n_images;
 };
 
+// Read::convertPhred64To33 (src/read.cpp, called from FastqReader::read when --phred64 is given): the quality characters of
+// the n parsed records become max(33, q - 31) - in the TEXT (what the formatter copies and the text kernel reads) and in
+// the packed rows (bit 7 of a row byte marks an N base and stays).  One wavefront per record.
+struct Phred64Args {
+    int n;
+    int qs;                 // bytes between two packed quality rows
+    u8* text;
+    const u32* line_off;    // [4 * n]
+    const u32* line_len;
+    u8* qual;
+};
+FQ_DEV void phred64_body(const Phred64Args& a) {
+    const int waves = block_threads() >> 6;
+    for (int r = block_id() * waves + wave_id(); r < a.n; r += grid_blocks() * waves) {
+        const u32 off = a.line_off[4 * (size_t)r + 3], len = a.line_len[4 * (size_t)r + 3];
+        u8* t = a.text + off;
+        u8* q = a.qual + (size_t)r * (size_t)a.qs;
+        for (u32 j = (u32)lane_id(); j < len; j += 64u) {
+            const u32 c = t[j];
+            const u32 v = c > 64u ? c - 31u : 33u;
+            t[j] = (u8)v;
+            q[j] = (u8)((q[j] & 0x80u) | v);
+        }
+    }
+}
+
 enum { DUP_IDX_BITS = 25 };  // pairs per launch < 2^25
 // bit position of unit g in buffer i: (base-value part + position part) mod mBufLenInBits
 FQ_DEV u64 dup_bit(const DupArgs& d, int g, int i) {

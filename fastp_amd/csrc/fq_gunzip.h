@@ -242,6 +242,7 @@ class Gunzip {
   public:
     int fd = -1;
     int64_t fpos = 0, fsize = 0;   // file bytes read so far / the file's size
+    bool seekable = true;          // false: a pipe (--stdin) - read() in sequence until it returns 0, fsize is not used
     bool at_eof = false;           // every member has been delivered and the file has ended
 
     Gunzip() : in_((size_t)IN_CAP + 64), win_((size_t)WIN + OUT_CAP + 512) {}
@@ -294,21 +295,25 @@ class Gunzip {
                 in_len_ -= ip_;
                 ip_ = 0;
             }
-            const int64_t ask = std::min<int64_t>((int64_t)IN_CAP - (int64_t)in_len_, fsize - fpos);
+            const int64_t room = (int64_t)IN_CAP - (int64_t)in_len_;
+            const int64_t ask = seekable ? std::min<int64_t>(room, fsize - fpos) : room;
             if (ask <= 0) {
                 file_done_ = true;
                 break;
             }
             int64_t got = 0;
             while (got < ask) {
-                const ssize_t r = pread(fd, in_.data() + in_len_ + got, (size_t)(ask - got), (off_t)(fpos + got));
+                const ssize_t r = seekable ? pread(fd, in_.data() + in_len_ + got, (size_t)(ask - got), (off_t)(fpos + got))
+                                           : ::read(fd, in_.data() + in_len_ + got, (size_t)(ask - got));
                 if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) return false;
+                if (r < 0 || (r == 0 && seekable)) return false;
+                if (r == 0) { file_done_ = true; break; }
                 got += r;
+                if (!seekable) break;   // a pipe hands over what it has: decode that first
             }
             fpos += got;
             in_len_ += (size_t)got;
-            if (fpos >= fsize) file_done_ = true;
+            if (seekable && fpos >= fsize) file_done_ = true;
         }
         if (file_done_) memset(in_.data() + in_len_, 0, 64);   // loads past the end read zeros; bit accounting catches an overrun
         return true;

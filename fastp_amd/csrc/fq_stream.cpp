@@ -62,6 +62,8 @@ int env_int(const char* name, int dflt) {
 // 0 plain text, 1 gzip, 2 BGZF (SRC_* below)
 int input_kind(const std::string& path) {
     if (path.size() < 3 || path.compare(path.size() - 3, 3, ".gz") != 0) return 0;
+    struct stat sb;
+    if (stat(path.c_str(), &sb) == 0 && !S_ISREG(sb.st_mode)) return 1;   // a pipe cannot be looked into twice: the host inflater takes any gzip stream
     unsigned char h[18];
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return 1;   // the run reports the open error
@@ -695,6 +697,7 @@ struct Run {
     fastp_gpu_stream* s;
     int fds[2] = {-1, -1};
     int64_t sizes[2] = {0, 0};
+    bool pipe[2] = {false, false};   // not a regular file (--stdin, a FIFO): read() in sequence, no size
     std::atomic<int> io_err{0}, emit_err{0};
     Channel<ReadReq> q_req;
     Channel<ReadDone> q_done;
@@ -715,16 +718,18 @@ struct GzSource {
     int64_t fpos = 0, fsize = 0;
     std::vector<uint8_t> in;
     size_t in_at = 0, in_len = 0;
+    bool seekable = true;
     std::unique_ptr<fqgz::Gunzip> fast;   // the inflater of fq_gunzip.h (default); FASTP_GPU_STREAM_GUNZIP=zlib: zlib's, for comparison
     ~GzSource() { if (open) inflateEnd(&z); }
     // up to `want` bytes of text to dst; < 0: damaged stream / read error
     int64_t fill(uint8_t* dst, int64_t want, int* err) {
         static const bool use_zlib = getenv("FASTP_GPU_STREAM_GUNZIP") && !strcmp(getenv("FASTP_GPU_STREAM_GUNZIP"), "zlib");
-        if (!use_zlib) {
+        if (!use_zlib || !seekable) {
             if (!fast) {
                 fast.reset(new fqgz::Gunzip());
                 fast->fd = fd;
                 fast->fsize = fsize;
+                fast->seekable = seekable;
             }
             const int64_t made = fast->read(dst, want, err);
             fpos = fast->fpos;
@@ -791,7 +796,7 @@ void reader_main(Run* R) {
     bool src_eof[2] = {false, false};
     std::vector<uint32_t> ix32[4];
     std::vector<uint64_t> ix64;
-    for (int m = 0; m < s->nf; m++) { gz[m].fd = R->fds[m]; gz[m].fsize = R->sizes[m]; }
+    for (int m = 0; m < s->nf; m++) { gz[m].fd = R->fds[m]; gz[m].fsize = R->sizes[m]; gz[m].seekable = !R->pipe[m]; }
     auto pread_pieces = [&](int fd, uint8_t* dst, int64_t off0, int64_t want) {
         for (int64_t a = 0; a < want; a += IO_PIECE) {
             const int64_t e = std::min(want, a + IO_PIECE);
@@ -817,7 +822,24 @@ void reader_main(Run* R) {
         int gz_err[2] = {0, 0};
         for (int m = 0; m < s->nf; m++) {
             uint8_t* dst = s->pin_in[rq.slot][m] + rq.carry[m];
-            if (s->src_kind[m] == SRC_PLAIN) {
+            if (s->src_kind[m] == SRC_PLAIN && R->pipe[m]) {
+                if (rq.budget[m] > 0 && !src_eof[m]) {   // what the pipe has, up to the trip's size; 0 bytes = its writer is done
+                    const int fd = R->fds[m];
+                    const int64_t want = rq.budget[m];
+                    int64_t* made = &gz_made[m];
+                    pool.submit([fd, dst, want, made] {
+                        int64_t got = 0;
+                        while (got < want) {
+                            const ssize_t r = read(fd, dst + got, (size_t)(want - got));
+                            if (r < 0 && errno == EINTR) continue;
+                            if (r < 0) { *made = -1; return; }
+                            if (r == 0) { *made = -2 - got; return; }   // end of the pipe after `got` bytes
+                            got += r;
+                        }
+                        *made = got;
+                    });
+                }
+            } else if (s->src_kind[m] == SRC_PLAIN) {
                 const int64_t want = std::max<int64_t>(0, std::min(rq.budget[m], R->sizes[m] - pos[m]));
                 pread_pieces(R->fds[m], dst, pos[m], want);
                 pos[m] += want;
@@ -842,6 +864,13 @@ void reader_main(Run* R) {
         }
         pool.wait();
         if (R->io_err.load()) d.err = 1;
+        for (int m = 0; m < s->nf && !d.err; m++)
+            if (s->src_kind[m] == SRC_PLAIN && R->pipe[m] && rq.budget[m] > 0 && !src_eof[m]) {
+                if (gz_made[m] == -1) { d.err = 1; break; }
+                if (gz_made[m] <= -2) { src_eof[m] = true; gz_made[m] = -2 - gz_made[m]; }
+                d.nb[m] = d.file_bytes[m] = gz_made[m];
+                pos[m] += gz_made[m];
+            }
         for (int m = 0; m < s->nf && !d.err; m++)
             if (s->src_kind[m] == SRC_GZIP && rq.budget[m] > 0 && !src_eof[m]) {
                 if (gz_made[m] < 0) { d.err = gz_err[m] ? gz_err[m] : 4; break; }
@@ -1159,6 +1188,13 @@ int run_loop(Run* R) {
             S_HIP(s, hipStreamSynchronize(s->sx));
             s->st.parse_s += now_s() - t0;
         }
+        if (n > 0 && s->cfg.phred64) {   // FastqReader::read's convertPhred64To33, before anything looks at a quality
+            t0 = now_s();
+            for (int m = 0; m < nm; m++)
+                if (fastp_gpu_phred64_to_33(s->ctx, n, s->d_text[slot][file_of(m)], s->d_loff[m], s->d_llen[m], s->d_qual[m]) != FASTP_GPU_OK)
+                    return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_phred64_to_33");
+            s->st.parse_s += now_s() - t0;
+        }
         if (n > 0) {
             // ---- the worker loop ----
             t0 = now_s();
@@ -1307,11 +1343,12 @@ extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
     for (int m = 0; m < s->nf; m++) {
         R.fds[m] = open(paths[m], O_RDONLY);
         struct stat sb;
-        if (R.fds[m] < 0 || fstat(R.fds[m], &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        if (R.fds[m] < 0 || fstat(R.fds[m], &sb) != 0 || S_ISDIR(sb.st_mode)) {
             for (int k = 0; k <= m; k++) if (R.fds[k] >= 0) close(R.fds[k]);
-            return s->fail(FASTP_GPU_E_INVALID, std::string("cannot open as a regular file: ") + paths[m]);
+            return s->fail(FASTP_GPU_E_INVALID, std::string("cannot open as a file or a pipe: ") + paths[m]);
         }
-        R.sizes[m] = (int64_t)sb.st_size;
+        R.pipe[m] = !S_ISREG(sb.st_mode);   // --stdin, a FIFO: read in sequence (a bgzip-written stream then goes through the host inflater)
+        R.sizes[m] = R.pipe[m] ? ((int64_t)1 << 62) : (int64_t)sb.st_size;
     }
     for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) R.out_pos[q] = s->cfg.out_offset[q];
     R.q_ofree.put(0);

@@ -380,6 +380,13 @@ int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbyte
                           uint32_t* line_off,  /* [4*max_records] offset of each record line in `text`      */
                           uint32_t* line_len,  /* [4*max_records] its length without the terminator        */
                           fastp_gpu_parse_info* info);
+/* --phred64 (Read::convertPhred64To33 src/read.cpp, applied by FastqReader::read src/fastqreader.cpp:309-368 to every read of
+ * such a run): the quality characters of the n records fastp_gpu_parse_fastq found become max(33, q - 31), in place, in
+ * `text` (what the formatter copies and the text kernel reads) and in the packed rows `qual_rows` (the N marks stay).
+ * line_off / line_len are the parser's tables.  DEVICE pointers; synchronous. */
+int fastp_gpu_phred64_to_33(fastp_gpu_ctx* ctx, int32_t n, uint8_t* text, const uint32_t* line_off, const uint32_t* line_len,
+                            uint8_t* qual_rows);
+
 /* The records of the LAST fastp_gpu_parse_fastq call on this context that hold a letter outside ACGTN
  * (info->n_exotic of them): ascending record indexes into units[0, capacity); returns their number.
  * They go into fastp_gpu_batch::exotic_unit (the union of both mates' lists for paired input), with

@@ -47,7 +47,8 @@ extern "C" {
 typedef int (*fastp_gpu_stream_emit_fn)(void* user, int stream, const char* data, int64_t len);
 
 typedef struct fastp_gpu_stream_config {
-    const char* in1;            /* FASTQ file (a regular file: it is read with pread).  A name that ends in ".gz" is a
+    const char* in1;            /* FASTQ file: a regular file (read with pread, several pieces at a time) or a pipe /
+                                 * FIFO / "/dev/stdin" (--stdin: read in sequence).  A name that ends in ".gz" is a
                                  * gzip stream, as for FastqReader::init (src/fastqreader.cpp:169-199): a bgzip-written
                                  * one (isBgzf, src/bgzf.h:17-27) goes to the device compressed and is inflated there
                                  * (fastp_gpu_bgzf_index + fastp_gpu_inflate_bgzf in place of BgzfMtReader), any other
@@ -68,6 +69,8 @@ typedef struct fastp_gpu_stream_config {
     int32_t interleaved;        /* --interleaved_in: a paired run whose mates alternate in in1 (in2 = NULL), as
                                  * FastqReaderPair::read takes them (src/fastqreader.cpp:470-478) in
                                  * PairEndProcessor::interleavedReaderTask (src/peprocessor.cpp:890-1013)          */
+    int32_t phred64;            /* --phred64: quality characters are converted as FastqReader::read does
+                                 * (fastp_gpu_phred64_to_33 after the parser)                                        */
 } fastp_gpu_stream_config;
 
 typedef struct fastp_gpu_stream_stats {

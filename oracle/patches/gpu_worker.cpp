@@ -230,8 +230,7 @@ void fill_params(Options* o, bool paired, int max_len, ParamBlock* s) {
 void make_state(Options* o, bool paired) {
     State* s = new State();
     s->paired = paired;
-    // pack mode is what is left for the option sets the stream binding below does not take (--overlapped_out, phred64,
-    // piped input); it is bound by the reference's reader thread, so the rows are sized generously rather
+    // pack mode is what is left for the option sets the stream binding below does not take (--overlapped_out); it is bound by the reference's reader thread, so the rows are sized generously rather
     // than by the first 1000 reads (Evaluator::computeSeqLen evaluator.cpp:54-76): a longer read later in the file is
     // what the reference takes in its stride (Stats::extendBuffer stats.cpp:65-83)
     s->max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);
@@ -813,15 +812,15 @@ bool plain_regular_file(const std::string& path) {
     if (path.empty()) return false;
     if (ends_with(path, ".gz"))
         if (const char* v = getenv("FASTP_GPU_STREAM_GZ")) if (atoi(v) == 0) return false;
-    struct stat sb;
-    return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode);
+    struct stat sb;   // (a pipe as well: --stdin = "/dev/stdin", a FIFO)
+    return stat(path.c_str(), &sb) == 0 && (S_ISREG(sb.st_mode) || S_ISFIFO(sb.st_mode));
 }
 
 // the option sets the stream loop takes; everything else goes through pack mode
 bool stream_mode(Options* o, bool paired) {
     if (!enabled()) return false;
     if (const char* v = getenv("FASTP_GPU_STREAM")) if (atoi(v) == 0) return false;
-    if (o->phred64 || !o->overlappedOut.empty()) return false;
+    if (!o->overlappedOut.empty()) return false;
     if (o->interleavedInput) {
         if (const char* v = getenv("FASTP_GPU_STREAM_INTERLEAVED")) if (atoi(v) == 0) return false;   // (pack mode for comparison)
     }
@@ -853,6 +852,7 @@ void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU
     cfg.in1 = o->in1.c_str();
     cfg.in2 = paired && !o->interleavedInput ? o->in2.c_str() : NULL;
     cfg.interleaved = paired && o->interleavedInput ? 1 : 0;
+    cfg.phred64 = o->phred64 ? 1 : 0;
     cfg.reads_to_process = o->readsToProcess;
     cfg.format.want_failed = S->B.ho.want_failed;
     cfg.format.want_unpaired1 = S->B.ho.want_unpaired1;

@@ -24,7 +24,7 @@ class StreamConfig(C.Structure):
     _fields_ = [("in1", C.c_char_p), ("in2", C.c_char_p), ("chunk_bytes", C.c_int64), ("io_threads", C.c_int32), ("device", C.c_int32),
                 ("reads_to_process", C.c_int64), ("format", FormatOptions), ("want", C.c_int32 * N_OUT), ("compress", C.c_int32 * N_OUT),
                 ("out_fd", C.c_int32 * N_OUT), ("out_offset", C.c_int64 * N_OUT), ("emit", EMIT_FN), ("user", C.c_void_p),
-                ("host", C.c_void_p), ("interleaved", C.c_int32)]
+                ("host", C.c_void_p), ("interleaved", C.c_int32), ("phred64", C.c_int32)]
 
 
 class StreamStats(C.Structure):
@@ -42,7 +42,7 @@ class StreamError(RuntimeError):
 
 
 def run_files(lib, params: abi.Params, in1: str, in2, outdir: str, want=("out1", "out2", "failed"), chunk_bytes=0, umi=None,
-              compress=(), emit=False, reads_to_process=0, device=0, interleaved=False):
+              compress=(), emit=False, reads_to_process=0, device=0, interleaved=False, phred64=False):
     """returns (outputs: dict name -> bytes, counters, layout, AdapterMaps, StreamStats)"""
     paired = bool(params.paired)
     lib.fastp_gpu_stream_last_error.restype = C.c_char_p
@@ -55,6 +55,7 @@ def run_files(lib, params: abi.Params, in1: str, in2, outdir: str, want=("out1",
     cfg.device = device
     cfg.reads_to_process = reads_to_process
     cfg.interleaved = int(interleaved)
+    cfg.phred64 = int(phred64)
     cfg.format.want_failed = int("failed" in want)
     cfg.format.want_unpaired1 = int("unpaired1" in want)
     cfg.format.want_unpaired2 = int("unpaired2" in want)

@@ -390,3 +390,74 @@ def test_sim_stream_interleaved_limits_odd_tail_and_replan(tmp_path):
     assert rp[4].replans >= 1 and rp[0] == two[0]
     with pytest.raises(streamlib.StreamError):
         streamlib.run_files(lib, params, il, p2, str(tmp_path), interleaved=True)     # interleaved input is ONE file
+
+
+def test_sim_stream_phred64_input(tmp_path):
+    """--phred64 through the C ABI: the run on phred+64 text with config.phred64 equals the run on the same reads written as
+    phred+33 (convertPhred64To33: max(33, q - 31), so qualities below '@' come out as '!'), two files and interleaved"""
+    import synth
+    lib = engine.load_library(engines.build_sim())
+    d = synth.synth_pairs(900, L=150, seed=96)
+    rng = np.random.default_rng(4)
+    q64 = {}
+    for m in ("1", "2"):
+        q = d["qual" + m]
+        body = q >= 33
+        hi = q.copy()
+        hi[body] = np.minimum(q[body] + 31, 126)
+        low = body & (rng.random(q.shape) < 0.01)
+        hi[low] = rng.integers(59, 64, size=int(low.sum())).astype(q.dtype)
+        q64[m] = hi
+        conv = hi.copy()
+        conv[body] = np.maximum(33, hi[body].astype(np.int32) - 31).astype(q.dtype)
+        d["qual" + m] = conv                       # what the reference's reader hands on
+    a1, a2 = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1), synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2)
+    b1, b2 = synth.to_fastq(d["seq1"], q64["1"], d["len1"], 1), synth.to_fastq(d["seq2"], q64["2"], d["len2"], 2)
+    params = golden_util.params_for("pe_cut_right", max_len=152)
+    params.dup_enabled = 0
+    p1, p2 = _files(tmp_path, a1, a2)
+    want = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000)
+    p1, p2 = _files(tmp_path, b1, b2)
+    got = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000, phred64=True)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[3].a1 == want[3].a1
+    il = os.path.join(str(tmp_path), "il64.fq")
+    open(il, "wb").write(_interleave(b1, b2))
+    got = streamlib.run_files(lib, params, il, None, str(tmp_path), chunk_bytes=60000, phred64=True, interleaved=True)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1])
+
+
+def test_sim_stream_reads_pipes(tmp_path):
+    """inputs that are not regular files (--stdin, FIFOs): read in sequence, plain and gzip (a bgzip-written stream through a pipe
+    takes the host inflater: a pipe cannot be looked into twice); same result as the files"""
+    import threading
+    lib = engine.load_library(engines.build_sim())
+    fq1, fq2 = _synthetic(900, seed=97)
+    params = golden_util.params_for("pe_cut_right", max_len=152)
+    params.dup_enabled = 0
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    want = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=60000)
+
+    def through_pipes(blob1, blob2, suffix):
+        f1, f2 = os.path.join(str(tmp_path), "pipe1.fq" + suffix), os.path.join(str(tmp_path), "pipe2.fq" + suffix)
+        for f in (f1, f2):
+            if os.path.exists(f):
+                os.remove(f)
+            os.mkfifo(f)
+
+        def feed(path, blob):
+            with open(path, "wb") as w:
+                for a in range(0, len(blob), 7001):      # in dribbles: short reads on the other side
+                    w.write(blob[a:a + 7001])
+        ts = [threading.Thread(target=feed, args=(f1, blob1)), threading.Thread(target=feed, args=(f2, blob2))]
+        for t in ts:
+            t.start()
+        try:
+            return streamlib.run_files(lib, params, f1, f2, str(tmp_path), chunk_bytes=60000)
+        finally:
+            for t in ts:
+                t.join()
+    got = through_pipes(fq1, fq2, "")
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[4].units == 900
+    import bgzf_util
+    got = through_pipes(gzip.compress(fq1, 4), bgzf_util.compress(fq2, block_bytes=9000), ".gz")
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and list(got[4].input_kind) == [1, 1]

@@ -71,3 +71,19 @@ def test_gpu_patched_reference_interleaved_input(name, kw, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
         pytest.skip("oracle/_ref binaries did not travel to this box")
     rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=45, interleaved=True, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", rb.PHRED64_CASES)
+def test_gpu_patched_reference_phred64_input(name, kw, tmp_path):
+    if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=46, mutate=rb._to_phred64, more_flags=("--phred64",), **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw", rb.STDIN_CASES)
+def test_gpu_patched_reference_stdin_input(name, kw, tmp_path):
+    if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=47, stdin_pipe=True, **kw)

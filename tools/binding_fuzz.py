@@ -143,7 +143,13 @@ def random_command(seed):
     interleaved = bool(paired and rng2.random() < 0.2)   # --interleaved_in: both mates in one file
     if interleaved and gz_in:
         gz_in = gz_in[:1]
-    return dict(paired=paired, flags=f, L=L, n=n, skw=skw, eol=eol, threads=threads, gz=gz, mode=mode, umi=umi, gz_in=gz_in, interleaved=interleaved)
+    if interleaved and "--detect_adapter_for_pe" in f:   # the reference itself cannot: its Evaluator opens <in2> ("Failed to open file: ")
+        f = [x for x in f if x != "--detect_adapter_for_pe"]
+    phred64 = bool(rng2.random() < 0.15)                 # --phred64: the input's qualities on the +64 scale
+    if phred64:
+        f = f + ["--phred64"]
+    return dict(paired=paired, flags=f, L=L, n=n, skw=skw, eol=eol, threads=threads, gz=gz, mode=mode, umi=umi, gz_in=gz_in, interleaved=interleaved,
+                phred64=phred64)
 
 
 def run(seed, binary, sim):
@@ -151,6 +157,8 @@ def run(seed, binary, sim):
     tmp = tempfile.mkdtemp(prefix="bfz")
     try:
         d = synth.synth_pairs(c["n"], L=c["L"], seed=seed, paired=c["paired"], **c["skw"])
+        if c["phred64"]:
+            rb._to_phred64(d)
         open(os.path.join(tmp, "in1.fq"), "wb").write(synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1).replace(b"\n", c["eol"]))
         if c["paired"]:
             open(os.path.join(tmp, "in2.fq"), "wb").write(synth.to_fastq(d["seq2"], d["qual2"], d["len2"], 2).replace(b"\n", c["eol"]))
@@ -199,7 +207,7 @@ def main():
             problems, c = [f"run failed: {str(e)[-400:]}"], random_command(seed)
         if problems:
             failed += 1
-            print(f"seed {seed}: {' '.join(c['flags'])} [{c['mode']}, -w {c['threads']},  paired={c['paired']}, gz={c['gz']}, gz_in={c['gz_in']}, interleaved={c['interleaved']}]: " + "; ".join(problems[:4]), flush=True)
+            print(f"seed {seed}: {' '.join(c['flags'])} [{c['mode']}, -w {c['threads']},  paired={c['paired']}, gz={c['gz']}, gz_in={c['gz_in']}, interleaved={c['interleaved']}, phred64={c['phred64']}]: " + "; ".join(problems[:4]), flush=True)
         else:
             ok += 1
     print(f"seeds {first}..{last - 1}: {ok} command lines with every output file and the JSON report equal to the reference's, {failed} FAILED, {time.time() - t0:.0f}s")
