@@ -236,6 +236,7 @@ struct fastp_gpu_ctx {
     u8* d_dupflag = nullptr; size_t dupflag_cap = 0;   // --dedup: per-unit duplicate decision
     u32* d_prefix = nullptr;                           // sharded runs: OR of the preceding shards' bitmaps
     bool has_prefix = false;
+    bool host_overlapped = false;   // fastp_gpu_host_writes_overlapped: the caller assembles --overlapped_out's stream from the records
     // overrepresentation analysis
     u32* d_ovr_table[2] = {nullptr, nullptr};
     u8* d_ovr_sym[2] = {nullptr, nullptr};
@@ -1480,6 +1481,12 @@ extern "C" int fastp_gpu_prefix_or_images(fastp_gpu_ctx* ctx, void* images_devic
     return FASTP_GPU_OK;
 }
 
+extern "C" int fastp_gpu_host_writes_overlapped(fastp_gpu_ctx* ctx, int on) {
+    if (!ctx) return FASTP_GPU_E_INVALID;
+    ctx->host_overlapped = on != 0;
+    return FASTP_GPU_OK;
+}
+
 extern "C" int fastp_gpu_phred64_to_33(fastp_gpu_ctx* ctx, int32_t n, uint8_t* text, const uint32_t* line_off, const uint32_t* line_len, uint8_t* qual_rows) {
     if (!ctx || n < 0) return fail(ctx, FASTP_GPU_E_INVALID, "bad argument");
     if (n == 0) return FASTP_GPU_OK;
@@ -1772,7 +1779,8 @@ extern "C" int fastp_gpu_format_streams(fastp_gpu_ctx* ctx, int32_t n, const fas
     const bool paired = ctx->dp.paired != 0;
     if (paired != (m2 != nullptr)) return fail(ctx, FASTP_GPU_E_INVALID, "mate 2 must be given exactly for a paired engine");
     if (paired && !pair) return fail(ctx, FASTP_GPU_E_INVALID, "a paired engine needs the pair records");
-    if (ctx->dp.overlapped_out) return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "--overlapped_out's stream is written by the host glue (fastp_gpu_host.h)");
+    if (ctx->dp.overlapped_out && !ctx->host_overlapped)
+        return fail(ctx, FASTP_GPU_E_UNSUPPORTED, "--overlapped_out's stream is written by the host (fastp_gpu_host.h, or fastp_gpu_host_writes_overlapped)");
     FmtsArgs f;
     memset(&f, 0, sizeof(f));
     f.n = n;

@@ -156,8 +156,10 @@ struct ReadDone {
 };
 enum { SRC_PLAIN = 0, SRC_GZIP = 1, SRC_BGZF = 2 };
 struct WriteJob {
-    int oslot = -1;                // -1: stop
+    int oslot = -1;                // -1: stop; 3: only the host-built stream below (a trip whose device streams are all unwanted)
     int64_t len[FASTP_GPU_N_OUTPUTS] = {0, 0, 0, 0, 0, 0};
+    bool has_ov = false;           // --overlapped_out's records of this chunk (may be empty: the writer takes one string per chunk)
+    std::string ov;
 };
 // the adapter strings of one chunk, in input order: entries [kind u8][len1 u16][len2 u16][bytes1][bytes2]
 struct ReplayJob {
@@ -384,7 +386,7 @@ int alloc_buffers(fastp_gpu_stream* s) {
         if (s->cfg.want[q])
             for (int sl = 0; sl < 2; sl++) S_HIP(s, hipHostMalloc((void**)&s->pin_out[sl][q], (size_t)host_bytes));
     }
-    if (s->cfg.host) {
+    if (s->cfg.host || s->cfg.want_overlapped) {
         for (int m = 0; m < nm; m++) {
             S_HIP(s, hipHostMalloc((void**)&s->h_res[m], (size_t)s->max_records * sizeof(fastp_gpu_read_result)));
             S_HIP(s, hipHostMalloc((void**)&s->h_loff[m], (size_t)s->max_records * 16));
@@ -456,6 +458,7 @@ int replan(fastp_gpu_stream* s, int needed) {
     s->p.max_len = target;
     rc = fastp_gpu_create(&s->p, s->cfg.device, &s->ctx);
     if (rc != FASTP_GPU_OK) { if (image) (void)hipFree(image); return s->fail(rc, std::string("fastp_gpu_create (re-plan): ") + fastp_gpu_last_error(nullptr)); }
+    if (s->cfg.want_overlapped) (void)fastp_gpu_host_writes_overlapped(s->ctx, 1);
     if (image) {
         rc = fastp_gpu_dup_bitmap_import(s->ctx, image);
         (void)hipFree(image);
@@ -509,8 +512,8 @@ struct Extractor {
         *la = std::min<size_t>(rr.adapter_len, (size_t)read_len - from);
     }
 
-    void run(int n, const uint8_t* const text[2], int32_t ncorr, int32_t nev, std::vector<uint8_t>& blob) {
-        const bool paired = s->paired;
+    // the chunk's sparse lists by read
+    void index(int32_t ncorr, int32_t nev) {
         corr.clear();
         events.clear();
         for (int32_t i = 0; i < ncorr; i++) corr[s->h_corr[i].read].push_back(&s->h_corr[i]);
@@ -518,6 +521,74 @@ struct Extractor {
         for (auto& kv : events)   // the device emits them unordered; per read they apply in adapter order
             std::sort(kv.second.begin(), kv.second.end(),
                       [](const fastp_gpu_adapter_event* x, const fastp_gpu_adapter_event* y) { return x->adapter < y->adapter; });
+    }
+
+    // --overlapped_out's stream (src/peprocessor.cpp:488-495): for a pair the third analysis finds overlapped, a record with
+    // read 1's name (after the UMI edit), strand line, and the bases / qualities of read 1 - as BaseCorrector left them - that
+    // the reference's string(substr(max(0, offset)), overlap_len) prints: std::string's (str, pos) constructor, i.e. what lies
+    // BEHIND the overlapped region.  The engine leaves first position | FASTP_GPU_OVOUT_HIT and count in the records.
+    void overlapped(int n, const uint8_t* const text[2], std::string& out) {
+        auto line_end = [](const char* p, const char* lim) { while (p < lim && *p != '\r' && *p != '\n') p++; return p; };
+        const fastp_gpu_format_options& fo = s->cfg.format;
+        for (int i = 0; i < n; i++) {
+            const fastp_gpu_read_result& r1 = s->h_res[0][i];
+            if (!(r1.reserved & FASTP_GPU_OVOUT_HIT)) continue;
+            const fastp_gpu_read_result& r2 = s->h_res[1][i];
+            const size_t pos = (size_t)(r1.reserved & 0x7FFF) + (size_t)r1.front, cnt = r2.reserved;
+            const uint32_t* lo = s->h_loff[0] + 4 * (size_t)i;
+            const char* t = (const char*)text[0];
+            const char* name = t + lo[0];
+            const char* name_end = line_end(name, t + lo[1]);
+            const char* strand = t + lo[2];
+            const char* strand_end = line_end(strand, t + lo[3]);
+            // the name after UmiProcessor::process (src/umiprocessor.cpp:19-81): the tag goes in front of the first space
+            if (fo.umi_loc != FASTP_GPU_UMI_NONE) {
+                const size_t ul = (size_t)std::max(0, fo.umi_len);
+                const char* s1 = t + lo[1];
+                const size_t l1 = (size_t)(line_end(s1, t + lo[2]) - s1);
+                const uint32_t* lo2 = s->h_loff[1] + 4 * (size_t)i;
+                const char* s2 = (const char*)text[1] + lo2[1];
+                const size_t l2 = (size_t)(line_end(s2, (const char*)text[1] + lo2[2]) - s2);
+                std::string umi;
+                if (fo.umi_loc == FASTP_GPU_UMI_READ1) umi.assign(s1, std::min(ul, l1));
+                else if (fo.umi_loc == FASTP_GPU_UMI_READ2) umi.assign(s2, std::min(ul, l2));
+                else { umi.assign(s1, std::min(ul, l1)); umi += "_"; umi.append(s2, std::min(ul, l2)); }
+                if (fo.umi_loc == FASTP_GPU_UMI_PER_READ || !umi.empty()) {
+                    const char* sp = name;
+                    while (sp < name_end && *sp != ' ') sp++;
+                    out.append(name, (size_t)(sp - name));
+                    out += s->umi_delim;
+                    if (!s->umi_prefix.empty()) { out += s->umi_prefix; out += '_'; }
+                    out += umi;
+                    out.append(sp, (size_t)(name_end - sp));
+                } else {
+                    out.append(name, (size_t)(name_end - name));
+                }
+            } else {
+                out.append(name, (size_t)(name_end - name));
+            }
+            out += '\n';
+            const size_t at_seq = out.size();
+            out.append(t + lo[1] + pos, cnt);
+            out += '\n';
+            out.append(strand, (size_t)(strand_end - strand));
+            out += '\n';
+            const size_t at_qual = out.size();
+            out.append(t + lo[3] + pos, cnt);
+            out += '\n';
+            auto it = corr.find(2u * (uint32_t)i);   // BaseCorrector's edits of read 1 (base and quality, basecorrector.cpp:39-57)
+            if (it != corr.end())
+                for (const fastp_gpu_correction* c : it->second)
+                    if (c->pos >= pos && c->pos < pos + cnt) {
+                        out[at_seq + (c->pos - pos)] = (char)c->base;
+                        out[at_qual + (c->pos - pos)] = (char)c->qual;
+                    }
+        }
+    }
+
+    void run(int n, const uint8_t* const text[2], std::vector<uint8_t>& blob) {
+        const bool paired = s->paired;
+        const int32_t nev = (int32_t)events.size();
         const uint8_t flagmask = FASTP_GPU_RF_ADAPTER | FASTP_GPU_RF_ADAPTER_OV;
         for (int i = 0; i < n; i++) {
             const fastp_gpu_read_result& r1 = s->h_res[0][i];
@@ -601,7 +672,11 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     if (s->interleaved && (!s->paired || cfg->in2)) { g_stream_error = "interleaved input is one file of a paired run"; return FASTP_GPU_E_INVALID; }
     s->nf = s->interleaved ? 1 : s->nm;
     if (!s->interleaved && s->paired != (cfg->in2 != nullptr)) { g_stream_error = "a paired engine needs two input files (or one interleaved file), a single-end engine one"; return FASTP_GPU_E_INVALID; }
-    if (params->overlapped_out) { g_stream_error = "--overlapped_out's stream is written by the host glue (fastp_gpu_host.h), not by the device formatter"; return FASTP_GPU_E_UNSUPPORTED; }
+    if (params->overlapped_out && !(cfg->want_overlapped && cfg->emit && s->paired)) {
+        g_stream_error = "--overlapped_out's stream is assembled on the host: config.want_overlapped and an emit callback are needed (paired input)";
+        return FASTP_GPU_E_UNSUPPORTED;
+    }
+    if (cfg->want_overlapped && !params->overlapped_out) { g_stream_error = "want_overlapped without params->overlapped_out"; return FASTP_GPU_E_INVALID; }
     s->in1 = cfg->in1;
     if (cfg->in2) s->in2 = cfg->in2;
     // own copies of every string the parameter block points at: a re-plan creates a context again
@@ -644,6 +719,7 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     int rc = fastp_gpu_create(&s->p, s->cfg.device, &s->ctx);
     if (rc != FASTP_GPU_OK) { g_stream_error = std::string("fastp_gpu_create: ") + fastp_gpu_last_error(nullptr); return rc; }
     s->st.max_len = s->p.max_len;
+    if (s->cfg.want_overlapped) (void)fastp_gpu_host_writes_overlapped(s->ctx, 1);
     rc = alloc_buffers(s.get());
     if (rc != FASTP_GPU_OK) {
         g_stream_error = s->err;
@@ -949,7 +1025,11 @@ void writer_main(Run* R) {
         WriteJob j = R->q_write.get();
         if (j.oslot < 0) return;
         const double t0 = now_s();
-        for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
+        if (j.has_ov && !R->emit_err.load()) {   // --overlapped_out's records of the chunk, assembled on the host
+            if (s->cfg.emit(s->cfg.user, FASTP_GPU_OVERLAPPED, j.ov.data(), (int64_t)j.ov.size()) != 0) R->emit_err.store(1);
+            s->st.bytes_overlapped += (int64_t)j.ov.size();
+        }
+        for (int q = 0; q < FASTP_GPU_N_OUTPUTS && j.oslot != 3; q++) {
             if (!s->cfg.want[q]) continue;
             const uint8_t* src = j.oslot >= 2 ? BGZF_EOF : s->pin_out[j.oslot][q];   // oslot 2: the end-of-file members of the compressed streams
             if (j.oslot >= 2 && !j.len[q]) continue;
@@ -1230,7 +1310,8 @@ int run_loop(Run* R) {
             t0 = now_s();
             S_HIP(s, hipMemcpyAsync(&s->h_counts[0], s->d_nc, 4, hipMemcpyDeviceToHost, s->sx));
             S_HIP(s, hipMemcpyAsync(&s->h_counts[1], s->d_nev, 4, hipMemcpyDeviceToHost, s->sx));
-            if (s->cfg.host)
+            const bool host_records = s->cfg.host || s->cfg.want_overlapped;
+            if (host_records)
                 for (int m = 0; m < nm; m++) {
                     S_HIP(s, hipMemcpyAsync(s->h_res[m], s->d_res[m], (size_t)n * sizeof(fastp_gpu_read_result), hipMemcpyDeviceToHost, s->sx));
                     S_HIP(s, hipMemcpyAsync(s->h_loff[m], s->d_loff[m], (size_t)n * 16, hipMemcpyDeviceToHost, s->sx));
@@ -1239,18 +1320,29 @@ int run_loop(Run* R) {
             const int32_t ncorr = s->corr_cap ? s->h_counts[0] : 0, nev = s->ev_cap ? s->h_counts[1] : 0;
             if (ncorr > s->corr_cap) return s->fail(FASTP_GPU_E_OVERFLOW, "correction list overflow: lower the chunk size");
             if (nev > s->ev_cap) return s->fail(FASTP_GPU_E_OVERFLOW, "adapter event list overflow: lower the chunk size");
-            if (s->cfg.host) {
+            WriteJob wj;
+            if (host_records) {
                 if (ncorr) S_HIP(s, hipMemcpyAsync(s->h_corr, s->d_corr, (size_t)ncorr * sizeof(fastp_gpu_correction), hipMemcpyDeviceToHost, s->sx));
                 if (nev) S_HIP(s, hipMemcpyAsync(s->h_ev, s->d_ev, (size_t)nev * sizeof(fastp_gpu_adapter_event), hipMemcpyDeviceToHost, s->sx));
                 if (ncorr || nev) S_HIP(s, hipStreamSynchronize(s->sx));
-                ReplayJob job;
                 const uint8_t* text[2] = {s->pin_in[slot][0], nm > 1 ? s->pin_in[slot][file_of(1)] : nullptr};
-                ex.run(n, text, ncorr, nev, job.blob);
-                if (!job.blob.empty()) R->q_replay.put(std::move(job));
+                ex.index(ncorr, nev);
+                if (s->cfg.host) {
+                    ReplayJob job;
+                    ex.run(n, text, job.blob);
+                    if (!job.blob.empty()) R->q_replay.put(std::move(job));
+                }
+                if (s->cfg.want_overlapped) {
+                    wj.has_ov = true;
+                    ex.overlapped(n, text, wj.ov);
+                }
             }
             s->st.d2h_s += now_s() - t0;
             // ---- records -> the text of every output stream (-> gzip members) ----
-            WriteJob wj;
+            if (!s->any_out && wj.has_ov) {
+                wj.oslot = 3;
+                R->q_write.put(std::move(wj));
+            }
             if (s->any_out) {
                 t0 = now_s();
                 fastp_gpu_format_io io[2];
@@ -1286,7 +1378,7 @@ int run_loop(Run* R) {
                 }
                 S_HIP(s, hipStreamSynchronize(s->sx));
                 s->st.d2h_s += now_s() - t0;
-                R->q_write.put(wj);
+                R->q_write.put(std::move(wj));
             }
             s->st.units += n;
             s->st.chunks++;

@@ -17,7 +17,7 @@ _LIBS: dict[str, C.CDLL] = {}
 EXPORTS = [
     "fastp_gpu_default_params", "fastp_gpu_seq_stride", "fastp_gpu_qual_stride", "fastp_gpu_cycles_for",
     "fastp_gpu_counter_layout_for", "fastp_gpu_counter_layout_for_params", "fastp_gpu_create", "fastp_gpu_destroy", "fastp_gpu_last_error",
-    "fastp_gpu_pack_reads", "fastp_gpu_pack_reads_x", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_parse_exotic", "fastp_gpu_phred64_to_33", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_deflate_bgzf", "fastp_gpu_device_alloc", "fastp_gpu_device_free", "fastp_gpu_device_upload", "fastp_gpu_device_download", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
+    "fastp_gpu_pack_reads", "fastp_gpu_pack_reads_x", "fastp_gpu_bgzf_index", "fastp_gpu_inflate_bgzf", "fastp_gpu_parse_fastq", "fastp_gpu_parse_exotic", "fastp_gpu_phred64_to_33", "fastp_gpu_host_writes_overlapped", "fastp_gpu_format_fastq", "fastp_gpu_format_streams", "fastp_gpu_deflate_bgzf", "fastp_gpu_device_alloc", "fastp_gpu_device_free", "fastp_gpu_device_upload", "fastp_gpu_device_download", "fastp_gpu_eval_seq_len", "fastp_gpu_eval_adapter_kmers", "fastp_gpu_eval_overrep", "fastp_gpu_submit_host", "fastp_gpu_submit_device", "fastp_gpu_synchronize",
     "fastp_gpu_counters_device", "fastp_gpu_counters", "fastp_gpu_kernel_time",
     "fastp_gpu_counters_export", "fastp_gpu_counters_import",
     "fastp_gpu_dup_scan_bytes", "fastp_gpu_submit_pass1_device", "fastp_gpu_dup_bitmap_bytes", "fastp_gpu_dup_bitmap_export",

@@ -380,6 +380,13 @@ int fastp_gpu_parse_fastq(fastp_gpu_ctx* ctx, const uint8_t* text, int64_t nbyte
                           uint32_t* line_off,  /* [4*max_records] offset of each record line in `text`      */
                           uint32_t* line_len,  /* [4*max_records] its length without the terminator        */
                           fastp_gpu_parse_info* info);
+/* --overlapped_out (src/peprocessor.cpp:488-495) makes a seventh stream that the device formatter does not write: by
+ * default fastp_gpu_format_streams refuses a context with that option (FASTP_GPU_E_UNSUPPORTED) so that nobody loses the
+ * stream unnoticed.  A caller that assembles it itself from the records (read 1's `reserved` = FASTP_GPU_OVOUT_HIT | first
+ * printed position, read 2's = the number of printed bases; what fastp_gpu_host.h and fastp_gpu_stream.h do) says so
+ * here; the other six streams are then formatted as usual (merged part lengths come from the pair records). */
+int fastp_gpu_host_writes_overlapped(fastp_gpu_ctx* ctx, int on);
+
 /* --phred64 (Read::convertPhred64To33 src/read.cpp, applied by FastqReader::read src/fastqreader.cpp:309-368 to every read of
  * such a run): the quality characters of the n records fastp_gpu_parse_fastq found become max(33, q - 31), in place, in
  * `text` (what the formatter copies and the text kernel reads) and in the packed rows `qual_rows` (the N marks stay).

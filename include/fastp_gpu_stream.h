@@ -71,6 +71,10 @@ typedef struct fastp_gpu_stream_config {
                                  * PairEndProcessor::interleavedReaderTask (src/peprocessor.cpp:890-1013)          */
     int32_t phred64;            /* --phred64: quality characters are converted as FastqReader::read does
                                  * (fastp_gpu_phred64_to_33 after the parser)                                        */
+    int32_t want_overlapped;    /* --overlapped_out (params->overlapped_out): its stream - the bases of read 1 the reference
+                                 * prints for an overlapped pair, src/peprocessor.cpp:488-495 - is assembled on the host from
+                                 * the records and the chunk's text and handed to emit() as stream FASTP_GPU_OVERLAPPED (one
+                                 * call per chunk, in order, also with len == 0); emit must be given                     */
 } fastp_gpu_stream_config;
 
 typedef struct fastp_gpu_stream_stats {
@@ -85,6 +89,7 @@ typedef struct fastp_gpu_stream_stats {
     double inflate_s;           /* BGZF inputs: the device inflate + the text's copy to the host                */
     int64_t bytes_file[2];      /* bytes read from each input file (bytes_in counts TEXT)                        */
     int32_t input_kind[2];      /* 0 plain text, 1 gzip inflated on the host, 2 BGZF inflated on the device      */
+    int64_t bytes_overlapped;   /* bytes handed to emit() for --overlapped_out's stream                          */
 } fastp_gpu_stream_stats;
 
 typedef struct fastp_gpu_stream fastp_gpu_stream;

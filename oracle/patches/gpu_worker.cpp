@@ -230,7 +230,7 @@ void fill_params(Options* o, bool paired, int max_len, ParamBlock* s) {
 void make_state(Options* o, bool paired) {
     State* s = new State();
     s->paired = paired;
-    // pack mode is what is left for the option sets the stream binding below does not take (--overlapped_out); it is bound by the reference's reader thread, so the rows are sized generously rather
+    // pack mode is what is left for the option sets the stream binding below does not take (none any more: FASTP_GPU_STREAM=0 and the FASTP_GPU_STREAM_* switches select it); it is bound by the reference's reader thread, so the rows are sized generously rather
     // than by the first 1000 reads (Evaluator::computeSeqLen evaluator.cpp:54-76): a longer read later in the file is
     // what the reference takes in its stride (Stats::extendBuffer stats.cpp:65-83)
     s->max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);
@@ -798,8 +798,8 @@ struct StreamState {
     ParamBlock B;
     fastp_gpu_stream* st = nullptr;
     fastp_gpu_host* host = nullptr;
-    WriterThread* writer[FASTP_GPU_N_OUTPUTS] = {};
-    long fed[FASTP_GPU_N_OUTPUTS] = {};     // strings handed to each writer so far (FASTP_GPU_WRITER=input)
+    WriterThread* writer[FASTP_GPU_N_HOST_OUTPUTS] = {};   // [FASTP_GPU_OVERLAPPED]: --overlapped_out's writer, always fed through input()
+    long fed[FASTP_GPU_N_HOST_OUTPUTS] = {};     // strings handed to each writer so far (FASTP_GPU_WRITER=input)
     int W = 1;
     bool paired = false, ran = false;
 };
@@ -820,7 +820,9 @@ bool plain_regular_file(const std::string& path) {
 bool stream_mode(Options* o, bool paired) {
     if (!enabled()) return false;
     if (const char* v = getenv("FASTP_GPU_STREAM")) if (atoi(v) == 0) return false;
-    if (!o->overlappedOut.empty()) return false;
+    if (!o->overlappedOut.empty()) {
+        if (const char* v = getenv("FASTP_GPU_STREAM_OVERLAPPED")) if (atoi(v) == 0) return false;   // (pack mode for comparison)
+    }
     if (o->interleavedInput) {
         if (const char* v = getenv("FASTP_GPU_STREAM_INTERLEAVED")) if (atoi(v) == 0) return false;   // (pack mode for comparison)
     }
@@ -838,7 +840,7 @@ int emit_to_writer(void* user, int stream, const char* data, int64_t len) {
     return 0;
 }
 
-void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU_N_OUTPUTS]) {
+void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU_N_OUTPUTS], WriterThread* overlapped_writer = NULL) {
     StreamState* S = new StreamState();
     S->paired = paired;
     S->W = std::max(1, o->thread);
@@ -873,6 +875,8 @@ void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU
         cfg.compress[q] = ends_with(w->getFilename(), ".gz") ? 1 : 0;
         cfg.out_fd[q] = w->mPwriteMode ? w->mFd : fileno(w->mWriter1->mFP);
     }
+    S->writer[FASTP_GPU_OVERLAPPED] = overlapped_writer;   // its records are assembled on the host by the stream (peprocessor.cpp:488-495)
+    cfg.want_overlapped = overlapped_writer && S->B.params.overlapped_out ? 1 : 0;
     cfg.emit = emit_to_writer;
     cfg.user = S;
     cfg.host = S->host;
@@ -954,7 +958,7 @@ int fastp_gpu_stream_reader_pe(PairEndProcessor* pp, bool isLeft) {
     if (!isLeft) return 1;   // the read-1 reader thread drives both files
     WriterThread* const writers[FASTP_GPU_N_OUTPUTS] = {pp->mLeftWriter, pp->mRightWriter, pp->mFailedWriter, pp->mMergedWriter,
                                                         pp->mUnpairedLeftWriter, pp->mUnpairedRightWriter};
-    stream_setup(pp->mOptions, true, writers);
+    stream_setup(pp->mOptions, true, writers, pp->mOverlappedWriter);
     stream_run();
     for (int t = 0; t < pp->mOptions->thread; t++) {   // what both reader threads do when their file is exhausted (peprocessor.cpp:866-872)
         pp->mLeftInputLists[t]->setProducerFinished();
@@ -969,7 +973,7 @@ int fastp_gpu_stream_reader_interleaved(PairEndProcessor* pp) {
     if (!stream_mode(pp->mOptions, true)) return -1;
     WriterThread* const writers[FASTP_GPU_N_OUTPUTS] = {pp->mLeftWriter, pp->mRightWriter, pp->mFailedWriter, pp->mMergedWriter,
                                                         pp->mUnpairedLeftWriter, pp->mUnpairedRightWriter};
-    stream_setup(pp->mOptions, true, writers);
+    stream_setup(pp->mOptions, true, writers, pp->mOverlappedWriter);
     stream_run();
     for (int t = 0; t < pp->mOptions->thread; t++) {   // the task's own tail (:1001-1012)
         pp->mLeftInputLists[t]->setProducerFinished();

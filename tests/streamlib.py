@@ -24,7 +24,7 @@ class StreamConfig(C.Structure):
     _fields_ = [("in1", C.c_char_p), ("in2", C.c_char_p), ("chunk_bytes", C.c_int64), ("io_threads", C.c_int32), ("device", C.c_int32),
                 ("reads_to_process", C.c_int64), ("format", FormatOptions), ("want", C.c_int32 * N_OUT), ("compress", C.c_int32 * N_OUT),
                 ("out_fd", C.c_int32 * N_OUT), ("out_offset", C.c_int64 * N_OUT), ("emit", EMIT_FN), ("user", C.c_void_p),
-                ("host", C.c_void_p), ("interleaved", C.c_int32), ("phred64", C.c_int32)]
+                ("host", C.c_void_p), ("interleaved", C.c_int32), ("phred64", C.c_int32), ("want_overlapped", C.c_int32)]
 
 
 class StreamStats(C.Structure):
@@ -32,7 +32,7 @@ class StreamStats(C.Structure):
                 ("bytes_in", C.c_int64 * 2), ("bytes_out", C.c_int64 * N_OUT)] + \
                [(k, C.c_double) for k in ("wall_s", "setup_s", "wait_read_s", "parse_s", "engine_s", "format_s", "deflate_s", "d2h_s",
                                           "wait_write_s", "write_s", "replay_s", "inflate_s")] + \
-               [("bytes_file", C.c_int64 * 2), ("input_kind", C.c_int32 * 2)]
+               [("bytes_file", C.c_int64 * 2), ("input_kind", C.c_int32 * 2), ("bytes_overlapped", C.c_int64)]
 
 
 class StreamError(RuntimeError):
@@ -63,7 +63,8 @@ def run_files(lib, params: abi.Params, in1: str, in2, outdir: str, want=("out1",
         cfg.format.umi_loc, cfg.format.umi_len = cpphost.UMI_LOC[umi.loc], umi.umi_len
         cfg.format.umi_prefix = umi.prefix or None
         cfg.format.umi_delimiter = umi.delimiter
-    fds, paths, collected = {}, {}, {q: bytearray() for q in range(N_OUT)}
+    cfg.want_overlapped = int(bool(params.overlapped_out) and "overlapped" in want)
+    fds, paths, collected = {}, {}, {q: bytearray() for q in range(N_OUT + 1)}
     for q, name in enumerate(STREAM_NAMES):
         cfg.out_fd[q] = -1
         if name not in want or (not paired and q in (1, 3, 4, 5)):
@@ -116,6 +117,9 @@ def run_files(lib, params: abi.Params, in1: str, in2, outdir: str, want=("out1",
     for q, name in enumerate(STREAM_NAMES):
         if cfg.want[q]:
             outs[name] = bytes(collected[q]) if emit else open(paths[q], "rb").read()
+    if cfg.want_overlapped:      # the host-assembled stream always arrives through the emit callback (stream 6)
+        outs["overlapped"] = bytes(collected[N_OUT])
+        assert st.bytes_overlapped == len(outs["overlapped"])
     return outs, ctr, lay, amaps, st
 
 
@@ -126,6 +130,8 @@ def as_outputs(outs: dict, paired: bool):
     o.failed = outs.get("failed")
     o.merged = outs.get("merged", b"")
     o.unpaired1, o.unpaired2 = outs.get("unpaired1"), outs.get("unpaired2")
+    if "overlapped" in outs:
+        o.overlapped = outs["overlapped"]
     return o
 
 

@@ -173,9 +173,9 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     got_files, got_rep = _run(binary, tmp, "gpu", flags, paired, env, threads=threads, gz=gz, in1=in1, in2=in2, interleaved=interleaved, stdin_pipe=stdin_pipe)
     err = got_rep.pop("__stderr__")
     want_rep.pop("__stderr__")
-    # which binding ran: the stream loop says so; --overlapped_out is pack mode's
+    # which binding ran: the stream loop says so
     streamed = "fastp_gpu: stream mode:" in err
-    assert streamed == (mode == "stream" and not _overlapped_out(name)), err[-800:]
+    assert streamed == (mode == "stream"), err[-800:]
     if "overrep" in name and "exotic" not in name:   # -p: the Evaluator's substring census ran on the device too (fastp_gpu_eval_overrep;
         # a sample with letters outside ACGTN is left to the reference's own Evaluator)
         assert err.count("computeOverRepSeq on the device") == (2 if paired else 1), err[-800:]
@@ -293,13 +293,13 @@ def test_patched_reference_on_emulator_equals_reference(name, tmp_path):
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
     err = _check(name, REF_SIM, 600, tmp_path, seed=41)
-    if not _overlapped_out(name):
-        import re
-        m = re.search(r"stream mode: 600 units in (\d+) chunks", err)
-        assert m and int(m.group(1)) >= 2, err[-600:]    # several trips, so partial records were carried
+    import re
+    m = re.search(r"stream mode: 600 units in (\d+) chunks", err)
+    assert m and int(m.group(1)) >= 2, err[-600:]    # several trips, so partial records were carried
 
 
-@pytest.mark.parametrize("name", ["pe_correction", "pe_adapter_fasta", "pe_merge", "se_umi_read1", "pe_exotic_dedup_adapters", "se_exotic_adapter"])
+@pytest.mark.parametrize("name", ["pe_correction", "pe_adapter_fasta", "pe_merge", "se_umi_read1", "pe_exotic_dedup_adapters", "se_exotic_adapter",
+                                  "pe_overlapped_out_trims"])
 def test_patched_reference_pack_mode_on_emulator(name, tmp_path):
     """pack mode: the reference's own reader threads, the hook at the top of the worker-loop body"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
