@@ -13,7 +13,8 @@ import golden_util
 import streamlib
 from fastp_amd import abi, engine
 
-STREAM_GOLDENS = [n for n in golden_util.names() if n != "pe_exotic_default"]
+STREAM_GOLDENS = [n for n in golden_util.names() if "overlapped_out" not in n and n != "pe_exotic_default"]
+OVERLAPPED_GOLDENS = [n for n in golden_util.names() if "overlapped_out" in n]   # (their -m gpu runs: tests/test_zz_gpu_compressed_inputs.py)
 SIM_CASES = ["pe_overlapped_out_trims", "pe_merge_overlapped_out_trims", "pe_correction", "pe_merge_unmerged", "pe_filters", "pe_adapter_fasta", "pe_umi_per_read", "pe_overrep", "pe_noadapter_dedup",
              "se_adapter_cut", "se_adapter_fasta", "testdata_pe", "pe_exotic_merge", "pe_exotic_dedup_adapters", "se_exotic_adapter", "pe_exotic_overrep_merge"]
 

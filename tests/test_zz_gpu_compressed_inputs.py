@@ -11,7 +11,7 @@ import pytest
 import streamlib
 import test_ref_binding as rb
 from fastp_amd import abi, engine
-from test_stream_abi import GZ_CASES, IL_CASES, _files, _golden_gz, _golden_interleaved, _run_plain_and
+from test_stream_abi import GZ_CASES, IL_CASES, OVERLAPPED_GOLDENS, _files, _golden, _golden_gz, _golden_interleaved, _run_plain_and
 
 
 @pytest.mark.gpu
@@ -87,3 +87,19 @@ def test_gpu_patched_reference_stdin_input(name, kw, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
         pytest.skip("oracle/_ref binaries did not travel to this box")
     rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=47, stdin_pipe=True, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", OVERLAPPED_GOLDENS)
+def test_gpu_stream_overlapped_out_equals_reference_golden(name, tmp_path):
+    """--overlapped_out in stream mode: six streams from the device formatter, the seventh assembled on the host of the loop"""
+    lib = engine.load_library()
+    _golden(lib, name, tmp_path, chunk_bytes=1 << 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in rb.BINDING_CASES if rb._overlapped_out(n)])
+def test_gpu_patched_reference_overlapped_out_stream_mode(name, tmp_path):
+    if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
+        pytest.skip("oracle/_ref binaries did not travel to this box")
+    rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=48, threads=3)
