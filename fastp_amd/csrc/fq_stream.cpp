@@ -575,6 +575,8 @@ struct Extractor {
             out += '\n';
             const size_t at_qual = out.size();
             out.append(t + lo[3] + pos, cnt);
+            if (s->cfg.phred64)   // the host's text is the file's: convertPhred64To33 as the device did for everything else
+                for (size_t k = at_qual; k < out.size(); k++) out[k] = (char)std::max(33, (int)(unsigned char)out[k] - 31);
             out += '\n';
             auto it = corr.find(2u * (uint32_t)i);   // BaseCorrector's edits of read 1 (base and quality, basecorrector.cpp:39-57)
             if (it != corr.end())

@@ -398,7 +398,7 @@ def test_sim_stream_phred64_input(tmp_path):
     phred+33 (convertPhred64To33: max(33, q - 31), so qualities below '@' come out as '!'), two files and interleaved"""
     import synth
     lib = engine.load_library(engines.build_sim())
-    d = synth.synth_pairs(900, L=150, seed=96)
+    d = synth.synth_pairs(900, L=150, seed=96, insert_mean=120.0, insert_sd=30.0)   # inserts shorter than the reads: read-through
     rng = np.random.default_rng(4)
     q64 = {}
     for m in ("1", "2"):
@@ -425,6 +425,18 @@ def test_sim_stream_phred64_input(tmp_path):
     open(il, "wb").write(_interleave(b1, b2))
     got = streamlib.run_files(lib, params, il, None, str(tmp_path), chunk_bytes=60000, phred64=True, interleaved=True)
     assert got[0] == want[0] and np.array_equal(got[1], want[1])
+    # --overlapped_out's stream is assembled on the host, from the file's text: its qualities are converted there as well
+    # (binding fuzz seed 3821)
+    ov = golden_util.params_for("pe_overlapped_out_noadapter", max_len=152)   # (no adapter trimming: read 1 reaches past the overlap)
+    ov.dup_enabled = 0
+    ov.correction = 1
+    streams = ("out1", "out2", "failed", "overlapped")
+    p1, p2 = _files(tmp_path, a1, a2)
+    want = streamlib.run_files(lib, ov, p1, p2, str(tmp_path), chunk_bytes=60000, want=streams)
+    p1, p2 = _files(tmp_path, b1, b2)
+    got = streamlib.run_files(lib, ov, p1, p2, str(tmp_path), chunk_bytes=60000, want=streams, phred64=True)
+    body = [ln for ln in want[0]["overlapped"].split(b"\n")[3::4] if ln]
+    assert len(body) > 100 and got[0] == want[0] and np.array_equal(got[1], want[1])
 
 
 def test_sim_stream_reads_pipes(tmp_path):
