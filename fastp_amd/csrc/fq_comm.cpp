@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -77,8 +78,10 @@ struct Comm {
     void* images = nullptr;   // exchange buffers of the duplicate prefix step (allocated on first use)
     void* slices = nullptr;
     int64_t image_bytes = 0;
+    int users = 0;            // collectives holding a pointer to this entry outside g_mu (Pin); drop_comm waits for 0
 };
 std::map<fastp_gpu_ctx*, Comm> g_comms;
+std::condition_variable g_idle;   // signalled when a Comm's `users` falls to 0
 
 int fail(int code, const std::string& msg) {
     t_err = msg;
@@ -105,9 +108,12 @@ struct Group {
 };
 
 void drop_comm(fastp_gpu_ctx* ctx) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     auto it = g_comms.find(ctx);
     if (it == g_comms.end()) return;
+    // a collective of another thread may be using this entry outside the lock: the entry (and its RCCL communicator,
+    // stream and exchange buffers) goes only when that call has returned (std::map nodes do not move meanwhile)
+    g_idle.wait(lk, [&] { return it->second.users == 0; });
     Comm& c = it->second;
     (void)hipSetDevice(c.device);
     if (c.comm && g_rccl.handle) (void)g_rccl.CommDestroy(c.comm);
@@ -121,6 +127,32 @@ Comm* find_comm(fastp_gpu_ctx* ctx) {
     auto it = g_comms.find(ctx);
     return it == g_comms.end() ? nullptr : &it->second;
 }
+
+// The communicators of one collective call, looked up and pinned under g_mu, released (and drop_comm woken) when the
+// call returns on whatever path.
+struct Pin {
+    std::vector<Comm*> cs;
+    bool take(fastp_gpu_ctx* const* ctxs, int n) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (int i = 0; i < n; i++) {
+            Comm* c = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
+            if (!c) { release_locked(); return false; }
+            c->users++;
+            cs.push_back(c);
+        }
+        return true;
+    }
+    void release_locked() {
+        for (Comm* c : cs) c->users--;
+        cs.clear();
+        g_idle.notify_all();
+    }
+    ~Pin() {
+        if (cs.empty()) return;
+        std::lock_guard<std::mutex> lk(g_mu);
+        release_locked();
+    }
+};
 
 }  // namespace
 
@@ -199,15 +231,11 @@ int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n) {
     if (!ctxs || n < 1) return fail(FASTP_GPU_E_INVALID, "bad argument");
     // g_mu guards the context -> communicator map only: the collectives below block on the other ranks, and a process
     // that drives its ranks from separate threads (each calling with n = 1) must not serialise them behind one mutex.
-    // A context's communicator is used by one call at a time (the caller's contract, as for every fastp_gpu_* call).
-    std::vector<Comm*> cs(n);
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        for (int i = 0; i < n; i++) {
-            cs[i] = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
-            if (!cs[i]) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
-        }
-    }
+    // A context's communicator is used by one collective at a time (the caller's contract, as for every fastp_gpu_* call);
+    // destroying it from another thread meanwhile is safe: the entries are pinned for the length of the call.
+    Pin pin;   // a concurrent fastp_gpu_comm_destroy / fastp_gpu_destroy of one of the contexts waits for this call
+    if (!pin.take(ctxs, n)) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
+    const std::vector<Comm*>& cs = pin.cs;
     std::vector<int64_t*> ptr(n);
     std::vector<int64_t> cnt(n);
     for (int i = 0; i < n; i++) {
@@ -245,14 +273,9 @@ int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n) {
 // the links per rank instead of the N-1 of an all-gather.
 int fastp_gpu_exchange_dup_prefix(fastp_gpu_ctx* const* ctxs, int n) {
     if (!ctxs || n < 1) return fail(FASTP_GPU_E_INVALID, "bad argument");
-    std::vector<Comm*> cs(n);
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        for (int i = 0; i < n; i++) {
-            cs[i] = ctxs[i] ? find_comm(ctxs[i]) : nullptr;
-            if (!cs[i]) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
-        }
-    }
+    Pin pin;   // a concurrent fastp_gpu_comm_destroy / fastp_gpu_destroy of one of the contexts waits for this call
+    if (!pin.take(ctxs, n)) return fail(FASTP_GPU_E_INVALID, "context has no communicator (fastp_gpu_comm_init*)");
+    const std::vector<Comm*>& cs = pin.cs;
     int64_t bytes = 0;
     for (int i = 0; i < n; i++) {
         const int64_t b = fastp_gpu_dup_bitmap_bytes(ctxs[i]);

@@ -43,7 +43,7 @@
 #include <vector>
 
 #include "../../include/fastp_gpu_stream.h"
-#include "fq_gunzip.h"
+#include "fq_pgunzip.h"
 
 namespace {
 
@@ -797,11 +797,33 @@ struct GzSource {
     std::vector<uint8_t> in;
     size_t in_at = 0, in_len = 0;
     bool seekable = true;
-    std::unique_ptr<fqgz::Gunzip> fast;   // the inflater of fq_gunzip.h (default); FASTP_GPU_STREAM_GUNZIP=zlib: zlib's, for comparison
+    std::unique_ptr<fqgz::Gunzip> fast;   // the inflater of fq_gunzip.h: pipes, and FASTP_GPU_STREAM_GUNZIP_THREADS=1; FASTP_GPU_STREAM_GUNZIP=zlib: zlib's, for comparison
+    std::unique_ptr<fqgz::ParallelGunzip> par;   // regular files (default): several threads on the one stream (fq_pgunzip.h)
     ~GzSource() { if (open) inflateEnd(&z); }
+    // threads per ".gz" file: a quarter of the host's, at most 12 (a paired run has two such files, and the loop its own pools)
+    static int gunzip_threads() {
+        static const int n = [] {
+            const int hw = (int)std::thread::hardware_concurrency();
+            return env_int("FASTP_GPU_STREAM_GUNZIP_THREADS", std::max(1, std::min(12, hw / 4)));
+        }();
+        return n;
+    }
     // up to `want` bytes of text to dst; < 0: damaged stream / read error
     int64_t fill(uint8_t* dst, int64_t want, int* err) {
         static const bool use_zlib = getenv("FASTP_GPU_STREAM_GUNZIP") && !strcmp(getenv("FASTP_GPU_STREAM_GUNZIP"), "zlib");
+        if (!use_zlib && seekable && gunzip_threads() > 1) {
+            if (!par) {
+                par.reset(new fqgz::ParallelGunzip());
+                par->fd = fd;
+                par->fsize = fsize;
+                par->threads = gunzip_threads();
+                par->chunk = (size_t)std::max(256, env_int("FASTP_GPU_STREAM_GUNZIP_CHUNK_KB", 2048)) << 10;
+            }
+            const int64_t made = par->read(dst, want, err);
+            fpos = par->fpos;
+            at_eof = par->at_eof;
+            return made;
+        }
         if (!use_zlib || !seekable) {
             if (!fast) {
                 fast.reset(new fqgz::Gunzip());
@@ -1394,8 +1416,16 @@ int run_loop(Run* R) {
 
 }  // namespace
 
+template <class G>
+static int gunzip_file_with(G* g, int fd, uint8_t* out, int64_t capacity, int64_t piece, int64_t* out_len);
+
 extern "C" int fastp_gpu_stream_gunzip_file(const char* path, uint8_t* out, int64_t capacity, int64_t piece, int64_t* out_len) {
-    if (!path || !out || !out_len || capacity < 0) return FASTP_GPU_E_INVALID;
+    return fastp_gpu_stream_gunzip_file_mt(path, out, capacity, piece, 1, 0, out_len);
+}
+
+extern "C" int fastp_gpu_stream_gunzip_file_mt(const char* path, uint8_t* out, int64_t capacity, int64_t piece, int threads, int64_t chunk_bytes,
+                                               int64_t* out_len) {
+    if (!path || !out || !out_len || capacity < 0 || threads < 1 || chunk_bytes < 0) return FASTP_GPU_E_INVALID;
     *out_len = 0;
     const int fd = open(path, O_RDONLY);
     struct stat sb;
@@ -1404,9 +1434,22 @@ extern "C" int fastp_gpu_stream_gunzip_file(const char* path, uint8_t* out, int6
         g_stream_error = std::string("cannot open ") + path;
         return FASTP_GPU_E_INVALID;
     }
+    if (threads > 1 || chunk_bytes > 0) {   // (one thread with a chunk size: fq_pgunzip.h's decoder on its own)
+        std::unique_ptr<fqgz::ParallelGunzip> g(new fqgz::ParallelGunzip());
+        g->fd = fd;
+        g->fsize = (int64_t)sb.st_size;
+        g->threads = threads;
+        if (chunk_bytes > 0) g->chunk = (size_t)chunk_bytes;
+        return gunzip_file_with(g.get(), fd, out, capacity, piece, out_len);
+    }
     std::unique_ptr<fqgz::Gunzip> g(new fqgz::Gunzip());
     g->fd = fd;
     g->fsize = (int64_t)sb.st_size;
+    return gunzip_file_with(g.get(), fd, out, capacity, piece, out_len);
+}
+
+template <class G>
+static int gunzip_file_with(G* g, int fd, uint8_t* out, int64_t capacity, int64_t piece, int64_t* out_len) {
     if (piece <= 0) piece = 1 << 20;
     int rc = FASTP_GPU_OK;
     for (;;) {

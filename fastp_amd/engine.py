@@ -31,7 +31,7 @@ EXPORTS = [
     "fastp_gpu_host_adapter_entries", "fastp_gpu_host_adapter_entry", "fastp_gpu_host_add_adapter", "fastp_gpu_host_add_adapter_pair",
     # include/fastp_gpu_stream.h
     "fastp_gpu_stream_create", "fastp_gpu_stream_run", "fastp_gpu_stream_layout", "fastp_gpu_stream_counters", "fastp_gpu_stream_get_stats",
-    "fastp_gpu_stream_last_error", "fastp_gpu_stream_destroy", "fastp_gpu_stream_gunzip_file",
+    "fastp_gpu_stream_last_error", "fastp_gpu_stream_destroy", "fastp_gpu_stream_gunzip_file", "fastp_gpu_stream_gunzip_file_mt",
 ]
 
 

@@ -658,9 +658,10 @@ int fastp_gpu_comm_init(fastp_gpu_ctx* ctx, const uint8_t id[FASTP_GPU_COMM_ID_B
 int fastp_gpu_comm_init_local(fastp_gpu_ctx* const* ctxs, int n);
 void fastp_gpu_comm_destroy(fastp_gpu_ctx* ctx);   /* also done by fastp_gpu_destroy */
 /* Stats::merge / FilterResult::merge: every rank's counter block <- the sum over all ranks */
-/* Contract of both collectives: the contexts passed in (and their communicators) must stay alive until the call returns -
- * fastp_gpu_destroy / fastp_gpu_comm_destroy of one of them from another thread while a collective is in flight is a
- * use-after-free (the registry lock is NOT held across the RCCL calls, so that two ranks living in one process can meet). */
+/* Contract of both collectives: a context's communicator carries ONE collective at a time.  The registry lock is not held
+ * across the RCCL calls (two ranks living in one process must be able to meet), the entries are pinned instead:
+ * fastp_gpu_comm_destroy / fastp_gpu_destroy of one of the contexts from another thread blocks until the collective in
+ * flight has returned (so it must not be called from the thread the other ranks are waiting for). */
 int fastp_gpu_allreduce(fastp_gpu_ctx* const* ctxs, int n);
 /* between pass 1 and pass 2 of a sharded run: rank r's prefix <- OR of the bitmaps of ranks 0..r-1
  * (slices all-to-all, fastp_gpu_prefix_or_images on the slice owner, all-to-all back, fastp_gpu_dup_prefix_set) */

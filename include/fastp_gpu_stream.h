@@ -114,6 +114,14 @@ void fastp_gpu_stream_destroy(fastp_gpu_stream* s);
  * ISIZE mismatch, no gzip header behind a member, end of file inside one), FASTP_GPU_E_OVERFLOW if capacity is too small.
  * Needs no device. */
 int fastp_gpu_stream_gunzip_file(const char* path, uint8_t* out, int64_t capacity, int64_t piece, int64_t* out_len);
+/* The same through the inflater the stream uses on regular files by default (fastp_amd/csrc/fq_pgunzip.h): `threads` host
+ * threads on the ONE gzip stream - block starts found by parsing candidate headers every `chunk_bytes` of compressed data
+ * (0 = 2 MiB), chunks decoded with their 32 KiB window unknown (16-bit symbols, markers), windows and markers resolved in
+ * order, a chunk whose predecessor did not end on its first bit thrown away; CRC-32 / ISIZE of every member checked from the
+ * chunks' partial CRCs.  Same results and errors as fastp_gpu_stream_gunzip_file at any `threads` / `chunk_bytes` (the tests
+ * use chunks of a few kilobytes so that small files cross many boundaries).  threads = 1, chunk_bytes = 0: fq_gunzip.h. */
+int fastp_gpu_stream_gunzip_file_mt(const char* path, uint8_t* out, int64_t capacity, int64_t piece, int threads, int64_t chunk_bytes,
+                                    int64_t* out_len);
 
 #ifdef __cplusplus
 }

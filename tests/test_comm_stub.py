@@ -107,6 +107,47 @@ def test_cabi_collectives_error_paths():
     os.environ.pop("FASTP_STUB_TIMEOUT_MS", None)
 
 
+def test_comm_destroy_waits_for_a_collective_in_flight():
+    """fastp_gpu_comm_destroy from another thread while fastp_gpu_allreduce is inside the (stand-in) RCCL call: the registry
+    entry is pinned for the length of the call, so the destroy returns only after the collective has (here: with the
+    stand-in's 'rank missing' error) - it used to erase the entry under the call."""
+    import threading
+    import time
+    from fastp_amd import abi
+    p = abi.default_params(True, 100)
+    p.dup_enabled = 0
+    engines.build_sim()
+    os.environ["FASTP_GPU_RCCL_LIB"] = STUB
+    os.environ["FASTP_STUB_TIMEOUT_MS"] = "1500"
+    e = engines.sim_engine(p)
+    e.comm_init(e.comm_id(), 2, 0)          # the other rank never shows up: the collective sits in the stand-in for 1.5 s
+    done = {}
+
+    def collective():
+        try:
+            e.allreduce()
+            done["rc"] = "ok"
+        except Exception as ex:             # noqa: BLE001
+            done["rc"] = str(ex)
+        done["t"] = time.time()
+
+    th = threading.Thread(target=collective)
+    t0 = time.time()
+    th.start()
+    time.sleep(0.4)                          # the collective is inside the library by now
+    e.lib.fastp_gpu_comm_destroy.argtypes = [C.c_void_p]
+    e.lib.fastp_gpu_comm_destroy.restype = None
+    e.lib.fastp_gpu_comm_destroy(e.h)
+    t_destroy = time.time()
+    th.join()
+    assert done["rc"] != "ok"
+    assert t_destroy >= done["t"] - 0.05 and t_destroy - t0 > 1.0, (t_destroy - t0, done["t"] - t0)
+    with pytest.raises(Exception):
+        e.allreduce()                        # the communicator is gone
+    e.close()
+    os.environ.pop("FASTP_STUB_TIMEOUT_MS", None)
+
+
 def test_run_shard_with_the_cabi_exchange_two_ranks_as_threads():
     """multigpu.run_shard(exchange="cabi") - what bench.py --gpus N does by default: pass 1, fastp_gpu_exchange_dup_prefix,
     pass 2 - with the two ranks as two threads of this process (one context each, the stand-in librccl makes them meet);

@@ -1,6 +1,6 @@
-"""fastp_amd/csrc/fq_gunzip.h - the host inflater the stream reads non-bgzip ".gz" inputs with (in place of ISA-L's igzip
-behind FastqReader::readToBufIgzip, src/fastqreader.cpp:88-149) - against zlib, through its C entry
-fastp_gpu_stream_gunzip_file: every block type, compression level and strategy, several members, random and degenerate
+"""fastp_amd/csrc/fq_gunzip.h and fq_pgunzip.h - the host inflaters the stream reads non-bgzip ".gz" inputs with (in place of
+ISA-L's igzip behind FastqReader::readToBufIgzip, src/fastqreader.cpp:88-149; one thread / several threads on one stream) -
+against zlib, through their C entries fastp_gpu_stream_gunzip_file / fastp_gpu_stream_gunzip_file_mt: every block type, compression level and strategy, several members, random and degenerate
 data, arbitrary hand-over points; damaged streams must be errors.  Host code: runs from the emulator build of the library
 in the CPU suite (no device needed either way)."""
 import ctypes as C
@@ -16,11 +16,22 @@ import synth
 from fastp_amd import abi, engine
 
 
-@pytest.fixture(scope="module")
-def lib():
+# (threads, chunk bytes): fq_gunzip.h alone; fq_pgunzip.h with chunks so small that every block of these files is a chunk of its
+# own (they grow until a block fits), with chunks of a few blocks, and with the stream's own geometry
+MODES = [(1, 0), (4, 1500), (4, 16000), (3, 40000), (1, 9000), (8, 2 << 20)]
+
+
+class _Lib:
+    def __init__(self, lib, threads, chunk):
+        self.lib, self.threads, self.chunk = lib, threads, chunk
+
+
+@pytest.fixture(scope="module", params=MODES, ids=lambda m: f"t{m[0]}_c{m[1]}")
+def lib(request):
     lib = engine.load_library(engines.build_sim())
     lib.fastp_gpu_stream_gunzip_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
-    return lib
+    lib.fastp_gpu_stream_gunzip_file_mt.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
+    return _Lib(lib, *request.param)
 
 
 def _gunzip(lib, tmp_path, blob: bytes, capacity: int, piece=0):
@@ -29,7 +40,10 @@ def _gunzip(lib, tmp_path, blob: bytes, capacity: int, piece=0):
         f.write(blob)
     out = np.zeros(max(capacity, 1), dtype=np.uint8)
     n = C.c_int64(0)
-    rc = lib.fastp_gpu_stream_gunzip_file(p.encode(), out.ctypes.data, capacity, piece, C.byref(n))
+    if lib.threads == 1 and lib.chunk == 0:
+        rc = lib.lib.fastp_gpu_stream_gunzip_file(p.encode(), out.ctypes.data, capacity, piece, C.byref(n))
+    else:
+        rc = lib.lib.fastp_gpu_stream_gunzip_file_mt(p.encode(), out.ctypes.data, capacity, piece, lib.threads, lib.chunk, C.byref(n))
     return rc, out[:n.value].tobytes()
 
 
@@ -193,3 +207,38 @@ def test_gunzip_random_streams_against_zlib(lib, tmp_path):
                        int(rng.integers(9, 16)), int(rng.integers(1, 10)))
         rc, got = _gunzip(lib, tmp_path, blob, len(data), int(rng.choice([0, 1000, 77777])))
         assert rc == 0 and got == data, k
+
+
+def test_gunzip_block_headers_inside_stored_data_are_no_chunk_starts(lib, tmp_path):
+    """a deflate stream stored inside another one (level 0: stored blocks): every block header of the inner stream parses as
+    one where it lies, and is no block start of the outer stream - fq_pgunzip.h's chunks that begin there are thrown away when
+    their predecessor does not end on their first bit; the text must not depend on it"""
+    fq = _fastq(6000, 31)
+    inner = _member(fq, 6, memlevel=2)                         # blocks of 256 symbols: thousands of headers
+    data = b"@" + inner + fq[:50000] + inner[::-1]
+    for outer_level, memlevel in ((0, 8), (1, 1), (6, 8)):
+        rc, got = _gunzip(lib, tmp_path, _member(data, outer_level, memlevel=memlevel), len(data))
+        assert rc == 0 and got == data, (outer_level, memlevel, rc, len(got))
+
+
+def test_gunzip_match_in_front_of_the_member_found_in_a_later_chunk(lib, tmp_path):
+    """the rule of test_gunzip_members_and_hand_over_points - no distance may reach in front of its member - where the offending
+    match lies blocks behind the member's start: with several threads it is decoded with the window unknown and caught when the
+    markers are resolved (the trailer would not tell: the bytes in front of the member are the dictionary's)"""
+    rng = np.random.default_rng(5)
+    dic = rng.integers(0, 256, size=30000, dtype=np.uint8).tobytes()
+    first = _member(dic, 6)                                      # incompressible: stored blocks; its text = the dictionary
+    for lead in (300, 4000, 20000):
+        head = rng.integers(65, 70, size=lead, dtype=np.uint8).tobytes()
+        tail = dic[20000:30000] + _fastq(300, 3)[:60000]            # matches into the dictionary (within 32 KiB), then text: a dynamic block
+        data = head + tail
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zdict=dic)
+        body = c.compress(head) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(tail) + c.flush()   # a block boundary in front of the matches
+        bad = b"\x1f\x8b\x08\x00\0\0\0\0\x00\x03" + body + (zlib.crc32(data) & 0xFFFFFFFF).to_bytes(4, "little") + len(data).to_bytes(4, "little")
+        with pytest.raises(zlib.error):
+            zlib.decompressobj(-15).decompress(body)                # "invalid distance too far back"
+        rc, _ = _gunzip(lib, tmp_path, first + bad, len(dic) + len(data) + 10)
+        assert rc == abi.E_INVALID, lead
+        # the same bytes as ONE member's continuation are fine: the control that the stream is otherwise sound
+        d2 = zlib.decompressobj(-15, zdict=dic)
+        assert d2.decompress(body) == data

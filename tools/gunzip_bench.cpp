@@ -1,6 +1,7 @@
-// tools/gunzip_bench.cpp - the stream's host inflater (fastp_amd/csrc/fq_gunzip.h) next to zlib's on one gzip file, both
-// taking the text 16 MiB at a time as the stream's trips do.  CRC-32 / ISIZE checked by both.
-//   g++ -O2 -std=c++17 tools/gunzip_bench.cpp -lz -o /tmp/gunzip_bench && /tmp/gunzip_bench reads.fq.gz
+// tools/gunzip_bench.cpp - the stream's host inflaters (fastp_amd/csrc/fq_gunzip.h: one thread; fq_pgunzip.h: several threads
+// on one stream) next to zlib's on one gzip file, all taking the text 16 MiB at a time as the stream's trips do.  CRC-32 /
+// ISIZE checked by all.
+//   g++ -O2 -std=c++17 -pthread tools/gunzip_bench.cpp -lz -o /tmp/gunzip_bench && /tmp/gunzip_bench reads.fq.gz [threads ...]
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,7 +12,7 @@
 #include <memory>
 #include <vector>
 
-#include "../fastp_amd/csrc/fq_gunzip.h"
+#include "../fastp_amd/csrc/fq_pgunzip.h"
 
 static double now() {
     timespec t;
@@ -26,6 +27,29 @@ int main(int argc, char** argv) {
     if (fd < 0 || fstat(fd, &sb)) return 1;
     std::vector<uint8_t> out(16 << 20);
     for (int rep = 0; rep < 3; rep++) {
+        for (int a = 2; a < argc; a++) {
+            std::unique_ptr<fqgz::ParallelGunzip> g(new fqgz::ParallelGunzip());
+            g->fd = fd;
+            g->fsize = sb.st_size;
+            g->threads = atoi(argv[a]);
+            if (getenv("PG_CHUNK")) g->chunk = (size_t)atol(getenv("PG_CHUNK"));
+            const double t0 = now();
+            int64_t total = 0;
+            uint64_t sum = 0;
+            for (;;) {
+                int err = 0;
+                const int64_t n = g->read(out.data(), (int64_t)out.size(), &err);
+                if (n < 0) { printf("fq_pgunzip: error %d (%lld batches, %lld chunks used, %lld dropped, %lld marker faults)\n", err, (long long)g->batches, (long long)g->chunks_used, (long long)g->chunks_dropped, (long long)g->marker_faults); return 1; }
+                total += n;
+                sum += out[0] + out[(size_t)(n > 0 ? n - 1 : 0)];
+                if (n < (int64_t)out.size()) break;
+            }
+            const double dt = now() - t0;
+            printf("fq_pgunzip.h x%-2d: %lld bytes of text in %.3f s = %7.1f MB/s  (check %llu; %lld batches, %lld chunks used, %lld dropped)\n", g->threads,
+                   (long long)total, dt, total / dt / 1e6, (unsigned long long)sum, (long long)g->batches, (long long)g->chunks_used, (long long)g->chunks_dropped);
+            printf("                  seconds in: read %.3f, find %.3f, decode %.3f, windows %.3f, resolve + CRC %.3f, trailers %.3f\n", g->t_phase[0], g->t_phase[1],
+                   g->t_phase[2], g->t_phase[3], g->t_phase[4], g->t_phase[5]);
+        }
         {
             std::unique_ptr<fqgz::Gunzip> g(new fqgz::Gunzip());
             g->fd = fd;
