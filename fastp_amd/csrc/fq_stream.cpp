@@ -802,22 +802,19 @@ struct GzSource {
     ~GzSource() { if (open) inflateEnd(&z); }
     // threads per ".gz" file: a quarter of the host's, at most 12 (a paired run has two such files, and the loop its own pools)
     static int gunzip_threads() {
-        static const int n = [] {
-            const int hw = (int)std::thread::hardware_concurrency();
-            return env_int("FASTP_GPU_STREAM_GUNZIP_THREADS", std::max(1, std::min(12, hw / 4)));
-        }();
-        return n;
+        const int hw = (int)std::thread::hardware_concurrency();
+        return env_int("FASTP_GPU_STREAM_GUNZIP_THREADS", std::max(1, std::min(12, hw / 4)));
     }
     // up to `want` bytes of text to dst; < 0: damaged stream / read error
     int64_t fill(uint8_t* dst, int64_t want, int* err) {
         static const bool use_zlib = getenv("FASTP_GPU_STREAM_GUNZIP") && !strcmp(getenv("FASTP_GPU_STREAM_GUNZIP"), "zlib");
-        if (!use_zlib && seekable && gunzip_threads() > 1) {
+        if (!use_zlib && seekable && !fast && (par || gunzip_threads() > 1)) {
             if (!par) {
                 par.reset(new fqgz::ParallelGunzip());
                 par->fd = fd;
                 par->fsize = fsize;
                 par->threads = gunzip_threads();
-                par->chunk = (size_t)std::max(256, env_int("FASTP_GPU_STREAM_GUNZIP_CHUNK_KB", 2048)) << 10;
+                par->chunk = (size_t)std::max(1, env_int("FASTP_GPU_STREAM_GUNZIP_CHUNK_KB", 2048)) << 10;   // (the tests: a few KiB, so that small files cross chunks)
             }
             const int64_t made = par->read(dst, want, err);
             fpos = par->fpos;

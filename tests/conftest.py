@@ -21,3 +21,11 @@ except ImportError:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# The stream inflates a non-bgzip ".gz" input with several host threads (fastp_amd/csrc/fq_pgunzip.h), by default in chunks of
+# 2 MiB of compressed data - more than any test file has.  The stream and binding tests run it with three threads and chunks
+# of a few KiB (they grow until a deflate block fits), so that their small inputs cross many chunk boundaries;
+# tests/test_gunzip.py covers the production geometry.  (Read when an input is opened; inherited by the patched reference.)
+os.environ.setdefault("FASTP_GPU_STREAM_GUNZIP_THREADS", "3")
+os.environ.setdefault("FASTP_GPU_STREAM_GUNZIP_CHUNK_KB", "6")

@@ -242,3 +242,22 @@ def test_gunzip_match_in_front_of_the_member_found_in_a_later_chunk(lib, tmp_pat
         # the same bytes as ONE member's continuation are fine: the control that the stream is otherwise sound
         d2 = zlib.decompressobj(-15, zdict=dic)
         assert d2.decompress(body) == data
+
+
+def test_pgunzip_stream_geometry_on_a_file_of_many_chunks(tmp_path):
+    """fq_pgunzip.h as the stream runs it (2 MiB chunks; and 1 MiB with another thread count) on ~50 MB of FASTQ text: a dozen
+    chunks in several batches, two members, every hand-over between chunks, batches and members at production sizes"""
+    lib = engine.load_library(engines.build_sim())
+    lib.fastp_gpu_stream_gunzip_file_mt.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int64)]
+    d = synth.synth_pairs(150000, L=150, seed=41, paired=False)
+    fq = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    cut = len(fq) * 2 // 3
+    blob = _member(fq[:cut], 1) + _member(fq[cut:], 6)
+    assert len(blob) > 5 * (2 << 20)
+    for threads, chunk in ((8, 2 << 20), (3, 1 << 20)):
+        rc, got = _gunzip(_Lib(lib, threads, chunk), tmp_path, blob, len(fq), 16 << 20)
+        assert rc == 0 and got == fq, (threads, chunk, rc, len(got))
+    # a bit flipped far into the file: found whichever chunk it lands in
+    pos = len(blob) * 3 // 5
+    rc, _ = _gunzip(_Lib(lib, 8, 2 << 20), tmp_path, blob[:pos] + bytes([blob[pos] ^ 0x10]) + blob[pos + 1:], len(fq), 16 << 20)
+    assert rc == abi.E_INVALID
