@@ -431,7 +431,7 @@ class ParallelGunzip {
     size_t chunk = 2 << 20;        // compressed bytes per thread and batch
     // statistics (tests, FASTP_GPU_VERBOSE)
     int64_t batches = 0, chunks_used = 0, chunks_dropped = 0, marker_faults = 0;
-    double t_phase[6] = {0, 0, 0, 0, 0, 0};   // seconds in: reading, finding, decoding, windows, resolving + CRC, trailers
+    double t_phase[6] = {0, 0, 0, 0, 0, 0};   // seconds in: -, -, reading + finding + decoding, windows, resolving + CRC, trailers
 
     ~ParallelGunzip() { if (worker_.joinable()) worker_.join(); }
 
@@ -553,53 +553,70 @@ class ParallelGunzip {
         std::atomic<int> io_err{0};
         double t0 = now(), t1;
         auto lap = [&](int k) { t1 = now(); t_phase[k] += t1 - t0; t0 = t1; };
-        // ---- 1: read the slices, find the block starts ----
-        fan_out(T, [&](int k) {
-            const int64_t a = std::min<int64_t>(have, (int64_t)k * (int64_t)chunk), e = std::min<int64_t>(have, a + (int64_t)chunk);
-            int64_t got = 0;
-            while (got < e - a) {
-                const ssize_t r = pread(fd, in + a + got, (size_t)(e - a - got), (off_t)(base + a + got));
-                if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) { io_err = 1; return; }
-                got += r;
-            }
-            Chunk& c = B.ck[(size_t)k];
-            const size_t want = (k ? ocap : ocap / 2) + 64;
-            if (c.sym_cap < want) { c.sym.reset(new uint16_t[want]); c.sym_cap = want; }
-            if (c.lt.empty()) { c.lt.resize(LTAB); c.dt.resize(DTAB); }
-        });
-        if (io_err) return 1;
-        lap(0);
+        // ---- 1 + 2: one thread per chunk: read the slice, find the block start, decode up to the next chunk that has a start ----
+        // (no barrier between the steps: a thread waits only for what it is about to touch - the slices behind its own before it
+        // parses anything, the neighbours' block starts when its own decode has reached their range)
         const uint64_t bit0 = bit_ - 8 * (uint64_t)base;     // positions below are relative to B.in
+        std::unique_ptr<std::atomic<int>[]> slice_read(new std::atomic<int>[(size_t)T + 1]), start_known(new std::atomic<int>[(size_t)T + 1]);
+        for (int k = 0; k <= T; k++) { slice_read[k] = k == T; start_known[k] = k == T; }
+        auto wait_for = [](std::atomic<int>& f) { while (!f.load(std::memory_order_acquire)) std::this_thread::yield(); };
         fan_out(T, [&](int k) {
             Chunk& c = B.ck[(size_t)k];
             c.start = ~0ull;
-            if (k == 0) { c.start = bit0; return; }
-            const uint64_t from = 8 * (uint64_t)k * chunk, to = std::min<uint64_t>(8 * (uint64_t)len, from + 8 * (uint64_t)chunk);
-            if (from < to) c.start = find_block(in, len, from, to, c.lt.data(), c.dt.data());
-        });
-        lap(1);
-        // ---- 2: decode, every chunk up to the next one that has a start ----
-        fan_out(T, [&](int k) {
-            Chunk& c = B.ck[(size_t)k];
-            if (c.start == ~0ull) return;
-            uint64_t stop = ~0ull;
-            for (int j = k + 1; j < T; j++)
-                if (B.ck[(size_t)j].start != ~0ull) { stop = B.ck[(size_t)j].start; break; }
+            c.rc = PG_STOP;
+            {
+                const int64_t a = std::min<int64_t>(have, (int64_t)k * (int64_t)chunk), e = std::min<int64_t>(have, a + (int64_t)chunk);
+                int64_t got = 0;
+                while (got < e - a) {
+                    const ssize_t r = pread(fd, in + a + got, (size_t)(e - a - got), (off_t)(base + a + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) { io_err = 1; break; }
+                    got += r;
+                }
+                slice_read[k].store(1, std::memory_order_release);
+            }
+            const size_t want = (k ? ocap : ocap / 2) + 64;
+            if (c.sym_cap < want) { c.sym.reset(new uint16_t[want]); c.sym_cap = want; }
+            if (c.lt.empty()) { c.lt.resize(LTAB); c.dt.resize(DTAB); }
+            for (int j = k + 1; j < T; j++) wait_for(slice_read[j]);   // a header parse or a block may run through any number of (small) slices
+            if (!io_err) {
+                if (k == 0) {
+                    c.start = bit0;
+                } else {
+                    const uint64_t from = 8 * (uint64_t)k * chunk, to = std::min<uint64_t>(8 * (uint64_t)len, from + 8 * (uint64_t)chunk);
+                    if (from < to) c.start = find_block(in, len, from, to, c.lt.data(), c.dt.data());
+                }
+            }
+            start_known[k].store(1, std::memory_order_release);
+            if (io_err || c.start == ~0ull) return;
             c.st = ChunkState();
             c.st.bit = c.start;
+            uint8_t* const o8 = (uint8_t*)c.sym.get();
+            uint16_t* const o16 = c.sym.get();
             if (k == 0) {
-                uint8_t* o = (uint8_t*)c.sym.get();
-                memcpy(o, window_, PG_WIN);
+                memcpy(o8, window_, PG_WIN);
                 c.st.at_header = at_header_;
                 c.st.mstart = PG_WIN - (size_t)std::min<uint64_t>(PG_WIN, since_member_);
-                c.rc = decode_blocks<uint8_t>(in, len, final_input, stop, o, ocap, c.st, c.lt.data(), c.dt.data());
             } else {
-                uint16_t* o = c.sym.get();
-                for (uint32_t i = 0; i < PG_WIN; i++) o[i] = (uint16_t)(0x8000u | i);
-                c.rc = decode_blocks<uint16_t>(in, len, final_input, stop, o, ocap, c.st, c.lt.data(), c.dt.data());
+                for (uint32_t i = 0; i < PG_WIN; i++) o16[i] = (uint16_t)(0x8000u | i);
             }
+            auto run = [&](uint64_t stop) {
+                return k == 0 ? decode_blocks<uint8_t>(in, len, final_input, stop, o8, ocap, c.st, c.lt.data(), c.dt.data())
+                              : decode_blocks<uint16_t>(in, len, final_input, stop, o16, ocap, c.st, c.lt.data(), c.dt.data());
+            };
+            // first to the first block boundary in the next chunk's range (its start cannot lie in front of that one) ...
+            c.rc = run(std::min<uint64_t>(8 * (uint64_t)(k + 1) * chunk, 8 * (uint64_t)len + 64));
+            if (c.rc != PG_STOP) return;
+            // ... then to the start of the next chunk that has one (none: as far as the input goes)
+            uint64_t stop = ~0ull;
+            for (int j = k + 1; j < T && stop == ~0ull; j++) {
+                wait_for(start_known[j]);
+                stop = B.ck[(size_t)j].start;
+            }
+            if (io_err) return;
+            c.rc = run(stop);
         });
+        if (io_err) return 1;
         lap(2);
         // ---- 3: the chain: which chunks count, and the window in front of each ----
         std::vector<int> used;

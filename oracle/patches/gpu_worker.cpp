@@ -909,7 +909,7 @@ void stream_run() {
         for (int m = 0; m < (S->paired ? 2 : 1); m++)
             if (st.input_kind[m])
                 fprintf(stderr, "fastp_gpu: stream mode: input %d is %s: %lld bytes of the file -> %lld bytes of text (inflate + its copy to the host %.3f s)\n", m + 1,
-                        st.input_kind[m] == 2 ? "BGZF, inflated on the device" : "gzip, inflated on a host thread of the stream (fq_gunzip.h)", (long long)st.bytes_file[m],
+                        st.input_kind[m] == 2 ? "BGZF, inflated on the device" : "gzip, inflated on host threads of the stream (fq_pgunzip.h; a pipe: one thread, fq_gunzip.h)", (long long)st.bytes_file[m],
                         (long long)st.bytes_in[m], st.inflate_s);
     S->ran = true;
 }
