@@ -18,7 +18,8 @@
 //   4. every thread replaces the markers of its chunk (narrow: in place, 16 symbols at a time where there is none) and takes the
 //      CRC-32 of its members' pieces; the pieces' CRCs are combined (crc32_combine: x^(8 n) mod P) and compared with the trailers
 //
-// The next batch is decoded while the caller takes the text of the current one.  Contract as fq_gunzip.h's: RFC 1951 / 1952,
+// Three batches are in flight: steps 1 - 3 of one (stage A), step 4 and the trailers of the one before it (stage B, a third of the
+// threads), the caller taking the text of the one before that.  Contract as fq_gunzip.h's: RFC 1951 / 1952,
 // members one behind the other, CRC-32 and ISIZE of every member checked, a damaged or cut-off stream is an error.
 // tests/test_gunzip.py runs both inflaters on the same streams, with chunk sizes from a few hundred bytes upwards so that small
 // files cross many chunk boundaries.
@@ -26,6 +27,9 @@
 #include <time.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <memory>
 #include <thread>
 
@@ -347,7 +351,18 @@ int decode_blocks(const uint8_t* in, size_t len, bool final_input, uint64_t stop
                         o += per8;
                     } while (o < stop);
                 } else {
-                    do { *o++ = *src++; } while (o < stop);
+                    // a period shorter than a word (runs of one quality character: distance 1): symbol by symbol until a
+                    // multiple of the period that fills a word has been written, then word-wise from that far back
+                    uint32_t d2 = dist;
+                    while (d2 < per8) d2 += dist;
+                    T* const lim = o + d2 < stop ? o + d2 : stop;
+                    do { *o++ = *src++; } while (o < lim);
+                    while (o < stop) {
+                        uint64_t x;
+                        memcpy(&x, o - d2, 8);
+                        memcpy(o, &x, 8);
+                        o += per8;
+                    }
                 }
                 o = stop;
             }
@@ -433,7 +448,14 @@ class ParallelGunzip {
     int64_t batches = 0, chunks_used = 0, chunks_dropped = 0, marker_faults = 0;
     double t_phase[6] = {0, 0, 0, 0, 0, 0};   // seconds in: -, -, reading + finding + decoding, windows, resolving + CRC, trailers
 
-    ~ParallelGunzip() { if (worker_.joinable()) worker_.join(); }
+    ~ParallelGunzip() {
+        stop_ = true;
+        free_.close();
+        to_b_.close();
+        to_c_.close();
+        if (thread_a_.joinable()) thread_a_.join();
+        if (thread_b_.joinable()) thread_b_.join();
+    }
 
     // up to `want` bytes of text to dst; fewer only at the end of the file; < 0: error (*err: 1 reading failed, 4 damaged stream)
     int64_t read(uint8_t* dst, int64_t want, int* err) {
@@ -452,12 +474,18 @@ class ParallelGunzip {
                 fpos = cur_->end_byte;
                 if (cur_->rc) { *err = cur_->rc; return -1; }
                 if (cur_->eof) { at_eof = true; break; }
+                free_.push(cur_idx_);
+                cur_ = nullptr;
             }
-            if (!started_) launch(0);
-            worker_.join();
-            cur_ = &slot_[next_slot_];
-            next_slot_ ^= 1;
-            if (!cur_->rc && !cur_->eof) launch(next_slot_);   // the batch behind it, while this one is copied out
+            if (!started_) {
+                started_ = true;
+                for (int i = 0; i < N_SLOTS; i++) free_.push(i);
+                thread_a_ = std::thread([this] { main_a(); });
+                thread_b_ = std::thread([this] { main_b(); });
+            }
+            cur_idx_ = to_c_.pop();
+            if (cur_idx_ < 0) { *err = 4; return -1; }   // (only after the destructor has closed the queues)
+            cur_ = &slot_[cur_idx_];
         }
         return made;
     }
@@ -481,32 +509,87 @@ class ParallelGunzip {
     struct Batch {
         std::vector<uint8_t> in;
         std::vector<Chunk> ck;
+        // stage A (read, find, decode, the chain) leaves:
+        std::vector<int> used;                       // the chunks that count, in order
+        std::vector<std::vector<uint8_t>> win;       // win[i] = the 32 KiB in front of used[i]
+        std::vector<uint64_t> since_at;              // text bytes of the open member in front of used[i]
+        int a_rc = 0;
+        bool a_eof = false;
+        // stage B (markers -> bytes, CRC-32, trailers) leaves:
         std::vector<Piece> pieces;
         size_t piece = 0;
         int rc = 0;
         bool eof = false;
         int64_t end_byte = 0;
     };
-    Batch slot_[2];
+    // a queue of slot numbers between the stages; pop() = -1 once it is closed and empty
+    struct Queue {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<int> q;
+        bool closed = false;
+        void push(int v) {
+            { std::lock_guard<std::mutex> lk(mu); q.push_back(v); }
+            cv.notify_one();
+        }
+        int pop() {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return closed || !q.empty(); });
+            if (q.empty()) return -1;
+            const int v = q.front();
+            q.pop_front();
+            return v;
+        }
+        void close() {
+            { std::lock_guard<std::mutex> lk(mu); closed = true; }
+            cv.notify_all();
+        }
+    };
+    // Three batches in flight: stage A of batch b+2 (its threads decode) beside stage B of batch b+1 (its threads resolve) beside the
+    // caller copying batch b out.  Stage A needs of its predecessor only what ITS stage A left (position, window, member length),
+    // stage B only what its predecessor's stage B left (the open member's CRC-32 and length).
+    enum { N_SLOTS = 3 };
+    Batch slot_[N_SLOTS];
     Batch* cur_ = nullptr;
-    int next_slot_ = 0;
+    int cur_idx_ = -1;
     bool started_ = false;
-    std::thread worker_;
+    std::atomic<bool> stop_{false};
+    std::thread thread_a_, thread_b_;
+    Queue free_, to_b_, to_c_;
     // where the stream stands behind the last batch that was produced
     uint64_t bit_ = 0;             // absolute bit position in the file
     bool at_header_ = true;
     uint8_t window_[PG_WIN] = {0};
     uint64_t since_member_ = 0;    // text bytes of the open member so far
-    uint32_t crc_ = 0;
+    // stage B's own
+    uint32_t crc_ = 0;             // of the open member's text so far
     uint64_t isize_ = 0;
     static const Crc32& crc_tab() {
         static const Crc32 c;
         return c;
     }
 
-    void launch(int slot) {
-        started_ = true;
-        worker_ = std::thread([this, slot] { produce(slot_[slot]); });
+    void main_a() {
+        for (;;) {
+            const int i = free_.pop();
+            if (i < 0 || stop_) return;
+            Batch& B = slot_[i];
+            stage_a(B);
+            const bool last = B.a_rc != 0 || B.a_eof;
+            to_b_.push(i);
+            if (last) return;
+        }
+    }
+    void main_b() {
+        for (;;) {
+            const int i = to_b_.pop();
+            if (i < 0 || stop_) return;
+            Batch& B = slot_[i];
+            stage_b(B);
+            const bool last = B.rc != 0 || B.eof;
+            to_c_.push(i);
+            if (last) return;
+        }
     }
 
     static double now() {
@@ -516,32 +599,34 @@ class ParallelGunzip {
     }
     template <class F>
     static void fan_out(int n, F f) {
+        if (n <= 0) return;
         std::vector<std::thread> th;
         for (int k = 1; k < n; k++) th.emplace_back([&f, k] { f(k); });
         f(0);
         for (auto& t : th) t.join();
     }
 
-    void produce(Batch& B) {
-        B.pieces.clear();
-        B.piece = 0;
-        B.rc = 0;
-        B.eof = false;
-        for (int attempt = 0;; attempt++) {
-            const int rc = produce_once(B);
-            if (rc != -2) { B.rc = rc; return; }
+    void stage_a(Batch& B) {
+        B.a_rc = 0;
+        B.a_eof = false;
+        for (;;) {
+            const int rc = stage_a_once(B);
+            if (rc != -2) { B.a_rc = rc; return; }
             // not one block of the first chunk fits: larger chunks (a block of gigabytes is no FASTQ file's)
-            if (chunk >= ((size_t)1 << 30)) { B.rc = 4; return; }
+            if (chunk >= ((size_t)1 << 30)) { B.a_rc = 4; B.used.clear(); return; }
             chunk *= 4;
         }
     }
 
     // 0 fine, 1 / 4 errors, -2: no progress with this chunk size
-    int produce_once(Batch& B) {
+    int stage_a_once(Batch& B) {
+        B.used.clear();
+        B.win.clear();
+        B.since_at.clear();
         const int T = std::max(1, threads);
         const int64_t base = (int64_t)(bit_ >> 3);          // file offset of B.in[0]
         const int64_t have = std::min<int64_t>(fsize - base, (int64_t)T * (int64_t)chunk);
-        if (have < 0) return 4;
+        if (have < 0) return 4;   // (B.used is empty: stage B hands out nothing)
         const size_t len = (size_t)have;
         const bool final_input = base + have >= fsize;
         B.in.resize(len + PG_PAD);
@@ -619,12 +704,13 @@ class ParallelGunzip {
         if (io_err) return 1;
         lap(2);
         // ---- 3: the chain: which chunks count, and the window in front of each ----
-        std::vector<int> used;
-        std::vector<std::vector<uint8_t>> win;               // win[i] = the 32 KiB in front of used[i]
+        std::vector<int>& used = B.used;
+        std::vector<std::vector<uint8_t>>& win = B.win;
         int result = 0;
         bool eof = false;
         {
             uint64_t expect = bit0;
+            const uint64_t since0 = since_member_;
             std::vector<uint8_t> w(window_, window_ + PG_WIN), lut(65536);
             for (int k = 0; k < T; k++) {
                 Chunk& c = B.ck[(size_t)k];
@@ -633,6 +719,8 @@ class ParallelGunzip {
                 used.push_back(k);
                 win.push_back(w);
                 const size_t n = c.st.op - PG_WIN;
+                B.since_at.push_back(since_member_);
+                since_member_ = c.st.ends.empty() ? since_member_ + n : (uint64_t)(c.st.op - c.st.ends.back().out_at);
                 // the window behind it = the last 32 KiB of (w ++ its text)
                 std::vector<uint8_t> nw(PG_WIN);
                 if (n >= PG_WIN) {
@@ -652,12 +740,32 @@ class ParallelGunzip {
             chunks_used += (int64_t)used.size();
             for (int k = 0; k < T; k++) chunks_dropped += B.ck[(size_t)k].start != ~0ull && std::find(used.begin(), used.end(), k) == used.end();
             const Chunk& l = B.ck[(size_t)used.back()];
-            if (!result && !eof && l.st.bit == bit0 && l.st.at_header == at_header_) return -2;   // (used is never empty: chunk 0 starts at bit0)
+            if (!result && !eof && l.st.bit == bit0 && l.st.at_header == at_header_) { since_member_ = since0; return -2; }   // (used is never empty: chunk 0 starts at bit0)
             memcpy(window_, w.data(), PG_WIN);
         }
         lap(3);
+        const Chunk& l = B.ck[(size_t)used.back()];
+        bit_ = l.st.bit + 8 * (uint64_t)base;
+        at_header_ = l.st.at_header;
+        B.end_byte = (int64_t)((bit_ + 7) >> 3);
+        B.a_eof = eof && !result;
+        batches++;
+        return result;
+    }
+
+    void stage_b(Batch& B) {
+        B.pieces.clear();
+        B.piece = 0;
+        std::vector<int>& used = B.used;
+        std::vector<std::vector<uint8_t>>& win = B.win;
+        int result = B.a_rc;
+        double t0 = now(), t1;
+        auto lap = [&](int k) { t1 = now(); t_phase[k] += t1 - t0; t0 = t1; };
         // ---- 4: markers -> bytes, CRC-32 of the members' pieces ----
-        fan_out((int)used.size(), [&](int i) {
+        // (a chunk's share of this stage is a fifth of its decode: a third of the threads keep up with stage A of the next batch)
+        const int nb = std::min<int>((int)used.size(), (std::max(1, threads) + 2) / 3);
+        fan_out(nb, [&](int j) {
+          for (int i = j; i < (int)used.size(); i += nb) {
             Chunk& c = B.ck[(size_t)used[(size_t)i]];
             uint8_t* text = (uint8_t*)c.sym.get() + (used[(size_t)i] == 0 ? PG_WIN : 0);
             const size_t n = c.st.op - PG_WIN;
@@ -670,6 +778,7 @@ class ParallelGunzip {
                 c.seg_crc.push_back(crc_tab().update(0, text + at, e - at));
                 at = e;
             }
+          }
         });
         lap(4);
         // ---- 5: trailers ----
@@ -679,32 +788,25 @@ class ParallelGunzip {
             const size_t n = c.st.op - PG_WIN;
             // a member is a stream of its own: text must not be fetched from in front of it.  Inside a chunk decode_blocks sees to
             // that (mstart); what a chunk took from the window in front of it is known only now
-            if (c.low_marker < PG_WIN - std::min<uint64_t>(PG_WIN, since_member_)) { marker_faults++; result = 4; break; }
+            if (c.low_marker < PG_WIN - std::min<uint64_t>(PG_WIN, B.since_at[i])) { marker_faults++; result = 4; break; }
             size_t at = 0;
             for (size_t m = 0; m <= c.st.ends.size(); m++) {
                 const size_t e = m < c.st.ends.size() ? c.st.ends[m].out_at - PG_WIN : n;
                 crc_ = crc_concat(crc_, c.seg_crc[m], e - at);
                 isize_ += e - at;
-                since_member_ += e - at;
                 at = e;
                 if (m < c.st.ends.size()) {
                     if (crc_ != c.st.ends[m].crc || (uint32_t)isize_ != c.st.ends[m].isize) { result = 4; break; }
                     crc_ = 0;
                     isize_ = 0;
-                    since_member_ = 0;
                 }
             }
             if (result == 4) break;   // the text in front of the damaged member has been handed out; this chunk's is not
             if (n) B.pieces.push_back(Piece{text, n, 0});
         }
-        const Chunk& l = B.ck[(size_t)used.back()];
-        bit_ = l.st.bit + 8 * (uint64_t)base;
-        at_header_ = l.st.at_header;
-        B.end_byte = (int64_t)((bit_ + 7) >> 3);
-        B.eof = eof && !result;
-        batches++;
+        B.rc = result;
+        B.eof = B.a_eof && !result;
         lap(5);
-        return result;
     }
 };
 
