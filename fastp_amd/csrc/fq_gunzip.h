@@ -4,8 +4,8 @@
 // Reference code this stands in for: FastqReader::readToBufIgzip (src/fastqreader.cpp:88-149) = ISA-L's igzip on the
 // reference's reader thread (isal_read_gzip_header / isal_inflate, CRC-32 and ISIZE of every member checked).  A general
 // gzip stream has no member boundaries that can be found without decoding it, so it cannot be cut up for the device the way
-// bgzip's members are (fastp_gpu_inflate_bgzf); it is inflated by one host thread per file, and that thread bounds a run on
-// such inputs - zlib's inflate does ~0.35 GB/s of FASTQ text on the build host, this one ~2 x that (tools/gunzip_bench.cpp),
+// bgzip's members are (fastp_gpu_inflate_bgzf); it is inflated on the host - by this class on one thread (pipes; the tables and
+// the CRC also serve fq_pgunzip.h, which puts several threads on one stream of a regular file) - zlib's inflate does ~0.35 GB/s of FASTQ text on the build host, this one ~2 x that (tools/gunzip_bench.cpp),
 // by the usual means: a 64-bit bit buffer refilled with one unaligned load, an 11-bit direct table whose entries carry the
 // literal / length base / extra-bit count, matches copied eight bytes at a time, CRC-32 by carry-less multiplication.
 //

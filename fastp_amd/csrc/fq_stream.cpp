@@ -9,8 +9,9 @@
 //                   (".gz" inputs, FastqReader::init src/fastqreader.cpp:169-199: a bgzip-written file - isBgzf,
 //                   src/bgzf.h:17-27 - is shipped COMPRESSED, cut at member boundaries by fastp_gpu_bgzf_index, and
 //                   inflated on the device by the caller thread, which stands in for BgzfMtReader src/bgzf.h:36-239;
-//                   any other gzip stream is inflated here (fq_gunzip.h), one pool thread per file, as
-//                   FastqReader::readToBufIgzip src/fastqreader.cpp:88-149 does with ISA-L on the reference's reader thread)
+//                   any other gzip stream is inflated here, by several threads per file (fq_pgunzip.h; a pipe: one thread,
+//                   fq_gunzip.h), where FastqReader::readToBufIgzip src/fastqreader.cpp:88-149 has ISA-L on the reference's
+//                   one reader thread)
 //   caller thread   parse -> worker loop -> format (-> deflate) on the context's stream, D2H of the output text
 //   writer thread   pwrite pieces of a chunk's output (or the emit callback), in chunk order
 //   replay thread   FilterResult::addAdapterTrimmed for the reads the records flag, in input order

@@ -52,7 +52,8 @@ typedef struct fastp_gpu_stream_config {
                                  * gzip stream, as for FastqReader::init (src/fastqreader.cpp:169-199): a bgzip-written
                                  * one (isBgzf, src/bgzf.h:17-27) goes to the device compressed and is inflated there
                                  * (fastp_gpu_bgzf_index + fastp_gpu_inflate_bgzf in place of BgzfMtReader), any other
-                                 * is inflated on one host thread per file (fq_gunzip.h; readToBufIgzip :88-149)      */
+                                 * is inflated on the host, several threads per file (fq_pgunzip.h; a pipe: one thread,
+                                 * fq_gunzip.h; readToBufIgzip :88-149 has ISA-L on the reference's reader thread)   */
     const char* in2;            /* second file of a paired run, NULL for single-end                        */
     int64_t chunk_bytes;        /* text per file and trip; 0 = 16 MiB (FASTP_GPU_STREAM_CHUNK_MB)          */
     int32_t io_threads;         /* positional reads / writes in flight; 0 = 8 (FASTP_GPU_STREAM_IO_THREADS) */
