@@ -224,6 +224,51 @@ def e2e_compressed_leg(sample_pairs, flags, dev):
             return hsh.hexdigest()
         t_a, _ = run(refgpu, f1, f2, "z", ".fq.gz", genv)
         kept = _json.load(open(J("z.json")))["summary"]["after_filtering"]["total_reads"]
+        # (d) the same inputs as ORDINARY gzip files (no bgzip fields: what sequencers and pigz deliver; eight members per file so
+        # that making them takes seconds): the stream inflates each with several host threads (fastp_amd/csrc/fq_pgunzip.h), the
+        # reference with its one reader thread per file.  Never at the expense of the legs above and below.
+        plain_gz = None
+        try:
+            t0 = time.time()
+            procs, parts = [], {f1: [], f2: []}
+            for f in (f1, f2):
+                size = os.path.getsize(f)
+                step = (size + 7) // 8
+                for i in range(8):
+                    part = J(os.path.basename(f) + f".part{i}.gz")
+                    parts[f].append(part)
+                    procs.append(subprocess.Popen(["bash", "-c", f"tail -c +{i * step + 1} '{f}' | head -c {step} | gzip -1 > '{part}'"]))
+            if any(p.wait() != 0 for p in procs):
+                raise RuntimeError("gzip failed")
+            for f, tag in ((f1, "p1.fq.gz"), (f2, "p2.fq.gz")):
+                with open(J(tag), "wb") as dst:
+                    for part in parts[f]:
+                        with open(part, "rb") as src:
+                            shutil.copyfileobj(src, dst, 1 << 24)
+                        os.remove(part)
+            t_gz = time.time() - t0
+            best_p, err_p = None, ""
+            for _ in range(2):
+                t_p, e = run(refgpu, J("p1.fq.gz"), J("p2.fq.gz"), "g", ".fq", genv)
+                if best_p is None or t_p < best_p:
+                    best_p, err_p = t_p, e
+            t_q, _ = run(ref, J("p1.fq.gz"), J("p2.fq.gz"), "h", ".fq", dict(os.environ))
+            mp = re.search(r"stream mode: \d+ units in (\d+) chunks, ([0-9.]+) s", err_p)
+            hw = os.cpu_count() or 1
+            plain_gz = {"gpu": round(kept / best_p / 1e6, 3), "cpu": round(kept / t_q / 1e6, 3), "unit": "Mreads/s",
+                        "outputs_identical": md5(J("g1.fq")) == md5(J("h1.fq")) and md5(J("g2.fq")) == md5(J("h2.fq")),
+                        "inflated_on_host_threads": "inflated on host threads" in err_p,
+                        "inflater_threads_per_file": int(os.environ.get("FASTP_GPU_STREAM_GUNZIP_THREADS", max(1, min(12, hw // 4)))),
+                        "compressed_bytes": os.path.getsize(J("p1.fq.gz")) + os.path.getsize(J("p2.fq.gz")),
+                        "wall_s": round(best_p, 3), "stream_s": float(mp.group(2)) if mp else None, "making_the_files_s": round(t_gz, 1),
+                        "what": f"the same {sample_pairs} pairs as two ordinary gzip files (gzip -1, eight members each): FASTP_GPU=1 fastp_ref_gpu "
+                                f"(fq_pgunzip.h: several host threads per stream) vs fastp_ref -w {cores} (one reader thread per file, zlib behind "
+                                f"the ISA-L shim), whole-process wall, best of 2"}
+            for n in ("p1.fq.gz", "p2.fq.gz", "g1.fq", "g2.fq", "h1.fq", "h2.fq"):
+                if os.path.exists(J(n)):
+                    os.remove(J(n))
+        except Exception as e:   # noqa: BLE001
+            plain_gz = {"gpu": None, "error": repr(e)[:300]}
         os.remove(f1)
         os.remove(f2)
         best, err = None, ""
@@ -240,7 +285,7 @@ def e2e_compressed_leg(sample_pairs, flags, dev):
                 "inflated_on_the_device": "BGZF, inflated on the device" in err,
                 "compressed_bytes": os.path.getsize(J("z1.fq.gz")) + os.path.getsize(J("z2.fq.gz")),
                 "wall_s": round(best, 3), "stream_s": float(m.group(2)) if m else None, "chunks": int(m.group(1)) if m else None,
-                "inflate_s": float(k.group(1)) if k else None,
+                "inflate_s": float(k.group(1)) if k else None, "plain_gzip_inputs": plain_gz,
                 "what": f"FASTP_GPU=1 fastp_ref_gpu -w {cores}: {sample_pairs} pairs written as .fq.gz (gzip members made on the device), then those "
                         f"files as the input of a second run (compressed to HBM, fastp_gpu_inflate_bgzf in place of BgzfMtReader) vs fastp_ref -w {cores} "
                         f"on the same .gz files (zlib behind the ISA-L shim), whole-process wall, best of 2"}
