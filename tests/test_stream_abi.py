@@ -255,6 +255,31 @@ def _run_plain_and(lib, tmp_path, fq1, fq2, packed1, packed2, chunk_bytes=70000,
     return params, a, b
 
 
+def _plain_gzip_geometries(lib, tmp_path, monkeypatch, n, chunk_bytes, geometries):
+    """both inputs ordinary gzip streams of two members (levels 1 and 6), inflated by the stream's host threads (fq_pgunzip.h) in each
+    of `geometries` = (threads, chunk KiB): every run == the run on the plain files, and the file was read to its end"""
+    fq1, fq2 = _synthetic(n, seed=97)
+    params = golden_util.params_for("pe_cut_right", max_len=152)
+    p1, p2 = _files(tmp_path, fq1, fq2)
+    a = streamlib.run_files(lib, params, p1, p2, str(tmp_path), chunk_bytes=chunk_bytes)
+    two = lambda t: gzip.compress(t[:len(t) // 3], 1) + gzip.compress(t[len(t) // 3:], 6)   # noqa: E731
+    g1, g2 = os.path.join(str(tmp_path), "pg1.fq.gz"), os.path.join(str(tmp_path), "pg2.fq.gz")
+    open(g1, "wb").write(two(fq1))
+    open(g2, "wb").write(two(fq2))
+    for threads, kb in geometries:
+        monkeypatch.setenv("FASTP_GPU_STREAM_GUNZIP_THREADS", str(threads))
+        monkeypatch.setenv("FASTP_GPU_STREAM_GUNZIP_CHUNK_KB", str(kb))
+        b = streamlib.run_files(lib, params, g1, g2, str(tmp_path), chunk_bytes=chunk_bytes)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[3].a1 == b[3].a1 and a[3].a2 == b[3].a2, (threads, kb)
+        assert b[4].input_kind[0] == 1 and b[4].input_kind[1] == 1
+        assert b[4].bytes_file[0] == os.path.getsize(g1) and b[4].bytes_in[0] == len(fq1) and b[4].bytes_in[1] == len(fq2), (threads, kb)
+
+
+def test_sim_stream_plain_gzip_inputs_inflater_geometries(tmp_path, monkeypatch):
+    lib = engine.load_library(engines.build_sim())
+    _plain_gzip_geometries(lib, tmp_path, monkeypatch, 700, 60000, [(1, 2048), (2, 1), (5, 3), (8, 2048)])
+
+
 def test_sim_stream_reads_its_own_compressed_output(tmp_path):
     """round trip: the ".gz" streams the device deflate writes are bgzip members - fed back as inputs they are inflated on the
     device and give the run its plain files give; bgzip-sized members (64 KiB of text) with the default trip size class"""

@@ -11,7 +11,7 @@ import pytest
 import streamlib
 import test_ref_binding as rb
 from fastp_amd import abi, engine
-from test_stream_abi import GZ_CASES, IL_CASES, OVERLAPPED_GOLDENS, _files, _golden, _golden_gz, _golden_interleaved, _run_plain_and
+from test_stream_abi import GZ_CASES, IL_CASES, OVERLAPPED_GOLDENS, _files, _golden, _golden_gz, _golden_interleaved, _plain_gzip_geometries, _run_plain_and
 
 
 @pytest.mark.gpu
@@ -46,6 +46,14 @@ def test_gpu_stream_large_bgzf_input_default_chunks(tmp_path):
     t1, t2 = gzip.decompress(z[0]["out1"]), gzip.decompress(z[0]["out2"])
     _, c, e = _run_plain_and(lib, tmp_path, t1, t2, z[0]["out1"], z[0]["out2"], chunk_bytes=0)
     assert c[0] == e[0] and np.array_equal(c[1], e[1]) and e[4].input_kind[0] == 2
+
+
+@pytest.mark.gpu
+def test_gpu_stream_plain_gzip_inputs_inflater_geometries(tmp_path, monkeypatch):
+    """120 000 pairs as two ordinary gzip files: the stream's several-threads host inflater in its production geometry (2 MiB
+    chunks: half a dozen per file), with more threads than chunks, with one thread (fq_gunzip.h) and with small chunks"""
+    lib = engine.load_library()
+    _plain_gzip_geometries(lib, tmp_path, monkeypatch, 120000, 0, [(8, 2048), (16, 2048), (1, 2048), (3, 64)])
 
 
 @pytest.mark.gpu
