@@ -574,7 +574,12 @@ class ParallelGunzip {
             const int i = free_.pop();
             if (i < 0 || stop_) return;
             Batch& B = slot_[i];
-            stage_a(B);
+            try {
+                stage_a(B);
+            } catch (...) {   // (memory for a chunk's symbols, a thread that cannot be started): an error of the run, not std::terminate
+                B.used.clear();
+                B.a_rc = 1;
+            }
             const bool last = B.a_rc != 0 || B.a_eof;
             to_b_.push(i);
             if (last) return;
@@ -585,7 +590,12 @@ class ParallelGunzip {
             const int i = to_b_.pop();
             if (i < 0 || stop_) return;
             Batch& B = slot_[i];
-            stage_b(B);
+            try {
+                stage_b(B);
+            } catch (...) {
+                B.pieces.clear();
+                B.rc = 1;
+            }
             const bool last = B.rc != 0 || B.eof;
             to_c_.push(i);
             if (last) return;
@@ -601,7 +611,8 @@ class ParallelGunzip {
     static void fan_out(int n, F f) {
         if (n <= 0) return;
         std::vector<std::thread> th;
-        for (int k = 1; k < n; k++) th.emplace_back([&f, k] { f(k); });
+        th.reserve((size_t)n);
+        for (int k = 1; k < n; k++) th.emplace_back([&f, k] { f(k); });   // (std::system_error here ends the process as it would the reference's own thread starts)
         f(0);
         for (auto& t : th) t.join();
     }

@@ -23,6 +23,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -803,7 +804,9 @@ struct GzSource {
     ~GzSource() { if (open) inflateEnd(&z); }
     // threads per ".gz" file: a quarter of the host's, at most 12 (a paired run has two such files, and the loop its own pools)
     static int gunzip_threads() {
-        const int hw = (int)std::thread::hardware_concurrency();
+        int hw = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;   // a process confined to fewer CPUs (taskset, a container's cpuset) counts those
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) hw = std::min(hw > 0 ? hw : CPU_COUNT(&set), CPU_COUNT(&set));
         return env_int("FASTP_GPU_STREAM_GUNZIP_THREADS", std::max(1, std::min(12, hw / 4)));
     }
     // up to `want` bytes of text to dst; < 0: damaged stream / read error
