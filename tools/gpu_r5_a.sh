@@ -6,7 +6,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_zz_gpu_compressed_inputs.py -m gpu -q > gpurun_out/r5a_pytest_gz.log 2>&1; echo "pytest (compressed inputs) rc=$?"; tail -3 gpurun_out/r5a_pytest_gz.log
+timeout 600 python -m pytest tests/test_zz_gpu_compressed_inputs.py -m gpu -q --durations=25 > gpurun_out/r5a_pytest_gz.log 2>&1; echo "pytest (compressed inputs) rc=$?"; tail -3 gpurun_out/r5a_pytest_gz.log
 # the drop-in on its own .gz output, 12 M pairs, trip sizes 16 .. 128 MiB (members per inflate launch: ~520 .. ~4100)
 timeout 800 python - > gpurun_out/r5a_bgzf_chunk_sweep.txt 2>&1 <<'PY'
 import os, re, subprocess, sys, time, shutil
