@@ -1441,12 +1441,17 @@ extern "C" int fastp_gpu_stream_gunzip_file_mt(const char* path, uint8_t* out, i
         g->fsize = (int64_t)sb.st_size;
         g->threads = threads;
         if (chunk_bytes > 0) g->chunk = (size_t)chunk_bytes;
-        return gunzip_file_with(g.get(), fd, out, capacity, piece, out_len);
+        const int rc = gunzip_file_with(g.get(), fd, out, capacity, piece, out_len);
+        g.reset();   // joins the threads that read ahead
+        close(fd);
+        return rc;
     }
     std::unique_ptr<fqgz::Gunzip> g(new fqgz::Gunzip());
     g->fd = fd;
     g->fsize = (int64_t)sb.st_size;
-    return gunzip_file_with(g.get(), fd, out, capacity, piece, out_len);
+    const int rc = gunzip_file_with(g.get(), fd, out, capacity, piece, out_len);
+    close(fd);
+    return rc;
 }
 
 template <class G>
@@ -1468,7 +1473,7 @@ static int gunzip_file_with(G* g, int fd, uint8_t* out, int64_t capacity, int64_
         *out_len += made;
         if (made < want) break;   // fewer than asked: the file has ended
     }
-    close(fd);
+    (void)fd;   // closed by the caller once the inflater - whose threads may still be reading ahead - is gone
     return rc;
 }
 
