@@ -245,7 +245,8 @@ class Gunzip {
     bool seekable = true;          // false: a pipe (--stdin) - read() in sequence until it returns 0, fsize is not used
     bool at_eof = false;           // every member has been delivered and the file has ended
 
-    Gunzip() : in_((size_t)IN_CAP + 64), win_((size_t)WIN + OUT_CAP + 512) {}
+    // FASTP_GPU_STREAM_GUNZIP_INCAP_KB: the input buffer's size (tests: a small one, so that small files cross many refills)
+    Gunzip() : in_cap_(in_cap_from_env()), in_(in_cap_ + 64), win_((size_t)WIN + OUT_CAP + 512) {}
 
     // up to `want` bytes of text to dst; fewer only at the end of the file; < 0: error (*err as above)
     int64_t read(uint8_t* dst, int64_t want, int* err) {
@@ -268,6 +269,12 @@ class Gunzip {
   private:
     enum { IN_CAP = 4 << 20, WIN = 32768, OUT_CAP = 1 << 20 };
     enum State { S_HEADER, S_BLOCK, S_STORED, S_CODES, S_TRAILER };
+    static size_t in_cap_from_env() {
+        const char* e = getenv("FASTP_GPU_STREAM_GUNZIP_INCAP_KB");
+        const long kb = e ? atol(e) : 0;
+        return kb > 0 ? (size_t)std::max(192L, kb) << 10 : (size_t)IN_CAP;   // (a header asks for 64 KiB at once)
+    }
+    size_t in_cap_;
     std::vector<uint8_t> in_, win_;
     size_t ip_ = 0, in_len_ = 0;       // unread input = in_[ip_, in_len_)
     bool file_done_ = false;           // the file has been read to its end (the input then carries 64 zero bytes of padding)
@@ -278,6 +285,7 @@ class Gunzip {
                                        // a distance must not reach below it - a member is a stream of its own
     State st_ = S_HEADER;
     bool last_block_ = false;
+    bool member_seen_ = false;
     uint32_t stored_left_ = 0;
     uint32_t crc_ = 0, isize_ = 0;
     size_t crc_from_ = WIN;            // text of the current member in win_[crc_from_, op_) is not in crc_ yet
@@ -290,12 +298,15 @@ class Gunzip {
     // make at least `need` unread bytes available (or everything up to the end of the file); false: read error
     bool fill(size_t need) {
         while (in_len_ - ip_ < need && !file_done_) {
-            if (ip_ > 0) {
-                memmove(in_.data(), in_.data() + ip_, in_len_ - ip_);
-                in_len_ -= ip_;
-                ip_ = 0;
+            // the bytes whose bits still sit in the bit buffer stay in front of ip_: unread_bits() steps back over them
+            const size_t keep = std::min(ip_, (size_t)((bc_ + 7) >> 3));
+            if (ip_ > keep) {
+                const size_t drop = ip_ - keep;
+                memmove(in_.data(), in_.data() + drop, in_len_ - drop);
+                in_len_ -= drop;
+                ip_ = keep;
             }
-            const int64_t room = (int64_t)IN_CAP - (int64_t)in_len_;
+            const int64_t room = (int64_t)in_cap_ - (int64_t)in_len_;
             const int64_t ask = seekable ? std::min<int64_t>(room, fsize - fpos) : room;
             if (ask <= 0) {
                 file_done_ = true;
@@ -362,7 +373,14 @@ class Gunzip {
         switch (st_) {
             case S_HEADER: {
                 if (!fill(1 << 16)) return 1;
-                if (avail() == 0) { at_eof = true; return 0; }
+                if (avail() == 0) {
+                    // a file that ends before its first member header is no gzip file: FastqReader::init stops there
+                    // ("igzip: Error invalid gzip header found", fastqreader.cpp:193-196)
+                    if (!member_seen_) return 4;
+                    at_eof = true;
+                    return 0;
+                }
+                member_seen_ = true;
                 const uint8_t* p = in_.data() + ip_;
                 const size_t n = avail();
                 if (n < 18 && !file_done_) return 4;
@@ -507,7 +525,7 @@ class Gunzip {
     // symbols of the current block until its end, the output buffer's end or the input's
     int codes() {
         make_room();
-        if (!fill(IN_CAP / 2)) return 1;
+        if (!fill(in_cap_ / 2)) return 1;
         uint8_t* const w = win_.data();
         uint8_t* op = w + op_;
         uint8_t* const oend = w + win_.size() - 512 - 258;   // a match and the copy's overshoot fit behind it

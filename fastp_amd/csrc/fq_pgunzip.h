@@ -31,6 +31,8 @@
 #include <deque>
 #include <mutex>
 #include <memory>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 #include "fq_gunzip.h"
@@ -478,6 +480,7 @@ class ParallelGunzip {
                 cur_ = nullptr;
             }
             if (!started_) {
+                if (fsize == 0) { *err = 4; return -1; }   // no member header at all: the reference's "invalid gzip header" (fastqreader.cpp:193-196)
                 started_ = true;
                 for (int i = 0; i < N_SLOTS; i++) free_.push(i);
                 thread_a_ = std::thread([this] { main_a(); });
@@ -612,9 +615,21 @@ class ParallelGunzip {
         if (n <= 0) return;
         std::vector<std::thread> th;
         th.reserve((size_t)n);
-        for (int k = 1; k < n; k++) th.emplace_back([&f, k] { f(k); });   // (std::system_error here ends the process as it would the reference's own thread starts)
-        f(0);
+        // an exception of any f(k) (bad_alloc) leaves through the caller's thread once every thread has been joined
+        std::mutex em;
+        std::exception_ptr first;
+        auto guarded = [&f, &em, &first](int k) {
+            try {
+                f(k);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(em);
+                if (!first) first = std::current_exception();
+            }
+        };
+        for (int k = 1; k < n; k++) th.emplace_back([&guarded, k] { guarded(k); });   // (std::system_error here ends the process as it would the reference's own thread starts)
+        guarded(0);
         for (auto& t : th) t.join();
+        if (first) std::rethrow_exception(first);
     }
 
     void stage_a(Batch& B) {
@@ -656,7 +671,7 @@ class ParallelGunzip {
         std::unique_ptr<std::atomic<int>[]> slice_read(new std::atomic<int>[(size_t)T + 1]), start_known(new std::atomic<int>[(size_t)T + 1]);
         for (int k = 0; k <= T; k++) { slice_read[k] = k == T; start_known[k] = k == T; }
         auto wait_for = [](std::atomic<int>& f) { while (!f.load(std::memory_order_acquire)) std::this_thread::yield(); };
-        fan_out(T, [&](int k) {
+        fan_out(T, [&](int k) { try {
             Chunk& c = B.ck[(size_t)k];
             c.start = ~0ull;
             c.rc = PG_STOP;
@@ -711,7 +726,11 @@ class ParallelGunzip {
             }
             if (io_err) return;
             c.rc = run(stop);
-        });
+        } catch (...) {   // no memory for this chunk's symbols: an error of the run; nobody may be left waiting for this thread's flags
+            io_err = 1;
+            slice_read[k].store(1, std::memory_order_release);
+            start_known[k].store(1, std::memory_order_release);
+        } });
         if (io_err) return 1;
         lap(2);
         // ---- 3: the chain: which chunks count, and the window in front of each ----

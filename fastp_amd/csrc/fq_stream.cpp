@@ -1264,8 +1264,9 @@ int run_loop(Run* R) {
         } else if (n == 0) {
             for (int m = 0; m < nf; m++)
                 if (left[m] >= s->chunk) return s->fail(FASTP_GPU_E_INVALID, "a record does not fit the chunk size (FASTP_GPU_STREAM_CHUNK_MB)");
-            // nothing parsed and nothing new arrived: a BGZF member (up to 64 KiB of text) takes whole-member room behind the carried text
-            if (!any_fresh && total[0] + total[1] > 0)
+            // nothing parsed and nothing new arrived: a BGZF member (up to 64 KiB of text) takes whole-member room behind the carried
+            // text.  (Also with nothing carried: a chunk smaller than the file's first member would ask for the same trip for ever.)
+            if (!any_fresh)
                 return s->fail(FASTP_GPU_E_INVALID, "a record (or a BGZF member) does not fit the chunk size (FASTP_GPU_STREAM_CHUNK_MB)");
         }
         // the text the records do not cover moves to the front of the other slot; the reader fills in behind it while

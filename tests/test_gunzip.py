@@ -254,10 +254,55 @@ def test_pgunzip_stream_geometry_on_a_file_of_many_chunks(tmp_path):
     cut = len(fq) * 2 // 3
     blob = _member(fq[:cut], 1) + _member(fq[cut:], 6)
     assert len(blob) > 5 * (2 << 20)
-    for threads, chunk in ((8, 2 << 20), (3, 1 << 20)):
+    for threads, chunk in ((8, 2 << 20), (3, 1 << 20), (1, 0)):   # (1, 0): fq_gunzip.h, whose 4 MiB input buffer this file refills a few times
         rc, got = _gunzip(_Lib(lib, threads, chunk), tmp_path, blob, len(fq), 16 << 20)
         assert rc == 0 and got == fq, (threads, chunk, rc, len(got))
     # a bit flipped far into the file: found whichever chunk it lands in
     pos = len(blob) * 3 // 5
     rc, _ = _gunzip(_Lib(lib, 8, 2 << 20), tmp_path, blob[:pos] + bytes([blob[pos] ^ 0x10]) + blob[pos + 1:], len(fq), 16 << 20)
     assert rc == abi.E_INVALID
+
+
+def _sync_flush_members(text: bytes, pieces: int) -> bytes:
+    """members whose deflate streams end in an empty stored block (Z_SYNC_FLUSH) followed by an empty fixed block (Z_FINISH
+    with nothing pending): the few-bits-then-a-byte-wise-read endings of the one-thread inflater's refill path"""
+    out, step = b"", max(1, len(text) // pieces)
+    for a in range(0, len(text), step):
+        part = text[a:a + step]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(part) + c.flush(zlib.Z_SYNC_FLUSH) + c.flush(zlib.Z_FINISH)
+        out += b"\x1f\x8b\x08\0\0\0\0\0\x00\x03" + body + zlib.crc32(part).to_bytes(4, "little") + (len(part) & 0xffffffff).to_bytes(4, "little")
+    return out
+
+
+@pytest.mark.parametrize("incap_kb", [192, 256, 400, 0])
+def test_gunzip_one_thread_refills_between_a_short_block_and_a_byte_wise_read(tmp_path, monkeypatch, incap_kb):
+    """fq_gunzip.h with files LARGER than its input buffer (FASTP_GPU_STREAM_GUNZIP_INCAP_KB makes the buffer small; 0 = the
+    production 4 MiB with a 12 MB file): after a refill has moved the unread input to the front, an end-of-block a few bits on
+    and a stored block / trailer behind it (unread_bits stepping back over bytes the bit buffer still holds) must read the
+    bytes that were in front of the refill point.  The round-4 advisor's reproduction (sync-flush + finish members)."""
+    lib = engine.load_library(engines.build_sim())
+    lib.fastp_gpu_stream_gunzip_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    if incap_kb:
+        monkeypatch.setenv("FASTP_GPU_STREAM_GUNZIP_INCAP_KB", str(incap_kb))
+    else:
+        monkeypatch.delenv("FASTP_GPU_STREAM_GUNZIP_INCAP_KB", raising=False)
+    d = synth.synth_pairs(150000 if not incap_kb else 12000, L=150, seed=43 + incap_kb, paired=False)
+    fq = synth.to_fastq(d["seq1"], d["qual1"], d["len1"], 1)
+    rng = np.random.default_rng(incap_kb)
+    for pieces in (3, 40, 700):
+        blob = _sync_flush_members(fq, pieces)
+        assert len(blob) > (incap_kb << 10 if incap_kb else 2 * (4 << 20))
+        assert gzip.decompress(blob) == fq
+        rc, got = _gunzip(_Lib(lib, 1, 0), tmp_path, blob, len(fq), int(rng.integers(1 << 16, 1 << 22)))
+        assert rc == 0 and got == fq, (incap_kb, pieces, rc, len(got))
+    # stored members (level 0: every block is a byte-wise read) and a mixture, same geometry
+    blob = b"".join(_member(fq[a:a + 70001], int(lv)) for a, lv in zip(range(0, len(fq), 70001), rng.integers(0, 3, size=len(fq) // 70001 + 1)))
+    rc, got = _gunzip(_Lib(lib, 1, 0), tmp_path, blob, len(fq), 1 << 20)
+    assert rc == 0 and got == fq
+
+
+def test_gunzip_empty_file_is_no_gzip_stream(lib, tmp_path):
+    """a 0-byte ".gz": FastqReader::init stops with "invalid gzip header" (fastqreader.cpp:193-196) - an error here as well"""
+    rc, got = _gunzip(lib, tmp_path, b"", 16)
+    assert rc == abi.E_INVALID and got == b""

@@ -130,7 +130,12 @@ PACK_MODE = {"FASTP_GPU_STREAM": "0"}   # the reference's own reader threads + t
 
 
 def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n", trailing=True, gz=False, more_flags=(),
-           mode="stream", mutate=None, expect_units=None, gz_in=None, interleaved=False, stdin_pipe=False):
+           mode="stream", mutate=None, expect_units=None, gz_in=None, interleaved=False, stdin_pipe=False, ref_on_phred33=False):
+    """ref_on_phred33: the REFERENCE run gets the same records with their qualities already converted (max(33, q - 31)) and no
+    --phred64 - what --phred64 means.  The reference's own --phred64 converts in Read's constructor only
+    (fastqreader.cpp:364-367): a Read object that comes back from its ReadPool keeps the file's characters, so once the pool
+    has objects to hand out (after the first pack of 1000 has been processed - a matter of thread timing) its output is a
+    mixture of converted and unconverted reads.  Direct comparisons with `fastp_ref --phred64` therefore use inputs of one pack."""
     paired, flags, pf, skw = cases.CASES[name]
     flags = list(flags) + BINDING_CASES[name] + list(more_flags)
     tmp = str(tmp_path)
@@ -163,7 +168,28 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     in1 = in2 = None
     if gz_in:   # ".gz" inputs, read by BOTH binaries (the reference here inflates through oracle/shims/isa-l over zlib)
         in1, in2 = _compress_inputs(tmp, paired, gz_in)
-    want_files, want_rep = _run(REF, tmp, "ref", flags, paired, {}, gz=gz, in1=in1, in2=in2, interleaved=interleaved, stdin_pipe=stdin_pipe)
+    ref_flags, ref_in1, ref_in2, ref_tmp = flags, in1, in2, tmp
+    if ref_on_phred33:
+        assert "--phred64" in flags
+        ref_flags = [f for f in flags if f != "--phred64"]
+        ref_tmp = os.path.join(tmp, "ref33")
+        os.makedirs(ref_tmp, exist_ok=True)
+        for fn in ("in1.fq", "in2.fq"):
+            if not os.path.exists(os.path.join(tmp, fn)):
+                continue
+            lines = open(os.path.join(tmp, fn), "rb").read().split(eol)
+            for i in range(3, len(lines), 4):
+                lines[i] = bytes(max(33, c - 31) for c in lines[i])
+            with open(os.path.join(ref_tmp, fn), "wb") as f:
+                f.write(eol.join(lines))
+        ref_in1 = ref_in2 = None
+        if gz_in:
+            ref_in1, ref_in2 = _compress_inputs(ref_tmp, paired, gz_in)
+        for fn, content in cases.FILES.get(name, {}).items():
+            os.makedirs(os.path.join(ref_tmp, "ref"), exist_ok=True)
+            with open(os.path.join(ref_tmp, "ref", fn), "wb") as f:
+                f.write(content)
+    want_files, want_rep = _run(REF, ref_tmp, "ref", ref_flags, paired, {}, gz=gz, in1=ref_in1, in2=ref_in2, interleaved=interleaved, stdin_pipe=stdin_pipe)
     env = {"FASTP_GPU": "1", "FASTP_GPU_VERBOSE": "1"}
     if binary == REF_SIM:
         env.update(SIM_ENV)
@@ -178,7 +204,8 @@ def _check(name, binary, n, tmp_path, seed, threads=1, extra_env=None, eol=b"\n"
     assert streamed == (mode == "stream"), err[-800:]
     if "overrep" in name and "exotic" not in name:   # -p: the Evaluator's substring census ran on the device too (fastp_gpu_eval_overrep;
         # a sample with letters outside ACGTN is left to the reference's own Evaluator)
-        assert err.count("computeOverRepSeq on the device") == (2 if paired else 1), err[-800:]
+        # (with --interleaved_in the reference itself calls computeOverRepSeq ONCE: in2 is empty, evaluator.cpp:171-176)
+        assert err.count("computeOverRepSeq on the device") == (2 if (paired and not interleaved) else 1), err[-800:]
         if n >= 10000:   # (600 reads do not reach the count thresholds: both sides then agree on "none")
             assert len(want_rep["read1_before_filtering"]["overrepresented_sequences"]) > 0
     assert sorted(want_files) == sorted(got_files)
@@ -195,8 +222,10 @@ IL_BINDING_CASES = [("pe_default", dict(threads=2)), ("pe_merge_unmerged", dict(
                     ("pe_exotic_dedup_adapters", dict(threads=3, gz_in=("bgzf",), gz=True)), ("pe_overrep", dict(threads=4, gz_in=("members",)))]
 
 
-@pytest.mark.parametrize("name,kw", [("pe_merge_unmerged", dict(threads=1, eol=b"\r\n", more_flags=("--reads_to_process", "500"), expect_units=500)),
-                                     ("pe_exotic_dedup_adapters", dict(threads=3, gz_in=("bgzf",), gz=True)),
+# (every `-m gpu` parametrisation of tests/test_zz_gpu_compressed_inputs.py runs here on the emulator first: the lists are shared and
+# tests/conftest.py refuses a collection in which a GPU case has no emulator twin)
+@pytest.mark.parametrize("name,kw", IL_BINDING_CASES +
+                                    [("pe_merge_unmerged", dict(threads=1, eol=b"\r\n", more_flags=("--reads_to_process", "500"), expect_units=500)),
                                      ("pe_correction", dict(threads=2, mode="pack", extra_env={"FASTP_GPU_STREAM_INTERLEAVED": "0"}))])
 def test_patched_reference_interleaved_input(name, kw, tmp_path):
     """--interleaved_in (PairEndProcessor::interleavedReaderTask): the stream deals the one file's records out to the mates on the
@@ -210,7 +239,7 @@ STDIN_CASES = [("se_adapter_cut", dict(threads=2)), ("pe_filters", dict(threads=
                ("pe_merge_unmerged", dict(threads=2, interleaved=True, more_flags=("--reads_to_process", "400"), expect_units=400))]
 
 
-@pytest.mark.parametrize("name,kw", [c for c in STDIN_CASES if c[0] in ("se_adapter_cut", "pe_merge_unmerged")])
+@pytest.mark.parametrize("name,kw", STDIN_CASES)
 def test_patched_reference_stdin_input(name, kw, tmp_path):
     """--stdin (in1 = "/dev/stdin", a pipe; with --interleaved_in for paired data): the stream reads the pipe in sequence into
     its page-locked slots; the Evaluator does not run on such input in the reference (main.cpp:437), so the evaluated read
@@ -238,7 +267,7 @@ PHRED64_CASES = [("pe_default", dict(threads=2)), ("se_adapter_cut", dict(thread
                  ("pe_filters", dict(threads=2, interleaved=True)), ("se_overrep", dict(threads=2, gz=True))]
 
 
-@pytest.mark.parametrize("name,kw", [c for c in PHRED64_CASES if c[0] in ("se_adapter_cut", "pe_filters")] +
+@pytest.mark.parametrize("name,kw", PHRED64_CASES +
                          [("pe_correction", dict(threads=2, mode="pack", extra_env={"FASTP_GPU_STREAM": "0"}))])
 def test_patched_reference_phred64_input(name, kw, tmp_path):
     """--phred64: FastqReader::read converts every read's qualities (Read::convertPhred64To33); the stream does it on the device
@@ -246,7 +275,11 @@ def test_patched_reference_phred64_input(name, kw, tmp_path):
     converted reads from the reference's reader"""
     if not _ensure_built() or not os.path.exists(REF_SIM):
         pytest.skip("reference binaries not built (no /root/reference here)")
-    _check(name, REF_SIM, 700, tmp_path, seed=59, mutate=_to_phred64, more_flags=("--phred64",), **kw)
+    _check(name, REF_SIM, 700, tmp_path, seed=59, mutate=_to_phred64, more_flags=("--phred64",), **kw)   # one pack: the reference converts every read
+    if kw.get("mode") != "pack":   # several packs against what --phred64 means (pack mode takes the reference's own reads: its mixture)
+        sub = tmp_path / "twin"
+        sub.mkdir()
+        _check(name, REF_SIM, 3000, sub, seed=61, mutate=_to_phred64, more_flags=("--phred64",), ref_on_phred33=True, **kw)
 
 
 def _compress_inputs(tmp, paired, how):
@@ -276,10 +309,9 @@ def _compress_inputs(tmp, paired, how):
     return paths[0], (paths[1] if len(paths) > 1 else None)
 
 
-# on the emulator (CPU suite) a representative half of the flag sets - every one of them runs against the real library in
-# test_gpu_patched_reference_equals_reference; each costs seconds here because the emulator clears Duplicate's 1 GiB
-EMULATOR_CASES = ["pe_filters", "pe_noadapter_dedup", "pe_umi_per_read", "pe_adapter_fasta", "pe_overrep", "pe_allow_gap_indel",
-                  "pe_merge_overlapped_out_trims", "se_adapter_cut", "se_adapter_long_indel", "pe_exotic_merge", "pe_exotic_default", "se_exotic_overrep"]
+# on the emulator (CPU suite) every flag set the real library sees in test_gpu_patched_reference_equals_reference (the twin rule of
+# tests/conftest.py), at 600 units
+EMULATOR_CASES = list(BINDING_CASES)
 assert all(n in BINDING_CASES for n in EMULATOR_CASES)
 
 
@@ -326,7 +358,12 @@ def test_patched_reference_stream_gz_outputs(name, threads, writer, tmp_path):
     _check(name, REF_SIM, 700, tmp_path, seed=53, threads=threads, gz=True, extra_env={"FASTP_GPU_WRITER": writer} if writer else None)
 
 
-@pytest.mark.parametrize("name,how,kw", [("se_adapter_cut", ("bgzf",), dict(threads=3, gz=True)),
+GZ_BINDING_CASES = [("pe_default", ("bgzf", "bgzf"), dict(threads=4)), ("pe_overrep", ("bgzf", "gzip"), dict(threads=4)),
+                    ("se_adapter_cut", ("bgzf",), dict(threads=4)), ("se_default_noadapter", ("members",), dict(threads=4))]   # (also the -m gpu list)
+
+
+@pytest.mark.parametrize("name,how,kw", GZ_BINDING_CASES +
+                                        [("se_adapter_cut", ("bgzf",), dict(threads=3, gz=True)),
                                          ("pe_exotic_dedup_adapters", ("members", "bgzf"), dict(threads=2, more_flags=("--reads_to_process", "500"), expect_units=500)),
                                          ("pe_correction", ("bgzf", "gzip"), dict(threads=2, mode="pack", extra_env={"FASTP_GPU_STREAM_GZ": "0"}))])
 def test_patched_reference_compressed_inputs(name, how, kw, tmp_path):
@@ -494,6 +531,7 @@ def test_patched_reference_random_command_lines(seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_patched_reference_on_emulator_equals_reference")
 @pytest.mark.parametrize("name", list(BINDING_CASES))
 def test_gpu_patched_reference_equals_reference(name, tmp_path):
     """the same on the real library: fastp_ref_gpu (FASTP_GPU=1) vs fastp_ref, 30 000 units"""

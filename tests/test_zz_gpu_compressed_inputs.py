@@ -15,7 +15,8 @@ from test_stream_abi import GZ_CASES, IL_CASES, OVERLAPPED_GOLDENS, _files, _gol
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,how1,how2", GZ_CASES + [("pe_overrep_merge", "bgzf_big", "bgzf_big"), ("pe_noadapter_dedup", "bgzf_big", "gzip")])
+@pytest.mark.twin("test_sim_stream_compressed_inputs_equal_reference_golden")
+@pytest.mark.parametrize("name,how1,how2", GZ_CASES)
 def test_gpu_stream_compressed_inputs_equal_reference_golden(name, how1, how2, tmp_path):
     lib = engine.load_library()
     _golden_gz(lib, name, tmp_path, 1 << 20, how1, how2)
@@ -57,16 +58,17 @@ def test_gpu_stream_plain_gzip_inputs_inflater_geometries(tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,how", [("pe_default", ("bgzf", "bgzf")), ("pe_overrep_merge" if "pe_overrep_merge" in rb.BINDING_CASES else "pe_overrep", ("bgzf", "gzip")),
-                                      ("se_adapter_cut", ("bgzf",)), ("se_default_noadapter", ("members",))])
-def test_gpu_patched_reference_compressed_inputs(name, how, tmp_path):
+@pytest.mark.twin("test_patched_reference_compressed_inputs")
+@pytest.mark.parametrize("name,how,kw", rb.GZ_BINDING_CASES)
+def test_gpu_patched_reference_compressed_inputs(name, how, kw, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
         pytest.skip("oracle/_ref binaries did not travel to this box")
-    err = rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=44, gz_in=how, threads=4)
+    err = rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=44, gz_in=how, **kw)
     assert ("inflated on the device" in err) == ("bgzf" in how), err[-800:]
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_sim_stream_interleaved_input_equals_reference_golden")
 @pytest.mark.parametrize("name,pack", IL_CASES)
 def test_gpu_stream_interleaved_input_equals_reference_golden(name, pack, tmp_path):
     lib = engine.load_library()
@@ -74,6 +76,7 @@ def test_gpu_stream_interleaved_input_equals_reference_golden(name, pack, tmp_pa
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_patched_reference_interleaved_input")
 @pytest.mark.parametrize("name,kw", rb.IL_BINDING_CASES)
 def test_gpu_patched_reference_interleaved_input(name, kw, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
@@ -82,14 +85,21 @@ def test_gpu_patched_reference_interleaved_input(name, kw, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_patched_reference_phred64_input")
 @pytest.mark.parametrize("name,kw", rb.PHRED64_CASES)
 def test_gpu_patched_reference_phred64_input(name, kw, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
         pytest.skip("oracle/_ref binaries did not travel to this box")
-    rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=46, mutate=rb._to_phred64, more_flags=("--phred64",), **kw)
+    # 30 000 units against the reference run on the converted qualities (its own --phred64 leaves the reads that come back
+    # from its ReadPool unconverted, rb._check), one pack of 900 against `fastp_ref --phred64` itself
+    rb._check(name, rb.REF_GPU, 30000, tmp_path, seed=46, mutate=rb._to_phred64, more_flags=("--phred64",), ref_on_phred33=True, **kw)
+    sub = tmp_path / "one_pack"
+    sub.mkdir()
+    rb._check(name, rb.REF_GPU, 900, sub, seed=49, mutate=rb._to_phred64, more_flags=("--phred64",), **kw)
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_patched_reference_stdin_input")
 @pytest.mark.parametrize("name,kw", rb.STDIN_CASES)
 def test_gpu_patched_reference_stdin_input(name, kw, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
@@ -98,6 +108,7 @@ def test_gpu_patched_reference_stdin_input(name, kw, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_sim_stream_equals_reference_golden")
 @pytest.mark.parametrize("name", OVERLAPPED_GOLDENS)
 def test_gpu_stream_overlapped_out_equals_reference_golden(name, tmp_path):
     """--overlapped_out in stream mode: six streams from the device formatter, the seventh assembled on the host of the loop"""
@@ -106,6 +117,7 @@ def test_gpu_stream_overlapped_out_equals_reference_golden(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.twin("test_patched_reference_on_emulator_equals_reference")
 @pytest.mark.parametrize("name", [n for n in rb.BINDING_CASES if rb._overlapped_out(n)])
 def test_gpu_patched_reference_overlapped_out_stream_mode(name, tmp_path):
     if not (os.path.exists(rb.REF) and os.path.exists(rb.REF_GPU)):
