@@ -492,7 +492,10 @@ def main():
     else:
         B = 4 * 1024 * 1024
     log(f"generating {NB} resident batches of {B} pairs")
+    t_gen = time.perf_counter()
     resident = [ResidentBatch(B, 42 + 1000 * rank + k, dev) for k in range(NB)]
+    torch.cuda.synchronize(dev)
+    t_gen = time.perf_counter() - t_gen      # outside the timed region; every rank generates its own shard on its own GPU
     r1 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
     r2 = torch.zeros(B * 12, dtype=torch.uint8, device=dev)
     pr = torch.zeros(B * 8, dtype=torch.uint8, device=dev)
@@ -696,6 +699,7 @@ def main():
                                    f"counters per run)",
                        "pairs_per_run_per_gpu": NB * B, "pairs_per_step_per_gpu": B, "timed_pairs_total": total_pairs,
                        "read_len": L, "parallelism": f"shard x{world}", "counter_merge": merge_how,
+                       "generate_s": round(t_gen, 2),
                        # per-run constants of an N > 1 run, inside the timed region but reported apart so that a 1 -> N curve
                        # can be read: the bitmap prefix exchange (once per run of NB steps) and the counter all-reduce (once)
                        "bitmap_exchange": exchange_how,

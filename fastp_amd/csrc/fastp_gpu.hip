@@ -60,7 +60,14 @@ __global__ void __launch_bounds__(LaneGeom<SWM>::MAX_THREADS, 1) fq_lane_kernel(
 }
 extern "C" __global__ void __launch_bounds__(1024, 8) fq_stats_kernel(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
-    stats_body(a, fq_lds);
+    if (a.form == 4) {   // (uniform)
+        if ((a.debug_skip & 0x1C0u) && a.kc == 4) stats_body4<4, true>(a, fq_lds);   // profiling only (FASTP_GPU_DEBUG_SKIP)
+        else if (a.kc == 4) stats_body4<4, false>(a, fq_lds);
+        else if (a.kc == 2) stats_body4<2, false>(a, fq_lds);
+        else stats_body4<1, false>(a, fq_lds);
+    } else {
+        stats_body(a, fq_lds);
+    }
 }
 extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -190,6 +197,7 @@ struct fastp_gpu_ctx {
     bool split = false;
     int st_threads = 0, st_blocks = 0;     // the Stats kernel's workgroup size and the most workgroups it is launched with
     int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
+    int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
     // lane plan (fq_lane.h): one lane per pair, reads in registers - the option family lane_plan_supported() admits
@@ -480,7 +488,33 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
         ctx->st_H = ctx->dp.qw_g / 2;
+        ctx->st_form = env_int("FASTP_GPU_STATS_V", 4) == 3 ? 3 : 4;
+        if (ctx->st_form == 4) {
+            // round 5's form: [2][8][ST4_ROWS][Hs] u32 per-cycle cells of ONE mate, KC copies of its 5-mer counters, its histogram
+            ctx->st_kc = env_int("FASTP_GPU_STATS_KC", 4);
+            if (ctx->st_kc != 1 && ctx->st_kc != 2 && ctx->st_kc != 4) ctx->st_kc = 4;
+            ctx->st_Hs = env_int("FASTP_GPU_STATS_HS", 0);
+            if (ctx->st_Hs < ctx->st_H) ctx->st_Hs = ctx->st_H < 32 ? 32 : ctx->st_H;
+            ctx->st_max_reads = ST4_MAX_READS;
+            for (;;) {
+                ctx->st_wl_cap = 511;
+                int o = 0;
+                ctx->st_l_cyc = o; o += 2 * 8 * ST4_ROWS * ctx->st_Hs;
+                ctx->st_l_kmer = o; o += 2 * KMER_BINS * ctx->st_kc;
+                ctx->st_l_qh = o; o += ST_QH_COPIES * 2 * 128;
+                o = (o + 3) & ~3;
+                ctx->st_l_lut = o; o += 4 * 256;
+                ctx->st_l_mt = o; o += 18 + 2;
+                ctx->st_l_wl = o; o += 1 + ctx->st_wl_cap;
+                ctx->st_lds_dwords = o;
+                if (2 * o * 4 <= 160 * 1024) break;                       // two workgroups per CU
+                if (ctx->st_Hs > ctx->st_H) ctx->st_Hs = ctx->st_H;       // first the padding,
+                else if (ctx->st_kc > 1) ctx->st_kc /= 2;                 // then the copies
+                else break;
+            }
+        } else {
         // class stride of the per-cycle table: 32 items (= all 64 banks) where two workgroups per CU still fit
+        ctx->st_max_reads = CYC_MAX_READS;
         ctx->st_Hs = ctx->st_H;
         if (env_int("FASTP_GPU_STATS_PAD", 1) && ctx->st_H < 32) ctx->st_Hs = 32;
         ctx->st_wl_cap = ctx->st_Hs > ctx->st_H ? 511 : 2047;
@@ -499,6 +533,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->st_l_mt = o; o += 18 + 2;
         ctx->st_l_wl = o; o += 1 + ctx->st_wl_cap;
         ctx->st_lds_dwords = o;
+        }
         ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
         ctx->st_threads = env_int("FASTP_GPU_STATS_THREADS", 1024);
         if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63)) ctx->st_threads = 1024;
@@ -554,7 +589,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     auto set_launch_size = [&]() {
         long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
         if (ctx->split) {   // the per-read kernel has no packed counters; a Stats workgroup takes <= CYC_MAX_READS units
-            mp = (long long)ctx->st_blocks * CYC_MAX_READS;
+            mp = (long long)ctx->st_blocks * CYC_MAX_READS;   // (form 4 takes such a launch as several rounds of workgroups)
             if (cap_tiles > 0) mp = std::min(mp, (long long)ctx->blocks * cap_tiles * ctx->L.P);
         }
         if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
@@ -639,7 +674,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
-        CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_blocks * ctx->st_slab_dwords * 4));
+        // a slab per workgroup of the largest launch: st_blocks of them for the packed u64 form, rounds of st_blocks for the u32 form
+        ctx->st_max_grid = ctx->st_form == 4 ? (ctx->max_pairs_per_launch + ST4_MAX_READS - 1) / ST4_MAX_READS + ctx->st_blocks : ctx->st_blocks;
+        CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_max_grid * ctx->st_slab_dwords * 4));
         if (env_int("FASTP_GPU_DUP_OVERLAP", 1)) {
             CREATE_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
             CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming));
@@ -1234,11 +1271,16 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.H = ctx->st_H; sa.Hs = ctx->st_Hs;
         sa.magic_H = magic_for((u32)ctx->st_H);
         sa.Cp = ctx->L.Cp;
-        int upb = (n + ctx->st_blocks - 1) / ctx->st_blocks;
+        // whole rounds of the resident workgroups: 4.19 M pairs = 3 rounds of 512 workgroups with 2731 units each in form 4
+        const int rounds = (int)(((long long)n + (long long)ctx->st_blocks * ctx->st_max_reads - 1) / ((long long)ctx->st_blocks * ctx->st_max_reads));
+        int upb = (n + ctx->st_blocks * rounds - 1) / (ctx->st_blocks * rounds);
         upb = std::max(upb, std::min(n, 64));
-        if (upb > CYC_MAX_READS) return fail(ctx, FASTP_GPU_E_INVALID, "launch too large for the Stats kernel");
+        if (upb > ctx->st_max_reads) return fail(ctx, FASTP_GPU_E_INVALID, "launch too large for the Stats kernel");
         sa.units_per_block = upb;
         st_grid = (n + upb - 1) / upb;
+        if (st_grid > ctx->st_max_grid) return fail(ctx, FASTP_GPU_E_INVALID, "launch too large for the Stats kernel's slabs");
+        sa.form = ctx->st_form;
+        sa.kc = ctx->st_kc;
         for (int m = 0; m < 2; m++) { sa.seq[m] = a.seq[m]; sa.qual[m] = a.qual[m]; sa.swin[m] = ctx->d_swin[m]; }
         sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut; sa.l_mt = ctx->st_l_mt;
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;

@@ -48,6 +48,8 @@ struct StatsArgs {
     u32* slabs;
     int slab_dwords;
     u32 debug_skip;         // profiling only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
+    int form;               // 4: u32 cells, one mate's tables at a time (stats_body4, round 5); 3: round 3's packed u64 cells (stats_body)
+    int kc;                 // form 4: copies of the 5-mer table (1, 2 or 4)
 };
 
 enum { ST_QH_COPIES = 8 };
@@ -244,6 +246,207 @@ FQ_DEV void stats_body(const StatsArgs& a, u32* lds) {
         if (i & 127)   // bin 0 of a slot collects the "no base" characters of the fast path
             for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
         slab[2 * n_cyc + 4 * KMER_BINS + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same pass with u32 cells (stats_body4).  What round 3/4's form (stats_body, kept as FASTP_GPU_STATS_V=3)
+// spends on the LDS pipe per base is one table read, one ds_add_u64 into the packed [cnt|q20|q30|qsum] cell (9.2 cycles
+// per wave instruction: twice a 32-bit one, profiles/r02c_issue_rate_microbench.txt), one ds_add_u32 into the 5-mer table
+// whose 64 random bins meet in banks (39 % of the pipe's busy cycles, profiles/r04_sq_counters.txt) and the histogram add.
+// Here
+//   * a per-cycle cell is ONE dword [count : 12 | sum of (quality - 33) : 20] and the Q20 / Q30 counts come from WHICH
+//     cell the base lands in: the table has a row per (class, level) with level = (q >= Q20) + (q >= Q30), read off the
+//     character's table row like the increment.  cnt = c0 + c1 + c2, q20 = c1 + c2, q30 = c2 when the table is flushed into
+//     the slab's packed u64 form (the slab fold and everything behind it are unchanged).  A workgroup therefore takes at
+//     most ST4_MAX_READS = 4095 units (93 * 4095 < 2^20),
+//   * the tables hold ONE mate at a time (its dropped and kept slots): half the LDS, which pays for
+//   * KC copies of the 5-mer table, lane l adds to copy l % KC, the copies of a bin in consecutive banks: the KC lanes groups
+//     of a wave instruction meet in 64 / KC banks each instead of all 64 lanes in 64 (KC = 4: 16 balls into 16 bins),
+//   * the wavefront's mode character is counted with three SWAR instructions + v_bcnt per dword instead of a compare,
+//     a select and an add per base.
+// ---------------------------------------------------------------------------------------------------------------------
+enum { ST4_ROWS = 3 * N_CLS, ST4_CNT_BITS = 12, ST4_MAX_READS = (1 << ST4_CNT_BITS) - 1 };
+
+FQ_DEV u32 stats4_inc_of(u32 q) { return 1u | ((q - 33u) << ST4_CNT_BITS); }
+FQ_DEV u32 stats4_level_of(u32 q) { return (q >= 53u ? 1u : 0u) + (q >= 63u ? 1u : 0u); }   // stats.cpp:209-222
+
+// an item with an N among its 8 bases or the 4 before: base by base (dense pass over the work list), one mate's tables
+template <int KC>
+FQ_DEV void stats4_item_general(const StatsArgs* ap, u32* lds, int h, int rl0, int lk, u32 q0, u32 q1, u32 qp, u32 codes, u32 prev8, int lane) {
+    const StatsArgs& a = *ap;
+    u32* cyc = lds + a.l_cyc;
+    const u32 nb0 = (q0 >> 7) & 0x01010101u, nb1 = (q1 >> 7) & 0x01010101u, nbp = (qp >> 7) & 0x01010101u;
+    u32 n12 = ((nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu) | (((nb0 | (nb0 >> 7) | (nb0 >> 14) | (nb0 >> 21)) & 0xFu) << 4) |
+              (((nb1 | (nb1 >> 7) | (nb1 >> 14) | (nb1 >> 21)) & 0xFu) << 8);
+    if (h == 0) n12 |= 0xFu;
+    const u32 c24 = prev8 | (codes << 8);
+    const int j0 = 8 * h;
+    u32* qh = lds + a.l_qh + (lane & (ST_QH_COPIES - 1));
+    for (int k = 0; k < 8; k++) {
+        const int j = j0 + k;
+        if (j >= rl0) break;
+        const u32 q = ((k < 4 ? q0 : q1) >> (8 * (k & 3))) & 0x7Fu;
+        const bool isn = ((n12 >> (4 + k)) & 1u) != 0;
+        const int cls = isn ? (int)CLS_N : (int)((codes >> (2 * k)) & 3u);
+        const int slot = j < lk ? 1 : 0;
+        lds_add_u32(&cyc[((slot * 8 + k) * ST4_ROWS + cls * 3 + (int)stats4_level_of(q)) * a.Hs + h], stats4_inc_of(q));
+        lds_add_u32(&qh[(slot * 128 + (int)q) * ST_QH_COPIES], 1u);
+        if (((n12 >> k) & 0x1Fu) == 0u)
+            lds_add_u32(&lds[a.l_kmer + (slot * KMER_BINS + (int)((c24 >> (2 * k)) & 0x3FFu)) * KC + (lane & (KC - 1))], 1u);
+    }
+}
+
+// ABL: the profiling instantiation (FASTP_GPU_DEBUG_SKIP 64 / 128 / 256 leave out the per-cycle / 5-mer / histogram adds:
+// what is left is the measured floor of the pass - results are meaningless then); the product instantiation has no such branch
+template <int KC, bool ABL>
+FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
+    const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
+    const int H = a.H;
+    const u32 H4 = (u32)a.Hs * 4u;            // bytes between the rows of one (slot, k)
+    const u32 C4 = 3u * H4;                   // bytes between the classes
+    const u32 K4 = (u32)ST4_ROWS * H4;        // bytes between the k of one slot
+    const u32 S4 = 8u * K4;                   // bytes between the two slots
+    const int u0 = block_id() * a.units_per_block;
+    const int nu = imax(0, imin(a.units_per_block, a.n - u0));
+    const int per_mate = nu * H;
+    u8* ldsw = (u8*)lds;
+    const u32x4* lut = (const u32x4*)__builtin_assume_aligned(lds + a.l_lut, 16);
+    u32* wl = lds + a.l_wl;
+    const u32x2* mt = (const u32x2*)__builtin_assume_aligned(lds + a.l_mt, 8);
+    u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
+    const int n_cyc = 4 * a.Cp * N_CLS;       // u64 items of the slab's per-cycle part
+    const int nm = a.paired ? 2 : 1;
+    for (int m = 0; m < 2; m++) {             // uniform
+        // ---- clear this mate's accumulators; the character table and the byte masks once ----
+        for (int i = tid; i < a.l_lut; i += nt) lds[i] = 0;          // [cyc | kmer | qh] sit in front of the table
+        if (tid == 0) wl[0] = 0;
+        if (m == 0) {
+            for (int e = tid; e < 256; e += nt) {
+                const u32 q = (u32)e & 0x7Fu, kept = (u32)e >> 7;
+                u32* t = lds + a.l_lut + 4 * e;
+                // characters below '!' never occur in a read (the packers refuse them): 0 stands for "no base here" and adds nothing
+                t[0] = q < 33u ? 0u : stats4_inc_of(q);
+                t[1] = (kept ? S4 : 0u) + (q < 33u ? 0u : stats4_level_of(q) * H4);
+                t[2] = kept ? (u32)(KMER_BINS * KC * 4) : 0u;
+                t[3] = 0u;
+            }
+            for (int i = tid; i < 9; i += nt) {
+                lds[a.l_mt + 2 * i] = lowmask32(8 * imin(i, 4));
+                lds[a.l_mt + 2 * i + 1] = lowmask32(8 * imax(0, i - 4));
+            }
+        }
+        block_sync();
+        if (m < nm) {
+            const u32* qual = a.qual[m] + (size_t)u0 * a.qw_g;
+            const u32* seq = a.seq[m] + (size_t)u0 * a.sw_g;
+            const u32* swin = a.swin[m] + u0;
+            const u32 cyc_m = (u32)a.l_cyc * 4u;
+            const u32 kmer_m = (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
+            const u32 qh_m = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 4u;
+            // The wavefront's mode = the character (with its kept bit) of the first item's first base, fixed at its first
+            // appearance: bases that hit it are counted per lane and added once at the end.
+            u32 mode_e = 0xFFFFFFFFu, mode4 = 0;
+            u32 n_other = 0, n_items = 0;     // bytes that are not the mode / items looked at since the mode was fixed
+            for (int base = tid - lane; base < per_mate; base += nt) {   // wave-uniform trip count (ballots inside)
+                const int it = base + lane;
+                StatsItem s;
+                stats_fetch(a, qual, seq, swin, it, it < per_mate, s);
+                const u32 nany = (s.q0 | s.q1 | s.qp) & 0x80808080u;   // an N among the 8 bases or the 4 before
+                const bool plain = s.act && nany == 0u;
+                if (s.act && !plain) {                                  // rare: queued for the base-by-base pass
+                    const u32 slot = lds_add_ret_u32(wl, 1u);
+                    if (slot < (u32)a.wl_cap) wl[1 + slot] = (u32)it;
+                    else stats4_item_general<KC>(&a, lds, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);   // list full: here and now
+                }
+                const int j0 = 8 * s.h;
+                const int nv = plain ? s.rl0 - j0 : 0, nk = s.lk - j0;   // not plain: eight "no base" characters
+                const u32x2 vm = mt[imax(0, imin(nv, 8))], km = mt[imax(0, imin(nk, 8))];
+                const u32 e0 = (s.q0 | (km.x & 0x80808080u)) & vm.x, e1 = (s.q1 | (km.y & 0x80808080u)) & vm.y;
+                if (mode_e == 0xFFFFFFFFu) {                           // wave-uniform
+                    const u64 cand = ballot(plain);
+                    if (cand) {
+                        mode_e = shfl(e0 & 0xFFu, ffs64(cand) - 1);
+                        mode4 = mode_e * 0x01010101u;
+                    }
+                }
+                if (mode_e != 0xFFFFFFFFu) {                           // wave-uniform: bytes of the item that differ from the mode
+                    const u32 x0 = e0 ^ mode4, x1 = e1 ^ mode4;
+                    n_other = (u32)popc32((((x0 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x0) & 0x80808080u) + n_other;
+                    n_other = (u32)popc32((((x1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x1) & 0x80808080u) + n_other;
+                    n_items++;
+                }
+                const u32 c24 = s.prev8 | (s.codes << 8);              // bases j0-4 .. j0+7, 2 bits each
+                const u32 cyc0 = cyc_m + (u32)s.h * 4u;
+                const u32 hpos = s.h > 0 ? 1u : 0u;                    // 5-mers need positions >= 4 (stats.cpp:224-266)
+#pragma unroll
+                for (int kb = 0; kb < 8; kb += 4) {
+                    u32x4 t[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) t[i] = lut[bfe(kb ? e1 : e0, 8 * i, 8)];   // character | kept << 7
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int k = kb + i;
+                        const u32 e = bfe(kb ? e1 : e0, 8 * i, 8);
+                        if (!ABL || !(a.debug_skip & 64u))
+                            lds_add_u32((u32*)(ldsw + mul24(bfe(s.codes, 2 * k, 2), C4) + (cyc0 + t[i].y + (u32)k * K4)), t[i].x);
+                        const u32 one = k < 4 ? (t[i].x & hpos) : (t[i].x & 1u);
+                        if (!ABL || !(a.debug_skip & 128u))
+                            lds_add_u32((u32*)(ldsw + ((kmer_m + t[i].z) + bfe(c24, 2 * k, 10) * (u32)(4 * KC))), one);
+                        // character 0 ("no base") lands in bin 0 of the dropped slot, which the flush leaves out
+                        if ((!ABL || !(a.debug_skip & 256u)) && e != mode_e) lds_add_u32((u32*)(ldsw + (qh_m + e * (4u * ST_QH_COPIES))), 1u);
+                    }
+                }
+            }
+            if (mode_e != 0xFFFFFFFFu) {
+                u32 agg = 8u * n_items - n_other;
+#pragma unroll
+                for (int sh = 1; sh < 64; sh <<= 1) agg += shfl_xor(agg, sh);
+                if (lane == 0 && agg) lds_add_u32(&lds[a.l_qh + (int)mode_e * ST_QH_COPIES], agg);
+            }
+            block_sync();
+            // ---- the queued items, every lane busy ----
+            const int nw = imin((int)wl[0], a.wl_cap);
+            for (int i = tid; i < nw; i += nt) {
+                StatsItem s;
+                stats_fetch(a, qual, seq, swin, (int)wl[1 + i], true, s);
+                stats4_item_general<KC>(&a, lds, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);
+            }
+        }
+        block_sync();
+        // ---- flush the mate's two slots to the slab in its canonical packed form ([slot][cycle][class] u64, reduce_body) ----
+        const int per_slot = a.Cp * N_CLS;
+        for (int i = tid; i < 2 * per_slot; i += nt) {
+            const int sl = i >= per_slot ? 1 : 0;
+            const int rem = i - sl * per_slot;
+            const int pos = rem / N_CLS, cls = rem - pos * N_CLS;
+            const int h = pos >> 3, k = pos & 7;
+            u64 v = 0;
+            if (m < nm && h < H) {
+                const int w = a.l_cyc + ((sl * 8 + k) * ST4_ROWS + cls * 3) * a.Hs + h;
+                const u32 c0 = lds[w], c1 = lds[w + a.Hs], c2 = lds[w + 2 * a.Hs];
+                const u32 M = (1u << ST4_CNT_BITS) - 1u;
+                const u64 cnt = (u64)((c0 & M) + (c1 & M) + (c2 & M)), q20 = (u64)((c1 & M) + (c2 & M)), q30 = (u64)(c2 & M);
+                const u64 qs = (u64)((c0 >> ST4_CNT_BITS) + (c1 >> ST4_CNT_BITS) + (c2 >> ST4_CNT_BITS));
+                v = cnt | (q20 << CYC_Q20_SHIFT) | (q30 << CYC_Q30_SHIFT) | (qs << CYC_QSUM_SHIFT);
+            }
+            const int o = 2 * ((2 * m + sl) * per_slot + rem);
+            slab[o] = (u32)v;
+            slab[o + 1] = (u32)(v >> 32);
+        }
+        for (int i = tid; i < 2 * KMER_BINS; i += nt) {
+            u32 v = 0;
+            if (m < nm)
+                for (int c = 0; c < KC; c++) v += lds[a.l_kmer + i * KC + c];
+            slab[2 * n_cyc + 2 * m * KMER_BINS + i] = v;
+        }
+        for (int i = tid; i < 2 * 128; i += nt) {
+            u32 v = 0;
+            if (m < nm && (i & 127))   // bin 0 of a slot collects the "no base" characters of the fast path
+                for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
+            slab[2 * n_cyc + 4 * KMER_BINS + 2 * m * 128 + i] = v;
+        }
+        block_sync();
     }
 }
 

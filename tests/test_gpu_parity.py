@@ -1120,3 +1120,28 @@ def test_gpu_plans_agree(paired, L, monkeypatch):
 
 
 
+
+
+@pytest.mark.gpu
+def test_gpu_stats_cells_at_their_capacity():
+    """Every Stats workgroup of a launch with as many units as its 12-bit cell counts hold (4095), all of them identical reads
+    with the largest quality character: each workgroup's [count : 12 | quality sum : 20] cells end at 4095 | 93 * 4095.
+    Records + every counter against the oracle.  (tests/test_hostsim_parity.py::test_sim_stats_cells_at_their_capacity: one
+    workgroup on the emulator)"""
+    import test_hostsim_parity as hs
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.dup_enabled = 0
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n = 2 * cus * 4095            # two workgroups per CU
+    d = hs._saturating_reads(n)
+    o = oraclelib.Oracle(p)
+    g = engines.gpu_engine(p)
+    ro, rg = o.process(d["seq1"], d["qual1"], d["len1"]), g.process(d["seq1"], d["qual1"], d["len1"])
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    assert ro[0].tobytes() == rg[0].tobytes()
+    assert np.array_equal(co, cg), int((co != cg).sum())

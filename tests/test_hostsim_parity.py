@@ -908,3 +908,30 @@ def test_sim_deflate_bgzf_members_round_trip():
     """fastp_gpu_deflate_bgzf: every member inflates (gzip, zlib per block, our own BGZF inflate) to the text"""
     import format_util
     _deflate_case(engines.sim_engine, format_util.NumpyMem())
+
+
+def _saturating_reads(n, L=150):
+    """n identical reads: every base an A, every quality '~' (the largest character the packers take): each unit adds 1 and
+    93 to the SAME cell of every cycle - what fills a workgroup's [count : 12 | quality sum : 20] cells of the Stats kernel"""
+    stride = (L + 7) // 8 * 8
+    seq = np.zeros((n, stride), dtype=np.uint8)
+    qual = np.zeros((n, stride), dtype=np.uint8)
+    seq[:, :L] = ord("A")
+    qual[:, :L] = ord("~")
+    return {"seq1": seq, "qual1": qual, "len1": np.full(n, L, dtype=np.int32)}
+
+
+def test_sim_stats_cells_at_their_capacity(monkeypatch):
+    """ONE Stats workgroup with the 4095 units its 12-bit cell counts hold, all of them in the same cells with the largest
+    quality sum (93 * 4095 < 2^20), then 4096 units (the launch is cut into two workgroups' ranges)"""
+    monkeypatch.setenv("FASTP_SIM_CUS", "1")
+    monkeypatch.setenv("FASTP_GPU_STATS_BLOCKS_PER_CU", "1")
+    p = abi.default_params(False, 150)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.dup_enabled = 0
+    for n in (4095, 4096):
+        d = _saturating_reads(n)
+        ro, rg, co, cg = _both(p, d, False)
+        assert ro[0].tobytes() == rg[0].tobytes()
+        assert np.array_equal(co, cg), int((co != cg).sum())
