@@ -347,8 +347,11 @@ def other_configs(dev):
         eng.synchronize()
         dt = (time.perf_counter() - t0) / steps
         reads = n * (2 if paired else 1)
+        # the HBM roofline of the whole step (kernels + folds + Duplicate's tail): algorithmic bytes of SURVEY.md 8(d) / wall / 8 TB/s
+        bpp = algorithmic_bytes_per_pair(Lr) if paired else algorithmic_bytes_per_pair(Lr) // 2
         res.append({"config": name, "units_per_step": n, "ms_per_step": round(dt * 1e3, 3),
-                    "Mreads_per_s": round(reads / dt / 1e6, 1), "plan": eng.plan()})
+                    "Mreads_per_s": round(reads / dt / 1e6, 1), "plan": eng.plan(),
+                    "algorithmic_GBps": round(n * bpp / dt / 1e9, 1), "frac": round(n * bpp / dt / 1e9 / HBM_PEAK_GBPS, 4)})
         eng.close()
         del bufs, r1, r2, pr
         torch.cuda.empty_cache()
@@ -370,6 +373,25 @@ def other_configs(dev):
     p.adapter_seq_r2 = b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
     p.cut_right = 1
     run("PE 2x150 --adapter_sequence/--adapter_sequence_r2 + --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
+    # everyday flags that move kept bases: -f / a UMI are on the lane plan since round 5 (the same front for every read that is
+    # written out); -c and --merge still take the tile kernel (fused plan) - listed so that the difference is on the line
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.trim_front1 = p.trim_front2 = 5
+    run("PE 2x150 -f 5 -F 5 --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.umi_len1, p.umi_len2 = 8, 0
+    run("PE 2x150 --umi --umi_loc read1 --umi_len 8 --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.correction = 1
+    run("PE 2x150 -c --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.merge = 1
+    p.correction = 1
+    run("PE 2x150 --merge --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
     # letters outside ACGTN (soft-masked reads): one pair in a thousand goes through the text kernel, the rest through the lane plan
     p = abi.default_params(True, 150)
     p.cut_right = 1

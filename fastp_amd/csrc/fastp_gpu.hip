@@ -371,7 +371,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
-    if (!p.stats_one_pass || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
+    if (!(p.stats_one_pass || p.front_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
     if ((p.has_a1 && p.alen1 > 64) || (p.has_a2 && p.alen2 > 64)) return false;   // the lane kernel keeps an adapter in four uniform words
     if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
     if (p.cut_right && (p.wR < 1 || p.wR > 8)) return false;
@@ -393,7 +393,7 @@ static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
     return paired ? fq_lane_kernel<16, 4, 3, true, EXT> : fq_lane_kernel<16, 4, 3, false, EXT>;
 }
 // ext: adapter sequences, polyX trimming or the complexity filter are on (the instantiation that carries those steps)
-static bool lane_ext(const DevParams& p) { return p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter; }
+static bool lane_ext(const DevParams& p) { return p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter || p.front_lane; }
 static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, bool ext) {
     return ext ? lane_kernel_pick<true>(swm, B, paired) : lane_kernel_pick<false>(swm, B, paired);
 }
@@ -440,7 +440,10 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     const int lds_kb_default = (int)(prop.sharedMemPerBlock / 1024) >= 160 ? 160 : (int)(prop.sharedMemPerBlock / 1024);
     // The split plan (per-read kernel as 256-lane workgroups, several per CU, + the streaming Stats kernel) whenever no
     // option moves or edits a kept base; FASTP_GPU_SPLIT=0 keeps Stats inside the one-workgroup-per-CU fused kernel.
-    ctx->split = ctx->dp.stats_one_pass && env_int("FASTP_GPU_SPLIT", 1) != 0;
+    // the Stats kernel as its own launch: options that leave every kept base where it was, or (lane plan only) move it by the
+    // same front for every read that is written out (DevParams::front_lane)
+    const bool lane_wanted = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
+    ctx->split = (ctx->dp.stats_one_pass || (ctx->dp.front_lane && lane_wanted)) && env_int("FASTP_GPU_SPLIT", 1) != 0;
     ctx->cfg.split = ctx->split ? 1 : 0;
     ctx->cfg.threads = env_int("FASTP_GPU_THREADS", ctx->split ? 256 : 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
@@ -488,7 +491,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
         ctx->st_H = ctx->dp.qw_g / 2;
-        ctx->st_form = env_int("FASTP_GPU_STATS_V", 4) == 3 ? 3 : 4;
+        ctx->st_form = (env_int("FASTP_GPU_STATS_V", 4) == 3 && !ctx->dp.front_lane) ? 3 : 4;   // (a front: form 4 only)
         if (ctx->st_form == 4) {
             // round 5's form: [2][8][ST4_ROWS][Hs] u32 per-cycle cells of ONE mate, KC copies of its 5-mer counters, its histogram
             ctx->st_kc = env_int("FASTP_GPU_STATS_KC", 4);
@@ -1281,6 +1284,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (st_grid > ctx->st_max_grid) return fail(ctx, FASTP_GPU_E_INVALID, "launch too large for the Stats kernel's slabs");
         sa.form = ctx->st_form;
         sa.kc = ctx->st_kc;
+        if (ctx->dp.front_lane) { sa.front[0] = ctx->dp.lane_front1; sa.front[1] = ctx->dp.lane_front2; }
         for (int m = 0; m < 2; m++) { sa.seq[m] = a.seq[m]; sa.qual[m] = a.qual[m]; sa.swin[m] = ctx->d_swin[m]; }
         sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut; sa.l_mt = ctx->st_l_mt;
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
@@ -1302,7 +1306,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     memset(&r, 0, sizeof(r));
     r.L = ctx->L;
     r.isize_max = ctx->dp.isize_max;
-    r.one_pass = ctx->dp.stats_one_pass;
+    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && ctx->dp.front_lane);
+    if (ctx->split && ctx->dp.front_lane) { r.front[0] = ctx->dp.lane_front1; r.front[1] = ctx->dp.lane_front2; }
     r.ctr = ctx->d_ctr;
     r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
     r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;

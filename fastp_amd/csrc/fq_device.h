@@ -1929,20 +1929,23 @@ FQ_DEV void write_dup_pos(const KernelArgs& a, u32* lds, int u, int gp) {
 // convention of phase_stats_both (every read counts in its PRE slot, a read that is written out also in its POST
 // slot with its kept length) - and the unit's entry of the swin arrays the Stats kernel reads.  The addresses are
 // uniform: the compiler folds each of these into one LDS atomic per wavefront.
-FQ_DEV void split_stat_reads(const KernelArgs& a, u32* misc, int gp, u32 sw1, u32 sw2) {
+// (kept1 / kept2: the lengths of the reads that are written out - what swin's upper half holds unless the option set has a
+// front, DevParams::front_lane: then it holds the END of the kept range, front + length)
+FQ_DEV void split_stat_reads(const KernelArgs& a, u32* misc, int gp, u32 sw1, u32 sw2, u32 kept1, u32 kept2) {
     lds_add_u32(&misc[MISC_STAT_READS + 0], 1u);
     lds_add_u32(&misc[MISC_STAT_LENSUM + 0], sw1 & 0xFFFFu);
     lds_add_u32(&misc[MISC_STAT_READS + 1], (sw1 >> 16) ? 1u : 0u);
-    lds_add_u32(&misc[MISC_STAT_LENSUM + 1], sw1 >> 16);
+    lds_add_u32(&misc[MISC_STAT_LENSUM + 1], kept1);
     a.swin_out[0][gp] = sw1;
     if (a.p.paired) {
         lds_add_u32(&misc[MISC_STAT_READS + 2], 1u);
         lds_add_u32(&misc[MISC_STAT_LENSUM + 2], sw2 & 0xFFFFu);
         lds_add_u32(&misc[MISC_STAT_READS + 3], (sw2 >> 16) ? 1u : 0u);
-        lds_add_u32(&misc[MISC_STAT_LENSUM + 3], sw2 >> 16);
+        lds_add_u32(&misc[MISC_STAT_LENSUM + 3], kept2);
         a.swin_out[1][gp] = sw2;
     }
 }
+FQ_DEV void split_stat_reads(const KernelArgs& a, u32* misc, int gp, u32 sw1, u32 sw2) { split_stat_reads(a, misc, gp, sw1, sw2, sw1 >> 16, sw2 >> 16); }
 
 // Phase E3 (paired): lane = one pair.  Filter::passFilter and routing, peprocessor.cpp:563-591.
 // passFilter (filter.cpp:15-66) with the two LUT entries of the read's length already in registers
@@ -2008,7 +2011,10 @@ FQ_DEV void phase_filter_pe_plain(const KernelArgs& a, u32* lds, int tile_first,
         const u32 sw2 = rl2 | ((f2 & RS_STAT_POST) ? (u32)len2 << 16 : 0u);
         lds[L.swin + R1] = sw1;
         lds[L.swin + R2] = sw2;
-        if (a.split) split_stat_reads(a, misc, gp, sw1, sw2);
+        if (a.split && p.front_lane)   // the Stats kernel's kept range ends at front + length (fq_stats.h)
+            split_stat_reads(a, misc, gp, rl1 | ((f1 & RS_STAT_POST) ? (front1 + (u32)len1) << 16 : 0u), rl2 | ((f2 & RS_STAT_POST) ? (front2 + (u32)len2) << 16 : 0u),
+                             (f1 & RS_STAT_POST) ? (u32)len1 : 0u, (f2 & RS_STAT_POST) ? (u32)len2 : 0u);
+        else if (a.split) split_stat_reads(a, misc, gp, sw1, sw2);
         u32* o1 = a.res[0] + (size_t)gp * 3;
         u32* o2 = a.res[1] + (size_t)gp * 3;
         o1[0] = (front1 & 0xFFFFu) | ((u32)len1 << 16);
@@ -2157,7 +2163,10 @@ FQ_DEV void phase_filter_se(const KernelArgs& a, u32* lds, int tile_first, int t
         if (!dedup_out && alive && code == 0) flags[R] |= RS_STAT_POST;  // :280-286
         const u32 sw = (u32)lds_i(lds, L.rlen0)[R] | ((flags[R] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R] << 16 : 0u);
         lds[L.swin + R] = sw;
-        if (a.split) split_stat_reads(a, misc, gp, sw, 0u);
+        if (a.split && p.front_lane) {
+            const u32 kept = (flags[R] & RS_STAT_POST) ? (u32)lds_i(lds, L.len)[R] : 0u;
+            split_stat_reads(a, misc, gp, (u32)lds_i(lds, L.rlen0)[R] | (kept ? ((u32)lds_i(lds, L.front)[R] + kept) << 16 : 0u), 0u, kept, 0u);
+        } else if (a.split) split_stat_reads(a, misc, gp, sw, 0u);
         write_dup_pos(a, lds, R, gp);
         write_read_result(a, lds, 0, R, gp);
     }
@@ -2420,6 +2429,8 @@ struct ReduceArgs {
     int parts;
     int isize_max;
     int one_pass;      // slabs hold kept (POST slot) / dropped (PRE slot): PRE = kept + dropped
+    int front[2];      // one_pass with a uniform front trim (DevParams::front_lane): the kept bases of mate m sit at their
+                       // ORIGINAL cycle; in the POST Stats a read starts behind its front
     int64_t* ctr;      // counter block
     // fastp_gpu_counter_layout offsets
     int64_t o_filter, o_adapter_reads, o_adapter_bases, o_polyx_reads, o_polyx_bases, o_correction,
@@ -2471,12 +2482,16 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
         const int bin = (int)sym_bin((u32)cls);  // 'A'&7=1 'T'&7=4 'C'&7=3 'G'&7=7 'N'&7=6
         for (int tgt = slot; tgt >= 0; tgt -= 1) {
             int64_t* st = r.ctr + r.o_stats[tgt] + r.st_cycle;  // Stats::mCycleBuffer layout (stats.cpp:54-63)
-            if (q30) g_atomic_add_i64(&st[(0 * 8 + bin) * CC + c], q30);  // mCycleQ30Bases
-            if (q20) g_atomic_add_i64(&st[(1 * 8 + bin) * CC + c], q20);  // mCycleQ20Bases
-            g_atomic_add_i64(&st[(2 * 8 + bin) * CC + c], cnt);           // mCycleBaseContents
-            g_atomic_add_i64(&st[(3 * 8 + bin) * CC + c], qs);            // mCycleBaseQual
-            g_atomic_add_i64(&st[32 * CC + c], cnt);                      // mCycleTotalBase
-            g_atomic_add_i64(&st[33 * CC + c], qs);                       // mCycleTotalQual
+            // the POST Stats of a front-trimmed mate: cycle c of the original read is cycle c - front of the read that is written out
+            const int cc = (r.one_pass && (tgt & 1)) ? c - r.front[tgt >> 1] : c;
+            if (cc >= 0) {
+                if (q30) g_atomic_add_i64(&st[(0 * 8 + bin) * CC + cc], q30);  // mCycleQ30Bases
+                if (q20) g_atomic_add_i64(&st[(1 * 8 + bin) * CC + cc], q20);  // mCycleQ20Bases
+                g_atomic_add_i64(&st[(2 * 8 + bin) * CC + cc], cnt);           // mCycleBaseContents
+                g_atomic_add_i64(&st[(3 * 8 + bin) * CC + cc], qs);            // mCycleBaseQual
+                g_atomic_add_i64(&st[32 * CC + cc], cnt);                      // mCycleTotalBase
+                g_atomic_add_i64(&st[33 * CC + cc], qs);                       // mCycleTotalQual
+            }
             if (!(r.one_pass && (tgt & 1))) break;  // kept -> also the PRE Stats of the mate
         }
         return;

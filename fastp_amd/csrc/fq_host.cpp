@@ -154,6 +154,14 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     p.umi_skip = in.umi_skip > 0 ? in.umi_skip : 0;
     p.need_overlap = p.paired && (p.adapter_enabled || p.correction);
     p.stats_one_pass = !p.correction && !p.merge && !p.cut_front && !p.trim_front1 && !p.trim_front2 && !p.umi_len1 && !p.umi_len2;
+    // Front trims the lane plan takes: what moves a kept base is the same number of positions for every read that is written
+    // out.  -f / -F are (Filter::trimAndCut :74-77: a shorter read is NULL); Read::trimFront of the UMI step is
+    // min(length() - 1, umi + skip) (read.cpp:69-73) - a read too short for its UMI is left with one base, which no run with a
+    // length filter of two or more writes out.  --cut_front moves every read by its own amount: the tile kernels.
+    const bool any_umi = p.umi_len1 > 0 || p.umi_len2 > 0;
+    p.front_lane = !p.stats_one_pass && !p.correction && !p.merge && !p.cut_front && (!any_umi || (p.length_filter && p.length_required >= 2));
+    p.lane_front1 = (p.umi_len1 > 0 ? p.umi_len1 + p.umi_skip : 0) + p.trim_front1;
+    p.lane_front2 = p.paired ? (p.umi_len2 > 0 ? p.umi_len2 + p.umi_skip : 0) + p.trim_front2 : 0;
 
     // ---- overrepresentation analysis seeds -> hash tables ----
     p.overrep = in.overrep_enabled != 0;

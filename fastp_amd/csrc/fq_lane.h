@@ -391,6 +391,51 @@ FQ_DEV bool lane_trim_and_cut(const KernelArgs& a, const LaneRead<SWM>& r, const
     return true;
 }
 
+// Filter::trimAndCut (filter.cpp:68-207) with a front trim and / or behind a UMI (DevParams::front_lane: no cut_front): the read
+// as trimAndCut sees it is [u, u + l) of the row - u = what Read::trimFront took for the UMI (read.cpp:69-73) - `front` / `tail`
+// are -f / -t.  out_front = frontTrimmed (without u), out_len the new length; false = NULL.  trim_and_cut() of the tile kernel
+// on the register masks.
+template <int SWM>
+FQ_DEV bool lane_trim_and_cut_front(const KernelArgs& a, const LaneRead<SWM>& r, const u8* qrow, int u, int l, int front, int tail, int& out_front,
+                                    int& out_len) {
+    const DevParams& p = a.p;
+    const bool enT = p.cut_tail, enR = p.cut_right;
+    out_front = 0;
+    out_len = l;
+    if (front == 0 && tail == 0 && !enT && !enR) return true;   // :71-72
+    int rlen = l - front - tail;
+    if (rlen < 0) return false;                                 // :76-77
+    if (!enT && !enR) {                                         // :79-89
+        out_front = front;
+        out_len = rlen;
+        return true;
+    }
+    if (enR) {                                                  // :130-163
+        const int w = p.wR;
+        if (l - front - tail - w <= 0) return false;
+        const int end = l - tail - w;
+        int s = mask_first<SWM / 2>(r.bad, u + front, u + end, true) - u;   // first window below the threshold
+        if (s < end) {                                          // foundLowQualWindow: while (s < l-1 && qual[s] >= 33+Q) s++
+            const u32 qmin = (u32)imin(imax(p.qRmin, 0), 127);
+            while (s < l - 1 && ((u32)qrow[u + s] & 0x7Fu) >= qmin) s++;
+            rlen = s - front;
+        }
+    }
+    if (!enR && enT) {                                          // :166-194
+        const int w = p.wT;
+        if (l - front - tail - w <= 0) return false;
+        const int sp = mask_last<SWM / 2>(r.bad, u + front + 1, u + l - tail - w + 1, false) - u;   // none: front
+        int t = sp + w - 1;
+        if (t < l - 1) t = t - w + 1;
+        while (t >= 0 && ((u32)qrow[u + t] & 0x80u)) t--;       // while (t >= 0 && seq[t] == 'N') t--
+        rlen = t - front + 1;
+    }
+    if (rlen <= 0 || front >= l - 1) return false;              // :196-197
+    out_front = front;
+    out_len = rlen;
+    return true;
+}
+
 // word idx of a register array, idx per lane (0 outside the array): a compare + select per word
 template <int N>
 FQ_DEV u32 lane_word_at(const u32 (&a)[N], int idx) {
@@ -575,6 +620,17 @@ FQ_DEV void lane_metrics_stage(const KernelArgs& a, const u32* row, const LaneRe
     low = len - (int)ge;
     nb = lane_count_n<SWM>(r, len);
 }
+// The same with a front (DevParams::front_lane): the window is [f, f + len) of the row = the prefix up to f + len minus the
+// prefix up to f (the N count comes from the N mask, which has been moved down by f with the bases).
+template <int SWM>
+FQ_DEV void lane_metrics_stage_front(const KernelArgs& a, const u32* row, const LaneRead<SWM>& r, int f, int len, int& tot, int& low, int& nb) {
+    int t1, l1, n1, t0, l0, n0;
+    lane_metrics_stage<SWM>(a, row, r, f + len, t1, l1, n1);   // tot = sum - 33 x, low = x - ge
+    lane_metrics_stage<SWM>(a, row, r, f, t0, l0, n0);
+    tot = t1 - t0;
+    low = l1 - l0;
+    nb = lane_count_n<SWM>(r, len);
+}
 // read 1 of a pair: partial sums + the cut word
 struct LaneCutWord {
     u64 v[4];   // the 32 quality bytes of the word the window's end cuts
@@ -610,6 +666,17 @@ FQ_DEV void lane_metrics_part(const KernelArgs& a, const LaneRead<SWM>& r, const
     }
     tot = (int)((acc & 0xFFFFu) + t) - 33 * len;
     low = len - (int)((acc >> 16) + ge);
+    nb = lane_count_n<SWM>(r, len);
+}
+
+template <int SWM>
+FQ_DEV void lane_metrics_part_front(const KernelArgs& a, const LaneRead<SWM>& r, const u32* part, int lane, const LaneCutWord& cwe, const LaneCutWord& cwf,
+                                    int f, int len, int& tot, int& low, int& nb) {
+    int t1, l1, n1, t0, l0, n0;
+    lane_metrics_part<SWM>(a, r, part, lane, cwe, f + len, t1, l1, n1);
+    lane_metrics_part<SWM>(a, r, part, lane, cwf, f, t0, l0, n0);
+    tot = t1 - t0;
+    low = l1 - l0;
     nb = lane_count_n<SWM>(r, len);
 }
 
@@ -903,6 +970,29 @@ FQ_DEV void lane_metrics_staged(const KernelArgs& a, u32* stage, const u32* qual
     nb = (int)n;
 }
 
+// UMI front trim (umiprocessor.cpp:19-49 -> Read::trimFront, read.cpp:69-73), then Filter::trimAndCut with -f / -t: phase_trim of
+// the tile kernel.  r.len = the new length (the length behind the UMI for a NULL read), fr / ft as in lane_body.
+template <int SWM>
+FQ_DEV void lane_front_trim(const KernelArgs& a, LaneRead<SWM>& r, const u8* qrow, int umi, int front, int tail, int& fr, int& ft) {
+    int u = 0, l = r.rl0;
+    if (umi > 0) {   // Read::trimFront(min(len, umi) + skip): len = min(length() - 1, len)
+        int t = imin(l, umi) + a.p.umi_skip;
+        t = imin(l - 1, t);
+        if (t > 0) { u = t; l -= t; }
+    }
+    int f2 = 0, l2 = l;
+    if (lane_trim_and_cut_front<SWM>(a, r, qrow, u, l, front, tail, f2, l2)) {
+        fr = u + f2;
+        ft = f2;
+        r.len = l2;
+    } else {
+        fr = u;
+        ft = 0;
+        r.len = l;
+        r.flags |= RS_NULL;
+    }
+}
+
 FQ_DEV void lane_claim(const KernelArgs& a, int gp, int tl, const u64* h, int B, u32& won) {
     // Duplicate's claim (dup_claim_issue / dup_claim_collect of the tile kernel) for this unit
     const u64 words = a.dup_bits >> 5;
@@ -913,6 +1003,22 @@ FQ_DEV void lane_claim(const KernelArgs& a, int gp, int tl, const u64* h, int B,
         const u32 bit = 1u << (pos & 31);
         const u32 old = g_atomic_or_u32(&a.dup_bitmap[(size_t)i * words + (pos >> 5)], bit);
         if (!(old & bit)) won |= 1u << i;
+    }
+}
+
+// split_stat_reads() with a front: the swin word holds the END of the kept range, the Stats objects' length sums the kept LENGTH
+FQ_DEV void lane_stat_reads_front(const KernelArgs& a, u32* misc, int gp, u32 sw1, u32 sw2, int kept1, int kept2) {
+    lds_add_u32(&misc[MISC_STAT_READS + 0], 1u);
+    lds_add_u32(&misc[MISC_STAT_LENSUM + 0], sw1 & 0xFFFFu);
+    lds_add_u32(&misc[MISC_STAT_READS + 1], (sw1 >> 16) ? 1u : 0u);
+    lds_add_u32(&misc[MISC_STAT_LENSUM + 1], (u32)kept1);
+    a.swin_out[0][gp] = sw1;
+    if (a.p.paired) {
+        lds_add_u32(&misc[MISC_STAT_READS + 2], 1u);
+        lds_add_u32(&misc[MISC_STAT_LENSUM + 2], sw2 & 0xFFFFu);
+        lds_add_u32(&misc[MISC_STAT_READS + 3], (sw2 >> 16) ? 1u : 0u);
+        lds_add_u32(&misc[MISC_STAT_LENSUM + 3], (u32)kept2);
+        a.swin_out[1][gp] = sw2;
     }
 }
 
@@ -956,6 +1062,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
 #pragma unroll
     for (int w = 0; w < LANE_ADAPTER_WORDS; w++) { aw1[w] = p.a1w[w]; aw2[w] = p.a2w[w]; }
     const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
+    const bool FR = EXT && p.front_lane != 0;         // (uniform) -f / -F / a UMI at the reads' start
     const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
@@ -975,12 +1082,18 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         const int g = valid ? gp : 0;
         LaneRead<SWM> r1, r2;
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
+        // DevParams::front_lane (EXT): fr = the read's front in the row (UMI + -f), ft = trimAndCut's part of it (frontTrimmed)
+        int fr1 = 0, ft1 = 0, fr2 = 0, ft2 = 0;
         lane_load_read<SWM, PAIRED>(a, stage, part, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, thr4, r1);
-        if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
+        if (FR) {
+            if (valid) lane_front_trim<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.umi_len1, p.trim_front1, p.trim_tail1, fr1, ft1);
+        } else if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
         if (PAIRED) {
             lane_load_read<SWM, false>(a, stage, part, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, thr4, r2);
-            if (valid && !lane_trim_and_cut<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
+            if (FR) {
+                if (valid) lane_front_trim<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.umi_len2, p.trim_front2, p.trim_tail2, fr2, ft2);
+            } else if (valid && !lane_trim_and_cut<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
             sched_fence();
         }
         if (a.dupflag && valid && a.dupflag[g]) {   // --dedup: Duplicate::checkPair/checkRead already ran for this batch
@@ -1002,6 +1115,14 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 if (a.dup_pos)
                     for (int i = 0; i < B; i++) a.dup_pos[(size_t)g * B + i] = hs[i];
                 if (claim) lane_claim(a, g, r1.rl0 + (PAIRED ? r2.rl0 : 0), hs, B, won);
+            }
+        }
+        if (FR) {   // from here on a read starts at base 0 of its registers (Duplicate hashed the original read, duplicate.cpp:111-148)
+            base_shift_down<SWM>(r1.s, (u32)fr1);
+            bit_shift_down<SWM / 2>(r1.n, (u32)fr1);
+            if (PAIRED) {
+                base_shift_down<SWM>(r2.s, (u32)fr2);
+                bit_shift_down<SWM / 2>(r2.n, (u32)fr2);
             }
         }
         // ---- PolyX::trimPolyG ----
@@ -1079,7 +1200,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             bool isize_done = false;
             if (both && thread0) {   // statInsertSize (peprocessor.cpp:710-723)
                 int isize = p.isize_max;
-                if (ovl) isize = ov_off > 0 ? cur1 + cur2 - ov_len : ov_len;
+                if (ovl) isize = (ov_off > 0 ? cur1 + cur2 - ov_len : ov_len) + ft1 + ft2;
                 if (isize > p.isize_max) isize = p.isize_max;
                 if (isize >= 0) lds_add_u32(&misc[MISC_ISIZE + isize], 1u);
                 isize_done = true;
@@ -1088,7 +1209,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 const bool adapt = both && p.need_overlap && p.adapter_enabled;   // per lane; the sequence scans below are wave collectives
                 bool trimmed = false;
                 if (adapt && ovl && ov_off < 0) {   // trimByOverlapAnalysis adaptertrimmer.cpp:17-46
-                    const int len1 = imin(cur1, ov_len), len2 = imin(cur2, ov_len);
+                    const int len1 = imin(cur1, ov_len + ft2), len2 = imin(cur2, ov_len + ft1);
                     apos1 = (u32)len1; alen1 = (u32)(cur1 - len1);
                     apos2 = (u32)len2; alen2 = (u32)(cur2 - len2);
                     lds_add_u32(&misc[MISC_ADAPTER_BASES], (u32)((cur1 - len1) + (cur2 - len2)));
@@ -1170,7 +1291,17 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
 #else
         if (!(skip & 8u)) {
             const u32* row = stage + lane * p.qw_g;   // the quality row of the read that was staged last
-            if (PAIRED) {
+            if (FR) {   // (uniform) the windows start at the reads' fronts
+                if (PAIRED) {
+                    LaneCutWord c1e, c1f;
+                    lane_cut_fetch(a, a.qual[0], g, a1, fr1 + r1.len, c1e);
+                    lane_cut_fetch(a, a.qual[0], g, a1, fr1, c1f);
+                    lane_metrics_stage_front<SWM>(a, row, r2, fr2, r2.len, tot2, low2, nb2);
+                    lane_metrics_part_front<SWM>(a, r1, part, lane, c1e, c1f, fr1, r1.len, tot1, low1, nb1);
+                } else {
+                    lane_metrics_stage_front<SWM>(a, row, r1, fr1, r1.len, tot1, low1, nb1);
+                }
+            } else if (PAIRED) {
                 LaneCutWord c1;
                 lane_cut_fetch(a, a.qual[0], g, a1, r1.len, c1);
                 lane_metrics_stage<SWM>(a, row, r2, r2.len, tot2, low2, nb2);      // (read 1's cut word is on its way meanwhile)
@@ -1198,15 +1329,18 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
             const bool dedup_out = p.dedup && (r1.flags & RS_DUP);
             const bool post = !dedup_out && a1 && a2 && code1 == 0 && code2 == 0;   // written to out1 / out2 (:577-591)
-            const u32 sw1 = (u32)r1.rl0 | (post ? (u32)r1.len << 16 : 0u);
-            split_stat_reads(a, misc, g, sw1, PAIRED ? ((u32)r2.rl0 | (post ? (u32)r2.len << 16 : 0u)) : 0u);
+            // what the Stats kernel reads: original length | END of the kept range << 16 (the range starts at the mate's front)
+            const u32 sw1 = (u32)r1.rl0 | (post ? (u32)(fr1 + r1.len) << 16 : 0u);
+            const u32 sw2 = PAIRED ? ((u32)r2.rl0 | (post ? (u32)(fr2 + r2.len) << 16 : 0u)) : 0u;
+            if (FR) lane_stat_reads_front(a, misc, g, sw1, sw2, post ? r1.len : 0, post ? r2.len : 0);
+            else split_stat_reads(a, misc, g, sw1, sw2);
             u32* o1 = a.res[0] + (size_t)g * 3;
-            o1[0] = (u32)r1.len << 16;
+            o1[0] = ((u32)fr1 & 0xFFFFu) | ((u32)r1.len << 16);
             o1[1] = ((u32)code1 & 0xFFu) | ((r1.flags & 0xFFu) << 8) | (apos1 << 16);
             o1[2] = alen1 & 0xFFFFu;
             if (PAIRED) {
                 u32* o2 = a.res[1] + (size_t)g * 3;
-                o2[0] = (u32)r2.len << 16;
+                o2[0] = ((u32)fr2 & 0xFFFFu) | ((u32)r2.len << 16);
                 o2[1] = ((u32)code2 & 0xFFu) | ((r2.flags & 0xFFu) << 8) | (apos2 << 16);
                 o2[2] = alen2 & 0xFFFFu;
             }

@@ -50,6 +50,10 @@ struct StatsArgs {
     u32 debug_skip;         // profiling only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
     int form;               // 4: u32 cells, one mate's tables at a time (stats_body4, round 5); 3: round 3's packed u64 cells (stats_body)
     int kc;                 // form 4: copies of the 5-mer table (1, 2 or 4)
+    int front[2];           // form 4, DevParams::front_lane: the kept bases of a read of mate m are [front[m], swin >> 16) - the same
+                            // front for every read that is written out; they are counted at their ORIGINAL cycle (the slab fold
+                            // moves the POST Stats, reduce_body); the 5-mers that end on the first four kept bases exist in the
+                            // original read only (stats.cpp:224-227: five bases of the read the Stats object is given)
 };
 
 enum { ST_QH_COPIES = 8 };
@@ -68,7 +72,7 @@ struct StatsItem {
 // of the range is simply the it-th 8-byte word behind `qual`.
 FQ_DEV void stats_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, int it, bool tv, StatsItem& s) {
     const u32 ur = fastdiv((u32)(tv ? it : 0), a.magic_H);
-    s.h = (tv ? it : 0) - (int)ur * a.H;
+    s.h = (tv ? it : 0) - (int)mul24(ur, (u32)a.H);     // (units < 2^14, H < 2^8: the full-rate 24-bit multiply)
     u32 sw = 0;
     s.q0 = s.q1 = s.qp = s.codes = s.prev8 = 0;
     if (tv) {   // the item's 8 quality bytes and 8 bases, the 4 of each before them - all loads independent of each other:
@@ -77,7 +81,7 @@ FQ_DEV void stats_fetch(const StatsArgs& a, const u32* qual, const u32* seq, con
         const u64 qq = ((const u64*)qual)[(u32)it];
         s.q0 = (u32)qq;
         s.q1 = (u32)(qq >> 32);
-        const u32 sb = ur * (u32)(a.sw_g * 4) + 2u * (u32)s.h;   // byte of the row's packed bases
+        const u32 sb = mul24(ur, (u32)(a.sw_g * 4)) + 2u * (u32)s.h;   // byte of the row's packed bases
         s.codes = (u32)*(const u16*)((const u8*)seq + sb);
         if (s.h > 0) {
             s.qp = qual[2u * (u32)it - 1u];
@@ -273,7 +277,7 @@ FQ_DEV u32 stats4_level_of(u32 q) { return (q >= 53u ? 1u : 0u) + (q >= 63u ? 1u
 
 // an item with an N among its 8 bases or the 4 before: base by base (dense pass over the work list), one mate's tables
 template <int KC>
-FQ_DEV void stats4_item_general(const StatsArgs* ap, u32* lds, int h, int rl0, int lk, u32 q0, u32 q1, u32 qp, u32 codes, u32 prev8, int lane) {
+FQ_DEV void stats4_item_general(const StatsArgs* ap, u32* lds, int F, int h, int rl0, int lk, u32 q0, u32 q1, u32 qp, u32 codes, u32 prev8, int lane) {
     const StatsArgs& a = *ap;
     u32* cyc = lds + a.l_cyc;
     const u32 nb0 = (q0 >> 7) & 0x01010101u, nb1 = (q1 >> 7) & 0x01010101u, nbp = (qp >> 7) & 0x01010101u;
@@ -289,11 +293,39 @@ FQ_DEV void stats4_item_general(const StatsArgs* ap, u32* lds, int h, int rl0, i
         const u32 q = ((k < 4 ? q0 : q1) >> (8 * (k & 3))) & 0x7Fu;
         const bool isn = ((n12 >> (4 + k)) & 1u) != 0;
         const int cls = isn ? (int)CLS_N : (int)((codes >> (2 * k)) & 3u);
-        const int slot = j < lk ? 1 : 0;
+        const int slot = (j >= F && j < lk) ? 1 : 0;   // (5-mers of the first four kept bases: stats4_front_kmers moves them)
         lds_add_u32(&cyc[((slot * 8 + k) * ST4_ROWS + cls * 3 + (int)stats4_level_of(q)) * a.Hs + h], stats4_inc_of(q));
         lds_add_u32(&qh[(slot * 128 + (int)q) * ST_QH_COPIES], 1u);
         if (((n12 >> k) & 0x1Fu) == 0u)
             lds_add_u32(&lds[a.l_kmer + (slot * KMER_BINS + (int)((c24 >> (2 * k)) & 0x3FFu)) * KC + (lane & (KC - 1))], 1u);
+    }
+}
+
+// DevParams::front_lane: the 5-mers that end on the first four kept bases [F, F + 4) of a read that is written out were counted
+// into the kept slot like every 5-mer of a kept base (fast path and work list alike).  They are 5-mers of the ORIGINAL read
+// only - the read the POST Stats object is given starts at F, and a 5-mer needs four bases in front of it (stats.cpp:224-227) -
+// so each of them moves to the dropped slot (PRE = kept + dropped is unchanged).  One lane per read, at most four 5-mers.
+template <int KC>
+FQ_DEV void stats4_front_kmers(const StatsArgs& a, u32* lds, const u32* qual, const u32* seq, const u32* swin, int nu, int F, int tid, int nt) {
+    const int copy = tid & (KC - 1);
+    for (int u = tid; u < nu; u += nt) {
+        const u32 sw = swin[u];
+        const int lk = (int)(sw >> 16);
+        if (lk <= F) continue;                                  // not written out (or nothing kept)
+        const u8* q = (const u8*)(qual + (size_t)u * a.qw_g);
+        const u32* srow = seq + (size_t)u * a.sw_g;
+        for (int j = imax(F, 4); j < imin(F + 4, lk); j++) {    // the 5-mer of bases j - 4 .. j
+            bool ok = true;
+            u32 idx = 0;
+            for (int t = 0; t < 5; t++) {
+                const int b = j - 4 + t;
+                ok = ok && !(q[b] & 0x80u);                                            // an N: no 5-mer here in either Stats
+                idx |= ((srow[b >> 4] >> (2 * (b & 15))) & 3u) << (2 * t);             // earliest base in the low bits (reduce_body)
+            }
+            if (!ok) continue;
+            lds_add_u32(&lds[a.l_kmer + (1 * KMER_BINS + (int)idx) * KC + copy], 0xFFFFFFFFu);   // kept - 1
+            lds_add_u32(&lds[a.l_kmer + (0 * KMER_BINS + (int)idx) * KC + copy], 1u);            // dropped + 1
+        }
     }
 }
 
@@ -329,7 +361,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
                 t[0] = q < 33u ? 0u : stats4_inc_of(q);
                 t[1] = (kept ? S4 : 0u) + (q < 33u ? 0u : stats4_level_of(q) * H4);
                 t[2] = kept ? (u32)(KMER_BINS * KC * 4) : 0u;
-                t[3] = 0u;
+                t[3] = q < 33u ? 0u : 1u;                        // what a 5-mer add takes
             }
             for (int i = tid; i < 9; i += nt) {
                 lds[a.l_mt + 2 * i] = lowmask32(8 * imin(i, 4));
@@ -344,6 +376,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
             const u32 cyc_m = (u32)a.l_cyc * 4u;
             const u32 kmer_m = (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
             const u32 qh_m = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 4u;
+            const int F = a.front[m];             // (uniform; 0 unless DevParams::front_lane)
             // The wavefront's mode = the character (with its kept bit) of the first item's first base, fixed at its first
             // appearance: bases that hit it are counted per lane and added once at the end.
             u32 mode_e = 0xFFFFFFFFu, mode4 = 0;
@@ -357,11 +390,17 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
                 if (s.act && !plain) {                                  // rare: queued for the base-by-base pass
                     const u32 slot = lds_add_ret_u32(wl, 1u);
                     if (slot < (u32)a.wl_cap) wl[1 + slot] = (u32)it;
-                    else stats4_item_general<KC>(&a, lds, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);   // list full: here and now
+                    else stats4_item_general<KC>(&a, lds, F, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);   // list full: here and now
                 }
                 const int j0 = 8 * s.h;
                 const int nv = plain ? s.rl0 - j0 : 0, nk = s.lk - j0;   // not plain: eight "no base" characters
-                const u32x2 vm = mt[imax(0, imin(nv, 8))], km = mt[imax(0, imin(nk, 8))];
+                const u32x2 vm = mt[imax(0, imin(nv, 8))];
+                u32x2 km = mt[imax(0, imin(nk, 8))];
+                if (F > 0) {                                           // (uniform) kept = [F, lk): not the bytes in front of F
+                    const u32x2 fm = mt[imax(0, imin(F - j0, 8))];
+                    km.x &= ~fm.x;
+                    km.y &= ~fm.y;
+                }
                 const u32 e0 = (s.q0 | (km.x & 0x80808080u)) & vm.x, e1 = (s.q1 | (km.y & 0x80808080u)) & vm.y;
                 if (mode_e == 0xFFFFFFFFu) {                           // wave-uniform
                     const u64 cand = ballot(plain);
@@ -390,7 +429,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
                         const u32 e = bfe(kb ? e1 : e0, 8 * i, 8);
                         if (!ABL || !(a.debug_skip & 64u))
                             lds_add_u32((u32*)(ldsw + mul24(bfe(s.codes, 2 * k, 2), C4) + (cyc0 + t[i].y + (u32)k * K4)), t[i].x);
-                        const u32 one = k < 4 ? (t[i].x & hpos) : (t[i].x & 1u);
+                        const u32 one = k < 4 ? (t[i].w & hpos) : t[i].w;
                         if (!ABL || !(a.debug_skip & 128u))
                             lds_add_u32((u32*)(ldsw + ((kmer_m + t[i].z) + bfe(c24, 2 * k, 10) * (u32)(4 * KC))), one);
                         // character 0 ("no base") lands in bin 0 of the dropped slot, which the flush leaves out
@@ -410,7 +449,11 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
             for (int i = tid; i < nw; i += nt) {
                 StatsItem s;
                 stats_fetch(a, qual, seq, swin, (int)wl[1 + i], true, s);
-                stats4_item_general<KC>(&a, lds, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);
+                stats4_item_general<KC>(&a, lds, F, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);
+            }
+            if (F > 0) {   // (uniform)
+                block_sync();
+                stats4_front_kmers<KC>(a, lds, a.qual[m] + (size_t)u0 * a.qw_g, a.seq[m] + (size_t)u0 * a.sw_g, swin, nu, F, tid, nt);
             }
         }
         block_sync();

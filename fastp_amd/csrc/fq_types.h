@@ -88,6 +88,11 @@ struct DevParams {
     int overrep, overrep_sampling;  // OverrepresentedSequenceAnasysOptions (-p, -P)
     int stats_one_pass;     // no option can move or edit a kept base (no front trim, no correction):
                             // one Stats pass classifies each base as kept / dropped (see phase_stats)
+    int front_lane;         // round 5: the only such option is a front trim that is the SAME for every read that is written out
+                            // (-f / -F, the UMI of --umi_loc read1 / read2 / per_read): kept bases stay at their original
+                            // cycle in the Stats kernel's tables and the slab fold moves the POST Stats by the mate's front
+                            // (lane plan only; fq_lane.h, fq_stats.h)
+    int lane_front1, lane_front2;   // that front: UMI length + skip + --trim_front of the mate
 };
 
 // LUTs living in global memory (built on the host with the reference's own
