@@ -108,6 +108,10 @@ extern "C" __global__ void __launch_bounds__(64) fq_inflate_kernel(InflateArgs a
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     inflate_body(a, (u16*)fq_lds);
 }
+extern "C" __global__ void __launch_bounds__(256) fq_dedup_apply_kernel(DedupApplyArgs d) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    dedup_apply_body(d, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_dup_final_kernel(DupFinalArgs d) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     dup_final_body(d, fq_lds);
@@ -1043,10 +1047,21 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     const fastp_gpu_counter_layout& cl = ctx->cl;
     int rc;
 
+    // the lane kernel copies rows with 16-byte accesses: a batch whose arrays are not 16-byte aligned takes the tile kernel
+    bool use_lane = ctx->lane;
+    {
+        const void* ptrs[4] = {a.seq[0], a.qual[0], ctx->dp.paired ? a.seq[1] : a.seq[0], ctx->dp.paired ? a.qual[1] : a.qual[0]};
+        for (const void* q : ptrs) use_lane = use_lane && (((uintptr_t)q & 15u) == 0);
+    }
     // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
-    // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers, the context's own stream order
-    const bool claim_fused = ctx->dp.dup_enabled && !ctx->dp.dedup && mode == CHUNK_STREAM && !piped && ctx->dp.dup_bufnum <= 2 &&
-                             !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1) && !exact;
+    // --dedup without the hash pre-pass (round 5, lane plan, plain stream mode): the lane kernel hashes and claims as without
+    // --dedup, Duplicate's tail decides, fq_dedup_apply_kernel takes the duplicates out again before the Stats kernel counts
+    const bool dedup_folded = ctx->dp.dedup && use_lane && mode == CHUNK_STREAM && !piped && !exact && !env_int("FASTP_GPU_DUP_TABLE", 0) &&
+                              env_int("FASTP_GPU_DEDUP_FOLD", 1);
+    // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers (the lane kernel: four as well), the
+    // context's own stream order
+    const bool claim_fused = ctx->dp.dup_enabled && (!ctx->dp.dedup || dedup_folded) && mode == CHUNK_STREAM && !piped &&
+                             (ctx->dp.dup_bufnum <= 2 || dedup_folded) && !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1) && !exact;
     // the text kernel: a lane per unit with a private stretch of HBM for its text buffers; counters straight into d_ctr
     auto launch_exact = [&](int hash_only) -> int {
         ExactArgs e;
@@ -1193,7 +1208,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (!ctx->dp.dedup) return FASTP_GPU_OK;  // the records are pass 1's
         a.dup_pos = nullptr;
         a.dupflag = ctx->d_dupflag;
-    } else if (ctx->dp.dedup) {
+    } else if (ctx->dp.dedup && !dedup_folded) {
         // --dedup: hash pass -> duplicate decision -> fused kernel reads the decision
         rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
         if (rc) return rc;
@@ -1212,12 +1227,6 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     if (claim_fused) {
         rc = launch_dup(nullptr, false, nullptr, 1);
         if (rc) return rc;
-    }
-    // the lane kernel copies rows with 16-byte accesses: a batch whose arrays are not 16-byte aligned takes the tile kernel
-    bool use_lane = ctx->lane;
-    {
-        const void* ptrs[4] = {a.seq[0], a.qual[0], ctx->dp.paired ? a.seq[1] : a.seq[0], ctx->dp.paired ? a.qual[1] : a.qual[0]};
-        for (const void* q : ptrs) use_lane = use_lane && (((uintptr_t)q & 15u) == 0);
     }
     int ln_grid = 0;
     hipEvent_t e0, e1;
@@ -1253,7 +1262,28 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     // the claim ran inside that kernel: what is left of Duplicate (losers / winners / finish) needs nothing of the Stats
     // kernel and runs beside it on its own stream; the launch stream joins it before anything else touches the records
     bool dup_tail_launched = false;
-    if (ctx->split && ctx->tail && dup_prepared && n > 0) {
+    bool dedup_applied = false;
+    if (dedup_folded && dup_prepared && n > 0) {
+        // --dedup: the decisions are needed before the Stats kernel classifies a base as kept - on the launch stream
+        rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
+        if (rc) return rc;
+        rc = launch_dup(ctx->d_dupflag, false, st, 2);
+        if (rc) return rc;
+        DedupApplyArgs da;
+        memset(&da, 0, sizeof(da));
+        da.n = n;
+        da.paired = ctx->dp.paired;
+        da.dupflag = ctx->d_dupflag;
+        for (int m = 0; m < 2; m++) {
+            da.res[m] = a.res[m];
+            da.swin[m] = ctx->d_swin[m];
+            da.st_reads[m] = ctx->d_ctr + cl.stats[2 * m + 1] + cl.st_reads;
+            da.st_lensum[m] = ctx->d_ctr + cl.stats[2 * m + 1] + cl.st_length_sum;
+        }
+        hipLaunchKernelGGL(fq_dedup_apply_kernel, dim3((n + 255) / 256), dim3(256), 16, st, da);
+        HIP_TRY(ctx, hipGetLastError());
+        dedup_applied = true;
+    } else if (ctx->split && ctx->tail && dup_prepared && n > 0) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
         rc = launch_dup(nullptr, mode == CHUNK_PASS1, ctx->tail, 2);
@@ -1370,6 +1400,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         ctx->launch_seq++;
     } else if (dup_tail_launched) {
         HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_tail, 0));
+    } else if (dedup_applied) {
+        // (Duplicate's tail ran in front of the Stats kernel)
     } else if (ctx->dp.dup_enabled && !ctx->dp.dedup) {
         rc = launch_dup(nullptr, mode == CHUNK_PASS1, nullptr, dup_prepared ? 2 : 0);
         if (rc) return rc;

@@ -2588,6 +2588,55 @@ struct DupFinalArgs {
     int64_t* ctr_dups;
 };
 
+// --dedup on the lane plan (round 5): the per-read kernel hashes and claims as it does without --dedup and writes its records
+// as if no unit were a duplicate; Duplicate's tail then leaves the decisions in dupflag, and this kernel applies them BEFORE the
+// Stats kernel runs.  What `dedupOut` changes in the worker loop is only the last step (peprocessor.cpp:574-591,
+// seprocessor.cpp:280-286): the unit is not written out and not given to the post-filtering Stats objects - so a duplicate
+// gets its RS_DUP flag, and one that had been marked as written out loses its kept range (swin: the Stats kernel then counts
+// every base as dropped) and is taken out of the POST Stats' read count and length sum.
+struct DedupApplyArgs {
+    int n, paired;
+    const u8* dupflag;
+    u32* res[2];
+    u32* swin[2];
+    int64_t* st_reads[2];   // POST Stats of mate m: mReads, mLengthSum (counter block)
+    int64_t* st_lensum[2];
+};
+FQ_DEV void dedup_apply_body(const DedupApplyArgs& d, u32* lds) {
+    if (thread_id() < 4) lds[thread_id()] = 0;
+    block_sync();
+    const int g = block_id() * block_threads() + thread_id();
+    u32 rd[2] = {0, 0}, ln[2] = {0, 0};
+    if (g < d.n && d.dupflag[g]) {
+        for (int m = 0; m < (d.paired ? 2 : 1); m++) {
+            d.res[m][(size_t)g * 3 + 1] |= (u32)RS_DUP << 8;
+            const u32 sw = d.swin[m][g];
+            if (sw >> 16) {   // had been counted as written out
+                rd[m] = 1;
+                ln[m] = d.res[m][(size_t)g * 3] >> 16;   // the record's length
+                d.swin[m][g] = sw & 0xFFFFu;
+            }
+        }
+    }
+    for (int m = 0; m < 2; m++) {   // (uniform)
+        const u64 any = ballot(rd[m] != 0);
+        if (any) {
+            u32 l = ln[m];
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) l += shfl_xor(l, sh);
+            if (lane_id() == 0) {
+                lds_add_u32(&lds[2 * m], (u32)popc64(any));
+                lds_add_u32(&lds[2 * m + 1], l);
+            }
+        }
+    }
+    block_sync();
+    if (thread_id() < 2 && lds[2 * thread_id()]) {
+        g_atomic_add_i64(d.st_reads[thread_id()], -(int64_t)lds[2 * thread_id()]);
+        g_atomic_add_i64(d.st_lensum[thread_id()], -(int64_t)lds[2 * thread_id() + 1]);
+    }
+}
+
 // images[k] <- OR of images[j], j < k (exclusive prefix, in place; images[0] <- 0); `chunks` 16-byte chunks each.
 // With dst != nullptr instead: dst <- OR of all n_images (images untouched).
 struct OrArgs {
