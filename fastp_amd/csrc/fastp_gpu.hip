@@ -108,6 +108,8 @@ extern "C" __global__ void __launch_bounds__(64) fq_inflate_kernel(InflateArgs a
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     inflate_body(a, (u16*)fq_lds);
 }
+extern "C" __global__ void __launch_bounds__(256) fq_corr_stats_kernel(CorrStatsArgs c) { corr_stats_body(c); }
+extern "C" __global__ void __launch_bounds__(256) fq_corr_link_kernel(OvrArgs o) { corr_link_stride_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_dedup_apply_kernel(DedupApplyArgs d) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     dedup_apply_body(d, fq_lds);
@@ -201,6 +203,8 @@ struct fastp_gpu_ctx {
     bool split = false;
     int st_threads = 0, st_blocks = 0;     // the Stats kernel's workgroup size and the most workgroups it is launched with
     int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
+    u32* d_corr_int = nullptr; size_t corr_int_cap = 0;      // -c on the lane plan: the launch's corrections (KernelArgs::corr_int) + 1 counter word
+    u32* d_corr_chain = nullptr; size_t corr_chain_cap = 0;  // their per-read chains: head[reads] | next[capacity]
     int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
@@ -361,7 +365,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
                     ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr,
-                    ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
+                    ctx->d_corr_int, ctx->d_corr_chain, ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
@@ -375,7 +379,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
-    if (!(p.stats_one_pass || p.front_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
+    if (!(p.stats_one_pass || p.front_lane || p.corr_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
     if ((p.has_a1 && p.alen1 > 64) || (p.has_a2 && p.alen2 > 64)) return false;   // the lane kernel keeps an adapter in four uniform words
     if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
     if (p.cut_right && (p.wR < 1 || p.wR > 8)) return false;
@@ -397,7 +401,7 @@ static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
     return paired ? fq_lane_kernel<16, 4, 3, true, EXT> : fq_lane_kernel<16, 4, 3, false, EXT>;
 }
 // ext: adapter sequences, polyX trimming or the complexity filter are on (the instantiation that carries those steps)
-static bool lane_ext(const DevParams& p) { return p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter || p.front_lane; }
+static bool lane_ext(const DevParams& p) { return p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter || p.front_lane || p.corr_lane; }
 static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, bool ext) {
     return ext ? lane_kernel_pick<true>(swm, B, paired) : lane_kernel_pick<false>(swm, B, paired);
 }
@@ -447,7 +451,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     // the Stats kernel as its own launch: options that leave every kept base where it was, or (lane plan only) move it by the
     // same front for every read that is written out (DevParams::front_lane)
     const bool lane_wanted = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
-    ctx->split = (ctx->dp.stats_one_pass || (ctx->dp.front_lane && lane_wanted)) && env_int("FASTP_GPU_SPLIT", 1) != 0;
+    ctx->split = (ctx->dp.stats_one_pass || ((ctx->dp.front_lane || ctx->dp.corr_lane) && lane_wanted)) && env_int("FASTP_GPU_SPLIT", 1) != 0;
     ctx->cfg.split = ctx->split ? 1 : 0;
     ctx->cfg.threads = env_int("FASTP_GPU_THREADS", ctx->split ? 256 : 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
@@ -495,7 +499,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
         ctx->st_H = ctx->dp.qw_g / 2;
-        ctx->st_form = (env_int("FASTP_GPU_STATS_V", 4) == 3 && !ctx->dp.front_lane) ? 3 : 4;   // (a front: form 4 only)
+        ctx->st_form = (env_int("FASTP_GPU_STATS_V", 4) == 3 && !ctx->dp.front_lane && !ctx->dp.corr_lane) ? 3 : 4;   // (a front / -c: form 4 only)
         if (ctx->st_form == 4) {
             // round 5's form: [2][8][ST4_ROWS][Hs] u32 per-cycle cells of ONE mate, KC copies of its 5-mer counters, its histogram
             ctx->st_kc = env_int("FASTP_GPU_STATS_KC", 4);
@@ -570,7 +574,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             l.part_dwords = ctx->dp.paired ? (ctx->ln_swm / 2) * 64 : 0;   // read 1 of a pair: [ln_swm / 2 words][64 lanes]
             // as many wavefronts per workgroup as the LDS holds (up to three per SIMD for reads <= 160 bases, two above)
             const int max_waves = (ctx->ln_swm > 10 ? 512 : 256 * FQ_LANE_WAVES) / 64;
-            int waves = (int)(((long long)prop.sharedMemPerBlock / 4 - o) / (l.stage_dwords + l.part_dwords));
+            l.clist_dwords = (ctx->dp.corr_lane && ctx->dp.paired) ? (ctx->ln_swm / 2) * 64 : 0;   // -c: read 1's edited positions, a bit mask per lane
+            int waves = (int)(((long long)prop.sharedMemPerBlock / 4 - o) / (l.stage_dwords + l.part_dwords + l.clist_dwords));
             waves = std::max(1, std::min(waves, max_waves));
             const int env_threads = env_int("FASTP_GPU_LANE_THREADS", 0);   // A/B: 256 = round 3's geometry (several workgroups per CU)
             if (env_threads >= 64 && env_threads <= max_waves * 64) waves = env_threads / 64;
@@ -578,6 +583,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             o += waves * l.stage_dwords;
             l.part = o;
             o += waves * l.part_dwords;
+            l.clist = o;
+            o += waves * l.clist_dwords;
             l.total = o;
             int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);
 #ifndef FQ_HOSTSIM
@@ -600,6 +607,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             if (cap_tiles > 0) mp = std::min(mp, (long long)ctx->blocks * cap_tiles * ctx->L.P);
         }
         if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
+        if (ctx->split && ctx->dp.corr_lane) mp = std::min(mp, (1ll << 28) / std::max(1, ctx->dp.max_len));   // the launch's correction list (launch_chunk)
         mp = mp / ctx->L.P * ctx->L.P;
         ctx->max_pairs_per_launch = (int)mp;
     };
@@ -1019,6 +1027,19 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         a.dup_pos = dup_pos_buf;
     }
     a.split = ctx->split ? 1 : 0;
+    const bool corr_lane = ctx->split && ctx->dp.corr_lane && mode != CHUNK_OVERREP && !(mode == CHUNK_PASS1 && ctx->dp.dedup);
+    if (corr_lane) {
+        // the engine's own correction list of this launch.  A pair can have as many edits as its overlap is long (only the first
+        // 50 bases are held to the mismatch limit, overlapanalysis.cpp:34-44): the list is sized for that - it cannot overflow,
+        // and set_launch_size keeps it below 2^28 entries (2 GiB; memory laid out for 288 GB of HBM)
+        const size_t cap = (size_t)n * (size_t)ctx->dp.max_len;
+        const int rc0 = ensure(ctx, (void**)&ctx->d_corr_int, &ctx->corr_int_cap, (cap * 2 + 4) * 4);
+        if (rc0) return rc0;
+        a.n_corr_int = (int*)ctx->d_corr_int;
+        a.corr_int = ctx->d_corr_int + 4;
+        a.corr_int_cap = (int)std::min<size_t>(cap, 0x7FFFFFFF);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_corr_int, 0, 16, st));
+    }
     if (ctx->split) {
         const size_t need = ((size_t)n * 4 + 255) & ~(size_t)255;
         if (need > ctx->swin_cap) {
@@ -1329,6 +1350,49 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             st_grid = 0;
         }
     }
+    if (corr_lane && ctx->split && n > 0 && st_grid > 0) {
+        // -c: the corrected positions' share of the POST Stats moves from the original base / quality to the corrected one
+        const size_t reads = (size_t)n * (ctx->dp.paired ? 2 : 1);
+        rc = ensure(ctx, (void**)&ctx->d_corr_chain, &ctx->corr_chain_cap, (reads + (size_t)a.corr_int_cap) * 4);
+        if (rc) return rc;
+        OvrArgs lo;
+        memset(&lo, 0, sizeof(lo));
+        lo.n = n;
+        lo.first = a.first;
+        lo.paired = ctx->dp.paired;
+        lo.corr = a.corr_int;
+        lo.n_corr = a.n_corr_int;
+        lo.corr_cap = a.corr_int_cap;
+        lo.corr_head = ctx->d_corr_chain;
+        lo.corr_next = ctx->d_corr_chain + reads;
+        HIP_TRY(ctx, hipMemsetAsync(lo.corr_head, 0, reads * 4, st));
+        // (one lane per possible entry would be n x limit lanes; the list is short - a grid-stride walk over what it holds)
+        hipLaunchKernelGGL(fq_corr_link_kernel, dim3(std::min(4096, (a.corr_int_cap + 255) / 256)), dim3(256), 0, st, lo);
+        HIP_TRY(ctx, hipGetLastError());
+        CorrStatsArgs cs;
+        memset(&cs, 0, sizeof(cs));
+        cs.n = n;
+        cs.paired = ctx->dp.paired;
+        cs.sw_g = ctx->dp.sw_g;
+        cs.qw_g = ctx->dp.qw_g;
+        for (int m = 0; m < 2; m++) {
+            cs.seq[m] = a.seq[m];
+            cs.qual[m] = a.qual[m];
+            cs.swin[m] = ctx->d_swin[m];
+            cs.post[m] = ctx->d_ctr + cl.stats[2 * m + 1];
+        }
+        cs.front[0] = ctx->dp.front_lane ? ctx->dp.lane_front1 : 0;
+        cs.front[1] = ctx->dp.front_lane ? ctx->dp.lane_front2 : 0;
+        cs.corr = a.corr_int;
+        cs.corr_head = lo.corr_head;
+        cs.corr_next = lo.corr_next;
+        cs.st_qual_hist = cl.st_qual_hist;
+        cs.st_kmer = cl.st_kmer;
+        cs.st_cycle = cl.st_cycle;
+        cs.cycles = cl.cycles;
+        hipLaunchKernelGGL(fq_corr_stats_kernel, dim3((unsigned)((reads + 255) / 256)), dim3(256), 0, st, cs);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipEventRecord(e1, st));
     ctx->pending_events.push_back({e0, e1});
 
@@ -1336,7 +1400,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     memset(&r, 0, sizeof(r));
     r.L = ctx->L;
     r.isize_max = ctx->dp.isize_max;
-    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && ctx->dp.front_lane);
+    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && (ctx->dp.front_lane || ctx->dp.corr_lane));
     if (ctx->split && ctx->dp.front_lane) { r.front[0] = ctx->dp.lane_front1; r.front[1] = ctx->dp.lane_front2; }
     r.ctr = ctx->d_ctr;
     r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;

@@ -1764,6 +1764,13 @@ FQ_DEV void phase_decide_pe(const KernelArgs& a, u32* lds, int tile_first, int t
                                     a.corrections[2 * slot + 1] = (u32)cpos | (sym_ascii(nb) << 16) | (nq << 24);
                                 }
                             }
+                            if (a.corr_int) {   // the engine's own list (-c with the Stats kernel as its own launch: fq_corr_stats_kernel reads it)
+                                const int slot = g_atomic_add_i32(a.n_corr_int, 1);
+                                if (slot < a.corr_int_cap) {
+                                    a.corr_int[2 * slot] = (u32)(2 * (a.first + gp) + which);
+                                    a.corr_int[2 * slot + 1] = (u32)cpos | (sym_ascii(nb) << 16) | (nq << 24);
+                                }
+                            }
                         }
                     }
                 }
@@ -2637,6 +2644,95 @@ FQ_DEV void dedup_apply_body(const DedupApplyArgs& d, u32* lds) {
     }
 }
 
+// -c on the lane plan (round 5): the Stats kernel has counted every kept base of a corrected read with its ORIGINAL letter and
+// quality (into the kept slot: PRE and POST alike).  The PRE Stats are right that way (statRead runs before BaseCorrector,
+// peprocessor.cpp:393-394); the POST Stats see the corrected read (:583-586).  One lane per read that has corrections (their
+// chain: ovr_corr_link_body) and was written out: for each corrected position inside the kept range the POST Stats' per-cycle
+// arrays and quality histogram move from the old (class, quality) to the new, and the 5-mers that cover a corrected position
+// are taken out as the original read gives them and put back as the corrected read gives them.  Sparse: a few global atomics
+// per corrected read.
+struct CorrStatsArgs {
+    int n, paired;
+    int sw_g, qw_g;
+    const u32* seq[2];
+    const u32* qual[2];
+    const u32* swin[2];       // original length | END of the kept range << 16 (0: not written out), after --dedup's decisions
+    int front[2];             // start of the kept range (DevParams::lane_front*)
+    const u32* corr;          // the launch's corrections (fastp_gpu_correction: read | pos, base << 16, qual << 24)
+    const u32* corr_head;     // [n * (paired ? 2 : 1)] chain heads (entry + 1), corr_next [capacity]
+    const u32* corr_next;
+    int64_t* post[2];         // the POST Stats object of mate m in the counter block
+    int64_t st_qual_hist, st_kmer, st_cycle, cycles;
+};
+FQ_DEV u32 ascii_sym(u32 b) { return b == 'A' ? 0u : b == 'T' ? 1u : b == 'C' ? 2u : b == 'G' ? 3u : 4u; }
+FQ_DEV u32 row_sym(const u32* srow, const u8* qrow, int j) { return (qrow[j] & 0x80u) ? 4u : ((srow[j >> 4] >> ((j & 15) * 2)) & 3u); }   // A0 T1 C2 G3 N4
+FQ_DEV void corr_stats_body(const CorrStatsArgs& c) {
+    const int t = block_id() * block_threads() + thread_id();
+    const int reads = c.paired ? 2 * c.n : c.n;
+    if (t >= reads) return;
+    const u32 head = c.corr_head[t];
+    if (!head) return;
+    const int g = c.paired ? t >> 1 : t, m = c.paired ? (t & 1) : 0;
+    const u32 sw = c.swin[m][g];
+    const int lk = (int)(sw >> 16), F = c.front[m];
+    if (lk <= F) return;                                   // not written out: no POST Stats
+    const u32* srow = c.seq[m] + (size_t)g * c.sw_g;
+    const u8* qrow = (const u8*)(c.qual[m] + (size_t)g * c.qw_g);
+    // (a read can hold any number of edits - only the first 50 bases of an overlap are held to the mismatch limit: the chain is
+    // walked again wherever the edits of other positions matter; such reads are few)
+    auto sym_new = [&](int j) -> u32 {                     // symbol j of the corrected read
+        u32 s2 = row_sym(srow, qrow, j);
+        for (u32 e = head; e; e = c.corr_next[e - 1]) {
+            const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
+            if ((int)(w1 & 0xFFFFu) == j) s2 = ascii_sym((w1 >> 16) & 0xFFu);
+        }
+        return s2;
+    };
+    int64_t* st = c.post[m];
+    int64_t* cyc = st + c.st_cycle;
+    const int64_t CC = c.cycles;
+    for (u32 e = head; e; e = c.corr_next[e - 1]) {
+        const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
+        const int P = (int)(w1 & 0xFFFFu);
+        if (P < F || P >= lk) continue;                    // trimmed away afterwards: the POST Stats never saw the base
+        const int cc = P - F;
+        const u32 so = row_sym(srow, qrow, P), qo = (u32)qrow[P] & 0x7Fu, sn = ascii_sym((w1 >> 16) & 0xFFu), qn = w1 >> 24;
+        const int bo = (int)sym_bin(so), bn = (int)sym_bin(sn);
+        if (qo >= 63u) g_atomic_add_i64(&cyc[(0 * 8 + bo) * CC + cc], -1);     // stats.cpp:209-222
+        if (qo >= 53u) g_atomic_add_i64(&cyc[(1 * 8 + bo) * CC + cc], -1);
+        g_atomic_add_i64(&cyc[(2 * 8 + bo) * CC + cc], -1);
+        g_atomic_add_i64(&cyc[(3 * 8 + bo) * CC + cc], -(int64_t)(qo - 33u));
+        if (qn >= 63u) g_atomic_add_i64(&cyc[(0 * 8 + bn) * CC + cc], 1);
+        if (qn >= 53u) g_atomic_add_i64(&cyc[(1 * 8 + bn) * CC + cc], 1);
+        g_atomic_add_i64(&cyc[(2 * 8 + bn) * CC + cc], 1);
+        g_atomic_add_i64(&cyc[(3 * 8 + bn) * CC + cc], (int64_t)(qn - 33u));
+        g_atomic_add_i64(&cyc[33 * CC + cc], (int64_t)qn - (int64_t)qo);       // mCycleTotalQual (mCycleTotalBase is unchanged)
+        g_atomic_add_i64(&st[c.st_qual_hist + qo], -1);
+        g_atomic_add_i64(&st[c.st_qual_hist + qn], 1);
+        // 5-mers: every end position j in [P, P + 4]; a j that an edit at a SMALLER position also covers is that edit's
+        for (int j = P; j <= P + 4; j++) {
+            if (j - 4 < F || j >= lk) continue;            // a 5-mer of the read that is written out needs j - 4 >= F
+            bool other = false;
+            for (u32 e2 = head; e2; e2 = c.corr_next[e2 - 1]) {
+                const int P2 = (int)(c.corr[2 * (size_t)(e2 - 1) + 1] & 0xFFFFu);
+                other = other || (P2 < P && j <= P2 + 4);
+            }
+            if (other) continue;
+            u32 ko = 0, kn = 0;
+            bool vo = true, vn = true;
+            for (int b = j - 4; b <= j; b++) {             // fastp's index: the earliest base in the high bits (stats.cpp:236, :250)
+                const u32 s0 = row_sym(srow, qrow, b), s1 = sym_new(b);
+                vo = vo && s0 < 4u;
+                vn = vn && s1 < 4u;
+                ko = (ko << 2) | (s0 & 3u);
+                kn = (kn << 2) | (s1 & 3u);
+            }
+            if (vo) g_atomic_add_i64(&st[c.st_kmer + ko], -1);
+            if (vn) g_atomic_add_i64(&st[c.st_kmer + kn], 1);
+        }
+    }
+}
+
 // images[k] <- OR of images[j], j < k (exclusive prefix, in place; images[0] <- 0); `chunks` 16-byte chunks each.
 // With dst != nullptr instead: dst <- OR of all n_images (images untouched).
 struct OrArgs {
@@ -3130,6 +3226,18 @@ FQ_DEV void ovr_corr_link_body(const OvrArgs& o) {
     if (unit < 0 || unit >= o.n) return;
     const u32 key = o.paired ? (u32)unit * 2u + (read & 1u) : (u32)unit;
     o.corr_next[e] = g_atomic_exch_u32(&o.corr_head[key], (u32)e + 1u);
+}
+
+// the same over a list whose capacity is far larger than its fill (the engine's own list of -c on the lane plan): grid-stride
+FQ_DEV void corr_link_stride_body(const OvrArgs& o) {
+    const int ne = (int)imin(*o.n_corr, o.corr_cap);
+    for (int e = block_id() * block_threads() + thread_id(); e < ne; e += grid_blocks() * block_threads()) {
+        const u32 read = o.corr[2 * (size_t)e];
+        const int unit = (int)(o.paired ? read >> 1 : read) - o.first;
+        if (unit < 0 || unit >= o.n) continue;
+        const u32 key = o.paired ? (u32)unit * 2u + (read & 1u) : (u32)unit;
+        o.corr_next[e] = g_atomic_exch_u32(&o.corr_head[key], (u32)e + 1u);
+    }
 }
 
 // symbol j of a read as the post-filtering Stats see it: BaseCorrector's edits applied (basecorrector.cpp:45-63)

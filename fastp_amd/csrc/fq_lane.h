@@ -48,6 +48,8 @@ struct LaneLds {
     int stage_dwords;   // loads and read back one row per lane (16-byte aligned, 64 * qw_g dwords each)
     int part;       // per wavefront: countQualityMetrics' per-32-base partial sums of READ 1 of a pair [word][lane] (lane-contiguous:
     int part_dwords;    // conflict-free; registers do not hold them - ten more live VGPRs spilled 270 dwords at the cap of 168)
+    int clist;      // -c on the lane plan, per wavefront: the positions of read 1 that BaseCorrector edited, one bit per base,
+    int clist_dwords;   // [SWM / 2 words][lane]: read 1's rows are gone when countQualityMetrics runs (lane_apply_corrected)
     int total;
 };
 
@@ -970,6 +972,163 @@ FQ_DEV void lane_metrics_staged(const KernelArgs& a, u32* stage, const u32* qual
     nb = (int)n;
 }
 
+// ---------------------------------------------------------------------------
+// BaseCorrector::correctByOverlapAnalysis (basecorrector.cpp:16-83) with both reads in registers (-c on the lane plan, round 5).
+// The mismatch positions of the accepted overlap come from the same XOR words as the verification; they are taken one per
+// round (a wave loop: at most the mismatch limit, five by default).  A corrected base changes the read's registers (what the
+// adapter scan by sequence, polyX, the complexity filter and the N count look at), its quality changes what
+// countQualityMetrics will add up: read 2's rows are still in the wavefront's stage - the byte is rewritten there; read 1's
+// are not - its edited positions are marked in a per-lane bit mask (LaneLds::clist) and added up when the final window is
+// known (lane_apply_corrected: the new quality of such a position is read 2's at the position it was compared with - any
+// number of them: only the first 50 bases of an overlap are held to the mismatch limit, overlapanalysis.cpp:34-44).  Every edit goes
+// to the engine's own correction list (the Stats fix-up, fq_corr_stats_kernel, and the overrepresentation analysis read it)
+// and to the caller's, if there is one.
+// ---------------------------------------------------------------------------
+// symbol (A0 T1 C2 G3 N4) of base j of a row in registers
+template <int SWM>
+FQ_DEV u32 lane_sym_of(const u32 (&s)[SWM], const u32 (&n)[SWM / 2], int j) {
+    const u32 w = lane_word_at<SWM>(s, j >> 4), nw = lane_word_at<SWM / 2>(n, j >> 5);
+    return ((nw >> (j & 31)) & 1u) ? 4u : ((w >> (2 * (j & 15))) & 3u);
+}
+// base j of the read becomes symbol sym
+template <int SWM>
+FQ_DEV void lane_set_sym(LaneRead<SWM>& r, int j, u32 sym) {
+    const u32 code = sym < 4u ? sym : 0u, sh = 2u * (u32)(j & 15);
+#pragma unroll
+    for (int w = 0; w < SWM; w++) {
+        const u32 v = (r.s[w] & ~(3u << sh)) | (code << sh);
+        r.s[w] = (j >> 4) == w ? v : r.s[w];
+    }
+    const u32 bit = 1u << (j & 31);
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) {
+        const u32 v = sym == 4u ? (r.n[w] | bit) : (r.n[w] & ~bit);
+        r.n[w] = (j >> 5) == w ? v : r.n[w];
+    }
+    if (sym == 4u) r.flags |= RS_HAS_N;
+}
+FQ_DEV void lane_emit_correction(const KernelArgs& a, int gp, int which, int rowpos, u32 nb, u32 nq) {
+    const u32 w0 = (u32)(2 * (a.first + gp) + which), w1 = (u32)rowpos | (sym_ascii(nb) << 16) | (nq << 24);
+    const int slot = g_atomic_add_i32(a.n_corr_int, 1);       // never full: sized for the mismatch limit of every pair
+    if (slot < a.corr_int_cap) { a.corr_int[2 * slot] = w0; a.corr_int[2 * slot + 1] = w1; }
+    if (a.corrections) {
+        const int cs = g_atomic_add_i32(a.n_corrections, 1);
+        if (cs < a.corr_capacity) { a.corrections[2 * cs] = w0; a.corrections[2 * cs + 1] = w1; }
+    }
+}
+// key = the pair's accepted overlap (no gap), l1 / l2 the lengths it was found on; rc / rcn = rc(r2') as the scan built it.
+// q1row: read 1's quality row in memory, q2row: read 2's in the stage (both at the ORIGINAL read's start).  nc1 = entries of clist.
+template <int SWM>
+FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, LaneRead<SWM>& r2, const u32 (&rc)[SWM], const u32 (&rcn)[SWM / 2], bool go,
+                         u32 key, int l1, int l2, int fr1, int fr2, const u8* q1row, u8* q2row, u32* clist, int lane, int gp, int& geom) {
+    int ovl, off, ol, diff;
+    decode_overlap(key, l1, l2, ovl, off, ol, diff);
+    go = go && ovl && diff != 0;                               // :18-19
+    if (ballot(go) == 0ull) return;
+    const bool hasN = ((r1.flags | r2.flags) & RS_HAS_N) != 0;
+    const int o1 = imax(0, off), o2 = imax(0, -off);           // start1, and where the overlap starts in rc(r2')
+    // D = the overlap's mismatches, bit 2 i = position i of the overlap: r1'[o1 + i] against rc(r2')[o2 + i]
+    u32 D[SWM];
+    {
+        u32 xs[SWM], ys[SWM];
+#pragma unroll
+        for (int w = 0; w < SWM; w++) { xs[w] = r1.s[w]; ys[w] = rc[w]; }
+        base_shift_down<SWM>(xs, (u32)o1);
+        base_shift_down<SWM>(ys, (u32)o2);
+        u32 dn[SWM / 2];
+        if (hasN) {
+            u32 yn[SWM / 2];
+#pragma unroll
+            for (int w = 0; w < SWM / 2; w++) { dn[w] = r1.n[w]; yn[w] = rcn[w]; }
+            bit_shift_down<SWM / 2>(dn, (u32)o1);
+            bit_shift_down<SWM / 2>(yn, (u32)o2);
+#pragma unroll
+            for (int w = 0; w < SWM / 2; w++) dn[w] ^= yn[w];
+        }
+#pragma unroll
+        for (int w = 0; w < SWM; w++) {
+            u32 dd = fold_diff(xs[w] ^ ys[w]);
+            if (hasN) dd |= nmask_word<SWM / 2>(dn, w);
+            const int rem = ol - 16 * w;
+            D[w] = !go ? 0u : (rem >= 16 ? dd : (rem <= 0 ? 0u : (dd & lowmask32(2 * rem))));
+        }
+    }
+    int corrected = 0;
+    bool r1c = false, r2c = false;
+    for (;;) {
+        int i = -1;                                            // the smallest mismatch position left
+#pragma unroll
+        for (int w = SWM - 1; w >= 0; w--)
+            if (D[w]) i = 16 * w + ((ffs32(D[w]) - 1) >> 1);
+        if (ballot(i >= 0) == 0ull) break;
+        if (i >= 0) {
+#pragma unroll
+            for (int w = 0; w < SWM; w++)
+                if ((i >> 4) == w) D[w] &= ~(1u << (2 * (i & 15)));
+            const int p1 = o1 + i, k = o2 + i, p2 = l2 - 1 - k;    // :24-25, :38-39
+            const u32 b1 = lane_sym_of<SWM>(r1.s, r1.n, p1), brc = lane_sym_of<SWM>(rc, rcn, k);
+            const u32 b2 = sym_complement(brc);                    // r2'[p2] itself
+            const u32 c1 = (u32)q1row[fr1 + p1] & 0x7Fu, c2 = (u32)q2row[fr2 + p2] & 0x7Fu;
+            if (c1 >= 63u && c2 <= 47u) {                          // GOOD_QUAL = Q30, BAD_QUAL = Q14 (:32-33): use R1
+                const u32 nb = sym_complement(b1);
+                lane_set_sym<SWM>(r2, p2, nb);
+                q2row[fr2 + p2] = (u8)(c1 | (nb == 4u ? 0x80u : 0u));
+                lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b2) * 8 + sym_bin(nb)], 1u);
+                lane_emit_correction(a, gp, 1, fr2 + p2, nb, c1);
+                corrected++;
+                r2c = true;
+            } else if (c2 >= 63u && c1 <= 47u) {                   // use R2
+                const u32 nb = brc;                                // complement(seq2[p2])
+                lane_set_sym<SWM>(r1, p1, nb);
+                clist[(p1 >> 5) * 64 + lane] |= 1u << (p1 & 31);
+                lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b1) * 8 + sym_bin(nb)], 1u);
+                lane_emit_correction(a, gp, 0, fr1 + p1, nb, c2);
+                corrected++;
+                r1c = true;
+            }
+        }
+    }
+    if (corrected > 0) {                                           // :75-80
+        lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
+        if (r1c) r1.flags |= RS_CORRECTED;
+        if (r2c) r2.flags |= RS_CORRECTED;
+    }
+    // where read 1's position p1 was compared with read 2: p2 = geom's high half - p1 (= l2 - 1 - o2 + o1 - p1)
+    if (r1c) geom = 1 | ((l2 - 1 - o2 + o1) << 1);
+}
+// read 1's edited positions inside its final window [0, len) (registers' coordinates; the rows': + fr1): what
+// countQualityMetrics adds up changes from the old quality (read 1's row in memory) to the new one (read 2's at the position
+// it was compared with, still in the stage: a position where read 1 was edited is one where read 2 was not)
+template <int SWM>
+FQ_DEV void lane_apply_corrected(const KernelArgs& a, const u32* clist, int lane, int geom, const u8* q1row, const u8* q2row, int fr1, int fr2, int len,
+                                 int& tot, int& low) {
+    const u32 thr = (u32)a.p.qual_thr;
+    const bool any = (geom & 1) != 0;
+    const int pivot = geom >> 1;
+    u32 m[SWM / 2];
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) {
+        const int left = len - 32 * w;
+        const u32 v = any ? clist[w * 64 + lane] : 0u;
+        m[w] = left >= 32 ? v : (left <= 0 ? 0u : (v & lowmask32(left)));
+    }
+    for (;;) {
+        int p1 = -1;
+#pragma unroll
+        for (int w = SWM / 2 - 1; w >= 0; w--)
+            if (m[w]) p1 = 32 * w + ffs32(m[w]) - 1;
+        if (ballot(p1 >= 0) == 0ull) break;
+        if (p1 >= 0) {
+#pragma unroll
+            for (int w = 0; w < SWM / 2; w++)
+                if ((p1 >> 5) == w) m[w] &= m[w] - 1u;
+            const u32 qo = (u32)q1row[fr1 + p1] & 0x7Fu, qn = (u32)q2row[fr2 + pivot - p1] & 0x7Fu;
+            tot += (int)qn - (int)qo;
+            low += (qn < thr ? 1 : 0) - (qo < thr ? 1 : 0);
+        }
+    }
+}
+
 // UMI front trim (umiprocessor.cpp:19-49 -> Read::trimFront, read.cpp:69-73), then Filter::trimAndCut with -f / -t: phase_trim of
 // the tile kernel.  r.len = the new length (the length behind the UMI for a NULL read), fr / ft as in lane_body.
 template <int SWM>
@@ -1063,6 +1222,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     for (int w = 0; w < LANE_ADAPTER_WORDS; w++) { aw1[w] = p.a1w[w]; aw2[w] = p.a2w[w]; }
     const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
     const bool FR = EXT && p.front_lane != 0;         // (uniform) -f / -F / a UMI at the reads' start
+    const bool CR = EXT && PAIRED && p.corr_lane != 0;   // (uniform) -c
     const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
@@ -1079,6 +1239,12 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         const int rows = imin(64, a.n - chunk * 64);
         u32* stage = lds + ll.stage + (tid >> 6) * ll.stage_dwords;
         u32* part = lds + ll.part + (tid >> 6) * ll.part_dwords;
+        u32* clist = lds + ll.clist + (tid >> 6) * ll.clist_dwords;
+        int geom = 0;  // -c: bit 0 = read 1 has edited positions (their mask: clist), the rest: lane_correct
+        if (CR) {
+#pragma unroll
+            for (int w = 0; w < SWM / 2; w++) clist[w * 64 + lane] = 0;
+        }
         const int g = valid ? gp : 0;
         LaneRead<SWM> r1, r2;
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
@@ -1192,6 +1358,10 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                         }
                     }
                 }
+                // ---- BaseCorrector::correctByOverlapAnalysis (peprocessor.cpp:453-456; no gap on this plan) ----
+                if (CR && p.need_overlap)
+                    lane_correct<SWM>(a, misc, r1, r2, rc, rcn, both, key, l1, l2, fr1, fr2, (const u8*)(a.qual[0] + (size_t)g * p.qw_g),
+                                      (u8*)(stage + lane * p.qw_g), clist, lane, g, geom);
             }
             // ---- peprocessor.cpp:443-516: insert size, adapter trimming by overlap, max_len ----
             int cur1 = r1.len, cur2 = r2.len;
@@ -1311,6 +1481,9 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
         }
 #endif
+        if (CR && !(skip & 8u) && ballot((geom & 1) != 0) != 0ull)   // read 1's edited positions inside its final window
+            lane_apply_corrected<SWM>(a, clist, lane, geom, (const u8*)(a.qual[0] + (size_t)g * p.qw_g), (const u8*)(stage + lane * p.qw_g), fr1, fr2, r1.len,
+                                      tot1, low1);
         int dif1 = 0, dif2 = 0;
         if (EXT && p.complexity_filter) {   // (uniform) filter.cpp:51-54: countAdjacentDiffs of the final window
             dif1 = lane_adjacent_diffs<SWM>(r1, r1.len);

@@ -160,6 +160,7 @@ enum { SRC_PLAIN = 0, SRC_GZIP = 1, SRC_BGZF = 2 };
 struct WriteJob {
     int oslot = -1;                // -1: stop; 3: only the host-built stream below (a trip whose device streams are all unwanted)
     int64_t len[FASTP_GPU_N_OUTPUTS] = {0, 0, 0, 0, 0, 0};
+    bool copy_pending = false;     // the device-to-host copy into pin_out[oslot] is in flight: wait for ev_out[oslot] first
     bool has_ov = false;           // --overlapped_out's records of this chunk (may be empty: the writer takes one string per chunk)
     std::string ov;
 };
@@ -216,8 +217,13 @@ struct fastp_gpu_stream {
     int32_t *d_nc = nullptr, *d_nev = nullptr;
     int32_t corr_cap = 0, ev_cap = 0;
     uint8_t* d_zero = nullptr;
-    uint8_t* d_out[FASTP_GPU_N_OUTPUTS] = {};
-    uint8_t* d_gz[FASTP_GPU_N_OUTPUTS] = {};
+    // the output streams' text (and its gzip members) on the device, one set per page-locked output slot: the copy of chunk k
+    // to the host runs on its own stream under the parser / worker loop / formatter of chunk k + 1 (round 5; the caller's
+    // thread used to wait for it - 2 of the 6.5 s of a 100 M-pair run, profiles/r04_dropin_100M_reader_ab.txt)
+    uint8_t* d_out[2][FASTP_GPU_N_OUTPUTS] = {};
+    uint8_t* d_gz[2][FASTP_GPU_N_OUTPUTS] = {};
+    hipStream_t cp_out = nullptr;
+    hipEvent_t ev_out[2] = {nullptr, nullptr};   // the copy into pin_out[slot] has landed (the writer thread waits for it)
     int64_t out_cap[FASTP_GPU_N_OUTPUTS] = {}, gz_cap[FASTP_GPU_N_OUTPUTS] = {};
     uint8_t* pin_out[2][FASTP_GPU_N_OUTPUTS] = {};
     // host copies for the adapter replay
@@ -274,10 +280,16 @@ void free_buffers(fastp_gpu_stream* s) {
     hfree(s->h_corr); hfree(s->h_ev); hfree(s->h_counts);
     s->h_corr = nullptr; s->h_ev = nullptr; s->h_counts = nullptr;
     for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
-        dfree(s->d_out[q]); dfree(s->d_gz[q]);
-        s->d_out[q] = s->d_gz[q] = nullptr;
+        if (s->d_out[1][q] == s->d_out[0][q]) s->d_out[1][q] = nullptr;   // (an unwanted stream's two sets are one buffer)
+        for (int sl = 0; sl < 2; sl++) {
+            dfree(s->d_out[sl][q]); dfree(s->d_gz[sl][q]);
+            s->d_out[sl][q] = s->d_gz[sl][q] = nullptr;
+        }
         for (int sl = 0; sl < 2; sl++) { hfree(s->pin_out[sl][q]); s->pin_out[sl][q] = nullptr; }
     }
+    for (int sl = 0; sl < 2; sl++)
+        if (s->ev_out[sl]) { (void)hipEventDestroy(s->ev_out[sl]); s->ev_out[sl] = nullptr; }
+    if (s->cp_out) { (void)hipStreamDestroy(s->cp_out); s->cp_out = nullptr; }
     if (s->sx) { (void)hipStreamDestroy(s->sx); s->sx = nullptr; }
     if (s->cp_in) { (void)hipStreamDestroy(s->cp_in); s->cp_in = nullptr; }
 }
@@ -306,6 +318,8 @@ int alloc_buffers(fastp_gpu_stream* s) {
     S_HIP(s, hipSetDevice(s->cfg.device));
     S_HIP(s, hipStreamCreateWithFlags(&s->sx, hipStreamNonBlocking));
     S_HIP(s, hipStreamCreateWithFlags(&s->cp_in, hipStreamNonBlocking));
+    S_HIP(s, hipStreamCreateWithFlags(&s->cp_out, hipStreamNonBlocking));
+    for (int sl = 0; sl < 2; sl++) S_HIP(s, hipEventCreateWithFlags(&s->ev_out[sl], hipEventDisableTiming));
     const int nm = s->nm, nf = s->nf;
     s->text_cap = (s->chunk + 4096 + 255) / 256 * 256;   // a trip's text never exceeds chunk bytes (see the loop)
     s->max_records = (int32_t)std::max<int64_t>(1024, s->chunk / 32);
@@ -378,11 +392,15 @@ int alloc_buffers(fastp_gpu_stream* s) {
     for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
         if (!s->any_out || !(need[q] || s->cfg.want[q])) continue;
         s->out_cap[q] = caps[q];
-        S_HIP(s, hipMalloc((void**)&s->d_out[q], (size_t)caps[q]));
+        // (a stream nobody asked for is written by the formatter and never copied: its two sets are one buffer)
+        for (int sl = 0; sl < 2; sl++) {
+            if (sl == 1 && !s->cfg.want[q]) { s->d_out[1][q] = s->d_out[0][q]; continue; }
+            S_HIP(s, hipMalloc((void**)&s->d_out[sl][q], (size_t)caps[q]));
+        }
         int64_t host_bytes = caps[q];
         if (s->cfg.want[q] && s->cfg.compress[q]) {
             s->gz_cap[q] = caps[q] + 31 * (caps[q] / 65280 + 1) + 64;
-            S_HIP(s, hipMalloc((void**)&s->d_gz[q], (size_t)s->gz_cap[q]));
+            for (int sl = 0; sl < 2; sl++) S_HIP(s, hipMalloc((void**)&s->d_gz[sl][q], (size_t)s->gz_cap[q]));
             host_bytes = s->gz_cap[q];
         }
         if (s->cfg.want[q])
@@ -1049,6 +1067,7 @@ void writer_main(Run* R) {
     for (;;) {
         WriteJob j = R->q_write.get();
         if (j.oslot < 0) return;
+        if (j.copy_pending && j.oslot < 2 && hipEventSynchronize(s->ev_out[j.oslot]) != hipSuccess) R->io_err.store(4);
         const double t0 = now_s();
         if (j.has_ov && !R->emit_err.load()) {   // --overlapped_out's records of the chunk, assembled on the host
             if (s->cfg.emit(s->cfg.user, FASTP_GPU_OVERLAPPED, j.ov.data(), (int64_t)j.ov.size()) != 0) R->emit_err.store(1);
@@ -1375,34 +1394,41 @@ int run_loop(Run* R) {
                 for (int m = 0; m < nm; m++) { io[m].text = s->d_text[slot][file_of(m)]; io[m].line_off = s->d_loff[m]; io[m].line_len = s->d_llen[m]; io[m].res = s->d_res[m]; }
                 fastp_gpu_format_options fo = s->cfg.format;
                 fo.corrections_capacity = s->corr_cap;
+                // the output slot first: its device buffers and its page-locked ones are free again when the writer has
+                // written what the slot held (which also says that the slot's last copy has landed)
+                const double tw = now_s();
+                wj.oslot = R->q_ofree.get();
+                s->st.wait_write_s += now_s() - tw;
+                t0 = now_s();
+                uint8_t* const* d_out = s->d_out[wj.oslot];
                 int64_t lens[FASTP_GPU_N_OUTPUTS];
-                if (fastp_gpu_format_streams(s->ctx, n, &io[0], s->paired ? &io[1] : nullptr, s->d_pair, s->d_corr, s->corr_cap ? s->d_nc : nullptr, &fo, s->d_out,
-                                             s->out_cap, lens) != FASTP_GPU_OK)
+                if (fastp_gpu_format_streams(s->ctx, n, &io[0], s->paired ? &io[1] : nullptr, s->d_pair, s->d_corr, s->corr_cap ? s->d_nc : nullptr, &fo,
+                                             const_cast<uint8_t**>(d_out), s->out_cap, lens) != FASTP_GPU_OK)
                     return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_format_streams");
                 s->st.format_s += now_s() - t0;
                 t0 = now_s();
                 const uint8_t* src[FASTP_GPU_N_OUTPUTS];
                 for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
-                    src[q] = s->d_out[q];
+                    src[q] = d_out[q];
                     if (!s->cfg.want[q]) { lens[q] = 0; continue; }
                     if (s->cfg.compress[q] && lens[q] > 0) {
                         int64_t glen = 0;
-                        if (fastp_gpu_deflate_bgzf(s->ctx, s->d_out[q], lens[q], 0, s->d_gz[q], s->gz_cap[q], &glen) != FASTP_GPU_OK)
+                        if (fastp_gpu_deflate_bgzf(s->ctx, d_out[q], lens[q], 0, s->d_gz[wj.oslot][q], s->gz_cap[q], &glen) != FASTP_GPU_OK)
                             return s->fail_ctx(FASTP_GPU_E_HIP, "fastp_gpu_deflate_bgzf");
                         lens[q] = glen;
-                        src[q] = s->d_gz[q];
+                        src[q] = s->d_gz[wj.oslot][q];
                     }
                 }
                 s->st.deflate_s += now_s() - t0;
                 t0 = now_s();
-                wj.oslot = R->q_ofree.get();
-                s->st.wait_write_s += now_s() - t0;
-                t0 = now_s();
+                // (the formatter / deflater have returned their lengths: the text is complete on the device)  The copy runs on its
+                // own stream; the writer thread waits for its event, this thread goes on to the next chunk
                 for (int q = 0; q < FASTP_GPU_N_OUTPUTS; q++) {
                     wj.len[q] = lens[q];
-                    if (lens[q] > 0) S_HIP(s, hipMemcpyAsync(s->pin_out[wj.oslot][q], src[q], (size_t)lens[q], hipMemcpyDeviceToHost, s->sx));
+                    if (lens[q] > 0) S_HIP(s, hipMemcpyAsync(s->pin_out[wj.oslot][q], src[q], (size_t)lens[q], hipMemcpyDeviceToHost, s->cp_out));
                 }
-                S_HIP(s, hipStreamSynchronize(s->sx));
+                S_HIP(s, hipEventRecord(s->ev_out[wj.oslot], s->cp_out));
+                wj.copy_pending = true;
                 s->st.d2h_s += now_s() - t0;
                 R->q_write.put(std::move(wj));
             }

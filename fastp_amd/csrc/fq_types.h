@@ -93,6 +93,9 @@ struct DevParams {
                             // cycle in the Stats kernel's tables and the slab fold moves the POST Stats by the mate's front
                             // (lane plan only; fq_lane.h, fq_stats.h)
     int lane_front1, lane_front2;   // that front: UMI length + skip + --trim_front of the mate
+    int corr_lane;          // round 5: -c on the lane plan - BaseCorrector's edits are applied to the reads in registers, the Stats
+                            // kernel counts the ORIGINAL reads (kept -> PRE and POST), fq_corr_stats_kernel then moves the corrected
+                            // positions' contributions to the POST Stats from the old base / quality to the new one
 };
 
 // LUTs living in global memory (built on the host with the reference's own
@@ -334,6 +337,12 @@ struct KernelArgs {
     u32* corrections;   // fastp_gpu_correction, 2 dwords each
     int corr_capacity;
     int* n_corrections;
+    // -c on the lane plan: the engine's own list of the launch's corrections (same entries; sized for the mismatch limit of
+    // every pair, so it never overflows) - what the Stats fix-up and the overrepresentation analysis read, whether or not the
+    // caller asked for the list
+    u32* corr_int;
+    int corr_int_cap;
+    int* n_corr_int;
     u32* adapter_events;   // fastp_gpu_adapter_event, 3 dwords each
     int adapter_events_capacity;
     int* n_adapter_events;
