@@ -53,7 +53,7 @@ extern "C" __global__ void __launch_bounds__(256, 4) fq_scan_kernel(FusedArgs a)
 // read 1's partial quality sums (three 256-lane workgroups of 51 KB fitted, of 56 KB they do not: two per CU, a third of
 // the wavefronts gone - profiles/r04_lane_metrics_ab.txt).  FQ_LANE_WAVES wavefronts per SIMD: 168 VGPRs.
 template <int SWM> struct LaneGeom { enum { MAX_THREADS = SWM > 10 ? 512 : 256 * FQ_LANE_WAVES }; };
-template <int SWM, int B, int NPL, bool PAIRED, bool EXT>
+template <int SWM, int B, int NPL, bool PAIRED, int EXT>
 __global__ void __launch_bounds__(LaneGeom<SWM>::MAX_THREADS, 1) fq_lane_kernel(LaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     lane_body<SWM, B, NPL, PAIRED, EXT>(*kernel_args(&a), fq_lds);
@@ -205,6 +205,7 @@ struct fastp_gpu_ctx {
     int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
     u32* d_corr_int = nullptr; size_t corr_int_cap = 0;      // -c on the lane plan: the launch's corrections (KernelArgs::corr_int) + 1 counter word
     u32* d_corr_chain = nullptr; size_t corr_chain_cap = 0;  // their per-read chains: head[reads] | next[capacity]
+    int ln_glds = 1;   // FASTP_GPU_LANE_GLDS (A/B): LaneArgs::glds
     int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
@@ -389,7 +390,7 @@ static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
 }
 
 typedef void (*lane_kernel_fn)(LaneArgs);
-template <bool EXT>
+template <int EXT>
 static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
     if (swm == 10) {
         if (B == 0) return paired ? fq_lane_kernel<10, 0, 3, true, EXT> : fq_lane_kernel<10, 0, 3, false, EXT>;
@@ -400,10 +401,14 @@ static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
     if (B == 2) return paired ? fq_lane_kernel<16, 2, 3, true, EXT> : fq_lane_kernel<16, 2, 3, false, EXT>;
     return paired ? fq_lane_kernel<16, 4, 3, true, EXT> : fq_lane_kernel<16, 4, 3, false, EXT>;
 }
-// ext: adapter sequences, polyX trimming or the complexity filter are on (the instantiation that carries those steps)
-static bool lane_ext(const DevParams& p) { return p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter || p.front_lane || p.corr_lane; }
-static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, bool ext) {
-    return ext ? lane_kernel_pick<true>(swm, B, paired) : lane_kernel_pick<false>(swm, B, paired);
+// ext: 1 = adapter sequences, polyX trimming or the complexity filter are on (the instantiation that carries those steps);
+// 2 = a front trim or -c as well (round 5; an instantiation of its own: with their code in it the first one spilled 77 dwords)
+static int lane_ext(const DevParams& p) {
+    if (p.front_lane || p.corr_lane) return 2;
+    return (p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter) ? 1 : 0;
+}
+static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, int ext) {
+    return ext == 2 ? lane_kernel_pick<2>(swm, B, paired) : ext == 1 ? lane_kernel_pick<1>(swm, B, paired) : lane_kernel_pick<0>(swm, B, paired);
 }
 
 extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fastp_gpu_ctx** out) {
@@ -553,6 +558,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));
         ctx->st_blocks = ctx->cus * std::max(1, st_per_cu);
         ctx->lane = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
+        ctx->ln_glds = env_int("FASTP_GPU_LANE_GLDS", 1);
         if (ctx->lane) {
             ctx->ln_swm = ctx->dp.sw_g <= 10 ? 10 : 16;
             LaneLds& l = ctx->ln_lds;
@@ -1266,6 +1272,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.k.slab_dwords = ctx->ln_lds.n_misc;
             la.l = ctx->ln_lds;
             la.chunk_ctr = ctx->d_ln_ctr;
+            la.glds = ctx->ln_glds;
             if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
             lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp));

@@ -59,6 +59,23 @@ FQ_DEV void touch_done(u32 v) {
 #endif
 }
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no VGPR, asynchronous - counted by vmcnt).
+// The LDS destination is wave-uniform base + lane * 16 whatever the lane asks for, so `lds_wave_base` must be uniform and the
+// image lane-linear.  glds_wait() before anything reads the image.
+FQ_DEV void glds16(const void* g, void* lds_wave_base, int lane) {
+#ifdef FQ_HOSTSIM
+    memcpy((char*)lds_wave_base + 16 * lane, g, 16);
+#else
+    (void)lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+FQ_DEV void glds_wait() {
+#ifndef FQ_HOSTSIM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // a value that is the same in every lane of the wavefront, moved to a scalar register
 FQ_DEV u32 uniform(u32 v) {
 #ifdef FQ_HOSTSIM

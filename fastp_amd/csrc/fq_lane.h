@@ -58,6 +58,7 @@ struct LaneArgs {
     LaneLds l;
     int* chunk_ctr; // zero at launch: chunks beyond every wave's first are handed out by this counter (a static stride
                     // leaves a third of the waves one chunk short at 21.3 chunks per wave); nullptr = static stride
+    int glds;       // read 2's quality rows come into the stage by global_load_lds while read 1 is hashed (FASTP_GPU_LANE_GLDS, A/B)
 };
 
 // ---------------------------------------------------------------------------
@@ -239,6 +240,23 @@ FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int 
     wave_order();
 }
 
+// The same copy without registers (round 5): global_load_lds_dwordx4, 16 bytes per lane straight into the stage, asynchronous.
+// Issued for read 2's quality rows as soon as read 1 is done with the stage; Duplicate's hash of read 1 runs while they are on
+// their way (lane_body); lane_stage_rows_done() before the sweep.  The image is the same flat copy (lane-linear: piece k of the
+// wave = vectors 64 k .. 64 k + 63).
+FQ_DEV void lane_stage_rows_async(u32* buf, const u32* src, int rows, int stride, int lane) {
+    wave_order();   // the buffer's previous contents have been read
+    const int n16 = (rows * stride * 4) >> 4;
+    for (int base = 0; base < n16; base += 64)
+        if (base + lane < n16) glds16((const char*)src + 16 * (size_t)(base + lane), (char*)buf + 16 * (size_t)base, lane);
+}
+FQ_DEV void lane_stage_rows_done(u32* buf, const u32* src, int rows, int stride, int lane) {
+    glds_wait();
+    const int bytes = rows * stride * 4, n16 = bytes >> 4;
+    if ((bytes & 8) && lane == 0) ((u64*)buf)[2 * n16] = ((const u64*)src)[2 * n16];
+    wave_order();
+}
+
 // bit j of the result = the window that starts at base j of this 32-base word (q[0..7] its quality dwords, q[8..9] the
 // two behind them) has total quality < threshold: v_alignbit (the window's bytes), v_sad_u8 with -threshold as the
 // addend, v_alignbit to shift the sign into the mask.  WIDE: windows of 5..8 bases need a second v_sad_u8.
@@ -280,11 +298,10 @@ FQ_DEV u32 lane_window_word(const u32 (&q)[10], u32 keep_lo, u32 keep_hi, u32 nt
 // Load read `g` of one mate: bases, N mask, and in ONE sweep over the quality row the window predicate of cut_right /
 // cut_tail (the one that is enabled) and the per-32-base partial sums of countQualityMetrics.  `stage` = this
 // wavefront's LDS buffer, chunk0 = first unit of its chunk, rows = units the chunk has.
-template <int SWM, bool KEEP>   // KEEP: leave countQualityMetrics' per-word sums in `part` (read 1 of a pair: its rows leave the stage)
-FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32* seq, const u32* qual, const u16* lenp, int chunk0, int rows, int lane,
-                           bool valid, int win, int thr, u32 thr4, LaneRead<SWM>& r) {
-    const DevParams& p = a.p;
-    const int swg = p.sw_g, qwg = p.qw_g;
+// the read's length and packed bases (the mate's base rows through the stage)
+template <int SWM>
+FQ_DEV void lane_load_bases(const KernelArgs& a, u32* stage, const u32* seq, const u16* lenp, int chunk0, int rows, int lane, bool valid, LaneRead<SWM>& r) {
+    const int swg = a.p.sw_g;
     const int g = chunk0 + lane;
     r.rl0 = valid ? (int)lenp[g] : 0;
     r.len = r.rl0;
@@ -300,7 +317,20 @@ FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32
             r.s[w + 1] = (u32)(v >> 32);
         }
     }
-    lane_stage_rows<FQ_LANE_STAGE_BATCH>(stage, qual + (size_t)chunk0 * qwg, rows, qwg, lane);
+}
+template <int SWM, bool KEEP>
+FQ_DEV void lane_sweep_quality(const KernelArgs& a, u32* stage, u32* part, int lane, int win, int thr, u32 thr4, LaneRead<SWM>& r);
+template <int SWM, bool KEEP>   // KEEP: leave countQualityMetrics' per-word sums in `part` (read 1 of a pair: its rows leave the stage)
+FQ_DEV void lane_load_read(const KernelArgs& a, u32* stage, u32* part, const u32* seq, const u32* qual, const u16* lenp, int chunk0, int rows, int lane,
+                           bool valid, int win, int thr, u32 thr4, LaneRead<SWM>& r) {
+    lane_load_bases<SWM>(a, stage, seq, lenp, chunk0, rows, lane, valid, r);
+    lane_stage_rows<FQ_LANE_STAGE_BATCH>(stage, qual + (size_t)chunk0 * a.p.qw_g, rows, a.p.qw_g, lane);
+    lane_sweep_quality<SWM, KEEP>(a, stage, part, lane, win, thr, thr4, r);
+}
+// the sweep over the mate's quality rows in the stage: N mask, window predicate, read 1's partial sums
+template <int SWM, bool KEEP>
+FQ_DEV void lane_sweep_quality(const KernelArgs& a, u32* stage, u32* part, int lane, int win, int thr, u32 thr4, LaneRead<SWM>& r) {
+    const int qwg = a.p.qw_g;
     const u64* qrow = (const u64*)(stage + lane * qwg);
     const u32 nthr = (u32)(-thr);
     const u64 nthr4 = 0x0001000100010001ull * (u64)(nthr & 0xFFFFu);
@@ -1055,38 +1085,58 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
     }
     int corrected = 0;
     bool r1c = false, r2c = false;
-    for (;;) {
-        int i = -1;                                            // the smallest mismatch position left
+    auto next_mismatch = [&]() -> int {                        // the smallest mismatch position left (taken out of D), or -1
+        int i = -1;
 #pragma unroll
         for (int w = SWM - 1; w >= 0; w--)
             if (D[w]) i = 16 * w + ((ffs32(D[w]) - 1) >> 1);
-        if (ballot(i >= 0) == 0ull) break;
         if (i >= 0) {
 #pragma unroll
             for (int w = 0; w < SWM; w++)
                 if ((i >> 4) == w) D[w] &= ~(1u << (2 * (i & 15)));
-            const int p1 = o1 + i, k = o2 + i, p2 = l2 - 1 - k;    // :24-25, :38-39
-            const u32 b1 = lane_sym_of<SWM>(r1.s, r1.n, p1), brc = lane_sym_of<SWM>(rc, rcn, k);
-            const u32 b2 = sym_complement(brc);                    // r2'[p2] itself
-            const u32 c1 = (u32)q1row[fr1 + p1] & 0x7Fu, c2 = (u32)q2row[fr2 + p2] & 0x7Fu;
-            if (c1 >= 63u && c2 <= 47u) {                          // GOOD_QUAL = Q30, BAD_QUAL = Q14 (:32-33): use R1
-                const u32 nb = sym_complement(b1);
-                lane_set_sym<SWM>(r2, p2, nb);
-                q2row[fr2 + p2] = (u8)(c1 | (nb == 4u ? 0x80u : 0u));
-                lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b2) * 8 + sym_bin(nb)], 1u);
-                lane_emit_correction(a, gp, 1, fr2 + p2, nb, c1);
-                corrected++;
-                r2c = true;
-            } else if (c2 >= 63u && c1 <= 47u) {                   // use R2
-                const u32 nb = brc;                                // complement(seq2[p2])
-                lane_set_sym<SWM>(r1, p1, nb);
-                clist[(p1 >> 5) * 64 + lane] |= 1u << (p1 & 31);
-                lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b1) * 8 + sym_bin(nb)], 1u);
-                lane_emit_correction(a, gp, 0, fr1 + p1, nb, c2);
-                corrected++;
-                r1c = true;
-            }
         }
+        return i;
+    };
+    auto edit = [&](int i, u32 c1) {                           // one mismatch: :38-66
+        const int p1 = o1 + i, k = o2 + i, p2 = l2 - 1 - k;    // :24-25, :38-39
+        const u32 b1 = lane_sym_of<SWM>(r1.s, r1.n, p1), brc = lane_sym_of<SWM>(rc, rcn, k);
+        const u32 b2 = sym_complement(brc);                    // r2'[p2] itself
+        const u32 c2 = (u32)q2row[fr2 + p2] & 0x7Fu;
+        if (c1 >= 63u && c2 <= 47u) {                          // GOOD_QUAL = Q30, BAD_QUAL = Q14 (:32-33): use R1
+            const u32 nb = sym_complement(b1);
+            lane_set_sym<SWM>(r2, p2, nb);
+            q2row[fr2 + p2] = (u8)(c1 | (nb == 4u ? 0x80u : 0u));
+            lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b2) * 8 + sym_bin(nb)], 1u);
+            lane_emit_correction(a, gp, 1, fr2 + p2, nb, c1);
+            corrected++;
+            r2c = true;
+        } else if (c2 >= 63u && c1 <= 47u) {                   // use R2
+            const u32 nb = brc;                                // complement(seq2[p2])
+            lane_set_sym<SWM>(r1, p1, nb);
+            clist[(p1 >> 5) * 64 + lane] |= 1u << (p1 & 31);
+            lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b1) * 8 + sym_bin(nb)], 1u);
+            lane_emit_correction(a, gp, 0, fr1 + p1, nb, c2);
+            corrected++;
+            r1c = true;
+        }
+    };
+    // read 1's quality at a mismatch comes from memory (its rows have left the stage): the first four positions' bytes are
+    // asked for together - one round trip for nearly every pair - the rest one per round
+    int pi[4];
+    u32 pq[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) pi[t] = next_mismatch();
+#pragma unroll
+    for (int t = 0; t < 4; t++) pq[t] = pi[t] >= 0 ? ((u32)q1row[fr1 + o1 + pi[t]] & 0x7Fu) : 0u;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        if (ballot(pi[t] >= 0) == 0ull) break;
+        if (pi[t] >= 0) edit(pi[t], pq[t]);
+    }
+    for (;;) {
+        const int i = next_mismatch();
+        if (ballot(i >= 0) == 0ull) break;
+        if (i >= 0) edit(i, (u32)q1row[fr1 + o1 + i] & 0x7Fu);
     }
     if (corrected > 0) {                                           // :75-80
         lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
@@ -1186,7 +1236,7 @@ FQ_DEV void lane_stat_reads_front(const KernelArgs& a, u32* misc, int gp, u32 sw
 // ---------------------------------------------------------------------------
 // EXT: the option family with adapter sequences, polyX trimming or the complexity filter - a second instantiation, so that
 // the registers those steps need (+30) are not taken from the kernel of the options that do not use them
-template <int SWM, int B, int NPL, bool PAIRED, bool EXT>
+template <int SWM, int B, int NPL, bool PAIRED, int EXT>
 FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const KernelArgs& a = la.k;
     const LaneLds& ll = la.l;
@@ -1221,8 +1271,8 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
 #pragma unroll
     for (int w = 0; w < LANE_ADAPTER_WORDS; w++) { aw1[w] = p.a1w[w]; aw2[w] = p.a2w[w]; }
     const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
-    const bool FR = EXT && p.front_lane != 0;         // (uniform) -f / -F / a UMI at the reads' start
-    const bool CR = EXT && PAIRED && p.corr_lane != 0;   // (uniform) -c
+    const bool FR = EXT >= 2 && p.front_lane != 0;         // (uniform) -f / -F / a UMI at the reads' start
+    const bool CR = EXT >= 2 && PAIRED && p.corr_lane != 0;   // (uniform) -c
     const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
@@ -1255,8 +1305,22 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             if (valid) lane_front_trim<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.umi_len1, p.trim_front1, p.trim_tail1, fr1, ft1);
         } else if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
+        // Duplicate::seq2intvector of read 1 in front of read 2's sweep (B > 0, the asynchronous stage): what it needs of read 1
+        // is final, and it covers the round trip of read 2's quality rows
+        const bool GL = PAIRED && B > 0 && la.glds != 0;   // (uniform)
+        u64 hs_early[B > 0 ? B : 1];
         if (PAIRED) {
-            lane_load_read<SWM, false>(a, stage, part, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, thr4, r2);
+            if (GL) {
+                if constexpr (B > 0) {
+                    lane_load_bases<SWM>(a, stage, a.seq[1], a.len[1], chunk * 64, rows, lane, valid, r2);
+                    lane_stage_rows_async(stage, a.qual[1] + (size_t)(chunk * 64) * p.qw_g, rows, p.qw_g, lane);
+                    lane_hash<SWM, B, NPL>(a, lds, ll, r1, 0, hs_early);
+                    lane_stage_rows_done(stage, a.qual[1] + (size_t)(chunk * 64) * p.qw_g, rows, p.qw_g, lane);
+                    lane_sweep_quality<SWM, false>(a, stage, part, lane, win, thr, thr4, r2);
+                }
+            } else {
+                lane_load_read<SWM, false>(a, stage, part, a.seq[1], a.qual[1], a.len[1], chunk * 64, rows, lane, valid, win, thr, thr4, r2);
+            }
             if (FR) {
                 if (valid) lane_front_trim<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.umi_len2, p.trim_front2, p.trim_tail2, fr2, ft2);
             } else if (valid && !lane_trim_and_cut<SWM>(a, r2, (const u8*)(stage + lane * p.qw_g), p.trim_tail2, r2.len)) r2.flags |= RS_NULL;
@@ -1271,7 +1335,12 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         const bool claim = B > 0 && a.claim_won != nullptr;
         if constexpr (B > 0) {
             u64 hs[B], h2[B];
-            lane_hash<SWM, B, NPL>(a, lds, ll, r1, 0, hs);
+            if (GL) {
+#pragma unroll
+                for (int i = 0; i < B; i++) hs[i] = hs_early[i];
+            } else {
+                lane_hash<SWM, B, NPL>(a, lds, ll, r1, 0, hs);
+            }
             if (PAIRED) {
                 lane_hash<SWM, B, NPL>(a, lds, ll, r2, r1.rl0, h2);
 #pragma unroll
