@@ -108,7 +108,10 @@ extern "C" __global__ void __launch_bounds__(64) fq_inflate_kernel(InflateArgs a
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     inflate_body(a, (u16*)fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(256) fq_corr_stats_kernel(CorrStatsArgs c) { corr_stats_body(c); }
+extern "C" __global__ void __launch_bounds__(1024) fq_corr_stats_kernel(CorrStatsArgs c) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    corr_stats_body(c, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_corr_link_kernel(OvrArgs o) { corr_link_stride_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_dedup_apply_kernel(DedupApplyArgs d) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -205,7 +208,7 @@ struct fastp_gpu_ctx {
     int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
     u32* d_corr_int = nullptr; size_t corr_int_cap = 0;      // -c on the lane plan: the launch's corrections (KernelArgs::corr_int) + 1 counter word
     u32* d_corr_chain = nullptr; size_t corr_chain_cap = 0;  // their per-read chains: head[reads] | next[capacity]
-    int ln_glds = 1;   // FASTP_GPU_LANE_GLDS (A/B): LaneArgs::glds
+    int ln_glds = 0;   // FASTP_GPU_LANE_GLDS (A/B, measured null: profiles/r05_lane_glds_ab.txt): LaneArgs::glds
     int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
@@ -558,7 +561,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));
         ctx->st_blocks = ctx->cus * std::max(1, st_per_cu);
         ctx->lane = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
-        ctx->ln_glds = env_int("FASTP_GPU_LANE_GLDS", 1);
+        ctx->ln_glds = env_int("FASTP_GPU_LANE_GLDS", 0);
         if (ctx->lane) {
             ctx->ln_swm = ctx->dp.sw_g <= 10 ? 10 : 16;
             LaneLds& l = ctx->ln_lds;
@@ -613,7 +616,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             if (cap_tiles > 0) mp = std::min(mp, (long long)ctx->blocks * cap_tiles * ctx->L.P);
         }
         if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
-        if (ctx->split && ctx->dp.corr_lane) mp = std::min(mp, (1ll << 28) / std::max(1, ctx->dp.max_len));   // the launch's correction list (launch_chunk)
+        if (ctx->split && ctx->dp.corr_lane) mp = std::min(mp, (1ll << 29) / std::max(1, ctx->dp.max_len));   // the launch's correction list (launch_chunk)
         mp = mp / ctx->L.P * ctx->L.P;
         ctx->max_pairs_per_launch = (int)mp;
     };
@@ -695,6 +698,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
+        if (ctx->dp.corr_lane)
+            CREATE_TRY(hipFuncSetAttribute((const void*)fq_corr_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((ctx->dp.paired ? 2 : 1) * (33 * (size_t)ctx->cl.cycles + 128 + KMER_BINS) * 4)));
         // a slab per workgroup of the largest launch: st_blocks of them for the packed u64 form, rounds of st_blocks for the u32 form
         ctx->st_max_grid = ctx->st_form == 4 ? (ctx->max_pairs_per_launch + ST4_MAX_READS - 1) / ST4_MAX_READS + ctx->st_blocks : ctx->st_blocks;
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_max_grid * ctx->st_slab_dwords * 4));
@@ -1037,7 +1043,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     if (corr_lane) {
         // the engine's own correction list of this launch.  A pair can have as many edits as its overlap is long (only the first
         // 50 bases are held to the mismatch limit, overlapanalysis.cpp:34-44): the list is sized for that - it cannot overflow,
-        // and set_launch_size keeps it below 2^28 entries (2 GiB; memory laid out for 288 GB of HBM)
+        // and set_launch_size keeps it below 2^29 entries (4 GiB; memory laid out for 288 GB of HBM)
         const size_t cap = (size_t)n * (size_t)ctx->dp.max_len;
         const int rc0 = ensure(ctx, (void**)&ctx->d_corr_int, &ctx->corr_int_cap, (cap * 2 + 4) * 4);
         if (rc0) return rc0;
@@ -1397,7 +1403,11 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         cs.st_kmer = cl.st_kmer;
         cs.st_cycle = cl.st_cycle;
         cs.cycles = cl.cycles;
-        hipLaunchKernelGGL(fq_corr_stats_kernel, dim3((unsigned)((reads + 255) / 256)), dim3(256), 0, st, cs);
+        {   // persistent workgroups: the deltas of a workgroup's reads meet in its LDS tables first (corr_stats_body)
+            const size_t lds_bytes = (size_t)(ctx->dp.paired ? 2 : 1) * (33 * (size_t)cl.cycles + 128 + KMER_BINS) * 4;
+            const int cgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->cus / 2), (reads + 1023) / 1024));
+            hipLaunchKernelGGL(fq_corr_stats_kernel, dim3(cgrid), dim3(1024), lds_bytes, st, cs);
+        }
         HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(e1, st));

@@ -2666,70 +2666,90 @@ struct CorrStatsArgs {
 };
 FQ_DEV u32 ascii_sym(u32 b) { return b == 'A' ? 0u : b == 'T' ? 1u : b == 'C' ? 2u : b == 'G' ? 3u : 4u; }
 FQ_DEV u32 row_sym(const u32* srow, const u8* qrow, int j) { return (qrow[j] & 0x80u) ? 4u : ((srow[j >> 4] >> ((j & 15) * 2)) & 3u); }   // A0 T1 C2 G3 N4
-FQ_DEV void corr_stats_body(const CorrStatsArgs& c) {
-    const int t = block_id() * block_threads() + thread_id();
+// Persistent workgroups (a few per launch), the reads dealt out grid-stride; the deltas are gathered in LDS as signed 32-bit
+// sums and folded into the int64 block once per workgroup - the first form added every delta to the block with a global
+// atomic: a thousand per counter and launch, 0.69 ms (profiles/r05_other_configs_kernels.txt).
+// LDS per mate: [33 * cycles] = the Stats object's arrays 0..31 (Q30 / Q20 / content / quality sum x 8 bins) + mCycleTotalQual,
+// [128] the quality histogram, [1024] the 5-mers.
+FQ_DEV void corr_stats_body(const CorrStatsArgs& c, u32* lds) {
+    const int tid = thread_id(), nt = block_threads();
+    const int CC = (int)c.cycles;
+    const int per_mate = 33 * CC + 128 + KMER_BINS, mates = c.paired ? 2 : 1;
+    for (int i = tid; i < mates * per_mate; i += nt) lds[i] = 0;
+    block_sync();
     const int reads = c.paired ? 2 * c.n : c.n;
-    if (t >= reads) return;
-    const u32 head = c.corr_head[t];
-    if (!head) return;
-    const int g = c.paired ? t >> 1 : t, m = c.paired ? (t & 1) : 0;
-    const u32 sw = c.swin[m][g];
-    const int lk = (int)(sw >> 16), F = c.front[m];
-    if (lk <= F) return;                                   // not written out: no POST Stats
-    const u32* srow = c.seq[m] + (size_t)g * c.sw_g;
-    const u8* qrow = (const u8*)(c.qual[m] + (size_t)g * c.qw_g);
-    // (a read can hold any number of edits - only the first 50 bases of an overlap are held to the mismatch limit: the chain is
-    // walked again wherever the edits of other positions matter; such reads are few)
-    auto sym_new = [&](int j) -> u32 {                     // symbol j of the corrected read
-        u32 s2 = row_sym(srow, qrow, j);
+    for (int t = block_id() * nt + tid; t < reads; t += grid_blocks() * nt) {
+        const u32 head = c.corr_head[t];
+        if (!head) continue;
+        const int g = c.paired ? t >> 1 : t, m = c.paired ? (t & 1) : 0;
+        const u32 sw = c.swin[m][g];
+        const int lk = (int)(sw >> 16), F = c.front[m];
+        if (lk <= F) continue;                                 // not written out: no POST Stats
+        const u32* srow = c.seq[m] + (size_t)g * c.sw_g;
+        const u8* qrow = (const u8*)(c.qual[m] + (size_t)g * c.qw_g);
+        u32* cyc = lds + m * per_mate;
+        u32* hist = cyc + 33 * CC;
+        u32* kmer = hist + 128;
+        // (a read can hold any number of edits - only the first 50 bases of an overlap are held to the mismatch limit: the chain
+        // is walked again wherever the edits of other positions matter; such reads are few)
+        auto sym_new = [&](int j) -> u32 {                     // symbol j of the corrected read
+            u32 s2 = row_sym(srow, qrow, j);
+            for (u32 e = head; e; e = c.corr_next[e - 1]) {
+                const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
+                if ((int)(w1 & 0xFFFFu) == j) s2 = ascii_sym((w1 >> 16) & 0xFFu);
+            }
+            return s2;
+        };
         for (u32 e = head; e; e = c.corr_next[e - 1]) {
             const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
-            if ((int)(w1 & 0xFFFFu) == j) s2 = ascii_sym((w1 >> 16) & 0xFFu);
-        }
-        return s2;
-    };
-    int64_t* st = c.post[m];
-    int64_t* cyc = st + c.st_cycle;
-    const int64_t CC = c.cycles;
-    for (u32 e = head; e; e = c.corr_next[e - 1]) {
-        const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
-        const int P = (int)(w1 & 0xFFFFu);
-        if (P < F || P >= lk) continue;                    // trimmed away afterwards: the POST Stats never saw the base
-        const int cc = P - F;
-        const u32 so = row_sym(srow, qrow, P), qo = (u32)qrow[P] & 0x7Fu, sn = ascii_sym((w1 >> 16) & 0xFFu), qn = w1 >> 24;
-        const int bo = (int)sym_bin(so), bn = (int)sym_bin(sn);
-        if (qo >= 63u) g_atomic_add_i64(&cyc[(0 * 8 + bo) * CC + cc], -1);     // stats.cpp:209-222
-        if (qo >= 53u) g_atomic_add_i64(&cyc[(1 * 8 + bo) * CC + cc], -1);
-        g_atomic_add_i64(&cyc[(2 * 8 + bo) * CC + cc], -1);
-        g_atomic_add_i64(&cyc[(3 * 8 + bo) * CC + cc], -(int64_t)(qo - 33u));
-        if (qn >= 63u) g_atomic_add_i64(&cyc[(0 * 8 + bn) * CC + cc], 1);
-        if (qn >= 53u) g_atomic_add_i64(&cyc[(1 * 8 + bn) * CC + cc], 1);
-        g_atomic_add_i64(&cyc[(2 * 8 + bn) * CC + cc], 1);
-        g_atomic_add_i64(&cyc[(3 * 8 + bn) * CC + cc], (int64_t)(qn - 33u));
-        g_atomic_add_i64(&cyc[33 * CC + cc], (int64_t)qn - (int64_t)qo);       // mCycleTotalQual (mCycleTotalBase is unchanged)
-        g_atomic_add_i64(&st[c.st_qual_hist + qo], -1);
-        g_atomic_add_i64(&st[c.st_qual_hist + qn], 1);
-        // 5-mers: every end position j in [P, P + 4]; a j that an edit at a SMALLER position also covers is that edit's
-        for (int j = P; j <= P + 4; j++) {
-            if (j - 4 < F || j >= lk) continue;            // a 5-mer of the read that is written out needs j - 4 >= F
-            bool other = false;
-            for (u32 e2 = head; e2; e2 = c.corr_next[e2 - 1]) {
-                const int P2 = (int)(c.corr[2 * (size_t)(e2 - 1) + 1] & 0xFFFFu);
-                other = other || (P2 < P && j <= P2 + 4);
+            const int P = (int)(w1 & 0xFFFFu);
+            if (P < F || P >= lk) continue;                    // trimmed away afterwards: the POST Stats never saw the base
+            const int cc = P - F;
+            const u32 so = row_sym(srow, qrow, P), qo = (u32)qrow[P] & 0x7Fu, sn = ascii_sym((w1 >> 16) & 0xFFu), qn = w1 >> 24;
+            const int bo = (int)sym_bin(so), bn = (int)sym_bin(sn);
+            if (qo >= 63u) lds_add_u32(&cyc[(0 * 8 + bo) * CC + cc], (u32)-1);     // stats.cpp:209-222
+            if (qo >= 53u) lds_add_u32(&cyc[(1 * 8 + bo) * CC + cc], (u32)-1);
+            lds_add_u32(&cyc[(2 * 8 + bo) * CC + cc], (u32)-1);
+            lds_add_u32(&cyc[(3 * 8 + bo) * CC + cc], 0u - (qo - 33u));
+            if (qn >= 63u) lds_add_u32(&cyc[(0 * 8 + bn) * CC + cc], 1u);
+            if (qn >= 53u) lds_add_u32(&cyc[(1 * 8 + bn) * CC + cc], 1u);
+            lds_add_u32(&cyc[(2 * 8 + bn) * CC + cc], 1u);
+            lds_add_u32(&cyc[(3 * 8 + bn) * CC + cc], qn - 33u);
+            lds_add_u32(&cyc[32 * CC + cc], qn - qo);          // mCycleTotalQual (mCycleTotalBase is unchanged)
+            lds_add_u32(&hist[qo], (u32)-1);
+            lds_add_u32(&hist[qn], 1u);
+            // 5-mers: every end position j in [P, P + 4]; a j that an edit at a SMALLER position also covers is that edit's
+            for (int j = P; j <= P + 4; j++) {
+                if (j - 4 < F || j >= lk) continue;            // a 5-mer of the read that is written out needs j - 4 >= F
+                bool other = false;
+                for (u32 e2 = head; e2; e2 = c.corr_next[e2 - 1]) {
+                    const int P2 = (int)(c.corr[2 * (size_t)(e2 - 1) + 1] & 0xFFFFu);
+                    other = other || (P2 < P && j <= P2 + 4);
+                }
+                if (other) continue;
+                u32 ko = 0, kn = 0;
+                bool vo = true, vn = true;
+                for (int b = j - 4; b <= j; b++) {             // fastp's index: the earliest base in the high bits (stats.cpp:236, :250)
+                    const u32 s0 = row_sym(srow, qrow, b), s1 = sym_new(b);
+                    vo = vo && s0 < 4u;
+                    vn = vn && s1 < 4u;
+                    ko = (ko << 2) | (s0 & 3u);
+                    kn = (kn << 2) | (s1 & 3u);
+                }
+                if (vo) lds_add_u32(&kmer[ko], (u32)-1);
+                if (vn) lds_add_u32(&kmer[kn], 1u);
             }
-            if (other) continue;
-            u32 ko = 0, kn = 0;
-            bool vo = true, vn = true;
-            for (int b = j - 4; b <= j; b++) {             // fastp's index: the earliest base in the high bits (stats.cpp:236, :250)
-                const u32 s0 = row_sym(srow, qrow, b), s1 = sym_new(b);
-                vo = vo && s0 < 4u;
-                vn = vn && s1 < 4u;
-                ko = (ko << 2) | (s0 & 3u);
-                kn = (kn << 2) | (s1 & 3u);
-            }
-            if (vo) g_atomic_add_i64(&st[c.st_kmer + ko], -1);
-            if (vn) g_atomic_add_i64(&st[c.st_kmer + kn], 1);
         }
+    }
+    block_sync();
+    for (int i = tid; i < mates * per_mate; i += nt) {
+        const int v = (int)lds[i];
+        if (!v) continue;
+        const int m = i / per_mate, k = i - m * per_mate;
+        int64_t* st = c.post[m];
+        int64_t* dst = k < 32 * CC ? st + c.st_cycle + k : k < 33 * CC ? st + c.st_cycle + 33 * (int64_t)CC + (k - 32 * CC)
+                     : k < 33 * CC + 128 ? st + c.st_qual_hist + (k - 33 * CC) : st + c.st_kmer + (k - 33 * CC - 128);
+        g_atomic_add_i64(dst, (int64_t)v);
     }
 }
 
