@@ -1405,7 +1405,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         cs.cycles = cl.cycles;
         {   // persistent workgroups: the deltas of a workgroup's reads meet in its LDS tables first (corr_stats_body)
             const size_t lds_bytes = (size_t)(ctx->dp.paired ? 2 : 1) * (33 * (size_t)cl.cycles + 128 + KMER_BINS) * 4;
-            const int cgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, ctx->cus / 2), (reads + 1023) / 1024));
+            const int cgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ctx->cus * 2, (reads + 1023) / 1024));
             hipLaunchKernelGGL(fq_corr_stats_kernel, dim3(cgrid), dim3(1024), lds_bytes, st, cs);
         }
         HIP_TRY(ctx, hipGetLastError());

@@ -2690,23 +2690,37 @@ FQ_DEV void corr_stats_body(const CorrStatsArgs& c, u32* lds) {
         u32* cyc = lds + m * per_mate;
         u32* hist = cyc + 33 * CC;
         u32* kmer = hist + 128;
-        // (a read can hold any number of edits - only the first 50 bases of an overlap are held to the mismatch limit: the chain
-        // is walked again wherever the edits of other positions matter; such reads are few)
-        auto sym_new = [&](int j) -> u32 {                     // symbol j of the corrected read
-            u32 s2 = row_sym(srow, qrow, j);
-            for (u32 e = head; e; e = c.corr_next[e - 1]) {
-                const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
-                if ((int)(w1 & 0xFFFFu) == j) s2 = ascii_sym((w1 >> 16) & 0xFFu);
-            }
-            return s2;
-        };
+        // (a read can hold any number of edits - only the first 50 bases of an overlap are held to the mismatch limit: for every
+        // edit the chain is walked once more, for the neighbours within four bases; such reads are few)
+        const int rl0 = (int)(sw & 0xFFFFu);
         for (u32 e = head; e; e = c.corr_next[e - 1]) {
             const u32 w1 = c.corr[2 * (size_t)(e - 1) + 1];
             const int P = (int)(w1 & 0xFFFFu);
             if (P < F || P >= lk) continue;                    // trimmed away afterwards: the POST Stats never saw the base
             const int cc = P - F;
-            const u32 so = row_sym(srow, qrow, P), qo = (u32)qrow[P] & 0x7Fu, sn = ascii_sym((w1 >> 16) & 0xFFu), qn = w1 >> 24;
-            const int bo = (int)sym_bin(so), bn = (int)sym_bin(sn);
+            // the nine bases P - 4 .. P + 4 of the original read (independent loads: one round trip), 4 = N / outside the read
+            u32 so[9], sn[9];
+#pragma unroll
+            for (int d = 0; d < 9; d++) {
+                const int j = P - 4 + d;
+                so[d] = (j >= 0 && j < rl0) ? row_sym(srow, qrow, j) : 4u;
+                sn[d] = so[d];
+            }
+            const u32 qo = (u32)qrow[P] & 0x7Fu, qn = w1 >> 24;
+            // ... as the corrected read has them; and which of the five 5-mers that cover P belong to an edit at a smaller position
+            u32 other = 0;                                     // bit jj: the 5-mer that ends at P + jj is a smaller edit's
+            for (u32 e2 = head; e2; e2 = c.corr_next[e2 - 1]) {
+                const u32 v1 = c.corr[2 * (size_t)(e2 - 1) + 1];
+                const int P2 = (int)(v1 & 0xFFFFu), d2 = P2 - (P - 4);
+                const u32 s2 = ascii_sym((v1 >> 16) & 0xFFu);
+#pragma unroll
+                for (int d = 0; d < 9; d++) sn[d] = d == d2 ? s2 : sn[d];
+                if (P2 < P) {
+#pragma unroll
+                    for (int jj = 0; jj < 5; jj++) other |= (P + jj <= P2 + 4) ? (1u << jj) : 0u;
+                }
+            }
+            const int bo = (int)sym_bin(so[4]), bn = (int)sym_bin(sn[4]);
             if (qo >= 63u) lds_add_u32(&cyc[(0 * 8 + bo) * CC + cc], (u32)-1);     // stats.cpp:209-222
             if (qo >= 53u) lds_add_u32(&cyc[(1 * 8 + bo) * CC + cc], (u32)-1);
             lds_add_u32(&cyc[(2 * 8 + bo) * CC + cc], (u32)-1);
@@ -2718,23 +2732,19 @@ FQ_DEV void corr_stats_body(const CorrStatsArgs& c, u32* lds) {
             lds_add_u32(&cyc[32 * CC + cc], qn - qo);          // mCycleTotalQual (mCycleTotalBase is unchanged)
             lds_add_u32(&hist[qo], (u32)-1);
             lds_add_u32(&hist[qn], 1u);
-            // 5-mers: every end position j in [P, P + 4]; a j that an edit at a SMALLER position also covers is that edit's
-            for (int j = P; j <= P + 4; j++) {
-                if (j - 4 < F || j >= lk) continue;            // a 5-mer of the read that is written out needs j - 4 >= F
-                bool other = false;
-                for (u32 e2 = head; e2; e2 = c.corr_next[e2 - 1]) {
-                    const int P2 = (int)(c.corr[2 * (size_t)(e2 - 1) + 1] & 0xFFFFu);
-                    other = other || (P2 < P && j <= P2 + 4);
-                }
-                if (other) continue;
+            // 5-mers: the one that ends at j = P + jj is bases jj .. jj + 4 of the window
+#pragma unroll
+            for (int jj = 0; jj < 5; jj++) {
+                const int j = P + jj;
+                if (j - 4 < F || j >= lk || ((other >> jj) & 1u)) continue;   // a 5-mer of the read that is written out needs j - 4 >= F
                 u32 ko = 0, kn = 0;
                 bool vo = true, vn = true;
-                for (int b = j - 4; b <= j; b++) {             // fastp's index: the earliest base in the high bits (stats.cpp:236, :250)
-                    const u32 s0 = row_sym(srow, qrow, b), s1 = sym_new(b);
-                    vo = vo && s0 < 4u;
-                    vn = vn && s1 < 4u;
-                    ko = (ko << 2) | (s0 & 3u);
-                    kn = (kn << 2) | (s1 & 3u);
+#pragma unroll
+                for (int t = 0; t < 5; t++) {                  // fastp's index: the earliest base in the high bits (stats.cpp:236, :250)
+                    vo = vo && so[jj + t] < 4u;
+                    vn = vn && sn[jj + t] < 4u;
+                    ko = (ko << 2) | (so[jj + t] & 3u);
+                    kn = (kn << 2) | (sn[jj + t] & 3u);
                 }
                 if (vo) lds_add_u32(&kmer[ko], (u32)-1);
                 if (vn) lds_add_u32(&kmer[kn], 1u);

@@ -1037,13 +1037,23 @@ FQ_DEV void lane_set_sym(LaneRead<SWM>& r, int j, u32 sym) {
     }
     if (sym == 4u) r.flags |= RS_HAS_N;
 }
-FQ_DEV void lane_emit_correction(const KernelArgs& a, int gp, int which, int rowpos, u32 nb, u32 nq) {
+// the round's edits of a wavefront go to the lists together: ONE atomic per list and round takes the slots of all lanes that
+// have one (a million atomics on one counter per launch serialise at L2; which < 0: this lane has none).  A wave collective.
+FQ_DEV void lane_emit_corrections(const KernelArgs& a, int lane, int gp, int which, int rowpos, u32 nb, u32 nq) {
+    const u64 em = ballot(which >= 0);
+    if (em == 0ull) return;
+    const int cnt = popc64(em), leader = ffs64(em) - 1;
+    const int rank = popc64(em & ((1ull << lane) - 1ull));
     const u32 w0 = (u32)(2 * (a.first + gp) + which), w1 = (u32)rowpos | (sym_ascii(nb) << 16) | (nq << 24);
-    const int slot = g_atomic_add_i32(a.n_corr_int, 1);       // never full: sized for the mismatch limit of every pair
-    if (slot < a.corr_int_cap) { a.corr_int[2 * slot] = w0; a.corr_int[2 * slot + 1] = w1; }
-    if (a.corrections) {
-        const int cs = g_atomic_add_i32(a.n_corrections, 1);
-        if (cs < a.corr_capacity) { a.corrections[2 * cs] = w0; a.corrections[2 * cs + 1] = w1; }
+    int base = 0;
+    if (lane == leader) base = g_atomic_add_i32(a.n_corr_int, cnt);   // never full: sized for an edit at every base of every pair
+    base = (int)shfl((u32)base, leader);
+    if (which >= 0 && base + rank < a.corr_int_cap) { a.corr_int[2 * (base + rank)] = w0; a.corr_int[2 * (base + rank) + 1] = w1; }
+    if (a.corrections) {   // (uniform)
+        int cb = 0;
+        if (lane == leader) cb = g_atomic_add_i32(a.n_corrections, cnt);
+        cb = (int)shfl((u32)cb, leader);
+        if (which >= 0 && cb + rank < a.corr_capacity) { a.corrections[2 * (cb + rank)] = w0; a.corrections[2 * (cb + rank) + 1] = w1; }
     }
 }
 // key = the pair's accepted overlap (no gap), l1 / l2 the lengths it was found on; rc / rcn = rc(r2') as the scan built it.
@@ -1097,6 +1107,8 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
         }
         return i;
     };
+    int em_which = -1, em_pos = 0;                             // this round's edit of the lane, for the lists
+    u32 em_nb = 0, em_nq = 0;
     auto edit = [&](int i, u32 c1) {                           // one mismatch: :38-66
         const int p1 = o1 + i, k = o2 + i, p2 = l2 - 1 - k;    // :24-25, :38-39
         const u32 b1 = lane_sym_of<SWM>(r1.s, r1.n, p1), brc = lane_sym_of<SWM>(rc, rcn, k);
@@ -1107,7 +1119,7 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
             lane_set_sym<SWM>(r2, p2, nb);
             q2row[fr2 + p2] = (u8)(c1 | (nb == 4u ? 0x80u : 0u));
             lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b2) * 8 + sym_bin(nb)], 1u);
-            lane_emit_correction(a, gp, 1, fr2 + p2, nb, c1);
+            em_which = 1; em_pos = fr2 + p2; em_nb = nb; em_nq = c1;
             corrected++;
             r2c = true;
         } else if (c2 >= 63u && c1 <= 47u) {                   // use R2
@@ -1115,7 +1127,7 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
             lane_set_sym<SWM>(r1, p1, nb);
             clist[(p1 >> 5) * 64 + lane] |= 1u << (p1 & 31);
             lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b1) * 8 + sym_bin(nb)], 1u);
-            lane_emit_correction(a, gp, 0, fr1 + p1, nb, c2);
+            em_which = 0; em_pos = fr1 + p1; em_nb = nb; em_nq = c2;
             corrected++;
             r1c = true;
         }
@@ -1131,12 +1143,16 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         if (ballot(pi[t] >= 0) == 0ull) break;
+        em_which = -1;
         if (pi[t] >= 0) edit(pi[t], pq[t]);
+        lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
     }
     for (;;) {
         const int i = next_mismatch();
         if (ballot(i >= 0) == 0ull) break;
+        em_which = -1;
         if (i >= 0) edit(i, (u32)q1row[fr1 + o1 + i] & 0x7Fu);
+        lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
     }
     if (corrected > 0) {                                           // :75-80
         lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
