@@ -3419,32 +3419,58 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
         int i = 0;
         u32 h = 0;
         bool fresh = true;  // h has to be computed from scratch for the window at i
+        // Four positions per trip (round 5): the symbols the next three slides need and the first table slot of all four
+        // windows are asked for together - independent LDS reads, two round trips per four positions instead of three per
+        // position on a lane's critical path - then looked at in order; a hit (rare) throws the rest of the block away.
         while (i < len - L) {  // for (i = 0; i < len - step; i++) (:276)
             if (fresh) {
                 h = 0;
                 for (int k = 0; k < L; k++) h = h * OVR_HASH_MUL + OVR_SYM(f + i + k) + 1u;
                 fresh = false;
             }
-            const u32 key = h ^ salt;
-            int hit = -1;
-            for (u32 sl = (key * OVR_SALT_MUL) & M.table_mask;; sl = (sl + 1) & M.table_mask) {
-                const u32 id1 = tab[2 * sl + 1];
-                if (id1 == 0u) break;
-                if (tab[2 * sl] == key && M.seed_len[id1 - 1] == L) {
-                    const u8* sd = M.seed_sym + (size_t)(id1 - 1) * OVR_SEED_STRIDE;
-                    bool same = true;
-                    for (int k = 0; k < L && same; k++) same = sd[k] == (u8)OVR_SYM(f + i + k);
-                    if (same) { hit = (int)id1 - 1; break; }
+            const int nb = imin(4, len - L - i);   // positions i .. i + nb - 1 are inside the loop's range
+            u32 so[4], si[4];                      // the symbols that leave / enter when the window slides from i + b to i + b + 1
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                so[b] = b < nb ? OVR_SYM(f + i + b) : 0u;
+                si[b] = b < nb ? OVR_SYM(f + i + b + L) : 0u;   // (i + b + L <= len - 1)
+            }
+            u32 hh[5];
+            hh[0] = h;
+#pragma unroll
+            for (int b = 0; b < 4; b++) hh[b + 1] = (hh[b] - (so[b] + 1u) * pw) * OVR_HASH_MUL + si[b] + 1u;
+            u32 s0[4], id0[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                s0[b] = ((hh[b] ^ salt) * OVR_SALT_MUL) & M.table_mask;
+                id0[b] = b < nb ? tab[2 * s0[b] + 1] : 0u;
+            }
+            int hit = -1, hit_b = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if (b < nb && hit < 0 && id0[b] != 0u) {   // an occupied first slot: the probe as the table defines it
+                    const u32 key = hh[b] ^ salt;
+                    for (u32 sl = s0[b];; sl = (sl + 1) & M.table_mask) {
+                        const u32 id1 = tab[2 * sl + 1];
+                        if (id1 == 0u) break;
+                        if (tab[2 * sl] == key && M.seed_len[id1 - 1] == L) {
+                            const u8* sd = M.seed_sym + (size_t)(id1 - 1) * OVR_SEED_STRIDE;
+                            bool same = true;
+                            for (int k = 0; k < L && same; k++) same = sd[k] == (u8)OVR_SYM(f + i + b + k);
+                            if (same) { hit = (int)id1 - 1; hit_b = b; break; }
+                        }
+                    }
                 }
             }
             if (hit >= 0) {  // mOverRepSeq[seq]++, the covered positions of mOverRepSeqDist, i += step (:279-284)
+                const int at = i + hit_b;
                 g_atomic_add_i64(&cnt[hit], 1);
-                for (int pp = i; pp < i + L && pp < M.eval_len; pp++) g_atomic_add_i64(&dist[(size_t)hit * M.eval_len + pp], 1);
-                i += L + 1;
+                for (int pp = at; pp < at + L && pp < M.eval_len; pp++) g_atomic_add_i64(&dist[(size_t)hit * M.eval_len + pp], 1);
+                i = at + L + 1;
                 fresh = true;
-            } else {  // slide the window by one base
-                h = (h - (OVR_SYM(f + i) + 1u) * pw) * OVR_HASH_MUL + OVR_SYM(f + i + L) + 1u;
-                i++;
+            } else {  // the window has slid by nb bases
+                h = nb == 4 ? hh[4] : nb == 3 ? hh[3] : nb == 2 ? hh[2] : hh[1];
+                i += nb;
             }
         }
     }
