@@ -3402,7 +3402,29 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
     u8* symv = (u8*)lds + tk;
     const bool staged = o.sym_cap > 0;   // (uniform; launch_overrep sizes the rows for the longest read or not at all)
     if (staged) {
-        for (int j = my_step; j < len; j += OVR_STEPS) symv[(size_t)j * OVR_SYM_STRIDE] = (u8)ovr_fetch(o, r, j);
+        // the plain case (a mate's packed row, no correction chain, no text): eight symbols' loads in flight at a time - as one
+        // ovr_fetch per trip every symbol was a round trip to memory of its own, fifty in a row for a lane of a 250-base read
+        const bool simple = src != OVR_SRC_MERGED && !r.raw[mt] && !r.chain[mt];
+        if (ballot(work && !simple) == 0ull) {   // (wave-uniform)
+            const u32* srow = r.srow[mt];
+            const u8* qrow = r.qrow[mt];
+            for (int j0 = my_step; j0 < len; j0 += 8 * OVR_STEPS) {
+                u32 w[8], qb[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = j0 + u * OVR_STEPS, at = r.f[0] + imin(j, len - 1);
+                    w[u] = srow[at >> 4];
+                    qb[u] = qrow[at];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = j0 + u * OVR_STEPS, at = r.f[0] + j;
+                    if (j < len) symv[(size_t)j * OVR_SYM_STRIDE] = (u8)((qb[u] & 0x80u) ? 4u : ((w[u] >> ((at & 15) * 2)) & 3u));
+                }
+            }
+        } else {
+            for (int j = my_step; j < len; j += OVR_STEPS) symv[(size_t)j * OVR_SYM_STRIDE] = (u8)ovr_fetch(o, r, j);
+        }
         block_sync();
     }
     if (!work) return;

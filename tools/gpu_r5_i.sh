@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -k "correction or corr or random_option or plans_agree" > gpurun_out/r5i_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r5i_pytest.log
+timeout 600 python -m pytest tests -m gpu -q -p no:cacheprovider -k "correction or corr or random_option or plans_agree or overrep or config4 or config5" > gpurun_out/r5i_pytest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r5i_pytest.log
 rm -rf gpurun_out/prof/r5i_cfg
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/r5i_cfg -o t -- python -c "
 import sys, json, torch
