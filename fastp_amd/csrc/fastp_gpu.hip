@@ -479,7 +479,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->cfg.halves = 1;
         rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
     }
-    if (rc && ctx->split && ctx->cfg.P == 0 && !getenv("FASTP_GPU_LDS_KB")) {  // long reads: the small budget holds no tile
+    if (rc && ctx->split && !getenv("FASTP_GPU_LDS_KB")) {  // long reads (or a tile size asked for): the small budget holds no such tile
         ctx->cfg.lds_budget = lds_kb_default * 1024;
         rc = compute_lds_layout(ctx->dp, ctx->cfg, ctx->L, err, ctx->luts.dup_nq);
     }
@@ -1096,7 +1096,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     const bool claim_fused = ctx->dp.dup_enabled && (!ctx->dp.dedup || dedup_folded) && mode == CHUNK_STREAM && !piped &&
                              (ctx->dp.dup_bufnum <= 2 || dedup_folded) && !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1) && !exact;
     // the text kernel: a lane per unit with a private stretch of HBM for its text buffers; counters straight into d_ctr
-    auto launch_exact = [&](int hash_only) -> int {
+    auto launch_exact = [&](int hash_only, hipStream_t xst = nullptr) -> int {
+        hipStream_t st = xst ? xst : st_main;   // (shadows the launch stream: the text kernel may run beside the Stats kernel)
         ExactArgs e;
         memset(&e, 0, sizeof(e));
         e.k = a;
@@ -1289,7 +1290,18 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         else hipLaunchKernelGGL(fq_fused_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (exact) {   // behind the plan's kernel: the records and hash values of its units are overwritten
+    // The text kernel of the units with letters outside ACGTN runs behind the plan's kernel (the records and hash values of its
+    // units are overwritten) - and, in the split plans, BESIDE the Stats kernel (round 5): the Stats kernel needs nothing of it
+    // (the listed units are empty reads to it, the text kernel adds their Stats itself), only Duplicate's kernels do, so both go
+    // to the tail stream.  A launch with a handful of such units used to wait 2.6 - 3.1 ms for one lane's walk before anything else ran.
+    bool exact_on_tail = false;
+    if (exact && ctx->split && ctx->tail && mode == CHUNK_STREAM && !piped && !ctx->dp.dedup && n > 0 && env_int("FASTP_GPU_EXACT_TAIL", 1)) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
+        rc = launch_exact(0, ctx->tail);
+        if (rc) return rc;
+        exact_on_tail = true;
+    } else if (exact) {
         rc = launch_exact(0);
         if (rc) return rc;
     }
@@ -1322,6 +1334,14 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
         rc = launch_dup(nullptr, mode == CHUNK_PASS1, ctx->tail, 2);
         if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
+        dup_tail_launched = true;
+    } else if (exact_on_tail) {
+        // Duplicate's kernels behind the text kernel, on its stream (the claim is not fused into a launch that has such units)
+        if (ctx->dp.dup_enabled) {
+            rc = launch_dup(nullptr, false, ctx->tail, 0);
+            if (rc) return rc;
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
         dup_tail_launched = true;
     }
