@@ -293,8 +293,9 @@ def e2e_compressed_leg(sample_pairs, flags, dev):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def other_configs(dev):
-    """the other single-GPU BASELINE.json configurations, inputs resident in HBM (not bench lines: reported beside it)"""
+def other_configs(dev, only=None):
+    """the other single-GPU BASELINE.json configurations, inputs resident in HBM (not bench lines: reported beside it);
+    only: run the configurations whose name contains this text"""
     import numpy as np
     import torch
     import synth_torch
@@ -302,6 +303,8 @@ def other_configs(dev):
     res = []
 
     def run(name, params, Lr, n, paired, steps=4, soft_masked_every=0):
+        if only and only not in name:
+            return
         d = synth_torch.synth_pairs_torch(n, L=Lr, seed=5, device=dev)
         bufs = {}
         for m in ("1", "2") if paired else ("1",):
@@ -373,8 +376,8 @@ def other_configs(dev):
     p.adapter_seq_r2 = b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT"
     p.cut_right = 1
     run("PE 2x150 --adapter_sequence/--adapter_sequence_r2 + --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
-    # everyday flags that move kept bases: -f / a UMI are on the lane plan since round 5 (the same front for every read that is
-    # written out); -c and --merge still take the tile kernel (fused plan) - listed so that the difference is on the line
+    # everyday flags that move or edit kept bases, all on the lane plan since round 5: -f / a UMI (the same front for every read
+    # that is written out), -c, --merge (which switches -c on, options.cpp:119-121)
     p = abi.default_params(True, 150)
     p.cut_right = 1
     p.trim_front1 = p.trim_front2 = 5

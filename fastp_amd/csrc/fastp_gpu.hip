@@ -90,6 +90,7 @@ extern "C" __global__ void __launch_bounds__(OVR_BLOCK) fq_ovr_count_kernel(OvrA
     ovr_count_body(o, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(256) fq_ovr_corr_link_kernel(OvrArgs o) { ovr_corr_link_body(o); }
+extern "C" __global__ void __launch_bounds__(64) fq_ovr_dist_kernel(OvrArgs o) { ovr_dist_body(o); }
 extern "C" __global__ void __launch_bounds__(256) fq_parse_count_kernel(ParseArgs p) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     parse_count_body(p, fq_lds);
@@ -277,6 +278,9 @@ struct fastp_gpu_ctx {
     bool exact_all = false;                                // FASTP_GPU_EXACT=1: every unit takes it (tests)
     u8* d_x_scratch = nullptr; size_t x_scratch_cap = 0;   // [lanes][lane_bytes]
     int* d_x_unit = nullptr; size_t x_unit_cap = 0;        // the submitted batch's exotic unit list
+    u8* d_x_skip = nullptr; size_t x_skip_cap = 0;          // KernelArgs::xskip of the launch
+    u32* d_al[4] = {nullptr, nullptr, nullptr, nullptr}; size_t al_cap[4] = {0, 0, 0, 0};   // merge mode: 16-byte aligned copies of a launch's rows
+    int* d_ovr_diff = nullptr; size_t ovr_diff_cap = 0;     // OvrArgs::dist_diff, the four slots one behind the other (zero between launches)
     u16* d_x_len = nullptr; size_t x_len_cap = 0;          // the launch's length arrays with the text kernel's units zeroed (what the plan's kernels see)
     void* d_x_text[2] = {nullptr, nullptr}; size_t x_text_cap[2] = {0, 0};   // host submits: the raw text + offsets staged in HBM
     void* d_x_off[2] = {nullptr, nullptr}; size_t x_off_cap[2] = {0, 0};
@@ -369,7 +373,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
                     ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr,
-                    ctx->d_corr_int, ctx->d_corr_chain, ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
+                    ctx->d_corr_int, ctx->d_corr_chain, ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_skip, ctx->d_ovr_diff, ctx->d_al[0], ctx->d_al[1], ctx->d_al[2], ctx->d_al[3], ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
@@ -383,7 +387,8 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
-    if (!(p.stats_one_pass || p.front_lane || p.corr_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
+    if (!(p.stats_one_pass || p.front_lane || p.corr_lane || p.merge_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
+    if (p.merge && !p.merge_lane) return false;
     if ((p.has_a1 && p.alen1 > 64) || (p.has_a2 && p.alen2 > 64)) return false;   // the lane kernel keeps an adapter in four uniform words
     if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
     if (p.cut_right && (p.wR < 1 || p.wR > 8)) return false;
@@ -406,11 +411,18 @@ static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
 }
 // ext: 1 = adapter sequences, polyX trimming or the complexity filter are on (the instantiation that carries those steps);
 // 2 = a front trim or -c as well (round 5; an instantiation of its own: with their code in it the first one spilled 77 dwords)
+// 3 = --merge as well (paired only)
 static int lane_ext(const DevParams& p) {
+    if (p.merge_lane) return 3;
     if (p.front_lane || p.corr_lane) return 2;
     return (p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter) ? 1 : 0;
 }
+static lane_kernel_fn lane_kernel_merge(int swm, int B) {
+    if (swm == 10) return B == 0 ? fq_lane_kernel<10, 0, 3, true, 3> : B == 2 ? fq_lane_kernel<10, 2, 3, true, 3> : fq_lane_kernel<10, 4, 3, true, 3>;
+    return B == 0 ? fq_lane_kernel<16, 0, 3, true, 3> : B == 2 ? fq_lane_kernel<16, 2, 3, true, 3> : fq_lane_kernel<16, 4, 3, true, 3>;
+}
 static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, int ext) {
+    if (ext == 3) return lane_kernel_merge(swm, B);
     return ext == 2 ? lane_kernel_pick<2>(swm, B, paired) : ext == 1 ? lane_kernel_pick<1>(swm, B, paired) : lane_kernel_pick<0>(swm, B, paired);
 }
 
@@ -459,7 +471,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     // the Stats kernel as its own launch: options that leave every kept base where it was, or (lane plan only) move it by the
     // same front for every read that is written out (DevParams::front_lane)
     const bool lane_wanted = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
-    ctx->split = (ctx->dp.stats_one_pass || ((ctx->dp.front_lane || ctx->dp.corr_lane) && lane_wanted)) && env_int("FASTP_GPU_SPLIT", 1) != 0;
+    ctx->split = (ctx->dp.stats_one_pass || ((ctx->dp.front_lane || ctx->dp.corr_lane || ctx->dp.merge_lane) && lane_wanted)) && env_int("FASTP_GPU_SPLIT", 1) != 0;
     ctx->cfg.split = ctx->split ? 1 : 0;
     ctx->cfg.threads = env_int("FASTP_GPU_THREADS", ctx->split ? 256 : 1024);
     ctx->cfg.P = env_int("FASTP_GPU_TILE", 0);
@@ -507,7 +519,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
         ctx->st_H = ctx->dp.qw_g / 2;
-        ctx->st_form = (env_int("FASTP_GPU_STATS_V", 4) == 3 && !ctx->dp.front_lane && !ctx->dp.corr_lane) ? 3 : 4;   // (a front / -c: form 4 only)
+        ctx->st_form = (env_int("FASTP_GPU_STATS_V", 4) == 3 && !ctx->dp.front_lane && !ctx->dp.corr_lane && !ctx->dp.merge_lane) ? 3 : 4;   // (a front / -c / --merge: form 4 only)
         if (ctx->st_form == 4) {
             // round 5's form: [2][8][ST4_ROWS][Hs] u32 per-cycle cells of ONE mate, KC copies of its 5-mer counters, its histogram
             ctx->st_kc = env_int("FASTP_GPU_STATS_KC", 4);
@@ -567,6 +579,11 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             LaneLds& l = ctx->ln_lds;
             int o = 0;
             l.n_misc = MISC_ISIZE + ctx->dp.isize_max + 1;
+            l.jkmer = 0;
+            if (ctx->dp.merge_lane) {   // the merged reads' junction 5-mers: counters behind the MISC_* ones (ReduceArgs::merge_tail)
+                l.jkmer = o + l.n_misc;
+                l.n_misc += KMER_BINS;
+            }
             l.misc = o; o += l.n_misc;
             const int lw = (ctx->dp.cycles + 2) / 2;
             l.lut_ov = o; o += lw;
@@ -867,6 +884,24 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         }
         o.ctr = ctx->d_ctr;
         for (int k = 0; k < 4; k++) { o.o_count[k] = cl.overrep_count[k]; o.o_dist[k] = cl.overrep_dist[k]; }
+        int diff_rows = 0;
+        // mOverRepSeqDist as a difference array (OvrArgs::dist_diff): measured, no gain - configs[4] 4.90 ms without, 5.11 ms with
+        // (the fold's 130 lanes walk 251 positions each; profiles/r05_ovr_diff_ab.txt) - off unless asked for
+        if (env_int("FASTP_GPU_OVR_DIFF", 0)) {
+            size_t words = 0;
+            for (int k = 0; k < 4; k++) words += (size_t)o.mate[k >> 1].n_seeds * (size_t)(o.mate[k >> 1].eval_len + 1);
+            const size_t had = ctx->ovr_diff_cap;
+            rc = ensure(ctx, (void**)&ctx->d_ovr_diff, &ctx->ovr_diff_cap, words * 4 + 4);
+            if (rc) return rc;
+            if (ctx->ovr_diff_cap != had) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ovr_diff, 0, ctx->ovr_diff_cap, st));   // (a new buffer: the fold leaves it zero)
+            size_t at = 0;
+            for (int k = 0; k < 4; k++) {
+                const OvrMate& M = o.mate[k >> 1];
+                o.dist_diff[k] = M.n_seeds ? ctx->d_ovr_diff + at : nullptr;
+                at += (size_t)M.n_seeds * (size_t)(M.eval_len + 1);
+                diff_rows += M.n_seeds;
+            }
+        }
         if (ctx->dp.correction && !(a.corrections && a.corr_capacity > 0))
             return fail(ctx, FASTP_GPU_E_INVALID, "overrepresentation analysis with correction needs the correction list in the results");
         if (a.corrections && a.corr_capacity > 0) {  // the post-filtering Stats analyse the corrected reads
@@ -906,6 +941,10 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
             hipLaunchKernelGGL(fq_ovr_count_kernel, dim3((task_cap + OVR_TPB - 1) / OVR_TPB), dim3(OVR_BLOCK), (size_t)lds_bytes, st, o);
         }
         HIP_TRY(ctx, hipGetLastError());
+        if (diff_rows > 0) {
+            hipLaunchKernelGGL(fq_ovr_dist_kernel, dim3((diff_rows + 63) / 64), dim3(64), 0, st, o);
+            HIP_TRY(ctx, hipGetLastError());
+        }
     }
     ctx->units_seen += (uint64_t)n;
     return FASTP_GPU_OK;
@@ -997,11 +1036,21 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             else HIP_TRY(ctx, hipMemcpyAsync(copy, a.len[m], (size_t)n * sizeof(u16), hipMemcpyDeviceToDevice, st));
             a.len[m] = copy;
         }
+        // the lane plan runs the text kernel BESIDE its kernels: the lane kernel is told which units not to write (xskip)
+        u8* skip = nullptr;
+        if (ctx->lane && ctx->split && ctx->tail && mode == CHUNK_STREAM && !ctx->dp.dedup) {
+            rx = ensure(ctx, (void**)&ctx->d_x_skip, &ctx->x_skip_cap, (size_t)n);
+            if (rx) return rx;
+            skip = ctx->d_x_skip;
+            HIP_TRY(ctx, hipMemsetAsync(skip, ctx->exact_all ? 1 : 0, (size_t)n, st));
+            a.xskip = skip;
+        }
         if (!ctx->exact_all) {
             ExactMaskArgs mk;
             mk.units = ctx->d_x_unit + xk0;
             mk.count = xk1 - xk0;
             mk.first = first;
+            mk.skip = skip;
             mk.len[0] = ctx->d_x_len;
             mk.len[1] = mates == 2 ? ctx->d_x_len + n : nullptr;
             hipLaunchKernelGGL(fq_exact_mask_kernel, dim3((mk.count + 255) / 256), dim3(256), 0, st, mk);
@@ -1086,11 +1135,24 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         const void* ptrs[4] = {a.seq[0], a.qual[0], ctx->dp.paired ? a.seq[1] : a.seq[0], ctx->dp.paired ? a.qual[1] : a.qual[0]};
         for (const void* q : ptrs) use_lane = use_lane && (((uintptr_t)q & 15u) == 0);
     }
+    if (ctx->lane && !use_lane && ctx->dp.merge_lane) {
+        // --merge has this plan only in its lane form: the launch's rows move to 16-byte aligned arrays of the engine
+        for (int k = 0; k < 4; k++) {
+            const size_t bytes = (size_t)n * (size_t)((k & 1) ? ctx->dp.qw_g : ctx->dp.sw_g) * 4;
+            rc = ensure(ctx, (void**)&ctx->d_al[k], &ctx->al_cap[k], bytes + 256);
+            if (rc) return rc;
+            const u32* src = (k & 1) ? a.qual[k >> 1] : a.seq[k >> 1];
+            if (bytes) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_al[k], src, bytes, hipMemcpyDeviceToDevice, st));
+            if (k & 1) a.qual[k >> 1] = ctx->d_al[k]; else a.seq[k >> 1] = ctx->d_al[k];
+        }
+        use_lane = true;
+    }
     // Duplicate::checkPair/checkRead over this chunk, in input order (probe + resolve)
     // --dedup without the hash pre-pass (round 5, lane plan, plain stream mode): the lane kernel hashes and claims as without
     // --dedup, Duplicate's tail decides, fq_dedup_apply_kernel takes the duplicates out again before the Stats kernel counts
+    // (not in merge mode: a pair that merges is written out whatever Duplicate says, peprocessor.cpp:523-535)
     const bool dedup_folded = ctx->dp.dedup && use_lane && mode == CHUNK_STREAM && !piped && !exact && !env_int("FASTP_GPU_DUP_TABLE", 0) &&
-                              env_int("FASTP_GPU_DEDUP_FOLD", 1);
+                              !ctx->dp.merge_lane && env_int("FASTP_GPU_DEDUP_FOLD", 1);
     // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers (the lane kernel: four as well), the
     // context's own stream order
     const bool claim_fused = ctx->dp.dup_enabled && (!ctx->dp.dedup || dedup_folded) && mode == CHUNK_STREAM && !piped &&
@@ -1263,6 +1325,18 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (rc) return rc;
     }
     int ln_grid = 0;
+    // The text kernel of the units with letters outside ACGTN, lane plan (round 5): it runs on the tail stream from here on,
+    // BESIDE the lane kernel (which counts such a unit as the empty unit it sees and writes nothing of it, KernelArgs::xskip)
+    // and the Stats kernel (to which it is an empty read); Duplicate's kernels wait for both.  A launch with a handful of such
+    // units used to wait 2.6 - 3.1 ms for one lane's walk between the two kernels.
+    bool exact_early = exact && use_lane && a.xskip != nullptr && !piped && env_int("FASTP_GPU_EXACT_EARLY", 1) != 0;
+    if (!exact_early) a.xskip = nullptr;
+    if (exact_early) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
+        rc = launch_exact(0, ctx->tail);
+        if (rc) return rc;
+    }
     hipEvent_t e0, e1;
     rc = get_events(ctx, &e0, &e1);
     if (rc) return rc;
@@ -1280,6 +1354,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.l = ctx->ln_lds;
             la.chunk_ctr = ctx->d_ln_ctr;
             la.glds = ctx->ln_glds;
+            la.post1 = ctx->d_ctr + cl.stats[1];
+            la.st_qual_hist = cl.st_qual_hist; la.st_kmer = cl.st_kmer; la.st_cycle = cl.st_cycle; la.cycles = cl.cycles;
             if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
             lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp));
@@ -1295,7 +1371,12 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     // (the listed units are empty reads to it, the text kernel adds their Stats itself), only Duplicate's kernels do, so both go
     // to the tail stream.  A launch with a handful of such units used to wait 2.6 - 3.1 ms for one lane's walk before anything else ran.
     bool exact_on_tail = false;
-    if (exact && ctx->split && ctx->tail && mode == CHUNK_STREAM && !piped && !ctx->dp.dedup && n > 0 && env_int("FASTP_GPU_EXACT_TAIL", 1)) {
+    if (exact_early) {
+        // (launched in front of the plan's kernel) Duplicate's kernels need that kernel's hash values as well: the tail stream joins it
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
+        exact_on_tail = true;
+    } else if (exact && ctx->split && ctx->tail && mode == CHUNK_STREAM && !piped && !ctx->dp.dedup && n > 0 && env_int("FASTP_GPU_EXACT_TAIL", 1)) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
         rc = launch_exact(0, ctx->tail);
@@ -1369,6 +1450,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.form = ctx->st_form;
         sa.kc = ctx->st_kc;
         if (ctx->dp.front_lane) { sa.front[0] = ctx->dp.lane_front1; sa.front[1] = ctx->dp.lane_front2; }
+        sa.merge = ctx->dp.merge_lane;
         for (int m = 0; m < 2; m++) { sa.seq[m] = a.seq[m]; sa.qual[m] = a.qual[m]; sa.swin[m] = ctx->d_swin[m]; }
         sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut; sa.l_mt = ctx->st_l_mt;
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
@@ -1412,8 +1494,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             cs.seq[m] = a.seq[m];
             cs.qual[m] = a.qual[m];
             cs.swin[m] = ctx->d_swin[m];
-            cs.post[m] = ctx->d_ctr + cl.stats[2 * m + 1];
+            cs.post[m] = ctx->d_ctr + cl.stats[ctx->dp.merge_lane ? 1 : 2 * m + 1];
         }
+        cs.merge = ctx->dp.merge_lane;
         cs.front[0] = ctx->dp.front_lane ? ctx->dp.lane_front1 : 0;
         cs.front[1] = ctx->dp.front_lane ? ctx->dp.lane_front2 : 0;
         cs.corr = a.corr_int;
@@ -1437,7 +1520,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     memset(&r, 0, sizeof(r));
     r.L = ctx->L;
     r.isize_max = ctx->dp.isize_max;
-    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && (ctx->dp.front_lane || ctx->dp.corr_lane));
+    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && (ctx->dp.front_lane || ctx->dp.corr_lane || ctx->dp.merge_lane));
+    r.merge_tail = (ctx->split && ctx->dp.merge_lane) ? 1 : 0;
     if (ctx->split && ctx->dp.front_lane) { r.front[0] = ctx->dp.lane_front1; r.front[1] = ctx->dp.lane_front2; }
     r.ctr = ctx->d_ctr;
     r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
@@ -1446,7 +1530,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
     r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
     r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
-    const int n_stats = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128, n_misc = MISC_ISIZE + ctx->dp.isize_max + 1;
+    const int n_stats = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128, n_misc = MISC_ISIZE + ctx->dp.isize_max + 1 + (r.merge_tail ? (int)KMER_BINS : 0);
     auto fold = [&](int parts, int nblocks, hipStream_t st) -> int {
         if (nblocks <= 0) return 0;
         r.parts = parts;

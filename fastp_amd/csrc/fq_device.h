@@ -2438,6 +2438,9 @@ struct ReduceArgs {
     int one_pass;      // slabs hold kept (POST slot) / dropped (PRE slot): PRE = kept + dropped
     int front[2];      // one_pass with a uniform front trim (DevParams::front_lane): the kept bases of mate m sit at their
                        // ORIGINAL cycle; in the POST Stats a read starts behind its front
+    int merge_tail;    // one_pass, DevParams::merge_lane: slot 3 of the Stats slabs = what read 2 gives to the POST Stats object of read 1
+                       // (stats4_tail_pass) - added to that object only; the per-read kernel's slabs carry KMER_BINS more counters
+                       // behind the MISC_* ones: the merged reads' junction 5-mers (LaneLds::jkmer, fastp's index)
     int64_t* ctr;      // counter block
     // fastp_gpu_counter_layout offsets
     int64_t o_filter, o_adapter_reads, o_adapter_bases, o_polyx_reads, o_polyx_bases, o_correction,
@@ -2459,7 +2462,7 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
     const LdsLayout& L = r.L;
     const int C = L.C, Cp = L.Cp;
     const int n_cyc = 4 * N_CLS * Cp, n_kmer = 4 * KMER_BINS, n_qh = 4 * 128;
-    const int n_misc = MISC_ISIZE + r.isize_max + 1;
+    const int n_misc = MISC_ISIZE + r.isize_max + 1 + (r.merge_tail ? (int)KMER_BINS : 0);
     const int n_stats = n_cyc + n_kmer + n_qh;
     const int lo = (r.parts & 1) ? 0 : n_stats;
     const int total = ((r.parts & 2) ? n_stats + n_misc : n_stats) - lo;
@@ -2487,7 +2490,8 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
         }
         if (!(cnt | qs)) return;
         const int bin = (int)sym_bin((u32)cls);  // 'A'&7=1 'T'&7=4 'C'&7=3 'G'&7=7 'N'&7=6
-        for (int tgt = slot; tgt >= 0; tgt -= 1) {
+        const bool tail = r.merge_tail && slot == 3;
+        for (int tgt = tail ? 1 : slot; tgt >= 0; tgt -= 1) {
             int64_t* st = r.ctr + r.o_stats[tgt] + r.st_cycle;  // Stats::mCycleBuffer layout (stats.cpp:54-63)
             // the POST Stats of a front-trimmed mate: cycle c of the original read is cycle c - front of the read that is written out
             const int cc = (r.one_pass && (tgt & 1)) ? c - r.front[tgt >> 1] : c;
@@ -2499,7 +2503,7 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
                 g_atomic_add_i64(&st[32 * CC + cc], cnt);                      // mCycleTotalBase
                 g_atomic_add_i64(&st[33 * CC + cc], qs);                       // mCycleTotalQual
             }
-            if (!(r.one_pass && (tgt & 1))) break;  // kept -> also the PRE Stats of the mate
+            if (tail || !(r.one_pass && (tgt & 1))) break;  // kept -> also the PRE Stats of the mate
         }
         return;
     }
@@ -2516,12 +2520,14 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
         // LDS index has the earliest base in the low bits; fastp's has it in the high bits
         const u32 fk = ((km & 3u) << 8) | (((km >> 2) & 3u) << 6) | (((km >> 4) & 3u) << 4) | (((km >> 6) & 3u) << 2) |
                        ((km >> 8) & 3u);
+        if (r.merge_tail && slot == 3) { g_atomic_add_i64(&r.ctr[r.o_stats[1] + r.st_kmer + fk], sum); return; }
         g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_kmer + fk], sum);
         if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_kmer + fk], sum);
     } else if (item < n_stats) {
         const int k = item - n_cyc - n_kmer;
         const int slot = k / 128, q = k - slot * 128;
         if (q == 0) return;  // character 0 = "no base" (bytes past a read's end): never a real quality (>= '!')
+        if (r.merge_tail && slot == 3) { g_atomic_add_i64(&r.ctr[r.o_stats[1] + r.st_qual_hist + q], sum); return; }
         g_atomic_add_i64(&r.ctr[r.o_stats[slot] + r.st_qual_hist + q], sum);
         if (r.one_pass && (slot & 1)) g_atomic_add_i64(&r.ctr[r.o_stats[slot - 1] + r.st_qual_hist + q], sum);
     } else {
@@ -2537,7 +2543,8 @@ FQ_DEV void reduce_body(const ReduceArgs& r) {
         else if (k == MISC_MERGED) dst = r.o_merged;
         else if (k < MISC_STAT_LENSUM) dst = r.o_stats[k - MISC_STAT_READS] + r.st_reads;
         else if (k < MISC_ISIZE) dst = r.o_stats[k - MISC_STAT_LENSUM] + r.st_length_sum;
-        else dst = r.o_isize + (k - MISC_ISIZE);
+        else if (k <= MISC_ISIZE + r.isize_max) dst = r.o_isize + (k - MISC_ISIZE);
+        else dst = r.o_stats[1] + r.st_kmer + (k - (MISC_ISIZE + r.isize_max + 1));   // (merge_tail) the junction 5-mers
         g_atomic_add_i64(&r.ctr[dst], sum);
     }
 }
@@ -2658,6 +2665,7 @@ struct CorrStatsArgs {
     const u32* qual[2];
     const u32* swin[2];       // original length | END of the kept range << 16 (0: not written out), after --dedup's decisions
     int front[2];             // start of the kept range (DevParams::lane_front*)
+    int merge;                // DevParams::merge_lane: post[1] is the POST Stats object of read 1 as well (--include_unmerged)
     const u32* corr;          // the launch's corrections (fastp_gpu_correction: read | pos, base << 16, qual << 24)
     const u32* corr_head;     // [n * (paired ? 2 : 1)] chain heads (entry + 1), corr_next [capacity]
     const u32* corr_next;
@@ -2683,7 +2691,9 @@ FQ_DEV void corr_stats_body(const CorrStatsArgs& c, u32* lds) {
         if (!head) continue;
         const int g = c.paired ? t >> 1 : t, m = c.paired ? (t & 1) : 0;
         const u32 sw = c.swin[m][g];
-        const int lk = (int)(sw >> 16), F = c.front[m];
+        // (DevParams::merge_lane, read 2: a merged read's second part - bit 15 - holds no edit, or the lane kernel counted it itself)
+        if (c.merge && m == 1 && (sw >> 31)) continue;
+        const int lk = (int)((sw >> 16) & (c.merge ? 0x3FFFu : 0xFFFFu)), F = c.front[m];
         if (lk <= F) continue;                                 // not written out: no POST Stats
         const u32* srow = c.seq[m] + (size_t)g * c.sw_g;
         const u8* qrow = (const u8*)(c.qual[m] + (size_t)g * c.qw_g);
@@ -3487,7 +3497,16 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
             if (hit >= 0) {  // mOverRepSeq[seq]++, the covered positions of mOverRepSeqDist, i += step (:279-284)
                 const int at = i + hit_b;
                 g_atomic_add_i64(&cnt[hit], 1);
-                for (int pp = at; pp < at + L && pp < M.eval_len; pp++) g_atomic_add_i64(&dist[(size_t)hit * M.eval_len + pp], 1);
+                if (o.dist_diff[slot]) {
+                    const int e0 = imin(at, M.eval_len), e1 = imin(at + L, M.eval_len);
+                    if (e0 < e1) {
+                        int* dd = o.dist_diff[slot] + (size_t)hit * (M.eval_len + 1);
+                        g_atomic_add_i32(&dd[e0], 1);
+                        g_atomic_add_i32(&dd[e1], -1);
+                    }
+                } else {
+                    for (int pp = at; pp < at + L && pp < M.eval_len; pp++) g_atomic_add_i64(&dist[(size_t)hit * M.eval_len + pp], 1);
+                }
                 i = at + L + 1;
                 fresh = true;
             } else {  // the window has slid by nb bases
@@ -3499,6 +3518,28 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
 }
 #undef OVR_SYM
 
+
+// one lane per (slot, seed) row of the difference arrays: running sums -> mOverRepSeqDist in the counter block, array cleared
+FQ_DEV void ovr_dist_body(const OvrArgs& o) {
+    int t = block_id() * block_threads() + thread_id();
+    for (int slot = 0; slot < 4; slot++) {
+        const OvrMate& M = o.mate[slot >> 1];
+        if (!o.dist_diff[slot]) continue;
+        if (t >= 0 && t < M.n_seeds) {
+            int* dd = o.dist_diff[slot] + (size_t)t * (M.eval_len + 1);
+            int64_t* dist = o.ctr + o.o_dist[slot] + (size_t)t * M.eval_len;
+            int run = 0;
+            for (int p = 0; p < M.eval_len; p++) {
+                const int v = dd[p];
+                if (v) dd[p] = 0;
+                run += v;
+                if (run) g_atomic_add_i64(&dist[p], (int64_t)run);
+            }
+            dd[M.eval_len] = 0;
+        }
+        t -= M.n_seeds;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // FASTQ text -> packed batch: FastqReader::getLine / read

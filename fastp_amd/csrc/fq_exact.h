@@ -70,6 +70,7 @@ struct ExactMaskArgs {
     const int* units;   // listed units of this launch (batch indexes)
     int count, first;
     u16* len[2];        // the launch's copies of the length arrays
+    u8* skip;           // [n] or nullptr: 1 for the listed units (KernelArgs::xskip)
 };
 FQ_DEV void exact_mask_body(const ExactMaskArgs& m) {
     const int i = block_id() * block_threads() + thread_id();
@@ -77,6 +78,7 @@ FQ_DEV void exact_mask_body(const ExactMaskArgs& m) {
     const int gp = m.units[i] - m.first;
     m.len[0][gp] = 0;
     if (m.len[1]) m.len[1][gp] = 0;
+    if (m.skip) m.skip[gp] = 1;
 }
 
 FQ_DEV void x_add(const ExactArgs& E, long long off, long long v) { g_atomic_add_i64(E.ctr + off, (int64_t)(v * E.sign)); }

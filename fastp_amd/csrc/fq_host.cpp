@@ -161,7 +161,9 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     const bool any_umi = p.umi_len1 > 0 || p.umi_len2 > 0;
     p.front_lane = !p.stats_one_pass && !p.correction && !p.merge && !p.cut_front && (!any_umi || (p.length_filter && p.length_required >= 2));
     // -c on the lane plan: same condition on the fronts
-    p.corr_lane = p.correction && !p.merge && !p.cut_front && (!any_umi || (p.length_filter && p.length_required >= 2));
+    // --merge on the lane plan: nothing in front of a read at all (merge mode switches -c on, options.cpp:119-121)
+    p.merge_lane = p.merge && p.paired && !p.cut_front && !any_umi && !p.trim_front1 && !p.trim_front2;
+    p.corr_lane = p.correction && (!p.merge || p.merge_lane) && !p.cut_front && (!any_umi || (p.length_filter && p.length_required >= 2));
     if (p.corr_lane) p.front_lane = (p.trim_front1 || p.trim_front2 || any_umi) ? 1 : 0;
     p.lane_front1 = (p.umi_len1 > 0 ? p.umi_len1 + p.umi_skip : 0) + p.trim_front1;
     p.lane_front2 = p.paired ? (p.umi_len2 > 0 ? p.umi_len2 + p.umi_skip : 0) + p.trim_front2 : 0;

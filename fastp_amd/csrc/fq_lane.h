@@ -50,6 +50,8 @@ struct LaneLds {
     int part_dwords;    // conflict-free; registers do not hold them - ten more live VGPRs spilled 270 dwords at the cap of 168)
     int clist;      // -c on the lane plan, per wavefront: the positions of read 1 that BaseCorrector edited, one bit per base,
     int clist_dwords;   // [SWM / 2 words][lane]: read 1's rows are gone when countQualityMetrics runs (lane_apply_corrected)
+    int jkmer;      // --merge on the lane plan (DevParams::merge_lane): [KMER_BINS] behind the MISC_* counters (inside n_misc, so in the
+                    // slab) - the merged reads' 5-mers that straddle the junction of the two parts (fastp's index: earliest base high)
     int total;
 };
 
@@ -59,6 +61,10 @@ struct LaneArgs {
     int* chunk_ctr; // zero at launch: chunks beyond every wave's first are handed out by this counter (a static stride
                     // leaves a third of the waves one chunk short at 21.3 chunks per wave); nullptr = static stride
     int glds;       // read 2's quality rows come into the stage by global_load_lds while read 1 is hashed (FASTP_GPU_LANE_GLDS, A/B)
+    // --merge with -c: the POST Stats object of read 1 in the counter block, for the (rare) merged read whose tail holds an edited
+    // base - the lane that has the corrected tail in registers counts it itself (lane_merge_tail_slow)
+    int64_t* post1;
+    int64_t st_qual_hist, st_kmer, st_cycle, cycles;
 };
 
 // ---------------------------------------------------------------------------
@@ -1060,7 +1066,7 @@ FQ_DEV void lane_emit_corrections(const KernelArgs& a, int lane, int gp, int whi
 // q1row: read 1's quality row in memory, q2row: read 2's in the stage (both at the ORIGINAL read's start).  nc1 = entries of clist.
 template <int SWM>
 FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, LaneRead<SWM>& r2, const u32 (&rc)[SWM], const u32 (&rcn)[SWM / 2], bool go,
-                         u32 key, int l1, int l2, int fr1, int fr2, const u8* q1row, u8* q2row, u32* clist, int lane, int gp, int& geom) {
+                         u32 key, int l1, int l2, int fr1, int fr2, const u8* q1row, u8* q2row, u32* clist, int lane, int gp, int& geom, int& r2min) {
     int ovl, off, ol, diff;
     decode_overlap(key, l1, l2, ovl, off, ol, diff);
     go = go && ovl && diff != 0;                               // :18-19
@@ -1120,6 +1126,7 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
             q2row[fr2 + p2] = (u8)(c1 | (nb == 4u ? 0x80u : 0u));
             lds_add_u32(&misc[MISC_CORRECTION + sym_bin(b2) * 8 + sym_bin(nb)], 1u);
             em_which = 1; em_pos = fr2 + p2; em_nb = nb; em_nq = c1;
+            r2min = imin(r2min, p2);
             corrected++;
             r2c = true;
         } else if (c2 >= 63u && c1 <= 47u) {                   // use R2
@@ -1248,6 +1255,120 @@ FQ_DEV void lane_stat_reads_front(const KernelArgs& a, u32* misc, int gp, u32 sw
 }
 
 // ---------------------------------------------------------------------------
+// --merge on the lane plan (DevParams::merge_lane, peprocessor.cpp:518-561)
+// ---------------------------------------------------------------------------
+// OverlapAnalysis::analyze once more, on the reads as trimmed (peprocessor.cpp:522): lane_body's analysis with the lengths of now
+// (a wave collective; the bases behind l1 / l2 in the registers are masked / shifted out as there)
+template <int SWM>
+FQ_DEV u32 lane_overlap_again(const DevParams& p, const LaneRead<SWM>& r1, const LaneRead<SWM>& r2, int l1, int l2, bool both, const u16* lut_ov) {
+    u32 key = OV_KEY_NONE;
+    const bool hasN = ((r1.flags | r2.flags) & RS_HAS_N) != 0;
+    u32 rc[SWM], rcn[SWM / 2];
+#pragma unroll
+    for (int w = 0; w < SWM; w++) rc[w] = reverse_groups(r2.s[SWM - 1 - w]) ^ 0x55555555u;
+#pragma unroll
+    for (int w = 0; w < SWM / 2; w++) rcn[w] = 0;
+    const u32 D = (u32)(16 * SWM - l2);
+    base_shift_down<SWM>(rc, D);
+    if (hasN) {
+#pragma unroll
+        for (int w = 0; w < SWM / 2; w++) rcn[w] = brev32(r2.n[SWM / 2 - 1 - w]);
+        bit_shift_down<SWM / 2>(rcn, D);
+#pragma unroll
+        for (int w = 0; w < SWM; w++) {
+            const u32 sp = nmask_word<SWM / 2>(rcn, w);
+            rc[w] &= ~(sp | (sp << 1));
+        }
+    }
+    const u32 nlim = (u32)(-(p.ov_limit_max + 1));
+    u32 cm[SWM / 2];
+    {
+        const int nvalid = both ? l1 - p.overlap_require : 0;
+        const int npre = imin(16, imin(p.overlap_require + 1, l2));
+        const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+        lane_scan<SWM>(r1.s, rc[0], nvalid, premask, nlim, cm);
+        for (;;) {
+            const int o = key == OV_KEY_NONE ? lane_next_candidate<SWM>(cm) : -1;
+            if (ballot(o >= 0) == 0ull) break;
+            if (o >= 0) {
+                const int diff = lane_verify<SWM>(r1.s, r1.n, rc, rcn, hasN, o, l1, l2, lut_ov);
+                if (diff >= 0) key = ov_key(0, o, diff);
+            }
+        }
+    }
+    if (ballot(both && key == OV_KEY_NONE) != 0ull) {
+        const int nvalid = (both && key == OV_KEY_NONE) ? l2 - p.overlap_require : 0;
+        const int npre = imin(16, imin(p.overlap_require + 1, l1));
+        const u32 premask = lowmask32(2 * npre) & 0x55555555u;
+        lane_scan<SWM>(rc, r1.s[0], nvalid, premask, nlim, cm);
+        for (;;) {
+            const int o = key == OV_KEY_NONE ? lane_next_candidate<SWM>(cm) : -1;
+            if (ballot(o >= 0) == 0ull) break;
+            if (o >= 0) {
+                const int diff = lane_verify<SWM>(rc, rcn, r1.s, r1.n, hasN, o, l2, l1, lut_ov);
+                if (diff >= 0) key = ov_key(1, o, diff);
+            }
+        }
+    }
+    return key;
+}
+// the merged read = r1[0, m1) + reverse complement of r2[0, m2) (OverlapAnalysis::merge, overlapanalysis.cpp:148-179): its 5-mers
+// that end on the first four bases of the second part hold bases of both (the Stats kernel counts the 5-mers inside either
+// part) - Stats::statRead's index, the earliest base in the high bits (stats.cpp:236, :250)
+template <int SWM>
+FQ_DEV void lane_merge_junction_kmers(u32* jk, const LaneRead<SWM>& r1, const LaneRead<SWM>& r2, int m1, int m2) {
+    u32 sy[8];   // merged[m1 - 4 + i]; 5 = no such base
+#pragma unroll
+    for (int i = 0; i < 4; i++) sy[i] = m1 - 4 + i >= 0 ? lane_sym_at<SWM>(r1, m1 - 4 + i) : 5u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) sy[4 + i] = i < m2 ? sym_complement(lane_sym_at<SWM>(r2, m2 - 1 - i)) : 5u;
+#pragma unroll
+    for (int qj = 0; qj < 4; qj++) {
+        u32 idx = 0;
+        bool ok = true;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            ok = ok && sy[qj + t] < 4u;
+            idx = (idx << 2) | (sy[qj + t] & 3u);
+        }
+        if (ok) lds_add_u32(&jk[idx], 1u);
+    }
+}
+// A merged read that passed and whose second part holds a base BaseCorrector edited (possible only when the two overlap analyses
+// disagree about the geometry: the edits sit inside the FIRST analysis' overlap, the second part is what lies outside the
+// second's): the Stats kernel would count the original bases there, so this lane - it has the corrected read 2 in registers and
+// its corrected qualities in the stage - counts the part itself, straight into the POST Stats object of read 1
+// (Stats::statRead, stats.cpp:191-266, positions m1 .. m1 + m2 - 1 of the merged read; the 5-mers that lie inside the part).
+template <int SWM>
+FQ_DEV void lane_merge_tail_slow(const LaneArgs& la, const LaneRead<SWM>& r2, const u8* q2row, int m1, int m2) {
+    int64_t* st = la.post1 + la.st_cycle;
+    const int64_t CC = la.cycles;
+    for (int j = 0; j < m2; j++) {
+        const int c = m1 + m2 - 1 - j;
+        const u32 sym = sym_complement(lane_sym_at<SWM>(r2, j));
+        const u32 q = (u32)q2row[j] & 0x7Fu;
+        const int bin = (int)sym_bin(sym);
+        if (q >= 63u) g_atomic_add_i64(&st[(0 * 8 + bin) * CC + c], 1);
+        if (q >= 53u) g_atomic_add_i64(&st[(1 * 8 + bin) * CC + c], 1);
+        g_atomic_add_i64(&st[(2 * 8 + bin) * CC + c], 1);
+        g_atomic_add_i64(&st[(3 * 8 + bin) * CC + c], (int64_t)(q - 33u));
+        g_atomic_add_i64(&st[32 * CC + c], 1);
+        g_atomic_add_i64(&st[33 * CC + c], (int64_t)(q - 33u));
+        g_atomic_add_i64(&la.post1[la.st_qual_hist + q], 1);
+        if (j + 4 < m2) {   // the 5-mer that ends at merged position c: r2[j + 4] .. r2[j], complemented
+            u32 idx = 0;
+            bool ok = true;
+            for (int t = 0; t < 5; t++) {
+                const u32 sy = sym_complement(lane_sym_at<SWM>(r2, j + 4 - t));
+                ok = ok && sy < 4u;
+                idx = (idx << 2) | (sy & 3u);
+            }
+            if (ok) g_atomic_add_i64(&la.post1[la.st_kmer + idx], 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // the kernel body: persistent wavefronts, a wavefront takes 64 consecutive units at a time
 // ---------------------------------------------------------------------------
 // EXT: the option family with adapter sequences, polyX trimming or the complexity filter - a second instantiation, so that
@@ -1289,7 +1410,9 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const bool thread0 = (a.batch_flags & 1u) != 0;   // FASTP_GPU_BATCH_STAT_ISIZE
     const bool FR = EXT >= 2 && p.front_lane != 0;         // (uniform) -f / -F / a UMI at the reads' start
     const bool CR = EXT >= 2 && PAIRED && p.corr_lane != 0;   // (uniform) -c
+    const bool MG = EXT >= 3 && PAIRED && p.merge_lane != 0;  // (uniform) --merge
     const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
+                                     // (512: a test switch that leaves the results as they are, see `slow` below)
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
     const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
@@ -1307,11 +1430,16 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         u32* part = lds + ll.part + (tid >> 6) * ll.part_dwords;
         u32* clist = lds + ll.clist + (tid >> 6) * ll.clist_dwords;
         int geom = 0;  // -c: bit 0 = read 1 has edited positions (their mask: clist), the rest: lane_correct
+        int r2min = 0x7FFF;   // -c: the smallest edited position of read 2
+        int m1 = 0, m2 = 0;   // --merge: the two parts of the merged read (mov: the second analysis found an overlap)
+        bool mov = false;
         if (CR) {
 #pragma unroll
             for (int w = 0; w < SWM / 2; w++) clist[w * 64 + lane] = 0;
         }
         const int g = valid ? gp : 0;
+        // a unit of the text kernel (which runs beside this kernel): an empty unit here, counted and not written
+        const bool xs = a.xskip != nullptr && valid && a.xskip[g] != 0;
         LaneRead<SWM> r1, r2;
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
         // DevParams::front_lane (EXT): fr = the read's front in the row (UMI + -f), ft = trimAndCut's part of it (frontTrimmed)
@@ -1362,7 +1490,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
 #pragma unroll
                 for (int i = 0; i < B; i++) hs[i] += h2[i];
             }
-            if (valid) {
+            if (valid && !xs) {
                 if (a.dup_pos)
                     for (int i = 0; i < B; i++) a.dup_pos[(size_t)g * B + i] = hs[i];
                 if (claim) lane_claim(a, g, r1.rl0 + (PAIRED ? r2.rl0 : 0), hs, B, won);
@@ -1446,7 +1574,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 // ---- BaseCorrector::correctByOverlapAnalysis (peprocessor.cpp:453-456; no gap on this plan) ----
                 if (CR && p.need_overlap)
                     lane_correct<SWM>(a, misc, r1, r2, rc, rcn, both, key, l1, l2, fr1, fr2, (const u8*)(a.qual[0] + (size_t)g * p.qw_g),
-                                      (u8*)(stage + lane * p.qw_g), clist, lane, g, geom);
+                                      (u8*)(stage + lane * p.qw_g), clist, lane, g, geom, r2min);
             }
             // ---- peprocessor.cpp:443-516: insert size, adapter trimming by overlap, max_len ----
             int cur1 = r1.len, cur2 = r2.len;
@@ -1512,7 +1640,18 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
             r1.len = cur1;
             r2.len = cur2;
-            if (valid) write_pair_result(a, g, ovl, ov_off, ov_len, ov_diff, isize_done);
+            if (MG && ballot(both) != 0ull) {   // peprocessor.cpp:518-527: the analysis of the reads as they are now decides about merging
+                const u32 key2 = lane_overlap_again<SWM>(p, r1, r2, cur1, cur2, both, lut_ov);
+                if (both) {
+                    decode_overlap(key2, cur1, cur2, ovl, ov_off, ov_len, ov_diff);
+                    if (ovl) {   // OverlapAnalysis::merge, overlapanalysis.cpp:148-179 (substr clamps)
+                        m1 = imin(ov_len + imax(0, ov_off), cur1);
+                        m2 = imax(0, imin(ov_off > 0 ? cur2 - ov_len : 0, cur2 - ov_len));
+                        mov = true;
+                    }
+                }
+            }
+            if (valid && !xs) write_pair_result(a, g, ovl, ov_off, ov_len, ov_diff, isize_done);
         } else {
             if (EXT && p.adapter_enabled && p.has_a1 && ballot(a1) != 0ull) {   // seprocessor.cpp:244-261
                 int pos = 0, cur = r1.len;
@@ -1538,6 +1677,8 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         }
         // ---- Filter::passFilter (filter.cpp:15-57), routing, records ----
         int tot1 = 0, low1 = 0, nb1 = 0, tot2 = 0, low2 = 0, nb2 = 0;
+        // (--merge: a pair that merges is filtered as its merged read - the two parts' metrics add up, peprocessor.cpp:524-526)
+        const int ml1 = (MG && mov) ? m1 : r1.len, ml2 = (MG && mov) ? m2 : (PAIRED ? r2.len : 0);
 #if FQ_LANE_METRICS == 0
         if (!(skip & 8u)) {
             lane_metrics_staged<SWM>(a, stage, a.qual[0], chunk * 64, rows, lane, r1.len, tot1, low1, nb1);
@@ -1558,23 +1699,83 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 }
             } else if (PAIRED) {
                 LaneCutWord c1;
-                lane_cut_fetch(a, a.qual[0], g, a1, r1.len, c1);
-                lane_metrics_stage<SWM>(a, row, r2, r2.len, tot2, low2, nb2);      // (read 1's cut word is on its way meanwhile)
-                lane_metrics_part<SWM>(a, r1, part, lane, c1, r1.len, tot1, low1, nb1);
+                lane_cut_fetch(a, a.qual[0], g, a1, ml1, c1);
+                lane_metrics_stage<SWM>(a, row, r2, ml2, tot2, low2, nb2);      // (read 1's cut word is on its way meanwhile)
+                lane_metrics_part<SWM>(a, r1, part, lane, c1, ml1, tot1, low1, nb1);
             } else {
                 lane_metrics_stage<SWM>(a, row, r1, r1.len, tot1, low1, nb1);
             }
         }
 #endif
         if (CR && !(skip & 8u) && ballot((geom & 1) != 0) != 0ull)   // read 1's edited positions inside its final window
-            lane_apply_corrected<SWM>(a, clist, lane, geom, (const u8*)(a.qual[0] + (size_t)g * p.qw_g), (const u8*)(stage + lane * p.qw_g), fr1, fr2, r1.len,
+            lane_apply_corrected<SWM>(a, clist, lane, geom, (const u8*)(a.qual[0] + (size_t)g * p.qw_g), (const u8*)(stage + lane * p.qw_g), fr1, fr2, ml1,
                                       tot1, low1);
         int dif1 = 0, dif2 = 0;
         if (EXT && p.complexity_filter) {   // (uniform) filter.cpp:51-54: countAdjacentDiffs of the final window
-            dif1 = lane_adjacent_diffs<SWM>(r1, r1.len);
-            if (PAIRED) dif2 = lane_adjacent_diffs<SWM>(r2, r2.len);
+            dif1 = lane_adjacent_diffs<SWM>(r1, ml1);
+            if (PAIRED) dif2 = lane_adjacent_diffs<SWM>(r2, ml2);
         }
-        if (valid) {
+        bool merged_out = false;   // --merge: this pair's merged read passed the filter
+        if (MG && valid) {   // peprocessor.cpp:518-591 in merge mode
+            const bool dedup_out = p.dedup && (r1.flags & RS_DUP);
+            int code1, code2;
+            bool post1 = false, post2 = false;   // given to the POST Stats object (of read 1: all of them, :529, :548, :554)
+            if (both && mov) {                   // :523-535 (neither the dimer evidence nor --dedup's decision is looked at here)
+                int dif = dif1 + dif2;
+                if (EXT && p.complexity_filter && m1 > 0 && m2 > 0 && lane_sym_at<SWM>(r1, m1 - 1) != sym_complement(lane_sym_at<SWM>(r2, m2 - 1))) dif++;
+                const int ml = m1 + m2;
+                code1 = code2 = filter_code_pre(p, ml, tot1 + tot2, low1 + low2, nb1 + nb2, dif, (int)lut_lowq[ml], (int)lut_cplx[ml]);
+                lds_add_u32(&misc[MISC_FILTER + code1], 2u);
+                if (code1 == 0) {
+                    r1.flags |= RS_MERGED;
+                    r2.flags |= RS_MERGED;
+                    lds_add_u32(&misc[MISC_MERGED], 1u);
+                    post1 = post2 = merged_out = true;
+                }
+            } else {
+                code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, dif1, (int)lut_lowq[r1.len], (int)lut_cplx[r1.len]) : 16;
+                code2 = a2 ? filter_code_pre(p, r2.len, tot2, low2, nb2, dif2, (int)lut_lowq[r2.len], (int)lut_cplx[r2.len]) : 16;
+                if (dimer) { code1 = 28; code2 = 28; }
+                if (both && p.merge_include_unmerged) {   // :536-559
+                    lds_add_u32(&misc[MISC_FILTER + code1], 1u);
+                    lds_add_u32(&misc[MISC_FILTER + code2], 1u);
+                    post1 = code1 == 0 && !dedup_out;
+                    post2 = code2 == 0 && !dedup_out;
+                } else {                                  // :563-591: written to out1 / out2, no Stats object sees them (:588)
+                    lds_add_u32(&misc[MISC_FILTER + imax(code1, code2)], 2u);
+                }
+            }
+            // what the Stats kernel reads: read 1's kept range is the first part / the whole read; read 2's the second part (bit 15:
+            // reverse-complemented behind the first; bit 14: counted here already, lane_merge_tail_slow) / the whole read
+            const bool slow = merged_out && ((CR && r2min < m2) || (skip & 512u));   // (512: tests - every merged read's second part this way)
+            const u32 k1 = (u32)(merged_out ? m1 : r1.len), k2 = (u32)(merged_out ? m2 : r2.len);
+            const u32 sw1 = (u32)r1.rl0 | (post1 ? k1 << 16 : 0u);
+            const u32 sw2 = (u32)r2.rl0 | (post2 ? (k2 | (merged_out ? 0x8000u : 0u) | (slow ? 0x4000u : 0u)) << 16 : 0u);
+            lds_add_u32(&misc[MISC_STAT_READS + 0], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + 0], (u32)r1.rl0);
+            lds_add_u32(&misc[MISC_STAT_READS + 2], 1u);
+            lds_add_u32(&misc[MISC_STAT_LENSUM + 2], (u32)r2.rl0);
+            lds_add_u32(&misc[MISC_STAT_READS + 1], merged_out ? 1u : (post1 ? 1u : 0u) + (post2 ? 1u : 0u));   // a merged read is ONE read
+            lds_add_u32(&misc[MISC_STAT_LENSUM + 1], (post1 ? k1 : 0u) + (post2 ? k2 : 0u));
+            a.swin_out[0][g] = sw1;
+            a.swin_out[1][g] = sw2;
+            if (!xs) {
+                // reserved: the bases of the mate in the merged read when the second analysis found an overlap (write_read_result)
+                u32* o1 = a.res[0] + (size_t)g * 3;
+                o1[0] = (u32)r1.len << 16;
+                o1[1] = ((u32)code1 & 0xFFu) | ((r1.flags & 0xFFu) << 8) | (apos1 << 16);
+                o1[2] = (alen1 & 0xFFFFu) | (mov ? (u32)m1 << 16 : 0u);
+                u32* o2 = a.res[1] + (size_t)g * 3;
+                o2[0] = (u32)r2.len << 16;
+                o2[1] = ((u32)code2 & 0xFFu) | ((r2.flags & 0xFFu) << 8) | (apos2 << 16);
+                o2[2] = (alen2 & 0xFFFFu) | (mov ? (u32)m2 << 16 : 0u);
+                if (claim) a.claim_won[g] = (u8)won;
+            }
+            if (slow) lane_merge_tail_slow<SWM>(la, r2, (const u8*)(stage + lane * p.qw_g), m1, m2);
+        }
+        if (MG) {
+            if (ballot(merged_out) != 0ull && merged_out) lane_merge_junction_kmers<SWM>(lds + ll.jkmer, r1, r2, m1, m2);
+        } else if (valid) {
             int code1 = a1 ? filter_code_pre(p, r1.len, tot1, low1, nb1, dif1, (int)lut_lowq[r1.len], (int)lut_cplx[r1.len]) : 16;
             int code2 = 0;
             if (PAIRED) {
@@ -1592,17 +1793,19 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             const u32 sw2 = PAIRED ? ((u32)r2.rl0 | (post ? (u32)(fr2 + r2.len) << 16 : 0u)) : 0u;
             if (FR) lane_stat_reads_front(a, misc, g, sw1, sw2, post ? r1.len : 0, post ? r2.len : 0);
             else split_stat_reads(a, misc, g, sw1, sw2);
-            u32* o1 = a.res[0] + (size_t)g * 3;
-            o1[0] = ((u32)fr1 & 0xFFFFu) | ((u32)r1.len << 16);
-            o1[1] = ((u32)code1 & 0xFFu) | ((r1.flags & 0xFFu) << 8) | (apos1 << 16);
-            o1[2] = alen1 & 0xFFFFu;
-            if (PAIRED) {
-                u32* o2 = a.res[1] + (size_t)g * 3;
-                o2[0] = ((u32)fr2 & 0xFFFFu) | ((u32)r2.len << 16);
-                o2[1] = ((u32)code2 & 0xFFu) | ((r2.flags & 0xFFu) << 8) | (apos2 << 16);
-                o2[2] = alen2 & 0xFFFFu;
+            if (!xs) {
+                u32* o1 = a.res[0] + (size_t)g * 3;
+                o1[0] = ((u32)fr1 & 0xFFFFu) | ((u32)r1.len << 16);
+                o1[1] = ((u32)code1 & 0xFFu) | ((r1.flags & 0xFFu) << 8) | (apos1 << 16);
+                o1[2] = alen1 & 0xFFFFu;
+                if (PAIRED) {
+                    u32* o2 = a.res[1] + (size_t)g * 3;
+                    o2[0] = ((u32)fr2 & 0xFFFFu) | ((u32)r2.len << 16);
+                    o2[1] = ((u32)code2 & 0xFFu) | ((r2.flags & 0xFFu) << 8) | (apos2 << 16);
+                    o2[2] = alen2 & 0xFFFFu;
+                }
+                if (claim) a.claim_won[g] = (u8)won;
             }
-            if (claim) a.claim_won[g] = (u8)won;
         }
     }
     block_sync();

@@ -50,6 +50,9 @@ struct StatsArgs {
     u32 debug_skip;         // profiling only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
     int form;               // 4: u32 cells, one mate's tables at a time (stats_body4, round 5); 3: round 3's packed u64 cells (stats_body)
     int kc;                 // form 4: copies of the 5-mer table (1, 2 or 4)
+    int merge;              // form 4, DevParams::merge_lane: read 2 has no POST Stats object of its own - every base of it is "dropped" in its
+                            // pass; a third pass (stats4_tail_pass) counts what swin[1] marks as kept once more into slot 3, the merged
+                            // reads' second parts at the merged reads' cycles (the slab fold adds slot 3 to the POST Stats of read 1)
     int front[2];           // form 4, DevParams::front_lane: the kept bases of a read of mate m are [front[m], swin >> 16) - the same
                             // front for every read that is written out; they are counted at their ORIGINAL cycle (the slab fold
                             // moves the POST Stats, reduce_body); the 5-mers that end on the first four kept bases exist in the
@@ -329,6 +332,65 @@ FQ_DEV void stats4_front_kmers(const StatsArgs& a, u32* lds, const u32* qual, co
     }
 }
 
+// DevParams::merge_lane, the third pass: what read 2 gives to the POST Stats object of read 1 (peprocessor.cpp:529, :554).
+// swin[1] >> 16 of a unit = kept bases k2 | flags: bit 15 = the unit merged and r2[0, k2) is the merged read's second part, i.e.
+// base j sits at the merged read's position m1 + k2 - 1 - j (m1 = swin[0] >> 16, the first part) as its complement; no bit 15
+// (--include_unmerged): read 2 as it is.  Bit 14: the lane kernel counted the part itself (lane_merge_tail_slow).
+// lane = (read 2, 8 bases); the table is ONE slot with twice the columns (a merged read is up to two reads long): it takes the place
+// of the two slots of a mate's pass, [8][ST4_ROWS][2 Hs]; 5-mers and histogram use slot 0's regions.  5-mers: the ones whose five
+// bases lie inside the part (the lane kernel adds the four that straddle the junction, lane_merge_junction_kmers).
+template <int KC>
+FQ_DEV void stats4_tail_pass(const StatsArgs& a, u32* lds, int u0, int nu, int tid, int nt, int lane) {
+    const int H = a.H, Hs2 = 2 * a.Hs;
+    const u32* qual = a.qual[1] + (size_t)u0 * a.qw_g;
+    const u32* seq = a.seq[1] + (size_t)u0 * a.sw_g;
+    const u32* swin1 = a.swin[0] + u0;
+    const u32* swin2 = a.swin[1] + u0;
+    u32* cyc = lds + a.l_cyc;
+    u32* kmer = lds + a.l_kmer + (lane & (KC - 1));
+    u32* qh = lds + a.l_qh + (lane & (ST_QH_COPIES - 1));
+    const int items = nu * H;
+    for (int it = tid; it < items; it += nt) {
+        const u32 ur = fastdiv((u32)it, a.magic_H);
+        const int h = it - (int)mul24(ur, (u32)H);
+        const u32 hi = swin2[ur] >> 16;
+        if (!hi || (hi & 0x4000u)) continue;
+        const int lk = (int)(hi & 0x3FFFu), j0 = 8 * h;
+        if (j0 >= lk) continue;
+        const bool rcf = (hi & 0x8000u) != 0;
+        const int base_c = rcf ? (int)(swin1[ur] >> 16) + lk - 1 : 0;   // merged position of r2[j] = base_c - j
+        const u32* qrow = qual + (size_t)ur * a.qw_g;
+        const u8* sb = (const u8*)(seq + (size_t)ur * a.sw_g) + 2 * h;
+        const u32 q0 = qrow[2 * h], q1 = qrow[2 * h + 1];
+        const u32 qp = h > 0 ? qrow[2 * h - 1] : 0u, qn = 2 * h + 2 < a.qw_g ? qrow[2 * h + 2] : 0u;
+        // bases j0 - 4 .. j0 + 11, two bits each; bit i of n16 = base j0 - 4 + i is an N (or lies in front of the read)
+        const u32 c32 = (h > 0 ? (u32)sb[-1] : 0u) | ((u32)sb[0] << 8) | ((u32)sb[1] << 16) | (2 * h + 2 < 4 * a.sw_g ? (u32)sb[2] << 24 : 0u);
+        auto nib = [](u32 q) { const u32 b = (q >> 7) & 0x01010101u; return (b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xFu; };
+        u32 n16 = nib(qp) | (nib(q0) << 4) | (nib(q1) << 8) | (nib(qn) << 12);
+        if (h == 0) n16 |= 0xFu;
+        for (int k = 0; k < 8; k++) {
+            const int j = j0 + k;
+            if (j >= lk) break;
+            const u32 q = ((k < 4 ? q0 : q1) >> (8 * (k & 3))) & 0x7Fu;
+            const bool isn = ((n16 >> (4 + k)) & 1u) != 0;
+            const u32 code = (c32 >> (2 * (k + 4))) & 3u;
+            const int c = rcf ? base_c - j : j;
+            const int cls = isn ? (int)CLS_N : (int)(rcf ? code ^ 1u : code);   // the complement: A0 <-> T1, C2 <-> G3
+            lds_add_u32(&cyc[(((c & 7) * ST4_ROWS) + cls * 3 + (int)stats4_level_of(q)) * Hs2 + (c >> 3)], stats4_inc_of(q));
+            lds_add_u32(&qh[(int)q * ST_QH_COPIES], 1u);
+            if (rcf) {   // the 5-mer that ends at merged position c: r2[j + 4] .. r2[j], complemented - inside the part when j + 4 < lk
+                if (j + 4 < lk && ((n16 >> (4 + k)) & 0x1Fu) == 0u) {
+                    const u32 x = (c32 >> (2 * (k + 4))) & 0x3FFu;   // r2[j] in the low bits
+                    const u32 rv = ((x & 3u) << 8) | (((x >> 2) & 3u) << 6) | (x & 0x30u) | (((x >> 6) & 3u) >> 0 << 2) | ((x >> 8) & 3u);
+                    lds_add_u32(&kmer[(int)(rv ^ 0x155u) * KC], 1u);   // earliest base of the merged read in the low bits (reduce_body)
+                }
+            } else if (((n16 >> k) & 0x1Fu) == 0u) {
+                lds_add_u32(&kmer[(int)((c32 >> (2 * k)) & 0x3FFu) * KC], 1u);
+            }
+        }
+    }
+}
+
 // ABL: the profiling instantiation (FASTP_GPU_DEBUG_SKIP 64 / 128 / 256 leave out the per-cycle / 5-mer / histogram adds:
 // what is left is the measured floor of the pass - results are meaningless then); the product instantiation has no such branch
 template <int KC, bool ABL>
@@ -377,6 +439,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
             const u32 kmer_m = (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
             const u32 qh_m = (u32)a.l_qh * 4u + (u32)(lane & (ST_QH_COPIES - 1)) * 4u;
             const int F = a.front[m];             // (uniform; 0 unless DevParams::front_lane)
+            const bool no_kept = a.merge != 0 && m == 1;   // (uniform) merge mode: read 2's swin word is for the third pass
             // The wavefront's mode = the character (with its kept bit) of the first item's first base, fixed at its first
             // appearance: bases that hit it are counted per lane and added once at the end.
             u32 mode_e = 0xFFFFFFFFu, mode4 = 0;
@@ -385,6 +448,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
                 const int it = base + lane;
                 StatsItem s;
                 stats_fetch(a, qual, seq, swin, it, it < per_mate, s);
+                if (no_kept) s.lk = 0;
                 const u32 nany = (s.q0 | s.q1 | s.qp) & 0x80808080u;   // an N among the 8 bases or the 4 before
                 const bool plain = s.act && nany == 0u;
                 if (s.act && !plain) {                                  // rare: queued for the base-by-base pass
@@ -449,7 +513,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
             for (int i = tid; i < nw; i += nt) {
                 StatsItem s;
                 stats_fetch(a, qual, seq, swin, (int)wl[1 + i], true, s);
-                stats4_item_general<KC>(&a, lds, F, s.h, s.rl0, s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);
+                stats4_item_general<KC>(&a, lds, F, s.h, s.rl0, no_kept ? 0 : s.lk, s.q0, s.q1, s.qp, s.codes, s.prev8, lane);
             }
             if (F > 0) {   // (uniform)
                 block_sync();
@@ -459,7 +523,8 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
         block_sync();
         // ---- flush the mate's two slots to the slab in its canonical packed form ([slot][cycle][class] u64, reduce_body) ----
         const int per_slot = a.Cp * N_CLS;
-        for (int i = tid; i < 2 * per_slot; i += nt) {
+        const int nsl = (a.merge && m == 1) ? 1 : 2;   // (merge mode: slot 3 is the third pass')
+        for (int i = tid; i < nsl * per_slot; i += nt) {
             const int sl = i >= per_slot ? 1 : 0;
             const int rem = i - sl * per_slot;
             const int pos = rem / N_CLS, cls = rem - pos * N_CLS;
@@ -477,19 +542,52 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
             slab[o] = (u32)v;
             slab[o + 1] = (u32)(v >> 32);
         }
-        for (int i = tid; i < 2 * KMER_BINS; i += nt) {
+        for (int i = tid; i < nsl * KMER_BINS; i += nt) {
             u32 v = 0;
             if (m < nm)
                 for (int c = 0; c < KC; c++) v += lds[a.l_kmer + i * KC + c];
             slab[2 * n_cyc + 2 * m * KMER_BINS + i] = v;
         }
-        for (int i = tid; i < 2 * 128; i += nt) {
+        for (int i = tid; i < nsl * 128; i += nt) {
             u32 v = 0;
             if (m < nm && (i & 127))   // bin 0 of a slot collects the "no base" characters of the fast path
                 for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
             slab[2 * n_cyc + 4 * KMER_BINS + 2 * m * 128 + i] = v;
         }
         block_sync();
+    }
+    if (a.merge) {   // (uniform) the third pass -> slot 3
+        for (int i = tid; i < a.l_lut; i += nt) lds[i] = 0;
+        block_sync();
+        stats4_tail_pass<KC>(a, lds, u0, nu, tid, nt, lane);
+        block_sync();
+        const int per_slot = a.Cp * N_CLS, Hs2 = 2 * a.Hs;
+        for (int i = tid; i < per_slot; i += nt) {
+            const int pos = i / N_CLS, cls = i - pos * N_CLS;
+            const int h = pos >> 3, k = pos & 7;
+            u64 v = 0;
+            if (h < Hs2) {
+                const int w = a.l_cyc + (k * ST4_ROWS + cls * 3) * Hs2 + h;
+                const u32 c0 = lds[w], c1 = lds[w + Hs2], c2 = lds[w + 2 * Hs2];
+                const u32 M = (1u << ST4_CNT_BITS) - 1u;
+                const u64 cnt = (u64)((c0 & M) + (c1 & M) + (c2 & M)), q20 = (u64)((c1 & M) + (c2 & M)), q30 = (u64)(c2 & M);
+                const u64 qs = (u64)((c0 >> ST4_CNT_BITS) + (c1 >> ST4_CNT_BITS) + (c2 >> ST4_CNT_BITS));
+                v = cnt | (q20 << CYC_Q20_SHIFT) | (q30 << CYC_Q30_SHIFT) | (qs << CYC_QSUM_SHIFT);
+            }
+            const int o = 2 * (3 * per_slot + i);
+            slab[o] = (u32)v;
+            slab[o + 1] = (u32)(v >> 32);
+        }
+        for (int i = tid; i < KMER_BINS; i += nt) {
+            u32 v = 0;
+            for (int c = 0; c < KC; c++) v += lds[a.l_kmer + i * KC + c];
+            slab[2 * n_cyc + 3 * KMER_BINS + i] = v;
+        }
+        for (int i = tid; i < 128; i += nt) {
+            u32 v = 0;
+            for (int c = 0; c < ST_QH_COPIES; c++) v += lds[a.l_qh + i * ST_QH_COPIES + c];
+            slab[2 * n_cyc + 4 * KMER_BINS + 3 * 128 + i] = v;
+        }
     }
 }
 

@@ -93,6 +93,10 @@ struct DevParams {
                             // cycle in the Stats kernel's tables and the slab fold moves the POST Stats by the mate's front
                             // (lane plan only; fq_lane.h, fq_stats.h)
     int lane_front1, lane_front2;   // that front: UMI length + skip + --trim_front of the mate
+    int merge_lane;         // round 5: --merge on the lane plan (no front trims, no UMI, no --cut_front) - the lane kernel runs the second
+                            // overlap analysis on the trimmed reads, filters the merged read and leaves the part lengths in swin; the
+                            // Stats kernel counts read 2's kept bases once more as the merged read's tail (reverse-complemented, at
+                            // the merged read's cycles: slot 3 of its slabs, which the fold adds to the POST Stats of read 1)
     int corr_lane;          // round 5: -c on the lane plan - BaseCorrector's edits are applied to the reads in registers, the Stats
                             // kernel counts the ORIGINAL reads (kept -> PRE and POST), fq_corr_stats_kernel then moves the corrected
                             // positions' contributions to the POST Stats from the old base / quality to the new one
@@ -213,6 +217,10 @@ struct OvrArgs {
     OvrMate mate[2];
     int64_t* ctr;
     int64_t o_count[4], o_dist[4];   // fastp_gpu_counter_layout::overrep_count / overrep_dist
+    // mOverRepSeqDist of a launch as a DIFFERENCE array (round 5): a hit of a seed at `at` covers positions [at, at + L) -
+    // +1 at its start, -1 behind its end, two atomics instead of up to 150; ovr_dist_body takes the running sums into the
+    // int64 block and clears the array.  [slot][n_seeds of the slot's mate][eval_len + 1] i32; nullptr: straight into the block
+    int* dist_diff[4];
     // LDS staging of the counting kernel: the task's symbols ([position][lane] bytes, sym_cap positions) and, when
     // they fit, the seed hash tables (table_lds[m] = dword offset in LDS, or -1: probe the global copy)
     int sym_cap;
@@ -346,6 +354,8 @@ struct KernelArgs {
     u32* adapter_events;   // fastp_gpu_adapter_event, 3 dwords each
     int adapter_events_capacity;
     int* n_adapter_events;
+    const u8* xskip;    // lane plan, units with letters outside ACGTN: [n] 1 = the text kernel writes this unit's records and hash
+                        // values (it runs BESIDE this kernel: nothing of such a unit may be written here, only counted)
     u64* dup_pos;       // [n][bufnum] hash values (Duplicate::seq2intvector), for the dup kernels
     // the claim step of Duplicate inside this kernel (dup_claim_issue; plain stream mode, at most two buffers):
     u8* claim_won;      // [n] or null: mask of the buffers whose bloom bit this unit found clear and set

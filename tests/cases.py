@@ -264,3 +264,29 @@ MERGE_STRESS = [
     dict(merge=1, correction=1, adapter_enabled=0, cut_front=1, cut_tail=1, overlap_require=10, max_len1=120, max_len2=90),
     dict(merge=1, correction=1, merge_include_unmerged=1, poly_x=1, trim_front1=3, trim_front2=7, avg_qual_req=30),
 ]
+
+
+# --merge on the lane plan (DevParams::merge_lane): params overrides on top of --merge -c --cut_right
+MERGE_LANE = [
+    dict(),
+    dict(merge_include_unmerged=1, dedup=1, dup_accuracy_level=2),
+    dict(complexity_filter=1, complexity_threshold=0.45, n_base_limit=2, length_required=60, poly_x=1),
+    dict(merge_include_unmerged=1, adapter_seq_r1=ADAPTER_R1.encode(), adapter_seq_r2=ADAPTER_R2.encode(), max_len1=140, max_len2=120,
+         trim_tail1=3, cut_tail=1),
+    dict(adapter_enabled=0, overlap_require=12, overlap_diff_limit=9, overlap_diff_percent_limit=35, avg_qual_req=20, dup_enabled=0),
+]
+
+
+def merge_lane_case(k, L=150, n=900):
+    """--merge on the lane plan (DevParams::merge_lane): option set k, and the two kinds of input - inserts around the read length
+    and the overlap stress pairs (every insert size, mismatch bursts: the two overlap analyses of a pair can disagree there)"""
+    import synth
+    p = abi.default_params(True, L)
+    p.cut_right = 1
+    p.merge, p.correction = 1, 1
+    for key, v in MERGE_LANE[k].items():
+        setattr(p, key, v)
+    a = synth.synth_pairs(n, L=L, seed=900 + k, insert_mean=L * 1.2, insert_sd=L * 0.5, polyg_frac=0.05, polyx_frac=0.1, dup_frac=0.2,
+                          ragged_frac=0.1, lowq_site_rate=0.05)
+    b = synth.overlap_pairs(n, L=L, seed=950 + k, err=0.04, n_rate=0.01)
+    return p, [a, b]

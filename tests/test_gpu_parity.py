@@ -122,6 +122,22 @@ def test_gpu_merge_stress(k):
     _compare(f"merge_stress{k}", p, d, True)
 
 
+@pytest.mark.twin("test_sim_merge_on_the_lane_plan")
+@pytest.mark.parametrize("k", range(len(cases.MERGE_LANE)))
+@pytest.mark.parametrize("slow", [0, 1])
+def test_gpu_merge_on_the_lane_plan(k, slow, monkeypatch):
+    """--merge on the lane plan: the second overlap analysis, the merged read's filter and Stats, --include_unmerged, -c's edits in
+    either part; slow: every merged read's second part counted by the lane kernel itself (tests/test_hostsim_parity.py)"""
+    if slow:
+        monkeypatch.setenv("FASTP_GPU_DEBUG_SKIP", "512")
+    p, sets = cases.merge_lane_case(k, n=5000)
+    g = engines.gpu_engine(p)
+    assert g.plan() == "lane"
+    g.close()
+    for i, d in enumerate(sets):
+        _compare(f"merge_lane{k}/{i}", p, d, True)
+
+
 def test_gpu_stats_work_list_overflow():
     """one-pass Stats: so many N-containing quality dwords that the LDS work list overflows"""
     p = abi.default_params(True, 150)

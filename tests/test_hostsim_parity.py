@@ -285,6 +285,80 @@ def test_sim_merge_stress(k):
     assert len(bad) == 0, f"merge stress {k}: counters differ at {bad[:8]}: oracle {co[bad[:8]]} device {cg[bad[:8]]}"
 
 
+def check_merge_lane(mk, k, plan="lane"):
+    p, sets = cases.merge_lane_case(k)
+    for d in sets:
+        args = (d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+        o = oraclelib.Oracle(p)
+        g = mk(p)
+        assert g.plan() == plan
+        ro, rg = o.process(*args), g.process(*args)
+        co, cg = o.counters(), g.counters()
+        o.close()
+        g.close()
+        for i in range(3):
+            bad = np.nonzero(ro[i] != rg[i])[0]
+            assert len(bad) == 0, f"merge on the lane plan {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
+        assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"]))
+        bad = np.nonzero(co != cg)[0]
+        assert len(bad) == 0, f"merge on the lane plan {k}: counters differ at {bad[:8]}: oracle {co[bad[:8]]} device {cg[bad[:8]]}"
+        assert int(co[g.layout.merged_pairs]) > 50   # (the case does merge)
+
+
+@pytest.mark.parametrize("k", range(len(cases.MERGE_LANE)))
+@pytest.mark.parametrize("slow", [0, 1])
+def test_sim_merge_on_the_lane_plan(k, slow, monkeypatch):
+    """the second overlap analysis, the merged read's filter, its Stats (read 1's part, the reverse-complemented part of read 2 at
+    the merged read's cycles, the junction 5-mers), --include_unmerged, -c's edits in either part - every record and counter
+    against the oracle.  slow: every merged read's second part counted by the lane kernel itself (the path a pair takes whose
+    second part holds an edited base)"""
+    if slow:
+        monkeypatch.setenv("FASTP_GPU_DEBUG_SKIP", "512")
+    check_merge_lane(engines.sim_engine, k)
+
+
+def test_sim_merge_on_the_lane_plan_rows_not_16_byte_aligned():
+    """a device batch whose arrays start 4 bytes off a 16-byte boundary: merge mode has no tile form of this plan, the engine moves
+    the rows to aligned arrays of its own - the same records and counters"""
+    p, sets = cases.merge_lane_case(1, n=400)
+    d = sets[1]
+    g = engines.sim_engine(p)
+    n = len(d["len1"])
+    packed = [engine.pack_ascii(g.lib, p.max_len, d["seq" + m], d["qual" + m], d["len" + m]) for m in "12"]
+    want = g.submit_packed(*packed[0], *packed[1])
+    cw = g.counters()
+    g.close()
+    g = engines.sim_engine(p)
+    keep = []
+
+    def off4(a):   # a copy of the array that starts 4 bytes behind a 16-byte boundary
+        raw = np.zeros(a.nbytes + 64, dtype=np.uint8)
+        start = (-raw.ctypes.data) % 16 + 4
+        raw[start:start + a.nbytes] = a.view(np.uint8).reshape(-1)
+        keep.append(raw)
+        return raw.ctypes.data + start
+    b = abi.Batch()
+    b.n, b.flags = n, abi.BATCH_STAT_ISIZE
+    b.seq1, b.qual1, b.len1 = off4(packed[0][0]), off4(packed[0][1]), packed[0][2].ctypes.data
+    b.seq2, b.qual2, b.len2 = off4(packed[1][0]), off4(packed[1][1]), packed[1][2].ctypes.data
+    assert b.seq1 % 16 == 4 and b.qual2 % 16 == 4
+    r1 = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
+    r2 = np.zeros(n, dtype=abi.READ_RESULT_DTYPE)
+    pr = np.zeros(n, dtype=abi.PAIR_RESULT_DTYPE)
+    corr = np.zeros(n * 32, dtype=abi.CORRECTION_DTYPE)
+    nc = np.zeros(1, dtype=np.int32)
+    res = abi.Results()
+    res.r1, res.r2, res.pair = r1.ctypes.data, r2.ctypes.data, pr.ctypes.data
+    res.corrections, res.corrections_capacity, res.n_corrections = corr.ctypes.data, len(corr), nc.ctypes.data
+    g.submit_device(b, res)
+    g.synchronize()
+    cg = g.counters()
+    g.close()
+    assert r1.tobytes() == want[0].tobytes() and r2.tobytes() == want[1].tobytes() and pr.tobytes() == want[2].tobytes()
+    assert np.array_equal(np.sort(corr[:nc[0]], order=["read", "pos"]), np.sort(want[3], order=["read", "pos"]))
+    assert np.array_equal(cw, cg)
+
+
 def test_sim_stats_work_list_overflow():
     """one-pass Stats: so many N-containing quality dwords that the LDS work list overflows and the
     fast path has to run the general code in place"""
