@@ -1272,11 +1272,11 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         return launch_dup(nullptr, true);
     }
     // the overrepresentation analysis reads the rows by their TRUE lengths, and the listed units' symbols from their text
-    auto overrep = [&]() -> int {
+    auto overrep = [&](hipStream_t ost = nullptr) -> int {
         KernelArgs ao = a;
         ao.len[0] = true_len[0];
         ao.len[1] = true_len[1];
-        return launch_overrep(ctx, ao, n, st, b);
+        return launch_overrep(ctx, ao, n, ost ? ost : st, b);
     };
     if (mode == CHUNK_OVERREP) return overrep();
     if (mode == CHUNK_PASS2) {
@@ -1425,6 +1425,18 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
         dup_tail_launched = true;
+    }
+    // The overrepresentation analysis needs the records (and --dedup's decisions), nothing of the Stats kernel: on the tail stream
+    // BESIDE it (round 5; behind Duplicate's tail / the text kernel when they are there - they write record flags), joined at the end
+    bool ovr_early = false;
+    if (ctx->dp.overrep && !(b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) && ctx->split && ctx->tail && mode == CHUNK_STREAM && !piped && n > 0 &&
+        env_int("FASTP_GPU_OVR_TAIL", 1)) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
+        rc = overrep(ctx->tail);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
+        ovr_early = true;           // (the launch stream waits for the tail stream below)
     }
     int st_grid = 0;
     if (ctx->split && n > 0) {
@@ -1591,7 +1603,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         rc = launch_dup(nullptr, mode == CHUNK_PASS1, nullptr, dup_prepared ? 2 : 0);
         if (rc) return rc;
     }
-    if (b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) return FASTP_GPU_OK;
+    if (ovr_early && !dup_tail_launched && !piped) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_tail, 0));
+    if ((b->flags & FASTP_GPU_BATCH_DEFER_OVERREP) || ovr_early) return FASTP_GPU_OK;
     return overrep();
 }
 
