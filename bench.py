@@ -295,7 +295,7 @@ def e2e_compressed_leg(sample_pairs, flags, dev):
 
 def other_configs(dev, only=None):
     """the other single-GPU BASELINE.json configurations, inputs resident in HBM (not bench lines: reported beside it);
-    only: run the configurations whose name contains this text"""
+    only: run the configurations whose name contains this text (several: separated by |)"""
     import numpy as np
     import torch
     import synth_torch
@@ -303,7 +303,7 @@ def other_configs(dev, only=None):
     res = []
 
     def run(name, params, Lr, n, paired, steps=4, soft_masked_every=0):
-        if only and only not in name:
+        if only and not any(o in name for o in only.split("|")):
             return
         d = synth_torch.synth_pairs_torch(n, L=Lr, seed=5, device=dev)
         bufs = {}

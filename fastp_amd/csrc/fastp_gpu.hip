@@ -58,6 +58,13 @@ __global__ void __launch_bounds__(LaneGeom<SWM>::MAX_THREADS, 1) fq_lane_kernel(
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     lane_body<SWM, B, NPL, PAIRED, EXT>(*kernel_args(&a), fq_lds);
 }
+// EXT >= 2 (fronts, -c, --merge) at 168 VGPRs spills ~150 dwords per lane; the same body compiled for two wavefronts per SIMD
+// (512 lanes, 256 VGPRs) - FASTP_GPU_LANE_EXT_WAVES picks (A/B, profiles/r05_lane_ext_waves_ab.txt)
+template <int B, int EXT>
+__global__ void __launch_bounds__(512, 1) fq_lane_pair2w_kernel(LaneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    lane_body<10, B, 3, true, EXT>(*kernel_args(&a), fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(1024, 8) fq_stats_kernel(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     if (a.form == 4) {   // (uniform)
@@ -210,6 +217,7 @@ struct fastp_gpu_ctx {
     u32* d_corr_int = nullptr; size_t corr_int_cap = 0;      // -c on the lane plan: the launch's corrections (KernelArgs::corr_int) + 1 counter word
     u32* d_corr_chain = nullptr; size_t corr_chain_cap = 0;  // their per-read chains: head[reads] | next[capacity]
     int ln_glds = 0;   // FASTP_GPU_LANE_GLDS (A/B, measured null: profiles/r05_lane_glds_ab.txt): LaneArgs::glds
+    bool ln_2w = false;   // the lane kernel's EXT >= 2 instantiation compiled for two wavefronts per SIMD (FASTP_GPU_LANE_EXT_WAVES=2)
     int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
     u32* d_st_slabs = nullptr;
@@ -421,7 +429,9 @@ static lane_kernel_fn lane_kernel_merge(int swm, int B) {
     if (swm == 10) return B == 0 ? fq_lane_kernel<10, 0, 3, true, 3> : B == 2 ? fq_lane_kernel<10, 2, 3, true, 3> : fq_lane_kernel<10, 4, 3, true, 3>;
     return B == 0 ? fq_lane_kernel<16, 0, 3, true, 3> : B == 2 ? fq_lane_kernel<16, 2, 3, true, 3> : fq_lane_kernel<16, 4, 3, true, 3>;
 }
-static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, int ext) {
+static lane_kernel_fn lane_kernel_for(int swm, int B, bool paired, int ext, bool two_waves = false) {
+    if (two_waves && swm == 10 && paired && ext == 3) return B == 0 ? fq_lane_pair2w_kernel<0, 3> : B == 2 ? fq_lane_pair2w_kernel<2, 3> : fq_lane_pair2w_kernel<4, 3>;
+    if (two_waves && swm == 10 && paired && ext == 2) return B == 0 ? fq_lane_pair2w_kernel<0, 2> : B == 2 ? fq_lane_pair2w_kernel<2, 2> : fq_lane_pair2w_kernel<4, 2>;
     if (ext == 3) return lane_kernel_merge(swm, B);
     return ext == 2 ? lane_kernel_pick<2>(swm, B, paired) : ext == 1 ? lane_kernel_pick<1>(swm, B, paired) : lane_kernel_pick<0>(swm, B, paired);
 }
@@ -599,7 +609,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             l.stage_dwords = (64 * std::max(ctx->dp.qw_g, ctx->dp.sw_g) + 4 * ctx->ln_swm + 3) & ~3;   // + the over-read of the last row
             l.part_dwords = ctx->dp.paired ? (ctx->ln_swm / 2) * 64 : 0;   // read 1 of a pair: [ln_swm / 2 words][64 lanes]
             // as many wavefronts per workgroup as the LDS holds (up to three per SIMD for reads <= 160 bases, two above)
-            const int max_waves = (ctx->ln_swm > 10 ? 512 : 256 * FQ_LANE_WAVES) / 64;
+            ctx->ln_2w = ctx->ln_swm == 10 && ctx->dp.paired && lane_ext(ctx->dp) >= 2 && env_int("FASTP_GPU_LANE_EXT_WAVES", 3) == 2;
+            const int max_waves = (ctx->ln_swm > 10 || ctx->ln_2w ? 512 : 256 * FQ_LANE_WAVES) / 64;
             l.clist_dwords = (ctx->dp.corr_lane && ctx->dp.paired) ? (ctx->ln_swm / 2) * 64 : 0;   // -c: read 1's edited positions, a bit mask per lane
             int waves = (int)(((long long)prop.sharedMemPerBlock / 4 - o) / (l.stage_dwords + l.part_dwords + l.clist_dwords));
             waves = std::max(1, std::min(waves, max_waves));
@@ -616,7 +627,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
 #ifndef FQ_HOSTSIM
             if (per_cu <= 0) {
                 int nb = 0;
-                lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0, lane_ext(ctx->dp));
+                lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0, ctx->dp.paired != 0, lane_ext(ctx->dp), ctx->ln_2w);
                 (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, l.total * 4);
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, ctx->ln_threads, (size_t)l.total * 4) == hipSuccess && nb > 0) per_cu = nb;
                 (void)hipGetLastError();
@@ -730,7 +741,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
             if (env_int("FASTP_GPU_LANE_DYNAMIC", 1)) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_ctr, sizeof(int)));
             for (int Bh : {0, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0})
-                CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp)),
+                CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp), ctx->ln_2w),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, ctx->ln_lds.total * 4));
         }
     }
@@ -1358,7 +1369,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.st_qual_hist = cl.st_qual_hist; la.st_kmer = cl.st_kmer; la.st_cycle = cl.st_cycle; la.cycles = cl.cycles;
             if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
-            lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp));
+            lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp), ctx->ln_2w);
             ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
             hipLaunchKernelGGL(fn, dim3(ln_grid), dim3(ctx->ln_threads), (size_t)ctx->ln_lds.total * 4, st, la);
         } else if (ctx->split && ctx->cfg.threads > 256) hipLaunchKernelGGL(fq_scan_wide_kernel, dim3(grid), dim3(ctx->cfg.threads), (size_t)ctx->L.total * 4, st, fa);
