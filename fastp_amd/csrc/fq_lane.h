@@ -1051,16 +1051,15 @@ FQ_DEV void lane_emit_corrections(const KernelArgs& a, int lane, int gp, int whi
     const int cnt = popc64(em), leader = ffs64(em) - 1;
     const int rank = popc64(em & ((1ull << lane) - 1ull));
     const u32 w0 = (u32)(2 * (a.first + gp) + which), w1 = (u32)rowpos | (sym_ascii(nb) << 16) | (nq << 24);
-    int base = 0;
-    if (lane == leader) base = g_atomic_add_i32(a.n_corr_int, cnt);   // never full: sized for an edit at every base of every pair
-    base = (int)shfl((u32)base, leader);
-    if (which >= 0 && base + rank < a.corr_int_cap) { a.corr_int[2 * (base + rank)] = w0; a.corr_int[2 * (base + rank) + 1] = w1; }
-    if (a.corrections) {   // (uniform)
-        int cb = 0;
-        if (lane == leader) cb = g_atomic_add_i32(a.n_corrections, cnt);
-        cb = (int)shfl((u32)cb, leader);
-        if (which >= 0 && cb + rank < a.corr_capacity) { a.corrections[2 * (cb + rank)] = w0; a.corrections[2 * (cb + rank) + 1] = w1; }
+    int base = 0, cb = 0;
+    if (lane == leader) {   // both lists' slots in ONE round trip (the two atomics are in flight together)
+        base = g_atomic_add_i32(a.n_corr_int, cnt);   // never full: sized for an edit at every base of every pair
+        if (a.corrections) cb = g_atomic_add_i32(a.n_corrections, cnt);
     }
+    base = (int)shfl((u32)base, leader);
+    cb = (int)shfl((u32)cb, leader);
+    if (which >= 0 && base + rank < a.corr_int_cap) { a.corr_int[2 * (base + rank)] = w0; a.corr_int[2 * (base + rank) + 1] = w1; }
+    if (a.corrections && which >= 0 && cb + rank < a.corr_capacity) { a.corrections[2 * (cb + rank)] = w0; a.corrections[2 * (cb + rank) + 1] = w1; }
 }
 // key = the pair's accepted overlap (no gap), l1 / l2 the lengths it was found on; rc / rcn = rc(r2') as the scan built it.
 // q1row: read 1's quality row in memory, q2row: read 2's in the stage (both at the ORIGINAL read's start).  nc1 = entries of clist.

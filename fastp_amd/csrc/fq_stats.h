@@ -311,21 +311,31 @@ FQ_DEV void stats4_item_general(const StatsArgs* ap, u32* lds, int F, int h, int
 template <int KC>
 FQ_DEV void stats4_front_kmers(const StatsArgs& a, u32* lds, const u32* qual, const u32* seq, const u32* swin, int nu, int F, int tid, int nt) {
     const int copy = tid & (KC - 1);
+    // the eight bases [b0, b0 + 8) hold every such 5-mer; the front is the same for every read, so where they sit in a row is
+    // uniform: three quality dwords and two dwords of packed bases per read, asked for together (the first form read them byte by
+    // byte, forty dependent loads a read, each a cache line of its own per lane: the -f 5 -F 5 line's Stats kernel took 2.35 ms
+    // instead of 1.07, profiles/r05_front_line_kernels.txt)
+    const int b0 = imax(F - 4, 0);
+    const int qd = b0 >> 2, qs = 8 * (b0 & 3);
+    const int sd = b0 >> 4, ss = 2 * (b0 & 15);
     for (int u = tid; u < nu; u += nt) {
         const u32 sw = swin[u];
         const int lk = (int)(sw >> 16);
         if (lk <= F) continue;                                  // not written out (or nothing kept)
-        const u8* q = (const u8*)(qual + (size_t)u * a.qw_g);
+        const u32* qrow = qual + (size_t)u * a.qw_g;
         const u32* srow = seq + (size_t)u * a.sw_g;
+        const u32 w0 = qrow[qd], w1 = qd + 1 < a.qw_g ? qrow[qd + 1] : 0u, w2 = qd + 2 < a.qw_g ? qrow[qd + 2] : 0u;
+        const u32 s0 = srow[sd], s1 = sd + 1 < a.sw_g ? srow[sd + 1] : 0u;
+        const u64 lo = (u64)w0 | ((u64)w1 << 32);
+        const u64 q8 = qs ? ((lo >> qs) | ((u64)w2 << (64 - qs))) : lo;   // the quality bytes of bases b0 .. b0 + 7 (bit 7: an N)
+        const u32 c16 = ss ? ((s0 >> ss) | (s1 << (32 - ss))) : s0;       // their codes, the earliest base in the low bits (reduce_body)
+        u32 nm = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) nm |= (u32)((q8 >> (8 * i + 7)) & 1ull) << i;
         for (int j = imax(F, 4); j < imin(F + 4, lk); j++) {    // the 5-mer of bases j - 4 .. j
-            bool ok = true;
-            u32 idx = 0;
-            for (int t = 0; t < 5; t++) {
-                const int b = j - 4 + t;
-                ok = ok && !(q[b] & 0x80u);                                            // an N: no 5-mer here in either Stats
-                idx |= ((srow[b >> 4] >> (2 * (b & 15))) & 3u) << (2 * t);             // earliest base in the low bits (reduce_body)
-            }
-            if (!ok) continue;
+            const int r = j - 4 - b0;
+            if ((nm >> r) & 0x1Fu) continue;                    // an N: no 5-mer here in either Stats
+            const u32 idx = (c16 >> (2 * r)) & 0x3FFu;
             lds_add_u32(&lds[a.l_kmer + (1 * KMER_BINS + (int)idx) * KC + copy], 0xFFFFFFFFu);   // kept - 1
             lds_add_u32(&lds[a.l_kmer + (0 * KMER_BINS + (int)idx) * KC + copy], 1u);            // dropped + 1
         }
@@ -442,7 +452,7 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
             const bool no_kept = a.merge != 0 && m == 1;   // (uniform) merge mode: read 2's swin word is for the third pass
             // The wavefront's mode = the character (with its kept bit) of the first item's first base, fixed at its first
             // appearance: bases that hit it are counted per lane and added once at the end.
-            u32 mode_e = 0xFFFFFFFFu, mode4 = 0;
+            u32 mode_e = 0xFFFFFFFFu, mode4 = 0, mode_tries = 0;
             u32 n_other = 0, n_items = 0;     // bytes that are not the mode / items looked at since the mode was fixed
             for (int base = tid - lane; base < per_mate; base += nt) {   // wave-uniform trip count (ballots inside)
                 const int it = base + lane;
@@ -467,7 +477,14 @@ FQ_DEV void stats_body4(const StatsArgs& a, u32* lds) {
                 }
                 const u32 e0 = (s.q0 | (km.x & 0x80808080u)) & vm.x, e1 = (s.q1 | (km.y & 0x80808080u)) & vm.y;
                 if (mode_e == 0xFFFFFFFFu) {                           // wave-uniform
-                    const u64 cand = ballot(plain);
+                    // (a KEPT character: most bases of a run are kept ones.  The first item's first base as it came used to fix a
+                    // dropped character for the whole pass when the wavefront's first read was filtered out - and for every wavefront
+                    // when a front trim drops each read's first bases: the kept bases' histogram adds then all met on a few addresses,
+                    // the -f 5 -F 5 line's Stats kernel took 2.35 ms instead of 1.07, profiles/r05_front_line_kernels.txt.  No such
+                    // lane in this trip: tried again in the next, every byte goes through its atomic meanwhile)
+                    // (read 2 in merge mode has no kept base in this pass; after a few trips without one any character will do)
+                    const u64 cand = ballot(plain && ((e0 & 0x80u) != 0u || no_kept || mode_tries >= 4u));
+                    mode_tries++;
                     if (cand) {
                         mode_e = shfl(e0 & 0xFFu, ffs64(cand) - 1);
                         mode4 = mode_e * 0x01010101u;
