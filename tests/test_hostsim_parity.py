@@ -317,6 +317,30 @@ def test_sim_merge_on_the_lane_plan(k, slow, monkeypatch):
     check_merge_lane(engines.sim_engine, k)
 
 
+@pytest.mark.parametrize("k", [0, 1, 3])
+def test_sim_merge_lane_and_fused_plans_agree(k, monkeypatch):
+    """the same merge-mode input through the lane plan and (FASTP_GPU_LANE=0) through the fused kernel the options took until
+    round 5: the same records, corrections and counters from both, equal to the oracle's"""
+    p, sets = cases.merge_lane_case(k, n=500)
+    d = sets[1]
+    args = (d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    o = oraclelib.Oracle(p)
+    ro, co = o.process(*args), o.counters()
+    o.close()
+    for env, want in (({}, "lane"), ({"FASTP_GPU_LANE": "0"}, "fused")):
+        monkeypatch.delenv("FASTP_GPU_LANE", raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        g = engines.sim_engine(p)
+        assert g.plan() == want
+        rg, cg = g.process(*args), g.counters()
+        g.close()
+        for i in range(3):
+            assert ro[i].tobytes() == rg[i].tobytes(), (want, i)
+        assert np.array_equal(np.sort(ro[3], order=["read", "pos"]), np.sort(rg[3], order=["read", "pos"])), want
+        assert np.array_equal(co, cg), (want, int((co != cg).sum()))
+
+
 def test_sim_merge_on_the_lane_plan_rows_not_16_byte_aligned():
     """a device batch whose arrays start 4 bytes off a 16-byte boundary: merge mode has no tile form of this plan, the engine moves
     the rows to aligned arrays of its own - the same records and counters"""
