@@ -12,6 +12,7 @@
 
 #include "fq_device.h"
 #include "fq_stats.h"
+#include "fq_stats5.h"
 #include "fq_lane.h"
 #include "fq_exact.h"
 #include "fq_inflate.h"
@@ -68,13 +69,25 @@ __global__ void __launch_bounds__(512, 1) fq_lane_pair2w_kernel(LaneArgs a) {
 extern "C" __global__ void __launch_bounds__(1024, 8) fq_stats_kernel(StatsArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     if (a.form == 4) {   // (uniform)
-        if ((a.debug_skip & 0x1C0u) && a.kc == 4) stats_body4<4, true>(a, fq_lds);   // profiling only (FASTP_GPU_DEBUG_SKIP)
-        else if (a.kc == 4) stats_body4<4, false>(a, fq_lds);
+#ifdef FQ_PROFILE_ABLATION
+        if ((a.debug_skip & 0x1C0u) && a.kc == 4) { stats_body4<4, true>(a, fq_lds); return; }   // profiling build only (FASTP_GPU_DEBUG_SKIP)
+#endif
+        if (a.kc == 4) stats_body4<4, false>(a, fq_lds);
         else if (a.kc == 2) stats_body4<2, false>(a, fq_lds);
         else stats_body4<1, false>(a, fq_lds);
     } else {
         stats_body(a, fq_lds);
     }
+}
+// form 5 of the Stats kernel (fq_stats5.h): one 1024-lane workgroup per CU that owns the joint table (110 KB at ten item columns)
+extern "C" __global__ void __launch_bounds__(1024) fq_stats5_kernel(StatsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+#ifdef FQ_PROFILE_ABLATION
+    if ((a.debug_skip & 0xC0u) && a.Hs == 10 && a.kc == 2) { stats_body5<2, 10, true>(a, fq_lds); return; }   // profiling build only
+#endif
+    if (a.Hs == 10 && a.kc == 2) stats_body5<2, 10, false>(a, fq_lds);   // reads of up to 160 bases (uniform)
+    else if (a.kc == 2) stats_body5<2, 0, false>(a, fq_lds);
+    else stats_body5<1, 0, false>(a, fq_lds);
 }
 extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
@@ -216,10 +229,12 @@ struct fastp_gpu_ctx {
     int st_H = 0, st_Hs = 0, st_lds_dwords = 0, st_slab_dwords = 0;
     u32* d_corr_int = nullptr; size_t corr_int_cap = 0;      // -c on the lane plan: the launch's corrections (KernelArgs::corr_int) + 1 counter word
     u32* d_corr_chain = nullptr; size_t corr_chain_cap = 0;  // their per-read chains: head[reads] | next[capacity]
+    int ln_prefetch = 0;   // FASTP_GPU_LANE_PREFETCH (round 6): LaneArgs::prefetch
     int ln_glds = 0;   // FASTP_GPU_LANE_GLDS (A/B, measured null: profiles/r05_lane_glds_ab.txt): LaneArgs::glds
     bool ln_2w = false;   // the lane kernel's EXT >= 2 instantiation compiled for two wavefronts per SIMD (FASTP_GPU_LANE_EXT_WAVES=2)
     int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
     int st_l_cyc = 0, st_l_kmer = 0, st_l_qh = 0, st_l_lut = 0, st_l_mt = 0, st_l_wl = 0, st_wl_cap = 0;
+    int st_H16 = 0, st_l_ovf = 0;          // form 5 (fq_stats5.h)
     u32* d_st_slabs = nullptr;
     // lane plan (fq_lane.h): one lane per pair, reads in registers - the option family lane_plan_supported() admits
     bool lane = false;
@@ -529,8 +544,33 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     if (ctx->split) {
         // the Stats kernel: [4][8][N_CLS][H] u64 per-cycle accumulators, k-mer and histogram counters, the increment table
         ctx->st_H = ctx->dp.qw_g / 2;
-        ctx->st_form = (env_int("FASTP_GPU_STATS_V", 4) == 3 && !ctx->dp.front_lane && !ctx->dp.corr_lane && !ctx->dp.merge_lane) ? 3 : 4;   // (a front / -c / --merge: form 4 only)
-        if (ctx->st_form == 4) {
+        const int st_want = env_int("FASTP_GPU_STATS_V", 5);
+        ctx->st_form = (st_want == 3 && !ctx->dp.front_lane && !ctx->dp.corr_lane && !ctx->dp.merge_lane) ? 3 : 4;   // (a front / -c / --merge: form 4 only)
+        if (st_want >= 5 && !ctx->dp.merge_lane) {
+            // round 6's form (fq_stats5.h): the joint table [2][8][4][ST5_QN][H16] of 16-bit cell pairs, KC copies of the mate's 5-mer
+            // counters, the packed cells of what the table has no cell for, the histogram of those, a list per wavefront - where it
+            // fits one workgroup's LDS (reads of up to 176 bases; merge mode's third pass exists in form 4 only)
+            ctx->st_H16 = (ctx->dp.qw_g + 3) / 4;
+            for (int kc = 2; kc >= 1; kc--) {
+                int o = 0;
+                ctx->st_l_cyc = o; o += 2 * 8 * 4 * ST5_QN * ctx->st_H16;
+                ctx->st_l_kmer = o; o += 2 * KMER_BINS * kc;
+                o = (o + 1) & ~1;
+                ctx->st_l_ovf = o; o += 2 * ctx->L.Cp * N_CLS * 2;
+                ctx->st_l_qh = o; o += 2 * 128;
+                ctx->st_l_wl = o; o += (1024 / 64) * ST5_WL;
+                if (o * 4 <= (int)prop.sharedMemPerBlock) {
+                    ctx->st_form = 5;
+                    ctx->st_kc = kc;
+                    ctx->st_Hs = ctx->st_H16;
+                    ctx->st_lds_dwords = o;
+                    ctx->st_max_reads = CYC_MAX_READS;
+                    break;
+                }
+            }
+        }
+        if (ctx->st_form == 5) {
+        } else if (ctx->st_form == 4) {
             // round 5's form: [2][8][ST4_ROWS][Hs] u32 per-cycle cells of ONE mate, KC copies of its 5-mer counters, its histogram
             ctx->st_kc = env_int("FASTP_GPU_STATS_KC", 4);
             if (ctx->st_kc != 1 && ctx->st_kc != 2 && ctx->st_kc != 4) ctx->st_kc = 4;
@@ -577,13 +617,14 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         }
         ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
         ctx->st_threads = env_int("FASTP_GPU_STATS_THREADS", 1024);
-        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63)) ctx->st_threads = 1024;
+        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63) || ctx->st_form == 5) ctx->st_threads = 1024;
         if (ctx->st_lds_dwords * 4 > (int)prop.sharedMemPerBlock) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "reads too long for the Stats kernel's LDS"); }
         int st_per_cu = std::min(2048 / ctx->st_threads, (int)((160 * 1024) / (ctx->st_lds_dwords * 4)));
         st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));
         ctx->st_blocks = ctx->cus * std::max(1, st_per_cu);
         ctx->lane = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
         ctx->ln_glds = env_int("FASTP_GPU_LANE_GLDS", 0);
+        ctx->ln_prefetch = env_int("FASTP_GPU_LANE_PREFETCH", 0);
         if (ctx->lane) {
             ctx->ln_swm = ctx->dp.sw_g <= 10 ? 10 : 16;
             LaneLds& l = ctx->ln_lds;
@@ -622,6 +663,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             o += waves * l.part_dwords;
             l.clist = o;
             o += waves * l.clist_dwords;
+            o = (o + 3) & ~3;
+            l.sink = o;          // where the row prefetches land (LaneArgs::prefetch): 64 lanes x 4 bytes, every wavefront's
+            o += 64;
             l.total = o;
             int per_cu = env_int("FASTP_GPU_LANE_BLOCKS_PER_CU", 0);
 #ifndef FQ_HOSTSIM
@@ -641,6 +685,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         long long mp = (long long)ctx->blocks * tiles_per_block * ctx->L.P;
         if (ctx->split) {   // the per-read kernel has no packed counters; a Stats workgroup takes <= CYC_MAX_READS units
             mp = (long long)ctx->st_blocks * CYC_MAX_READS;   // (form 4 takes such a launch as several rounds of workgroups)
+            if (ctx->st_form == 5) mp *= 2;                   // (one workgroup per CU: two rounds, as many units per launch as before)
             if (cap_tiles > 0) mp = std::min(mp, (long long)ctx->blocks * cap_tiles * ctx->L.P);
         }
         if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
@@ -653,9 +698,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     ctx->exact_all = env_int("FASTP_GPU_EXACT", 0) != 0;   // tests: every unit through the text kernel (fq_exact.h)
     if (ctx->exact_all && env_int("FASTP_GPU_VERBOSE", 0)) fprintf(stderr, "fastp_gpu: FASTP_GPU_EXACT=1, every unit takes the text kernel\n");
     if (env_int("FASTP_GPU_VERBOSE", 0))
-        fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel %d x %d threads, LDS %d bytes\n",
+        fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel form %d, %d x %d threads, LDS %d bytes\n",
                 ctx->lane ? "lane plan" : (ctx->split ? "split plan" : "fused plan"), ctx->L.P, ctx->L.NR, ctx->cfg.threads, ctx->L.total * 4, ctx->blocks,
-                ctx->max_pairs_per_launch, ctx->st_blocks, ctx->st_threads, ctx->st_lds_dwords * 4);
+                ctx->max_pairs_per_launch, ctx->st_form, ctx->st_blocks, ctx->st_threads, ctx->st_lds_dwords * 4);
     if (env_int("FASTP_GPU_VERBOSE", 0) && ctx->lane)
         fprintf(stderr, "fastp_gpu: lane kernel %d x %d threads (%d per CU), LDS %d bytes per workgroup (stage %d + read-1 sums %d per wavefront), SWM %d, ext %d\n",
                 ctx->ln_blocks, ctx->ln_threads, ctx->ln_blocks / std::max(1, ctx->cus), ctx->ln_lds.total * 4, ctx->ln_lds.stage_dwords * 4,
@@ -730,7 +775,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipFuncSetAttribute((const void*)fq_corr_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)((ctx->dp.paired ? 2 : 1) * (33 * (size_t)ctx->cl.cycles + 128 + KMER_BINS) * 4)));
         // a slab per workgroup of the largest launch: st_blocks of them for the packed u64 form, rounds of st_blocks for the u32 form
-        ctx->st_max_grid = ctx->st_form == 4 ? (ctx->max_pairs_per_launch + ST4_MAX_READS - 1) / ST4_MAX_READS + ctx->st_blocks : ctx->st_blocks;
+        ctx->st_max_grid = ctx->st_form == 4 ? (ctx->max_pairs_per_launch + ST4_MAX_READS - 1) / ST4_MAX_READS + ctx->st_blocks
+                                             : (ctx->st_form == 5 ? 2 * ctx->st_blocks + 2 : ctx->st_blocks);
+        if (ctx->st_form == 5) CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_max_grid * ctx->st_slab_dwords * 4));
         if (env_int("FASTP_GPU_DUP_OVERLAP", 1)) {
             CREATE_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
@@ -1126,7 +1173,15 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         a.swin_out[1] = ctx->d_swin[1];
     }
     a.phase_cycles = ctx->d_phase;
-    a.debug_skip = (u32)env_int("FASTP_GPU_DEBUG_SKIP", 0);
+    // The product library has no switch that changes a result: FASTP_GPU_DEBUG_SKIP (steps left out of the kernels, for the measured
+    // floors under profiles/) exists only in a library built with -DFQ_PROFILE_ABLATION (tools/build_ablation.sh).  Bit 512 is a TEST
+    // switch that leaves every result as it is (each merged read's second part counted by the lane kernel, fq_lane.h).
+#ifdef FQ_PROFILE_ABLATION
+    a.debug_skip = (u32)env_int("FASTP_GPU_DEBUG_SKIP", 0) & ~512u;
+#else
+    a.debug_skip = 0;
+#endif
+    if (env_int("FASTP_GPU_TEST_MERGE_SLOW", 0)) a.debug_skip |= 512u;
     a.slabs = ctx->d_slabs;
     a.slab_dwords = ctx->slab_dwords;
     a.tiles = (n + ctx->L.P - 1) / ctx->L.P;
@@ -1365,6 +1420,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.l = ctx->ln_lds;
             la.chunk_ctr = ctx->d_ln_ctr;
             la.glds = ctx->ln_glds;
+            la.prefetch = ctx->ln_prefetch;
             la.post1 = ctx->d_ctr + cl.stats[1];
             la.st_qual_hist = cl.st_qual_hist; la.st_kmer = cl.st_kmer; la.st_cycle = cl.st_cycle; la.cycles = cl.cycles;
             if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
@@ -1478,11 +1534,13 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut; sa.l_mt = ctx->st_l_mt;
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
         sa.l_total = ctx->st_lds_dwords;
+        sa.H16 = ctx->st_H16; sa.magic_H16 = ctx->st_H16 ? magic_for((u32)ctx->st_H16) : 0u; sa.l_ovf = ctx->st_l_ovf;
         sa.slabs = ctx->d_st_slabs;
         sa.slab_dwords = ctx->st_slab_dwords;
         sa.debug_skip = a.debug_skip;
         if (!(a.debug_skip & 16u)) {
-            hipLaunchKernelGGL(fq_stats_kernel, dim3(st_grid), dim3(ctx->st_threads), (size_t)ctx->st_lds_dwords * 4, st, sa);
+            if (ctx->st_form == 5) hipLaunchKernelGGL(fq_stats5_kernel, dim3(st_grid), dim3(ctx->st_threads), (size_t)ctx->st_lds_dwords * 4, st, sa);
+            else hipLaunchKernelGGL(fq_stats_kernel, dim3(st_grid), dim3(ctx->st_threads), (size_t)ctx->st_lds_dwords * 4, st, sa);
             HIP_TRY(ctx, hipGetLastError());
         } else {
             st_grid = 0;

@@ -531,7 +531,11 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
     const int qual_b = L.qual * 4, seq_b = L.seq * 4;
     const int lane = tid & 63;
     const int total = NR * 4;
-    const u32 dbg = a.debug_skip;   // profiling only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
+#ifdef FQ_PROFILE_ABLATION
+    const u32 dbg = a.debug_skip;   // profiling build only: 64 no per-cycle atomics, 128 no k-mer atomics, 256 no histogram atomics
+#else
+    const u32 dbg = 0;
+#endif
     for (int base = tid - lane; base < total; base += nthreads) {  // wave-uniform trip count (ballots inside)
         const int task = base + lane;
         const bool tv = task < total;
@@ -2313,7 +2317,11 @@ FQ_DEV void fused_body(const FusedArgs& fa, u32* lds0) {
         if (touch) touch_done(warm);
         tile_sync(a, lds, nt);
         FQ_STAMP(0)
-        const u32 skip = a.debug_skip;   // profiling only: 0 in any real run
+#ifdef FQ_PROFILE_ABLATION
+        const u32 skip = a.debug_skip;   // profiling build only: 0 in any real run
+#else
+        const u32 skip = 0;
+#endif
         if (!SPLIT && !a.p.stats_one_pass) phase_stats<ST_PRE, false>(a, lds, n_valid, tid, nt);  // Stats::statRead on the original reads
         if (!(skip & 1u)) {
             phase_masks(a, lds, n_valid, tid, nt);

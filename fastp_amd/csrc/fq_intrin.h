@@ -7,6 +7,10 @@
 
 #define FQ_DEV __device__ __forceinline__
 
+#ifdef FQ_HOSTSIM
+extern uint32_t fq_lds[];   // the emulator's LDS (tests/hostsim/sim.cpp): what `extern __shared__ u32 fq_lds[]` names in a kernel
+#endif
+
 namespace fq {
 
 FQ_DEV int thread_id() { return (int)threadIdx.x; }
@@ -68,6 +72,15 @@ FQ_DEV void glds16(const void* g, void* lds_wave_base, int lane) {
 #else
     (void)lane;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+// 4 bytes per lane the same way (global_load_lds_dword): what a line prefetch needs - the data is never read
+FQ_DEV void glds4(const void* g, void* lds_wave_base, int lane) {
+#ifdef FQ_HOSTSIM
+    memcpy((char*)lds_wave_base + 4 * lane, g, 4);
+#else
+    (void)lane;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 #endif
 }
 FQ_DEV void glds_wait() {
@@ -193,6 +206,51 @@ FQ_DEV u32 sum_bytes(u32 a, u32 c) { return __builtin_amdgcn_sad_u8(a, 0u, c); }
 FQ_DEV u64 sum_bytes_sliding4(u32 lo, u32 hi, u64 acc) { return __builtin_amdgcn_qsad_pk_u16_u8((u64)lo | ((u64)hi << 32), 0u, acc); }
 // (v >> off) & ((1 << width) - 1)  -> v_bfe_u32 (kept as one instruction next to the shift-add that uses it)
 FQ_DEV u32 bfe(u32 v, u32 off, u32 width) { return __builtin_amdgcn_ubfe(v, off, width); }
+// a * b + c on 24-bit operands, b uniform (a scalar register or an inline constant), pinned as ONE v_mad_u32_u24: left to itself the
+// compiler re-associates an address a * S1 + b * S2 + base into multiplies and three-operand adds that re-add the base's parts per
+// element (fq_stats5.h: 6 instead of 4 instructions per base)
+FQ_DEV u32 mad24_su(u32 a, u32 b_uniform, u32 c) {
+#ifdef FQ_HOSTSIM
+    return (a & 0xFFFFFFu) * (b_uniform & 0xFFFFFFu) + c;
+#else
+    u32 r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+#endif
+}
+// (x << SH) + y as ONE v_lshl_add_u32
+template <int SH> FQ_DEV u32 lshl_add(u32 x, u32 y) {
+#ifdef FQ_HOSTSIM
+    return (x << SH) + y;
+#else
+    u32 r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(SH), "v"(y));
+    return r;
+#endif
+}
+// LDS by its 32-bit address (what a DS instruction takes): a generic pointer + an offset costs an add of the LDS aperture's base
+// per access even where that base is zero
+FQ_DEV u32 lds_addr_of(const void* p) {
+#ifdef FQ_HOSTSIM
+    return (u32)(size_t)((const char*)p - (const char*)::fq_lds);
+#else
+    return (u32)(size_t)((__attribute__((address_space(3))) const char*)p);
+#endif
+}
+FQ_DEV void lds_add_u32_at(u32 addr, u32 v) {
+#ifdef FQ_HOSTSIM
+    __hip_atomic_fetch_add((u32*)((char*)::fq_lds + addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) u32*)(size_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+// the value as it is, but opaque to the optimiser: what is computed from it stays computed from it
+FQ_DEV u32 opaque(u32 v) {
+#ifndef FQ_HOSTSIM
+    asm("" : "+v"(v));
+#endif
+    return v;
+}
 // c + sum of the four byte products a.b[k] * b.b[k]  -> v_dot4_u32_u8
 FQ_DEV u32 dot4_u8(u32 a, u32 b, u32 c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 

@@ -50,6 +50,7 @@ struct LaneLds {
     int part_dwords;    // conflict-free; registers do not hold them - ten more live VGPRs spilled 270 dwords at the cap of 168)
     int clist;      // -c on the lane plan, per wavefront: the positions of read 1 that BaseCorrector edited, one bit per base,
     int clist_dwords;   // [SWM / 2 words][lane]: read 1's rows are gone when countQualityMetrics runs (lane_apply_corrected)
+    int sink;       // 64 dwords every wavefront's row prefetches are written to (never read): global_load_lds needs a destination
     int jkmer;      // --merge on the lane plan (DevParams::merge_lane): [KMER_BINS] behind the MISC_* counters (inside n_misc, so in the
                     // slab) - the merged reads' 5-mers that straddle the junction of the two parts (fastp's index: earliest base high)
     int total;
@@ -61,6 +62,10 @@ struct LaneArgs {
     int* chunk_ctr; // zero at launch: chunks beyond every wave's first are handed out by this counter (a static stride
                     // leaves a third of the waves one chunk short at 21.3 chunks per wave); nullptr = static stride
     int glds;       // read 2's quality rows come into the stage by global_load_lds while read 1 is hashed (FASTP_GPU_LANE_GLDS, A/B)
+    int prefetch;   // FASTP_GPU_LANE_PREFETCH (round 6), bit mask: 1 = read 2's rows of the chunk are pulled into L2 while read 1 is
+                    // staged and swept, 2 = read 1's rows of the wavefront's NEXT chunk while read 2 is - one dword per 128-byte line
+                    // by global_load_lds into a sink (no register, no wait): the four row stagings of a chunk then find their lines
+                    // in L2 / the Infinity Cache instead of paying a trip to HBM each
     // --merge with -c: the POST Stats object of read 1 in the counter block, for the (rare) merged read whose tail holds an edited
     // base - the lane that has the corrected tail in registers counts it itself (lane_merge_tail_slow)
     int64_t* post1;
@@ -244,6 +249,12 @@ FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int 
     }
     if ((bytes & 8) && lane == 0) ((u64*)buf)[2 * n16] = ((const u64*)src)[2 * n16];
     wave_order();
+}
+
+// Pull `bytes` bytes behind `src` into L2: one dword of every 128-byte line by global_load_lds_dword into `sink` (64 dwords of LDS
+// nobody reads).  Nothing waits for it; the later loads of the same lines by lane_stage_rows are L2 hits.
+FQ_DEV void lane_prefetch_lines(u32* sink, const u32* src, int bytes, int lane) {
+    for (int off = lane * 128; off < bytes; off += 64 * 128) glds4((const char*)src + off, (char*)sink, lane);
 }
 
 // The same copy without registers (round 5): global_load_lds_dwordx4, 16 bytes per lane straight into the stage, asynchronous.
@@ -1410,8 +1421,11 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const bool FR = EXT >= 2 && p.front_lane != 0;         // (uniform) -f / -F / a UMI at the reads' start
     const bool CR = EXT >= 2 && PAIRED && p.corr_lane != 0;   // (uniform) -c
     const bool MG = EXT >= 3 && PAIRED && p.merge_lane != 0;  // (uniform) --merge
-    const u32 skip = a.debug_skip;   // profiling only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
-                                     // (512: a test switch that leaves the results as they are, see `slow` below)
+#ifdef FQ_PROFILE_ABLATION
+    const u32 skip = a.debug_skip;   // profiling build only (FASTP_GPU_DEBUG_SKIP): 1 window predicate, 4 overlap, 8 metrics; results are then meaningless
+#else
+    const u32 skip = a.debug_skip & 512u;   // (512: a test switch that leaves the results as they are, see `slow` below)
+#endif
     const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
     const int thr = p.cut_right ? p.thrR : p.thrT;
     const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
@@ -1443,11 +1457,23 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         // each read is trimmed (Filter::trimAndCut) as soon as it is loaded: its window predicate is dead after that
         // DevParams::front_lane (EXT): fr = the read's front in the row (UMI + -f), ft = trimAndCut's part of it (frontTrimmed)
         int fr1 = 0, ft1 = 0, fr2 = 0, ft2 = 0;
+        if (PAIRED && (la.prefetch & 1)) {   // (uniform) read 2's rows on their way to L2 while read 1 is staged and swept
+            lane_prefetch_lines(lds + ll.sink, a.seq[1] + (size_t)(chunk * 64) * p.sw_g, rows * p.sw_g * 4, lane);
+            lane_prefetch_lines(lds + ll.sink, a.qual[1] + (size_t)(chunk * 64) * p.qw_g, rows * p.qw_g * 4, lane);
+        }
         lane_load_read<SWM, PAIRED>(a, stage, part, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, thr4, r1);
         if (FR) {
             if (valid) lane_front_trim<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.umi_len1, p.trim_front1, p.trim_tail1, fr1, ft1);
         } else if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
+        if ((la.prefetch & 2) && la.chunk_ctr) {   // (uniform) the next chunk's read 1 (its number came back long ago)
+            const int nxc = nstatic + (int)uniform((u32)nx);
+            if (nxc < chunks) {
+                const int nrows = imin(64, a.n - nxc * 64);
+                lane_prefetch_lines(lds + ll.sink, a.seq[0] + (size_t)(nxc * 64) * p.sw_g, nrows * p.sw_g * 4, lane);
+                lane_prefetch_lines(lds + ll.sink, a.qual[0] + (size_t)(nxc * 64) * p.qw_g, nrows * p.qw_g * 4, lane);
+            }
+        }
         // Duplicate::seq2intvector of read 1 in front of read 2's sweep (B > 0, the asynchronous stage): what it needs of read 1
         // is final, and it covers the round trip of read 2's quality rows
         const bool GL = PAIRED && B > 0 && la.glds != 0;   // (uniform)

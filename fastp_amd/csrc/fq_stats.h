@@ -53,6 +53,9 @@ struct StatsArgs {
     int merge;              // form 4, DevParams::merge_lane: read 2 has no POST Stats object of its own - every base of it is "dropped" in its
                             // pass; a third pass (stats4_tail_pass) counts what swin[1] marks as kept once more into slot 3, the merged
                             // reads' second parts at the merged reads' cycles (the slab fold adds slot 3 to the POST Stats of read 1)
+    int H16;                // form 5 (fq_stats5.h): 16-base items per row = ceil(qw_g / 4), Hs = the item columns of its table
+    u32 magic_H16;          // ceil(2^32 / H16)
+    int l_ovf;              // form 5: [2][Cp][N_CLS] u64 packed cells of the bases its joint table has no cell for (N, qualities above 'K')
     int front[2];           // form 4, DevParams::front_lane: the kept bases of a read of mate m are [front[m], swin >> 16) - the same
                             // front for every read that is written out; they are counted at their ORIGINAL cycle (the slab fold
                             // moves the POST Stats, reduce_body); the 5-mers that end on the first four kept bases exist in the

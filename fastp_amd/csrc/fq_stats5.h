@@ -1,0 +1,266 @@
+// fq_stats5.h - Stats::statRead (src/stats.cpp:191-266), form 5 of the streaming Stats kernel (round 6, gfx950).
+//
+// Form 4 (fq_stats.h) spends, per base, one table read and three LDS atomics (per-cycle cell, 5-mer, quality histogram) and
+// 23.5 VALU wave-instructions per 64 bases - it is bound by VALU issue (profiles/r05_stats_forms_and_floor.txt).  Per-cycle
+// count, Q20 / Q30 counts, quality sum AND the quality histogram are all projections of ONE joint histogram
+//     J[slot][cycle][class][quality]
+// so a base costs ONE atomic for all of them (plus the 5-mer add), no table read, and the address is two multiply-adds:
+//   * item = 16 consecutive bases of a read (four quality dwords + one dword of packed bases + the byte of bases in front);
+//   * a cell is 16 bits wide: the dword [slot][k & 7][class][quality - 33][h] holds base k of item column h in its low half and
+//     base k + 8 in its high half, so the increment (1 or 1 << 16) and the k-part of the address are compile-time constants of
+//     the unrolled loop.  A workgroup takes at most CYC_MAX_READS (16383) units, a cell sees at most one base per unit: no
+//     half ever carries into the other;
+//   * the FAST path takes an item whose 16 bases all exist, hold no N (nor do the 4 in front), have qualities below
+//     '!' + ST5_QN, and are all kept or all dropped (the slot is then part of the item's base address).  Everything else - a
+//     read's last, ragged item, the item a trim ends in, items with an N, exotic qualities - is queued in a per-WAVEFRONT list
+//     (ballot + prefix count: no atomic, no workgroup barrier) and taken base by base by all 64 lanes whenever 64 are queued;
+//   * N bases and qualities outside the table go to a small packed-u64 table [slot][cycle][class] and the histogram proper;
+//   * flush: cnt = sum over q, q20 = sum over q >= 20, q30 = sum over q >= 30, qsum = sum of q x cell, histogram = sum over
+//     (cycle, class) - once per workgroup and mate, into the slab's canonical packed form (reduce_body is unchanged).
+// A front trim (DevParams::front_lane): kept bases are [F, lk) at their ORIGINAL cycle (the slab fold moves the POST Stats);
+// the 5-mer that ends on base j belongs to the POST Stats only when j - 4 >= F (stats.cpp:224-227 on the read that starts at
+// F) - items that touch [0, F + 4) take the base-by-base path, which applies exactly that rule (form 4 needs a fix-up pass).
+#pragma once
+#include "fq_stats.h"
+
+namespace fq {
+
+enum { ST5_QN = 43,            // quality rows of the joint table: '!' .. 'K' (Q0 .. Q42); anything above takes the slow path
+       ST5_QADD = 127 - 32 - ST5_QN,   // q + ST5_QADD has bit 7 set exactly when q >= '!' + ST5_QN (q < 128: no N flag)
+       ST5_WL = 128 };         // queued items per wavefront (drained in batches of 64: never more than 127)
+
+FQ_DEV int lane_rank(u64 mask) {   // set bits of `mask` below this lane
+#ifdef FQ_HOSTSIM
+    const int l = lane_id();
+    return popc64(mask & (l ? (~0ull >> (64 - l)) : 0ull));
+#else
+    return (int)__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+#endif
+}
+
+struct Stats5Item {
+    u32 q[4], qp, codes, prev8;
+    int h, rl0, lk;
+};
+
+// item `it` of the workgroup's unit range of one mate: qual / seq / swin = the mate's arrays at the workgroup's first unit
+FQ_DEV void stats5_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 it, bool tv, Stats5Item& s) {
+    const u32 ur = fastdiv(tv ? it : 0u, a.magic_H16);
+    const u32 h = (tv ? it : 0u) - mul24(ur, (u32)a.H16);
+    s.h = (int)h;
+    u32 sw = 0;
+    s.q[0] = s.q[1] = s.q[2] = s.q[3] = s.qp = s.codes = s.prev8 = 0;
+    if (tv) {   // (all loads independent of each other)
+        sw = swin[ur];
+        const u32 qd = mul24(ur, (u32)a.qw_g) + 4u * h;          // dword of the row's quality bytes (rows are 8-byte aligned)
+        const u64 q01 = *(const u64*)(qual + qd);
+        s.q[0] = (u32)q01;
+        s.q[1] = (u32)(q01 >> 32);
+        if (4u * h + 4u <= (u32)a.qw_g) {                         // (the last item of a row may be half a vector)
+            const u64 q23 = *(const u64*)(qual + qd + 2u);
+            s.q[2] = (u32)q23;
+            s.q[3] = (u32)(q23 >> 32);
+        }
+        const u32 sd = mul24(ur, (u32)a.sw_g) + h;
+        if (h < (u32)a.sw_g) s.codes = seq[sd];
+        if (h > 0) {
+            s.qp = qual[qd - 1u];
+            s.prev8 = (u32)((const u8*)seq)[4u * sd - 1u];
+        }
+    }
+    s.rl0 = (int)(sw & 0xFFFFu);
+    s.lk = (int)(sw >> 16);
+}
+
+// LDS addresses (bytes) of the joint table
+struct Stats5Geo {
+    u32 HS4;     // bytes between two quality rows (= 4 * item columns)
+    u32 C4;      // bytes between classes  = ST5_QN * HS4
+    u32 K4;      // bytes between the k & 7 = 4 * C4
+    u32 S4;      // bytes between the two slots = 8 * K4
+};
+
+// one item, base by base (the per-wavefront list): any state
+template <int KC>
+FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, int F, const Stats5Item& s, int lane) {
+    u8* ldsw = (u8*)lds;
+    const u32 nbp = (s.qp >> 7) & 0x01010101u;
+    u32 n20 = (nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu;   // bit i = base j0 - 4 + i is an N
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const u32 nb = (s.q[d] >> 7) & 0x01010101u;
+        n20 |= ((nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu) << (4 + 4 * d);
+    }
+    if (s.h == 0) n20 |= 0xFu;                                  // in front of the read: no 5-mer (stats.cpp:224-227)
+    const u64 c40 = (u64)s.prev8 | ((u64)s.codes << 8);         // bases j0 - 4 .. j0 + 15, two bits each
+    const int j0 = 16 * s.h;
+    const int Fk = F > 0 ? F + 4 : 0;
+    u64* ovf = (u64*)(lds + a.l_ovf);
+    u32* qh = lds + a.l_qh;
+    u32* kmer = lds + a.l_kmer + (lane & (KC - 1));
+    for (int k = 0; k < 16; k++) {
+        const int j = j0 + k;
+        if (j >= s.rl0) break;
+        const u32 qb = (s.q[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        const u32 q = qb & 0x7Fu;
+        const bool isn = (qb & 0x80u) != 0;
+        const u32 code = (s.codes >> (2 * k)) & 3u;
+        const u32 slot = (j >= F && j < s.lk) ? 1u : 0u;
+        const u32 e = q - 33u;
+        if (!isn && e < (u32)ST5_QN) {
+            lds_add_u32((u32*)(ldsw + ((u32)a.l_cyc * 4u + slot * g.S4 + (u32)(k & 7) * g.K4 + code * g.C4 + e * g.HS4 + (u32)s.h * 4u)), k < 8 ? 1u : 0x10000u);
+        } else {
+            lds_add_u64(&ovf[(slot * (u32)a.Cp + (u32)j) * N_CLS + (isn ? (u32)CLS_N : code)], stats_inc_of(q));
+            lds_add_u32(&qh[slot * 128u + q], 1u);
+        }
+        if (((n20 >> k) & 0x1Fu) == 0u) {
+            const u32 ks = (j >= Fk && j < s.lk) ? 1u : 0u;
+            lds_add_u32(&kmer[(ks * KMER_BINS + (u32)((c40 >> (2 * k)) & 0x3FFull)) * KC], 1u);
+        }
+    }
+}
+
+// HS: the item columns of the table as a compile-time constant (the k-part of a cell's address then sits in the DS instruction's
+// offset field, the class and quality strides are literals of the two multiply-adds); 0 = read from the arguments
+template <int KC, int HS, bool ABL>
+FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
+    const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
+    const int H16 = a.H16;
+    Stats5Geo g;
+    g.HS4 = HS ? (u32)HS * 4u : (u32)a.Hs * 4u;
+    g.C4 = (u32)ST5_QN * g.HS4;
+    g.K4 = 4u * g.C4;
+    g.S4 = 8u * g.K4;
+    const int u0 = block_id() * a.units_per_block;
+    const int nu = imax(0, imin(a.units_per_block, a.n - u0));
+    const u32 per_mate = (u32)(nu * H16);
+    u32* wl = lds + a.l_wl + (tid >> 6) * ST5_WL;                 // this wavefront's list
+    u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
+    const int n_cyc = 4 * a.Cp * N_CLS;                           // u64 items of the slab's per-cycle part
+    const int nm = a.paired ? 2 : 1;
+    for (int m = 0; m < 2; m++) {                                 // uniform
+        for (int i = tid; i < a.l_wl; i += nt) lds[i] = 0;       // [cyc | kmer | ovf | qh] sit in front of the lists
+        block_sync();
+        if (m < nm) {
+            const u32* qual = a.qual[m] + (size_t)u0 * a.qw_g;
+            const u32* seq = a.seq[m] + (size_t)u0 * a.sw_g;
+            const u32* swin = a.swin[m] + u0;
+            const int F = a.front[m];                             // (uniform; 0 unless DevParams::front_lane)
+            const int Fk = F > 0 ? F + 4 : 0;
+            const u32 lds0 = lds_addr_of(lds);                    // (DS addresses, not generic pointers: no aperture add per access)
+            const u32 cyc_b = lds0 + (u32)a.l_cyc * 4u - (u32)(33 + ST5_QADD) * g.HS4;   // the row of byte value q + ST5_QADD is q - 33
+            const u32 kmer_b = lds0 + (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
+            int wn = 0;                                           // queued items of this wavefront (uniform)
+            for (u32 base = (u32)(tid - lane); base < per_mate; base += (u32)nt) {   // wave-uniform trip count (ballots inside)
+                const u32 it = base + (u32)lane;
+                const bool tv = it < per_mate;
+                Stats5Item s;
+                stats5_fetch(a, qual, seq, swin, it, tv, s);
+                const int j0 = 16 * s.h;
+                const bool act = tv && j0 < s.rl0;
+                const u32 nany = (s.q[0] | s.q[1] | s.q[2] | s.q[3] | s.qp) & 0x80808080u;   // an N among the 16 bases or the 4 before
+                const u32 e0 = s.q[0] + 0x01010101u * (u32)ST5_QADD, e1 = s.q[1] + 0x01010101u * (u32)ST5_QADD;
+                const u32 e2 = s.q[2] + 0x01010101u * (u32)ST5_QADD, e3 = s.q[3] + 0x01010101u * (u32)ST5_QADD;
+                const u32 oor = (e0 | e1 | e2 | e3) & 0x80808080u;                             // a quality the table has no row for
+                const bool all_kept = j0 >= Fk && j0 + 16 <= s.lk;
+                const bool all_drop = s.lk <= j0 || j0 + 16 <= F;
+                const bool fast = act && j0 + 16 <= s.rl0 && (nany | oor) == 0u && (all_kept || all_drop);
+                const bool slow = act && !fast;
+                {   // queue the rest: this wavefront's own list, positions by a prefix count over the ballot
+                    const u64 sm = ballot(slow);
+                    if (sm) {                                     // (uniform)
+                        if (slow) wl[wn + lane_rank(sm)] = it;
+                        wn += popc64(sm);
+                    }
+                }
+                if (fast) {
+                    const u32 ib = opaque(cyc_b + (all_kept ? g.S4 : 0u) + (u32)s.h * 4u);
+                    const u32 kb = opaque(kmer_b + (all_kept ? (u32)(KMER_BINS * KC * 4) : 0u));
+                    const u32 c_lo = s.prev8 | (s.codes << 8);    // bases j0 - 4 .. j0 + 11
+                    const u32 c_hi = s.codes >> 8;                // bases j0 + 4 .. j0 + 15
+                    const u32 hpos = s.h > 0 ? 1u : 0u;           // 5-mers need positions >= 4 (stats.cpp:224-266)
+                    const u32 ev[4] = {e0, e1, e2, e3};
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const u32 e = bfe(ev[k >> 2], 8 * (k & 3), 8);
+                        const u32 cl = bfe(s.codes, 2 * k, 2);
+                        const u32 t = mad24_su(cl, g.C4, ib);                    // four instructions per base and cell:
+                        const u32 ca = mad24_su(e, g.HS4, t);                    // two field extracts, two multiply-adds
+                        if (!ABL || !(a.debug_skip & 64u)) lds_add_u32_at(ca + (u32)(k & 7) * g.K4, k < 8 ? 1u : 0x10000u);
+                        const u32 x = k < 8 ? bfe(c_lo, 2 * k, 10) : bfe(c_hi, 2 * k - 16, 10);
+                        if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kb), k < 4 ? hpos : 1u);
+                    }
+                }
+                if (wn >= 64) {                                   // (uniform) a full wavefront of queued items
+                    wave_sync();
+                    wn -= 64;
+                    Stats5Item t;
+                    stats5_fetch(a, qual, seq, swin, wl[wn + lane], true, t);
+                    stats5_item_general<KC>(a, lds, g, F, t, lane);
+                    wave_sync();
+                }
+            }
+            if (wn > 0) {                                         // (uniform) what is left of the list
+                wave_sync();
+                Stats5Item t;
+                stats5_fetch(a, qual, seq, swin, lane < wn ? wl[lane] : 0u, lane < wn, t);
+                if (lane < wn) stats5_item_general<KC>(a, lds, g, F, t, lane);
+            }
+        }
+        block_sync();
+        // ---- flush the mate's two slots to the slab in its canonical packed form ([slot][cycle][class] u64, reduce_body) ----
+        const int per_slot = a.Cp * N_CLS;
+        const u64* ovf = (const u64*)(lds + a.l_ovf);
+        for (int i = tid; i < 2 * per_slot; i += nt) {
+            const int sl = i >= per_slot ? 1 : 0;
+            const int rem = i - sl * per_slot;
+            const int pos = rem / N_CLS, cls = rem - pos * N_CLS;
+            u64 v = 0;
+            if (m < nm) {
+                u32 cnt = 0, q20 = 0, q30 = 0, qs = 0;
+                const int h = pos >> 4, k = pos & 15;
+                if (cls < 4 && h < H16) {
+                    const u32* row = lds + a.l_cyc + ((sl * 8 + (k & 7)) * 4 + cls) * ST5_QN * a.Hs + h;
+                    const int sh = k < 8 ? 0 : 16;
+                    for (int e = 0; e < ST5_QN; e++) {
+                        const u32 c = (row[e * a.Hs] >> sh) & 0xFFFFu;
+                        cnt += c;
+                        qs += c * (u32)e;
+                        if (e >= 20) q20 += c;                   // stats.cpp:209-222: '5' counts into Q20, '?' into Q30 and Q20
+                        if (e >= 30) q30 += c;
+                    }
+                }
+                const u64 o = ovf[(sl * a.Cp + pos) * N_CLS + cls];
+                const u64 M = (1ull << CYC_CNT_BITS) - 1ull;
+                v = ((u64)cnt + (o & M)) | (((u64)q20 + ((o >> CYC_Q20_SHIFT) & M)) << CYC_Q20_SHIFT) |
+                    (((u64)q30 + ((o >> CYC_Q30_SHIFT) & M)) << CYC_Q30_SHIFT) | (((u64)qs + (o >> CYC_QSUM_SHIFT)) << CYC_QSUM_SHIFT);
+            }
+            const int o2 = 2 * ((2 * m + sl) * per_slot + rem);
+            slab[o2] = (u32)v;
+            slab[o2 + 1] = (u32)(v >> 32);
+        }
+        for (int i = tid; i < 2 * KMER_BINS; i += nt) {
+            u32 v = 0;
+            if (m < nm)
+                for (int c = 0; c < KC; c++) v += lds[a.l_kmer + i * KC + c];
+            slab[2 * n_cyc + 2 * m * KMER_BINS + i] = v;
+        }
+        for (int i = tid; i < 2 * 128; i += nt) {
+            u32 v = 0;
+            if (m < nm) {
+                v = lds[a.l_qh + i];
+                const int sl = i >> 7, e = (i & 127) - 33;
+                if (e >= 0 && e < ST5_QN) {                       // the histogram of the table's bases: the sum over (cycle, class)
+                    for (int kc = 0; kc < 8 * 4; kc++) {
+                        const u32* row = lds + a.l_cyc + (((sl * 8 * 4 + kc) * ST5_QN) + e) * a.Hs;
+                        for (int h = 0; h < H16; h++) v += (row[h] & 0xFFFFu) + (row[h] >> 16);
+                    }
+                }
+            }
+            slab[2 * n_cyc + 4 * KMER_BINS + 2 * m * 128 + i] = v;
+        }
+        block_sync();
+    }
+}
+
+}  // namespace fq

@@ -129,7 +129,7 @@ def test_gpu_merge_on_the_lane_plan(k, slow, monkeypatch):
     """--merge on the lane plan: the second overlap analysis, the merged read's filter and Stats, --include_unmerged, -c's edits in
     either part; slow: every merged read's second part counted by the lane kernel itself (tests/test_hostsim_parity.py)"""
     if slow:
-        monkeypatch.setenv("FASTP_GPU_DEBUG_SKIP", "512")
+        monkeypatch.setenv("FASTP_GPU_TEST_MERGE_SLOW", "1")
     p, sets = cases.merge_lane_case(k, n=5000)
     g = engines.gpu_engine(p)
     assert g.plan() == "lane"
@@ -1160,4 +1160,57 @@ def test_gpu_stats_cells_at_their_capacity():
     o.close()
     g.close()
     assert ro[0].tobytes() == rg[0].tobytes()
+    assert np.array_equal(co, cg), int((co != cg).sum())
+
+
+@pytest.mark.gpu
+def test_gpu_stats_joint_table_at_its_capacity():
+    """Form 5 of the Stats kernel (fq_stats5.h): every workgroup of a launch with the 16383 units the slab's packed cells hold, all
+    of them the same read - the same 16-bit halves of the joint table's cells ('K', its last quality row), then the packed cells of
+    what the table has no row for ('~').  (tests/test_hostsim_parity.py::test_sim_stats_joint_table_at_its_capacity: one workgroup)"""
+    import test_hostsim_parity as hs
+    import torch
+    p = abi.default_params(False, 160)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.dup_enabled = 0
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for n, ch in ((cus * 16383, "K"), (cus * 16383 + 1, "K"), (cus * 16383, "~")):
+        d = hs._filled_reads(n, 160, ch, base="G")
+        o = oraclelib.Oracle(p)
+        g = engines.gpu_engine(p)
+        ro, rg = o.process(d["seq1"], d["qual1"], d["len1"]), g.process(d["seq1"], d["qual1"], d["len1"])
+        co, cg = o.counters(), g.counters()
+        o.close()
+        g.close()
+        assert ro[0].tobytes() == rg[0].tobytes()
+        assert np.array_equal(co, cg), (n, ch, int((co != cg).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(6))
+def test_gpu_stats_every_quality_character(k):
+    """every quality character '!' .. '~' around the joint table's edge, N runs, ragged lengths, trimmed ranges (the emulator twin:
+    tests/test_hostsim_parity.py::test_sim_stats_every_quality_character, 3000 units): 300 000 units, records + every counter"""
+    import test_hostsim_parity as hs
+    paired, L, extra = hs.STATS5_RANGE_CASES[k]
+    p = abi.default_params(paired, L)
+    p.qualified_qual = 48
+    p.unqualified_percent_limit = 90
+    p.n_base_limit = 50
+    p.length_required = 1
+    for kk, v in extra.items():
+        setattr(p, kk, v)
+    d = hs.quality_range_reads(300000, L, 100 + k, paired)
+    o = oraclelib.Oracle(p)
+    g = engines.gpu_engine(p)
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    for i in range(3 if paired else 1):
+        assert ro[i].tobytes() == rg[i].tobytes()
+    if p.dedup or p.dup_enabled:   # (one launch on the GPU = the oracle's order: the duplicate decisions are the stream's)
+        pass
     assert np.array_equal(co, cg), int((co != cg).sum())

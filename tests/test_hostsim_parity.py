@@ -313,7 +313,7 @@ def test_sim_merge_on_the_lane_plan(k, slow, monkeypatch):
     against the oracle.  slow: every merged read's second part counted by the lane kernel itself (the path a pair takes whose
     second part holds an edited base)"""
     if slow:
-        monkeypatch.setenv("FASTP_GPU_DEBUG_SKIP", "512")
+        monkeypatch.setenv("FASTP_GPU_TEST_MERGE_SLOW", "1")
     check_merge_lane(engines.sim_engine, k)
 
 
@@ -1033,3 +1033,76 @@ def test_sim_stats_cells_at_their_capacity(monkeypatch):
         ro, rg, co, cg = _both(p, d, False)
         assert ro[0].tobytes() == rg[0].tobytes()
         assert np.array_equal(co, cg), int((co != cg).sum())
+
+
+def _filled_reads(n, L, ch, base="A"):
+    stride = (L + 7) // 8 * 8
+    seq = np.zeros((n, stride), dtype=np.uint8)
+    qual = np.zeros((n, stride), dtype=np.uint8)
+    seq[:, :L] = ord(base)
+    qual[:, :L] = ord(ch)
+    return {"seq1": seq, "qual1": qual, "len1": np.full(n, L, dtype=np.int32)}
+
+
+def test_sim_stats_joint_table_at_its_capacity(monkeypatch):
+    """Form 5 of the Stats kernel (fq_stats5.h): ONE workgroup with the 16383 units the slab's packed cells hold, every unit the
+    same read - all of them in the SAME 16-bit halves of the joint table's cells ('K': the table's last quality row, 160 bases:
+    every item whole, both halves of every dword), then in the packed cells of what the table has no row for ('L' and '~')"""
+    monkeypatch.setenv("FASTP_SIM_CUS", "1")
+    p = abi.default_params(False, 160)
+    p.adapter_seq_r1 = None
+    p.adapter_enabled = 0
+    p.dup_enabled = 0
+    for n, ch in ((16383, "K"), (16384, "K"), (16383, "L"), (16383, "~")):
+        d = _filled_reads(n, 160, ch, base="G")
+        ro, rg, co, cg = _both(p, d, False)
+        assert ro[0].tobytes() == rg[0].tobytes()
+        assert np.array_equal(co, cg), (n, ch, int((co != cg).sum()))
+
+
+def quality_range_reads(n, L, seed, paired):
+    """every quality character the packers take ('!' .. '~') with the table's edge ('K' | 'L') over-represented, runs of N, ragged
+    lengths (reads that end inside an item, one-base reads, empty reads)"""
+    rng = np.random.default_rng(seed)
+    stride = (L + 7) // 8 * 8
+    out = {}
+    for tag in ("1", "2") if paired else ("1",):
+        lens = rng.integers(0, L + 1, n).astype(np.int32)
+        lens[rng.random(n) < 0.5] = L
+        q = rng.integers(33, 127, (n, L))
+        edge = rng.random((n, L)) < 0.3
+        q[edge] = rng.integers(72, 79, int(edge.sum()))
+        plain = rng.random(n) < 0.4                       # reads the fast path takes whole: Q2 .. Q41
+        q[plain] = rng.integers(35, 75, (int(plain.sum()), L))
+        c = rng.integers(0, 4, (n, L))
+        isn = (rng.random((n, L)) < 0.01) & ~plain[:, None]
+        seq = np.zeros((n, stride), dtype=np.uint8)
+        qual = np.zeros((n, stride), dtype=np.uint8)
+        valid = np.arange(L)[None, :] < lens[:, None]
+        seq[:, :L] = np.where(valid, np.where(isn, ord("N"), np.frombuffer(b"ATCG", dtype=np.uint8)[c]), 0)
+        qual[:, :L] = np.where(valid, q, 0)
+        out["seq" + tag], out["qual" + tag], out["len" + tag] = seq, qual, lens
+    return out
+
+
+STATS5_RANGE_CASES = [(True, 150, {}), (False, 150, {"cut_right": 1}), (True, 100, {"trim_front1": 5, "trim_front2": 9, "cut_tail": 1}),
+                      (False, 151, {"trim_front1": 17, "trim_tail1": 3}), (True, 165, {"cut_right": 1, "correction": 1}), (True, 76, {"dedup": 1})]
+
+
+@pytest.mark.parametrize("k", range(len(STATS5_RANGE_CASES)))
+def test_sim_stats_every_quality_character(k):
+    """the Stats kernel's joint table holds '!' .. 'K'; every other character, N bases, ragged items and trimmed ranges take the
+    base-by-base path: all of them at once, records + every counter against the oracle"""
+    paired, L, extra = STATS5_RANGE_CASES[k]
+    p = abi.default_params(paired, L)
+    p.qualified_qual = 48
+    p.unqualified_percent_limit = 90
+    p.n_base_limit = 50
+    p.length_required = 1
+    for kk, v in extra.items():
+        setattr(p, kk, v)
+    d = quality_range_reads(3000, L, 100 + k, paired)
+    ro, rg, co, cg = _both(p, d, paired)
+    for i in range(3 if paired else 1):
+        assert ro[i].tobytes() == rg[i].tobytes()
+    assert np.array_equal(co, cg), int((co != cg).sum())
