@@ -27,7 +27,7 @@ namespace fq {
 
 enum { ST5_QN = 43,            // quality rows of the joint table: '!' .. 'K' (Q0 .. Q42); anything above takes the slow path
        ST5_QADD = 127 - 32 - ST5_QN,   // q + ST5_QADD has bit 7 set exactly when q >= '!' + ST5_QN (q < 128: no N flag)
-       ST5_WL = 128 };         // queued items per wavefront (drained in batches of 64: never more than 127)
+       ST5_WL = 128 };         // queued items per wavefront and list (drained in batches of 64: never more than 127)
 
 FQ_DEV int lane_rank(u64 mask) {   // set bits of `mask` below this lane
 #ifdef FQ_HOSTSIM
@@ -40,37 +40,8 @@ FQ_DEV int lane_rank(u64 mask) {   // set bits of `mask` below this lane
 
 struct Stats5Item {
     u32 q[4], qp, codes, prev8;
-    int h, rl0, lk;
+    int rl0, lk;
 };
-
-// item `it` of the workgroup's unit range of one mate: qual / seq / swin = the mate's arrays at the workgroup's first unit
-FQ_DEV void stats5_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 it, bool tv, Stats5Item& s) {
-    const u32 ur = fastdiv(tv ? it : 0u, a.magic_H16);
-    const u32 h = (tv ? it : 0u) - mul24(ur, (u32)a.H16);
-    s.h = (int)h;
-    u32 sw = 0;
-    s.q[0] = s.q[1] = s.q[2] = s.q[3] = s.qp = s.codes = s.prev8 = 0;
-    if (tv) {   // (all loads independent of each other)
-        sw = swin[ur];
-        const u32 qd = mul24(ur, (u32)a.qw_g) + 4u * h;          // dword of the row's quality bytes (rows are 8-byte aligned)
-        const u64 q01 = *(const u64*)(qual + qd);
-        s.q[0] = (u32)q01;
-        s.q[1] = (u32)(q01 >> 32);
-        if (4u * h + 4u <= (u32)a.qw_g) {                         // (the last item of a row may be half a vector)
-            const u64 q23 = *(const u64*)(qual + qd + 2u);
-            s.q[2] = (u32)q23;
-            s.q[3] = (u32)(q23 >> 32);
-        }
-        const u32 sd = mul24(ur, (u32)a.sw_g) + h;
-        if (h < (u32)a.sw_g) s.codes = seq[sd];
-        if (h > 0) {
-            s.qp = qual[qd - 1u];
-            s.prev8 = (u32)((const u8*)seq)[4u * sd - 1u];
-        }
-    }
-    s.rl0 = (int)(sw & 0xFFFFu);
-    s.lk = (int)(sw >> 16);
-}
 
 // LDS addresses (bytes) of the joint table
 struct Stats5Geo {
@@ -80,9 +51,60 @@ struct Stats5Geo {
     u32 S4;      // bytes between the two slots = 8 * K4
 };
 
-// one item, base by base (the per-wavefront list): any state
+// item column h of unit u of the workgroup's range (qual / seq / swin = the mate's arrays at the workgroup's first unit).  Every
+// load is unconditional - a lane without an item passes u = 0, and what a column does not have (the dword and the byte in front
+// of column 0, the second half of a row's last, half vector) is read from a valid neighbour and masked off - so the five of them
+// leave together and no lane waits behind a branch.
+FQ_DEV void stats5_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 u, u32 h, Stats5Item& s) {
+    const bool has23 = 4u * h + 4u <= (u32)a.qw_g;    // (the last item of a row may be half a vector)
+    const u32 m23 = has23 ? 0xFFFFFFFFu : 0u, mh = h > 0 ? 0xFFFFFFFFu : 0u;
+    const u32 qd = mul24(u, (u32)a.qw_g) + 4u * h;      // dword of the row's quality bytes (rows are 8-byte aligned)
+    const u32 sd = mul24(u, (u32)a.sw_g) + h;
+    const u32 sw = swin[u];
+    const u64 q01 = *(const u64*)(qual + qd);
+    const u64 q23 = *(const u64*)(qual + qd + (has23 ? 2u : 0u));
+    const u32 qp = qual[qd - (h > 0 ? 1u : 0u)];
+    const u32 cd = seq[sd];
+    const u32 p8 = (u32)((const u8*)seq)[4u * sd - (h > 0 ? 1u : 0u)];
+    s.q[0] = (u32)q01;
+    s.q[1] = (u32)(q01 >> 32);
+    s.q[2] = (u32)q23 & m23;
+    s.q[3] = (u32)(q23 >> 32) & m23;
+    s.qp = qp & mh;
+    s.codes = cd;
+    s.prev8 = p8 & mh;
+    s.rl0 = (int)(sw & 0xFFFFu);
+    s.lk = (int)(sw >> 16);
+}
+
+// The cells of one item whose bases [0, nv) are clean (no N among them or the four in front, qualities the table has rows for)
+// and all in one slot: 6 VALU + 2 DS instructions per base - two field extracts and two multiply-adds for the cell, an extract
+// and a shift-add for the 5-mer.  MASKED: nv < 16 (a read's last item), the lanes of a wavefront stop at their own nv.
+template <int KC, bool MASKED, bool ABL>
+FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb, const Stats5Item& s, u32 h, int nv) {
+    const u32 qadd = 0x01010101u * (u32)ST5_QADD;
+    const u32 ev[4] = {s.q[0] + qadd, s.q[1] + qadd, s.q[2] + qadd, s.q[3] + qadd};   // byte q + ST5_QADD: row q - 33 (ib holds the difference)
+    const u32 c_lo = s.prev8 | (s.codes << 8);    // bases j0 - 4 .. j0 + 11
+    const u32 c_hi = s.codes >> 8;                // bases j0 + 4 .. j0 + 15
+    const u32 hpos = h > 0 ? 1u : 0u;             // 5-mers need positions >= 4 (stats.cpp:224-266)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (MASKED && (k & 3) == 0 && ballot(k < nv) == 0ull) return;   // (uniform) nobody has a base left
+        if (!MASKED || k < nv) {
+            const u32 e = bfe(ev[k >> 2], 8 * (k & 3), 8);
+            const u32 cl = bfe(s.codes, 2 * k, 2);
+            const u32 t = mad24_su(cl, g.C4, ib);
+            const u32 ca = mad24_su(e, g.HS4, t);
+            if (!ABL || !(a.debug_skip & 64u)) lds_add_u32_at(ca + (u32)(k & 7) * g.K4, k < 8 ? 1u : 0x10000u);
+            const u32 x = k < 8 ? bfe(c_lo, 2 * k, 10) : bfe(c_hi, 2 * k - 16, 10);
+            if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kb), k < 4 ? hpos : 1u);
+        }
+    }
+}
+
+// one item, base by base: any state (an N, a quality the table has no row for, a kept range that ends inside the item)
 template <int KC>
-FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, int F, const Stats5Item& s, int lane) {
+FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, int F, const Stats5Item& s, int h, int lane) {
     u8* ldsw = (u8*)lds;
     const u32 nbp = (s.qp >> 7) & 0x01010101u;
     u32 n20 = (nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu;   // bit i = base j0 - 4 + i is an N
@@ -91,9 +113,9 @@ FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g
         const u32 nb = (s.q[d] >> 7) & 0x01010101u;
         n20 |= ((nb | (nb >> 7) | (nb >> 14) | (nb >> 21)) & 0xFu) << (4 + 4 * d);
     }
-    if (s.h == 0) n20 |= 0xFu;                                  // in front of the read: no 5-mer (stats.cpp:224-227)
+    if (h == 0) n20 |= 0xFu;                                    // in front of the read: no 5-mer (stats.cpp:224-227)
     const u64 c40 = (u64)s.prev8 | ((u64)s.codes << 8);         // bases j0 - 4 .. j0 + 15, two bits each
-    const int j0 = 16 * s.h;
+    const int j0 = 16 * h;
     const int Fk = F > 0 ? F + 4 : 0;
     u64* ovf = (u64*)(lds + a.l_ovf);
     u32* qh = lds + a.l_qh;
@@ -108,7 +130,7 @@ FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g
         const u32 slot = (j >= F && j < s.lk) ? 1u : 0u;
         const u32 e = q - 33u;
         if (!isn && e < (u32)ST5_QN) {
-            lds_add_u32((u32*)(ldsw + ((u32)a.l_cyc * 4u + slot * g.S4 + (u32)(k & 7) * g.K4 + code * g.C4 + e * g.HS4 + (u32)s.h * 4u)), k < 8 ? 1u : 0x10000u);
+            lds_add_u32((u32*)(ldsw + ((u32)a.l_cyc * 4u + slot * g.S4 + (u32)(k & 7) * g.K4 + code * g.C4 + e * g.HS4 + (u32)h * 4u)), k < 8 ? 1u : 0x10000u);
         } else {
             lds_add_u64(&ovf[(slot * (u32)a.Cp + (u32)j) * N_CLS + (isn ? (u32)CLS_N : code)], stats_inc_of(q));
             lds_add_u32(&qh[slot * 128u + q], 1u);
@@ -133,8 +155,16 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     g.S4 = 8u * g.K4;
     const int u0 = block_id() * a.units_per_block;
     const int nu = imax(0, imin(a.units_per_block, a.n - u0));
-    const u32 per_mate = (u32)(nu * H16);
-    u32* wl = lds + a.l_wl + (tid >> 6) * ST5_WL;                 // this wavefront's list
+    // lane = (unit of the wavefront's trip, item column): both are constants of the lane for the whole kernel - no division, no
+    // per-item address arithmetic beyond a multiply-add per array; 64 / H16 units per trip (60 of 64 lanes at ten columns)
+    const int upw = 64 / H16;
+    const u32 lu = HS ? (u32)lane / (u32)HS : (u32)lane / (u32)H16;
+    const u32 h = (u32)lane - lu * (u32)H16;
+    const bool used = (int)lu < upw;
+    const int j0 = 16 * (int)h;
+    const int ustride = (nt >> 6) * upw;
+    u32* wlT = lds + a.l_wl + (tid >> 6) * (2 * ST5_WL);          // this wavefront's two lists: a read's clean last item ...
+    u32* wlG = wlT + ST5_WL;                                      // ... and everything else the fast path does not take
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     const int n_cyc = 4 * a.Cp * N_CLS;                           // u64 items of the slab's per-cycle part
     const int nm = a.paired ? 2 : 1;
@@ -150,61 +180,63 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
             const u32 lds0 = lds_addr_of(lds);                    // (DS addresses, not generic pointers: no aperture add per access)
             const u32 cyc_b = lds0 + (u32)a.l_cyc * 4u - (u32)(33 + ST5_QADD) * g.HS4;   // the row of byte value q + ST5_QADD is q - 33
             const u32 kmer_b = lds0 + (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
-            int wn = 0;                                           // queued items of this wavefront (uniform)
-            for (u32 base = (u32)(tid - lane); base < per_mate; base += (u32)nt) {   // wave-uniform trip count (ballots inside)
-                const u32 it = base + (u32)lane;
-                const bool tv = it < per_mate;
-                Stats5Item s;
-                stats5_fetch(a, qual, seq, swin, it, tv, s);
-                const int j0 = 16 * s.h;
-                const bool act = tv && j0 < s.rl0;
-                const u32 nany = (s.q[0] | s.q[1] | s.q[2] | s.q[3] | s.qp) & 0x80808080u;   // an N among the 16 bases or the 4 before
-                const u32 e0 = s.q[0] + 0x01010101u * (u32)ST5_QADD, e1 = s.q[1] + 0x01010101u * (u32)ST5_QADD;
-                const u32 e2 = s.q[2] + 0x01010101u * (u32)ST5_QADD, e3 = s.q[3] + 0x01010101u * (u32)ST5_QADD;
-                const u32 oor = (e0 | e1 | e2 | e3) & 0x80808080u;                             // a quality the table has no row for
-                const bool all_kept = j0 >= Fk && j0 + 16 <= s.lk;
-                const bool all_drop = s.lk <= j0 || j0 + 16 <= F;
-                const bool fast = act && j0 + 16 <= s.rl0 && (nany | oor) == 0u && (all_kept || all_drop);
-                const bool slow = act && !fast;
-                {   // queue the rest: this wavefront's own list, positions by a prefix count over the ballot
-                    const u64 sm = ballot(slow);
-                    if (sm) {                                     // (uniform)
-                        if (slow) wl[wn + lane_rank(sm)] = it;
-                        wn += popc64(sm);
+            const u32 slotK = (u32)(KMER_BINS * KC * 4);
+            int wnT = 0, wnG = 0;                                 // queued items of this wavefront (uniform)
+            for (int ub = (tid >> 6) * upw;; ub += ustride) {     // wave-uniform (ballots inside)
+                const bool more = ub < nu;
+                if (more) {
+                    const u32 u = (u32)ub + lu;
+                    const bool tv = used && (int)u < nu;
+                    Stats5Item s;
+                    stats5_fetch(a, qual, seq, swin, tv ? u : 0u, h, s);
+                    const int nv = s.rl0 - j0, nk = s.lk - j0;
+                    const bool act = tv && nv > 0;
+                    const u32 qadd = 0x01010101u * (u32)ST5_QADD;
+                    const u32 dirty = (s.q[0] | s.q[1] | s.q[2] | s.q[3] | s.qp |                          // an N among the 16 bases or the 4 before,
+                                       (s.q[0] + qadd) | (s.q[1] + qadd) | (s.q[2] + qadd) | (s.q[3] + qadd)) & 0x80808080u;   // a quality without a row
+                    const bool kept = j0 >= Fk && nk >= imin(nv, 16);              // every base of the item (and its 5-mer) is a kept one
+                    const bool drop = nk <= 0 || j0 + 16 <= F;                     // ... a dropped one
+                    const bool clean = act && dirty == 0u && (kept || drop);
+                    const bool fast = clean && nv >= 16;
+                    const u64 mT = ballot(clean && nv < 16), mG = ballot(act && !clean);
+                    if (mT) {                                     // (uniform) positions by a prefix count over the ballot: no atomic
+                        if (clean && nv < 16) wlT[wnT + lane_rank(mT)] = u | (h << 16);
+                        wnT += popc64(mT);
                     }
-                }
-                if (fast) {
-                    const u32 ib = opaque(cyc_b + (all_kept ? g.S4 : 0u) + (u32)s.h * 4u);
-                    const u32 kb = opaque(kmer_b + (all_kept ? (u32)(KMER_BINS * KC * 4) : 0u));
-                    const u32 c_lo = s.prev8 | (s.codes << 8);    // bases j0 - 4 .. j0 + 11
-                    const u32 c_hi = s.codes >> 8;                // bases j0 + 4 .. j0 + 15
-                    const u32 hpos = s.h > 0 ? 1u : 0u;           // 5-mers need positions >= 4 (stats.cpp:224-266)
-                    const u32 ev[4] = {e0, e1, e2, e3};
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const u32 e = bfe(ev[k >> 2], 8 * (k & 3), 8);
-                        const u32 cl = bfe(s.codes, 2 * k, 2);
-                        const u32 t = mad24_su(cl, g.C4, ib);                    // four instructions per base and cell:
-                        const u32 ca = mad24_su(e, g.HS4, t);                    // two field extracts, two multiply-adds
-                        if (!ABL || !(a.debug_skip & 64u)) lds_add_u32_at(ca + (u32)(k & 7) * g.K4, k < 8 ? 1u : 0x10000u);
-                        const u32 x = k < 8 ? bfe(c_lo, 2 * k, 10) : bfe(c_hi, 2 * k - 16, 10);
-                        if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kb), k < 4 ? hpos : 1u);
+                    if (mG) {
+                        if (act && !clean) wlG[wnG + lane_rank(mG)] = u | (h << 16);
+                        wnG += popc64(mG);
                     }
+                    if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + h * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
                 }
-                if (wn >= 64) {                                   // (uniform) a full wavefront of queued items
+                // a full wavefront of queued items (behind the last trip: what is left)
+                while (wnT >= 64 || (!more && wnT > 0)) {         // (uniform)
+                    const int cnt = imin(wnT, 64);
                     wave_sync();
-                    wn -= 64;
+                    wnT -= cnt;
+                    const bool on = lane < cnt;
+                    const u32 w = on ? wlT[wnT + lane] : 0u;
+                    const u32 hh = w >> 16;
                     Stats5Item t;
-                    stats5_fetch(a, qual, seq, swin, wl[wn + lane], true, t);
-                    stats5_item_general<KC>(a, lds, g, F, t, lane);
+                    stats5_fetch(a, qual, seq, swin, w & 0xFFFFu, hh, t);
+                    const int tj0 = 16 * (int)hh;
+                    const int tnv = t.rl0 - tj0;
+                    const bool tk = tj0 >= Fk && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
+                    stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (tk ? g.S4 : 0u) + hh * 4u), opaque(kmer_b + (tk ? slotK : 0u)), t, hh, on ? tnv : 0);
                     wave_sync();
                 }
-            }
-            if (wn > 0) {                                         // (uniform) what is left of the list
-                wave_sync();
-                Stats5Item t;
-                stats5_fetch(a, qual, seq, swin, lane < wn ? wl[lane] : 0u, lane < wn, t);
-                if (lane < wn) stats5_item_general<KC>(a, lds, g, F, t, lane);
+                while (wnG >= 64 || (!more && wnG > 0)) {         // (uniform)
+                    const int cnt = imin(wnG, 64);
+                    wave_sync();
+                    wnG -= cnt;
+                    const bool on = lane < cnt;
+                    const u32 w = on ? wlG[wnG + lane] : 0u;
+                    Stats5Item t;
+                    stats5_fetch(a, qual, seq, swin, w & 0xFFFFu, w >> 16, t);
+                    if (on) stats5_item_general<KC>(a, lds, g, F, t, (int)(w >> 16), lane);
+                    wave_sync();
+                }
+                if (!more) break;
             }
         }
         block_sync();
