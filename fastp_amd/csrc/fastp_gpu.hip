@@ -558,13 +558,13 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
                 o = (o + 1) & ~1;
                 ctx->st_l_ovf = o; o += 2 * ctx->L.Cp * N_CLS * 2;
                 ctx->st_l_qh = o; o += 2 * 128;
-                ctx->st_l_wl = o; o += (1024 / 64) * 2 * ST5_WL;
+                ctx->st_l_wl = o; o += (1024 / 64) * 2 * ST5_WL / 2;   // (u16 entries)
                 if (o * 4 <= (int)prop.sharedMemPerBlock && ctx->st_H16 <= ctx->dp.sw_g && ctx->st_H16 <= 64) {
                     ctx->st_form = 5;
                     ctx->st_kc = kc;
                     ctx->st_Hs = ctx->st_H16;
                     ctx->st_lds_dwords = o;
-                    ctx->st_max_reads = CYC_MAX_READS;
+                    ctx->st_max_reads = CYC_MAX_READS;   // (a list entry holds the trip in 10 bits: 16 wavefronts x (64 / H16 >= 4) units per trip, <= 256 trips)
                     break;
                 }
             }
@@ -617,7 +617,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         }
         ctx->st_slab_dwords = 4 * ctx->L.Cp * N_CLS * 2 + 4 * KMER_BINS + 4 * 128;
         ctx->st_threads = env_int("FASTP_GPU_STATS_THREADS", 1024);
-        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63)) ctx->st_threads = 1024;
+        if (ctx->st_threads < 64 || ctx->st_threads > 1024 || (ctx->st_threads & 63) || ctx->st_form == 5) ctx->st_threads = 1024;
         if (ctx->st_lds_dwords * 4 > (int)prop.sharedMemPerBlock) { delete ctx; return fail(nullptr, FASTP_GPU_E_INVALID, "reads too long for the Stats kernel's LDS"); }
         int st_per_cu = std::min(2048 / ctx->st_threads, (int)((160 * 1024) / (ctx->st_lds_dwords * 4)));
         st_per_cu = env_int("FASTP_GPU_STATS_BLOCKS_PER_CU", std::max(1, st_per_cu));

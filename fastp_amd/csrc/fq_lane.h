@@ -253,8 +253,8 @@ FQ_DEV void lane_stage_rows(u32* buf, const u32* src, int rows, int stride, int 
 
 // Pull `bytes` bytes behind `src` into L2: one dword of every 128-byte line by global_load_lds_dword into `sink` (64 dwords of LDS
 // nobody reads).  Nothing waits for it; the later loads of the same lines by lane_stage_rows are L2 hits.
-FQ_DEV void lane_prefetch_lines(u32* sink, const u32* src, int bytes, int lane) {
-    for (int off = lane * 128; off < bytes; off += 64 * 128) glds4((const char*)src + off, (char*)sink, lane);
+FQ_DEV void lane_prefetch_lines(u32* sink, const u32* src, int bytes, int lane, int step) {
+    for (int off = lane * step; off < bytes; off += 64 * step) glds4((const char*)src + off, (char*)sink, lane);
 }
 
 // The same copy without registers (round 5): global_load_lds_dwordx4, 16 bytes per lane straight into the stage, asynchronous.
@@ -1458,8 +1458,9 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         // DevParams::front_lane (EXT): fr = the read's front in the row (UMI + -f), ft = trimAndCut's part of it (frontTrimmed)
         int fr1 = 0, ft1 = 0, fr2 = 0, ft2 = 0;
         if (PAIRED && (la.prefetch & 1)) {   // (uniform) read 2's rows on their way to L2 while read 1 is staged and swept
-            lane_prefetch_lines(lds + ll.sink, a.seq[1] + (size_t)(chunk * 64) * p.sw_g, rows * p.sw_g * 4, lane);
-            lane_prefetch_lines(lds + ll.sink, a.qual[1] + (size_t)(chunk * 64) * p.qw_g, rows * p.qw_g * 4, lane);
+            const int step = 128 >> ((la.prefetch >> 2) & 3);   // (A/B: bits 2-3 = a dword every 128 / 64 / 32 bytes)
+            lane_prefetch_lines(lds + ll.sink, a.seq[1] + (size_t)(chunk * 64) * p.sw_g, rows * p.sw_g * 4, lane, step);
+            lane_prefetch_lines(lds + ll.sink, a.qual[1] + (size_t)(chunk * 64) * p.qw_g, rows * p.qw_g * 4, lane, step);
         }
         lane_load_read<SWM, PAIRED>(a, stage, part, a.seq[0], a.qual[0], a.len[0], chunk * 64, rows, lane, valid, win, thr, thr4, r1);
         if (FR) {
@@ -1470,8 +1471,9 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             const int nxc = nstatic + (int)uniform((u32)nx);
             if (nxc < chunks) {
                 const int nrows = imin(64, a.n - nxc * 64);
-                lane_prefetch_lines(lds + ll.sink, a.seq[0] + (size_t)(nxc * 64) * p.sw_g, nrows * p.sw_g * 4, lane);
-                lane_prefetch_lines(lds + ll.sink, a.qual[0] + (size_t)(nxc * 64) * p.qw_g, nrows * p.qw_g * 4, lane);
+                const int step = 128 >> ((la.prefetch >> 2) & 3);
+                lane_prefetch_lines(lds + ll.sink, a.seq[0] + (size_t)(nxc * 64) * p.sw_g, nrows * p.sw_g * 4, lane, step);
+                lane_prefetch_lines(lds + ll.sink, a.qual[0] + (size_t)(nxc * 64) * p.qw_g, nrows * p.qw_g * 4, lane, step);
             }
         }
         // Duplicate::seq2intvector of read 1 in front of read 2's sweep (B > 0, the asynchronous stage): what it needs of read 1

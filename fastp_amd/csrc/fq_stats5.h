@@ -23,11 +23,15 @@
 #pragma once
 #include "fq_stats.h"
 
+#ifndef FQ_ST5_DEPTH
+#define FQ_ST5_DEPTH 3   // trips whose loads a wavefront keeps in flight (A/B: tools/gpu_r6_c.sh)
+#endif
+
 namespace fq {
 
 enum { ST5_QN = 43,            // quality rows of the joint table: '!' .. 'K' (Q0 .. Q42); anything above takes the slow path
        ST5_QADD = 127 - 32 - ST5_QN,   // q + ST5_QADD has bit 7 set exactly when q >= '!' + ST5_QN (q < 128: no N flag)
-       ST5_WL = 128 };         // queued items per wavefront and list (drained in batches of 64: never more than 127)
+       ST5_WL = 256 };         // queued items (u16) per wavefront and list: <= 63 left over + 60 per trip of the FQ_ST5_DEPTH <= 3 between two drains
 
 FQ_DEV int lane_rank(u64 mask) {   // set bits of `mask` below this lane
 #ifdef FQ_HOSTSIM
@@ -53,28 +57,42 @@ struct Stats5Geo {
 
 // item column h of unit u of the workgroup's range (qual / seq / swin = the mate's arrays at the workgroup's first unit).  Every
 // load is unconditional - a lane without an item passes u = 0, and what a column does not have (the dword and the byte in front
-// of column 0, the second half of a row's last, half vector) is read from a valid neighbour and masked off - so the five of them
-// leave together and no lane waits behind a branch.
-FQ_DEV void stats5_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 u, u32 h, Stats5Item& s) {
+// of column 0, the second half of a row's last, half vector) is read from a valid neighbour and masked off - so the six of them
+// leave together and no lane waits behind a branch.  Issue and use are apart: the main loop keeps FQ_ST5_DEPTH trips' loads in
+// flight (a wavefront that waits for one trip's 1.2 KB at a time leaves the CU with < 20 KB on its way: the pass then runs at the
+// memory system's latency, 1.7 TB/s - profiles/r06_b_stats5_lane_mapping_ab_and_sq_counters.txt: 54 % of the wave cycles waiting).
+struct Stats5Raw {
+    u64 q01, q23;
+    u32 sw, qp, cd, p8;
+};
+FQ_DEV void stats5_issue(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 u, u32 h, Stats5Raw& r) {
     const bool has23 = 4u * h + 4u <= (u32)a.qw_g;    // (the last item of a row may be half a vector)
-    const u32 m23 = has23 ? 0xFFFFFFFFu : 0u, mh = h > 0 ? 0xFFFFFFFFu : 0u;
     const u32 qd = mul24(u, (u32)a.qw_g) + 4u * h;      // dword of the row's quality bytes (rows are 8-byte aligned)
     const u32 sd = mul24(u, (u32)a.sw_g) + h;
-    const u32 sw = swin[u];
-    const u64 q01 = *(const u64*)(qual + qd);
-    const u64 q23 = *(const u64*)(qual + qd + (has23 ? 2u : 0u));
-    const u32 qp = qual[qd - (h > 0 ? 1u : 0u)];
-    const u32 cd = seq[sd];
-    const u32 p8 = (u32)((const u8*)seq)[4u * sd - (h > 0 ? 1u : 0u)];
-    s.q[0] = (u32)q01;
-    s.q[1] = (u32)(q01 >> 32);
-    s.q[2] = (u32)q23 & m23;
-    s.q[3] = (u32)(q23 >> 32) & m23;
-    s.qp = qp & mh;
-    s.codes = cd;
-    s.prev8 = p8 & mh;
-    s.rl0 = (int)(sw & 0xFFFFu);
-    s.lk = (int)(sw >> 16);
+    r.sw = swin[u];
+    r.q01 = *(const u64*)(qual + qd);
+    r.q23 = *(const u64*)(qual + qd + (has23 ? 2u : 0u));
+    r.qp = qual[qd - (h > 0 ? 1u : 0u)];
+    r.cd = seq[sd];
+    r.p8 = (u32)((const u8*)seq)[4u * sd - (h > 0 ? 1u : 0u)];
+}
+FQ_DEV void stats5_finish(const StatsArgs& a, u32 h, const Stats5Raw& r, Stats5Item& s) {
+    const bool has23 = 4u * h + 4u <= (u32)a.qw_g;
+    const u32 m23 = has23 ? 0xFFFFFFFFu : 0u, mh = h > 0 ? 0xFFFFFFFFu : 0u;
+    s.q[0] = (u32)r.q01;
+    s.q[1] = (u32)(r.q01 >> 32);
+    s.q[2] = (u32)r.q23 & m23;
+    s.q[3] = (u32)(r.q23 >> 32) & m23;
+    s.qp = r.qp & mh;
+    s.codes = r.cd;
+    s.prev8 = r.p8 & mh;
+    s.rl0 = (int)(r.sw & 0xFFFFu);
+    s.lk = (int)(r.sw >> 16);
+}
+FQ_DEV void stats5_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 u, u32 h, Stats5Item& s) {
+    Stats5Raw r;
+    stats5_issue(a, qual, seq, swin, u, h, r);
+    stats5_finish(a, h, r, s);
 }
 
 // The cells of one item whose bases [0, nv) are clean (no N among them or the four in front, qualities the table has rows for)
@@ -163,8 +181,8 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     const bool used = (int)lu < upw;
     const int j0 = 16 * (int)h;
     const int ustride = (nt >> 6) * upw;
-    u32* wlT = lds + a.l_wl + (tid >> 6) * (2 * ST5_WL);          // this wavefront's two lists: a read's clean last item ...
-    u32* wlG = wlT + ST5_WL;                                      // ... and everything else the fast path does not take
+    u16* wlT = (u16*)(lds + a.l_wl) + (tid >> 6) * (2 * ST5_WL);   // this wavefront's two lists: a read's clean last item ...
+    u16* wlG = wlT + ST5_WL;                                      // ... and everything else the fast path does not take
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     const int n_cyc = 4 * a.Cp * N_CLS;                           // u64 items of the slab's per-cycle part
     const int nm = a.paired ? 2 : 1;
@@ -182,43 +200,73 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
             const u32 kmer_b = lds0 + (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
             const u32 slotK = (u32)(KMER_BINS * KC * 4);
             int wnT = 0, wnG = 0;                                 // queued items of this wavefront (uniform)
-            for (int ub = (tid >> 6) * upw;; ub += ustride) {     // wave-uniform (ballots inside)
-                const bool more = ub < nu;
-                if (more) {
-                    const u32 u = (u32)ub + lu;
-                    const bool tv = used && (int)u < nu;
-                    Stats5Item s;
-                    stats5_fetch(a, qual, seq, swin, tv ? u : 0u, h, s);
-                    const int nv = s.rl0 - j0, nk = s.lk - j0;
-                    const bool act = tv && nv > 0;
-                    const u32 qadd = 0x01010101u * (u32)ST5_QADD;
-                    const u32 dirty = (s.q[0] | s.q[1] | s.q[2] | s.q[3] | s.qp |                          // an N among the 16 bases or the 4 before,
-                                       (s.q[0] + qadd) | (s.q[1] + qadd) | (s.q[2] + qadd) | (s.q[3] + qadd)) & 0x80808080u;   // a quality without a row
-                    const bool kept = j0 >= Fk && nk >= imin(nv, 16);              // every base of the item (and its 5-mer) is a kept one
-                    const bool drop = nk <= 0 || j0 + 16 <= F;                     // ... a dropped one
-                    const bool clean = act && dirty == 0u && (kept || drop);
-                    const bool fast = clean && nv >= 16;
-                    const u64 mT = ballot(clean && nv < 16), mG = ballot(act && !clean);
-                    if (mT) {                                     // (uniform) positions by a prefix count over the ballot: no atomic
-                        if (clean && nv < 16) wlT[wnT + lane_rank(mT)] = u | (h << 16);
-                        wnT += popc64(mT);
+            // The loads of FQ_ST5_DEPTH trips are in flight: the trip loop is unrolled by that many with one register set per
+            // position (a rotating set would have to MOVE registers that loads are still on their way to, i.e. wait for them).
+            Stats5Raw ring[FQ_ST5_DEPTH];
+#pragma unroll
+            for (int d = 0; d < FQ_ST5_DEPTH; d++) {
+                const u32 ud = (u32)((tid >> 6) * upw + d * ustride) + lu;
+                stats5_issue(a, qual, seq, swin, (used && (int)ud < nu) ? ud : 0u, h, ring[d]);
+            }
+            const u32 ent_lane = (u32)lane;                       // a queued item: trip << 6 | the lane that found it (its unit and column)
+            const int ub0 = (tid >> 6) * upw;
+            int tr = 0;
+            bool more = ub0 < nu;
+            for (;;) {                                            // wave-uniform (ballots inside)
+              // the steady loop: blocks of FQ_ST5_DEPTH trips while no list holds a wavefront's worth.  The lists are emptied
+              // OUTSIDE it: with their loads (and the fences around them) inside, the compiler's s_waitcnt at the loop's head was
+              // vmcnt(0) - every block began by waiting for the loads just issued for the NEXT ones
+#pragma unroll 1
+              while (more && wnT < 64 && wnG < 64) {
+#pragma unroll
+                for (int d = 0; d < FQ_ST5_DEPTH; d++) {
+                    const int ub = ub0 + (tr + d) * ustride;
+                    {   // (no branch around a trip behind the range's end - its lanes have no item: the loads of the other positions
+                        // stay countable for the compiler's s_waitcnt only on a straight path)
+                        const u32 u = (u32)ub + lu;
+                        const bool tv = used && (int)u < nu;
+                        Stats5Item s;
+                        stats5_finish(a, h, ring[d], s);
+                        const int nv = s.rl0 - j0, nk = s.lk - j0;
+                        const bool act = tv && nv > 0;
+                        const u32 qadd = 0x01010101u * (u32)ST5_QADD;
+                        const u32 dirty = (s.q[0] | s.q[1] | s.q[2] | s.q[3] | s.qp |                          // an N among the 16 bases or the 4 before,
+                                           (s.q[0] + qadd) | (s.q[1] + qadd) | (s.q[2] + qadd) | (s.q[3] + qadd)) & 0x80808080u;   // a quality without a row
+                        const bool kept = j0 >= Fk && nk >= imin(nv, 16);              // every base of the item (and its 5-mer) is a kept one
+                        const bool drop = nk <= 0 || j0 + 16 <= F;                     // ... a dropped one
+                        const bool clean = act && dirty == 0u && (kept || drop);
+                        const bool fast = clean && nv >= 16;
+                        const u64 mT = ballot(clean && nv < 16), mG = ballot(act && !clean);
+                        const u32 ent = ((u32)(tr + d) << 6) | ent_lane;
+                        if (mT) {                                 // (uniform) positions by a prefix count over the ballot: no atomic
+                            if (clean && nv < 16) wlT[wnT + lane_rank(mT)] = (u16)ent;
+                            wnT += popc64(mT);
+                        }
+                        if (mG) {
+                            if (act && !clean) wlG[wnG + lane_rank(mG)] = (u16)ent;
+                            wnG += popc64(mG);
+                        }
+                        if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + h * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
+                        {   // this position's registers are free again: the trip FQ_ST5_DEPTH ahead
+                            const u32 un = u + (u32)(FQ_ST5_DEPTH * ustride);
+                            stats5_issue(a, qual, seq, swin, (used && (int)un < nu) ? un : 0u, h, ring[d]);
+                        }
                     }
-                    if (mG) {
-                        if (act && !clean) wlG[wnG + lane_rank(mG)] = u | (h << 16);
-                        wnG += popc64(mG);
-                    }
-                    if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + h * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
                 }
+                tr += FQ_ST5_DEPTH;
+                more = ub0 + tr * ustride < nu;
+              }
                 // a full wavefront of queued items (behind the last trip: what is left)
                 while (wnT >= 64 || (!more && wnT > 0)) {         // (uniform)
                     const int cnt = imin(wnT, 64);
                     wave_sync();
                     wnT -= cnt;
                     const bool on = lane < cnt;
-                    const u32 w = on ? wlT[wnT + lane] : 0u;
-                    const u32 hh = w >> 16;
+                    const u32 w = on ? (u32)wlT[wnT + lane] : 0u;
+                    const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
+                    const u32 hh = (w & 63u) - wl_ * (u32)H16, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
-                    stats5_fetch(a, qual, seq, swin, w & 0xFFFFu, hh, t);
+                    stats5_fetch(a, qual, seq, swin, on ? uu : 0u, hh, t);
                     const int tj0 = 16 * (int)hh;
                     const int tnv = t.rl0 - tj0;
                     const bool tk = tj0 >= Fk && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
@@ -230,10 +278,12 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     wave_sync();
                     wnG -= cnt;
                     const bool on = lane < cnt;
-                    const u32 w = on ? wlG[wnG + lane] : 0u;
+                    const u32 w = on ? (u32)wlG[wnG + lane] : 0u;
+                    const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
+                    const u32 hh = (w & 63u) - wl_ * (u32)H16, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
-                    stats5_fetch(a, qual, seq, swin, w & 0xFFFFu, w >> 16, t);
-                    if (on) stats5_item_general<KC>(a, lds, g, F, t, (int)(w >> 16), lane);
+                    stats5_fetch(a, qual, seq, swin, on ? uu : 0u, hh, t);
+                    if (on) stats5_item_general<KC>(a, lds, g, F, t, (int)hh, lane);
                     wave_sync();
                 }
                 if (!more) break;
