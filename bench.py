@@ -82,12 +82,12 @@ def timed_ref(binary, tmp, f1, f2, flags, cores, env=None, tag="o"):
     cmd = [binary, "-i", f1, "-I", f2, "-o", os.path.join(tmp, tag + "1.fq"), "-O", os.path.join(tmp, tag + "2.fq"),
            "-j", os.path.join(tmp, tag + ".json"), "-h", os.path.join(tmp, tag + ".html"), "-w", str(cores)] + flags
     times = []
-    for _ in range(2):
+    for _ in range(3):   # median of 3: the reference's own convention (scripts/bench_e2e.sh:10), SURVEY.md 8(d)
         t0 = time.time()
         subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900,
                        env=dict(os.environ, **(env or {})))
         times.append(time.time() - t0)
-    return min(times)
+    return sorted(times)[1]
 
 
 def cpu_baseline(sample_pairs, flags, params, dev, files=None):
@@ -105,7 +105,7 @@ def cpu_baseline(sample_pairs, flags, params, dev, files=None):
                 "kind": "reference",
                 "sample": f"{sample_pairs} synthetic 2x{L} pairs, plain FASTQ -> FASTQ on tmpfs, fastp_ref -w {cores} "
                           f"(scalar shim for Highway SIMD; the box has {os.cpu_count()} logical cores), end-to-end wall incl. "
-                          f"FASTQ parse/write and the reference's start-up (bloom allocation, pre-pass), best of 2"}
+                          f"FASTQ parse/write and the reference's start-up (bloom allocation, pre-pass), median of 3"}
     import oraclelib
     sample_pairs = min(sample_pairs, 500_000)
     d = synth_torch.synth_pairs_torch(sample_pairs, L=L, seed=4242, device=dev)
@@ -119,7 +119,14 @@ def cpu_baseline(sample_pairs, flags, params, dev, files=None):
             "sample": f"{sample_pairs} synthetic 2x{L} pairs through the plain-C oracle (per-read loop only, 1 thread)"}
 
 
-def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False):
+def report_sections_that_differ(path_a, path_b, ignore=("command",)):
+    """top-level sections of two fastp JSON reports whose contents differ (scripts/bench_e2e.sh:171-209 compares the outputs; the report
+    is what the counter block produces: every Stats / FilterResult / Duplicate number)"""
+    a, b = json.load(open(path_a)), json.load(open(path_b))
+    return sorted(k for k in set(a) | set(b) if k not in ignore and a.get(k) != b.get(k))
+
+
+def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False, full_json=False):
     """the same files end to end through the GPU path, two ways (never the headline `value`):
     e2e_gpu    : fastp_amd.pipeline - raw text to HBM, parse / worker loop / format on the device, text back, file I/O
     e2e_dropin : the real reference with its worker loops bound to the engine (oracle/_ref/fastp_ref_gpu, FASTP_GPU=1)
@@ -173,18 +180,43 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False):
                             hsh.update(blk)
                     return hsh.hexdigest()
                 same = md5(o1) == md5(d1) and md5(os.path.join(tmp, "o2.fq")) == md5(os.path.join(tmp, "d2.fq"))
+            # The report: the reference's own JSON depends on -w in exactly two sections (insert_size: sampled on worker thread 0 only,
+            # peprocessor.cpp:449,497; adapter_cutting: one FilterResult map per thread with its own caps, filterresult.cpp:38-89 -
+            # profiles/r04_ref_thread_dependence.txt), the binding has fastp_ref -w 1's.  Against the -w <cores> report of the CPU
+            # leg everything else must be identical; against a -w 1 run of the same files (full_json: the 4 M-pair sample) all of it.
+            json_diff_w, json_diff_1 = None, None
+            oj, dj = os.path.join(tmp, "o.json"), os.path.join(tmp, "d.json")
+            if os.path.exists(oj) and os.path.exists(dj):
+                json_diff_w = [k for k in report_sections_that_differ(oj, dj) if k not in ("insert_size", "adapter_cutting")]
+                if full_json:
+                    ref1 = os.path.join(ROOT, "oracle", "_ref", "fastp_ref")
+                    subprocess.run([ref1, "-i", f1, "-I", f2, "-o", os.path.join(tmp, "s1.fq"), "-O", os.path.join(tmp, "s2.fq"), "-j",
+                                    os.path.join(tmp, "s.json"), "-h", os.path.join(tmp, "s.html"), "-w", "1"] + flags,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900)
+                    json_diff_1 = report_sections_that_differ(os.path.join(tmp, "s.json"), dj)
+                    if same is not None:
+                        same = same and md5(os.path.join(tmp, "s1.fq")) == md5(d1)
+                    for n in ("s1.fq", "s2.fq"):
+                        os.remove(os.path.join(tmp, n))
+                if same is not None:   # outputs_identical = the FASTQ files AND the report
+                    same = same and not json_diff_w and not json_diff_1
             # what a run costs whatever its size: process start, HIP runtime, engine + page-locked buffers (the first 1000 pairs only)
             t0 = time.time()
             subprocess.run(cmd + ["--reads_to_process", "1000"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300,
                            env=dict(os.environ, FASTP_GPU="1"))
             startup = time.time() - t0
             out["e2e_dropin"] = {"gpu": round(2 * sample_pairs / best / 1e6, 3), "cpu": cpu_value, "unit": "Mreads/s", "cores": cores,
-                                 "outputs_identical": same, "wall_s": round(best, 3), "startup_s": round(startup, 3),
+                                 "outputs_identical": same,
+                                 "report_sections_differing_from_w%d" % cores: json_diff_w,
+                                 "report_sections_differing_from_w1": json_diff_1,
+                                 "wall_s": round(best, 3), "startup_s": round(startup, 3),
                                  "stream_s": stream_s, "stream_setup_s": setup_s,
                                  "stream_Mreads_per_s": round(2 * sample_pairs / stream_s / 1e6, 2) if stream_s else None,
                                  "what": f"FASTP_GPU=1 fastp_ref_gpu -w {cores} (stream binding: raw chunks -> device parser / worker loop / formatter -> "
                                          f"the writers' files) vs fastp_ref -w {cores}, same files on tmpfs, whole-process wall, best of 2; startup_s = the same "
-                                         f"binary on the first 1000 pairs; stream_s = the file loop alone"}
+                                         f"binary on the first 1000 pairs; stream_s = the file loop alone; outputs_identical = out1 / out2 md5 AND the "
+                                         f"JSON report minus `command` (against fastp_ref -w {cores}: minus the two sections the reference itself makes "
+                                         f"depend on -w; against fastp_ref -w 1 where report_sections_differing_from_w1 is a list: the whole report)"}
         except Exception as e:
             out["e2e_dropin"] = {"gpu": None, "error": repr(e)[:200]}
     return out
@@ -302,7 +334,7 @@ def other_configs(dev, only=None):
     from fastp_amd import abi, engine
     res = []
 
-    def run(name, params, Lr, n, paired, steps=4, soft_masked_every=0):
+    def run(name, params, Lr, n, paired, steps=12, soft_masked_every=0):
         if only and not any(o in name for o in only.split("|")):
             return
         d = synth_torch.synth_pairs_torch(n, L=Lr, seed=5, device=dev)
@@ -340,9 +372,10 @@ def other_configs(dev, only=None):
             r.r2, r.pair = r2.data_ptr(), pr.data_ptr()
         r.n_corrections = nc.data_ptr()
         torch.cuda.synchronize()
-        eng.submit_device(b, r)
+        for _ in range(3):   # (warm-up: the first launches of an engine pay its lazy allocations and the clocks' ramp)
+            eng.submit_device(b, r)
+            eng.reset()
         eng.synchronize()
-        eng.reset()
         t0 = time.perf_counter()
         for _ in range(steps):
             eng.submit_device(b, r)
@@ -395,6 +428,26 @@ def other_configs(dev, only=None):
     p.merge = 1
     p.correction = 1
     run("PE 2x150 --merge --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True)
+    # the option families that are not on the lane plan (or were not until round 6): what they cost
+    p = abi.default_params(True, 150)
+    p.cut_front = 1
+    p.cut_tail = 1
+    run("PE 2x150 --cut_front --cut_tail (-5 -3), 4 Mi pairs", p, 150, 4 * 1024 * 1024, True, steps=6)
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.allow_gap_overlap_trimming = 1
+    run("PE 2x150 --allow_gap_overlap_trimming --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True, steps=6)
+    p = abi.default_params(True, 150)
+    p.cut_right = 1
+    p.overlapped_out = 1
+    run("PE 2x150 --overlapped_out --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True, steps=6)
+    try:
+        p = abi.default_params(True, 150)
+        p.cut_right = 1
+        abi.set_adapter_fasta(p, [b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT", b"CTGTCTCTTATACACATCT", b"TGGAATTCTCGGGTGCCAAGG"])
+        run("PE 2x150 --adapter_fasta (4 adapters) --cut_right, 4 Mi pairs", p, 150, 4 * 1024 * 1024, True, steps=6)
+    except Exception as e:   # noqa: BLE001
+        res.append({"config": "PE 2x150 --adapter_fasta", "error": repr(e)[:200]})
     # letters outside ACGTN (soft-masked reads): one pair in a thousand goes through the text kernel, the rest through the lane plan
     p = abi.default_params(True, 150)
     p.cut_right = 1
@@ -469,6 +522,13 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+
+    # Every FASTP_GPU_* variable of the environment is an A/B switch of the library: a bench line says which ones it ran
+    # with (`config.switches`), and does not run at all with the profiling build's ablation switch - its results are meaningless.
+    switches = {k: v for k, v in sorted(os.environ.items()) if k.startswith("FASTP_GPU_") or k == "GPU_MAX_HW_QUEUES"}
+    if int(os.environ.get("FASTP_GPU_DEBUG_SKIP", "0") or 0) != 0 and not os.environ.get("BENCH_ALLOW_ABLATION"):
+        raise SystemExit("bench.py: FASTP_GPU_DEBUG_SKIP is set - a kernel with steps left out is not a bench line "
+                         "(BENCH_ALLOW_ABLATION=1 for the profiling runs under profiles/, which never produce BENCH_*.json)")
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -740,6 +800,7 @@ def main():
         if compute is not None:
             out["compute_roofline"] = compute
         out["config"]["kernel_plan"] = plan
+        out["config"]["switches"] = switches   # {} = the library's defaults
         if world == 1 and not args.no_cpu:
             resident = None
             torch.cuda.empty_cache()
@@ -747,7 +808,7 @@ def main():
             files = write_sample_files(args.cpu_sample, dev) if have_ref else None
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, ref_flags, params, dev, files)
             if files is not None and not args.no_extras:
-                out.update(e2e_legs(args.cpu_sample, ref_flags, params, files, out["cpu_baseline"]["value"]))
+                out.update(e2e_legs(args.cpu_sample, ref_flags, params, files, out["cpu_baseline"]["value"], full_json=True))
             if files is not None:
                 import shutil
                 shutil.rmtree(files[0], ignore_errors=True)

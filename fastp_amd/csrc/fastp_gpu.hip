@@ -230,6 +230,7 @@ struct fastp_gpu_ctx {
     u32* d_corr_int = nullptr; size_t corr_int_cap = 0;      // -c on the lane plan: the launch's corrections (KernelArgs::corr_int) + 1 counter word
     u32* d_corr_chain = nullptr; size_t corr_chain_cap = 0;  // their per-read chains: head[reads] | next[capacity]
     int ln_prefetch = 0;   // FASTP_GPU_LANE_PREFETCH (round 6): LaneArgs::prefetch
+    int ln_grab = 1;       // FASTP_GPU_LANE_GRAB (round 6): LaneArgs::grab
     int ln_glds = 0;   // FASTP_GPU_LANE_GLDS (A/B, measured null: profiles/r05_lane_glds_ab.txt): LaneArgs::glds
     bool ln_2w = false;   // the lane kernel's EXT >= 2 instantiation compiled for two wavefronts per SIMD (FASTP_GPU_LANE_EXT_WAVES=2)
     int st_form = 4, st_kc = 4, st_max_reads = CYC_MAX_READS, st_max_grid = 0;   // FASTP_GPU_STATS_V / _KC: the Stats kernel's form (fq_stats.h)
@@ -625,6 +626,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->lane = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
         ctx->ln_glds = env_int("FASTP_GPU_LANE_GLDS", 0);
         ctx->ln_prefetch = env_int("FASTP_GPU_LANE_PREFETCH", 0);
+        ctx->ln_grab = env_int("FASTP_GPU_LANE_GRAB", 1);
         if (ctx->lane) {
             ctx->ln_swm = ctx->dp.sw_g <= 10 ? 10 : 16;
             LaneLds& l = ctx->ln_lds;
@@ -1421,6 +1423,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.chunk_ctr = ctx->d_ln_ctr;
             la.glds = ctx->ln_glds;
             la.prefetch = ctx->ln_prefetch;
+            la.grab = ctx->ln_grab;
             la.post1 = ctx->d_ctr + cl.stats[1];
             la.st_qual_hist = cl.st_qual_hist; la.st_kmer = cl.st_kmer; la.st_cycle = cl.st_cycle; la.cycles = cl.cycles;
             if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));

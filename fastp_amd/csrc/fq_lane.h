@@ -62,6 +62,7 @@ struct LaneArgs {
     int* chunk_ctr; // zero at launch: chunks beyond every wave's first are handed out by this counter (a static stride
                     // leaves a third of the waves one chunk short at 21.3 chunks per wave); nullptr = static stride
     int glds;       // read 2's quality rows come into the stage by global_load_lds while read 1 is hashed (FASTP_GPU_LANE_GLDS, A/B)
+    int grab;       // FASTP_GPU_LANE_GRAB (round 6): chunks a wavefront takes from the counter at a time
     int prefetch;   // FASTP_GPU_LANE_PREFETCH (round 6), bit mask: 1 = read 2's rows of the chunk are pulled into L2 while read 1 is
                     // staged and swept, 2 = read 1's rows of the wavefront's NEXT chunk while read 2 is - one dword per 128-byte line
                     // by global_load_lds into a sink (no register, no wait): the four row stagings of a chunk then find their lines
@@ -1432,10 +1433,18 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const int chunks = (a.n + 63) >> 6;
     const int wpb = nt >> 6;
     const int nstatic = grid_blocks() * wpb;
-    int nx = 0;
-    for (int chunk = block_id() * wpb + (tid >> 6); chunk < chunks;
-         chunk = la.chunk_ctr ? nstatic + (int)shfl((u32)nx, 0) : chunk + nstatic) {   // wave-uniform
-        if (la.chunk_ctr && lane == 0) nx = g_atomic_add_i32(la.chunk_ctr, 1);   // the next chunk's number, looked at in the loop header
+    // Chunks beyond a wavefront's first come from the counter, `grab` at a time while the end of the launch is far (one returning atomic
+    // per chunk is 62 500 of them on ONE word per 4 Mi pairs: a word takes ~88 per microsecond - MI355X_MICROARCH.md, "dequeue" - which
+    // bounds the kernel at 0.7 ms whatever else it does), one at a time over the last chunks so that the wavefronts still end together
+    int nx = 0, gsz = 1;
+    const int grab = la.chunk_ctr ? imax(1, la.grab) : 1;
+    int chunk_end = block_id() * wpb + (tid >> 6) + 1;          // (the range in hand: [chunk, chunk_end))
+    for (int chunk = chunk_end - 1; chunk < chunks;) {         // wave-uniform
+        const bool last_in_hand = chunk + 1 == chunk_end;
+        if (la.chunk_ctr && last_in_hand) {
+            gsz = (chunk + 4 * grab * nstatic < chunks) ? grab : 1;   // (uniform)
+            if (lane == 0) nx = g_atomic_add_i32(la.chunk_ctr, gsz);   // the next range's first chunk, looked at at the loop's end
+        }
         const int gp = chunk * 64 + lane;
         const bool valid = gp < a.n;
         const int rows = imin(64, a.n - chunk * 64);
@@ -1468,7 +1477,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
         } else if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
         if ((la.prefetch & 2) && la.chunk_ctr) {   // (uniform) the next chunk's read 1 (its number came back long ago)
-            const int nxc = nstatic + (int)uniform((u32)nx);
+            const int nxc = last_in_hand ? nstatic + (int)uniform((u32)nx) : chunk + 1;
             if (nxc < chunks) {
                 const int nrows = imin(64, a.n - nxc * 64);
                 const int step = 128 >> ((la.prefetch >> 2) & 3);
@@ -1834,6 +1843,10 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                 if (claim) a.claim_won[g] = (u8)won;
             }
         }
+        // the next chunk: the range in hand, then the counter's (or the static stride's) next range
+        if (!last_in_hand) chunk++;
+        else if (la.chunk_ctr) { chunk = nstatic + (int)shfl((u32)nx, 0); chunk_end = chunk + gsz; }
+        else { chunk += nstatic; chunk_end = chunk + 1; }
     }
     block_sync();
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
