@@ -626,7 +626,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         ctx->lane = env_int("FASTP_GPU_LANE", 1) != 0 && lane_plan_supported(ctx->dp, ctx->luts);
         ctx->ln_glds = env_int("FASTP_GPU_LANE_GLDS", 0);
         ctx->ln_prefetch = env_int("FASTP_GPU_LANE_PREFETCH", 0);
-        ctx->ln_grab = env_int("FASTP_GPU_LANE_GRAB", 1);
+        ctx->ln_grab = env_int("FASTP_GPU_LANE_GRAB", 4);   // (1.400 -> 1.350 ms per 4 Mi pairs, profiles/r06_d_lane_grab_prefetch_ab.txt)
         if (ctx->lane) {
             ctx->ln_swm = ctx->dp.sw_g <= 10 ? 10 : 16;
             LaneLds& l = ctx->ln_lds;
@@ -1220,7 +1220,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     // --dedup, Duplicate's tail decides, fq_dedup_apply_kernel takes the duplicates out again before the Stats kernel counts
     // (not in merge mode: a pair that merges is written out whatever Duplicate says, peprocessor.cpp:523-535)
     const bool dedup_folded = ctx->dp.dedup && use_lane && mode == CHUNK_STREAM && !piped && !exact && !env_int("FASTP_GPU_DUP_TABLE", 0) &&
-                              !ctx->dp.merge_lane && env_int("FASTP_GPU_DEDUP_FOLD", 1);
+                              !ctx->dp.merge_lane && env_int("FASTP_GPU_DEDUP_FOLD", 1) &&
+                              env_int("FASTP_GPU_CLAIM_FUSED", 1);   // (the fold IS the fused claim: without it the hash pre-pass decides)
     // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers (the lane kernel: four as well), the
     // context's own stream order
     const bool claim_fused = ctx->dp.dup_enabled && (!ctx->dp.dedup || dedup_folded) && mode == CHUNK_STREAM && !piped &&

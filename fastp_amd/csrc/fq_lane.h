@@ -1608,7 +1608,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                     }
                 }
                 // ---- BaseCorrector::correctByOverlapAnalysis (peprocessor.cpp:453-456; no gap on this plan) ----
-                if (CR && p.need_overlap)
+                if (CR && p.need_overlap && !(skip & 32u))   // (32: profiling build only - the correction rounds left out)
                     lane_correct<SWM>(a, misc, r1, r2, rc, rcn, both, key, l1, l2, fr1, fr2, (const u8*)(a.qual[0] + (size_t)g * p.qw_g),
                                       (u8*)(stage + lane * p.qw_g), clist, lane, g, geom, r2min);
             }
@@ -1676,7 +1676,8 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
             r1.len = cur1;
             r2.len = cur2;
-            if (MG && ballot(both) != 0ull) {   // peprocessor.cpp:518-527: the analysis of the reads as they are now decides about merging
+            if (MG && !(skip & 64u) && ballot(both) != 0ull) {   // peprocessor.cpp:518-527: the analysis of the reads as they are now decides about merging
+                                                                  // (64: profiling build only - the second analysis left out)
                 const u32 key2 = lane_overlap_again<SWM>(p, r1, r2, cur1, cur2, both, lut_ov);
                 if (both) {
                     decode_overlap(key2, cur1, cur2, ovl, ov_off, ov_len, ov_diff);

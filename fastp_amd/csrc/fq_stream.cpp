@@ -1068,6 +1068,10 @@ void writer_main(Run* R) {
         WriteJob j = R->q_write.get();
         if (j.oslot < 0) return;
         if (j.copy_pending && j.oslot < 2 && hipEventSynchronize(s->ev_out[j.oslot]) != hipSuccess) R->io_err.store(4);
+        if (R->io_err.load()) {   // the chunk's bytes may not have landed (or an earlier write failed): nothing of it - and of the
+            if (j.oslot < 2) R->q_ofree.put(j.oslot);   // chunks behind it - goes to the files; the slot still returns so that the loop ends
+            continue;
+        }
         const double t0 = now_s();
         if (j.has_ov && !R->emit_err.load()) {   // --overlapped_out's records of the chunk, assembled on the host
             if (s->cfg.emit(s->cfg.user, FASTP_GPU_OVERLAPPED, j.ov.data(), (int64_t)j.ov.size()) != 0) R->emit_err.store(1);

@@ -71,6 +71,26 @@ def test_sim_duplicates_when_workgroups_run_out_of_order(name, table, monkeypatc
     assert np.array_equal(co, cg)
 
 
+@pytest.mark.parametrize("switch", ["FASTP_GPU_CLAIM_FUSED", "FASTP_GPU_DEDUP_FOLD"])
+def test_sim_dedup_without_the_fused_claim(switch, monkeypatch):
+    """--dedup on the lane plan with the claim step taken out of the lane kernel (the A/B switches of DESIGN.md 5): the hash
+    pre-pass has to decide then - with FASTP_GPU_CLAIM_FUSED=0 alone Duplicate used not to run at all (round 5's advisor finding)"""
+    monkeypatch.setenv(switch, "0")
+    paired, flags, pf, skw = cases.CASES["pe_noadapter_dedup"]
+    d = synth.synth_pairs(1500, L=150, seed=41, paired=paired, **skw)
+    rng = np.random.default_rng(42)
+    dst = rng.choice(np.arange(1, 1500), size=500, replace=False)
+    src = (rng.random(500) * dst).astype(np.int64)
+    for k in d:
+        d[k][dst] = d[k][src]
+    params = cases.finalize_params("pe_noadapter_dedup", pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    ro, rg, co, cg = _both(params, d, paired)
+    assert int((ro[0]["flags"] & abi.RF_DUP != 0).sum()) > 100
+    for k in range(3):
+        assert np.array_equal(ro[k], rg[k]), f"records {k} differ"
+    assert np.array_equal(co, cg)
+
+
 @pytest.mark.parametrize("level,L,paired", [(1, 150, True), (3, 150, True), (1, 37, True), (1, 250, True), (1, 150, False), (-3, 100, True)])
 def test_sim_duplicate_hash_bit_positions_equal_oracle(level, L, paired, monkeypatch):
     """the hash itself (Duplicate::seq2intvector mod mBufLenInBits), not only the decisions it leads to: every
