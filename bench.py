@@ -371,6 +371,10 @@ def other_configs(dev, only=None):
         if paired:
             r.r2, r.pair = r2.data_ptr(), pr.data_ptr()
         r.n_corrections = nc.data_ptr()
+        if params.n_adapter_fasta:   # --adapter_fasta: the trims' event list (the host replays FilterResult's adapter map from it)
+            ev = torch.zeros(4 * n * 12, dtype=torch.uint8, device=dev)
+            nev = torch.zeros(1, dtype=torch.int32, device=dev)
+            r.adapter_events, r.adapter_events_capacity, r.n_adapter_events = ev.data_ptr(), 4 * n, nev.data_ptr()
         torch.cuda.synchronize()
         for _ in range(3):   # (warm-up: the first launches of an engine pay its lazy allocations and the clocks' ramp)
             eng.submit_device(b, r)

@@ -89,6 +89,34 @@ extern "C" __global__ void __launch_bounds__(1024) fq_stats5_kernel(StatsArgs a)
     else if (a.kc == 2) stats_body5<2, 0, false>(a, fq_lds);
     else stats_body5<1, 0, false>(a, fq_lds);
 }
+// Do two streams run BESIDE each other?  HIP hands a stream one of a few hardware queues when it is created; two streams of one
+// engine can land on the same queue (other engines, torch's and the caller's streams hold the others) and then run one behind the
+// other whatever the events between them say - the kernels the engine puts beside the lane / Stats kernels on its second stream (the
+// text kernel, Duplicate's tail, the overrepresentation analysis) lost exactly that inside a process that held a second engine
+// (profiles/r06_e_*: one soft-masked pair in 1000, 4.48 ms alone, 6.43 ms inside bench.py).  The probe: one kernel on the first
+// stream waits (bounded) for a word that a kernel on the second stream sets.
+extern "C" __global__ void __launch_bounds__(64) fq_probe_wait_kernel(int* flag, long long budget_cycles) {
+#ifndef FQ_HOSTSIM
+    if (threadIdx.x == 0) {
+        const long long t0 = clock64();
+        int seen = 0;
+        while (clock64() - t0 < budget_cycles) {
+            if (__hip_atomic_load(&flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { seen = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        flag[1] = seen;
+    }
+#else
+    (void)flag; (void)budget_cycles;
+#endif
+}
+extern "C" __global__ void __launch_bounds__(64) fq_probe_set_kernel(int* flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(&flag[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" __global__ void __launch_bounds__(256) fq_front_stats_kernel(FrontStatsArgs c) {
+    extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
+    front_stats_body(c, fq_lds);
+}
 extern "C" __global__ void __launch_bounds__(1024) fq_hash_kernel(KernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
     hash_body(*kernel_args(&a), fq_lds);
@@ -410,7 +438,21 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // the option family the lane kernel covers: nothing moves or edits a kept base (split plan), no step that needs an
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
+// form 5 of the Stats kernel (fq_stats5.h): the copies of the 5-mer table its LDS layout has room for (0: it does not fit)
+static int stats5_copies(const DevParams& p, int lds_bytes) {
+    if (env_int("FASTP_GPU_STATS_V", 5) < 5 || p.merge_lane) return 0;
+    const int H16 = (p.qw_g + 3) / 4, Cp = (p.cycles + 3) & ~3;
+    if (H16 > p.sw_g || H16 > 64) return 0;
+    for (int kc = 2; kc >= 1; kc--) {
+        int o = 2 * 8 * 4 * ST5_QN * H16 + 2 * KMER_BINS * kc;
+        o = (o + 1) & ~1;
+        o += 2 * Cp * N_CLS * 2 + 2 * 128 + (1024 / 64) * 2 * ST5_WL / 2;
+        if (o * 4 <= lds_bytes) return kc;
+    }
+    return 0;
+}
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
+    if (p.front_per_read && !stats5_copies(p, 160 * 1024)) return false;   // a front per read: form 5 of the Stats kernel only
     if (!(p.stats_one_pass || p.front_lane || p.corr_lane || p.merge_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
     if (p.merge && !p.merge_lane) return false;
     if ((p.has_a1 && p.alen1 > 64) || (p.has_a2 && p.alen2 > 64)) return false;   // the lane kernel keeps an adapter in four uniform words
@@ -666,6 +708,8 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             l.clist = o;
             o += waves * l.clist_dwords;
             o = (o + 3) & ~3;
+            l.ctr = o;           // the workgroup's chunk counter (LaneArgs::local_ctr)
+            o += 4;
             l.sink = o;          // where the row prefetches land (LaneArgs::prefetch): 64 lanes x 4 bytes, every wavefront's
             o += 64;
             l.total = o;
@@ -773,6 +817,9 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     if (ctx->split) {
         CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
+        if (ctx->dp.front_per_read)
+            CREATE_TRY(hipFuncSetAttribute((const void*)fq_front_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((ctx->dp.paired ? 2 : 1) * 34 * (size_t)ctx->cl.cycles * 4)));
         if (ctx->dp.corr_lane)
             CREATE_TRY(hipFuncSetAttribute((const void*)fq_corr_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)((ctx->dp.paired ? 2 : 1) * (33 * (size_t)ctx->cl.cycles + 128 + KMER_BINS) * 4)));
@@ -782,7 +829,38 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         if (ctx->st_form == 5) CREATE_TRY(hipFuncSetAttribute((const void*)fq_stats5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->st_lds_dwords * 4));
         CREATE_TRY(hipMalloc((void**)&ctx->d_st_slabs, (size_t)ctx->st_max_grid * ctx->st_slab_dwords * 4));
         if (env_int("FASTP_GPU_DUP_OVERLAP", 1)) {
+#ifdef FQ_HOSTSIM
             CREATE_TRY(hipStreamCreateWithFlags(&ctx->tail, hipStreamNonBlocking));
+#else
+            // a second stream that really runs beside the first (fq_probe_wait_kernel): up to six candidates, the ones that share the
+            // first stream's queue are held until the search ends (the next one is then given another queue) and closed afterwards
+            int* d_flag = nullptr;
+            CREATE_TRY(hipMalloc((void**)&d_flag, 2 * sizeof(int)));
+            std::vector<hipStream_t> rejected;
+            const int tries = env_int("FASTP_GPU_TAIL_TRIES", 6);
+            for (int t = 0; t < std::max(1, tries) && !ctx->tail; t++) {
+                hipStream_t cand = nullptr;
+                CREATE_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+                bool beside = tries <= 1;
+                if (!beside) {
+                    CREATE_TRY(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), ctx->stream));
+                    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+                    hipLaunchKernelGGL(fq_probe_wait_kernel, dim3(1), dim3(64), 0, ctx->stream, d_flag, 2000000ll);
+                    hipLaunchKernelGGL(fq_probe_set_kernel, dim3(1), dim3(64), 0, cand, d_flag);
+                    CREATE_TRY(hipStreamSynchronize(cand));
+                    CREATE_TRY(hipStreamSynchronize(ctx->stream));
+                    int h[2] = {0, 0};
+                    CREATE_TRY(hipMemcpy(h, d_flag, sizeof(h), hipMemcpyDeviceToHost));
+                    beside = h[1] != 0;
+                }
+                if (beside) ctx->tail = cand;
+                else rejected.push_back(cand);
+            }
+            if (!ctx->tail) { ctx->tail = rejected.back(); rejected.pop_back(); }   // (none runs beside it: correct, one behind the other)
+            if (env_int("FASTP_GPU_VERBOSE", 0)) fprintf(stderr, "fastp_gpu: second stream: candidate %d of %d runs beside the first\n", (int)rejected.size() + 1, tries);
+            for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+            (void)hipFree(d_flag);
+#endif
             CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
         }
@@ -1425,9 +1503,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.glds = ctx->ln_glds;
             la.prefetch = ctx->ln_prefetch;
             la.grab = ctx->ln_grab;
+            la.local_ctr = env_int("FASTP_GPU_LANE_DYNAMIC", 2) == 2 ? 1 : 0;
             la.post1 = ctx->d_ctr + cl.stats[1];
             la.st_qual_hist = cl.st_qual_hist; la.st_kmer = cl.st_kmer; la.st_cycle = cl.st_cycle; la.cycles = cl.cycles;
-            if (la.chunk_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
+            if (la.chunk_ctr && !la.local_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
             const int Bh = (ctx->dp.dup_enabled && (a.dup_pos || a.claim_won) && !(a.debug_skip & 2u)) ? ctx->dp.dup_bufnum : 0;
             lane_kernel_fn fn = lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp), ctx->ln_2w);
             ln_grid = std::max(1, std::min(ctx->ln_blocks, (n + 255) / 256));
@@ -1539,6 +1618,9 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
         sa.l_total = ctx->st_lds_dwords;
         sa.H16 = ctx->st_H16; sa.magic_H16 = ctx->st_H16 ? magic_for((u32)ctx->st_H16) : 0u; sa.l_ovf = ctx->st_l_ovf;
+        sa.front_per_read = ctx->dp.front_per_read;
+        sa.fr_stride = ctx->dp.front_per_read ? 3 : 0;
+        for (int m = 0; m < 2; m++) sa.fr_rec[m] = ctx->dp.front_per_read ? (const u32*)a.res[m] : ctx->d_swin[m];
         sa.slabs = ctx->d_st_slabs;
         sa.slab_dwords = ctx->st_slab_dwords;
         sa.debug_skip = a.debug_skip;
@@ -1549,6 +1631,31 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         } else {
             st_grid = 0;
         }
+    }
+    if (ctx->dp.front_per_read && ctx->lane && ctx->split && n > 0 && st_grid > 0) {
+        // --cut_front on the lane plan: the reads whose own front is beyond the mate's common one (fq_stats5.h, front_stats_body)
+        FrontStatsArgs fs;
+        memset(&fs, 0, sizeof(fs));
+        fs.n = n;
+        fs.paired = ctx->dp.paired;
+        fs.sw_g = ctx->dp.sw_g;
+        fs.qw_g = ctx->dp.qw_g;
+        for (int m = 0; m < 2; m++) {
+            fs.seq[m] = a.seq[m];
+            fs.qual[m] = a.qual[m];
+            fs.swin[m] = ctx->d_swin[m];
+            fs.rec[m] = (const u32*)a.res[m];
+            fs.post[m] = ctx->d_ctr + ctx->cl.stats[2 * m + 1];
+        }
+        fs.front0[0] = ctx->dp.lane_front1;
+        fs.front0[1] = ctx->dp.lane_front2;
+        fs.st_cycle = ctx->cl.st_cycle;
+        fs.cycles = ctx->cl.cycles;
+        const size_t reads = (size_t)n * (ctx->dp.paired ? 2 : 1);
+        const size_t lds_bytes = (size_t)(ctx->dp.paired ? 2 : 1) * 34 * (size_t)ctx->cl.cycles * 4;
+        const int fgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ctx->cus * 4, (reads + 255) / 256));
+        hipLaunchKernelGGL(fq_front_stats_kernel, dim3(fgrid), dim3(256), lds_bytes, st, fs);
+        HIP_TRY(ctx, hipGetLastError());
     }
     if (corr_lane && ctx->split && n > 0 && st_grid > 0) {
         // -c: the corrected positions' share of the POST Stats moves from the original base / quality to the corrected one

@@ -159,7 +159,12 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
     // min(length() - 1, umi + skip) (read.cpp:69-73) - a read too short for its UMI is left with one base, which no run with a
     // length filter of two or more writes out.  --cut_front moves every read by its own amount: the tile kernels.
     const bool any_umi = p.umi_len1 > 0 || p.umi_len2 > 0;
-    p.front_lane = !p.stats_one_pass && !p.correction && !p.merge && !p.cut_front && (!any_umi || (p.length_filter && p.length_required >= 2));
+    // --cut_front (round 6): a front of its own per read - on the lane plan when its window predicate is the one the kernel builds
+    // anyway (the enabled right / tail cut's window and quality, or its own when it is the only cut), without -c / --merge
+    const bool cutf_same = p.cut_front && (p.cut_right ? (p.wF == p.wR && p.thrF == p.thrR) : p.cut_tail ? (p.wF == p.wT && p.thrF == p.thrT) : true) &&
+                           p.wF >= 1 && p.wF <= 8;
+    p.front_per_read = (cutf_same && !p.correction && !p.merge && (!any_umi || (p.length_filter && p.length_required >= 2))) ? 1 : 0;
+    p.front_lane = !p.stats_one_pass && !p.correction && !p.merge && (!p.cut_front || p.front_per_read) && (!any_umi || (p.length_filter && p.length_required >= 2));
     // -c on the lane plan: same condition on the fronts
     // --merge on the lane plan: nothing in front of a read at all (merge mode switches -c on, options.cpp:119-121)
     p.merge_lane = p.merge && p.paired && !p.cut_front && !any_umi && !p.trim_front1 && !p.trim_front2;

@@ -50,6 +50,7 @@ struct LaneLds {
     int part_dwords;    // conflict-free; registers do not hold them - ten more live VGPRs spilled 270 dwords at the cap of 168)
     int clist;      // -c on the lane plan, per wavefront: the positions of read 1 that BaseCorrector edited, one bit per base,
     int clist_dwords;   // [SWM / 2 words][lane]: read 1's rows are gone when countQualityMetrics runs (lane_apply_corrected)
+    int ctr;        // the workgroup's own chunk counter (LaneArgs::local_ctr)
     int sink;       // 64 dwords every wavefront's row prefetches are written to (never read): global_load_lds needs a destination
     int jkmer;      // --merge on the lane plan (DevParams::merge_lane): [KMER_BINS] behind the MISC_* counters (inside n_misc, so in the
                     // slab) - the merged reads' 5-mers that straddle the junction of the two parts (fastp's index: earliest base high)
@@ -62,6 +63,10 @@ struct LaneArgs {
     int* chunk_ctr; // zero at launch: chunks beyond every wave's first are handed out by this counter (a static stride
                     // leaves a third of the waves one chunk short at 21.3 chunks per wave); nullptr = static stride
     int glds;       // read 2's quality rows come into the stage by global_load_lds while read 1 is hashed (FASTP_GPU_LANE_GLDS, A/B)
+    int local_ctr;  // round 6, the default (FASTP_GPU_LANE_DYNAMIC=2): a workgroup owns a contiguous share of the launch's chunks and
+                    // hands them to its wavefronts from a counter in ITS LDS - the balance of a shared counter inside a CU, none of
+                    // its traffic: the kernel's loads-only skeleton takes 0.58 ms with a static stride, 0.92 with one returning
+                    // global atomic per chunk on one word, 0.78 with one per four chunks (profiles/r06_e_*)
     int grab;       // FASTP_GPU_LANE_GRAB (round 6): chunks a wavefront takes from the counter at a time
     int prefetch;   // FASTP_GPU_LANE_PREFETCH (round 6), bit mask: 1 = read 2's rows of the chunk are pulled into L2 while read 1 is
                     // staged and swept, 2 = read 1's rows of the wavefront's NEXT chunk while read 2 is - one dword per 128-byte line
@@ -449,16 +454,26 @@ template <int SWM>
 FQ_DEV bool lane_trim_and_cut_front(const KernelArgs& a, const LaneRead<SWM>& r, const u8* qrow, int u, int l, int front, int tail, int& out_front,
                                     int& out_len) {
     const DevParams& p = a.p;
-    const bool enT = p.cut_tail, enR = p.cut_right;
+    const bool enT = p.cut_tail, enR = p.cut_right, enF = p.front_per_read != 0;   // (--cut_front reaches this kernel only as front_per_read)
     out_front = 0;
     out_len = l;
-    if (front == 0 && tail == 0 && !enT && !enR) return true;   // :71-72
+    if (front == 0 && tail == 0 && !enT && !enR && !enF) return true;   // :71-72
     int rlen = l - front - tail;
     if (rlen < 0) return false;                                 // :76-77
-    if (!enT && !enR) {                                         // :79-89
+    if (!enT && !enR && !enF) {                                 // :79-89
         out_front = front;
         out_len = rlen;
         return true;
+    }
+    if (enF) {                                                  // :97-127 quality cutting forward, on the same window predicate
+        const int w = p.wF;
+        if (l - front - tail - w <= 0) return false;
+        const int end = l - tail - w;
+        int s = mask_first<SWM / 2>(r.bad, u + front, u + end, false) - u;   // first window AT the threshold (none: s = end, the loop's exit)
+        if (s > 0) s = s + w - 1;                               // "the trimming in front is forwarded"
+        while (s < l && ((u32)qrow[u + s] & 0x80u)) s++;        // while (s < l && seq[s] == 'N') s++
+        front = s;
+        rlen = l - front - tail;
     }
     if (enR) {                                                  // :130-163
         const int w = p.wR;
@@ -1392,6 +1407,7 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
     {   // one-time per workgroup
         for (int i = tid; i < ll.n_misc; i += nt) lds[ll.misc + i] = 0;
+        if (tid == 0) lds[ll.ctr] = 0;
         const int lw = (p.cycles + 2) / 2;
         const u32* g0 = (const u32*)a.lut.ov_limit;
         const u32* g1 = (const u32*)a.lut.lowq_limit;
@@ -1427,8 +1443,8 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
 #else
     const u32 skip = a.debug_skip & 512u;   // (512: a test switch that leaves the results as they are, see `slow` below)
 #endif
-    const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : 0));
-    const int thr = p.cut_right ? p.thrR : p.thrT;
+    const int win = (skip & 1u) ? 0 : (p.cut_right ? p.wR : (p.cut_tail ? p.wT : (p.front_per_read ? p.wF : 0)));
+    const int thr = p.cut_right ? p.thrR : (p.cut_tail ? p.thrT : p.thrF);
     const u32 thr4 = (u32)p.qual_thr * 0x01010101u;
     const int chunks = (a.n + 63) >> 6;
     const int wpb = nt >> 6;
@@ -1437,11 +1453,18 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     // per chunk is 62 500 of them on ONE word per 4 Mi pairs: a word takes ~88 per microsecond - MI355X_MICROARCH.md, "dequeue" - which
     // bounds the kernel at 0.7 ms whatever else it does), one at a time over the last chunks so that the wavefronts still end together
     int nx = 0, gsz = 1;
-    const int grab = la.chunk_ctr ? imax(1, la.grab) : 1;
-    int chunk_end = block_id() * wpb + (tid >> 6) + 1;          // (the range in hand: [chunk, chunk_end))
-    for (int chunk = chunk_end - 1; chunk < chunks;) {         // wave-uniform
+    const bool LC = la.local_ctr != 0;                          // (uniform)
+    const int grab = (la.chunk_ctr && !LC) ? imax(1, la.grab) : 1;
+    // the workgroup's share of the chunks (local_ctr): the first (chunks % workgroups) workgroups take one more
+    const int sq = chunks / grid_blocks(), sr = chunks - sq * grid_blocks();
+    const int share_lo = LC ? block_id() * sq + imin(block_id(), sr) : 0;
+    const int share_hi = LC ? share_lo + sq + (block_id() < sr ? 1 : 0) : chunks;
+    int chunk_end = (LC ? share_lo + (tid >> 6) : block_id() * wpb + (tid >> 6)) + 1;   // (the range in hand: [chunk, chunk_end))
+    for (int chunk = chunk_end - 1; chunk < share_hi;) {       // wave-uniform
         const bool last_in_hand = chunk + 1 == chunk_end;
-        if (la.chunk_ctr && last_in_hand) {
+        if (LC) {
+            if (lane == 0) nx = (int)lds_add_ret_u32(&lds[ll.ctr], 1u);   // the workgroup's next chunk, looked at at the loop's end
+        } else if (la.chunk_ctr && last_in_hand) {
             gsz = (chunk + 4 * grab * nstatic < chunks) ? grab : 1;   // (uniform)
             if (lane == 0) nx = g_atomic_add_i32(la.chunk_ctr, gsz);   // the next range's first chunk, looked at at the loop's end
         }
@@ -1476,9 +1499,9 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             if (valid) lane_front_trim<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.umi_len1, p.trim_front1, p.trim_tail1, fr1, ft1);
         } else if (valid && !lane_trim_and_cut<SWM>(a, r1, (const u8*)(stage + lane * p.qw_g), p.trim_tail1, r1.len)) r1.flags |= RS_NULL;
         sched_fence();
-        if ((la.prefetch & 2) && la.chunk_ctr) {   // (uniform) the next chunk's read 1 (its number came back long ago)
-            const int nxc = last_in_hand ? nstatic + (int)uniform((u32)nx) : chunk + 1;
-            if (nxc < chunks) {
+        if ((la.prefetch & 2) && (la.chunk_ctr || LC)) {   // (uniform) the next chunk's read 1 (its number came back long ago)
+            const int nxc = LC ? share_lo + wpb + (int)uniform((u32)nx) : last_in_hand ? nstatic + (int)uniform((u32)nx) : chunk + 1;
+            if (nxc < share_hi) {
                 const int nrows = imin(64, a.n - nxc * 64);
                 const int step = 128 >> ((la.prefetch >> 2) & 3);
                 lane_prefetch_lines(lds + ll.sink, a.seq[0] + (size_t)(nxc * 64) * p.sw_g, nrows * p.sw_g * 4, lane, step);
@@ -1845,7 +1868,8 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
         }
         // the next chunk: the range in hand, then the counter's (or the static stride's) next range
-        if (!last_in_hand) chunk++;
+        if (LC) { chunk = share_lo + wpb + (int)shfl((u32)nx, 0); chunk_end = chunk + 1; }
+        else if (!last_in_hand) chunk++;
         else if (la.chunk_ctr) { chunk = nstatic + (int)shfl((u32)nx, 0); chunk_end = chunk + gsz; }
         else { chunk += nstatic; chunk_end = chunk + 1; }
     }

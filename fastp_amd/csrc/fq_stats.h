@@ -56,6 +56,9 @@ struct StatsArgs {
     int H16;                // form 5 (fq_stats5.h): 16-base items per row = ceil(qw_g / 4), Hs = the item columns of its table
     u32 magic_H16;          // ceil(2^32 / H16)
     int l_ovf;              // form 5: [2][Cp][N_CLS] u64 packed cells of the bases its joint table has no cell for (N, qualities above 'K')
+    const u32* fr_rec[2];   // form 5: where a read's own front is read from - its result record (stride fr_stride = 3 dwords, low 16 bits)
+    int fr_stride;          // with DevParams::front_per_read (--cut_front), else the mate's swin array with stride 0 (a load nobody uses)
+    int front_per_read;
     int front[2];           // form 4, DevParams::front_lane: the kept bases of a read of mate m are [front[m], swin >> 16) - the same
                             // front for every read that is written out; they are counted at their ORIGINAL cycle (the slab fold
                             // moves the POST Stats, reduce_body); the 5-mers that end on the first four kept bases exist in the

@@ -45,6 +45,7 @@ FQ_DEV int lane_rank(u64 mask) {   // set bits of `mask` below this lane
 struct Stats5Item {
     u32 q[4], qp, codes, prev8;
     int rl0, lk;
+    int F;          // the start of the kept range: the mate's front, or the read's own (DevParams::front_per_read)
 };
 
 // LDS addresses (bytes) of the joint table
@@ -63,9 +64,20 @@ struct Stats5Geo {
 // memory system's latency, 1.7 TB/s - profiles/r06_b_stats5_lane_mapping_ab_and_sq_counters.txt: 54 % of the wave cycles waiting).
 struct Stats5Raw {
     u64 q01, q23;
-    u32 sw, qp, cd, p8;
+    u32 sw, qp, cd, p8, fr;
 };
-FQ_DEV void stats5_issue(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 u, u32 h, Stats5Raw& r) {
+struct Stats5Src {   // one mate's arrays at the workgroup's first unit
+    const u32* qual;
+    const u32* seq;
+    const u32* swin;
+    const u32* frec;   // StatsArgs::fr_rec
+    int F0;            // StatsArgs::front of the mate
+};
+FQ_DEV void stats5_issue(const StatsArgs& a, const Stats5Src& src, u32 u, u32 h, Stats5Raw& r) {
+    const u32* qual = src.qual;
+    const u32* seq = src.seq;
+    const u32* swin = src.swin;
+    r.fr = src.frec[mul24(u, (u32)a.fr_stride)];
     const bool has23 = 4u * h + 4u <= (u32)a.qw_g;    // (the last item of a row may be half a vector)
     const u32 qd = mul24(u, (u32)a.qw_g) + 4u * h;      // dword of the row's quality bytes (rows are 8-byte aligned)
     const u32 sd = mul24(u, (u32)a.sw_g) + h;
@@ -76,7 +88,8 @@ FQ_DEV void stats5_issue(const StatsArgs& a, const u32* qual, const u32* seq, co
     r.cd = seq[sd];
     r.p8 = (u32)((const u8*)seq)[4u * sd - (h > 0 ? 1u : 0u)];
 }
-FQ_DEV void stats5_finish(const StatsArgs& a, u32 h, const Stats5Raw& r, Stats5Item& s) {
+FQ_DEV void stats5_finish(const StatsArgs& a, const Stats5Src& src, u32 h, const Stats5Raw& r, Stats5Item& s) {
+    s.F = a.front_per_read ? (int)(r.fr & 0xFFFFu) : src.F0;
     const bool has23 = 4u * h + 4u <= (u32)a.qw_g;
     const u32 m23 = has23 ? 0xFFFFFFFFu : 0u, mh = h > 0 ? 0xFFFFFFFFu : 0u;
     s.q[0] = (u32)r.q01;
@@ -89,10 +102,10 @@ FQ_DEV void stats5_finish(const StatsArgs& a, u32 h, const Stats5Raw& r, Stats5I
     s.rl0 = (int)(r.sw & 0xFFFFu);
     s.lk = (int)(r.sw >> 16);
 }
-FQ_DEV void stats5_fetch(const StatsArgs& a, const u32* qual, const u32* seq, const u32* swin, u32 u, u32 h, Stats5Item& s) {
+FQ_DEV void stats5_fetch(const StatsArgs& a, const Stats5Src& src, u32 u, u32 h, Stats5Item& s) {
     Stats5Raw r;
-    stats5_issue(a, qual, seq, swin, u, h, r);
-    stats5_finish(a, h, r, s);
+    stats5_issue(a, src, u, h, r);
+    stats5_finish(a, src, h, r, s);
 }
 
 // The cells of one item whose bases [0, nv) are clean (no N among them or the four in front, qualities the table has rows for)
@@ -122,7 +135,8 @@ FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb,
 
 // one item, base by base: any state (an N, a quality the table has no row for, a kept range that ends inside the item)
 template <int KC>
-FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, int F, const Stats5Item& s, int h, int lane) {
+FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, const Stats5Item& s, int h, int lane) {
+    const int F = s.F;
     u8* ldsw = (u8*)lds;
     const u32 nbp = (s.qp >> 7) & 0x01010101u;
     u32 n20 = (nbp | (nbp >> 7) | (nbp >> 14) | (nbp >> 21)) & 0xFu;   // bit i = base j0 - 4 + i is an N
@@ -190,11 +204,12 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
         for (int i = tid; i < a.l_wl; i += nt) lds[i] = 0;       // [cyc | kmer | ovf | qh] sit in front of the lists
         block_sync();
         if (m < nm) {
-            const u32* qual = a.qual[m] + (size_t)u0 * a.qw_g;
-            const u32* seq = a.seq[m] + (size_t)u0 * a.sw_g;
-            const u32* swin = a.swin[m] + u0;
-            const int F = a.front[m];                             // (uniform; 0 unless DevParams::front_lane)
-            const int Fk = F > 0 ? F + 4 : 0;
+            Stats5Src src;
+            src.qual = a.qual[m] + (size_t)u0 * a.qw_g;
+            src.seq = a.seq[m] + (size_t)u0 * a.sw_g;
+            src.swin = a.swin[m] + u0;
+            src.frec = a.fr_rec[m] + (size_t)u0 * a.fr_stride;
+            src.F0 = a.front[m];                                  // (uniform; 0 unless DevParams::front_lane)
             const u32 lds0 = lds_addr_of(lds);                    // (DS addresses, not generic pointers: no aperture add per access)
             const u32 cyc_b = lds0 + (u32)a.l_cyc * 4u - (u32)(33 + ST5_QADD) * g.HS4;   // the row of byte value q + ST5_QADD is q - 33
             const u32 kmer_b = lds0 + (u32)a.l_kmer * 4u + (u32)(lane & (KC - 1)) * 4u;
@@ -206,7 +221,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
 #pragma unroll
             for (int d = 0; d < FQ_ST5_DEPTH; d++) {
                 const u32 ud = (u32)((tid >> 6) * upw + d * ustride) + lu;
-                stats5_issue(a, qual, seq, swin, (used && (int)ud < nu) ? ud : 0u, h, ring[d]);
+                stats5_issue(a, src, (used && (int)ud < nu) ? ud : 0u, h, ring[d]);
             }
             const u32 ent_lane = (u32)lane;                       // a queued item: trip << 6 | the lane that found it (its unit and column)
             const int ub0 = (tid >> 6) * upw;
@@ -226,12 +241,13 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                         const u32 u = (u32)ub + lu;
                         const bool tv = used && (int)u < nu;
                         Stats5Item s;
-                        stats5_finish(a, h, ring[d], s);
+                        stats5_finish(a, src, h, ring[d], s);
                         const int nv = s.rl0 - j0, nk = s.lk - j0;
                         const bool act = tv && nv > 0;
                         const u32 qadd = 0x01010101u * (u32)ST5_QADD;
                         const u32 dirty = (s.q[0] | s.q[1] | s.q[2] | s.q[3] | s.qp |                          // an N among the 16 bases or the 4 before,
                                            (s.q[0] + qadd) | (s.q[1] + qadd) | (s.q[2] + qadd) | (s.q[3] + qadd)) & 0x80808080u;   // a quality without a row
+                        const int F = s.F, Fk = F > 0 ? F + 4 : 0;
                         const bool kept = j0 >= Fk && nk >= imin(nv, 16);              // every base of the item (and its 5-mer) is a kept one
                         const bool drop = nk <= 0 || j0 + 16 <= F;                     // ... a dropped one
                         const bool clean = act && dirty == 0u && (kept || drop);
@@ -249,7 +265,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                         if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + h * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
                         {   // this position's registers are free again: the trip FQ_ST5_DEPTH ahead
                             const u32 un = u + (u32)(FQ_ST5_DEPTH * ustride);
-                            stats5_issue(a, qual, seq, swin, (used && (int)un < nu) ? un : 0u, h, ring[d]);
+                            stats5_issue(a, src, (used && (int)un < nu) ? un : 0u, h, ring[d]);
                         }
                     }
                 }
@@ -266,10 +282,10 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
                     const u32 hh = (w & 63u) - wl_ * (u32)H16, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
-                    stats5_fetch(a, qual, seq, swin, on ? uu : 0u, hh, t);
+                    stats5_fetch(a, src, on ? uu : 0u, hh, t);
                     const int tj0 = 16 * (int)hh;
                     const int tnv = t.rl0 - tj0;
-                    const bool tk = tj0 >= Fk && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
+                    const bool tk = tj0 >= (t.F > 0 ? t.F + 4 : 0) && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
                     stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (tk ? g.S4 : 0u) + hh * 4u), opaque(kmer_b + (tk ? slotK : 0u)), t, hh, on ? tnv : 0);
                     wave_sync();
                 }
@@ -282,8 +298,8 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
                     const u32 hh = (w & 63u) - wl_ * (u32)H16, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
-                    stats5_fetch(a, qual, seq, swin, on ? uu : 0u, hh, t);
-                    if (on) stats5_item_general<KC>(a, lds, g, F, t, (int)hh, lane);
+                    stats5_fetch(a, src, on ? uu : 0u, hh, t);
+                    if (on) stats5_item_general<KC>(a, lds, g, t, (int)hh, lane);
                     wave_sync();
                 }
                 if (!more) break;
@@ -342,6 +358,66 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
             slab[2 * n_cyc + 4 * KMER_BINS + 2 * m * 128 + i] = v;
         }
         block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DevParams::front_per_read (--cut_front on the lane plan): the Stats kernel counted a written-out read's kept bases at their
+// ORIGINAL cycle and the slab fold moved the POST Stats by the mate's common front F0; a read whose own front F is larger (its
+// forward quality cut found a bad window: few reads) has its kept bases F - F0 cycles too late there.  One lane per such read
+// moves them: every per-cycle array of the POST Stats object (stats.cpp:206-222) from cycle j - F0 to cycle j - F.  Deltas are
+// gathered in LDS as signed 32-bit sums ([34 * cycles] per mate) and added to the int64 block once per workgroup.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FrontStatsArgs {
+    int n, paired;
+    int sw_g, qw_g;
+    const u32* seq[2];
+    const u32* qual[2];
+    const u32* swin[2];       // original length | END of the kept range << 16 (0: not written out), after --dedup's decisions
+    const u32* rec[2];        // result records, 3 dwords a read: the low 16 bits of the first = the read's front
+    int front0[2];            // DevParams::lane_front*
+    int64_t* post[2];         // the POST Stats object of mate m in the counter block
+    int64_t st_cycle, cycles;
+};
+FQ_DEV void front_stats_body(const FrontStatsArgs& c, u32* lds) {
+    const int tid = thread_id(), nt = block_threads();
+    const int CC = (int)c.cycles;
+    const int per_mate = 34 * CC, mates = c.paired ? 2 : 1;
+    for (int i = tid; i < mates * per_mate; i += nt) lds[i] = 0;
+    block_sync();
+    const int reads = c.paired ? 2 * c.n : c.n;
+    for (int t = block_id() * nt + tid; t < reads; t += grid_blocks() * nt) {
+        const int g = c.paired ? t >> 1 : t, m = c.paired ? (t & 1) : 0;
+        const u32 sw = c.swin[m][g];
+        const int lk = (int)(sw >> 16), F0 = c.front0[m];
+        if (lk == 0) continue;                                 // not written out: no POST Stats
+        const int F = (int)(c.rec[m][(size_t)g * 3] & 0xFFFFu);
+        if (F <= F0 || lk <= F) continue;
+        const u32* srow = c.seq[m] + (size_t)g * c.sw_g;
+        const u8* qrow = (const u8*)(c.qual[m] + (size_t)g * c.qw_g);
+        u32* cyc = lds + m * per_mate;
+        for (int j = F; j < lk; j++) {
+            const u32 q = (u32)qrow[j] & 0x7Fu;
+            const int b = (int)sym_bin(row_sym(srow, qrow, j));
+            const int co = j - F0, cn = j - F;
+            if (q >= 63u) { lds_add_u32(&cyc[(0 * 8 + b) * CC + co], (u32)-1); lds_add_u32(&cyc[(0 * 8 + b) * CC + cn], 1u); }   // stats.cpp:209-222
+            if (q >= 53u) { lds_add_u32(&cyc[(1 * 8 + b) * CC + co], (u32)-1); lds_add_u32(&cyc[(1 * 8 + b) * CC + cn], 1u); }
+            lds_add_u32(&cyc[(2 * 8 + b) * CC + co], (u32)-1);
+            lds_add_u32(&cyc[(2 * 8 + b) * CC + cn], 1u);
+            lds_add_u32(&cyc[(3 * 8 + b) * CC + co], 0u - (q - 33u));
+            lds_add_u32(&cyc[(3 * 8 + b) * CC + cn], q - 33u);
+            lds_add_u32(&cyc[32 * CC + co], (u32)-1);          // mCycleTotalBase
+            lds_add_u32(&cyc[32 * CC + cn], 1u);
+            lds_add_u32(&cyc[33 * CC + co], 0u - (q - 33u));   // mCycleTotalQual
+            lds_add_u32(&cyc[33 * CC + cn], q - 33u);
+        }
+    }
+    block_sync();
+    for (int i = tid; i < mates * per_mate; i += nt) {
+        const int v = (int)lds[i];
+        if (!v) continue;
+        const int m = i / per_mate, k = i - m * per_mate;
+        g_atomic_add_i64(c.post[m] + c.st_cycle + k, (int64_t)v);
     }
 }
 

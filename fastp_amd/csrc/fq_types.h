@@ -93,6 +93,11 @@ struct DevParams {
                             // cycle in the Stats kernel's tables and the slab fold moves the POST Stats by the mate's front
                             // (lane plan only; fq_lane.h, fq_stats.h)
     int lane_front1, lane_front2;   // that front: UMI length + skip + --trim_front of the mate
+    int front_per_read;     // round 6: --cut_front on the lane plan - a front of its own for every read (Filter::trimAndCut's forward
+                            // quality cut, filter.cpp:97-127, on the window predicate the enabled tail / right cut already builds:
+                            // same window and quality).  The Stats kernel (form 5) reads a read's front from its result record and
+                            // counts kept bases at their ORIGINAL cycle; the slab fold moves the POST Stats by lane_front*, and
+                            // fq_front_stats_kernel moves what a read's own cut adds to that, read by read (few reads have one)
     int merge_lane;         // round 5: --merge on the lane plan (no front trims, no UMI, no --cut_front) - the lane kernel runs the second
                             // overlap analysis on the trimmed reads, filters the merged read and leaves the part lengths in swin; the
                             // Stats kernel counts read 2's kept bases once more as the merged read's tail (reverse-complemented, at

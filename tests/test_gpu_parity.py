@@ -1214,3 +1214,32 @@ def test_gpu_stats_every_quality_character(k):
     if p.dedup or p.dup_enabled:   # (one launch on the GPU = the oracle's order: the duplicate decisions are the stream's)
         pass
     assert np.array_equal(co, cg), int((co != cg).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(7))
+def test_gpu_cut_front_on_the_lane_plan(k):
+    """--cut_front on the lane plan (DevParams::front_per_read): a front per read in the lane kernel, in form 5 of the Stats kernel and
+    in fq_front_stats_kernel; 200 000 noisy units, records + every counter against the oracle
+    (tests/test_hostsim_parity.py::test_sim_cut_front_on_the_lane_plan: 700 units on the emulator)"""
+    import test_hostsim_parity as hs
+    paired, L, kw = hs.CUT_FRONT_LANE[k]
+    p = abi.default_params(paired, L)
+    if not paired:
+        p.adapter_seq_r1 = None
+    p.length_required = 8
+    for key, v in kw.items():
+        setattr(p, key, v)
+    d = synth.noisy_reads(200000, L=L, seed=300 + k, paired=paired)
+    o = oraclelib.Oracle(p)
+    g = engines.gpu_engine(p)
+    assert g.plan() == "lane"
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    for i in range(3 if paired else 1):
+        bad = np.nonzero(ro[i] != rg[i])[0]
+        assert len(bad) == 0, f"case {k}: result {i} differs at {bad[:5]}"
+    assert np.array_equal(co, cg), int((co != cg).sum())

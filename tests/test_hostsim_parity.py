@@ -1126,3 +1126,42 @@ def test_sim_stats_every_quality_character(k):
     for i in range(3 if paired else 1):
         assert ro[i].tobytes() == rg[i].tobytes()
     assert np.array_equal(co, cg), int((co != cg).sum())
+
+
+# --cut_front on the lane plan (round 6, DevParams::front_per_read): the forward quality cut on the window predicate the enabled
+# right / tail cut builds (same window and quality), every read its own front: (paired, L, overrides)
+CUT_FRONT_LANE = [
+    (True, 150, dict(cut_front=1, cut_tail=1)),
+    (True, 150, dict(cut_front=1, cut_right=1)),
+    (False, 150, dict(cut_front=1)),
+    (True, 150, dict(cut_front=1, cut_tail=1, cut_right=1, cut_front_window=6, cut_tail_window=9, cut_right_window=6, cut_front_quality=24,
+                     cut_right_quality=24, trim_front1=2, trim_tail1=3, trim_front2=5, trim_tail2=1)),
+    (True, 100, dict(cut_front=1, cut_front_window=8, cut_front_quality=28, umi_len1=4, umi_len2=6, umi_skip=1, trim_tail1=7, poly_x=1)),
+    (False, 76, dict(cut_front=1, cut_right=1, cut_front_window=1, cut_right_window=1, cut_front_quality=30, cut_right_quality=30, dedup=1)),
+    (True, 150, dict(cut_front=1, cut_tail=1, cut_front_window=5, cut_tail_window=5, cut_front_quality=18, cut_tail_quality=18,
+                     adapter_seq_r1=b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", adapter_seq_r2=b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT", complexity_filter=1)),
+]
+
+
+@pytest.mark.parametrize("k", range(len(CUT_FRONT_LANE)))
+def test_sim_cut_front_on_the_lane_plan(k):
+    """Filter::trimAndCut's forward cut (filter.cpp:97-127) in the lane kernel, a front per read in the Stats kernel (form 5) and
+    the POST Stats' cycles moved read by read (fq_front_stats_kernel): noisy reads - most of them have a bad first window -
+    records + every counter against the oracle, and the plan IS the lane plan"""
+    paired, L, kw = CUT_FRONT_LANE[k]
+    p = abi.default_params(paired, L)
+    if not paired:
+        p.adapter_seq_r1 = None
+    p.length_required = 8
+    for key, v in kw.items():
+        setattr(p, key, v)
+    d = synth.noisy_reads(700, L=L, seed=300 + k, paired=paired)
+    g = engines.sim_engine(p)
+    assert g.plan() == "lane"
+    g.close()
+    ro, rg, co, cg = _both(p, d, paired)
+    assert int((ro[0]["front"] > 0).sum()) > 50
+    for i in range(3 if paired else 1):
+        bad = np.nonzero(ro[i] != rg[i])[0]
+        assert len(bad) == 0, f"case {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
+    assert np.array_equal(co, cg), int((co != cg).sum())
