@@ -805,6 +805,10 @@ def main():
             out["compute_roofline"] = compute
         out["config"]["kernel_plan"] = plan
         out["config"]["switches"] = switches   # {} = the library's defaults
+        if world == 1:
+            # the legs below make engines of their own: this one (its streams, bloom filter and the resident batches) is done
+            eng.close()
+            eng = None
         if world == 1 and not args.no_cpu:
             resident = None
             torch.cuda.empty_cache()
@@ -851,7 +855,8 @@ def main():
                 except Exception as e:
                     out["e2e_dropin_bgzf"] = {"gpu": None, "error": repr(e)[:300]}
         print(json.dumps(out))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -453,7 +453,8 @@ static int stats5_copies(const DevParams& p, int lds_bytes) {
 }
 static bool lane_plan_supported(const DevParams& p, const HostLuts& luts) {
     if (p.front_per_read && !stats5_copies(p, 160 * 1024)) return false;   // a front per read: form 5 of the Stats kernel only
-    if (!(p.stats_one_pass || p.front_lane || p.corr_lane || p.merge_lane) || p.allow_gap || p.n_fasta || p.overlapped_out) return false;
+    if (!(p.stats_one_pass || p.front_lane || p.corr_lane || p.merge_lane) || p.allow_gap || p.overlapped_out) return false;
+    if (p.n_fasta && p.fasta_max_len > 64) return false;   // (--adapter_fasta: each sequence like -a, in four uniform words)
     if (p.merge && !p.merge_lane) return false;
     if ((p.has_a1 && p.alen1 > 64) || (p.has_a2 && p.alen2 > 64)) return false;   // the lane kernel keeps an adapter in four uniform words
     if (p.max_len > 256 || p.sw_g > 16 || (p.qw_g & 1)) return false;
@@ -481,7 +482,7 @@ static lane_kernel_fn lane_kernel_pick(int swm, int B, bool paired) {
 static int lane_ext(const DevParams& p) {
     if (p.merge_lane) return 3;
     if (p.front_lane || p.corr_lane) return 2;
-    return (p.has_a1 || p.has_a2 || p.poly_x || p.complexity_filter) ? 1 : 0;
+    return (p.has_a1 || p.has_a2 || p.n_fasta || p.poly_x || p.complexity_filter) ? 1 : 0;
 }
 static lane_kernel_fn lane_kernel_merge(int swm, int B) {
     if (swm == 10) return B == 0 ? fq_lane_kernel<10, 0, 3, true, 3> : B == 2 ? fq_lane_kernel<10, 2, 3, true, 3> : fq_lane_kernel<10, 4, 3, true, 3>;

@@ -130,6 +130,8 @@ int build_dev_params(const fastp_gpu_params& in, DevParams& p, HostLuts& luts, s
         luts.fasta_len.push_back(alen);
     }
     p.n_fasta = in.n_adapter_fasta;
+    p.fasta_max_len = 0;
+    for (int v : luts.fasta_len) p.fasta_max_len = std::max(p.fasta_max_len, v);
     p.fasta_match_req = p.n_fasta > 256 ? 6 : (p.n_fasta > 16 ? 5 : 4);  // adaptertrimmer.cpp:49-53
     p.correction = (in.correction != 0) && p.paired;  // options.cpp:401-404
     p.allow_gap = (in.allow_gap_overlap_trimming != 0) && p.paired;

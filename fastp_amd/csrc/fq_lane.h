@@ -919,6 +919,40 @@ FQ_DEV void lane_apply_adapter(u32* misc, int pos, int alen, int& len, u32& apos
     alen_out = (u32)adapter_len;
 }
 
+// AdapterTrimmer::trimByMultiSequences (adaptertrimmer.cpp:48-62) on a read in registers (round 6: --adapter_fasta lists whose
+// sequences are <= 64 bases): every sequence of the list in turn on the shrinking read - trimBySequence as for -a - each cut
+// reported as a fastp_gpu_adapter_event (the host replays FilterResult's adapter map from them).  A wave collective: `go` lanes
+// take part, `cur` = the lane's read length in / out.  which: the read's index in the run's stream (2 g + mate, or g).
+template <int SWM>
+FQ_DEV bool lane_fasta_trims(const KernelArgs& a, u32* misc, const LaneRead<SWM>& r, bool go, int& cur, u32 read_index) {
+    const DevParams& p = a.p;
+    bool trimmed = false;
+    for (int i = 0; i < p.n_fasta; i++) {                      // (uniform)
+        if (ballot(go && cur > 0) == 0ull) break;
+        u32 fw[LANE_ADAPTER_WORDS];
+#pragma unroll
+        for (int w = 0; w < LANE_ADAPTER_WORDS; w++) fw[w] = a.lut.fasta_words[(size_t)i * ADAPT_WORDS + w];   // (uniform loads)
+        const int alen = a.lut.fasta_len[i];
+        int pos = 0;
+        const int rlen = cur;
+        const bool hit = lane_trim_by_sequence<SWM>(r, go ? rlen : 0, fw, alen, p.fasta_match_req, pos);
+        if (go && hit) {
+            u32 ap, al;
+            lane_apply_adapter(misc, pos, alen, cur, ap, al);
+            trimmed = true;
+            if (a.adapter_events) {
+                const int slot = g_atomic_add_i32(a.n_adapter_events, 1);
+                if (slot < a.adapter_events_capacity) {
+                    a.adapter_events[3 * slot] = read_index;
+                    a.adapter_events[3 * slot + 1] = ((u32)pos & 0xFFFFu) | ((al & 0xFFFFu) << 16);
+                    a.adapter_events[3 * slot + 2] = (u32)i;
+                }
+            }
+        }
+    }
+    return trimmed;
+}
+
 // ---------------------------------------------------------------------------
 // PolyX::trimPolyX (polyx.cpp:49-116) on [0, rlen) of a read in registers: the walk from the tail over 32-base windows
 // (codes and N flags cut out of the registers), then the reference's step back to the first base of the winning letter.
@@ -1674,6 +1708,10 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
                         if (go && hit) { lane_apply_adapter(misc, pos, p.alen2, cur2, apos2, alen2); t2 = true; }
                     }
                 }
+                if (EXT && p.n_fasta) {   // (uniform) :467-470: every pair, whatever trimmed it before
+                    t1 |= lane_fasta_trims<SWM>(a, misc, r1, adapt, cur1, 2u * (u32)(a.first + gp));
+                    t2 |= lane_fasta_trims<SWM>(a, misc, r2, adapt, cur2, 2u * (u32)(a.first + gp) + 1u);
+                }
                 if (t1) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); r1.flags |= RS_ADAPTER; }   // :472-475
                 if (t2) { lds_add_u32(&misc[MISC_ADAPTER_READS], 1u); r2.flags |= RS_ADAPTER; }
                 if ((t1 || t2) && cur1 <= p.dimer_max_len && cur2 <= p.dimer_max_len) dimer = true;   // :480-484
@@ -1713,11 +1751,18 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
             if (valid && !xs) write_pair_result(a, g, ovl, ov_off, ov_len, ov_diff, isize_done);
         } else {
-            if (EXT && p.adapter_enabled && p.has_a1 && ballot(a1) != 0ull) {   // seprocessor.cpp:244-261
+            if (EXT && p.adapter_enabled && (p.has_a1 || p.n_fasta) && ballot(a1) != 0ull) {   // seprocessor.cpp:244-261
                 int pos = 0, cur = r1.len;
-                const bool hit = lane_trim_by_sequence<SWM>(r1, a1 ? cur : 0, aw1, p.alen1, 4, pos);
-                if (a1 && hit) {
-                    lane_apply_adapter(misc, pos, p.alen1, cur, apos1, alen1);
+                bool trimmed = false;
+                if (p.has_a1) {
+                    const bool hit = lane_trim_by_sequence<SWM>(r1, a1 ? cur : 0, aw1, p.alen1, 4, pos);
+                    if (a1 && hit) {
+                        lane_apply_adapter(misc, pos, p.alen1, cur, apos1, alen1);
+                        trimmed = true;
+                    }
+                }
+                if (p.n_fasta) trimmed |= lane_fasta_trims<SWM>(a, misc, r1, a1, cur, (u32)(a.first + gp));   // :249-251
+                if (a1 && trimmed) {
                     r1.len = cur;
                     lds_add_u32(&misc[MISC_ADAPTER_READS], 1u);
                     r1.flags |= RS_ADAPTER;

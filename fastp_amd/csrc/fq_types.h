@@ -69,6 +69,7 @@ struct DevParams {
     int adapter_enabled, dimer_max_len;
     int has_a1, has_a2, alen1, alen2;
     int n_fasta, fasta_match_req;   // --adapter_fasta list (adaptertrimmer.cpp:48-55)
+    int fasta_max_len;              // its longest sequence (the lane plan takes lists of sequences <= 64 bases, round 6)
     u32 a1w[MAX_ADAPTER_WORDS], a2w[MAX_ADAPTER_WORDS];
     int correction;
     int merge, merge_include_unmerged;  // MergeOptions (peprocessor.cpp:518-561)

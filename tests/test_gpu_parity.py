@@ -1243,3 +1243,30 @@ def test_gpu_cut_front_on_the_lane_plan(k):
         bad = np.nonzero(ro[i] != rg[i])[0]
         assert len(bad) == 0, f"case {k}: result {i} differs at {bad[:5]}"
     assert np.array_equal(co, cg), int((co != cg).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paired", [True, False])
+def test_gpu_adapter_fasta_on_the_lane_plan(paired):
+    """--adapter_fasta in the lane kernel (lists of sequences <= 64 bases): 150 000 units that begin with adapters carrying indels,
+    records + adapter events + every counter against the oracle
+    (tests/test_hostsim_parity.py::test_sim_adapter_fasta_on_the_lane_plan: 600 units on the emulator)"""
+    import test_hostsim_parity as hs
+    p = abi.default_params(paired, 150)
+    if not paired:
+        p.adapter_seq_r1 = None
+    abi.set_adapter_fasta(p, hs.FASTA_LANE_LIST)
+    d = synth.adapter_indel_reads(150000, L=150, seed=78, paired=paired)
+    o = oraclelib.Oracle(p)
+    g = engines.gpu_engine(p)
+    assert g.plan() == "lane"
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    eo, eg = o.last_adapter_events, g.last_adapter_events
+    o.close()
+    g.close()
+    for i in range(3 if paired else 1):
+        assert ro[i].tobytes() == rg[i].tobytes(), f"records {i} differ"
+    assert len(eo) > 1000 and eo.tobytes() == eg.tobytes(), (len(eo), len(eg))
+    assert np.array_equal(co, cg), int((co != cg).sum())

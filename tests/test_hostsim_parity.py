@@ -1165,3 +1165,43 @@ def test_sim_cut_front_on_the_lane_plan(k):
         bad = np.nonzero(ro[i] != rg[i])[0]
         assert len(bad) == 0, f"case {k}: result {i} differs at {bad[:5]}: oracle {ro[i][bad[:3]]} device {rg[i][bad[:3]]}"
     assert np.array_equal(co, cg), int((co != cg).sum())
+
+
+FASTA_LANE_LIST = [b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT", b"CTGTCTCTTATACACATCT", b"TGGAATTCTCGGGTGCCAAGG",
+                   b"AATGATACGGCGACCACCGAGATCTACACTCTTTCCCTACACGACGCTCTTCCGATCT", b"GATCGGAAGAGC"]
+
+
+@pytest.mark.parametrize("paired,extra", [(True, {}), (False, {}), (True, {"adapter_seq_r1": b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", "trim_front1": 3, "cut_right": 1}),
+                                          (False, {"poly_x": 1, "complexity_filter": 1, "cut_tail": 1})])
+def test_sim_adapter_fasta_on_the_lane_plan(paired, extra):
+    """AdapterTrimmer::trimByMultiSequences (adaptertrimmer.cpp:48-62) in the lane kernel (round 6: lists of sequences <= 64 bases):
+    every sequence in turn on the shrinking read, the adapter events for the host's map replay - on reads that begin with an adapter
+    carrying an inserted / a deleted base, exact adapters at negative positions and inside the read; records, events and every
+    counter against the oracle, and a list with a longer sequence still takes the tile kernels"""
+    p = abi.default_params(paired, 150)
+    if not paired:
+        p.adapter_seq_r1 = None
+    for k, v in extra.items():
+        setattr(p, k, v)
+    abi.set_adapter_fasta(p, FASTA_LANE_LIST)
+    g = engines.sim_engine(p)
+    assert g.plan() == "lane"
+    g.close()
+    d = synth.adapter_indel_reads(600, L=150, seed=77, paired=paired)
+    o = oraclelib.Oracle(p)
+    g = engines.sim_engine(p)
+    args = (d["seq1"], d["qual1"], d["len1"]) + ((d["seq2"], d["qual2"], d["len2"]) if paired else ())
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    eo, eg = o.last_adapter_events, g.last_adapter_events
+    o.close()
+    g.close()
+    for i in range(3 if paired else 1):
+        assert ro[i].tobytes() == rg[i].tobytes(), f"records {i} differ"
+    assert len(eo) > 100 and eo.tobytes() == eg.tobytes(), (len(eo), len(eg))
+    assert np.array_equal(co, cg), int((co != cg).sum())
+    q = abi.default_params(paired, 150)
+    abi.set_adapter_fasta(q, FASTA_LANE_LIST + [b"ACGT" * 20])
+    g = engines.sim_engine(q)
+    assert g.plan() != "lane"
+    g.close()
