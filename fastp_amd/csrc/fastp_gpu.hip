@@ -86,6 +86,7 @@ extern "C" __global__ void __launch_bounds__(1024) fq_stats5_kernel(StatsArgs a)
     if ((a.debug_skip & 0xC0u) && a.Hs == 10 && a.kc == 2) { stats_body5<2, 10, true>(a, fq_lds); return; }   // profiling build only
 #endif
     if (a.Hs == 10 && a.kc == 2) stats_body5<2, 10, false>(a, fq_lds);   // reads of up to 160 bases (uniform)
+    else if (a.Hs == 8 && a.kc == 2) stats_body5<2, 8, false>(a, fq_lds);  // two blocks of eight columns: reads of up to 256 bases
     else if (a.kc == 2) stats_body5<2, 0, false>(a, fq_lds);
     else stats_body5<1, 0, false>(a, fq_lds);
 }
@@ -439,15 +440,22 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
 // unbounded indexed walk along a read (adapter sequences, one-gap overlap, polyX, complexity), windows of up to 8
 // bases, reads of up to 256 bases, a duplicate hash with the byte-plane table and 3-byte primes
 // form 5 of the Stats kernel (fq_stats5.h): the copies of the 5-mer table its LDS layout has room for (0: it does not fit)
-static int stats5_copies(const DevParams& p, int lds_bytes) {
+// (and, through hb, the columns its table holds: reads with more 16-base columns than fit are taken in blocks of hb columns)
+static int stats5_copies(const DevParams& p, int lds_bytes, int* hb_out = nullptr) {
     if (env_int("FASTP_GPU_STATS_V", 5) < 5 || p.merge_lane) return 0;
     const int H16 = (p.qw_g + 3) / 4, Cp = (p.cycles + 3) & ~3;
     if (H16 > p.sw_g || H16 > 64) return 0;
-    for (int kc = 2; kc >= 1; kc--) {
-        int o = 2 * 8 * 4 * ST5_QN * H16 + 2 * KMER_BINS * kc;
-        o = (o + 1) & ~1;
-        o += 2 * Cp * N_CLS * 2 + 2 * 128 + (1024 / 64) * 2 * ST5_WL / 2;
-        if (o * 4 <= lds_bytes) return kc;
+    for (int nblk = 1; nblk <= 4; nblk++) {
+        const int hb = (H16 + nblk - 1) / nblk;
+        for (int kc = 2; kc >= 1; kc--) {
+            int o = 2 * 8 * 4 * ST5_QN * hb + 2 * KMER_BINS * kc;
+            o = (o + 1) & ~1;
+            o += 2 * Cp * N_CLS * 2 + 2 * 128 + (1024 / 64) * 2 * ST5_WL / 2;
+            if (o * 4 <= lds_bytes) {
+                if (hb_out) *hb_out = hb;
+                return kc;
+            }
+        }
     }
     return 0;
 }
@@ -595,22 +603,21 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             // counters, the packed cells of what the table has no cell for, the histogram of those, a list per wavefront - where it
             // fits one workgroup's LDS (reads of up to 176 bases; merge mode's third pass exists in form 4 only)
             ctx->st_H16 = (ctx->dp.qw_g + 3) / 4;
-            for (int kc = 2; kc >= 1; kc--) {
+            int hb = 0;
+            const int kc = stats5_copies(ctx->dp, (int)prop.sharedMemPerBlock, &hb);
+            if (kc) {
                 int o = 0;
-                ctx->st_l_cyc = o; o += 2 * 8 * 4 * ST5_QN * ctx->st_H16;
+                ctx->st_l_cyc = o; o += 2 * 8 * 4 * ST5_QN * hb;
                 ctx->st_l_kmer = o; o += 2 * KMER_BINS * kc;
                 o = (o + 1) & ~1;
                 ctx->st_l_ovf = o; o += 2 * ctx->L.Cp * N_CLS * 2;
                 ctx->st_l_qh = o; o += 2 * 128;
                 ctx->st_l_wl = o; o += (1024 / 64) * 2 * ST5_WL / 2;   // (u16 entries)
-                if (o * 4 <= (int)prop.sharedMemPerBlock && ctx->st_H16 <= ctx->dp.sw_g && ctx->st_H16 <= 64) {
-                    ctx->st_form = 5;
-                    ctx->st_kc = kc;
-                    ctx->st_Hs = ctx->st_H16;
-                    ctx->st_lds_dwords = o;
-                    ctx->st_max_reads = CYC_MAX_READS;   // (a list entry holds the trip in 10 bits: 16 wavefronts x (64 / H16 >= 4) units per trip, <= 256 trips)
-                    break;
-                }
+                ctx->st_form = 5;
+                ctx->st_kc = kc;
+                ctx->st_Hs = hb;                     // the table's columns: all of a read's (st_H16), or a block of them
+                ctx->st_lds_dwords = o;
+                ctx->st_max_reads = CYC_MAX_READS;   // (a list entry holds the trip in 10 bits: 16 wavefronts x (64 / hb >= 4) units per trip, <= 256 trips)
             }
         }
         if (ctx->st_form == 5) {
@@ -1618,7 +1625,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         sa.l_cyc = ctx->st_l_cyc; sa.l_kmer = ctx->st_l_kmer; sa.l_qh = ctx->st_l_qh; sa.l_lut = ctx->st_l_lut; sa.l_mt = ctx->st_l_mt;
         sa.l_wl = ctx->st_l_wl; sa.wl_cap = ctx->st_wl_cap;
         sa.l_total = ctx->st_lds_dwords;
-        sa.H16 = ctx->st_H16; sa.magic_H16 = ctx->st_H16 ? magic_for((u32)ctx->st_H16) : 0u; sa.l_ovf = ctx->st_l_ovf;
+        sa.H16 = ctx->st_H16; sa.magic_H16 = (ctx->st_form == 5 && ctx->st_Hs) ? magic_for((u32)ctx->st_Hs) : 0u; sa.l_ovf = ctx->st_l_ovf;   // (the magic of the table's columns)
         sa.front_per_read = ctx->dp.front_per_read;
         sa.fr_stride = ctx->dp.front_per_read ? 3 : 0;
         for (int m = 0; m < 2; m++) sa.fr_rec[m] = ctx->dp.front_per_read ? (const u32*)a.res[m] : ctx->d_swin[m];

@@ -54,7 +54,7 @@ struct StatsArgs {
                             // pass; a third pass (stats4_tail_pass) counts what swin[1] marks as kept once more into slot 3, the merged
                             // reads' second parts at the merged reads' cycles (the slab fold adds slot 3 to the POST Stats of read 1)
     int H16;                // form 5 (fq_stats5.h): 16-base items per row = ceil(qw_g / 4), Hs = the item columns of its table
-    u32 magic_H16;          // ceil(2^32 / H16)
+    u32 magic_H16;          // ceil(2^32 / Hs): a lane number -> (unit of the trip, column of the block)
     int l_ovf;              // form 5: [2][Cp][N_CLS] u64 packed cells of the bases its joint table has no cell for (N, qualities above 'K')
     const u32* fr_rec[2];   // form 5: where a read's own front is read from - its result record (stride fr_stride = 3 dwords, low 16 bits)
     int fr_stride;          // with DevParams::front_per_read (--cut_front), else the mate's swin array with stride 0 (a load nobody uses)

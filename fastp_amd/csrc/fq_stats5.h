@@ -135,7 +135,7 @@ FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb,
 
 // one item, base by base: any state (an N, a quality the table has no row for, a kept range that ends inside the item)
 template <int KC>
-FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, const Stats5Item& s, int h, int lane) {
+FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g, const Stats5Item& s, int h, int hq, int lane) {   // hq: h inside its block
     const int F = s.F;
     u8* ldsw = (u8*)lds;
     const u32 nbp = (s.qp >> 7) & 0x01010101u;
@@ -162,7 +162,7 @@ FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g
         const u32 slot = (j >= F && j < s.lk) ? 1u : 0u;
         const u32 e = q - 33u;
         if (!isn && e < (u32)ST5_QN) {
-            lds_add_u32((u32*)(ldsw + ((u32)a.l_cyc * 4u + slot * g.S4 + (u32)(k & 7) * g.K4 + code * g.C4 + e * g.HS4 + (u32)h * 4u)), k < 8 ? 1u : 0x10000u);
+            lds_add_u32((u32*)(ldsw + ((u32)a.l_cyc * 4u + slot * g.S4 + (u32)(k & 7) * g.K4 + code * g.C4 + e * g.HS4 + (u32)hq * 4u)), k < 8 ? 1u : 0x10000u);
         } else {
             lds_add_u64(&ovf[(slot * (u32)a.Cp + (u32)j) * N_CLS + (isn ? (u32)CLS_N : code)], stats_inc_of(q));
             lds_add_u32(&qh[slot * 128u + q], 1u);
@@ -189,11 +189,13 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     const int nu = imax(0, imin(a.units_per_block, a.n - u0));
     // lane = (unit of the wavefront's trip, item column): both are constants of the lane for the whole kernel - no division, no
     // per-item address arithmetic beyond a multiply-add per array; 64 / H16 units per trip (60 of 64 lanes at ten columns)
-    const int upw = 64 / H16;
-    const u32 lu = HS ? (u32)lane / (u32)HS : (u32)lane / (u32)H16;
-    const u32 h = (u32)lane - lu * (u32)H16;
-    const bool used = (int)lu < upw;
-    const int j0 = 16 * (int)h;
+    // Reads longer than the table has columns for (HB = a.Hs < H16: 250-base reads are 16 columns, the table holds 8) are taken
+    // in column BLOCKS: a pass over a mate's rows per block, each reading only its own columns' bytes; the per-cycle cells of a
+    // block are flushed and cleared behind it, the 5-mer table, the packed cells and the histogram stay for the whole mate.
+    const int HB = HS ? HS : a.Hs, nblk = (H16 + HB - 1) / HB;
+    const int upw = 64 / HB;
+    const u32 lu = HS ? (u32)lane / (u32)HS : (u32)lane / (u32)HB;
+    const u32 hl = (u32)lane - lu * (u32)HB;                      // the lane's column inside a block
     const int ustride = (nt >> 6) * upw;
     u16* wlT = (u16*)(lds + a.l_wl) + (tid >> 6) * (2 * ST5_WL);   // this wavefront's two lists: a read's clean last item ...
     u16* wlG = wlT + ST5_WL;                                      // ... and everything else the fast path does not take
@@ -203,6 +205,11 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     for (int m = 0; m < 2; m++) {                                 // uniform
         for (int i = tid; i < a.l_wl; i += nt) lds[i] = 0;       // [cyc | kmer | ovf | qh] sit in front of the lists
         block_sync();
+      for (int cb = 0; cb < nblk; cb++) {                         // uniform
+        const bool hcol = cb * HB + (int)hl < H16;                // (the last block may hold fewer columns)
+        const u32 h = hcol ? (u32)(cb * HB) + hl : 0u;            // the lane's item column
+        const bool used = (int)lu < upw && hcol;
+        const int j0 = 16 * (int)h;
         if (m < nm) {
             Stats5Src src;
             src.qual = a.qual[m] + (size_t)u0 * a.qw_g;
@@ -262,7 +269,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                             if (act && !clean) wlG[wnG + lane_rank(mG)] = (u16)ent;
                             wnG += popc64(mG);
                         }
-                        if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + h * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
+                        if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + hl * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
                         {   // this position's registers are free again: the trip FQ_ST5_DEPTH ahead
                             const u32 un = u + (u32)(FQ_ST5_DEPTH * ustride);
                             stats5_issue(a, src, (used && (int)un < nu) ? un : 0u, h, ring[d]);
@@ -280,13 +287,13 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     const bool on = lane < cnt;
                     const u32 w = on ? (u32)wlT[wnT + lane] : 0u;
                     const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
-                    const u32 hh = (w & 63u) - wl_ * (u32)H16, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
+                    const u32 hq = (w & 63u) - wl_ * (u32)HB, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
                     stats5_fetch(a, src, on ? uu : 0u, hh, t);
                     const int tj0 = 16 * (int)hh;
                     const int tnv = t.rl0 - tj0;
                     const bool tk = tj0 >= (t.F > 0 ? t.F + 4 : 0) && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
-                    stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (tk ? g.S4 : 0u) + hh * 4u), opaque(kmer_b + (tk ? slotK : 0u)), t, hh, on ? tnv : 0);
+                    stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (tk ? g.S4 : 0u) + hq * 4u), opaque(kmer_b + (tk ? slotK : 0u)), t, hh, on ? tnv : 0);
                     wave_sync();
                 }
                 while (wnG >= 64 || (!more && wnG > 0)) {         // (uniform)
@@ -296,32 +303,35 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     const bool on = lane < cnt;
                     const u32 w = on ? (u32)wlG[wnG + lane] : 0u;
                     const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
-                    const u32 hh = (w & 63u) - wl_ * (u32)H16, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
+                    const u32 hq = (w & 63u) - wl_ * (u32)HB, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
                     stats5_fetch(a, src, on ? uu : 0u, hh, t);
-                    if (on) stats5_item_general<KC>(a, lds, g, t, (int)hh, lane);
+                    if (on) stats5_item_general<KC>(a, lds, g, t, (int)hh, (int)hq, lane);
                     wave_sync();
                 }
                 if (!more) break;
             }
         }
         block_sync();
-        // ---- flush the mate's two slots to the slab in its canonical packed form ([slot][cycle][class] u64, reduce_body) ----
+        // ---- flush the block's cycles of the mate's two slots to the slab in its canonical packed form ([slot][cycle][class] u64,
+        // reduce_body); the last block also takes the cycles behind the last column ----
         const int per_slot = a.Cp * N_CLS;
         const u64* ovf = (const u64*)(lds + a.l_ovf);
-        for (int i = tid; i < 2 * per_slot; i += nt) {
-            const int sl = i >= per_slot ? 1 : 0;
-            const int rem = i - sl * per_slot;
+        const int pos_lo = cb * HB * 16, pos_hi = cb + 1 < nblk ? (cb + 1) * HB * 16 : a.Cp;
+        const int blk_items = imax(0, imin(pos_hi, a.Cp) - pos_lo) * N_CLS;
+        for (int i = tid; i < 2 * blk_items; i += nt) {
+            const int sl = i >= blk_items ? 1 : 0;
+            const int rem = i - sl * blk_items + pos_lo * N_CLS;
             const int pos = rem / N_CLS, cls = rem - pos * N_CLS;
             u64 v = 0;
             if (m < nm) {
                 u32 cnt = 0, q20 = 0, q30 = 0, qs = 0;
-                const int h = pos >> 4, k = pos & 15;
-                if (cls < 4 && h < H16) {
-                    const u32* row = lds + a.l_cyc + ((sl * 8 + (k & 7)) * 4 + cls) * ST5_QN * a.Hs + h;
+                const int hq = (pos - pos_lo) >> 4, k = pos & 15;
+                if (cls < 4 && hq < HB && (pos >> 4) < H16) {
+                    const u32* row = lds + a.l_cyc + ((sl * 8 + (k & 7)) * 4 + cls) * ST5_QN * HB + hq;
                     const int sh = k < 8 ? 0 : 16;
                     for (int e = 0; e < ST5_QN; e++) {
-                        const u32 c = (row[e * a.Hs] >> sh) & 0xFFFFu;
+                        const u32 c = (row[e * HB] >> sh) & 0xFFFFu;
                         cnt += c;
                         qs += c * (u32)e;
                         if (e >= 20) q20 += c;                   // stats.cpp:209-222: '5' counts into Q20, '?' into Q30 and Q20
@@ -337,26 +347,30 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
             slab[o2] = (u32)v;
             slab[o2 + 1] = (u32)(v >> 32);
         }
+        // the histogram of the block's table bases - the sum over (cycle, class) - joins the histogram proper
+        for (int i = tid; i < 2 * ST5_QN; i += nt) {
+            if (m >= nm) break;
+            const int sl = i >= ST5_QN ? 1 : 0, e = i - sl * ST5_QN;
+            u32 v = 0;
+            for (int kc = 0; kc < 8 * 4; kc++) {
+                const u32* row = lds + a.l_cyc + (((sl * 8 * 4 + kc) * ST5_QN) + e) * HB;
+                for (int hq = 0; hq < HB; hq++) v += (row[hq] & 0xFFFFu) + (row[hq] >> 16);
+            }
+            lds[a.l_qh + sl * 128 + 33 + e] += v;                 // (one thread per bin)
+        }
+        block_sync();
+        if (cb + 1 < nblk) {                                      // (uniform) the next block starts on an empty table
+            for (int i = tid; i < a.l_kmer - a.l_cyc; i += nt) lds[a.l_cyc + i] = 0;
+            block_sync();
+        }
+      }
         for (int i = tid; i < 2 * KMER_BINS; i += nt) {
             u32 v = 0;
             if (m < nm)
                 for (int c = 0; c < KC; c++) v += lds[a.l_kmer + i * KC + c];
             slab[2 * n_cyc + 2 * m * KMER_BINS + i] = v;
         }
-        for (int i = tid; i < 2 * 128; i += nt) {
-            u32 v = 0;
-            if (m < nm) {
-                v = lds[a.l_qh + i];
-                const int sl = i >> 7, e = (i & 127) - 33;
-                if (e >= 0 && e < ST5_QN) {                       // the histogram of the table's bases: the sum over (cycle, class)
-                    for (int kc = 0; kc < 8 * 4; kc++) {
-                        const u32* row = lds + a.l_cyc + (((sl * 8 * 4 + kc) * ST5_QN) + e) * a.Hs;
-                        for (int h = 0; h < H16; h++) v += (row[h] & 0xFFFFu) + (row[h] >> 16);
-                    }
-                }
-            }
-            slab[2 * n_cyc + 4 * KMER_BINS + 2 * m * 128 + i] = v;
-        }
+        for (int i = tid; i < 2 * 128; i += nt) slab[2 * n_cyc + 4 * KMER_BINS + 2 * m * 128 + i] = m < nm ? lds[a.l_qh + i] : 0u;
         block_sync();
     }
 }

@@ -1188,7 +1188,7 @@ def test_gpu_stats_joint_table_at_its_capacity():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", range(6))
+@pytest.mark.parametrize("k", range(9))
 def test_gpu_stats_every_quality_character(k):
     """every quality character '!' .. '~' around the joint table's edge, N runs, ragged lengths, trimmed ranges (the emulator twin:
     tests/test_hostsim_parity.py::test_sim_stats_every_quality_character, 3000 units): 300 000 units, records + every counter"""

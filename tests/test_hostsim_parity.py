@@ -1106,7 +1106,8 @@ def quality_range_reads(n, L, seed, paired):
 
 
 STATS5_RANGE_CASES = [(True, 150, {}), (False, 150, {"cut_right": 1}), (True, 100, {"trim_front1": 5, "trim_front2": 9, "cut_tail": 1}),
-                      (False, 151, {"trim_front1": 17, "trim_tail1": 3}), (True, 165, {"cut_right": 1, "correction": 1}), (True, 76, {"dedup": 1})]
+                      (False, 151, {"trim_front1": 17, "trim_tail1": 3}), (True, 165, {"cut_right": 1, "correction": 1}), (True, 76, {"dedup": 1}),
+                      (True, 250, {"cut_right": 1, "trim_front2": 6}), (False, 400, {"cut_tail": 1}), (True, 203, {"cut_front": 1, "cut_right": 1})]   # (column blocks)
 
 
 @pytest.mark.parametrize("k", range(len(STATS5_RANGE_CASES)))
