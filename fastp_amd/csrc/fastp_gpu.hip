@@ -1073,7 +1073,7 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         HIP_TRY(ctx, hipGetLastError());
         {   // LDS plan of the counting kernel: symbols of one task per lane, then the seed tables that still fit
             const int longest = ctx->dp.max_len * (ctx->dp.merge ? 2 : 1);
-            int lds_bytes = ((longest * OVR_SYM_STRIDE + 15) / 16) * 16;
+            int lds_bytes = (((longest + 4) * OVR_SYM_STRIDE + 15) / 16) * 16;   // (+ 4 rows: a trip's four slides read unguarded)
             o.sym_cap = longest;
             if (lds_bytes > 120 * 1024) { o.sym_cap = 0; lds_bytes = 0; }   // reads too long to stage: the global path
             for (int m = 0; m < 2; m++) {

@@ -3451,7 +3451,90 @@ FQ_DEV void ovr_count_body(const OvrArgs& o, u32* lds) {
     const int f = 0;
     int64_t* cnt = o.ctr + o.o_count[slot];
     int64_t* dist = o.ctr + o.o_dist[slot];
-    {
+    if (staged && o.table_lds[0] >= 0 && (o.table_lds[1] >= 0 || o.mate[1].n_seeds == 0)) {   // (uniform)
+        // Round 6: symbols and seed tables are both in LDS (the usual case) - read through DS addresses (the generic pointers of
+        // the form below are FLAT loads: 6.3e7 of them per launch, and 5.9e8 SALU + 2.3e8 branch instructions against 4.0e8 VALU,
+        // profiles/r06_i_config4_sq_counters.txt: the kernel - configs[4]'s critical path behind the lane kernel - was bound by
+        // instruction issue, most of it exec-mask bookkeeping around the per-position guards).  The symbol rows are four
+        // positions longer than the longest read, so the four slides of a trip read unguarded; positions behind the loop's range
+        // are masked out of ONE "any first slot occupied" test, the only branch of a trip without a hit.
+        const int s = my_step;
+        const int L = M.steps[s];
+        if (L <= 0 || len - L <= 0) return;
+        const u32 salt = (u32)L * OVR_SALT_MUL, pw = M.pw[s];
+        const u32 sym0 = lds_addr_of(symv);
+        const u32 tab0 = lds_addr_of(lds + o.table_lds[slot >> 1]);
+#define SYMF(j) lds_read_u8_at(sym0 + (u32)(j) * (u32)OVR_SYM_STRIDE)
+#define TABF(w) lds_read_u32_at(tab0 + 4u * (u32)(w))
+        int i = 0;
+        u32 h = 0;
+        bool fresh = true;
+        while (i < len - L) {  // for (i = 0; i < len - step; i++) (:276)
+            if (fresh) {
+                h = 0;
+                for (int k = 0; k < L; k++) h = h * OVR_HASH_MUL + SYMF(i + k) + 1u;
+                fresh = false;
+            }
+            const int nb = imin(4, len - L - i);
+            u32 so[4], si[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                so[b] = SYMF(i + b);
+                si[b] = SYMF(i + b + L);
+            }
+            u32 hh[5];
+            hh[0] = h;
+#pragma unroll
+            for (int b = 0; b < 4; b++) hh[b + 1] = (hh[b] - (so[b] + 1u) * pw) * OVR_HASH_MUL + si[b] + 1u;
+            u32 s0[4], id0[4], anyid = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                s0[b] = ((hh[b] ^ salt) * OVR_SALT_MUL) & M.table_mask;
+                id0[b] = TABF(2u * s0[b] + 1u);
+                anyid |= b < nb ? id0[b] : 0u;
+            }
+            int hit = -1, hit_b = 0;
+            if (anyid != 0u) {   // an occupied first slot somewhere in the trip (rare): the probe as the table defines it
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if (b < nb && hit < 0 && id0[b] != 0u) {
+                        const u32 key = hh[b] ^ salt;
+                        for (u32 sl = s0[b];; sl = (sl + 1) & M.table_mask) {
+                            const u32 id1 = TABF(2u * sl + 1u);
+                            if (id1 == 0u) break;
+                            if (TABF(2u * sl) == key && M.seed_len[id1 - 1] == L) {
+                                const u8* sd = M.seed_sym + (size_t)(id1 - 1) * OVR_SEED_STRIDE;
+                                bool same = true;
+                                for (int k = 0; k < L && same; k++) same = sd[k] == (u8)SYMF(i + b + k);
+                                if (same) { hit = (int)id1 - 1; hit_b = b; break; }
+                            }
+                        }
+                    }
+                }
+            }
+            if (hit >= 0) {  // mOverRepSeq[seq]++, the covered positions of mOverRepSeqDist, i += step (:279-284)
+                const int at = i + hit_b;
+                g_atomic_add_i64(&cnt[hit], 1);
+                if (o.dist_diff[slot]) {
+                    const int e0 = imin(at, M.eval_len), e1 = imin(at + L, M.eval_len);
+                    if (e0 < e1) {
+                        int* dd = o.dist_diff[slot] + (size_t)hit * (M.eval_len + 1);
+                        g_atomic_add_i32(&dd[e0], 1);
+                        g_atomic_add_i32(&dd[e1], -1);
+                    }
+                } else {
+                    for (int pp = at; pp < at + L && pp < M.eval_len; pp++) g_atomic_add_i64(&dist[(size_t)hit * M.eval_len + pp], 1);
+                }
+                i = at + L + 1;
+                fresh = true;
+            } else {  // the window has slid by nb bases
+                h = nb == 4 ? hh[4] : nb == 3 ? hh[3] : nb == 2 ? hh[2] : hh[1];
+                i += nb;
+            }
+        }
+#undef SYMF
+#undef TABF
+    } else {
         const int s = my_step;
         const int L = M.steps[s];
         if (L <= 0 || len - L <= 0) return;

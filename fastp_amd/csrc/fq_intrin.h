@@ -244,6 +244,20 @@ FQ_DEV void lds_add_u32_at(u32 addr, u32 v) {
     __hip_atomic_fetch_add((__attribute__((address_space(3))) u32*)(size_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }
+FQ_DEV u32 lds_read_u8_at(u32 addr) {
+#ifdef FQ_HOSTSIM
+    return (u32)*((const u8*)::fq_lds + addr);
+#else
+    return (u32)*(const __attribute__((address_space(3))) u8*)(size_t)addr;
+#endif
+}
+FQ_DEV u32 lds_read_u32_at(u32 addr) {
+#ifdef FQ_HOSTSIM
+    return *(const u32*)((const u8*)::fq_lds + addr);
+#else
+    return *(const __attribute__((address_space(3))) u32*)(size_t)addr;
+#endif
+}
 // the value as it is, but opaque to the optimiser: what is computed from it stays computed from it
 FQ_DEV u32 opaque(u32 v) {
 #ifndef FQ_HOSTSIM
