@@ -14,7 +14,7 @@
 #include "fq_stats.h"
 #include "fq_stats5.h"
 #include "fq_lane.h"
-#include "fq_exact.h"
+#include "fq_text.h"
 #include "fq_inflate.h"
 #include "fq_eval.h"
 #include "fq_deflate.h"
@@ -216,11 +216,11 @@ extern "C" __global__ void __launch_bounds__(256) fq_fmts_write_kernel(FmtsArgs 
     extern __shared__ u32 fq_lds[];
     fmts_write_body(f, fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(512) fq_exact_kernel(ExactArgs e) {
+extern "C" __global__ void __launch_bounds__(64 * TEXT_WAVES) fq_text_kernel(TextArgs e) {
     extern __shared__ __attribute__((aligned(16))) u32 fq_lds[];
-    exact_body(e, fq_lds);
+    text_body(*kernel_args(&e), fq_lds);
 }
-extern "C" __global__ void __launch_bounds__(256) fq_exact_mask_kernel(ExactMaskArgs m) { exact_mask_body(m); }
+extern "C" __global__ void __launch_bounds__(256) fq_text_mask_kernel(TextMaskArgs m) { text_mask_body(m); }
 extern "C" __global__ void __launch_bounds__(256) fq_reduce_kernel(ReduceArgs r) { reduce_body(r); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_probe_kernel(DupArgs d) { dup_probe_body(d); }
 extern "C" __global__ void __launch_bounds__(256) fq_dup_claim_kernel(DupArgs d) { dup_claim_body(d); }
@@ -327,9 +327,8 @@ struct fastp_gpu_ctx {
     const void* last_corr = nullptr; int32_t last_corr_cap = 0;   // the correction list of the last submit and its capacity
     std::vector<std::string> ovr_strings[2];
     std::vector<const char*> ovr_ptrs[2];
-    // exact plan (fq_exact.h): the worker loop on the text, for units with letters outside ACGTN
+    // exact plan (fq_text.h): the worker loop on the text, for units with letters outside ACGTN
     bool exact_all = false;                                // FASTP_GPU_EXACT=1: every unit takes it (tests)
-    u8* d_x_scratch = nullptr; size_t x_scratch_cap = 0;   // [lanes][lane_bytes]
     int* d_x_unit = nullptr; size_t x_unit_cap = 0;        // the submitted batch's exotic unit list
     u8* d_x_skip = nullptr; size_t x_skip_cap = 0;          // KernelArgs::xskip of the launch
     u32* d_al[4] = {nullptr, nullptr, nullptr, nullptr}; size_t al_cap[4] = {0, 0, 0, 0};   // merge mode: 16-byte aligned copies of a launch's rows
@@ -426,7 +425,7 @@ extern "C" void fastp_gpu_destroy(fastp_gpu_ctx* ctx) {
                     ctx->d_ovr_table[0], ctx->d_ovr_table[1], ctx->d_ovr_sym[0], ctx->d_ovr_sym[1], ctx->d_ovr_len[0],
                     ctx->d_ovr_len[1], ctx->d_post_seen, ctx->d_ovr_work, ctx->d_parse, ctx->d_fmt, ctx->d_prefix, ctx->d_inf, ctx->d_ovr_corr, ctx->d_eval, ctx->d_def, ctx->d_setw, ctx->d_cfilter,
                     ctx->d_st_slabs, ctx->d_swin[0], ctx->d_swin[1], ctx->d_ln_slabs, ctx->d_ln_ctr,
-                    ctx->d_corr_int, ctx->d_corr_chain, ctx->d_x_scratch, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_skip, ctx->d_ovr_diff, ctx->d_al[0], ctx->d_al[1], ctx->d_al[2], ctx->d_al[3], ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
+                    ctx->d_corr_int, ctx->d_corr_chain, ctx->d_x_unit, ctx->d_x_len, ctx->d_x_skip, ctx->d_ovr_diff, ctx->d_al[0], ctx->d_al[1], ctx->d_al[2], ctx->d_al[3], ctx->d_x_text[0], ctx->d_x_text[1], ctx->d_x_off[0], ctx->d_x_off[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->tail) (void)hipStreamDestroy(ctx->tail);
@@ -749,7 +748,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     };
     set_launch_size();
     fastp_gpu_counter_layout_for_params(&ctx->params, &ctx->cl);
-    ctx->exact_all = env_int("FASTP_GPU_EXACT", 0) != 0;   // tests: every unit through the text kernel (fq_exact.h)
+    ctx->exact_all = env_int("FASTP_GPU_EXACT", 0) != 0;   // tests: every unit through the text kernel (fq_text.h)
     if (ctx->exact_all && env_int("FASTP_GPU_VERBOSE", 0)) fprintf(stderr, "fastp_gpu: FASTP_GPU_EXACT=1, every unit takes the text kernel\n");
     if (env_int("FASTP_GPU_VERBOSE", 0))
         fprintf(stderr, "fastp_gpu: %s, tile P=%d (%d rows), %d threads, LDS %d bytes, %d workgroups, %d units/launch; stats kernel form %d, %d x %d threads, LDS %d bytes\n",
@@ -881,7 +880,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         }
     }
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_ovr_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)fq_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)fq_text_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DefLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IwLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1161,7 +1160,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         a.n_adapter_events = res->n_adapter_events;
     }
     // Units with letters outside ACGTN (fastp_gpu_batch::exotic_*; FASTP_GPU_EXACT=1: every unit) take the text kernel
-    // (fq_exact.h).  The plan's kernels still run over the whole launch, on a copy of the length arrays in which those units
+    // (fq_text.h).  The plan's kernels still run over the whole launch, on a copy of the length arrays in which those units
     // are EMPTY; the text kernel then runs once over the listed units: it takes back what an empty unit added to the
     // counters (the same loop on an empty unit, sign -1), adds the real unit, and overwrites the unit's records and hash
     // values.  Duplicate's kernels run once over the whole launch afterwards: input order holds across both kinds.
@@ -1192,14 +1191,14 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             a.xskip = skip;
         }
         if (!ctx->exact_all) {
-            ExactMaskArgs mk;
+            TextMaskArgs mk;
             mk.units = ctx->d_x_unit + xk0;
             mk.count = xk1 - xk0;
             mk.first = first;
             mk.skip = skip;
             mk.len[0] = ctx->d_x_len;
             mk.len[1] = mates == 2 ? ctx->d_x_len + n : nullptr;
-            hipLaunchKernelGGL(fq_exact_mask_kernel, dim3((mk.count + 255) / 256), dim3(256), 0, st, mk);
+            hipLaunchKernelGGL(fq_text_mask_kernel, dim3((mk.count + 255) / 256), dim3(256), 0, st, mk);
             HIP_TRY(ctx, hipGetLastError());
         }
     }
@@ -1310,12 +1309,18 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
                               env_int("FASTP_GPU_CLAIM_FUSED", 1);   // (the fold IS the fused claim: without it the hash pre-pass decides)
     // the claim step inside the fused kernel: plain stream mode, one or two bloom buffers (the lane kernel: four as well), the
     // context's own stream order
+    // ... and a launch with units for the text kernel when that kernel runs beside the lane kernel (exact_early below): the lane kernel
+    // claims nothing for such a unit (KernelArgs::xskip), the text kernel claims its units' bits itself (fq_text.h t_claim) and
+    // Duplicate's tail - which orders the claims by unit index, whoever fired them first - runs behind both
+    const bool exact_early = exact && use_lane && a.xskip != nullptr && !piped && env_int("FASTP_GPU_EXACT_EARLY", 1) != 0;
     const bool claim_fused = ctx->dp.dup_enabled && (!ctx->dp.dedup || dedup_folded) && mode == CHUNK_STREAM && !piped &&
-                             (ctx->dp.dup_bufnum <= 2 || dedup_folded) && !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1) && !exact;
-    // the text kernel: a lane per unit with a private stretch of HBM for its text buffers; counters straight into d_ctr
+                             (ctx->dp.dup_bufnum <= 2 || dedup_folded) && !env_int("FASTP_GPU_DUP_TABLE", 0) && env_int("FASTP_GPU_CLAIM_FUSED", 1) &&
+                             (!exact || (exact_early && env_int("FASTP_GPU_EXACT_CLAIM", 1)));
+    // the text kernel (fq_text.h): a wavefront per listed unit, its texts in the wavefront's stretch of LDS, Stats' per-base
+    // counters in the workgroup's LDS tables (added to d_ctr once), everything else straight into d_ctr
     auto launch_exact = [&](int hash_only, hipStream_t xst = nullptr) -> int {
         hipStream_t st = xst ? xst : st_main;   // (shadows the launch stream: the text kernel may run beside the Stats kernel)
-        ExactArgs e;
+        TextArgs e;
         memset(&e, 0, sizeof(e));
         e.k = a;
         const fastp_gpu_counter_layout& c = ctx->cl;
@@ -1333,25 +1338,20 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         e.x_all = ctx->exact_all ? 1 : 0;
         e.x_k0 = xk0;
         e.x_count = ctx->exact_all ? n : xk1 - xk0;
-        e.sign = 1;
-        e.ghost = 0;
         e.x_dense = b->exotic_dense;
         for (int m = 0; m < 2; m++) { e.x_text[m] = b->exotic_text[m]; e.x_off[m] = b->exotic_off[m]; }
         e.ML = (ctx->dp.max_len + 8 + 7) & ~7;
-        e.lane_bytes = (u32)(EXACT_BUFS * e.ML + EXACT_ADAPTER_BYTES);
         e.hash_only = hash_only;
-        // Stats' per-base tables of a workgroup in LDS when four of them fit (not the hash pre-pass, which counts nothing)
+        // Stats' per-base tables of a workgroup in LDS when they fit beside the wavefronts' texts (not the hash pre-pass, which
+        // counts nothing; reads too long for it add to the block with global atomics)
+        const size_t text_bytes = (size_t)TEXT_WAVES * text_wave_bytes(e.ML);
         const int slot_dwords = 34 * (int)c.cycles + 1024 + 128;
         const int slots = !ctx->dp.paired ? 2 : ctx->dp.merge ? 3 : 4;   // the Stats objects a unit can reach
-        const bool lds_tables = !hash_only && (size_t)slots * slot_dwords * 4 <= (size_t)150 * 1024 && env_int("FASTP_GPU_EXACT_LDS", 1);
+        const bool lds_tables = !hash_only && (size_t)slots * slot_dwords * 4 + text_bytes <= (size_t)150 * 1024 && env_int("FASTP_GPU_EXACT_LDS", 1);
         e.lds_slot_dwords = lds_tables ? slot_dwords : 0;
         e.lds_slots = lds_tables ? slots : 0;
-        const int wg = lds_tables ? 512 : 64;   // one 512-lane workgroup per CU owns the tables; without them small workgroups
-        const int lanes = std::min((e.x_count + wg - 1) / wg * wg, env_int("FASTP_GPU_EXACT_LANES", lds_tables ? ctx->cus * 512 : 16384) / wg * wg);
-        int r2 = ensure(ctx, (void**)&ctx->d_x_scratch, &ctx->x_scratch_cap, (size_t)lanes * e.lane_bytes);
-        if (r2) return r2;
-        e.scratch = ctx->d_x_scratch;
-        hipLaunchKernelGGL(fq_exact_kernel, dim3(lanes / wg), dim3(wg), (size_t)e.lds_slots * e.lds_slot_dwords * 4, st, e);
+        const int blocks = std::max(1, std::min((e.x_count + TEXT_WAVES - 1) / TEXT_WAVES, env_int("FASTP_GPU_EXACT_BLOCKS", ctx->cus)));
+        hipLaunchKernelGGL(fq_text_kernel, dim3(blocks), dim3(64 * TEXT_WAVES), (size_t)e.lds_slots * e.lds_slot_dwords * 4 + text_bytes, st, e);
         HIP_TRY(ctx, hipGetLastError());
         return 0;
     };
@@ -1484,7 +1484,6 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     // BESIDE the lane kernel (which counts such a unit as the empty unit it sees and writes nothing of it, KernelArgs::xskip)
     // and the Stats kernel (to which it is an empty read); Duplicate's kernels wait for both.  A launch with a handful of such
     // units used to wait 2.6 - 3.1 ms for one lane's walk between the two kernels.
-    bool exact_early = exact && use_lane && a.xskip != nullptr && !piped && env_int("FASTP_GPU_EXACT_EARLY", 1) != 0;
     if (!exact_early) a.xskip = nullptr;
     if (exact_early) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
@@ -1820,7 +1819,7 @@ static int submit_chunks(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, const fas
         if (res->n_adapter_events) HIP_TRY(ctx, hipMemsetAsync(res->n_adapter_events, 0, sizeof(int32_t), st));
     }
     if (b->n_exotic > 0) {
-        // units with letters outside ACGTN: the text kernel (fq_exact.h) takes them, launch by launch (launch_chunk)
+        // units with letters outside ACGTN: the text kernel (fq_text.h) takes them, launch by launch (launch_chunk)
         if (!b->exotic_unit || !b->exotic_text[0] || !b->exotic_off[0] || (ctx->dp.paired && (!b->exotic_text[1] || !b->exotic_off[1])))
             return fail(ctx, FASTP_GPU_E_INVALID, "n_exotic > 0 needs exotic_unit, exotic_text and exotic_off");
         for (int k = 0; k < b->n_exotic; k++)

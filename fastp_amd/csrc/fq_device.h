@@ -3856,7 +3856,7 @@ FQ_DEV void parse_pack_body(const ParseArgs& p) {
             const u32 q_lt33 = ~(((qw & 0x7F7F7F7Fu) | 0x80808080u) - 0x21212121u) & 0x80808080u;
             const u32 q_127 = zero_bytes(qw ^ 0x7F7F7F7Fu);
             if ((qw & 0x80808080u) | ((q_lt33 | q_127) & live)) alpha_bad = true;
-            // a letter outside ACGTN: the record is listed for the text kernel (fq_exact.h) - its packed row is a placeholder
+            // a letter outside ACGTN: the record is listed for the text kernel (fq_text.h) - its packed row is a placeholder
             const u32 fm = ~(is_letter | is_n) & live;
             if (fm) foreign = true;
             const u32 zero = is_n | fm;

@@ -578,7 +578,7 @@ static int pack_reads(int max_len, int n, const char* const* seqs, const char* c
                 if (bad_read) *bad_read = i;
                 return FASTP_GPU_E_ALPHABET;
             }
-            if (foreign) exotic[i] = 1;   // the unit goes through the text kernel (fq_exact.h); its packed row is a placeholder
+            if (foreign) exotic[i] = 1;   // the unit goes through the text kernel (fq_text.h); its packed row is a placeholder
             uint64_t code = (c >> 1) & 0x0303030303030303ull;
             code = ((code >> 1) | (code << 1)) & 0x0303030303030303ull;   // swap the two bits: A 0, T 1, C 2, G 3
             code &= ~(((isn | foreign) >> 7) * 3ull);                     // an N (and a foreign letter) is code 0

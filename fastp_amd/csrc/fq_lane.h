@@ -1159,6 +1159,12 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
             D[w] = !go ? 0u : (rem >= 16 ? dd : (rem <= 0 ? 0u : (dd & lowmask32(2 * rem))));
         }
     }
+#ifdef FQ_PROFILE_ABLATION
+    const u32 abl = a.debug_skip;   // profiling build only: 1024 no list entries, 2048 no edits, 4096 the mismatch words only
+    if (abl & 4096u) { if (D[0] == 0xFFFFFFFFu) geom = 2; return; }
+#else
+    const u32 abl = 0;
+#endif
     int corrected = 0;
     bool r1c = false, r2c = false;
     auto next_mismatch = [&]() -> int {                        // the smallest mismatch position left (taken out of D), or -1
@@ -1211,15 +1217,15 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
     for (int t = 0; t < 4; t++) {
         if (ballot(pi[t] >= 0) == 0ull) break;
         em_which = -1;
-        if (pi[t] >= 0) edit(pi[t], pq[t]);
-        lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
+        if (pi[t] >= 0 && !(abl & 2048u)) edit(pi[t], pq[t]);
+        if (!(abl & 1024u)) lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
     }
     for (;;) {
         const int i = next_mismatch();
         if (ballot(i >= 0) == 0ull) break;
         em_which = -1;
-        if (i >= 0) edit(i, (u32)q1row[fr1 + o1 + i] & 0x7Fu);
-        lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
+        if (i >= 0 && !(abl & 2048u)) edit(i, (u32)q1row[fr1 + o1 + i] & 0x7Fu);
+        if (!(abl & 1024u)) lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
     }
     if (corrected > 0) {                                           // :75-80
         lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);

@@ -264,7 +264,7 @@ struct ParseArgs {
     u32 max_lines;
     u32* totals;          // [0] terminators, [1] first bad record (atomic min), [2] lines incl. unterminated tail,
                           // [3] records, [4] bytes consumed, [5] longest sequence line, [6] records with letters outside ACGTN
-    u32* exotic_list;     // [exotic_cap] those records (unordered), for the text kernel (fq_exact.h)
+    u32* exotic_list;     // [exotic_cap] those records (unordered), for the text kernel (fq_text.h)
     u32 exotic_cap;
     // packing
     int max_len, sw_g, qw_g, max_records;
