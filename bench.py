@@ -29,7 +29,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 G
 # the kernels whose summed duration per launch is `roofline.kernel_avg_ms` (one HIP-event pair around them)
 KERNELS = {"fused": "fq_fused_kernel",
            "split": "fq_scan_kernel + fq_stats_kernel (the fused kernel's work as two launches)",
-           "lane": "fq_lane_kernel + fq_stats_kernel (the fused kernel's work as two launches)"}
+           "lane": "fq_lane_kernel + fq_stats5_kernel (the fused kernel's work as two launches; form 5 of the Stats kernel at this read length)"}
 L = 150
 
 
@@ -342,7 +342,7 @@ def other_configs(dev, only=None):
         for m in ("1", "2") if paired else ("1",):
             bufs[m] = synth_torch.pack_torch(d["seq" + m], d["qual" + m], d["len" + m], Lr)
         xkeep = None
-        if soft_masked_every:   # every k-th unit in lower case: letters outside ACGTN, the text kernel (fq_exact.h) takes those units
+        if soft_masked_every:   # every k-th unit in lower case: letters outside ACGTN, the text kernel (fq_text.h) takes those units
             xu = np.arange(0, n, soft_masked_every, dtype=np.int32)
             xt = torch.from_numpy(xu.astype(np.int64)).to(dev)
             xkeep = [xu]

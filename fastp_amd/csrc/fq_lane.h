@@ -1122,6 +1122,36 @@ FQ_DEV void lane_emit_corrections(const KernelArgs& a, int lane, int gp, int whi
     if (which >= 0 && base + rank < a.corr_int_cap) { a.corr_int[2 * (base + rank)] = w0; a.corr_int[2 * (base + rank) + 1] = w1; }
     if (a.corrections && which >= 0 && cb + rank < a.corr_capacity) { a.corrections[2 * (cb + rank)] = w0; a.corrections[2 * (cb + rank) + 1] = w1; }
 }
+// The same for a whole chunk: a lane keeps its first two edits (the list's second word each; which read: bits 2 / 3 of `st`, how
+// many: its low two bits) and the wavefront takes the slots of all of them with ONE atomic per list when the rounds are over.
+// Measured on the -c line (profiles/r06_l_corr_rounds_ablation.txt): the per-round form - a ballot, a returning atomic per
+// list and the stores in EVERY round that edits - was 0.12 of the correction rounds' 0.20 ms per 2 Mi pairs.  A lane's third
+// and later edits (rare) still go out round by round.
+FQ_DEV void lane_flush_corrections(const KernelArgs& a, int lane, int gp, u32 st, u32 e0, u32 e1) {
+    const u32 n = st & 3u;
+    const u64 m1 = ballot(n >= 1u), m2 = ballot(n >= 2u);
+    if (m1 == 0ull) return;
+    const int cnt = popc64(m1) + popc64(m2), leader = ffs64(m1) - 1;
+    const u64 below = (1ull << lane) - 1ull;
+    const int rank = popc64(m1 & below) + popc64(m2 & below);
+    int base = 0, cb = 0;
+    if (lane == leader) {
+        base = g_atomic_add_i32(a.n_corr_int, cnt);   // never full: sized for an edit at every base of every pair
+        if (a.corrections) cb = g_atomic_add_i32(a.n_corrections, cnt);
+    }
+    base = (int)shfl((u32)base, leader);
+    cb = (int)shfl((u32)cb, leader);
+    const u32 r0 = (u32)(2 * (a.first + gp));
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (n > (u32)k) {
+            const u32 w0 = r0 + ((st >> (2 + k)) & 1u), w1 = k ? e1 : e0;
+            const int si = base + rank + k, sc = cb + rank + k;
+            if (si < a.corr_int_cap) { a.corr_int[2 * si] = w0; a.corr_int[2 * si + 1] = w1; }
+            if (a.corrections && sc < a.corr_capacity) { a.corrections[2 * sc] = w0; a.corrections[2 * sc + 1] = w1; }
+        }
+    }
+}
 // key = the pair's accepted overlap (no gap), l1 / l2 the lengths it was found on; rc / rcn = rc(r2') as the scan built it.
 // q1row: read 1's quality row in memory, q2row: read 2's in the stage (both at the ORIGINAL read's start).  nc1 = entries of clist.
 template <int SWM>
@@ -1205,6 +1235,15 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
             r1c = true;
         }
     };
+    u32 rec_st = 0, rec0 = 0, rec1 = 0;                         // the lane's first two edits, for the lists (lane_flush_corrections)
+    auto record = [&]() {                                      // this round's edit: kept, or (a third one) sent right away
+        const u32 n = rec_st & 3u;
+        const bool have = em_which >= 0;
+        const u32 w1 = (u32)em_pos | (sym_ascii(em_nb) << 16) | (em_nq << 24);
+        if (have && n == 0u) { rec0 = w1; rec_st = 1u | ((u32)em_which << 2); }
+        else if (have && n == 1u) { rec1 = w1; rec_st = (rec_st & ~3u) | 2u | ((u32)em_which << 3); }
+        if (ballot(have && n >= 2u) != 0ull) lane_emit_corrections(a, lane, gp, (have && n >= 2u) ? em_which : -1, em_pos, em_nb, em_nq);
+    };
     // read 1's quality at a mismatch comes from memory (its rows have left the stage): the first four positions' bytes are
     // asked for together - one round trip for nearly every pair - the rest one per round
     int pi[4];
@@ -1218,15 +1257,16 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
         if (ballot(pi[t] >= 0) == 0ull) break;
         em_which = -1;
         if (pi[t] >= 0 && !(abl & 2048u)) edit(pi[t], pq[t]);
-        if (!(abl & 1024u)) lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
+        if (!(abl & 1024u)) record();
     }
     for (;;) {
         const int i = next_mismatch();
         if (ballot(i >= 0) == 0ull) break;
         em_which = -1;
         if (i >= 0 && !(abl & 2048u)) edit(i, (u32)q1row[fr1 + o1 + i] & 0x7Fu);
-        if (!(abl & 1024u)) lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq);
+        if (!(abl & 1024u)) record();
     }
+    lane_flush_corrections(a, lane, gp, rec_st, rec0, rec1);
     if (corrected > 0) {                                           // :75-80
         lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
         if (r1c) r1.flags |= RS_CORRECTED;

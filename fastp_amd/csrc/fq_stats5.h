@@ -11,11 +11,9 @@
 //     the unrolled loop.  A workgroup takes at most CYC_MAX_READS (16383) units, a cell sees at most one base per unit: no
 //     half ever carries into the other;
 //   * the FAST path takes an item whose 16 bases all exist, hold no N (nor do the 4 in front), have qualities below
-//     '!' + ST5_QN, and are all kept or all dropped (the slot is then part of the item's base address).  Everything else is
-//     queued in one of two per-WAVEFRONT lists (ballot + prefix count: no atomic, no workgroup barrier) and taken by all 64
-//     lanes whenever 64 are queued: a read's last, ragged item and the item a trim ends in - clean otherwise - by the same
-//     unrolled body with a per-base guard and a per-base slot (stats5_cells<MASKED>); items with an N, exotic qualities or a
-//     front trim's boundary base by base (stats5_item_general);
+//     '!' + ST5_QN, and are all kept or all dropped (the slot is then part of the item's base address).  Everything else - a
+//     read's last, ragged item, the item a trim ends in, items with an N, exotic qualities - is queued in a per-WAVEFRONT list
+//     (ballot + prefix count: no atomic, no workgroup barrier) and taken base by base by all 64 lanes whenever 64 are queued;
 //   * N bases and qualities outside the table go to a small packed-u64 table [slot][cycle][class] and the histogram proper;
 //   * flush: cnt = sum over q, q20 = sum over q >= 20, q30 = sum over q >= 30, qsum = sum of q x cell, histogram = sum over
 //     (cycle, class) - once per workgroup and mate, into the slab's canonical packed form (reduce_body is unchanged).
@@ -113,10 +111,8 @@ FQ_DEV void stats5_fetch(const StatsArgs& a, const Stats5Src& src, u32 u, u32 h,
 // The cells of one item whose bases [0, nv) are clean (no N among them or the four in front, qualities the table has rows for)
 // and all in one slot: 6 VALU + 2 DS instructions per base - two field extracts and two multiply-adds for the cell, an extract
 // and a shift-add for the 5-mer.  MASKED: nv < 16 (a read's last item), the lanes of a wavefront stop at their own nv.
-// and, MASKED only, take their slot base by base: bases [0, nk) of the item are kept ones (ib / kb then name the DROPPED slot): the
-// item a trim ends in costs a compare, two selects and two adds per base more - not the base-by-base path's 47 instructions.
 template <int KC, bool MASKED, bool ABL>
-FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb, const Stats5Item& s, u32 h, int nv, int nk = 16, u32 slotK = 0u) {
+FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb, const Stats5Item& s, u32 h, int nv) {
     const u32 qadd = 0x01010101u * (u32)ST5_QADD;
     const u32 ev[4] = {s.q[0] + qadd, s.q[1] + qadd, s.q[2] + qadd, s.q[3] + qadd};   // byte q + ST5_QADD: row q - 33 (ib holds the difference)
     const u32 c_lo = s.prev8 | (s.codes << 8);    // bases j0 - 4 .. j0 + 11
@@ -128,13 +124,11 @@ FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb,
         if (!MASKED || k < nv) {
             const u32 e = bfe(ev[k >> 2], 8 * (k & 3), 8);
             const u32 cl = bfe(s.codes, 2 * k, 2);
-            const bool kp = MASKED && k < nk;
-            const u32 ibk = MASKED ? ib + (kp ? g.S4 : 0u) : ib, kbk = MASKED ? kb + (kp ? slotK : 0u) : kb;
-            const u32 t = mad24_su(cl, g.C4, ibk);
+            const u32 t = mad24_su(cl, g.C4, ib);
             const u32 ca = mad24_su(e, g.HS4, t);
             if (!ABL || !(a.debug_skip & 64u)) lds_add_u32_at(ca + (u32)(k & 7) * g.K4, k < 8 ? 1u : 0x10000u);
             const u32 x = k < 8 ? bfe(c_lo, 2 * k, 10) : bfe(c_hi, 2 * k - 16, 10);
-            if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kbk), k < 4 ? hpos : 1u);
+            if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kb), k < 4 ? hpos : 1u);
         }
     }
 }
@@ -203,7 +197,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     const u32 lu = HS ? (u32)lane / (u32)HS : (u32)lane / (u32)HB;
     const u32 hl = (u32)lane - lu * (u32)HB;                      // the lane's column inside a block
     const int ustride = (nt >> 6) * upw;
-    u16* wlT = (u16*)(lds + a.l_wl) + (tid >> 6) * (2 * ST5_WL);   // this wavefront's two lists: clean last items / items a trim ends in ...
+    u16* wlT = (u16*)(lds + a.l_wl) + (tid >> 6) * (2 * ST5_WL);   // this wavefront's two lists: a read's clean last item ...
     u16* wlG = wlT + ST5_WL;                                      // ... and everything else the fast path does not take
     u32* slab = a.slabs + (size_t)block_id() * a.slab_dwords;
     const int n_cyc = 4 * a.Cp * N_CLS;                           // u64 items of the slab's per-cycle part
@@ -263,13 +257,12 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                         const int F = s.F, Fk = F > 0 ? F + 4 : 0;
                         const bool kept = j0 >= Fk && nk >= imin(nv, 16);              // every base of the item (and its 5-mer) is a kept one
                         const bool drop = nk <= 0 || j0 + 16 <= F;                     // ... a dropped one
-                        const bool mixed = F == 0 && !kept && !drop;                   // a trim ends inside the item (no front trim): the masked path
-                        const bool clean = act && dirty == 0u && (kept || drop || mixed);
-                        const bool fast = clean && nv >= 16 && !mixed;
-                        const u64 mT = ballot(clean && !fast), mG = ballot(act && !clean);
+                        const bool clean = act && dirty == 0u && (kept || drop);
+                        const bool fast = clean && nv >= 16;
+                        const u64 mT = ballot(clean && nv < 16), mG = ballot(act && !clean);
                         const u32 ent = ((u32)(tr + d) << 6) | ent_lane;
                         if (mT) {                                 // (uniform) positions by a prefix count over the ballot: no atomic
-                            if (clean && !fast) wlT[wnT + lane_rank(mT)] = (u16)ent;
+                            if (clean && nv < 16) wlT[wnT + lane_rank(mT)] = (u16)ent;
                             wnT += popc64(mT);
                         }
                         if (mG) {
@@ -299,10 +292,8 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     stats5_fetch(a, src, on ? uu : 0u, hh, t);
                     const int tj0 = 16 * (int)hh;
                     const int tnv = t.rl0 - tj0;
-                    // queued as all kept, all dropped, or (no front trim) kept up to the trim's end inside the item: bases [0, tnk) are kept
-                    const bool tk = tj0 >= (t.F > 0 ? t.F + 4 : 0) && t.lk - tj0 >= imin(tnv, 16);
-                    const int tnk = t.F == 0 ? imax(0, imin(16, t.lk - tj0)) : (tk ? 16 : 0);
-                    stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + hq * 4u), opaque(kmer_b), t, hh, on ? tnv : 0, tnk, slotK);
+                    const bool tk = tj0 >= (t.F > 0 ? t.F + 4 : 0) && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
+                    stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (tk ? g.S4 : 0u) + hq * 4u), opaque(kmer_b + (tk ? slotK : 0u)), t, hh, on ? tnv : 0);
                     wave_sync();
                 }
                 while (wnG >= 64 || (!more && wnG > 0)) {         // (uniform)

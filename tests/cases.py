@@ -100,7 +100,7 @@ CASES["pe_merge_overlapped_out_trims"] = (True, ["-G", "-m", "--include_unmerged
                                           {"insert_mean": 170.0, "polyx_frac": 0.2})
 # letters outside ACGTN: soft-masked stretches and reads, IUPAC codes, '.' - the reference
 # bins them by `base & 7`, hashes them as 13, complements a/c/g/t to T/G/C/A and the rest to N, compares raw bytes
-# everywhere else; the engine runs those units through the text kernel (fq_exact.h)
+# everywhere else; the engine runs those units through the text kernel (fq_text.h)
 CASES["pe_exotic_default"] = (True, ["-G", "--cut_right", "--overlapped_out", "@TMP@/overlapped.fq"], _pe(cut_right=1, overlapped_out=1),
                               {"insert_mean": 190.0, "exotic_frac": 0.12})
 CASES["pe_exotic_merge"] = (True, ["-G", "-m", "--include_unmerged", "--merged_out", "@TMP@/merged.fq", "-x", "-y", "--cut_front", "--cut_tail"],

@@ -68,7 +68,7 @@ def test_gpu_equals_reference_golden(name):
                                   "pe_noadapter_dedup", "pe_overrep", "pe_polyg_polyx", "pe_merge_overlapped_out_trims",
                                   "se_adapter_long_indel", "se_polyx_complexity", "pe_exotic_merge"])
 def test_gpu_text_kernel_on_every_unit_equals_reference_golden(name, monkeypatch):
-    """FASTP_GPU_EXACT=1: the plan's kernels see only empty reads, every unit goes through the text kernel (fq_exact.h) -
+    """FASTP_GPU_EXACT=1: the plan's kernels see only empty reads, every unit goes through the text kernel (fq_text.h) -
     the kernel that takes the units with letters outside ACGTN - and through its compensation of the empty units"""
     monkeypatch.setenv("FASTP_GPU_EXACT", "1")
     fq1, fq2, meta = golden_util.load(name)

@@ -93,7 +93,7 @@ def random_case(seed):
         p.adapter_seq_r1 = cases.LONG_R1.encode()
         if paired:
             p.adapter_seq_r2 = cases.LONG_R2.encode()
-    # letters outside ACGTN (soft-masked stretches, IUPAC codes, '.'): the text kernel (fq_exact.h) takes those units
+    # letters outside ACGTN (soft-masked stretches, IUPAC codes, '.'): the text kernel (fq_text.h) takes those units
     # (with -p the seeds were evaluated on the reads as they were before: seeds are ACGTN, fq_host.cpp refuses others)
     if pick(0.3):
         synth.add_exotic(d, seed=seed, read_frac=float(rng.choice([0.005, 0.05, 0.4])), paired=paired)

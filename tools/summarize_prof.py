@@ -72,7 +72,7 @@ for extra in ("bench.log", "phase.log"):
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 # what bench.py reports as roofline.traffic: HBM bytes per launch of the kernels that run the worker loop (the fused
 # kernel, or the per-read kernel + the Stats kernel of the split / lane plan), PMC-derived
-main = [k for k in out["kernels"] if k == "fq_fused_kernel" or k.startswith("fq_scan") or "fq_lane_kernel" in k or k == "fq_stats_kernel"]
+main = [k for k in out["kernels"] if k == "fq_fused_kernel" or k.startswith("fq_scan") or "fq_lane_kernel" in k or k in ("fq_stats_kernel", "fq_stats5_kernel")]
 main = [k for k in main if "hbm_bytes_per_launch" in out["kernels"][k]]
 if main:
     tot = {f: sum(out["kernels"][k][f] for k in main) for f in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch")}
@@ -91,7 +91,7 @@ for d in sorted(glob.glob(os.path.join(src, tag + "_sq*"))):
     for fcsv in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fcsv)):
             kn = r["Kernel_Name"]
-            if "fq_lane_kernel" in kn or kn in ("fq_stats_kernel", "fq_fused_kernel", "fq_scan_kernel"):
+            if "fq_lane_kernel" in kn or kn in ("fq_stats_kernel", "fq_stats5_kernel", "fq_fused_kernel", "fq_scan_kernel"):
                 sq["fq_lane_kernel" if "fq_lane_kernel" in kn else kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if sq:
     per = {}
