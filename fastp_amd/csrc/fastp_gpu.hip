@@ -85,7 +85,16 @@ extern "C" __global__ void __launch_bounds__(1024) fq_stats5_kernel(StatsArgs a)
 #ifdef FQ_PROFILE_ABLATION
     if ((a.debug_skip & 0xC0u) && a.Hs == 10 && a.kc == 2) { stats_body5<2, 10, true>(a, fq_lds); return; }   // profiling build only
 #endif
-    if (a.Hs == 10 && a.kc == 2) stats_body5<2, 10, false>(a, fq_lds);   // reads of up to 160 bases (uniform)
+#ifndef FQ_ST5_ONEBLK
+#define FQ_ST5_ONEBLK 1   // (A/B: 0 = the block form for every length, tools/gpu_r6_n.sh)
+#endif
+#ifndef FQ_ST5_NOFRONT
+#define FQ_ST5_NOFRONT 1   // (A/B: 0 = the front read from the arguments / the records whatever the options)
+#endif
+    const bool nofront = FQ_ST5_NOFRONT && !a.front_per_read && a.front[0] == 0 && a.front[1] == 0;   // (uniform)
+    if (FQ_ST5_ONEBLK && a.Hs == 10 && a.kc == 2 && a.H16 <= 10 && nofront) stats_body5<2, 10, false, true, true>(a, fq_lds);   // reads of up to 160 bases, no front trim
+    else if (FQ_ST5_ONEBLK && a.Hs == 10 && a.kc == 2 && a.H16 <= 10) stats_body5<2, 10, false, true>(a, fq_lds);   // reads of up to 160 bases (uniform)
+    else if (a.Hs == 10 && a.kc == 2) stats_body5<2, 10, false>(a, fq_lds);
     else if (a.Hs == 8 && a.kc == 2) stats_body5<2, 8, false>(a, fq_lds);  // two blocks of eight columns: reads of up to 256 bases
     else if (a.kc == 2) stats_body5<2, 0, false>(a, fq_lds);
     else stats_body5<1, 0, false>(a, fq_lds);

@@ -1122,6 +1122,9 @@ FQ_DEV void lane_emit_corrections(const KernelArgs& a, int lane, int gp, int whi
     if (which >= 0 && base + rank < a.corr_int_cap) { a.corr_int[2 * (base + rank)] = w0; a.corr_int[2 * (base + rank) + 1] = w1; }
     if (a.corrections && which >= 0 && cb + rank < a.corr_capacity) { a.corrections[2 * (cb + rank)] = w0; a.corrections[2 * (cb + rank) + 1] = w1; }
 }
+#ifndef FQ_CORR_FLUSH
+#define FQ_CORR_FLUSH 1   // (A/B: 0 = a list entry per round, tools/gpu_r6_n.sh)
+#endif
 // The same for a whole chunk: a lane keeps its first two edits (the list's second word each; which read: bits 2 / 3 of `st`, how
 // many: its low two bits) and the wavefront takes the slots of all of them with ONE atomic per list when the rounds are over.
 // Measured on the -c line (profiles/r06_l_corr_rounds_ablation.txt): the per-round form - a ballot, a returning atomic per
@@ -1257,16 +1260,16 @@ FQ_DEV void lane_correct(const KernelArgs& a, u32* misc, LaneRead<SWM>& r1, Lane
         if (ballot(pi[t] >= 0) == 0ull) break;
         em_which = -1;
         if (pi[t] >= 0 && !(abl & 2048u)) edit(pi[t], pq[t]);
-        if (!(abl & 1024u)) record();
+        if (!(abl & 1024u)) { if (FQ_CORR_FLUSH) record(); else lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq); }
     }
     for (;;) {
         const int i = next_mismatch();
         if (ballot(i >= 0) == 0ull) break;
         em_which = -1;
         if (i >= 0 && !(abl & 2048u)) edit(i, (u32)q1row[fr1 + o1 + i] & 0x7Fu);
-        if (!(abl & 1024u)) record();
+        if (!(abl & 1024u)) { if (FQ_CORR_FLUSH) record(); else lane_emit_corrections(a, lane, gp, em_which, em_pos, em_nb, em_nq); }
     }
-    lane_flush_corrections(a, lane, gp, rec_st, rec0, rec1);
+    if (FQ_CORR_FLUSH) lane_flush_corrections(a, lane, gp, rec_st, rec0, rec1);
     if (corrected > 0) {                                           // :75-80
         lds_add_u32(&misc[MISC_CORRECTED_READS], (r1c && r2c) ? 2u : 1u);
         if (r1c) r1.flags |= RS_CORRECTED;

@@ -23,6 +23,9 @@
 #pragma once
 #include "fq_stats.h"
 
+#ifndef FQ_ST5_BOUNDARY
+#define FQ_ST5_BOUNDARY 1   // the clean item a trim ends in takes the masked path (a per-base slot) instead of the base-by-base one (A/B: 0.927 -> 0.916 ms, profiles/r06_n_*)
+#endif
 #ifndef FQ_ST5_DEPTH
 #define FQ_ST5_DEPTH 3   // trips whose loads a wavefront keeps in flight (A/B: tools/gpu_r6_c.sh)
 #endif
@@ -73,11 +76,12 @@ struct Stats5Src {   // one mate's arrays at the workgroup's first unit
     const u32* frec;   // StatsArgs::fr_rec
     int F0;            // StatsArgs::front of the mate
 };
+template <bool NF = false>   // NF: no front trim of any kind in this run (the kept range starts at base 0): no record is read
 FQ_DEV void stats5_issue(const StatsArgs& a, const Stats5Src& src, u32 u, u32 h, Stats5Raw& r) {
     const u32* qual = src.qual;
     const u32* seq = src.seq;
     const u32* swin = src.swin;
-    r.fr = src.frec[mul24(u, (u32)a.fr_stride)];
+    r.fr = NF ? 0u : src.frec[mul24(u, (u32)a.fr_stride)];
     const bool has23 = 4u * h + 4u <= (u32)a.qw_g;    // (the last item of a row may be half a vector)
     const u32 qd = mul24(u, (u32)a.qw_g) + 4u * h;      // dword of the row's quality bytes (rows are 8-byte aligned)
     const u32 sd = mul24(u, (u32)a.sw_g) + h;
@@ -88,8 +92,9 @@ FQ_DEV void stats5_issue(const StatsArgs& a, const Stats5Src& src, u32 u, u32 h,
     r.cd = seq[sd];
     r.p8 = (u32)((const u8*)seq)[4u * sd - (h > 0 ? 1u : 0u)];
 }
+template <bool NF = false>
 FQ_DEV void stats5_finish(const StatsArgs& a, const Stats5Src& src, u32 h, const Stats5Raw& r, Stats5Item& s) {
-    s.F = a.front_per_read ? (int)(r.fr & 0xFFFFu) : src.F0;
+    s.F = NF ? 0 : (a.front_per_read ? (int)(r.fr & 0xFFFFu) : src.F0);
     const bool has23 = 4u * h + 4u <= (u32)a.qw_g;
     const u32 m23 = has23 ? 0xFFFFFFFFu : 0u, mh = h > 0 ? 0xFFFFFFFFu : 0u;
     s.q[0] = (u32)r.q01;
@@ -102,17 +107,19 @@ FQ_DEV void stats5_finish(const StatsArgs& a, const Stats5Src& src, u32 h, const
     s.rl0 = (int)(r.sw & 0xFFFFu);
     s.lk = (int)(r.sw >> 16);
 }
+template <bool NF = false>
 FQ_DEV void stats5_fetch(const StatsArgs& a, const Stats5Src& src, u32 u, u32 h, Stats5Item& s) {
     Stats5Raw r;
-    stats5_issue(a, src, u, h, r);
-    stats5_finish(a, src, h, r, s);
+    stats5_issue<NF>(a, src, u, h, r);
+    stats5_finish<NF>(a, src, h, r, s);
 }
 
 // The cells of one item whose bases [0, nv) are clean (no N among them or the four in front, qualities the table has rows for)
 // and all in one slot: 6 VALU + 2 DS instructions per base - two field extracts and two multiply-adds for the cell, an extract
 // and a shift-add for the 5-mer.  MASKED: nv < 16 (a read's last item), the lanes of a wavefront stop at their own nv.
+// FQ_ST5_BOUNDARY, MASKED only: bases [0, nk) of the item are kept ones (ib / kb then name the DROPPED slot)
 template <int KC, bool MASKED, bool ABL>
-FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb, const Stats5Item& s, u32 h, int nv) {
+FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb, const Stats5Item& s, u32 h, int nv, int nk = 16, u32 slotK = 0u) {
     const u32 qadd = 0x01010101u * (u32)ST5_QADD;
     const u32 ev[4] = {s.q[0] + qadd, s.q[1] + qadd, s.q[2] + qadd, s.q[3] + qadd};   // byte q + ST5_QADD: row q - 33 (ib holds the difference)
     const u32 c_lo = s.prev8 | (s.codes << 8);    // bases j0 - 4 .. j0 + 11
@@ -124,11 +131,14 @@ FQ_DEV void stats5_cells(const StatsArgs& a, const Stats5Geo& g, u32 ib, u32 kb,
         if (!MASKED || k < nv) {
             const u32 e = bfe(ev[k >> 2], 8 * (k & 3), 8);
             const u32 cl = bfe(s.codes, 2 * k, 2);
-            const u32 t = mad24_su(cl, g.C4, ib);
+            const bool BD = MASKED && FQ_ST5_BOUNDARY;
+            const bool kp = BD && k < nk;
+            const u32 ibk = BD ? ib + (kp ? g.S4 : 0u) : ib, kbk = BD ? kb + (kp ? slotK : 0u) : kb;
+            const u32 t = mad24_su(cl, g.C4, ibk);
             const u32 ca = mad24_su(e, g.HS4, t);
             if (!ABL || !(a.debug_skip & 64u)) lds_add_u32_at(ca + (u32)(k & 7) * g.K4, k < 8 ? 1u : 0x10000u);
             const u32 x = k < 8 ? bfe(c_lo, 2 * k, 10) : bfe(c_hi, 2 * k - 16, 10);
-            if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kb), k < 4 ? hpos : 1u);
+            if (!ABL || !(a.debug_skip & 128u)) lds_add_u32_at(lshl_add<KC == 2 ? 3 : 2>(x, kbk), k < 4 ? hpos : 1u);
         }
     }
 }
@@ -176,7 +186,11 @@ FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g
 
 // HS: the item columns of the table as a compile-time constant (the k-part of a cell's address then sits in the DS instruction's
 // offset field, the class and quality strides are literals of the two multiply-adds); 0 = read from the arguments
-template <int KC, int HS, bool ABL>
+// ONE: the table holds every column of the reads (H16 <= HS) - one block, known at compile time: the lane's column, its first
+// base and the block loop are constants again (the block form cost the 150-base configuration 9 %: 1.014 against 0.927 ms per
+// 4,194,304 pairs on the same box, profiles/r06_n_compile_time_ab.txt).  NF: no front trim of any kind (uniform) - the kept
+// range starts at base 0 and no result record is read (a seventh load per item otherwise)
+template <int KC, int HS, bool ABL, bool ONE = false, bool NF = false>
 FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
     const int H16 = a.H16;
@@ -192,7 +206,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     // Reads longer than the table has columns for (HB = a.Hs < H16: 250-base reads are 16 columns, the table holds 8) are taken
     // in column BLOCKS: a pass over a mate's rows per block, each reading only its own columns' bytes; the per-cycle cells of a
     // block are flushed and cleared behind it, the 5-mer table, the packed cells and the histogram stay for the whole mate.
-    const int HB = HS ? HS : a.Hs, nblk = (H16 + HB - 1) / HB;
+    const int HB = HS ? HS : a.Hs, nblk = ONE ? 1 : (H16 + HB - 1) / HB;
     const int upw = 64 / HB;
     const u32 lu = HS ? (u32)lane / (u32)HS : (u32)lane / (u32)HB;
     const u32 hl = (u32)lane - lu * (u32)HB;                      // the lane's column inside a block
@@ -228,7 +242,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
 #pragma unroll
             for (int d = 0; d < FQ_ST5_DEPTH; d++) {
                 const u32 ud = (u32)((tid >> 6) * upw + d * ustride) + lu;
-                stats5_issue(a, src, (used && (int)ud < nu) ? ud : 0u, h, ring[d]);
+                stats5_issue<NF>(a, src, (used && (int)ud < nu) ? ud : 0u, h, ring[d]);
             }
             const u32 ent_lane = (u32)lane;                       // a queued item: trip << 6 | the lane that found it (its unit and column)
             const int ub0 = (tid >> 6) * upw;
@@ -248,7 +262,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                         const u32 u = (u32)ub + lu;
                         const bool tv = used && (int)u < nu;
                         Stats5Item s;
-                        stats5_finish(a, src, h, ring[d], s);
+                        stats5_finish<NF>(a, src, h, ring[d], s);
                         const int nv = s.rl0 - j0, nk = s.lk - j0;
                         const bool act = tv && nv > 0;
                         const u32 qadd = 0x01010101u * (u32)ST5_QADD;
@@ -257,12 +271,13 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                         const int F = s.F, Fk = F > 0 ? F + 4 : 0;
                         const bool kept = j0 >= Fk && nk >= imin(nv, 16);              // every base of the item (and its 5-mer) is a kept one
                         const bool drop = nk <= 0 || j0 + 16 <= F;                     // ... a dropped one
-                        const bool clean = act && dirty == 0u && (kept || drop);
-                        const bool fast = clean && nv >= 16;
-                        const u64 mT = ballot(clean && nv < 16), mG = ballot(act && !clean);
+                        const bool mixed = FQ_ST5_BOUNDARY && F == 0 && !kept && !drop;   // a trim ends inside the item (no front trim)
+                        const bool clean = act && dirty == 0u && (kept || drop || mixed);
+                        const bool fast = clean && nv >= 16 && !mixed;
+                        const u64 mT = ballot(clean && !fast), mG = ballot(act && !clean);
                         const u32 ent = ((u32)(tr + d) << 6) | ent_lane;
                         if (mT) {                                 // (uniform) positions by a prefix count over the ballot: no atomic
-                            if (clean && nv < 16) wlT[wnT + lane_rank(mT)] = (u16)ent;
+                            if (clean && !fast) wlT[wnT + lane_rank(mT)] = (u16)ent;
                             wnT += popc64(mT);
                         }
                         if (mG) {
@@ -272,7 +287,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                         if (fast) stats5_cells<KC, false, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + hl * 4u), opaque(kmer_b + (kept ? slotK : 0u)), s, h, 16);
                         {   // this position's registers are free again: the trip FQ_ST5_DEPTH ahead
                             const u32 un = u + (u32)(FQ_ST5_DEPTH * ustride);
-                            stats5_issue(a, src, (used && (int)un < nu) ? un : 0u, h, ring[d]);
+                            stats5_issue<NF>(a, src, (used && (int)un < nu) ? un : 0u, h, ring[d]);
                         }
                     }
                 }
@@ -289,10 +304,14 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
                     const u32 hq = (w & 63u) - wl_ * (u32)HB, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
-                    stats5_fetch(a, src, on ? uu : 0u, hh, t);
+                    stats5_fetch<NF>(a, src, on ? uu : 0u, hh, t);
                     const int tj0 = 16 * (int)hh;
                     const int tnv = t.rl0 - tj0;
                     const bool tk = tj0 >= (t.F > 0 ? t.F + 4 : 0) && t.lk - tj0 >= imin(tnv, 16);   // (queued as all kept or all dropped: `kept` above)
+                    if (FQ_ST5_BOUNDARY) {   // ... or (no front trim) kept up to the trim's end inside the item: bases [0, tnk) are kept
+                        const int tnk = t.F == 0 ? imax(0, imin(16, t.lk - tj0)) : (tk ? 16 : 0);
+                        stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + hq * 4u), opaque(kmer_b), t, hh, on ? tnv : 0, tnk, slotK);
+                    } else
                     stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (tk ? g.S4 : 0u) + hq * 4u), opaque(kmer_b + (tk ? slotK : 0u)), t, hh, on ? tnv : 0);
                     wave_sync();
                 }
@@ -305,7 +324,7 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
                     const u32 hq = (w & 63u) - wl_ * (u32)HB, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
-                    stats5_fetch(a, src, on ? uu : 0u, hh, t);
+                    stats5_fetch<NF>(a, src, on ? uu : 0u, hh, t);
                     if (on) stats5_item_general<KC>(a, lds, g, t, (int)hh, (int)hq, lane);
                     wave_sync();
                 }
