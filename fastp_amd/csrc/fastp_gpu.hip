@@ -92,7 +92,11 @@ extern "C" __global__ void __launch_bounds__(1024) fq_stats5_kernel(StatsArgs a)
 #define FQ_ST5_NOFRONT 1   // (A/B: 0 = the front read from the arguments / the records whatever the options)
 #endif
     const bool nofront = FQ_ST5_NOFRONT && !a.front_per_read && a.front[0] == 0 && a.front[1] == 0;   // (uniform)
-    if (FQ_ST5_ONEBLK && a.Hs == 10 && a.kc == 2 && a.H16 <= 10 && nofront) stats_body5<2, 10, false, true, true>(a, fq_lds);   // reads of up to 160 bases, no front trim
+#ifndef FQ_ST5_TAILCOL
+#define FQ_ST5_TAILCOL 1   // (A/B: 0 = the last column in the lane mapping like every other)
+#endif
+    if (FQ_ST5_TAILCOL && FQ_ST5_ONEBLK && a.Hs == 10 && a.kc == 2 && a.H16 == 10 && nofront) stats_body5<2, 10, false, true, true, true>(a, fq_lds);   // 145 - 160 bases, no front trim
+    else if (FQ_ST5_ONEBLK && a.Hs == 10 && a.kc == 2 && a.H16 <= 10 && nofront) stats_body5<2, 10, false, true, true>(a, fq_lds);   // reads of up to 160 bases, no front trim
     else if (FQ_ST5_ONEBLK && a.Hs == 10 && a.kc == 2 && a.H16 <= 10) stats_body5<2, 10, false, true>(a, fq_lds);   // reads of up to 160 bases (uniform)
     else if (a.Hs == 10 && a.kc == 2) stats_body5<2, 10, false>(a, fq_lds);
     else if (a.Hs == 8 && a.kc == 2) stats_body5<2, 8, false>(a, fq_lds);  // two blocks of eight columns: reads of up to 256 bases
@@ -751,7 +755,16 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             if (cap_tiles > 0) mp = std::min(mp, (long long)ctx->blocks * cap_tiles * ctx->L.P);
         }
         if (mp > (1ll << DUP_IDX_BITS) - 1) mp = (1ll << DUP_IDX_BITS) - 1;
-        if (ctx->split && ctx->dp.corr_lane) mp = std::min(mp, (1ll << 29) / std::max(1, ctx->dp.max_len));   // the launch's correction list (launch_chunk)
+        if (ctx->split && ctx->dp.corr_lane) {   // the launch's correction list (launch_chunk): an entry for every base of every pair
+            // 2^29 entries (6 GiB with the chains) - or, on a card with 64 GiB to spare, just under 2^30: a -c / --merge step of 4 Mi
+            // pairs of 2x150 is then ONE launch instead of two (2 * index + 1 still fits an int)
+            long long entries = 1ll << 29;
+            size_t mfree = 0, mtotal = 0;
+            const int want = env_int("FASTP_GPU_CORR_LIST_LOG2", 0);
+            if (want == 30 || (want == 0 && hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree >= ((size_t)64 << 30))) entries = (1ll << 30) - 64;
+            (void)hipGetLastError();
+            mp = std::min(mp, entries / std::max(1, ctx->dp.max_len));
+        }
         mp = mp / ctx->L.P * ctx->L.P;
         ctx->max_pairs_per_launch = (int)mp;
     };
@@ -1246,7 +1259,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     if (corr_lane) {
         // the engine's own correction list of this launch.  A pair can have as many edits as its overlap is long (only the first
         // 50 bases are held to the mismatch limit, overlapanalysis.cpp:34-44): the list is sized for that - it cannot overflow,
-        // and set_launch_size keeps it below 2^29 entries (4 GiB; memory laid out for 288 GB of HBM)
+        // and set_launch_size keeps it below 2^29 entries (2^30 where the card has the memory to spare: laid out for 288 GB of HBM)
         const size_t cap = (size_t)n * (size_t)ctx->dp.max_len;
         const int rc0 = ensure(ctx, (void**)&ctx->d_corr_int, &ctx->corr_int_cap, (cap * 2 + 4) * 4);
         if (rc0) return rc0;

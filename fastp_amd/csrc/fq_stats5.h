@@ -190,7 +190,11 @@ FQ_DEV void stats5_item_general(const StatsArgs& a, u32* lds, const Stats5Geo& g
 // base and the block loop are constants again (the block form cost the 150-base configuration 9 %: 1.014 against 0.927 ms per
 // 4,194,304 pairs on the same box, profiles/r06_n_compile_time_ab.txt).  NF: no front trim of any kind (uniform) - the kept
 // range starts at base 0 and no result record is read (a seventh load per item otherwise)
-template <int KC, int HS, bool ABL, bool ONE = false, bool NF = false>
+// TC (with ONE, H16 == HS): the reads' LAST column - a ragged item for every read of the usual length (6 bases of a 150-base read),
+// which no lane could ever take on the fast path - leaves the lane mapping: lane = (unit, one of the HS - 1 FULL columns), 7 x 9 =
+// 63 lanes with fast work per trip instead of 6 x 9 = 54 of 60, and the last column is swept behind the trips, a lane per unit,
+// straight through the masked body (no list, no second fetch for the clean ones)
+template <int KC, int HS, bool ABL, bool ONE = false, bool NF = false, bool TC = false>
 FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     const int tid = thread_id(), nt = block_threads(), lane = tid & 63;
     const int H16 = a.H16;
@@ -207,9 +211,10 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
     // in column BLOCKS: a pass over a mate's rows per block, each reading only its own columns' bytes; the per-cycle cells of a
     // block are flushed and cleared behind it, the 5-mer table, the packed cells and the histogram stay for the whole mate.
     const int HB = HS ? HS : a.Hs, nblk = ONE ? 1 : (H16 + HB - 1) / HB;
-    const int upw = 64 / HB;
-    const u32 lu = HS ? (u32)lane / (u32)HS : (u32)lane / (u32)HB;
-    const u32 hl = (u32)lane - lu * (u32)HB;                      // the lane's column inside a block
+    const int HM = TC ? HS - 1 : HB;                              // the columns of the lane mapping
+    const int upw = 64 / HM;
+    const u32 lu = TC ? (u32)lane / (u32)(HS - 1) : HS ? (u32)lane / (u32)HS : (u32)lane / (u32)HB;
+    const u32 hl = (u32)lane - lu * (u32)HM;                      // the lane's column inside a block
     const int ustride = (nt >> 6) * upw;
     u16* wlT = (u16*)(lds + a.l_wl) + (tid >> 6) * (2 * ST5_WL);   // this wavefront's two lists: a read's clean last item ...
     u16* wlG = wlT + ST5_WL;                                      // ... and everything else the fast path does not take
@@ -301,8 +306,8 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     wnT -= cnt;
                     const bool on = lane < cnt;
                     const u32 w = on ? (u32)wlT[wnT + lane] : 0u;
-                    const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
-                    const u32 hq = (w & 63u) - wl_ * (u32)HB, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
+                    const u32 wl_ = TC ? (w & 63u) / (u32)(HS - 1) : HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
+                    const u32 hq = (w & 63u) - wl_ * (u32)HM, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
                     stats5_fetch<NF>(a, src, on ? uu : 0u, hh, t);
                     const int tj0 = 16 * (int)hh;
@@ -321,14 +326,58 @@ FQ_DEV void stats_body5(const StatsArgs& a, u32* lds) {
                     wnG -= cnt;
                     const bool on = lane < cnt;
                     const u32 w = on ? (u32)wlG[wnG + lane] : 0u;
-                    const u32 wl_ = HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
-                    const u32 hq = (w & 63u) - wl_ * (u32)HB, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
+                    const u32 wl_ = TC ? (w & 63u) / (u32)(HS - 1) : HS ? (w & 63u) / (u32)HS : fastdiv(w & 63u, a.magic_H16);
+                    const u32 hq = (w & 63u) - wl_ * (u32)HM, hh = (u32)(cb * HB) + hq, uu = (u32)(ub0 + (int)(w >> 6) * ustride) + wl_;
                     Stats5Item t;
                     stats5_fetch<NF>(a, src, on ? uu : 0u, hh, t);
                     if (on) stats5_item_general<KC>(a, lds, g, t, (int)hh, (int)hq, lane);
                     wave_sync();
                 }
                 if (!more) break;
+            }
+            if (TC) {   // the last column, a lane per unit (both lists are empty here: wlG now holds UNIT indexes of what is not clean)
+                const u32 hh = (u32)(HS - 1);
+                const int tj0 = 16 * (HS - 1);
+                const int wstep = (nt >> 6) * 64;
+                int wnD = 0;
+                for (int ut = (tid >> 6) * 64; ut < nu; ut += wstep) {   // wave-uniform
+                    const u32 u = (u32)(ut + lane);
+                    const bool on = (int)u < nu;
+                    Stats5Item t;
+                    stats5_fetch<NF>(a, src, on ? u : 0u, hh, t);
+                    const int tnv = t.rl0 - tj0, tnkr = t.lk - tj0;
+                    const bool act = on && tnv > 0;
+                    const u32 qadd = 0x01010101u * (u32)ST5_QADD;
+                    const u32 dirty = (t.q[0] | t.q[1] | t.q[2] | t.q[3] | t.qp | (t.q[0] + qadd) | (t.q[1] + qadd) | (t.q[2] + qadd) | (t.q[3] + qadd)) & 0x80808080u;
+                    const int F = t.F, Fk = F > 0 ? F + 4 : 0;
+                    const bool kept = tj0 >= Fk && tnkr >= imin(tnv, 16);
+                    const bool drop = tnkr <= 0 || tj0 + 16 <= F;
+                    const bool mixed = FQ_ST5_BOUNDARY && F == 0 && !kept && !drop;
+                    const bool clean = act && dirty == 0u && (kept || drop || mixed);
+                    const u64 mD = ballot(act && !clean);
+                    if (mD) {
+                        if (act && !clean) wlG[wnD + lane_rank(mD)] = (u16)u;
+                        wnD += popc64(mD);
+                    }
+                    if (FQ_ST5_BOUNDARY) {
+                        const int tnk = F == 0 ? imax(0, imin(16, tnkr)) : (kept ? 16 : 0);
+                        stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + hh * 4u), opaque(kmer_b), t, hh, clean ? tnv : 0, tnk, slotK);
+                    } else {
+                        stats5_cells<KC, true, ABL>(a, g, opaque(cyc_b + (kept ? g.S4 : 0u) + hh * 4u), opaque(kmer_b + (kept ? slotK : 0u)), t, hh, clean ? tnv : 0);
+                    }
+                    const bool last = ut + wstep >= nu;
+                    while (wnD >= 64 || (last && wnD > 0)) {          // (uniform)
+                        const int cnt = imin(wnD, 64);
+                        wave_sync();
+                        wnD -= cnt;
+                        const bool on2 = lane < cnt;
+                        const u32 w = on2 ? (u32)wlG[wnD + lane] : 0u;
+                        Stats5Item t2;
+                        stats5_fetch<NF>(a, src, w, hh, t2);
+                        if (on2) stats5_item_general<KC>(a, lds, g, t2, (int)hh, (int)hh, lane);
+                        wave_sync();
+                    }
+                }
             }
         }
         block_sync();
