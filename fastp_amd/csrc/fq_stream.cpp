@@ -46,6 +46,7 @@
 
 #include "../../include/fastp_gpu_stream.h"
 #include "fq_pgunzip.h"
+#include "fq_timeline.h"
 
 namespace {
 
@@ -140,7 +141,9 @@ class Channel {
     std::deque<T> q_;
 };
 
-const int IO_PIECE = 8 << 20;
+// a chunk's read is cut into pieces for the reader's threads (FASTP_GPU_STREAM_READ_PIECE_KB; 8 MiB pieces used 4 of the 16
+// threads on a 16 MiB chunk per file)
+const int64_t IO_PIECE = (int64_t)std::max(64, env_int("FASTP_GPU_STREAM_READ_PIECE_KB", 2048)) << 10;
 const unsigned char BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct ReadReq {
@@ -742,7 +745,9 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
     if (rc != FASTP_GPU_OK) { g_stream_error = std::string("fastp_gpu_create: ") + fastp_gpu_last_error(nullptr); return rc; }
     s->st.max_len = s->p.max_len;
     if (s->cfg.want_overlapped) (void)fastp_gpu_host_writes_overlapped(s->ctx, 1);
+    fq::timeline("stream: engine created");
     rc = alloc_buffers(s.get());
+    fq::timeline("stream: buffers allocated (device + page-locked)");
     if (rc != FASTP_GPU_OK) {
         g_stream_error = s->err;
         free_buffers(s.get());
@@ -756,10 +761,13 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
 
 void fastp_gpu_stream_destroy(fastp_gpu_stream* s) {
     if (!s) return;
+    fq::timeline("stream: destroy begin");
     (void)hipSetDevice(s->cfg.device);
     free_buffers(s);
+    fq::timeline("stream: buffers freed");
     if (s->ctx) fastp_gpu_destroy(s->ctx);
     delete s;
+    fq::timeline("stream: destroy end");
 }
 
 int fastp_gpu_stream_get_stats(const fastp_gpu_stream* s, fastp_gpu_stream_stats* out) {
@@ -1511,6 +1519,7 @@ static int gunzip_file_with(G* g, int fd, uint8_t* out, int64_t capacity, int64_
 extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
     if (!s || !s->ctx) return FASTP_GPU_E_INVALID;
     const double t_start = now_s();
+    fq::timeline("stream: run begin");
     S_HIP(s, hipSetDevice(s->cfg.device));
     Run R(s);
     const char* paths[2] = {s->cfg.in1, s->cfg.in2};
@@ -1551,5 +1560,6 @@ extern "C" int fastp_gpu_stream_run(fastp_gpu_stream* s) {
     if (rc == FASTP_GPU_OK && R.io_err.load()) rc = s->fail(FASTP_GPU_E_INVALID, "file I/O failed");
     if (rc == FASTP_GPU_OK && R.emit_err.load()) rc = s->fail(FASTP_GPU_E_INVALID, "the emit callback stopped the run");
     s->st.wall_s = now_s() - t_start;
+    fq::timeline("stream: run end");
     return rc;
 }

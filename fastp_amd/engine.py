@@ -161,6 +161,8 @@ class GpuEngine:
         r2 = np.zeros(n if paired else 0, dtype=abi.READ_RESULT_DTYPE)
         pr = np.zeros(n if paired else 0, dtype=abi.PAIR_RESULT_DTYPE)
         if corr_capacity is None:
+            corr_capacity = getattr(self, "corr_capacity", None)   # (tests: a caller's list that is too small)
+        if corr_capacity is None:
             corr_capacity = max(1024, n * 32)
         corr = np.zeros(corr_capacity, dtype=abi.CORRECTION_DTYPE)
         ncorr = C.c_int32(0)
@@ -194,7 +196,7 @@ class GpuEngine:
         self._check(self.lib.fastp_gpu_submit_host(self.h, C.byref(b), C.byref(res)))
         # --adapter_fasta trims of this batch, per read in adapter order (the device emits them unordered)
         self.last_adapter_events = np.sort(ev[:nev.value].copy(), order=["read", "adapter"])
-        return r1, (r2 if paired else None), (pr if paired else None), corr[:ncorr.value].copy()
+        return r1, (r2 if paired else None), (pr if paired else None), corr[:min(ncorr.value, corr_capacity)].copy()
 
     # -- ASCII rows (what the FASTQ decoder produces) -> results -------------------------------
     def process(self, seq1, qual1, len1, seq2=None, qual2=None, len2=None, flags=abi.BATCH_STAT_ISIZE):

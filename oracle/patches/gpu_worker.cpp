@@ -31,6 +31,7 @@
 #include <zlib.h>
 #include <libdeflate.h>
 #include "isa-l/igzip_lib.h"
+#include "../../fastp_amd/csrc/fq_timeline.h"   // FASTP_GPU_TIMELINE=1: where the start-up goes
 
 #define private public
 #define protected public
@@ -143,7 +144,12 @@ bool enabled() {
 // the HIP runtime comes up on a helper thread from the moment the binary is loaded: it overlaps main()'s option parsing
 // and the Evaluator pre-pass instead of preceding the first chunk (fastp_gpu_warmup)
 struct WarmUp {
-    WarmUp() { if (enabled()) std::thread([] { (void)fastp_gpu_warmup(0); }).detach(); }
+    WarmUp() {
+        if (!enabled()) return;
+        fq::timeline("binding: static initialisers (the binary and its libraries are mapped)");
+        atexit([] { fq::timeline("binding: atexit (reports written)"); });
+        std::thread([] { (void)fastp_gpu_warmup(0); }).detach();
+    }
 } g_warm_up;
 
 void refuse(const char* what) { error_exit(std::string("FASTP_GPU=1: ") + what + " is outside the engine's scope"); }
@@ -842,6 +848,7 @@ int emit_to_writer(void* user, int stream, const char* data, int64_t len) {
 
 void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU_N_OUTPUTS], WriterThread* overlapped_writer = NULL) {
     StreamState* S = new StreamState();
+    fq::timeline("binding: stream_setup begin (options parsed, Evaluator pre-pass done, threads started)");
     S->paired = paired;
     S->W = std::max(1, o->thread);
     int max_len = std::max(o->seqLen1, paired ? o->seqLen2 : 0);   // Evaluator::computeSeqLen: the first 1000 reads
@@ -882,6 +889,7 @@ void stream_setup(Options* o, bool paired, WriterThread* const writers[FASTP_GPU
     cfg.host = S->host;
     if (fastp_gpu_stream_create(&S->B.params, &cfg, &S->st) != FASTP_GPU_OK)
         error_exit(std::string("fastp_gpu_stream_create: ") + fastp_gpu_stream_last_error(NULL));   // never a silent CPU fallback
+    fq::timeline("binding: stream_setup end");
     SG = S;
 }
 
@@ -915,6 +923,7 @@ void stream_run() {
 }
 
 void stream_shutdown() {
+    fq::timeline("binding: counters loaded into the reference's objects");
     fastp_gpu_stream_destroy(SG->st);
     fastp_gpu_host_destroy(SG->host);
     delete SG;

@@ -91,6 +91,29 @@ def test_sim_dedup_without_the_fused_claim(switch, monkeypatch):
     assert np.array_equal(co, cg)
 
 
+def test_sim_overrep_with_correction_reads_the_engines_own_list():
+    """-p with -c on the lane plan: the POST overrepresentation counts are taken from the launch's own correction list (sized for
+    an edit at every base: it cannot overflow).  A caller's list that is too small for the batch's edits - the results then hold
+    its first entries only - must not change a counter (round 5's advisor finding: the analysis used to read the caller's)"""
+    name = "pe_overrep_correction"
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(1500, L=150, seed=21, paired=paired, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    o = oraclelib.Oracle(params)
+    g = engines.sim_engine(params)
+    assert g.plan() == "lane"
+    g.corr_capacity = 2
+    args = (d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    ro, rg = o.process(*args), g.process(*args)
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    assert len(ro[3]) > 50 and len(rg[3]) == 2, (len(ro[3]), len(rg[3]))
+    for k in range(3):
+        assert np.array_equal(ro[k], rg[k]), f"records {k} differ"
+    assert np.array_equal(co, cg), f"{int((co != cg).sum())} counters differ"
+
+
 @pytest.mark.parametrize("level,L,paired", [(1, 150, True), (3, 150, True), (1, 37, True), (1, 250, True), (1, 150, False), (-3, 100, True)])
 def test_sim_duplicate_hash_bit_positions_equal_oracle(level, L, paired, monkeypatch):
     """the hash itself (Duplicate::seq2intvector mod mBufLenInBits), not only the decisions it leads to: every
