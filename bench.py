@@ -78,11 +78,20 @@ def host_cores():
     return min(os.cpu_count() or 1, 16)   # the reference stops scaling long before that (reader-thread bound)
 
 
+def fresh_outputs(cmd):
+    """every timed run writes NEW output files: opening an existing file of gigabytes with O_TRUNC frees its tmpfs pages first, 0.1 - 0.5 s
+    that belong to the previous run (profiles/r06_r_dropin_probe.txt: the runs behind the first of a series were that much slower)"""
+    for i, a in enumerate(cmd):
+        if a in ("-o", "-O") and os.path.exists(cmd[i + 1]):
+            os.remove(cmd[i + 1])
+
+
 def timed_ref(binary, tmp, f1, f2, flags, cores, env=None, tag="o"):
     cmd = [binary, "-i", f1, "-I", f2, "-o", os.path.join(tmp, tag + "1.fq"), "-O", os.path.join(tmp, tag + "2.fq"),
            "-j", os.path.join(tmp, tag + ".json"), "-h", os.path.join(tmp, tag + ".html"), "-w", str(cores)] + flags
     times = []
     for _ in range(3):   # median of 3: the reference's own convention (scripts/bench_e2e.sh:10), SURVEY.md 8(d)
+        fresh_outputs(cmd)
         t0 = time.time()
         subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=900,
                        env=dict(os.environ, **(env or {})))
@@ -160,6 +169,7 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False, f
                    "-h", os.path.join(tmp, "d.html"), "-w", str(cores)] + flags
             best, stream_s, setup_s = None, None, None
             for _ in range(2):
+                fresh_outputs(cmd)
                 t0 = time.time()
                 pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, timeout=900,
                                     env=dict(os.environ, FASTP_GPU="1", FASTP_GPU_VERBOSE="1"))
@@ -201,6 +211,7 @@ def e2e_legs(sample_pairs, flags, params, files, cpu_value, dropin_only=False, f
                 if same is not None:   # outputs_identical = the FASTQ files AND the report
                     same = same and not json_diff_w and not json_diff_1
             # what a run costs whatever its size: process start, HIP runtime, engine + page-locked buffers (the first 1000 pairs only)
+            fresh_outputs(cmd)
             t0 = time.time()
             subprocess.run(cmd + ["--reads_to_process", "1000"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, timeout=300,
                            env=dict(os.environ, FASTP_GPU="1"))
@@ -244,6 +255,7 @@ def e2e_compressed_leg(sample_pairs, flags, dev):
         def run(binary, i1, i2, tag, ext, env):
             cmd = [binary, "-i", i1, "-I", i2, "-o", J(tag + "1" + ext), "-O", J(tag + "2" + ext), "-j", J(tag + ".json"), "-h", J(tag + ".html"),
                    "-w", str(cores)] + flags
+            fresh_outputs(cmd)
             t0 = time.time()
             pr = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, timeout=240, env=env)
             return time.time() - t0, pr.stderr.decode(errors="replace")

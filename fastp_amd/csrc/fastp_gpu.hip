@@ -845,6 +845,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         }
     }
+    fq::timeline("create: launch stream created");
     CREATE_TRY(hipFuncSetAttribute(ctx->split ? (ctx->cfg.threads > 256 ? (const void*)fq_scan_wide_kernel : (const void*)fq_scan_kernel) : (const void*)fq_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->L.total * 4));
     if (ctx->split) {
@@ -870,8 +871,14 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             CREATE_TRY(hipMalloc((void**)&d_flag, 2 * sizeof(int)));
             std::vector<hipStream_t> rejected;
             const int tries = env_int("FASTP_GPU_TAIL_TRIES", 6);
+            const bool tail_prio = env_int("FASTP_GPU_TAIL_PRIORITY", 0) != 0;
             for (int t = 0; t < std::max(1, tries) && !ctx->tail; t++) {
                 hipStream_t cand = nullptr;
+                if (tail_prio) {   // (A/B, FASTP_GPU_TAIL_PRIORITY=1: the tail stream's workgroups first when a CU frees up)
+                    int lo = 0, hi = 0;
+                    CREATE_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    CREATE_TRY(hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, hi));
+                } else
                 CREATE_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
                 bool beside = tries <= 1;
                 if (!beside) {
@@ -893,6 +900,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
             for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
             (void)hipFree(d_flag);
 #endif
+            fq::timeline("create: second stream probed");
             CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_k1, hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming));
         }
@@ -910,7 +918,7 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(IwLds)));
     CREATE_TRY(hipFuncSetAttribute((const void*)fq_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    INF_ENTRIES * INF_LANES * 2 + INF_SBUF * INF_LANES * 4));
-    fq::timeline("create: streams, second-stream probe, kernel attributes");
+    fq::timeline("create: kernel attributes set");
     auto upload = [&](void** dptr, const void* src, size_t bytes) -> int {
         if (bytes == 0) { *dptr = nullptr; return 0; }
         HIP_TRY(ctx, hipMalloc(dptr, bytes));
@@ -1076,7 +1084,9 @@ static int launch_overrep(fastp_gpu_ctx* ctx, const KernelArgs& a, int n, hipStr
         }
         // the post-filtering Stats analyse the corrected reads: from the engine's own list of this launch where it keeps one (-c with
         // the Stats kernel as its own launch: sized for an edit at every base, it cannot overflow), else from the caller's
-        const bool own_list = a.corr_int != nullptr && a.corr_int_cap > 0;
+        // (a launch with units for the text kernel: that kernel's edits are in the caller's list only - it counts its units' POST
+        // Stats itself, fq_corr_stats_kernel must not see them - so such a launch reads the caller's list as before)
+        const bool own_list = a.corr_int != nullptr && a.corr_int_cap > 0 && !(b && b->n_exotic > 0) && !ctx->exact_all;
         if (ctx->dp.correction && !own_list && !(a.corrections && a.corr_capacity > 0))
             return fail(ctx, FASTP_GPU_E_INVALID, "overrepresentation analysis with correction needs the correction list in the results");
         if (own_list || (a.corrections && a.corr_capacity > 0)) {
@@ -1419,7 +1429,11 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         d.paired = ctx->dp.paired;
         d.ctr_total = ctx->d_ctr + cl.dup_total;
         d.ctr_dups = ctx->d_ctr + cl.dup_count;
-        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, st));
+        // Stage 1's clears (128 MB of table for 4 Mi pairs: 21 + 6 us) are needed by the kernels of stage 2 only, not by the kernel
+        // that claims: where stage 2 will run on the tail stream they go there, beside the per-read kernel instead of in front of it
+        // (that stream is past the previous launch's tail by then; the launch stream joins it at the end of every launch)
+        hipStream_t cst = (stage == 1 && ctx->split && ctx->tail && !dedup_folded && n > 0 && env_int("FASTP_GPU_DUP_CLEAR_TAIL", 1)) ? ctx->tail : st;
+        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, cst));
         const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
         if (env_int("FASTP_GPU_DUP_TABLE", 0)) {      // the first form: probe (read + table insert for every unit) -> resolve
             hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
@@ -1433,7 +1447,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (!ctx->d_cfilter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cfilter, (size_t)1 << (DUP_CF_LOG2 - 3)));
         d.setw = ctx->d_setw;
         d.cfilter = ctx->d_cfilter;
-        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), st));
+        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), cst));
         if (stage == 1) {
             a.claim_won = ctx->d_need;
             a.dup_bitmap = ctx->d_bitmap;
@@ -1577,10 +1591,37 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         rc = launch_exact(0);
         if (rc) return rc;
     }
+    // the slab folds (set up here: the per-read kernel's MISC_* fold may go to the tail stream in front of Duplicate's kernels)
+    ReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.L = ctx->L;
+    r.isize_max = ctx->dp.isize_max;
+    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && (ctx->dp.front_lane || ctx->dp.corr_lane || ctx->dp.merge_lane));
+    r.merge_tail = (ctx->split && ctx->dp.merge_lane) ? 1 : 0;
+    if (ctx->split && ctx->dp.front_lane) { r.front[0] = ctx->dp.lane_front1; r.front[1] = ctx->dp.lane_front2; }
+    r.ctr = ctx->d_ctr;
+    r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
+    r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;
+    r.o_corrected_reads = cl.corrected_reads; r.o_merged = cl.merged_pairs; r.o_isize = cl.isize;
+    for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
+    r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
+    r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
+    const int n_stats = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128, n_misc = MISC_ISIZE + ctx->dp.isize_max + 1 + (r.merge_tail ? (int)KMER_BINS : 0);
+    auto fold = [&](int parts, int nblocks, hipStream_t st) -> int {
+        if (nblocks <= 0) return 0;
+        r.parts = parts;
+        r.nblocks = nblocks;
+        const int items = ((parts & 1) ? n_stats : 0) + ((parts & 2) ? n_misc : 0);
+        const int rgroups = (nblocks + REDUCE_GROUP - 1) / REDUCE_GROUP;
+        hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
+        HIP_TRY(ctx, hipGetLastError());
+        return 0;
+    };
     // the claim ran inside that kernel: what is left of Duplicate (losers / winners / finish) needs nothing of the Stats
     // kernel and runs beside it on its own stream; the launch stream joins it before anything else touches the records
     bool dup_tail_launched = false;
     bool dedup_applied = false;
+    bool misc_folded = false;
     if (dedup_folded && dup_prepared && n > 0) {
         // --dedup: the decisions are needed before the Stats kernel classifies a base as kept - on the launch stream
         rc = ensure(ctx, (void**)&ctx->d_dupflag, &ctx->dupflag_cap, (size_t)n);
@@ -1604,6 +1645,17 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     } else if (ctx->split && ctx->tail && dup_prepared && n > 0) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
+        // The MISC_* fold needs the per-read kernel only: FIRST on the tail stream.  Behind Duplicate's kernels - which the Stats
+        // kernel's workgroups starve until its last round ends (profiles/r06_s_step_timeline.txt: losers 0.45 ms, winners 0.50 ms
+        // beside it, 0.01 / 0.03 alone) - it was 27 + 9 us at the very end of every step, with nothing else on the chip.
+        if (env_int("FASTP_GPU_MISC_FOLD_FIRST", 1)) {
+            r.slabs = use_lane ? ctx->d_ln_slabs : ctx->d_slabs;
+            r.slab_dwords = use_lane ? ctx->ln_lds.n_misc : ctx->slab_dwords;
+            r.off_misc = use_lane ? 0 : ctx->L.acc_misc - ctx->L.acc_cyc;
+            rc = fold(2, use_lane ? ln_grid : grid, ctx->tail);
+            if (rc) return rc;
+            misc_folded = true;
+        }
         rc = launch_dup(nullptr, mode == CHUNK_PASS1, ctx->tail, 2);
         if (rc) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
@@ -1749,31 +1801,6 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     HIP_TRY(ctx, hipEventRecord(e1, st));
     ctx->pending_events.push_back({e0, e1});
 
-    ReduceArgs r;
-    memset(&r, 0, sizeof(r));
-    r.L = ctx->L;
-    r.isize_max = ctx->dp.isize_max;
-    r.one_pass = ctx->dp.stats_one_pass || (ctx->split && (ctx->dp.front_lane || ctx->dp.corr_lane || ctx->dp.merge_lane));
-    r.merge_tail = (ctx->split && ctx->dp.merge_lane) ? 1 : 0;
-    if (ctx->split && ctx->dp.front_lane) { r.front[0] = ctx->dp.lane_front1; r.front[1] = ctx->dp.lane_front2; }
-    r.ctr = ctx->d_ctr;
-    r.o_filter = cl.filter_stats; r.o_adapter_reads = cl.adapter_reads; r.o_adapter_bases = cl.adapter_bases;
-    r.o_polyx_reads = cl.polyx_reads; r.o_polyx_bases = cl.polyx_bases; r.o_correction = cl.correction;
-    r.o_corrected_reads = cl.corrected_reads; r.o_merged = cl.merged_pairs; r.o_isize = cl.isize;
-    for (int s = 0; s < 4; s++) r.o_stats[s] = cl.stats[s];
-    r.st_reads = cl.st_reads; r.st_length_sum = cl.st_length_sum; r.st_qual_hist = cl.st_qual_hist;
-    r.st_kmer = cl.st_kmer; r.st_cycle = cl.st_cycle; r.cycles = cl.cycles;
-    const int n_stats = 4 * N_CLS * ctx->L.Cp + 4 * KMER_BINS + 4 * 128, n_misc = MISC_ISIZE + ctx->dp.isize_max + 1 + (r.merge_tail ? (int)KMER_BINS : 0);
-    auto fold = [&](int parts, int nblocks, hipStream_t st) -> int {
-        if (nblocks <= 0) return 0;
-        r.parts = parts;
-        r.nblocks = nblocks;
-        const int items = ((parts & 1) ? n_stats : 0) + ((parts & 2) ? n_misc : 0);
-        const int rgroups = (nblocks + REDUCE_GROUP - 1) / REDUCE_GROUP;
-        hipLaunchKernelGGL(fq_reduce_kernel, dim3(((items + 255) / 256) * rgroups), dim3(256), 0, st, r);
-        HIP_TRY(ctx, hipGetLastError());
-        return 0;
-    };
     if (ctx->split) {
         // the Stats kernel's slabs: per-cycle u64s, k-mer counters, one histogram counter per (slot, character)
         r.slabs = ctx->d_st_slabs;
@@ -1789,8 +1816,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         r.slab_dwords = use_lane ? ctx->ln_lds.n_misc : ctx->slab_dwords;
         r.off_misc = use_lane ? 0 : ctx->L.acc_misc - ctx->L.acc_cyc;
         // (needs nothing of the Stats kernel either: beside it, behind Duplicate's tail, when that stream is in use)
-        rc = fold(2, use_lane ? ln_grid : grid, dup_tail_launched ? ctx->tail : st);
-        if (rc) return rc;
+        if (!misc_folded) {
+            rc = fold(2, use_lane ? ln_grid : grid, dup_tail_launched ? ctx->tail : st);
+            if (rc) return rc;
+        }
         if (dup_tail_launched) HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
     } else {
         r.slabs = ctx->d_slabs;

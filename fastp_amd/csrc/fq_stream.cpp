@@ -741,18 +741,26 @@ int fastp_gpu_stream_create(const fastp_gpu_params* params, const fastp_gpu_stre
         // merge mode without --merged_out: legal for the reference (the merged reads are dropped); nothing to check
     }
     const double t0 = now_s();
+    // the stream's buffers (the page-locked ones are the slow part: 40 ms of a 4 M-pair run's 0.57 s) are allocated on a helper
+    // thread BESIDE the engine's creation (66 ms: runtime, second-stream probe, tables) - neither needs anything of the other
+    int rc_buf = FASTP_GPU_OK;
+    std::thread buf_thread([&] {
+        rc_buf = alloc_buffers(s.get());
+        fq::timeline("stream: buffers allocated (device + page-locked)");
+    });
     int rc = fastp_gpu_create(&s->p, s->cfg.device, &s->ctx);
-    if (rc != FASTP_GPU_OK) { g_stream_error = std::string("fastp_gpu_create: ") + fastp_gpu_last_error(nullptr); return rc; }
+    std::string create_err;
+    if (rc != FASTP_GPU_OK) create_err = std::string("fastp_gpu_create: ") + fastp_gpu_last_error(nullptr);
+    fq::timeline("stream: engine created");
+    buf_thread.join();
+    if (rc != FASTP_GPU_OK) { free_buffers(s.get()); g_stream_error = create_err; return rc; }
     s->st.max_len = s->p.max_len;
     if (s->cfg.want_overlapped) (void)fastp_gpu_host_writes_overlapped(s->ctx, 1);
-    fq::timeline("stream: engine created");
-    rc = alloc_buffers(s.get());
-    fq::timeline("stream: buffers allocated (device + page-locked)");
-    if (rc != FASTP_GPU_OK) {
+    if (rc_buf != FASTP_GPU_OK) {
         g_stream_error = s->err;
         free_buffers(s.get());
         fastp_gpu_destroy(s->ctx);
-        return rc;
+        return rc_buf;
     }
     s->st.setup_s = now_s() - t0;
     *out = s.release();

@@ -94,7 +94,8 @@ def test_sim_dedup_without_the_fused_claim(switch, monkeypatch):
 def test_sim_overrep_with_correction_reads_the_engines_own_list():
     """-p with -c on the lane plan: the POST overrepresentation counts are taken from the launch's own correction list (sized for
     an edit at every base: it cannot overflow).  A caller's list that is too small for the batch's edits - the results then hold
-    its first entries only - must not change a counter (round 5's advisor finding: the analysis used to read the caller's)"""
+    its first entries only and the submit returns FASTP_GPU_E_CAPACITY - must not change a counter (round 5's advisor finding: the
+    analysis used to read the caller's)"""
     name = "pe_overrep_correction"
     paired, flags, pf, skw = cases.CASES[name]
     d = synth.synth_pairs(1500, L=150, seed=21, paired=paired, **skw)
@@ -104,13 +105,13 @@ def test_sim_overrep_with_correction_reads_the_engines_own_list():
     assert g.plan() == "lane"
     g.corr_capacity = 2
     args = (d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
-    ro, rg = o.process(*args), g.process(*args)
+    ro = o.process(*args)
+    assert len(ro[3]) > 50, len(ro[3])
+    with pytest.raises(engine.EngineError, match="correction list capacity exceeded"):   # the caller is told that its list is short
+        g.process(*args)
     co, cg = o.counters(), g.counters()
     o.close()
     g.close()
-    assert len(ro[3]) > 50 and len(rg[3]) == 2, (len(ro[3]), len(rg[3]))
-    for k in range(3):
-        assert np.array_equal(ro[k], rg[k]), f"records {k} differ"
     assert np.array_equal(co, cg), f"{int((co != cg).sum())} counters differ"
 
 
