@@ -1401,7 +1401,8 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
     };
     bool dup_prepared = false;
     auto launch_dup = [&](u8* dupflag, bool scan = false, hipStream_t st = nullptr, int stage = 0) -> int {
-        // stage 0: everything; 1: only the buffers + clears (before a fused kernel that claims); 2: what follows that kernel
+        // stage 0: everything; 1: only the buffers + clears (before a fused kernel that claims); 2: what follows that kernel;
+        // 3: of that only fq_dup_losers_kernel, 4: only the two kernels behind it (the two on different streams, launch_chunk)
         if (!st) st = st_main;
         DupArgs d;
         memset(&d, 0, sizeof(d));
@@ -1433,7 +1434,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         // that claims: where stage 2 will run on the tail stream they go there, beside the per-read kernel instead of in front of it
         // (that stream is past the previous launch's tail by then; the launch stream joins it at the end of every launch)
         hipStream_t cst = (stage == 1 && ctx->split && ctx->tail && !dedup_folded && n > 0 && env_int("FASTP_GPU_DUP_CLEAR_TAIL", 1)) ? ctx->tail : st;
-        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, cst));
+        if (stage < 2) HIP_TRY(ctx, hipMemsetAsync(d.table, 0xFF, (size_t)8 << lg, cst));
         const int g2 = std::max(1, (n + 255) / 256);  // one unit per lane: the kernels are chains of dependent random accesses
         if (env_int("FASTP_GPU_DUP_TABLE", 0)) {      // the first form: probe (read + table insert for every unit) -> resolve
             hipLaunchKernelGGL(fq_dup_probe_kernel, dim3(g2), dim3(256), 0, st, d);
@@ -1447,7 +1448,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         if (!ctx->d_cfilter) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cfilter, (size_t)1 << (DUP_CF_LOG2 - 3)));
         d.setw = ctx->d_setw;
         d.cfilter = ctx->d_cfilter;
-        if (stage != 2) HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), cst));
+        if (stage < 2) HIP_TRY(ctx, hipMemsetAsync(d.cfilter, 0, (size_t)1 << (DUP_CF_LOG2 - 3), cst));
         if (stage == 1) {
             a.claim_won = ctx->d_need;
             a.dup_bitmap = ctx->d_bitmap;
@@ -1455,9 +1456,10 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             dup_prepared = true;
             return 0;
         }
-        if (stage == 2) hipLaunchKernelGGL(fq_dup_losers_kernel, dim3(g2), dim3(256), 0, st, d);
-        else hipLaunchKernelGGL(fq_dup_claim_kernel, dim3(g2), dim3(256), 0, st, d);
+        if (stage == 2 || stage == 3) hipLaunchKernelGGL(fq_dup_losers_kernel, dim3(g2), dim3(256), 0, st, d);
+        else if (stage != 4) hipLaunchKernelGGL(fq_dup_claim_kernel, dim3(g2), dim3(256), 0, st, d);
         HIP_TRY(ctx, hipGetLastError());
+        if (stage == 3) return 0;
         hipLaunchKernelGGL(fq_dup_winners_kernel, dim3(g2), dim3(256), 0, st, d);
         HIP_TRY(ctx, hipGetLastError());
         hipLaunchKernelGGL(fq_dup_finish_kernel, dim3(std::max(1, (n + 1023) / 1024)), dim3(1024), 16, st, d);
@@ -1643,12 +1645,28 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
         HIP_TRY(ctx, hipGetLastError());
         dedup_applied = true;
     } else if (ctx->split && ctx->tail && dup_prepared && n > 0) {
+        // The Stats kernel's workgroups own every CU (a 1024-lane workgroup at 128 VGPRs is the whole register file): a kernel on
+        // the tail stream gets through when one of the Stats kernel's two rounds of workgroups ends, ONE kernel per such moment
+        // (profiles/r06_s_step_timeline.txt, r06_t_step_timeline.txt: each tail kernel "takes" 0.43 - 0.50 ms, 0.01 - 0.03 alone).
+        // A/B, FASTP_GPU_DUP_LOSERS_FIRST=1: fq_dup_losers_kernel on the launch stream IN FRONT of the Stats kernel, so that
+        // winners gets through between the rounds - measured SLOWER (profiles/r06_u_losers_first_ab.txt: step 2.409 -> 2.440 ms):
+        // winners is then dispatched together with the Stats kernel's first round and shares the CUs with it from the start (the
+        // Stats kernel 0.89 -> 0.95 ms), finish still waits for its end.  Off.
+        // (never with units for the text kernel on the tail stream: the Stats kernel would wait for that kernel too)
+        const bool losers_first = env_int("FASTP_GPU_DUP_LOSERS_FIRST", 0) != 0 && mode != CHUNK_PASS1 && !exact;
+        if (losers_first) {
+            // (the tail stream holds the clears of this launch's table and filter: the launch stream waits for them first)
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_tail, 0));
+            rc = launch_dup(nullptr, false, st, 3);
+            if (rc) return rc;
+        }
         HIP_TRY(ctx, hipEventRecord(ctx->ev_k1, st));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->tail, ctx->ev_k1, 0));
         // The MISC_* fold needs the per-read kernel only: FIRST on the tail stream.  Behind Duplicate's kernels - which the Stats
         // kernel's workgroups starve until its last round ends (profiles/r06_s_step_timeline.txt: losers 0.45 ms, winners 0.50 ms
         // beside it, 0.01 / 0.03 alone) - it was 27 + 9 us at the very end of every step, with nothing else on the chip.
-        if (env_int("FASTP_GPU_MISC_FOLD_FIRST", 1)) {
+        if (env_int("FASTP_GPU_MISC_FOLD_FIRST", losers_first ? 0 : 1)) {
             r.slabs = use_lane ? ctx->d_ln_slabs : ctx->d_slabs;
             r.slab_dwords = use_lane ? ctx->ln_lds.n_misc : ctx->slab_dwords;
             r.off_misc = use_lane ? 0 : ctx->L.acc_misc - ctx->L.acc_cyc;
@@ -1656,7 +1674,7 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             if (rc) return rc;
             misc_folded = true;
         }
-        rc = launch_dup(nullptr, mode == CHUNK_PASS1, ctx->tail, 2);
+        rc = launch_dup(nullptr, mode == CHUNK_PASS1, ctx->tail, losers_first ? 4 : 2);
         if (rc) return rc;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_tail, ctx->tail));
         dup_tail_launched = true;

@@ -584,7 +584,7 @@ FQ_DEV void phase_stats_both(const KernelArgs& a, u32* lds, int n_valid, int tid
             const u32 qp = qw[-1], qd = qw[0];
             const u32* sw2 = (const u32*)(srow_p + ((cr - 1) & ~3));
             const u32 pc16 = alignbit(sw2[1], sw2[0], (u32)((cr - 1) & 3) * 8u);
-            const u32 prev8 = pc16 & 0xFFu, cur8 = (pc16 >> 8) & 0xFFu;
+            const u32 cur8 = (pc16 >> 8) & 0xFFu;   // (pc16's low byte: the base byte in front, part of the 5-mer word below)
             const bool kept = c < ck;
             const u32 nany = (qd | (c > 0 ? qp : 0u)) & 0x80808080u;   // an N among the four bases or the four before
             const bool plain = (int)act & (int)(nany == 0u) & ((int)kept | (int)(c >= cd));
