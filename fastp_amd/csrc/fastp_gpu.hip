@@ -286,6 +286,7 @@ struct fastp_gpu_ctx {
     LaneLds ln_lds;
     u32* d_ln_slabs = nullptr;
     int* d_ln_ctr = nullptr;       // the lane kernel's chunk counter
+    int ln_pool_base = 0;          // ... as the pool's counter (LaneArgs::pool_base): what it may have reached by the next launch
     // split plans: Duplicate's losers / winners / finish kernels of a launch run on this stream beside its Stats kernel
     hipStream_t tail = nullptr;
     hipEvent_t ev_k1 = nullptr, ev_tail = nullptr;
@@ -906,7 +907,10 @@ extern "C" int fastp_gpu_create(const fastp_gpu_params* params, int device, fast
         }
         if (ctx->lane) {
             CREATE_TRY(hipMalloc((void**)&ctx->d_ln_slabs, (size_t)ctx->ln_blocks * ctx->ln_lds.n_misc * 4));
-            if (env_int("FASTP_GPU_LANE_DYNAMIC", 1)) CREATE_TRY(hipMalloc((void**)&ctx->d_ln_ctr, sizeof(int)));
+            if (env_int("FASTP_GPU_LANE_DYNAMIC", 1)) {
+                CREATE_TRY(hipMalloc((void**)&ctx->d_ln_ctr, sizeof(int)));
+                CREATE_TRY(hipMemset(ctx->d_ln_ctr, 0, sizeof(int)));
+            }
             for (int Bh : {0, ctx->dp.dup_enabled ? ctx->dp.dup_bufnum : 0})
                 CREATE_TRY(hipFuncSetAttribute((const void*)lane_kernel_for(ctx->ln_swm, Bh, ctx->dp.paired != 0, lane_ext(ctx->dp), ctx->ln_2w),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, ctx->ln_lds.total * 4));
@@ -1561,6 +1565,25 @@ static int launch_chunk(fastp_gpu_ctx* ctx, const fastp_gpu_batch* b, int first,
             la.prefetch = ctx->ln_prefetch;
             la.grab = ctx->ln_grab;
             la.local_ctr = env_int("FASTP_GPU_LANE_DYNAMIC", 2) == 2 ? 1 : 0;
+            la.pool = 0;
+            la.pool_base = 0;
+            la.pool_grab = 1;
+            if (la.local_ctr && la.chunk_ctr) {   // the chunks no workgroup owns (LaneArgs::pool)
+                // A/B, off: profiles/r06_x_lane_chunk_pool_ab.txt, r06_y_*: an 8th of the chunks -2 %, a 16th 0, a 32nd .. a 128th +0.2 % on the
+                // headline (noise), the single-end lines, -c and configs[4] 0.4 - 2 % SLOWER - the CUs' equal shares already end
+                // together; the asks of the pool cost what little imbalance there is
+                const int lg = env_int("FASTP_GPU_LANE_POOL_LOG2", 0);
+                const int chunks = (n + 63) >> 6;
+                la.pool = lg > 0 && lg < 31 ? chunks >> lg : 0;
+                if (ctx->ln_pool_base > 0x60000000) {   // (the counter only counts up: back to zero long before it could wrap)
+                    HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));
+                    ctx->ln_pool_base = 0;
+                }
+                la.pool_base = ctx->ln_pool_base;
+                la.pool_grab = std::max(1, la.pool >> 11);   // at most ~2 k asks per launch
+                // every wavefront asks once more than it gets: the counter ends at most (asks that get chunks) + wavefronts beyond the base
+                ctx->ln_pool_base += (la.pool + la.pool_grab - 1) / la.pool_grab + ctx->ln_blocks * (ctx->ln_threads >> 6) + 64;
+            }
             la.post1 = ctx->d_ctr + cl.stats[1];
             la.st_qual_hist = cl.st_qual_hist; la.st_kmer = cl.st_kmer; la.st_cycle = cl.st_cycle; la.cycles = cl.cycles;
             if (la.chunk_ctr && !la.local_ctr) HIP_TRY(ctx, hipMemsetAsync(la.chunk_ctr, 0, sizeof(int), st));

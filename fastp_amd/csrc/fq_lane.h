@@ -68,6 +68,14 @@ struct LaneArgs {
                     // its traffic: the kernel's loads-only skeleton takes 0.58 ms with a static stride, 0.92 with one returning
                     // global atomic per chunk on one word, 0.78 with one per four chunks (profiles/r06_e_*)
     int grab;       // FASTP_GPU_LANE_GRAB (round 6): chunks a wavefront takes from the counter at a time
+    int pool;       // with local_ctr: the launch's LAST `pool` chunks belong to no workgroup - a wavefront whose workgroup's share is
+                    // used up takes them one at a time from chunk_ctr (a word that only ever counts up: a chunk's number in the pool
+                    // is what the atomic returns minus pool_base, the host adds `pool` to pool_base per launch - no reset between
+                    // launches).  The shares are equal, the work per chunk is not (overlap verifications, trims): the kernel ended
+                    // when its slowest CU did.  FASTP_GPU_LANE_POOL_LOG2 (0: no pool, the default - measured: no gain; 5: a 32nd of the chunks)
+    int pool_base;
+    int pool_grab;  // chunks per ask of the pool (>= 1): a launch of many small chunks (single-end runs: 156 k of them) would otherwise
+                    // put ten thousand returning atomics on the one word while its last part runs
     int prefetch;   // FASTP_GPU_LANE_PREFETCH (round 6), bit mask: 1 = read 2's rows of the chunk are pulled into L2 while read 1 is
                     // staged and swept, 2 = read 1's rows of the wavefront's NEXT chunk while read 2 is - one dword per 128-byte line
                     // by global_load_lds into a sink (no register, no wait): the four row stagings of a chunk then find their lines
@@ -1482,6 +1490,19 @@ FQ_DEV void lane_merge_tail_slow(const LaneArgs& la, const LaneRead<SWM>& r2, co
 // ---------------------------------------------------------------------------
 // EXT: the option family with adapter sequences, polyX trimming or the complexity filter - a second instantiation, so that
 // the registers those steps need (+30) are not taken from the kernel of the options that do not use them
+// a chunk of the pool (LaneArgs::pool): its number is what the counter returns minus the launch's base.  The base is where the counter
+// CAN be at most when the launch starts (the host adds the pool and one ask per wavefront per launch); where fewer wavefronts asked, the
+// first askers of the next launch get numbers below its base and ask again.
+FQ_DEV int lane_pool_take(const LaneArgs& la, int lane) {
+    int gx;
+    do {
+        gx = 0;
+        if (lane == 0) gx = g_atomic_add_i32(la.chunk_ctr, 1) - la.pool_base;
+        gx = (int)shfl((u32)gx, 0);
+    } while (gx < 0);   // (wave-uniform)
+    return gx;
+}
+
 template <int SWM, int B, int NPL, bool PAIRED, int EXT>
 FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const KernelArgs& a = la.k;
@@ -1539,14 +1560,27 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
     const bool LC = la.local_ctr != 0;                          // (uniform)
     const int grab = (la.chunk_ctr && !LC) ? imax(1, la.grab) : 1;
     // the workgroup's share of the chunks (local_ctr): the first (chunks % workgroups) workgroups take one more
-    const int sq = chunks / grid_blocks(), sr = chunks - sq * grid_blocks();
+    const int pool = (LC && la.chunk_ctr) ? imin(la.pool, chunks) : 0;   // (uniform) the chunks behind the workgroups' shares
+    const int shared = chunks - pool;
+    const int pg = imax(1, la.pool_grab), pgroups = (pool + pg - 1) / pg;
+    const int sq = shared / grid_blocks(), sr = shared - sq * grid_blocks();
     const int share_lo = LC ? block_id() * sq + imin(block_id(), sr) : 0;
     const int share_hi = LC ? share_lo + sq + (block_id() < sr ? 1 : 0) : chunks;
     int chunk_end = (LC ? share_lo + (tid >> 6) : block_id() * wpb + (tid >> 6)) + 1;   // (the range in hand: [chunk, chunk_end))
-    for (int chunk = chunk_end - 1; chunk < share_hi;) {       // wave-uniform
+    int chunk0 = chunk_end - 1;
+    bool in_pool = false;                                       // (uniform)
+    if (pool && chunk0 >= share_hi) {                           // a share smaller than the workgroup: straight to the pool
+        const int gx = lane_pool_take(la, lane);
+        in_pool = true;
+        chunk0 = gx < pgroups ? shared + gx * pg : chunks;
+        chunk_end = imin(chunk0 + pg, chunks);
+    }
+    for (int chunk = chunk0; chunk < (in_pool ? chunks : share_hi);) {       // wave-uniform
         const bool last_in_hand = chunk + 1 == chunk_end;
         if (LC) {
-            if (lane == 0) nx = (int)lds_add_ret_u32(&lds[ll.ctr], 1u);   // the workgroup's next chunk, looked at at the loop's end
+            if (in_pool) {   // (the pool's next range is asked for here as well, when the one in hand ends with this chunk)
+                if (last_in_hand && lane == 0) nx = g_atomic_add_i32(la.chunk_ctr, 1) - la.pool_base;
+            } else if (lane == 0) nx = (int)lds_add_ret_u32(&lds[ll.ctr], 1u);   // the workgroup's next chunk, looked at at the loop's end
         } else if (la.chunk_ctr && last_in_hand) {
             gsz = (chunk + 4 * grab * nstatic < chunks) ? grab : 1;   // (uniform)
             if (lane == 0) nx = g_atomic_add_i32(la.chunk_ctr, gsz);   // the next range's first chunk, looked at at the loop's end
@@ -1962,7 +1996,19 @@ FQ_DEV void lane_body(const LaneArgs& la, u32* lds) {
             }
         }
         // the next chunk: the range in hand, then the counter's (or the static stride's) next range
-        if (LC) { chunk = share_lo + wpb + (int)shfl((u32)nx, 0); chunk_end = chunk + 1; }
+        if (LC) {
+            if (in_pool && !last_in_hand) chunk++;
+            else {
+                if (!in_pool) { chunk = share_lo + wpb + (int)shfl((u32)nx, 0); chunk_end = chunk + 1; }
+                if (pool && (in_pool || chunk >= share_hi)) {   // the share is used up: the pool's next chunks (a global atomic, few of them)
+                    int gx = in_pool ? (int)shfl((u32)nx, 0) : -1;   // (asked for at the loop's head; the first one here)
+                    if (gx < 0) gx = lane_pool_take(la, lane);
+                    in_pool = true;
+                    chunk = gx < pgroups ? shared + gx * pg : chunks;
+                    chunk_end = imin(chunk + pg, chunks);
+                }
+            }
+        }
         else if (!last_in_hand) chunk++;
         else if (la.chunk_ctr) { chunk = nstatic + (int)shfl((u32)nx, 0); chunk_end = chunk + gsz; }
         else { chunk += nstatic; chunk_end = chunk + 1; }

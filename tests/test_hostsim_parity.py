@@ -91,6 +91,30 @@ def test_sim_dedup_without_the_fused_claim(switch, monkeypatch):
     assert np.array_equal(co, cg)
 
 
+@pytest.mark.parametrize("name,log2", [("pe_default", 1), ("pe_default", 2), ("se_default_noadapter", 1), ("pe_correction", 1), ("pe_noadapter_dedup", 2)])
+def test_sim_lane_chunk_pool(name, log2, monkeypatch):
+    """the lane kernel's chunks behind the workgroups' shares (LaneArgs::pool: taken from a global counter that only counts up, its
+    base moved on by the host per launch): half / a quarter of a launch's chunks in the pool, three launches on one context - every
+    unit exactly once (records, counters), whatever the counter's state between launches"""
+    monkeypatch.setenv("FASTP_GPU_LANE_POOL_LOG2", str(log2))
+    paired, flags, pf, skw = cases.CASES[name]
+    d = synth.synth_pairs(2600, L=150, seed=61, paired=paired, **skw)
+    params = cases.finalize_params(name, pf(150), d["seq1"], d["len1"], d.get("seq2"), d.get("len2"))
+    o = oraclelib.Oracle(params)
+    g = engines.sim_engine(params)
+    assert g.plan() == "lane"
+    for lo, hi in ((0, 1100), (1100, 1200), (1200, 2600)):
+        args = tuple(d[k][lo:hi] for k in (("seq1", "qual1", "len1", "seq2", "qual2", "len2") if paired else ("seq1", "qual1", "len1")))
+        ro, rg = o.process(*args), g.process(*args)
+        for k in range(3):
+            if ro[k] is not None:
+                assert np.array_equal(ro[k], rg[k]), f"{name}: records {k} of units [{lo}, {hi}) differ"
+    co, cg = o.counters(), g.counters()
+    o.close()
+    g.close()
+    assert np.array_equal(co, cg), f"{name}: {int((co != cg).sum())} counters differ"
+
+
 def test_sim_overrep_with_correction_reads_the_engines_own_list():
     """-p with -c on the lane plan: the POST overrepresentation counts are taken from the launch's own correction list (sized for
     an edit at every base: it cannot overflow).  A caller's list that is too small for the batch's edits - the results then hold
